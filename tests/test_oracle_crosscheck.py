@@ -1,0 +1,84 @@
+"""The two independently written CPU restatements (NumPy, PyTorch-CPU) must agree, and the
+NumPy oracle must reproduce the committed golden fixtures (which it generated)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+from oracle.torch_restatement import TorchModel, chainer_adam_step
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+@pytest.mark.parametrize('mt,nm,T', [('CDNA', 10, 3), ('STP', 10, 3), ('DNA', 1, 3)])
+def test_numpy_vs_torch_restatement(mt, nm, T):
+    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, num_masks=nm, model_type=mt)
+    imgs, acts, stas = R.synthetic_batch(2, T)
+    kw = dict(is_cdna=mt == 'CDNA', is_stp=mt == 'STP', is_dna=mt == 'DNA')
+    m = R.Model(nm, params=P, dtype=np.float64, prefix='x', **kw); m.train = False
+    loss = m([imgs, acts, stas], 0)
+    tm = TorchModel(nm, params=P, **kw); tm.train = False
+    with torch.no_grad():
+        lt = tm([imgs, acts, stas], 0)
+    a = np.stack(m.gen_images); b = np.stack([g.numpy() for g in tm.gen_images])
+    assert np.abs(a - b).max() < 1e-10
+    assert abs(loss - float(lt)) < 1e-12
+
+
+def test_stp_zero_border_mode_crosscheck():
+    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, num_masks=10, model_type='STP')
+    P['model/identity_params/b'] = P['model/identity_params/b'] + 0.3   # push samples off the image
+    imgs, acts, stas = R.synthetic_batch(2, 3)
+    for border in ('clamp', 'zeros'):
+        m = R.Model(10, is_cdna=False, is_stp=True, params=P, dtype=np.float64, prefix='x', stp_border=border)
+        m.train = False
+        m([imgs, acts, stas], 0)
+        tm = TorchModel(10, is_cdna=False, is_stp=True, params=P, stp_border=border); tm.train = False
+        with torch.no_grad():
+            tm([imgs, acts, stas], 0)
+        a = np.stack(m.gen_images); b = np.stack([g.numpy() for g in tm.gen_images])
+        assert np.abs(a - b).max() < 1e-10
+
+
+def test_scheduled_sampling_paths_agree():
+    P = R.init_params(seed=1, dtype=np.float64, scale=1.0)
+    imgs, acts, stas = R.synthetic_batch(4, 5)
+    m = R.Model(10, params=P, dtype=np.float64, prefix='x', scheduled_sampling_k=2.0)
+    m.rng = np.random.RandomState(7)
+    m([imgs, acts, stas], 1.0)
+    tm = TorchModel(10, params=P, scheduled_sampling_k=2.0)
+    tm.rng = np.random.RandomState(7)
+    with torch.no_grad():
+        tm([imgs, acts, stas], 1.0)
+    a = np.stack(m.gen_images); b = np.stack([g.numpy() for g in tm.gen_images])
+    assert np.abs(a - b).max() < 1e-6   # the scheduled-sample round trip casts to float32 (TM:120)
+
+
+@pytest.mark.parametrize('name,mt,nm', [('cdna_b2_t10', 'CDNA', 10), ('stp_b2_t4', 'STP', 10), ('dna_b2_t4', 'DNA', 1)])
+def test_oracle_reproduces_golden(name, mt, nm):
+    g = np.load(os.path.join(GOLD, name + '.npz'))
+    B, T = int(g['batch']), int(g['seq_len'])
+    if name == 'cdna_b2_t10':
+        T = 3   # keep the CPU suite fast: the first frames pin the fixture; full length runs on the GPU
+    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, num_masks=nm, model_type=mt)
+    assert abs(sum(float(np.abs(v).sum()) for v in P.values()) - float(g['param_checksum'])) < 1e-6
+    imgs, acts, stas = R.synthetic_batch(B, int(g['seq_len']))
+    m = R.Model(nm, is_cdna=mt == 'CDNA', is_stp=mt == 'STP', is_dna=mt == 'DNA',
+                params=P, dtype=np.float64, prefix='x')
+    m.train = False
+    m([imgs[:T], acts[:T], stas[:T]], 0, tap_steps=(0,))
+    got = np.stack(m.gen_images)
+    assert np.abs(got - g['gen_images'][:T - 1]).max() < 1e-6
+    assert np.abs(m.taps[0]['enc6'].ravel()[::97] - g['tap0_enc6']).max() < 1e-5
+
+
+def test_chainer_adam_step_kat():
+    # one step from m=v=0 with gradient g: m = .1 g, v = .001 g^2, lr = a*sqrt(1-b2)/(1-b1)
+    p = {'w': np.array([1.0, -2.0])}; g = {'w': np.array([0.5, -0.25])}
+    m = {'w': np.zeros(2)}; v = {'w': np.zeros(2)}
+    chainer_adam_step(p, g, m, v, 1)
+    lr = 0.001 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    expect = np.array([1.0, -2.0]) - lr * (0.1 * g['w']) / (np.sqrt(0.001 * g['w'] ** 2) + 1e-8)
+    assert np.allclose(p['w'], expect, rtol=1e-12)
