@@ -1,0 +1,142 @@
+/* pivp_hip.h -- C ABI of the MI355X (gfx950) ConvLSTM + CDNA/STP/DNA video-prediction hot path.
+ *
+ * Drop-in scope: the reference (kristofbc/physical-interaction-video-prediction) has no FFI or
+ * plugin interface; its hot path is the Python method Model.__call__ (src/models/train_model.py,
+ * "TM", lines 620-764) built on Chainer ops.  This library replaces the arithmetic under that
+ * method.  Every entry point cites the reference code it stands in for.  Signatures carry plain
+ * device pointers, sizes and a hipStream_t passed as void*; no torch / C++ types.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to fp32 unless stated; the caller owns every buffer
+ *   - return value: 0 = ok, <0 = error (PIVP_ERR_*); functions never throw and never synchronise
+ *   - re-entrant per plan + stream; no global mutable state besides lazily set kernel attributes
+ *   - feature maps are NHWC with an explicit pixel stride `ld` (floats); frames and mask planes are
+ *     planar NCHW exactly as the reference holds them
+ */
+#ifndef PIVP_HIP_H
+#define PIVP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIVP_OK 0
+#define PIVP_ERR_BADARG (-1)
+#define PIVP_ERR_LAUNCH (-2)
+#define PIVP_ERR_STATE (-3)
+
+#define PIVP_MODEL_CDNA 0
+#define PIVP_MODEL_STP 1
+#define PIVP_MODEL_DNA 2
+
+int pivp_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Plan = Model.__init__ (TM:484-602): layer table, op program, variant head.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pivp_plan pivp_plan_t;
+
+typedef struct pivp_config {
+    int batch;             /* B, sequences per call on this device                               */
+    int seq_len;           /* T, frames per sequence incl. context (TM:659 iterates T-1 steps)   */
+    int height, width;     /* frame size; multiples of 8 (TM:505-507 hard-codes 64, generalised) */
+    int num_masks;         /* TM:484 num_masks (10 for CDNA/STP, 1 for DNA)                      */
+    int model_type;        /* PIVP_MODEL_*; precedence cdna > stp > dna is resolved by the host  */
+    int use_state;         /* TM:556-567 smear of [action,state] before enc3                     */
+    int context_frames;    /* TM:484 num_frame_before_prediction                                 */
+    int keep_activations;  /* 1: keep every timestep's activations (training/BPTT); 0: rolling   */
+    float ln_eps;          /* chainer.links.LayerNormalization eps (1e-6 in 2.0.x)               */
+    int stp_zero_border;   /* 0: clamp sampling coords (Chainer 2.0.x), 1: zero outside          */
+} pivp_config_t;
+
+int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out);
+void pivp_plan_destroy(pivp_plan_t* plan);
+
+/* Parameters, in the library's internal layout (the host permutes the reference's
+ * Chainer-npz arrays, keys = SURVEY.md App. B, when loading a checkpoint). */
+int pivp_param_count(const pivp_plan_t* plan);
+const char* pivp_param_name(const pivp_plan_t* plan, int idx);      /* Chainer save_npz key        */
+long long pivp_param_numel(const pivp_plan_t* plan, int idx);       /* elements in internal layout */
+int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr);
+
+long long pivp_plan_workspace_bytes(const pivp_plan_t* plan);
+int pivp_plan_set_workspace(pivp_plan_t* plan, void* dptr, long long bytes);
+
+/* Model.reset_state (TM:604-618): zero the seven ConvLSTM (c, h) pairs. */
+int pivp_reset_state(pivp_plan_t* plan, void* stream);
+
+/* Model.__call__ forward (TM:620-764): T-1 timesteps, loss and PSNR.
+ *   images  [T][B][3][H][W], actions [T][B][5], states [T][B][5]   (time-major, as concat_examples TM:51-71)
+ *   gt_select [T-1][B] bytes or NULL: 1 = feed the ground-truth frame at that step (scheduled sampling,
+ *             TM:73-122; the host draws the indices from NumPy's global RNG exactly as the reference);
+ *             NULL = feed-self after the context frames (TM:664-666)
+ *   gen_images [T-1][B][3][H][W], gen_states [T-1][B][5]
+ *   results [2 + 3*(T-ctx)]: loss, psnr_all, recon_cost[i], psnr[i], state_cost[i]   (TM:739-759)
+ */
+int pivp_rollout_forward(pivp_plan_t* plan, const float* images, const float* actions, const float* states,
+                         const unsigned char* gt_select, float* gen_images, float* gen_states, float* results,
+                         void* stream);
+
+/* Activation taps of a timestep still held in the workspace, returned planar NCHW like the
+ * reference's conv_res / hiddens (TM:703-708, TM:734).  name: enc0..enc7, hidden1..hidden7, masks,
+ * cdna_kerns, lstm1_h.. lstm7_h, lstm1_c..lstm7_c.  Returns the number of floats written or <0. */
+long long pivp_get_tap(pivp_plan_t* plan, const char* name, int step, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-op entry points (used by the parity tests and usable on their own).
+ * ------------------------------------------------------------------------------------------ */
+
+/* BasicConvLSTMCell.__call__ (TM:234-276): gates = conv5x5(concat(x,h)) ; c,h update, forget bias 1.
+ * x NHWC (cx channels, stride ldx), h_prev/c NHWC [B][H][W][C]; w [25][cx+C][4C] gate order j,i,f,o. */
+int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
+                  const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream);
+
+/* L.Convolution2D(cout,(3,3),stride=2,pad=1) (TM:501-502) + optional ReLU; w [9][cin][cout]. */
+int pivp_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
+                   int ldo, int relu, int B, int Hin, int Win, void* stream);
+
+/* L.Deconvolution2D(cout,(3,3),stride=2,pad=1,outsize=2*in) (TM:505-507) + optional ReLU; w [9][cin][cout]. */
+int pivp_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
+                     int ldo, int relu, int B, int Hin, int Win, void* stream);
+
+/* L.Convolution2D(32,(5,5),stride=2,pad=2) on a planar 3-channel frame (TM:500); w [75][32]. */
+int pivp_conv_enc0(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, void* stream);
+
+/* LayerNormalizationConv2D.__call__ (TM:203-208); x NHWC-flat [B][n], gamma/beta NHWC-flat [n];
+ * partials: scratch of pivp_layernorm_scratch_floats(B,n) floats. */
+long long pivp_layernorm_scratch_floats(int B, int n);
+int pivp_layernorm(const float* x, const float* gamma, const float* beta, float* out, float* partials,
+                   int B, int n, int C, int ldo, float eps, int relu, void* stream);
+
+/* smear + enc3 1x1 + ReLU and current_state Linear (TM:556-567, TM:503, TM:676, TM:730). */
+int pivp_enc3_state(const float* e2, const float* action, const float* state, const float* w3, const float* b3,
+                    const float* wcs, const float* bcs, float* e3, float* state_out, int B, int HW8, int use_state,
+                    void* stream);
+
+/* masks / enc7 1x1 heads (TM:718-719, TM:315-317 | TM:454-455 | TM:387-388). */
+int pivp_heads(const float* e6, const float* wm, const float* bm, const float* we, const float* be,
+               float* mask_logits, float* enc7, float* layer0, int B, int HW, int num_masks, int model_type,
+               void* stream);
+
+/* CDNA kernel generator (TM:321-329); wt [K][256]; partials scratch of pivp_linear_scratch_floats(B,K). */
+long long pivp_linear_scratch_floats(int B, int K);
+int pivp_cdna_kernels(const float* hidden5, const float* wt, const float* bias, float* partials, float* kerns,
+                      int B, int K, int num_masks, void* stream);
+
+/* STP affine parameters (TM:457-468). */
+int pivp_stp_params(const float* hidden5, const float* wt1, const float* b1, const float* w2, const float* b2,
+                    float* partials, float* theta, int B, int K, void* stream);
+
+/* flat softmax + transform + compositing (TM:720-728). aux: CDNA kerns | STP theta | DNA enc7 planes. */
+int pivp_composite(const float* prev, const float* mask_logits, const float* layer0, const float* aux, float* out,
+                   float* masks_out, int B, int H, int W, int num_masks, int model_type, int stp_zero_border,
+                   void* stream);
+
+/* scheduled_sample (TM:73-122) as an on-device per-sample select. */
+int pivp_select_frames(const float* ground_truth, const float* generated, const unsigned char* take_gt, float* out,
+                       int B, int frame_numel, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIVP_HIP_H */

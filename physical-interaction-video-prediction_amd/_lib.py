@@ -1,0 +1,82 @@
+"""ctypes binding of libpivp_hip.so (the C ABI declared in include/pivp_hip.h).
+
+There is no CPU fallback: if the library is missing or fails to load, `load()` raises."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libpivp_hip.so')
+
+PIVP_OK = 0
+MODEL_CDNA, MODEL_STP, MODEL_DNA = 0, 1, 2
+
+_c = ctypes
+_vp, _i, _f, _ll = _c.c_void_p, _c.c_int, _c.c_float, _c.c_longlong
+
+
+class PivpConfig(ctypes.Structure):
+    _fields_ = [('batch', _i), ('seq_len', _i), ('height', _i), ('width', _i), ('num_masks', _i),
+                ('model_type', _i), ('use_state', _i), ('context_frames', _i), ('keep_activations', _i),
+                ('ln_eps', _f), ('stp_zero_border', _i)]
+
+
+# name -> (restype, argtypes); every symbol include/pivp_hip.h declares
+SIGNATURES = {
+    'pivp_abi_version': (_i, []),
+    'pivp_plan_create': (_i, [_c.POINTER(PivpConfig), _c.POINTER(_vp)]),
+    'pivp_plan_destroy': (None, [_vp]),
+    'pivp_param_count': (_i, [_vp]),
+    'pivp_param_name': (_c.c_char_p, [_vp, _i]),
+    'pivp_param_numel': (_ll, [_vp, _i]),
+    'pivp_plan_set_param': (_i, [_vp, _i, _vp]),
+    'pivp_plan_workspace_bytes': (_ll, [_vp]),
+    'pivp_plan_set_workspace': (_i, [_vp, _vp, _ll]),
+    'pivp_reset_state': (_i, [_vp, _vp]),
+    'pivp_rollout_forward': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'pivp_get_tap': (_ll, [_vp, _c.c_char_p, _i, _vp, _vp]),
+    'pivp_convlstm': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pivp_conv3x3s2': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'pivp_deconv3x3s2': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'pivp_conv_enc0': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pivp_layernorm_scratch_floats': (_ll, [_i, _i]),
+    'pivp_layernorm': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    'pivp_enc3_state': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pivp_heads': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'pivp_linear_scratch_floats': (_ll, [_i, _i]),
+    'pivp_cdna_kernels': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pivp_stp_params': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'pivp_composite': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'pivp_select_frames': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libpivp_hip.so (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libpivp_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `python physical-interaction-video-prediction_amd/build.py`. There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the ABI and the header drift apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class PivpError(RuntimeError):
+    pass
+
+
+_ERR = {-1: 'PIVP_ERR_BADARG', -2: 'PIVP_ERR_LAUNCH', -3: 'PIVP_ERR_STATE'}
+
+
+def check(rc, what):
+    if rc != PIVP_OK:
+        raise PivpError('%s failed: %s (%d)' % (what, _ERR.get(rc, 'unknown'), rc))

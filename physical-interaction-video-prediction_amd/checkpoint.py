@@ -1,0 +1,68 @@
+"""Checkpoint layout: the reference's Chainer `save_npz` files <-> the library's internal layouts.
+
+Reference: chainer.serializers.save_npz/load_npz at train_model.py:865, 1035-1037 and
+predict_model.py:110; keys are link paths, files carry no extension
+(README.md:24, predict_model.py:80).  Shapes in the file: conv W (Cout,Cin,kh,kw); deconv W
+(Cin,Cout,kh,kw); Linear W (out,in); LN gamma/beta flat in NCHW order c*H*W + y*W + x.
+
+Internal layouts (csrc/pivp_kernels.h): conv/deconv W [tap][Cin][Cout]; LN gamma/beta NHWC-flat;
+cdna_kerns / stp_input W K-major over the NHWC-flat hidden5 index with 256 padded columns."""
+import numpy as np
+
+DECONV_KEYS = ('enc4/W', 'enc5/W', 'enc6/W', 'masks/W', 'model/enc7/W')
+LN_CHANNELS = {'norm_enc0': 32, 'hidden1': 32, 'hidden2': 32, 'hidden3': 64, 'hidden4': 64,
+               'hidden5': 128, 'hidden6': 64, 'hidden7': 32, 'norm_enc6': 64}
+SKINNY_KEYS = ('model/cdna_kerns/W', 'model/stp_input/W')
+
+
+def to_internal(key, arr):
+    """Reference-layout array -> flat float32 array in the library's layout."""
+    a = np.asarray(arr, dtype=np.float32)
+    if key in SKINNY_KEYS:
+        nout, K = a.shape
+        hw8 = K // 128
+        t = a.reshape(nout, 128, hw8).transpose(2, 1, 0).reshape(K, nout)   # k = pix*128 + c
+        out = np.zeros((K, 256), np.float32)
+        out[:, :nout] = t
+        return out.ravel()
+    if key.endswith('/W') and a.ndim == 4:
+        if key in DECONV_KEYS:
+            return np.ascontiguousarray(a.transpose(2, 3, 0, 1)).ravel()     # (Cin,Cout,kh,kw) -> [tap][Cin][Cout]
+        return np.ascontiguousarray(a.transpose(2, 3, 1, 0)).ravel()         # (Cout,Cin,kh,kw) -> [tap][Cin][Cout]
+    if key.endswith('/norm/gamma') or key.endswith('/norm/beta'):
+        C = LN_CHANNELS[key.split('/')[0]]
+        return np.ascontiguousarray(a.reshape(C, -1).T).ravel()              # c*HW+p -> p*C+c
+    return a.ravel()
+
+
+def from_internal(key, flat, ref_shape):
+    """Inverse of to_internal: flat internal array -> array of the reference's shape."""
+    f = np.asarray(flat, dtype=np.float32)
+    if key in SKINNY_KEYS:
+        nout, K = ref_shape
+        hw8 = K // 128
+        t = f.reshape(K, 256)[:, :nout]
+        return np.ascontiguousarray(t.reshape(hw8, 128, nout).transpose(2, 1, 0)).reshape(nout, K)
+    if key.endswith('/W') and len(ref_shape) == 4:
+        if key in DECONV_KEYS:
+            ci, co, kh, kw = ref_shape
+            return np.ascontiguousarray(f.reshape(kh, kw, ci, co).transpose(2, 3, 0, 1))
+        co, ci, kh, kw = ref_shape
+        return np.ascontiguousarray(f.reshape(kh, kw, ci, co).transpose(3, 2, 0, 1))
+    if key.endswith('/norm/gamma') or key.endswith('/norm/beta'):
+        C = LN_CHANNELS[key.split('/')[0]]
+        return np.ascontiguousarray(f.reshape(-1, C).T).ravel()
+    return f.reshape(ref_shape)
+
+
+def save_npz(filename, model):
+    """chainer.serializers.save_npz(filename, model) equivalent (compressed, no extension added)."""
+    params = model.state_dict_reference()
+    with open(filename, 'wb') as f:
+        np.savez_compressed(f, **params)
+
+
+def load_npz(filename, model):
+    """chainer.serializers.load_npz(filename, model) equivalent; missing keys raise KeyError."""
+    with np.load(filename) as npz:
+        model.load_state_dict_reference({k: npz[k] for k in npz.files})

@@ -1,0 +1,386 @@
+// Output heads of one timestep: 1x1 channel mixes on enc6 (mask logits + enc7), the CDNA kernel
+// generator, the STP parameter regressor, and the fused flat-softmax + transform + compositing
+// kernel that produces the next frame.  "TM" = src/models/train_model.py of the reference.
+#include "pivp_kernels.h"
+
+namespace pivp {
+
+// ------------------------------------------------------------------------------------------
+// heads_1x1: masks = relu(Deconv1x1(enc6)) (TM:718-719) and enc7 = Deconv1x1(enc6) with the
+// variant's activation (CDNA TM:315-317, STP TM:454-455, DNA TM:387-388) in ONE pass over enc6.
+// e6 NHWC [B][HW][64]; wm [64][NP], we [64][NE] (the reference's deconv (Cin,Cout,1,1) layout);
+// outputs planar [B][planes][HW] because the mask softmax is defined on the NCHW-flat order.
+// Each 256-thread block stages 64-pixel sub-tiles through LDS with coalesced 16-B loads; wave w
+// computes outputs w, w+4, ... for all 64 pixels (lane = pixel), weights are wave-uniform.
+// ------------------------------------------------------------------------------------------
+constexpr int HD_MAXOUT = 36;
+constexpr int HD_XP = 68;  // 272-B rows: conflict-free per-lane ds_read_b128
+
+__global__ __launch_bounds__(256) void heads_1x1_kernel(const float* __restrict__ e6, const float* __restrict__ wm,
+                                                        const float* __restrict__ bm, const float* __restrict__ we,
+                                                        const float* __restrict__ be, float* __restrict__ mask_logits,
+                                                        float* __restrict__ enc7, float* __restrict__ layer0,
+                                                        int total_px, int HW, int NP, int NE, int mode) {
+    __shared__ __attribute__((aligned(16))) float xt[64 * HD_XP];
+    __shared__ float wl[64 * HD_MAXOUT];
+    __shared__ float bl[HD_MAXOUT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NO = NP + NE;
+    for (int i = tid; i < 64 * NO; i += 256) {
+        const int k = i / NO, o = i - k * NO;
+        wl[k * HD_MAXOUT + o] = o < NP ? wm[k * NP + o] : we[k * NE + (o - NP)];
+    }
+    if (tid < NO) bl[tid] = tid < NP ? bm[tid] : be[tid - NP];
+    for (int sub = 0; sub < 4; ++sub) {
+        const int px0 = (blockIdx.x * 4 + sub) * 64;
+        if (px0 >= total_px) break;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + 256 * j;       // float4 index within the 64x64 tile
+            const int p = f >> 4, cv = (f & 15) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (px0 + p < total_px) v = *reinterpret_cast<const f32x4*>(e6 + (size_t)(px0 + p) * 64 + cv);
+            *reinterpret_cast<f32x4*>(xt + p * HD_XP + cv) = v;
+        }
+        __syncthreads();
+        float xr[64];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xt + lane * HD_XP + q * 4);
+            xr[q * 4] = v[0]; xr[q * 4 + 1] = v[1]; xr[q * 4 + 2] = v[2]; xr[q * 4 + 3] = v[3];
+        }
+        const int px = px0 + lane;
+        const int b = px / HW, p = px - b * HW;
+        for (int o = wave; o < NO; o += 4) {
+            float acc = bl[o];
+#pragma unroll
+            for (int k = 0; k < 64; ++k) acc = fmaf(xr[k], wl[k * HD_MAXOUT + o], acc);
+            if (px < total_px) {
+                if (o < NP) {
+                    mask_logits[((size_t)b * NP + o) * HW + p] = fmaxf(acc, 0.f);
+                } else {
+                    const int oe = o - NP;
+                    if (mode != 1) acc = fmaxf(acc, 0.f);
+                    enc7[((size_t)b * NE + oe) * HW + p] = acc;
+                    if (mode != 2) layer0[((size_t)b * NE + oe) * HW + p] = sigmoidf_(acc);
+                }
+            }
+        }
+    }
+}
+
+int heads_1x1(const float* e6, const float* wm, const float* bm, const float* we, const float* be,
+              float* mask_logits, float* enc7, float* layer0, int B, int HW, int nmask_planes, int nenc7,
+              int enc7_mode, hipStream_t s) {
+    PIVP_CHECK_ARG(e6 && wm && bm && we && be && mask_logits && enc7 && B > 0 && HW > 0);
+    PIVP_CHECK_ARG(nmask_planes >= 1 && nenc7 >= 1 && nmask_planes + nenc7 <= HD_MAXOUT);
+    PIVP_CHECK_ARG(enc7_mode >= 0 && enc7_mode <= 2 && (enc7_mode == 2 || layer0));
+    const int total = B * HW;
+    hipLaunchKernelGGL(heads_1x1_kernel, dim3((total + 255) / 256), dim3(256), 0, s, e6, wm, bm, we, be,
+                       mask_logits, enc7, layer0, total, HW, nmask_planes, nenc7, enc7_mode);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
+// Skinny Linear on flatten(hidden5): out[b][o] = sum_k x[b][k] * wt[k][o]  (B <= 32 per block row).
+// K is split in slices of 128 so the 8 MB weight matrix is streamed once by K/128 blocks; each
+// slice writes its partial sums and the finisher adds them in a fixed order (bitwise reproducible).
+// wt is K-major with 256 padded columns; x is the NHWC-flat hidden5 (the checkpoint permutes
+// cdna_kerns/W's in-feature axis from c*64+y*8+x to (y*8+x)*128+c at load time).
+// ------------------------------------------------------------------------------------------
+constexpr int LIN_KS = 128;
+int cdna_kernel_partials_slices(int K) { return (K + LIN_KS - 1) / LIN_KS; }
+
+__global__ __launch_bounds__(256) void skinny_linear_partials_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                                     float* __restrict__ partials, int B, int K) {
+    __shared__ __attribute__((aligned(16))) float xs[32 * LIN_KS];
+    const int ks = blockIdx.x, b0 = blockIdx.y * 32, o = threadIdx.x;
+    const int k0 = ks * LIN_KS;
+    const int nb = min(32, B - b0);
+    for (int i = threadIdx.x; i < 32 * LIN_KS; i += 256) {
+        const int bb = i / LIN_KS, k = i - bb * LIN_KS;
+        xs[i] = (bb < nb && k0 + k < K) ? x[(size_t)(b0 + bb) * K + k0 + k] : 0.f;
+    }
+    __syncthreads();
+    float acc[32];
+#pragma unroll
+    for (int bb = 0; bb < 32; ++bb) acc[bb] = 0.f;
+    for (int k = 0; k < LIN_KS; k += 4) {
+        float w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (k0 + k + e < K) ? wt[(size_t)(k0 + k + e) * 256 + o] : 0.f;
+#pragma unroll
+        for (int bb = 0; bb < 32; ++bb) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + bb * LIN_KS + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[bb] = fmaf(xv[e], w[e], acc[bb]);
+        }
+    }
+    for (int bb = 0; bb < nb; ++bb) partials[((size_t)ks * B + b0 + bb) * 256 + o] = acc[bb];
+}
+
+// CDNA finisher (TM:326-329): + bias, relu(k - RELU_SHIFT) + RELU_SHIFT, divide by the 5x5 sum.
+__global__ __launch_bounds__(256) void cdna_kernels_finish_kernel(const float* __restrict__ partials, const float* __restrict__ bias,
+                                                                  float* __restrict__ kerns, int B, int KS, int nout) {
+    __shared__ float v[256];
+    const int b = blockIdx.x, o = threadIdx.x;
+    float acc = 0.f;
+    if (o < nout) {
+        acc = bias[o];
+        for (int ks = 0; ks < KS; ++ks) acc += partials[((size_t)ks * B + b) * 256 + o];
+        acc = fmaxf(acc - 1e-12f, 0.f) + 1e-12f;
+    }
+    v[o] = acc;
+    __syncthreads();
+    if (o < nout) {
+        const int g = (o / 25) * 25;
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 25; ++i) sum += v[g + i];
+        kerns[(size_t)b * nout + o] = acc / sum;
+    }
+}
+
+int cdna_kernels(const float* hidden5, const float* wt, const float* bias, float* partials, float* kerns,
+                 int B, int K, int num_masks, hipStream_t s) {
+    PIVP_CHECK_ARG(hidden5 && wt && bias && partials && kerns && B > 0 && K > 0 && num_masks >= 1 && num_masks * 25 <= 256);
+    const int KS = cdna_kernel_partials_slices(K);
+    hipLaunchKernelGGL(skinny_linear_partials_kernel, dim3(KS, (B + 31) / 32), dim3(256), 0, s, hidden5, wt, partials, B, K);
+    hipLaunchKernelGGL(cdna_kernels_finish_kernel, dim3(B), dim3(256), 0, s, partials, bias, kerns, B, KS, num_masks * 25);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// STP finisher (TM:458-468): relu(Linear(100)) -> shared Linear(6) + identity.  w2 reference layout (6,100).
+__global__ __launch_bounds__(128) void stp_params_finish_kernel(const float* __restrict__ partials, const float* __restrict__ b1,
+                                                                const float* __restrict__ w2, const float* __restrict__ b2,
+                                                                float* __restrict__ theta, int B, int KS) {
+    __shared__ float s1[100];
+    const int b = blockIdx.x, o = threadIdx.x;
+    if (o < 100) {
+        float acc = b1[o];
+        for (int ks = 0; ks < KS; ++ks) acc += partials[((size_t)ks * B + b) * 256 + o];
+        s1[o] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    if (o < 6) {
+        float acc = b2[o];
+        for (int i = 0; i < 100; ++i) acc = fmaf(w2[o * 100 + i], s1[i], acc);
+        theta[b * 6 + o] = acc + ((o == 0 || o == 4) ? 1.0f : 0.0f);
+    }
+}
+
+int stp_params(const float* hidden5, const float* wt1, const float* b1, const float* w2, const float* b2,
+               float* partials, float* theta, int B, int K, hipStream_t s) {
+    PIVP_CHECK_ARG(hidden5 && wt1 && b1 && w2 && b2 && partials && theta && B > 0 && K > 0);
+    const int KS = cdna_kernel_partials_slices(K);
+    hipLaunchKernelGGL(skinny_linear_partials_kernel, dim3(KS, (B + 31) / 32), dim3(256), 0, s, hidden5, wt1, partials, B, K);
+    hipLaunchKernelGGL(stp_params_finish_kernel, dim3(B), dim3(128), 0, s, partials, b1, w2, b2, theta, B, KS);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
+// composite: flat softmax of the mask logits + motion transform of the previous frame + mask
+// weighted sum -> next frame, one pass, nothing intermediate written to HBM.
+//   masks (TM:720-722): the reference reshapes the NCHW mask tensor to (-1, NP) and softmaxes
+//     axis 1, i.e. over NP CONSECUTIVE elements of the per-sample planar buffer (NP = num_masks+1);
+//     groups cut across pixels/rows/planes.  Reproduced exactly: group of flat index f is f / NP.
+//   CDNA (TM:341-349, TM:725-727): out = m0*prev + m1*sigmoid(enc7) + sum_{k<NM-1} m_{k+2} * (prev (*) kern_k);
+//     the last generated kernel never pairs with a mask (zip truncation) and is skipped.
+//     Evaluated as one 5x5 correlation with the per-pixel blended kernel sum_k m_{k+2} kern_k.
+//   STP (TM:465-471): all NM-1 warps are the same affine warp -> (sum_{q>=2} m_q) * warp(prev).
+//   DNA (TM:392-415): per-pixel 25-tap kernel from enc7, with the reference's slice quirk
+//     (shifted copies are cut at H-xk / W-yk).
+// One block = one sample x 8 image rows; the frame tile with its 2-pixel halo, the logit windows
+// (tile +- NP-1 flat elements per plane) and the sample's kernels are staged in LDS.
+// ------------------------------------------------------------------------------------------
+constexpr int CP_TR = 8;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ prev, const float* __restrict__ logits,
+                                                        const float* __restrict__ layer0, const float* __restrict__ aux,
+                                                        float* __restrict__ out, float* __restrict__ masks_out,
+                                                        int H, int W, int NM, int stp_zero) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int NP = NM + 1;
+    const int HW = H * W;
+    const int b = blockIdx.y;
+    const int y0 = blockIdx.x * CP_TR;
+    const int rows = min(CP_TR, H - y0);
+    const int p0 = y0 * W, np = rows * W;
+    const int win = np + 2 * (NP - 1);
+    const int G = np / NP + 2;
+    float* lg = sm;                         // [NP][win]
+    float* gmx = lg + NP * win;             // [NP][G]
+    float* ginv = gmx + NP * G;             // [NP][G]
+    float* prevt = ginv + NP * G;           // [3][CP_TR+4][W+4]
+    float* kl = prevt + 3 * (CP_TR + 4) * (W + 4);  // [NM*25] (CDNA)
+    const int PW = W + 4;
+    const int tid = threadIdx.x;
+    const float* lgb = logits + (size_t)b * NP * HW;
+
+    for (int i = tid; i < NP * win; i += 256) {
+        const int m = i / win, j = i - m * win;
+        const int F = m * HW + p0 - (NP - 1) + j;
+        lg[i] = (F >= 0 && F < NP * HW) ? lgb[F] : 0.f;
+    }
+    if (MODE != 1) {
+        const float* pb = prev + (size_t)b * 3 * HW;
+        for (int i = tid; i < 3 * (CP_TR + 4) * PW; i += 256) {
+            const int c = i / ((CP_TR + 4) * PW);
+            const int r = (i / PW) % (CP_TR + 4);
+            const int x = i % PW;
+            const int iy = y0 + r - 2, ix = x - 2;
+            prevt[i] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? pb[(size_t)c * HW + iy * W + ix] : 0.f;
+        }
+    }
+    if (MODE == 0) {
+        for (int i = tid; i < NM * 25; i += 256) kl[i] = aux[(size_t)b * NM * 25 + i];
+    }
+    __syncthreads();
+    // per-group max and 1/sum
+    for (int i = tid; i < NP * G; i += 256) {
+        const int m = i / G, gi = i - m * G;
+        const int gfirst = (m * HW + p0) / NP;
+        const int glast = (m * HW + p0 + np - 1) / NP;
+        if (gfirst + gi <= glast) {
+            const int j0 = (gfirst + gi) * NP - (m * HW + p0 - (NP - 1));
+            const float* e = lg + m * win + j0;
+            float mx = e[0];
+            for (int u = 1; u < NP; ++u) mx = fmaxf(mx, e[u]);
+            float sum = 0.f;
+            for (int u = 0; u < NP; ++u) sum += expf(e[u] - mx);
+            gmx[i] = mx;
+            ginv[i] = 1.0f / sum;
+        }
+    }
+    __syncthreads();
+
+    for (int pp = tid; pp < np; pp += 256) {
+        const int p = p0 + pp;
+        const int y = p / W, x = p - y * W;
+        const int ry = y - y0;
+        float mk[12];
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+            if (m < NP) {
+                const int F = m * HW + p;
+                const int gi = F / NP - (m * HW + p0) / NP;
+                const float v = lg[m * win + pp + (NP - 1)];
+                mk[m] = expf(v - gmx[m * G + gi]) * ginv[m * G + gi];
+                if (masks_out) masks_out[((size_t)b * NP + m) * HW + p] = mk[m];
+            } else {
+                mk[m] = 0.f;
+            }
+        }
+        float o3[3];
+        if (MODE == 0) {
+            float keff[25];
+#pragma unroll
+            for (int i = 0; i < 25; ++i) keff[i] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {   // static indices keep mk[] in registers
+                if (k < NM - 1) {
+                    const float mq = mk[k + 2];
+#pragma unroll
+                    for (int i = 0; i < 25; ++i) keff[i] = fmaf(mq, kl[k * 25 + i], keff[i]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* pt = prevt + (c * (CP_TR + 4) + ry) * PW + x;
+                float t = 0.f;
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) t = fmaf(keff[i * 5 + j], pt[i * PW + j], t);
+                const float pc = pt[2 * PW + 2];
+                o3[c] = mk[0] * pc + mk[1] * layer0[((size_t)b * 3 + c) * HW + p] + t;
+            }
+        } else if (MODE == 1) {
+            const float* th = aux + (size_t)b * 6;
+            const float xs = -1.0f + 2.0f * (float)x / (float)(W - 1);
+            const float ys = -1.0f + 2.0f * (float)y / (float)(H - 1);
+            float gu = th[0] * xs + th[1] * ys + th[2];
+            float gv = th[3] * xs + th[4] * ys + th[5];
+            if (!stp_zero) { gu = fminf(fmaxf(gu, -1.f), 1.f); gv = fminf(fmaxf(gv, -1.f), 1.f); }
+            const float u = (gu + 1.f) * (float)(W - 1) * 0.5f;
+            const float v = (gv + 1.f) * (float)(H - 1) * 0.5f;
+            float u0 = floorf(u), v0 = floorf(v);
+            if (!stp_zero) { u0 = fminf(fmaxf(u0, 0.f), (float)(W - 2)); v0 = fminf(fmaxf(v0, 0.f), (float)(H - 2)); }
+            const float wu1 = u - u0, wv1 = v - v0;
+            const int iu = (int)u0, iv = (int)v0;
+            float msum = 0.f;
+#pragma unroll
+            for (int q = 2; q < 12; ++q) msum += mk[q];   // mk[q >= NP] is 0
+            const float* pb = prev + (size_t)b * 3 * HW;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float t = 0.f;
+#pragma unroll
+                for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+                    for (int du = 0; du < 2; ++du) {
+                        const int uu = iu + du, vv = iv + dv;
+                        const float wgt = (dv ? wv1 : 1.f - wv1) * (du ? wu1 : 1.f - wu1);
+                        if ((unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H)
+                            t = fmaf(wgt, pb[(size_t)c * HW + vv * W + uu], t);
+                    }
+                o3[c] = mk[0] * pb[(size_t)c * HW + p] + mk[1] * layer0[((size_t)b * 3 + c) * HW + p] + msum * t;
+            }
+        } else {
+            float kn[25];
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 25; ++i) {
+                kn[i] = fmaxf(aux[((size_t)b * 25 + i) * HW + p] - 1e-12f, 0.f) + 1e-12f;
+                sum += kn[i];
+            }
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* pt = prevt + (c * (CP_TR + 4) + ry) * PW + x;
+                float t = 0.f;
+#pragma unroll
+                for (int xk = 0; xk < 5; ++xk)
+#pragma unroll
+                    for (int yk = 0; yk < 5; ++yk) {
+                        const bool ok = (y + xk < H) && (x + yk < W);   // TM:400 slice quirk
+                        t = fmaf(kn[xk * 5 + yk] * inv, ok ? pt[xk * PW + yk] : 0.f, t);
+                    }
+                o3[c] = mk[0] * pt[2 * PW + 2] + mk[1] * t;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[((size_t)b * 3 + c) * HW + p] = o3[c];
+    }
+}
+
+int composite(const float* prev, const float* mask_logits, const float* layer0, const float* aux,
+              float* out, float* masks_out, int B, int H, int W, int num_masks, int mode, int stp_zero_border,
+              hipStream_t s) {
+    PIVP_CHECK_ARG(prev && mask_logits && aux && out && B > 0 && H > 1 && W > 1 && num_masks >= 1 && num_masks <= 11);
+    PIVP_CHECK_ARG(mode >= 0 && mode <= 2 && (mode == 2 || layer0));
+    PIVP_CHECK_ARG(mode != 2 || num_masks == 1);   // TM:389-390
+    const int NP = num_masks + 1;
+    const int np = CP_TR * W;
+    const int win = np + 2 * (NP - 1);
+    const int G = np / NP + 2;
+    const size_t lds = sizeof(float) * ((size_t)NP * win + 2 * NP * G + 3 * (CP_TR + 4) * (W + 4) + num_masks * 25);
+    PIVP_CHECK_ARG(lds <= 160 * 1024);
+    dim3 grid((H + CP_TR - 1) / CP_TR, B);
+#define PIVP_LAUNCH_CP(M)                                                                                   \
+    do {                                                                                                    \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_kernel<M>),                            \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
+        hipLaunchKernelGGL((composite_kernel<M>), grid, dim3(256), lds, s, prev, mask_logits, layer0, aux,  \
+                           out, masks_out, H, W, num_masks, stp_zero_border);                               \
+    } while (0)
+    if (mode == 0) PIVP_LAUNCH_CP(0);
+    else if (mode == 1) PIVP_LAUNCH_CP(1);
+    else PIVP_LAUNCH_CP(2);
+#undef PIVP_LAUNCH_CP
+    return PIVP_LAUNCH_STATUS();
+}
+
+}  // namespace pivp

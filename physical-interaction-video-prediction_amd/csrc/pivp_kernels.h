@@ -1,0 +1,82 @@
+// Internal launcher interface between the C-ABI layer (pivp_c_api.hip) and the gfx950 kernels.
+// Internal data layout (DESIGN.md "Data layout in HBM"):
+//   * feature maps: NHWC fp32, `ld` = floats between consecutive pixels (lets a producer write
+//     straight into a channel slice of a skip-concat buffer; TM:569-576 never materialises a copy)
+//   * frames (prev image, generated image, mask logits, enc7): planar [B][planes][H*W] fp32, i.e.
+//     the reference's NCHW, because the flat-11 mask softmax (TM:720-722) and the per-plane 5x5 CDNA
+//     transform (TM:341) are defined on that order
+//   * conv / deconv weights: [tap][Cin][Cout]; Linear weights K-major; LN gamma/beta NHWC-flat.
+#pragma once
+#include "pivp_common.h"
+
+namespace pivp {
+
+constexpr int IG_MAX_TAPS = 32;
+
+struct IgemmDesc {
+    const float* x0; const float* x1;   // input sources (channel-concatenated: x0 then x1)
+    int c0, ld0, c1, ld1;
+    const float* w;                      // [wtaps][c0+c1][N]
+    const float* bias;                   // [N] or null
+    int B, Hin, Win;                     // input feature-map size
+    int Hg, Wg, in_step;                 // anchor grid; input coord = anchor*in_step + (dy,dx)
+    int N, M;                            // output columns; M = B*Hg*Wg
+    int nphase;
+    int tap_start[4], tap_count[4], oy0[4], ox0[4];
+    signed char dy[IG_MAX_TAPS], dx[IG_MAX_TAPS];
+    short wi[IG_MAX_TAPS];               // weight tap index of each entry
+    int out_step, Hout, Wout;            // output coord = anchor*out_step + (oy0,ox0)
+    float* out; int ldo; int relu;
+    // ConvLSTM epilogue
+    const float* cstate_in; float* cstate_out; float* hout; int C;
+};
+
+int igemm_lstm(const IgemmDesc& d, hipStream_t stream);
+int igemm_conv(const IgemmDesc& d, hipStream_t stream);
+
+// enc0: 5x5 stride-2 pad-2 conv on a planar 3-channel frame -> NHWC 32 channels (TM:500)
+int conv_enc0(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s);
+
+// LayerNorm over the flattened C*H*W vector of each sample with per-element gamma/beta (TM:203-208)
+int ln_stats_slices(int n);  // number of partial slices per sample for n elements
+int ln_stats(const float* x, float* partials, int B, int n, hipStream_t s);
+int ln_apply(const float* x, const float* partials, const float* gamma, const float* beta, float* out,
+             int B, int n, int C, int ldo, float eps, int relu, hipStream_t s);
+
+// enc3: smear(action,state) + 1x1 conv + ReLU (TM:556-567, TM:503) and the state predictor (TM:730)
+int enc3_state(const float* e2, const float* action, const float* state, const float* w3, const float* b3,
+               const float* wcs, const float* bcs, float* e3, float* state_out,
+               int B, int HW8, int use_state, hipStream_t s);
+
+// 1x1 heads on enc6: mask logits (relu) and enc7 (TM:288/315-317, TM:429/454-455, TM:364/387-388, TM:718-719)
+// enc7_mode: 0 = CDNA (relu; layer0 = sigmoid), 1 = STP (no relu; layer0 = sigmoid), 2 = DNA (relu; no layer0)
+int heads_1x1(const float* e6, const float* wm, const float* bm, const float* we, const float* be,
+              float* mask_logits, float* enc7, float* layer0, int B, int HW, int nmask_planes, int nenc7,
+              int enc7_mode, hipStream_t s);
+
+// CDNA kernel generator: Linear(hidden5) -> relu shift -> per-kernel normalisation (TM:321-329)
+int cdna_kernel_partials_slices(int K);
+int cdna_kernels(const float* hidden5, const float* wt, const float* bias, float* partials, float* kerns,
+                 int B, int K, int num_masks, hipStream_t s);
+
+// STP parameters: Linear -> relu -> shared Linear(6) + identity (TM:457-468)
+int stp_params(const float* hidden5, const float* wt1, const float* b1, const float* w2, const float* b2,
+               float* partials, float* theta, int B, int K, hipStream_t s);
+
+// flat-11 softmax + transform + compositing -> next frame (TM:720-728 with TM:341-349 / TM:469-470 / TM:392-415)
+// mode 0 = CDNA (kerns [B][num_masks][25]), 1 = STP (theta [B][6]), 2 = DNA (enc7 planes [B][25][HW])
+int composite(const float* prev, const float* mask_logits, const float* layer0, const float* aux,
+              float* out, float* masks_out, int B, int H, int W, int num_masks, int mode, int stp_zero_border,
+              hipStream_t s);
+
+// loss / PSNR (TM:737-759)
+int loss_partials_count(int n);
+int frame_sqerr_partials(const float* a, const float* b, float* partials, int n, hipStream_t s);
+int loss_finalize(const float* frame_partials, int nparts, int nframes, int frame_numel,
+                  const float* states_true, const float* states_gen, int state_numel,
+                  float denom, float* results, hipStream_t s);
+
+// planar NCHW <-> NHWC helpers for taps (conv_res) and tests
+int nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, int ld, hipStream_t s);
+
+}  // namespace pivp

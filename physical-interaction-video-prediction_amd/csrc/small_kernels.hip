@@ -1,0 +1,337 @@
+// HBM-bound helper kernels of the per-timestep program: enc0 conv, flattened-CHW LayerNorm,
+// enc3 (smear + 1x1) with the state predictor, loss / PSNR reductions, layout taps.
+// Reference call sites are cited per kernel ("TM" = src/models/train_model.py).
+#include "pivp_kernels.h"
+
+namespace pivp {
+
+// ------------------------------------------------------------------------------------------
+// enc0: L.Convolution2D(32, (5,5), stride=2, pad=2) on the 3-channel frame (TM:500, run at TM:595).
+// img planar [B][3][H][W]; w [75][32] with k = (ky*5+kx)*3 + ci; out NHWC [B][H/2][W/2][32].
+// 64 output pixels x (4 groups of 8 channels) per 256-thread block; weights live in LDS.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_enc0_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        int B, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float wl[75 * 32];
+    for (int i = threadIdx.x; i < 75 * 32; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const int H2 = H >> 1, W2 = W >> 1;
+    const int total = B * H2 * W2;
+    const int pix = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int cg = threadIdx.x & 3;
+    if (pix >= total) return;
+    const int b = pix / (H2 * W2);
+    const int rem = pix - b * H2 * W2;
+    const int oy = rem / W2, ox = rem - oy * W2;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = bias[cg * 8 + o];
+    const float* ib = img + (size_t)b * 3 * H * W;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+        const int iy = 2 * oy - 2 + ky;
+        if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+            const int ix = 2 * ox - 2 + kx;
+            if ((unsigned)ix >= (unsigned)W) continue;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const float v = ib[(size_t)ci * H * W + iy * W + ix];
+                const float* wr = wl + ((ky * 5 + kx) * 3 + ci) * 32 + cg * 8;
+#pragma unroll
+                for (int o = 0; o < 8; ++o) acc[o] = fmaf(v, wr[o], acc[o]);
+            }
+        }
+    }
+    float* op = out + (size_t)pix * 32 + cg * 8;
+    *reinterpret_cast<f32x4*>(op) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    *reinterpret_cast<f32x4*>(op + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+}
+
+int conv_enc0(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s) {
+    PIVP_CHECK_ARG(img && w && bias && out && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0);
+    const int total = B * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(conv_enc0_kernel, dim3((total + 63) / 64), dim3(256), 0, s, img, w, bias, out, B, H, W);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNormalizationConv2D (TM:203-208): LayerNorm over the flattened C*H*W vector of each sample,
+// gamma/beta of size C*H*W (here stored in NHWC-flat order to match the activations).
+// Two launches: per-slice (count, mean, M2) partials with a local two-pass (values stay in
+// registers), then an apply pass that merges the slices with Chan's formula.  Slices are 4096
+// floats so a B=32, n=32768 LayerNorm fills the chip with 256 blocks.
+// ------------------------------------------------------------------------------------------
+constexpr int LN_SLICE = 4096;
+
+int ln_stats_slices(int n) { return (n + LN_SLICE - 1) / LN_SLICE; }
+
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, float* __restrict__ partials, int n) {
+    __shared__ float red[4];
+    const int s = blockIdx.x, b = blockIdx.y, S = gridDim.x;
+    const float* xb = x + (size_t)b * n;
+    const int base = s * LN_SLICE;
+    const int cnt = min(LN_SLICE, n - base);
+    f32x4 v[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = (j * 256 + threadIdx.x) * 4;
+        if (i < cnt) {
+            v[j] = *reinterpret_cast<const f32x4*>(xb + base + i);
+            sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        } else {
+            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = block_sum<256>(sum, red) / (float)cnt;
+    float m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = (j * 256 + threadIdx.x) * 4;
+        if (i < cnt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float dd = v[j][e] - mean; m2 = fmaf(dd, dd, m2); }
+        }
+    }
+    m2 = block_sum<256>(m2, red);
+    if (threadIdx.x == 0) {
+        float* p = partials + ((size_t)b * S + s) * 4;
+        p[0] = (float)cnt; p[1] = mean; p[2] = m2; p[3] = 0.f;
+    }
+}
+
+int ln_stats(const float* x, float* partials, int B, int n, hipStream_t s) {
+    PIVP_CHECK_ARG(x && partials && B > 0 && n > 0 && n % 4 == 0);
+    hipLaunchKernelGGL(ln_stats_kernel, dim3(ln_stats_slices(n), B), dim3(256), 0, s, x, partials, n);
+    return PIVP_LAUNCH_STATUS();
+}
+
+__global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__ x, const float* __restrict__ partials,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ out, int n, int C, int ldo, float eps, int relu) {
+    __shared__ float stat[2];
+    const int s = blockIdx.x, b = blockIdx.y, S = gridDim.x;
+    if (threadIdx.x < 64) {
+        float cn = 0.f, mean = 0.f, m2 = 0.f;
+        for (int i = threadIdx.x; i < S; i += 64) {
+            const float* p = partials + ((size_t)b * S + i) * 4;
+            chan_combine(cn, mean, m2, p[0], p[1], p[2]);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float on = __shfl_xor(cn, off, 64), om = __shfl_xor(mean, off, 64), o2 = __shfl_xor(m2, off, 64);
+            // symmetric merge so both partners end with the same value
+            float a_n = cn, a_m = mean, a_2 = m2;
+            if ((threadIdx.x & off) == 0) { chan_combine(a_n, a_m, a_2, on, om, o2); }
+            else { a_n = on; a_m = om; a_2 = o2; chan_combine(a_n, a_m, a_2, cn, mean, m2); }
+            cn = a_n; mean = a_m; m2 = a_2;
+        }
+        if (threadIdx.x == 0) { stat[0] = mean; stat[1] = 1.0f / sqrtf(m2 / cn + eps); }
+    }
+    __syncthreads();
+    const float mean = stat[0], rstd = stat[1];
+    const float* xb = x + (size_t)b * n;
+    const int base = s * LN_SLICE;
+    const int cnt = min(LN_SLICE, n - base);
+    const size_t pix0 = (size_t)b * (n / C);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = (j * 256 + threadIdx.x) * 4;
+        if (i < cnt) {
+            const int idx = base + i;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xb + idx);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + idx);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(beta + idx);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = (v[e] - mean) * rstd * g[e] + be[e];
+                y[e] = relu ? fmaxf(t, 0.f) : t;
+            }
+            const int pix = idx / C, ch = idx - pix * C;
+            *reinterpret_cast<f32x4*>(out + (pix0 + pix) * ldo + ch) = y;
+        }
+    }
+}
+
+int ln_apply(const float* x, const float* partials, const float* gamma, const float* beta, float* out,
+             int B, int n, int C, int ldo, float eps, int relu, hipStream_t s) {
+    PIVP_CHECK_ARG(x && partials && gamma && beta && out && B > 0 && n > 0 && C > 0 && C % 4 == 0 && n % C == 0);
+    PIVP_CHECK_ARG(ldo >= C && ldo % 4 == 0);
+    hipLaunchKernelGGL(ln_apply_kernel, dim3(ln_stats_slices(n), B), dim3(256), 0, s,
+                       x, partials, gamma, beta, out, n, C, ldo, eps, relu);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
+// Group 3 of the op program (TM:598): smear(state_action) -> concat -> 1x1 conv (74 -> 64) -> ReLU.
+// Algebraically the tiled 10-vector only adds a per-sample bias W[:,64:74].sa, so nothing is
+// tiled or concatenated.  The same launch evaluates current_state = Linear(state_action) (TM:730).
+// e2/e3 NHWC [B][HW8][64]; w3 [64 (+10)][64] K-major; wcs reference layout (5,10).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void enc3_state_kernel(const float* __restrict__ e2, const float* __restrict__ action,
+                                                         const float* __restrict__ state, const float* __restrict__ w3,
+                                                         const float* __restrict__ b3, const float* __restrict__ wcs,
+                                                         const float* __restrict__ bcs, float* __restrict__ e3,
+                                                         float* __restrict__ state_out, int HW8, int use_state) {
+    __shared__ float xt[64 * 65];
+    __shared__ __attribute__((aligned(16))) float wl[64 * 64];
+    __shared__ float sb[64];
+    __shared__ float sa[10];
+    const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    if (tid < 5) sa[tid] = action[b * 5 + tid];
+    else if (tid < 10) sa[tid] = state[b * 5 + tid - 5];
+    for (int i = tid; i < 64 * 64; i += 256) wl[i] = w3[i];
+    const int npx = min(64, HW8 - tile * 64);
+    const float* src = e2 + ((size_t)b * HW8 + tile * 64) * 64;
+    for (int i = tid; i < 64 * 64; i += 256) {
+        const int p = i >> 6, k = i & 63;
+        xt[p * 65 + k] = p < npx ? src[i] : 0.f;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float v = b3[tid];
+        if (use_state) {
+#pragma unroll
+            for (int j = 0; j < 10; ++j) v = fmaf(sa[j], w3[(64 + j) * 64 + tid], v);
+        }
+        sb[tid] = v;
+    }
+    if (tile == 0 && tid >= 64 && tid < 69) {
+        const int o = tid - 64;
+        float v = bcs[o];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v = fmaf(wcs[o * 10 + j], sa[j], v);
+        state_out[b * 5 + o] = v;
+    }
+    __syncthreads();
+    const int p = tid >> 2, cg = tid & 3;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = sb[cg * 16 + o];
+    for (int k = 0; k < 64; ++k) {
+        const float xv = xt[p * 65 + k];
+        const f32x4* wr = reinterpret_cast<const f32x4*>(wl + k * 64 + cg * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 wv = wr[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[q * 4 + e] = fmaf(xv, wv[e], acc[q * 4 + e]);
+        }
+    }
+    if (p < npx) {
+        float* op = e3 + ((size_t)b * HW8 + tile * 64 + p) * 64 + cg * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(op + q * 4) = f32x4{fmaxf(acc[q * 4], 0.f), fmaxf(acc[q * 4 + 1], 0.f),
+                                                          fmaxf(acc[q * 4 + 2], 0.f), fmaxf(acc[q * 4 + 3], 0.f)};
+    }
+}
+
+int enc3_state(const float* e2, const float* action, const float* state, const float* w3, const float* b3,
+               const float* wcs, const float* bcs, float* e3, float* state_out,
+               int B, int HW8, int use_state, hipStream_t s) {
+    PIVP_CHECK_ARG(e2 && action && state && w3 && b3 && wcs && bcs && e3 && state_out && B > 0 && HW8 > 0);
+    hipLaunchKernelGGL(enc3_state_kernel, dim3((HW8 + 63) / 64, B), dim3(256), 0, s,
+                       e2, action, state, w3, b3, wcs, bcs, e3, state_out, HW8, use_state);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
+// Loss / PSNR (TM:737-759).  Deterministic two-stage reductions (no float atomics).
+// ------------------------------------------------------------------------------------------
+constexpr int LOSS_CHUNK = 8192;
+int loss_partials_count(int n) { return (n + LOSS_CHUNK - 1) / LOSS_CHUNK; }
+
+__global__ __launch_bounds__(256) void sqerr_partials_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             float* __restrict__ partials, int n) {
+    __shared__ float red[4];
+    const int base = blockIdx.x * LOSS_CHUNK;
+    float acc = 0.f;
+    for (int i = base + threadIdx.x * 4; i < min(n, base + LOSS_CHUNK); i += 1024) {
+        if (i + 3 < n) {
+            const f32x4 va = *reinterpret_cast<const f32x4*>(a + i), vb = *reinterpret_cast<const f32x4*>(b + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float dd = va[e] - vb[e]; acc = fmaf(dd, dd, acc); }
+        } else {
+            for (int e = i; e < n; ++e) { const float dd = a[e] - b[e]; acc = fmaf(dd, dd, acc); }
+        }
+    }
+    acc = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+int frame_sqerr_partials(const float* a, const float* b, float* partials, int n, hipStream_t s) {
+    PIVP_CHECK_ARG(a && b && partials && n > 0 && n % 4 == 0);
+    hipLaunchKernelGGL(sqerr_partials_kernel, dim3(loss_partials_count(n)), dim3(256), 0, s, a, b, partials, n);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// results: [0] loss, [1] psnr_all, [2..2+nf) recon_cost, [2+nf..2+2nf) psnr, [2+2nf..2+3nf) state_cost
+__global__ __launch_bounds__(64) void loss_finalize_kernel(const float* __restrict__ fp, int nparts, int nframes,
+                                                           int frame_numel, const float* __restrict__ st,
+                                                           const float* __restrict__ sg, int state_numel, float denom,
+                                                           float* __restrict__ results) {
+    float loss = 0.f, psnr_all = 0.f;
+    for (int f = 0; f < nframes; ++f) {
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < nparts; i += 64) acc += fp[f * nparts + i];
+        acc = wave_sum(acc);
+        const float mse = acc / (float)frame_numel;
+        const float psnr = 10.0f * logf(1.0f / mse) / 2.302585092994046f;
+        float sacc = 0.f;
+        for (int i = threadIdx.x; i < state_numel; i += 64) {
+            const float dd = st[f * state_numel + i] - sg[f * state_numel + i];
+            sacc = fmaf(dd, dd, sacc);
+        }
+        sacc = wave_sum(sacc);
+        const float scost = sacc / (float)state_numel * 1e-4f;
+        loss += mse + scost;
+        psnr_all += psnr;
+        if (threadIdx.x == 0) {
+            results[2 + f] = mse;
+            results[2 + nframes + f] = psnr;
+            results[2 + 2 * nframes + f] = scost;
+        }
+    }
+    if (threadIdx.x == 0) { results[0] = loss / denom; results[1] = psnr_all; }
+}
+
+int loss_finalize(const float* frame_partials, int nparts, int nframes, int frame_numel,
+                  const float* states_true, const float* states_gen, int state_numel,
+                  float denom, float* results, hipStream_t s) {
+    PIVP_CHECK_ARG(frame_partials && states_true && states_gen && results && nparts > 0 && nframes >= 0 && denom != 0.f);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, frame_partials, nparts, nframes, frame_numel,
+                       states_true, states_gen, state_numel, denom, results);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
+// NHWC (pixel stride ld) -> planar NCHW, for the conv_res taps (TM:734) and tests.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           int C, int HW, int ld) {
+    __shared__ float t[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        t[r][tx] = (p < HW && c < C) ? in[((size_t)b * HW + p) * ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (c < C && p < HW) out[((size_t)b * C + c) * HW + p] = t[tx][r];
+    }
+}
+
+int nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, int ld, hipStream_t s) {
+    PIVP_CHECK_ARG(in && out && B > 0 && C > 0 && HW > 0 && ld >= C);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, s, in, out, C, HW, ld);
+    return PIVP_LAUNCH_STATUS();
+}
+
+}  // namespace pivp

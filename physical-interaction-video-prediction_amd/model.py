@@ -1,0 +1,393 @@
+"""Host-side mirror of the reference's `Model` (src/models/train_model.py:478-764, "TM").
+
+Same constructor, call, `reset_state()` and attribute surface:
+    model = Model(num_masks, is_cdna=True, is_dna=False, is_stp=False, use_state=True,
+                  scheduled_sampling_k=-1, num_frame_before_prediction=2, prefix=None)
+    loss = model([images, actions, states], iter_num)      # time-major, NCHW float32 frames in [0,1]
+    model.gen_images, model.psnr_all, model.summaries, model.conv_res, model.loss
+    model.reset_state()
+All arithmetic runs in the gfx950 HIP library behind include/pivp_hip.h; PyTorch supplies device
+memory and the stream only.  There is no CPU fallback: without the built library or without a
+GPU the call raises.
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import checkpoint as ckpt
+
+
+class _Config(object):
+    """Stand-in for chainer.config: only the `train` flag matters on this path (TM:649)."""
+    train = True
+
+
+config = _Config()
+
+
+@contextlib.contextmanager
+def using_config(name, value):
+    """chainer.using_config equivalent (used as `with using_config('train', False)`, predict_model.py:126)."""
+    old = getattr(config, name)
+    setattr(config, name, value)
+    try:
+        yield
+    finally:
+        setattr(config, name, old)
+
+
+LSTM_SIZES = OrderedDict(lstm1=(32, 32), lstm2=(32, 32), lstm3=(32, 64), lstm4=(64, 64),
+                         lstm5=(64, 128), lstm6=(128, 64), lstm7=(96, 32))   # name -> (x channels, C); TM:509-515
+
+
+def reference_param_shapes(num_masks, model_type, use_state, height, width):
+    """Key -> shape in the reference's Chainer npz layout (TM:499-542)."""
+    h2, w2, h4, w4, h8, w8 = height // 2, width // 2, height // 4, width // 4, height // 8, width // 8
+    s = OrderedDict()
+    s['enc0/W'] = (32, 3, 5, 5); s['enc0/b'] = (32,)
+    s['enc1/W'] = (32, 32, 3, 3); s['enc1/b'] = (32,)
+    s['enc2/W'] = (64, 64, 3, 3); s['enc2/b'] = (64,)
+    s['enc3/W'] = (64, 64 + (10 if use_state else 0), 1, 1); s['enc3/b'] = (64,)
+    s['enc4/W'] = (128, 128, 3, 3); s['enc4/b'] = (128,)
+    s['enc5/W'] = (96, 96, 3, 3); s['enc5/b'] = (96,)
+    s['enc6/W'] = (64, 64, 3, 3); s['enc6/b'] = (64,)
+    for name, (cx, c) in LSTM_SIZES.items():
+        s[name + '/conv/W'] = (4 * c, cx + c, 5, 5)
+        s[name + '/conv/b'] = (4 * c,)
+    ln = OrderedDict(norm_enc0=32 * h2 * w2, hidden1=32 * h2 * w2, hidden2=32 * h2 * w2, hidden3=64 * h4 * w4,
+                     hidden4=64 * h4 * w4, hidden5=128 * h8 * w8, hidden6=64 * h4 * w4, hidden7=32 * h2 * w2,
+                     norm_enc6=64 * height * width)
+    for name, n in ln.items():
+        s[name + '/norm/gamma'] = (n,)
+        s[name + '/norm/beta'] = (n,)
+    s['masks/W'] = (64, num_masks + 1, 1, 1); s['masks/b'] = (num_masks + 1,)
+    s['current_state/W'] = (5, 10); s['current_state/b'] = (5,)
+    if model_type == 'CDNA':
+        s['model/enc7/W'] = (64, 3, 1, 1); s['model/enc7/b'] = (3,)
+        s['model/cdna_kerns/W'] = (25 * num_masks, 128 * h8 * w8); s['model/cdna_kerns/b'] = (25 * num_masks,)
+    elif model_type == 'STP':
+        s['model/enc7/W'] = (64, 3, 1, 1); s['model/enc7/b'] = (3,)
+        s['model/stp_input/W'] = (100, 128 * h8 * w8); s['model/stp_input/b'] = (100,)
+        s['model/identity_params/W'] = (6, 100); s['model/identity_params/b'] = (6,)
+    else:
+        s['model/enc7/W'] = (64, 25, 1, 1); s['model/enc7/b'] = (25,)
+    return s
+
+
+def default_init(shapes, rng=None):
+    """Chainer 2 defaults: LeCunNormal W (std sqrt(1/fan_in)), zero bias, LN gamma 1 / beta 0."""
+    rng = np.random if rng is None else rng
+    out = OrderedDict()
+    for key, shape in shapes.items():
+        if key.endswith('/W'):
+            fan_in = shape[1] if len(shape) == 2 else shape[1] * shape[2] * shape[3]
+            out[key] = (rng.standard_normal(shape) * math.sqrt(1.0 / fan_in)).astype(np.float32)
+        elif key.endswith('/gamma'):
+            out[key] = np.ones(shape, np.float32)
+        else:
+            out[key] = np.zeros(shape, np.float32)
+    return out
+
+
+def scheduled_sampling_masks(batch_size, seq_len, context_frames, k, iter_num, rng=None):
+    """Per-step ground-truth selection of the reference's scheduled sampling (TM:654-656, TM:73-122).
+
+    Returns uint8 [T-1][B]; one `shuffle(arange(B))` is drawn from NumPy's global RNG per step that
+    the reference would call scheduled_sample for (t >= context_frames), in the same order."""
+    rng = np.random if rng is None else rng
+    ngt = int(np.int32(np.round(np.float32(batch_size) * (k / (k + np.exp(iter_num / k))))))
+    mask = np.zeros((seq_len - 1, batch_size), np.uint8)
+    for t in range(seq_len - 1):
+        if t > context_frames - 1:
+            idx = np.arange(int(batch_size))
+            rng.shuffle(idx)
+            mask[t, idx[:ngt]] = 1
+    return mask
+
+
+class _Plan(object):
+    def __init__(self, lib, cfg):
+        self.lib = lib
+        self.cfg = cfg
+        h = ctypes.c_void_p()
+        _lib.check(lib.pivp_plan_create(ctypes.byref(cfg), ctypes.byref(h)), 'pivp_plan_create')
+        self.h = h
+        self.names = [lib.pivp_param_name(h, i).decode() for i in range(lib.pivp_param_count(h))]
+        self.numel = [lib.pivp_param_numel(h, i) for i in range(len(self.names))]
+        self.workspace = None
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.pivp_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class Model(object):
+    """MI355X drop-in for the reference's `Model` (TM:478-764)."""
+
+    def __init__(self, num_masks, is_cdna=True, is_dna=False, is_stp=False, use_state=True,
+                 scheduled_sampling_k=-1, num_frame_before_prediction=2, prefix=None,
+                 device='cuda:0', ln_eps=1e-6, stp_border='clamp', keep_activations=False):
+        if is_cdna:                      # TM:531-542, precedence cdna > stp > dna
+            self.model_type = 'CDNA'
+        elif is_stp:
+            self.model_type = 'STP'
+        elif is_dna:
+            self.model_type = 'DNA'
+        else:
+            raise ValueError("No network specified")
+        self.num_masks = num_masks
+        self.use_state = use_state
+        self.scheduled_sampling_k = scheduled_sampling_k
+        self.num_frame_before_prediction = num_frame_before_prediction
+        self.prefix = prefix
+        self.device = torch.device(device)
+        self.ln_eps = float(ln_eps)
+        if stp_border not in ('clamp', 'zeros'):
+            raise ValueError("stp_border must be 'clamp' or 'zeros'")
+        self.stp_border = stp_border
+        self.keep_activations = bool(keep_activations)
+        self._ref_pending = None       # reference-layout arrays loaded before the first call
+        self._params = None            # name -> flat device tensor, internal layout
+        self._hw = None
+        self._plans = {}
+        self._active = None
+        self._results = None
+        self._gen = None
+        self.gen_states = None
+        self.loss = 0.0
+        self.psnr_all = 0.0
+        self.gen_images = []
+
+    # ---- parameters ---------------------------------------------------------------------
+    def _shapes(self):
+        H, W = self._hw
+        return reference_param_shapes(self.num_masks, self.model_type, self.use_state, H, W)
+
+    def _require_gpu(self):
+        if not torch.cuda.is_available():
+            raise RuntimeError('no MI355X visible: this path has no CPU fallback (torch.cuda.is_available() is False)')
+        return _lib.load()
+
+    def _ensure_params(self, H, W):
+        if self._params is not None:
+            if self._hw != (H, W):
+                # TM:186-208 / quirk 3: lazily sized LN gamma/beta weld a model to one frame size
+                raise ValueError('model was sized for %dx%d frames, got %dx%d' % (self._hw + (H, W)))
+            return
+        self._hw = (H, W)
+        shapes = self._shapes()
+        ref = self._ref_pending if self._ref_pending is not None else default_init(shapes)
+        self._ref_pending = None
+        self._upload(ref, shapes)
+
+    def _upload(self, ref, shapes):
+        params = OrderedDict()
+        for key, shape in shapes.items():
+            if key not in ref:
+                raise KeyError('checkpoint is missing %r' % key)
+            a = np.asarray(ref[key])
+            if tuple(a.shape) != tuple(shape):
+                raise ValueError('%s: expected shape %s, got %s' % (key, shape, a.shape))
+            params[key] = torch.from_numpy(ckpt.to_internal(key, a)).to(self.device)
+        self._params = params
+        for plan in self._plans.values():
+            self._bind(plan)
+
+    def load_state_dict_reference(self, ref):
+        """Load arrays in the reference's Chainer-npz layout (chainer.serializers.load_npz target)."""
+        ref = {k: np.asarray(v) for k, v in ref.items()}
+        if self._hw is None:
+            self._ref_pending = ref
+        else:
+            self._require_gpu()
+            self._upload(ref, self._shapes())
+
+    def state_dict_reference(self):
+        """Parameters in the reference's Chainer-npz layout (what save_npz would write)."""
+        if self._params is None:
+            if self._ref_pending is not None:
+                return OrderedDict(self._ref_pending)
+            raise RuntimeError('parameters are lazily sized from the first input (as in the reference); call the model first')
+        out = OrderedDict()
+        for key, shape in self._shapes().items():
+            out[key] = ckpt.from_internal(key, self._params[key].cpu().numpy(), shape)
+        return out
+
+    def count_params(self):
+        return sum(int(np.prod(s)) for s in self._shapes().values())
+
+    # ---- plans --------------------------------------------------------------------------
+    def _bind(self, plan):
+        lib = plan.lib
+        for i, (name, n) in enumerate(zip(plan.names, plan.numel)):
+            t = self._params[name]
+            if t.numel() != n:
+                raise ValueError('%s: internal size %d != library size %d' % (name, t.numel(), n))
+            _lib.check(lib.pivp_plan_set_param(plan.h, i, t.data_ptr()), 'pivp_plan_set_param(%s)' % name)
+
+    def _plan_for(self, B, T, H, W):
+        key = (B, T, H, W, self.keep_activations)
+        plan = self._plans.get(key)
+        if plan is None:
+            lib = self._require_gpu()
+            cfg = _lib.PivpConfig(batch=B, seq_len=T, height=H, width=W, num_masks=self.num_masks,
+                                  model_type={'CDNA': 0, 'STP': 1, 'DNA': 2}[self.model_type],
+                                  use_state=1 if self.use_state else 0,
+                                  context_frames=self.num_frame_before_prediction,
+                                  keep_activations=1 if self.keep_activations else 0,
+                                  ln_eps=self.ln_eps, stp_zero_border=1 if self.stp_border == 'zeros' else 0)
+            plan = _Plan(lib, cfg)
+            nbytes = lib.pivp_plan_workspace_bytes(plan.h)
+            plan.workspace = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.device)
+            base = plan.workspace.data_ptr()
+            aligned = (base + 255) // 256 * 256
+            _lib.check(lib.pivp_plan_set_workspace(plan.h, aligned, nbytes), 'pivp_plan_set_workspace')
+            self._bind(plan)
+            self._plans[key] = plan
+            self._reset_plan(plan)
+        return plan
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _reset_plan(self, plan):
+        _lib.check(plan.lib.pivp_reset_state(plan.h, self._stream()), 'pivp_reset_state')
+
+    # ---- reference surface ----------------------------------------------------------------
+    def reset_state(self):
+        """TM:604-618: clears loss/PSNR/summaries/conv_res and the seven ConvLSTM (c, h) pairs."""
+        self.loss = 0.0
+        self.psnr_all = 0.0
+        self._results = None
+        if self._active is not None:
+            self._reset_plan(self._active)
+
+    def to_gpu(self, device=None):
+        if device is not None:
+            self.device = torch.device('cuda:%d' % device if isinstance(device, int) else device)
+        return self
+
+    def _as_device(self, a, shape_tail):
+        if isinstance(a, (list, tuple)):
+            a = torch.stack([x if torch.is_tensor(x) else torch.from_numpy(np.asarray(x, dtype=np.float32)) for x in a])
+        elif not torch.is_tensor(a):
+            a = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32)))
+        a = a.to(device=self.device, dtype=torch.float32).contiguous()
+        if tuple(a.shape[-len(shape_tail):]) != tuple(shape_tail) and shape_tail:
+            raise ValueError('unexpected trailing shape %s' % (tuple(a.shape),))
+        return a
+
+    def __call__(self, x, iter_num=-1.0):
+        """TM:620-764.  x = [images (T,B,3,H,W), actions (T,B,5), states (T,B,5)], time-major."""
+        if len(x) > 1:
+            images, actions, states = x
+        else:
+            images, actions, states = x[0], None, None
+        if actions is None or states is None:
+            # the reference dereferences states[0] (TM:646) and fails the same way
+            raise TypeError("'NoneType' object is not subscriptable")
+        with torch.cuda.device(self.device) if torch.cuda.is_available() else contextlib.nullcontext():
+            self._require_gpu()
+            images = self._as_device(images, ())
+            if images.dim() != 5 or images.shape[2] != 3:
+                raise ValueError('images must be time-major (T, B, 3, H, W)')
+            T, B, _, H, W = images.shape
+            actions = self._as_device(actions, (5,))
+            states = self._as_device(states, (5,))
+            self._ensure_params(H, W)
+            plan = self._plan_for(B, T, H, W)
+            self._active = plan
+            ctx = self.num_frame_before_prediction
+            # feed-self when not training or k == -1 (TM:649-657)
+            gt_ptr = None
+            if config.train and self.scheduled_sampling_k != -1:
+                mask = scheduled_sampling_masks(B, T, ctx, self.scheduled_sampling_k, iter_num)
+                self._gt_mask = torch.from_numpy(mask).to(self.device)
+                gt_ptr = self._gt_mask.data_ptr()
+            gen = torch.empty((T - 1, B, 3, H, W), dtype=torch.float32, device=self.device)
+            gen_states = torch.empty((T - 1, B, 5), dtype=torch.float32, device=self.device)
+            nf = T - ctx
+            results = torch.empty(2 + 3 * nf, dtype=torch.float32, device=self.device)
+            _lib.check(plan.lib.pivp_rollout_forward(plan.h, images.data_ptr(), actions.data_ptr(), states.data_ptr(),
+                                                     gt_ptr, gen.data_ptr(), gen_states.data_ptr(), results.data_ptr(),
+                                                     self._stream()), 'pivp_rollout_forward')
+            self._inputs = (images, actions, states)   # keep alive until the stream has consumed them
+            self._gen = gen
+            self._results = results
+            self._nf = nf
+            self.gen_images = [gen[t] for t in range(T - 1)]
+            self.gen_states = [gen_states[t] for t in range(T - 1)]
+            self.loss = results[0]
+            self.psnr_all = results[1]
+        return self.loss
+
+    @property
+    def summaries(self):
+        """TM:744-759: strings '<prefix>_recon_cost<i>: v', '_psnr<i>', '_state_cost<i>', '_psnr_all', '_loss'."""
+        if self._results is None:
+            return []
+        r = self._results.cpu().numpy()
+        nf = self._nf
+        p = str(self.prefix)
+        out = []
+        for i in range(nf):
+            out.append(p + '_recon_cost' + str(i) + ': ' + str(r[2 + i]))
+            out.append(p + '_psnr' + str(i) + ': ' + str(r[2 + nf + i]))
+        for i in range(nf):
+            out.append(p + '_state_cost' + str(i) + ': ' + str(r[2 + 2 * nf + i]))
+        out.append(p + '_psnr_all: ' + str(r[1]))
+        out.append(p + '_loss: ' + str(r[0]))
+        return out
+
+    def tap(self, name, step=None):
+        """Activation of a timestep, planar NCHW like the reference's encs/hiddens (TM:703-708)."""
+        plan = self._active
+        if plan is None or self._results is None:
+            raise RuntimeError('call the model first')
+        cfg = plan.cfg
+        T1 = cfg.seq_len - 1
+        step = T1 - 1 if step is None else step
+        H, W, B = cfg.height, cfg.width, cfg.batch
+        lv = {'enc0': (32, 2), 'enc1': (32, 4), 'enc2': (64, 8), 'enc3': (64, 8), 'enc4': (128, 4), 'enc5': (96, 2),
+              'enc6': (64, 1), 'hidden1': (32, 2), 'hidden2': (32, 2), 'hidden3': (64, 4), 'hidden4': (64, 4),
+              'hidden5': (128, 8), 'hidden6': (64, 4), 'hidden7': (32, 2)}
+        for i, (nm, (_, c)) in enumerate(LSTM_SIZES.items()):
+            d = [2, 2, 4, 4, 8, 4, 2][i]
+            lv[nm + '_h'] = (c, d); lv[nm + '_c'] = (c, d)
+        if name in lv:
+            C, d = lv[name]
+            shape = (B, C, H // d, W // d)
+        elif name == 'enc7':
+            shape = (B, 25 if self.model_type == 'DNA' else 3, H, W)
+        elif name == 'masks':
+            shape = (B, self.num_masks + 1, H, W)
+        elif name == 'cdna_kerns':
+            shape = (B, self.num_masks, 5, 5)
+        elif name == 'stp_theta':
+            shape = (B, 2, 3)
+        else:
+            raise KeyError(name)
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        n = plan.lib.pivp_get_tap(plan.h, name.encode(), step, out.data_ptr(), self._stream())
+        if n < 0:
+            _lib.check(int(n), 'pivp_get_tap(%s, %d)' % (name, step))
+        assert n == out.numel()
+        return out
+
+    @property
+    def conv_res(self):
+        """TM:715, TM:734: [enc0..enc6, enc7] of the LAST timestep."""
+        if self._results is None:
+            return []
+        return [self.tap(n) for n in ('enc0', 'enc1', 'enc2', 'enc3', 'enc4', 'enc5', 'enc6', 'enc7')]

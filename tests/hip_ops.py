@@ -1,0 +1,169 @@
+"""NumPy-in / NumPy-out wrappers around the per-op C-ABI entry points, for the GPU parity tests.
+Inputs and outputs use the reference's NCHW layouts; the wrappers do the NHWC permutations."""
+import numpy as np
+import torch
+
+import pivp_amd
+from pivp_amd import _lib
+
+DEV = 'cuda:0'
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).to(DEV)
+
+
+def nhwc(a):            # (B,C,H,W) -> device NHWC
+    return _t(np.asarray(a).transpose(0, 2, 3, 1))
+
+
+def nchw(t, B, H, W, C):
+    return t.cpu().numpy().reshape(B, H, W, C).transpose(0, 3, 1, 2)
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def convlstm(x, h, c, W, b):
+    lib = _lib.load()
+    B, cx, H, Wd = x.shape
+    C = h.shape[1]
+    xd, hd, cd = nhwc(x), nhwc(h), nhwc(c)
+    wd, bd = _t(pivp_amd.to_internal('lstm1/conv/W', W)), _t(b)
+    c_out = torch.empty_like(cd); h_out = torch.empty_like(hd)
+    _lib.check(lib.pivp_convlstm(xd.data_ptr(), cx, cx, hd.data_ptr(), C, wd.data_ptr(), bd.data_ptr(), cd.data_ptr(),
+                                 c_out.data_ptr(), h_out.data_ptr(), B, H, Wd, stream()), 'convlstm')
+    torch.cuda.synchronize()
+    return nchw(h_out, B, H, Wd, C), nchw(c_out, B, H, Wd, C)
+
+
+def conv3x3s2(x, W, b, relu):
+    lib = _lib.load()
+    B, cin, H, Wd = x.shape
+    cout = W.shape[0]
+    xd, wd, bd = nhwc(x), _t(pivp_amd.to_internal('enc1/W', W)), _t(b)
+    out = torch.empty((B, H // 2, Wd // 2, cout), dtype=torch.float32, device=DEV)
+    _lib.check(lib.pivp_conv3x3s2(xd.data_ptr(), cin, cin, wd.data_ptr(), bd.data_ptr(), out.data_ptr(), cout, cout,
+                                  int(relu), B, H, Wd, stream()), 'conv3x3s2')
+    torch.cuda.synchronize()
+    return nchw(out, B, H // 2, Wd // 2, cout)
+
+
+def deconv3x3s2(x, W, b, relu):
+    lib = _lib.load()
+    B, cin, H, Wd = x.shape
+    cout = W.shape[1]
+    xd, wd, bd = nhwc(x), _t(pivp_amd.to_internal('enc4/W', W)), _t(b)
+    out = torch.empty((B, 2 * H, 2 * Wd, cout), dtype=torch.float32, device=DEV)
+    _lib.check(lib.pivp_deconv3x3s2(xd.data_ptr(), cin, cin, wd.data_ptr(), bd.data_ptr(), out.data_ptr(), cout, cout,
+                                    int(relu), B, H, Wd, stream()), 'deconv3x3s2')
+    torch.cuda.synchronize()
+    return nchw(out, B, 2 * H, 2 * Wd, cout)
+
+
+def conv_enc0(img, W, b):
+    lib = _lib.load()
+    B, _, H, Wd = img.shape
+    out = torch.empty((B, H // 2, Wd // 2, 32), dtype=torch.float32, device=DEV)
+    imgd, wd, bd = _t(img), _t(pivp_amd.to_internal('enc0/W', W)), _t(b)
+    _lib.check(lib.pivp_conv_enc0(imgd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, Wd, stream()), 'enc0')
+    torch.cuda.synchronize()
+    return nchw(out, B, H // 2, Wd // 2, 32)
+
+
+def layernorm(x, gamma, beta, eps, relu, name='hidden1'):
+    lib = _lib.load()
+    B, C, H, Wd = x.shape
+    n = C * H * Wd
+    xd = nhwc(x)
+    perm = lambda v: _t(np.asarray(v).reshape(C, H * Wd).T)
+    gd, bd = perm(gamma), perm(beta)
+    out = torch.empty_like(xd)
+    scratch = torch.empty(lib.pivp_layernorm_scratch_floats(B, n), dtype=torch.float32, device=DEV)
+    _lib.check(lib.pivp_layernorm(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), out.data_ptr(), scratch.data_ptr(),
+                                  B, n, C, C, eps, int(relu), stream()), 'layernorm')
+    torch.cuda.synchronize()
+    return nchw(out, B, H, Wd, C)
+
+
+def enc3_state(e2, action, state, W3, b3, Wcs, bcs, use_state=True):
+    lib = _lib.load()
+    B, _, H, Wd = e2.shape
+    e2d = nhwc(e2)
+    out = torch.empty_like(e2d)
+    st = torch.empty((B, 5), dtype=torch.float32, device=DEV)
+    args = [_t(action), _t(state), _t(pivp_amd.to_internal('enc3/W', W3)), _t(b3), _t(Wcs), _t(bcs)]
+    _lib.check(lib.pivp_enc3_state(e2d.data_ptr(), *[a.data_ptr() for a in args], out.data_ptr(), st.data_ptr(),
+                                   B, H * Wd, int(use_state), stream()), 'enc3_state')
+    torch.cuda.synchronize()
+    return nchw(out, B, H, Wd, 64), st.cpu().numpy()
+
+
+def heads(e6, Wm, bm, We, be, num_masks, model_type):
+    lib = _lib.load()
+    B, _, H, Wd = e6.shape
+    NP, NE = num_masks + 1, We.shape[1]
+    e6d = nhwc(e6)
+    logits = torch.empty((B, NP, H, Wd), dtype=torch.float32, device=DEV)
+    enc7 = torch.empty((B, NE, H, Wd), dtype=torch.float32, device=DEV)
+    layer0 = torch.empty((B, 3, H, Wd), dtype=torch.float32, device=DEV)
+    args = [_t(pivp_amd.to_internal('masks/W', Wm)), _t(bm), _t(pivp_amd.to_internal('model/enc7/W', We)), _t(be)]
+    _lib.check(lib.pivp_heads(e6d.data_ptr(), *[a.data_ptr() for a in args], logits.data_ptr(), enc7.data_ptr(),
+                              layer0.data_ptr(), B, H * Wd, num_masks, model_type, stream()), 'heads')
+    torch.cuda.synchronize()
+    return logits.cpu().numpy(), enc7.cpu().numpy(), layer0.cpu().numpy()
+
+
+def cdna_kernels(hidden5, W, b, num_masks):
+    lib = _lib.load()
+    B, C, H, Wd = hidden5.shape
+    K = C * H * Wd
+    hd = nhwc(hidden5)
+    wd, bd = _t(pivp_amd.to_internal('model/cdna_kerns/W', W)), _t(b)
+    scratch = torch.empty(lib.pivp_linear_scratch_floats(B, K), dtype=torch.float32, device=DEV)
+    kern = torch.empty((B, num_masks, 5, 5), dtype=torch.float32, device=DEV)
+    _lib.check(lib.pivp_cdna_kernels(hd.data_ptr(), wd.data_ptr(), bd.data_ptr(), scratch.data_ptr(), kern.data_ptr(),
+                                     B, K, num_masks, stream()), 'cdna_kernels')
+    torch.cuda.synchronize()
+    return kern.cpu().numpy()
+
+
+def stp_params(hidden5, W1, b1, W2, b2):
+    lib = _lib.load()
+    B, C, H, Wd = hidden5.shape
+    K = C * H * Wd
+    hd = nhwc(hidden5)
+    args = [_t(pivp_amd.to_internal('model/stp_input/W', W1)), _t(b1), _t(W2), _t(b2)]
+    scratch = torch.empty(lib.pivp_linear_scratch_floats(B, K), dtype=torch.float32, device=DEV)
+    theta = torch.empty((B, 6), dtype=torch.float32, device=DEV)
+    _lib.check(lib.pivp_stp_params(hd.data_ptr(), *[a.data_ptr() for a in args], scratch.data_ptr(), theta.data_ptr(),
+                                   B, K, stream()), 'stp_params')
+    torch.cuda.synchronize()
+    return theta.cpu().numpy()
+
+
+def composite(prev, logits, layer0, aux, num_masks, model_type, stp_zero=0):
+    lib = _lib.load()
+    B, _, H, Wd = prev.shape
+    pd, ld, ad = _t(prev), _t(logits), _t(aux)
+    l0 = _t(layer0) if layer0 is not None else None
+    out = torch.empty((B, 3, H, Wd), dtype=torch.float32, device=DEV)
+    masks = torch.empty((B, num_masks + 1, H, Wd), dtype=torch.float32, device=DEV)
+    _lib.check(lib.pivp_composite(pd.data_ptr(), ld.data_ptr(), l0.data_ptr() if l0 is not None else None, ad.data_ptr(),
+                                  out.data_ptr(), masks.data_ptr(), B, H, Wd, num_masks, model_type, stp_zero, stream()),
+               'composite')
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), masks.cpu().numpy()
+
+
+def select_frames(gt, gen, take):
+    lib = _lib.load()
+    B = gt.shape[0]
+    g, p = _t(gt), _t(gen)
+    tk = torch.from_numpy(np.asarray(take, dtype=np.uint8)).to(DEV)
+    out = torch.empty_like(g)
+    _lib.check(lib.pivp_select_frames(g.data_ptr(), p.data_ptr(), tk.data_ptr(), out.data_ptr(), B, g[0].numel(), stream()),
+               'select_frames')
+    torch.cuda.synchronize()
+    return out.cpu().numpy()

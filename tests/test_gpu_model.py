@@ -1,0 +1,159 @@
+"""GPU parity tests of the whole rollout through the reference's Model surface, against the
+committed golden fixtures (float64 oracle) and against the oracle run live on small cases.
+Gate: max per-pixel L2 over the colour axis < 1e-4 in fp32."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import restatement as R
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+GATE = 1e-4
+
+
+@pytest.fixture(scope='module')
+def pivp():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need the MI355X'
+    import pivp_amd
+    return pivp_amd
+
+
+def _run(pivp, mt, nm, imgs, acts, stas, P, train=False, k=-1, it=0, **kw):
+    import torch
+    m = pivp.Model(nm, is_cdna=mt == 'CDNA', is_stp=mt == 'STP', is_dna=mt == 'DNA', prefix='test',
+                   scheduled_sampling_k=k, **kw)
+    m.load_state_dict_reference(P)
+    with pivp.using_config('train', train):
+        loss = m([imgs, acts, stas], it)
+    return m, float(loss), torch.stack(m.gen_images).cpu().numpy()
+
+
+@pytest.mark.parametrize('name,mt,nm', [('cdna_b2_t10', 'CDNA', 10), ('stp_b2_t4', 'STP', 10), ('dna_b2_t4', 'DNA', 1)])
+def test_rollout_matches_golden(pivp, name, mt, nm):
+    g = np.load(os.path.join(GOLD, name + '.npz'))
+    B, T = int(g['batch']), int(g['seq_len'])
+    P = R.init_params(seed=1, dtype=np.float32, scale=1.0, num_masks=nm, model_type=mt)
+    imgs, acts, stas = R.synthetic_batch(B, T)
+    m, loss, gen = _run(pivp, mt, nm, imgs, acts, stas, P)
+    l2 = R.per_pixel_l2(gen, g['gen_images'])
+    print('%s: max per-pixel L2 %.3e, rms %.3e, loss %.8f vs %.8f' % (name, l2.max(), np.sqrt((l2 ** 2).mean()), loss, float(g['loss'])))
+    assert l2.max() < GATE
+    assert abs(loss - float(g['loss'])) < 1e-5
+    assert abs(float(m.psnr_all) - float(g['psnr_all'])) < 1e-2
+    import torch
+    gs = torch.stack(m.gen_states).cpu().numpy()
+    assert np.abs(gs - g['gen_states']).max() < 1e-5
+    # last-step taps (T-2) against the fixture's strided samples
+    last = T - 2
+    for tap in ('enc0', 'enc1', 'enc2', 'enc3', 'enc4', 'enc5', 'enc6', 'enc7', 'hidden5', 'masks'):
+        key = 'tap%d_%s' % (last, tap)
+        if key in g.files:
+            got = m.tap(tap).cpu().numpy().ravel()[::97]
+            assert np.abs(got - g[key]).max() < 5e-4, tap
+    res = m.conv_res
+    assert len(res) == 8 and tuple(res[6].shape) == (B, 64, 64, 64)
+    summ = m.summaries
+    assert len(summ) == 3 * (T - 2) + 2 and summ[0].startswith('test_recon_cost0: ') and summ[-1].startswith('test_loss: ')
+
+
+def test_default_init_runs_and_reset_state(pivp):
+    import torch
+    imgs, acts, stas = R.synthetic_batch(2, 4)
+    np.random.seed(3)
+    m = pivp.Model(10, prefix='x')
+    with pivp.using_config('train', False):
+        l1 = float(m([imgs, acts, stas], 0))
+        g1 = torch.stack(m.gen_images).clone()
+        m.reset_state()
+        assert m.loss == 0.0 and m.psnr_all == 0.0 and m.summaries == [] and m.conv_res == []
+        l2 = float(m([imgs, acts, stas], 0))
+        g2 = torch.stack(m.gen_images)
+    assert l1 == l2 and torch.equal(g1, g2)                  # deterministic, state fully reset
+    assert m.count_params() == 9212159
+    assert np.isfinite(l1)
+
+
+def test_checkpoint_roundtrip_reference_layout(pivp, tmp_path):
+    import torch
+    P = R.init_params(seed=5, dtype=np.float32, scale=1.0)
+    imgs, acts, stas = R.synthetic_batch(2, 3)
+    m, loss, gen = _run(pivp, 'CDNA', 10, imgs, acts, stas, P)
+    path = str(tmp_path / 'training-0')                      # the reference writes files without extension (TM:1035)
+    pivp.save_npz(path, m)
+    with np.load(path) as z:
+        assert sorted(z.files) == sorted(P.keys())
+        for k in P:
+            assert z[k].shape == P[k].shape and np.array_equal(z[k], P[k]), k
+    m2 = pivp.Model(10, prefix='test')
+    pivp.load_npz(path, m2)                                  # before the first call: lazily bound like chainer
+    with pivp.using_config('train', False):
+        loss2 = float(m2([imgs, acts, stas], 0))
+    assert loss2 == loss and np.array_equal(torch.stack(m2.gen_images).cpu().numpy(), gen)
+
+
+def test_scheduled_sampling_matches_oracle(pivp):
+    P = R.init_params(seed=1, dtype=np.float32, scale=1.0)
+    imgs, acts, stas = R.synthetic_batch(4, 5)
+    ref = R.Model(10, params=P, dtype=np.float64, prefix='x', scheduled_sampling_k=2.0)
+    np.random.seed(21)
+    ref([imgs, acts, stas], 1.0)
+    np.random.seed(21)
+    m, loss, gen = _run(pivp, 'CDNA', 10, imgs, acts, stas, P, train=True, k=2.0, it=1.0)
+    assert R.per_pixel_l2(gen, np.stack(ref.gen_images)).max() < GATE
+    assert abs(loss - float(ref.loss)) < 1e-5
+    # eval mode ignores the schedule (TM:649)
+    _, loss_eval, gen_eval = _run(pivp, 'CDNA', 10, imgs, acts, stas, P, train=False, k=2.0, it=1.0)
+    ref2 = R.Model(10, params=P, dtype=np.float64, prefix='x', scheduled_sampling_k=2.0); ref2.train = False
+    ref2([imgs, acts, stas], 1.0)
+    assert R.per_pixel_l2(gen_eval, np.stack(ref2.gen_images)).max() < GATE
+
+
+def test_use_state_false_and_keep_activations(pivp):
+    P = R.init_params(seed=2, dtype=np.float32, scale=1.0, use_state=False)
+    imgs, acts, stas = R.synthetic_batch(2, 4)
+    ref = R.Model(10, params=P, dtype=np.float64, prefix='x', use_state=False); ref.train = False
+    ref([imgs, acts, stas], 0, tap_steps=(0, 1, 2))
+    m, loss, gen = _run(pivp, 'CDNA', 10, imgs, acts, stas, P, use_state=False, keep_activations=True)
+    assert R.per_pixel_l2(gen, np.stack(ref.gen_images)).max() < GATE
+    for step in (0, 1, 2):                                   # every timestep's activations are retained
+        for tap in ('enc0', 'enc3', 'hidden5', 'enc5', 'enc6', 'hidden7'):
+            got = m.tap(tap, step).cpu().numpy()
+            assert np.abs(got - ref.taps[step][tap]).max() < 5e-4, (step, tap)
+
+
+def test_batch32_properties(pivp):
+    """Full-size batch (config 2: B=32, T=10): size-independent properties instead of the slow oracle.
+    (a) samples are independent: rows of a B=32 run equal the same sequences run as B=2;
+    (b) a sample duplicated inside the batch yields bit-identical frames;
+    (c) outputs are finite and the loss equals the mean of per-frame costs recomputed on the host."""
+    import torch
+    P = R.init_params(seed=1, dtype=np.float32, scale=1.0)
+    imgs, acts, stas = R.synthetic_batch(32, 10)
+    imgs[:, 7] = imgs[:, 3]; acts[:, 7] = acts[:, 3]; stas[:, 7] = stas[:, 3]
+    m, loss, gen = _run(pivp, 'CDNA', 10, imgs, acts, stas, P)
+    assert np.isfinite(gen).all()
+    assert np.array_equal(gen[:, 7], gen[:, 3])
+    _, _, gen2 = _run(pivp, 'CDNA', 10, imgs[:, 2:4], acts[:, 2:4], stas[:, 2:4], P)
+    assert R.per_pixel_l2(gen[:, 2:4], gen2).max() < 2e-5
+    gs = torch.stack(m.gen_states).cpu().numpy()
+    fr = [np.mean((imgs[t + 2].astype(np.float64) - gen[t + 1]) ** 2) for t in range(8)]
+    st = [np.mean((stas[t + 2].astype(np.float64) - gs[t + 1]) ** 2) * 1e-4 for t in range(8)]
+    assert abs(loss - (sum(fr) + sum(st)) / 8.0) < 1e-6
+    g = np.load(os.path.join(GOLD, 'cdna_b2_t10.npz'))        # first two sequences are the golden batch
+    imgs_g, _, _ = R.synthetic_batch(2, 10)
+    if np.array_equal(imgs_g, imgs[:, :2]):
+        assert R.per_pixel_l2(gen[:, :2], g['gen_images']).max() < GATE
+
+
+def test_frame_size_128_generalisation(pivp):
+    # BASELINE.json config 5 needs outsize = 2*in (the reference hard-codes 16/32/64, TM:505-507)
+    P = R.init_params(seed=1, dtype=np.float32, scale=1.0, height=128, width=128)
+    imgs, acts, stas = R.synthetic_batch(1, 3, 128, 128)
+    ref = R.Model(10, params=P, dtype=np.float64, prefix='x'); ref.train = False
+    ref([imgs, acts, stas], 0)
+    m, loss, gen = _run(pivp, 'CDNA', 10, imgs, acts, stas, P)
+    assert R.per_pixel_l2(gen, np.stack(ref.gen_images)).max() < GATE
+    assert m.count_params() == 18059519

@@ -1,0 +1,137 @@
+"""CPU-side tests of the host logic and of the C-ABI surface (no compute calls, no GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pivp_amd
+from pivp_amd import _lib
+from oracle import restatement as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    header = open(os.path.join(ROOT, 'include', 'pivp_hip.h')).read()
+    declared = set(re.findall(r'\b(pivp_[a-z0-9_]+)\s*\(', header))
+    declared -= {'pivp_config', 'pivp_plan'}
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), 'libpivp_hip.so does not export %s' % name
+    assert declared == set(_lib.SIGNATURES), 'ctypes table and header disagree: %s' % (declared ^ set(_lib.SIGNATURES))
+    assert _lib.load().pivp_abi_version() == 1
+
+
+def test_plan_param_table_matches_reference_keys():
+    lib = _lib.load()
+    for mt, nm, code in (('CDNA', 10, 0), ('STP', 10, 1), ('DNA', 1, 2)):
+        cfg = _lib.PivpConfig(batch=2, seq_len=10, height=64, width=64, num_masks=nm, model_type=code, use_state=1,
+                              context_frames=2, keep_activations=0, ln_eps=1e-6, stp_zero_border=0)
+        h = ctypes.c_void_p()
+        assert lib.pivp_plan_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+        names = [lib.pivp_param_name(h, i).decode() for i in range(lib.pivp_param_count(h))]
+        shapes = pivp_amd.reference_param_shapes(nm, mt, True, 64, 64)
+        assert sorted(names) == sorted(shapes)
+        assert sorted(names) == sorted(R.param_shapes(num_masks=nm, model_type=mt))
+        for i, n in enumerate(names):
+            dummy = np.zeros(shapes[n], np.float32)
+            assert lib.pivp_param_numel(h, i) == pivp_amd.to_internal(n, dummy).size, n
+        assert lib.pivp_plan_workspace_bytes(h) > 0
+        lib.pivp_plan_destroy(h)
+    # bad configs are rejected, not crashed on
+    bad = _lib.PivpConfig(batch=2, seq_len=10, height=60, width=64, num_masks=10, model_type=0, use_state=1,
+                          context_frames=2, keep_activations=0, ln_eps=1e-6, stp_zero_border=0)
+    h = ctypes.c_void_p()
+    assert lib.pivp_plan_create(ctypes.byref(bad), ctypes.byref(h)) == -1
+    bad2 = _lib.PivpConfig(batch=2, seq_len=10, height=64, width=64, num_masks=2, model_type=2, use_state=1,
+                           context_frames=2, keep_activations=0, ln_eps=1e-6, stp_zero_border=0)
+    assert lib.pivp_plan_create(ctypes.byref(bad2), ctypes.byref(h)) == -1   # DNA needs num_masks == 1 (TM:390)
+
+
+def test_reference_param_shapes_match_oracle_and_count():
+    for mt, nm in (('CDNA', 10), ('STP', 10), ('DNA', 1)):
+        a = pivp_amd.reference_param_shapes(nm, mt, True, 64, 64)
+        b = R.param_shapes(num_masks=nm, model_type=mt)
+        assert dict(a) == dict(b)
+    assert sum(int(np.prod(s)) for s in pivp_amd.reference_param_shapes(10, 'CDNA', True, 64, 64).values()) == 9212159
+    assert sum(int(np.prod(s)) for s in pivp_amd.reference_param_shapes(10, 'CDNA', True, 128, 128).values()) == 18059519
+
+
+def test_checkpoint_layout_roundtrip_and_permutations():
+    shapes = pivp_amd.reference_param_shapes(10, 'CDNA', True, 64, 64)
+    rs = np.random.RandomState(0)
+    for key in ('enc0/W', 'enc4/W', 'lstm5/conv/W', 'hidden5/norm/gamma', 'masks/W', 'model/cdna_kerns/W', 'enc3/W',
+                'current_state/W', 'lstm1/conv/b'):
+        a = rs.randn(*shapes[key]).astype(np.float32)
+        flat = pivp_amd.to_internal(key, a)
+        back = pivp_amd.from_internal(key, flat, shapes[key])
+        assert np.array_equal(a, back), key
+    # conv: internal [tap][Cin][Cout]
+    W = rs.randn(*shapes['lstm5/conv/W']).astype(np.float32)
+    f = pivp_amd.to_internal('lstm5/conv/W', W).reshape(25, 192, 512)
+    assert f[7, 100, 300] == W[300, 100, 1, 2]
+    # deconv: reference (Cin,Cout,kh,kw)
+    Wd = rs.randn(*shapes['enc5/W']).astype(np.float32)
+    fd = pivp_amd.to_internal('enc5/W', Wd).reshape(9, 96, 96)
+    assert fd[5, 10, 20] == Wd[10, 20, 1, 2]
+    # LN gamma: NCHW-flat c*HW+p -> NHWC-flat p*C+c
+    g = np.arange(8192, dtype=np.float32)
+    fg = pivp_amd.to_internal('hidden5/norm/gamma', g)
+    assert fg[5 * 128 + 7] == g[7 * 64 + 5]
+    # cdna_kerns: in-feature c*64+p -> row p*128+c, 256 padded columns
+    Wk = rs.randn(250, 8192).astype(np.float32)
+    fk = pivp_amd.to_internal('model/cdna_kerns/W', Wk).reshape(8192, 256)
+    assert fk[9 * 128 + 3, 17] == Wk[17, 3 * 64 + 9] and np.all(fk[:, 250:] == 0)
+
+
+def test_scheduled_sampling_masks_match_reference_rng_use():
+    # same global-RNG consumption as the reference: one shuffle(arange(B)) per step t >= ctx (TM:93-94, TM:669)
+    B, T, ctx, k, it = 8, 6, 2, 4.0, 3.0
+    np.random.seed(11)
+    mask = pivp_amd.scheduled_sampling_masks(B, T, ctx, k, it)
+    np.random.seed(11)
+    ngt = R.num_ground_truth_schedule(B, k, it)
+    gt = np.zeros((B, 1, 1, 1), np.float32); gen = np.ones((B, 1, 1, 1), np.float32)
+    for t in range(T - 1):
+        if t >= ctx:
+            out = R.scheduled_sample(gt, gen, B, ngt)
+            assert np.array_equal(out[:, 0, 0, 0] == 0, mask[t] == 1)
+        else:
+            assert mask[t].sum() == 0
+    assert mask[ctx:].sum(axis=1).tolist() == [ngt] * (T - 1 - ctx)
+
+
+def test_concat_examples_matches_reference_layout():
+    rs = np.random.RandomState(0)
+    batch = [(rs.rand(4, 8, 8, 3).astype(np.float32), rs.rand(4, 5).astype(np.float32), rs.rand(4, 5).astype(np.float32))
+             for _ in range(3)]
+    a = pivp_amd.concat_examples(batch)
+    b = R.concat_examples(batch)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and np.array_equal(x, y)
+
+
+def test_constructor_surface_and_errors():
+    with pytest.raises(ValueError, match='No network specified'):
+        pivp_amd.Model(10, is_cdna=False, is_dna=False, is_stp=False)       # TM:540
+    m = pivp_amd.Model(10, is_cdna=True, is_stp=True)
+    assert m.model_type == 'CDNA'                                           # precedence cdna > stp > dna (TM:532-537)
+    assert pivp_amd.Model(10, is_cdna=False, is_stp=True, is_dna=True).model_type == 'STP'
+    assert pivp_amd.config.train is True
+    with pivp_amd.using_config('train', False):
+        assert pivp_amd.config.train is False
+    assert pivp_amd.config.train is True
+    with pytest.raises(TypeError):
+        m([np.zeros((3, 1, 3, 64, 64), np.float32)])                        # images only -> states[0] fails (TM:646)
+
+
+def test_product_path_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, 'physical-interaction-video-prediction_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            src = open(os.path.join(pkg, fn)).read()
+            assert 'oracle' not in src.replace('no oracle', ''), fn
