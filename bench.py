@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: predicted frames/s of the 10-frame 64x64x3 CDNA rollout (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches one rank per GPU through torch.distributed.run; every rank runs the
+same per-GPU workload (weak scaling; the forward rollout shards over the batch with no data-path
+collective: SURVEY.md 8e "inference rollout: replicas only").
+
+A "step" is one Model.__call__ (TM:620-764) over one synthetic batch already resident in HBM:
+B sequences x (T-1) predicted frames, feed-self after the context frames as predict_model.py:126-128.
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : the dominant kernel (ConvLSTM gate conv, fp32 MFMA implicit GEMM), algorithmic flops of
+                 its launches / their HIP-event time measured on the launch stream in a second,
+                 instrumented pass over the same K steps (events perturb the clean timing slightly,
+                 so `value` comes from the un-instrumented pass)
+  cpu_baseline : the CPU restatement of the reference path (oracle/torch_restatement.py, fp32, all
+                 host threads) on a bounded sample, rank 0 at N=1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA dense peak (= vector peak)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='sequences per GPU (config 2: 32)')
+    ap.add_argument('--seq-len', type=int, default=10)
+    ap.add_argument('--size', type=int, default=64)
+    ap.add_argument('--model', default='CDNA', choices=['CDNA', 'STP', 'DNA'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import pivp_amd
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    torch.cuda.set_device(local_rank)
+    dev = 'cuda:%d' % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device(dev))
+
+    B, T, S = args.batch, args.seq_len, args.size
+    nm = 1 if args.model == 'DNA' else 10
+    np.random.seed(1234 + rank)
+    model = pivp_amd.Model(nm, is_cdna=args.model == 'CDNA', is_stp=args.model == 'STP', is_dna=args.model == 'DNA',
+                           prefix='bench', device=dev)
+    rs = np.random.RandomState(rank)
+    images = torch.from_numpy(rs.random_sample((T, B, 3, S, S)).astype(np.float32)).to(dev)
+    actions = torch.from_numpy((0.1 * rs.standard_normal((T, B, 5))).astype(np.float32)).to(dev)
+    states = torch.from_numpy((0.1 * rs.standard_normal((T, B, 5))).astype(np.float32)).to(dev)
+
+    def step():
+        model.reset_state()
+        return model([images, actions, states], 0)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    with pivp_amd.using_config('train', False):
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        loss_val = float(loss)
+
+        roofline = None
+        if not args.no_roofline and rank == 0:
+            plan = model._active
+            lib = plan.lib
+            lib.pivp_plan_set_profiling(plan.h, 1)
+            ms_tot = np.zeros(7); n_tot = np.zeros(7, dtype=np.int64); flops = np.zeros(7)
+            for _ in range(args.steps):
+                step()
+                torch.cuda.synchronize()
+                ms = (ctypes.c_double * 7)(); n = (ctypes.c_int * 7)(); fl = (ctypes.c_double * 7)()
+                rc = lib.pivp_plan_profile_read(plan.h, ms, n, fl)
+                assert rc == 0, rc
+                ms_tot += np.array(ms[:]); n_tot += np.array(n[:]); flops = np.array(fl[:])
+            lib.pivp_plan_set_profiling(plan.h, 0)
+            total_flops = float((flops * n_tot).sum())
+            total_s = float(ms_tot.sum()) * 1e-3
+            achieved = total_flops / total_s / 1e12
+            roofline = {
+                'bound': 'mfma', 'kernel': 'igemm_f32_kernel<4,true> (ConvLSTM 5x5 gate conv + fused gates)',
+                'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                'traffic': None,
+                'launches': int(n_tot.sum()), 'avg_launch_us': round(total_s / max(1, int(n_tot.sum())) * 1e6, 2),
+                'algorithmic_gflop_per_launch': round(total_flops / max(1, int(n_tot.sum())) / 1e9, 3),
+                'per_layer_tflops': {('lstm%d' % (i + 1)): round(float(flops[i] * n_tot[i] / (ms_tot[i] * 1e-3) / 1e12), 2)
+                                     for i in range(7) if ms_tot[i] > 0},
+                'share_of_step_time': round(total_s / args.steps / (elapsed / args.steps), 3),
+            }
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import restatement as R
+        from oracle.torch_restatement import TorchModel
+        cb, ct = 2, T
+        P = R.init_params(seed=1, dtype=np.float32, scale=1.0, num_masks=nm, model_type=args.model, height=S, width=S)
+        ci, ca, cs = R.synthetic_batch(cb, ct, S, S)
+        tm = TorchModel(nm, is_cdna=args.model == 'CDNA', is_stp=args.model == 'STP', is_dna=args.model == 'DNA',
+                        params=P, dtype=torch.float32)
+        tm.train = False
+        with torch.no_grad():
+            tm([ci, ca, cs], 0); tm.reset_state()      # warm-up
+            reps, c0 = 0, time.perf_counter()
+            while time.perf_counter() - c0 < args.cpu_seconds:
+                tm([ci, ca, cs], 0); tm.reset_state()
+                reps += 1
+            cel = time.perf_counter() - c0
+        cpu_baseline = {'value': round(cb * (ct - 1) * reps / cel, 2), 'unit': 'predicted frames/s',
+                        'cores': torch.get_num_threads(), 'kind': 'port',
+                        'sample': '%d rollouts of B=%d T=%d %dx%d %s, fp32 PyTorch-CPU restatement of the reference path '
+                                  '(oracle/torch_restatement.py), %.1f s' % (reps, cb, ct, S, S, args.model, cel)}
+
+    if rank == 0:
+        frames = world * B * (T - 1) * args.steps
+        out = {
+            'metric': 'predicted frames/sec (64x64x3, 10-step rollout)',
+            'value': round(frames / elapsed, 1),
+            'unit': 'frames/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': '%s rollout forward (Model.__call__, feed-self), batch %d/GPU, %d-frame %dx%dx3 sequences, '
+                                   'action-conditioned, num_masks=%d, random-init weights' % (args.model, B, T, S, S, nm),
+                       'global_batch': world * B, 'frames_per_step': world * B * (T - 1), 'parallelism': 'replicas x%d' % world,
+                       'loss': loss_val},
+            'roofline': roofline,
+            'cpu_baseline': cpu_baseline,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -77,6 +77,13 @@ int pivp_rollout_forward(pivp_plan_t* plan, const float* images, const float* ac
                          const unsigned char* gt_select, float* gen_images, float* gen_states, float* results,
                          void* stream);
 
+/* Measurement hooks (bench.py): when enabled, every ConvLSTM launch of pivp_rollout_forward is bracketed
+ * by hipEvents recorded on the launch stream.  After the caller has synchronised the stream,
+ * pivp_plan_profile_read returns, per ConvLSTM layer (lstm1..lstm7): summed milliseconds, launch count
+ * and the ALGORITHMIC flops of one launch, 2*M*4C*25*(Cx+C)  (TM:224 conv inside TM:262-272). */
+int pivp_plan_set_profiling(pivp_plan_t* plan, int enable);
+int pivp_plan_profile_read(pivp_plan_t* plan, double* ms_per_layer, int* launches_per_layer, double* flops_per_layer);
+
 /* Activation taps of a timestep still held in the workspace, returned planar NCHW like the
  * reference's conv_res / hiddens (TM:703-708, TM:734).  name: enc0..enc7, hidden1..hidden7, masks,
  * cdna_kerns, lstm1_h.. lstm7_h, lstm1_c..lstm7_c.  Returns the number of floats written or <0. */

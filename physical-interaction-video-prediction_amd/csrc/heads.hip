@@ -103,9 +103,11 @@ __global__ __launch_bounds__(256) void skinny_linear_partials_kernel(const float
         xs[i] = (bb < nb && k0 + k < K) ? x[(size_t)(b0 + bb) * K + k0 + k] : 0.f;
     }
     __syncthreads();
-    float acc[32];
+    // fp64 accumulation: the work is tiny (B x 256 x K MACs) and the STP warp / CDNA kernels that
+    // consume these sums amplify their error (a 1e-6 error in theta moves a sample by 3e-5 pixels)
+    double acc[32];
 #pragma unroll
-    for (int bb = 0; bb < 32; ++bb) acc[bb] = 0.f;
+    for (int bb = 0; bb < 32; ++bb) acc[bb] = 0.0;
     for (int k = 0; k < LIN_KS; k += 4) {
         float w[4];
 #pragma unroll
@@ -114,10 +116,10 @@ __global__ __launch_bounds__(256) void skinny_linear_partials_kernel(const float
         for (int bb = 0; bb < 32; ++bb) {
             const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + bb * LIN_KS + k);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[bb] = fmaf(xv[e], w[e], acc[bb]);
+            for (int e = 0; e < 4; ++e) acc[bb] = fma((double)xv[e], (double)w[e], acc[bb]);
         }
     }
-    for (int bb = 0; bb < nb; ++bb) partials[((size_t)ks * B + b0 + bb) * 256 + o] = acc[bb];
+    for (int bb = 0; bb < nb; ++bb) partials[((size_t)ks * B + b0 + bb) * 256 + o] = (float)acc[bb];
 }
 
 // CDNA finisher (TM:326-329): + bias, relu(k - RELU_SHIFT) + RELU_SHIFT, divide by the 5x5 sum.
@@ -127,9 +129,9 @@ __global__ __launch_bounds__(256) void cdna_kernels_finish_kernel(const float* _
     const int b = blockIdx.x, o = threadIdx.x;
     float acc = 0.f;
     if (o < nout) {
-        acc = bias[o];
-        for (int ks = 0; ks < KS; ++ks) acc += partials[((size_t)ks * B + b) * 256 + o];
-        acc = fmaxf(acc - 1e-12f, 0.f) + 1e-12f;
+        double a = bias[o];
+        for (int ks = 0; ks < KS; ++ks) a += (double)partials[((size_t)ks * B + b) * 256 + o];
+        acc = fmaxf((float)a - 1e-12f, 0.f) + 1e-12f;
     }
     v[o] = acc;
     __syncthreads();
@@ -158,15 +160,15 @@ __global__ __launch_bounds__(128) void stp_params_finish_kernel(const float* __r
     __shared__ float s1[100];
     const int b = blockIdx.x, o = threadIdx.x;
     if (o < 100) {
-        float acc = b1[o];
-        for (int ks = 0; ks < KS; ++ks) acc += partials[((size_t)ks * B + b) * 256 + o];
-        s1[o] = fmaxf(acc, 0.f);
+        double acc = b1[o];
+        for (int ks = 0; ks < KS; ++ks) acc += (double)partials[((size_t)ks * B + b) * 256 + o];
+        s1[o] = fmaxf((float)acc, 0.f);
     }
     __syncthreads();
     if (o < 6) {
-        float acc = b2[o];
-        for (int i = 0; i < 100; ++i) acc = fmaf(w2[o * 100 + i], s1[i], acc);
-        theta[b * 6 + o] = acc + ((o == 0 || o == 4) ? 1.0f : 0.0f);
+        double acc = b2[o];
+        for (int i = 0; i < 100; ++i) acc = fma((double)w2[o * 100 + i], (double)s1[i], acc);
+        theta[b * 6 + o] = (float)(acc + ((o == 0 || o == 4) ? 1.0 : 0.0));
     }
 }
 
@@ -299,16 +301,17 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
             }
         } else if (MODE == 1) {
             const float* th = aux + (size_t)b * 6;
-            const float xs = -1.0f + 2.0f * (float)x / (float)(W - 1);
-            const float ys = -1.0f + 2.0f * (float)y / (float)(H - 1);
-            float gu = th[0] * xs + th[1] * ys + th[2];
-            float gv = th[3] * xs + th[4] * ys + th[5];
-            if (!stp_zero) { gu = fminf(fmaxf(gu, -1.f), 1.f); gv = fminf(fmaxf(gv, -1.f), 1.f); }
-            const float u = (gu + 1.f) * (float)(W - 1) * 0.5f;
-            const float v = (gv + 1.f) * (float)(H - 1) * 0.5f;
-            float u0 = floorf(u), v0 = floorf(v);
-            if (!stp_zero) { u0 = fminf(fmaxf(u0, 0.f), (float)(W - 2)); v0 = fminf(fmaxf(v0, 0.f), (float)(H - 2)); }
-            const float wu1 = u - u0, wv1 = v - v0;
+            // coordinates in fp64 (two dozen flops per pixel): a 1e-5 pixel error is visible at 1e-4 parity
+            const double xs = -1.0 + 2.0 * (double)x / (double)(W - 1);
+            const double ys = -1.0 + 2.0 * (double)y / (double)(H - 1);
+            double gu = (double)th[0] * xs + (double)th[1] * ys + (double)th[2];
+            double gv = (double)th[3] * xs + (double)th[4] * ys + (double)th[5];
+            if (!stp_zero) { gu = fmin(fmax(gu, -1.0), 1.0); gv = fmin(fmax(gv, -1.0), 1.0); }
+            const double u = (gu + 1.0) * (double)(W - 1) * 0.5;
+            const double v = (gv + 1.0) * (double)(H - 1) * 0.5;
+            double u0 = floor(u), v0 = floor(v);
+            if (!stp_zero) { u0 = fmin(fmax(u0, 0.0), (double)(W - 2)); v0 = fmin(fmax(v0, 0.0), (double)(H - 2)); }
+            const float wu1 = (float)(u - u0), wv1 = (float)(v - v0);
             const int iu = (int)u0, iv = (int)v0;
             float msum = 0.f;
 #pragma unroll

@@ -133,6 +133,12 @@ struct pivp_plan {
            o_e0raw, o_e6raw, o_losspart;
     int loss_nparts;
     int last_steps;  // timesteps run by the last rollout
+    // optional event timing of the dominant kernel (ConvLSTM gate conv), per layer
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;   // pairs
+    std::vector<int> prof_layer;
+    size_t prof_used = 0;
+    ~pivp_plan() { for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e); }
 };
 
 static const float* P(const pivp_plan* p, int idx) { return p->params[idx].ptr; }
@@ -272,8 +278,16 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     auto hp = [&](int i) { return Sp ? ws + Sp->h[i] : ws + p->o_zero; };
     auto cp = [&](int i) { return Sp ? ws + Sp->c[i] : ws + p->o_zero; };
     auto lstm = [&](int i, const float* x, int ldx, int hh, int wwid) {
-        return run_convlstm(x, kLstm[i].cx, ldx, hp(i), kLstm[i].C, P(p, p->i_lstm_w[i]), P(p, p->i_lstm_b[i]),
-                            cp(i), ws + S.c[i], ws + S.h[i], B, hh, wwid, s);
+        const bool prof = p->prof_on && p->prof_used + 2 <= p->prof_ev.size();
+        if (prof) (void)hipEventRecord(p->prof_ev[p->prof_used], s);
+        int rc = run_convlstm(x, kLstm[i].cx, ldx, hp(i), kLstm[i].C, P(p, p->i_lstm_w[i]), P(p, p->i_lstm_b[i]),
+                              cp(i), ws + S.c[i], ws + S.h[i], B, hh, wwid, s);
+        if (prof) {
+            (void)hipEventRecord(p->prof_ev[p->prof_used + 1], s);
+            p->prof_layer[p->prof_used / 2] = i;
+            p->prof_used += 2;
+        }
+        return rc;
     };
     auto ln = [&](int j, const float* x, float* out, int n, int C, int ldo, int relu) {
         return run_layernorm(x, P(p, p->i_ln_g[j]), P(p, p->i_ln_b[j]), out, lnp, B, n, C, ldo, eps, relu, s);
@@ -365,6 +379,39 @@ extern "C" int pivp_rollout_forward(pivp_plan_t* plan, const float* images, cons
                                 lp + (size_t)i * plan->loss_nparts, (int)fr, s));
     RC(loss_finalize(lp, plan->loss_nparts, nf, (int)fr, states + (size_t)ctx * B * 5, gen_states + (size_t)(ctx - 1) * B * 5,
                      B * 5, (float)(T - ctx), results, s));
+    return PIVP_OK;
+}
+
+extern "C" int pivp_plan_set_profiling(pivp_plan_t* plan, int enable) {
+    if (!plan) return PIVP_ERR_BADARG;
+    if (enable && plan->prof_ev.empty()) {
+        const size_t n = (size_t)2 * 7 * (plan->cfg.seq_len - 1);
+        plan->prof_ev.resize(n);
+        plan->prof_layer.assign(n / 2, 0);
+        for (size_t i = 0; i < n; ++i)
+            if (hipEventCreate(&plan->prof_ev[i]) != hipSuccess) { plan->prof_ev.resize(i); return PIVP_ERR_LAUNCH; }
+    }
+    plan->prof_on = enable != 0;
+    plan->prof_used = 0;
+    return PIVP_OK;
+}
+
+extern "C" int pivp_plan_profile_read(pivp_plan_t* plan, double* ms_per_layer, int* launches_per_layer, double* flops_per_layer) {
+    if (!plan || !ms_per_layer || !launches_per_layer || !flops_per_layer) return PIVP_ERR_BADARG;
+    const pivp_config_t& c = plan->cfg;
+    for (int i = 0; i < 7; ++i) {
+        ms_per_layer[i] = 0.0; launches_per_layer[i] = 0;
+        const int lv = kLstm[i].level;
+        const double M = (double)c.batch * (c.height / lv) * (c.width / lv);
+        flops_per_layer[i] = 2.0 * M * 4.0 * kLstm[i].C * 25.0 * (kLstm[i].cx + kLstm[i].C);
+    }
+    for (size_t k = 0; k + 1 < plan->prof_used; k += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, plan->prof_ev[k], plan->prof_ev[k + 1]) != hipSuccess) return PIVP_ERR_STATE;
+        const int L = plan->prof_layer[k / 2];
+        ms_per_layer[L] += ms; launches_per_layer[L] += 1;
+    }
+    plan->prof_used = 0;
     return PIVP_OK;
 }
 
