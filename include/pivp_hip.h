@@ -94,15 +94,19 @@ long long pivp_get_tap(pivp_plan_t* plan, const char* name, int step, float* out
  * ------------------------------------------------------------------------------------------ */
 
 /* BasicConvLSTMCell.__call__ (TM:234-276): gates = conv5x5(concat(x,h)) ; c,h update, forget bias 1.
- * x NHWC (cx channels, stride ldx), h_prev/c NHWC [B][H][W][C]; w [25][cx+C][4C] gate order j,i,f,o. */
+ * x NHWC (cx channels, stride ldx), h_prev/c NHWC [B][H][W][C]; w [25][(cx+C)/32][4C][32] (K-inner packed), gate order j,i,f,o. */
 int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                   const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream);
 
-/* L.Convolution2D(cout,(3,3),stride=2,pad=1) (TM:501-502) + optional ReLU; w [9][cin][cout]. */
+/* Same, with the block-tile variant forced (0 auto, 1: BM 128, 2: BM 64, 3: BM 32) -- tests and tuning. */
+int pivp_convlstm_v(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
+                    const float* c_in, float* c_out, float* h_out, int B, int H, int W, int variant, void* stream);
+
+/* L.Convolution2D(cout,(3,3),stride=2,pad=1) (TM:501-502) + optional ReLU; w [9][cin/32][cout][32]. */
 int pivp_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                    int ldo, int relu, int B, int Hin, int Win, void* stream);
 
-/* L.Deconvolution2D(cout,(3,3),stride=2,pad=1,outsize=2*in) (TM:505-507) + optional ReLU; w [9][cin][cout]. */
+/* L.Deconvolution2D(cout,(3,3),stride=2,pad=1,outsize=2*in) (TM:505-507) + optional ReLU; w [9][cin/32][cout][32]. */
 int pivp_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                      int ldo, int relu, int B, int Hin, int Win, void* stream);
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     'pivp_plan_profile_read': (_i, [_vp, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int), _c.POINTER(_c.c_double)]),
     'pivp_get_tap': (_ll, [_vp, _c.c_char_p, _i, _vp, _vp]),
     'pivp_convlstm': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pivp_convlstm_v': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'pivp_conv3x3s2': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'pivp_deconv3x3s2': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'pivp_conv_enc0': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

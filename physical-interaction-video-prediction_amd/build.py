@@ -13,6 +13,8 @@ SOURCES = ['igemm_f32.hip', 'small_kernels.hip', 'heads.hip', 'pivp_c_api.hip']
 LIB = os.path.join(HERE, 'libpivp_hip.so')
 STAMP = os.path.join(HERE, '.libpivp_hip.stamp')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
+if os.environ.get('PIVP_ABLATE'):   # timing-only diagnostic variants of the igemm kernel (scripts/bench_lstm_layers.py)
+    FLAGS.append('-DPIVP_ABLATE')
 
 
 def _digest():

@@ -5,7 +5,8 @@ predict_model.py:110; keys are link paths, files carry no ext
 (README.md:24, predict_model.py:80).  Shapes in the file: conv W (Cout,Cin,kh,kw); deconv W
 (Cin,Cout,kh,kw); Linear W (out,in); LN gamma/beta flat in NCHW order c*H*W + y*W + x.
 
-Internal layouts (csrc/pivp_kernels.h): conv/deconv W [tap][Cin][Cout]; LN gamma/beta NHWC-flat;
+Internal layouts (csrc/pivp_kernels.h): conv/deconv W of the MFMA kernels [tap][Cin/32][Cout][32]
+(K-inner packed); enc0, enc3 and the 1x1 heads [tap][Cin][Cout]; LN gamma/beta NHWC-flat;
 cdna_kerns / stp_input W K-major over the NHWC-flat hidden5 index with 256 padded columns."""
 import numpy as np
 
@@ -13,6 +14,17 @@ DECONV_KEYS = ('enc4/W', 'enc5/W', 'enc6/W', 'masks/W', 'model/enc7/W')
 LN_CHANNELS = {'norm_enc0': 32, 'hidden1': 32, 'hidden2': 32, 'hidden3': 64, 'hidden4': 64,
                'hidden5': 128, 'hidden6': 64, 'hidden7': 32, 'norm_enc6': 64}
 SKINNY_KEYS = ('model/cdna_kerns/W', 'model/stp_input/W')
+UNPACKED_KEYS = ('enc0/W', 'enc3/W', 'masks/W', 'model/enc7/W')   # Cin not a multiple of 32 or VALU kernels
+
+
+def _pack_k_inner(t):
+    """[tap][Cin][Cout] -> [tap][Cin/32][Cout][32]"""
+    taps, cin, cout = t.shape
+    return np.ascontiguousarray(t.reshape(taps, cin // 32, 32, cout).transpose(0, 1, 3, 2))
+
+
+def _unpack_k_inner(f, taps, cin, cout):
+    return np.ascontiguousarray(f.reshape(taps, cin // 32, cout, 32).transpose(0, 1, 3, 2)).reshape(taps, cin, cout)
 
 
 def to_internal(key, arr):
@@ -27,8 +39,13 @@ def to_internal(key, arr):
         return out.ravel()
     if key.endswith('/W') and a.ndim == 4:
         if key in DECONV_KEYS:
-            return np.ascontiguousarray(a.transpose(2, 3, 0, 1)).ravel()     # (Cin,Cout,kh,kw) -> [tap][Cin][Cout]
-        return np.ascontiguousarray(a.transpose(2, 3, 1, 0)).ravel()         # (Cout,Cin,kh,kw) -> [tap][Cin][Cout]
+            t = np.ascontiguousarray(a.transpose(2, 3, 0, 1))                # (Cin,Cout,kh,kw) -> [kh][kw][Cin][Cout]
+        else:
+            t = np.ascontiguousarray(a.transpose(2, 3, 1, 0))                # (Cout,Cin,kh,kw) -> [kh][kw][Cin][Cout]
+        t = t.reshape(-1, t.shape[2], t.shape[3])
+        if key not in UNPACKED_KEYS:
+            t = _pack_k_inner(t)
+        return t.ravel()
     if key.endswith('/norm/gamma') or key.endswith('/norm/beta'):
         C = LN_CHANNELS[key.split('/')[0]]
         return np.ascontiguousarray(a.reshape(C, -1).T).ravel()              # c*HW+p -> p*C+c
@@ -46,9 +63,11 @@ def from_internal(key, flat, ref_shape):
     if key.endswith('/W') and len(ref_shape) == 4:
         if key in DECONV_KEYS:
             ci, co, kh, kw = ref_shape
-            return np.ascontiguousarray(f.reshape(kh, kw, ci, co).transpose(2, 3, 0, 1))
-        co, ci, kh, kw = ref_shape
-        return np.ascontiguousarray(f.reshape(kh, kw, ci, co).transpose(3, 2, 0, 1))
+        else:
+            co, ci, kh, kw = ref_shape
+        t = f.reshape(kh * kw, ci, co) if key in UNPACKED_KEYS else _unpack_k_inner(f, kh * kw, ci, co)
+        t = t.reshape(kh, kw, ci, co)
+        return np.ascontiguousarray(t.transpose(2, 3, 0, 1) if key in DECONV_KEYS else t.transpose(3, 2, 0, 1))
     if key.endswith('/norm/gamma') or key.endswith('/norm/beta'):
         C = LN_CHANNELS[key.split('/')[0]]
         return np.ascontiguousarray(f.reshape(-1, C).T).ravel()

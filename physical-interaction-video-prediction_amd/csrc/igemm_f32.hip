@@ -9,185 +9,278 @@
 //     sub-pixel phases (1/2/2/4 taps) so no zero-stuffed input is ever touched.
 //
 // GEMM view: M = anchors (b, ay, ax) of an anchor grid, N = output channels, K = taps x Cin.
-// A[m][k] is gathered on the fly from NHWC activations (zero outside the image), B[k][n] is the
-// weight matrix stored [tap][Cin][N].  fp32 in / fp32 accumulate: the MFMA result is bit-for-bit a
-// k-ordered fmaf chain, so parity with the fp32/fp64 oracle is an ordering question only.
+// A[m][k] is gathered on the fly from NHWC activations (zero outside the image); B is the weight
+// matrix, pre-packed K-inner as [tap][Cin/32][N][32] so that a 32-deep K chunk of any column is
+// 128 contiguous bytes.  fp32 in / fp32 accumulate: the MFMA result is bit-for-bit a k-ordered
+// fmaf chain, so parity with the fp32/fp64 oracle is an ordering question only.
 //
-// Tiling: 256 threads = 4 waves; wave w owns anchors [32w, 32w+32) x all BN = 32*NT columns
-// (NT 32x32 accumulators).  K is consumed in chunks of one tap x 32 input channels, staged
-// global -> registers -> LDS with the loads for chunk i+1 issued before the MFMAs of chunk i
-// and written after them (one barrier per chunk, two LDS buffers).
-//   A tile  [128][36] floats: 144-B rows make the per-lane ds_read_b128 conflict-free
-//   B tile  [32][BN]  floats: ds_read_b32, 32 consecutive columns per half-wave
-// For the ConvLSTM the four accumulators of a wave are the four gates (j,i,f,o) of the same
-// 32 channels, so the epilogue holds j,i,f,o of one (pixel, channel) in one lane and the 4C-wide
-// gate tensor is never written.
+// Tiling: 256 threads = 4 waves arranged WM x WN.  A wave owns 32 anchors x (32/WN channels x all
+// of its gates/columns); a block owns BM = 32*WM anchors x BN columns.  K is consumed in chunks of
+// one tap x 32 input channels, staged global -> registers -> LDS (two LDS buffers, one barrier per
+// chunk): the buffer loads of chunk i+1 are issued at the top of chunk i and written to LDS at
+// its end.
+//   A tile [BM][36] and B tile [BN][36] floats: 144-B rows make every per-lane ds_read_b128
+//   (4 consecutive k of one row) conflict-free within its 16-lane group.
+// What it took to keep ONE wave per SIMD (all the parallelism a B = 32 rollout offers) on the
+// matrix pipe, in the order the measurements found it (profiles/r01/NOTES.md):
+//   * operand fragments by ds_read_b128 from K-inner tiles (5 LDS reads per 16 MFMAs);
+//   * no table lookups in the loop: taps are decoded with scalar counters (a kernarg byte-array
+//     lookup compiled to a VECTOR load + vmcnt(0), i.e. two memory round trips per chunk);
+//   * raw buffer loads, out-of-image taps get an out-of-range offset and the hardware returns 0:
+//     no branches, 32-bit offsets, and the whole chunk body is ONE basic block;
+//   * that block's staging instructions are spread over the MFMA gaps (sched_group_barrier).
+// ConvLSTM: the block's 128 columns are the 4 gates (j,i,f,o) of 32 channels.  With WN = 1 a wave's
+// four accumulators are the four gates of the same channels; with WN = 2 / 4 a 32-column tile holds
+// 2 / 4 gates of 16 / 8 channels and the epilogue gathers the four gates of a channel with wave
+// shuffles.  The 4C-wide gate tensor is never written.
+#include <type_traits>
+
 #include "pivp_kernels.h"
 
 namespace pivp {
 
-constexpr int IG_BM = 128;
 constexpr int IG_KC = 32;
-constexpr int IG_AP = 36;  // A row pitch in floats
+constexpr int IG_P = 36;  // LDS row pitch in floats (A and B tiles)
 
-template <int NT>
-constexpr int ig_lds_bytes() { return 2 * (IG_BM * IG_AP + IG_KC * 32 * NT) * 4; }
+template <int WM, int NTB>
+constexpr int ig_lds_bytes() { return 2 * (32 * WM + 32 * NTB) * IG_P * 4; }
 
-template <int NT, bool LSTM>
-__global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmDesc d) {
-    constexpr int BN = 32 * NT;
+// sigmoid / tanh of the gate epilogue through v_exp_f32 / v_rcp_f32: |error| <= ~2e-7 absolute, an order
+// below the fp32 accumulation noise of the K = 1600..4800 dot products in front of them.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+
+// ABL: timing-only ablations for scripts/bench_lstm_layers.py (built with -DPIVP_ABLATE; outputs are wrong):
+//   1 = no global loads and no LDS stores, 2 = loads but no LDS stores, 3 = as 1 without the barrier.
+template <int WM, int WN, int NTB, bool LSTM, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(!LSTM || NTB == 4, "ConvLSTM blocks own 4 gates x 32 channels");
+    constexpr int BM = 32 * WM;
+    constexpr int BN = 32 * NTB;
+    constexpr int TPW = LSTM ? 4 / WN : NTB / WN;
+    constexpr int CPW = 32 / WN;  // LSTM: channels per wave
+    constexpr int NMF = 16 * TPW; // MFMAs per wave per chunk
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    auto lds_a = [&](int buf) { return lds + buf * (IG_BM * IG_AP); };
-    auto lds_b = [&](int buf) { return lds + 2 * IG_BM * IG_AP + buf * (IG_KC * BN); };
+    constexpr int A_FLOATS = BM * IG_P, B_FLOATS = BN * IG_P;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
     const int phase = blockIdx.y;
     const int n_nblk = LSTM ? (d.C >> 5) : (d.N / BN);
     const int nblk = blockIdx.x % n_nblk;
     const int mblk = blockIdx.x / n_nblk;
-    const int m0 = mblk * IG_BM;
+    const int m0 = mblk * BM;
     const int cin = d.c0 + d.c1;
     const int ncc = cin >> 5;
-    const int tap0 = d.tap_start[phase];
-    const int nchunks = d.tap_count[phase] * ncc;
+    const int py = phase >> 1, px = phase & 1;
+    // tap set: conv K x K (rows ky, cols kx) or, for the transposed 3x3 s2 conv, the taps of output parity
+    // (py, px): oy = 2*iy - 1 + ky  =>  ky = 1 (py = 0) or ky in {0, 2} (py = 1), iy = a + (py + 1 - ky)/2.
+    const int nty = d.deconv ? 1 + py : d.ksize;
+    const int ntx = d.deconv ? 1 + px : d.ksize;
+    const int nchunks = nty * ntx * ncc;
     const int HWg = d.Hg * d.Wg;
 
-    // ---- staging roles -------------------------------------------------------------------
-    const int cvec = tid & 7;   // float4 within the 32-channel chunk
-    const int prow = tid >> 3;  // 0..31
-    int a_boff[4], a_iy0[4], a_ix0[4];
+    // ---- staging roles ---------------------------------------------------------------------
+    constexpr int NA = (BM * 8 + 255) / 256;  // float4 per thread for the A tile
+    constexpr int NB = BN * 8 / 256;          // float4 per thread for the B tile
+    constexpr unsigned OOB = 0xC0000000u;     // beyond num_records of any descriptor: the load returns 0
+    const int cvec = tid & 7;                 // float4 within the 32-float chunk row
+    const int prow = tid >> 3;                // 0..31
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x0), 0, d.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.c1 ? d.x1 : d.x0), 0, d.c1 ? d.bytes1 : d.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, d.bytesw, 0x00020000);
+    int a_pix[NA], a_iy0[NA], a_ix0[NA];      // anchor's input pixel index (b, iy0, ix0) and coords
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NA; ++j) {
         const int m = m0 + prow + 32 * j;
-        if (m < d.M) {
+        if (m < d.M && prow + 32 * j < BM) {
             const int b = m / HWg;
             const int rem = m - b * HWg;
             const int ay = rem / d.Wg;
             const int ax = rem - ay * d.Wg;
-            a_boff[j] = b * d.Hin * d.Win;
             a_iy0[j] = ay * d.in_step;
             a_ix0[j] = ax * d.in_step;
+            a_pix[j] = b * d.Hin * d.Win + a_iy0[j] * d.Win + a_ix0[j];
         } else {
-            a_boff[j] = 0;
+            a_pix[j] = 0;
             a_iy0[j] = -(1 << 20);  // never in range
             a_ix0[j] = 0;
         }
     }
-    // B staging: f = tid + 256*j -> row k = f / (BN/4), float4 column cv = f % (BN/4)
-    int b_k[NT], b_col[NT];  // global column of the float4
+    int b_goff[NB];                           // byte offset of this thread's float4 inside a [N][32] weight chunk
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int f = tid + 256 * j;
-        const int k = f / (BN / 4);
-        const int cv = (f - k * (BN / 4)) * 4;
-        b_k[j] = k;
-        if (LSTM) b_col[j] = (cv >> 5) * d.C + nblk * 32 + (cv & 31);
-        else      b_col[j] = nblk * BN + cv;
+    for (int j = 0; j < NB; ++j) {
+        const int r = prow + 32 * j;
+        const int col = LSTM ? (r >> 5) * d.C + nblk * 32 + (r & 31) : nblk * BN + r;
+        b_goff[j] = (col * 32 + cvec * 4) * 4;
     }
+    const int lds_wa = (prow * IG_P + cvec * 4);          // this thread's write slot inside the A / B tile (floats)
 
-    f32x4 ra[4];
-    f32x4 rb[NT];
+    f32x4 ra[NA];
+    f32x4 rb[NB];
 
-    auto load_chunk = [&](int it) {
-        const int t = tap0 + it / ncc;
-        const int cc = it - (it / ncc) * ncc;
-        const int dy = d.dy[t], dx = d.dx[t];
-        const int ch = cc << 5;
-        const float* src;
-        int ld, cbase;
-        if (ch < d.c0) { src = d.x0; ld = d.ld0; cbase = ch; }
-        else           { src = d.x1; ld = d.ld1; cbase = ch - d.c0; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int iy = a_iy0[j] + dy;
-            const int ix = a_ix0[j] + dx;
+    // scalar state of the NEXT chunk to load: channel chunk l_cc of tap (l_ty, l_tx); no division, no branch
+    int l_cc = 0, l_ty = 0, l_tx = 0;
+    int s_dy = 0, s_dx = 0, s_delta = 0, s_ld = 0, s_wbase = 0;
+    bool s_first = true;
+    auto stage_begin = [&]() {            // scalar prelude of one chunk's loads, then advance the counters
+        int wi;
+        if (d.deconv) {
+            const int ky = py ? 2 * l_ty : 1, kx = px ? 2 * l_tx : 1;
+            s_dy = (py + 1 - ky) >> 1; s_dx = (px + 1 - kx) >> 1; wi = ky * 3 + kx;
+        } else {
+            s_dy = l_ty - d.pad; s_dx = l_tx - d.pad; wi = l_ty * d.ksize + l_tx;
+        }
+        const int ch = l_cc << 5;
+        s_first = ch < d.c0;
+        s_ld = s_first ? d.ld0 : d.ld1;
+        const int cbase = s_first ? ch : ch - d.c0;
+        s_delta = ((s_dy * d.Win + s_dx) * s_ld + cbase) * 4;               // bytes, relative to the anchor pixel
+        s_wbase = (wi * ncc + l_cc) * d.N * 128;                             // bytes
+        ++l_cc;
+        const bool w0 = l_cc == ncc;
+        l_cc = w0 ? 0 : l_cc;
+        l_tx += w0 ? 1 : 0;
+        const bool w1 = l_tx == ntx;
+        l_tx = w1 ? 0 : l_tx;
+        l_ty += w1 ? 1 : 0;
+    };
+    auto load_piece = [&](auto J) {        // piece j < NA: A-tile load j; NA <= j < NA+NB: B-tile load j-NA
+        constexpr int j = decltype(J)::value;
+        if constexpr (j < NA) {
+            const int iy = a_iy0[j] + s_dy;
+            const int ix = a_ix0[j] + s_dx;
             const bool ok = (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                const size_t off = (size_t)(a_boff[j] + iy * d.Win + ix) * ld + cbase + cvec * 4;
-                v = *reinterpret_cast<const f32x4*>(src + off);
-            }
-            ra[j] = v;
+            const unsigned off = ok ? (unsigned)(a_pix[j] * s_ld * 4 + s_delta + cvec * 16) : OOB;
+            ra[j] = __builtin_bit_cast(f32x4, s_first ? __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0)
+                                                      : __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
+        } else if constexpr (j < NA + NB) {
+            rb[j - NA] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, b_goff[j - NA], s_wbase, 0));
         }
-        const size_t wrow = (size_t)d.wi[t] * cin + ch;
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-            rb[j] = *reinterpret_cast<const f32x4*>(d.w + (wrow + b_k[j]) * d.N + b_col[j]);
     };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            *reinterpret_cast<f32x4*>(lds_a(buf) + (prow + 32 * j) * IG_AP + cvec * 4) = ra[j];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int f = tid + 256 * j;
-            *reinterpret_cast<f32x4*>(lds_b(buf) + f * 4) = rb[j];
+    auto store_piece = [&](auto J, int buf) {
+        constexpr int j = decltype(J)::value;
+        if constexpr (j < NA) {
+            if (BM >= 32 * (j + 1)) *reinterpret_cast<f32x4*>(lds + buf * A_FLOATS + lds_wa + 32 * j * IG_P) = ra[j];
+        } else if constexpr (j < NA + NB) {
+            *reinterpret_cast<f32x4*>(lds + 2 * A_FLOATS + buf * B_FLOATS + lds_wa + 32 * (j - NA) * IG_P) = rb[j - NA];
         }
     };
 
-    f32x16 acc[NT];
+    f32x16 acc[TPW];
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+    for (int n = 0; n < TPW; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
     const int half = lane >> 5;
     const int l31 = lane & 31;
-    const int a_off = (wave * 32 + l31) * IG_AP + 4 * half;
-    const int b_off = (4 * half) * BN + l31;
+    const int a_off = (wm * 32 + l31) * IG_P + 4 * half;
+    int b_off[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        int row;
+        if (LSTM) row = (t * WN + l31 / CPW) * 32 + wn * CPW + (l31 % CPW);   // gate-major rows of the block tile
+        else      row = (wn * TPW + t) * 32 + l31;
+        b_off[t] = 2 * A_FLOATS + row * IG_P + 4 * half;
+    }
 
-    if (nchunks > 0) {
-        load_chunk(0);
-        store_chunk(0);
-    }
-    __syncthreads();
-    for (int it = 0; it < nchunks; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < nchunks) load_chunk(it + 1);
-        const float* As = lds_a(buf) + a_off;
-        const float* Bs = lds_b(buf) + b_off;
+    // One chunk = 16 micro-steps (k-group q, k-step s) of TPW MFMAs each.  The fragments of k-group q+1 are read
+    // from LDS ahead of group q's MFMAs; when STAGE, micro-step i < NA+NB is followed by the i-th buffer load of
+    // the NEXT chunk and micro-step 16-(NA+NB)+i by its ds_write, so no stretch without an MFMA is longer than
+    // one load's address arithmetic.  sched_barrier(0) pins this order (left alone, hipcc sinks the loads to
+    // just above their ds_writes and exposes the whole L2 round trip every chunk).
+    constexpr int NST = NA + NB;
+    static_assert(NST <= 8, "staging pieces must fit the 16 micro-steps twice");
+    auto chunk = [&](auto STAGE, int buf) {
+        constexpr bool stage = decltype(STAGE)::value && ABL != 1 && ABL != 3;
+        constexpr bool do_store = stage && ABL == 0;
+        const float* As = lds + buf * A_FLOATS + a_off;
+        const float* Bs = lds + buf * B_FLOATS;
+        f32x4 fa[2];
+        f32x4 fb[2][TPW];
+        fa[0] = *reinterpret_cast<const f32x4*>(As);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(As + 8 * q);
+        for (int t = 0; t < TPW; ++t) fb[0][t] = *reinterpret_cast<const f32x4*>(Bs + b_off[t]);
+        __builtin_amdgcn_sched_barrier(0);
+        auto micro = [&](auto Q, auto S2) {
+            constexpr int q = decltype(Q)::value, s2 = decltype(S2)::value, step = q * 4 + s2;
+            constexpr int cur = q & 1, nxt = cur ^ 1;
+            if constexpr (s2 == 0 && q < 3) {
+                fa[nxt] = *reinterpret_cast<const f32x4*>(As + 8 * (q + 1));
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const float b = Bs[(8 * q + s) * BN + n * 32];
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b, acc[n], 0, 0, 0);
-                }
+                for (int t = 0; t < TPW; ++t) fb[nxt][t] = *reinterpret_cast<const f32x4*>(Bs + b_off[t] + 8 * (q + 1));
             }
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s2], fb[cur][t][s2], acc[t], 0, 0, 0);
+            if constexpr (stage && step == 0) stage_begin();   // scalar prelude runs in the shadow of this step's MFMAs
+            if constexpr (stage && step < NST) load_piece(std::integral_constant<int, step>{});
+            if constexpr (do_store && step >= 16 - NST) store_piece(std::integral_constant<int, step - (16 - NST)>{}, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto qgroup = [&](auto Q) {
+            micro(Q, std::integral_constant<int, 0>{}); micro(Q, std::integral_constant<int, 1>{});
+            micro(Q, std::integral_constant<int, 2>{}); micro(Q, std::integral_constant<int, 3>{});
+        };
+        qgroup(std::integral_constant<int, 0>{}); qgroup(std::integral_constant<int, 1>{});
+        qgroup(std::integral_constant<int, 2>{}); qgroup(std::integral_constant<int, 3>{});
+    };
+
+    // prologue: chunk 0 straight into buffer 0
+    stage_begin();
+    load_piece(std::integral_constant<int, 0>{}); load_piece(std::integral_constant<int, 1>{});
+    load_piece(std::integral_constant<int, 2>{}); load_piece(std::integral_constant<int, 3>{});
+    load_piece(std::integral_constant<int, 4>{}); load_piece(std::integral_constant<int, 5>{});
+    load_piece(std::integral_constant<int, 6>{}); load_piece(std::integral_constant<int, 7>{});
+    store_piece(std::integral_constant<int, 0>{}, 0); store_piece(std::integral_constant<int, 1>{}, 0);
+    store_piece(std::integral_constant<int, 2>{}, 0); store_piece(std::integral_constant<int, 3>{}, 0);
+    store_piece(std::integral_constant<int, 4>{}, 0); store_piece(std::integral_constant<int, 5>{}, 0);
+    store_piece(std::integral_constant<int, 6>{}, 0); store_piece(std::integral_constant<int, 7>{}, 0);
+    __syncthreads();
+    for (int it = 0; it + 1 < nchunks; ++it) {
+        chunk(std::true_type{}, it & 1);
+        if (ABL == 2) {   // keep the loaded registers alive without writing LDS
+#pragma unroll
+            for (int j = 0; j < NA; ++j) asm volatile("" :: "v"(ra[j]));
+#pragma unroll
+            for (int j = 0; j < NB; ++j) asm volatile("" :: "v"(rb[j]));
         }
-        if (it + 1 < nchunks) store_chunk(buf ^ 1);
-        __syncthreads();
+        if (ABL != 3) __syncthreads();
     }
+    chunk(std::false_type{}, (nchunks - 1) & 1);
 
     // ---- epilogue --------------------------------------------------------------------------
     if (LSTM) {
         const int C = d.C;
-        const int ch = nblk * 32 + l31;
+        const int chl = wn * CPW + (l31 % CPW);
+        const int ch = nblk * 32 + chl;
+        const int grp = l31 / CPW;  // which gate-group of the tile this lane's column belongs to
         const float bj = d.bias[ch], bi = d.bias[C + ch], bf = d.bias[2 * C + ch] + 1.0f, bo = d.bias[3 * C + ch];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m < d.M) {
+            float g4[4];
+#pragma unroll
+            for (int G = 0; G < 4; ++G) {
+                const float v = acc[G / WN][r];
+                g4[G] = (WN == 1) ? v : __shfl(v, (l31 % CPW) + CPW * (G % WN) + 32 * half, 64);
+            }
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < d.M && grp == (r % WN)) {
                 const size_t o = (size_t)m * C + ch;
-                const float gj = acc[0][r] + bj;
-                const float gi = acc[1 % NT][r] + bi;
-                const float gf = acc[2 % NT][r] + bf;
-                const float go = acc[3 % NT][r] + bo;
-                const float cn = d.cstate_in[o] * sigmoidf_(gf) + sigmoidf_(gi) * tanhf(gj);
+                const float cn = d.cstate_in[o] * fast_sigmoid(g4[2] + bf) + fast_sigmoid(g4[1] + bi) * fast_tanh(g4[0] + bj);
                 d.cstate_out[o] = cn;
-                d.hout[o] = tanhf(cn) * sigmoidf_(go);
+                d.hout[o] = fast_tanh(cn) * fast_sigmoid(g4[3] + bo);
             }
         }
     } else {
-        const int oy0 = d.oy0[phase], ox0 = d.ox0[phase];
+        const int oy0 = d.deconv ? py : 0, ox0 = d.deconv ? px : 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (m < d.M) {
                 const int b = m / HWg;
                 const int rem = m - b * HWg;
@@ -195,9 +288,9 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmDesc d) {
                 const int ax = rem - ay * d.Wg;
                 const size_t o = ((size_t)(b * d.Hout + ay * d.out_step + oy0) * d.Wout + ax * d.out_step + ox0) * d.ldo;
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int col = nblk * BN + n * 32 + l31;
-                    float v = acc[n][r] + (d.bias ? d.bias[col] : 0.f);
+                for (int t = 0; t < TPW; ++t) {
+                    const int col = nblk * BN + (wn * TPW + t) * 32 + l31;
+                    float v = acc[t][r] + (d.bias ? d.bias[col] : 0.f);
                     if (d.relu) v = fmaxf(v, 0.f);
                     d.out[o + col] = v;
                 }
@@ -206,19 +299,20 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmDesc d) {
     }
 }
 
-template <int NT, bool LSTM>
+template <int WM, int WN, int NTB, bool LSTM, int ABL = 0>
 static int launch_igemm(const IgemmDesc& d, hipStream_t stream) {
-    constexpr int BN = 32 * NT;
+    constexpr int BM = 32 * WM, BN = 32 * NTB;
     const int n_nblk = LSTM ? (d.C >> 5) : (d.N / BN);
-    const int mblk = (d.M + IG_BM - 1) / IG_BM;
+    const int mblk = (d.M + BM - 1) / BM;
+    constexpr int lds_bytes = ig_lds_bytes<WM, NTB>();
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f32_kernel<NT, LSTM>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, ig_lds_bytes<NT>());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f32_kernel<WM, WN, NTB, LSTM, ABL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
     dim3 grid(mblk * n_nblk, d.nphase);
-    hipLaunchKernelGGL((igemm_f32_kernel<NT, LSTM>), grid, dim3(256), ig_lds_bytes<NT>(), stream, d);
+    hipLaunchKernelGGL((igemm_f32_kernel<WM, WN, NTB, LSTM, ABL>), grid, dim3(256), lds_bytes, stream, d);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -228,38 +322,55 @@ int igemm_validate(const IgemmDesc& d, bool lstm) {
     PIVP_CHECK_ARG(d.ld0 >= d.c0 && d.ld0 % 4 == 0 && (d.c1 == 0 || (d.ld1 >= d.c1 && d.ld1 % 4 == 0)));
     PIVP_CHECK_ARG(d.B > 0 && d.Hin > 0 && d.Win > 0 && d.Hg > 0 && d.Wg > 0 && d.in_step >= 1);
     PIVP_CHECK_ARG(d.M == d.B * d.Hg * d.Wg);
-    PIVP_CHECK_ARG(d.nphase >= 1 && d.nphase <= 4);
-    for (int p = 0; p < d.nphase; ++p) {
-        PIVP_CHECK_ARG(d.tap_start[p] >= 0 && d.tap_count[p] >= 1 && d.tap_start[p] + d.tap_count[p] <= IG_MAX_TAPS);
-    }
+    PIVP_CHECK_ARG(d.deconv ? (d.nphase == 4 && d.in_step == 1 && d.out_step == 2) : (d.nphase == 1 && d.ksize >= 1 && d.ksize <= 7 && d.pad >= 0));
+    PIVP_CHECK_ARG(d.bytes0 > 0 && d.bytesw > 0 && (d.c1 == 0 || d.bytes1 > 0));
     if (lstm) {
         PIVP_CHECK_ARG(d.C > 0 && d.C % 32 == 0 && d.N == 4 * d.C && d.bias && d.cstate_in && d.cstate_out && d.hout);
         PIVP_CHECK_ARG(d.nphase == 1 && d.in_step == 1 && d.Hg == d.Hin && d.Wg == d.Win);
     } else {
         PIVP_CHECK_ARG(d.out && d.N % 32 == 0 && d.N >= 32 && d.N <= 128 && d.ldo >= d.N);
         PIVP_CHECK_ARG(d.out_step >= 1 && d.Hout > 0 && d.Wout > 0);
-        for (int p = 0; p < d.nphase; ++p) {
-            PIVP_CHECK_ARG((d.Hg - 1) * d.out_step + d.oy0[p] < d.Hout && (d.Wg - 1) * d.out_step + d.ox0[p] < d.Wout);
-            PIVP_CHECK_ARG(d.oy0[p] >= 0 && d.ox0[p] >= 0);
-        }
+        PIVP_CHECK_ARG((d.Hg - 1) * d.out_step + (d.deconv ? 1 : 0) < d.Hout && (d.Wg - 1) * d.out_step + (d.deconv ? 1 : 0) < d.Wout);
     }
     return PIVP_OK;
 }
 
-int igemm_lstm(const IgemmDesc& d, hipStream_t stream) {
+// Tile choice: the largest block tile that still gives every one of the 256 CUs a block.
+// variant 0 = auto, 1 = 4x1 waves (BM 128), 2 = 2x2 (BM 64), 3 = 1x4 (BM 32).
+int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant) {
     int rc = igemm_validate(d, true);
     if (rc != PIVP_OK) return rc;
-    return launch_igemm<4, true>(d, stream);
+#ifdef PIVP_ABLATE
+    if (variant >= 11 && variant <= 13) {   // timing-only diagnostic builds of the 4x1 tile (outputs are wrong)
+        if (variant == 11) return launch_igemm<4, 1, 4, true, 1>(d, stream);
+        if (variant == 12) return launch_igemm<4, 1, 4, true, 2>(d, stream);
+        return launch_igemm<4, 1, 4, true, 3>(d, stream);
+    }
+#endif
+    if (variant == 0) {
+        // measured at B = 32 (scripts/bench_lstm_layers.py): two resident blocks per CU beat one larger tile,
+        // so take BM = 128 only when it still leaves >= 2 blocks per CU, BM = 64 while that fills the chip
+        const long nb = d.C / 32;
+        if ((long)(d.M / 128) * nb >= 512) variant = 1;
+        else if ((long)(d.M / 64) * nb >= 256) variant = 2;
+        else variant = 3;
+    }
+    switch (variant) {
+        case 1: return launch_igemm<4, 1, 4, true>(d, stream);
+        case 2: return launch_igemm<2, 2, 4, true>(d, stream);
+        case 3: return launch_igemm<1, 4, 4, true>(d, stream);
+    }
+    return PIVP_ERR_BADARG;
 }
 
 int igemm_conv(const IgemmDesc& d, hipStream_t stream) {
     int rc = igemm_validate(d, false);
     if (rc != PIVP_OK) return rc;
     switch (d.N / 32) {
-        case 1: return launch_igemm<1, false>(d, stream);
-        case 2: return launch_igemm<2, false>(d, stream);
-        case 3: return launch_igemm<3, false>(d, stream);
-        case 4: return launch_igemm<4, false>(d, stream);
+        case 1: return launch_igemm<4, 1, 1, false>(d, stream);
+        case 2: return launch_igemm<4, 1, 2, false>(d, stream);
+        case 3: return launch_igemm<4, 1, 3, false>(d, stream);
+        case 4: return launch_igemm<4, 1, 4, false>(d, stream);
     }
     return PIVP_ERR_BADARG;
 }

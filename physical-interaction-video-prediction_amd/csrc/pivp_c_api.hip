@@ -24,51 +24,25 @@ struct Slab {                 // per-timestep activations, offsets in floats fro
     size_t h[7], c[7];
 };
 
-void fill_taps_conv(IgemmDesc& d, int k, int pad) {
-    d.nphase = 1;
-    d.tap_start[0] = 0; d.tap_count[0] = k * k; d.oy0[0] = 0; d.ox0[0] = 0;
-    for (int ky = 0; ky < k; ++ky)
-        for (int kx = 0; kx < k; ++kx) {
-            const int t = ky * k + kx;
-            d.dy[t] = (signed char)(ky - pad); d.dx[t] = (signed char)(kx - pad); d.wi[t] = (short)t;
-        }
-}
-
-// Transposed 3x3 stride-2 pad-1 conv with outsize = 2*in, as four sub-pixel phases:
-// oy = 2*iy - 1 + ky  =>  output parity py uses ky with (py + 1 - ky) even, iy = a + (py + 1 - ky)/2.
-void fill_taps_deconv(IgemmDesc& d) {
-    d.nphase = 4;
-    int t = 0;
-    for (int py = 0; py < 2; ++py)
-        for (int px = 0; px < 2; ++px) {
-            const int ph = py * 2 + px;
-            d.tap_start[ph] = t; d.oy0[ph] = py; d.ox0[ph] = px;
-            for (int ky = 0; ky < 3; ++ky) {
-                if ((py + 1 - ky) & 1) continue;
-                for (int kx = 0; kx < 3; ++kx) {
-                    if ((px + 1 - kx) & 1) continue;
-                    d.dy[t] = (signed char)((py + 1 - ky) / 2);
-                    d.dx[t] = (signed char)((px + 1 - kx) / 2);
-                    d.wi[t] = (short)(ky * 3 + kx);
-                    ++t;
-                }
-            }
-            d.tap_count[ph] = t - d.tap_start[ph];
-        }
-}
+// extent in bytes of an NHWC view with pixel stride ld (for the kernels' buffer descriptors)
+long long view_bytes(int B, int H, int W, int ld) { return (long long)B * H * W * ld * 4; }
+bool fits31(long long v) { return v > 0 && v < (1LL << 31); }
 
 int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
-                 const float* c_in, float* c_out, float* h_out, int B, int H, int W, hipStream_t s) {
+                 const float* c_in, float* c_out, float* h_out, int B, int H, int W, hipStream_t s, int variant = 0) {
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
     d.x0 = x; d.c0 = cx; d.ld0 = ldx; d.x1 = h_prev; d.c1 = C; d.ld1 = C;
     d.w = w; d.bias = bias;
     d.B = B; d.Hin = H; d.Win = W; d.Hg = H; d.Wg = W; d.in_step = 1;
     d.N = 4 * C; d.M = B * H * W;
-    fill_taps_conv(d, 5, 2);
+    d.nphase = 1; d.deconv = 0; d.ksize = 5; d.pad = 2;
+    const long long b0 = view_bytes(B, H, W, ldx), b1 = view_bytes(B, H, W, C), bw = 25LL * (cx + C) * 4 * C * 4;
+    if (!fits31(b0) || !fits31(b1) || !fits31(bw)) return PIVP_ERR_BADARG;
+    d.bytes0 = (int)b0; d.bytes1 = (int)b1; d.bytesw = (int)bw;
     d.out_step = 1; d.Hout = H; d.Wout = W;
     d.cstate_in = c_in; d.cstate_out = c_out; d.hout = h_out; d.C = C;
-    return igemm_lstm(d, s);
+    return igemm_lstm(d, s, variant);
 }
 
 int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
@@ -79,7 +53,10 @@ int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float*
     d.x0 = x; d.c0 = cin; d.ld0 = ldx; d.w = w; d.bias = bias;
     d.B = B; d.Hin = Hin; d.Win = Win; d.Hg = Hin / 2; d.Wg = Win / 2; d.in_step = 2;
     d.N = cout; d.M = B * d.Hg * d.Wg;
-    fill_taps_conv(d, 3, 1);
+    d.nphase = 1; d.deconv = 0; d.ksize = 3; d.pad = 1;
+    const long long b0 = view_bytes(B, Hin, Win, ldx), bw = 9LL * cin * cout * 4;
+    if (!fits31(b0) || !fits31(bw)) return PIVP_ERR_BADARG;
+    d.bytes0 = (int)b0; d.bytesw = (int)bw;
     d.out_step = 1; d.Hout = d.Hg; d.Wout = d.Wg; d.out = out; d.ldo = ldo; d.relu = relu;
     return igemm_conv(d, s);
 }
@@ -91,7 +68,10 @@ int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const floa
     d.x0 = x; d.c0 = cin; d.ld0 = ldx; d.w = w; d.bias = bias;
     d.B = B; d.Hin = Hin; d.Win = Win; d.Hg = Hin; d.Wg = Win; d.in_step = 1;
     d.N = cout; d.M = B * Hin * Win;
-    fill_taps_deconv(d);
+    d.nphase = 4; d.deconv = 1; d.ksize = 3; d.pad = 1;
+    const long long b0 = view_bytes(B, Hin, Win, ldx), bw = 9LL * cin * cout * 4;
+    if (!fits31(b0) || !fits31(bw)) return PIVP_ERR_BADARG;
+    d.bytes0 = (int)b0; d.bytesw = (int)bw;
     d.out_step = 2; d.Hout = 2 * Hin; d.Wout = 2 * Win; d.out = out; d.ldo = ldo; d.relu = relu;
     return igemm_conv(d, s);
 }
@@ -463,6 +443,11 @@ extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_pre
                              const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream) {
     if (!x || !h_prev || !w || !bias || !c_in || !c_out || !h_out) return PIVP_ERR_BADARG;
     return run_convlstm(x, cx, ldx, h_prev, C, w, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream);
+}
+extern "C" int pivp_convlstm_v(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
+                               const float* c_in, float* c_out, float* h_out, int B, int H, int W, int variant, void* stream) {
+    if (!x || !h_prev || !w || !bias || !c_in || !c_out || !h_out || variant < 0 || variant > 13) return PIVP_ERR_BADARG;
+    return run_convlstm(x, cx, ldx, h_prev, C, w, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, variant);
 }
 extern "C" int pivp_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                               int ldo, int relu, int B, int Hin, int Win, void* stream) {

@@ -5,33 +5,32 @@
 //   * frames (prev image, generated image, mask logits, enc7): planar [B][planes][H*W] fp32, i.e.
 //     the reference's NCHW, because the flat-11 mask softmax (TM:720-722) and the per-plane 5x5 CDNA
 //     transform (TM:341) are defined on that order
-//   * conv / deconv weights: [tap][Cin][Cout]; Linear weights K-major; LN gamma/beta NHWC-flat.
+//   * conv / deconv weights of the MFMA kernels: [tap][Cin/32][Cout][32] (K-inner packed, so a K chunk of a
+//     column is one 128-B line); enc0 / enc3 / 1x1 heads: [tap][Cin][Cout]; Linear weights K-major;
+//     LN gamma/beta NHWC-flat.
 #pragma once
 #include "pivp_common.h"
 
 namespace pivp {
 
-constexpr int IG_MAX_TAPS = 32;
-
 struct IgemmDesc {
     const float* x0; const float* x1;   // input sources (channel-concatenated: x0 then x1)
     int c0, ld0, c1, ld1;
-    const float* w;                      // [wtaps][c0+c1][N]
+    const float* w;                      // [wtaps][(c0+c1)/32][N][32]  (K-inner packed)
     const float* bias;                   // [N] or null
     int B, Hin, Win;                     // input feature-map size
     int Hg, Wg, in_step;                 // anchor grid; input coord = anchor*in_step + (dy,dx)
     int N, M;                            // output columns; M = B*Hg*Wg
-    int nphase;
-    int tap_start[4], tap_count[4], oy0[4], ox0[4];
-    signed char dy[IG_MAX_TAPS], dx[IG_MAX_TAPS];
-    short wi[IG_MAX_TAPS];               // weight tap index of each entry
-    int out_step, Hout, Wout;            // output coord = anchor*out_step + (oy0,ox0)
+    int nphase;                          // 1 (conv) or 4 (sub-pixel phases of the stride-2 transposed conv)
+    int deconv, ksize, pad;              // tap set: conv ksize x ksize with `pad`, or transposed 3x3 s2 p1
+    int bytes0, bytes1, bytesw;          // extents of x0 / x1 / w for the buffer descriptors (< 2^31)
+    int out_step, Hout, Wout;            // output coord = anchor*out_step + phase parity
     float* out; int ldo; int relu;
     // ConvLSTM epilogue
     const float* cstate_in; float* cstate_out; float* hout; int C;
 };
 
-int igemm_lstm(const IgemmDesc& d, hipStream_t stream);
+int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant = 0);  // 0 auto, 1: 4x1 waves, 2: 2x2, 3: 1x4
 int igemm_conv(const IgemmDesc& d, hipStream_t stream);
 
 // enc0: 5x5 stride-2 pad-2 conv on a planar 3-channel frame -> NHWC 32 channels (TM:500)

@@ -25,15 +25,15 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def convlstm(x, h, c, W, b):
+def convlstm(x, h, c, W, b, variant=0):
     lib = _lib.load()
     B, cx, H, Wd = x.shape
     C = h.shape[1]
     xd, hd, cd = nhwc(x), nhwc(h), nhwc(c)
     wd, bd = _t(pivp_amd.to_internal('lstm1/conv/W', W)), _t(b)
     c_out = torch.empty_like(cd); h_out = torch.empty_like(hd)
-    _lib.check(lib.pivp_convlstm(xd.data_ptr(), cx, cx, hd.data_ptr(), C, wd.data_ptr(), bd.data_ptr(), cd.data_ptr(),
-                                 c_out.data_ptr(), h_out.data_ptr(), B, H, Wd, stream()), 'convlstm')
+    _lib.check(lib.pivp_convlstm_v(xd.data_ptr(), cx, cx, hd.data_ptr(), C, wd.data_ptr(), bd.data_ptr(), cd.data_ptr(),
+                                   c_out.data_ptr(), h_out.data_ptr(), B, H, Wd, variant, stream()), 'convlstm')
     torch.cuda.synchronize()
     return nchw(h_out, B, H, Wd, C), nchw(c_out, B, H, Wd, C)
 

@@ -26,13 +26,14 @@ def _lstm_ref(x, h, c, W, b):
     return np.tanh(cn) * R.sigmoid(o), cn
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize('B,cx,C,H', [(2, 32, 32, 32), (2, 32, 64, 16), (3, 64, 128, 8), (2, 128, 64, 16), (1, 96, 32, 32), (5, 64, 64, 16)])
-def test_convlstm_parity(ops, B, cx, C, H):
+def test_convlstm_parity(ops, B, cx, C, H, variant):
     rs = np.random.RandomState(B * 100 + C)
     x = rs.randn(B, cx, H, H); h = rs.randn(B, C, H, H) * 0.5; c = rs.randn(B, C, H, H)
     W = rs.randn(4 * C, cx + C, 5, 5) / np.sqrt(25 * (cx + C)); b = rs.randn(4 * C) * 0.1
     hr, cr = _lstm_ref(x, h, c, W, b)
-    hg, cg = ops.convlstm(x, h, c, W, b)
+    hg, cg = ops.convlstm(x, h, c, W, b, variant)
     assert np.abs(hg - hr).max() < TOL and np.abs(cg - cr).max() < TOL
 
 

@@ -70,14 +70,17 @@ def test_checkpoint_layout_roundtrip_and_permutations():
         flat = pivp_amd.to_internal(key, a)
         back = pivp_amd.from_internal(key, flat, shapes[key])
         assert np.array_equal(a, back), key
-    # conv: internal [tap][Cin][Cout]
+    # conv: internal [tap][Cin/32][Cout][32] (K-inner packed)
     W = rs.randn(*shapes['lstm5/conv/W']).astype(np.float32)
-    f = pivp_amd.to_internal('lstm5/conv/W', W).reshape(25, 192, 512)
-    assert f[7, 100, 300] == W[300, 100, 1, 2]
+    f = pivp_amd.to_internal('lstm5/conv/W', W).reshape(25, 6, 512, 32)
+    assert f[7, 100 // 32, 300, 100 % 32] == W[300, 100, 1, 2]
     # deconv: reference (Cin,Cout,kh,kw)
     Wd = rs.randn(*shapes['enc5/W']).astype(np.float32)
-    fd = pivp_amd.to_internal('enc5/W', Wd).reshape(9, 96, 96)
-    assert fd[5, 10, 20] == Wd[10, 20, 1, 2]
+    fd = pivp_amd.to_internal('enc5/W', Wd).reshape(9, 3, 96, 32)
+    assert fd[5, 0, 20, 10] == Wd[10, 20, 1, 2]
+    # enc0 (Cin = 3) stays [tap][Cin][Cout]
+    W0 = rs.randn(32, 3, 5, 5).astype(np.float32)
+    assert pivp_amd.to_internal('enc0/W', W0).reshape(25, 3, 32)[7, 2, 9] == W0[9, 2, 1, 2]
     # LN gamma: NCHW-flat c*HW+p -> NHWC-flat p*C+c
     g = np.arange(8192, dtype=np.float32)
     fg = pivp_amd.to_internal('hidden5/norm/gamma', g)
