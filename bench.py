@@ -106,9 +106,9 @@ def main():
                 ms = (ctypes.c_double * 7)(); n = (ctypes.c_int * 7)(); fl = (ctypes.c_double * 7)()
                 rc = lib.pivp_plan_profile_read(plan.h, ms, n, fl)
                 assert rc == 0, rc
-                ms_tot += np.array(ms[:]); n_tot += np.array(n[:]); flops = np.array(fl[:])
+                ms_tot += np.array(ms[:]); n_tot += np.array(n[:]); flops += np.array(fl[:])
             lib.pivp_plan_set_profiling(plan.h, 0)
-            total_flops = float((flops * n_tot).sum())
+            total_flops = float(flops.sum())
             total_s = float(ms_tot.sum()) * 1e-3
             achieved = total_flops / total_s / 1e12
             roofline = {
@@ -118,7 +118,7 @@ def main():
                 'traffic': None,
                 'launches': int(n_tot.sum()), 'avg_launch_us': round(total_s / max(1, int(n_tot.sum())) * 1e6, 2),
                 'algorithmic_gflop_per_launch': round(total_flops / max(1, int(n_tot.sum())) / 1e9, 3),
-                'per_layer_tflops': {('lstm%d' % (i + 1)): round(float(flops[i] * n_tot[i] / (ms_tot[i] * 1e-3) / 1e12), 2)
+                'per_layer_tflops': {('lstm%d' % (i + 1)): round(float(flops[i] / (ms_tot[i] * 1e-3) / 1e12), 2)
                                      for i in range(7) if ms_tot[i] > 0},
                 'share_of_step_time': round(total_s / args.steps / (elapsed / args.steps), 3),
             }

@@ -80,7 +80,8 @@ int pivp_rollout_forward(pivp_plan_t* plan, const float* images, const float* ac
 /* Measurement hooks (bench.py): when enabled, every ConvLSTM launch of pivp_rollout_forward is bracketed
  * by hipEvents recorded on the launch stream.  After the caller has synchronised the stream,
  * pivp_plan_profile_read returns, per ConvLSTM layer (lstm1..lstm7): summed milliseconds, launch count
- * and the ALGORITHMIC flops of one launch, 2*M*4C*25*(Cx+C)  (TM:224 conv inside TM:262-272). */
+ * and the SUM of the algorithmic flops of those launches, 2*M*4C*25*(Cx+C) each (TM:224 conv inside TM:262-272;
+ * the first step after reset_state skips the all-zero h half of K and counts 2*M*4C*25*Cx). */
 int pivp_plan_set_profiling(pivp_plan_t* plan, int enable);
 int pivp_plan_profile_read(pivp_plan_t* plan, double* ms_per_layer, int* launches_per_layer, double* flops_per_layer);
 
@@ -94,7 +95,7 @@ long long pivp_get_tap(pivp_plan_t* plan, const char* name, int step, float* out
  * ------------------------------------------------------------------------------------------ */
 
 /* BasicConvLSTMCell.__call__ (TM:234-276): gates = conv5x5(concat(x,h)) ; c,h update, forget bias 1.
- * x NHWC (cx channels, stride ldx), h_prev/c NHWC [B][H][W][C]; w [25][(cx+C)/32][4C][32] (K-inner packed), gate order j,i,f,o. */
+ * x NHWC (cx channels, stride ldx), h_prev/c NHWC [B][H][W][C]; h_prev may be NULL = all zeros (first step); w [25][(cx+C)/32][4C][32] (K-inner packed), gate order j,i,f,o. */
 int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                   const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream);
 

@@ -83,43 +83,61 @@ int heads_1x1(const float* e6, const float* wm, const float* bm, const float* we
 }
 
 // ------------------------------------------------------------------------------------------
-// Skinny Linear on flatten(hidden5): out[b][o] = sum_k x[b][k] * wt[k][o]  (B <= 32 per block row).
-// K is split in slices of 128 so the 8 MB weight matrix is streamed once by K/128 blocks; each
-// slice writes its partial sums and the finisher adds them in a fixed order (bitwise reproducible).
+// Skinny Linear on flatten(hidden5): out[b][o] = sum_k x[b][k] * wt[k][o].
+// K is split in slices of 64 and the batch in groups of 8; each block writes its partial sums and the
+// finisher adds them in a fixed order (bitwise reproducible).
 // wt is K-major with 256 padded columns; x is the NHWC-flat hidden5 (the checkpoint permutes
 // cdna_kerns/W's in-feature axis from c*64+y*8+x to (y*8+x)*128+c at load time).
 // ------------------------------------------------------------------------------------------
-constexpr int LIN_KS = 128;
+constexpr int LIN_KS = 64;    // K per slice
+constexpr int LIN_BG = 8;     // batch rows per block
 int cdna_kernel_partials_slices(int K) { return (K + LIN_KS - 1) / LIN_KS; }
 
+// grid (K/64 slices, B/8 groups): 512 blocks at B = 32, K = 8192, so the 8 MB weight matrix streams across the
+// whole chip.  ACC = float for the CDNA kernels, double for the STP regressor (its output steers a bilinear warp
+// that amplifies a 1e-6 error in theta to ~3e-5 pixels).
+template <typename ACC>
 __global__ __launch_bounds__(256) void skinny_linear_partials_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                                      float* __restrict__ partials, int B, int K) {
-    __shared__ __attribute__((aligned(16))) float xs[32 * LIN_KS];
-    const int ks = blockIdx.x, b0 = blockIdx.y * 32, o = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float xs[LIN_BG * LIN_KS];
+    const int ks = blockIdx.x, b0 = blockIdx.y * LIN_BG, o = threadIdx.x;
     const int k0 = ks * LIN_KS;
-    const int nb = min(32, B - b0);
-    for (int i = threadIdx.x; i < 32 * LIN_KS; i += 256) {
+    const int nb = min(LIN_BG, B - b0);
+    for (int i = threadIdx.x; i < LIN_BG * LIN_KS; i += 256) {
         const int bb = i / LIN_KS, k = i - bb * LIN_KS;
         xs[i] = (bb < nb && k0 + k < K) ? x[(size_t)(b0 + bb) * K + k0 + k] : 0.f;
     }
     __syncthreads();
-    // fp64 accumulation: the work is tiny (B x 256 x K MACs) and the STP warp / CDNA kernels that
-    // consume these sums amplify their error (a 1e-6 error in theta moves a sample by 3e-5 pixels)
-    double acc[32];
+    ACC acc[LIN_BG];
 #pragma unroll
-    for (int bb = 0; bb < 32; ++bb) acc[bb] = 0.0;
+    for (int bb = 0; bb < LIN_BG; ++bb) acc[bb] = (ACC)0;
+#pragma unroll 4
     for (int k = 0; k < LIN_KS; k += 4) {
         float w[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] = (k0 + k + e < K) ? wt[(size_t)(k0 + k + e) * 256 + o] : 0.f;
 #pragma unroll
-        for (int bb = 0; bb < 32; ++bb) {
+        for (int bb = 0; bb < LIN_BG; ++bb) {
             const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + bb * LIN_KS + k);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[bb] = fma((double)xv[e], (double)w[e], acc[bb]);
+            for (int e = 0; e < 4; ++e) acc[bb] += (ACC)xv[e] * (ACC)w[e];
         }
     }
     for (int bb = 0; bb < nb; ++bb) partials[((size_t)ks * B + b0 + bb) * 256 + o] = (float)acc[bb];
+}
+
+// sum of the K-slice partials of output o of sample b, fixed order (bitwise reproducible), 4 independent chains
+__device__ __forceinline__ double sum_partials(const float* __restrict__ partials, int B, int KS, int b, int o) {
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int ks = 0;
+    for (; ks + 3 < KS; ks += 4) {
+        a0 += (double)partials[((size_t)(ks + 0) * B + b) * 256 + o];
+        a1 += (double)partials[((size_t)(ks + 1) * B + b) * 256 + o];
+        a2 += (double)partials[((size_t)(ks + 2) * B + b) * 256 + o];
+        a3 += (double)partials[((size_t)(ks + 3) * B + b) * 256 + o];
+    }
+    for (; ks < KS; ++ks) a0 += (double)partials[((size_t)ks * B + b) * 256 + o];
+    return (a0 + a1) + (a2 + a3);
 }
 
 // CDNA finisher (TM:326-329): + bias, relu(k - RELU_SHIFT) + RELU_SHIFT, divide by the 5x5 sum.
@@ -129,8 +147,7 @@ __global__ __launch_bounds__(256) void cdna_kernels_finish_kernel(const float* _
     const int b = blockIdx.x, o = threadIdx.x;
     float acc = 0.f;
     if (o < nout) {
-        double a = bias[o];
-        for (int ks = 0; ks < KS; ++ks) a += (double)partials[((size_t)ks * B + b) * 256 + o];
+        const double a = (double)bias[o] + sum_partials(partials, B, KS, b, o);
         acc = fmaxf((float)a - 1e-12f, 0.f) + 1e-12f;
     }
     v[o] = acc;
@@ -148,7 +165,7 @@ int cdna_kernels(const float* hidden5, const float* wt, const float* bias, float
                  int B, int K, int num_masks, hipStream_t s) {
     PIVP_CHECK_ARG(hidden5 && wt && bias && partials && kerns && B > 0 && K > 0 && num_masks >= 1 && num_masks * 25 <= 256);
     const int KS = cdna_kernel_partials_slices(K);
-    hipLaunchKernelGGL(skinny_linear_partials_kernel, dim3(KS, (B + 31) / 32), dim3(256), 0, s, hidden5, wt, partials, B, K);
+    hipLaunchKernelGGL(skinny_linear_partials_kernel<float>, dim3(KS, (B + LIN_BG - 1) / LIN_BG), dim3(256), 0, s, hidden5, wt, partials, B, K);
     hipLaunchKernelGGL(cdna_kernels_finish_kernel, dim3(B), dim3(256), 0, s, partials, bias, kerns, B, KS, num_masks * 25);
     return PIVP_LAUNCH_STATUS();
 }
@@ -160,8 +177,7 @@ __global__ __launch_bounds__(128) void stp_params_finish_kernel(const float* __r
     __shared__ float s1[100];
     const int b = blockIdx.x, o = threadIdx.x;
     if (o < 100) {
-        double acc = b1[o];
-        for (int ks = 0; ks < KS; ++ks) acc += (double)partials[((size_t)ks * B + b) * 256 + o];
+        const double acc = (double)b1[o] + sum_partials(partials, B, KS, b, o);
         s1[o] = fmaxf((float)acc, 0.f);
     }
     __syncthreads();
@@ -176,7 +192,7 @@ int stp_params(const float* hidden5, const float* wt1, const float* b1, const fl
                float* partials, float* theta, int B, int K, hipStream_t s) {
     PIVP_CHECK_ARG(hidden5 && wt1 && b1 && w2 && b2 && partials && theta && B > 0 && K > 0);
     const int KS = cdna_kernel_partials_slices(K);
-    hipLaunchKernelGGL(skinny_linear_partials_kernel, dim3(KS, (B + 31) / 32), dim3(256), 0, s, hidden5, wt1, partials, B, K);
+    hipLaunchKernelGGL(skinny_linear_partials_kernel<double>, dim3(KS, (B + LIN_BG - 1) / LIN_BG), dim3(256), 0, s, hidden5, wt1, partials, B, K);
     hipLaunchKernelGGL(stp_params_finish_kernel, dim3(B), dim3(128), 0, s, partials, b1, w2, b2, theta, B, KS);
     return PIVP_LAUNCH_STATUS();
 }

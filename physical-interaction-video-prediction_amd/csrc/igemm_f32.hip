@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
         s_ld = s_first ? d.ld0 : d.ld1;
         const int cbase = s_first ? ch : ch - d.c0;
         s_delta = ((s_dy * d.Win + s_dx) * s_ld + cbase) * 4;               // bytes, relative to the anchor pixel
-        s_wbase = (wi * ncc + l_cc) * d.N * 128;                             // bytes
+        s_wbase = (wi * (d.wcin >> 5) + l_cc) * d.N * 128;                   // bytes; the weight keeps all its Cin chunks
         ++l_cc;
         const bool w0 = l_cc == ncc;
         l_cc = w0 ? 0 : l_cc;
@@ -324,6 +324,7 @@ int igemm_validate(const IgemmDesc& d, bool lstm) {
     PIVP_CHECK_ARG(d.M == d.B * d.Hg * d.Wg);
     PIVP_CHECK_ARG(d.deconv ? (d.nphase == 4 && d.in_step == 1 && d.out_step == 2) : (d.nphase == 1 && d.ksize >= 1 && d.ksize <= 7 && d.pad >= 0));
     PIVP_CHECK_ARG(d.bytes0 > 0 && d.bytesw > 0 && (d.c1 == 0 || d.bytes1 > 0));
+    PIVP_CHECK_ARG(d.wcin >= d.c0 + d.c1 && d.wcin % 32 == 0);
     if (lstm) {
         PIVP_CHECK_ARG(d.C > 0 && d.C % 32 == 0 && d.N == 4 * d.C && d.bias && d.cstate_in && d.cstate_out && d.hout);
         PIVP_CHECK_ARG(d.nphase == 1 && d.in_step == 1 && d.Hg == d.Hin && d.Wg == d.Win);
@@ -363,16 +364,25 @@ int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant) {
     return PIVP_ERR_BADARG;
 }
 
+// Plain conv / transposed conv: pick the block tile that fills the 256 CUs.  Blocks = (M/BM) * (N/BN) * phases.
 int igemm_conv(const IgemmDesc& d, hipStream_t stream) {
     int rc = igemm_validate(d, false);
     if (rc != PIVP_OK) return rc;
-    switch (d.N / 32) {
-        case 1: return launch_igemm<4, 1, 1, false>(d, stream);
-        case 2: return launch_igemm<4, 1, 2, false>(d, stream);
-        case 3: return launch_igemm<4, 1, 3, false>(d, stream);
-        case 4: return launch_igemm<4, 1, 4, false>(d, stream);
+    const int nt = d.N / 32;
+    const long full = (long)((d.M + 127) / 128) * d.nphase;   // blocks with BM = 128 and the whole N in one block
+    if (full >= 256 || nt == 0) {
+        switch (nt) {
+            case 1: return launch_igemm<4, 1, 1, false>(d, stream);
+            case 2: return launch_igemm<4, 1, 2, false>(d, stream);
+            case 3: return launch_igemm<4, 1, 3, false>(d, stream);
+            case 4: return launch_igemm<4, 1, 4, false>(d, stream);
+        }
+        return PIVP_ERR_BADARG;
     }
-    return PIVP_ERR_BADARG;
+    if (nt == 4 && full * 2 < 256) return launch_igemm<1, 4, 4, false>(d, stream);   // BM 32
+    if (nt == 4) return launch_igemm<2, 2, 4, false>(d, stream);                      // BM 64
+    if (nt == 2 && full * 2 >= 128) return launch_igemm<2, 2, 2, false>(d, stream);  // BM 64
+    return launch_igemm<4, 1, 1, false>(d, stream);                                    // BN 32: N/32 column blocks
 }
 
 }  // namespace pivp

@@ -32,7 +32,9 @@ int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, co
                  const float* c_in, float* c_out, float* h_out, int B, int H, int W, hipStream_t s, int variant = 0) {
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
-    d.x0 = x; d.c0 = cx; d.ld0 = ldx; d.x1 = h_prev; d.c1 = C; d.ld1 = C;
+    // h_prev == nullptr: the recurrent input is identically zero (first timestep after reset_state, TM:254-257);
+    // its K range contributes exactly 0 and is skipped
+    d.x0 = x; d.c0 = cx; d.ld0 = ldx; d.x1 = h_prev; d.c1 = h_prev ? C : 0; d.ld1 = C; d.wcin = cx + C;
     d.w = w; d.bias = bias;
     d.B = B; d.Hin = H; d.Win = W; d.Hg = H; d.Wg = W; d.in_step = 1;
     d.N = 4 * C; d.M = B * H * W;
@@ -50,7 +52,7 @@ int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float*
     if (Hin % 2 || Win % 2) return PIVP_ERR_BADARG;
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
-    d.x0 = x; d.c0 = cin; d.ld0 = ldx; d.w = w; d.bias = bias;
+    d.x0 = x; d.c0 = cin; d.ld0 = ldx; d.wcin = cin; d.w = w; d.bias = bias;
     d.B = B; d.Hin = Hin; d.Win = Win; d.Hg = Hin / 2; d.Wg = Win / 2; d.in_step = 2;
     d.N = cout; d.M = B * d.Hg * d.Wg;
     d.nphase = 1; d.deconv = 0; d.ksize = 3; d.pad = 1;
@@ -65,7 +67,7 @@ int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const floa
                     int ldo, int relu, int B, int Hin, int Win, hipStream_t s) {
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
-    d.x0 = x; d.c0 = cin; d.ld0 = ldx; d.w = w; d.bias = bias;
+    d.x0 = x; d.c0 = cin; d.ld0 = ldx; d.wcin = cin; d.w = w; d.bias = bias;
     d.B = B; d.Hin = Hin; d.Win = Win; d.Hg = Hin; d.Wg = Win; d.in_step = 1;
     d.N = cout; d.M = B * Hin * Win;
     d.nphase = 4; d.deconv = 1; d.ksize = 3; d.pad = 1;
@@ -255,7 +257,7 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     const Slab* Sp = t > 0 ? &p->slabs[(t - 1) % p->nslabs] : nullptr;
     float* lnp = ws + p->o_lnpart;
     const float eps = c.ln_eps;
-    auto hp = [&](int i) { return Sp ? ws + Sp->h[i] : ws + p->o_zero; };
+    auto hp = [&](int i) -> const float* { return Sp ? ws + Sp->h[i] : nullptr; };   // t = 0: h == 0, skipped
     auto cp = [&](int i) { return Sp ? ws + Sp->c[i] : ws + p->o_zero; };
     auto lstm = [&](int i, const float* x, int ldx, int hh, int wwid) {
         const bool prof = p->prof_on && p->prof_used + 2 <= p->prof_ev.size();
@@ -264,7 +266,7 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
                               cp(i), ws + S.c[i], ws + S.h[i], B, hh, wwid, s);
         if (prof) {
             (void)hipEventRecord(p->prof_ev[p->prof_used + 1], s);
-            p->prof_layer[p->prof_used / 2] = i;
+            p->prof_layer[p->prof_used / 2] = i + (Sp ? 0 : 8);   // +8: first-step launch without the h half of K
             p->prof_used += 2;
         }
         return rc;
@@ -379,17 +381,21 @@ extern "C" int pivp_plan_set_profiling(pivp_plan_t* plan, int enable) {
 extern "C" int pivp_plan_profile_read(pivp_plan_t* plan, double* ms_per_layer, int* launches_per_layer, double* flops_per_layer) {
     if (!plan || !ms_per_layer || !launches_per_layer || !flops_per_layer) return PIVP_ERR_BADARG;
     const pivp_config_t& c = plan->cfg;
+    double fl_full[7], fl_first[7];
     for (int i = 0; i < 7; ++i) {
-        ms_per_layer[i] = 0.0; launches_per_layer[i] = 0;
+        ms_per_layer[i] = 0.0; launches_per_layer[i] = 0; flops_per_layer[i] = 0.0;
         const int lv = kLstm[i].level;
         const double M = (double)c.batch * (c.height / lv) * (c.width / lv);
-        flops_per_layer[i] = 2.0 * M * 4.0 * kLstm[i].C * 25.0 * (kLstm[i].cx + kLstm[i].C);
+        fl_full[i] = 2.0 * M * 4.0 * kLstm[i].C * 25.0 * (kLstm[i].cx + kLstm[i].C);
+        fl_first[i] = 2.0 * M * 4.0 * kLstm[i].C * 25.0 * kLstm[i].cx;     // executed flops when h == 0 is skipped
     }
     for (size_t k = 0; k + 1 < plan->prof_used; k += 2) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, plan->prof_ev[k], plan->prof_ev[k + 1]) != hipSuccess) return PIVP_ERR_STATE;
-        const int L = plan->prof_layer[k / 2];
+        const int tag = plan->prof_layer[k / 2];
+        const int L = tag & 7;
         ms_per_layer[L] += ms; launches_per_layer[L] += 1;
+        flops_per_layer[L] += (tag & 8) ? fl_first[L] : fl_full[L];   // SUM of executed flops over the launches
     }
     plan->prof_used = 0;
     return PIVP_OK;
@@ -441,12 +447,12 @@ extern "C" long long pivp_get_tap(pivp_plan_t* plan, const char* name, int step,
 // ---------------------------------------------------------------------------------------------
 extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                              const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream) {
-    if (!x || !h_prev || !w || !bias || !c_in || !c_out || !h_out) return PIVP_ERR_BADARG;
+    if (!x || !w || !bias || !c_in || !c_out || !h_out) return PIVP_ERR_BADARG;
     return run_convlstm(x, cx, ldx, h_prev, C, w, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream);
 }
 extern "C" int pivp_convlstm_v(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                                const float* c_in, float* c_out, float* h_out, int B, int H, int W, int variant, void* stream) {
-    if (!x || !h_prev || !w || !bias || !c_in || !c_out || !h_out || variant < 0 || variant > 13) return PIVP_ERR_BADARG;
+    if (!x || !w || !bias || !c_in || !c_out || !h_out || variant < 0 || variant > 13) return PIVP_ERR_BADARG;
     return run_convlstm(x, cx, ldx, h_prev, C, w, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, variant);
 }
 extern "C" int pivp_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,

@@ -16,6 +16,7 @@ namespace pivp {
 struct IgemmDesc {
     const float* x0; const float* x1;   // input sources (channel-concatenated: x0 then x1)
     int c0, ld0, c1, ld1;
+    int wcin;                            // Cin the weight was packed with (>= c0+c1: trailing sources may be skipped)
     const float* w;                      // [wtaps][(c0+c1)/32][N][32]  (K-inner packed)
     const float* bias;                   // [N] or null
     int B, Hin, Win;                     // input feature-map size

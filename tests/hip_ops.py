@@ -25,14 +25,14 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def convlstm(x, h, c, W, b, variant=0):
+def convlstm(x, h, c, W, b, variant=0, h_is_zero=False):
     lib = _lib.load()
     B, cx, H, Wd = x.shape
     C = h.shape[1]
     xd, hd, cd = nhwc(x), nhwc(h), nhwc(c)
     wd, bd = _t(pivp_amd.to_internal('lstm1/conv/W', W)), _t(b)
     c_out = torch.empty_like(cd); h_out = torch.empty_like(hd)
-    _lib.check(lib.pivp_convlstm_v(xd.data_ptr(), cx, cx, hd.data_ptr(), C, wd.data_ptr(), bd.data_ptr(), cd.data_ptr(),
+    _lib.check(lib.pivp_convlstm_v(xd.data_ptr(), cx, cx, None if h_is_zero else hd.data_ptr(), C, wd.data_ptr(), bd.data_ptr(), cd.data_ptr(),
                                    c_out.data_ptr(), h_out.data_ptr(), B, H, Wd, variant, stream()), 'convlstm')
     torch.cuda.synchronize()
     return nchw(h_out, B, H, Wd, C), nchw(c_out, B, H, Wd, C)

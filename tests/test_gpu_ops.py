@@ -37,6 +37,20 @@ def test_convlstm_parity(ops, B, cx, C, H, variant):
     assert np.abs(hg - hr).max() < TOL and np.abs(cg - cr).max() < TOL
 
 
+@pytest.mark.parametrize('variant', [1, 2, 3])
+def test_convlstm_first_step_skips_zero_h(ops, variant):
+    # h_prev = NULL (all zeros after reset_state, TM:254-257): the h half of K is skipped, result identical
+    rs = np.random.RandomState(77)
+    B, cx, C, H = 2, 64, 128, 8
+    x = rs.randn(B, cx, H, H); h = np.zeros((B, C, H, H)); c = np.zeros((B, C, H, H))
+    W = rs.randn(4 * C, cx + C, 5, 5) / np.sqrt(25 * (cx + C)); b = rs.randn(4 * C) * 0.1
+    hr, cr = _lstm_ref(x, h, c, W, b)
+    hg, cg = ops.convlstm(x, h, c, W, b, variant, h_is_zero=True)
+    hz, cz = ops.convlstm(x, h, c, W, b, variant, h_is_zero=False)
+    assert np.abs(hg - hr).max() < TOL and np.abs(cg - cr).max() < TOL
+    assert np.array_equal(hg, hz) and np.array_equal(cg, cz)      # skipping adds exact zeros: bit-identical
+
+
 def test_convlstm_zero_weights_kat(ops):
     # zero weights -> c = c * sigmoid(1), h = tanh(c)/2
     x = np.random.RandomState(0).randn(2, 32, 8, 8)
