@@ -103,6 +103,32 @@ int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, c
 int pivp_convlstm_v(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                     const float* c_in, float* c_out, float* h_out, int B, int H, int W, int variant, void* stream);
 
+/* --- training (what Chainer's autograd does under optimizer.update, TM:950) ---------------------------------- */
+/* pivp_convlstm with the gate activations kept for BPTT: gates_out [B*H*W][4C] = tanh(j), s(i), s(f+1), s(o). */
+int pivp_convlstm_train(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
+                        const float* c_in, float* c_out, float* h_out, float* gates_out, int B, int H, int W, void* stream);
+/* Backward of one ConvLSTM cell.  dh arrives as dh_a (stride lda) + dh_b (stride ldb, may be NULL); dc is the incoming
+ * d c_t (ignored when dc_valid == 0) and is overwritten with d c_{t-1}.  d_in [B*H*W][cx+C] receives d x | d h_{t-1};
+ * dW (packed like w) and db are ACCUMULATED.  dG [B*H*W][4C] and wt (size of w) are scratch. */
+int pivp_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
+                           const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
+                           float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
+                           int B, int H, int W, void* stream);
+/* Backward of conv3x3s2 (mode 0) / deconv3x3s2 (mode 1) given dy with the ReLU mask already applied: dx (NULL to skip;
+ * accum_dx adds into it), dW and db accumulated.  wt (size of w) is scratch. */
+int pivp_conv_backward(int mode, const float* x, int cin, int ldx, const float* w, const float* dy, int cout, int ldy,
+                       float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, void* stream);
+/* LayerNorm forward keeping (mean, rstd) per sample in stat [B][2], and its backward (dgamma/dbeta accumulated). */
+int pivp_layernorm_train(const float* x, const float* gamma, const float* beta, float* out, float* partials, float* stat,
+                         int B, int n, int C, int ldo, float eps, int relu, void* stream);
+long long pivp_layernorm_backward_scratch_floats(int B, int n);
+int pivp_layernorm_backward(const float* dy, int lddy, const float* y, int ldy, const float* x, const float* stat,
+                            const float* gamma, float* partials, float* dx, float* dgamma, float* dbeta,
+                            int B, int n, int C, int relu, void* stream);
+/* Chainer 2 Adam over a flat buffer (TM:860): lr_t = alpha*sqrt(1-beta2^t)/(1-beta1^t) from the host; g is scaled by gscale. */
+int pivp_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr_t, double beta1, double beta2,
+                   double eps, double gscale, void* stream);
+
 /* L.Convolution2D(cout,(3,3),stride=2,pad=1) (TM:501-502) + optional ReLU; w [9][cin/32][cout][32]. */
 int pivp_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                    int ldo, int relu, int B, int Hin, int Win, void* stream);

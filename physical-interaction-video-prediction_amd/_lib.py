@@ -38,6 +38,14 @@ SIGNATURES = {
     'pivp_get_tap': (_ll, [_vp, _c.c_char_p, _i, _vp, _vp]),
     'pivp_convlstm': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pivp_convlstm_v': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'pivp_convlstm_train': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pivp_convlstm_backward': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp,
+                                    _i, _i, _i, _vp]),
+    'pivp_conv_backward': (_i, [_i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
+    'pivp_layernorm_train': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    'pivp_layernorm_backward_scratch_floats': (_ll, [_i, _i]),
+    'pivp_layernorm_backward': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'pivp_adam_step': (_i, [_vp, _vp, _vp, _vp, _ll, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _vp]),
     'pivp_conv3x3s2': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'pivp_deconv3x3s2': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'pivp_conv_enc0': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -1,0 +1,254 @@
+// Backward (BPTT) kernels of the light ops and the optimizer step.  The reference gets all of this from Chainer's
+// autograd inside optimizer.update (train_model.py:950); each kernel cites the forward code it differentiates
+// ("TM" = src/models/train_model.py).  Heavy contractions (data / weight gradients of the convolutions) are in
+// igemm_f32.hip / igemm_wgrad.hip.  All gradient buffers ACCUMULATE (Chainer: cleargrads() then backward()).
+#include "pivp_kernels.h"
+
+namespace pivp {
+
+__device__ __forceinline__ float fast_tanh_b(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+
+// ------------------------------------------------------------------------------------------
+// ConvLSTM gate math backward (TM:269-272):  c' = c*f + i*j,  h = tanh(c')*o  with the stored activations
+// j = tanh(gj), i = s(gi), f = s(gf+1), o = s(go).  dh arrives in two pieces: from this step's LayerNorm backward
+// (dh_a) and from the NEXT timestep's gate-conv data gradient, whose last C channels are d h_t (dh_b, may be null).
+// Writes the pre-activation gate gradients dG [M][4C] (column order j,i,f,o like the weights) and turns dc into
+// d c_{t-1} in place.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_old,
+                                                             const float* __restrict__ c_new, const float* __restrict__ dh_a, int lda,
+                                                             const float* __restrict__ dh_b, int ldb, float* __restrict__ dc,
+                                                             int dc_valid, float* __restrict__ dG, int M, int C) {
+    const long total = (long)M * C;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int m = (int)(idx / C), ch = (int)(idx - (long)m * C);
+        const float* g = gates + (size_t)m * 4 * C + ch;
+        const float aj = g[0], ai = g[C], af = g[2 * C], ao = g[3 * C];
+        float dh = dh_a ? dh_a[(size_t)m * lda + ch] : 0.f;
+        if (dh_b) dh += dh_b[(size_t)m * ldb + ch];
+        const float tc = fast_tanh_b(c_new[idx]);
+        const float dct = dh * ao * (1.f - tc * tc) + (dc_valid ? dc[idx] : 0.f);
+        float* o = dG + (size_t)m * 4 * C + ch;
+        o[0] = dct * ai * (1.f - aj * aj);
+        o[C] = dct * aj * ai * (1.f - ai);
+        o[2 * C] = dct * c_old[idx] * af * (1.f - af);
+        o[3 * C] = dh * tc * ao * (1.f - ao);
+        dc[idx] = dct * af;
+    }
+}
+
+int lstm_gates_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_a, int lda,
+                   const float* dh_b, int ldb, float* dc, int dc_valid, float* dG, int M, int C, hipStream_t s) {
+    PIVP_CHECK_ARG(gates && c_old && c_new && dc && dG && M > 0 && C > 0 && (dh_a || dh_b));
+    const long total = (long)M * C;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(blocks), dim3(256), 0, s, gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc,
+                       dc_valid, dG, M, C);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
+// db[n] += sum over pixels of dY[pix][n]   (bias gradient of every conv / deconv / 1x1)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, int ld, int N, int M, float* __restrict__ db) {
+    __shared__ float part[8][33];
+    const int col0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    float acc = 0.f;
+    if (col0 + tx < N)
+        for (int r = r0 + ty; r < r1; r += 8) acc += dy[(size_t)r * ld + col0 + tx];
+    part[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && col0 + tx < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += part[i][tx];
+        atomicAdd(db + col0 + tx, t);
+    }
+}
+
+int bias_grad(const float* dy, int ld, int N, int M, float* db, hipStream_t s) {
+    PIVP_CHECK_ARG(dy && db && N > 0 && M > 0 && ld >= N);
+    int ysplit = M / 512; if (ysplit < 1) ysplit = 1; if (ysplit > 64) ysplit = 64;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3((N + 31) / 32, ysplit), dim3(256), 0, s, dy, ld, N, M, db);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// dy[pix][c] *= (y[pix][c] > 0)   (backward of the ReLU fused into a producer, TM:697-700)
+__global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
+                                                        int C, long npix) {
+    const long total = npix * (C / 4);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / (C / 4); const int c = (int)(i - p * (C / 4)) * 4;
+        f32x4 g = *reinterpret_cast<f32x4*>(dy + p * lddy + c);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(y + p * ldy + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = v[e] > 0.f ? g[e] : 0.f;
+        *reinterpret_cast<f32x4*>(dy + p * lddy + c) = g;
+    }
+}
+
+int relu_mask(float* dy, int lddy, const float* y, int ldy, int C, long npix, hipStream_t s) {
+    PIVP_CHECK_ARG(dy && y && C > 0 && C % 4 == 0 && npix > 0 && lddy % 4 == 0 && ldy % 4 == 0);
+    const long total = npix * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(blocks), dim3(256), 0, s, dy, lddy, y, ldy, C, npix);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNormalizationConv2D backward (TM:203-208): y = xhat*gamma + beta, xhat = (x - mean)*rstd per sample over
+// n = C*H*W elements (+ optional ReLU after it).  With g = dy*gamma:
+//   dx = rstd * (g - mean(g) - xhat * mean(g*xhat));  dgamma[e] += sum_b dy*xhat;  dbeta[e] += sum_b dy.
+// dy (and the ReLU mask source y) may be channel slices of concat buffers: element e of sample b sits at
+// (b*npix + e/C)*ld + e%C.  Three launches: per-slice partial sums, dx, parameter gradients.
+// ------------------------------------------------------------------------------------------
+constexpr int LNB_SLICE = 4096;
+
+__global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
+                                                           const float* __restrict__ x, const float* __restrict__ stat,
+                                                           const float* __restrict__ gamma, float* __restrict__ partials,
+                                                           int n, int C, int relu) {
+    __shared__ float red[4];
+    const int sl = blockIdx.x, b = blockIdx.y, S = gridDim.x;
+    const float mean = stat[b * 2], rstd = stat[b * 2 + 1];
+    const int base = sl * LNB_SLICE, cnt = min(LNB_SLICE, n - base);
+    const size_t pix0 = (size_t)b * (n / C);
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x * 4; i < cnt; i += 1024) {
+        const int e = base + i, pix = e / C, ch = e - pix * C;
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + (pix0 + pix) * lddy + ch);
+        if (relu) {
+            const f32x4 yy = *reinterpret_cast<const f32x4*>(y + (pix0 + pix) * ldy + ch);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = yy[k] > 0.f ? g[k] : 0.f;
+        }
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)b * n + e);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + e);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gg = g[k] * gm[k];
+            s1 += gg; s2 = fmaf(gg, (xv[k] - mean) * rstd, s2);
+        }
+    }
+    s1 = block_sum<256>(s1, red);
+    s2 = block_sum<256>(s2, red);
+    if (threadIdx.x == 0) { partials[((size_t)b * S + sl) * 2] = s1; partials[((size_t)b * S + sl) * 2 + 1] = s2; }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
+                                                           const float* __restrict__ x, const float* __restrict__ stat,
+                                                           const float* __restrict__ gamma, const float* __restrict__ partials,
+                                                           float* __restrict__ dx, int n, int C, int relu) {
+    __shared__ float sums[2];
+    const int sl = blockIdx.x, b = blockIdx.y, S = gridDim.x;
+    if (threadIdx.x < 64) {
+        float a = 0.f, c2 = 0.f;
+        for (int i = threadIdx.x; i < S; i += 64) { a += partials[((size_t)b * S + i) * 2]; c2 += partials[((size_t)b * S + i) * 2 + 1]; }
+        a = wave_sum(a); c2 = wave_sum(c2);
+        if (threadIdx.x == 0) { sums[0] = a / (float)n; sums[1] = c2 / (float)n; }
+    }
+    __syncthreads();
+    const float m1 = sums[0], m2 = sums[1];
+    const float mean = stat[b * 2], rstd = stat[b * 2 + 1];
+    const int base = sl * LNB_SLICE, cnt = min(LNB_SLICE, n - base);
+    const size_t pix0 = (size_t)b * (n / C);
+    for (int i = threadIdx.x * 4; i < cnt; i += 1024) {
+        const int e = base + i, pix = e / C, ch = e - pix * C;
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + (pix0 + pix) * lddy + ch);
+        if (relu) {
+            const f32x4 yy = *reinterpret_cast<const f32x4*>(y + (pix0 + pix) * ldy + ch);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = yy[k] > 0.f ? g[k] : 0.f;
+        }
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)b * n + e);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + e);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = rstd * (g[k] * gm[k] - m1 - (xv[k] - mean) * rstd * m2);
+        *reinterpret_cast<f32x4*>(dx + (size_t)b * n + e) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
+                                                            const float* __restrict__ x, const float* __restrict__ stat,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int B, int n, int C, int relu) {
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= n) return;
+    const int pix = e / C, ch = e - pix * C;
+    f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b) {
+        const size_t pb = (size_t)b * (n / C) + pix;
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + pb * lddy + ch);
+        if (relu) {
+            const f32x4 yy = *reinterpret_cast<const f32x4*>(y + pb * ldy + ch);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = yy[k] > 0.f ? g[k] : 0.f;
+        }
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)b * n + e);
+        const float mean = stat[b * 2], rstd = stat[b * 2 + 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ag[k] = fmaf(g[k], (xv[k] - mean) * rstd, ag[k]); ab[k] += g[k]; }
+    }
+    f32x4 og = *reinterpret_cast<f32x4*>(dgamma + e), ob = *reinterpret_cast<f32x4*>(dbeta + e);
+    *reinterpret_cast<f32x4*>(dgamma + e) = og + ag;
+    *reinterpret_cast<f32x4*>(dbeta + e) = ob + ab;
+}
+
+int ln_bwd_slices(int n) { return (n + LNB_SLICE - 1) / LNB_SLICE; }
+
+int ln_backward(const float* dy, int lddy, const float* y, int ldy, const float* x, const float* stat, const float* gamma,
+                float* partials, float* dx, float* dgamma, float* dbeta, int B, int n, int C, int relu, hipStream_t s) {
+    PIVP_CHECK_ARG(dy && x && stat && gamma && partials && dx && dgamma && dbeta && B > 0 && n > 0 && C > 0 && C % 4 == 0 && n % C == 0);
+    PIVP_CHECK_ARG(lddy >= C && lddy % 4 == 0 && (!relu || (y && ldy >= C && ldy % 4 == 0)));
+    const int S = ln_bwd_slices(n);
+    hipLaunchKernelGGL(ln_bwd_stats_kernel, dim3(S, B), dim3(256), 0, s, dy, lddy, y, ldy, x, stat, gamma, partials, n, C, relu);
+    hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3(S, B), dim3(256), 0, s, dy, lddy, y, ldy, x, stat, gamma, partials, dx, n, C, relu);
+    hipLaunchKernelGGL(ln_bwd_params_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, s, dy, lddy, y, ldy, x, stat, dgamma, dbeta, B, n, C, relu);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
+// Chainer 2 Adam (optimizers.Adam at TM:860; AdamRule.update_core): m += (1-b1)(g-m); v += (1-b2)(g*g-v);
+// p -= alpha*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)   -- eps is added to the UNcorrected sqrt(v).
+// One launch over the flat parameter buffer; `lr_t` is the bias-corrected step size computed on the host.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr_t, float omb1, float omb2, float eps,
+                                                   float gscale) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 3 < n) {
+            f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<const f32x4*>(g + i);
+            f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gk = gg[k] * gscale;
+                mm[k] += omb1 * (gk - mm[k]);
+                vv[k] += omb2 * (gk * gk - vv[k]);
+                pp[k] -= lr_t * mm[k] / (sqrtf(vv[k]) + eps);
+            }
+            *reinterpret_cast<f32x4*>(p + i) = pp; *reinterpret_cast<f32x4*>(m + i) = mm; *reinterpret_cast<f32x4*>(v + i) = vv;
+        } else {
+            for (long j = i; j < n; ++j) {
+                const float gk = g[j] * gscale;
+                m[j] += omb1 * (gk - m[j]);
+                v[j] += omb2 * (gk * gk - v[j]);
+                p[j] -= lr_t * m[j] / (sqrtf(v[j]) + eps);
+            }
+        }
+    }
+}
+
+int adam_step(float* p, const float* g, float* m, float* v, long n, double lr_t, double beta1, double beta2, double eps,
+              double gscale, hipStream_t s) {
+    PIVP_CHECK_ARG(p && g && m && v && n > 0);
+    const long blocks = (n / 4 + 255) / 256;
+    // (1 - beta) is formed in double like Chainer's Python float, then rounded once to fp32
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, p, g, m, v, n, (float)lr_t,
+                       (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)gscale);
+    return PIVP_LAUNCH_STATUS();
+}
+
+}  // namespace pivp

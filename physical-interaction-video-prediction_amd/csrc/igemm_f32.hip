@@ -271,9 +271,15 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (m < d.M && grp == (r % WN)) {
                 const size_t o = (size_t)m * C + ch;
-                const float cn = d.cstate_in[o] * fast_sigmoid(g4[2] + bf) + fast_sigmoid(g4[1] + bi) * fast_tanh(g4[0] + bj);
+                const float aj = fast_tanh(g4[0] + bj), ai = fast_sigmoid(g4[1] + bi);
+                const float af = fast_sigmoid(g4[2] + bf), ao = fast_sigmoid(g4[3] + bo);
+                const float cn = d.cstate_in[o] * af + ai * aj;
                 d.cstate_out[o] = cn;
-                d.hout[o] = fast_tanh(cn) * fast_sigmoid(g4[3] + bo);
+                d.hout[o] = fast_tanh(cn) * ao;
+                if (d.gates_out) {   // training: keep the gate activations for BPTT, [pixel][gate][C]
+                    float* gp = d.gates_out + (size_t)m * 4 * C + ch;
+                    gp[0] = aj; gp[C] = ai; gp[2 * C] = af; gp[3 * C] = ao;
+                }
             }
         }
     } else {
@@ -292,6 +298,7 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
                     const int col = nblk * BN + (wn * TPW + t) * 32 + l31;
                     float v = acc[t][r] + (d.bias ? d.bias[col] : 0.f);
                     if (d.relu) v = fmaxf(v, 0.f);
+                    if (d.accum) v += d.out[o + col];
                     d.out[o + col] = v;
                 }
             }
@@ -329,7 +336,7 @@ int igemm_validate(const IgemmDesc& d, bool lstm) {
         PIVP_CHECK_ARG(d.C > 0 && d.C % 32 == 0 && d.N == 4 * d.C && d.bias && d.cstate_in && d.cstate_out && d.hout);
         PIVP_CHECK_ARG(d.nphase == 1 && d.in_step == 1 && d.Hg == d.Hin && d.Wg == d.Win);
     } else {
-        PIVP_CHECK_ARG(d.out && d.N % 32 == 0 && d.N >= 32 && d.N <= 128 && d.ldo >= d.N);
+        PIVP_CHECK_ARG(d.out && d.N % 32 == 0 && d.N >= 32 && d.ldo >= d.N);
         PIVP_CHECK_ARG(d.out_step >= 1 && d.Hout > 0 && d.Wout > 0);
         PIVP_CHECK_ARG((d.Hg - 1) * d.out_step + (d.deconv ? 1 : 0) < d.Hout && (d.Wg - 1) * d.out_step + (d.deconv ? 1 : 0) < d.Wout);
     }
@@ -370,7 +377,13 @@ int igemm_conv(const IgemmDesc& d, hipStream_t stream) {
     if (rc != PIVP_OK) return rc;
     const int nt = d.N / 32;
     const long full = (long)((d.M + 127) / 128) * d.nphase;   // blocks with BM = 128 and the whole N in one block
-    if (full >= 256 || nt == 0) {
+    if (nt > 4) {                                             // wide outputs (data gradients): several column blocks
+        if (nt % 4 == 0) return full * (nt / 4) >= 256 ? launch_igemm<4, 1, 4, false>(d, stream) : launch_igemm<2, 2, 4, false>(d, stream);
+        if (nt % 3 == 0) return launch_igemm<4, 1, 3, false>(d, stream);
+        if (nt % 2 == 0) return full * (nt / 2) >= 256 ? launch_igemm<4, 1, 2, false>(d, stream) : launch_igemm<2, 2, 2, false>(d, stream);
+        return launch_igemm<4, 1, 1, false>(d, stream);
+    }
+    if (full >= 256) {
         switch (nt) {
             case 1: return launch_igemm<4, 1, 1, false>(d, stream);
             case 2: return launch_igemm<4, 1, 2, false>(d, stream);

@@ -29,7 +29,8 @@ long long view_bytes(int B, int H, int W, int ld) { return (long long)B * H * W 
 bool fits31(long long v) { return v > 0 && v < (1LL << 31); }
 
 int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
-                 const float* c_in, float* c_out, float* h_out, int B, int H, int W, hipStream_t s, int variant = 0) {
+                 const float* c_in, float* c_out, float* h_out, int B, int H, int W, hipStream_t s, int variant = 0,
+                 float* gates_out = nullptr) {
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
     // h_prev == nullptr: the recurrent input is identically zero (first timestep after reset_state, TM:254-257);
@@ -43,12 +44,12 @@ int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, co
     if (!fits31(b0) || !fits31(b1) || !fits31(bw)) return PIVP_ERR_BADARG;
     d.bytes0 = (int)b0; d.bytes1 = (int)b1; d.bytesw = (int)bw;
     d.out_step = 1; d.Hout = H; d.Wout = W;
-    d.cstate_in = c_in; d.cstate_out = c_out; d.hout = h_out; d.C = C;
+    d.cstate_in = c_in; d.cstate_out = c_out; d.hout = h_out; d.C = C; d.gates_out = gates_out;
     return igemm_lstm(d, s, variant);
 }
 
 int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
-                  int ldo, int relu, int B, int Hin, int Win, hipStream_t s) {
+                  int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0) {
     if (Hin % 2 || Win % 2) return PIVP_ERR_BADARG;
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
@@ -59,12 +60,12 @@ int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float*
     const long long b0 = view_bytes(B, Hin, Win, ldx), bw = 9LL * cin * cout * 4;
     if (!fits31(b0) || !fits31(bw)) return PIVP_ERR_BADARG;
     d.bytes0 = (int)b0; d.bytesw = (int)bw;
-    d.out_step = 1; d.Hout = d.Hg; d.Wout = d.Wg; d.out = out; d.ldo = ldo; d.relu = relu;
+    d.out_step = 1; d.Hout = d.Hg; d.Wout = d.Wg; d.out = out; d.ldo = ldo; d.relu = relu; d.accum = accum;
     return igemm_conv(d, s);
 }
 
 int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
-                    int ldo, int relu, int B, int Hin, int Win, hipStream_t s) {
+                    int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0) {
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
     d.x0 = x; d.c0 = cin; d.ld0 = ldx; d.wcin = cin; d.w = w; d.bias = bias;
@@ -74,15 +75,65 @@ int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const floa
     const long long b0 = view_bytes(B, Hin, Win, ldx), bw = 9LL * cin * cout * 4;
     if (!fits31(b0) || !fits31(bw)) return PIVP_ERR_BADARG;
     d.bytes0 = (int)b0; d.bytesw = (int)bw;
-    d.out_step = 2; d.Hout = 2 * Hin; d.Wout = 2 * Win; d.out = out; d.ldo = ldo; d.relu = relu;
+    d.out_step = 2; d.Hout = 2 * Hin; d.Wout = 2 * Win; d.out = out; d.ldo = ldo; d.relu = relu; d.accum = accum;
     return igemm_conv(d, s);
 }
 
+// stride-1 K x K "same" convolution through the generic kernel (used as the ConvLSTM data gradient)
+int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, int cout, int ldo, int ksize, int B, int H, int W,
+                hipStream_t s, int accum = 0) {
+    IgemmDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x0 = x; d.c0 = cin; d.ld0 = ldx; d.wcin = cin; d.w = w; d.bias = nullptr;
+    d.B = B; d.Hin = H; d.Win = W; d.Hg = H; d.Wg = W; d.in_step = 1;
+    d.N = cout; d.M = B * H * W;
+    d.nphase = 1; d.deconv = 0; d.ksize = ksize; d.pad = ksize / 2;
+    const long long b0 = view_bytes(B, H, W, ldx), bw = (long long)ksize * ksize * cin * cout * 4;
+    if (!fits31(b0) || !fits31(bw)) return PIVP_ERR_BADARG;
+    d.bytes0 = (int)b0; d.bytesw = (int)bw;
+    d.out_step = 1; d.Hout = H; d.Wout = W; d.out = out; d.ldo = ldo; d.relu = 0; d.accum = accum;
+    return igemm_conv(d, s);
+}
+
+// weight gradient of: mode 0 = conv K x K stride `stride` pad `pad`; mode 1 = transposed 3x3 s2 p1
+int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
+              float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s) {
+    WgradDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x0 = x0; d.c0 = c0; d.ld0 = ld0; d.x1 = x1; d.c1 = x1 ? c1 : 0; d.ld1 = ld1; d.cin = c0 + (x1 ? c1 : 0); d.wcin = wcin;
+    d.dy = dy; d.ldy = ldy; d.N = N; d.dw = dw;
+    d.B = B; d.Hx = Hx; d.Wx = Wx; d.Hy = Hy; d.Wy = Wy;
+    d.deconv = mode; d.ksize = ksize; d.pad = pad; d.stride = stride;
+    d.Hg = mode ? Hx : Hy; d.Wg = mode ? Wx : Wy; d.M = B * d.Hg * d.Wg;
+    const long long b0 = view_bytes(B, Hx, Wx, ld0), b1 = x1 ? view_bytes(B, Hx, Wx, ld1) : 0, by = view_bytes(B, Hy, Wy, ldy);
+    if (!fits31(b0) || (x1 && !fits31(b1)) || !fits31(by)) return PIVP_ERR_BADARG;
+    d.bytes0 = (int)b0; d.bytes1 = (int)b1; d.bytesy = (int)by;
+    return igemm_wgrad(d, s);
+}
+
+// ConvLSTM cell backward (TM:262-272): gate math, data gradient d[x,h_prev], weight and bias gradients.
+//   d_in [M][cx+C] receives d x (first cx channels) and d h_{t-1} (last C); dc is updated in place to d c_{t-1}.
+int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
+                          const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
+                          float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
+                          int B, int H, int W, hipStream_t s) {
+    const int M = B * H * W, cin = cx + C, N = 4 * C;
+    int rc = lstm_gates_bwd(gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc, dc_valid, dG, M, C, s);
+    if (rc != PIVP_OK) return rc;
+    rc = repack_transpose(w, wt, 25, cin, N, 1, s);                       // [25][cin/32][4C][32] -> flipped [25][4C/32][cin][32]
+    if (rc != PIVP_OK) return rc;
+    rc = run_conv_s1(dG, N, N, wt, d_in, cin, cin, 5, B, H, W, s);        // d[x,h] = conv5x5(dG, W^T flipped)
+    if (rc != PIVP_OK) return rc;
+    rc = run_wgrad(0, x, cx, ldx, h_prev, C, C, cin, dG, N, N, dW, B, H, W, H, W, 5, 2, 1, s);
+    if (rc != PIVP_OK) return rc;
+    return bias_grad(dG, N, N, M, db, s);
+}
+
 int run_layernorm(const float* x, const float* g, const float* b, float* out, float* partials, int B, int n, int C,
-                  int ldo, float eps, int relu, hipStream_t s) {
+                  int ldo, float eps, int relu, hipStream_t s, float* stat_out = nullptr) {
     int rc = ln_stats(x, partials, B, n, s);
     if (rc != PIVP_OK) return rc;
-    return ln_apply(x, partials, g, b, out, B, n, C, ldo, eps, relu, s);
+    return ln_apply(x, partials, g, b, out, B, n, C, ldo, eps, relu, s, stat_out);
 }
 
 __global__ __launch_bounds__(256) void select_frames_kernel(const float* __restrict__ gt, const float* __restrict__ gen,
@@ -454,6 +505,56 @@ extern "C" int pivp_convlstm_v(const float* x, int cx, int ldx, const float* h_p
                                const float* c_in, float* c_out, float* h_out, int B, int H, int W, int variant, void* stream) {
     if (!x || !w || !bias || !c_in || !c_out || !h_out || variant < 0 || variant > 13) return PIVP_ERR_BADARG;
     return run_convlstm(x, cx, ldx, h_prev, C, w, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, variant);
+}
+extern "C" int pivp_convlstm_train(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
+                                   const float* c_in, float* c_out, float* h_out, float* gates_out, int B, int H, int W, void* stream) {
+    if (!x || !w || !bias || !c_in || !c_out || !h_out || !gates_out) return PIVP_ERR_BADARG;
+    return run_convlstm(x, cx, ldx, h_prev, C, w, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, 0, gates_out);
+}
+extern "C" int pivp_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
+                                      const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
+                                      float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
+                                      int B, int H, int W, void* stream) {
+    if (!x || !w || !gates || !c_old || !c_new || !dc || !dG || !wt || !d_in || !dW || !db) return PIVP_ERR_BADARG;
+    return run_convlstm_backward(x, cx, ldx, h_prev, C, w, gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc, dc_valid, dG, wt, d_in,
+                                 dW, db, B, H, W, (hipStream_t)stream);
+}
+// conv3x3s2 (mode 0) / deconv3x3s2 (mode 1) backward given dy (already ReLU-masked): dx (optionally accumulated), dW, db
+extern "C" int pivp_conv_backward(int mode, const float* x, int cin, int ldx, const float* w, const float* dy, int cout, int ldy,
+                                  float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win,
+                                  void* stream) {
+    if (!x || !w || !dy || !wt || !dW || !db || mode < 0 || mode > 1) return PIVP_ERR_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int Hout = mode ? 2 * Hin : Hin / 2, Wout = mode ? 2 * Win : Win / 2;
+    int rc = PIVP_OK;
+    if (dx) {
+        rc = repack_transpose(w, wt, 9, cin, cout, 0, s);
+        if (rc != PIVP_OK) return rc;
+        rc = mode ? run_conv3x3s2(dy, cout, ldy, wt, nullptr, dx, cin, lddx, 0, B, Hout, Wout, s, accum_dx)
+                  : run_deconv3x3s2(dy, cout, ldy, wt, nullptr, dx, cin, lddx, 0, B, Hout, Wout, s, accum_dx);
+        if (rc != PIVP_OK) return rc;
+    }
+    rc = run_wgrad(mode, x, cin, ldx, nullptr, 0, 0, cin, dy, ldy, cout, dW, B, Hin, Win, Hout, Wout, 3, 1, 2, s);
+    if (rc != PIVP_OK) return rc;
+    return bias_grad(dy, ldy, cout, B * Hout * Wout, db, s);
+}
+extern "C" int pivp_layernorm_train(const float* x, const float* gamma, const float* beta, float* out, float* partials, float* stat,
+                                    int B, int n, int C, int ldo, float eps, int relu, void* stream) {
+    if (!stat) return PIVP_ERR_BADARG;
+    return run_layernorm(x, gamma, beta, out, partials, B, n, C, ldo, eps, relu, (hipStream_t)stream, stat);
+}
+extern "C" long long pivp_layernorm_backward_scratch_floats(int B, int n) {
+    if (B <= 0 || n <= 0) return PIVP_ERR_BADARG;
+    return (long long)B * ln_bwd_slices(n) * 2;
+}
+extern "C" int pivp_layernorm_backward(const float* dy, int lddy, const float* y, int ldy, const float* x, const float* stat,
+                                       const float* gamma, float* partials, float* dx, float* dgamma, float* dbeta,
+                                       int B, int n, int C, int relu, void* stream) {
+    return ln_backward(dy, lddy, y, ldy, x, stat, gamma, partials, dx, dgamma, dbeta, B, n, C, relu, (hipStream_t)stream);
+}
+extern "C" int pivp_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr_t, double beta1, double beta2,
+                              double eps, double gscale, void* stream) {
+    return adam_step(p, g, m, v, (long)n, lr_t, beta1, beta2, eps, gscale, (hipStream_t)stream);
 }
 extern "C" int pivp_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                               int ldo, int relu, int B, int Hin, int Win, void* stream) {

@@ -27,9 +27,25 @@ struct IgemmDesc {
     int bytes0, bytes1, bytesw;          // extents of x0 / x1 / w for the buffer descriptors (< 2^31)
     int out_step, Hout, Wout;            // output coord = anchor*out_step + phase parity
     float* out; int ldo; int relu;
+    int accum;                           // 1: out += result (gradient accumulation)
     // ConvLSTM epilogue
     const float* cstate_in; float* cstate_out; float* hout; int C;
+    float* gates_out;                    // optional [M][4C]: tanh(j), sigma(i), sigma(f+1), sigma(o) for the backward pass
 };
+
+// weight gradient of a conv / transposed conv (csrc/igemm_wgrad.hip)
+struct WgradDesc {
+    const float* x0; const float* x1;    // forward input sources (channel-concatenated), NHWC
+    int c0, ld0, c1, ld1, cin, wcin;     // cin = c0 + c1 channels differentiated; wcin = Cin of the packed weight
+    const float* dy; int ldy, N;         // output gradient NHWC (N columns, pixel stride ldy)
+    float* dw;                           // packed gradient [tap][wcin/32][N][32], accumulated with atomics
+    int B, Hx, Wx, Hy, Wy;               // input / output feature-map sizes
+    int Hg, Wg, M;                       // anchor grid (conv: output pixels, deconv: input pixels), M = B*Hg*Wg
+    int deconv, ksize, pad, stride;
+    int bytes0, bytes1, bytesy;
+};
+int igemm_wgrad(const WgradDesc& d, hipStream_t s);
+int repack_transpose(const float* w, float* wt, int taps, int cin, int N, int flip, hipStream_t s);
 
 int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant = 0);  // 0 auto, 1: 4x1 waves, 2: 2x2, 3: 1x4
 int igemm_conv(const IgemmDesc& d, hipStream_t stream);
@@ -41,7 +57,7 @@ int conv_enc0(const float* img, const float* w, const float* bias, float* out, i
 int ln_stats_slices(int n);  // number of partial slices per sample for n elements
 int ln_stats(const float* x, float* partials, int B, int n, hipStream_t s);
 int ln_apply(const float* x, const float* partials, const float* gamma, const float* beta, float* out,
-             int B, int n, int C, int ldo, float eps, int relu, hipStream_t s);
+             int B, int n, int C, int ldo, float eps, int relu, hipStream_t s, float* stat_out = nullptr);
 
 // enc3: smear(action,state) + 1x1 conv + ReLU (TM:556-567, TM:503) and the state predictor (TM:730)
 int enc3_state(const float* e2, const float* action, const float* state, const float* w3, const float* b3,
@@ -75,6 +91,17 @@ int frame_sqerr_partials(const float* a, const float* b, float* partials, int n,
 int loss_finalize(const float* frame_partials, int nparts, int nframes, int frame_numel,
                   const float* states_true, const float* states_gen, int state_numel,
                   float denom, float* results, hipStream_t s);
+
+// ---- backward (csrc/backward.hip) ----
+int lstm_gates_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_a, int lda,
+                   const float* dh_b, int ldb, float* dc, int dc_valid, float* dG, int M, int C, hipStream_t s);
+int bias_grad(const float* dy, int ld, int N, int M, float* db, hipStream_t s);
+int relu_mask(float* dy, int lddy, const float* y, int ldy, int C, long npix, hipStream_t s);
+int ln_bwd_slices(int n);
+int ln_backward(const float* dy, int lddy, const float* y, int ldy, const float* x, const float* stat, const float* gamma,
+                float* partials, float* dx, float* dgamma, float* dbeta, int B, int n, int C, int relu, hipStream_t s);
+int adam_step(float* p, const float* g, float* m, float* v, long n, double lr_t, double beta1, double beta2, double eps,
+              double gscale, hipStream_t s);
 
 // planar NCHW <-> NHWC helpers for taps (conv_res) and tests
 int nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, int ld, hipStream_t s);

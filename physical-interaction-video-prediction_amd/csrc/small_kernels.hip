@@ -111,7 +111,8 @@ int ln_stats(const float* x, float* partials, int B, int n, hipStream_t s) {
 
 __global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__ x, const float* __restrict__ partials,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float* __restrict__ out, int n, int C, int ldo, float eps, int relu) {
+                                                       float* __restrict__ out, int n, int C, int ldo, float eps, int relu,
+                                                       float* __restrict__ stat_out) {
     __shared__ float stat[2];
     const int s = blockIdx.x, b = blockIdx.y, S = gridDim.x;
     if (threadIdx.x < 64) {
@@ -129,7 +130,10 @@ __global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__
             else { a_n = on; a_m = om; a_2 = o2; chan_combine(a_n, a_m, a_2, cn, mean, m2); }
             cn = a_n; mean = a_m; m2 = a_2;
         }
-        if (threadIdx.x == 0) { stat[0] = mean; stat[1] = 1.0f / sqrtf(m2 / cn + eps); }
+        if (threadIdx.x == 0) {
+            stat[0] = mean; stat[1] = 1.0f / sqrtf(m2 / cn + eps);
+            if (stat_out && s == 0) { stat_out[b * 2] = stat[0]; stat_out[b * 2 + 1] = stat[1]; }   // kept for the backward pass
+        }
     }
     __syncthreads();
     const float mean = stat[0], rstd = stat[1];
@@ -158,11 +162,11 @@ __global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__
 }
 
 int ln_apply(const float* x, const float* partials, const float* gamma, const float* beta, float* out,
-             int B, int n, int C, int ldo, float eps, int relu, hipStream_t s) {
+             int B, int n, int C, int ldo, float eps, int relu, hipStream_t s, float* stat_out) {
     PIVP_CHECK_ARG(x && partials && gamma && beta && out && B > 0 && n > 0 && C > 0 && C % 4 == 0 && n % C == 0);
     PIVP_CHECK_ARG(ldo >= C && ldo % 4 == 0);
     hipLaunchKernelGGL(ln_apply_kernel, dim3(ln_stats_slices(n), B), dim3(256), 0, s,
-                       x, partials, gamma, beta, out, n, C, ldo, eps, relu);
+                       x, partials, gamma, beta, out, n, C, ldo, eps, relu, stat_out);
     return PIVP_LAUNCH_STATUS();
 }
 

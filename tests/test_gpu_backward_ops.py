@@ -1,0 +1,165 @@
+"""GPU parity tests of the backward kernels, per op: HIP (through the C ABI) vs PyTorch autograd in float64 on the CPU,
+on the same seeded inputs.  Gradients are O(1)-scaled test cotangents; tolerances are relative to the gradient scale."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def env():
+    assert torch.cuda.is_available(), 'GPU tests need the MI355X'
+    import pivp_amd
+    from pivp_amd import _lib
+    return pivp_amd, _lib, _lib.load()
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).to(DEV)
+
+
+def _nhwc(a):
+    return _t(np.asarray(a).transpose(0, 2, 3, 1))
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rel(a, b):
+    return np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max() / (np.abs(b).max() + 1e-30)
+
+
+@pytest.mark.parametrize('B,cx,C,H,first', [(2, 32, 32, 32, False), (2, 32, 64, 16, False), (3, 64, 128, 8, False),
+                                            (2, 96, 32, 32, False), (2, 128, 64, 16, True)])
+def test_convlstm_backward(env, B, cx, C, H, first):
+    pivp, _lib, lib = env
+    rs = np.random.RandomState(C + cx)
+    x = rs.randn(B, cx, H, H); h = np.zeros((B, C, H, H)) if first else rs.randn(B, C, H, H) * 0.5
+    c = np.zeros((B, C, H, H)) if first else rs.randn(B, C, H, H)
+    W = rs.randn(4 * C, cx + C, 5, 5) / np.sqrt(25 * (cx + C)); b = rs.randn(4 * C) * 0.1
+    dh = rs.randn(B, C, H, H); dh2 = rs.randn(B, C, H, H) * 0.5; dcn = rs.randn(B, C, H, H)
+    # reference: autograd
+    tx, th, tc = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (x, h, c)]
+    tW = torch.tensor(W, dtype=torch.float64, requires_grad=True); tb = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    g = F.conv2d(torch.cat((tx, th), 1), tW, tb, padding=2)
+    j, i, f, o = torch.split(g, C, dim=1)
+    cn = tc * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
+    hn = torch.tanh(cn) * torch.sigmoid(o)
+    (hn * torch.tensor(dh + dh2) + cn * torch.tensor(dcn)).sum().backward()
+    # HIP
+    xd, hd, cd = _nhwc(x), _nhwc(h), _nhwc(c)
+    wd, bd = _t(pivp.to_internal('lstm1/conv/W', W)), _t(b)
+    c_out = torch.empty_like(cd); h_out = torch.empty_like(hd)
+    M = B * H * H
+    gates = torch.empty((M, 4 * C), dtype=torch.float32, device=DEV)
+    _lib.check(lib.pivp_convlstm_train(xd.data_ptr(), cx, cx, None if first else hd.data_ptr(), C, wd.data_ptr(), bd.data_ptr(),
+                                       cd.data_ptr(), c_out.data_ptr(), h_out.data_ptr(), gates.data_ptr(), B, H, H, _st()), 'fwd')
+    # dh_b arrives as the last C channels of a wider buffer (the next step's d_in), exercise that stride
+    wide = torch.zeros((M, cx + C), dtype=torch.float32, device=DEV)
+    wide[:, cx:] = _nhwc(dh2).reshape(M, C)
+    dha = _nhwc(dh)
+    dc = _nhwc(dcn).clone()
+    dG = torch.empty((M, 4 * C), dtype=torch.float32, device=DEV)
+    wt = torch.empty_like(wd)
+    d_in = torch.empty((M, cx + C), dtype=torch.float32, device=DEV)
+    dW = torch.zeros_like(wd); db = torch.zeros_like(bd)
+    _lib.check(lib.pivp_convlstm_backward(xd.data_ptr(), cx, cx, None if first else hd.data_ptr(), C, wd.data_ptr(), gates.data_ptr(),
+                                          cd.data_ptr(), c_out.data_ptr(), dha.data_ptr(), C, (wide.data_ptr() + cx * 4), cx + C,
+                                          dc.data_ptr(), 1, dG.data_ptr(), wt.data_ptr(), d_in.data_ptr(), dW.data_ptr(), db.data_ptr(),
+                                          B, H, H, _st()), 'bwd')
+    torch.cuda.synchronize()
+    din = d_in.cpu().numpy().reshape(B, H, H, cx + C).transpose(0, 3, 1, 2)
+    assert _rel(din[:, :cx], tx.grad.numpy()) < 2e-5
+    if not first:
+        assert _rel(din[:, cx:], th.grad.numpy()) < 2e-5
+    assert _rel(dc.cpu().numpy().reshape(B, H, H, C).transpose(0, 3, 1, 2), tc.grad.numpy()) < 2e-5
+    dW_ref = tW.grad.numpy().copy()
+    if first:
+        dW_ref[:, cx:] = 0          # the skipped zero-h K range gets no gradient (h == 0 => it is exactly 0 anyway)
+    got_dW = pivp.from_internal('lstm1/conv/W', dW.cpu().numpy(), W.shape)
+    assert _rel(got_dW, dW_ref) < 2e-5
+    assert _rel(db.cpu().numpy(), tb.grad.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize('mode,B,cin,cout,H', [(0, 2, 32, 32, 32), (0, 3, 64, 64, 16), (1, 2, 128, 128, 8), (1, 2, 96, 96, 16), (1, 2, 64, 64, 32)])
+def test_conv_deconv_backward(env, mode, B, cin, cout, H):
+    pivp, _lib, lib = env
+    rs = np.random.RandomState(cin + mode)
+    x = rs.randn(B, cin, H, H)
+    Ho = 2 * H if mode else H // 2
+    dy = rs.randn(B, cout, Ho, Ho)
+    if mode:
+        W = rs.randn(cin, cout, 3, 3) / np.sqrt(9 * cin); key = 'enc4/W'
+    else:
+        W = rs.randn(cout, cin, 3, 3) / np.sqrt(9 * cin); key = 'enc1/W'
+    tx = torch.tensor(x, dtype=torch.float64, requires_grad=True); tW = torch.tensor(W, dtype=torch.float64, requires_grad=True)
+    tb = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    y = F.conv_transpose2d(tx, tW, tb, stride=2, padding=1, output_padding=1) if mode else F.conv2d(tx, tW, tb, stride=2, padding=1)
+    (y * torch.tensor(dy)).sum().backward()
+    xd, dyd = _nhwc(x), _nhwc(dy)
+    wd = _t(pivp.to_internal(key, W))
+    wt = torch.empty_like(wd); dW = torch.zeros_like(wd); db = torch.zeros(cout, dtype=torch.float32, device=DEV)
+    prior = rs.randn(B, H, H, cin).astype(np.float32)
+    dx = _t(prior)
+    _lib.check(lib.pivp_conv_backward(mode, xd.data_ptr(), cin, cin, wd.data_ptr(), dyd.data_ptr(), cout, cout, wt.data_ptr(),
+                                      dx.data_ptr(), cin, 1, dW.data_ptr(), db.data_ptr(), B, H, H, _st()), 'conv_backward')
+    torch.cuda.synchronize()
+    got_dx = (dx.cpu().numpy() - prior).transpose(0, 3, 1, 2)      # accum_dx = 1 adds into the existing buffer
+    assert _rel(got_dx, tx.grad.numpy()) < 2e-5
+    assert _rel(pivp.from_internal(key, dW.cpu().numpy(), W.shape), tW.grad.numpy()) < 2e-5
+    assert _rel(db.cpu().numpy(), tb.grad.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize('B,C,H,relu', [(2, 32, 32, True), (3, 64, 16, False), (2, 128, 8, False), (2, 64, 64, True)])
+def test_layernorm_backward(env, B, C, H, relu):
+    pivp, _lib, lib = env
+    rs = np.random.RandomState(C)
+    n = C * H * H
+    x = rs.randn(B, C, H, H) * 2 + 0.5; g = 1 + 0.1 * rs.randn(n); be = 0.1 * rs.randn(n); dy = rs.randn(B, C, H, H)
+    tx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    tg = torch.tensor(g, dtype=torch.float64, requires_grad=True); tb = torch.tensor(be, dtype=torch.float64, requires_grad=True)
+    y = F.layer_norm(tx.reshape(B, -1), (n,), tg, tb, 1e-6).reshape(x.shape)
+    if relu:
+        y = F.relu(y)
+    (y * torch.tensor(dy)).sum().backward()
+    perm = lambda v: _t(np.asarray(v).reshape(C, H * H).T)
+    xd, gd, bd = _nhwc(x), perm(g), perm(be)
+    ldo = C + 32                                               # output / dy live in a wider concat buffer
+    out = torch.zeros((B, H, H, ldo), dtype=torch.float32, device=DEV)
+    scratch = torch.empty(lib.pivp_layernorm_scratch_floats(B, n), dtype=torch.float32, device=DEV)
+    stat = torch.empty((B, 2), dtype=torch.float32, device=DEV)
+    _lib.check(lib.pivp_layernorm_train(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), out.data_ptr() + 32 * 4, scratch.data_ptr(),
+                                        stat.data_ptr(), B, n, C, ldo, 1e-6, int(relu), _st()), 'ln fwd')
+    dyw = torch.zeros((B, H, H, ldo), dtype=torch.float32, device=DEV)
+    dyw[..., 32:] = _nhwc(dy)
+    dx = torch.empty_like(xd); dg = torch.zeros_like(gd); dbt = torch.zeros_like(bd)
+    sc2 = torch.empty(lib.pivp_layernorm_backward_scratch_floats(B, n), dtype=torch.float32, device=DEV)
+    _lib.check(lib.pivp_layernorm_backward(dyw.data_ptr() + 32 * 4, ldo, out.data_ptr() + 32 * 4, ldo, xd.data_ptr(), stat.data_ptr(),
+                                           gd.data_ptr(), sc2.data_ptr(), dx.data_ptr(), dg.data_ptr(), dbt.data_ptr(), B, n, C,
+                                           int(relu), _st()), 'ln bwd')
+    torch.cuda.synchronize()
+    assert _rel(dx.cpu().numpy().transpose(0, 3, 1, 2), tx.grad.numpy()) < 3e-5
+    unperm = lambda t: t.cpu().numpy().reshape(H * H, C).T.ravel()
+    assert _rel(unperm(dg), tg.grad.numpy()) < 3e-5 and _rel(unperm(dbt), tb.grad.numpy()) < 3e-5
+
+
+def test_adam_step_matches_chainer_rule(env):
+    pivp, _lib, lib = env
+    from oracle.torch_restatement import chainer_adam_step
+    rs = np.random.RandomState(0)
+    n = 100003
+    p = rs.randn(n); g = rs.randn(n) * 0.01
+    P = {'w': p.copy()}; G = {'w': g.copy()}; M = {'w': np.zeros(n)}; V = {'w': np.zeros(n)}
+    pd, gd = _t(p), _t(g); md = torch.zeros_like(pd); vd = torch.zeros_like(pd)
+    import math
+    for t in (1, 2, 3):
+        chainer_adam_step(P, G, M, V, t)
+        lr_t = 0.001 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        _lib.check(lib.pivp_adam_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, lr_t, 0.9, 0.999, 1e-8, 1.0, _st()), 'adam')
+    torch.cuda.synchronize()
+    assert np.abs(pd.cpu().numpy() - P['w']).max() < 2e-6
+    assert _rel(md.cpu().numpy(), M['w']) < 1e-5 and _rel(vd.cpu().numpy(), V['w']) < 1e-5
