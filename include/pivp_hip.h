@@ -77,6 +77,15 @@ int pivp_rollout_forward(pivp_plan_t* plan, const float* images, const float* ac
                          const unsigned char* gt_select, float* gen_images, float* gen_states, float* results,
                          void* stream);
 
+/* Backward through time of the last pivp_rollout_forward (same arguments; the plan must have keep_activations = 1):
+ * what loss.backward() does inside Chainer's optimizer.update (TM:950).  Gradients are ACCUMULATED into the buffers
+ * registered with pivp_plan_set_grad (same internal layouts as the parameters), so the host clears them first
+ * (Chainer: model.cleargrads()).  Frames fed by scheduled sampling are detached as in the reference (TM:669-670);
+ * in feed-self mode the gradient flows through the generated frames.  CDNA variant only in this round. */
+int pivp_plan_set_grad(pivp_plan_t* plan, int idx, float* dptr);
+int pivp_rollout_backward(pivp_plan_t* plan, const float* images, const float* actions, const float* states,
+                          const unsigned char* gt_select, const float* gen_images, const float* gen_states, void* stream);
+
 /* Measurement hooks (bench.py): when enabled, every ConvLSTM launch of pivp_rollout_forward is bracketed
  * by hipEvents recorded on the launch stream.  After the caller has synchronised the stream,
  * pivp_plan_profile_read returns, per ConvLSTM layer (lstm1..lstm7): summed milliseconds, launch count

@@ -12,6 +12,9 @@ with importlib or through the `pivp_amd` alias module at the repo root:
 from .model import Model, config, using_config, reference_param_shapes, default_init, scheduled_sampling_masks
 from .checkpoint import save_npz, load_npz, to_internal, from_internal
 from .data import concat_examples
+from .optimizer import Adam
+from .parallel import GradAllReduce, shard_batch
 
 __all__ = ['Model', 'config', 'using_config', 'reference_param_shapes', 'default_init',
-           'scheduled_sampling_masks', 'save_npz', 'load_npz', 'to_internal', 'from_internal', 'concat_examples']
+           'scheduled_sampling_masks', 'save_npz', 'load_npz', 'to_internal', 'from_internal', 'concat_examples',
+           'Adam', 'GradAllReduce', 'shard_batch']

@@ -33,6 +33,8 @@ SIGNATURES = {
     'pivp_plan_set_workspace': (_i, [_vp, _vp, _ll]),
     'pivp_reset_state': (_i, [_vp, _vp]),
     'pivp_rollout_forward': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'pivp_plan_set_grad': (_i, [_vp, _i, _vp]),
+    'pivp_rollout_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pivp_plan_set_profiling': (_i, [_vp, _i]),
     'pivp_plan_profile_read': (_i, [_vp, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int), _c.POINTER(_c.c_double)]),
     'pivp_get_tap': (_ll, [_vp, _c.c_char_p, _i, _vp, _vp]),

@@ -1,0 +1,587 @@
+// Backward of the output heads (CDNA variant) and of the small ops at both ends of the trunk.
+// Forward definitions: heads.hip / small_kernels.hip; reference code: train_model.py ("TM") lines cited per kernel.
+#include "pivp_kernels.h"
+
+namespace pivp {
+
+// ------------------------------------------------------------------------------------------
+// Loss gradient (TM:737-758): d loss / d gen[t] = 2 (gen[t] - images[t+1]) / (numel * (T-ctx)) for t >= ctx-1,
+// and 1e-4 times the same for the predicted states.  out = scale * (a - b)  (+ out when accum).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scaled_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                          long n, float scale, int accum) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = scale * (a[i] - b[i]);
+        out[i] = accum ? out[i] + v : v;
+    }
+}
+int scaled_diff(const float* a, const float* b, float* out, long n, float scale, int accum, hipStream_t s) {
+    PIVP_CHECK_ARG(a && b && out && n > 0);
+    const long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(scaled_diff_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, a, b, out, n, scale, accum);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
+// composite backward, CDNA (forward: composite_kernel<0>, TM:720-728 + TM:341-349).
+// Per block = one sample x 8 rows (like the forward).  Given go = d loss / d out:
+//   d mk[0] = sum_c go*prev, d mk[1] = sum_c go*L0, d mk[k+2] = sum_c go * (prev (*) kern_k)       -> dmk planar
+//   d z (enc7 pre-activation) = go * mk[1] * L0 (1 - L0) [L0 > 1/2]   (L0 = sigmoid(relu(z)), TM:315-317)   -> dz planar
+//   d kern[k][ij] partial = sum_{c,p in tile} go[c](p) mk[k+2](p) prev[c](p + ij - 2)                      -> dkpart
+//   d prev[c](q) = mk[0](q) go[c](q) + sum_ij sum_k kern[k][ij] (mk[k+2] go[c])(q - (ij - 2))     (when dprev != null)
+// The softmax Jacobian couples 11 consecutive flat elements and is applied by mask_softmax_bwd_kernel afterwards.
+// ------------------------------------------------------------------------------------------
+constexpr int CB_TR = 8;
+
+__global__ __launch_bounds__(256) void composite_bwd_cdna_kernel(const float* __restrict__ prev, const float* __restrict__ logits,
+                                                                 const float* __restrict__ layer0, const float* __restrict__ kerns,
+                                                                 const float* __restrict__ go, float* __restrict__ dmk,
+                                                                 float* __restrict__ dz, float* __restrict__ dkpart,
+                                                                 float* __restrict__ dprev, int dprev_accum, int H, int W, int NM) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int NP = NM + 1, HW = H * W, NK = NM - 1;
+    const int b = blockIdx.y, y0 = blockIdx.x * CB_TR;
+    const int rows = min(CB_TR, H - y0);
+    const int ey0 = max(0, y0 - 2), ey1 = min(H, y0 + rows + 2);       // extended rows (tile + 2-row halo inside the image)
+    const int erows = ey1 - ey0, enp = erows * W, ep0 = ey0 * W;
+    const int win = enp + 2 * (NP - 1);
+    const int G = enp / NP + 2;
+    const int PW = W + 4, PR = CB_TR + 4;
+    float* lg = sm;                              // [NP][win]     logits window
+    float* gmx = lg + NP * win;                  // [NP][G]
+    float* ginv = gmx + NP * G;                  // [NP][G]
+    float* mkx = ginv + NP * G;                  // [NP][(CB_TR+4)*W]  masks on the extended tile
+    float* gox = mkx + NP * PR * W;              // [3][(CB_TR+4)*W]   go on the extended tile
+    float* prevt = gox + 3 * PR * W;             // [3][PR][PW]        prev with zero halo, rows y0-2 ..
+    float* kl = prevt + 3 * PR * PW;             // [NM*25]
+    const int tid = threadIdx.x;
+    const float* lgb = logits + (size_t)b * NP * HW;
+    for (int i = tid; i < NP * win; i += 256) {
+        const int m = i / win, j = i - m * win;
+        const int F = m * HW + ep0 - (NP - 1) + j;
+        lg[i] = (F >= 0 && F < NP * HW) ? lgb[F] : 0.f;
+    }
+    const float* pb = prev + (size_t)b * 3 * HW;
+    for (int i = tid; i < 3 * PR * PW; i += 256) {
+        const int c = i / (PR * PW), r = (i / PW) % PR, x = i % PW;
+        const int iy = y0 + r - 2, ix = x - 2;
+        prevt[i] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? pb[(size_t)c * HW + iy * W + ix] : 0.f;
+    }
+    const float* gb = go + (size_t)b * 3 * HW;
+    for (int i = tid; i < 3 * enp; i += 256) {
+        const int c = i / enp, pp = i - c * enp;
+        gox[c * PR * W + pp] = gb[(size_t)c * HW + ep0 + pp];
+    }
+    for (int i = tid; i < NM * 25; i += 256) kl[i] = kerns[(size_t)b * NM * 25 + i];
+    __syncthreads();
+    for (int i = tid; i < NP * G; i += 256) {
+        const int m = i / G, gi = i - m * G;
+        const int gfirst = (m * HW + ep0) / NP, glast = (m * HW + ep0 + enp - 1) / NP;
+        if (gfirst + gi <= glast) {
+            const float* e = lg + m * win + (gfirst + gi) * NP - (m * HW + ep0 - (NP - 1));
+            float mx = e[0];
+            for (int u = 1; u < NP; ++u) mx = fmaxf(mx, e[u]);
+            float sum = 0.f;
+            for (int u = 0; u < NP; ++u) sum += expf(e[u] - mx);
+            gmx[i] = mx; ginv[i] = 1.0f / sum;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < NP * enp; i += 256) {
+        const int m = i / enp, pp = i - m * enp;
+        const int gi = (m * HW + ep0 + pp) / NP - (m * HW + ep0) / NP;
+        mkx[m * PR * W + pp] = expf(lg[m * win + pp + (NP - 1)] - gmx[m * G + gi]) * ginv[m * G + gi];
+    }
+    __syncthreads();
+    const int toff = (y0 - ey0) * W;             // tile offset inside the extended arrays
+    const int np = rows * W;
+    // ---- per-pixel gradients of the masks and of enc7 ----
+    for (int pp = tid; pp < np; pp += 256) {
+        const int p = y0 * W + pp, y = p / W, x = p - y * W, ry = y - y0;
+        const float g0 = gox[0 * PR * W + toff + pp], g1 = gox[1 * PR * W + toff + pp], g2 = gox[2 * PR * W + toff + pp];
+        const float* p0 = prevt + (0 * PR + ry) * PW + x;
+        const float* p1 = prevt + (1 * PR + ry) * PW + x;
+        const float* p2 = prevt + (2 * PR + ry) * PW + x;
+        float* dm = dmk + (size_t)b * NP * HW + p;
+        dm[0] = g0 * p0[2 * PW + 2] + g1 * p1[2 * PW + 2] + g2 * p2[2 * PW + 2];
+        const float l0 = layer0[((size_t)b * 3 + 0) * HW + p], l1 = layer0[((size_t)b * 3 + 1) * HW + p], l2 = layer0[((size_t)b * 3 + 2) * HW + p];
+        dm[(size_t)HW] = g0 * l0 + g1 * l1 + g2 * l2;
+        const float m1 = mkx[1 * PR * W + toff + pp];
+        dz[((size_t)b * 3 + 0) * HW + p] = l0 > 0.5f ? g0 * m1 * l0 * (1.f - l0) : 0.f;
+        dz[((size_t)b * 3 + 1) * HW + p] = l1 > 0.5f ? g1 * m1 * l1 * (1.f - l1) : 0.f;
+        dz[((size_t)b * 3 + 2) * HW + p] = l2 > 0.5f ? g2 * m1 * l2 * (1.f - l2) : 0.f;
+        for (int k = 0; k < NM; ++k) {
+            float t = 0.f;
+            if (k < NK) {
+                const float* kk = kl + k * 25;
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int j = 0; j < 5; ++j)
+                        t = fmaf(kk[i * 5 + j], g0 * p0[i * PW + j] + g1 * p1[i * PW + j] + g2 * p2[i * PW + j], t);
+            }
+            if (k + 2 < NP) dm[(size_t)(k + 2) * HW] = t;
+        }
+    }
+    // ---- kernel gradient partials: thread (k, ij) sums over the tile ----
+    if (tid < NK * 25) {
+        const int k = tid / 25, ij = tid - k * 25, i = ij / 5, j = ij - i * 5;
+        float acc = 0.f;
+        for (int pp = 0; pp < np; ++pp) {
+            const int ry = pp / W, x = pp - ry * W;
+            const float mq = mkx[(k + 2) * PR * W + toff + pp];
+            const float v = gox[toff + pp] * prevt[(0 * PR + ry + i) * PW + x + j] + gox[PR * W + toff + pp] * prevt[(1 * PR + ry + i) * PW + x + j] +
+                            gox[2 * PR * W + toff + pp] * prevt[(2 * PR + ry + i) * PW + x + j];
+            acc = fmaf(mq, v, acc);
+        }
+        dkpart[((size_t)b * gridDim.x + blockIdx.x) * 256 + tid] = acc;
+    } else if (tid < 256) {
+        dkpart[((size_t)b * gridDim.x + blockIdx.x) * 256 + tid] = 0.f;
+    }
+    // ---- gradient w.r.t. the previous frame (feed-self only) ----
+    if (dprev) {
+        for (int pp = tid; pp < np; pp += 256) {
+            const int p = y0 * W + pp, y = p / W, x = p - y * W;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int sy = y - (i - 2);                       // source pixel row: q - (ij - 2)
+                if (sy < ey0 || sy >= ey1) continue;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int sx = x - (j - 2);
+                    if ((unsigned)sx >= (unsigned)W) continue;
+                    const int sp = (sy - ey0) * W + sx;
+                    float wsum = 0.f;
+                    for (int k = 0; k < NK; ++k) wsum = fmaf(kl[k * 25 + i * 5 + j], mkx[(k + 2) * PR * W + sp], wsum);
+                    a0 = fmaf(wsum, gox[sp], a0); a1 = fmaf(wsum, gox[PR * W + sp], a1); a2 = fmaf(wsum, gox[2 * PR * W + sp], a2);
+                }
+            }
+            const float m0 = mkx[toff + pp];
+            float* dp = dprev + (size_t)b * 3 * HW + p;
+            const float v0 = a0 + m0 * gox[toff + pp], v1 = a1 + m0 * gox[PR * W + toff + pp], v2 = a2 + m0 * gox[2 * PR * W + toff + pp];
+            if (dprev_accum) { dp[0] += v0; dp[(size_t)HW] += v1; dp[2 * (size_t)HW] += v2; }
+            else { dp[0] = v0; dp[(size_t)HW] = v1; dp[2 * (size_t)HW] = v2; }
+        }
+    }
+}
+
+int composite_bwd_tiles(int H) { return (H + CB_TR - 1) / CB_TR; }
+
+int composite_bwd_cdna(const float* prev, const float* logits, const float* layer0, const float* kerns, const float* go,
+                       float* dmk, float* dz, float* dkpart, float* dprev, int dprev_accum, int B, int H, int W, int NM, hipStream_t s) {
+    PIVP_CHECK_ARG(prev && logits && layer0 && kerns && go && dmk && dz && dkpart && B > 0 && H > 1 && W > 1 && NM >= 1 && NM <= 10);
+    const int NP = NM + 1, PR = CB_TR + 4;
+    const int enp = PR * W, win = enp + 2 * (NP - 1), G = enp / NP + 2;
+    const size_t lds = sizeof(float) * ((size_t)NP * win + 2 * NP * G + (size_t)NP * PR * W + 3 * PR * W + 3 * PR * (W + 4) + NM * 25);
+    PIVP_CHECK_ARG(lds <= 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_cdna_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(composite_bwd_cdna_kernel, dim3(composite_bwd_tiles(H), B), dim3(256), lds, s, prev, logits, layer0, kerns, go, dmk,
+                       dz, dkpart, dprev, dprev_accum, H, W, NM);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward of the flat softmax + ReLU of the mask head (TM:719-722): for each group of NP consecutive flat
+// elements, d r = mk * (d mk - sum_group mk * d mk), masked by r > 0 (r = relu(masks conv)).  In place on dmk.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_softmax_bwd_kernel(const float* __restrict__ logits, float* __restrict__ dmk, long ngroups, int NP) {
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (long)gridDim.x * 256) {
+        const float* r = logits + g * NP;
+        float* d = dmk + g * NP;
+        float mx = r[0];
+        for (int u = 1; u < NP; ++u) mx = fmaxf(mx, r[u]);
+        float e[12], sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 12; ++u) { e[u] = u < NP ? expf(r[u] - mx) : 0.f; sum += e[u]; }
+        const float inv = 1.0f / sum;
+        float dot = 0.f;
+#pragma unroll
+        for (int u = 0; u < 12; ++u) if (u < NP) { e[u] *= inv; dot = fmaf(e[u], d[u], dot); }
+#pragma unroll
+        for (int u = 0; u < 12; ++u) if (u < NP) d[u] = r[u] > 0.f ? e[u] * (d[u] - dot) : 0.f;
+    }
+}
+int mask_softmax_bwd(const float* logits, float* dmk, int B, int HW, int NP, hipStream_t s) {
+    PIVP_CHECK_ARG(logits && dmk && B > 0 && HW > 0 && NP >= 2 && NP <= 12);
+    const long ng = (long)B * HW;          // B*NP*HW / NP groups
+    hipLaunchKernelGGL(mask_softmax_bwd_kernel, dim3((unsigned)((ng + 255) / 256 < 2048 ? (ng + 255) / 256 : 2048)), dim3(256), 0, s, logits, dmk, ng, NP);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
+// 1x1 heads backward (forward heads_1x1_kernel; masks TM:718, enc7 TM:315): with d pre-activation planes dp[o]
+// (o < NP: masks after mask_softmax_bwd; o >= NP: enc7 dz):
+//   d e6[pix][k] = sum_o W[k][o] dp[o][pix];  dW[k][o] += sum_pix e6[pix][k] dp[o][pix];  db[o] += sum_pix dp[o][pix]
+// One block = 128 pixels.  dW/db through atomics (one [64][NO] tile per block).
+// ------------------------------------------------------------------------------------------
+constexpr int HB_PX = 128;
+constexpr int HB_MAXOUT = 36;
+__global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ e6, const float* __restrict__ wm, const float* __restrict__ we,
+                                                        const float* __restrict__ dpm, const float* __restrict__ dpe,
+                                                        float* __restrict__ de6, float* __restrict__ dwm, float* __restrict__ dbm,
+                                                        float* __restrict__ dwe, float* __restrict__ dbe, int total_px, int HW, int NP, int NE) {
+    __shared__ float xt[HB_PX * 65];
+    __shared__ float dpt[HB_MAXOUT * HB_PX];
+    __shared__ float wl[64 * HB_MAXOUT];
+    const int tid = threadIdx.x, NO = NP + NE;
+    const int px0 = blockIdx.x * HB_PX;
+    for (int i = tid; i < 64 * NO; i += 256) {
+        const int k = i / NO, o = i - k * NO;
+        wl[k * HB_MAXOUT + o] = o < NP ? wm[k * NP + o] : we[k * NE + (o - NP)];
+    }
+    for (int i = tid; i < HB_PX * 64; i += 256) {
+        const int p = i >> 6, k = i & 63;
+        xt[p * 65 + k] = px0 + p < total_px ? e6[(size_t)(px0 + p) * 64 + k] : 0.f;
+    }
+    for (int i = tid; i < NO * HB_PX; i += 256) {
+        const int o = i / HB_PX, p = i - o * HB_PX;
+        float v = 0.f;
+        if (px0 + p < total_px) {
+            const int b = (px0 + p) / HW, q = (px0 + p) - b * HW;
+            v = o < NP ? dpm[((size_t)b * NP + o) * HW + q] : dpe[((size_t)b * NE + (o - NP)) * HW + q];
+        }
+        dpt[i] = v;
+    }
+    __syncthreads();
+    {   // d e6: thread = (pixel, 32-channel half)
+        const int p = tid >> 1, kh = (tid & 1) * 32;
+        if (px0 + p < total_px) {
+            float acc[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) acc[k] = 0.f;
+            for (int o = 0; o < NO; ++o) {
+                const float d = dpt[o * HB_PX + p];
+#pragma unroll
+                for (int k = 0; k < 32; ++k) acc[k] = fmaf(wl[(kh + k) * HB_MAXOUT + o], d, acc[k]);
+            }
+            float* op = de6 + (size_t)(px0 + p) * 64 + kh;
+#pragma unroll
+            for (int k = 0; k < 32; k += 4) *reinterpret_cast<f32x4*>(op + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+        }
+    }
+    // dW: thread = (k = tid / 4, outputs o = tid % 4, +4, ...)
+    {
+        const int k = tid >> 2, og = tid & 3;
+        for (int o = og; o < NO; o += 4) {
+            float acc = 0.f;
+            for (int p = 0; p < HB_PX; ++p) acc = fmaf(xt[p * 65 + k], dpt[o * HB_PX + p], acc);
+            if (o < NP) atomicAdd(dwm + k * NP + o, acc); else atomicAdd(dwe + k * NE + (o - NP), acc);
+        }
+    }
+    if (tid < NO) {
+        float acc = 0.f;
+        for (int p = 0; p < HB_PX; ++p) acc += dpt[tid * HB_PX + p];
+        if (tid < NP) atomicAdd(dbm + tid, acc); else atomicAdd(dbe + (tid - NP), acc);
+    }
+}
+int heads_bwd(const float* e6, const float* wm, const float* we, const float* dpm, const float* dpe, float* de6,
+              float* dwm, float* dbm, float* dwe, float* dbe, int B, int HW, int NP, int NE, hipStream_t s) {
+    PIVP_CHECK_ARG(e6 && wm && we && dpm && dpe && de6 && dwm && dbm && dwe && dbe && B > 0 && HW > 0 && NP + NE <= HB_MAXOUT);
+    const int total = B * HW;
+    hipLaunchKernelGGL(heads_bwd_kernel, dim3((total + HB_PX - 1) / HB_PX), dim3(256), 0, s, e6, wm, we, dpm, dpe, de6, dwm, dbm, dwe, dbe,
+                       total, HW, NP, NE);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
+// CDNA kernel generator backward (forward TM:321-329): v = W x + b, u = relu(v - 1e-12) + 1e-12, k = u / sum_25 u.
+//   dk from the composite partials (the last generated kernel never reaches the output: zero gradient, TM:726)
+//   du = (dk - sum_j dk_j k_j) / S,  dv = du [v - 1e-12 > 0]
+//   d x[b][kk] = sum_o Wt[kk][o] dv[b][o];  dWt[kk][o] += sum_b x[b][kk] dv[b][o];  db[o] += sum_b dv[b][o]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cdna_kernels_bwd_dv_kernel(const float* __restrict__ vpre, const float* __restrict__ dkpart, int ntiles,
+                                                                  float* __restrict__ dv, float* __restrict__ db, int NM) {
+    __shared__ float u[256], dk[256];
+    const int b = blockIdx.x, o = threadIdx.x, nout = NM * 25, nused = (NM - 1) * 25;
+    float uu = 0.f, d = 0.f;
+    if (o < nout) {
+        uu = fmaxf(vpre[(size_t)b * 256 + o] - 1e-12f, 0.f) + 1e-12f;
+        if (o < nused) for (int t = 0; t < ntiles; ++t) d += dkpart[((size_t)b * ntiles + t) * 256 + o];
+    }
+    u[o] = uu; dk[o] = d;
+    __syncthreads();
+    float out = 0.f;
+    if (o < nout) {
+        const int g = (o / 25) * 25;
+        float S = 0.f, dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 25; ++i) S += u[g + i];
+#pragma unroll
+        for (int i = 0; i < 25; ++i) dot = fmaf(dk[g + i], u[g + i], dot);
+        const float du = (d - dot / S) / S;
+        out = (vpre[(size_t)b * 256 + o] - 1e-12f > 0.f) ? du : 0.f;
+        atomicAdd(db + o, out);
+    }
+    dv[(size_t)b * 256 + o] = out;
+}
+
+// d x[b][kk] = sum_o Wt[kk][o] dv[b][o]; block = 32 rows kk, all b (<= 32 per pass)
+__global__ __launch_bounds__(256) void skinny_linear_bwd_x_kernel(const float* __restrict__ wt, const float* __restrict__ dv,
+                                                                  float* __restrict__ dx, int B, int K, int accum) {
+    __shared__ float wl[32 * 257];
+    __shared__ float dl[32 * 257];
+    const int k0 = blockIdx.x * 32, b0 = blockIdx.y * 32, tid = threadIdx.x;
+    for (int i = tid; i < 32 * 256; i += 256) {
+        const int r = i >> 8, o = i & 255;
+        wl[r * 257 + o] = (k0 + r < K) ? wt[(size_t)(k0 + r) * 256 + o] : 0.f;
+        dl[r * 257 + o] = (b0 + r < B) ? dv[(size_t)(b0 + r) * 256 + o] : 0.f;
+    }
+    __syncthreads();
+    const int kk = tid & 31, bg = tid >> 5;       // 8 groups of 4 samples
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int o = 0; o < 256; ++o) {
+        const float w = wl[kk * 257 + o];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(w, dl[(bg * 4 + j) * 257 + o], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = b0 + bg * 4 + j;
+        if (b < B && k0 + kk < K) {
+            float* p = dx + (size_t)b * K + k0 + kk;
+            *p = accum ? *p + acc[j] : acc[j];
+        }
+    }
+}
+
+// dWt[kk][o] += sum_b x[b][kk] dv[b][o]; block = 8 rows kk x 256 columns
+__global__ __launch_bounds__(256) void skinny_linear_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dv,
+                                                                  float* __restrict__ dwt, int B, int K) {
+    __shared__ float xl[8 * 33];
+    const int k0 = blockIdx.x * 8, o = threadIdx.x;
+    float acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+    for (int b0 = 0; b0 < B; b0 += 32) {
+        __syncthreads();
+        {
+            const int r = threadIdx.x >> 5, bb = threadIdx.x & 31;
+            xl[r * 33 + bb] = (b0 + bb < B && k0 + r < K) ? x[(size_t)(b0 + bb) * K + k0 + r] : 0.f;
+        }
+        __syncthreads();
+        for (int bb = 0; bb < 32 && b0 + bb < B; ++bb) {
+            const float d = dv[(size_t)(b0 + bb) * 256 + o];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = fmaf(xl[r * 33 + bb], d, acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        if (k0 + r < K) dwt[(size_t)(k0 + r) * 256 + o] += acc[r];
+}
+
+int cdna_kernels_bwd(const float* hidden5, const float* wt, const float* vpre, const float* dkpart, int ntiles, float* dv,
+                     float* dhidden5, int accum_dx, float* dwt, float* db, int B, int K, int NM, hipStream_t s) {
+    PIVP_CHECK_ARG(hidden5 && wt && vpre && dkpart && dv && dhidden5 && dwt && db && B > 0 && K > 0 && NM >= 1 && NM * 25 <= 256);
+    hipLaunchKernelGGL(cdna_kernels_bwd_dv_kernel, dim3(B), dim3(256), 0, s, vpre, dkpart, ntiles, dv, db, NM);
+    hipLaunchKernelGGL(skinny_linear_bwd_x_kernel, dim3((K + 31) / 32, (B + 31) / 32), dim3(256), 0, s, wt, dv, dhidden5, B, K, accum_dx);
+    hipLaunchKernelGGL(skinny_linear_bwd_w_kernel, dim3((K + 7) / 8), dim3(256), 0, s, hidden5, dv, dwt, B, K);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
+// enc3 (smear + 1x1 + ReLU) and state predictor backward (forward enc3_state_kernel; TM:556-567, 503, 730).
+//   dpre = d e3 [e3 > 0];  d e2 = dpre W3x^T;  dW3x += e2^T dpre;  db3 += colsum(dpre);
+//   dW3s[j] += sa[j] colsum;  d sa[j] = W3s[j] . colsum + sum_o Wcs[o][j] d snew[o];  dWcs, dbcs from d snew.
+//   d state_prev = d sa[5:10]  (the predicted state is fed back, TM:676)
+// One block per (64-pixel tile, sample); small sums through atomics.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void enc3_state_bwd_kernel(const float* __restrict__ e2, const float* __restrict__ e3, const float* __restrict__ de3, int ldd3,
+                                                             const float* __restrict__ action, const float* __restrict__ state,
+                                                             const float* __restrict__ w3, const float* __restrict__ wcs,
+                                                             const float* __restrict__ dsnew, float* __restrict__ de2,
+                                                             float* __restrict__ dw3, float* __restrict__ db3, float* __restrict__ dwcs,
+                                                             float* __restrict__ dbcs, float* __restrict__ dstate_prev,
+                                                             int HW8, int use_state) {
+    __shared__ float xt[64 * 65];
+    __shared__ float dt[64 * 65];
+    __shared__ __attribute__((aligned(16))) float wl[64 * 64];
+    __shared__ float colsum[64], sa[10], dsa[10];
+    const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    if (tid < 5) sa[tid] = action[b * 5 + tid]; else if (tid < 10) sa[tid] = state[b * 5 + tid - 5];
+    if (tid < 10) dsa[tid] = 0.f;
+    for (int i = tid; i < 64 * 64; i += 256) wl[i] = w3[i];
+    const int npx = min(64, HW8 - tile * 64);
+    const size_t base = ((size_t)b * HW8 + tile * 64) * 64;
+    for (int i = tid; i < 64 * 64; i += 256) {
+        const int p = i >> 6, k = i & 63;
+        const bool ok = p < npx;
+        xt[p * 65 + k] = ok ? e2[base + i] : 0.f;
+        dt[p * 65 + k] = (ok && e3[base + i] > 0.f) ? de3[((size_t)b * HW8 + tile * 64 + p) * ldd3 + k] : 0.f;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float c = 0.f;
+        for (int p = 0; p < 64; ++p) c += dt[p * 65 + tid];
+        colsum[tid] = c;
+        atomicAdd(db3 + tid, c);
+    }
+    {   // d e2[p][ci] = sum_co w3[ci][co] dpre[p][co]: thread (p = tid/4, 16 ci)
+        const int p = tid >> 2, cg = (tid & 3) * 16;
+        float acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int co = 0; co < 64; ++co) {
+            const float d = dt[p * 65 + co];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = fmaf(wl[(cg + i) * 64 + co], d, acc[i]);
+        }
+        if (p < npx) {
+            float* op = de2 + base + (size_t)p * 64 + cg;
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) *reinterpret_cast<f32x4*>(op + i) = f32x4{acc[i], acc[i + 1], acc[i + 2], acc[i + 3]};
+        }
+    }
+    {   // dW3x[ci][co] += sum_p e2[p][ci] dpre[p][co]: thread (ci = tid/4, co group of 16)
+        const int ci = tid >> 2, cg = (tid & 3) * 16;
+        float acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int p = 0; p < 64; ++p) {
+            const float xv = xt[p * 65 + ci];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = fmaf(xv, dt[p * 65 + cg + i], acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) atomicAdd(dw3 + ci * 64 + cg + i, acc[i]);
+    }
+    __syncthreads();
+    if (use_state && tid < 64) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) atomicAdd(dw3 + (64 + j) * 64 + tid, sa[j] * colsum[tid]);
+    }
+    if (tid < 10) {
+        float v = 0.f;
+        if (use_state) for (int co = 0; co < 64; ++co) v = fmaf(w3[(64 + tid) * 64 + co], colsum[co], v);
+        if (tile == 0) for (int o = 0; o < 5; ++o) v = fmaf(wcs[o * 10 + tid], dsnew[b * 5 + o], v);
+        if (tid >= 5) atomicAdd(dstate_prev + b * 5 + tid - 5, v);
+    }
+    if (tile == 0 && tid >= 64 && tid < 64 + 50) {
+        const int o = (tid - 64) / 10, j = (tid - 64) % 10;
+        atomicAdd(dwcs + o * 10 + j, dsnew[b * 5 + o] * sa[j]);
+        if (j == 0) atomicAdd(dbcs + o, dsnew[b * 5 + o]);
+    }
+}
+int enc3_state_bwd(const float* e2, const float* e3, const float* de3, int ldd3, const float* action, const float* state, const float* w3,
+                   const float* wcs, const float* dsnew, float* de2, float* dw3, float* db3, float* dwcs, float* dbcs,
+                   float* dstate_prev, int B, int HW8, int use_state, hipStream_t s) {
+    PIVP_CHECK_ARG(e2 && e3 && de3 && action && state && w3 && wcs && dsnew && de2 && dw3 && db3 && dwcs && dbcs && dstate_prev && B > 0 && HW8 > 0);
+    hipLaunchKernelGGL(enc3_state_bwd_kernel, dim3((HW8 + 63) / 64, B), dim3(256), 0, s, e2, e3, de3, ldd3, action, state, w3, wcs, dsnew, de2,
+                       dw3, db3, dwcs, dbcs, dstate_prev, HW8, use_state);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
+// enc0 backward (forward conv_enc0_kernel, TM:500): dW[k][co] += sum_pix patch[pix][k] d[pix][co], db, and
+// (feed-self) d img[c](y,x) = sum over taps with matching parity.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void enc0_wgrad_kernel(const float* __restrict__ img, const float* __restrict__ d, float* __restrict__ dw,
+                                                         float* __restrict__ db, int B, int H, int W) {
+    __shared__ float pt[64 * 76];
+    __shared__ float dtl[64 * 33];
+    const int H2 = H >> 1, W2 = W >> 1, total = B * H2 * W2, tid = threadIdx.x;
+    const int co = tid & 31, kg = tid >> 5;          // k = kg, kg+8, ...
+    float acc[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+    float bacc = 0.f;
+    for (int t0 = blockIdx.x * 64; t0 < total; t0 += gridDim.x * 64) {
+        __syncthreads();
+        for (int i = tid; i < 64 * 75; i += 256) {
+            const int p = i / 75, k = i - p * 75;
+            const int pix = t0 + p;
+            float v = 0.f;
+            if (pix < total) {
+                const int b = pix / (H2 * W2), rem = pix - b * H2 * W2, oy = rem / W2, ox = rem - oy * W2;
+                const int tap = k / 3, ci = k - tap * 3, ky = tap / 5, kx = tap - ky * 5;
+                const int iy = 2 * oy - 2 + ky, ix = 2 * ox - 2 + kx;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = img[((size_t)b * 3 + ci) * H * W + iy * W + ix];
+            }
+            pt[p * 76 + k] = v;
+        }
+        for (int i = tid; i < 64 * 32; i += 256) {
+            const int p = i >> 5, c = i & 31;
+            dtl[p * 33 + c] = t0 + p < total ? d[(size_t)(t0 + p) * 32 + c] : 0.f;
+        }
+        __syncthreads();
+        for (int p = 0; p < 64; ++p) {
+            const float dv = dtl[p * 33 + co];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) { const int k = kg + 8 * i; if (k < 75) acc[i] = fmaf(pt[p * 76 + k], dv, acc[i]); }
+            if (kg == 0) bacc += dv;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { const int k = kg + 8 * i; if (k < 75) atomicAdd(dw + k * 32 + co, acc[i]); }
+    if (kg == 0) atomicAdd(db + co, bacc);
+}
+
+__global__ __launch_bounds__(256) void enc0_dgrad_kernel(const float* __restrict__ d, const float* __restrict__ w, float* __restrict__ dimg,
+                                                         int accum, int B, int H, int W) {
+    __shared__ float wl[75 * 32];
+    for (int i = threadIdx.x; i < 75 * 32; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const int H2 = H >> 1, W2 = W >> 1;
+    const long total = (long)B * H * W;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int b = (int)(idx / (H * W)), rem = (int)(idx - (long)b * H * W), y = rem / W, x = rem - y * W;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) {
+            const int ty = y + 2 - ky;
+            if (ty & 1) continue;
+            const int oy = ty >> 1;
+            if ((unsigned)oy >= (unsigned)H2) continue;
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const int tx = x + 2 - kx;
+                if (tx & 1) continue;
+                const int ox = tx >> 1;
+                if ((unsigned)ox >= (unsigned)W2) continue;
+                const float* dp = d + ((size_t)(b * H2 + oy) * W2 + ox) * 32;
+                const float* wr = wl + (ky * 5 + kx) * 3 * 32;
+                for (int co = 0; co < 32; ++co) {
+                    const float dv = dp[co];
+                    a0 = fmaf(wr[co], dv, a0); a1 = fmaf(wr[32 + co], dv, a1); a2 = fmaf(wr[64 + co], dv, a2);
+                }
+            }
+        }
+        float* o = dimg + (size_t)b * 3 * H * W + rem;
+        if (accum) { o[0] += a0; o[(size_t)H * W] += a1; o[2 * (size_t)H * W] += a2; }
+        else { o[0] = a0; o[(size_t)H * W] = a1; o[2 * (size_t)H * W] = a2; }
+    }
+}
+
+int enc0_bwd(const float* img, const float* w, const float* d, float* dw, float* db, float* dimg, int dimg_accum, int B, int H, int W,
+             hipStream_t s) {
+    PIVP_CHECK_ARG(img && w && d && dw && db && B > 0 && H > 0 && W > 0);
+    const int total = B * (H / 2) * (W / 2);
+    int blocks = (total + 63) / 64; if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(enc0_wgrad_kernel, dim3(blocks), dim3(256), 0, s, img, d, dw, db, B, H, W);
+    if (dimg) {
+        const long tp = (long)B * H * W;
+        hipLaunchKernelGGL(enc0_dgrad_kernel, dim3((unsigned)((tp + 255) / 256 < 2048 ? (tp + 255) / 256 : 2048)), dim3(256), 0, s, d, w, dimg,
+                           dimg_accum, B, H, W);
+    }
+    return PIVP_LAUNCH_STATUS();
+}
+
+// out[i] = a[i] + b[i] over n floats with row strides (sum of two gradient contributions into one buffer)
+__global__ __launch_bounds__(256) void add_strided_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds_, int C, long npix) {
+    const long total = npix * (C / 4);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / (C / 4); const int c = (int)(i - p * (C / 4)) * 4;
+        f32x4 a = *reinterpret_cast<f32x4*>(dst + p * ldd + c);
+        a += *reinterpret_cast<const f32x4*>(src + p * lds_ + c);
+        *reinterpret_cast<f32x4*>(dst + p * ldd + c) = a;
+    }
+}
+int add_strided(float* dst, int ldd, const float* src, int lds_, int C, long npix, hipStream_t s) {
+    PIVP_CHECK_ARG(dst && src && C > 0 && C % 4 == 0 && npix > 0 && ldd % 4 == 0 && lds_ % 4 == 0);
+    const long total = npix * (C / 4);
+    hipLaunchKernelGGL(add_strided_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, s, dst, ldd, src, lds_, C, npix);
+    return PIVP_LAUNCH_STATUS();
+}
+
+}  // namespace pivp

@@ -142,12 +142,13 @@ __device__ __forceinline__ double sum_partials(const float* __restrict__ partial
 
 // CDNA finisher (TM:326-329): + bias, relu(k - RELU_SHIFT) + RELU_SHIFT, divide by the 5x5 sum.
 __global__ __launch_bounds__(256) void cdna_kernels_finish_kernel(const float* __restrict__ partials, const float* __restrict__ bias,
-                                                                  float* __restrict__ kerns, int B, int KS, int nout) {
+                                                                  float* __restrict__ kerns, int B, int KS, int nout, float* __restrict__ vpre) {
     __shared__ float v[256];
     const int b = blockIdx.x, o = threadIdx.x;
     float acc = 0.f;
     if (o < nout) {
         const double a = (double)bias[o] + sum_partials(partials, B, KS, b, o);
+        if (vpre) vpre[(size_t)b * 256 + o] = (float)a;
         acc = fmaxf((float)a - 1e-12f, 0.f) + 1e-12f;
     }
     v[o] = acc;
@@ -162,11 +163,11 @@ __global__ __launch_bounds__(256) void cdna_kernels_finish_kernel(const float* _
 }
 
 int cdna_kernels(const float* hidden5, const float* wt, const float* bias, float* partials, float* kerns,
-                 int B, int K, int num_masks, hipStream_t s) {
+                 int B, int K, int num_masks, hipStream_t s, float* vpre) {
     PIVP_CHECK_ARG(hidden5 && wt && bias && partials && kerns && B > 0 && K > 0 && num_masks >= 1 && num_masks * 25 <= 256);
     const int KS = cdna_kernel_partials_slices(K);
     hipLaunchKernelGGL(skinny_linear_partials_kernel<float>, dim3(KS, (B + LIN_BG - 1) / LIN_BG), dim3(256), 0, s, hidden5, wt, partials, B, K);
-    hipLaunchKernelGGL(cdna_kernels_finish_kernel, dim3(B), dim3(256), 0, s, partials, bias, kerns, B, KS, num_masks * 25);
+    hipLaunchKernelGGL(cdna_kernels_finish_kernel, dim3(B), dim3(256), 0, s, partials, bias, kerns, B, KS, num_masks * 25, vpre);
     return PIVP_LAUNCH_STATUS();
 }
 

@@ -1,0 +1,30 @@
+// Host-side launch helpers shared by the per-op C ABI (pivp_c_api.hip) and the plan (pivp_plan.hip).
+#pragma once
+#include "pivp_kernels.h"
+
+namespace pivp {
+
+long long view_bytes(int B, int H, int W, int ld);
+bool fits31(long long v);
+int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
+                 const float* c_in, float* c_out, float* h_out, int B, int H, int W, hipStream_t s, int variant = 0,
+                 float* gates_out = nullptr);
+int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
+                  int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0);
+int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
+                    int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0);
+int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, int cout, int ldo, int ksize, int B, int H, int W,
+                hipStream_t s, int accum = 0);
+int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
+              float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s);
+int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
+                          const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
+                          float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
+                          int B, int H, int W, hipStream_t s);
+int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w, float* dy, int cout, int ldy, const float* y, int ldyy,
+                      float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, hipStream_t s);
+int run_layernorm(const float* x, const float* g, const float* b, float* out, float* partials, int B, int n, int C,
+                  int ldo, float eps, int relu, hipStream_t s, float* stat_out = nullptr);
+int run_select_frames(const float* gt, const float* gen, const unsigned char* take, float* out, int B, int frame_numel, hipStream_t s);
+
+}  // namespace pivp

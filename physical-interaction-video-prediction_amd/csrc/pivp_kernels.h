@@ -73,7 +73,7 @@ int heads_1x1(const float* e6, const float* wm, const float* bm, const float* we
 // CDNA kernel generator: Linear(hidden5) -> relu shift -> per-kernel normalisation (TM:321-329)
 int cdna_kernel_partials_slices(int K);
 int cdna_kernels(const float* hidden5, const float* wt, const float* bias, float* partials, float* kerns,
-                 int B, int K, int num_masks, hipStream_t s);
+                 int B, int K, int num_masks, hipStream_t s, float* vpre = nullptr);   // vpre [B][256]: pre-activation, kept for backward
 
 // STP parameters: Linear -> relu -> shared Linear(6) + identity (TM:457-468)
 int stp_params(const float* hidden5, const float* wt1, const float* b1, const float* w2, const float* b2,
@@ -102,6 +102,23 @@ int ln_backward(const float* dy, int lddy, const float* y, int ldy, const float*
                 float* partials, float* dx, float* dgamma, float* dbeta, int B, int n, int C, int relu, hipStream_t s);
 int adam_step(float* p, const float* g, float* m, float* v, long n, double lr_t, double beta1, double beta2, double eps,
               double gscale, hipStream_t s);
+
+// ---- backward of the heads / trunk ends (csrc/backward_heads.hip) ----
+int scaled_diff(const float* a, const float* b, float* out, long n, float scale, int accum, hipStream_t s);
+int composite_bwd_tiles(int H);
+int composite_bwd_cdna(const float* prev, const float* logits, const float* layer0, const float* kerns, const float* go,
+                       float* dmk, float* dz, float* dkpart, float* dprev, int dprev_accum, int B, int H, int W, int NM, hipStream_t s);
+int mask_softmax_bwd(const float* logits, float* dmk, int B, int HW, int NP, hipStream_t s);
+int heads_bwd(const float* e6, const float* wm, const float* we, const float* dpm, const float* dpe, float* de6,
+              float* dwm, float* dbm, float* dwe, float* dbe, int B, int HW, int NP, int NE, hipStream_t s);
+int cdna_kernels_bwd(const float* hidden5, const float* wt, const float* vpre, const float* dkpart, int ntiles, float* dv,
+                     float* dhidden5, int accum_dx, float* dwt, float* db, int B, int K, int NM, hipStream_t s);
+int enc3_state_bwd(const float* e2, const float* e3, const float* de3, int ldd3, const float* action, const float* state, const float* w3,
+                   const float* wcs, const float* dsnew, float* de2, float* dw3, float* db3, float* dwcs, float* dbcs,
+                   float* dstate_prev, int B, int HW8, int use_state, hipStream_t s);
+int enc0_bwd(const float* img, const float* w, const float* d, float* dw, float* db, float* dimg, int dimg_accum, int B, int H, int W,
+             hipStream_t s);
+int add_strided(float* dst, int ldd, const float* src, int lds_, int C, long npix, hipStream_t s);
 
 // planar NCHW <-> NHWC helpers for taps (conv_res) and tests
 int nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, int ld, hipStream_t s);

@@ -1,0 +1,543 @@
+// The plan: Model.__init__ / reset_state / __call__ of the reference (TM:484-764) and the backward pass that
+// Chainer's autograd performs under optimizer.update (TM:950), sequenced in native code on one HIP stream.
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/pivp_hip.h"
+#include "pivp_host.h"
+
+using namespace pivp;
+
+namespace {
+
+struct LstmSpec { const char* name; int cx; int C; int level; };  // level: 2 -> H/2, 4 -> H/4, 8 -> H/8
+const LstmSpec kLstm[7] = {
+    {"lstm1", 32, 32, 2}, {"lstm2", 32, 32, 2}, {"lstm3", 32, 64, 4}, {"lstm4", 64, 64, 4},
+    {"lstm5", 64, 128, 8}, {"lstm6", 128, 64, 4}, {"lstm7", 96, 32, 2}};
+
+struct ParamInfo { std::string name; long long numel; const float* ptr; float* grad; };
+
+// Per-timestep activations (offsets in floats from the workspace base).  Two rolling slabs for inference, T-1 slabs
+// when keep_activations (BPTT needs every step).
+struct Slab {
+    size_t cat7, n1, n2, cat6, n3, n4, e2, e3, n5, e4, e5, e6;   // NHWC feature maps (cat7 = [hidden7|enc0], cat6 = [hidden6|enc1])
+    size_t h[7], c[7];                                           // ConvLSTM states
+    size_t e0raw, e6raw;                                         // LayerNorm inputs of norm_enc0 / norm_enc6
+    size_t gates[7];                                             // gate activations [M][4C] (training)
+    size_t lnstat;                                               // [9][B][2] mean, rstd (training)
+    size_t logits, enc7, layer0, kerns, vpre, theta;             // head tensors of the step
+    size_t prevsel;                                              // scheduled-sampling input frame of the step
+};
+
+struct Grads {   // gradient workspace (single copy, reused by every timestep of the backward sweep)
+    size_t cat7, n2, cat6, n4, e2, n5, e6, e6raw, e0raw;
+    size_t hln[7], din[7][2], dc[7];
+    size_t dG, wt, go[2], dmk, dz, dkpart, dv, dstate, lnpart;
+};
+
+}  // namespace
+
+struct pivp_plan {
+    pivp_config_t cfg;
+    std::vector<ParamInfo> params;
+    int i_enc_w[7], i_enc_b[7], i_lstm_w[7], i_lstm_b[7];
+    int i_ln_g[9], i_ln_b[9];   // order: norm_enc0, hidden1..hidden7, norm_enc6
+    int i_masks_w, i_masks_b, i_cs_w, i_cs_b, i_enc7_w, i_enc7_b;
+    int i_head_w, i_head_b, i_head2_w, i_head2_b;
+    int H2, W2, H4, W4, H8, W8, NP, NE, K5;
+    float* ws; long long ws_floats;
+    int nslabs;
+    std::vector<Slab> slabs;
+    Grads g;
+    bool has_grads;
+    size_t o_zero, o_lnpart, o_linpart, o_masks, o_losspart;
+    int loss_nparts;
+    int last_steps;
+    bool last_sched;                  // last forward used scheduled sampling (frames detached, TM:669-670)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<int> prof_layer;
+    size_t prof_used = 0;
+    ~pivp_plan() { for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e); }
+};
+
+static const float* P(const pivp_plan* p, int idx) { return p->params[idx].ptr; }
+static float* G(const pivp_plan* p, int idx) { return p->params[idx].grad; }
+
+extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
+    if (!cfg || !out) return PIVP_ERR_BADARG;
+    if (cfg->batch <= 0 || cfg->seq_len < 2 || cfg->height < 16 || cfg->width < 16) return PIVP_ERR_BADARG;
+    if (cfg->height % 8 || cfg->width % 8) return PIVP_ERR_BADARG;
+    if (cfg->model_type < 0 || cfg->model_type > 2) return PIVP_ERR_BADARG;
+    if (cfg->num_masks < 1 || cfg->num_masks > 11) return PIVP_ERR_BADARG;
+    if (cfg->model_type == PIVP_MODEL_DNA && cfg->num_masks != 1) return PIVP_ERR_BADARG;  // TM:389-390
+    if (cfg->context_frames < 1 || cfg->context_frames >= cfg->seq_len) return PIVP_ERR_BADARG;
+    pivp_plan* p = new pivp_plan();
+    p->cfg = *cfg;
+    const int H = cfg->height, W = cfg->width, B = cfg->batch, T = cfg->seq_len;
+    p->H2 = H / 2; p->W2 = W / 2; p->H4 = H / 4; p->W4 = W / 4; p->H8 = H / 8; p->W8 = W / 8;
+    p->NP = cfg->num_masks + 1;
+    p->NE = cfg->model_type == PIVP_MODEL_DNA ? 25 : 3;
+    p->K5 = 128 * p->H8 * p->W8;
+    p->ws = nullptr; p->ws_floats = 0; p->last_steps = 0; p->last_sched = false;
+
+    auto add = [&](const std::string& name, long long n) { p->params.push_back({name, n, nullptr, nullptr}); return (int)p->params.size() - 1; };
+    const int cin3 = 64 + (cfg->use_state ? 10 : 0);
+    const long long encw[7] = {75 * 32, 9 * 32 * 32, 9 * 64 * 64, (long long)cin3 * 64, 9 * 128 * 128, 9 * 96 * 96, 9 * 64 * 64};
+    const int encb[7] = {32, 32, 64, 64, 128, 96, 64};
+    for (int i = 0; i < 7; ++i) {
+        p->i_enc_w[i] = add("enc" + std::to_string(i) + "/W", encw[i]);
+        p->i_enc_b[i] = add("enc" + std::to_string(i) + "/b", encb[i]);
+    }
+    for (int i = 0; i < 7; ++i) {
+        const LstmSpec& L = kLstm[i];
+        p->i_lstm_w[i] = add(std::string(L.name) + "/conv/W", 25LL * (L.cx + L.C) * 4 * L.C);
+        p->i_lstm_b[i] = add(std::string(L.name) + "/conv/b", 4 * L.C);
+    }
+    const char* lnn[9] = {"norm_enc0", "hidden1", "hidden2", "hidden3", "hidden4", "hidden5", "hidden6", "hidden7", "norm_enc6"};
+    const long long lnsz[9] = {32LL * p->H2 * p->W2, 32LL * p->H2 * p->W2, 32LL * p->H2 * p->W2, 64LL * p->H4 * p->W4,
+                               64LL * p->H4 * p->W4, 128LL * p->H8 * p->W8, 64LL * p->H4 * p->W4, 32LL * p->H2 * p->W2,
+                               64LL * H * W};
+    for (int i = 0; i < 9; ++i) {
+        p->i_ln_g[i] = add(std::string(lnn[i]) + "/norm/gamma", lnsz[i]);
+        p->i_ln_b[i] = add(std::string(lnn[i]) + "/norm/beta", lnsz[i]);
+    }
+    p->i_masks_w = add("masks/W", 64LL * p->NP);
+    p->i_masks_b = add("masks/b", p->NP);
+    p->i_cs_w = add("current_state/W", 50);
+    p->i_cs_b = add("current_state/b", 5);
+    p->i_enc7_w = add("model/enc7/W", 64LL * p->NE);
+    p->i_enc7_b = add("model/enc7/b", p->NE);
+    p->i_head_w = p->i_head_b = p->i_head2_w = p->i_head2_b = -1;
+    if (cfg->model_type == PIVP_MODEL_CDNA) {
+        p->i_head_w = add("model/cdna_kerns/W", (long long)p->K5 * 256);
+        p->i_head_b = add("model/cdna_kerns/b", 25LL * cfg->num_masks);
+    } else if (cfg->model_type == PIVP_MODEL_STP) {
+        p->i_head_w = add("model/stp_input/W", (long long)p->K5 * 256);
+        p->i_head_b = add("model/stp_input/b", 100);
+        p->i_head2_w = add("model/identity_params/W", 600);
+        p->i_head2_b = add("model/identity_params/b", 6);
+    }
+
+    // ---- workspace carve (offsets in floats, 256-B aligned) ----
+    size_t off = 0;
+    auto carve = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };
+    const size_t HW = (size_t)H * W, HW2 = (size_t)p->H2 * p->W2, HW4 = (size_t)p->H4 * p->W4, HW8 = (size_t)p->H8 * p->W8;
+    const size_t hsz[7] = {HW2 * 32, HW2 * 32, HW4 * 64, HW4 * 64, HW8 * 128, HW4 * 64, HW2 * 32};
+    const bool train = cfg->keep_activations != 0;
+    p->o_zero = carve((size_t)B * HW2 * 32);
+    p->o_lnpart = carve((size_t)B * ln_stats_slices((int)(64 * HW)) * 4);
+    p->o_linpart = carve((size_t)cdna_kernel_partials_slices(p->K5) * B * 256);
+    p->o_masks = carve((size_t)B * p->NP * HW);
+    p->loss_nparts = loss_partials_count((int)(B * 3 * HW));
+    p->o_losspart = carve((size_t)T * p->loss_nparts);
+    p->nslabs = train ? T - 1 : 2;
+    p->slabs.resize(p->nslabs);
+    for (int s = 0; s < p->nslabs; ++s) {
+        Slab& S = p->slabs[s];
+        S.cat7 = carve(B * HW2 * 64); S.n1 = carve(B * HW2 * 32); S.n2 = carve(B * HW2 * 32);
+        S.cat6 = carve(B * HW4 * 96); S.n3 = carve(B * HW4 * 64); S.n4 = carve(B * HW4 * 64);
+        S.e2 = carve(B * HW8 * 64); S.e3 = carve(B * HW8 * 64); S.n5 = carve(B * HW8 * 128);
+        S.e4 = carve(B * HW4 * 128); S.e5 = carve(B * HW2 * 96); S.e6 = carve(B * HW * 64);
+        for (int i = 0; i < 7; ++i) { S.h[i] = carve(B * hsz[i]); S.c[i] = carve(B * hsz[i]); }
+        S.e0raw = carve(B * HW2 * 32); S.e6raw = carve(B * HW * 64);
+        for (int i = 0; i < 7; ++i) S.gates[i] = train ? carve(B * hsz[i] * 4) : 0;
+        S.lnstat = carve((size_t)9 * B * 2);
+        S.logits = carve((size_t)B * p->NP * HW); S.enc7 = carve((size_t)B * p->NE * HW); S.layer0 = carve((size_t)B * 3 * HW);
+        S.kerns = carve((size_t)B * 25 * cfg->num_masks); S.vpre = carve((size_t)B * 256); S.theta = carve((size_t)B * 6);
+        S.prevsel = carve((size_t)B * 3 * HW);
+    }
+    p->has_grads = train && cfg->model_type == PIVP_MODEL_CDNA;
+    if (p->has_grads) {
+        Grads& g = p->g;
+        g.cat7 = carve(B * HW2 * 64); g.n2 = carve(B * HW2 * 32); g.cat6 = carve(B * HW4 * 96); g.n4 = carve(B * HW4 * 64);
+        g.e2 = carve(B * HW8 * 64); g.n5 = carve(B * HW8 * 128); g.e6 = carve(B * HW * 64); g.e6raw = carve(B * HW * 64);
+        g.e0raw = carve(B * HW2 * 32);
+        size_t maxdG = 0, maxw = 0;
+        for (int i = 0; i < 7; ++i) {
+            const size_t M = hsz[i] / kLstm[i].C * B;
+            g.hln[i] = carve(B * hsz[i]); g.dc[i] = carve(B * hsz[i]);
+            g.din[i][0] = carve(M * (kLstm[i].cx + kLstm[i].C)); g.din[i][1] = carve(M * (kLstm[i].cx + kLstm[i].C));
+            if (M * 4 * kLstm[i].C > maxdG) maxdG = M * 4 * kLstm[i].C;
+            const size_t wn = (size_t)25 * (kLstm[i].cx + kLstm[i].C) * 4 * kLstm[i].C;
+            if (wn > maxw) maxw = wn;
+        }
+        g.dG = carve(maxdG); g.wt = carve(maxw);
+        g.go[0] = carve((size_t)B * 3 * HW); g.go[1] = carve((size_t)B * 3 * HW);
+        g.dmk = carve((size_t)B * p->NP * HW); g.dz = carve((size_t)B * 3 * HW);
+        g.dkpart = carve((size_t)B * composite_bwd_tiles(H) * 256); g.dv = carve((size_t)B * 256);
+        g.dstate = carve((size_t)T * B * 5);
+        g.lnpart = carve((size_t)B * ln_bwd_slices((int)(64 * HW)) * 2);
+    }
+    p->ws_floats = (long long)off;
+    *out = p;
+    return PIVP_OK;
+}
+
+extern "C" void pivp_plan_destroy(pivp_plan_t* plan) { delete plan; }
+extern "C" int pivp_param_count(const pivp_plan_t* plan) { return plan ? (int)plan->params.size() : PIVP_ERR_BADARG; }
+extern "C" const char* pivp_param_name(const pivp_plan_t* plan, int idx) {
+    if (!plan || idx < 0 || idx >= (int)plan->params.size()) return nullptr;
+    return plan->params[idx].name.c_str();
+}
+extern "C" long long pivp_param_numel(const pivp_plan_t* plan, int idx) {
+    if (!plan || idx < 0 || idx >= (int)plan->params.size()) return PIVP_ERR_BADARG;
+    return plan->params[idx].numel;
+}
+extern "C" int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr) {
+    if (!plan || idx < 0 || idx >= (int)plan->params.size() || !dptr) return PIVP_ERR_BADARG;
+    plan->params[idx].ptr = dptr;
+    return PIVP_OK;
+}
+extern "C" int pivp_plan_set_grad(pivp_plan_t* plan, int idx, float* dptr) {
+    if (!plan || idx < 0 || idx >= (int)plan->params.size() || !dptr) return PIVP_ERR_BADARG;
+    plan->params[idx].grad = dptr;
+    return PIVP_OK;
+}
+extern "C" long long pivp_plan_workspace_bytes(const pivp_plan_t* plan) { return plan ? plan->ws_floats * 4 : PIVP_ERR_BADARG; }
+extern "C" int pivp_plan_set_workspace(pivp_plan_t* plan, void* dptr, long long bytes) {
+    if (!plan || !dptr || bytes < plan->ws_floats * 4 || ((uintptr_t)dptr & 255)) return PIVP_ERR_BADARG;
+    plan->ws = (float*)dptr;
+    return PIVP_OK;
+}
+extern "C" int pivp_reset_state(pivp_plan_t* plan, void* stream) {
+    if (!plan || !plan->ws) return PIVP_ERR_STATE;
+    const size_t n = (size_t)plan->cfg.batch * plan->H2 * plan->W2 * 32;
+    if (hipMemsetAsync(plan->ws + plan->o_zero, 0, n * 4, (hipStream_t)stream) != hipSuccess) return PIVP_ERR_LAUNCH;
+    return PIVP_OK;
+}
+
+#define RC(call) do { int rc_ = (call); if (rc_ != PIVP_OK) return rc_; } while (0)
+
+// ------------------------------------------------------------------------------------------------------------
+// forward, one timestep (TM:659-731)
+// ------------------------------------------------------------------------------------------------------------
+static int run_step(pivp_plan* p, int t, const float* prev, const float* action, const float* state_prev,
+                    float* gen_out, float* state_out, hipStream_t s) {
+    const pivp_config_t& c = p->cfg;
+    const int B = c.batch, H = c.height, W = c.width;
+    float* ws = p->ws;
+    const Slab& S = p->slabs[t % p->nslabs];
+    const Slab* Sp = t > 0 ? &p->slabs[(t - 1) % p->nslabs] : nullptr;
+    float* lnp = ws + p->o_lnpart;
+    const float eps = c.ln_eps;
+    const bool train = c.keep_activations != 0;
+    auto hp = [&](int i) -> const float* { return Sp ? ws + Sp->h[i] : nullptr; };   // t = 0: h == 0, skipped
+    auto cp = [&](int i) { return Sp ? ws + Sp->c[i] : ws + p->o_zero; };
+    auto lstm = [&](int i, const float* x, int ldx, int hh, int wwid) {
+        const bool prof = p->prof_on && p->prof_used + 2 <= p->prof_ev.size();
+        if (prof) (void)hipEventRecord(p->prof_ev[p->prof_used], s);
+        int rc = run_convlstm(x, kLstm[i].cx, ldx, hp(i), kLstm[i].C, P(p, p->i_lstm_w[i]), P(p, p->i_lstm_b[i]),
+                              cp(i), ws + S.c[i], ws + S.h[i], B, hh, wwid, s, 0, train ? ws + S.gates[i] : nullptr);
+        if (prof) {
+            (void)hipEventRecord(p->prof_ev[p->prof_used + 1], s);
+            p->prof_layer[p->prof_used / 2] = i + (Sp ? 0 : 8);   // +8: first-step launch without the h half of K
+            p->prof_used += 2;
+        }
+        return rc;
+    };
+    auto ln = [&](int j, const float* x, float* out, int n, int C, int ldo, int relu) {
+        return run_layernorm(x, P(p, p->i_ln_g[j]), P(p, p->i_ln_b[j]), out, lnp, B, n, C, ldo, eps, relu, s,
+                             ws + S.lnstat + (size_t)j * B * 2);
+    };
+    const int n2 = 32 * p->H2 * p->W2, n4 = 64 * p->H4 * p->W4, n8 = 128 * p->H8 * p->W8;
+
+    // group 0 (TM:595): enc0 -> norm_enc0 -> relu   => cat7[:, 32:64]
+    RC(conv_enc0(prev, P(p, p->i_enc_w[0]), P(p, p->i_enc_b[0]), ws + S.e0raw, B, H, W, s));
+    RC(ln(0, ws + S.e0raw, ws + S.cat7 + 32, n2, 32, 64, 1));
+    // group 1 (TM:596): lstm1 -> hidden1 -> lstm2 -> hidden2 -> enc1 -> relu  => cat6[:, 64:96]
+    RC(lstm(0, ws + S.cat7 + 32, 64, p->H2, p->W2));
+    RC(ln(1, ws + S.h[0], ws + S.n1, n2, 32, 32, 0));
+    RC(lstm(1, ws + S.n1, 32, p->H2, p->W2));
+    RC(ln(2, ws + S.h[1], ws + S.n2, n2, 32, 32, 0));
+    RC(run_conv3x3s2(ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), P(p, p->i_enc_b[1]), ws + S.cat6 + 64, 32, 96, 1, B, p->H2, p->W2, s));
+    // group 2 (TM:597)
+    RC(lstm(2, ws + S.cat6 + 64, 96, p->H4, p->W4));
+    RC(ln(3, ws + S.h[2], ws + S.n3, n4, 64, 64, 0));
+    RC(lstm(3, ws + S.n3, 64, p->H4, p->W4));
+    RC(ln(4, ws + S.h[3], ws + S.n4, n4, 64, 64, 0));
+    RC(run_conv3x3s2(ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), P(p, p->i_enc_b[2]), ws + S.e2, 64, 64, 1, B, p->H4, p->W4, s));
+    // group 3 (TM:598) + state predictor (TM:730)
+    RC(enc3_state(ws + S.e2, action, state_prev, P(p, p->i_enc_w[3]), P(p, p->i_enc_b[3]), P(p, p->i_cs_w), P(p, p->i_cs_b),
+                  ws + S.e3, state_out, B, p->H8 * p->W8, c.use_state, s));
+    // group 4 (TM:599)
+    RC(lstm(4, ws + S.e3, 64, p->H8, p->W8));
+    RC(ln(5, ws + S.h[4], ws + S.n5, n8, 128, 128, 0));
+    RC(run_deconv3x3s2(ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), P(p, p->i_enc_b[4]), ws + S.e4, 128, 128, 1, B, p->H8, p->W8, s));
+    // group 5 (TM:600): lstm6 -> hidden6 -> concat(., enc1) -> enc5 -> relu
+    RC(lstm(5, ws + S.e4, 128, p->H4, p->W4));
+    RC(ln(6, ws + S.h[5], ws + S.cat6, n4, 64, 96, 0));
+    RC(run_deconv3x3s2(ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), P(p, p->i_enc_b[5]), ws + S.e5, 96, 96, 1, B, p->H4, p->W4, s));
+    // group 6 (TM:601): lstm7 -> hidden7 -> concat(., enc0) -> enc6 -> norm_enc6 -> relu
+    RC(lstm(6, ws + S.e5, 96, p->H2, p->W2));
+    RC(ln(7, ws + S.h[6], ws + S.cat7, n2, 32, 64, 0));
+    RC(run_deconv3x3s2(ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), P(p, p->i_enc_b[6]), ws + S.e6raw, 64, 64, 0, B, p->H2, p->W2, s));
+    RC(ln(8, ws + S.e6raw, ws + S.e6, 64 * H * W, 64, 64, 1));
+    // heads (TM:711-728)
+    RC(heads_1x1(ws + S.e6, P(p, p->i_masks_w), P(p, p->i_masks_b), P(p, p->i_enc7_w), P(p, p->i_enc7_b),
+                 ws + S.logits, ws + S.enc7, ws + S.layer0, B, H * W, p->NP, p->NE, c.model_type, s));
+    const float* aux = nullptr;
+    if (c.model_type == PIVP_MODEL_CDNA) {
+        RC(cdna_kernels(ws + S.n5, P(p, p->i_head_w), P(p, p->i_head_b), ws + p->o_linpart, ws + S.kerns, B, p->K5, c.num_masks, s,
+                        ws + S.vpre));
+        aux = ws + S.kerns;
+    } else if (c.model_type == PIVP_MODEL_STP) {
+        RC(stp_params(ws + S.n5, P(p, p->i_head_w), P(p, p->i_head_b), P(p, p->i_head2_w), P(p, p->i_head2_b),
+                      ws + p->o_linpart, ws + S.theta, B, p->K5, s));
+        aux = ws + S.theta;
+    } else {
+        aux = ws + S.enc7;
+    }
+    RC(composite(prev, ws + S.logits, ws + S.layer0, aux, gen_out, ws + p->o_masks, B, H, W, c.num_masks,
+                 c.model_type, c.stp_zero_border, s));
+    return PIVP_OK;
+}
+
+// the frame fed to step t (TM:663-673)
+static const float* step_input(pivp_plan* plan, int t, const float* images, const unsigned char* gt_select, const float* gen_images, size_t fr) {
+    const int ctx = plan->cfg.context_frames;
+    if (t < ctx) return images + t * fr;
+    if (!gt_select) return gen_images + (t - 1) * fr;
+    return plan->ws + plan->slabs[t % plan->nslabs].prevsel;
+}
+
+extern "C" int pivp_rollout_forward(pivp_plan_t* plan, const float* images, const float* actions, const float* states,
+                                    const unsigned char* gt_select, float* gen_images, float* gen_states, float* results,
+                                    void* stream) {
+    if (!plan || !images || !actions || !states || !gen_images || !gen_states || !results) return PIVP_ERR_BADARG;
+    if (!plan->ws) return PIVP_ERR_STATE;
+    for (const ParamInfo& pi : plan->params) if (!pi.ptr) return PIVP_ERR_STATE;
+    hipStream_t s = (hipStream_t)stream;
+    const pivp_config_t& c = plan->cfg;
+    const int B = c.batch, T = c.seq_len, ctx = c.context_frames;
+    const size_t fr = (size_t)B * 3 * c.height * c.width;
+    for (int t = 0; t < T - 1; ++t) {
+        if (t >= ctx && gt_select)                                     // TM:667-670
+            RC(run_select_frames(images + t * fr, gen_images + (t - 1) * fr, gt_select + (size_t)t * B,
+                                 plan->ws + plan->slabs[t % plan->nslabs].prevsel, B, (int)(fr / B), s));
+        const float* prev = step_input(plan, t, images, gt_select, gen_images, fr);
+        const float* st_prev = t == 0 ? states : gen_states + (size_t)(t - 1) * B * 5;   // TM:646, TM:730
+        RC(run_step(plan, t, prev, actions + (size_t)t * B * 5, st_prev, gen_images + t * fr, gen_states + (size_t)t * B * 5, s));
+    }
+    plan->last_steps = T - 1;
+    plan->last_sched = gt_select != nullptr;
+    // loss (TM:737-759): frames ctx..T-1 vs gen[ctx-1..T-2]
+    const int nf = T - ctx;
+    float* lp = plan->ws + plan->o_losspart;
+    for (int i = 0; i < nf; ++i)
+        RC(frame_sqerr_partials(images + (size_t)(ctx + i) * fr, gen_images + (size_t)(ctx - 1 + i) * fr,
+                                lp + (size_t)i * plan->loss_nparts, (int)fr, s));
+    RC(loss_finalize(lp, plan->loss_nparts, nf, (int)fr, states + (size_t)ctx * B * 5, gen_states + (size_t)(ctx - 1) * B * 5,
+                     B * 5, (float)(T - ctx), results, s));
+    return PIVP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward through time (what loss.backward() does inside Chainer's optimizer.update, TM:950).  CDNA only this round.
+// Gradients are ACCUMULATED into the buffers registered with pivp_plan_set_grad (same layouts as the parameters).
+// ------------------------------------------------------------------------------------------------------------
+static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_grad, const float* action, const float* state_prev,
+                         bool has_go, float* go, float* go_prev, bool last_step, hipStream_t s) {
+    const pivp_config_t& c = p->cfg;
+    const int B = c.batch, H = c.height, W = c.width, HW = H * W;
+    float* ws = p->ws;
+    const Slab& S = p->slabs[t];
+    const Slab* Sp = t > 0 ? &p->slabs[t - 1] : nullptr;
+    const Grads& g = p->g;
+    const int par = t & 1, npar = par ^ 1;
+    const int n2 = 32 * p->H2 * p->W2, n4 = 64 * p->H4 * p->W4, n8 = 128 * p->H8 * p->W8;
+    float* lnpart = ws + g.lnpart;
+    float* wt = ws + g.wt;
+    auto lnb = [&](int j, const float* dy, int lddy, const float* y, int ldy, const float* x, float* dx, int n, int C, int relu) {
+        return ln_backward(dy, lddy, y, ldy, x, ws + S.lnstat + (size_t)j * B * 2, P(p, p->i_ln_g[j]), lnpart, dx,
+                           G(p, p->i_ln_g[j]), G(p, p->i_ln_b[j]), B, n, C, relu, s);
+    };
+    auto lstmb = [&](int i, const float* x, int ldx, int hh, int wwid) {
+        const LstmSpec& L = kLstm[i];
+        const int cin = L.cx + L.C;
+        return run_convlstm_backward(x, L.cx, ldx, Sp ? ws + Sp->h[i] : nullptr, L.C, P(p, p->i_lstm_w[i]), ws + S.gates[i],
+                                     Sp ? ws + Sp->c[i] : ws + p->o_zero, ws + S.c[i], ws + g.hln[i], L.C,
+                                     last_step ? nullptr : ws + g.din[i][npar] + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
+                                     ws + g.dG, wt, ws + g.din[i][par], G(p, p->i_lstm_w[i]), G(p, p->i_lstm_b[i]), B, hh, wwid, s);
+    };
+    const long px2 = (long)B * p->H2 * p->W2, px4 = (long)B * p->H4 * p->W4, px8 = (long)B * p->H8 * p->W8;
+
+    // ---- heads (TM:711-728) ----
+    if (has_go) {
+        RC(composite_bwd_cdna(prev, ws + S.logits, ws + S.layer0, ws + S.kerns, go, ws + g.dmk, ws + g.dz, ws + g.dkpart,
+                              prev_has_grad ? go_prev : nullptr, 1, B, H, W, c.num_masks, s));
+        RC(mask_softmax_bwd(ws + S.logits, ws + g.dmk, B, HW, p->NP, s));
+        RC(heads_bwd(ws + S.e6, P(p, p->i_masks_w), P(p, p->i_enc7_w), ws + g.dmk, ws + g.dz, ws + g.e6, G(p, p->i_masks_w),
+                     G(p, p->i_masks_b), G(p, p->i_enc7_w), G(p, p->i_enc7_b), B, HW, p->NP, p->NE, s));
+        RC(cdna_kernels_bwd(ws + S.n5, P(p, p->i_head_w), ws + S.vpre, ws + g.dkpart, composite_bwd_tiles(H), ws + g.dv, ws + g.n5, 0,
+                            G(p, p->i_head_w), G(p, p->i_head_b), B, p->K5, c.num_masks, s));
+        // group 6 (TM:601), reversed: norm_enc6 (+relu) <- enc6 deconv <- [hidden7 | enc0]
+        RC(lnb(8, ws + g.e6, 64, ws + S.e6, 64, ws + S.e6raw, ws + g.e6raw, 64 * HW, 64, 1));
+        RC(run_conv_backward(1, ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), ws + g.e6raw, 64, 64, nullptr, 0, wt, ws + g.cat7, 64, 0,
+                             G(p, p->i_enc_w[6]), G(p, p->i_enc_b[6]), B, p->H2, p->W2, s));
+    } else {
+        // no gradient reaches this step's frame: only the recurrent paths are live
+        if (hipMemsetAsync(ws + g.cat7, 0, (size_t)px2 * 64 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
+        if (hipMemsetAsync(ws + g.n5, 0, (size_t)px8 * 128 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
+    }
+    RC(lnb(7, ws + g.cat7, 64, nullptr, 0, ws + S.h[6], ws + g.hln[6], n2, 32, 0));
+    RC(lstmb(6, ws + S.e5, 96, p->H2, p->W2));
+    // group 5 (TM:600): d e5 = x-part of lstm7's d_in (ReLU fused in enc5) <- enc5 deconv <- [hidden6 | enc1]
+    RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ws + S.e5, 96, wt, ws + g.cat6, 96, 0,
+                         G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s));
+    RC(lnb(6, ws + g.cat6, 96, nullptr, 0, ws + S.h[5], ws + g.hln[5], n4, 64, 0));
+    RC(lstmb(5, ws + S.e4, 128, p->H4, p->W4));
+    // group 4 (TM:599): d e4 = x-part of lstm6's d_in <- enc4 deconv <- hidden5 (also read by the CDNA kernel generator)
+    RC(run_conv_backward(1, ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), ws + g.din[5][par], 128, 192, ws + S.e4, 128, wt, ws + g.n5, 128, 1,
+                         G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s));
+    RC(lnb(5, ws + g.n5, 128, nullptr, 0, ws + S.h[4], ws + g.hln[4], n8, 128, 0));
+    RC(lstmb(4, ws + S.e3, 64, p->H8, p->W8));
+    // group 3 (TM:598) + state predictor (TM:730): d e3 = x-part of lstm5's d_in (ld 192)
+    RC(enc3_state_bwd(ws + S.e2, ws + S.e3, ws + g.din[4][par], 192, action, state_prev, P(p, p->i_enc_w[3]), P(p, p->i_cs_w),
+                      ws + g.dstate + (size_t)t * B * 5, ws + g.e2, G(p, p->i_enc_w[3]), G(p, p->i_enc_b[3]), G(p, p->i_cs_w),
+                      G(p, p->i_cs_b), t > 0 ? ws + g.dstate + (size_t)(t - 1) * B * 5 : ws + g.dstate + (size_t)(c.seq_len - 1) * B * 5,
+                      B, p->H8 * p->W8, c.use_state, s));
+    // group 2 (TM:597): enc2 conv (ReLU) <- hidden4 <- lstm4 <- hidden3 <- lstm3 <- enc1
+    RC(run_conv_backward(0, ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), ws + g.e2, 64, 64, ws + S.e2, 64, wt, ws + g.n4, 64, 0,
+                         G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s));
+    RC(lnb(4, ws + g.n4, 64, nullptr, 0, ws + S.h[3], ws + g.hln[3], n4, 64, 0));
+    RC(lstmb(3, ws + S.n3, 64, p->H4, p->W4));
+    RC(lnb(3, ws + g.din[3][par], 128, nullptr, 0, ws + S.h[2], ws + g.hln[2], n4, 64, 0));
+    RC(lstmb(2, ws + S.cat6 + 64, 96, p->H4, p->W4));
+    RC(add_strided(ws + g.cat6 + 64, 96, ws + g.din[2][par], 96, 32, px4, s));          // d enc1: from enc5's concat + from lstm3
+    // group 1 (TM:596): enc1 conv (ReLU) <- hidden2 <- lstm2 <- hidden1 <- lstm1 <- enc0
+    RC(run_conv_backward(0, ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), ws + g.cat6 + 64, 32, 96, ws + S.cat6 + 64, 96, wt, ws + g.n2, 32, 0,
+                         G(p, p->i_enc_w[1]), G(p, p->i_enc_b[1]), B, p->H2, p->W2, s));
+    RC(lnb(2, ws + g.n2, 32, nullptr, 0, ws + S.h[1], ws + g.hln[1], n2, 32, 0));
+    RC(lstmb(1, ws + S.n1, 32, p->H2, p->W2));
+    RC(lnb(1, ws + g.din[1][par], 64, nullptr, 0, ws + S.h[0], ws + g.hln[0], n2, 32, 0));
+    RC(lstmb(0, ws + S.cat7 + 32, 64, p->H2, p->W2));
+    RC(add_strided(ws + g.cat7 + 32, 64, ws + g.din[0][par], 64, 32, px2, s));          // d enc0: from enc6's concat + from lstm1
+    // group 0 (TM:595): norm_enc0 (+relu) <- enc0 conv <- frame
+    RC(lnb(0, ws + g.cat7 + 32, 64, ws + S.cat7 + 32, 64, ws + S.e0raw, ws + g.e0raw, n2, 32, 1));
+    RC(enc0_bwd(prev, P(p, p->i_enc_w[0]), ws + g.e0raw, G(p, p->i_enc_w[0]), G(p, p->i_enc_b[0]), prev_has_grad ? go_prev : nullptr, 1,
+                B, H, W, s));
+    return PIVP_OK;
+}
+
+extern "C" int pivp_rollout_backward(pivp_plan_t* plan, const float* images, const float* actions, const float* states,
+                                     const unsigned char* gt_select, const float* gen_images, const float* gen_states, void* stream) {
+    if (!plan || !images || !actions || !states || !gen_images || !gen_states) return PIVP_ERR_BADARG;
+    if (!plan->ws || !plan->has_grads || plan->last_steps != plan->cfg.seq_len - 1) return PIVP_ERR_STATE;
+    if ((gt_select != nullptr) != plan->last_sched) return PIVP_ERR_STATE;
+    for (const ParamInfo& pi : plan->params) if (!pi.ptr || !pi.grad) return PIVP_ERR_STATE;
+    hipStream_t s = (hipStream_t)stream;
+    const pivp_config_t& c = plan->cfg;
+    const int B = c.batch, T = c.seq_len, ctx = c.context_frames;
+    const size_t fr = (size_t)B * 3 * c.height * c.width;
+    float* ws = plan->ws;
+    const Grads& g = plan->g;
+    const float fscale = 2.0f / ((float)fr * (float)(T - ctx));              // d/d gen of mean-squared error / (T - ctx)
+    const float sscale = 2.0f * 1e-4f / ((float)(B * 5) * (float)(T - ctx));
+    // d loss / d gen_states[t] for every t (zero before ctx-1), later accumulated with the state recurrence
+    if (hipMemsetAsync(ws + g.dstate, 0, (size_t)T * B * 5 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
+    for (int t = ctx - 1; t < T - 1; ++t)
+        RC(scaled_diff(gen_states + (size_t)t * B * 5, states + (size_t)(t + 1) * B * 5, ws + g.dstate + (size_t)t * B * 5, (long)B * 5, sscale, 0, s));
+    bool has_go = false;
+    for (int t = T - 2; t >= 0; --t) {
+        float* go = ws + g.go[t & 1];
+        float* go_prev = ws + g.go[(t & 1) ^ 1];
+        const bool last = t == T - 2;
+        if (last) {   // d gen[T-2] comes from the loss only
+            RC(scaled_diff(gen_images + (size_t)t * fr, images + (size_t)(t + 1) * fr, go, (long)fr, fscale, 0, s));
+            has_go = true;
+        }
+        const bool prev_has_grad = (t >= ctx) && !gt_select;                // feed-self: prev = gen[t-1] is differentiable (TM:664-666)
+        // prepare d gen[t-1] = loss term (if any); this step's composite / enc0 backward add the feed-back term
+        const bool next_loss = (t - 1) >= ctx - 1 && t >= 1;
+        if (next_loss) RC(scaled_diff(gen_images + (size_t)(t - 1) * fr, images + (size_t)t * fr, go_prev, (long)fr, fscale, 0, s));
+        else if (prev_has_grad) { if (hipMemsetAsync(go_prev, 0, fr * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH; }
+        const float* prev = step_input(plan, t, images, gt_select, gen_images, fr);
+        const float* st_prev = t == 0 ? states : gen_states + (size_t)(t - 1) * B * 5;
+        RC(backward_step(plan, t, prev, prev_has_grad && has_go, actions + (size_t)t * B * 5, st_prev, has_go, go, go_prev, last, s));
+        has_go = next_loss || (prev_has_grad && has_go);
+    }
+    return PIVP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// measurement hooks and taps
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int pivp_plan_set_profiling(pivp_plan_t* plan, int enable) {
+    if (!plan) return PIVP_ERR_BADARG;
+    if (enable && plan->prof_ev.empty()) {
+        const size_t n = (size_t)2 * 7 * (plan->cfg.seq_len - 1);
+        plan->prof_ev.resize(n);
+        plan->prof_layer.assign(n / 2, 0);
+        for (size_t i = 0; i < n; ++i)
+            if (hipEventCreate(&plan->prof_ev[i]) != hipSuccess) { plan->prof_ev.resize(i); return PIVP_ERR_LAUNCH; }
+    }
+    plan->prof_on = enable != 0;
+    plan->prof_used = 0;
+    return PIVP_OK;
+}
+
+extern "C" int pivp_plan_profile_read(pivp_plan_t* plan, double* ms_per_layer, int* launches_per_layer, double* flops_per_layer) {
+    if (!plan || !ms_per_layer || !launches_per_layer || !flops_per_layer) return PIVP_ERR_BADARG;
+    const pivp_config_t& c = plan->cfg;
+    double fl_full[7], fl_first[7];
+    for (int i = 0; i < 7; ++i) {
+        ms_per_layer[i] = 0.0; launches_per_layer[i] = 0; flops_per_layer[i] = 0.0;
+        const int lv = kLstm[i].level;
+        const double M = (double)c.batch * (c.height / lv) * (c.width / lv);
+        fl_full[i] = 2.0 * M * 4.0 * kLstm[i].C * 25.0 * (kLstm[i].cx + kLstm[i].C);
+        fl_first[i] = 2.0 * M * 4.0 * kLstm[i].C * 25.0 * kLstm[i].cx;     // executed flops when h == 0 is skipped
+    }
+    for (size_t k = 0; k + 1 < plan->prof_used; k += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, plan->prof_ev[k], plan->prof_ev[k + 1]) != hipSuccess) return PIVP_ERR_STATE;
+        const int tag = plan->prof_layer[k / 2];
+        const int L = tag & 7;
+        ms_per_layer[L] += ms; launches_per_layer[L] += 1;
+        flops_per_layer[L] += (tag & 8) ? fl_first[L] : fl_full[L];   // SUM of executed flops over the launches
+    }
+    plan->prof_used = 0;
+    return PIVP_OK;
+}
+
+extern "C" long long pivp_get_tap(pivp_plan_t* plan, const char* name, int step, float* out, void* stream) {
+    if (!plan || !name || !out || !plan->ws) return PIVP_ERR_BADARG;
+    if (step < 0 || step >= plan->last_steps) return PIVP_ERR_BADARG;
+    if (!plan->cfg.keep_activations && step < plan->last_steps - 2) return PIVP_ERR_STATE;
+    hipStream_t s = (hipStream_t)stream;
+    const pivp_config_t& c = plan->cfg;
+    const int B = c.batch;
+    const Slab& S = plan->slabs[step % plan->nslabs];
+    float* ws = plan->ws;
+    const int HW = c.height * c.width, HW2 = plan->H2 * plan->W2, HW4 = plan->H4 * plan->W4, HW8 = plan->H8 * plan->W8;
+    struct T { const char* n; size_t off; int C, hw, ld; };
+    const T taps[] = {
+        {"enc0", S.cat7 + 32, 32, HW2, 64}, {"enc1", S.cat6 + 64, 32, HW4, 96}, {"enc2", S.e2, 64, HW8, 64},
+        {"enc3", S.e3, 64, HW8, 64}, {"enc4", S.e4, 128, HW4, 128}, {"enc5", S.e5, 96, HW2, 96}, {"enc6", S.e6, 64, HW, 64},
+        {"hidden1", S.n1, 32, HW2, 32}, {"hidden2", S.n2, 32, HW2, 32}, {"hidden3", S.n3, 64, HW4, 64},
+        {"hidden4", S.n4, 64, HW4, 64}, {"hidden5", S.n5, 128, HW8, 128}, {"hidden6", S.cat6, 64, HW4, 96},
+        {"hidden7", S.cat7, 32, HW2, 64},
+        {"lstm1_h", S.h[0], 32, HW2, 32}, {"lstm2_h", S.h[1], 32, HW2, 32}, {"lstm3_h", S.h[2], 64, HW4, 64},
+        {"lstm4_h", S.h[3], 64, HW4, 64}, {"lstm5_h", S.h[4], 128, HW8, 128}, {"lstm6_h", S.h[5], 64, HW4, 64},
+        {"lstm7_h", S.h[6], 32, HW2, 32},
+        {"lstm1_c", S.c[0], 32, HW2, 32}, {"lstm2_c", S.c[1], 32, HW2, 32}, {"lstm3_c", S.c[2], 64, HW4, 64},
+        {"lstm4_c", S.c[3], 64, HW4, 64}, {"lstm5_c", S.c[4], 128, HW8, 128}, {"lstm6_c", S.c[5], 64, HW4, 64},
+        {"lstm7_c", S.c[6], 32, HW2, 32}};
+    for (const T& t : taps) {
+        if (strcmp(t.n, name) == 0) {
+            int rc = nhwc_to_nchw(ws + t.off, out, B, t.C, t.hw, t.ld, s);
+            return rc == PIVP_OK ? (long long)B * t.C * t.hw : rc;
+        }
+    }
+    size_t off = 0, n = 0;
+    if (strcmp(name, "enc7") == 0) { off = S.enc7; n = (size_t)B * plan->NE * HW; }
+    else if (strcmp(name, "cdna_kerns") == 0 && c.model_type == PIVP_MODEL_CDNA) { off = S.kerns; n = (size_t)B * 25 * c.num_masks; }
+    else if (strcmp(name, "stp_theta") == 0 && c.model_type == PIVP_MODEL_STP) { off = S.theta; n = (size_t)B * 6; }
+    else if (strcmp(name, "masks") == 0) {
+        if (step != plan->last_steps - 1) return PIVP_ERR_STATE;      // softmaxed masks exist only for the most recent step
+        off = plan->o_masks; n = (size_t)B * plan->NP * HW;
+    } else return PIVP_ERR_BADARG;
+    if (hipMemcpyAsync(out, ws + off, n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return PIVP_ERR_LAUNCH;
+    return (long long)n;
+}

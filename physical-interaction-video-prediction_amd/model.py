@@ -158,7 +158,12 @@ class Model(object):
         self.stp_border = stp_border
         self.keep_activations = bool(keep_activations)
         self._ref_pending = None       # reference-layout arrays loaded before the first call
-        self._params = None            # name -> flat device tensor, internal layout
+        self._params = None            # name -> view into _flat_params (internal layout)
+        self._flat_params = None
+        self._flat_grads = None
+        self._grads = None
+        self._offsets = None
+        self._gt_mask = None
         self._hw = None
         self._plans = {}
         self._active = None
@@ -192,17 +197,42 @@ class Model(object):
         self._upload(ref, shapes)
 
     def _upload(self, ref, shapes):
-        params = OrderedDict()
+        """Parameters live in ONE flat device buffer (internal layouts, 256-B aligned slices): Adam is a single
+        launch over it and the data-parallel gradient all-reduce a single collective on its twin `_flat_grads`."""
+        host = OrderedDict()
         for key, shape in shapes.items():
             if key not in ref:
                 raise KeyError('checkpoint is missing %r' % key)
             a = np.asarray(ref[key])
             if tuple(a.shape) != tuple(shape):
                 raise ValueError('%s: expected shape %s, got %s' % (key, shape, a.shape))
-            params[key] = torch.from_numpy(ckpt.to_internal(key, a)).to(self.device)
-        self._params = params
+            host[key] = ckpt.to_internal(key, a)
+        offsets, off = OrderedDict(), 0
+        for key, v in host.items():
+            offsets[key] = (off, v.size)
+            off += (v.size + 63) // 64 * 64
+        flat = np.zeros(off, np.float32)
+        for key, v in host.items():
+            o, n = offsets[key]
+            flat[o:o + n] = v
+        new_flat = torch.from_numpy(flat).to(self.device)
+        if self._flat_params is not None and self._flat_params.numel() == new_flat.numel():
+            self._flat_params.copy_(new_flat)          # keep addresses stable for plans and optimizers
+        else:
+            self._flat_params = new_flat
+            self._flat_grads = None
+        self._offsets = offsets
+        self._params = OrderedDict((k, self._flat_params[o:o + n]) for k, (o, n) in offsets.items())
         for plan in self._plans.values():
             self._bind(plan)
+
+    def _ensure_grads(self):
+        if self._flat_grads is None:
+            self._flat_grads = torch.zeros_like(self._flat_params)
+            self._grads = OrderedDict((k, self._flat_grads[o:o + n]) for k, (o, n) in self._offsets.items())
+            for plan in self._plans.values():
+                self._bind(plan)
+        return self._flat_grads
 
     def load_state_dict_reference(self, ref):
         """Load arrays in the reference's Chainer-npz layout (chainer.serializers.load_npz target)."""
@@ -235,6 +265,8 @@ class Model(object):
             if t.numel() != n:
                 raise ValueError('%s: internal size %d != library size %d' % (name, t.numel(), n))
             _lib.check(lib.pivp_plan_set_param(plan.h, i, t.data_ptr()), 'pivp_plan_set_param(%s)' % name)
+            if self._grads is not None:
+                _lib.check(lib.pivp_plan_set_grad(plan.h, i, self._grads[name].data_ptr()), 'pivp_plan_set_grad(%s)' % name)
 
     def _plan_for(self, B, T, H, W):
         key = (B, T, H, W, self.keep_activations)
@@ -311,6 +343,7 @@ class Model(object):
             ctx = self.num_frame_before_prediction
             # feed-self when not training or k == -1 (TM:649-657)
             gt_ptr = None
+            self._gt_mask = None
             if config.train and self.scheduled_sampling_k != -1:
                 mask = scheduled_sampling_masks(B, T, ctx, self.scheduled_sampling_k, iter_num)
                 self._gt_mask = torch.from_numpy(mask).to(self.device)
@@ -324,6 +357,7 @@ class Model(object):
                                                      self._stream()), 'pivp_rollout_forward')
             self._inputs = (images, actions, states)   # keep alive until the stream has consumed them
             self._gen = gen
+            self._gen_states = gen_states
             self._results = results
             self._nf = nf
             self.gen_images = [gen[t] for t in range(T - 1)]
@@ -331,6 +365,38 @@ class Model(object):
             self.loss = results[0]
             self.psnr_all = results[1]
         return self.loss
+
+    # ---- training surface (Chainer: model.cleargrads(); loss.backward(); TM:950 via optimizer.update) -------
+    def cleargrads(self):
+        if self._flat_params is None:
+            raise RuntimeError('call the model first (parameters are lazily sized)')
+        self._ensure_grads().zero_()
+
+    def backward(self):
+        """Back-propagate the loss of the LAST call through time (needs keep_activations=True).  Gradients
+        accumulate into `model._flat_grads` (internal layouts); `grads_reference()` returns them in checkpoint layout."""
+        plan = self._active
+        if plan is None or self._results is None:
+            raise RuntimeError('call the model first')
+        if not self.keep_activations:
+            raise RuntimeError('backward() needs Model(..., keep_activations=True)')
+        if self.model_type != 'CDNA':
+            raise NotImplementedError('backward is implemented for the CDNA variant only')
+        self._ensure_grads()
+        images, actions, states = self._inputs
+        gt_ptr = self._gt_mask.data_ptr() if self._gt_mask is not None else None
+        _lib.check(plan.lib.pivp_rollout_backward(plan.h, images.data_ptr(), actions.data_ptr(), states.data_ptr(), gt_ptr,
+                                                  self._gen.data_ptr(), self._gen_states.data_ptr(), self._stream()),
+                   'pivp_rollout_backward')
+
+    def grads_reference(self):
+        """Gradients in the reference's Chainer-npz layout (same permutations as the parameters)."""
+        if self._grads is None:
+            raise RuntimeError('no gradients: call cleargrads()/backward() first')
+        out = OrderedDict()
+        for key, shape in self._shapes().items():
+            out[key] = ckpt.from_internal(key, self._grads[key].cpu().numpy(), shape)
+        return out
 
     @property
     def summaries(self):
