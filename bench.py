@@ -38,6 +38,9 @@ def main():
     ap.add_argument('--seq-len', type=int, default=10)
     ap.add_argument('--size', type=int, default=64)
     ap.add_argument('--model', default='CDNA', choices=['CDNA', 'STP', 'DNA'])
+    ap.add_argument('--mode', default='rollout', choices=['rollout', 'train'],
+                    help='rollout: Model.__call__ forward (predict_model.py:126-128); train: optimizer.update = forward + '
+                         'BPTT backward + gradient all-reduce + Adam (train_model.py:950)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
@@ -65,15 +68,27 @@ def main():
     B, T, S = args.batch, args.seq_len, args.size
     nm = 1 if args.model == 'DNA' else 10
     np.random.seed(1234 + rank)
+    train = args.mode == 'train'
     model = pivp_amd.Model(nm, is_cdna=args.model == 'CDNA', is_stp=args.model == 'STP', is_dna=args.model == 'DNA',
-                           prefix='bench', device=dev)
+                           prefix='bench', device=dev, keep_activations=train)
     rs = np.random.RandomState(rank)
     images = torch.from_numpy(rs.random_sample((T, B, 3, S, S)).astype(np.float32)).to(dev)
     actions = torch.from_numpy((0.1 * rs.standard_normal((T, B, 5))).astype(np.float32)).to(dev)
     states = torch.from_numpy((0.1 * rs.standard_normal((T, B, 5))).astype(np.float32)).to(dev)
 
+    opt = None
+    if train:
+        dp = pivp_amd.GradAllReduce() if world > 1 else None
+        opt = pivp_amd.Adam(alpha=0.001).setup(model, data_parallel=dp)   # TM:860-861
+        if world > 1:                                                        # identical replicas: broadcast rank 0's init
+            with pivp_amd.using_config('train', False):
+                model([images, actions, states], 0)
+            dist.broadcast(model._flat_params, src=0)
+
     def step():
         model.reset_state()
+        if train:
+            return opt.update(model, [images, actions, states], 0)          # schedsamp_k = -1: feed-self, deterministic
         return model([images, actions, states], 0)
 
     def barrier():
@@ -145,10 +160,25 @@ def main():
                 tm([ci, ca, cs], 0); tm.reset_state()
                 reps += 1
             cel = time.perf_counter() - c0
+        if train:      # same bounded sample, but forward + autograd backward + Chainer-rule Adam
+            from oracle.torch_restatement import chainer_adam_step
+            tmt = TorchModel(nm, is_cdna=True, params=P, dtype=torch.float32, requires_grad=True)
+            Pm = {k: v.detach().numpy() for k, v in tmt.p.items()}
+            Mm = {k: np.zeros_like(v) for k, v in Pm.items()}; Vm = {k: np.zeros_like(v) for k, v in Pm.items()}
+            reps, c0 = 0, time.perf_counter()
+            while time.perf_counter() - c0 < args.cpu_seconds:
+                for v in tmt.p.values():
+                    v.grad = None
+                l = tmt([ci, ca, cs], 0); l.backward(); tmt.reset_state()
+                with torch.no_grad():
+                    chainer_adam_step(Pm, {k: v.grad.numpy() for k, v in tmt.p.items()}, Mm, Vm, reps + 1)
+                reps += 1
+            cel = time.perf_counter() - c0
         cpu_baseline = {'value': round(cb * (ct - 1) * reps / cel, 2), 'unit': 'predicted frames/s',
                         'cores': torch.get_num_threads(), 'kind': 'port',
-                        'sample': '%d rollouts of B=%d T=%d %dx%d %s, fp32 PyTorch-CPU restatement of the reference path '
-                                  '(oracle/torch_restatement.py), %.1f s' % (reps, cb, ct, S, S, args.model, cel)}
+                        'sample': '%d %s of B=%d T=%d %dx%d %s, fp32 PyTorch-CPU restatement of the reference path '
+                                  '(oracle/torch_restatement.py), %.1f s' % (reps, 'train steps (fwd+bwd+Adam)' if train else 'rollouts',
+                                                                              cb, ct, S, S, args.model, cel)}
 
     if rank == 0:
         frames = world * B * (T - 1) * args.steps
@@ -165,9 +195,12 @@ def main():
             'vs_baseline': None,
             'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': '%s rollout forward (Model.__call__, feed-self), batch %d/GPU, %d-frame %dx%dx3 sequences, '
-                                   'action-conditioned, num_masks=%d, random-init weights' % (args.model, B, T, S, S, nm),
-                       'global_batch': world * B, 'frames_per_step': world * B * (T - 1), 'parallelism': 'replicas x%d' % world,
+            'config': {'workload': '%s %s, batch %d/GPU, %d-frame %dx%dx3 sequences, action-conditioned, num_masks=%d, '
+                                   'random-init weights' % (args.model, 'train step (optimizer.update: forward + BPTT backward + grad '
+                                   'all-reduce + Adam, schedsamp_k=-1)' if train else 'rollout forward (Model.__call__, feed-self)',
+                                   B, T, S, S, nm),
+                       'global_batch': world * B, 'frames_per_step': world * B * (T - 1),
+                       'parallelism': ('dp%d (RCCL all-reduce of the flat gradient)' if train else 'replicas x%d') % world,
                        'loss': loss_val},
             'roofline': roofline,
             'cpu_baseline': cpu_baseline,

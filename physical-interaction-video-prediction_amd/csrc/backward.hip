@@ -51,27 +51,29 @@ int lstm_gates_bwd(const float* gates, const float* c_old, const float* c_new, c
 // db[n] += sum over pixels of dY[pix][n]   (bias gradient of every conv / deconv / 1x1)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, int ld, int N, int M, float* __restrict__ db) {
-    __shared__ float part[8][33];
-    const int col0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int rows_per = (M + gridDim.y - 1) / gridDim.y;
-    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
-    float acc = 0.f;
-    if (col0 + tx < N)
-        for (int r = r0 + ty; r < r1; r += 8) acc += dy[(size_t)r * ld + col0 + tx];
-    part[ty][tx] = acc;
+    // block = 128 columns (32 float4 lanes) x 8 row-lanes; rows strided over gridDim.y
+    __shared__ f32x4 part[8][33];
+    const int c4 = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int col = blockIdx.x * 128 + c4 * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (col < N)
+        for (int r = blockIdx.y * 8 + ty; r < M; r += gridDim.y * 8) acc += *reinterpret_cast<const f32x4*>(dy + (size_t)r * ld + col);
+    part[ty][c4] = acc;
     __syncthreads();
-    if (ty == 0 && col0 + tx < N) {
-        float t = 0.f;
+    if (ty == 0 && col < N) {
+        f32x4 t = part[0][c4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t += part[i][tx];
-        atomicAdd(db + col0 + tx, t);
+        for (int i = 1; i < 8; ++i) t += part[i][c4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (col + e < N) atomicAdd(db + col + e, t[e]);
     }
 }
 
 int bias_grad(const float* dy, int ld, int N, int M, float* db, hipStream_t s) {
-    PIVP_CHECK_ARG(dy && db && N > 0 && M > 0 && ld >= N);
-    int ysplit = M / 512; if (ysplit < 1) ysplit = 1; if (ysplit > 64) ysplit = 64;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3((N + 31) / 32, ysplit), dim3(256), 0, s, dy, ld, N, M, db);
+    PIVP_CHECK_ARG(dy && db && N > 0 && M > 0 && ld >= N && N % 4 == 0 && ld % 4 == 0);
+    const int xb = (N + 127) / 128;
+    int yb = (M + 511) / 512; if (yb > 64) yb = 64; if (yb < 1) yb = 1;   // few row-groups: their sums meet in atomics on N addresses
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(xb, yb), dim3(256), 0, s, dy, ld, N, M, db);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -175,11 +177,12 @@ __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restr
                                                             const float* __restrict__ x, const float* __restrict__ stat,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int B, int n, int C, int relu) {
+    // thread = 4 consecutive elements x one group of samples (blockIdx.y); groups combine with atomics
     const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= n) return;
     const int pix = e / C, ch = e - pix * C;
     f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < B; ++b) {
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
         const size_t pb = (size_t)b * (n / C) + pix;
         f32x4 g = *reinterpret_cast<const f32x4*>(dy + pb * lddy + ch);
         if (relu) {
@@ -192,9 +195,8 @@ __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < 4; ++k) { ag[k] = fmaf(g[k], (xv[k] - mean) * rstd, ag[k]); ab[k] += g[k]; }
     }
-    f32x4 og = *reinterpret_cast<f32x4*>(dgamma + e), ob = *reinterpret_cast<f32x4*>(dbeta + e);
-    *reinterpret_cast<f32x4*>(dgamma + e) = og + ag;
-    *reinterpret_cast<f32x4*>(dbeta + e) = ob + ab;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { atomicAdd(dgamma + e + k, ag[k]); atomicAdd(dbeta + e + k, ab[k]); }
 }
 
 int ln_bwd_slices(int n) { return (n + LNB_SLICE - 1) / LNB_SLICE; }
@@ -206,7 +208,11 @@ int ln_backward(const float* dy, int lddy, const float* y, int ldy, const float*
     const int S = ln_bwd_slices(n);
     hipLaunchKernelGGL(ln_bwd_stats_kernel, dim3(S, B), dim3(256), 0, s, dy, lddy, y, ldy, x, stat, gamma, partials, n, C, relu);
     hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3(S, B), dim3(256), 0, s, dy, lddy, y, ldy, x, stat, gamma, partials, dx, n, C, relu);
-    hipLaunchKernelGGL(ln_bwd_params_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, s, dy, lddy, y, ldy, x, stat, dgamma, dbeta, B, n, C, relu);
+    {
+        const int xb = (n / 4 + 255) / 256;
+        int yb = 512 / xb; if (yb < 1) yb = 1; if (yb > B) yb = B; if (yb > 8) yb = 8;
+        hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(xb, yb), dim3(256), 0, s, dy, lddy, y, ldy, x, stat, dgamma, dbeta, B, n, C, relu);
+    }
     return PIVP_LAUNCH_STATUS();
 }
 

@@ -78,8 +78,13 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
     const int py = phase >> 1, px = phase & 1;
     // tap set: conv K x K (rows ky, cols kx) or, for the transposed 3x3 s2 conv, the taps of output parity
     // (py, px): oy = 2*iy - 1 + ky  =>  ky = 1 (py = 0) or ky in {0, 2} (py = 1), iy = a + (py + 1 - ky)/2.
-    const int nty = d.deconv ? 1 + py : d.ksize;
+    const int nty_all = d.deconv ? 1 + py : d.ksize;
     const int ntx = d.deconv ? 1 + px : d.ksize;
+    // optional split of K over blockIdx.z by kernel rows (data gradients of small-M layers); partial sums are atomically
+    // added into a pre-zeroed output
+    const int ksplit = gridDim.z;
+    const int ty_begin = (nty_all * (int)blockIdx.z) / ksplit, ty_end = (nty_all * ((int)blockIdx.z + 1)) / ksplit;
+    const int nty = ty_end - ty_begin;
     const int nchunks = nty * ntx * ncc;
     const int HWg = d.Hg * d.Wg;
 
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
     f32x4 rb[NB];
 
     // scalar state of the NEXT chunk to load: channel chunk l_cc of tap (l_ty, l_tx); no division, no branch
-    int l_cc = 0, l_ty = 0, l_tx = 0;
+    int l_cc = 0, l_ty = ty_begin, l_tx = 0;
     int s_dy = 0, s_dx = 0, s_delta = 0, s_ld = 0, s_wbase = 0;
     bool s_first = true;
     auto stage_begin = [&]() {            // scalar prelude of one chunk's loads, then advance the counters
@@ -231,6 +236,7 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
     };
 
     // prologue: chunk 0 straight into buffer 0
+    if (nchunks > 0) {
     stage_begin();
     load_piece(std::integral_constant<int, 0>{}); load_piece(std::integral_constant<int, 1>{});
     load_piece(std::integral_constant<int, 2>{}); load_piece(std::integral_constant<int, 3>{});
@@ -252,6 +258,7 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
         if (ABL != 3) __syncthreads();
     }
     chunk(std::false_type{}, (nchunks - 1) & 1);
+    }
 
     // ---- epilogue --------------------------------------------------------------------------
     if (LSTM) {
@@ -296,10 +303,14 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) {
                     const int col = nblk * BN + (wn * TPW + t) * 32 + l31;
-                    float v = acc[t][r] + (d.bias ? d.bias[col] : 0.f);
-                    if (d.relu) v = fmaxf(v, 0.f);
-                    if (d.accum) v += d.out[o + col];
-                    d.out[o + col] = v;
+                    if (ksplit > 1) {
+                        if (nchunks > 0) atomicAdd(d.out + o + col, acc[t][r]);
+                    } else {
+                        float v = acc[t][r] + (d.bias ? d.bias[col] : 0.f);
+                        if (d.relu) v = fmaxf(v, 0.f);
+                        if (d.accum) v += d.out[o + col];
+                        d.out[o + col] = v;
+                    }
                 }
             }
         }
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
 }
 
 template <int WM, int WN, int NTB, bool LSTM, int ABL = 0>
-static int launch_igemm(const IgemmDesc& d, hipStream_t stream) {
+static int launch_igemm(const IgemmDesc& d, hipStream_t stream, int ksplit = 1) {
     constexpr int BM = 32 * WM, BN = 32 * NTB;
     const int n_nblk = LSTM ? (d.C >> 5) : (d.N / BN);
     const int mblk = (d.M + BM - 1) / BM;
@@ -318,7 +329,7 @@ static int launch_igemm(const IgemmDesc& d, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
-    dim3 grid(mblk * n_nblk, d.nphase);
+    dim3 grid(mblk * n_nblk, d.nphase, ksplit);
     hipLaunchKernelGGL((igemm_f32_kernel<WM, WN, NTB, LSTM, ABL>), grid, dim3(256), lds_bytes, stream, d);
     return PIVP_LAUNCH_STATUS();
 }
@@ -377,7 +388,22 @@ int igemm_conv(const IgemmDesc& d, hipStream_t stream) {
     if (rc != PIVP_OK) return rc;
     const int nt = d.N / 32;
     const long full = (long)((d.M + 127) / 128) * d.nphase;   // blocks with BM = 128 and the whole N in one block
-    if (nt > 4) {                                             // wide outputs (data gradients): several column blocks
+    if (d.ksplit_ok && !d.deconv && !d.bias && !d.relu && !d.accum && (nt > 4 || full * (nt > 2 ? 1 : 1) < 256)) {
+        // data gradients: BN = 64 column blocks on BM = 64 tiles, K split over kernel rows until the chip is full;
+        // the output must have been zeroed by the caller (partials are added atomically)
+        if (nt % 2 == 0) {
+            const long blocks = (long)((d.M + 63) / 64) * (nt / 2);
+            int ks = blocks >= 256 ? 1 : (int)((256 + blocks - 1) / blocks);
+            if (ks > d.ksize) ks = d.ksize;
+            return launch_igemm<2, 2, 2, false>(d, stream, ks);
+        } else {
+            const long blocks = full * nt;
+            int ks = blocks >= 256 ? 1 : (int)((256 + blocks - 1) / blocks);
+            if (ks > d.ksize) ks = d.ksize;
+            return launch_igemm<4, 1, 1, false>(d, stream, ks);
+        }
+    }
+    if (nt > 4) {                                             // wide outputs: several column blocks
         if (nt % 4 == 0) return full * (nt / 4) >= 256 ? launch_igemm<4, 1, 4, false>(d, stream) : launch_igemm<2, 2, 4, false>(d, stream);
         if (nt % 3 == 0) return launch_igemm<4, 1, 3, false>(d, stream);
         if (nt % 2 == 0) return full * (nt / 2) >= 256 ? launch_igemm<4, 1, 2, false>(d, stream) : launch_igemm<2, 2, 2, false>(d, stream);

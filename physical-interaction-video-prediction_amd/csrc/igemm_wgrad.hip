@@ -136,11 +136,189 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fast path for the ConvLSTM weight gradient (5x5, stride 1, pad 2): 93 % of all wgrad flops.
+//   * one WAVE = one worker on 32-pixel chunks (32 consecutive pixels of image rows): it stages, for kernel row ky,
+//     an X strip with a 2-pixel x-halo ([R rows][SW+4][32 ci]) and the dY tile ([32 pixels][32*NTW n]) into its own
+//     double-buffered LDS region, then runs the 5 taps kx = 0..4 of that kernel row against the SAME dY fragments:
+//     16 k-steps x 5 taps x NTW tiles = 80*NTW MFMAs per chunk for ~12 16-byte loads per lane, and no block barrier
+//     anywhere in the main loop (a wave only ever reads what it wrote itself);
+//   * the 4 waves of a block work on the same (ky, 32 ci, 32*NTW n) tile over interleaved chunks; their accumulators are
+//     summed through LDS and the block issues ONE set of atomics, transposed through LDS so that a wave-instruction adds
+//     two contiguous 128-B segments of the K-inner packed gradient (full atomic rate) instead of 64 scattered words.
+// ---------------------------------------------------------------------------------------------------------
+template <int NTW, int SW>   // NTW: 32-column tiles per wave (1 or 2); SW: pixels of one image row inside a chunk (min(W, 32))
+__global__ __launch_bounds__(256, 1) void wgrad5x5_kernel(const WgradDesc d) {
+    constexpr int R = 32 / SW;                  // image rows per chunk
+    constexpr int SP = R * (SW + 4);            // strip pixels
+    constexpr int XP = 32, YP = 32 * NTW;       // LDS row lengths (floats): lane-contiguous reads, no padding needed
+    constexpr int WBUF = SP * XP + 32 * YP;     // floats per wave per buffer
+    constexpr int NACC = 5 * NTW;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ncb = d.cin >> 5, nnb = d.N / (32 * NTW);
+    int bid = blockIdx.x;
+    const int nb = bid % nnb; bid /= nnb;
+    const int cb = bid % ncb; bid /= ncb;
+    const int ky = bid;                          // 0..4
+    const int ci0 = cb * 32, n0 = nb * 32 * NTW;
+    const int HWg = d.Hg * d.Wg, Wd = d.Wg, Hd = d.Hg;
+    const int nchunks_total = d.M / 32;
+    const int nsplit = gridDim.y, split = blockIdx.y;
+    const int c_begin = (int)((long)nchunks_total * split / nsplit), c_end = (int)((long)nchunks_total * (split + 1) / nsplit);
+    constexpr unsigned OOB = 0xC0000000u;
+    const bool from0 = ci0 < d.c0;               // a 32-channel block never straddles the two sources (c0 % 32 == 0)
+    const __amdgpu_buffer_rsrc_t rx = from0 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x0), 0, d.bytes0, 0x00020000)
+                                            : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x1), 0, d.bytes1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy), 0, d.bytesy, 0x00020000);
+    const int xld = from0 ? d.ld0 : d.ld1;
+    const int xc0 = from0 ? ci0 : ci0 - d.c0;
+    float* wbase = sm + wave * 2 * WBUF;
+
+    // staging roles inside a wave: X strip: 8 lanes per strip pixel (float4 of 4 channels), 8 pixels per pass
+    constexpr int NXP = (SP + 7) / 8;
+    // dY tile: YP/4 lanes per pixel, 64/(YP/4) pixels per pass
+    constexpr int YL = YP / 4, YPP = 64 / YL, NYP = 32 / YPP;
+    const int xl = lane & 7, xq = lane >> 3;
+    const int yl = lane % YL, yq = lane / YL;
+    f32x4 rx4[NXP], ry4[NYP];
+    auto issue = [&](int chunk) {
+        const int p0 = chunk * 32;
+        const int b = p0 / HWg, rem = p0 - b * HWg, y0 = rem / Wd, x0 = rem - y0 * Wd;
+#pragma unroll
+        for (int j = 0; j < NXP; ++j) {
+            const int sp = xq + 8 * j;                     // strip pixel
+            unsigned off = OOB;
+            if (sp < SP) {
+                const int r = sp / (SW + 4), xx = sp - r * (SW + 4);
+                const int iy = y0 + r + ky - 2, ix = x0 + xx - 2;
+                if ((unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd)
+                    off = (unsigned)((((b * Hd + iy) * Wd + ix) * xld + xc0 + xl * 4) * 4);
+            }
+            rx4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < NYP; ++j) {
+            const int pix = yq + YPP * j;
+            const unsigned off = (unsigned)(((p0 + pix) * d.ldy + n0 + yl * 4) * 4);
+            ry4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0));
+        }
+    };
+    auto store = [&](int buf) {
+        float* xs = wbase + buf * WBUF;
+        float* ys = xs + SP * XP;
+#pragma unroll
+        for (int j = 0; j < NXP; ++j) {
+            const int sp = xq + 8 * j;
+            if (sp < SP) *reinterpret_cast<f32x4*>(xs + sp * XP + xl * 4) = rx4[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NYP; ++j) *reinterpret_cast<f32x4*>(ys + (yq + YPP * j) * YP + yl * 4) = ry4[j];
+    };
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int t = 0; t < NACC; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    int c = c_begin + wave;
+    if (c < c_end) { issue(c); store(0); }
+    int buf = 0;
+    for (; c < c_end; c += 4) {
+        const bool more = c + 4 < c_end;
+        if (more) issue(c + 4);
+        const float* xs = wbase + buf * WBUF + l31;
+        const float* ys = xs - l31 + SP * XP + l31;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            constexpr int dummy = 0; (void)dummy;
+            const int pix = 2 * s2 + half;                               // this half-wave's pixel (MFMA k index)
+            const int sidx = (2 * s2 / SW) * (SW + 4) + (2 * s2 % SW) + half;   // strip index of (pixel, kx = 0)
+            float bf[NTW];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bf[t] = ys[pix * YP + t * 32];
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const float a = xs[(sidx + kx) * XP];
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
+                    acc[kx * NTW + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[t], acc[kx * NTW + t], 0, 0, 0);
+            }
+        }
+        if (more) store(buf ^ 1);
+        buf ^= 1;
+    }
+    // ---- block reduction of the 4 workers + transposed atomics -------------------------------------------------
+    // LDS image of one worker's result: [tap kx][tile t][n 0..31][ci 0..31]  (NACC * 1024 floats = 20/40 KB)
+    __syncthreads();                               // every wave is done with its staging buffers
+    constexpr int IMG = NACC * 1024;
+    auto put = [&](float* img) {
+#pragma unroll
+        for (int t = 0; t < NACC; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) img[t * 1024 + l31 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = acc[t][r];
+    };
+    auto add = [&](const float* img) {
+#pragma unroll
+        for (int t = 0; t < NACC; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += img[t * 1024 + l31 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+    };
+    if (wave >= 2) put(sm + (wave - 2) * IMG);
+    __syncthreads();
+    if (wave < 2) add(sm + wave * IMG);
+    __syncthreads();
+    if (wave == 1) put(sm);
+    __syncthreads();
+    if (wave == 0) { add(sm); }
+    __syncthreads();
+    if (wave == 0) put(sm);
+    __syncthreads();
+    // packed gradient [tap][wcin/32][N][32]: for tap (ky,kx), tile t: rows n0 + t*32 + n, 32 contiguous ci each
+    for (int i = tid; i < IMG; i += 256) {
+        const int t = i >> 10, rem = i & 1023, n = rem >> 5, ci = rem & 31;
+        const int kx = t / NTW, tt = t - kx * NTW;
+        const int tap = ky * 5 + kx;
+        float* g = d.dw + (((size_t)tap * (d.wcin >> 5) + cb) * d.N + n0 + tt * 32 + n) * 32 + ci;
+        atomicAdd(g, sm[i]);
+    }
+    // bias gradient for free: the kernel-row 0 / channel-block 0 blocks have every dY pixel of their chunks in LDS... not kept; see bias_grad
+}
+
+template <int NTW, int SW>
+static int launch_wgrad5x5(const WgradDesc& d, hipStream_t s) {
+    constexpr int R = 32 / SW, SP = R * (SW + 4);
+    constexpr int WBUF = SP * 32 + 32 * 32 * NTW;
+    constexpr int IMG = 5 * NTW * 1024;
+    constexpr int lds_floats = (4 * 2 * WBUF > 2 * IMG) ? 4 * 2 * WBUF : 2 * IMG;
+    constexpr int lds_bytes = lds_floats * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad5x5_kernel<NTW, SW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        attr_set = true;
+    }
+    const int tiles = 5 * (d.cin / 32) * (d.N / (32 * NTW));
+    const int chunks = d.M / 32;
+    int nsplit = (512 + tiles - 1) / tiles;              // ~2 blocks per CU
+    if (nsplit > chunks / 16) nsplit = chunks / 16;      // >= 4 chunks per wave
+    if (nsplit < 1) nsplit = 1;
+    hipLaunchKernelGGL((wgrad5x5_kernel<NTW, SW>), dim3(tiles, nsplit), dim3(256), lds_bytes, s, d);
+    return PIVP_LAUNCH_STATUS();
+}
+
 int igemm_wgrad(const WgradDesc& d, hipStream_t s) {
     PIVP_CHECK_ARG(d.x0 && d.dy && d.dw && d.c0 > 0 && d.c0 % 32 == 0 && d.c1 >= 0 && d.c1 % 32 == 0 && (d.c1 == 0 || d.x1));
     PIVP_CHECK_ARG(d.cin == d.c0 + d.c1 && d.wcin >= d.cin && d.wcin % 32 == 0 && d.N > 0 && d.N % 32 == 0);
     PIVP_CHECK_ARG(d.M == d.B * d.Hg * d.Wg && d.M > 0 && d.ksize >= 1 && d.ksize <= 7);
     PIVP_CHECK_ARG(d.bytes0 > 0 && d.bytesy > 0 && (d.c1 == 0 || d.bytes1 > 0));
+    if (!d.deconv && d.ksize == 5 && d.pad == 2 && d.stride == 1 && d.M % 32 == 0 && d.N % 64 == 0 &&
+        (d.Wg == 8 || d.Wg == 16 || d.Wg % 32 == 0) && d.Hx == d.Hy && d.Wx == d.Wy) {
+        if (d.Wg == 8) return launch_wgrad5x5<2, 8>(d, s);
+        if (d.Wg == 16) return launch_wgrad5x5<2, 16>(d, s);
+        return launch_wgrad5x5<2, 32>(d, s);
+    }
     const int ncb = (d.cin + WG_CI - 1) / WG_CI, nnb = (d.N + WG_N - 1) / WG_N;
     const int tiles = d.ksize * d.ksize * ncb * nnb;
     const int chunks = (d.M + WG_PIX - 1) / WG_PIX;

@@ -80,6 +80,10 @@ int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, in
     if (!fits31(b0) || !fits31(bw)) return PIVP_ERR_BADARG;
     d.bytes0 = (int)b0; d.bytesw = (int)bw;
     d.out_step = 1; d.Hout = H; d.Wout = W; d.out = out; d.ldo = ldo; d.relu = 0; d.accum = accum;
+    if (!accum && ldo == cout) {     // contiguous fresh output: allow the K-split path (needs a zeroed destination)
+        if (hipMemsetAsync(out, 0, (size_t)B * H * W * cout * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
+        d.ksplit_ok = 1;
+    }
     return igemm_conv(d, s);
 }
 
@@ -104,12 +108,14 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
 int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
                           const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                           float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
-                          int B, int H, int W, hipStream_t s) {
+                          int B, int H, int W, hipStream_t s, int wt_ready) {
     const int M = B * H * W, cin = cx + C, N = 4 * C;
     int rc = lstm_gates_bwd(gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc, dc_valid, dG, M, C, s);
     if (rc != PIVP_OK) return rc;
-    rc = repack_transpose(w, wt, 25, cin, N, 1, s);                       // [25][cin/32][4C][32] -> flipped [25][4C/32][cin][32]
-    if (rc != PIVP_OK) return rc;
+    if (!wt_ready) {
+        rc = repack_transpose(w, wt, 25, cin, N, 1, s);                   // [25][cin/32][4C][32] -> flipped [25][4C/32][cin][32]
+        if (rc != PIVP_OK) return rc;
+    }
     rc = run_conv_s1(dG, N, N, wt, d_in, cin, cin, 5, B, H, W, s);        // d[x,h] = conv5x5(dG, W^T flipped)
     if (rc != PIVP_OK) return rc;
     rc = run_wgrad(0, x, cx, ldx, h_prev, C, C, cin, dG, N, N, dW, B, H, W, H, W, 5, 2, 1, s);
@@ -142,13 +148,16 @@ int run_select_frames(const float* gt, const float* gen, const unsigned char* ta
 
 // conv3x3s2 (mode 0) / deconv3x3s2 (mode 1) backward.  dy is masked in place by (y > 0) when y != null (fused ReLU).
 int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w, float* dy, int cout, int ldy, const float* y, int ldyy,
-                      float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, hipStream_t s) {
+                      float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, hipStream_t s,
+                      int wt_ready) {
     const int Hout = mode ? 2 * Hin : Hin / 2, Wout = mode ? 2 * Win : Win / 2;
     int rc = PIVP_OK;
     if (y) { rc = relu_mask(dy, ldy, y, ldyy, cout, (long)B * Hout * Wout, s); if (rc != PIVP_OK) return rc; }
     if (dx) {
-        rc = repack_transpose(w, wt, 9, cin, cout, 0, s);
-        if (rc != PIVP_OK) return rc;
+        if (!wt_ready) {
+            rc = repack_transpose(w, wt, 9, cin, cout, 0, s);
+            if (rc != PIVP_OK) return rc;
+        }
         rc = mode ? run_conv3x3s2(dy, cout, ldy, wt, nullptr, dx, cin, lddx, 0, B, Hout, Wout, s, accum_dx)
                   : run_deconv3x3s2(dy, cout, ldy, wt, nullptr, dx, cin, lddx, 0, B, Hout, Wout, s, accum_dx);
         if (rc != PIVP_OK) return rc;

@@ -20,9 +20,10 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
 int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
                           const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                           float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
-                          int B, int H, int W, hipStream_t s);
+                          int B, int H, int W, hipStream_t s, int wt_ready = 0);
 int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w, float* dy, int cout, int ldy, const float* y, int ldyy,
-                      float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, hipStream_t s);
+                      float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, hipStream_t s,
+                      int wt_ready = 0);
 int run_layernorm(const float* x, const float* g, const float* b, float* out, float* partials, int B, int n, int C,
                   int ldo, float eps, int relu, hipStream_t s, float* stat_out = nullptr);
 int run_select_frames(const float* gt, const float* gen, const unsigned char* take, float* out, int B, int frame_numel, hipStream_t s);

@@ -28,6 +28,7 @@ struct IgemmDesc {
     int out_step, Hout, Wout;            // output coord = anchor*out_step + phase parity
     float* out; int ldo; int relu;
     int accum;                           // 1: out += result (gradient accumulation)
+    int ksplit_ok;                       // 1: `out` is pre-zeroed and may be produced by K-split blocks with atomic adds
     // ConvLSTM epilogue
     const float* cstate_in; float* cstate_out; float* hout; int C;
     float* gates_out;                    // optional [M][4C]: tanh(j), sigma(i), sigma(f+1), sigma(o) for the backward pass

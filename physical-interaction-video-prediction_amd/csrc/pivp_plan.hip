@@ -33,7 +33,8 @@ struct Slab {
 struct Grads {   // gradient workspace (single copy, reused by every timestep of the backward sweep)
     size_t cat7, n2, cat6, n4, e2, n5, e6, e6raw, e0raw;
     size_t hln[7], din[7][2], dc[7];
-    size_t dG, wt, go[2], dmk, dz, dkpart, dv, dstate, lnpart;
+    size_t dG, go[2], dmk, dz, dkpart, dv, dstate, lnpart;
+    size_t wt_lstm[7], wt_enc[7];   // re-packed (transposed) weights for the data gradients, rebuilt once per backward
 };
 
 }  // namespace
@@ -154,16 +155,16 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
         g.cat7 = carve(B * HW2 * 64); g.n2 = carve(B * HW2 * 32); g.cat6 = carve(B * HW4 * 96); g.n4 = carve(B * HW4 * 64);
         g.e2 = carve(B * HW8 * 64); g.n5 = carve(B * HW8 * 128); g.e6 = carve(B * HW * 64); g.e6raw = carve(B * HW * 64);
         g.e0raw = carve(B * HW2 * 32);
-        size_t maxdG = 0, maxw = 0;
+        size_t maxdG = 0;
         for (int i = 0; i < 7; ++i) {
             const size_t M = hsz[i] / kLstm[i].C * B;
             g.hln[i] = carve(B * hsz[i]); g.dc[i] = carve(B * hsz[i]);
             g.din[i][0] = carve(M * (kLstm[i].cx + kLstm[i].C)); g.din[i][1] = carve(M * (kLstm[i].cx + kLstm[i].C));
             if (M * 4 * kLstm[i].C > maxdG) maxdG = M * 4 * kLstm[i].C;
-            const size_t wn = (size_t)25 * (kLstm[i].cx + kLstm[i].C) * 4 * kLstm[i].C;
-            if (wn > maxw) maxw = wn;
+            g.wt_lstm[i] = carve((size_t)25 * (kLstm[i].cx + kLstm[i].C) * 4 * kLstm[i].C);
+            g.wt_enc[i] = (i == 0 || i == 3) ? 0 : carve((size_t)encw[i]);
         }
-        g.dG = carve(maxdG); g.wt = carve(maxw);
+        g.dG = carve(maxdG);
         g.go[0] = carve((size_t)B * 3 * HW); g.go[1] = carve((size_t)B * 3 * HW);
         g.dmk = carve((size_t)B * p->NP * HW); g.dz = carve((size_t)B * 3 * HW);
         g.dkpart = carve((size_t)B * composite_bwd_tiles(H) * 256); g.dv = carve((size_t)B * 256);
@@ -348,7 +349,6 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     const int par = t & 1, npar = par ^ 1;
     const int n2 = 32 * p->H2 * p->W2, n4 = 64 * p->H4 * p->W4, n8 = 128 * p->H8 * p->W8;
     float* lnpart = ws + g.lnpart;
-    float* wt = ws + g.wt;
     auto lnb = [&](int j, const float* dy, int lddy, const float* y, int ldy, const float* x, float* dx, int n, int C, int relu) {
         return ln_backward(dy, lddy, y, ldy, x, ws + S.lnstat + (size_t)j * B * 2, P(p, p->i_ln_g[j]), lnpart, dx,
                            G(p, p->i_ln_g[j]), G(p, p->i_ln_b[j]), B, n, C, relu, s);
@@ -359,7 +359,8 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         return run_convlstm_backward(x, L.cx, ldx, Sp ? ws + Sp->h[i] : nullptr, L.C, P(p, p->i_lstm_w[i]), ws + S.gates[i],
                                      Sp ? ws + Sp->c[i] : ws + p->o_zero, ws + S.c[i], ws + g.hln[i], L.C,
                                      last_step ? nullptr : ws + g.din[i][npar] + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
-                                     ws + g.dG, wt, ws + g.din[i][par], G(p, p->i_lstm_w[i]), G(p, p->i_lstm_b[i]), B, hh, wwid, s);
+                                     ws + g.dG, ws + g.wt_lstm[i], ws + g.din[i][par], G(p, p->i_lstm_w[i]), G(p, p->i_lstm_b[i]), B, hh, wwid,
+                                     s, 1);
     };
     const long px2 = (long)B * p->H2 * p->W2, px4 = (long)B * p->H4 * p->W4, px8 = (long)B * p->H8 * p->W8;
 
@@ -374,8 +375,8 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                             G(p, p->i_head_w), G(p, p->i_head_b), B, p->K5, c.num_masks, s));
         // group 6 (TM:601), reversed: norm_enc6 (+relu) <- enc6 deconv <- [hidden7 | enc0]
         RC(lnb(8, ws + g.e6, 64, ws + S.e6, 64, ws + S.e6raw, ws + g.e6raw, 64 * HW, 64, 1));
-        RC(run_conv_backward(1, ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), ws + g.e6raw, 64, 64, nullptr, 0, wt, ws + g.cat7, 64, 0,
-                             G(p, p->i_enc_w[6]), G(p, p->i_enc_b[6]), B, p->H2, p->W2, s));
+        RC(run_conv_backward(1, ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), ws + g.e6raw, 64, 64, nullptr, 0, ws + g.wt_enc[6], ws + g.cat7, 64, 0,
+                             G(p, p->i_enc_w[6]), G(p, p->i_enc_b[6]), B, p->H2, p->W2, s, 1));
     } else {
         // no gradient reaches this step's frame: only the recurrent paths are live
         if (hipMemsetAsync(ws + g.cat7, 0, (size_t)px2 * 64 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
@@ -384,13 +385,13 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(lnb(7, ws + g.cat7, 64, nullptr, 0, ws + S.h[6], ws + g.hln[6], n2, 32, 0));
     RC(lstmb(6, ws + S.e5, 96, p->H2, p->W2));
     // group 5 (TM:600): d e5 = x-part of lstm7's d_in (ReLU fused in enc5) <- enc5 deconv <- [hidden6 | enc1]
-    RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ws + S.e5, 96, wt, ws + g.cat6, 96, 0,
-                         G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s));
+    RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ws + S.e5, 96, ws + g.wt_enc[5], ws + g.cat6, 96, 0,
+                         G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1));
     RC(lnb(6, ws + g.cat6, 96, nullptr, 0, ws + S.h[5], ws + g.hln[5], n4, 64, 0));
     RC(lstmb(5, ws + S.e4, 128, p->H4, p->W4));
     // group 4 (TM:599): d e4 = x-part of lstm6's d_in <- enc4 deconv <- hidden5 (also read by the CDNA kernel generator)
-    RC(run_conv_backward(1, ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), ws + g.din[5][par], 128, 192, ws + S.e4, 128, wt, ws + g.n5, 128, 1,
-                         G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s));
+    RC(run_conv_backward(1, ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), ws + g.din[5][par], 128, 192, ws + S.e4, 128, ws + g.wt_enc[4], ws + g.n5, 128, 1,
+                         G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s, 1));
     RC(lnb(5, ws + g.n5, 128, nullptr, 0, ws + S.h[4], ws + g.hln[4], n8, 128, 0));
     RC(lstmb(4, ws + S.e3, 64, p->H8, p->W8));
     // group 3 (TM:598) + state predictor (TM:730): d e3 = x-part of lstm5's d_in (ld 192)
@@ -399,16 +400,16 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                       G(p, p->i_cs_b), t > 0 ? ws + g.dstate + (size_t)(t - 1) * B * 5 : ws + g.dstate + (size_t)(c.seq_len - 1) * B * 5,
                       B, p->H8 * p->W8, c.use_state, s));
     // group 2 (TM:597): enc2 conv (ReLU) <- hidden4 <- lstm4 <- hidden3 <- lstm3 <- enc1
-    RC(run_conv_backward(0, ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), ws + g.e2, 64, 64, ws + S.e2, 64, wt, ws + g.n4, 64, 0,
-                         G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s));
+    RC(run_conv_backward(0, ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), ws + g.e2, 64, 64, ws + S.e2, 64, ws + g.wt_enc[2], ws + g.n4, 64, 0,
+                         G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s, 1));
     RC(lnb(4, ws + g.n4, 64, nullptr, 0, ws + S.h[3], ws + g.hln[3], n4, 64, 0));
     RC(lstmb(3, ws + S.n3, 64, p->H4, p->W4));
     RC(lnb(3, ws + g.din[3][par], 128, nullptr, 0, ws + S.h[2], ws + g.hln[2], n4, 64, 0));
     RC(lstmb(2, ws + S.cat6 + 64, 96, p->H4, p->W4));
     RC(add_strided(ws + g.cat6 + 64, 96, ws + g.din[2][par], 96, 32, px4, s));          // d enc1: from enc5's concat + from lstm3
     // group 1 (TM:596): enc1 conv (ReLU) <- hidden2 <- lstm2 <- hidden1 <- lstm1 <- enc0
-    RC(run_conv_backward(0, ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), ws + g.cat6 + 64, 32, 96, ws + S.cat6 + 64, 96, wt, ws + g.n2, 32, 0,
-                         G(p, p->i_enc_w[1]), G(p, p->i_enc_b[1]), B, p->H2, p->W2, s));
+    RC(run_conv_backward(0, ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), ws + g.cat6 + 64, 32, 96, ws + S.cat6 + 64, 96, ws + g.wt_enc[1], ws + g.n2, 32, 0,
+                         G(p, p->i_enc_w[1]), G(p, p->i_enc_b[1]), B, p->H2, p->W2, s, 1));
     RC(lnb(2, ws + g.n2, 32, nullptr, 0, ws + S.h[1], ws + g.hln[1], n2, 32, 0));
     RC(lstmb(1, ws + S.n1, 32, p->H2, p->W2));
     RC(lnb(1, ws + g.din[1][par], 64, nullptr, 0, ws + S.h[0], ws + g.hln[0], n2, 32, 0));
@@ -439,6 +440,13 @@ extern "C" int pivp_rollout_backward(pivp_plan_t* plan, const float* images, con
     if (hipMemsetAsync(ws + g.dstate, 0, (size_t)T * B * 5 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     for (int t = ctx - 1; t < T - 1; ++t)
         RC(scaled_diff(gen_states + (size_t)t * B * 5, states + (size_t)(t + 1) * B * 5, ws + g.dstate + (size_t)t * B * 5, (long)B * 5, sscale, 0, s));
+    // weights are constant during the sweep: build the transposed packs for the data gradients once
+    for (int i = 0; i < 7; ++i)
+        RC(repack_transpose(P(plan, plan->i_lstm_w[i]), ws + g.wt_lstm[i], 25, kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C, 1, s));
+    {
+        const int ecin[7] = {0, 32, 64, 0, 128, 96, 64};
+        for (int i : {1, 2, 4, 5, 6}) RC(repack_transpose(P(plan, plan->i_enc_w[i]), ws + g.wt_enc[i], 9, ecin[i], ecin[i], 0, s));
+    }
     bool has_go = false;
     for (int t = T - 2; t >= 0; --t) {
         float* go = ws + g.go[t & 1];

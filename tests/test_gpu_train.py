@@ -98,3 +98,23 @@ def test_adam_update_matches_chainer_rule(pivp):
         bad = np.abs(du - du_ref) > 0.25 * 0.001 * 2      # > 25 % of the two-step movement
         assert bad.mean() < 2e-3, '%s: %.4f of the entries moved differently' % (k, bad.mean())
     assert opt.t == 2
+
+
+def test_data_parallel_equals_large_batch(pivp):
+    """samples are independent, the loss is a batch mean, so the average of the per-shard gradients equals
+    the gradient of the global batch (feed-self, schedsamp_k = -1).  Two "ranks" run one after the other on one GPU."""
+    P = R.init_params(seed=1, dtype=np.float32, scale=1.0)
+    imgs, acts, stas = R.synthetic_batch(4, 4)
+    full = pivp.Model(10, prefix='t', keep_activations=True); full.load_state_dict_reference(P)
+    full([imgs, acts, stas], 0); full.cleargrads(); full.backward()
+    gfull = full._flat_grads.clone()
+    acc = torch.zeros_like(gfull)
+    for rank in range(2):
+        si, sa, ss = pivp.shard_batch([imgs, acts, stas], rank, 2)
+        m = pivp.Model(10, prefix='t', keep_activations=True); m.load_state_dict_reference(P)
+        m([np.ascontiguousarray(si), np.ascontiguousarray(sa), np.ascontiguousarray(ss)], 0)
+        m.cleargrads(); m.backward()
+        acc += m._flat_grads
+    acc /= 2
+    scale = gfull.abs().max()
+    assert float((acc - gfull).abs().max() / scale) < 1e-4
