@@ -29,6 +29,24 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA dense peak (= vector peak)
 
 
+def _pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), or None.
+    PMC counters cannot be collected inside this process; the passes are re-run per round on the same command."""
+    try:
+        best = None
+        pdir = os.path.join(ROOT, 'profiles')
+        for rnd in sorted(os.listdir(pdir)):
+            f = os.path.join(pdir, rnd, 'pmc_traffic.json')
+            if os.path.exists(f):
+                best = f
+        if best is None:
+            return None
+        with open(best) as fh:
+            return round(json.load(fh)['hbm_bytes_per_launch'])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -130,7 +148,7 @@ def main():
                 'bound': 'mfma', 'kernel': 'igemm_f32_kernel<4,true> (ConvLSTM 5x5 gate conv + fused gates)',
                 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                'traffic': None,
+                'traffic': _pmc_traffic(),
                 'launches': int(n_tot.sum()), 'avg_launch_us': round(total_s / max(1, int(n_tot.sum())) * 1e6, 2),
                 'algorithmic_gflop_per_launch': round(total_flops / max(1, int(n_tot.sum())) / 1e9, 3),
                 'per_layer_tflops': {('lstm%d' % (i + 1)): round(float(flops[i] / (ms_tot[i] * 1e-3) / 1e12), 2)
