@@ -182,6 +182,132 @@ int composite_bwd_cdna(const float* prev, const float* logits, const float* laye
 }
 
 // ------------------------------------------------------------------------------------------
+// composite backward, DNA (forward: composite_kernel<2>, TM:392-415 + TM:720-728, num_masks = 1 so NP = 2):
+//   kn_i = relu(e7_i - 1e-12) + 1e-12, w_i = kn_i / sum kn, t[c] = sum_i w_i in_i[c], out = mk0*prev + mk1*t
+//   in_(xk,yk)[c](y,x) = prev[c](y+xk-2, x+yk-2) if (y+xk < H and x+yk < W) else 0      (the reference's slice quirk, TM:400)
+//   d mk0 = sum_c go*prev, d mk1 = sum_c go*t;  a_i = sum_c go[c] mk1 in_i[c];  d kn_j = (a_j - sum_i a_i w_i) / S
+//   d e7_j = d kn_j [e7_j - 1e-12 > 0]  (e7 = relu(conv): same mask)  -> dz planar [25]
+//   d prev[c](q) = mk0 go + sum_i [q.y+2 < H and q.x+2 < W] (w_i mk1 go[c])(q - (xk-2, yk-2))
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void composite_bwd_dna_kernel(const float* __restrict__ prev, const float* __restrict__ logits,
+                                                                const float* __restrict__ e7, const float* __restrict__ go,
+                                                                float* __restrict__ dmk, float* __restrict__ dz,
+                                                                float* __restrict__ dprev, int dprev_accum, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int NP = 2;
+    const int HW = H * W;
+    const int b = blockIdx.y, y0 = blockIdx.x * CB_TR;
+    const int rows = min(CB_TR, H - y0);
+    const int ey0 = max(0, y0 - 2), ey1 = min(H, y0 + rows + 2);
+    const int erows = ey1 - ey0, enp = erows * W, ep0 = ey0 * W;
+    const int PR = CB_TR + 4, PW = W + 4;
+    float* wx = sm;                          // [25][PR*W]   normalised kernels on the extended tile
+    float* dtx = wx + 25 * PR * W;           // [3][PR*W]    mk1 * go on the extended tile
+    float* m0x = dtx + 3 * PR * W;           // [PR*W]       mk0 on the extended tile
+    float* prevt = m0x + PR * W;             // [3][PR][PW]
+    const int tid = threadIdx.x;
+    const float* lgb = logits + (size_t)b * NP * HW;
+    const float* pb = prev + (size_t)b * 3 * HW;
+    const float* gb = go + (size_t)b * 3 * HW;
+    const float* eb = e7 + (size_t)b * 25 * HW;
+    for (int i = tid; i < 3 * PR * PW; i += 256) {
+        const int c = i / (PR * PW), r = (i / PW) % PR, x = i % PW;
+        const int iy = y0 + r - 2, ix = x - 2;
+        prevt[i] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? pb[(size_t)c * HW + iy * W + ix] : 0.f;
+    }
+    for (int pp = tid; pp < enp; pp += 256) {
+        const int p = ep0 + pp;
+        // flat softmax over NP = 2 consecutive elements of the planar logits (TM:720-722)
+        float mk[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int F = m * HW + p, g0 = (F / 2) * 2;
+            const float a = lgb[g0], c2 = lgb[g0 + 1], mx = fmaxf(a, c2);
+            const float ea = expf(a - mx), ec = expf(c2 - mx);
+            mk[m] = (F == g0 ? ea : ec) / (ea + ec);
+        }
+        m0x[pp] = mk[0];
+        float kn[25], S = 0.f;
+#pragma unroll
+        for (int i = 0; i < 25; ++i) { kn[i] = fmaxf(eb[(size_t)i * HW + p] - 1e-12f, 0.f) + 1e-12f; S += kn[i]; }
+        const float inv = 1.0f / S;
+#pragma unroll
+        for (int i = 0; i < 25; ++i) wx[i * PR * W + pp] = kn[i] * inv;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dtx[c * PR * W + pp] = mk[1] * gb[(size_t)c * HW + p];
+    }
+    __syncthreads();
+    const int toff = (y0 - ey0) * W, np = rows * W;
+    for (int pp = tid; pp < np; pp += 256) {
+        const int p = y0 * W + pp, y = p / W, x = p - y * W, ry = y - y0;
+        const float g0 = gb[p], g1 = gb[(size_t)HW + p], g2 = gb[2 * (size_t)HW + p];
+        const float* p0 = prevt + (0 * PR + ry) * PW + x;
+        const float* p1 = prevt + (1 * PR + ry) * PW + x;
+        const float* p2 = prevt + (2 * PR + ry) * PW + x;
+        const float d0 = dtx[toff + pp], d1 = dtx[PR * W + toff + pp], d2 = dtx[2 * PR * W + toff + pp];
+        float a[25], dot = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f, S = 0.f;
+#pragma unroll
+        for (int xk = 0; xk < 5; ++xk)
+#pragma unroll
+            for (int yk = 0; yk < 5; ++yk) {
+                const int i = xk * 5 + yk;
+                const bool ok = (y + xk < H) && (x + yk < W);
+                const float i0 = ok ? p0[xk * PW + yk] : 0.f, i1 = ok ? p1[xk * PW + yk] : 0.f, i2 = ok ? p2[xk * PW + yk] : 0.f;
+                const float w = wx[i * PR * W + toff + pp];
+                a[i] = d0 * i0 + d1 * i1 + d2 * i2;
+                dot = fmaf(a[i], w, dot);
+                t0 = fmaf(w, i0, t0); t1 = fmaf(w, i1, t1); t2 = fmaf(w, i2, t2);
+                const float kn = fmaxf(eb[(size_t)i * HW + p] - 1e-12f, 0.f) + 1e-12f;
+                S += kn;
+            }
+        const float inv = 1.0f / S;
+#pragma unroll
+        for (int i = 0; i < 25; ++i) {
+            const float ev = eb[(size_t)i * HW + p];
+            dz[((size_t)b * 25 + i) * HW + p] = (ev - 1e-12f > 0.f) ? (a[i] - dot) * inv : 0.f;
+        }
+        float* dm = dmk + (size_t)b * NP * HW + p;
+        dm[0] = g0 * p0[2 * PW + 2] + g1 * p1[2 * PW + 2] + g2 * p2[2 * PW + 2];
+        dm[(size_t)HW] = g0 * t0 + g1 * t1 + g2 * t2;
+        if (dprev) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            if (y + 2 < H && x + 2 < W) {
+#pragma unroll
+                for (int xk = 0; xk < 5; ++xk) {
+                    const int sy = y - (xk - 2);
+                    if (sy < ey0 || sy >= ey1) continue;
+#pragma unroll
+                    for (int yk = 0; yk < 5; ++yk) {
+                        const int sx = x - (yk - 2);
+                        if ((unsigned)sx >= (unsigned)W) continue;
+                        const int sp = (sy - ey0) * W + sx;
+                        const float w = wx[(xk * 5 + yk) * PR * W + sp];
+                        a0 = fmaf(w, dtx[sp], a0); a1 = fmaf(w, dtx[PR * W + sp], a1); a2 = fmaf(w, dtx[2 * PR * W + sp], a2);
+                    }
+                }
+            }
+            const float m0 = m0x[toff + pp];
+            float* dp = dprev + (size_t)b * 3 * HW + p;
+            const float v0 = a0 + m0 * g0, v1 = a1 + m0 * g1, v2 = a2 + m0 * g2;
+            if (dprev_accum) { dp[0] += v0; dp[(size_t)HW] += v1; dp[2 * (size_t)HW] += v2; }
+            else { dp[0] = v0; dp[(size_t)HW] = v1; dp[2 * (size_t)HW] = v2; }
+        }
+    }
+}
+
+int composite_bwd_dna(const float* prev, const float* logits, const float* e7, const float* go, float* dmk, float* dz,
+                      float* dprev, int dprev_accum, int B, int H, int W, hipStream_t s) {
+    PIVP_CHECK_ARG(prev && logits && e7 && go && dmk && dz && B > 0 && H > 1 && W > 1);
+    const int PR = CB_TR + 4;
+    const size_t lds = sizeof(float) * ((size_t)29 * PR * W + 3 * PR * (W + 4));
+    PIVP_CHECK_ARG(lds <= 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_dna_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(composite_bwd_dna_kernel, dim3(composite_bwd_tiles(H), B), dim3(256), lds, s, prev, logits, e7, go, dmk, dz, dprev,
+                       dprev_accum, H, W);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
 // Backward of the flat softmax + ReLU of the mask head (TM:719-722): for each group of NP consecutive flat
 // elements, d r = mk * (d mk - sum_group mk * d mk), masked by r > 0 (r = relu(masks conv)).  In place on dmk.
 // ------------------------------------------------------------------------------------------
@@ -377,6 +503,170 @@ int cdna_kernels_bwd(const float* hidden5, const float* wt, const float* vpre, c
     hipLaunchKernelGGL(cdna_kernels_bwd_dv_kernel, dim3(B), dim3(256), 0, s, vpre, dkpart, ntiles, dv, db, NM);
     hipLaunchKernelGGL(skinny_linear_bwd_x_kernel, dim3((K + 31) / 32, (B + 31) / 32), dim3(256), 0, s, wt, dv, dhidden5, B, K, accum_dx);
     hipLaunchKernelGGL(skinny_linear_bwd_w_kernel, dim3((K + 7) / 8), dim3(256), 0, s, hidden5, dv, dwt, B, K);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
+// composite backward, STP (forward: composite_kernel<1>, TM:465-471 + TM:720-728):
+//   out = mk0*prev + mk1*L0 + (sum_{q>=2} mk_q) * warp,  warp = bilinear(prev; theta),  L0 = sigmoid(z)  (no ReLU, TM:454-455)
+//   d mk0 = sum_c go*prev, d mk1 = sum_c go*L0, d mk_{q>=2} = sum_c go*warp;  d z = go*mk1*L0(1-L0)
+//   d theta: through the sampling coordinates (u, v) = ((g+1)(W-1)/2), g = theta . (xs, ys, 1); zero where the coordinate was
+//            clamped (stp 'clamp' mode) -> per-tile partial sums dthpart[b][tile][6]
+//   d prev (feed-self): mk0*go plus the bilinear weights scattered to the 4 neighbours (atomics into a buffer the caller has
+//            initialised with the loss term)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void composite_bwd_stp_kernel(const float* __restrict__ prev, const float* __restrict__ logits,
+                                                                const float* __restrict__ layer0, const float* __restrict__ theta,
+                                                                const float* __restrict__ go, float* __restrict__ dmk, float* __restrict__ dz,
+                                                                float* __restrict__ dthpart, float* __restrict__ dprev,
+                                                                int H, int W, int NM, int stp_zero) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float red[4][6];
+    const int NP = NM + 1, HW = H * W;
+    const int b = blockIdx.y, y0 = blockIdx.x * CB_TR;
+    const int rows = min(CB_TR, H - y0);
+    const int p0 = y0 * W, np = rows * W;
+    const int win = np + 2 * (NP - 1), G = np / NP + 2;
+    float* lg = sm;                      // [NP][win]
+    float* gmx = lg + NP * win;          // [NP][G]
+    float* ginv = gmx + NP * G;          // [NP][G]
+    const int tid = threadIdx.x;
+    const float* lgb = logits + (size_t)b * NP * HW;
+    for (int i = tid; i < NP * win; i += 256) {
+        const int m = i / win, j = i - m * win;
+        const int F = m * HW + p0 - (NP - 1) + j;
+        lg[i] = (F >= 0 && F < NP * HW) ? lgb[F] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < NP * G; i += 256) {
+        const int m = i / G, gi = i - m * G;
+        const int gfirst = (m * HW + p0) / NP, glast = (m * HW + p0 + np - 1) / NP;
+        if (gfirst + gi <= glast) {
+            const float* e = lg + m * win + (gfirst + gi) * NP - (m * HW + p0 - (NP - 1));
+            float mx = e[0];
+            for (int u = 1; u < NP; ++u) mx = fmaxf(mx, e[u]);
+            float sum = 0.f;
+            for (int u = 0; u < NP; ++u) sum += expf(e[u] - mx);
+            gmx[i] = mx; ginv[i] = 1.0f / sum;
+        }
+    }
+    __syncthreads();
+    const float* th = theta + (size_t)b * 6;
+    const float* pb = prev + (size_t)b * 3 * HW;
+    float dth[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int pp = tid; pp < np; pp += 256) {
+        const int p = p0 + pp, y = p / W, x = p - y * W;
+        float mk0 = 0.f, mk1 = 0.f, msum = 0.f;
+        for (int m = 0; m < NP; ++m) {
+            const int gi = (m * HW + p) / NP - (m * HW + p0) / NP;
+            const float v = expf(lg[m * win + pp + (NP - 1)] - gmx[m * G + gi]) * ginv[m * G + gi];
+            if (m == 0) mk0 = v; else if (m == 1) mk1 = v; else msum += v;
+        }
+        const double xs = -1.0 + 2.0 * (double)x / (double)(W - 1), ys = -1.0 + 2.0 * (double)y / (double)(H - 1);
+        double gu = (double)th[0] * xs + (double)th[1] * ys + (double)th[2];
+        double gv = (double)th[3] * xs + (double)th[4] * ys + (double)th[5];
+        bool live_u = true, live_v = true;
+        if (!stp_zero) {
+            live_u = gu > -1.0 && gu < 1.0; live_v = gv > -1.0 && gv < 1.0;
+            gu = fmin(fmax(gu, -1.0), 1.0); gv = fmin(fmax(gv, -1.0), 1.0);
+        }
+        const double u = (gu + 1.0) * (double)(W - 1) * 0.5, v = (gv + 1.0) * (double)(H - 1) * 0.5;
+        double u0 = floor(u), v0 = floor(v);
+        if (!stp_zero) { u0 = fmin(fmax(u0, 0.0), (double)(W - 2)); v0 = fmin(fmax(v0, 0.0), (double)(H - 2)); }
+        const float wu1 = (float)(u - u0), wv1 = (float)(v - v0);
+        const int iu = (int)u0, iv = (int)v0;
+        float dmq = 0.f, dmk0 = 0.f, dmk1 = 0.f, du = 0.f, dvv = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g = go[((size_t)b * 3 + c) * HW + p];
+            float nb[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int uu = iu + e, vv = iv + a;
+                    nb[a][e] = ((unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H) ? pb[(size_t)c * HW + vv * W + uu] : 0.f;
+                }
+            const float warp = (1.f - wv1) * ((1.f - wu1) * nb[0][0] + wu1 * nb[0][1]) + wv1 * ((1.f - wu1) * nb[1][0] + wu1 * nb[1][1]);
+            const float l0 = layer0[((size_t)b * 3 + c) * HW + p];
+            const float pc = pb[(size_t)c * HW + p];
+            dmk0 = fmaf(g, pc, dmk0); dmk1 = fmaf(g, l0, dmk1); dmq = fmaf(g, warp, dmq);
+            dz[((size_t)b * 3 + c) * HW + p] = g * mk1 * l0 * (1.f - l0);
+            const float dw = g * msum;                                   // d loss / d warp[c](p)
+            du = fmaf(dw, (1.f - wv1) * (nb[0][1] - nb[0][0]) + wv1 * (nb[1][1] - nb[1][0]), du);
+            dvv = fmaf(dw, (1.f - wu1) * (nb[1][0] - nb[0][0]) + wu1 * (nb[1][1] - nb[0][1]), dvv);
+            if (dprev) {
+                float* dp = dprev + ((size_t)b * 3 + c) * HW;
+                atomicAdd(dp + p, mk0 * g);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int uu = iu + e, vv = iv + a;
+                        if ((unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H)
+                            atomicAdd(dp + vv * W + uu, dw * (a ? wv1 : 1.f - wv1) * (e ? wu1 : 1.f - wu1));
+                    }
+            }
+        }
+        float* dm = dmk + (size_t)b * NP * HW + p;
+        dm[0] = dmk0; dm[(size_t)HW] = dmk1;
+        for (int q = 2; q < NP; ++q) dm[(size_t)q * HW] = dmq;
+        const float dgu = live_u ? du * (float)(W - 1) * 0.5f : 0.f, dgv = live_v ? dvv * (float)(H - 1) * 0.5f : 0.f;
+        dth[0] += dgu * (float)xs; dth[1] += dgu * (float)ys; dth[2] += dgu;
+        dth[3] += dgv * (float)xs; dth[4] += dgv * (float)ys; dth[5] += dgv;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dth[j] = wave_sum(dth[j]);
+    if ((tid & 63) == 0) for (int j = 0; j < 6; ++j) red[tid >> 6][j] = dth[j];
+    __syncthreads();
+    if (tid < 6) dthpart[((size_t)b * gridDim.x + blockIdx.x) * 8 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+int composite_bwd_stp(const float* prev, const float* logits, const float* layer0, const float* theta, const float* go,
+                      float* dmk, float* dz, float* dthpart, float* dprev, int B, int H, int W, int NM, int stp_zero, hipStream_t s) {
+    PIVP_CHECK_ARG(prev && logits && layer0 && theta && go && dmk && dz && dthpart && B > 0 && H > 1 && W > 1 && NM >= 2 && NM <= 10);
+    const int NP = NM + 1, np = CB_TR * W, win = np + 2 * (NP - 1), G = np / NP + 2;
+    const size_t lds = sizeof(float) * ((size_t)NP * win + 2 * NP * G);
+    PIVP_CHECK_ARG(lds <= 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_stp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(composite_bwd_stp_kernel, dim3(composite_bwd_tiles(H), B), dim3(256), lds, s, prev, logits, layer0, theta, go, dmk, dz,
+                       dthpart, dprev, H, W, NM, stp_zero);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// STP regressor backward (forward TM:457-468): theta = W2 s1 + b2 + ident, s1 = relu(W1 x + b1).
+//   d theta = sum of the tile partials; dW2 += d theta (x) s1; db2 += d theta; dv = (W2^T d theta) [s1 > 0]; db1 += dv
+__global__ __launch_bounds__(128) void stp_params_bwd_kernel(const float* __restrict__ dthpart, int ntiles, const float* __restrict__ s1,
+                                                             const float* __restrict__ w2, float* __restrict__ dw2, float* __restrict__ db2,
+                                                             float* __restrict__ db1, float* __restrict__ dv) {
+    __shared__ float dth[6];
+    const int b = blockIdx.x, o = threadIdx.x;
+    if (o < 6) {
+        float a = 0.f;
+        for (int t = 0; t < ntiles; ++t) a += dthpart[((size_t)b * ntiles + t) * 8 + o];
+        dth[o] = a;
+        atomicAdd(db2 + o, a);
+    }
+    __syncthreads();
+    float out = 0.f;
+    if (o < 100) {
+        const float sv = s1[(size_t)b * 256 + o];
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { d = fmaf(w2[j * 100 + o], dth[j], d); atomicAdd(dw2 + j * 100 + o, dth[j] * sv); }
+        out = sv > 0.f ? d : 0.f;
+        atomicAdd(db1 + o, out);
+    }
+    dv[(size_t)b * 256 + o] = out;
+    dv[(size_t)b * 256 + 128 + o] = 0.f;
+}
+
+int stp_params_bwd(const float* hidden5, const float* wt1, const float* s1, const float* w2, const float* dthpart, int ntiles, float* dv,
+                   float* dhidden5, float* dwt1, float* db1, float* dw2, float* db2, int B, int K, hipStream_t s) {
+    PIVP_CHECK_ARG(hidden5 && wt1 && s1 && w2 && dthpart && dv && dhidden5 && dwt1 && db1 && dw2 && db2 && B > 0 && K > 0);
+    hipLaunchKernelGGL(stp_params_bwd_kernel, dim3(B), dim3(128), 0, s, dthpart, ntiles, s1, w2, dw2, db2, db1, dv);
+    hipLaunchKernelGGL(skinny_linear_bwd_x_kernel, dim3((K + 31) / 32, (B + 31) / 32), dim3(256), 0, s, wt1, dv, dhidden5, B, K, 0);
+    hipLaunchKernelGGL(skinny_linear_bwd_w_kernel, dim3((K + 7) / 8), dim3(256), 0, s, hidden5, dv, dwt1, B, K);
     return PIVP_LAUNCH_STATUS();
 }
 

@@ -174,12 +174,13 @@ int cdna_kernels(const float* hidden5, const float* wt, const float* bias, float
 // STP finisher (TM:458-468): relu(Linear(100)) -> shared Linear(6) + identity.  w2 reference layout (6,100).
 __global__ __launch_bounds__(128) void stp_params_finish_kernel(const float* __restrict__ partials, const float* __restrict__ b1,
                                                                 const float* __restrict__ w2, const float* __restrict__ b2,
-                                                                float* __restrict__ theta, int B, int KS) {
+                                                                float* __restrict__ theta, int B, int KS, float* __restrict__ s1_out) {
     __shared__ float s1[100];
     const int b = blockIdx.x, o = threadIdx.x;
     if (o < 100) {
         const double acc = (double)b1[o] + sum_partials(partials, B, KS, b, o);
         s1[o] = fmaxf((float)acc, 0.f);
+        if (s1_out) s1_out[(size_t)b * 256 + o] = s1[o];
     }
     __syncthreads();
     if (o < 6) {
@@ -190,11 +191,11 @@ __global__ __launch_bounds__(128) void stp_params_finish_kernel(const float* __r
 }
 
 int stp_params(const float* hidden5, const float* wt1, const float* b1, const float* w2, const float* b2,
-               float* partials, float* theta, int B, int K, hipStream_t s) {
+               float* partials, float* theta, int B, int K, hipStream_t s, float* s1_out) {
     PIVP_CHECK_ARG(hidden5 && wt1 && b1 && w2 && b2 && partials && theta && B > 0 && K > 0);
     const int KS = cdna_kernel_partials_slices(K);
     hipLaunchKernelGGL(skinny_linear_partials_kernel<double>, dim3(KS, (B + LIN_BG - 1) / LIN_BG), dim3(256), 0, s, hidden5, wt1, partials, B, K);
-    hipLaunchKernelGGL(stp_params_finish_kernel, dim3(B), dim3(128), 0, s, partials, b1, w2, b2, theta, B, KS);
+    hipLaunchKernelGGL(stp_params_finish_kernel, dim3(B), dim3(128), 0, s, partials, b1, w2, b2, theta, B, KS, s1_out);
     return PIVP_LAUNCH_STATUS();
 }
 

@@ -78,7 +78,7 @@ int cdna_kernels(const float* hidden5, const float* wt, const float* bias, float
 
 // STP parameters: Linear -> relu -> shared Linear(6) + identity (TM:457-468)
 int stp_params(const float* hidden5, const float* wt1, const float* b1, const float* w2, const float* b2,
-               float* partials, float* theta, int B, int K, hipStream_t s);
+               float* partials, float* theta, int B, int K, hipStream_t s, float* s1_out = nullptr);   // s1_out [B][256] kept for backward
 
 // flat-11 softmax + transform + compositing -> next frame (TM:720-728 with TM:341-349 / TM:469-470 / TM:392-415)
 // mode 0 = CDNA (kerns [B][num_masks][25]), 1 = STP (theta [B][6]), 2 = DNA (enc7 planes [B][25][HW])
@@ -109,6 +109,12 @@ int scaled_diff(const float* a, const float* b, float* out, long n, float scale,
 int composite_bwd_tiles(int H);
 int composite_bwd_cdna(const float* prev, const float* logits, const float* layer0, const float* kerns, const float* go,
                        float* dmk, float* dz, float* dkpart, float* dprev, int dprev_accum, int B, int H, int W, int NM, hipStream_t s);
+int composite_bwd_stp(const float* prev, const float* logits, const float* layer0, const float* theta, const float* go,
+                      float* dmk, float* dz, float* dthpart, float* dprev, int B, int H, int W, int NM, int stp_zero, hipStream_t s);
+int stp_params_bwd(const float* hidden5, const float* wt1, const float* s1, const float* w2, const float* dthpart, int ntiles, float* dv,
+                   float* dhidden5, float* dwt1, float* db1, float* dw2, float* db2, int B, int K, hipStream_t s);
+int composite_bwd_dna(const float* prev, const float* logits, const float* e7, const float* go, float* dmk, float* dz,
+                      float* dprev, int dprev_accum, int B, int H, int W, hipStream_t s);
 int mask_softmax_bwd(const float* logits, float* dmk, int B, int HW, int NP, hipStream_t s);
 int heads_bwd(const float* e6, const float* wm, const float* we, const float* dpm, const float* dpe, float* de6,
               float* dwm, float* dbm, float* dwe, float* dbe, int B, int HW, int NP, int NE, hipStream_t s);

@@ -149,7 +149,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
         S.kerns = carve((size_t)B * 25 * cfg->num_masks); S.vpre = carve((size_t)B * 256); S.theta = carve((size_t)B * 6);
         S.prevsel = carve((size_t)B * 3 * HW);
     }
-    p->has_grads = train && cfg->model_type == PIVP_MODEL_CDNA;
+    p->has_grads = train;
     if (p->has_grads) {
         Grads& g = p->g;
         g.cat7 = carve(B * HW2 * 64); g.n2 = carve(B * HW2 * 32); g.cat6 = carve(B * HW4 * 96); g.n4 = carve(B * HW4 * 64);
@@ -166,7 +166,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
         }
         g.dG = carve(maxdG);
         g.go[0] = carve((size_t)B * 3 * HW); g.go[1] = carve((size_t)B * 3 * HW);
-        g.dmk = carve((size_t)B * p->NP * HW); g.dz = carve((size_t)B * 3 * HW);
+        g.dmk = carve((size_t)B * p->NP * HW); g.dz = carve((size_t)B * p->NE * HW);
         g.dkpart = carve((size_t)B * composite_bwd_tiles(H) * 256); g.dv = carve((size_t)B * 256);
         g.dstate = carve((size_t)T * B * 5);
         g.lnpart = carve((size_t)B * ln_bwd_slices((int)(64 * HW)) * 2);
@@ -285,7 +285,7 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
         aux = ws + S.kerns;
     } else if (c.model_type == PIVP_MODEL_STP) {
         RC(stp_params(ws + S.n5, P(p, p->i_head_w), P(p, p->i_head_b), P(p, p->i_head2_w), P(p, p->i_head2_b),
-                      ws + p->o_linpart, ws + S.theta, B, p->K5, s));
+                      ws + p->o_linpart, ws + S.theta, B, p->K5, s, ws + S.vpre));
         aux = ws + S.theta;
     } else {
         aux = ws + S.enc7;
@@ -335,7 +335,7 @@ extern "C" int pivp_rollout_forward(pivp_plan_t* plan, const float* images, cons
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// backward through time (what loss.backward() does inside Chainer's optimizer.update, TM:950).  CDNA only this round.
+// backward through time (what loss.backward() does inside Chainer's optimizer.update, TM:950), all three heads.
 // Gradients are ACCUMULATED into the buffers registered with pivp_plan_set_grad (same layouts as the parameters).
 // ------------------------------------------------------------------------------------------------------------
 static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_grad, const float* action, const float* state_prev,
@@ -366,13 +366,26 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
 
     // ---- heads (TM:711-728) ----
     if (has_go) {
-        RC(composite_bwd_cdna(prev, ws + S.logits, ws + S.layer0, ws + S.kerns, go, ws + g.dmk, ws + g.dz, ws + g.dkpart,
-                              prev_has_grad ? go_prev : nullptr, 1, B, H, W, c.num_masks, s));
+        if (c.model_type == PIVP_MODEL_CDNA)
+            RC(composite_bwd_cdna(prev, ws + S.logits, ws + S.layer0, ws + S.kerns, go, ws + g.dmk, ws + g.dz, ws + g.dkpart,
+                                  prev_has_grad ? go_prev : nullptr, 1, B, H, W, c.num_masks, s));
+        else if (c.model_type == PIVP_MODEL_STP)
+            RC(composite_bwd_stp(prev, ws + S.logits, ws + S.layer0, ws + S.theta, go, ws + g.dmk, ws + g.dz, ws + g.dkpart,
+                                 prev_has_grad ? go_prev : nullptr, B, H, W, c.num_masks, c.stp_zero_border, s));
+        else
+            RC(composite_bwd_dna(prev, ws + S.logits, ws + S.enc7, go, ws + g.dmk, ws + g.dz, prev_has_grad ? go_prev : nullptr, 1,
+                                 B, H, W, s));
         RC(mask_softmax_bwd(ws + S.logits, ws + g.dmk, B, HW, p->NP, s));
         RC(heads_bwd(ws + S.e6, P(p, p->i_masks_w), P(p, p->i_enc7_w), ws + g.dmk, ws + g.dz, ws + g.e6, G(p, p->i_masks_w),
                      G(p, p->i_masks_b), G(p, p->i_enc7_w), G(p, p->i_enc7_b), B, HW, p->NP, p->NE, s));
-        RC(cdna_kernels_bwd(ws + S.n5, P(p, p->i_head_w), ws + S.vpre, ws + g.dkpart, composite_bwd_tiles(H), ws + g.dv, ws + g.n5, 0,
-                            G(p, p->i_head_w), G(p, p->i_head_b), B, p->K5, c.num_masks, s));
+        if (c.model_type == PIVP_MODEL_CDNA)
+            RC(cdna_kernels_bwd(ws + S.n5, P(p, p->i_head_w), ws + S.vpre, ws + g.dkpart, composite_bwd_tiles(H), ws + g.dv, ws + g.n5, 0,
+                                G(p, p->i_head_w), G(p, p->i_head_b), B, p->K5, c.num_masks, s));
+        else if (c.model_type == PIVP_MODEL_STP)
+            RC(stp_params_bwd(ws + S.n5, P(p, p->i_head_w), ws + S.vpre, P(p, p->i_head2_w), ws + g.dkpart, composite_bwd_tiles(H),
+                              ws + g.dv, ws + g.n5, G(p, p->i_head_w), G(p, p->i_head_b), G(p, p->i_head2_w), G(p, p->i_head2_b),
+                              B, p->K5, s));
+        else if (hipMemsetAsync(ws + g.n5, 0, (size_t)px8 * 128 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;   // DNA: no hidden5 head
         // group 6 (TM:601), reversed: norm_enc6 (+relu) <- enc6 deconv <- [hidden7 | enc0]
         RC(lnb(8, ws + g.e6, 64, ws + S.e6, 64, ws + S.e6raw, ws + g.e6raw, 64 * HW, 64, 1));
         RC(run_conv_backward(1, ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), ws + g.e6raw, 64, 64, nullptr, 0, ws + g.wt_enc[6], ws + g.cat7, 64, 0,

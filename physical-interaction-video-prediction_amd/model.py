@@ -380,8 +380,6 @@ class Model(object):
             raise RuntimeError('call the model first')
         if not self.keep_activations:
             raise RuntimeError('backward() needs Model(..., keep_activations=True)')
-        if self.model_type != 'CDNA':
-            raise NotImplementedError('backward is implemented for the CDNA variant only')
         self._ensure_grads()
         images, actions, states = self._inputs
         gt_ptr = self._gt_mask.data_ptr() if self._gt_mask is not None else None

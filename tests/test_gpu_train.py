@@ -17,8 +17,8 @@ def pivp():
     return pivp_amd
 
 
-def _autograd(P, imgs, acts, stas, k=-1, it=0, seed=None):
-    tm = TorchModel(10, params=P, requires_grad=True, scheduled_sampling_k=k)
+def _autograd(P, imgs, acts, stas, k=-1, it=0, seed=None, **kw):
+    tm = TorchModel(kw.pop('num_masks', 10), params=P, requires_grad=True, scheduled_sampling_k=k, **kw)
     if seed is not None:
         tm.rng = np.random.RandomState(seed)
     loss = tm([imgs, acts, stas], it)
@@ -118,3 +118,35 @@ def test_data_parallel_equals_large_batch(pivp):
     acc /= 2
     scale = gfull.abs().max()
     assert float((acc - gfull).abs().max() / scale) < 1e-4
+
+
+def test_bptt_gradients_stp(pivp):
+    # STP head (TM:434-475): gradients through the bilinear sampler into theta and, in feed-self mode, into the frames
+    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, model_type='STP')
+    imgs, acts, stas = R.synthetic_batch(2, 4)
+    # smooth frames: the sampler's gradient w.r.t. theta is an image DIFFERENCE, ill-conditioned on white noise in fp32
+    from numpy.lib.stride_tricks import sliding_window_view
+    pad = np.pad(imgs, ((0, 0), (0, 0), (0, 0), (5, 5), (5, 5)), mode='reflect')
+    imgs = np.ascontiguousarray(sliding_window_view(pad, (11, 11), axis=(3, 4)).mean(axis=(-1, -2))).astype(np.float32)
+    loss_ref, gref = _autograd(P, imgs, acts, stas, is_cdna=False, is_stp=True)
+    m = pivp.Model(10, is_cdna=False, is_stp=True, prefix='t', keep_activations=True)
+    m.load_state_dict_reference(P)
+    loss = float(m([imgs, acts, stas], 0))
+    m.cleargrads(); m.backward()
+    assert abs(loss - loss_ref) < 1e-6
+    worst = _check_grads(m.grads_reference(), gref, 5e-3)
+    print('STP worst relative gradient error', worst)
+
+
+def test_bptt_gradients_dna(pivp):
+    # DNA head (TM:368-417), num_masks = 1, with the reference's slice quirk in forward and backward
+    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, model_type='DNA', num_masks=1)
+    imgs, acts, stas = R.synthetic_batch(2, 4)
+    loss_ref, gref = _autograd(P, imgs, acts, stas, is_cdna=False, is_dna=True, num_masks=1)
+    m = pivp.Model(1, is_cdna=False, is_dna=True, prefix='t', keep_activations=True)
+    m.load_state_dict_reference(P)
+    loss = float(m([imgs, acts, stas], 0))
+    m.cleargrads(); m.backward()
+    assert abs(loss - loss_ref) < 1e-6
+    worst = _check_grads(m.grads_reference(), gref, 5e-3)
+    print('DNA worst relative gradient error', worst)
