@@ -179,6 +179,10 @@ int pivp_composite(const float* prev, const float* mask_logits, const float* lay
                    float* masks_out, int B, int H, int W, int num_masks, int model_type, int stp_zero_border,
                    void* stream);
 
+/* F.resize_images(frame, (Hout, Wout)) of the predict path (predict_model.py:119-122): bilinear, align-corners sample grid,
+ * planar [planes][Hin][Win] -> [planes][Hout][Wout], result multiplied by `scale` (1/255 there). */
+int pivp_resize_images(const float* in, float* out, int planes, int Hin, int Win, int Hout, int Wout, float scale, void* stream);
+
 /* scheduled_sample (TM:73-122) as an on-device per-sample select. */
 int pivp_select_frames(const float* ground_truth, const float* generated, const unsigned char* take_gt, float* out,
                        int B, int frame_numel, void* stream);

@@ -543,6 +543,19 @@ class Model(object):
         return self.loss
 
 
+def resize_images(x, out_hw):
+    """chainer.functions.resize_images (2.0.x) as used at predict_model.py:120: bilinear on an align-corners grid
+    (u = linspace(0, W-1, out_W)), lower neighbour clipped to [0, size-2].  x (B,C,H,W)."""
+    B, C, H, W = x.shape
+    oh, ow = out_hw
+    u = np.linspace(0, W - 1, num=ow); v = np.linspace(0, H - 1, num=oh)
+    u0 = np.clip(np.floor(u).astype(np.int64), 0, W - 2); v0 = np.clip(np.floor(v).astype(np.int64), 0, H - 2)
+    wu = (u - u0)[None, None, None, :]; wv = (v - v0)[None, None, :, None]
+    a = x[:, :, v0][:, :, :, u0]; b = x[:, :, v0][:, :, :, u0 + 1]
+    c = x[:, :, v0 + 1][:, :, :, u0]; d = x[:, :, v0 + 1][:, :, :, u0 + 1]
+    return (1 - wu) * (1 - wv) * a + wu * (1 - wv) * b + (1 - wu) * wv * c + wu * wv * d
+
+
 def per_pixel_l2(a, b):
     """Per-pixel L2 over the colour axis: a, b (..., 3, H, W) -> (..., H, W)."""
     d = np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)

@@ -10,11 +10,12 @@ with importlib or through the `pivp_amd` alias module at the repo root:
     model = pivp_amd.Model(num_masks=10, is_cdna=True, prefix='predict')
 """
 from .model import Model, config, using_config, reference_param_shapes, default_init, scheduled_sampling_masks
-from .checkpoint import save_npz, load_npz, to_internal, from_internal
+from .checkpoint import save_npz, load_npz, to_internal, from_internal, save_optimizer_npz, load_optimizer_npz
+from . import dataset
 from .data import concat_examples
 from .optimizer import Adam
 from .parallel import GradAllReduce, shard_batch
 
 __all__ = ['Model', 'config', 'using_config', 'reference_param_shapes', 'default_init',
            'scheduled_sampling_masks', 'save_npz', 'load_npz', 'to_internal', 'from_internal', 'concat_examples',
-           'Adam', 'GradAllReduce', 'shard_batch']
+           'Adam', 'GradAllReduce', 'shard_batch', 'save_optimizer_npz', 'load_optimizer_npz', 'dataset']

@@ -59,6 +59,7 @@ SIGNATURES = {
     'pivp_cdna_kernels': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pivp_stp_params': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'pivp_composite': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'pivp_resize_images': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'pivp_select_frames': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
 }
 

@@ -85,3 +85,29 @@ def load_npz(filename, model):
     """chainer.serializers.load_npz(filename, model) equivalent; missing keys raise KeyError."""
     with np.load(filename) as npz:
         model.load_state_dict_reference({k: npz[k] for k in npz.files})
+
+
+def save_optimizer_npz(filename, optimizer, epoch=0):
+    """chainer.serializers.save_npz(filename, optimizer) equivalent (train_model.py:1037): `t`, `epoch` and per parameter
+    `<path>/t`, `<path>/m`, `<path>/v` in the reference's layouts."""
+    state = optimizer.state_dict_reference()
+    out = {'t': np.asarray(state.pop('t')), 'epoch': np.asarray(epoch)}
+    for k, v in state.items():
+        out[k] = v
+        if k.endswith('/m'):
+            out[k[:-2] + '/t'] = np.asarray(optimizer.t)
+    with open(filename, 'wb') as f:
+        np.savez_compressed(f, **out)
+
+
+def load_optimizer_npz(filename, optimizer):
+    """Inverse of save_optimizer_npz; the model must already be sized (call it once first)."""
+    import torch
+    model = optimizer.target
+    with np.load(filename) as z:
+        optimizer.t = int(z['t'])
+        m, v = optimizer._state(model)
+        for key, shape in model._shapes().items():
+            o, n = model._offsets[key]
+            m[o:o + n].copy_(torch.from_numpy(to_internal(key, z[key + '/m'])))
+            v[o:o + n].copy_(torch.from_numpy(to_internal(key, z[key + '/v'])))

@@ -271,6 +271,9 @@ extern "C" int pivp_composite(const float* prev, const float* mask_logits, const
     return composite(prev, mask_logits, layer0, aux, out, masks_out, B, H, W, num_masks, model_type, stp_zero_border,
                      (hipStream_t)stream);
 }
+extern "C" int pivp_resize_images(const float* in, float* out, int planes, int Hin, int Win, int Hout, int Wout, float scale, void* stream) {
+    return resize_bilinear(in, out, planes, Hin, Win, Hout, Wout, scale, (hipStream_t)stream);
+}
 extern "C" int pivp_select_frames(const float* ground_truth, const float* generated, const unsigned char* take_gt, float* out,
                                   int B, int frame_numel, void* stream) {
     if (!ground_truth || !generated || !take_gt || !out || B <= 0 || frame_numel <= 0 || frame_numel % 4) return PIVP_ERR_BADARG;

@@ -128,6 +128,7 @@ int enc0_bwd(const float* img, const float* w, const float* d, float* dw, float*
 int add_strided(float* dst, int ldd, const float* src, int lds_, int C, long npix, hipStream_t s);
 
 // planar NCHW <-> NHWC helpers for taps (conv_res) and tests
+int resize_bilinear(const float* in, float* out, int planes, int Hin, int Win, int Hout, int Wout, float scale, hipStream_t s);
 int nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, int ld, hipStream_t s);
 
 }  // namespace pivp

@@ -314,6 +314,33 @@ int loss_finalize(const float* frame_partials, int nparts, int nframes, int fram
 }
 
 // ------------------------------------------------------------------------------------------
+// F.resize_images of the predict path (predict_model.py:119-122): bilinear, sample positions linspace(0, in-1, out)
+// (align-corners), neighbours clamped to [0, in-2] as Chainer 2 does; planar [N][C][Hin][Win] -> [N][C][Hout][Wout], x scale.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int planes,
+                                                              int Hin, int Win, int Hout, int Wout, float scale) {
+    const long total = (long)planes * Hout * Wout;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int pl = (int)(i / (Hout * Wout)), rem = (int)(i - (long)pl * Hout * Wout), oy = rem / Wout, ox = rem - oy * Wout;
+        const double u = Wout > 1 ? (double)ox * (double)(Win - 1) / (double)(Wout - 1) : 0.0;
+        const double v = Hout > 1 ? (double)oy * (double)(Hin - 1) / (double)(Hout - 1) : 0.0;
+        int u0 = (int)floor(u), v0 = (int)floor(v);
+        u0 = min(max(u0, 0), Win - 2); v0 = min(max(v0, 0), Hin - 2);
+        const float wu = (float)(u - u0), wv = (float)(v - v0);
+        const float* p = in + (size_t)pl * Hin * Win;
+        const float a = p[v0 * Win + u0], b = p[v0 * Win + u0 + 1], c = p[(v0 + 1) * Win + u0], d = p[(v0 + 1) * Win + u0 + 1];
+        out[i] = scale * ((1.f - wu) * (1.f - wv) * a + wu * (1.f - wv) * b + (1.f - wu) * wv * c + wu * wv * d);
+    }
+}
+int resize_bilinear(const float* in, float* out, int planes, int Hin, int Win, int Hout, int Wout, float scale, hipStream_t s) {
+    PIVP_CHECK_ARG(in && out && planes > 0 && Hin >= 2 && Win >= 2 && Hout >= 1 && Wout >= 1);
+    const long total = (long)planes * Hout * Wout;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, s,
+                       in, out, planes, Hin, Win, Hout, Wout, scale);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------------------------------
 // NHWC (pixel stride ld) -> planar NCHW, for the conv_res taps (TM:734) and tests.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,

@@ -1,0 +1,116 @@
+"""On-disk dataset of the reference and the host-side feed of its training loop.
+
+Format (written by the reference's src/data/make_dataset.py:130-158, read at train_model.py:813-834 and
+predict_model.py:30-51): `<data_dir>/map.csv`, every field quoted, header
+`id,img_bitmap_path,img_np_path,action_np_path,state_np_path,img_bitmap_pred_path,img_np_pred_path`, one row per sequence;
+columns 2/3/4 name per-sequence `.npy` files relative to data_dir: images (T,H,W,3) float32 in [0,1], actions (T,5),
+states (T,5); column 6 the raw uint8 frames used by predict.  The split is by index, no shuffle (train_model.py:836-843)."""
+import csv
+import os
+
+import numpy as np
+
+MAP_HEADER = ['id', 'img_bitmap_path', 'img_np_path', 'action_np_path', 'state_np_path', 'img_bitmap_pred_path', 'img_np_pred_path']
+
+
+def read_map(data_dir):
+    """Rows of map.csv without the header; raises ValueError("No file map found") like predict_model.py:37-38."""
+    path = os.path.join(data_dir, 'map.csv')
+    with open(path, 'r', newline='') as f:
+        rows = [r for r in csv.reader(f)]
+    if len(rows) <= 1:
+        raise ValueError("No file map found")
+    return rows[1:]
+
+
+def write_map(data_dir, rows):
+    """Write map.csv the way make_dataset.py:153-158 does (QUOTE_ALL, same header)."""
+    with open(os.path.join(data_dir, 'map.csv'), 'w', newline='') as f:
+        w = csv.writer(f, quoting=csv.QUOTE_ALL)
+        w.writerow(MAP_HEADER)
+        for r in rows:
+            w.writerow(r)
+
+
+def load_dataset(data_dir):
+    """train_model.py:826-834: every sequence into RAM as float32: images (N,T,H,W,3), actions (N,T,5), states (N,T,5)."""
+    rows = read_map(data_dir)
+    images = np.asarray([np.float32(np.load(os.path.join(data_dir, r[2]))) for r in rows], dtype=np.float32)
+    actions = np.asarray([np.float32(np.load(os.path.join(data_dir, r[3]))) for r in rows], dtype=np.float32)
+    states = np.asarray([np.float32(np.load(os.path.join(data_dir, r[4]))) for r in rows], dtype=np.float32)
+    return images, actions, states
+
+
+def split_train_val(images, actions, states, train_val_split=0.95):
+    """train_model.py:836-843: first floor(split * N) sequences train, the rest validate."""
+    k = int(np.floor(train_val_split * len(images)))
+    return (images[:k], actions[:k], states[:k]), (images[k:], actions[k:], states[k:])
+
+
+def group_examples(images, actions, states):
+    """train_model.py:899-911: list of [images, actions, states] per sequence (what the iterator serves)."""
+    return [[images[i], actions[i], states[i]] for i in range(len(images))]
+
+
+def get_data_info(data_dir, data_index):
+    """predict_model.py:30-51: (image, image_pred, image_bitmap_pred, action, state) of one sequence."""
+    rows = read_map(data_dir)
+    data_index = int(data_index)
+    if data_index > len(rows) - 1:
+        raise ValueError("Data index {} is out of range for available data".format(data_index + 1))
+    r = rows[data_index]
+    image = np.float32(np.load(os.path.join(data_dir, r[2])))
+    image_pred = np.float32(np.load(os.path.join(data_dir, r[6])))
+    action = np.float32(np.load(os.path.join(data_dir, r[3])))
+    state = np.float32(np.load(os.path.join(data_dir, r[4])))
+    return image, image_pred, r[5], action, state
+
+
+class SerialIterator(object):
+    """chainer.iterators.SerialIterator (2.0.x) as used at train_model.py:914-915: a permutation drawn from NumPy's global
+    RNG at reset, reshuffled in place at every epoch boundary; with repeat=True the last batch of an epoch is completed
+    from the start of the next one."""
+
+    def __init__(self, dataset, batch_size, repeat=True, shuffle=True):
+        self.dataset = dataset
+        self.batch_size = batch_size
+        self._repeat = repeat
+        self._shuffle = shuffle
+        self.reset()
+
+    def reset(self):
+        self._order = np.random.permutation(len(self.dataset)) if self._shuffle else None
+        self.current_position = 0
+        self.epoch = 0
+        self.is_new_epoch = False
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if not self._repeat and self.epoch > 0:
+            raise StopIteration
+        i = self.current_position
+        i_end = i + self.batch_size
+        N = len(self.dataset)
+        pick = (lambda a, b: [self.dataset[j] for j in range(a, min(b, N))]) if self._order is None else \
+               (lambda a, b: [self.dataset[j] for j in self._order[a:b]])
+        batch = pick(i, i_end)
+        if i_end >= N:
+            if self._repeat:
+                rest = i_end - N
+                if self._order is not None:
+                    np.random.shuffle(self._order)
+                if rest > 0:
+                    batch.extend(pick(0, rest))
+                self.current_position = rest
+            else:
+                self.current_position = 0
+            self.epoch += 1
+            self.is_new_epoch = True
+        else:
+            self.is_new_epoch = False
+            self.current_position = i_end
+        return batch
+
+    next = __next__

@@ -70,6 +70,7 @@ class Adam(object):
         from . import checkpoint as ckpt
         model = self.target
         out = {'t': np.asarray(self.t)}
+        self._state(model)
         if self._m is not None:
             for key, shape in model._shapes().items():
                 o, n = model._offsets[key]

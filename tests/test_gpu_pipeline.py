@@ -1,0 +1,80 @@
+"""GPU tests of the rows SURVEY 8(f) marks "next": predict-side resize, training from the reference's on-disk dataset
+format with its checkpoint files, optimizer-state round trip, and the predict entry point."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def pivp():
+    assert torch.cuda.is_available(), 'GPU tests need the MI355X'
+    import pivp_amd
+    return pivp_amd
+
+
+def _make_dataset(root, n=6, T=4):
+    from pivp_amd import dataset as ds
+    rs = np.random.RandomState(0)
+    rows = []
+    for j in range(n):
+        np.save(os.path.join(root, 'image_batch_%d' % j), rs.rand(T, 64, 64, 3).astype(np.float32))
+        np.save(os.path.join(root, 'action_batch_%d' % j), (rs.randn(T, 5) * 0.1).astype(np.float32))
+        np.save(os.path.join(root, 'state_batch_%d' % j), (rs.randn(T, 5) * 0.1).astype(np.float32))
+        np.save(os.path.join(root, 'image_batch_pred_%d' % j), (rs.rand(T, 96, 120, 3) * 255).astype(np.uint8))
+        rows.append([j, '', 'image_batch_%d.npy' % j, 'action_batch_%d.npy' % j, 'state_batch_%d.npy' % j, '', 'image_batch_pred_%d.npy' % j])
+    ds.write_map(root, rows)
+
+
+def test_resize_images_matches_oracle(pivp):
+    from pivp_amd.predict import resize_images
+    rs = np.random.RandomState(2)
+    x = (rs.rand(2, 3, 512, 640) * 255).astype(np.float32)            # the reference's raw frame size (predict_model.py:71-72)
+    got = resize_images(x, (64, 64), scale=1.0 / 255.0).cpu().numpy()
+    ref = R.resize_images(x.astype(np.float64), (64, 64)) / 255.0
+    assert np.abs(got - ref).max() < 1e-5
+
+
+def test_train_checkpoint_resume_predict(pivp, tmp_path):
+    from pivp_amd import train as T, predict as Pm
+    data = tmp_path / 'data'; data.mkdir(); out = tmp_path / 'models'; out.mkdir()
+    _make_dataset(str(data))
+    np.random.seed(0)
+    save_dir = T.main(['--data_dir', str(data), '--output_dir', str(out), '--num_iterations', '6', '--batch_size', '2',
+                       '--schedsamp_k', '-1', '--save_interval', '1', '--validation_interval', '1', '--train_val_split', '0.7'])
+    files = sorted(os.listdir(save_dir))
+    assert 'version' in files and 'training-0' in files and 'state-0' in files and 'training-global_losses.npy' in files
+    losses = np.load(os.path.join(save_dir, 'training-global_losses.npy'))
+    assert losses.ndim == 2 and losses.shape[1] == 5 and np.isfinite(losses).all()      # mean, std, min, max, median per epoch
+    # model checkpoint: the reference's keys and shapes
+    last = sorted(f for f in files if f.startswith('training-') and f[9:].isdigit())[-1]
+    with np.load(os.path.join(save_dir, last)) as z:
+        assert sorted(z.files) == sorted(R.param_shapes())
+        assert z['lstm5/conv/W'].shape == (512, 192, 5, 5)
+    # optimizer state: t, epoch, per-parameter m / v
+    with np.load(os.path.join(save_dir, 'state-' + last[9:])) as z:
+        assert int(z['t']) >= 1 and 'epoch' in z.files and 'enc0/W/m' in z.files and 'enc0/W/v' in z.files
+        assert z['lstm1/conv/W/m'].shape == (128, 64, 5, 5)
+    # resume: model + optimizer state load and training continues from them
+    m = pivp.Model(10, prefix='r', keep_activations=True)
+    pivp.load_npz(os.path.join(save_dir, last), m)
+    imgs, acts, stas = R.synthetic_batch(2, 4)
+    with pivp.using_config('train', False):
+        m([imgs, acts, stas], 0)
+    m.reset_state()
+    opt = pivp.Adam().setup(m)
+    pivp.load_optimizer_npz(os.path.join(save_dir, 'state-' + last[9:]), opt)
+    t0 = opt.t
+    l1 = float(opt.update(m, [imgs, acts, stas], 0)); m.reset_state()
+    l2 = float(opt.update(m, [imgs, acts, stas], 1))
+    assert opt.t == t0 + 2 and np.isfinite(l1) and l2 < l1                      # two Adam steps on one batch lower its loss
+    # predict entry point: model type from the directory name (predict_model.py:91-95), one rollout, uint8 frames
+    args = Pm.build_parser().parse_args([os.path.basename(save_dir), last, '1', '--models_dir', str(out), '--data_dir', str(data)])
+    loss, frames = Pm.predict(args)
+    assert frames.shape == (3, 3, 64, 64) and frames.dtype == np.uint8 and np.isfinite(loss)
+    assert frames.reshape(3, -1).min(axis=1).tolist() == [0, 0, 0] and frames.reshape(3, -1).max(axis=1).tolist() == [255, 255, 255]
