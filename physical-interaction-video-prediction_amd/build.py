@@ -15,6 +15,7 @@ STAMP = os.path.join(HERE, '.libpivp_hip.stamp')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
 if os.environ.get('PIVP_ABLATE'):   # timing-only diagnostic variants of the igemm kernel (scripts/bench_lstm_layers.py)
     FLAGS.append('-DPIVP_ABLATE')
+FLAGS += os.environ.get('PIVP_EXTRA_FLAGS', '').split()   # experiments, e.g. -DPIVP_XCD_MAP=0
 
 
 def _digest():

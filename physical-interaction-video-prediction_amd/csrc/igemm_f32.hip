@@ -41,6 +41,10 @@ namespace pivp {
 
 constexpr int IG_KC = 32;
 constexpr int IG_P = 36;  // LDS row pitch in floats (A and B tiles)
+#ifndef PIVP_XCD_MAP
+#define PIVP_XCD_MAP 1
+#endif
+constexpr bool XCD_MAP = PIVP_XCD_MAP != 0;
 
 template <int WM, int NTB>
 constexpr int ig_lds_bytes() { return 2 * (32 * WM + 32 * NTB) * IG_P * 4; }
@@ -51,7 +55,8 @@ __device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f +
 __device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 // ABL: timing-only ablations for scripts/bench_lstm_layers.py (built with -DPIVP_ABLATE; outputs are wrong):
-//   1 = no global loads and no LDS stores, 2 = loads but no LDS stores, 3 = as 1 without the barrier.
+//   1 = no global loads and no LDS stores, 2 = loads but no LDS stores, 3 = as 1 without the barrier,
+//   4 = as 2 with constant load addresses (no per-chunk address math), 5 = address math only.
 template <int WM, int WN, int NTB, bool LSTM, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
     static_assert(WM * WN == 4, "4 waves");
@@ -70,16 +75,24 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
     const int wm = wave % WM, wn = wave / WM;
     const int phase = blockIdx.y;
     const int n_nblk = LSTM ? (d.C >> 5) : (d.N / BN);
-    const int nblk = blockIdx.x % n_nblk;
-    const int mblk = blockIdx.x / n_nblk;
+    // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so block b runs
+    // on XCD b % 8.  Give XCD k the k-th CONTIGUOUS eighth of the logical tile list, ordered column-block-major: its L2
+    // then holds one column block's weights (<= 2.5 MB for every layer here) and a contiguous band of anchors whose
+    // 5x5 halos overlap each other, instead of every XCD streaming all weights and all of the image.
+    int lid = blockIdx.x;
+    if (XCD_MAP && (gridDim.x & 7) == 0) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int n_mblk = gridDim.x / n_nblk;
+    const int nblk = XCD_MAP ? lid / n_mblk : lid % n_nblk;
+    const int mblk = XCD_MAP ? lid % n_mblk : lid / n_nblk;
     const int m0 = mblk * BM;
     const int cin = d.c0 + d.c1;
     const int ncc = cin >> 5;
     const int py = phase >> 1, px = phase & 1;
     // tap set: conv K x K (rows ky, cols kx) or, for the transposed 3x3 s2 conv, the taps of output parity
     // (py, px): oy = 2*iy - 1 + ky  =>  ky = 1 (py = 0) or ky in {0, 2} (py = 1), iy = a + (py + 1 - ky)/2.
-    const int nty_all = d.deconv ? 1 + py : d.ksize;
-    const int ntx = d.deconv ? 1 + px : d.ksize;
+    const bool deconv = LSTM ? false : d.deconv != 0;
+    const int nty_all = deconv ? 1 + py : d.ksize;
+    const int ntx = deconv ? 1 + px : d.ksize;
     // optional split of K over blockIdx.z by kernel rows (data gradients of small-M layers); partial sums are atomically
     // added into a pre-zeroed output
     const int ksplit = gridDim.z;
@@ -97,7 +110,7 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x0), 0, d.bytes0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.c1 ? d.x1 : d.x0), 0, d.c1 ? d.bytes1 : d.bytes0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, d.bytesw, 0x00020000);
-    int a_pix[NA], a_iy0[NA], a_ix0[NA];      // anchor's input pixel index (b, iy0, ix0) and coords
+    int a_off0[NA], a_off1[NA], a_iy0[NA], a_ix0[NA];   // anchor pixel's byte offset in either source, and its coords
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
         const int m = m0 + prow + 32 * j;
@@ -108,9 +121,11 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
             const int ax = rem - ay * d.Wg;
             a_iy0[j] = ay * d.in_step;
             a_ix0[j] = ax * d.in_step;
-            a_pix[j] = b * d.Hin * d.Win + a_iy0[j] * d.Win + a_ix0[j];
+            const int pix = b * d.Hin * d.Win + a_iy0[j] * d.Win + a_ix0[j];
+            a_off0[j] = (pix * d.ld0 + cvec * 4) * 4;
+            a_off1[j] = (pix * d.ld1 + cvec * 4) * 4;
         } else {
-            a_pix[j] = 0;
+            a_off0[j] = a_off1[j] = 0;
             a_iy0[j] = -(1 << 20);  // never in range
             a_ix0[j] = 0;
         }
@@ -133,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
     bool s_first = true;
     auto stage_begin = [&]() {            // scalar prelude of one chunk's loads, then advance the counters
         int wi;
-        if (d.deconv) {
+        if (deconv) {
             const int ky = py ? 2 * l_ty : 1, kx = px ? 2 * l_tx : 1;
             s_dy = (py + 1 - ky) >> 1; s_dx = (px + 1 - kx) >> 1; wi = ky * 3 + kx;
         } else {
@@ -143,8 +158,12 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
         s_first = ch < d.c0;
         s_ld = s_first ? d.ld0 : d.ld1;
         const int cbase = s_first ? ch : ch - d.c0;
-        s_delta = ((s_dy * d.Win + s_dx) * s_ld + cbase) * 4;               // bytes, relative to the anchor pixel
-        s_wbase = (wi * (d.wcin >> 5) + l_cc) * d.N * 128;                   // bytes; the weight keeps all its Cin chunks
+        // (readfirstlane: carried from one chunk to the next these values lose their "uniform" proof, and a divergent
+        // soffset turns every weight load into a waterfall loop)
+        s_delta = __builtin_amdgcn_readfirstlane(((s_dy * d.Win + s_dx) * s_ld + cbase) * 4);   // bytes, relative to the anchor pixel
+        s_wbase = __builtin_amdgcn_readfirstlane((wi * (d.wcin >> 5) + l_cc) * d.N * 128);       // bytes; the weight keeps all its Cin chunks
+        s_dy = __builtin_amdgcn_readfirstlane(s_dy);
+        s_dx = __builtin_amdgcn_readfirstlane(s_dx);
         ++l_cc;
         const bool w0 = l_cc == ncc;
         l_cc = w0 ? 0 : l_cc;
@@ -159,10 +178,13 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
             const int iy = a_iy0[j] + s_dy;
             const int ix = a_ix0[j] + s_dx;
             const bool ok = (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
-            const unsigned off = ok ? (unsigned)(a_pix[j] * s_ld * 4 + s_delta + cvec * 16) : OOB;
+            unsigned off = ok ? (unsigned)((s_first ? a_off0[j] : a_off1[j]) + s_delta) : OOB;
+            if constexpr (ABL == 4) off = (unsigned)a_off0[j];                       // loads without the address math
+            if constexpr (ABL == 5) { asm volatile("" :: "v"(off)); return; }        // address math without the loads
             ra[j] = __builtin_bit_cast(f32x4, s_first ? __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0)
                                                       : __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
         } else if constexpr (j < NA + NB) {
+            if constexpr (ABL == 5) return;
             rb[j - NA] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, b_goff[j - NA], s_wbase, 0));
         }
     };
@@ -200,20 +222,40 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
     // just above their ds_writes and exposes the whole L2 round trip every chunk).
     constexpr int NST = NA + NB;
     static_assert(NST <= 8, "staging pieces must fit the 16 micro-steps twice");
+    // The scalar prelude of a chunk's loads (~25 SALU) only has one MFMA's shadow to hide in (issue is in order), so it
+    // runs in a micro-step that carries no staging piece when there is one (step NST, for the chunk AFTER the one whose
+    // loads follow); tiles that use all 8+8 staging steps keep it in front of the first load.
+    constexpr int PRE = NST < 8 ? NST : 0;
+    // Barrier placement: BAR = 16 puts the block barrier at the chunk's end.  BAR = 12 (measured, profiles/r01/NOTES.md)
+    // moves it behind micro-step 11 -- all LDS reads of the chunk are issued by step 8 and the next tile is written in
+    // steps BAR-NST .. BAR-1 -- so the next chunk's first fragments are read under this chunk's last four micro-steps.
+    // It made no difference on any layer (the second resident block already covers that latency), so the simpler
+    // placement stays.
+    constexpr int BAR = 16;
+    static_assert(BAR - NST >= 4 && BAR >= 12, "loads need distance to their ds_writes; k-group 3 is read in step 8");
+    f32x4 fa[2];
+    f32x4 fb[2][TPW];
+    auto read_frag0 = [&](int slot) {
+        fa[0] = *reinterpret_cast<const f32x4*>(lds + slot * A_FLOATS + a_off);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) fb[0][t] = *reinterpret_cast<const f32x4*>(lds + slot * B_FLOATS + b_off[t]);
+    };
     auto chunk = [&](auto STAGE, int buf) {
         constexpr bool stage = decltype(STAGE)::value && ABL != 1 && ABL != 3;
-        constexpr bool do_store = stage && ABL == 0;
+        constexpr bool do_store = stage && ABL == 0;   // ABL 2, 4, 5: no LDS stores
         const float* As = lds + buf * A_FLOATS + a_off;
         const float* Bs = lds + buf * B_FLOATS;
-        f32x4 fa[2];
-        f32x4 fb[2][TPW];
-        fa[0] = *reinterpret_cast<const f32x4*>(As);
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) fb[0][t] = *reinterpret_cast<const f32x4*>(Bs + b_off[t]);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BAR == 16) {
+            read_frag0(buf);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         auto micro = [&](auto Q, auto S2) {
             constexpr int q = decltype(Q)::value, s2 = decltype(S2)::value, step = q * 4 + s2;
             constexpr int cur = q & 1, nxt = cur ^ 1;
+            if constexpr (decltype(STAGE)::value && BAR < 16 && step == BAR) {
+                if (ABL != 3) __syncthreads();
+                read_frag0(buf ^ 1);
+            }
             if constexpr (s2 == 0 && q < 3) {
                 fa[nxt] = *reinterpret_cast<const f32x4*>(As + 8 * (q + 1));
 #pragma unroll
@@ -222,9 +264,9 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
 #pragma unroll
             for (int t = 0; t < TPW; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s2], fb[cur][t][s2], acc[t], 0, 0, 0);
-            if constexpr (stage && step == 0) stage_begin();   // scalar prelude runs in the shadow of this step's MFMAs
+            if constexpr (stage && step == PRE) stage_begin();
             if constexpr (stage && step < NST) load_piece(std::integral_constant<int, step>{});
-            if constexpr (do_store && step >= 16 - NST) store_piece(std::integral_constant<int, step - (16 - NST)>{}, buf ^ 1);
+            if constexpr (do_store && step >= BAR - NST && step < BAR) store_piece(std::integral_constant<int, step - (BAR - NST)>{}, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto qgroup = [&](auto Q) {
@@ -246,16 +288,18 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
     store_piece(std::integral_constant<int, 2>{}, 0); store_piece(std::integral_constant<int, 3>{}, 0);
     store_piece(std::integral_constant<int, 4>{}, 0); store_piece(std::integral_constant<int, 5>{}, 0);
     store_piece(std::integral_constant<int, 6>{}, 0); store_piece(std::integral_constant<int, 7>{}, 0);
+    if constexpr (PRE > 0) stage_begin();   // parameters of chunk 1, loaded while chunk 0 is consumed
     __syncthreads();
+    if constexpr (BAR < 16) read_frag0(0);
     for (int it = 0; it + 1 < nchunks; ++it) {
         chunk(std::true_type{}, it & 1);
-        if (ABL == 2) {   // keep the loaded registers alive without writing LDS
+        if (ABL == 2 || ABL == 4) {   // keep the loaded registers alive without writing LDS
 #pragma unroll
             for (int j = 0; j < NA; ++j) asm volatile("" :: "v"(ra[j]));
 #pragma unroll
             for (int j = 0; j < NB; ++j) asm volatile("" :: "v"(rb[j]));
         }
-        if (ABL != 3) __syncthreads();
+        if (BAR == 16 && ABL != 3) __syncthreads();
     }
     chunk(std::false_type{}, (nchunks - 1) & 1);
     }
@@ -290,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
             }
         }
     } else {
-        const int oy0 = d.deconv ? py : 0, ox0 = d.deconv ? px : 0;
+        const int oy0 = deconv ? py : 0, ox0 = deconv ? px : 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -364,6 +408,18 @@ int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant) {
         if (variant == 11) return launch_igemm<4, 1, 4, true, 1>(d, stream);
         if (variant == 12) return launch_igemm<4, 1, 4, true, 2>(d, stream);
         return launch_igemm<4, 1, 4, true, 3>(d, stream);
+    }
+    if (variant >= 21 && variant <= 23) {   // the same ablations on the 2x2 tile
+        if (variant == 21) return launch_igemm<2, 2, 4, true, 1>(d, stream);
+        if (variant == 22) return launch_igemm<2, 2, 4, true, 2>(d, stream);
+        return launch_igemm<2, 2, 4, true, 3>(d, stream);
+    }
+    if (variant == 24) return launch_igemm<2, 2, 4, true, 4>(d, stream);
+    if (variant == 25) return launch_igemm<2, 2, 4, true, 5>(d, stream);
+    if (variant >= 31 && variant <= 33) {   // ... and on the 1x4 tile
+        if (variant == 31) return launch_igemm<1, 4, 4, true, 1>(d, stream);
+        if (variant == 32) return launch_igemm<1, 4, 4, true, 2>(d, stream);
+        return launch_igemm<1, 4, 4, true, 3>(d, stream);
     }
 #endif
     if (variant == 0) {

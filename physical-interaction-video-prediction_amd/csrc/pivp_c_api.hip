@@ -178,7 +178,7 @@ extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_pre
 }
 extern "C" int pivp_convlstm_v(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                                const float* c_in, float* c_out, float* h_out, int B, int H, int W, int variant, void* stream) {
-    if (!x || !w || !bias || !c_in || !c_out || !h_out || variant < 0 || variant > 13) return PIVP_ERR_BADARG;
+    if (!x || !w || !bias || !c_in || !c_out || !h_out || variant < 0 || variant > 33) return PIVP_ERR_BADARG;
     return run_convlstm(x, cx, ldx, h_prev, C, w, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, variant);
 }
 extern "C" int pivp_convlstm_train(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
