@@ -112,6 +112,16 @@ int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, c
 int pivp_convlstm_v(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                     const float* c_in, float* c_out, float* h_out, int B, int H, int W, int variant, void* stream);
 
+/* hidden = norm(lstm(x)) as the reference writes it at TM:596-601: the ConvLSTM above followed by its
+ * LayerNormalizationConv2D, with the per-sample statistics taken from the ConvLSTM kernel's epilogue (one (count, mean,
+ * M2) partial per block tile) instead of a second pass over h.  ln_out NHWC with pixel stride ldo; partials: scratch of
+ * pivp_convlstm_ln_scratch_floats(B,H,W,C) floats; *fused (optional) receives 1 when the statistics were fused, 0 when the
+ * tile shape made the call fall back to the separate statistics pass (same result either way). */
+long long pivp_convlstm_ln_scratch_floats(int B, int H, int W, int C);
+int pivp_convlstm_ln(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
+                     const float* c_in, float* c_out, float* h_out, const float* gamma, const float* beta, float* ln_out,
+                     int ldo, float* partials, float eps, int B, int H, int W, int variant, int* fused, void* stream);
+
 /* --- training (what Chainer's autograd does under optimizer.update, TM:950) ---------------------------------- */
 /* pivp_convlstm with the gate activations kept for BPTT: gates_out [B*H*W][4C] = tanh(j), s(i), s(f+1), s(o). */
 int pivp_convlstm_train(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,

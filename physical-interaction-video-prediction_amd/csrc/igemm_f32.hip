@@ -305,14 +305,45 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
     }
 
     // ---- epilogue --------------------------------------------------------------------------
+    // (count, mean, M2) of the block's output tile, two passes over the values held in registers, fixed summation
+    // order (bitwise reproducible); written as one LayerNorm partial of sample b.
+    auto tile_stats = [&](const float* v, auto ownmask, auto NV, int b, int slot) {
+        constexpr int nv = decltype(NV)::value;
+        float s1 = 0.f, c1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < nv; ++i)
+            if ((ownmask >> i) & 1) { s1 += v[i]; c1 += 1.f; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); c1 += __shfl_xor(c1, off, 64); }
+        __syncthreads();   // every wave is past its last LDS tile read: the tiles are dead, reuse their space
+        if (lane == 0) { lds[wave] = s1; lds[4 + wave] = c1; }
+        __syncthreads();
+        const float cnt = (lds[4] + lds[5]) + (lds[6] + lds[7]);
+        const float mean = ((lds[0] + lds[1]) + (lds[2] + lds[3])) / cnt;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < nv; ++i)
+            if ((ownmask >> i) & 1) { const float dd = v[i] - mean; q = fmaf(dd, dd, q); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+        if (lane == 0) lds[8 + wave] = q;
+        __syncthreads();
+        if (tid == 0) {
+            float* p = d.ln_part + ((size_t)b * d.ln_nparts + slot) * 4;
+            p[0] = cnt; p[1] = mean; p[2] = (lds[8] + lds[9]) + (lds[10] + lds[11]); p[3] = 0.f;
+        }
+    };
     if (LSTM) {
         const int C = d.C;
         const int chl = wn * CPW + (l31 % CPW);
         const int ch = nblk * 32 + chl;
         const int grp = l31 / CPW;  // which gate-group of the tile this lane's column belongs to
         const float bj = d.bias[ch], bi = d.bias[C + ch], bf = d.bias[2 * C + ch] + 1.0f, bo = d.bias[3 * C + ch];
+        float sv[16];          // this lane's h values (0 where it owns none), for the fused LayerNorm statistics
+        unsigned own = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+            sv[r] = 0.f;
             float g4[4];
 #pragma unroll
             for (int G = 0; G < 4; ++G) {
@@ -326,15 +357,23 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
                 const float af = fast_sigmoid(g4[2] + bf), ao = fast_sigmoid(g4[3] + bo);
                 const float cn = d.cstate_in[o] * af + ai * aj;
                 d.cstate_out[o] = cn;
-                d.hout[o] = fast_tanh(cn) * ao;
+                const float hn = fast_tanh(cn) * ao;
+                d.hout[o] = hn;
+                sv[r] = hn; own |= 1u << r;
                 if (d.gates_out) {   // training: keep the gate activations for BPTT, [pixel][gate][C]
                     float* gp = d.gates_out + (size_t)m * 4 * C + ch;
                     gp[0] = aj; gp[C] = ai; gp[2 * C] = af; gp[3 * C] = ao;
                 }
             }
         }
+        if (d.ln_part) {
+            const int b = m0 / HWg;
+            tile_stats(sv, own, std::integral_constant<int, 16>{}, b, ((m0 - b * HWg) / BM) * n_nblk + nblk);
+        }
     } else {
         const int oy0 = deconv ? py : 0, ox0 = deconv ? px : 0;
+        float sv[16 * TPW];
+        unsigned long long own = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -354,15 +393,21 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
                         if (d.relu) v = fmaxf(v, 0.f);
                         if (d.accum) v += d.out[o + col];
                         d.out[o + col] = v;
+                        sv[t * 16 + r] = v; own |= 1ull << (t * 16 + r);
                     }
                 }
             }
+        }
+        if (d.ln_part) {
+            const int b = m0 / HWg;
+            tile_stats(sv, own, std::integral_constant<int, 16 * TPW>{}, b,
+                       (((m0 - b * HWg) / BM) * n_nblk + nblk) * (int)gridDim.y + phase);
         }
     }
 }
 
 template <int WM, int WN, int NTB, bool LSTM, int ABL = 0>
-static int launch_igemm(const IgemmDesc& d, hipStream_t stream, int ksplit = 1) {
+static int launch_igemm(const IgemmDesc& d, hipStream_t stream, int ksplit = 1, int* ln_nparts = nullptr) {
     constexpr int BM = 32 * WM, BN = 32 * NTB;
     const int n_nblk = LSTM ? (d.C >> 5) : (d.N / BN);
     const int mblk = (d.M + BM - 1) / BM;
@@ -374,7 +419,14 @@ static int launch_igemm(const IgemmDesc& d, hipStream_t stream, int ksplit = 1) 
         attr_set = true;
     }
     dim3 grid(mblk * n_nblk, d.nphase, ksplit);
-    hipLaunchKernelGGL((igemm_f32_kernel<WM, WN, NTB, LSTM, ABL>), grid, dim3(256), lds_bytes, stream, d);
+    IgemmDesc dd = d;
+    // fused LayerNorm partials: only when no tile straddles two samples and the caller's buffer holds them
+    const int hwg = d.Hg * d.Wg;
+    const int np = (hwg / BM) * n_nblk * d.nphase;
+    dd.ln_nparts = (d.ln_part && ksplit == 1 && hwg % BM == 0 && np <= d.ln_cap) ? np : 0;
+    if (!dd.ln_nparts) dd.ln_part = nullptr;
+    if (ln_nparts) *ln_nparts = dd.ln_nparts;
+    hipLaunchKernelGGL((igemm_f32_kernel<WM, WN, NTB, LSTM, ABL>), grid, dim3(256), lds_bytes, stream, dd);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -400,26 +452,26 @@ int igemm_validate(const IgemmDesc& d, bool lstm) {
 
 // Tile choice: the largest block tile that still gives every one of the 256 CUs a block.
 // variant 0 = auto, 1 = 4x1 waves (BM 128), 2 = 2x2 (BM 64), 3 = 1x4 (BM 32).
-int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant) {
+int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant, int* ln_nparts) {
     int rc = igemm_validate(d, true);
     if (rc != PIVP_OK) return rc;
 #ifdef PIVP_ABLATE
     if (variant >= 11 && variant <= 13) {   // timing-only diagnostic builds of the 4x1 tile (outputs are wrong)
-        if (variant == 11) return launch_igemm<4, 1, 4, true, 1>(d, stream);
-        if (variant == 12) return launch_igemm<4, 1, 4, true, 2>(d, stream);
-        return launch_igemm<4, 1, 4, true, 3>(d, stream);
+        if (variant == 11) return launch_igemm<4, 1, 4, true, 1>(d, stream, 1, ln_nparts);
+        if (variant == 12) return launch_igemm<4, 1, 4, true, 2>(d, stream, 1, ln_nparts);
+        return launch_igemm<4, 1, 4, true, 3>(d, stream, 1, ln_nparts);
     }
     if (variant >= 21 && variant <= 23) {   // the same ablations on the 2x2 tile
-        if (variant == 21) return launch_igemm<2, 2, 4, true, 1>(d, stream);
-        if (variant == 22) return launch_igemm<2, 2, 4, true, 2>(d, stream);
-        return launch_igemm<2, 2, 4, true, 3>(d, stream);
+        if (variant == 21) return launch_igemm<2, 2, 4, true, 1>(d, stream, 1, ln_nparts);
+        if (variant == 22) return launch_igemm<2, 2, 4, true, 2>(d, stream, 1, ln_nparts);
+        return launch_igemm<2, 2, 4, true, 3>(d, stream, 1, ln_nparts);
     }
-    if (variant == 24) return launch_igemm<2, 2, 4, true, 4>(d, stream);
-    if (variant == 25) return launch_igemm<2, 2, 4, true, 5>(d, stream);
+    if (variant == 24) return launch_igemm<2, 2, 4, true, 4>(d, stream, 1, ln_nparts);
+    if (variant == 25) return launch_igemm<2, 2, 4, true, 5>(d, stream, 1, ln_nparts);
     if (variant >= 31 && variant <= 33) {   // ... and on the 1x4 tile
-        if (variant == 31) return launch_igemm<1, 4, 4, true, 1>(d, stream);
-        if (variant == 32) return launch_igemm<1, 4, 4, true, 2>(d, stream);
-        return launch_igemm<1, 4, 4, true, 3>(d, stream);
+        if (variant == 31) return launch_igemm<1, 4, 4, true, 1>(d, stream, 1, ln_nparts);
+        if (variant == 32) return launch_igemm<1, 4, 4, true, 2>(d, stream, 1, ln_nparts);
+        return launch_igemm<1, 4, 4, true, 3>(d, stream, 1, ln_nparts);
     }
 #endif
     if (variant == 0) {
@@ -431,15 +483,15 @@ int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant) {
         else variant = 3;
     }
     switch (variant) {
-        case 1: return launch_igemm<4, 1, 4, true>(d, stream);
-        case 2: return launch_igemm<2, 2, 4, true>(d, stream);
-        case 3: return launch_igemm<1, 4, 4, true>(d, stream);
+        case 1: return launch_igemm<4, 1, 4, true>(d, stream, 1, ln_nparts);
+        case 2: return launch_igemm<2, 2, 4, true>(d, stream, 1, ln_nparts);
+        case 3: return launch_igemm<1, 4, 4, true>(d, stream, 1, ln_nparts);
     }
     return PIVP_ERR_BADARG;
 }
 
 // Plain conv / transposed conv: pick the block tile that fills the 256 CUs.  Blocks = (M/BM) * (N/BN) * phases.
-int igemm_conv(const IgemmDesc& d, hipStream_t stream) {
+int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     int rc = igemm_validate(d, false);
     if (rc != PIVP_OK) return rc;
     const int nt = d.N / 32;
@@ -451,33 +503,33 @@ int igemm_conv(const IgemmDesc& d, hipStream_t stream) {
             const long blocks = (long)((d.M + 63) / 64) * (nt / 2);
             int ks = blocks >= 256 ? 1 : (int)((256 + blocks - 1) / blocks);
             if (ks > d.ksize) ks = d.ksize;
-            return launch_igemm<2, 2, 2, false>(d, stream, ks);
+            return launch_igemm<2, 2, 2, false>(d, stream, ks, ln_nparts);
         } else {
             const long blocks = full * nt;
             int ks = blocks >= 256 ? 1 : (int)((256 + blocks - 1) / blocks);
             if (ks > d.ksize) ks = d.ksize;
-            return launch_igemm<4, 1, 1, false>(d, stream, ks);
+            return launch_igemm<4, 1, 1, false>(d, stream, ks, ln_nparts);
         }
     }
     if (nt > 4) {                                             // wide outputs: several column blocks
-        if (nt % 4 == 0) return full * (nt / 4) >= 256 ? launch_igemm<4, 1, 4, false>(d, stream) : launch_igemm<2, 2, 4, false>(d, stream);
-        if (nt % 3 == 0) return launch_igemm<4, 1, 3, false>(d, stream);
-        if (nt % 2 == 0) return full * (nt / 2) >= 256 ? launch_igemm<4, 1, 2, false>(d, stream) : launch_igemm<2, 2, 2, false>(d, stream);
-        return launch_igemm<4, 1, 1, false>(d, stream);
+        if (nt % 4 == 0) return full * (nt / 4) >= 256 ? launch_igemm<4, 1, 4, false>(d, stream, 1, ln_nparts) : launch_igemm<2, 2, 4, false>(d, stream, 1, ln_nparts);
+        if (nt % 3 == 0) return launch_igemm<4, 1, 3, false>(d, stream, 1, ln_nparts);
+        if (nt % 2 == 0) return full * (nt / 2) >= 256 ? launch_igemm<4, 1, 2, false>(d, stream, 1, ln_nparts) : launch_igemm<2, 2, 2, false>(d, stream, 1, ln_nparts);
+        return launch_igemm<4, 1, 1, false>(d, stream, 1, ln_nparts);
     }
     if (full >= 256) {
         switch (nt) {
-            case 1: return launch_igemm<4, 1, 1, false>(d, stream);
-            case 2: return launch_igemm<4, 1, 2, false>(d, stream);
-            case 3: return launch_igemm<4, 1, 3, false>(d, stream);
-            case 4: return launch_igemm<4, 1, 4, false>(d, stream);
+            case 1: return launch_igemm<4, 1, 1, false>(d, stream, 1, ln_nparts);
+            case 2: return launch_igemm<4, 1, 2, false>(d, stream, 1, ln_nparts);
+            case 3: return launch_igemm<4, 1, 3, false>(d, stream, 1, ln_nparts);
+            case 4: return launch_igemm<4, 1, 4, false>(d, stream, 1, ln_nparts);
         }
         return PIVP_ERR_BADARG;
     }
-    if (nt == 4 && full * 2 < 256) return launch_igemm<1, 4, 4, false>(d, stream);   // BM 32
-    if (nt == 4) return launch_igemm<2, 2, 4, false>(d, stream);                      // BM 64
-    if (nt == 2 && full * 2 >= 128) return launch_igemm<2, 2, 2, false>(d, stream);  // BM 64
-    return launch_igemm<4, 1, 1, false>(d, stream);                                    // BN 32: N/32 column blocks
+    if (nt == 4 && full * 2 < 256) return launch_igemm<1, 4, 4, false>(d, stream, 1, ln_nparts);   // BM 32
+    if (nt == 4) return launch_igemm<2, 2, 4, false>(d, stream, 1, ln_nparts);                      // BM 64
+    if (nt == 2 && full * 2 >= 128) return launch_igemm<2, 2, 2, false>(d, stream, 1, ln_nparts);  // BM 64
+    return launch_igemm<4, 1, 1, false>(d, stream, 1, ln_nparts);                                    // BN 32: N/32 column blocks
 }
 
 }  // namespace pivp

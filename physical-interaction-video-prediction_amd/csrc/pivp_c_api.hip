@@ -18,7 +18,7 @@ bool fits31(long long v) { return v > 0 && v < (1LL << 31); }
 
 int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                  const float* c_in, float* c_out, float* h_out, int B, int H, int W, hipStream_t s, int variant,
-                 float* gates_out) {
+                 float* gates_out, float* ln_part, int ln_cap, int* ln_nparts) {
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
     // h_prev == nullptr: the recurrent input is identically zero (first timestep after reset_state, TM:254-257);
@@ -33,7 +33,8 @@ int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, co
     d.bytes0 = (int)b0; d.bytes1 = (int)b1; d.bytesw = (int)bw;
     d.out_step = 1; d.Hout = H; d.Wout = W;
     d.cstate_in = c_in; d.cstate_out = c_out; d.hout = h_out; d.C = C; d.gates_out = gates_out;
-    return igemm_lstm(d, s, variant);
+    d.ln_part = ln_part; d.ln_cap = ln_cap;
+    return igemm_lstm(d, s, variant, ln_nparts);
 }
 
 int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
@@ -53,7 +54,8 @@ int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float*
 }
 
 int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
-                    int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum) {
+                    int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum, float* ln_part, int ln_cap,
+                    int* ln_nparts) {
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
     d.x0 = x; d.c0 = cin; d.ld0 = ldx; d.wcin = cin; d.w = w; d.bias = bias;
@@ -64,7 +66,8 @@ int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const floa
     if (!fits31(b0) || !fits31(bw)) return PIVP_ERR_BADARG;
     d.bytes0 = (int)b0; d.bytesw = (int)bw;
     d.out_step = 2; d.Hout = 2 * Hin; d.Wout = 2 * Win; d.out = out; d.ldo = ldo; d.relu = relu; d.accum = accum;
-    return igemm_conv(d, s);
+    d.ln_part = ln_part; d.ln_cap = ln_cap;
+    return igemm_conv(d, s, ln_nparts);
 }
 
 // stride-1 K x K "same" convolution through the generic kernel (used as the ConvLSTM data gradient)
@@ -124,10 +127,13 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
 }
 
 int run_layernorm(const float* x, const float* g, const float* b, float* out, float* partials, int B, int n, int C,
-                  int ldo, float eps, int relu, hipStream_t s, float* stat_out) {
-    int rc = ln_stats(x, partials, B, n, s);
-    if (rc != PIVP_OK) return rc;
-    return ln_apply(x, partials, g, b, out, B, n, C, ldo, eps, relu, s, stat_out);
+                  int ldo, float eps, int relu, hipStream_t s, float* stat_out, int fused_nparts) {
+    // fused_nparts > 0: the kernel that produced x already wrote that many (count, mean, M2) partials per sample
+    if (fused_nparts <= 0) {
+        int rc = ln_stats(x, partials, B, n, s);
+        if (rc != PIVP_OK) return rc;
+    }
+    return ln_apply(x, partials, g, b, out, B, n, C, ldo, eps, relu, s, stat_out, fused_nparts);
 }
 
 __global__ __launch_bounds__(256) void select_frames_kernel(const float* __restrict__ gt, const float* __restrict__ gen,
@@ -206,6 +212,28 @@ extern "C" int pivp_layernorm_train(const float* x, const float* gamma, const fl
                                     int B, int n, int C, int ldo, float eps, int relu, void* stream) {
     if (!stat) return PIVP_ERR_BADARG;
     return run_layernorm(x, gamma, beta, out, partials, B, n, C, ldo, eps, relu, (hipStream_t)stream, stat);
+}
+static int convlstm_ln_cap(int H, int W, int C) {
+    const int tiles = ((H * W + 31) / 32) * (C / 32), slices = ln_stats_slices(H * W * C);
+    return tiles > slices ? tiles : slices;
+}
+extern "C" long long pivp_convlstm_ln_scratch_floats(int B, int H, int W, int C) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 32) return PIVP_ERR_BADARG;
+    return (long long)B * convlstm_ln_cap(H, W, C) * 4;
+}
+extern "C" int pivp_convlstm_ln(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
+                                const float* c_in, float* c_out, float* h_out, const float* gamma, const float* beta,
+                                float* ln_out, int ldo, float* partials, float eps, int B, int H, int W, int variant, int* fused,
+                                void* stream) {
+    if (!x || !w || !bias || !c_in || !c_out || !h_out || !gamma || !beta || !ln_out || !partials || variant < 0 || variant > 3)
+        return PIVP_ERR_BADARG;
+    if (C <= 0 || C % 32) return PIVP_ERR_BADARG;
+    int np = 0;
+    int rc = run_convlstm(x, cx, ldx, h_prev, C, w, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, variant, nullptr,
+                          partials, convlstm_ln_cap(H, W, C), &np);
+    if (rc != PIVP_OK) return rc;
+    if (fused) *fused = np > 0;
+    return run_layernorm(h_out, gamma, beta, ln_out, partials, B, H * W * C, C, ldo, eps, 0, (hipStream_t)stream, nullptr, np);
 }
 extern "C" long long pivp_layernorm_backward_scratch_floats(int B, int n) {
     if (B <= 0 || n <= 0) return PIVP_ERR_BADARG;

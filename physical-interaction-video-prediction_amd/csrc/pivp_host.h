@@ -8,11 +8,12 @@ long long view_bytes(int B, int H, int W, int ld);
 bool fits31(long long v);
 int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                  const float* c_in, float* c_out, float* h_out, int B, int H, int W, hipStream_t s, int variant = 0,
-                 float* gates_out = nullptr);
+                 float* gates_out = nullptr, float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr);
 int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                   int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0);
 int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
-                    int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0);
+                    int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0,
+                    float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr);
 int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, int cout, int ldo, int ksize, int B, int H, int W,
                 hipStream_t s, int accum = 0);
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
@@ -25,7 +26,7 @@ int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w
                       float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, hipStream_t s,
                       int wt_ready = 0);
 int run_layernorm(const float* x, const float* g, const float* b, float* out, float* partials, int B, int n, int C,
-                  int ldo, float eps, int relu, hipStream_t s, float* stat_out = nullptr);
+                  int ldo, float eps, int relu, hipStream_t s, float* stat_out = nullptr, int fused_nparts = 0);
 int run_select_frames(const float* gt, const float* gen, const unsigned char* take, float* out, int B, int frame_numel, hipStream_t s);
 
 }  // namespace pivp

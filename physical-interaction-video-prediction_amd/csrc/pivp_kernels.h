@@ -32,6 +32,10 @@ struct IgemmDesc {
     // ConvLSTM epilogue
     const float* cstate_in; float* cstate_out; float* hout; int C;
     float* gates_out;                    // optional [M][4C]: tanh(j), sigma(i), sigma(f+1), sigma(o) for the backward pass
+    // LayerNorm statistics of the OUTPUT, fused into the epilogue (the norm that follows every ConvLSTM and enc6, TM:595-601):
+    // each block writes (count, mean, M2) of its tile to ln_part[(b * ln_nparts + slot) * 4]; ln_apply merges them.
+    // The launcher fills ln_nparts (0 = tiles straddle samples or exceed ln_cap: not fused, run ln_stats instead).
+    float* ln_part; int ln_cap; int ln_nparts;
 };
 
 // weight gradient of a conv / transposed conv (csrc/igemm_wgrad.hip)
@@ -48,8 +52,9 @@ struct WgradDesc {
 int igemm_wgrad(const WgradDesc& d, hipStream_t s);
 int repack_transpose(const float* w, float* wt, int taps, int cin, int N, int flip, hipStream_t s);
 
-int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant = 0);  // 0 auto, 1: 4x1 waves, 2: 2x2, 3: 1x4
-int igemm_conv(const IgemmDesc& d, hipStream_t stream);
+// ln_nparts (optional): receives the number of LayerNorm partials per sample the launch writes to d.ln_part (0: none)
+int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant = 0, int* ln_nparts = nullptr);  // 0 auto, 1: 4x1 waves, 2: 2x2, 3: 1x4
+int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr);
 
 // enc0: 5x5 stride-2 pad-2 conv on a planar 3-channel frame -> NHWC 32 channels (TM:500)
 int conv_enc0(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s);
@@ -58,7 +63,8 @@ int conv_enc0(const float* img, const float* w, const float* bias, float* out, i
 int ln_stats_slices(int n);  // number of partial slices per sample for n elements
 int ln_stats(const float* x, float* partials, int B, int n, hipStream_t s);
 int ln_apply(const float* x, const float* partials, const float* gamma, const float* beta, float* out,
-             int B, int n, int C, int ldo, float eps, int relu, hipStream_t s, float* stat_out = nullptr);
+             int B, int n, int C, int ldo, float eps, int relu, hipStream_t s, float* stat_out = nullptr,
+             int nparts = 0);   // nparts > 0: `partials` holds that many producer-written partials per sample
 
 // enc3: smear(action,state) + 1x1 conv + ReLU (TM:556-567, TM:503) and the state predictor (TM:730)
 int enc3_state(const float* e2, const float* action, const float* state, const float* w3, const float* b3,

@@ -226,11 +226,15 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     const bool train = c.keep_activations != 0;
     auto hp = [&](int i) -> const float* { return Sp ? ws + Sp->h[i] : nullptr; };   // t = 0: h == 0, skipped
     auto cp = [&](int i) { return Sp ? ws + Sp->c[i] : ws + p->o_zero; };
+    const int ln_cap = ln_stats_slices(64 * H * W);   // partial slots per sample in lnp (see the workspace carve)
+    int np = 0;
     auto lstm = [&](int i, const float* x, int ldx, int hh, int wwid) {
         const bool prof = p->prof_on && p->prof_used + 2 <= p->prof_ev.size();
         if (prof) (void)hipEventRecord(p->prof_ev[p->prof_used], s);
+        // the LayerNorm behind every ConvLSTM gets its statistics from the ConvLSTM epilogue (np partials per sample)
         int rc = run_convlstm(x, kLstm[i].cx, ldx, hp(i), kLstm[i].C, P(p, p->i_lstm_w[i]), P(p, p->i_lstm_b[i]),
-                              cp(i), ws + S.c[i], ws + S.h[i], B, hh, wwid, s, 0, train ? ws + S.gates[i] : nullptr);
+                              cp(i), ws + S.c[i], ws + S.h[i], B, hh, wwid, s, 0, train ? ws + S.gates[i] : nullptr,
+                              lnp, ln_cap, &np);
         if (prof) {
             (void)hipEventRecord(p->prof_ev[p->prof_used + 1], s);
             p->prof_layer[p->prof_used / 2] = i + (Sp ? 0 : 8);   // +8: first-step launch without the h half of K
@@ -238,43 +242,44 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
         }
         return rc;
     };
-    auto ln = [&](int j, const float* x, float* out, int n, int C, int ldo, int relu) {
+    auto ln = [&](int j, const float* x, float* out, int n, int C, int ldo, int relu, int fused_nparts) {
         return run_layernorm(x, P(p, p->i_ln_g[j]), P(p, p->i_ln_b[j]), out, lnp, B, n, C, ldo, eps, relu, s,
-                             ws + S.lnstat + (size_t)j * B * 2);
+                             ws + S.lnstat + (size_t)j * B * 2, fused_nparts);
     };
     const int n2 = 32 * p->H2 * p->W2, n4 = 64 * p->H4 * p->W4, n8 = 128 * p->H8 * p->W8;
 
     // group 0 (TM:595): enc0 -> norm_enc0 -> relu   => cat7[:, 32:64]
     RC(conv_enc0(prev, P(p, p->i_enc_w[0]), P(p, p->i_enc_b[0]), ws + S.e0raw, B, H, W, s));
-    RC(ln(0, ws + S.e0raw, ws + S.cat7 + 32, n2, 32, 64, 1));
+    RC(ln(0, ws + S.e0raw, ws + S.cat7 + 32, n2, 32, 64, 1, 0));
     // group 1 (TM:596): lstm1 -> hidden1 -> lstm2 -> hidden2 -> enc1 -> relu  => cat6[:, 64:96]
     RC(lstm(0, ws + S.cat7 + 32, 64, p->H2, p->W2));
-    RC(ln(1, ws + S.h[0], ws + S.n1, n2, 32, 32, 0));
+    RC(ln(1, ws + S.h[0], ws + S.n1, n2, 32, 32, 0, np));
     RC(lstm(1, ws + S.n1, 32, p->H2, p->W2));
-    RC(ln(2, ws + S.h[1], ws + S.n2, n2, 32, 32, 0));
+    RC(ln(2, ws + S.h[1], ws + S.n2, n2, 32, 32, 0, np));
     RC(run_conv3x3s2(ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), P(p, p->i_enc_b[1]), ws + S.cat6 + 64, 32, 96, 1, B, p->H2, p->W2, s));
     // group 2 (TM:597)
     RC(lstm(2, ws + S.cat6 + 64, 96, p->H4, p->W4));
-    RC(ln(3, ws + S.h[2], ws + S.n3, n4, 64, 64, 0));
+    RC(ln(3, ws + S.h[2], ws + S.n3, n4, 64, 64, 0, np));
     RC(lstm(3, ws + S.n3, 64, p->H4, p->W4));
-    RC(ln(4, ws + S.h[3], ws + S.n4, n4, 64, 64, 0));
+    RC(ln(4, ws + S.h[3], ws + S.n4, n4, 64, 64, 0, np));
     RC(run_conv3x3s2(ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), P(p, p->i_enc_b[2]), ws + S.e2, 64, 64, 1, B, p->H4, p->W4, s));
     // group 3 (TM:598) + state predictor (TM:730)
     RC(enc3_state(ws + S.e2, action, state_prev, P(p, p->i_enc_w[3]), P(p, p->i_enc_b[3]), P(p, p->i_cs_w), P(p, p->i_cs_b),
                   ws + S.e3, state_out, B, p->H8 * p->W8, c.use_state, s));
     // group 4 (TM:599)
     RC(lstm(4, ws + S.e3, 64, p->H8, p->W8));
-    RC(ln(5, ws + S.h[4], ws + S.n5, n8, 128, 128, 0));
+    RC(ln(5, ws + S.h[4], ws + S.n5, n8, 128, 128, 0, np));
     RC(run_deconv3x3s2(ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), P(p, p->i_enc_b[4]), ws + S.e4, 128, 128, 1, B, p->H8, p->W8, s));
     // group 5 (TM:600): lstm6 -> hidden6 -> concat(., enc1) -> enc5 -> relu
     RC(lstm(5, ws + S.e4, 128, p->H4, p->W4));
-    RC(ln(6, ws + S.h[5], ws + S.cat6, n4, 64, 96, 0));
+    RC(ln(6, ws + S.h[5], ws + S.cat6, n4, 64, 96, 0, np));
     RC(run_deconv3x3s2(ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), P(p, p->i_enc_b[5]), ws + S.e5, 96, 96, 1, B, p->H4, p->W4, s));
     // group 6 (TM:601): lstm7 -> hidden7 -> concat(., enc0) -> enc6 -> norm_enc6 -> relu
     RC(lstm(6, ws + S.e5, 96, p->H2, p->W2));
-    RC(ln(7, ws + S.h[6], ws + S.cat7, n2, 32, 64, 0));
-    RC(run_deconv3x3s2(ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), P(p, p->i_enc_b[6]), ws + S.e6raw, 64, 64, 0, B, p->H2, p->W2, s));
-    RC(ln(8, ws + S.e6raw, ws + S.e6, 64 * H * W, 64, 64, 1));
+    RC(ln(7, ws + S.h[6], ws + S.cat7, n2, 32, 64, 0, np));
+    RC(run_deconv3x3s2(ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), P(p, p->i_enc_b[6]), ws + S.e6raw, 64, 64, 0, B, p->H2, p->W2, s, 0,
+                       lnp, ln_cap, &np));
+    RC(ln(8, ws + S.e6raw, ws + S.e6, 64 * H * W, 64, 64, 1, np));
     // heads (TM:711-728)
     RC(heads_1x1(ws + S.e6, P(p, p->i_masks_w), P(p, p->i_masks_b), P(p, p->i_enc7_w), P(p, p->i_enc7_b),
                  ws + S.logits, ws + S.enc7, ws + S.layer0, B, H * W, p->NP, p->NE, c.model_type, s));

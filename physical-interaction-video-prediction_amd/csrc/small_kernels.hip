@@ -112,9 +112,9 @@ int ln_stats(const float* x, float* partials, int B, int n, hipStream_t s) {
 __global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__ x, const float* __restrict__ partials,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ out, int n, int C, int ldo, float eps, int relu,
-                                                       float* __restrict__ stat_out) {
+                                                       float* __restrict__ stat_out, int S) {
     __shared__ float stat[2];
-    const int s = blockIdx.x, b = blockIdx.y, S = gridDim.x;
+    const int s = blockIdx.x, b = blockIdx.y;   // S partials per sample: ln_stats slices, or the tiles of a producer
     if (threadIdx.x < 64) {
         float cn = 0.f, mean = 0.f, m2 = 0.f;
         for (int i = threadIdx.x; i < S; i += 64) {
@@ -162,11 +162,11 @@ __global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__
 }
 
 int ln_apply(const float* x, const float* partials, const float* gamma, const float* beta, float* out,
-             int B, int n, int C, int ldo, float eps, int relu, hipStream_t s, float* stat_out) {
+             int B, int n, int C, int ldo, float eps, int relu, hipStream_t s, float* stat_out, int nparts) {
     PIVP_CHECK_ARG(x && partials && gamma && beta && out && B > 0 && n > 0 && C > 0 && C % 4 == 0 && n % C == 0);
-    PIVP_CHECK_ARG(ldo >= C && ldo % 4 == 0);
+    PIVP_CHECK_ARG(ldo >= C && ldo % 4 == 0 && nparts >= 0);
     hipLaunchKernelGGL(ln_apply_kernel, dim3(ln_stats_slices(n), B), dim3(256), 0, s,
-                       x, partials, gamma, beta, out, n, C, ldo, eps, relu, stat_out);
+                       x, partials, gamma, beta, out, n, C, ldo, eps, relu, stat_out, nparts > 0 ? nparts : ln_stats_slices(n));
     return PIVP_LAUNCH_STATUS();
 }
 

@@ -38,6 +38,26 @@ def convlstm(x, h, c, W, b, variant=0, h_is_zero=False):
     return nchw(h_out, B, H, Wd, C), nchw(c_out, B, H, Wd, C)
 
 
+def convlstm_ln(x, h, c, W, b, gamma, beta, eps, variant=0):
+    """hidden = norm(lstm(x)) with the LayerNorm statistics from the ConvLSTM epilogue; returns (ln(h), h, c, fused)."""
+    import ctypes
+    lib = _lib.load()
+    B, cx, H, Wd = x.shape
+    C = h.shape[1]
+    xd, hd, cd = nhwc(x), nhwc(h), nhwc(c)
+    wd, bd = _t(pivp_amd.to_internal('lstm1/conv/W', W)), _t(b)
+    perm = lambda v: _t(np.asarray(v).reshape(C, H * Wd).T)
+    gd, betad = perm(gamma), perm(beta)
+    c_out = torch.empty_like(cd); h_out = torch.empty_like(hd); ln_out = torch.empty_like(hd)
+    scratch = torch.empty(lib.pivp_convlstm_ln_scratch_floats(B, H, Wd, C), dtype=torch.float32, device=DEV)
+    fused = ctypes.c_int(-1)
+    _lib.check(lib.pivp_convlstm_ln(xd.data_ptr(), cx, cx, hd.data_ptr(), C, wd.data_ptr(), bd.data_ptr(), cd.data_ptr(),
+                                    c_out.data_ptr(), h_out.data_ptr(), gd.data_ptr(), betad.data_ptr(), ln_out.data_ptr(), C,
+                                    scratch.data_ptr(), eps, B, H, Wd, variant, ctypes.addressof(fused), stream()), 'convlstm_ln')
+    torch.cuda.synchronize()
+    return nchw(ln_out, B, H, Wd, C), nchw(h_out, B, H, Wd, C), nchw(c_out, B, H, Wd, C), fused.value
+
+
 def conv3x3s2(x, W, b, relu):
     lib = _lib.load()
     B, cin, H, Wd = x.shape

@@ -51,6 +51,31 @@ def test_convlstm_first_step_skips_zero_h(ops, variant):
     assert np.array_equal(hg, hz) and np.array_equal(cg, cz)      # skipping adds exact zeros: bit-identical
 
 
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
+@pytest.mark.parametrize('B,cx,C,H,expect_fused', [(2, 32, 32, 32, True), (3, 64, 128, 8, None), (2, 32, 64, 16, True),
+                                                   (2, 32, 32, 6, False)])
+def test_convlstm_layernorm_fused_stats(ops, B, cx, C, H, variant, expect_fused):
+    # hidden = norm(lstm(x)) (TM:596-601): LayerNorm statistics come from the ConvLSTM epilogue's per-tile partials;
+    # H = 6 (36 pixels per sample) has tiles straddling samples, so that case must fall back to the statistics pass
+    rs = np.random.RandomState(B * 10 + H + variant)
+    x = rs.randn(B, cx, H, H); h = rs.randn(B, C, H, H) * 0.5; c = rs.randn(B, C, H, H)
+    W = rs.randn(4 * C, cx + C, 5, 5) / np.sqrt(25 * (cx + C)); b = rs.randn(4 * C) * 0.1
+    gamma = 1.0 + 0.1 * rs.randn(C, H, H); beta = 0.1 * rs.randn(C, H, H)
+    hr, cr = _lstm_ref(x, h, c, W, b)
+    lr = R.layer_norm_conv2d(hr, gamma.reshape(-1), beta.reshape(-1), 1e-6)
+    lg, hg, cg, fused = ops.convlstm_ln(x, h, c, W, b, gamma, beta, 1e-6, variant)
+    assert np.abs(hg - hr).max() < TOL and np.abs(cg - cr).max() < TOL
+    assert np.abs(lg - lr).max() < 1e-4      # LayerNorm divides by std(h) ~ 0.3: 3x the error of h
+    bm = {1: 128, 2: 64, 3: 32}.get(variant)
+    if bm is not None:
+        assert fused == int((H * H) % bm == 0)
+    elif expect_fused is not None:
+        assert fused == int(expect_fused)
+    # and identical to LayerNorm run on the kernel's own h with the separate statistics pass, up to rounding
+    l2 = ops.layernorm(hg, gamma, beta, 1e-6, False)
+    assert np.abs(lg - l2).max() < 2e-6
+
+
 def test_convlstm_zero_weights_kat(ops):
     # zero weights -> c = c * sigmoid(1), h = tanh(c)/2
     x = np.random.RandomState(0).randn(2, 32, 8, 8)
