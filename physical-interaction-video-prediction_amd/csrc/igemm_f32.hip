@@ -33,6 +33,7 @@
 // four accumulators are the four gates of the same channels; with WN = 2 / 4 a 32-column tile holds
 // 2 / 4 gates of 16 / 8 channels and the epilogue gathers the four gates of a channel with wave
 // shuffles.  The 4C-wide gate tensor is never written.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "pivp_kernels.h"
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
-    const int phase = blockIdx.y;
+    const int phase = (int)gridDim.y - 1 - (int)blockIdx.y;   // transposed conv: the 4-tap phase is dispatched first, the 1-tap phase fills the tail
     const int n_nblk = LSTM ? (d.C >> 5) : (d.N / BN);
     // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so block b runs
     // on XCD b % 8.  Give XCD k the k-th CONTIGUOUS eighth of the logical tile list, ordered column-block-major: its L2
@@ -509,6 +510,19 @@ int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
             int ks = blocks >= 256 ? 1 : (int)((256 + blocks - 1) / blocks);
             if (ks > d.ksize) ks = d.ksize;
             return launch_igemm<4, 1, 1, false>(d, stream, ks, ln_nparts);
+        }
+    }
+    // Short K (the 3x3 stride-2 convs and the transposed convs: 2..18 chunks) or too few big tiles to fill the chip:
+    // 32-row tiles with K split over the waves (igemm_small.hip).  Measured at B = 32 (scripts/bench_tail_ops.py):
+    // enc1 15.0 -> 6.6 us, enc2 21.4 -> 9.7, enc4 19.3 -> 14.2, enc5 33.7 -> 23.8, enc6 47.6 -> 39.5.
+    {
+        static const int mode = [] { const char* e = getenv("PIVP_IGEMM_SMALL"); return e ? atoi(e) : -1; }();   // tuning: 0 never, 1 always
+        const bool can = !d.ln_part && d.ldo % 4 == 0 && ((uintptr_t)d.out & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0);
+        const long big = full * ((nt + 3) / 4);
+        const int chunks = (d.deconv ? 4 : d.ksize * d.ksize) * ((d.c0 + d.c1) / 32);
+        if (can && (mode == 1 || (mode != 0 && (big < 128 || chunks <= 40)))) {
+            if (ln_nparts) *ln_nparts = 0;
+            return igemm_small(d, stream);
         }
     }
     if (nt > 4) {                                             // wide outputs: several column blocks

@@ -1,0 +1,172 @@
+// Small-problem variant of the implicit-GEMM convolution (igemm_f32.hip): 32 x 32 output tiles whose K is
+// split over the block's four waves.
+//
+// The stride-2 convolutions enc1 / enc2 (TM:501-502) and the transposed convolution enc4 (TM:505) have M = 2048 ..
+// 8192 anchors and N = 32 .. 128 columns at B = 32: with the 128 x (32..128) tiles of the main kernel they give 16 ..
+// 64 workgroups on a 256-CU chip.  Here a workgroup owns a 32-anchor x 32-column tile (256 .. 1024 workgroups for
+// the same layers, several resident per CU: 18 KB of LDS each), each K chunk of one tap x 32 input channels is
+// staged once per block, and wave w multiplies the chunk's k-group w (8 of the 32 k) -- one ds_read_b128 per operand
+// and four v_mfma_f32_32x32x2_f32 per chunk and wave.  The four partial tiles are summed through LDS in a fixed
+// order (bitwise reproducible) and the bias / ReLU / accumulate epilogue writes float4 rows.
+// Same descriptor, operand layouts, tap enumeration and out-of-image handling (buffer loads with an out-of-range
+// offset return 0) as the main kernel.
+#include <stdlib.h>
+
+#include "pivp_kernels.h"
+
+namespace pivp {
+
+namespace {
+constexpr int SP = 36;   // LDS row pitch in floats: 144-B rows, conflict-free ds_read_b128 / ds_write_b128
+constexpr int TILE = 32 * SP;
+}
+
+// NTB: 32-column tiles per block (the A fragment is reused NTB times; fewer, longer-running blocks).
+template <int NTB>
+__global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
+    constexpr int BN = 32 * NTB;
+    constexpr int RP = BN + 4;                                    // row pitch of the partial-sum image
+    constexpr int A_OFF = 0, B_OFF = 2 * TILE;                    // A0 A1 | B0 B1 (NTB tiles each)
+    constexpr int STAGE_FLOATS = 2 * TILE + 2 * NTB * TILE, RED_FLOATS = 4 * 32 * RP;
+    __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int n_nblk = d.N / BN;
+    const int nblk = blockIdx.x % n_nblk, mblk = blockIdx.x / n_nblk;
+    const int m0 = mblk * 32;
+    const int phase = blockIdx.y, py = phase >> 1, px = phase & 1;
+    const bool deconv = d.deconv != 0;
+    const int nty = deconv ? 1 + py : d.ksize, ntx = deconv ? 1 + px : d.ksize;
+    const int ncc = (d.c0 + d.c1) >> 5;
+    const int nchunks = nty * ntx * ncc;
+    const int HWg = d.Hg * d.Wg;
+
+    // staging role: one float4 of the A tile and one of the B tile per thread
+    constexpr unsigned OOB = 0xC0000000u;
+    const int cvec = tid & 7, prow = tid >> 3;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x0), 0, d.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.c1 ? d.x1 : d.x0), 0, d.c1 ? d.bytes1 : d.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, d.bytesw, 0x00020000);
+    int a_off0 = 0, a_off1 = 0, a_iy0 = -(1 << 20), a_ix0 = 0;
+    {
+        const int m = m0 + prow;
+        if (m < d.M) {
+            const int b = m / HWg, rem = m - b * HWg;
+            const int ay = rem / d.Wg, ax = rem - ay * d.Wg;
+            a_iy0 = ay * d.in_step; a_ix0 = ax * d.in_step;
+            const int pix = b * d.Hin * d.Win + a_iy0 * d.Win + a_ix0;
+            a_off0 = (pix * d.ld0 + cvec * 4) * 4;
+            a_off1 = (pix * d.ld1 + cvec * 4) * 4;
+        }
+    }
+    int b_goff[NTB];
+#pragma unroll
+    for (int t = 0; t < NTB; ++t) b_goff[t] = ((nblk * BN + t * 32 + prow) * 32 + cvec * 4) * 4;
+    const int lds_w = prow * SP + cvec * 4;
+
+    int l_cc = 0, l_ty = 0, l_tx = 0;
+    f32x4 ra, rb[NTB];
+    auto load_next = [&]() {   // chunk (l_ty, l_tx, l_cc) -> registers, then advance
+        int dy, dx, wi;
+        if (deconv) {
+            const int ky = py ? 2 * l_ty : 1, kx = px ? 2 * l_tx : 1;
+            dy = (py + 1 - ky) >> 1; dx = (px + 1 - kx) >> 1; wi = ky * 3 + kx;
+        } else {
+            dy = l_ty - d.pad; dx = l_tx - d.pad; wi = l_ty * d.ksize + l_tx;
+        }
+        const int ch = l_cc << 5;
+        const bool first = ch < d.c0;
+        const int ld = first ? d.ld0 : d.ld1;
+        const int delta = ((dy * d.Win + dx) * ld + (first ? ch : ch - d.c0)) * 4;
+        const int wbase = (wi * (d.wcin >> 5) + l_cc) * d.N * 128;
+        const int iy = a_iy0 + dy, ix = a_ix0 + dx;
+        const bool ok = (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+        const unsigned off = ok ? (unsigned)((first ? a_off0 : a_off1) + delta) : OOB;
+        ra = __builtin_bit_cast(f32x4, first ? __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0)
+                                             : __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) rb[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, b_goff[t], wbase, 0));
+        if (++l_cc == ncc) { l_cc = 0; if (++l_tx == ntx) { l_tx = 0; ++l_ty; } }
+    };
+    auto store_regs = [&](int buf) {
+        *reinterpret_cast<f32x4*>(lds + A_OFF + buf * TILE + lds_w) = ra;
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) *reinterpret_cast<f32x4*>(lds + B_OFF + (buf * NTB + t) * TILE + lds_w) = rb[t];
+    };
+
+    f32x16 acc[NTB];
+#pragma unroll
+    for (int t = 0; t < NTB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int frag = l31 * SP + 8 * wave + 4 * half;   // k-group `wave` of row l31
+
+    if (nchunks > 0) {
+        load_next();
+        store_regs(0);
+        __syncthreads();
+        for (int it = 0; it < nchunks; ++it) {
+            const int buf = it & 1;
+            const bool more = it + 1 < nchunks;
+            if (more) load_next();   // in flight while this chunk is multiplied
+            const f32x4 fa = *reinterpret_cast<const f32x4*>(lds + A_OFF + buf * TILE + frag);
+            f32x4 fb[NTB];
+#pragma unroll
+            for (int t = 0; t < NTB; ++t) fb[t] = *reinterpret_cast<const f32x4*>(lds + B_OFF + (buf * NTB + t) * TILE + frag);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int t = 0; t < NTB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s2], fb[t][s2], acc[t], 0, 0, 0);
+            if (more) store_regs(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // sum of the four waves' partial tiles, then the epilogue on float4 rows
+#pragma unroll
+    for (int t = 0; t < NTB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+            lds[(wave * 32 + m) * RP + t * 32 + l31] = acc[t][r];
+        }
+    __syncthreads();
+    const int m = m0 + prow;
+    if (m >= d.M) return;
+    const int b = m / HWg, rem = m - b * HWg;
+    const int ay = rem / d.Wg, ax = rem - ay * d.Wg;
+    const int oy0 = deconv ? py : 0, ox0 = deconv ? px : 0;
+    float* orow = d.out + ((size_t)(b * d.Hout + ay * d.out_step + oy0) * d.Wout + ax * d.out_step + ox0) * d.ldo + nblk * BN;
+#pragma unroll
+    for (int t = 0; t < NTB; ++t) {
+        const int cl = t * 32 + cvec * 4;   // column within the block tile
+        f32x4 v = *reinterpret_cast<const f32x4*>(lds + prow * RP + cl);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(lds + (w * 32 + prow) * RP + cl);
+        if (d.bias) v += *reinterpret_cast<const f32x4*>(d.bias + nblk * BN + cl);
+        if (d.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (d.accum) v += *reinterpret_cast<const f32x4*>(orow + cl);
+        *reinterpret_cast<f32x4*>(orow + cl) = v;
+    }
+}
+
+// d has been validated by igemm_validate (igemm_f32.hip); additionally needs 16-B aligned out / bias rows.
+int igemm_small(const IgemmDesc& d, hipStream_t stream) {
+    PIVP_CHECK_ARG(d.ldo % 4 == 0 && ((uintptr_t)d.out & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0));
+    const int mblk = (d.M + 31) / 32, nt = d.N / 32;
+    // widest column block that still leaves >= 4 blocks per CU (enc4: 1 tile 14.2 us vs 2 tiles 15.3; enc5: 3 tiles 23.8 vs 1 tile
+    // 25.7; enc6: 2 tiles 39.5 vs 1 tile 44.9)
+    static const int force = [] { const char* e = getenv("PIVP_SMALL_NTB"); return e ? atoi(e) : 0; }();   // tuning
+    int ntb = 1;
+    if (nt % 3 == 0 && (long)mblk * (nt / 3) * d.nphase >= 1024) ntb = 3;
+    else if (nt % 2 == 0 && (long)mblk * (nt / 2) * d.nphase >= 1024) ntb = 2;
+    if (force >= 1 && force <= 3 && nt % force == 0) ntb = force;
+    dim3 grid(mblk * (nt / ntb), d.nphase);
+    if (ntb == 3) hipLaunchKernelGGL(igemm_small_kernel<3>, grid, dim3(256), 0, stream, d);
+    else if (ntb == 2) hipLaunchKernelGGL(igemm_small_kernel<2>, grid, dim3(256), 0, stream, d);
+    else hipLaunchKernelGGL(igemm_small_kernel<1>, grid, dim3(256), 0, stream, d);
+    return PIVP_LAUNCH_STATUS();
+}
+
+}  // namespace pivp
