@@ -11,7 +11,12 @@ namespace pivp {
 // e6 NHWC [B][HW][64]; wm [64][NP], we [64][NE] (the reference's deconv (Cin,Cout,1,1) layout);
 // outputs planar [B][planes][HW] because the mask softmax is defined on the NCHW-flat order.
 // Each 256-thread block stages 64-pixel sub-tiles through LDS with coalesced 16-B loads; wave w
-// computes outputs w, w+4, ... for all 64 pixels (lane = pixel), weights are wave-uniform.
+// computes outputs w, w+4, ... for all 64 pixels (lane = pixel); an output's 64 weights are read
+// from LDS as 16 wave-uniform ds_read_b128.
+// Optional fused input stage: with ln_part != null, e6 is the RAW enc6 output and
+// relu(LayerNorm(e6)) (norm_enc6, TM:601; statistics from the enc6 kernel's (count, mean, M2)
+// partials, gamma/beta NHWC-flat) is applied while the tile is staged, so the normalised map is
+// neither written nor re-read (it IS written to y_out when that is non-null: training keeps it).
 // ------------------------------------------------------------------------------------------
 constexpr int HD_MAXOUT = 36;
 constexpr int HD_XP = 68;  // 272-B rows: conflict-free per-lane ds_read_b128
@@ -20,27 +25,59 @@ __global__ __launch_bounds__(256) void heads_1x1_kernel(const float* __restrict_
                                                         const float* __restrict__ bm, const float* __restrict__ we,
                                                         const float* __restrict__ be, float* __restrict__ mask_logits,
                                                         float* __restrict__ enc7, float* __restrict__ layer0,
-                                                        int total_px, int HW, int NP, int NE, int mode) {
+                                                        int total_px, int HW, int NP, int NE, int mode,
+                                                        const float* __restrict__ ln_part, int ln_nparts,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                        float* __restrict__ y_out, float* __restrict__ stat_out) {
     __shared__ __attribute__((aligned(16))) float xt[64 * HD_XP];
-    __shared__ float wl[64 * HD_MAXOUT];
+    __shared__ __attribute__((aligned(16))) float wl[HD_MAXOUT * 64];   // [output][k]
     __shared__ float bl[HD_MAXOUT];
+    __shared__ float stat[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NO = NP + NE;
     for (int i = tid; i < 64 * NO; i += 256) {
         const int k = i / NO, o = i - k * NO;
-        wl[k * HD_MAXOUT + o] = o < NP ? wm[k * NP + o] : we[k * NE + (o - NP)];
+        wl[o * 64 + k] = o < NP ? wm[k * NP + o] : we[k * NE + (o - NP)];
     }
     if (tid < NO) bl[tid] = tid < NP ? bm[tid] : be[tid - NP];
+    int b_stat = -1;
     for (int sub = 0; sub < 4; ++sub) {
         const int px0 = (blockIdx.x * 4 + sub) * 64;
         if (px0 >= total_px) break;
         __syncthreads();
+        float mean = 0.f, rstd = 1.f;
+        if (ln_part) {   // sub-tiles never straddle samples (HW % 64 == 0, checked by the launcher)
+            const int bs = px0 / HW;
+            if (bs != b_stat) {
+                if (wave == 0) {
+                    float mu, rs;
+                    ln_merge_partials(ln_part, bs, ln_nparts, eps, mu, rs);
+                    if (lane == 0) {
+                        stat[0] = mu; stat[1] = rs;
+                        if (stat_out && px0 == bs * HW) { stat_out[bs * 2] = mu; stat_out[bs * 2 + 1] = rs; }
+                    }
+                }
+                __syncthreads();
+                b_stat = bs;
+            }
+            mean = stat[0]; rstd = stat[1];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int f = tid + 256 * j;       // float4 index within the 64x64 tile
             const int p = f >> 4, cv = (f & 15) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (px0 + p < total_px) v = *reinterpret_cast<const f32x4*>(e6 + (size_t)(px0 + p) * 64 + cv);
+            if (px0 + p < total_px) {
+                v = *reinterpret_cast<const f32x4*>(e6 + (size_t)(px0 + p) * 64 + cv);
+                if (ln_part) {
+                    const size_t gi = (size_t)(px0 + p - b_stat * HW) * 64 + cv;
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + gi);
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + gi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf((v[e] - mean) * rstd * g[e] + bb[e], 0.f);
+                    if (y_out) *reinterpret_cast<f32x4*>(y_out + (size_t)(px0 + p) * 64 + cv) = v;
+                }
+            }
             *reinterpret_cast<f32x4*>(xt + p * HD_XP + cv) = v;
         }
         __syncthreads();
@@ -54,8 +91,13 @@ __global__ __launch_bounds__(256) void heads_1x1_kernel(const float* __restrict_
         const int b = px / HW, p = px - b * HW;
         for (int o = wave; o < NO; o += 4) {
             float acc = bl[o];
+            const float* wo = wl + o * 64;
 #pragma unroll
-            for (int k = 0; k < 64; ++k) acc = fmaf(xr[k], wl[k * HD_MAXOUT + o], acc);
+            for (int q = 0; q < 16; ++q) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wo + q * 4);
+                acc = fmaf(xr[q * 4], w4[0], acc); acc = fmaf(xr[q * 4 + 1], w4[1], acc);
+                acc = fmaf(xr[q * 4 + 2], w4[2], acc); acc = fmaf(xr[q * 4 + 3], w4[3], acc);
+            }
             if (px < total_px) {
                 if (o < NP) {
                     mask_logits[((size_t)b * NP + o) * HW + p] = fmaxf(acc, 0.f);
@@ -72,13 +114,16 @@ __global__ __launch_bounds__(256) void heads_1x1_kernel(const float* __restrict_
 
 int heads_1x1(const float* e6, const float* wm, const float* bm, const float* we, const float* be,
               float* mask_logits, float* enc7, float* layer0, int B, int HW, int nmask_planes, int nenc7,
-              int enc7_mode, hipStream_t s) {
+              int enc7_mode, hipStream_t s, const float* ln_part, int ln_nparts, const float* gamma, const float* beta,
+              float eps, float* y_out, float* stat_out) {
     PIVP_CHECK_ARG(e6 && wm && bm && we && be && mask_logits && enc7 && B > 0 && HW > 0);
     PIVP_CHECK_ARG(nmask_planes >= 1 && nenc7 >= 1 && nmask_planes + nenc7 <= HD_MAXOUT);
     PIVP_CHECK_ARG(enc7_mode >= 0 && enc7_mode <= 2 && (enc7_mode == 2 || layer0));
+    PIVP_CHECK_ARG(!ln_part || (ln_nparts > 0 && gamma && beta && HW % 64 == 0));
     const int total = B * HW;
     hipLaunchKernelGGL(heads_1x1_kernel, dim3((total + 255) / 256), dim3(256), 0, s, e6, wm, bm, we, be,
-                       mask_logits, enc7, layer0, total, HW, nmask_planes, nenc7, enc7_mode);
+                       mask_logits, enc7, layer0, total, HW, nmask_planes, nenc7, enc7_mode,
+                       ln_part, ln_nparts, gamma, beta, eps, y_out, stat_out);
     return PIVP_LAUNCH_STATUS();
 }
 

@@ -56,4 +56,27 @@ __device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, f
     n = nt;
 }
 
+// Merge the S (count, mean, M2) LayerNorm partials of sample b; call with the 64 lanes of ONE wave.
+// Every lane returns the same (mean, 1/sqrt(var + eps)); the merge order is fixed (bitwise reproducible).
+__device__ __forceinline__ void ln_merge_partials(const float* __restrict__ partials, int b, int S, float eps, float& mean_out,
+                                                  float& rstd_out) {
+    const int lane = threadIdx.x & 63;
+    float cn = 0.f, mean = 0.f, m2 = 0.f;
+    for (int i = lane; i < S; i += 64) {
+        const float* p = partials + ((size_t)b * S + i) * 4;
+        chan_combine(cn, mean, m2, p[0], p[1], p[2]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float on = __shfl_xor(cn, off, 64), om = __shfl_xor(mean, off, 64), o2 = __shfl_xor(m2, off, 64);
+        // symmetric merge so both partners end with the same value
+        float a_n = cn, a_m = mean, a_2 = m2;
+        if ((lane & off) == 0) { chan_combine(a_n, a_m, a_2, on, om, o2); }
+        else { a_n = on; a_m = om; a_2 = o2; chan_combine(a_n, a_m, a_2, cn, mean, m2); }
+        cn = a_n; mean = a_m; m2 = a_2;
+    }
+    mean_out = mean;
+    rstd_out = 1.0f / sqrtf(m2 / cn + eps);
+}
+
 }  // namespace pivp

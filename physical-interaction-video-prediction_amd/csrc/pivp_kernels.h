@@ -76,7 +76,11 @@ int enc3_state(const float* e2, const float* action, const float* state, const f
 // enc7_mode: 0 = CDNA (relu; layer0 = sigmoid), 1 = STP (no relu; layer0 = sigmoid), 2 = DNA (relu; no layer0)
 int heads_1x1(const float* e6, const float* wm, const float* bm, const float* we, const float* be,
               float* mask_logits, float* enc7, float* layer0, int B, int HW, int nmask_planes, int nenc7,
-              int enc7_mode, hipStream_t s);
+              int enc7_mode, hipStream_t s,
+              // optional fused relu(LayerNorm(e6)) input stage: e6 is then the raw enc6 map, ln_part its ln_nparts
+              // (count, mean, M2) partials per sample; y_out (optional) receives the normalised map, stat_out [B][2]
+              const float* ln_part = nullptr, int ln_nparts = 0, const float* gamma = nullptr, const float* beta = nullptr,
+              float eps = 0.f, float* y_out = nullptr, float* stat_out = nullptr);
 
 // CDNA kernel generator: Linear(hidden5) -> relu shift -> per-kernel normalisation (TM:321-329)
 int cdna_kernel_partials_slices(int K);

@@ -279,10 +279,18 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     RC(ln(7, ws + S.h[6], ws + S.cat7, n2, 32, 64, 0, np));
     RC(run_deconv3x3s2(ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), P(p, p->i_enc_b[6]), ws + S.e6raw, 64, 64, 0, B, p->H2, p->W2, s, 0,
                        lnp, ln_cap, &np));
-    RC(ln(8, ws + S.e6raw, ws + S.e6, 64 * H * W, 64, 64, 1, np));
-    // heads (TM:711-728)
-    RC(heads_1x1(ws + S.e6, P(p, p->i_masks_w), P(p, p->i_masks_b), P(p, p->i_enc7_w), P(p, p->i_enc7_b),
-                 ws + S.logits, ws + S.enc7, ws + S.layer0, B, H * W, p->NP, p->NE, c.model_type, s));
+    // heads (TM:711-728).  norm_enc6 + relu is applied while the heads kernel stages its input: the normalised enc6 is only
+    // written when the activations are kept for BPTT (pivp_get_tap recomputes it on request otherwise).
+    if (np > 0 && (H * W) % 64 == 0) {
+        RC(heads_1x1(ws + S.e6raw, P(p, p->i_masks_w), P(p, p->i_masks_b), P(p, p->i_enc7_w), P(p, p->i_enc7_b),
+                     ws + S.logits, ws + S.enc7, ws + S.layer0, B, H * W, p->NP, p->NE, c.model_type, s,
+                     lnp, np, P(p, p->i_ln_g[8]), P(p, p->i_ln_b[8]), eps, train ? ws + S.e6 : nullptr,
+                     ws + S.lnstat + (size_t)8 * B * 2));
+    } else {
+        RC(ln(8, ws + S.e6raw, ws + S.e6, 64 * H * W, 64, 64, 1, np));
+        RC(heads_1x1(ws + S.e6, P(p, p->i_masks_w), P(p, p->i_masks_b), P(p, p->i_enc7_w), P(p, p->i_enc7_b),
+                     ws + S.logits, ws + S.enc7, ws + S.layer0, B, H * W, p->NP, p->NE, c.model_type, s));
+    }
     const float* aux = nullptr;
     if (c.model_type == PIVP_MODEL_CDNA) {
         RC(cdna_kernels(ws + S.n5, P(p, p->i_head_w), P(p, p->i_head_b), ws + p->o_linpart, ws + S.kerns, B, p->K5, c.num_masks, s,
@@ -550,6 +558,13 @@ extern "C" long long pivp_get_tap(pivp_plan_t* plan, const char* name, int step,
         {"lstm1_c", S.c[0], 32, HW2, 32}, {"lstm2_c", S.c[1], 32, HW2, 32}, {"lstm3_c", S.c[2], 64, HW4, 64},
         {"lstm4_c", S.c[3], 64, HW4, 64}, {"lstm5_c", S.c[4], 128, HW8, 128}, {"lstm6_c", S.c[5], 64, HW4, 64},
         {"lstm7_c", S.c[6], 32, HW2, 32}};
+    if (strcmp(name, "enc6") == 0 && !c.keep_activations) {
+        // inference does not materialise relu(norm_enc6(.)) (fused into the heads kernel): rebuild it from the raw map
+        // and the saved (mean, rstd)
+        int rc = ln_apply(ws + S.e6raw, ws + S.lnstat + (size_t)8 * B * 2, P(plan, plan->i_ln_g[8]), P(plan, plan->i_ln_b[8]),
+                          ws + S.e6, B, 64 * HW, 64, 64, c.ln_eps, 1, s, nullptr, -1);
+        if (rc != PIVP_OK) return rc;
+    }
     for (const T& t : taps) {
         if (strcmp(t.n, name) == 0) {
             int rc = nhwc_to_nchw(ws + t.off, out, B, t.C, t.hw, t.ld, s);

@@ -116,23 +116,12 @@ __global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__
     __shared__ float stat[2];
     const int s = blockIdx.x, b = blockIdx.y;   // S partials per sample: ln_stats slices, or the tiles of a producer
     if (threadIdx.x < 64) {
-        float cn = 0.f, mean = 0.f, m2 = 0.f;
-        for (int i = threadIdx.x; i < S; i += 64) {
-            const float* p = partials + ((size_t)b * S + i) * 4;
-            chan_combine(cn, mean, m2, p[0], p[1], p[2]);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float on = __shfl_xor(cn, off, 64), om = __shfl_xor(mean, off, 64), o2 = __shfl_xor(m2, off, 64);
-            // symmetric merge so both partners end with the same value
-            float a_n = cn, a_m = mean, a_2 = m2;
-            if ((threadIdx.x & off) == 0) { chan_combine(a_n, a_m, a_2, on, om, o2); }
-            else { a_n = on; a_m = om; a_2 = o2; chan_combine(a_n, a_m, a_2, cn, mean, m2); }
-            cn = a_n; mean = a_m; m2 = a_2;
-        }
+        float mean, rstd;
+        if (S > 0) ln_merge_partials(partials, b, S, eps, mean, rstd);
+        else { mean = partials[b * 2]; rstd = partials[b * 2 + 1]; }   // S == 0: `partials` is a saved [B][2] (mean, rstd)
         if (threadIdx.x == 0) {
-            stat[0] = mean; stat[1] = 1.0f / sqrtf(m2 / cn + eps);
-            if (stat_out && s == 0) { stat_out[b * 2] = stat[0]; stat_out[b * 2 + 1] = stat[1]; }   // kept for the backward pass
+            stat[0] = mean; stat[1] = rstd;
+            if (stat_out && s == 0) { stat_out[b * 2] = mean; stat_out[b * 2 + 1] = rstd; }   // kept for the backward pass
         }
     }
     __syncthreads();
@@ -164,9 +153,11 @@ __global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__
 int ln_apply(const float* x, const float* partials, const float* gamma, const float* beta, float* out,
              int B, int n, int C, int ldo, float eps, int relu, hipStream_t s, float* stat_out, int nparts) {
     PIVP_CHECK_ARG(x && partials && gamma && beta && out && B > 0 && n > 0 && C > 0 && C % 4 == 0 && n % C == 0);
-    PIVP_CHECK_ARG(ldo >= C && ldo % 4 == 0 && nparts >= 0);
+    PIVP_CHECK_ARG(ldo >= C && ldo % 4 == 0 && nparts >= -1);
+    // nparts: > 0 producer-written partials, 0 the ln_stats slices, -1 `partials` is a saved [B][2] (mean, rstd)
     hipLaunchKernelGGL(ln_apply_kernel, dim3(ln_stats_slices(n), B), dim3(256), 0, s,
-                       x, partials, gamma, beta, out, n, C, ldo, eps, relu, stat_out, nparts > 0 ? nparts : ln_stats_slices(n));
+                       x, partials, gamma, beta, out, n, C, ldo, eps, relu, stat_out,
+                       nparts > 0 ? nparts : nparts == 0 ? ln_stats_slices(n) : 0);
     return PIVP_LAUNCH_STATUS();
 }
 
