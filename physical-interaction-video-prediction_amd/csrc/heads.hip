@@ -259,8 +259,19 @@ int stp_params(const float* hidden5, const float* wt1, const float* b1, const fl
 // One block = one sample x 8 image rows; the frame tile with its 2-pixel halo, the logit windows
 // (tile +- NP-1 flat elements per plane) and the sample's kernels are staged in LDS.
 // ------------------------------------------------------------------------------------------
-constexpr int CP_TR = 8;
+// image rows per block.  Measured at B = 32, 64x64 (scripts/bench_tail_ops.py): 8 rows 14.3 us, 4 rows 12.2, 2 rows 14.2
+#ifndef PIVP_CP_TR
+#define PIVP_CP_TR 4
+#endif
+constexpr int CP_TR = PIVP_CP_TR;
+constexpr int CP_KL = 11 * 28;   // LDS floats of the CDNA kernel table
 
+#ifdef PIVP_CP_STAMPS
+__device__ long long pivp_cp_stamps[8];
+#define CP_STAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 3 && threadIdx.x == 0) pivp_cp_stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define CP_STAMP(i)
+#endif
 template <int MODE>
 __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ prev, const float* __restrict__ logits,
                                                         const float* __restrict__ layer0, const float* __restrict__ aux,
@@ -275,64 +286,130 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
     const int p0 = y0 * W, np = rows * W;
     const int win = np + 2 * (NP - 1);
     const int G = np / NP + 2;
-    float* lg = sm;                         // [NP][win]
+    float* kl = sm;                         // [11][28] (CDNA: 25 taps per kernel + 3 pad); 16-B aligned rows
+    float* lg = sm + CP_KL;                 // [NP][win]
     float* gmx = lg + NP * win;             // [NP][G]
     float* ginv = gmx + NP * G;             // [NP][G]
     float* prevt = ginv + NP * G;           // [3][CP_TR+4][W+4]
-    float* kl = prevt + 3 * (CP_TR + 4) * (W + 4);  // [NM*25] (CDNA)
     const int PW = W + 4;
     const int tid = threadIdx.x;
     const float* lgb = logits + (size_t)b * NP * HW;
+    // exact x / NP for x * NP < 2^32 (flat plane offsets are < 12 * H * W): one v_mul_hi instead of a ~35-instruction
+    // integer division, of which the first version executed two per mask plane and pixel
+    const unsigned magic = 0xFFFFFFFFu / (unsigned)NP + 1u;
+    auto div_np = [&](int x) { return (int)__umulhi((unsigned)x, magic); };
+    CP_STAMP(0);
 
-    for (int i = tid; i < NP * win; i += 256) {
-        const int m = i / win, j = i - m * win;
-        const int F = m * HW + p0 - (NP - 1) + j;
-        lg[i] = (F >= 0 && F < NP * HW) ? lgb[F] : 0.f;
-    }
-    if (MODE != 1) {
+    // ---- staging: EVERY global load of the block is issued before the first LDS store, so the block pays one L2 / MALL
+    // round trip (~2k cycles) instead of one per element (first version) or per batch --------------------------------
+    {
+        float tl[12][3];
+#pragma unroll
+        for (int m = 0; m < 12; ++m)
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                const int jx = tid + 256 * jj;
+                const int F = m * HW + p0 - (NP - 1) + jx;
+                tl[m][jj] = (m < NP && jx < win && F >= 0 && F < NP * HW) ? lgb[F] : 0.f;
+            }
+        constexpr int PR = (CP_TR + 4 + 2) / 3;      // prev rows per thread when 256 / PW >= 3 (W <= 81), else looped below
+        float tp[3][PR];
         const float* pb = prev + (size_t)b * 3 * HW;
-        for (int i = tid; i < 3 * (CP_TR + 4) * PW; i += 256) {
-            const int c = i / ((CP_TR + 4) * PW);
-            const int r = (i / PW) % (CP_TR + 4);
-            const int x = i % PW;
-            const int iy = y0 + r - 2, ix = x - 2;
-            prevt[i] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? pb[(size_t)c * HW + iy * W + ix] : 0.f;
+        const int x = tid % PW, r0 = tid / PW, rstep = 256 / PW;   // PW <= 256 (checked by the launcher)
+        const bool prow = MODE != 1 && tid < rstep * PW;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int u = 0; u < PR; ++u) {
+                const int r = r0 + u * rstep, iy = y0 + r - 2, ix = x - 2;
+                tp[c][u] = (prow && r < CP_TR + 4 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                               ? pb[(size_t)c * HW + iy * W + ix] : 0.f;
+            }
+        float tk[2] = {0.f, 0.f};
+        if (MODE == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i2 = tid + 256 * u, k = i2 / 28, e = i2 - k * 28;
+                tk[u] = (i2 < CP_KL && k < NM && e < 25) ? aux[((size_t)b * NM + k) * 25 + e] : 0.f;
+            }
         }
-    }
-    if (MODE == 0) {
-        for (int i = tid; i < NM * 25; i += 256) kl[i] = aux[(size_t)b * NM * 25 + i];
+#pragma unroll
+        for (int m = 0; m < 12; ++m)
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                const int jx = tid + 256 * jj;
+                if (m < NP && jx < win) lg[m * win + jx] = tl[m][jj];
+            }
+        if (prow) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int u = 0; u < PR; ++u) {
+                    const int r = r0 + u * rstep;
+                    if (r < CP_TR + 4) prevt[(c * (CP_TR + 4) + r) * PW + x] = tp[c][u];
+                }
+            for (int r = r0 + PR * rstep; r < CP_TR + 4; r += rstep) {   // wide frames: remaining rows
+                const int iy = y0 + r - 2, ix = x - 2;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    prevt[(c * (CP_TR + 4) + r) * PW + x] =
+                        ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? pb[(size_t)c * HW + iy * W + ix] : 0.f;
+            }
+        }
+        if (MODE == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (tid + 256 * u < CP_KL) kl[tid + 256 * u] = tk[u];
+        }
+        for (int m = 0; m < NP; ++m)                              // rows wider than 3 x 256 window elements (W > 93)
+            for (int jx = tid + 768; jx < win; jx += 256) {
+                const int F = m * HW + p0 - (NP - 1) + jx;
+                lg[m * win + jx] = (F >= 0 && F < NP * HW) ? lgb[F] : 0.f;
+            }
     }
     __syncthreads();
-    // per-group max and 1/sum
+    CP_STAMP(1);
+    // ---- per-group max and 1/sum (groups of NP consecutive flat elements, TM:720-722) ---------------------------------
     for (int i = tid; i < NP * G; i += 256) {
         const int m = i / G, gi = i - m * G;
-        const int gfirst = (m * HW + p0) / NP;
-        const int glast = (m * HW + p0 + np - 1) / NP;
+        const int gfirst = div_np(m * HW + p0);
+        const int glast = div_np(m * HW + p0 + np - 1);
         if (gfirst + gi <= glast) {
             const int j0 = (gfirst + gi) * NP - (m * HW + p0 - (NP - 1));
             const float* e = lg + m * win + j0;
-            float mx = e[0];
-            for (int u = 1; u < NP; ++u) mx = fmaxf(mx, e[u]);
+            float ev[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) ev[u] = u < NP ? e[u] : -3.0e38f;   // all reads in flight together
+            float mx = ev[0];
+#pragma unroll
+            for (int u = 1; u < 12; ++u) mx = fmaxf(mx, ev[u]);
             float sum = 0.f;
-            for (int u = 0; u < NP; ++u) sum += expf(e[u] - mx);
+#pragma unroll
+            for (int u = 0; u < 12; ++u) sum += u < NP ? __expf(ev[u] - mx) : 0.f;
             gmx[i] = mx;
             ginv[i] = 1.0f / sum;
         }
     }
     __syncthreads();
 
+    CP_STAMP(2);
     for (int pp = tid; pp < np; pp += 256) {
         const int p = p0 + pp;
         const int y = p / W, x = p - y * W;
         const int ry = y - y0;
+        float l0v[3] = {0.f, 0.f, 0.f};   // issued first: their latency hides under the mask / kernel arithmetic
+        if (MODE != 2) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) l0v[c] = layer0[((size_t)b * 3 + c) * HW + p];
+        }
         float mk[12];
 #pragma unroll
         for (int m = 0; m < 12; ++m) {
             if (m < NP) {
                 const int F = m * HW + p;
-                const int gi = F / NP - (m * HW + p0) / NP;
+                const int gi = div_np(F) - div_np(m * HW + p0);
                 const float v = lg[m * win + pp + (NP - 1)];
-                mk[m] = expf(v - gmx[m * G + gi]) * ginv[m * G + gi];
+                mk[m] = __expf(v - gmx[m * G + gi]) * ginv[m * G + gi];
                 if (masks_out) masks_out[((size_t)b * NP + m) * HW + p] = mk[m];
             } else {
                 mk[m] = 0.f;
@@ -347,8 +424,14 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
             for (int k = 0; k < 10; ++k) {   // static indices keep mk[] in registers
                 if (k < NM - 1) {
                     const float mq = mk[k + 2];
+                    float kv[28];   // kernel k's taps: 7 wave-uniform ds_read_b128
 #pragma unroll
-                    for (int i = 0; i < 25; ++i) keff[i] = fmaf(mq, kl[k * 25 + i], keff[i]);
+                    for (int q = 0; q < 7; ++q) {
+                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(kl + k * 28 + q * 4);
+                        kv[q * 4] = t4[0]; kv[q * 4 + 1] = t4[1]; kv[q * 4 + 2] = t4[2]; kv[q * 4 + 3] = t4[3];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 25; ++i) keff[i] = fmaf(mq, kv[i], keff[i]);
                 }
             }
 #pragma unroll
@@ -360,7 +443,7 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
 #pragma unroll
                     for (int j = 0; j < 5; ++j) t = fmaf(keff[i * 5 + j], pt[i * PW + j], t);
                 const float pc = pt[2 * PW + 2];
-                o3[c] = mk[0] * pc + mk[1] * layer0[((size_t)b * 3 + c) * HW + p] + t;
+                o3[c] = mk[0] * pc + mk[1] * l0v[c] + t;
             }
         } else if (MODE == 1) {
             const float* th = aux + (size_t)b * 6;
@@ -392,7 +475,7 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
                         if ((unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H)
                             t = fmaf(wgt, pb[(size_t)c * HW + vv * W + uu], t);
                     }
-                o3[c] = mk[0] * pb[(size_t)c * HW + p] + mk[1] * layer0[((size_t)b * 3 + c) * HW + p] + msum * t;
+                o3[c] = mk[0] * pb[(size_t)c * HW + p] + mk[1] * l0v[c] + msum * t;
             }
         } else {
             float kn[25];
@@ -419,8 +502,17 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) out[((size_t)b * 3 + c) * HW + p] = o3[c];
+        CP_STAMP(3 + (pp >= 256));
     }
+    CP_STAMP(5);
 }
+#ifdef PIVP_CP_STAMPS
+}
+extern "C" int pivp_debug_cp_stamps(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pivp::pivp_cp_stamps), 8 * sizeof(long long)) == hipSuccess ? 0 : -2;
+}
+namespace pivp {
+#endif
 
 int composite(const float* prev, const float* mask_logits, const float* layer0, const float* aux,
               float* out, float* masks_out, int B, int H, int W, int num_masks, int mode, int stp_zero_border,
@@ -432,8 +524,8 @@ int composite(const float* prev, const float* mask_logits, const float* layer0, 
     const int np = CP_TR * W;
     const int win = np + 2 * (NP - 1);
     const int G = np / NP + 2;
-    const size_t lds = sizeof(float) * ((size_t)NP * win + 2 * NP * G + 3 * (CP_TR + 4) * (W + 4) + num_masks * 25);
-    PIVP_CHECK_ARG(lds <= 160 * 1024);
+    const size_t lds = sizeof(float) * ((size_t)NP * win + 2 * NP * G + 3 * (CP_TR + 4) * (W + 4) + CP_KL);
+    PIVP_CHECK_ARG(lds <= 160 * 1024 && W + 4 <= 256);
     dim3 grid((H + CP_TR - 1) / CP_TR, B);
 #define PIVP_LAUNCH_CP(M)                                                                                   \
     do {                                                                                                    \
