@@ -517,12 +517,11 @@ int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     // enc1 15.0 -> 6.6 us, enc2 21.4 -> 9.7, enc4 19.3 -> 14.2, enc5 33.7 -> 23.8, enc6 47.6 -> 39.5.
     {
         static const int mode = [] { const char* e = getenv("PIVP_IGEMM_SMALL"); return e ? atoi(e) : -1; }();   // tuning: 0 never, 1 always
-        const bool can = !d.ln_part && d.ldo % 4 == 0 && ((uintptr_t)d.out & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0);
+        const bool can = d.ldo % 4 == 0 && ((uintptr_t)d.out & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0);
         const long big = full * ((nt + 3) / 4);
         const int chunks = (d.deconv ? 4 : d.ksize * d.ksize) * ((d.c0 + d.c1) / 32);
         if (can && (mode == 1 || (mode != 0 && (big < 128 || chunks <= 40)))) {
-            if (ln_nparts) *ln_nparts = 0;
-            return igemm_small(d, stream);
+            return igemm_small(d, stream, ln_nparts);
         }
     }
     if (nt > 4) {                                             // wide outputs: several column blocks

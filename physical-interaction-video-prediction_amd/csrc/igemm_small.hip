@@ -133,11 +133,12 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
         }
     __syncthreads();
     const int m = m0 + prow;
-    if (m >= d.M) return;
-    const int b = m / HWg, rem = m - b * HWg;
+    const bool valid = m < d.M;
+    const int b = valid ? m / HWg : 0, rem = m - b * HWg;
     const int ay = rem / d.Wg, ax = rem - ay * d.Wg;
     const int oy0 = deconv ? py : 0, ox0 = deconv ? px : 0;
     float* orow = d.out + ((size_t)(b * d.Hout + ay * d.out_step + oy0) * d.Wout + ax * d.out_step + ox0) * d.ldo + nblk * BN;
+    float sv[4 * NTB];   // this thread's outputs, for the fused LayerNorm partial
 #pragma unroll
     for (int t = 0; t < NTB; ++t) {
         const int cl = t * 32 + cvec * 4;   // column within the block tile
@@ -146,13 +147,40 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
         for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(lds + (w * 32 + prow) * RP + cl);
         if (d.bias) v += *reinterpret_cast<const f32x4*>(d.bias + nblk * BN + cl);
         if (d.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        if (d.accum) v += *reinterpret_cast<const f32x4*>(orow + cl);
-        *reinterpret_cast<f32x4*>(orow + cl) = v;
+        if (valid) {
+            if (d.accum) v += *reinterpret_cast<const f32x4*>(orow + cl);
+            *reinterpret_cast<f32x4*>(orow + cl) = v;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sv[t * 4 + e] = v[e];
+    }
+    if (d.ln_part) {   // (count, mean, M2) of the block's outputs, two passes over registers, fixed summation order
+        __syncthreads();   // the partial-sum image is dead
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4 * NTB; ++i) s1 += valid ? sv[i] : 0.f;
+        s1 = wave_sum(s1);
+        const float c1 = wave_sum(valid ? (float)(4 * NTB) : 0.f);
+        if (lane == 0) { lds[wave] = s1; lds[4 + wave] = c1; }
+        __syncthreads();
+        const float cnt = (lds[4] + lds[5]) + (lds[6] + lds[7]);
+        const float mean = ((lds[0] + lds[1]) + (lds[2] + lds[3])) / cnt;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4 * NTB; ++i) { const float dd = sv[i] - mean; q = valid ? fmaf(dd, dd, q) : q; }
+        q = wave_sum(q);
+        if (lane == 0) lds[8 + wave] = q;
+        __syncthreads();
+        if (tid == 0) {
+            const int bb = m0 / HWg;
+            float* pp = d.ln_part + ((size_t)bb * d.ln_nparts + (((m0 - bb * HWg) >> 5) * n_nblk + nblk) * (int)gridDim.y + phase) * 4;
+            pp[0] = cnt; pp[1] = mean; pp[2] = (lds[8] + lds[9]) + (lds[10] + lds[11]); pp[3] = 0.f;
+        }
     }
 }
 
 // d has been validated by igemm_validate (igemm_f32.hip); additionally needs 16-B aligned out / bias rows.
-int igemm_small(const IgemmDesc& d, hipStream_t stream) {
+int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     PIVP_CHECK_ARG(d.ldo % 4 == 0 && ((uintptr_t)d.out & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0));
     const int mblk = (d.M + 31) / 32, nt = d.N / 32;
     // widest column block that still leaves >= 4 blocks per CU (enc4: 1 tile 14.2 us vs 2 tiles 15.3; enc5: 3 tiles 23.8 vs 1 tile
@@ -163,9 +191,15 @@ int igemm_small(const IgemmDesc& d, hipStream_t stream) {
     else if (nt % 2 == 0 && (long)mblk * (nt / 2) * d.nphase >= 1024) ntb = 2;
     if (force >= 1 && force <= 3 && nt % force == 0) ntb = force;
     dim3 grid(mblk * (nt / ntb), d.nphase);
-    if (ntb == 3) hipLaunchKernelGGL(igemm_small_kernel<3>, grid, dim3(256), 0, stream, d);
-    else if (ntb == 2) hipLaunchKernelGGL(igemm_small_kernel<2>, grid, dim3(256), 0, stream, d);
-    else hipLaunchKernelGGL(igemm_small_kernel<1>, grid, dim3(256), 0, stream, d);
+    IgemmDesc dd = d;   // fused LayerNorm partials: one per block, when no tile straddles two samples
+    const int hwg = d.Hg * d.Wg;
+    const int np = (hwg / 32) * (nt / ntb) * d.nphase;
+    dd.ln_nparts = (d.ln_part && hwg % 32 == 0 && np <= d.ln_cap) ? np : 0;
+    if (!dd.ln_nparts) dd.ln_part = nullptr;
+    if (ln_nparts) *ln_nparts = dd.ln_nparts;
+    if (ntb == 3) hipLaunchKernelGGL(igemm_small_kernel<3>, grid, dim3(256), 0, stream, dd);
+    else if (ntb == 2) hipLaunchKernelGGL(igemm_small_kernel<2>, grid, dim3(256), 0, stream, dd);
+    else hipLaunchKernelGGL(igemm_small_kernel<1>, grid, dim3(256), 0, stream, dd);
     return PIVP_LAUNCH_STATUS();
 }
 

@@ -20,6 +20,13 @@ struct ParamInfo { std::string name; long long numel; const float* ptr; float* g
 
 // Per-timestep activations (offsets in floats from the workspace base).  Two rolling slabs for inference, T-1 slabs
 // when keep_activations (BPTT needs every step).
+// LayerNorm partial slots per sample: the ln_stats slices of the largest map (64 channels at full resolution) or the tiles
+// of the producers that write partials themselves (enc6 through igemm_small: HW/4 anchors / 32 x 2 column blocks x 4 parities)
+static int ln_partial_cap(int HW) {
+    const int a = ln_stats_slices(64 * HW), b = (HW / 4 / 32 + 1) * 2 * 4;
+    return a > b ? a : b;
+}
+
 struct Slab {
     size_t cat7, n1, n2, cat6, n3, n4, e2, e3, n5, e4, e5, e6;   // NHWC feature maps (cat7 = [hidden7|enc0], cat6 = [hidden6|enc1])
     size_t h[7], c[7];                                           // ConvLSTM states
@@ -128,7 +135,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
     const size_t hsz[7] = {HW2 * 32, HW2 * 32, HW4 * 64, HW4 * 64, HW8 * 128, HW4 * 64, HW2 * 32};
     const bool train = cfg->keep_activations != 0;
     p->o_zero = carve((size_t)B * HW2 * 32);
-    p->o_lnpart = carve((size_t)B * ln_stats_slices((int)(64 * HW)) * 4);
+    p->o_lnpart = carve((size_t)B * ln_partial_cap((int)HW) * 4);
     p->o_linpart = carve((size_t)cdna_kernel_partials_slices(p->K5) * B * 256);
     p->o_masks = carve((size_t)B * p->NP * HW);
     p->loss_nparts = loss_partials_count((int)(B * 3 * HW));
@@ -226,7 +233,7 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     const bool train = c.keep_activations != 0;
     auto hp = [&](int i) -> const float* { return Sp ? ws + Sp->h[i] : nullptr; };   // t = 0: h == 0, skipped
     auto cp = [&](int i) { return Sp ? ws + Sp->c[i] : ws + p->o_zero; };
-    const int ln_cap = ln_stats_slices(64 * H * W);   // partial slots per sample in lnp (see the workspace carve)
+    const int ln_cap = ln_partial_cap(H * W);   // partial slots per sample in lnp (see the workspace carve)
     int np = 0;
     auto lstm = [&](int i, const float* x, int ldx, int hh, int wwid) {
         const bool prof = p->prof_on && p->prof_used + 2 <= p->prof_ev.size();
