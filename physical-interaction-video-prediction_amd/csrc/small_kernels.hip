@@ -50,9 +50,87 @@ __global__ __launch_bounds__(256) void conv_enc0_kernel(const float* __restrict_
     *reinterpret_cast<f32x4*>(op + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
 }
 
+// Row-tile version (W/2 in {8, 16, 32, 64}): a block owns 64 output pixels = whole output rows; its input patch
+// ((2*rows+3) x (W+3) x 3, zero padded) and the weights are staged in LDS with every load of a thread in flight at
+// once.  The element-per-thread kernel above issued 75 image loads behind bounds branches and re-read the weights with
+// one load in flight: ~11 us for 6 MB of traffic.
+constexpr int E0_PR = 4;   // patch rows per thread and channel
+__global__ __launch_bounds__(256) void conv_enc0_rows_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             int B, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float sm0[];
+    float* wl = sm0;                 // [75][32]
+    float* patch = sm0 + 75 * 32;    // [3][R][PWc]
+    const int tid = threadIdx.x;
+    const int H2 = H >> 1, W2 = W >> 1;
+    const int rows = 64 / W2, R = 2 * rows + 3, PWc = W + 3;
+    const int tiles_per_img = H2 / rows;
+    const int b = blockIdx.x / tiles_per_img, oy0 = (blockIdx.x - b * tiles_per_img) * rows;
+    const float* ib = img + (size_t)b * 3 * H * W;
+    {
+        f32x4 tw[3];
+        float tp[3][E0_PR];
+        const int x = tid % PWc, r0 = tid / PWc, rstep = 256 / PWc;   // two divisions per thread, none per element
+        const bool lane_on = tid < rstep * PWc;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int f = min(tid + 256 * j, 599) * 4;                       // 600 float4 of weights (clamped: no branch)
+            tw[j] = *reinterpret_cast<const f32x4*>(w + f);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int u = 0; u < E0_PR; ++u) {
+                const int r = r0 + u * rstep, iy = 2 * oy0 - 2 + r, ix = x - 2;
+                const bool ok = lane_on && r < R && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                tp[c][u] = ok ? ib[(size_t)c * H * W + iy * W + ix] : 0.f;
+            }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (tid + 256 * j < 600) *reinterpret_cast<f32x4*>(wl + (tid + 256 * j) * 4) = tw[j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int u = 0; u < E0_PR; ++u) {
+                const int r = r0 + u * rstep;
+                if (lane_on && r < R) patch[(c * R + r) * PWc + x] = tp[c][u];
+            }
+    }
+    __syncthreads();
+    const int pl = tid >> 2, cg = tid & 3;
+    const int ry = pl / W2, ox = pl - ry * W2;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = bias[cg * 8 + o];
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const float v = patch[(ci * R + 2 * ry + ky) * PWc + 2 * ox + kx];
+                const float* wr = wl + ((ky * 5 + kx) * 3 + ci) * 32 + cg * 8;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4);
+                acc[0] = fmaf(v, w0[0], acc[0]); acc[1] = fmaf(v, w0[1], acc[1]); acc[2] = fmaf(v, w0[2], acc[2]); acc[3] = fmaf(v, w0[3], acc[3]);
+                acc[4] = fmaf(v, w1[0], acc[4]); acc[5] = fmaf(v, w1[1], acc[5]); acc[6] = fmaf(v, w1[2], acc[6]); acc[7] = fmaf(v, w1[3], acc[7]);
+            }
+    float* op = out + (((size_t)b * H2 + oy0 + ry) * W2 + ox) * 32 + cg * 8;
+    *reinterpret_cast<f32x4*>(op) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    *reinterpret_cast<f32x4*>(op + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+}
+
 int conv_enc0(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s) {
     PIVP_CHECK_ARG(img && w && bias && out && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0);
-    const int total = B * (H / 2) * (W / 2);
+    const int H2 = H / 2, W2 = W / 2;
+    const int total = B * H2 * W2;
+    if ((W2 == 8 || W2 == 16 || W2 == 32 || W2 == 64) && H2 % (64 / W2) == 0 && ((uintptr_t)w & 15) == 0) {
+        const int rows = 64 / W2, R = 2 * rows + 3, npatch = 3 * R * (W + 3);
+        if (W + 3 <= 256 && R <= E0_PR * (256 / (W + 3))) {
+            const size_t lds = sizeof(float) * (75 * 32 + npatch);
+            hipLaunchKernelGGL(conv_enc0_rows_kernel, dim3(B * (H2 / rows)), dim3(256), lds, s, img, w, bias, out, B, H, W);
+            return PIVP_LAUNCH_STATUS();
+        }
+    }
     hipLaunchKernelGGL(conv_enc0_kernel, dim3((total + 63) / 64), dim3(256), 0, s, img, w, bias, out, B, H, W);
     return PIVP_LAUNCH_STATUS();
 }
@@ -179,12 +257,22 @@ __global__ __launch_bounds__(256) void enc3_state_kernel(const float* __restrict
     const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     if (tid < 5) sa[tid] = action[b * 5 + tid];
     else if (tid < 10) sa[tid] = state[b * 5 + tid - 5];
-    for (int i = tid; i < 64 * 64; i += 256) wl[i] = w3[i];
     const int npx = min(64, HW8 - tile * 64);
     const float* src = e2 + ((size_t)b * HW8 + tile * 64) * 64;
-    for (int i = tid; i < 64 * 64; i += 256) {
-        const int p = i >> 6, k = i & 63;
-        xt[p * 65 + k] = p < npx ? src[i] : 0.f;
+    {   // all eight 16-B loads of a thread are issued before the first LDS store (one round trip, not thirty-two)
+        f32x4 tw[4], tx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = (tid + 256 * j) * 4;   // float index in the 64 x 64 weight block / pixel tile
+            tw[j] = *reinterpret_cast<const f32x4*>(w3 + f);
+            tx[j] = (f >> 6) < npx ? *reinterpret_cast<const f32x4*>(src + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = (tid + 256 * j) * 4, p = f >> 6, k = f & 63;
+            *reinterpret_cast<f32x4*>(wl + f) = tw[j];
+            xt[p * 65 + k] = tx[j][0]; xt[p * 65 + k + 1] = tx[j][1]; xt[p * 65 + k + 2] = tx[j][2]; xt[p * 65 + k + 3] = tx[j][3];
+        }
     }
     __syncthreads();
     if (tid < 64) {
