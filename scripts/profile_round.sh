@@ -1,0 +1,19 @@
+#!/bin/bash
+# One GPU-box call that produces every profile artefact kept under profiles/<round>/ (run from the repo root through gpurun):
+#   bash scripts/profile_round.sh <tag>        -> gpurun_out/prof_<tag>/{kt,train,fetch,write}/..., bench JSON lines
+set -e -o pipefail
+tag=${1:-cur}
+out=gpurun_out/prof_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+python3 bench.py > $out/bench.json 2> $out/bench.err
+python3 bench.py --mode train --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_train.json 2> $out/bench_train.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o rollout -- python3 bench.py --steps 7 --warmup 2 --no-cpu-baseline > $out/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/train -o train -- python3 bench.py --mode train --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > $out/train.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $out/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $out/write.log 2>&1
+python3 scripts/pmc_summary.py $out/fetch $out/write $out/pmc "bench.py --steps 2 --warmup 1 (config 2: CDNA B=32 T=10 64x64)"
+# keep the merge small: the raw per-dispatch traces are not needed back
+rm -f $out/kt/*kernel_trace.csv $out/train/*kernel_trace.csv
+find $out/fetch $out/write -name '*counter_collection.csv' -delete
+cat $out/bench.json; cat $out/bench_train.json
