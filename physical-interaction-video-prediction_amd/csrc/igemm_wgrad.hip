@@ -9,6 +9,8 @@
 // channels x 128 output columns, and a slice of the pixels; slices are combined with fp32 atomic adds straight into
 // the K-inner packed gradient (same layout as the weight, so Adam is elementwise).  Gradients therefore accumulate
 // across blocks, timesteps and calls until the host clears them (Chainer: cleargrads + backward, TM:950).
+#include <type_traits>
+
 #include "pivp_kernels.h"
 
 namespace pivp {
@@ -231,22 +233,36 @@ __global__ __launch_bounds__(256, 1) void wgrad5x5_kernel(const WgradDesc d) {
         if (more) issue(c + 4);
         const float* xs = wbase + buf * WBUF + l31;
         const float* ys = xs - l31 + SP * XP + l31;
+        // operands of k-step s2+1 are read from LDS BEFORE the 5*NTW MFMAs of k-step s2 are issued, and the order is pinned:
+        // left to itself hipcc reads each operand right in front of its MFMA and waits lgkmcnt(0) twice per k-step
+        // (two exposed LDS round trips per 10 MFMAs: the kernel ran at 70 TFLOP/s)
+        float av[2][5], bv[2][NTW];
+        auto read_step = [&](auto S2, int slot) {
+            constexpr int s2 = decltype(S2)::value;
+            constexpr int sidx0 = (2 * s2 / SW) * (SW + 4) + (2 * s2 % SW);   // strip index of (pixel 2*s2, kx = 0)
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) {
-            constexpr int dummy = 0; (void)dummy;
-            const int pix = 2 * s2 + half;                               // this half-wave's pixel (MFMA k index)
-            const int sidx = (2 * s2 / SW) * (SW + 4) + (2 * s2 % SW) + half;   // strip index of (pixel, kx = 0)
-            float bf[NTW];
+            for (int t = 0; t < NTW; ++t) bv[slot][t] = ys[(2 * s2 + half) * YP + t * 32];
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) bf[t] = ys[pix * YP + t * 32];
+            for (int kx = 0; kx < 5; ++kx) av[slot][kx] = xs[(sidx0 + half + kx) * XP];
+        };
+        auto kstep = [&](auto S2) {
+            constexpr int s2 = decltype(S2)::value, cur = s2 & 1;
+            if constexpr (s2 + 1 < 16) read_step(std::integral_constant<int, s2 + 1>{}, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx) {
-                const float a = xs[(sidx + kx) * XP];
+            for (int kx = 0; kx < 5; ++kx)
 #pragma unroll
                 for (int t = 0; t < NTW; ++t)
-                    acc[kx * NTW + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[t], acc[kx * NTW + t], 0, 0, 0);
-            }
-        }
+                    acc[kx * NTW + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][kx], bv[cur][t], acc[kx * NTW + t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        read_step(std::integral_constant<int, 0>{}, 0);
+        kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{}); kstep(std::integral_constant<int, 2>{});
+        kstep(std::integral_constant<int, 3>{}); kstep(std::integral_constant<int, 4>{}); kstep(std::integral_constant<int, 5>{});
+        kstep(std::integral_constant<int, 6>{}); kstep(std::integral_constant<int, 7>{}); kstep(std::integral_constant<int, 8>{});
+        kstep(std::integral_constant<int, 9>{}); kstep(std::integral_constant<int, 10>{}); kstep(std::integral_constant<int, 11>{});
+        kstep(std::integral_constant<int, 12>{}); kstep(std::integral_constant<int, 13>{}); kstep(std::integral_constant<int, 14>{});
+        kstep(std::integral_constant<int, 15>{});
         if (more) store(buf ^ 1);
         buf ^= 1;
     }
@@ -301,9 +317,25 @@ static int launch_wgrad5x5(const WgradDesc& d, hipStream_t s) {
     }
     const int tiles = 5 * (d.cin / 32) * (d.N / (32 * NTW));
     const int chunks = d.M / 32;
-    int nsplit = (512 + tiles - 1) / tiles;              // ~2 blocks per CU
-    if (nsplit > chunks / 16) nsplit = chunks / 16;      // >= 4 chunks per wave
-    if (nsplit < 1) nsplit = 1;
+    // One block per CU is resident (~100 KB of LDS), so the grid is sized to whole rounds of the chip's CUs: the first
+    // version asked for "about 512" blocks and got 520-600, i.e. a third round that ran 8-88 blocks on 256 CUs (lstm7: 264 us
+    // for 171 us of MFMA work).  Take the fewest rounds (1..3) whose last round is at least 90 % full.
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    int nsplit = 1;
+    double best = 0.0;
+    for (int r = 1; r <= 3; ++r) {
+        int ns = (cus * r) / tiles;
+        if (ns > chunks / 16) ns = chunks / 16;          // >= 4 chunks per wave
+        if (ns < 1) ns = 1;
+        const long blocks = (long)tiles * ns;
+        const double fill = (double)blocks / (double)(((blocks + cus - 1) / cus) * cus);
+        if (fill > best + 0.02) { best = fill; nsplit = ns; }
+        if (best >= 0.9) break;
+    }
     hipLaunchKernelGGL((wgrad5x5_kernel<NTW, SW>), dim3(tiles, nsplit), dim3(256), lds_bytes, s, d);
     return PIVP_LAUNCH_STATUS();
 }
