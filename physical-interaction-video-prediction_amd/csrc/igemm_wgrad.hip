@@ -225,6 +225,9 @@ __global__ __launch_bounds__(256, 1) void wgrad5x5_kernel(const WgradDesc d) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    float bsum[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) bsum[t] = 0.f;
     int c = c_begin + wave;
     if (c < c_end) { issue(c); store(0); }
     int buf = 0;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(256, 1) void wgrad5x5_kernel(const WgradDesc d) {
         // operands of k-step s2+1 are read from LDS BEFORE the 5*NTW MFMAs of k-step s2 are issued, and the order is pinned:
         // left to itself hipcc reads each operand right in front of its MFMA and waits lgkmcnt(0) twice per k-step
         // (two exposed LDS round trips per 10 MFMAs: the kernel ran at 70 TFLOP/s)
-        float av[2][5], bv[2][NTW];
+        float av[2][5], bv[2][NTW];   // (bsum: running column sums of the dY values this lane feeds the MFMAs = bias gradient)
         auto read_step = [&](auto S2, int slot) {
             constexpr int s2 = decltype(S2)::value;
             constexpr int sidx0 = (2 * s2 / SW) * (SW + 4) + (2 * s2 % SW);   // strip index of (pixel 2*s2, kx = 0)
@@ -249,6 +252,8 @@ __global__ __launch_bounds__(256, 1) void wgrad5x5_kernel(const WgradDesc d) {
             constexpr int s2 = decltype(S2)::value, cur = s2 & 1;
             if constexpr (s2 + 1 < 16) read_step(std::integral_constant<int, s2 + 1>{}, cur ^ 1);
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bsum[t] += bv[cur][t];
 #pragma unroll
             for (int kx = 0; kx < 5; ++kx)
 #pragma unroll
@@ -265,6 +270,15 @@ __global__ __launch_bounds__(256, 1) void wgrad5x5_kernel(const WgradDesc d) {
         kstep(std::integral_constant<int, 15>{});
         if (more) store(buf ^ 1);
         buf ^= 1;
+    }
+    // ---- bias gradient: the blocks of kernel row 2 / channel block 0 have fed every dY element of their pixel range through
+    // the MFMAs exactly once; lane (n, half) holds the sum over its half's pixels ---------------------------------------
+    if (d.db && ky == 2 && cb == 0) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const float v = bsum[t] + __shfl_xor(bsum[t], 32, 64);
+            if (half == 0) atomicAdd(d.db + n0 + t * 32 + l31, v);
+        }
     }
     // ---- block reduction of the 4 workers + transposed atomics -------------------------------------------------
     // LDS image of one worker's result: [tap kx][tile t][n 0..31][ci 0..31]  (NACC * 1024 floats = 20/40 KB)
@@ -340,13 +354,15 @@ static int launch_wgrad5x5(const WgradDesc& d, hipStream_t s) {
     return PIVP_LAUNCH_STATUS();
 }
 
-int igemm_wgrad(const WgradDesc& d, hipStream_t s) {
+int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done) {
+    if (bias_done) *bias_done = 0;
     PIVP_CHECK_ARG(d.x0 && d.dy && d.dw && d.c0 > 0 && d.c0 % 32 == 0 && d.c1 >= 0 && d.c1 % 32 == 0 && (d.c1 == 0 || d.x1));
     PIVP_CHECK_ARG(d.cin == d.c0 + d.c1 && d.wcin >= d.cin && d.wcin % 32 == 0 && d.N > 0 && d.N % 32 == 0);
     PIVP_CHECK_ARG(d.M == d.B * d.Hg * d.Wg && d.M > 0 && d.ksize >= 1 && d.ksize <= 7);
     PIVP_CHECK_ARG(d.bytes0 > 0 && d.bytesy > 0 && (d.c1 == 0 || d.bytes1 > 0));
     if (!d.deconv && d.ksize == 5 && d.pad == 2 && d.stride == 1 && d.M % 32 == 0 && d.N % 64 == 0 &&
         (d.Wg == 8 || d.Wg == 16 || d.Wg % 32 == 0) && d.Hx == d.Hy && d.Wx == d.Wy) {
+        if (bias_done) *bias_done = d.db ? 1 : 0;
         if (d.Wg == 8) return launch_wgrad5x5<2, 8>(d, s);
         if (d.Wg == 16) return launch_wgrad5x5<2, 16>(d, s);
         return launch_wgrad5x5<2, 32>(d, s);

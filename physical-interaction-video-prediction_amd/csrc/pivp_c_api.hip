@@ -92,7 +92,8 @@ int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, in
 
 // weight gradient of: mode 0 = conv K x K stride `stride` pad `pad`; mode 1 = transposed 3x3 s2 p1
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
-              float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s) {
+              float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s, float* db,
+              int* bias_done) {
     WgradDesc d;
     memset(&d, 0, sizeof(d));
     d.x0 = x0; d.c0 = c0; d.ld0 = ld0; d.x1 = x1; d.c1 = x1 ? c1 : 0; d.ld1 = ld1; d.cin = c0 + (x1 ? c1 : 0); d.wcin = wcin;
@@ -103,7 +104,8 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
     const long long b0 = view_bytes(B, Hx, Wx, ld0), b1 = x1 ? view_bytes(B, Hx, Wx, ld1) : 0, by = view_bytes(B, Hy, Wy, ldy);
     if (!fits31(b0) || (x1 && !fits31(b1)) || !fits31(by)) return PIVP_ERR_BADARG;
     d.bytes0 = (int)b0; d.bytes1 = (int)b1; d.bytesy = (int)by;
-    return igemm_wgrad(d, s);
+    d.db = db;
+    return igemm_wgrad(d, s, bias_done);
 }
 
 // ConvLSTM cell backward (TM:262-272): gate math, data gradient d[x,h_prev], weight and bias gradients.
@@ -121,9 +123,10 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
     }
     rc = run_conv_s1(dG, N, N, wt, d_in, cin, cin, 5, B, H, W, s);        // d[x,h] = conv5x5(dG, W^T flipped)
     if (rc != PIVP_OK) return rc;
-    rc = run_wgrad(0, x, cx, ldx, h_prev, C, C, cin, dG, N, N, dW, B, H, W, H, W, 5, 2, 1, s);
+    int bias_done = 0;   // the 5x5 weight-gradient kernel sums dG's columns on the side
+    rc = run_wgrad(0, x, cx, ldx, h_prev, C, C, cin, dG, N, N, dW, B, H, W, H, W, 5, 2, 1, s, db, &bias_done);
     if (rc != PIVP_OK) return rc;
-    return bias_grad(dG, N, N, M, db, s);
+    return bias_done ? PIVP_OK : bias_grad(dG, N, N, M, db, s);
 }
 
 int run_layernorm(const float* x, const float* g, const float* b, float* out, float* partials, int B, int n, int C,

@@ -48,8 +48,10 @@ struct WgradDesc {
     int Hg, Wg, M;                       // anchor grid (conv: output pixels, deconv: input pixels), M = B*Hg*Wg
     int deconv, ksize, pad, stride;
     int bytes0, bytes1, bytesy;
+    float* db;                           // optional bias gradient [N] (column sums of dy), accumulated with atomics when the
+                                         // kernel that runs can do it on the side (*bias_done = 1), else left to bias_grad
 };
-int igemm_wgrad(const WgradDesc& d, hipStream_t s);
+int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done = nullptr);
 int repack_transpose(const float* w, float* wt, int taps, int cin, int N, int flip, hipStream_t s);
 
 // ln_nparts (optional): receives the number of LayerNorm partials per sample the launch writes to d.ln_part (0: none)
