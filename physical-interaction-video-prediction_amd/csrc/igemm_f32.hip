@@ -497,20 +497,48 @@ int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     if (rc != PIVP_OK) return rc;
     const int nt = d.N / 32;
     const long full = (long)((d.M + 127) / 128) * d.nphase;   // blocks with BM = 128 and the whole N in one block
-    if (d.ksplit_ok && !d.deconv && !d.bias && !d.relu && !d.accum && (nt > 4 || full * (nt > 2 ? 1 : 1) < 256)) {
-        // data gradients: BN = 64 column blocks on BM = 64 tiles, K split over kernel rows until the chip is full;
-        // the output must have been zeroed by the caller (partials are added atomically)
-        if (nt % 2 == 0) {
-            const long blocks = (long)((d.M + 63) / 64) * (nt / 2);
-            int ks = blocks >= 256 ? 1 : (int)((256 + blocks - 1) / blocks);
-            if (ks > d.ksize) ks = d.ksize;
-            return launch_igemm<2, 2, 2, false>(d, stream, ks, ln_nparts);
-        } else {
-            const long blocks = full * nt;
-            int ks = blocks >= 256 ? 1 : (int)((256 + blocks - 1) / blocks);
-            if (ks > d.ksize) ks = d.ksize;
-            return launch_igemm<4, 1, 1, false>(d, stream, ks, ln_nparts);
+    if (d.ksplit_ok && !d.deconv && !d.bias && !d.relu && !d.accum && d.ksize * d.ksize * ((d.c0 + d.c1) / 32) > 40) {
+        // Long-K data gradients (the ConvLSTM's 5x5 over 4C channels).  The output is pre-zeroed and may be produced by K-split
+        // blocks with atomic adds, so both the tile AND the split are free: pick the pair with the least modelled time
+        //   rounds(blocks over the CUs) x rows-per-split x tile area / tile efficiency  (+ a per-block constant),
+        // because at M = 2048..8192 the block count, not the tile shape, decides: 384 blocks on 256 CUs run as 2 rounds.
+        struct Tile { int wm, wn, ntb; double eff; };
+        static const Tile tiles[] = {{2, 2, 2, 0.85}, {4, 1, 1, 0.70}, {4, 1, 2, 0.90}, {4, 1, 3, 0.95}, {4, 1, 4, 1.00}, {2, 2, 4, 0.95}, {1, 4, 4, 0.80}};
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         }
+        static const int force_t = [] { const char* e = getenv("PIVP_DGRAD_TILE"); return e ? atoi(e) : -1; }();   // tuning
+        static const int force_k = [] { const char* e = getenv("PIVP_DGRAD_KS"); return e ? atoi(e) : 0; }();
+        int bt = -1, bks = 1;
+        double bcost = 1e300;
+        for (int t = 0; t < 7; ++t) {
+            if (nt % tiles[t].ntb) continue;
+            if (force_t >= 0 && t != force_t) continue;
+            const int bm = 32 * tiles[t].wm, bn = 32 * tiles[t].ntb;
+            const long mb = (d.M + bm - 1) / bm, nb = d.N / bn;
+            for (int ks = 1; ks <= d.ksize; ++ks) {
+                if (force_k > 0 && ks != force_k) continue;
+                const long blocks = mb * nb * ks;
+                const long rounds = (blocks + cus - 1) / cus;
+                const int rows = (d.ksize + ks - 1) / ks;                   // kernel rows of the largest split
+                const double work = (double)bm * bn * (rows * d.ksize + 1.5) / tiles[t].eff;   // +1.5 taps: prologue / epilogue
+                // one resident block per CU hides no latency (lstm4, 64x64 tiles: 256 blocks 151 us, 2 x 256 K-split blocks 139)
+                const double cost = rounds * work * (ks > 1 ? 1.03 : 1.0) / (rounds >= 2 ? 1.0 : 0.75);
+                if (cost < bcost) { bcost = cost; bt = t; bks = ks; }
+            }
+        }
+        switch (bt) {
+            case 0: return launch_igemm<2, 2, 2, false>(d, stream, bks, ln_nparts);
+            case 1: return launch_igemm<4, 1, 1, false>(d, stream, bks, ln_nparts);
+            case 2: return launch_igemm<4, 1, 2, false>(d, stream, bks, ln_nparts);
+            case 3: return launch_igemm<4, 1, 3, false>(d, stream, bks, ln_nparts);
+            case 4: return launch_igemm<4, 1, 4, false>(d, stream, bks, ln_nparts);
+            case 5: return launch_igemm<2, 2, 4, false>(d, stream, bks, ln_nparts);
+            case 6: return launch_igemm<1, 4, 4, false>(d, stream, bks, ln_nparts);
+        }
+        return PIVP_ERR_BADARG;
     }
     // Short K (the 3x3 stride-2 convs and the transposed convs: 2..18 chunks) or too few big tiles to fill the chip:
     // 32-row tiles with K split over the waves (igemm_small.hip).  Measured at B = 32 (scripts/bench_tail_ops.py):
