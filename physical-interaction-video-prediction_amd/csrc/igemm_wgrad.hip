@@ -59,13 +59,27 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
     const bool in0 = xci < d.c0;
     const bool ycol_ok = (n0 + yc) < d.N;
     f32x4 rx[2], rY[4];
+    // anchor coordinates without per-load divisions: when chunks never straddle a sample and the anchor-grid width is a
+    // multiple or a divisor of 32 (every map of this model), row r of a chunk sits at a fixed (row, column) offset from the
+    // chunk's first anchor.  The first version divided twice per load: ~420 of the ~600 instructions between two chunks'
+    // 32 MFMAs.
+    const bool fast = HWg % WG_PIX == 0 && (d.Wg % WG_PIX == 0 || WG_PIX % d.Wg == 0);
+    int xdr[2], xdx[2], ydr[4], ydx[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int r = xr + 16 * j; xdr[j] = d.Wg >= WG_PIX ? 0 : r / d.Wg; xdx[j] = r - xdr[j] * d.Wg; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int r = yr + 8 * j; ydr[j] = d.Wg >= WG_PIX ? 0 : r / d.Wg; ydx[j] = r - ydr[j] * d.Wg; }
     auto issue = [&](int chunk) {
+        const int m0 = __builtin_amdgcn_readfirstlane(chunk * WG_PIX);
+        const int b0 = m0 / HWg, rem0 = m0 - b0 * HWg, ay0 = rem0 / d.Wg, ax0 = rem0 - ay0 * d.Wg;   // wave-uniform
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int m = chunk * WG_PIX + xr + 16 * j;
             unsigned off0 = OOB, off1 = OOB;
             if (m < d.M && xcol_ok) {
-                const int b = m / HWg, rem = m - b * HWg, ay = rem / d.Wg, ax = rem - ay * d.Wg;
+                int b, ay, ax;
+                if (fast) { b = b0; ay = ay0 + xdr[j]; ax = ax0 + xdx[j]; }
+                else { b = m / HWg; const int rem = m - b * HWg; ay = rem / d.Wg; ax = rem - ay * d.Wg; }
                 const int iy = ay * sa + ady, ix = ax * sa + adx;
                 if ((unsigned)iy < (unsigned)d.Hx && (unsigned)ix < (unsigned)d.Wx) {
                     const int pix = (b * d.Hx + iy) * d.Wx + ix;
@@ -82,7 +96,9 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
             const int m = chunk * WG_PIX + yr + 8 * j;
             unsigned off = OOB;
             if (m < d.M && ycol_ok) {
-                const int b = m / HWg, rem = m - b * HWg, ay = rem / d.Wg, ax = rem - ay * d.Wg;
+                int b, ay, ax;
+                if (fast) { b = b0; ay = ay0 + ydr[j]; ax = ax0 + ydx[j]; }
+                else { b = m / HWg; const int rem = m - b * HWg; ay = rem / d.Wg; ax = rem - ay * d.Wg; }
                 const int oy = ay * sb + bdy, ox = ax * sb + bdx;
                 if ((unsigned)oy < (unsigned)d.Hy && (unsigned)ox < (unsigned)d.Wy)
                     off = (unsigned)((((b * d.Hy + oy) * d.Wy + ox) * d.ldy + n0 + yc) * 4);
@@ -370,8 +386,9 @@ int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done) {
     const int ncb = (d.cin + WG_CI - 1) / WG_CI, nnb = (d.N + WG_N - 1) / WG_N;
     const int tiles = d.ksize * d.ksize * ncb * nnb;
     const int chunks = (d.M + WG_PIX - 1) / WG_PIX;
-    int nsplit = (1024 + tiles - 1) / tiles;              // aim at ~4 blocks per CU
-    if (nsplit > chunks / 8) nsplit = chunks / 8;         // but keep >= 8 chunks (256 pixels) per block
+    // every block ends with a tile of atomics (64 x 128), so no more pixel splits than fill the chip twice (3 blocks fit a CU)
+    int nsplit = (512 + tiles - 1) / tiles;
+    if (nsplit > chunks / 8) nsplit = chunks / 8;         // and >= 8 chunks (256 pixels) per block
     if (nsplit < 1) nsplit = 1;
     hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(tiles, nsplit), dim3(256), 0, s, d);
     return PIVP_LAUNCH_STATUS();
