@@ -133,9 +133,12 @@ def main():
             lib = plan.lib
             lib.pivp_plan_set_profiling(plan.h, 1)
             ms_tot = np.zeros(7); n_tot = np.zeros(7, dtype=np.int64); flops = np.zeros(7)
+            t_prof = 0.0
             for _ in range(args.steps):
+                tp0 = time.perf_counter()
                 step()
                 torch.cuda.synchronize()
+                t_prof += time.perf_counter() - tp0
                 ms = (ctypes.c_double * 7)(); n = (ctypes.c_int * 7)(); fl = (ctypes.c_double * 7)()
                 rc = lib.pivp_plan_profile_read(plan.h, ms, n, fl)
                 assert rc == 0, rc
@@ -154,6 +157,7 @@ def main():
                 'per_layer_tflops': {('lstm%d' % (i + 1)): round(float(flops[i] / (ms_tot[i] * 1e-3) / 1e12), 2)
                                      for i in range(7) if ms_tot[i] > 0},
                 'share_of_step_time': round(total_s / args.steps / (elapsed / args.steps), 3),
+                'ms_per_step_with_events': round(t_prof / args.steps * 1e3, 3),
             }
 
     if dist is not None:
