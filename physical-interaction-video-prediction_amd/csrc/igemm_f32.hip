@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x0), 0, d.bytes0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.c1 ? d.x1 : d.x0), 0, d.c1 ? d.bytes1 : d.bytes0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, d.bytesw, 0x00020000);
-    int a_off0[NA], a_off1[NA], a_iy0[NA], a_ix0[NA];   // anchor pixel's byte offset in either source, and its coords
+    int a_off0[NA], a_off1[NA];   // anchor pixel's byte offset in either source
+    unsigned a_mask[NA];          // bit (ty * 5 + tx): tap (ty, tx) of this anchor reads inside the image (ksize <= 5)
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
         const int m = m0 + prow + 32 * j;
@@ -120,15 +121,27 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
             const int rem = m - b * HWg;
             const int ay = rem / d.Wg;
             const int ax = rem - ay * d.Wg;
-            a_iy0[j] = ay * d.in_step;
-            a_ix0[j] = ax * d.in_step;
-            const int pix = b * d.Hin * d.Win + a_iy0[j] * d.Win + a_ix0[j];
+            const int iy0 = ay * d.in_step, ix0 = ax * d.in_step;
+            const int pix = b * d.Hin * d.Win + iy0 * d.Win + ix0;
             a_off0[j] = (pix * d.ld0 + cvec * 4) * 4;
             a_off1[j] = (pix * d.ld1 + cvec * 4) * 4;
+            // validity is separable: row ty is inside for all columns or none.  Ten range checks here replace two adds, two
+            // compares and an s_and per gathered piece and chunk in the loop.
+            unsigned colm = 0, m25 = 0;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const int dxx = deconv ? ((px + 1 - (px ? 2 * t : 1)) >> 1) : t - d.pad;
+                if (t < ntx && (unsigned)(ix0 + dxx) < (unsigned)d.Win) colm |= 1u << t;
+            }
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const int dyy = deconv ? ((py + 1 - (py ? 2 * t : 1)) >> 1) : t - d.pad;
+                if (t < nty_all && (unsigned)(iy0 + dyy) < (unsigned)d.Hin) m25 |= colm << (5 * t);
+            }
+            a_mask[j] = m25;
         } else {
             a_off0[j] = a_off1[j] = 0;
-            a_iy0[j] = -(1 << 20);  // never in range
-            a_ix0[j] = 0;
+            a_mask[j] = 0;            // never in range
         }
     }
     int b_goff[NB];                           // byte offset of this thread's float4 inside a [N][32] weight chunk
@@ -145,16 +158,18 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
 
     // scalar state of the NEXT chunk to load: channel chunk l_cc of tap (l_ty, l_tx); no division, no branch
     int l_cc = 0, l_ty = ty_begin, l_tx = 0;
-    int s_dy = 0, s_dx = 0, s_delta = 0, s_ld = 0, s_wbase = 0;
+    int s_delta = 0, s_ld = 0, s_wbase = 0;
+    unsigned s_bit = 0;
     bool s_first = true;
     auto stage_begin = [&]() {            // scalar prelude of one chunk's loads, then advance the counters
-        int wi;
+        int wi, s_dy, s_dx;
         if (deconv) {
             const int ky = py ? 2 * l_ty : 1, kx = px ? 2 * l_tx : 1;
             s_dy = (py + 1 - ky) >> 1; s_dx = (px + 1 - kx) >> 1; wi = ky * 3 + kx;
         } else {
             s_dy = l_ty - d.pad; s_dx = l_tx - d.pad; wi = l_ty * d.ksize + l_tx;
         }
+        s_bit = __builtin_amdgcn_readfirstlane(1u << (l_ty * 5 + l_tx));
         const int ch = l_cc << 5;
         s_first = ch < d.c0;
         s_ld = s_first ? d.ld0 : d.ld1;
@@ -163,8 +178,6 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
         // soffset turns every weight load into a waterfall loop)
         s_delta = __builtin_amdgcn_readfirstlane(((s_dy * d.Win + s_dx) * s_ld + cbase) * 4);   // bytes, relative to the anchor pixel
         s_wbase = __builtin_amdgcn_readfirstlane((wi * (d.wcin >> 5) + l_cc) * d.N * 128);       // bytes; the weight keeps all its Cin chunks
-        s_dy = __builtin_amdgcn_readfirstlane(s_dy);
-        s_dx = __builtin_amdgcn_readfirstlane(s_dx);
         ++l_cc;
         const bool w0 = l_cc == ncc;
         l_cc = w0 ? 0 : l_cc;
@@ -176,9 +189,7 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
     auto load_piece = [&](auto J) {        // piece j < NA: A-tile load j; NA <= j < NA+NB: B-tile load j-NA
         constexpr int j = decltype(J)::value;
         if constexpr (j < NA) {
-            const int iy = a_iy0[j] + s_dy;
-            const int ix = a_ix0[j] + s_dx;
-            const bool ok = (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+            const bool ok = (a_mask[j] & s_bit) != 0;
             unsigned off = ok ? (unsigned)((s_first ? a_off0[j] : a_off1[j]) + s_delta) : OOB;
             if constexpr (ABL == 4) off = (unsigned)a_off0[j];                       // loads without the address math
             if constexpr (ABL == 5) { asm volatile("" :: "v"(off)); return; }        // address math without the loads
@@ -437,7 +448,7 @@ int igemm_validate(const IgemmDesc& d, bool lstm) {
     PIVP_CHECK_ARG(d.ld0 >= d.c0 && d.ld0 % 4 == 0 && (d.c1 == 0 || (d.ld1 >= d.c1 && d.ld1 % 4 == 0)));
     PIVP_CHECK_ARG(d.B > 0 && d.Hin > 0 && d.Win > 0 && d.Hg > 0 && d.Wg > 0 && d.in_step >= 1);
     PIVP_CHECK_ARG(d.M == d.B * d.Hg * d.Wg);
-    PIVP_CHECK_ARG(d.deconv ? (d.nphase == 4 && d.in_step == 1 && d.out_step == 2) : (d.nphase == 1 && d.ksize >= 1 && d.ksize <= 7 && d.pad >= 0));
+    PIVP_CHECK_ARG(d.deconv ? (d.nphase == 4 && d.in_step == 1 && d.out_step == 2) : (d.nphase == 1 && d.ksize >= 1 && d.ksize <= 5 && d.pad >= 0));   // 5x5 tap bitmask
     PIVP_CHECK_ARG(d.bytes0 > 0 && d.bytesw > 0 && (d.c1 == 0 || d.bytes1 > 0));
     PIVP_CHECK_ARG(d.wcin >= d.c0 + d.c1 && d.wcin % 32 == 0);
     if (lstm) {
