@@ -26,12 +26,20 @@ namespace {
 constexpr int TP = 36;                 // LDS row pitch (floats)
 constexpr int TH = 8, TW = 20;         // halo patch: (4 + 4) rows x (16 + 4) columns
 constexpr int A_FL = TH * TW * TP;     // 5760 floats
-constexpr int B_FL = 128 * TP;         // 4608 floats
 __device__ __forceinline__ float t_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float t_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
 }
 
+// NCH: channels per block (x 4 gates = block columns).  32: wave tile 32 anchors x (4 gates x 16 channels), two MFMA tiles.
+// 16: wave tile 32 anchors x (4 gates x 8 channels), one MFMA tile -- twice the blocks, for the 16x16 maps whose 256 blocks
+// of 32 channels leave one block (one wave per SIMD) on every CU.
+template <int NCH>
 __global__ __launch_bounds__(256, 1) void convlstm_tile_kernel(const IgemmDesc d) {
+    constexpr int B_FL = 4 * NCH * TP;          // weight tile: [4 gates x NCH channels][36]
+    constexpr int TPW = NCH / 16;               // MFMA tiles per wave
+    constexpr int CPW = NCH / 2;                // channels per wave (all 4 gates of a channel stay in one wave)
+    constexpr int GPT = 32 / CPW;               // gates per MFMA tile
+    constexpr int NB = NCH / 8;                 // weight float4 per thread and chunk
     extern __shared__ __attribute__((aligned(16))) float lds[];   // A | B0 | B1
     float* const At = lds;
     float* const Bt = lds + A_FL;
@@ -39,7 +47,7 @@ __global__ __launch_bounds__(256, 1) void convlstm_tile_kernel(const IgemmDesc d
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
     const int half = lane >> 5, l31 = lane & 31;
-    const int C = d.C, n_nblk = C >> 5;
+    const int C = d.C, n_nblk = C / NCH;
     const int H = d.Hin, W = d.Win;
     const int pw = W >> 4, ph = H >> 2;                // patches per row / column
     const int n_patch = d.B * ph * pw;
@@ -73,14 +81,17 @@ __global__ __launch_bounds__(256, 1) void convlstm_tile_kernel(const IgemmDesc d
         a_go1[j] = ok ? (unsigned)((pix * d.ld1 + cvec * 4) * 4) : OOB;
         a_lw[j] = tp * TP + cvec * 4;
     }
-    // B tile: [128 rows = 4 gates x 32 channels][32 k]: 1024 float4, 4 per thread
+    // B tile: [4 gates x NCH channels][32 k]: NB float4 per thread; tile row = gate * NCH + channel
     const int prow = tid >> 3;
-    int b_go[4];
+    int b_go[NB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b_go[j] = ((j * C + nblk * 32 + prow) * 32 + cvec * 4) * 4;   // gate j, channel prow
+    for (int j = 0; j < NB; ++j) {
+        const int row = prow + 32 * j, g = row / NCH, cl = row - g * NCH;
+        b_go[j] = ((g * C + nblk * NCH + cl) * 32 + cvec * 4) * 4;
+    }
     const int b_lw = prow * TP + cvec * 4;
 
-    f32x4 ra[5], rb[4];
+    f32x4 ra[5], rb[NB];
     // next weight chunk to load: tap l_tap of channel chunk l_cc (taps innermost)
     int l_tap = 0, l_cc = 0;
     int s_wbase = 0;
@@ -92,11 +103,11 @@ __global__ __launch_bounds__(256, 1) void convlstm_tile_kernel(const IgemmDesc d
     };
     auto load_b = [&](auto J) {
         constexpr int j = decltype(J)::value;
-        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, b_go[j], s_wbase, 0));
+        if constexpr (j < NB) rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, b_go[j], s_wbase, 0));
     };
     auto store_b = [&](auto J, int buf) {
         constexpr int j = decltype(J)::value;
-        *reinterpret_cast<f32x4*>(Bt + buf * B_FL + b_lw + 32 * j * TP) = rb[j];
+        if constexpr (j < NB) *reinterpret_cast<f32x4*>(Bt + buf * B_FL + b_lw + 32 * j * TP) = rb[j];
     };
     auto load_a = [&](auto J, int cc) {     // piece J of channel chunk cc's patch
         constexpr int j = decltype(J)::value;
@@ -111,17 +122,17 @@ __global__ __launch_bounds__(256, 1) void convlstm_tile_kernel(const IgemmDesc d
         for (int j = 0; j < 5; ++j) *reinterpret_cast<f32x4*>(At + a_lw[j]) = ra[j];
     };
 
-    f32x16 acc[2];
+    f32x16 acc[TPW];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     // fragment addresses (floats): A row of lane l31 = anchor (2*wm + l31/16, l31%16) of the patch, shifted by the tap
     const int a_lane = ((2 * wm + (l31 >> 4)) * TW + (l31 & 15)) * TP + 4 * half;
-    int b_off[2];
+    int b_off[TPW];   // MFMA column l31 of tile t = gate t * GPT + l31 / CPW, channel wn * CPW + l31 % CPW
 #pragma unroll
-    for (int t = 0; t < 2; ++t) b_off[t] = ((t * 2 + (l31 >> 4)) * 32 + wn * 16 + (l31 & 15)) * TP + 4 * half;
+    for (int t = 0; t < TPW; ++t) b_off[t] = ((t * GPT + l31 / CPW) * NCH + wn * CPW + (l31 % CPW)) * TP + 4 * half;
 
     // ---- one chunk = tap c_tap of channel chunk c_cc: 16 micro-steps of 2 MFMAs ----------------------------------------
     int c_tap = 0, c_cc = 0;
@@ -131,10 +142,10 @@ __global__ __launch_bounds__(256, 1) void convlstm_tile_kernel(const IgemmDesc d
         const float* As = At + a_lane + (ty * TW + tx) * TP;
         const float* Bs = Bt + buf * B_FL;
         const bool a_next = stage && c_tap >= 19 && c_tap < 24 && c_cc + 1 < ncc;   // this chunk carries a piece of the next patch
-        f32x4 fa[2], fb[2][2];
+        f32x4 fa[2], fb[2][TPW];
         fa[0] = *reinterpret_cast<const f32x4*>(As);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) fb[0][t] = *reinterpret_cast<const f32x4*>(Bs + b_off[t]);
+        for (int t = 0; t < TPW; ++t) fb[0][t] = *reinterpret_cast<const f32x4*>(Bs + b_off[t]);
         __builtin_amdgcn_sched_barrier(0);
         auto micro = [&](auto Q, auto S2) {
             constexpr int q = decltype(Q)::value, s2 = decltype(S2)::value, step = q * 4 + s2;
@@ -142,10 +153,10 @@ __global__ __launch_bounds__(256, 1) void convlstm_tile_kernel(const IgemmDesc d
             if constexpr (s2 == 0 && q < 3) {
                 fa[nxt] = *reinterpret_cast<const f32x4*>(As + 8 * (q + 1));
 #pragma unroll
-                for (int t = 0; t < 2; ++t) fb[nxt][t] = *reinterpret_cast<const f32x4*>(Bs + b_off[t] + 8 * (q + 1));
+                for (int t = 0; t < TPW; ++t) fb[nxt][t] = *reinterpret_cast<const f32x4*>(Bs + b_off[t] + 8 * (q + 1));
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < TPW; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s2], fb[cur][t][s2], acc[t], 0, 0, 0);
             if constexpr (stage && step < 4) load_b(std::integral_constant<int, step>{});
             if constexpr (stage && step == 4) next_b();                    // scalars of the chunk after the next
@@ -194,9 +205,9 @@ __global__ __launch_bounds__(256, 1) void convlstm_tile_kernel(const IgemmDesc d
     chunk(std::false_type{}, (nchunks - 1) & 1);
 
     // ---- epilogue: gates, state update, optional gate activations and LayerNorm partial ------------------------------
-    const int chl = wn * 16 + (l31 & 15);
-    const int ch = nblk * 32 + chl;
-    const int grp = l31 >> 4;
+    const int chl = wn * CPW + (l31 % CPW);
+    const int ch = nblk * NCH + chl;
+    const int grp = l31 / CPW;
     const float bj = d.bias[ch], bi = d.bias[C + ch], bf = d.bias[2 * C + ch] + 1.0f, bo = d.bias[3 * C + ch];
     float sv[16];
     unsigned own = 0;
@@ -205,10 +216,10 @@ __global__ __launch_bounds__(256, 1) void convlstm_tile_kernel(const IgemmDesc d
         sv[r] = 0.f;
         float g4[4];
 #pragma unroll
-        for (int G = 0; G < 4; ++G) g4[G] = __shfl(acc[G >> 1][r], (l31 & 15) + 16 * (G & 1) + 32 * half, 64);
+        for (int G = 0; G < 4; ++G) g4[G] = __shfl(acc[G / GPT][r], (l31 % CPW) + CPW * (G % GPT) + 32 * half, 64);
         const int i = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;        // anchor within the block: patch (i / 16, i % 16)
         const int m = (b * H + y0 + (i >> 4)) * W + x0 + (i & 15);
-        if (grp == (r & 1)) {
+        if (grp == (r % GPT)) {
             const size_t o = (size_t)m * C + ch;
             const float aj = t_tanh(g4[0] + bj), ai = t_sigmoid(g4[1] + bi);
             const float af = t_sigmoid(g4[2] + bf), ao = t_sigmoid(g4[3] + bo);
@@ -252,23 +263,32 @@ bool convlstm_tile_ok(const IgemmDesc& d) {
     return d.Win % 16 == 0 && d.Hin % 4 == 0 && d.ksize == 5 && d.pad == 2 && d.in_step == 1 && d.C % 32 == 0;
 }
 
-// d validated by igemm_validate(d, true).  ln_nparts as in igemm_lstm.
-int convlstm_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
-    PIVP_CHECK_ARG(convlstm_tile_ok(d));
-    constexpr int lds_bytes = (A_FL + 2 * B_FL) * 4;
+template <int NCH>
+static int launch_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
+    constexpr int lds_bytes = (A_FL + 2 * 4 * NCH * TP) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_tile_kernel<NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
     IgemmDesc dd = d;
-    const int patches = (d.Hin / 4) * (d.Win / 16), nb = d.C / 32;
+    const int patches = (d.Hin / 4) * (d.Win / 16), nb = d.C / NCH;
     const int np = patches * nb;
     dd.ln_nparts = (d.ln_part && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
-    hipLaunchKernelGGL(convlstm_tile_kernel, dim3(d.B * patches * nb), dim3(256), lds_bytes, stream, dd);
+    hipLaunchKernelGGL(convlstm_tile_kernel<NCH>, dim3(d.B * patches * nb), dim3(256), lds_bytes, stream, dd);
     return PIVP_LAUNCH_STATUS();
+}
+
+// d validated by igemm_validate(d, true).  ln_nparts as in igemm_lstm.  nch: 0 = automatic, else 16 / 32 channels per block.
+int convlstm_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts, int nch) {
+    PIVP_CHECK_ARG(convlstm_tile_ok(d) && (nch == 0 || nch == 16 || nch == 32));
+    const long blocks32 = (long)d.B * (d.Hin / 4) * (d.Win / 16) * (d.C / 32);
+    // 16-channel blocks only when 32-channel ones cannot give every CU a block: on the 16x16 maps at B = 32 two resident
+    // 16-channel blocks per CU measured the same as one 32-channel block (lstm3/4/6: 83.8 / 110.5 / 162.6 vs 82.8 / 107.9 / 162.7 us)
+    if (nch == 0) nch = blocks32 < 256 ? 16 : 32;
+    return nch == 16 ? launch_tile<16>(d, stream, ln_nparts) : launch_tile<32>(d, stream, ln_nparts);
 }
 
 }  // namespace pivp

@@ -486,13 +486,13 @@ int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant, int* ln_npar
         return launch_igemm<1, 4, 4, true, 3>(d, stream, 1, ln_nparts);
     }
 #endif
-    if (variant == 7) {   // the spatial-tile kernel where the shape allows, else the automatic choice among the gather tiles
-        if (convlstm_tile_ok(d)) return convlstm_tile(d, stream, ln_nparts);
+    if (variant == 7 || variant == 8) {   // the spatial-tile kernel (32 / 16 channels per block) where the shape allows, else
+        if (convlstm_tile_ok(d)) return convlstm_tile(d, stream, ln_nparts, variant == 7 ? 32 : 16);   // the automatic gather tile
         variant = 0;
     }
     if (variant == 0) {
         static const int tile_mode = [] { const char* e = getenv("PIVP_LSTM_TILE"); return e ? atoi(e) : 1; }();   // tuning
-        if (tile_mode && convlstm_tile_ok(d) && (long)d.B * (d.Hin / 4) * (d.Win / 16) * (d.C / 32) >= 256)
+        if (tile_mode && convlstm_tile_ok(d) && (long)d.B * (d.Hin / 4) * (d.Win / 16) * (d.C / 16) >= 256)
             return convlstm_tile(d, stream, ln_nparts);
         // measured at B = 32 (scripts/bench_lstm_layers.py): two resident blocks per CU beat one larger tile,
         // so take BM = 128 only when it still leaves >= 2 blocks per CU, BM = 64 while that fills the chip

@@ -60,7 +60,7 @@ int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr)
 int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr);
 // ConvLSTM with the input patch staged once per channel chunk for all 25 taps (csrc/convlstm_tile.hip)
 bool convlstm_tile_ok(const IgemmDesc& d);
-int convlstm_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr);   // 32 x 32 tiles, K split over the waves (csrc/igemm_small.hip)
+int convlstm_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr, int nch = 0);   // nch: channels per block, 0 = auto   // 32 x 32 tiles, K split over the waves (csrc/igemm_small.hip)
 
 // enc0: 5x5 stride-2 pad-2 conv on a planar 3-channel frame -> NHWC 32 channels (TM:500)
 int conv_enc0(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s);
