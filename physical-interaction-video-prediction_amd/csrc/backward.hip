@@ -56,8 +56,19 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     const int c4 = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int col = blockIdx.x * 128 + c4 * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (col < N)
-        for (int r = blockIdx.y * 8 + ty; r < M; r += gridDim.y * 8) acc += *reinterpret_cast<const f32x4*>(dy + (size_t)r * ld + col);
+    if (col < N) {
+        // 8 independent 16-B loads in flight per thread (one load per trip left each wave waiting on its own previous load)
+        const int step = gridDim.y * 8;
+        int r = blockIdx.y * 8 + ty;
+        for (; r + 7 * step < M; r += 8 * step) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(dy + (size_t)(r + u * step) * ld + col);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; r < M; r += step) acc += *reinterpret_cast<const f32x4*>(dy + (size_t)r * ld + col);
+    }
     part[ty][c4] = acc;
     __syncthreads();
     if (ty == 0 && col < N) {
@@ -72,7 +83,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
 int bias_grad(const float* dy, int ld, int N, int M, float* db, hipStream_t s) {
     PIVP_CHECK_ARG(dy && db && N > 0 && M > 0 && ld >= N && N % 4 == 0 && ld % 4 == 0);
     const int xb = (N + 127) / 128;
-    int yb = (M + 511) / 512; if (yb > 64) yb = 64; if (yb < 1) yb = 1;   // few row-groups: their sums meet in atomics on N addresses
+    int yb = (M + 511) / 512; if (yb > 128) yb = 128; if (yb < 1) yb = 1;   // few row-groups: their sums meet in atomics on N addresses
     hipLaunchKernelGGL(bias_grad_kernel, dim3(xb, yb), dim3(256), 0, s, dy, ld, N, M, db);
     return PIVP_LAUNCH_STATUS();
 }
