@@ -56,41 +56,75 @@ __global__ __launch_bounds__(256) void composite_bwd_cdna_kernel(const float* __
     float* kl = prevt + 3 * PR * PW;             // [NM*25]
     const int tid = threadIdx.x;
     const float* lgb = logits + (size_t)b * NP * HW;
-    for (int i = tid; i < NP * win; i += 256) {
-        const int m = i / win, j = i - m * win;
-        const int F = m * HW + ep0 - (NP - 1) + j;
-        lg[i] = (F >= 0 && F < NP * HW) ? lgb[F] : 0.f;
+    // exact x / NP for x * NP < 2^32 (see composite_kernel); staging loops without per-element division and with four
+    // independent loads in flight per thread (the flat-index loops of the first version made one L2 round trip per element)
+    const unsigned magic = 0xFFFFFFFFu / (unsigned)NP + 1u;
+    auto div_np = [&](int x) { return (int)__umulhi((unsigned)x, magic); };
+    for (int m = 0; m < NP; ++m) {
+        const int F0 = m * HW + ep0 - (NP - 1);
+        for (int j0 = tid; j0 < win; j0 += 1024) {
+            float t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int j = j0 + 256 * u, F = F0 + j; t[u] = (j < win && F >= 0 && F < NP * HW) ? lgb[F] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (j0 + 256 * u < win) lg[m * win + j0 + 256 * u] = t[u];
+        }
     }
     const float* pb = prev + (size_t)b * 3 * HW;
-    for (int i = tid; i < 3 * PR * PW; i += 256) {
-        const int c = i / (PR * PW), r = (i / PW) % PR, x = i % PW;
-        const int iy = y0 + r - 2, ix = x - 2;
-        prevt[i] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? pb[(size_t)c * HW + iy * W + ix] : 0.f;
+    {
+        const int x = tid % PW, r0 = tid / PW, rstep = 256 / PW;   // PW <= 256 (checked by the launcher)
+        if (tid < rstep * PW)
+            for (int rb = r0; rb < PR; rb += 4 * rstep) {
+                float t[3][4];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = rb + u * rstep, iy = y0 + r - 2, ix = x - 2;
+                        t[c][u] = (r < PR && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? pb[(size_t)c * HW + iy * W + ix] : 0.f;
+                    }
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int r = rb + u * rstep; if (r < PR) prevt[(c * PR + r) * PW + x] = t[c][u]; }
+            }
     }
     const float* gb = go + (size_t)b * 3 * HW;
-    for (int i = tid; i < 3 * enp; i += 256) {
-        const int c = i / enp, pp = i - c * enp;
-        gox[c * PR * W + pp] = gb[(size_t)c * HW + ep0 + pp];
-    }
-    for (int i = tid; i < NM * 25; i += 256) kl[i] = kerns[(size_t)b * NM * 25 + i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        for (int p0_ = tid; p0_ < enp; p0_ += 1024) {
+            float t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int pp = p0_ + 256 * u; t[u] = pp < enp ? gb[(size_t)c * HW + ep0 + pp] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (p0_ + 256 * u < enp) gox[c * PR * W + p0_ + 256 * u] = t[u];
+        }
+    if (tid < NM * 25) kl[tid] = kerns[(size_t)b * NM * 25 + tid];
     __syncthreads();
     for (int i = tid; i < NP * G; i += 256) {
         const int m = i / G, gi = i - m * G;
-        const int gfirst = (m * HW + ep0) / NP, glast = (m * HW + ep0 + enp - 1) / NP;
+        const int gfirst = div_np(m * HW + ep0), glast = div_np(m * HW + ep0 + enp - 1);
         if (gfirst + gi <= glast) {
             const float* e = lg + m * win + (gfirst + gi) * NP - (m * HW + ep0 - (NP - 1));
-            float mx = e[0];
-            for (int u = 1; u < NP; ++u) mx = fmaxf(mx, e[u]);
+            float ev[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) ev[u] = u < NP ? e[u] : -3.0e38f;
+            float mx = ev[0];
+#pragma unroll
+            for (int u = 1; u < 12; ++u) mx = fmaxf(mx, ev[u]);
             float sum = 0.f;
-            for (int u = 0; u < NP; ++u) sum += expf(e[u] - mx);
+#pragma unroll
+            for (int u = 0; u < 12; ++u) sum += u < NP ? __expf(ev[u] - mx) : 0.f;
             gmx[i] = mx; ginv[i] = 1.0f / sum;
         }
     }
     __syncthreads();
-    for (int i = tid; i < NP * enp; i += 256) {
-        const int m = i / enp, pp = i - m * enp;
-        const int gi = (m * HW + ep0 + pp) / NP - (m * HW + ep0) / NP;
-        mkx[m * PR * W + pp] = expf(lg[m * win + pp + (NP - 1)] - gmx[m * G + gi]) * ginv[m * G + gi];
+    for (int m = 0; m < NP; ++m) {
+        const int gbase = div_np(m * HW + ep0);
+        for (int pp = tid; pp < enp; pp += 256) {
+            const int gi = div_np(m * HW + ep0 + pp) - gbase;
+            mkx[m * PR * W + pp] = __expf(lg[m * win + pp + (NP - 1)] - gmx[m * G + gi]) * ginv[m * G + gi];
+        }
     }
     __syncthreads();
     const int toff = (y0 - ey0) * W;             // tile offset inside the extended arrays
@@ -110,33 +144,56 @@ __global__ __launch_bounds__(256) void composite_bwd_cdna_kernel(const float* __
         dz[((size_t)b * 3 + 0) * HW + p] = l0 > 0.5f ? g0 * m1 * l0 * (1.f - l0) : 0.f;
         dz[((size_t)b * 3 + 1) * HW + p] = l1 > 0.5f ? g1 * m1 * l1 * (1.f - l1) : 0.f;
         dz[((size_t)b * 3 + 2) * HW + p] = l2 > 0.5f ? g2 * m1 * l2 * (1.f - l2) : 0.f;
+        float gp[25];   // sum_c go[c] * prev[c] at the 25 taps: shared by all NK kernels (the first version recomputed it per kernel)
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) gp[i * 5 + j] = g0 * p0[i * PW + j] + g1 * p1[i * PW + j] + g2 * p2[i * PW + j];
         for (int k = 0; k < NM; ++k) {
             float t = 0.f;
             if (k < NK) {
                 const float* kk = kl + k * 25;
 #pragma unroll
-                for (int i = 0; i < 5; ++i)
-#pragma unroll
-                    for (int j = 0; j < 5; ++j)
-                        t = fmaf(kk[i * 5 + j], g0 * p0[i * PW + j] + g1 * p1[i * PW + j] + g2 * p2[i * PW + j], t);
+                for (int i = 0; i < 25; ++i) t = fmaf(kk[i], gp[i], t);
             }
             if (k + 2 < NP) dm[(size_t)(k + 2) * HW] = t;
         }
     }
-    // ---- kernel gradient partials: thread (k, ij) sums over the tile ----
-    if (tid < NK * 25) {
-        const int k = tid / 25, ij = tid - k * 25, i = ij / 5, j = ij - i * 5;
+    // ---- kernel gradient partials: dK[k][ij] = sum_pixels mk[k+2] * (sum_c go[c] * prev[c](+ij)).  Thread (row of the tile,
+    // tap ij) forms the go*prev product ONCE per pixel and feeds all NK kernels (9 accumulators); the 8 rows are summed
+    // through LDS.  (One thread per (k, ij) walking all 512 pixels redid the product per kernel: 3.6k LDS reads per thread.)
+    __syncthreads();                                   // lg (the logits window) is dead: reuse it for the row partials
+    float* red = lg;                                   // [CB_TR][256]
+    if (tid < CB_TR * 25) {
+        const int ry = tid / 25, ij = tid - ry * 25, i = ij / 5, j = ij - i * 5;
+        float acc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+        if (ry < rows) {
+            const float* g0r = gox + toff + ry * W;
+            const float* q0 = prevt + (0 * PR + ry + i) * PW + j;
+            const float* q1 = prevt + (1 * PR + ry + i) * PW + j;
+            const float* q2 = prevt + (2 * PR + ry + i) * PW + j;
+            const float* mrow = mkx + 2 * PR * W + toff + ry * W;
+#pragma unroll 2
+            for (int x = 0; x < W; ++x) {
+                const float v = g0r[x] * q0[x] + g0r[PR * W + x] * q1[x] + g0r[2 * PR * W + x] * q2[x];
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    if (k < NK) acc[k] = fmaf(mrow[k * PR * W + x], v, acc[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) red[ry * 256 + k * 25 + ij] = acc[k];
+    }
+    __syncthreads();
+    {
         float acc = 0.f;
-        for (int pp = 0; pp < np; ++pp) {
-            const int ry = pp / W, x = pp - ry * W;
-            const float mq = mkx[(k + 2) * PR * W + toff + pp];
-            const float v = gox[toff + pp] * prevt[(0 * PR + ry + i) * PW + x + j] + gox[PR * W + toff + pp] * prevt[(1 * PR + ry + i) * PW + x + j] +
-                            gox[2 * PR * W + toff + pp] * prevt[(2 * PR + ry + i) * PW + x + j];
-            acc = fmaf(mq, v, acc);
+        if (tid < NK * 25) {
+#pragma unroll
+            for (int r = 0; r < CB_TR; ++r) acc += red[r * 256 + tid];
         }
         dkpart[((size_t)b * gridDim.x + blockIdx.x) * 256 + tid] = acc;
-    } else if (tid < 256) {
-        dkpart[((size_t)b * gridDim.x + blockIdx.x) * 256 + tid] = 0.f;
     }
     // ---- gradient w.r.t. the previous frame (feed-self only) ----
     if (dprev) {
@@ -174,7 +231,7 @@ int composite_bwd_cdna(const float* prev, const float* logits, const float* laye
     const int NP = NM + 1, PR = CB_TR + 4;
     const int enp = PR * W, win = enp + 2 * (NP - 1), G = enp / NP + 2;
     const size_t lds = sizeof(float) * ((size_t)NP * win + 2 * NP * G + (size_t)NP * PR * W + 3 * PR * W + 3 * PR * (W + 4) + NM * 25);
-    PIVP_CHECK_ARG(lds <= 160 * 1024);
+    PIVP_CHECK_ARG(lds <= 160 * 1024 && W + 4 <= 256 && NM * 25 <= 256);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_cdna_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(composite_bwd_cdna_kernel, dim3(composite_bwd_tiles(H), B), dim3(256), lds, s, prev, logits, layer0, kerns, go, dmk,
                        dz, dkpart, dprev, dprev_accum, H, W, NM);
