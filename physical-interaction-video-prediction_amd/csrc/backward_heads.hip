@@ -398,71 +398,112 @@ int mask_softmax_bwd(const float* logits, float* dmk, int B, int HW, int NP, hip
 //   d e6[pix][k] = sum_o W[k][o] dp[o][pix];  dW[k][o] += sum_pix e6[pix][k] dp[o][pix];  db[o] += sum_pix dp[o][pix]
 // One block = 128 pixels.  dW/db through atomics (one [64][NO] tile per block).
 // ------------------------------------------------------------------------------------------
-constexpr int HB_PX = 128;
+constexpr int HB_PX = 128;       // pixels per sub-tile
+constexpr int HB_SUB = 4;        // sub-tiles per block: dW / db are accumulated in registers over them, so each of the 910 gradient
+                                 // addresses receives one atomic per 512 pixels (1024 blocks x 910 atomics on the same addresses made
+                                 // the first version an L2-atomic queue)
 constexpr int HB_MAXOUT = 36;
 __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ e6, const float* __restrict__ wm, const float* __restrict__ we,
                                                         const float* __restrict__ dpm, const float* __restrict__ dpe,
                                                         float* __restrict__ de6, float* __restrict__ dwm, float* __restrict__ dbm,
                                                         float* __restrict__ dwe, float* __restrict__ dbe, int total_px, int HW, int NP, int NE) {
-    __shared__ float xt[HB_PX * 65];
-    __shared__ float dpt[HB_MAXOUT * HB_PX];
-    __shared__ float wl[64 * HB_MAXOUT];
+    __shared__ __attribute__((aligned(16))) float xt[HB_PX * 68];        // [pixel][64 + 4]
+    __shared__ __attribute__((aligned(16))) float dpt[HB_MAXOUT * HB_PX];   // [output][pixel]
+    __shared__ __attribute__((aligned(16))) float wl[HB_MAXOUT * 64];    // [output][k]
     const int tid = threadIdx.x, NO = NP + NE;
-    const int px0 = blockIdx.x * HB_PX;
     for (int i = tid; i < 64 * NO; i += 256) {
         const int k = i / NO, o = i - k * NO;
-        wl[k * HB_MAXOUT + o] = o < NP ? wm[k * NP + o] : we[k * NE + (o - NP)];
+        wl[o * 64 + k] = o < NP ? wm[k * NP + o] : we[k * NE + (o - NP)];
     }
-    for (int i = tid; i < HB_PX * 64; i += 256) {
-        const int p = i >> 6, k = i & 63;
-        xt[p * 65 + k] = px0 + p < total_px ? e6[(size_t)(px0 + p) * 64 + k] : 0.f;
-    }
-    for (int i = tid; i < NO * HB_PX; i += 256) {
-        const int o = i / HB_PX, p = i - o * HB_PX;
-        float v = 0.f;
-        if (px0 + p < total_px) {
-            const int b = (px0 + p) / HW, q = (px0 + p) - b * HW;
-            v = o < NP ? dpm[((size_t)b * NP + o) * HW + q] : dpe[((size_t)b * NE + (o - NP)) * HW + q];
-        }
-        dpt[i] = v;
-    }
-    __syncthreads();
-    {   // d e6: thread = (pixel, 32-channel half)
-        const int p = tid >> 1, kh = (tid & 1) * 32;
-        if (px0 + p < total_px) {
-            float acc[32];
+    const int kw = tid >> 2, og = tid & 3;          // dW role: input channel kw, outputs og, og+4, ...
+    float dwacc[HB_MAXOUT / 4], dbacc = 0.f;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) acc[k] = 0.f;
-            for (int o = 0; o < NO; ++o) {
-                const float d = dpt[o * HB_PX + p];
+    for (int u = 0; u < HB_MAXOUT / 4; ++u) dwacc[u] = 0.f;
+    for (int sub = 0; sub < HB_SUB; ++sub) {
+        const int px0 = (blockIdx.x * HB_SUB + sub) * HB_PX;
+        if (px0 >= total_px) break;
+        __syncthreads();
+        {   // staging: 8 + up to 18 independent loads per thread, then the LDS stores
+            f32x4 tx[8];
 #pragma unroll
-                for (int k = 0; k < 32; ++k) acc[k] = fmaf(wl[(kh + k) * HB_MAXOUT + o], d, acc[k]);
+            for (int u = 0; u < 8; ++u) {
+                const int f = tid + 256 * u, p = f >> 4, cv = (f & 15) * 4;
+                tx[u] = px0 + p < total_px ? *reinterpret_cast<const f32x4*>(e6 + (size_t)(px0 + p) * 64 + cv) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            float* op = de6 + (size_t)(px0 + p) * 64 + kh;
+            const int p = tid & (HB_PX - 1), oh = tid >> 7;                 // pixel p, outputs oh, oh+2, ...
+            const int px = px0 + p;
+            const bool pok = px < total_px;
+            const int bb = pok ? px / HW : 0, q = px - bb * HW;
+            float td[HB_MAXOUT / 2];
 #pragma unroll
-            for (int k = 0; k < 32; k += 4) *reinterpret_cast<f32x4*>(op + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+            for (int u = 0; u < HB_MAXOUT / 2; ++u) {
+                const int o = oh + 2 * u;
+                td[u] = (pok && o < NO) ? (o < NP ? dpm[((size_t)bb * NP + o) * HW + q] : dpe[((size_t)bb * NE + (o - NP)) * HW + q]) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int f = tid + 256 * u, pp = f >> 4, cv = (f & 15) * 4;
+                *reinterpret_cast<f32x4*>(xt + pp * 68 + cv) = tx[u];
+            }
+#pragma unroll
+            for (int u = 0; u < HB_MAXOUT / 2; ++u) { const int o = oh + 2 * u; if (o < NO) dpt[o * HB_PX + p] = td[u]; }
+        }
+        __syncthreads();
+        {   // d e6: thread = (pixel, 32-channel half); an output's 32 weights are 8 wave-uniform ds_read_b128
+            const int p = tid >> 1, kh = (tid & 1) * 32;
+            if (px0 + p < total_px) {
+                float acc[32];
+#pragma unroll
+                for (int k = 0; k < 32; ++k) acc[k] = 0.f;
+                for (int o = 0; o < NO; ++o) {
+                    const float dd = dpt[o * HB_PX + p];
+#pragma unroll
+                    for (int k4 = 0; k4 < 8; ++k4) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + o * 64 + kh + k4 * 4);
+                        acc[k4 * 4] = fmaf(w4[0], dd, acc[k4 * 4]); acc[k4 * 4 + 1] = fmaf(w4[1], dd, acc[k4 * 4 + 1]);
+                        acc[k4 * 4 + 2] = fmaf(w4[2], dd, acc[k4 * 4 + 2]); acc[k4 * 4 + 3] = fmaf(w4[3], dd, acc[k4 * 4 + 3]);
+                    }
+                }
+                float* op = de6 + (size_t)(px0 + p) * 64 + kh;
+#pragma unroll
+                for (int k = 0; k < 32; k += 4) *reinterpret_cast<f32x4*>(op + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+            }
+        }
+        // dW partial: this thread's channel column of the tile against its outputs' pixel rows (ds_read_b128 on dpt)
+#pragma unroll
+        for (int u = 0; u < HB_MAXOUT / 4; ++u) {
+            const int o = og + 4 * u;
+            if (o < NO) {
+                float a = dwacc[u];
+                for (int p4 = 0; p4 < HB_PX; p4 += 4) {
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(dpt + o * HB_PX + p4);
+                    a = fmaf(xt[p4 * 68 + kw], d4[0], a); a = fmaf(xt[(p4 + 1) * 68 + kw], d4[1], a);
+                    a = fmaf(xt[(p4 + 2) * 68 + kw], d4[2], a); a = fmaf(xt[(p4 + 3) * 68 + kw], d4[3], a);
+                }
+                dwacc[u] = a;
+            }
+        }
+        if (tid < NO) {
+            float a = dbacc;
+            for (int p4 = 0; p4 < HB_PX; p4 += 4) {
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dpt + tid * HB_PX + p4);
+                a += (d4[0] + d4[1]) + (d4[2] + d4[3]);
+            }
+            dbacc = a;
         }
     }
-    // dW: thread = (k = tid / 4, outputs o = tid % 4, +4, ...)
-    {
-        const int k = tid >> 2, og = tid & 3;
-        for (int o = og; o < NO; o += 4) {
-            float acc = 0.f;
-            for (int p = 0; p < HB_PX; ++p) acc = fmaf(xt[p * 65 + k], dpt[o * HB_PX + p], acc);
-            if (o < NP) atomicAdd(dwm + k * NP + o, acc); else atomicAdd(dwe + k * NE + (o - NP), acc);
-        }
+#pragma unroll
+    for (int u = 0; u < HB_MAXOUT / 4; ++u) {
+        const int o = og + 4 * u;
+        if (o < NO) { if (o < NP) atomicAdd(dwm + kw * NP + o, dwacc[u]); else atomicAdd(dwe + kw * NE + (o - NP), dwacc[u]); }
     }
-    if (tid < NO) {
-        float acc = 0.f;
-        for (int p = 0; p < HB_PX; ++p) acc += dpt[tid * HB_PX + p];
-        if (tid < NP) atomicAdd(dbm + tid, acc); else atomicAdd(dbe + (tid - NP), acc);
-    }
+    if (tid < NO) { if (tid < NP) atomicAdd(dbm + tid, dbacc); else atomicAdd(dbe + (tid - NP), dbacc); }
 }
 int heads_bwd(const float* e6, const float* wm, const float* we, const float* dpm, const float* dpe, float* de6,
               float* dwm, float* dbm, float* dwe, float* dbe, int B, int HW, int NP, int NE, hipStream_t s) {
     PIVP_CHECK_ARG(e6 && wm && we && dpm && dpe && de6 && dwm && dbm && dwe && dbe && B > 0 && HW > 0 && NP + NE <= HB_MAXOUT);
     const int total = B * HW;
-    hipLaunchKernelGGL(heads_bwd_kernel, dim3((total + HB_PX - 1) / HB_PX), dim3(256), 0, s, e6, wm, we, dpm, dpe, de6, dwm, dbm, dwe, dbe,
+    hipLaunchKernelGGL(heads_bwd_kernel, dim3((total + HB_PX * HB_SUB - 1) / (HB_PX * HB_SUB)), dim3(256), 0, s, e6, wm, we, dpm, dpe, de6, dwm, dbm, dwe, dbe,
                        total, HW, NP, NE);
     return PIVP_LAUNCH_STATUS();
 }
