@@ -17,16 +17,22 @@ namespace pivp {
 
 constexpr int WG_PIX = 32;     // pixels (GEMM K) per chunk
 constexpr int WG_CI = 64;      // input channels per block
-constexpr int WG_N = 128;      // output columns per block
 constexpr int WG_XP = WG_CI + 4;   // LDS pitches (floats); +4 keeps 16-B alignment of rows
-constexpr int WG_YP = WG_N + 4;
 
+// NT: 32-column MFMA tiles per wave; the block covers 64 input channels x 64*NT output columns.  NT = 1 for layers with at most
+// 64 output channels (enc1, enc2, enc6): with 128 columns half of the waves multiplied zero padding.
+template <int NT>
 __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) {
+    constexpr int WG_N = 64 * NT;      // output columns per block
+    constexpr int WG_YP = WG_N + 4;
+    constexpr int YL = 16 * NT;        // float4 lanes per dY row
+    constexpr int YRP = 256 / YL;      // dY rows per staging pass
+    constexpr int NYL = WG_PIX / YRP;  // passes
     __shared__ __attribute__((aligned(16))) float xs[2][WG_PIX * WG_XP];
     __shared__ __attribute__((aligned(16))) float ys[2][WG_PIX * WG_YP];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;             // wave tile: 32 ci x 64 n
+    const int wm = wave & 1, wn = wave >> 1;             // wave tile: 32 ci x 32*NT n
     const int l31 = lane & 31, half = lane >> 5;
     const int ncb = (d.cin + WG_CI - 1) / WG_CI, nnb = (d.N + WG_N - 1) / WG_N;
     int bid = blockIdx.x;
@@ -50,7 +56,7 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
 
     // staging: X tile 32 pix x 64 ci = 512 float4 (2 per thread), dY tile 32 pix x 128 n = 1024 float4 (4 per thread)
     const int xr = tid >> 4, xc = (tid & 15) * 4;        // rows xr, xr+16
-    const int yr = tid >> 5, yc = (tid & 31) * 4;        // rows yr, yr+8, yr+16, yr+24
+    const int yr = tid / YL, yc = (tid % YL) * 4;        // rows yr, yr+YRP, ...
     // this thread's 4 X columns live in x0 (channels [0,c0)) or x1 ([c0,c0+c1)); a 64-channel block may straddle
     // the two, so both descriptors are read and the one that does not hold the columns gets an out-of-range offset
     // (hardware returns 0) -- the sum is the value, no per-lane descriptor select.
@@ -58,17 +64,17 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
     const bool xcol_ok = xci < d.cin;
     const bool in0 = xci < d.c0;
     const bool ycol_ok = (n0 + yc) < d.N;
-    f32x4 rx[2], rY[4];
+    f32x4 rx[2], rY[NYL];
     // anchor coordinates without per-load divisions: when chunks never straddle a sample and the anchor-grid width is a
     // multiple or a divisor of 32 (every map of this model), row r of a chunk sits at a fixed (row, column) offset from the
     // chunk's first anchor.  The first version divided twice per load: ~420 of the ~600 instructions between two chunks'
     // 32 MFMAs.
     const bool fast = HWg % WG_PIX == 0 && (d.Wg % WG_PIX == 0 || WG_PIX % d.Wg == 0);
-    int xdr[2], xdx[2], ydr[4], ydx[4];
+    int xdr[2], xdx[2], ydr[NYL], ydx[NYL];
 #pragma unroll
     for (int j = 0; j < 2; ++j) { const int r = xr + 16 * j; xdr[j] = d.Wg >= WG_PIX ? 0 : r / d.Wg; xdx[j] = r - xdr[j] * d.Wg; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int r = yr + 8 * j; ydr[j] = d.Wg >= WG_PIX ? 0 : r / d.Wg; ydx[j] = r - ydr[j] * d.Wg; }
+    for (int j = 0; j < NYL; ++j) { const int r = yr + YRP * j; ydr[j] = d.Wg >= WG_PIX ? 0 : r / d.Wg; ydx[j] = r - ydr[j] * d.Wg; }
     auto issue = [&](int chunk) {
         const int m0 = __builtin_amdgcn_readfirstlane(chunk * WG_PIX);
         const int b0 = m0 / HWg, rem0 = m0 - b0 * HWg, ay0 = rem0 / d.Wg, ax0 = rem0 - ay0 * d.Wg;   // wave-uniform
@@ -92,8 +98,8 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
             rx[j] = v;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = chunk * WG_PIX + yr + 8 * j;
+        for (int j = 0; j < NYL; ++j) {
+            const int m = chunk * WG_PIX + yr + YRP * j;
             unsigned off = OOB;
             if (m < d.M && ycol_ok) {
                 int b, ay, ax;
@@ -110,11 +116,11 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
 #pragma unroll
         for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(&xs[buf][(xr + 16 * j) * WG_XP + xc]) = rx[j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&ys[buf][(yr + 8 * j) * WG_YP + yc]) = rY[j];
+        for (int j = 0; j < NYL; ++j) *reinterpret_cast<f32x4*>(&ys[buf][(yr + YRP * j) * WG_YP + yc]) = rY[j];
     };
-    f32x16 acc[2];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -126,13 +132,13 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
             const int buf = (c - c_begin) & 1;
             if (c + 1 < c_end) issue(c + 1);
             const float* X = &xs[buf][wm * 32 + l31];
-            const float* Y = &ys[buf][wn * 64 + l31];
+            const float* Y = &ys[buf][wn * 32 * NT + l31];
 #pragma unroll
             for (int k = 0; k < WG_PIX; k += 2) {
                 const float a = X[(k + half) * WG_XP];
-                const float b0 = Y[(k + half) * WG_YP], b1 = Y[(k + half) * WG_YP + 32];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Y[(k + half) * WG_YP + 32 * t], acc[t], 0, 0, 0);
             }
             if (c + 1 < c_end) store(buf ^ 1);
             __syncthreads();
@@ -141,8 +147,8 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
     // acc[t][r]: row i = ci (= (r&3) + 8*(r>>2) + 4*half), column j = n (= l31); packed gradient [tap][ci/32][n][ci%32]
     const int wtap = tap;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int n = n0 + wn * 64 + t * 32 + l31;
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + wn * 32 * NT + t * 32 + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = ci0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -383,14 +389,16 @@ int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done) {
         if (d.Wg == 16) return launch_wgrad5x5<2, 16>(d, s);
         return launch_wgrad5x5<2, 32>(d, s);
     }
-    const int ncb = (d.cin + WG_CI - 1) / WG_CI, nnb = (d.N + WG_N - 1) / WG_N;
+    const int wg_n = d.N <= 64 ? 64 : 128;
+    const int ncb = (d.cin + WG_CI - 1) / WG_CI, nnb = (d.N + wg_n - 1) / wg_n;
     const int tiles = d.ksize * d.ksize * ncb * nnb;
     const int chunks = (d.M + WG_PIX - 1) / WG_PIX;
     // every block ends with a tile of atomics (64 x 128), so no more pixel splits than fill the chip twice (3 blocks fit a CU)
     int nsplit = (512 + tiles - 1) / tiles;
-    if (nsplit > chunks / 8) nsplit = chunks / 8;         // and >= 8 chunks (256 pixels) per block
+    if (nsplit > chunks / 8) nsplit = chunks / 8;         // and >= 8 chunks (256 pixels) per block (enc4 with 4: 63 -> 94 us, atomics)
     if (nsplit < 1) nsplit = 1;
-    hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(tiles, nsplit), dim3(256), 0, s, d);
+    if (wg_n == 64) hipLaunchKernelGGL(igemm_wgrad_kernel<1>, dim3(tiles, nsplit), dim3(256), 0, s, d);
+    else hipLaunchKernelGGL(igemm_wgrad_kernel<2>, dim3(tiles, nsplit), dim3(256), 0, s, d);
     return PIVP_LAUNCH_STATUS();
 }
 
