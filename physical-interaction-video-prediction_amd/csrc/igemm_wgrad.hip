@@ -1,52042 +1,448 @@
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-7    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-E    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-^    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-O    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-K    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-9    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-"    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-"    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-V    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-V    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-E    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-K    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-z    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-z    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-z    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-z    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-z    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-?    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-?    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-?    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-?    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-?    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-?    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-O    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-O    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-?    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-?    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-'    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-'    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-~    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-~    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-'    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-?    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-?    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-O    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-O    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-O    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-O    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-O    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-O    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-^    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-z    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-9    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-V    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-E    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-E    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-~    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-O    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-E    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-K    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-U    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-7    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-7    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-O    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-O    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-?    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-?    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-?    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-U    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-7    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-7    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-q    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-q    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-q    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-O    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-O    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-q    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-U    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-q    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-q    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-V    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-V    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-U    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-E    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-O    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-E    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-7    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-O    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-V    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-^    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-7    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-9    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-V    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-V    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-^    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-V    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-"    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-"    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-"    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-"    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-"    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-"    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-"    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-"    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-^    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-'    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-'    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-K    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-#    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-z    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-U    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-U    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-?    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-U    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-!    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-z    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-O    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-U    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-~    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-K    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-z    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-'    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-U    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-"    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-"    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-U    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-7    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-7    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-F    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-9    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-!    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-!    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-!    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-9    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-K    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-V    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-U    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-U    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-D    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-V    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-E    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-K    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-V    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-E    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-K    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-V    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-E    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-K    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-B    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-z    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-z    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-7    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-V    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-E    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-K    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-!    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-z    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-|    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-?    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-?    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-z    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-z    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-M    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-U    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-9    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-4    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-K    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-K    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-V    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-U    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-U    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-'    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-'    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-`    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-`    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-X    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-Y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-W    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-j    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-g    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-z    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-b    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-z    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-?    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
--    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-:    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-z    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-.    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-1    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-y    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-<    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-8    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-+    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-x    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-[    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-]    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-*    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-{    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-V    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-E    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-K    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-R    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
->    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-&    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-%    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-=    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-h    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-K    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-G    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-o    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-k    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-d    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-3    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-2    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-5    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-6    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-0    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-w    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-,    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-f    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-l    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-t    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-u    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-r    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-I    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-V    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-P    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-L    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-U    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-N    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-C    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-H    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-_    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-A    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-T    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-U    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-S    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-(    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-)    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-;    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-}    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-/    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-n    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-m    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-s    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-a    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-c    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-e    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-     int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-i    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-v    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-p    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
-
-    int bid = blockIdx.x;
-    const int nsplit = gridDim.y, split = blockIdx.y;
+// Weight gradients of every MFMA convolution, and the weight re-pack the data-gradient needs.
+//
+// wgrad:  dW[tap][ci][n] += sum over anchors a of  X[pixA(a, tap)][ci] * dY[pixB(a, tap)][n]
+//   conv (ConvLSTM 5x5 p2, 3x3 s2 p1):  anchors = output pixels, pixA = a*stride - pad + k, pixB = a
+//   transposed 3x3 s2 p1 (TM:505-507):  anchors = input pixels,  pixA = a,                  pixB = 2a - 1 + k
+// i.e. a GEMM dW_tap = X_tap^T (Cin x M) . dY (M x N) whose reduction runs over pixels.  On the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32): A[i = ci][k = pixel], B[k = pixel][j = n]; both operands are read from pixel-major LDS
+// tiles [32 pixels][channels] with one conflict-free ds_read_b32 per lane.  A block owns one tap, 64 input
+// channels x 128 output columns, and a slice of the pixels; slices are combined with fp32 atomic adds straight into
+// the K-inner packed gradient (same layout as the weight, so Adam is elementwise).  Gradients therefore accumulate
+// across blocks, timesteps and calls until the host clears them (Chainer: cleargrads + backward, TM:950).
+#include <type_traits>
+
+#include "pivp_kernels.h"
+
+// timing-only ablations of wgrad5x5_kernel (results wrong): 1 = no global loads / LDS stores in the loop, 2 = also no LDS reads,
+// 3 = loads without stores, 4 = stores without loads.  lstm7 (us): full 265, 1: 222, 2: 208, 3: 221, 4: 217 -- loads and stores
+// cost nothing on their own and 43 us together, i.e. what costs is LDS contents that CHANGE between chunks (not understood).
+#ifndef PIVP_WG_ABL
+#define PIVP_WG_ABL 0
+#endif
+
+namespace pivp {
+
+constexpr int WG_PIX = 32;     // pixels (GEMM K) per chunk
+constexpr int WG_CI = 64;      // input channels per block
+constexpr int WG_XP = WG_CI + 4;   // LDS pitches (floats); +4 keeps 16-B alignment of rows
+
+// NT: 32-column MFMA tiles per wave; the block covers 64 input channels x 64*NT output columns.  NT = 1 for layers with at most
+// 64 output channels (enc1, enc2, enc6): with 128 columns half of the waves multiplied zero padding.
+template <int NT>
+__global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) {
+    constexpr int WG_N = 64 * NT;      // output columns per block
+    constexpr int WG_YP = WG_N + 4;
+    constexpr int YL = 16 * NT;        // float4 lanes per dY row
+    constexpr int YRP = 256 / YL;      // dY rows per staging pass
+    constexpr int NYL = WG_PIX / YRP;  // passes
+    __shared__ __attribute__((aligned(16))) float xs[2][WG_PIX * WG_XP];
+    __shared__ __attribute__((aligned(16))) float ys[2][WG_PIX * WG_YP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;             // wave tile: 32 ci x 32*NT n
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ncb = (d.cin + WG_CI - 1) / WG_CI, nnb = (d.N + WG_N - 1) / WG_N;
+    int bid = blockIdx.x;
+    const int nb = bid % nnb; bid /= nnb;
+    const int cb = bid % ncb; bid /= ncb;
+    const int tap = bid;                                  // 0 .. ksize*ksize-1
+    const int ky = tap / d.ksize, kx = tap - ky * d.ksize;
+    const int ci0 = cb * WG_CI, n0 = nb * WG_N;
+    const int nsplit = gridDim.y, split = blockIdx.y;
+    const int nchunks_total = (d.M + WG_PIX - 1) / WG_PIX;
+    const int c_begin = (int)((long)nchunks_total * split / nsplit), c_end = (int)((long)nchunks_total * (split + 1) / nsplit);
+    const int HWg = d.Hg * d.Wg;
+    // offsets of the two operands relative to the anchor
+    const int ady = d.deconv ? 0 : ky - d.pad, adx = d.deconv ? 0 : kx - d.pad;          // X side (after anchor*sa)
+    const int bdy = d.deconv ? ky - 1 : 0, bdx = d.deconv ? kx - 1 : 0;                   // dY side (after anchor*sb)
+    const int sa = d.deconv ? 1 : d.stride, sb = d.deconv ? 2 : 1;
+    constexpr unsigned OOB = 0xC0000000u;
+    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x0), 0, d.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.c1 ? d.x1 : d.x0), 0, d.c1 ? d.bytes1 : d.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy), 0, d.bytesy, 0x00020000);
+
+    // staging: X tile 32 pix x 64 ci = 512 float4 (2 per thread), dY tile 32 pix x 128 n = 1024 float4 (4 per thread)
+    const int xr = tid >> 4, xc = (tid & 15) * 4;        // rows xr, xr+16
+    const int yr = tid / YL, yc = (tid % YL) * 4;        // rows yr, yr+YRP, ...
+    // this thread's 4 X columns live in x0 (channels [0,c0)) or x1 ([c0,c0+c1)); a 64-channel block may straddle
+    // the two, so both descriptors are read and the one that does not hold the columns gets an out-of-range offset
+    // (hardware returns 0) -- the sum is the value, no per-lane descriptor select.
+    const int xci = ci0 + xc;
+    const bool xcol_ok = xci < d.cin;
+    const bool in0 = xci < d.c0;
+    const bool ycol_ok = (n0 + yc) < d.N;
+    f32x4 rx[2], rY[NYL];
+    // anchor coordinates without per-load divisions: when chunks never straddle a sample and the anchor-grid width is a
+    // multiple or a divisor of 32 (every map of this model), row r of a chunk sits at a fixed (row, column) offset from the
+    // chunk's first anchor.  The first version divided twice per load: ~420 of the ~600 instructions between two chunks'
+    // 32 MFMAs.
+    const bool fast = HWg % WG_PIX == 0 && (d.Wg % WG_PIX == 0 || WG_PIX % d.Wg == 0);
+    int xdr[2], xdx[2], ydr[NYL], ydx[NYL];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int r = xr + 16 * j; xdr[j] = d.Wg >= WG_PIX ? 0 : r / d.Wg; xdx[j] = r - xdr[j] * d.Wg; }
+#pragma unroll
+    for (int j = 0; j < NYL; ++j) { const int r = yr + YRP * j; ydr[j] = d.Wg >= WG_PIX ? 0 : r / d.Wg; ydx[j] = r - ydr[j] * d.Wg; }
+    auto issue = [&](int chunk) {
+        const int m0 = __builtin_amdgcn_readfirstlane(chunk * WG_PIX);
+        const int b0 = m0 / HWg, rem0 = m0 - b0 * HWg, ay0 = rem0 / d.Wg, ax0 = rem0 - ay0 * d.Wg;   // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = chunk * WG_PIX + xr + 16 * j;
+            unsigned off0 = OOB, off1 = OOB;
+            if (m < d.M && xcol_ok) {
+                int b, ay, ax;
+                if (fast) { b = b0; ay = ay0 + xdr[j]; ax = ax0 + xdx[j]; }
+                else { b = m / HWg; const int rem = m - b * HWg; ay = rem / d.Wg; ax = rem - ay * d.Wg; }
+                const int iy = ay * sa + ady, ix = ax * sa + adx;
+                if ((unsigned)iy < (unsigned)d.Hx && (unsigned)ix < (unsigned)d.Wx) {
+                    const int pix = (b * d.Hx + iy) * d.Wx + ix;
+                    if (in0) off0 = (unsigned)((pix * d.ld0 + xci) * 4);
+                    else     off1 = (unsigned)((pix * d.ld1 + xci - d.c0) * 4);
+                }
+            }
+            f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx0, off0, 0, 0));
+            if (d.c1) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx1, off1, 0, 0));
+            rx[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NYL; ++j) {
+            const int m = chunk * WG_PIX + yr + YRP * j;
+            unsigned off = OOB;
+            if (m < d.M && ycol_ok) {
+                int b, ay, ax;
+                if (fast) { b = b0; ay = ay0 + ydr[j]; ax = ax0 + ydx[j]; }
+                else { b = m / HWg; const int rem = m - b * HWg; ay = rem / d.Wg; ax = rem - ay * d.Wg; }
+                const int oy = ay * sb + bdy, ox = ax * sb + bdx;
+                if ((unsigned)oy < (unsigned)d.Hy && (unsigned)ox < (unsigned)d.Wy)
+                    off = (unsigned)((((b * d.Hy + oy) * d.Wy + ox) * d.ldy + n0 + yc) * 4);
+            }
+            rY[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0));
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(&xs[buf][(xr + 16 * j) * WG_XP + xc]) = rx[j];
+#pragma unroll
+        for (int j = 0; j < NYL; ++j) *reinterpret_cast<f32x4*>(&ys[buf][(yr + YRP * j) * WG_YP + yc]) = rY[j];
+    };
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (c_begin < c_end) {
+        issue(c_begin);
+        store(0);
+        __syncthreads();
+        for (int c = c_begin; c < c_end; ++c) {
+            const int buf = (c - c_begin) & 1;
+            if (c + 1 < c_end) issue(c + 1);
+            const float* X = &xs[buf][wm * 32 + l31];
+            const float* Y = &ys[buf][wn * 32 * NT + l31];
+#pragma unroll
+            for (int k = 0; k < WG_PIX; k += 2) {
+                const float a = X[(k + half) * WG_XP];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Y[(k + half) * WG_YP + 32 * t], acc[t], 0, 0, 0);
+            }
+            if (c + 1 < c_end) store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // acc[t][r]: row i = ci (= (r&3) + 8*(r>>2) + 4*half), column j = n (= l31); packed gradient [tap][ci/32][n][ci%32]
+    const int wtap = tap;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + wn * 32 * NT + t * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (n < d.N && ci < d.cin) {
+                float* g = d.dw + (((size_t)wtap * (d.wcin >> 5) + (ci >> 5)) * d.N + n) * 32 + (ci & 31);
+                atomicAdd(g, acc[t][r]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fast path for the ConvLSTM weight gradient (5x5, stride 1, pad 2): 93 % of all wgrad flops.
+//   * one WAVE = one worker on 32-pixel chunks (32 consecutive pixels of image rows): it stages, for kernel row ky,
+//     an X strip with a 2-pixel x-halo ([R rows][SW+4][32 ci]) and the dY tile ([32 pixels][32*NTW n]) into its own
+//     double-buffered LDS region, then runs the 5 taps kx = 0..4 of that kernel row against the SAME dY fragments:
+//     16 k-steps x 5 taps x NTW tiles = 80*NTW MFMAs per chunk for ~12 16-byte loads per lane, and no block barrier
+//     anywhere in the main loop (a wave only ever reads what it wrote itself);
+//   * the 4 waves of a block work on the same (ky, 32 ci, 32*NTW n) tile over interleaved chunks; their accumulators are
+//     summed through LDS and the block issues ONE set of atomics, transposed through LDS so that a wave-instruction adds
+//     two contiguous 128-B segments of the K-inner packed gradient (full atomic rate) instead of 64 scattered words.
+// ---------------------------------------------------------------------------------------------------------
+template <int NTW, int SW>   // NTW: 32-column tiles per wave (1 or 2); SW: pixels of one image row inside a chunk (min(W, 32))
+__global__ __launch_bounds__(256, 1) void wgrad5x5_kernel(const WgradDesc d) {
+    constexpr int R = 32 / SW;                  // image rows per chunk
+    constexpr int SP = R * (SW + 4);            // strip pixels
+    constexpr int XP = 32, YP = 32 * NTW;       // LDS row lengths (floats): lane-contiguous reads, no padding needed
+    constexpr int WBUF = SP * XP + 32 * YP;     // floats per wave per buffer
+    constexpr int NACC = 5 * NTW;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ncb = d.cin >> 5, nnb = d.N / (32 * NTW);
+    int bid = blockIdx.x;
+    const int nb = bid % nnb; bid /= nnb;
+    const int cb = bid % ncb; bid /= ncb;
+    const int ky = bid;                          // 0..4
+    const int ci0 = cb * 32, n0 = nb * 32 * NTW;
+    const int HWg = d.Hg * d.Wg, Wd = d.Wg, Hd = d.Hg;
+    const int nchunks_total = d.M / 32;
+    const int nsplit = gridDim.y, split = blockIdx.y;
+    const int c_begin = (int)((long)nchunks_total * split / nsplit), c_end = (int)((long)nchunks_total * (split + 1) / nsplit);
+    constexpr unsigned OOB = 0xC0000000u;
+    const bool from0 = ci0 < d.c0;               // a 32-channel block never straddles the two sources (c0 % 32 == 0)
+    const __amdgpu_buffer_rsrc_t rx = from0 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x0), 0, d.bytes0, 0x00020000)
+                                            : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x1), 0, d.bytes1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy), 0, d.bytesy, 0x00020000);
+    const int xld = from0 ? d.ld0 : d.ld1;
+    const int xc0 = from0 ? ci0 : ci0 - d.c0;
+    float* wbase = sm + wave * 2 * WBUF;
+
+    // staging roles inside a wave: X strip: 8 lanes per strip pixel (float4 of 4 channels), 8 pixels per pass
+    constexpr int NXP = (SP + 7) / 8;
+    // dY tile: YP/4 lanes per pixel, 64/(YP/4) pixels per pass
+    constexpr int YL = YP / 4, YPP = 64 / YL, NYP = 32 / YPP;
+    const int xl = lane & 7, xq = lane >> 3;
+    const int yl = lane % YL, yq = lane / YL;
+    f32x4 rx4[NXP], ry4[NYP];
+    auto issue = [&](int chunk) {
+        const int p0 = chunk * 32;
+        const int b = p0 / HWg, rem = p0 - b * HWg, y0 = rem / Wd, x0 = rem - y0 * Wd;
+#pragma unroll
+        for (int j = 0; j < NXP; ++j) {
+            const int sp = xq + 8 * j;                     // strip pixel
+            unsigned off = OOB;
+            if (sp < SP) {
+                const int r = sp / (SW + 4), xx = sp - r * (SW + 4);
+                const int iy = y0 + r + ky - 2, ix = x0 + xx - 2;
+                if ((unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd)
+                    off = (unsigned)((((b * Hd + iy) * Wd + ix) * xld + xc0 + xl * 4) * 4);
+            }
+            rx4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < NYP; ++j) {
+            const int pix = yq + YPP * j;
+            const unsigned off = (unsigned)(((p0 + pix) * d.ldy + n0 + yl * 4) * 4);
+            ry4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0));
+        }
+    };
+    auto store = [&](int buf) {
+        float* xs = wbase + buf * WBUF;
+        float* ys = xs + SP * XP;
+#pragma unroll
+        for (int j = 0; j < NXP; ++j) {
+            const int sp = xq + 8 * j;
+            if (sp < SP) *reinterpret_cast<f32x4*>(xs + sp * XP + xl * 4) = rx4[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NYP; ++j) *reinterpret_cast<f32x4*>(ys + (yq + YPP * j) * YP + yl * 4) = ry4[j];
+    };
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int t = 0; t < NACC; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    float bsum[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) bsum[t] = 0.f;
+    int c = c_begin + wave;
+    if (c < c_end) { issue(c); store(0); }
+    int buf = 0;
+    for (; c < c_end; c += 4) {
+        const bool more = c + 4 < c_end;
+#if PIVP_WG_ABL < 1 || PIVP_WG_ABL == 3
+        if (more) issue(c + 4);
+#endif
+        const float* xs = wbase + buf * WBUF + l31;
+        const float* ys = xs - l31 + SP * XP + l31;
+        // operands of k-step s2+1 are read from LDS BEFORE the 5*NTW MFMAs of k-step s2 are issued, and the order is pinned:
+        // left to itself hipcc reads each operand right in front of its MFMA and waits lgkmcnt(0) twice per k-step
+        // (two exposed LDS round trips per 10 MFMAs: the kernel ran at 70 TFLOP/s)
+        float av[2][5], bv[2][NTW];   // (bsum: running column sums of the dY values this lane feeds the MFMAs = bias gradient)
+        auto read_step = [&](auto S2, int slot) {
+            constexpr int s2 = decltype(S2)::value;
+            constexpr int sidx0 = (2 * s2 / SW) * (SW + 4) + (2 * s2 % SW);   // strip index of (pixel 2*s2, kx = 0)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bv[slot][t] = ys[(2 * s2 + half) * YP + t * 32];
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) av[slot][kx] = xs[(sidx0 + half + kx) * XP];
+        };
+        auto kstep = [&](auto S2) {
+            constexpr int s2 = decltype(S2)::value, cur = s2 & 1;
+#if PIVP_WG_ABL < 2
+            if constexpr (s2 + 1 < 16) read_step(std::integral_constant<int, s2 + 1>{}, cur ^ 1);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bsum[t] += bv[cur][t];
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
+                    acc[kx * NTW + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][kx], bv[cur][t], acc[kx * NTW + t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        read_step(std::integral_constant<int, 0>{}, 0);
+        kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{}); kstep(std::integral_constant<int, 2>{});
+        kstep(std::integral_constant<int, 3>{}); kstep(std::integral_constant<int, 4>{}); kstep(std::integral_constant<int, 5>{});
+        kstep(std::integral_constant<int, 6>{}); kstep(std::integral_constant<int, 7>{}); kstep(std::integral_constant<int, 8>{});
+        kstep(std::integral_constant<int, 9>{}); kstep(std::integral_constant<int, 10>{}); kstep(std::integral_constant<int, 11>{});
+        kstep(std::integral_constant<int, 12>{}); kstep(std::integral_constant<int, 13>{}); kstep(std::integral_constant<int, 14>{});
+        kstep(std::integral_constant<int, 15>{});
+#if PIVP_WG_ABL < 1 || PIVP_WG_ABL == 4
+        if (more) store(buf ^ 1);
+#endif
+#if PIVP_WG_ABL == 3
+#pragma unroll
+        for (int j = 0; j < NXP; ++j) asm volatile("" :: "v"(rx4[j]));
+#pragma unroll
+        for (int j = 0; j < NYP; ++j) asm volatile("" :: "v"(ry4[j]));
+#endif
+        buf ^= 1;
+    }
+    // ---- bias gradient: the blocks of kernel row 2 / channel block 0 have fed every dY element of their pixel range through
+    // the MFMAs exactly once; lane (n, half) holds the sum over its half's pixels ---------------------------------------
+    if (d.db && ky == 2 && cb == 0) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const float v = bsum[t] + __shfl_xor(bsum[t], 32, 64);
+            if (half == 0) atomicAdd(d.db + n0 + t * 32 + l31, v);
+        }
+    }
+    // ---- block reduction of the 4 workers + transposed atomics -------------------------------------------------
+    // LDS image of one worker's result: [tap kx][tile t][n 0..31][ci 0..31]  (NACC * 1024 floats = 20/40 KB)
+    __syncthreads();                               // every wave is done with its staging buffers
+    constexpr int IMG = NACC * 1024;
+    auto put = [&](float* img) {
+#pragma unroll
+        for (int t = 0; t < NACC; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) img[t * 1024 + l31 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = acc[t][r];
+    };
+    auto add = [&](const float* img) {
+#pragma unroll
+        for (int t = 0; t < NACC; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += img[t * 1024 + l31 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+    };
+    if (wave >= 2) put(sm + (wave - 2) * IMG);
+    __syncthreads();
+    if (wave < 2) add(sm + wave * IMG);
+    __syncthreads();
+    if (wave == 1) put(sm);
+    __syncthreads();
+    if (wave == 0) { add(sm); }
+    __syncthreads();
+    if (wave == 0) put(sm);
+    __syncthreads();
+    // packed gradient [tap][wcin/32][N][32]: for tap (ky,kx), tile t: rows n0 + t*32 + n, 32 contiguous ci each
+    for (int i = tid; i < IMG; i += 256) {
+        const int t = i >> 10, rem = i & 1023, n = rem >> 5, ci = rem & 31;
+        const int kx = t / NTW, tt = t - kx * NTW;
+        const int tap = ky * 5 + kx;
+        float* g = d.dw + (((size_t)tap * (d.wcin >> 5) + cb) * d.N + n0 + tt * 32 + n) * 32 + ci;
+        atomicAdd(g, sm[i]);
+    }
+    // bias gradient for free: the kernel-row 0 / channel-block 0 blocks have every dY pixel of their chunks in LDS... not kept; see bias_grad
+}
+
+template <int NTW, int SW>
+static int launch_wgrad5x5(const WgradDesc& d, hipStream_t s) {
+    constexpr int R = 32 / SW, SP = R * (SW + 4);
+    constexpr int WBUF = SP * 32 + 32 * 32 * NTW;
+    constexpr int IMG = 5 * NTW * 1024;
+    constexpr int lds_floats = (4 * 2 * WBUF > 2 * IMG) ? 4 * 2 * WBUF : 2 * IMG;
+    constexpr int lds_bytes = lds_floats * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad5x5_kernel<NTW, SW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        attr_set = true;
+    }
+    const int tiles = 5 * (d.cin / 32) * (d.N / (32 * NTW));
+    const int chunks = d.M / 32;
+    // One block per CU is resident (~100 KB of LDS), so the grid is sized to whole rounds of the chip's CUs: the first
+    // version asked for "about 512" blocks and got 520-600, i.e. a third round that ran 8-88 blocks on 256 CUs (lstm7: 264 us
+    // for 171 us of MFMA work).  Take the fewest rounds (1..3) whose last round is at least 90 % full.
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    int nsplit = 1;
+    double best = 0.0;
+    for (int r = 1; r <= 3; ++r) {
+        int ns = (cus * r) / tiles;
+        if (ns > chunks / 16) ns = chunks / 16;          // >= 4 chunks per wave
+        if (ns < 1) ns = 1;
+        const long blocks = (long)tiles * ns;
+        const double fill = (double)blocks / (double)(((blocks + cus - 1) / cus) * cus);
+        if (fill > best + 0.02) { best = fill; nsplit = ns; }
+        if (best >= 0.9) break;
+    }
+    hipLaunchKernelGGL((wgrad5x5_kernel<NTW, SW>), dim3(tiles, nsplit), dim3(256), lds_bytes, s, d);
+    return PIVP_LAUNCH_STATUS();
+}
+
+int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done) {
+    if (bias_done) *bias_done = 0;
+    PIVP_CHECK_ARG(d.x0 && d.dy && d.dw && d.c0 > 0 && d.c0 % 32 == 0 && d.c1 >= 0 && d.c1 % 32 == 0 && (d.c1 == 0 || d.x1));
+    PIVP_CHECK_ARG(d.cin == d.c0 + d.c1 && d.wcin >= d.cin && d.wcin % 32 == 0 && d.N > 0 && d.N % 32 == 0);
+    PIVP_CHECK_ARG(d.M == d.B * d.Hg * d.Wg && d.M > 0 && d.ksize >= 1 && d.ksize <= 7);
+    PIVP_CHECK_ARG(d.bytes0 > 0 && d.bytesy > 0 && (d.c1 == 0 || d.bytes1 > 0));
+    if (!d.deconv && d.ksize == 5 && d.pad == 2 && d.stride == 1 && d.M % 32 == 0 && d.N % 64 == 0 &&
+        (d.Wg == 8 || d.Wg == 16 || d.Wg % 32 == 0) && d.Hx == d.Hy && d.Wx == d.Wy) {
+        if (bias_done) *bias_done = d.db ? 1 : 0;
+        if (d.Wg == 8) return launch_wgrad5x5<2, 8>(d, s);
+        if (d.Wg == 16) return launch_wgrad5x5<2, 16>(d, s);
+        return launch_wgrad5x5<2, 32>(d, s);
+    }
+    const int wg_n = d.N <= 64 ? 64 : 128;
+    const int ncb = (d.cin + WG_CI - 1) / WG_CI, nnb = (d.N + wg_n - 1) / wg_n;
+    const int tiles = d.ksize * d.ksize * ncb * nnb;
+    const int chunks = (d.M + WG_PIX - 1) / WG_PIX;
+    // every block ends with a tile of atomics (64 x 128), so no more pixel splits than fill the chip twice (3 blocks fit a CU)
+    int nsplit = (512 + tiles - 1) / tiles;
+    if (nsplit > chunks / 8) nsplit = chunks / 8;         // and >= 8 chunks (256 pixels) per block (enc4 with 4: 63 -> 94 us, atomics)
+    if (nsplit < 1) nsplit = 1;
+    if (wg_n == 64) hipLaunchKernelGGL(igemm_wgrad_kernel<1>, dim3(tiles, nsplit), dim3(256), 0, s, d);
+    else hipLaunchKernelGGL(igemm_wgrad_kernel<2>, dim3(tiles, nsplit), dim3(256), 0, s, d);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Re-pack for the data gradient: W packed [tap][Cin/32][N][32]  ->  Wt packed [tap'][N/32][Cin][32] with
+// tap' = flipped tap when `flip` (stride-1 conv: dX = conv(dY, W flipped, in/out swapped)) or the same tap
+// (stride-2 conv <-> transposed conv are exact adjoints of each other on the same tap index).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void repack_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                               int taps, int cin, int N, int flip) {
+    __shared__ float t[32][33];
+    const int tap = blockIdx.z, cc = blockIdx.y, nc = blockIdx.x;   // 32 ci x 32 n tile
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = w + (((size_t)tap * (cin >> 5) + cc) * N + nc * 32) * 32;      // [n 0..31][ci 0..31]
+    for (int r = ty; r < 32; r += 8) t[r][tx] = src[r * 32 + tx];                      // t[n][ci]
+    __syncthreads();
+    const int tap2 = flip ? taps - 1 - tap : tap;
+    float* dst = wt + (((size_t)tap2 * (N >> 5) + nc) * cin + cc * 32) * 32;           // [ci 0..31][n 0..31]
+    for (int r = ty; r < 32; r += 8) dst[r * 32 + tx] = t[tx][r];
+}
+
+int repack_transpose(const float* w, float* wt, int taps, int cin, int N, int flip, hipStream_t s) {
+    PIVP_CHECK_ARG(w && wt && taps > 0 && cin > 0 && cin % 32 == 0 && N > 0 && N % 32 == 0);
+    hipLaunchKernelGGL(repack_transpose_kernel, dim3(N / 32, cin / 32, taps), dim3(256), 0, s, w, wt, taps, cin, N, flip);
+    return PIVP_LAUNCH_STATUS();
+}
+
+}  // namespace pivp
