@@ -214,8 +214,13 @@ __global__ __launch_bounds__(256, 1) void wgrad5x5_kernel(const WgradDesc d) {
     constexpr int YL = YP / 4, YPP = 64 / YL, NYP = 32 / YPP;
     const int xl = lane & 7, xq = lane >> 3;
     const int yl = lane % YL, yq = lane / YL;
-    f32x4 rx4[NXP], ry4[NYP];
-    auto issue = [&](int chunk) {
+    // two register sets: the loads of chunk c+8 are issued at the top of chunk c and written to LDS at the END of chunk c+4, so
+    // they have two chunks (~20k cycles) to arrive; with one set (issue at the top, ds_write at the end of the same chunk) the
+    // ds_writes waited for loads every chunk: the ablations price that wait at 43 of lstm7's 265 us.
+    f32x4 rxs[2][NXP], rys[2][NYP];
+    auto issue = [&](auto SET, int chunk) {
+        f32x4 (&rx4)[NXP] = rxs[decltype(SET)::value];
+        f32x4 (&ry4)[NYP] = rys[decltype(SET)::value];
         const int p0 = chunk * 32;
         const int b = p0 / HWg, rem = p0 - b * HWg, y0 = rem / Wd, x0 = rem - y0 * Wd;
 #pragma unroll
@@ -237,7 +242,9 @@ __global__ __launch_bounds__(256, 1) void wgrad5x5_kernel(const WgradDesc d) {
             ry4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0));
         }
     };
-    auto store = [&](int buf) {
+    auto store = [&](auto SET, int buf) {
+        f32x4 (&rx4)[NXP] = rxs[decltype(SET)::value];
+        f32x4 (&ry4)[NYP] = rys[decltype(SET)::value];
         float* xs = wbase + buf * WBUF;
         float* ys = xs + SP * XP;
 #pragma unroll
@@ -257,13 +264,15 @@ __global__ __launch_bounds__(256, 1) void wgrad5x5_kernel(const WgradDesc d) {
     float bsum[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) bsum[t] = 0.f;
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
     int c = c_begin + wave;
-    if (c < c_end) { issue(c); store(0); }
+    if (c < c_end) { issue(S0{}, c); store(S0{}, 0); }
+    if (c + 4 < c_end) issue(S1{}, c + 4);
     int buf = 0;
-    for (; c < c_end; c += 4) {
-        const bool more = c + 4 < c_end;
+    auto iter = [&](auto SET) {     // chunk c from LDS buffer `buf`; SET = register set that receives chunk c+8
+        using OTHER = std::integral_constant<int, decltype(SET)::value ^ 1>;
 #if PIVP_WG_ABL < 1 || PIVP_WG_ABL == 3
-        if (more) issue(c + 4);
+        if (c + 8 < c_end) issue(SET, c + 8);
 #endif
         const float* xs = wbase + buf * WBUF + l31;
         const float* ys = xs - l31 + SP * XP + l31;
@@ -302,15 +311,14 @@ __global__ __launch_bounds__(256, 1) void wgrad5x5_kernel(const WgradDesc d) {
         kstep(std::integral_constant<int, 12>{}); kstep(std::integral_constant<int, 13>{}); kstep(std::integral_constant<int, 14>{});
         kstep(std::integral_constant<int, 15>{});
 #if PIVP_WG_ABL < 1 || PIVP_WG_ABL == 4
-        if (more) store(buf ^ 1);
-#endif
-#if PIVP_WG_ABL == 3
-#pragma unroll
-        for (int j = 0; j < NXP; ++j) asm volatile("" :: "v"(rx4[j]));
-#pragma unroll
-        for (int j = 0; j < NYP; ++j) asm volatile("" :: "v"(ry4[j]));
+        if (c + 4 < c_end) store(OTHER{}, buf ^ 1);
 #endif
         buf ^= 1;
+        c += 4;
+    };
+    while (c < c_end) {
+        iter(S0{});
+        if (c < c_end) iter(S1{});
     }
     // ---- bias gradient: the blocks of kernel row 2 / channel block 0 have fed every dY element of their pixel range through
     // the MFMAs exactly once; lane (n, half) holds the sum over its half's pixels ---------------------------------------

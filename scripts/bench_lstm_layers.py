@@ -14,6 +14,7 @@ LAYERS = [('lstm1', 32, 32, 32), ('lstm2', 32, 32, 32), ('lstm3', 32, 64, 16), (
           ('lstm5', 64, 128, 8), ('lstm6', 128, 64, 16), ('lstm7', 96, 32, 32)]
 import os
 VARIANT = int(os.environ.get('PIVP_LSTM_VARIANT', '0'))
+DATA = os.environ.get('PIVP_BENCH_DATA', 'random')   # random | zero | const: does the MFMA rate depend on the operand values?
 lib = _lib.load()
 dev = 'cuda:0'
 st = torch.cuda.current_stream().cuda_stream
@@ -27,6 +28,10 @@ for name, cx, C, H in LAYERS:
     c = torch.from_numpy(rs.randn(B, H, H, C).astype(np.float32)).to(dev)
     w = torch.from_numpy((rs.randn(25 * (cx + C) * 4 * C) / np.sqrt(25 * (cx + C))).astype(np.float32)).to(dev)
     b = torch.from_numpy((rs.randn(4 * C) * 0.1).astype(np.float32)).to(dev)
+    if DATA == 'zero':
+        x.zero_(); h.zero_(); w.zero_()
+    elif DATA == 'const':
+        x.fill_(0.37); h.fill_(-0.21); w.fill_(0.013)
     co = torch.empty_like(c); ho = torch.empty_like(h)
     bufs[name] = (x, h, c, w, b, co, ho, cx, C, H)
 
