@@ -91,7 +91,10 @@ __global__ __launch_bounds__(256, 1) void convlstm_tile_kernel(const IgemmDesc d
     }
     const int b_lw = prow * TP + cvec * 4;
 
-    f32x4 ra[5], rb[NB];
+    // two weight register sets: the tile of chunk i+2 is loaded during chunk i and written to LDS during chunk i+1, so a load
+    // has a whole chunk (2-4k cycles) to arrive before its ds_write waits for it.  With one set (load in micro-steps 0-3, write
+    // in 12-15 of the same chunk) the writes waited on L2 / MALL latency every chunk (igemm_wgrad.hip found the same: -9 %).
+    f32x4 ra[5], rb[2][NB];
     // next weight chunk to load: tap l_tap of channel chunk l_cc (taps innermost)
     int l_tap = 0, l_cc = 0;
     int s_wbase = 0;
@@ -101,13 +104,13 @@ __global__ __launch_bounds__(256, 1) void convlstm_tile_kernel(const IgemmDesc d
         l_tap = w ? 0 : l_tap;
         l_cc += w ? 1 : 0;
     };
-    auto load_b = [&](auto J) {
+    auto load_b = [&](auto SET, auto J) {
         constexpr int j = decltype(J)::value;
-        if constexpr (j < NB) rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, b_go[j], s_wbase, 0));
+        if constexpr (j < NB) rb[decltype(SET)::value][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, b_go[j], s_wbase, 0));
     };
-    auto store_b = [&](auto J, int buf) {
+    auto store_b = [&](auto SET, auto J, int buf) {
         constexpr int j = decltype(J)::value;
-        if constexpr (j < NB) *reinterpret_cast<f32x4*>(Bt + buf * B_FL + b_lw + 32 * j * TP) = rb[j];
+        if constexpr (j < NB) *reinterpret_cast<f32x4*>(Bt + buf * B_FL + b_lw + 32 * j * TP) = rb[decltype(SET)::value][j];
     };
     auto load_a = [&](auto J, int cc) {     // piece J of channel chunk cc's patch
         constexpr int j = decltype(J)::value;
@@ -136,8 +139,11 @@ __global__ __launch_bounds__(256, 1) void convlstm_tile_kernel(const IgemmDesc d
 
     // ---- one chunk = tap c_tap of channel chunk c_cc: 16 micro-steps of 2 MFMAs ----------------------------------------
     int c_tap = 0, c_cc = 0;
-    auto chunk = [&](auto STAGE, int buf) {
-        constexpr bool stage = decltype(STAGE)::value;
+    // LOAD: this chunk issues the weight loads of chunk +2 into register set SET; STORE: it writes set SET^1 (chunk +1) to the
+    // other LDS buffer
+    auto chunk = [&](auto LOAD, auto STORE, auto SET, int buf) {
+        constexpr bool do_load = decltype(LOAD)::value, stage = decltype(STORE)::value;
+        using OTHER = std::integral_constant<int, decltype(SET)::value ^ 1>;
         const int ty = c_tap / 5, tx = c_tap - ty * 5;                     // scalar
         const float* As = At + a_lane + (ty * TW + tx) * TP;
         const float* Bs = Bt + buf * B_FL;
@@ -158,8 +164,8 @@ __global__ __launch_bounds__(256, 1) void convlstm_tile_kernel(const IgemmDesc d
 #pragma unroll
             for (int t = 0; t < TPW; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s2], fb[cur][t][s2], acc[t], 0, 0, 0);
-            if constexpr (stage && step < 4) load_b(std::integral_constant<int, step>{});
-            if constexpr (stage && step == 4) next_b();                    // scalars of the chunk after the next
+            if constexpr (do_load && step < 4) load_b(SET, std::integral_constant<int, step>{});
+            if constexpr (do_load && step == 4) next_b();                  // scalars of the loads of the next chunk
             if constexpr (stage && step == 5) {
                 if (a_next) {                                              // uniform branch
                     switch (c_tap) {
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(256, 1) void convlstm_tile_kernel(const IgemmDesc d
                     }
                 }
             }
-            if constexpr (stage && step >= 12) store_b(std::integral_constant<int, step - 12>{}, buf ^ 1);
+            if constexpr (stage && step >= 12) store_b(OTHER{}, std::integral_constant<int, step - 12>{}, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto qgroup = [&](auto Q) {
@@ -182,27 +188,45 @@ __global__ __launch_bounds__(256, 1) void convlstm_tile_kernel(const IgemmDesc d
         qgroup(std::integral_constant<int, 2>{}); qgroup(std::integral_constant<int, 3>{});
     };
 
-    // prologue: patch of channel chunk 0 and the weights of chunk 0
-    load_a(std::integral_constant<int, 0>{}, 0); load_a(std::integral_constant<int, 1>{}, 0); load_a(std::integral_constant<int, 2>{}, 0);
-    load_a(std::integral_constant<int, 3>{}, 0); load_a(std::integral_constant<int, 4>{}, 0);
+    // prologue: patch of channel chunk 0, weights of chunk 0 (to LDS) and of chunk 1 (stay in register set 1)
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    load_a(I0{}, 0); load_a(I1{}, 0); load_a(I2{}, 0); load_a(I3{}, 0); load_a(std::integral_constant<int, 4>{}, 0);
     next_b();
-    load_b(std::integral_constant<int, 0>{}); load_b(std::integral_constant<int, 1>{});
-    load_b(std::integral_constant<int, 2>{}); load_b(std::integral_constant<int, 3>{});
+    load_b(S0{}, I0{}); load_b(S0{}, I1{}); load_b(S0{}, I2{}); load_b(S0{}, I3{});
+    next_b();
+    if (nchunks > 1) { load_b(S1{}, I0{}); load_b(S1{}, I1{}); load_b(S1{}, I2{}); load_b(S1{}, I3{}); }
+    next_b();                                  // scalars of chunk 2 (loaded while chunk 0 is multiplied)
     store_a();
-    store_b(std::integral_constant<int, 0>{}, 0); store_b(std::integral_constant<int, 1>{}, 0);
-    store_b(std::integral_constant<int, 2>{}, 0); store_b(std::integral_constant<int, 3>{}, 0);
-    next_b();                                  // scalars of chunk 1 (loaded while chunk 0 is multiplied)
+    store_b(S0{}, I0{}, 0); store_b(S0{}, I1{}, 0); store_b(S0{}, I2{}, 0); store_b(S0{}, I3{}, 0);
     __syncthreads();
-    for (int it = 0; it + 1 < nchunks; ++it) {
-        chunk(std::true_type{}, it & 1);
+    auto advance = [&]() {
         __syncthreads();
         if (++c_tap == 25) {                   // channel-chunk boundary: the next patch moves from registers to LDS
             c_tap = 0; ++c_cc;
             store_a();
             __syncthreads();
         }
+    };
+    // two chunks per trip (register sets 0 and 1 alternate statically: a run-time parity branch made hipcc fall back to
+    // vmcnt(0) in front of every ds_write); nchunks = 25 * ncc, `it` stays even
+    int it = 0;
+    for (; it + 3 < nchunks; it += 2) {        // chunk it loads it+2 into set 0 and writes it+1 (set 1); chunk it+1 the reverse
+        chunk(std::true_type{}, std::true_type{}, S0{}, 0); advance();
+        chunk(std::true_type{}, std::true_type{}, S1{}, 1); advance();
     }
-    chunk(std::false_type{}, (nchunks - 1) & 1);
+    const int rest = nchunks - it;             // 1, 2 or 3 chunks left
+    if (rest == 3) {
+        chunk(std::true_type{}, std::true_type{}, S0{}, 0); advance();
+        chunk(std::false_type{}, std::true_type{}, S1{}, 1); advance();
+        chunk(std::false_type{}, std::false_type{}, S0{}, 0);
+    } else if (rest == 2) {
+        chunk(std::false_type{}, std::true_type{}, S0{}, 0); advance();
+        chunk(std::false_type{}, std::false_type{}, S0{}, 1);
+    } else {
+        chunk(std::false_type{}, std::false_type{}, S0{}, 0);
+    }
 
     // ---- epilogue: gates, state update, optional gate activations and LayerNorm partial ------------------------------
     const int chl = wn * CPW + (l31 % CPW);
