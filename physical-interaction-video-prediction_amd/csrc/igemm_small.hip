@@ -11,6 +11,7 @@
 // Same descriptor, operand layouts, tap enumeration and out-of-image handling (buffer loads with an out-of-range
 // offset return 0) as the main kernel.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "pivp_kernels.h"
 
@@ -66,8 +67,11 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     const int lds_w = prow * SP + cvec * 4;
 
     int l_cc = 0, l_ty = 0, l_tx = 0;
-    f32x4 ra, rb[NTB];
-    auto load_next = [&]() {   // chunk (l_ty, l_tx, l_cc) -> registers, then advance
+    // two register sets: chunk i+2 is loaded while chunk i is multiplied and written to LDS at the end of chunk i+1
+    f32x4 ras[2], rbs[2][NTB];
+    auto load_next = [&](auto SET) {   // chunk (l_ty, l_tx, l_cc) -> register set SET, then advance
+        f32x4& ra = ras[decltype(SET)::value];
+        f32x4 (&rb)[NTB] = rbs[decltype(SET)::value];
         int dy, dx, wi;
         if (deconv) {
             const int ky = py ? 2 * l_ty : 1, kx = px ? 2 * l_tx : 1;
@@ -89,7 +93,9 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
         for (int t = 0; t < NTB; ++t) rb[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, b_goff[t], wbase, 0));
         if (++l_cc == ncc) { l_cc = 0; if (++l_tx == ntx) { l_tx = 0; ++l_ty; } }
     };
-    auto store_regs = [&](int buf) {
+    auto store_regs = [&](auto SET, int buf) {
+        const f32x4& ra = ras[decltype(SET)::value];
+        const f32x4 (&rb)[NTB] = rbs[decltype(SET)::value];
         *reinterpret_cast<f32x4*>(lds + A_OFF + buf * TILE + lds_w) = ra;
 #pragma unroll
         for (int t = 0; t < NTB; ++t) *reinterpret_cast<f32x4*>(lds + B_OFF + (buf * NTB + t) * TILE + lds_w) = rb[t];
@@ -103,13 +109,8 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     const int frag = l31 * SP + 8 * wave + 4 * half;   // k-group `wave` of row l31
 
     if (nchunks > 0) {
-        load_next();
-        store_regs(0);
-        __syncthreads();
-        for (int it = 0; it < nchunks; ++it) {
-            const int buf = it & 1;
-            const bool more = it + 1 < nchunks;
-            if (more) load_next();   // in flight while this chunk is multiplied
+        using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+        auto mma = [&](int buf) {
             const f32x4 fa = *reinterpret_cast<const f32x4*>(lds + A_OFF + buf * TILE + frag);
             f32x4 fb[NTB];
 #pragma unroll
@@ -118,9 +119,24 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
             for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
                 for (int t = 0; t < NTB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s2], fb[t][s2], acc[t], 0, 0, 0);
-            if (more) store_regs(buf ^ 1);
+        };
+        load_next(S0{});
+        store_regs(S0{}, 0);
+        if (nchunks > 1) load_next(S1{});
+        __syncthreads();
+        int it = 0;
+        for (; it + 1 < nchunks; it += 2) {     // chunks it (LDS buffer 0) and it+1 (buffer 1)
+            if (it + 2 < nchunks) load_next(S0{});
+            mma(0);
+            store_regs(S1{}, 1);                // chunk it+1
+            __syncthreads();
+            if (it + 3 < nchunks) load_next(S1{});
+            mma(1);
+            if (it + 2 < nchunks) store_regs(S0{}, 0);
             __syncthreads();
         }
+        if (it < nchunks) mma(0);               // odd count: the last chunk sits in buffer 0
+        __syncthreads();
     }
 
     // sum of the four waves' partial tiles, then the epilogue on float4 rows
