@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
     const bool xcol_ok = xci < d.cin;
     const bool in0 = xci < d.c0;
     const bool ycol_ok = (n0 + yc) < d.N;
-    f32x4 rx[2], rY[NYL];
+    f32x4 rxs[2][2], rYs[2][NYL];   // two register sets: chunk c+2 is loaded during chunk c, written to LDS at the end of chunk c+1
     // anchor coordinates without per-load divisions: when chunks never straddle a sample and the anchor-grid width is a
     // multiple or a divisor of 32 (every map of this model), row r of a chunk sits at a fixed (row, column) offset from the
     // chunk's first anchor.  The first version divided twice per load: ~420 of the ~600 instructions between two chunks'
@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
     for (int j = 0; j < 2; ++j) { const int r = xr + 16 * j; xdr[j] = d.Wg >= WG_PIX ? 0 : r / d.Wg; xdx[j] = r - xdr[j] * d.Wg; }
 #pragma unroll
     for (int j = 0; j < NYL; ++j) { const int r = yr + YRP * j; ydr[j] = d.Wg >= WG_PIX ? 0 : r / d.Wg; ydx[j] = r - ydr[j] * d.Wg; }
-    auto issue = [&](int chunk) {
+    auto issue = [&](auto SET, int chunk) {
+        f32x4 (&rx)[2] = rxs[decltype(SET)::value];
+        f32x4 (&rY)[NYL] = rYs[decltype(SET)::value];
         const int m0 = __builtin_amdgcn_readfirstlane(chunk * WG_PIX);
         const int b0 = m0 / HWg, rem0 = m0 - b0 * HWg, ay0 = rem0 / d.Wg, ax0 = rem0 - ay0 * d.Wg;   // wave-uniform
 #pragma unroll
@@ -119,7 +121,9 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
             rY[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0));
         }
     };
-    auto store = [&](int buf) {
+    auto store = [&](auto SET, int buf) {
+        const f32x4 (&rx)[2] = rxs[decltype(SET)::value];
+        const f32x4 (&rY)[NYL] = rYs[decltype(SET)::value];
 #pragma unroll
         for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(&xs[buf][(xr + 16 * j) * WG_XP + xc]) = rx[j];
 #pragma unroll
@@ -132,12 +136,8 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     if (c_begin < c_end) {
-        issue(c_begin);
-        store(0);
-        __syncthreads();
-        for (int c = c_begin; c < c_end; ++c) {
-            const int buf = (c - c_begin) & 1;
-            if (c + 1 < c_end) issue(c + 1);
+        using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+        auto mma = [&](int buf) {
             const float* X = &xs[buf][wm * 32 + l31];
             const float* Y = &ys[buf][wn * 32 * NT + l31];
 #pragma unroll
@@ -147,9 +147,23 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
                 for (int t = 0; t < NT; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Y[(k + half) * WG_YP + 32 * t], acc[t], 0, 0, 0);
             }
-            if (c + 1 < c_end) store(buf ^ 1);
+        };
+        issue(S0{}, c_begin);
+        store(S0{}, 0);
+        if (c_begin + 1 < c_end) issue(S1{}, c_begin + 1);
+        __syncthreads();
+        int c = c_begin;
+        for (; c + 1 < c_end; c += 2) {          // chunks c (LDS buffer 0) and c+1 (buffer 1)
+            if (c + 2 < c_end) issue(S0{}, c + 2);
+            mma(0);
+            store(S1{}, 1);
+            __syncthreads();
+            if (c + 3 < c_end) issue(S1{}, c + 3);
+            mma(1);
+            if (c + 2 < c_end) store(S0{}, 0);
             __syncthreads();
         }
+        if (c < c_end) mma(0);
     }
     // acc[t][r]: row i = ci (= (r&3) + 8*(r>>2) + 4*half), column j = n (= l31); packed gradient [tap][ci/32][n][ci%32]
     const int wtap = tap;
