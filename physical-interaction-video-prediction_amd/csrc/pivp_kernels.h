@@ -63,7 +63,9 @@ bool convlstm_tile_ok(const IgemmDesc& d);
 int convlstm_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr, int nch = 0);   // nch: channels per block, 0 = auto   // 32 x 32 tiles, K split over the waves (csrc/igemm_small.hip)
 
 // enc0: 5x5 stride-2 pad-2 conv on a planar 3-channel frame -> NHWC 32 channels (TM:500)
-int conv_enc0(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s);
+// ln_part (optional): the launch also writes *ln_nparts LayerNorm partials per sample of its output (0 = not supported for the shape)
+int conv_enc0(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s,
+              float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr);
 
 // LayerNorm over the flattened C*H*W vector of each sample with per-element gamma/beta (TM:203-208)
 int ln_stats_slices(int n);  // number of partial slices per sample for n elements

@@ -256,8 +256,8 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     const int n2 = 32 * p->H2 * p->W2, n4 = 64 * p->H4 * p->W4, n8 = 128 * p->H8 * p->W8;
 
     // group 0 (TM:595): enc0 -> norm_enc0 -> relu   => cat7[:, 32:64]
-    RC(conv_enc0(prev, P(p, p->i_enc_w[0]), P(p, p->i_enc_b[0]), ws + S.e0raw, B, H, W, s));
-    RC(ln(0, ws + S.e0raw, ws + S.cat7 + 32, n2, 32, 64, 1, 0));
+    RC(conv_enc0(prev, P(p, p->i_enc_w[0]), P(p, p->i_enc_b[0]), ws + S.e0raw, B, H, W, s, lnp, ln_cap, &np));
+    RC(ln(0, ws + S.e0raw, ws + S.cat7 + 32, n2, 32, 64, 1, np));
     // group 1 (TM:596): lstm1 -> hidden1 -> lstm2 -> hidden2 -> enc1 -> relu  => cat6[:, 64:96]
     RC(lstm(0, ws + S.cat7 + 32, 64, p->H2, p->W2));
     RC(ln(1, ws + S.h[0], ws + S.n1, n2, 32, 32, 0, np));

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void conv_enc0_kernel(const float* __restrict_
 constexpr int E0_PR = 4;   // patch rows per thread and channel
 __global__ __launch_bounds__(256) void conv_enc0_rows_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ out,
-                                                             int B, int H, int W) {
+                                                             int B, int H, int W, float* __restrict__ ln_part) {
     extern __shared__ __attribute__((aligned(16))) float sm0[];
     float* wl = sm0;                 // [75][32]
     float* patch = sm0 + 75 * 32;    // [3][R][PWc]
@@ -117,9 +117,26 @@ __global__ __launch_bounds__(256) void conv_enc0_rows_kernel(const float* __rest
     float* op = out + (((size_t)b * H2 + oy0 + ry) * W2 + ox) * 32 + cg * 8;
     *reinterpret_cast<f32x4*>(op) = f32x4{acc[0], acc[1], acc[2], acc[3]};
     *reinterpret_cast<f32x4*>(op + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+    if (ln_part) {   // LayerNorm partial (count, mean, M2) of the block's 64 x 32 outputs (norm_enc0 follows, TM:595)
+        __shared__ float red[4];
+        float s1 = 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) s1 += acc[o];
+        const float mean = block_sum<256>(s1, red) * (1.0f / 2048.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) { const float dd = acc[o] - mean; q = fmaf(dd, dd, q); }
+        q = block_sum<256>(q, red);
+        if (tid == 0) {
+            float* pp = ln_part + (size_t)blockIdx.x * 4;   // blocks of a sample are consecutive: [b][tile]
+            pp[0] = 2048.f; pp[1] = mean; pp[2] = q; pp[3] = 0.f;
+        }
+    }
 }
 
-int conv_enc0(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s) {
+int conv_enc0(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, hipStream_t s, float* ln_part,
+              int ln_cap, int* ln_nparts) {
+    if (ln_nparts) *ln_nparts = 0;
     PIVP_CHECK_ARG(img && w && bias && out && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0);
     const int H2 = H / 2, W2 = W / 2;
     const int total = B * H2 * W2;
@@ -127,7 +144,10 @@ int conv_enc0(const float* img, const float* w, const float* bias, float* out, i
         const int rows = 64 / W2, R = 2 * rows + 3, npatch = 3 * R * (W + 3);
         if (W + 3 <= 256 && R <= E0_PR * (256 / (W + 3))) {
             const size_t lds = sizeof(float) * (75 * 32 + npatch);
-            hipLaunchKernelGGL(conv_enc0_rows_kernel, dim3(B * (H2 / rows)), dim3(256), lds, s, img, w, bias, out, B, H, W);
+            const int np = H2 / rows;   // row tiles = LayerNorm partials per sample
+            float* lp = (ln_part && np <= ln_cap) ? ln_part : nullptr;
+            if (lp && ln_nparts) *ln_nparts = np;
+            hipLaunchKernelGGL(conv_enc0_rows_kernel, dim3(B * np), dim3(256), lds, s, img, w, bias, out, B, H, W, lp);
             return PIVP_LAUNCH_STATUS();
         }
     }
