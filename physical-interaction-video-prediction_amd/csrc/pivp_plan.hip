@@ -346,9 +346,16 @@ extern "C" int pivp_rollout_forward(pivp_plan_t* plan, const float* images, cons
     // loss (TM:737-759): frames ctx..T-1 vs gen[ctx-1..T-2]
     const int nf = T - ctx;
     float* lp = plan->ws + plan->o_losspart;
-    for (int i = 0; i < nf; ++i)
-        RC(frame_sqerr_partials(images + (size_t)(ctx + i) * fr, gen_images + (size_t)(ctx - 1 + i) * fr,
-                                lp + (size_t)i * plan->loss_nparts, (int)fr, s));
+    // target frames and predictions are contiguous over time: when a frame is a whole number of partial chunks, ONE launch over
+    // all nf frames leaves the partials in the same per-frame layout as nf launches would
+    const bool whole_chunks = loss_partials_count((int)fr + 1) == loss_partials_count((int)fr) + 1;   // fr divisible by the chunk
+    if (nf > 0 && (whole_chunks || nf == 1) && fr * nf < (1u << 30)) {
+        RC(frame_sqerr_partials(images + (size_t)ctx * fr, gen_images + (size_t)(ctx - 1) * fr, lp, (int)(fr * nf), s));
+    } else {
+        for (int i = 0; i < nf; ++i)
+            RC(frame_sqerr_partials(images + (size_t)(ctx + i) * fr, gen_images + (size_t)(ctx - 1 + i) * fr,
+                                    lp + (size_t)i * plan->loss_nparts, (int)fr, s));
+    }
     RC(loss_finalize(lp, plan->loss_nparts, nf, (int)fr, states + (size_t)ctx * B * 5, gen_states + (size_t)(ctx - 1) * B * 5,
                      B * 5, (float)(T - ctx), results, s));
     return PIVP_OK;
