@@ -148,7 +148,7 @@ def main():
             total_s = float(ms_tot.sum()) * 1e-3
             achieved = total_flops / total_s / 1e12
             roofline = {
-                'bound': 'mfma', 'kernel': 'convlstm_tile_kernel / igemm_f32_kernel<WM,WN,4,true> (ConvLSTM 5x5 gate conv + fused gates)',
+                'bound': 'mfma', 'kernel': 'igemm_f32_kernel<WM,WN,4,true> (ConvLSTM 5x5 gate conv + fused gates)',
                 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                 'traffic': _pmc_traffic(),

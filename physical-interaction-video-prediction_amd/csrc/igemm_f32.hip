@@ -153,8 +153,10 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
     }
     const int lds_wa = (prow * IG_P + cvec * 4);          // this thread's write slot inside the A / B tile (floats)
 
-    f32x4 ra[NA];
-    f32x4 rb[NB];
+    // two register sets: the tiles of chunk i+2 are loaded during chunk i and written to LDS during chunk i+1 (under load an
+    // L2 / MALL round trip is longer than one chunk: profiles/r01/NOTES.md)
+    f32x4 ras[2][NA];
+    f32x4 rbs[2][NB];
 
     // scalar state of the NEXT chunk to load: channel chunk l_cc of tap (l_ty, l_tx); no division, no branch
     int l_cc = 0, l_ty = ty_begin, l_tx = 0;
@@ -186,8 +188,10 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
         l_tx = w1 ? 0 : l_tx;
         l_ty += w1 ? 1 : 0;
     };
-    auto load_piece = [&](auto J) {        // piece j < NA: A-tile load j; NA <= j < NA+NB: B-tile load j-NA
+    auto load_piece = [&](auto SET, auto J) {        // piece j < NA: A-tile load j; NA <= j < NA+NB: B-tile load j-NA
         constexpr int j = decltype(J)::value;
+        f32x4 (&ra)[NA] = ras[decltype(SET)::value];
+        f32x4 (&rb)[NB] = rbs[decltype(SET)::value];
         if constexpr (j < NA) {
             const bool ok = (a_mask[j] & s_bit) != 0;
             unsigned off = ok ? (unsigned)((s_first ? a_off0[j] : a_off1[j]) + s_delta) : OOB;
@@ -200,8 +204,10 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
             rb[j - NA] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, b_goff[j - NA], s_wbase, 0));
         }
     };
-    auto store_piece = [&](auto J, int buf) {
+    auto store_piece = [&](auto SET, auto J, int buf) {
         constexpr int j = decltype(J)::value;
+        const f32x4 (&ra)[NA] = ras[decltype(SET)::value];
+        const f32x4 (&rb)[NB] = rbs[decltype(SET)::value];
         if constexpr (j < NA) {
             if (BM >= 32 * (j + 1)) *reinterpret_cast<f32x4*>(lds + buf * A_FLOATS + lds_wa + 32 * j * IG_P) = ra[j];
         } else if constexpr (j < NA + NB) {
@@ -238,13 +244,8 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
     // runs in a micro-step that carries no staging piece when there is one (step NST, for the chunk AFTER the one whose
     // loads follow); tiles that use all 8+8 staging steps keep it in front of the first load.
     constexpr int PRE = NST < 8 ? NST : 0;
-    // Barrier placement: BAR = 16 puts the block barrier at the chunk's end.  BAR = 12 (measured, profiles/r01/NOTES.md)
-    // moves it behind micro-step 11 -- all LDS reads of the chunk are issued by step 8 and the next tile is written in
-    // steps BAR-NST .. BAR-1 -- so the next chunk's first fragments are read under this chunk's last four micro-steps.
-    // It made no difference on any layer (the second resident block already covers that latency), so the simpler
-    // placement stays.
-    constexpr int BAR = 16;
-    static_assert(BAR - NST >= 4 && BAR >= 12, "loads need distance to their ds_writes; k-group 3 is read in step 8");
+    // (A barrier after micro-step 11 with the next chunk's first fragments read behind it was measured and made no
+    // difference on any layer: the barrier stays at the chunk's end.)
     f32x4 fa[2];
     f32x4 fb[2][TPW];
     auto read_frag0 = [&](int slot) {
@@ -252,22 +253,19 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
 #pragma unroll
         for (int t = 0; t < TPW; ++t) fb[0][t] = *reinterpret_cast<const f32x4*>(lds + slot * B_FLOATS + b_off[t]);
     };
-    auto chunk = [&](auto STAGE, int buf) {
-        constexpr bool stage = decltype(STAGE)::value && ABL != 1 && ABL != 3;
-        constexpr bool do_store = stage && ABL == 0;   // ABL 2, 4, 5: no LDS stores
+    // LOAD: this chunk issues the loads of chunk +2 into register set SET; STORE: it writes set SET^1 (chunk +1) to the other
+    // LDS buffer
+    auto chunk = [&](auto LOAD, auto STORE, auto SET, int buf) {
+        constexpr bool do_load = decltype(LOAD)::value && ABL != 1 && ABL != 3;
+        constexpr bool do_store = decltype(STORE)::value && ABL == 0;   // ABL 2, 4, 5: no LDS stores
+        using OTHER = std::integral_constant<int, decltype(SET)::value ^ 1>;
         const float* As = lds + buf * A_FLOATS + a_off;
         const float* Bs = lds + buf * B_FLOATS;
-        if constexpr (BAR == 16) {
-            read_frag0(buf);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        read_frag0(buf);
+        __builtin_amdgcn_sched_barrier(0);
         auto micro = [&](auto Q, auto S2) {
             constexpr int q = decltype(Q)::value, s2 = decltype(S2)::value, step = q * 4 + s2;
             constexpr int cur = q & 1, nxt = cur ^ 1;
-            if constexpr (decltype(STAGE)::value && BAR < 16 && step == BAR) {
-                if (ABL != 3) __syncthreads();
-                read_frag0(buf ^ 1);
-            }
             if constexpr (s2 == 0 && q < 3) {
                 fa[nxt] = *reinterpret_cast<const f32x4*>(As + 8 * (q + 1));
 #pragma unroll
@@ -276,9 +274,9 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
 #pragma unroll
             for (int t = 0; t < TPW; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s2], fb[cur][t][s2], acc[t], 0, 0, 0);
-            if constexpr (stage && step == PRE) stage_begin();
-            if constexpr (stage && step < NST) load_piece(std::integral_constant<int, step>{});
-            if constexpr (do_store && step >= BAR - NST && step < BAR) store_piece(std::integral_constant<int, step - (BAR - NST)>{}, buf ^ 1);
+            if constexpr (do_load && step == PRE) stage_begin();
+            if constexpr (do_load && step < NST) load_piece(SET, std::integral_constant<int, step>{});
+            if constexpr (do_store && step >= 16 - NST) store_piece(OTHER{}, std::integral_constant<int, step - (16 - NST)>{}, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto qgroup = [&](auto Q) {
@@ -288,32 +286,53 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
         qgroup(std::integral_constant<int, 0>{}); qgroup(std::integral_constant<int, 1>{});
         qgroup(std::integral_constant<int, 2>{}); qgroup(std::integral_constant<int, 3>{});
     };
-
-    // prologue: chunk 0 straight into buffer 0
-    if (nchunks > 0) {
-    stage_begin();
-    load_piece(std::integral_constant<int, 0>{}); load_piece(std::integral_constant<int, 1>{});
-    load_piece(std::integral_constant<int, 2>{}); load_piece(std::integral_constant<int, 3>{});
-    load_piece(std::integral_constant<int, 4>{}); load_piece(std::integral_constant<int, 5>{});
-    load_piece(std::integral_constant<int, 6>{}); load_piece(std::integral_constant<int, 7>{});
-    store_piece(std::integral_constant<int, 0>{}, 0); store_piece(std::integral_constant<int, 1>{}, 0);
-    store_piece(std::integral_constant<int, 2>{}, 0); store_piece(std::integral_constant<int, 3>{}, 0);
-    store_piece(std::integral_constant<int, 4>{}, 0); store_piece(std::integral_constant<int, 5>{}, 0);
-    store_piece(std::integral_constant<int, 6>{}, 0); store_piece(std::integral_constant<int, 7>{}, 0);
-    if constexpr (PRE > 0) stage_begin();   // parameters of chunk 1, loaded while chunk 0 is consumed
-    __syncthreads();
-    if constexpr (BAR < 16) read_frag0(0);
-    for (int it = 0; it + 1 < nchunks; ++it) {
-        chunk(std::true_type{}, it & 1);
-        if (ABL == 2 || ABL == 4) {   // keep the loaded registers alive without writing LDS
+    auto keep = [&]() {   // ABL 2 / 4: keep the loaded registers alive without writing LDS
+        if (ABL == 2 || ABL == 4) {
 #pragma unroll
-            for (int j = 0; j < NA; ++j) asm volatile("" :: "v"(ra[j]));
+            for (int jj = 0; jj < NA; ++jj) { asm volatile("" :: "v"(ras[0][jj])); asm volatile("" :: "v"(ras[1][jj])); }
 #pragma unroll
-            for (int j = 0; j < NB; ++j) asm volatile("" :: "v"(rb[j]));
+            for (int jj = 0; jj < NB; ++jj) { asm volatile("" :: "v"(rbs[0][jj])); asm volatile("" :: "v"(rbs[1][jj])); }
         }
-        if (BAR == 16 && ABL != 3) __syncthreads();
-    }
-    chunk(std::false_type{}, (nchunks - 1) & 1);
+    };
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+    auto load_all = [&](auto SET) {
+        load_piece(SET, std::integral_constant<int, 0>{}); load_piece(SET, std::integral_constant<int, 1>{});
+        load_piece(SET, std::integral_constant<int, 2>{}); load_piece(SET, std::integral_constant<int, 3>{});
+        load_piece(SET, std::integral_constant<int, 4>{}); load_piece(SET, std::integral_constant<int, 5>{});
+        load_piece(SET, std::integral_constant<int, 6>{}); load_piece(SET, std::integral_constant<int, 7>{});
+    };
+    auto store_all = [&](auto SET, int buf) {
+        store_piece(SET, std::integral_constant<int, 0>{}, buf); store_piece(SET, std::integral_constant<int, 1>{}, buf);
+        store_piece(SET, std::integral_constant<int, 2>{}, buf); store_piece(SET, std::integral_constant<int, 3>{}, buf);
+        store_piece(SET, std::integral_constant<int, 4>{}, buf); store_piece(SET, std::integral_constant<int, 5>{}, buf);
+        store_piece(SET, std::integral_constant<int, 6>{}, buf); store_piece(SET, std::integral_constant<int, 7>{}, buf);
+    };
+    auto sync = [&]() { keep(); if (ABL != 3) __syncthreads(); };
+
+    // prologue: chunk 0 straight into buffer 0, chunk 1 into register set 1
+    if (nchunks > 0) {
+        stage_begin(); load_all(S0{}); store_all(S0{}, 0);
+        if (nchunks > 1) { stage_begin(); load_all(S1{}); }
+        if constexpr (PRE > 0) stage_begin();   // parameters of chunk 2, loaded while chunk 0 is consumed
+        __syncthreads();
+        // two chunks per trip: the register sets alternate statically (a run-time parity branch makes hipcc wait vmcnt(0) in
+        // front of every ds_write); `it` stays even
+        int it = 0;
+        for (; it + 3 < nchunks; it += 2) {
+            chunk(std::true_type{}, std::true_type{}, S0{}, 0); sync();
+            chunk(std::true_type{}, std::true_type{}, S1{}, 1); sync();
+        }
+        const int rest = nchunks - it;             // 1, 2 or 3 chunks left
+        if (rest == 3) {
+            chunk(std::true_type{}, std::true_type{}, S0{}, 0); sync();
+            chunk(std::false_type{}, std::true_type{}, S1{}, 1); sync();
+            chunk(std::false_type{}, std::false_type{}, S0{}, 0);
+        } else if (rest == 2) {
+            chunk(std::false_type{}, std::true_type{}, S0{}, 0); sync();
+            chunk(std::false_type{}, std::false_type{}, S0{}, 1);
+        } else {
+            chunk(std::false_type{}, std::false_type{}, S0{}, 0);
+        }
     }
 
     // ---- epilogue --------------------------------------------------------------------------
@@ -486,14 +505,7 @@ int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant, int* ln_npar
         return launch_igemm<1, 4, 4, true, 3>(d, stream, 1, ln_nparts);
     }
 #endif
-    if (variant == 7 || variant == 8) {   // the spatial-tile kernel (32 / 16 channels per block) where the shape allows, else
-        if (convlstm_tile_ok(d)) return convlstm_tile(d, stream, ln_nparts, variant == 7 ? 32 : 16);   // the automatic gather tile
-        variant = 0;
-    }
     if (variant == 0) {
-        static const int tile_mode = [] { const char* e = getenv("PIVP_LSTM_TILE"); return e ? atoi(e) : 1; }();   // tuning
-        if (tile_mode && convlstm_tile_ok(d) && (long)d.B * (d.Hin / 4) * (d.Win / 16) * (d.C / 16) >= 256)
-            return convlstm_tile(d, stream, ln_nparts);
         // measured at B = 32 (scripts/bench_lstm_layers.py): two resident blocks per CU beat one larger tile,
         // so take BM = 128 only when it still leaves >= 2 blocks per CU, BM = 64 while that fills the chip
         const long nb = d.C / 32;

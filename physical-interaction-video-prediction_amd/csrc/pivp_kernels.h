@@ -58,9 +58,6 @@ int repack_transpose(const float* w, float* wt, int taps, int cin, int N, int fl
 int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant = 0, int* ln_nparts = nullptr);  // 0 auto, 1: 4x1 waves, 2: 2x2, 3: 1x4
 int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr);
 int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr);
-// ConvLSTM with the input patch staged once per channel chunk for all 25 taps (csrc/convlstm_tile.hip)
-bool convlstm_tile_ok(const IgemmDesc& d);
-int convlstm_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr, int nch = 0);   // nch: channels per block, 0 = auto   // 32 x 32 tiles, K split over the waves (csrc/igemm_small.hip)
 
 // enc0: 5x5 stride-2 pad-2 conv on a planar 3-channel frame -> NHWC 32 channels (TM:500)
 // ln_part (optional): the launch also writes *ln_nparts LayerNorm partials per sample of its output (0 = not supported for the shape)

@@ -43,11 +43,11 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     write_summary(os.path.join(out_dir, 'pmc_fetch_size_summary.csv'), fe, 'avg_FETCH_SIZE_KB')
     write_summary(os.path.join(out_dir, 'pmc_write_size_summary.csv'), wr, 'avg_WRITE_SIZE_KB')
-    is_lstm = lambda k: ('igemm_f32_kernel' in k and 'true' in k) or 'convlstm_tile_kernel' in k
+    is_lstm = lambda k: 'igemm_f32_kernel' in k and 'true' in k
     nf = sum(n for k, (n, v) in fe.items() if is_lstm(k)); f_kb = sum(n * v for k, (n, v) in fe.items() if is_lstm(k)) / max(nf, 1)
     nw = sum(n for k, (n, v) in wr.items() if is_lstm(k)); w_kb = sum(n * v for k, (n, v) in wr.items() if is_lstm(k)) / max(nw, 1)
     out = {
-        'kernel': 'convlstm_tile_kernel + igemm_f32_kernel<*,*,4,true> (ConvLSTM)',
+        'kernel': 'igemm_f32_kernel<*,*,4,true> (ConvLSTM)',
         'workload': workload,
         'launches': nf,
         'fetch_size_KB_raw': f_kb,

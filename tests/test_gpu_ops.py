@@ -26,7 +26,7 @@ def _lstm_ref(x, h, c, W, b):
     return np.tanh(cn) * R.sigmoid(o), cn
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize('B,cx,C,H', [(2, 32, 32, 32), (2, 32, 64, 16), (3, 64, 128, 8), (2, 128, 64, 16), (1, 96, 32, 32), (5, 64, 64, 16)])
 def test_convlstm_parity(ops, B, cx, C, H, variant):
     rs = np.random.RandomState(B * 100 + C)
