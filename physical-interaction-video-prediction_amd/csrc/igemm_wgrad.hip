@@ -344,20 +344,23 @@ __global__ __launch_bounds__(256, 1) void wgrad5x5_kernel(const WgradDesc d) {
         }
     }
     // ---- block reduction of the 4 workers + transposed atomics -------------------------------------------------
-    // LDS image of one worker's result: [tap kx][tile t][n 0..31][ci 0..31]  (NACC * 1024 floats = 20/40 KB)
+    // LDS image of one worker's result: [tap kx][tile t][n 0..31][ci 0..31 (+1 pad)].  The n rows are 33 floats apart: with a
+    // 32-float pitch the 32 lanes of an accumulator register (same ci, n = lane) hit one bank, a 32-way conflict on every one of the
+    // 160 stores and loads of each pass.
     __syncthreads();                               // every wave is done with its staging buffers
-    constexpr int IMG = NACC * 1024;
+    constexpr int IT = 32 * 33;                    // floats per 32 x 32 tile image
+    constexpr int IMG = NACC * IT;
     auto put = [&](float* img) {
 #pragma unroll
         for (int t = 0; t < NACC; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) img[t * 1024 + l31 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = acc[t][r];
+            for (int r = 0; r < 16; ++r) img[t * IT + l31 * 33 + (r & 3) + 8 * (r >> 2) + 4 * half] = acc[t][r];
     };
     auto add = [&](const float* img) {
 #pragma unroll
         for (int t = 0; t < NACC; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] += img[t * 1024 + l31 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+            for (int r = 0; r < 16; ++r) acc[t][r] += img[t * IT + l31 * 33 + (r & 3) + 8 * (r >> 2) + 4 * half];
     };
     if (wave >= 2) put(sm + (wave - 2) * IMG);
     __syncthreads();
@@ -370,12 +373,12 @@ __global__ __launch_bounds__(256, 1) void wgrad5x5_kernel(const WgradDesc d) {
     if (wave == 0) put(sm);
     __syncthreads();
     // packed gradient [tap][wcin/32][N][32]: for tap (ky,kx), tile t: rows n0 + t*32 + n, 32 contiguous ci each
-    for (int i = tid; i < IMG; i += 256) {
+    for (int i = tid; i < NACC * 1024; i += 256) {
         const int t = i >> 10, rem = i & 1023, n = rem >> 5, ci = rem & 31;
         const int kx = t / NTW, tt = t - kx * NTW;
         const int tap = ky * 5 + kx;
         float* g = d.dw + (((size_t)tap * (d.wcin >> 5) + cb) * d.N + n0 + tt * 32 + n) * 32 + ci;
-        atomicAdd(g, sm[i]);
+        atomicAdd(g, sm[t * IT + n * 33 + ci]);
     }
     // bias gradient for free: the kernel-row 0 / channel-block 0 blocks have every dY pixel of their chunks in LDS... not kept; see bias_grad
 }
@@ -384,7 +387,7 @@ template <int NTW, int SW>
 static int launch_wgrad5x5(const WgradDesc& d, hipStream_t s) {
     constexpr int R = 32 / SW, SP = R * (SW + 4);
     constexpr int WBUF = SP * 32 + 32 * 32 * NTW;
-    constexpr int IMG = 5 * NTW * 1024;
+    constexpr int IMG = 5 * NTW * 32 * 33;
     constexpr int lds_floats = (4 * 2 * WBUF > 2 * IMG) ? 4 * 2 * WBUF : 2 * IMG;
     constexpr int lds_bytes = lds_floats * 4;
     static bool attr_set = false;
