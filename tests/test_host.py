@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -138,3 +139,12 @@ def test_product_path_does_not_import_the_oracle():
         if fn.endswith('.py'):
             src = open(os.path.join(pkg, fn)).read()
             assert 'oracle' not in src.replace('no oracle', ''), fn
+
+
+def test_graft_entry_build_in_a_fresh_interpreter():
+    # the driver calls build() from its own process: no module this suite happens to import may be relied on
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', 'import __graft_entry__ as g; g.build(); print("ok")'], cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-2000:]
