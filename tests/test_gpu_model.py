@@ -180,3 +180,15 @@ def test_frame_size_128_generalisation(pivp):
     m, loss, gen = _run(pivp, 'CDNA', 10, imgs, acts, stas, P)
     assert R.per_pixel_l2(gen, np.stack(ref.gen_images)).max() < GATE
     assert m.count_params() == 18059519
+
+
+@pytest.mark.parametrize('mt,nm', [('CDNA', 4), ('CDNA', 2), ('STP', 3)])
+def test_other_mask_counts(pivp, mt, nm):
+    # num_masks is a constructor argument of the reference (TM:484); the flat softmax groups are then nm+1 wide
+    P = R.init_params(seed=3, dtype=np.float32, scale=1.0, num_masks=nm, model_type=mt)
+    imgs, acts, stas = R.synthetic_batch(3, 4)
+    ref = R.Model(nm, params=P, dtype=np.float64, prefix='x', is_cdna=mt == 'CDNA', is_stp=mt == 'STP'); ref.train = False
+    ref([imgs, acts, stas], 0)
+    m, loss, gen = _run(pivp, mt, nm, imgs, acts, stas, P)
+    assert R.per_pixel_l2(gen, np.stack(ref.gen_images)).max() < (GATE_STP_WHITE_NOISE if mt == 'STP' else GATE)
+    assert abs(loss - float(ref.loss)) < 1e-5
