@@ -158,3 +158,16 @@ def test_bptt_gradients_dna(pivp):
     assert abs(loss - loss_ref) < 1e-6
     worst = _check_grads(m.grads_reference(), gref, 5e-3)
     print('DNA worst relative gradient error', worst)
+
+
+def test_bptt_gradients_cdna_four_masks(pivp):
+    # num_masks = 4: softmax groups of 5, 3 live kernels + the dropped one (TM:726)
+    P = R.init_params(seed=2, dtype=np.float64, scale=1.0, num_masks=4)
+    imgs, acts, stas = R.synthetic_batch(2, 3)
+    loss_ref, gref = _autograd(P, imgs, acts, stas, num_masks=4)
+    m = pivp.Model(4, prefix='t', keep_activations=True)
+    m.load_state_dict_reference(P)
+    loss = float(m([imgs, acts, stas], 0))
+    m.cleargrads(); m.backward()
+    assert abs(loss - loss_ref) < 1e-6
+    _check_grads(m.grads_reference(), gref, 2e-3)
