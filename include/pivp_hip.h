@@ -29,7 +29,7 @@ extern "C" {
 #define PIVP_MODEL_STP 1
 #define PIVP_MODEL_DNA 2
 
-int pivp_abi_version(void);
+int pivp_abi_version(void);   /* 3 (2: + training entry points, 3: + pivp_convlstm_ln) */
 
 /* ------------------------------------------------------------------------------------------
  * Plan = Model.__init__ (TM:484-602): layer table, op program, variant head.
