@@ -10,9 +10,11 @@ namespace pivp {
 // variant's activation (CDNA TM:315-317, STP TM:454-455, DNA TM:387-388) in ONE pass over enc6.
 // e6 NHWC [B][HW][64]; wm [64][NP], we [64][NE] (the reference's deconv (Cin,Cout,1,1) layout);
 // outputs planar [B][planes][HW] because the mask softmax is defined on the NCHW-flat order.
-// Each 256-thread block stages 64-pixel sub-tiles through LDS with coalesced 16-B loads; wave w
-// computes outputs w, w+4, ... for all 64 pixels (lane = pixel); an output's 64 weights are read
-// from LDS as 16 wave-uniform ds_read_b128.
+// Each WAVE owns 64 consecutive pixels: it loads its 64 x 64 tile with coalesced 16-B loads (1 KB per instruction), applies
+// the optional LayerNorm, passes the tile through its private LDS region to turn "lane = 4 channels of a pixel" into "lane =
+// pixel", and computes all outputs for its pixels; an output's 64 weights are 16 wave-uniform ds_read_b128.  No block
+// barrier after the weight table is in place (the first version had the four waves share each sub-tile, two barriers and one
+// load round trip per sub-tile: 1.5 TB/s).
 // Optional fused input stage: with ln_part != null, e6 is the RAW enc6 output and
 // relu(LayerNorm(e6)) (norm_enc6, TM:601; statistics from the enc6 kernel's (count, mean, M2)
 // partials, gamma/beta NHWC-flat) is applied while the tile is staged, so the normalised map is
@@ -29,10 +31,9 @@ __global__ __launch_bounds__(256) void heads_1x1_kernel(const float* __restrict_
                                                         const float* __restrict__ ln_part, int ln_nparts,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                         float* __restrict__ y_out, float* __restrict__ stat_out) {
-    __shared__ __attribute__((aligned(16))) float xt[64 * HD_XP];
+    __shared__ __attribute__((aligned(16))) float xt[4][64 * HD_XP];     // one tile per wave
     __shared__ __attribute__((aligned(16))) float wl[HD_MAXOUT * 64];   // [output][k]
     __shared__ float bl[HD_MAXOUT];
-    __shared__ float stat[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NO = NP + NE;
     for (int i = tid; i < 64 * NO; i += 256) {
@@ -40,73 +41,73 @@ __global__ __launch_bounds__(256) void heads_1x1_kernel(const float* __restrict_
         wl[o * 64 + k] = o < NP ? wm[k * NP + o] : we[k * NE + (o - NP)];
     }
     if (tid < NO) bl[tid] = tid < NP ? bm[tid] : be[tid - NP];
-    int b_stat = -1;
-    for (int sub = 0; sub < 4; ++sub) {
-        const int px0 = (blockIdx.x * 4 + sub) * 64;
-        if (px0 >= total_px) break;
-        __syncthreads();
-        float mean = 0.f, rstd = 1.f;
-        if (ln_part) {   // sub-tiles never straddle samples (HW % 64 == 0, checked by the launcher)
-            const int bs = px0 / HW;
-            if (bs != b_stat) {
-                if (wave == 0) {
-                    float mu, rs;
-                    ln_merge_partials(ln_part, bs, ln_nparts, eps, mu, rs);
-                    if (lane == 0) {
-                        stat[0] = mu; stat[1] = rs;
-                        if (stat_out && px0 == bs * HW) { stat_out[bs * 2] = mu; stat_out[bs * 2 + 1] = rs; }
-                    }
-                }
-                __syncthreads();
-                b_stat = bs;
-            }
-            mean = stat[0]; rstd = stat[1];
-        }
+    const int px0 = (blockIdx.x * 4 + wave) * 64;     // this wave's pixels
+    // the tile's loads go out before the barrier that publishes the weight table
+    f32x4 rx[16];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = tid + 256 * j;       // float4 index within the 64x64 tile
-            const int p = f >> 4, cv = (f & 15) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (px0 + p < total_px) {
-                v = *reinterpret_cast<const f32x4*>(e6 + (size_t)(px0 + p) * 64 + cv);
-                if (ln_part) {
-                    const size_t gi = (size_t)(px0 + p - b_stat * HW) * 64 + cv;
-                    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + gi);
-                    const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + gi);
+    for (int j = 0; j < 16; ++j) {
+        const int f = lane + 64 * j, p = f >> 4, cv = (f & 15) * 4;
+        rx[j] = *reinterpret_cast<const f32x4*>(e6 + (size_t)min(px0 + p, total_px - 1) * 64 + cv);   // clamped: rows past the end are never stored
+    }
+    if (ln_part && px0 < total_px) {   // a wave's 64 pixels never straddle samples (HW % 64 == 0, checked by the launcher)
+        const int bs = px0 / HW;
+        float mean, rstd;
+        ln_merge_partials(ln_part, bs, ln_nparts, eps, mean, rstd);
+        if (lane == 0 && stat_out && px0 == bs * HW) { stat_out[bs * 2] = mean; stat_out[bs * 2 + 1] = rstd; }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf((v[e] - mean) * rstd * g[e] + bb[e], 0.f);
-                    if (y_out) *reinterpret_cast<f32x4*>(y_out + (size_t)(px0 + p) * 64 + cv) = v;
-                }
+        for (int j4 = 0; j4 < 16; j4 += 4) {          // gamma / beta in batches of four rows: 8 more loads in flight
+            f32x4 g[4], bb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = lane + 64 * (j4 + u), p = f >> 4, cv = (f & 15) * 4;
+                const size_t gi = (size_t)(min(px0 + p, total_px - 1) - bs * HW) * 64 + cv;
+                g[u] = *reinterpret_cast<const f32x4*>(gamma + gi);
+                bb[u] = *reinterpret_cast<const f32x4*>(beta + gi);
             }
-            *reinterpret_cast<f32x4*>(xt + p * HD_XP + cv) = v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = lane + 64 * (j4 + u), p = f >> 4, cv = (f & 15) * 4;
+                f32x4 v = rx[j4 + u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf((v[e] - mean) * rstd * g[u][e] + bb[u][e], 0.f);
+                if (y_out && px0 + p < total_px) *reinterpret_cast<f32x4*>(y_out + (size_t)(px0 + p) * 64 + cv) = v;
+                rx[j4 + u] = v;
+            }
         }
-        __syncthreads();
-        float xr[64];
+    }
+    float* mt = xt[wave];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int f = lane + 64 * j, p = f >> 4, cv = (f & 15) * 4;
+        *reinterpret_cast<f32x4*>(mt + p * HD_XP + cv) = rx[j];
+    }
+    __syncthreads();                                  // weight table ready (and, within the wave, its tile)
+    if (px0 >= total_px) return;
+    float xr[64];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(mt + lane * HD_XP + q * 4);
+        xr[q * 4] = v[0]; xr[q * 4 + 1] = v[1]; xr[q * 4 + 2] = v[2]; xr[q * 4 + 3] = v[3];
+    }
+    const int px = px0 + lane;
+    const int b = px / HW, p = px - b * HW;
+    for (int o = 0; o < NO; ++o) {
+        float acc = bl[o];
+        const float* wo = wl + o * 64;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xt + lane * HD_XP + q * 4);
-            xr[q * 4] = v[0]; xr[q * 4 + 1] = v[1]; xr[q * 4 + 2] = v[2]; xr[q * 4 + 3] = v[3];
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wo + q * 4);
+            acc = fmaf(xr[q * 4], w4[0], acc); acc = fmaf(xr[q * 4 + 1], w4[1], acc);
+            acc = fmaf(xr[q * 4 + 2], w4[2], acc); acc = fmaf(xr[q * 4 + 3], w4[3], acc);
         }
-        const int px = px0 + lane;
-        const int b = px / HW, p = px - b * HW;
-        for (int o = wave; o < NO; o += 4) {
-            float acc = bl[o];
-            const float* wo = wl + o * 64;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wo + q * 4);
-                acc = fmaf(xr[q * 4], w4[0], acc); acc = fmaf(xr[q * 4 + 1], w4[1], acc);
-                acc = fmaf(xr[q * 4 + 2], w4[2], acc); acc = fmaf(xr[q * 4 + 3], w4[3], acc);
-            }
-            if (px < total_px) {
-                if (o < NP) {
-                    mask_logits[((size_t)b * NP + o) * HW + p] = fmaxf(acc, 0.f);
-                } else {
-                    const int oe = o - NP;
-                    if (mode != 1) acc = fmaxf(acc, 0.f);
-                    enc7[((size_t)b * NE + oe) * HW + p] = acc;
-                    if (mode != 2) layer0[((size_t)b * NE + oe) * HW + p] = sigmoidf_(acc);
-                }
+        if (px < total_px) {
+            if (o < NP) {
+                mask_logits[((size_t)b * NP + o) * HW + p] = fmaxf(acc, 0.f);
+            } else {
+                const int oe = o - NP;
+                if (mode != 1) acc = fmaxf(acc, 0.f);
+                enc7[((size_t)b * NE + oe) * HW + p] = acc;
+                if (mode != 2) layer0[((size_t)b * NE + oe) * HW + p] = sigmoidf_(acc);
             }
         }
     }
