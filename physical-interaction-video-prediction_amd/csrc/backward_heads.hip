@@ -789,14 +789,30 @@ __global__ __launch_bounds__(256) void enc3_state_bwd_kernel(const float* __rest
     const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     if (tid < 5) sa[tid] = action[b * 5 + tid]; else if (tid < 10) sa[tid] = state[b * 5 + tid - 5];
     if (tid < 10) dsa[tid] = 0.f;
-    for (int i = tid; i < 64 * 64; i += 256) wl[i] = w3[i];
     const int npx = min(64, HW8 - tile * 64);
     const size_t base = ((size_t)b * HW8 + tile * 64) * 64;
-    for (int i = tid; i < 64 * 64; i += 256) {
-        const int p = i >> 6, k = i & 63;
-        const bool ok = p < npx;
-        xt[p * 65 + k] = ok ? e2[base + i] : 0.f;
-        dt[p * 65 + k] = (ok && e3[base + i] > 0.f) ? de3[((size_t)b * HW8 + tile * 64 + p) * ldd3 + k] : 0.f;
+    {   // sixteen independent 16-B loads per thread, then the LDS stores (the element loops made ~48 serial round trips)
+        f32x4 tw[4], tx[4], ty[4], td[4];
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = (tid + 256 * j) * 4, pp = f >> 6, k = f & 63;
+            const bool ok = pp < npx;
+            tw[j] = *reinterpret_cast<const f32x4*>(w3 + f);
+            tx[j] = ok ? *reinterpret_cast<const f32x4*>(e2 + base + f) : z4;
+            ty[j] = ok ? *reinterpret_cast<const f32x4*>(e3 + base + f) : z4;
+            td[j] = ok ? *reinterpret_cast<const f32x4*>(de3 + ((size_t)b * HW8 + tile * 64 + pp) * ldd3 + k) : z4;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = (tid + 256 * j) * 4, pp = f >> 6, k = f & 63;
+            *reinterpret_cast<f32x4*>(wl + f) = tw[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xt[pp * 65 + k + e] = tx[j][e];
+                dt[pp * 65 + k + e] = ty[j][e] > 0.f ? td[j][e] : 0.f;
+            }
+        }
     }
     __syncthreads();
     if (tid < 64) {
