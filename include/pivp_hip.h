@@ -29,7 +29,7 @@ extern "C" {
 #define PIVP_MODEL_STP 1
 #define PIVP_MODEL_DNA 2
 
-int pivp_abi_version(void);   /* 3 (2: + training entry points, 3: + pivp_convlstm_ln) */
+int pivp_abi_version(void);   /* 4 (2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback) */
 
 /* ------------------------------------------------------------------------------------------
  * Plan = Model.__init__ (TM:484-602): layer table, op program, variant head.
@@ -83,6 +83,19 @@ int pivp_rollout_forward(pivp_plan_t* plan, const float* images, const float* ac
  * (Chainer: model.cleargrads()).  Frames fed by scheduled sampling are detached as in the reference (TM:669-670);
  * in feed-self mode the gradient flows through the generated frames.  CDNA variant only in this round. */
 int pivp_plan_set_grad(pivp_plan_t* plan, int idx, float* dptr);
+/* Overlapping the data-parallel gradient all-reduce with the backward sweep.  Every parameter is shared by all timesteps, so a
+ * gradient is only final once the sweep has passed its layer at t = 0; the layers finish in reverse program order, in
+ * PIVP_GRAD_GROUPS groups: 0 heads + motion-parameter head + norm_enc6 + enc6, 1 hidden7 + lstm7, 2 enc5 + hidden6 + lstm6,
+ * 3 enc4 + hidden5 + lstm5, 4 enc3 + current_state + enc2 + hidden4/3 + lstm4/3, 5 enc1 + hidden2/1 + lstm2/1 + norm_enc0 + enc0.
+ * pivp_param_group tells the host which group a parameter belongs to (so it can lay the flat gradient buffer out group by
+ * group); the callback is invoked on the calling thread from inside pivp_rollout_backward right after the last kernel that
+ * touches group g has been ENQUEUED on the stream (the host makes its communication stream wait on an event it records
+ * there).  cb = NULL removes it. */
+#define PIVP_GRAD_GROUPS 6
+typedef void (*pivp_grad_group_cb)(void* user, int group);
+int pivp_param_group(const pivp_plan_t* plan, int idx);
+int pivp_param_group_by_name(const char* name);            /* same mapping, from the checkpoint key alone */
+int pivp_plan_set_grad_callback(pivp_plan_t* plan, pivp_grad_group_cb cb, void* user);
 int pivp_rollout_backward(pivp_plan_t* plan, const float* images, const float* actions, const float* states,
                           const unsigned char* gt_select, const float* gen_images, const float* gen_states, void* stream);
 

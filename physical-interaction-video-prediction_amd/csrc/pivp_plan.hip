@@ -16,7 +16,19 @@ const LstmSpec kLstm[7] = {
     {"lstm1", 32, 32, 2}, {"lstm2", 32, 32, 2}, {"lstm3", 32, 64, 4}, {"lstm4", 64, 64, 4},
     {"lstm5", 64, 128, 8}, {"lstm6", 128, 64, 4}, {"lstm7", 96, 32, 2}};
 
-struct ParamInfo { std::string name; long long numel; const float* ptr; float* grad; };
+struct ParamInfo { std::string name; long long numel; const float* ptr; float* grad; int group; };
+
+// group of a parameter = position of its layer in the backward sweep of one timestep (include/pivp_hip.h, PIVP_GRAD_GROUPS)
+static int grad_group_of(const std::string& n) {
+    auto starts = [&](const char* p) { return n.rfind(p, 0) == 0; };
+    if (starts("masks/") || starts("model/") || starts("norm_enc6/") || starts("enc6/")) return 0;
+    if (starts("hidden7/") || starts("lstm7/")) return 1;
+    if (starts("enc5/") || starts("hidden6/") || starts("lstm6/")) return 2;
+    if (starts("enc4/") || starts("hidden5/") || starts("lstm5/")) return 3;
+    if (starts("enc3/") || starts("current_state/") || starts("enc2/") || starts("hidden4/") || starts("lstm4/") ||
+        starts("hidden3/") || starts("lstm3/")) return 4;
+    return 5;   // enc1, hidden2, lstm2, hidden1, lstm1, norm_enc0, enc0
+}
 
 // Per-timestep activations (offsets in floats from the workspace base).  Two rolling slabs for inference, T-1 slabs
 // when keep_activations (BPTT needs every step).
@@ -60,6 +72,7 @@ struct pivp_plan {
     Grads g;
     bool has_grads;
     size_t o_zero, o_lnpart, o_linpart, o_masks, o_losspart;
+    pivp_grad_group_cb grad_cb = nullptr; void* grad_cb_user = nullptr;   // gradient-group-final notifications (t = 0 sweep)
     int loss_nparts;
     int last_steps;
     bool last_sched;                  // last forward used scheduled sampling (frames detached, TM:669-670)
@@ -90,7 +103,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
     p->K5 = 128 * p->H8 * p->W8;
     p->ws = nullptr; p->ws_floats = 0; p->last_steps = 0; p->last_sched = false;
 
-    auto add = [&](const std::string& name, long long n) { p->params.push_back({name, n, nullptr, nullptr}); return (int)p->params.size() - 1; };
+    auto add = [&](const std::string& name, long long n) { p->params.push_back({name, n, nullptr, nullptr, grad_group_of(name)}); return (int)p->params.size() - 1; };
     const int cin3 = 64 + (cfg->use_state ? 10 : 0);
     const long long encw[7] = {75 * 32, 9 * 32 * 32, 9 * 64 * 64, (long long)cin3 * 64, 9 * 128 * 128, 9 * 96 * 96, 9 * 64 * 64};
     const int encb[7] = {32, 32, 64, 64, 128, 96, 64};
@@ -196,6 +209,16 @@ extern "C" long long pivp_param_numel(const pivp_plan_t* plan, int idx) {
 extern "C" int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr) {
     if (!plan || idx < 0 || idx >= (int)plan->params.size() || !dptr) return PIVP_ERR_BADARG;
     plan->params[idx].ptr = dptr;
+    return PIVP_OK;
+}
+extern "C" int pivp_param_group(const pivp_plan_t* plan, int idx) {
+    if (!plan || idx < 0 || idx >= (int)plan->params.size()) return PIVP_ERR_BADARG;
+    return plan->params[idx].group;
+}
+extern "C" int pivp_param_group_by_name(const char* name) { return name ? grad_group_of(name) : PIVP_ERR_BADARG; }
+extern "C" int pivp_plan_set_grad_callback(pivp_plan_t* plan, pivp_grad_group_cb cb, void* user) {
+    if (!plan) return PIVP_ERR_BADARG;
+    plan->grad_cb = cb; plan->grad_cb_user = user;
     return PIVP_OK;
 }
 extern "C" int pivp_plan_set_grad(pivp_plan_t* plan, int idx, float* dptr) {
@@ -422,18 +445,23 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         if (hipMemsetAsync(ws + g.cat7, 0, (size_t)px2 * 64 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
         if (hipMemsetAsync(ws + g.n5, 0, (size_t)px8 * 128 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     }
+    auto done = [&](int group) { if (t == 0 && p->grad_cb) p->grad_cb(p->grad_cb_user, group); };   // t = 0: the sweep's final timestep
+    done(0);
     RC(lnb(7, ws + g.cat7, 64, nullptr, 0, ws + S.h[6], ws + g.hln[6], n2, 32, 0));
     RC(lstmb(6, ws + S.e5, 96, p->H2, p->W2));
+    done(1);
     // group 5 (TM:600): d e5 = x-part of lstm7's d_in (ReLU fused in enc5) <- enc5 deconv <- [hidden6 | enc1]
     RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ws + S.e5, 96, ws + g.wt_enc[5], ws + g.cat6, 96, 0,
                          G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1));
     RC(lnb(6, ws + g.cat6, 96, nullptr, 0, ws + S.h[5], ws + g.hln[5], n4, 64, 0));
     RC(lstmb(5, ws + S.e4, 128, p->H4, p->W4));
+    done(2);
     // group 4 (TM:599): d e4 = x-part of lstm6's d_in <- enc4 deconv <- hidden5 (also read by the CDNA kernel generator)
     RC(run_conv_backward(1, ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), ws + g.din[5][par], 128, 192, ws + S.e4, 128, ws + g.wt_enc[4], ws + g.n5, 128, 1,
                          G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s, 1));
     RC(lnb(5, ws + g.n5, 128, nullptr, 0, ws + S.h[4], ws + g.hln[4], n8, 128, 0));
     RC(lstmb(4, ws + S.e3, 64, p->H8, p->W8));
+    done(3);
     // group 3 (TM:598) + state predictor (TM:730): d e3 = x-part of lstm5's d_in (ld 192)
     RC(enc3_state_bwd(ws + S.e2, ws + S.e3, ws + g.din[4][par], 192, action, state_prev, P(p, p->i_enc_w[3]), P(p, p->i_cs_w),
                       ws + g.dstate + (size_t)t * B * 5, ws + g.e2, G(p, p->i_enc_w[3]), G(p, p->i_enc_b[3]), G(p, p->i_cs_w),
@@ -446,6 +474,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(lstmb(3, ws + S.n3, 64, p->H4, p->W4));
     RC(lnb(3, ws + g.din[3][par], 128, nullptr, 0, ws + S.h[2], ws + g.hln[2], n4, 64, 0));
     RC(lstmb(2, ws + S.cat6 + 64, 96, p->H4, p->W4));
+    done(4);
     RC(add_strided(ws + g.cat6 + 64, 96, ws + g.din[2][par], 96, 32, px4, s));          // d enc1: from enc5's concat + from lstm3
     // group 1 (TM:596): enc1 conv (ReLU) <- hidden2 <- lstm2 <- hidden1 <- lstm1 <- enc0
     RC(run_conv_backward(0, ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), ws + g.cat6 + 64, 32, 96, ws + S.cat6 + 64, 96, ws + g.wt_enc[1], ws + g.n2, 32, 0,
@@ -459,6 +488,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(lnb(0, ws + g.cat7 + 32, 64, ws + S.cat7 + 32, 64, ws + S.e0raw, ws + g.e0raw, n2, 32, 1));
     RC(enc0_bwd(prev, P(p, p->i_enc_w[0]), ws + g.e0raw, G(p, p->i_enc_w[0]), G(p, p->i_enc_b[0]), prev_has_grad ? go_prev : nullptr, 1,
                 B, H, W, s));
+    done(5);
     return PIVP_OK;
 }
 

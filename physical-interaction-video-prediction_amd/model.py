@@ -207,10 +207,21 @@ class Model(object):
             if tuple(a.shape) != tuple(shape):
                 raise ValueError('%s: expected shape %s, got %s' % (key, shape, a.shape))
             host[key] = ckpt.to_internal(key, a)
+        # Flat layout: the parameters (and so their gradients) are laid out in the order in which the backward sweep finishes
+        # them at t = 0 (pivp_param_group: 6 groups, heads first, enc0 last), so that each group is ONE contiguous slice the
+        # data-parallel all-reduce can send while the sweep is still working on the next group.
+        lib = _lib.load()                                       # host-only query: works without a GPU
+        group = {key: int(lib.pivp_param_group_by_name(key.encode())) for key in host}
+        order = sorted(host, key=lambda k: group[k])            # stable: checkpoint order inside a group
         offsets, off = OrderedDict(), 0
-        for key, v in host.items():
-            offsets[key] = (off, v.size)
-            off += (v.size + 63) // 64 * 64
+        bounds = []
+        for key in order:
+            if not bounds or bounds[-1][0] != group[key]:
+                bounds.append([group[key], off, off])
+            offsets[key] = (off, host[key].size)
+            off += (host[key].size + 63) // 64 * 64
+            bounds[-1][2] = off
+        self._group_ranges = [(a, b) for _, a, b in bounds]     # [(start, end)] floats, one per gradient group in sweep order
         flat = np.zeros(off, np.float32)
         for key, v in host.items():
             o, n = offsets[key]
@@ -372,9 +383,19 @@ class Model(object):
             raise RuntimeError('call the model first (parameters are lazily sized)')
         self._ensure_grads().zero_()
 
-    def backward(self):
+    def grad_group_ranges(self):
+        """[(start, end)] slices of `_flat_grads`, in the order the backward sweep completes them (include/pivp_hip.h)."""
+        if self._offsets is None:
+            raise RuntimeError('call the model first (parameters are lazily sized)')
+        return list(self._group_ranges)
+
+    def backward(self, on_group=None):
         """Back-propagate the loss of the LAST call through time (needs keep_activations=True).  Gradients
-        accumulate into `model._flat_grads` (internal layouts); `grads_reference()` returns them in checkpoint layout."""
+        accumulate into `model._flat_grads` (internal layouts); `grads_reference()` returns them in checkpoint layout.
+
+        on_group(i): optional host callback, invoked from inside the sweep as soon as every kernel that contributes to
+        gradient group i (slice grad_group_ranges()[i]) has been enqueued on the model's stream -- the hook the
+        data-parallel all-reduce uses to overlap communication with the rest of the sweep."""
         plan = self._active
         if plan is None or self._results is None:
             raise RuntimeError('call the model first')
@@ -383,9 +404,27 @@ class Model(object):
         self._ensure_grads()
         images, actions, states = self._inputs
         gt_ptr = self._gt_mask.data_ptr() if self._gt_mask is not None else None
-        _lib.check(plan.lib.pivp_rollout_backward(plan.h, images.data_ptr(), actions.data_ptr(), states.data_ptr(), gt_ptr,
-                                                  self._gen.data_ptr(), self._gen_states.data_ptr(), self._stream()),
-                   'pivp_rollout_backward')
+        cb = None
+        if on_group is not None:
+            import ctypes
+            errors = []
+
+            def _trampoline(_user, g):
+                try:
+                    on_group(int(g))
+                except BaseException as e:      # never unwind through the C frames
+                    errors.append(e)
+            cb = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int)(_trampoline)
+            _lib.check(plan.lib.pivp_plan_set_grad_callback(plan.h, ctypes.cast(cb, ctypes.c_void_p), None), 'pivp_plan_set_grad_callback')
+        try:
+            _lib.check(plan.lib.pivp_rollout_backward(plan.h, images.data_ptr(), actions.data_ptr(), states.data_ptr(), gt_ptr,
+                                                      self._gen.data_ptr(), self._gen_states.data_ptr(), self._stream()),
+                       'pivp_rollout_backward')
+        finally:
+            if cb is not None:
+                plan.lib.pivp_plan_set_grad_callback(plan.h, None, None)
+        if cb is not None and errors:
+            raise errors[0]
 
     def grads_reference(self):
         """Gradients in the reference's Chainer-npz layout (same permutations as the parameters)."""

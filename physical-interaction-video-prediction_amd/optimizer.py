@@ -59,9 +59,10 @@ class Adam(object):
         model = self.target
         loss = lossfun(*args)
         model.cleargrads()
-        model.backward()
         if self._dp is not None:
-            self._dp.allreduce(model)
+            self._dp.backward_and_allreduce(model)   # all-reduce of each gradient group overlapped with the rest of the sweep
+        else:
+            model.backward()
         self.step(model)
         return loss
 

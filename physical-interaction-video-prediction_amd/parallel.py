@@ -53,6 +53,37 @@ class GradAllReduce(object):
     def allreduce(self, model):
         return self.allreduce_flat(model._ensure_grads())
 
+    def backward_and_allreduce(self, model, force_overlap=False):
+        """model.backward() with the all-reduce of each gradient group launched on the side stream as soon as the sweep
+        has finished that group at t = 0 (every parameter is shared by all timesteps, so nothing is final earlier): the
+        heads / enc6 slice travels while lstm7 .. enc0 of the last timestep are still being differentiated.  Six
+        contiguous slices of 1-11 MB (model.grad_group_ranges()); xGMI is point-to-point, a few large messages keep
+        its links busier than many small ones."""
+        flat = model._ensure_grads()
+        if (self.world_size == 1 and not force_overlap) or not flat.is_cuda:   # force_overlap: exercise the path on one rank (tests)
+            model.backward()
+            return self.allreduce_flat(flat)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=flat.device)
+        ranges = model.grad_group_ranges()
+        main = torch.cuda.current_stream(flat.device)
+        works = []
+
+        def on_group(g):
+            a, b = ranges[g]
+            ev = torch.cuda.Event()
+            ev.record(main)                      # everything that writes slice g is already enqueued on `main`
+            self._stream.wait_event(ev)
+            with torch.cuda.stream(self._stream):
+                works.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+        model.backward(on_group=on_group)
+        with torch.cuda.stream(self._stream):
+            for w in works:
+                w.wait()
+        main.wait_stream(self._stream)
+        return flat
+
 
 def shard_batch(arrays, rank, world_size):
     """Contiguous per-rank shard of time-major arrays (T, B, ...) along the batch axis."""
