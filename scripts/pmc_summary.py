@@ -35,7 +35,35 @@ def write_summary(path, rows, col):
             f.write('"%s",%d,%.1f\n' % (k[:70], n, v))
 
 
+def mfma_busy(d, out_path):
+    """MFMA-pipe utilisation per kernel from a `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` pass:
+    busy cycles summed over the 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs x 1024)."""
+    files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+    assert files, 'no counter_collection.csv under ' + d
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            acc[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+    rows = []
+    for k, v in acc.items():
+        if not v.get('SQ_VALU_MFMA_BUSY_CYCLES') or not v.get('GRBM_GUI_ACTIVE'):
+            continue
+        b = sum(v['SQ_VALU_MFMA_BUSY_CYCLES']) / len(v['SQ_VALU_MFMA_BUSY_CYCLES'])
+        g = sum(v['GRBM_GUI_ACTIVE']) / len(v['GRBM_GUI_ACTIVE'])
+        if b > 0:
+            rows.append((k, len(v['GRBM_GUI_ACTIVE']), b, g, b / (g / 8.0 * 1024.0)))
+    with open(out_path, 'w') as f:
+        f.write('kernel,launches,avg_SQ_VALU_MFMA_BUSY_CYCLES,avg_GRBM_GUI_ACTIVE,mfma_busy_fraction\n')
+        for k, n, b, g, u in sorted(rows, key=lambda r: -r[1] * r[3]):
+            f.write('"%s",%d,%.4e,%.4e,%.3f\n' % (k[:70], n, b, g, u))
+    return rows
+
+
 def main():
+    if sys.argv[1] == '--mfma':          # python scripts/pmc_summary.py --mfma <pmc_dir> <out_csv>
+        for r in mfma_busy(sys.argv[2], sys.argv[3])[:6]:
+            print('%-60s launches %4d  MFMA busy fraction %.3f' % (r[0][:60], r[1], r[4]))
+        return
     fetch_dir, write_dir, out_dir = sys.argv[1:4]
     workload = sys.argv[4] if len(sys.argv) > 4 else ''
     fe = per_kernel(fetch_dir, 'FETCH_SIZE')
