@@ -543,8 +543,9 @@ int composite(const float* prev, const float* mask_logits, const float* layer0, 
     dim3 grid((H + CP_TR - 1) / CP_TR, B);
 #define PIVP_LAUNCH_CP(M)                                                                                   \
     do {                                                                                                    \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_kernel<M>),                            \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_kernel<M>),                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)        \
+            return PIVP_ERR_LAUNCH;                                                                         \
         hipLaunchKernelGGL((composite_kernel<M>), grid, dim3(256), lds, s, prev, mask_logits, layer0, aux,  \
                            out, masks_out, H, W, num_masks, stp_zero_border);                               \
     } while (0)

@@ -40,7 +40,6 @@
 
 namespace pivp {
 
-constexpr int IG_KC = 32;
 constexpr int IG_P = 36;  // LDS row pitch in floats (A and B tiles)
 #ifndef PIVP_XCD_MAP
 #define PIVP_XCD_MAP 1
@@ -66,7 +65,6 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
     constexpr int BN = 32 * NTB;
     constexpr int TPW = LSTM ? 4 / WN : NTB / WN;
     constexpr int CPW = 32 / WN;  // LSTM: channels per wave
-    constexpr int NMF = 16 * TPW; // MFMAs per wave per chunk
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int A_FLOATS = BM * IG_P, B_FLOATS = BN * IG_P;
 
