@@ -135,6 +135,17 @@ int pivp_convlstm_ln(const float* x, int cx, int ldx, const float* h_prev, int C
                      const float* c_in, float* c_out, float* h_out, const float* gamma, const float* beta, float* ln_out,
                      int ldo, float* partials, float eps, int B, int H, int W, int variant, int* fused, void* stream);
 
+/* bf16-operand form of pivp_convlstm (BASELINE.json config 3): x, h and the weights are rounded to bf16 (nearest even) on the
+ * way into the matrix pipe; accumulation, gates, c and h stay fp32.  w_bf16 = pivp_pack_lstm_bf16(w) holds
+ * pivp_lstm_bf16_weight_elems(cx + C, C) 2-byte elements.  gates_out / ln_part / ln_nparts may be NULL (as pivp_convlstm_train /
+ * pivp_convlstm_ln: ln_part receives ln_cap-bounded (count, mean, M2, 0) partials per sample, *ln_nparts how many, 0 = none).
+ * nch: 0 automatic, 16 or 32 channels per block.  Needs H % 8 == 0 and W % 16 == 0 (or W % 8 == 0 with B even). */
+long long pivp_lstm_bf16_weight_elems(int cin_total, int C);
+int pivp_pack_lstm_bf16(const float* w, void* w_bf16, int cin_total, int C, void* stream);
+int pivp_convlstm_bf16(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
+                       const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
+                       int* ln_nparts, int B, int H, int W, int nch, void* stream);
+
 /* --- training (what Chainer's autograd does under optimizer.update, TM:950) ---------------------------------- */
 /* pivp_convlstm with the gate activations kept for BPTT: gates_out [B*H*W][4C] = tanh(j), s(i), s(f+1), s(o). */
 int pivp_convlstm_train(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,

@@ -1,0 +1,401 @@
+// ConvLSTM gate convolution with bf16 operands and fp32 accumulation (BASELINE.json config 3, "bf16"): the opt-in
+// reduced-precision form of igemm_lstm (igemm_f32.hip).  Reference op: BasicConvLSTMCell.__call__, TM:234-276.
+//
+// With v_mfma_f32_32x32x16_bf16 a 32x32 tile of a K = 32 chunk costs 64 MFMA cycles instead of the 1024 of the fp32
+// instruction, so the gather scheme of igemm_f32.hip (a fresh A tile per tap) would be bound by its staging, not by the
+// matrix pipe.  This kernel therefore keeps the block's INPUT PATCH resident: a block owns 128 anchors of one image
+// (8 x 16 pixels; on 8-wide maps 8 x 8 pixels of two images) and 4 gates x NCH channels.  For every group of 64 input
+// channels of concat(x, h) it stages the patch with its 2-pixel halo ONCE (fp32 NHWC in HBM -> bf16 in LDS, pixel pitch
+// 144 B so that the 16-lane phases of a ds_read_b128 hit distinct banks; out-of-image pixels and channels past Cin are
+// the hardware zeros of an out-of-range buffer load) and runs the 25 taps against it: a tap only shifts the LDS address
+// of the A fragment.  The weights ([group][tap][4C][64] bf16, packed once per rollout by pack_lstm_bf16) stream through a
+// 4-slot LDS ring filled by global_load_lds_dwordx4 three taps ahead of their use: no VGPRs, no ds_writes, and the
+// loads stay in flight across the per-tap barrier (raw s_barrier + counted vmcnt).  A ring slot is lane-linear (the DMA
+// writes base + lane * 16), so bank conflicts of the B fragment reads are removed by an XOR swizzle of the 16-B pieces
+// of a 128-B weight row, applied to the per-lane SOURCE address of the DMA and to the read address alike.
+// Accumulators, gate math, cell state, h and the LayerNorm partial stay fp32; the epilogue is that of igemm_f32.hip.
+#include <type_traits>
+
+#include "pivp_kernels.h"
+
+namespace pivp {
+
+namespace {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int PP = 144;                // patch pixel pitch (bytes): 64 bf16 + 16
+constexpr int TH = 8, PH = TH + 4;     // anchor rows per tile, patch rows
+constexpr int MAXPIX = 2 * PH * 12;    // 288 patch pixels (two 8x8 images); one 8x16 tile has 12 * 20 = 240
+constexpr int PATCH_BYTES = MAXPIX * PP;
+constexpr int NSLOT = 4, DEPTH = 3;    // weight ring slots; taps of prefetch
+
+__device__ __forceinline__ float b_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float b_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {   // two fp32 -> packed bf16, round to nearest even
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// LDS reads and their waits as inline asm (see the kernel: the compiler must not see them as LDS accesses)
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_b128(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+// the in/out operands tie the fragments to the wait so that no MFMA that consumes them moves above it
+__device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& e) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e));
+}
+__device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
+}
+}  // namespace
+
+// fp32 K-inner packed weights [25][wcin/32][N][32] -> bf16 [ceil(wcin/64)][25][N][64], channels past wcin zero
+__global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int N, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c64 = (int)(i & 63);
+    long r = i >> 6;
+    const int n = (int)(r % N); r /= N;
+    const int tap = (int)(r % 25);
+    const int cg = (int)(r / 25);
+    const int ch = cg * 64 + c64;
+    float v = 0.f;
+    if (ch < wcin) v = w[(((long)tap * (wcin >> 5) + (ch >> 5)) * N + n) * 32 + (ch & 31)];
+    const __bf16 h = (__bf16)v;
+    wb[i] = __builtin_bit_cast(unsigned short, h);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256, 1) void convlstm_bf16_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int tw) {
+    constexpr int BN = 4 * NCH;                 // block columns: [gate][channel]
+    constexpr int SLOT = BN * 128;              // bytes of one ring slot: BN rows x 64 bf16
+    constexpr int G = BN / 32;                  // global_load_lds per thread and tap
+    constexpr int TPW = NCH / 16;               // MFMA column tiles per wave
+    constexpr int CPW = NCH / 2;                // channels per wave (all 4 gates of a channel stay in one wave)
+    constexpr int GPT = 32 / CPW;               // gates per MFMA tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // patch | ring
+    unsigned char* const patch = lds;
+    unsigned char* const ring = lds + PATCH_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int C = d.C, N = d.N, n_nblk = C / NCH;
+    const int H = d.Hin, W = d.Win;
+    // tile geometry: tw = 16: one image, 8 x 16 anchors; tw = 8: two images, 8 x 8 anchors each
+    const int ti_n = tw == 16 ? 1 : 2;
+    const int PW = tw + 4;
+    const int npix = ti_n * PH * PW;
+    const int tpr = W / tw, tpi = (H / TH) * tpr;          // tiles per row / per image
+    const int n_tiles = (d.B / ti_n) * tpi;
+    int lid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware, column-block major
+    const int nblk = lid / n_tiles, tile = lid - nblk * n_tiles;
+    const int b0 = (tile / tpi) * ti_n, trem = tile - (tile / tpi) * tpi;
+    const int y0 = (trem / tpr) * TH, x0 = (trem - (trem / tpr) * tpr) * tw;
+    const int c0 = d.c0, ld0 = d.ld0, ld1 = d.ld1;
+    const int cin = c0 + d.c1;
+    const int ncg = (cin + 63) >> 6;
+    const int nchunks = 25 * ncg;
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x0), 0, d.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.c1 ? d.x1 : d.x0), 0, d.c1 ? d.bytes1 : d.bytes0, 0x00020000);
+    constexpr unsigned OOB = 0xC0000000u;
+
+    // ---- patch staging roles: thread = (pixel (tid >> 3) + 32 j, 8-channel piece tid & 7), j < 9 ------------------------
+    const int cpiece = tid & 7;
+    int a_pix[9];                                      // global pixel index, or -1 outside the image / past the patch
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int p = (tid >> 3) + 32 * j;
+        const int ti = p / (PH * PW), pr = p - ti * (PH * PW);
+        const int py = pr / PW, px = pr - py * PW;
+        const int iy = y0 - 2 + py, ix = x0 - 2 + px;
+        const bool ok = p < npix && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        a_pix[j] = ok ? ((b0 + ti) * H + iy) * W + ix : -1;
+    }
+    auto stage_patch = [&](int cg) {
+        const int ch = cg * 64 + cpiece * 8;           // first of this thread's 8 channels of concat(x, h)
+        const bool s0 = ch < c0, s1 = !s0 && ch < cin;
+        const int ld = s0 ? ld0 : ld1, co = s0 ? ch : ch - c0;
+        f32x4 lo[9], hi[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const unsigned off = (a_pix[j] >= 0 && (s0 || s1)) ? (unsigned)((a_pix[j] * ld + co) * 4) : OOB;
+            if (s0) {
+                lo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
+                hi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 16, 0));
+            } else {
+                lo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
+                hi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 16, 0));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            // unconditional (9 * 32 = MAXPIX pixels are allocated; pixels past npix receive zeros): a predicated write leaves the
+            // loads "pending" on the skipped path for hipcc's wait-count pass, which then drains vmcnt inside the tap loop
+            const int p = (tid >> 3) + 32 * j;
+            uint4 v;
+            v.x = pack2(lo[j][0], lo[j][1]); v.y = pack2(lo[j][2], lo[j][3]);
+            v.z = pack2(hi[j][0], hi[j][1]); v.w = pack2(hi[j][2], hi[j][3]);
+            *reinterpret_cast<uint4*>(patch + p * PP + cpiece * 16) = v;
+        }
+    };
+
+    // ---- weight ring: DMA j of a tap writes ring bytes [(j * 256 + tid) * 16, +16): row (j * 32 + tid / 8), piece tid % 8,
+    // which holds SOURCE piece (tid % 8) ^ (row % 8) of that row ------------------------------------------------------------
+    const unsigned char* wsrc[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const int row = j * 32 + (tid >> 3), g = row / NCH, cl = row - g * NCH;
+        const int piece = (tid & 7) ^ (row & 7);
+        wsrc[j] = reinterpret_cast<const unsigned char*>(wb) + ((size_t)(g * C + nblk * NCH + cl)) * 128 + piece * 16;
+    }
+    const size_t wstep = (size_t)N * 128;              // bytes between consecutive (group, tap) weight tiles
+    int issued = 0;                                    // taps whose DMAs have been issued
+    auto issue_weights = [&]() {
+        const int slot = issued & (NSLOT - 1);
+        const size_t goff = (size_t)issued * wstep;
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            unsigned char* dst = ring + slot * SLOT + (j * 256 + wave * 64) * 16;    // wave-uniform; the DMA adds lane * 16
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + goff),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+        ++issued;
+    };
+
+    f32x16 acc[2][TPW];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][t][r] = 0.f;
+
+    // fragment addresses (bytes).  A: row l31 of M tile mt = anchor 64 wm + 32 mt + l31; k piece `half` of the k-step
+    int a_off[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int i = 64 * wm + 32 * mt + l31;
+        const int ti = tw == 16 ? 0 : i >> 6, ay = tw == 16 ? i >> 4 : (i >> 3) & 7, ax = tw == 16 ? i & 15 : i & 7;
+        a_off[mt] = ((ti * PH + ay) * PW + ax) * PP + half * 16;
+    }
+    // B: MFMA column l31 of tile t = gate t * GPT + l31 / CPW, channel wn * CPW + l31 % CPW; ring row = gate * NCH + channel
+    int b_row[TPW], b_sw[4];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) b_row[t] = ((t * GPT + l31 / CPW) * NCH + wn * CPW + (l31 % CPW)) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b_sw[ks] = ((2 * ks + half) ^ (l31 & 7)) * 16;    // row % 8 == l31 % 8 (NCH, CPW multiples of 8)
+
+    // LDS reads go through inline asm: hipcc knows that an LDS-DMA writes LDS and puts s_waitcnt vmcnt(0) in front of every
+    // ds_read it can see, which would drain the prefetch every tap.  The waits below are explicit instead.
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    bf16x8 fa[2][2], fb[2][TPW];                       // [register set][tile]
+    auto wait_frags = [&](auto SET) {
+        constexpr int st = decltype(SET)::value;
+        if constexpr (TPW == 2) wait_lgkm(fa[st][0], fa[st][1], fb[st][0], fb[st][1]);
+        else wait_lgkm(fa[st][0], fa[st][1], fb[st][0]);
+    };
+    auto read_frags = [&](auto SET, auto KS, int tp, int slot) {   // fragments of k-step KS of tap tp (weights in ring slot `slot`)
+        constexpr int st = decltype(SET)::value, ks = decltype(KS)::value;
+        const int ty = tp / 5, tx = tp - ty * 5;
+        const unsigned ab = lds0 + (ty * PW + tx) * PP;
+        const unsigned bb = lds0 + PATCH_BYTES + slot * SLOT + b_sw[ks];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) fa[st][mt] = lds_read_b128<ks * 32>(ab + a_off[mt]);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) fb[st][t] = lds_read_b128<0>(bb + b_row[t]);
+    };
+    auto mfmas = [&](auto SET) {
+        constexpr int st = decltype(SET)::value;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], fb[st][t], acc[mt][t], 0, 0, 0);
+    };
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+
+    // ---- prologue: patch of channel group 0, weights of taps 0..2 -----------------------------------------------------------
+    stage_patch(0);
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i)
+        if (i < nchunks) issue_weights();
+    if (nchunks >= DEPTH) {                            // taps 0 and 1 landed
+        if constexpr (G == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    read_frags(S0{}, K0{}, 0, 0);
+
+    // One tap = 4 k-steps of 16 channels; fragments of the next k-step are requested before the MFMAs of the current one.  The
+    // barrier that publishes the NEXT tap's weights sits in the middle of the tap (its skew hides behind queued MFMAs), so the
+    // first fragments of the next tap can be requested right after the last k-step: at that barrier every wave is past tap it - 1,
+    // whose ring slot then takes the DMAs of tap it + 3.
+    int tap = 0, cg = 0;
+    for (int it = 0; it < nchunks; ++it) {
+        const int slot = it & (NSLOT - 1);
+        wait_frags(S0{}); read_frags(S1{}, K1{}, tap, slot); mfmas(S0{});
+        __builtin_amdgcn_sched_barrier(0);
+        wait_frags(S1{}); read_frags(S0{}, K2{}, tap, slot); mfmas(S1{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 2 < nchunks) {                        // DMAs of taps it + 1, it + 2 outstanding: it + 1 must have landed
+            if constexpr (G == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (it + DEPTH < nchunks) issue_weights();
+        __builtin_amdgcn_sched_barrier(0);
+        wait_frags(S0{}); read_frags(S1{}, K3{}, tap, slot); mfmas(S0{});
+        __builtin_amdgcn_sched_barrier(0);
+        const bool regroup = tap == 24;
+        tap = regroup ? 0 : tap + 1;
+        wait_frags(S1{});
+        if (!regroup) read_frags(S0{}, K0{}, tap, (it + 1) & (NSLOT - 1));
+        mfmas(S1{});
+        if (regroup && ++cg < ncg) {                   // next 64 input channels: restage the patch
+            __syncthreads();                           // every wave is done with the old patch
+            stage_patch(cg);
+            __syncthreads();
+            read_frags(S0{}, K0{}, 0, (it + 1) & (NSLOT - 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue: gates, state update, optional gate activations and LayerNorm partial ----------------------------------
+    const int chl = wn * CPW + (l31 % CPW);
+    const int ch = nblk * NCH + chl;
+    const int grp = l31 / CPW;
+    const float bj = d.bias[ch], bi = d.bias[C + ch], bf = d.bias[2 * C + ch] + 1.0f, bo = d.bias[3 * C + ch];
+    float sv[2][16];
+    unsigned own = 0;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sv[mt][r] = 0.f;
+            float g4[4];
+#pragma unroll
+            for (int Gt = 0; Gt < 4; ++Gt)
+                g4[Gt] = __shfl(acc[mt][Gt / GPT][r], (l31 % CPW) + CPW * (Gt % GPT) + 32 * half, 64);
+            const int i = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;       // anchor within the block
+            const int ti = tw == 16 ? 0 : i >> 6, ay = tw == 16 ? i >> 4 : (i >> 3) & 7, ax = tw == 16 ? i & 15 : i & 7;
+            const int m = ((b0 + ti) * H + y0 + ay) * W + x0 + ax;
+            if (grp == (r % GPT)) {
+                const size_t o = (size_t)m * C + ch;
+                const float aj = b_tanh(g4[0] + bj), ai = b_sigmoid(g4[1] + bi);
+                const float af = b_sigmoid(g4[2] + bf), ao = b_sigmoid(g4[3] + bo);
+                const float cn = d.cstate_in[o] * af + ai * aj;
+                d.cstate_out[o] = cn;
+                const float hn = b_tanh(cn) * ao;
+                d.hout[o] = hn;
+                sv[mt][r] = hn;
+                if (mt == 0) own |= 1u << r;
+                if (d.gates_out) {
+                    float* gp = d.gates_out + (size_t)m * 4 * C + ch;
+                    gp[0] = aj; gp[C] = ai; gp[2 * C] = af; gp[3 * C] = ao;
+                }
+            }
+        }
+    if (d.ln_part) {
+        // (count, mean, M2) of the h values of each image of the tile; with two images wave pair wm owns image wm.
+        float* red = reinterpret_cast<float*>(lds);
+        float s1 = 0.f, c1 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if ((own >> r) & 1) { s1 += sv[mt][r]; c1 += 1.f; }
+        s1 = wave_sum(s1); c1 = wave_sum(c1);
+        __syncthreads();
+        if (lane == 0) { red[wave] = s1; red[4 + wave] = c1; }
+        __syncthreads();
+        float cnt, mean;
+        if (ti_n == 1) {
+            cnt = (red[4] + red[5]) + (red[6] + red[7]);
+            mean = ((red[0] + red[1]) + (red[2] + red[3])) / cnt;
+        } else {
+            cnt = red[4 + wm] + red[6 + wm];
+            mean = (red[wm] + red[2 + wm]) / cnt;
+        }
+        float q = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if ((own >> r) & 1) { const float dd = sv[mt][r] - mean; q = fmaf(dd, dd, q); }
+        q = wave_sum(q);
+        if (lane == 0) red[8 + wave] = q;
+        __syncthreads();
+        if (ti_n == 1) {
+            if (tid == 0) {
+                float* p = d.ln_part + ((size_t)b0 * d.ln_nparts + (size_t)trem * n_nblk + nblk) * 4;
+                p[0] = cnt; p[1] = mean; p[2] = (red[8] + red[9]) + (red[10] + red[11]); p[3] = 0.f;
+            }
+        } else if (lane == 0 && wn == 0) {
+            float* p = d.ln_part + ((size_t)(b0 + wm) * d.ln_nparts + (size_t)trem * n_nblk + nblk) * 4;
+            p[0] = cnt; p[1] = mean; p[2] = red[8 + wm] + red[10 + wm]; p[3] = 0.f;
+        }
+    }
+}
+
+size_t lstm_bf16_weight_elems(int wcin, int N) { return (size_t)((wcin + 63) / 64) * 25 * N * 64; }
+
+int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s) {
+    PIVP_CHECK_ARG(w && wb && wcin > 0 && wcin % 32 == 0 && N > 0);
+    const long total = (long)lstm_bf16_weight_elems(wcin, N);
+    hipLaunchKernelGGL(pack_lstm_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, total);
+    return PIVP_LAUNCH_STATUS();
+}
+
+bool convlstm_bf16_ok(const IgemmDesc& d) {
+    if (d.ksize != 5 || d.pad != 2 || d.in_step != 1 || d.C % 16 || d.Hin % TH) return false;
+    if (d.c0 % 8 || d.c1 % 8 || d.ld0 % 4 || d.ld1 % 4) return false;
+    if (d.Win % 16 == 0) return true;
+    return d.Win % 8 == 0 && d.B % 2 == 0;
+}
+
+template <int NCH>
+static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts) {
+    constexpr int lds_bytes = PATCH_BYTES + NSLOT * 4 * NCH * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bf16_kernel<NCH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds_bytes) != hipSuccess)
+            return PIVP_ERR_LAUNCH;
+        attr_set = true;
+    }
+    IgemmDesc dd = d;
+    const int tw = d.Win % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
+    const int tpi = (d.Hin / TH) * (d.Win / tw), nb = d.C / NCH;
+    const int np = tpi * nb;
+    dd.ln_nparts = (d.ln_part && np <= d.ln_cap) ? np : 0;
+    if (!dd.ln_nparts) dd.ln_part = nullptr;
+    if (ln_nparts) *ln_nparts = dd.ln_nparts;
+    const int blocks = (d.B / ti_n) * tpi * nb;
+    hipLaunchKernelGGL(convlstm_bf16_kernel<NCH>, dim3(blocks), dim3(256), lds_bytes, stream, dd, wb, tw);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// d as for igemm_lstm (validated by the caller's igemm_validate(d, true) equivalent); wb = pack_lstm_bf16(d.w).
+int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nch) {
+    PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0)));
+    const int tw = d.Win % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
+    const long blocks32 = (long)(d.B / ti_n) * (d.Hin / TH) * (d.Win / tw) * (d.C / 32);
+    if (nch == 0) nch = (d.C % 32 || blocks32 < 256) ? 16 : 32;
+    return nch == 16 ? launch_bf16<16>(d, wb, stream, ln_nparts) : launch_bf16<32>(d, wb, stream, ln_nparts);
+}
+
+}  // namespace pivp

@@ -58,6 +58,11 @@ int repack_transpose(const float* w, float* wt, int taps, int cin, int N, int fl
 int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant = 0, int* ln_nparts = nullptr);  // 0 auto, 1: 4x1 waves, 2: 2x2, 3: 1x4
 int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr);
 int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr);
+// bf16-operand ConvLSTM (csrc/convlstm_bf16.hip): wb = pack_lstm_bf16 of d.w; nch: 0 auto, 16 / 32 channels per block
+size_t lstm_bf16_weight_elems(int wcin, int N);
+int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s);
+bool convlstm_bf16_ok(const IgemmDesc& d);
+int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts = nullptr, int nch = 0);
 
 // enc0: 5x5 stride-2 pad-2 conv on a planar 3-channel frame -> NHWC 32 channels (TM:500)
 // ln_part (optional): the launch also writes *ln_nparts LayerNorm partials per sample of its output (0 = not supported for the shape)

@@ -14,6 +14,7 @@ LAYERS = [('lstm1', 32, 32, 32), ('lstm2', 32, 32, 32), ('lstm3', 32, 64, 16), (
           ('lstm5', 64, 128, 8), ('lstm6', 128, 64, 16), ('lstm7', 96, 32, 32)]
 import os
 VARIANT = int(os.environ.get('PIVP_LSTM_VARIANT', '0'))
+BF16 = os.environ.get('PIVP_BENCH_BF16', '0') == '1'   # bf16-operand kernel (VARIANT = channels per block: 0 / 16 / 32)
 DATA = os.environ.get('PIVP_BENCH_DATA', 'random')   # random | zero | const: does the MFMA rate depend on the operand values?
 lib = _lib.load()
 dev = 'cuda:0'
@@ -33,10 +34,19 @@ for name, cx, C, H in LAYERS:
     elif DATA == 'const':
         x.fill_(0.37); h.fill_(-0.21); w.fill_(0.013)
     co = torch.empty_like(c); ho = torch.empty_like(h)
-    bufs[name] = (x, h, c, w, b, co, ho, cx, C, H)
+    wb = None
+    if BF16:
+        wb = torch.empty(lib.pivp_lstm_bf16_weight_elems(cx + C, C), dtype=torch.int16, device=dev)
+        assert lib.pivp_pack_lstm_bf16(w.data_ptr(), wb.data_ptr(), cx + C, C, st) == 0
+    bufs[name] = (x, h, c, w, b, co, ho, cx, C, H, wb)
 
 def launch(name):
-    x, h, c, w, b, co, ho, cx, C, H = bufs[name]
+    x, h, c, w, b, co, ho, cx, C, H, wb = bufs[name]
+    if BF16:
+        rc = lib.pivp_convlstm_bf16(x.data_ptr(), cx, cx, h.data_ptr(), C, wb.data_ptr(), b.data_ptr(), c.data_ptr(), co.data_ptr(),
+                                    ho.data_ptr(), None, None, 0, None, B, H, H, VARIANT, st)
+        assert rc == 0, rc
+        return
     rc = lib.pivp_convlstm_v(x.data_ptr(), cx, cx, h.data_ptr(), C, w.data_ptr(), b.data_ptr(), c.data_ptr(), co.data_ptr(),
                              ho.data_ptr(), B, H, H, VARIANT, st)
     assert rc == 0, rc
@@ -55,7 +65,7 @@ for r in range(5):
         res[name].append(e0.elapsed_time(e1) / iters)
 tot_f, tot_t = 0.0, 0.0
 for name in bufs:
-    x, h, c, w, b, co, ho, cx, C, H = bufs[name]
+    x, h, c, w, b, co, ho, cx, C, H, wb = bufs[name]
     fl = 2.0 * B * H * H * 4 * C * 25 * (cx + C)
     ms = float(np.median(res[name]))
     tot_f += fl; tot_t += ms

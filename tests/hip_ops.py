@@ -38,6 +38,35 @@ def convlstm(x, h, c, W, b, variant=0, h_is_zero=False):
     return nchw(h_out, B, H, Wd, C), nchw(c_out, B, H, Wd, C)
 
 
+def convlstm_bf16(x, h, c, W, b, nch=0, h_is_zero=False, want_gates=False, want_ln=False):
+    """bf16-operand ConvLSTM; returns (h, c[, gates NHWC-flat][, (ln partials [B][np][4], np)])."""
+    import ctypes
+    lib = _lib.load()
+    B, cx, H, Wd = x.shape
+    C = h.shape[1]
+    xd, hd, cd = nhwc(x), nhwc(h), nhwc(c)
+    wd, bd = _t(pivp_amd.to_internal('lstm1/conv/W', W)), _t(b)
+    wb = torch.empty(lib.pivp_lstm_bf16_weight_elems(cx + C, C), dtype=torch.int16, device=DEV)
+    _lib.check(lib.pivp_pack_lstm_bf16(wd.data_ptr(), wb.data_ptr(), cx + C, C, stream()), 'pack_lstm_bf16')
+    c_out = torch.empty_like(cd); h_out = torch.empty_like(hd)
+    gates = torch.empty((B * H * Wd, 4 * C), dtype=torch.float32, device=DEV) if want_gates else None
+    cap = (H * Wd // 128 + 1) * (C // 16)
+    part = torch.zeros((B, cap, 4), dtype=torch.float32, device=DEV) if want_ln else None
+    npart = ctypes.c_int(-1)
+    _lib.check(lib.pivp_convlstm_bf16(xd.data_ptr(), cx, cx, None if h_is_zero else hd.data_ptr(), C, wb.data_ptr(), bd.data_ptr(),
+                                      cd.data_ptr(), c_out.data_ptr(), h_out.data_ptr(), gates.data_ptr() if want_gates else None,
+                                      part.data_ptr() if want_ln else None, cap, ctypes.addressof(npart) if want_ln else None,
+                                      B, H, Wd, nch, stream()), 'convlstm_bf16')
+    torch.cuda.synchronize()
+    out = [nchw(h_out, B, H, Wd, C), nchw(c_out, B, H, Wd, C)]
+    if want_gates:
+        out.append(gates.cpu().numpy())
+    if want_ln:
+        n = npart.value
+        out.append((part.cpu().numpy().reshape(-1)[:B * n * 4].reshape(B, n, 4) if n > 0 else None, n))
+    return tuple(out)
+
+
 def convlstm_ln(x, h, c, W, b, gamma, beta, eps, variant=0):
     """hidden = norm(lstm(x)) with the LayerNorm statistics from the ConvLSTM epilogue; returns (ln(h), h, c, fused)."""
     import ctypes

@@ -1,0 +1,108 @@
+"""bf16-operand ConvLSTM (BASELINE.json config 3) against the float64 oracle.
+
+The kernel rounds x, h and the weights to bf16 (nearest even) and accumulates in fp32.  Two kinds of check:
+  * operands that ARE bf16 numbers: every product is exact in fp32, so the result must agree with the oracle to fp32
+    summation-order accuracy -- this pins every index of the patch / weight-ring scheme as tightly as the fp32 tests do;
+  * arbitrary fp32 operands: the difference to the oracle is the bf16 rounding of the operands, reported and bounded.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+SHAPES = [(2, 32, 32, 32), (2, 32, 64, 16), (4, 64, 128, 8), (2, 128, 64, 16), (1, 96, 32, 32), (3, 64, 64, 16), (2, 16, 16, 8),
+          (1, 32, 32, 64)]
+
+
+@pytest.fixture(scope='module')
+def ops():
+    import hip_ops
+    return hip_ops
+
+
+def _bf16(a):
+    return torch.from_numpy(np.asarray(a, dtype=np.float32)).bfloat16().float().numpy().astype(np.float64)
+
+
+def _lstm_ref(x, h, c, W, b):
+    g = R.conv2d(np.concatenate([x, h], 1), W, b, 1, 2)
+    j, i, f, o = np.split(g, 4, axis=1)
+    cn = c * R.sigmoid(f + 1.0) + R.sigmoid(i) * np.tanh(j)
+    return np.tanh(cn) * R.sigmoid(o), cn, (np.tanh(j), R.sigmoid(i), R.sigmoid(f + 1.0), R.sigmoid(o))
+
+
+def _case(B, cx, C, H, seed):
+    rs = np.random.RandomState(seed)
+    x = rs.randn(B, cx, H, H); h = rs.randn(B, C, H, H) * 0.5; c = rs.randn(B, C, H, H)
+    W = rs.randn(4 * C, cx + C, 5, 5) / np.sqrt(25 * (cx + C)); b = rs.randn(4 * C) * 0.1
+    return x, h, c, W, b
+
+
+@pytest.mark.parametrize('nch', [0, 16, 32])
+@pytest.mark.parametrize('B,cx,C,H', SHAPES)
+def test_convlstm_bf16_exact_on_bf16_operands(ops, B, cx, C, H, nch):
+    if nch == 32 and C % 32:
+        pytest.skip('32-channel blocks need C % 32 == 0')
+    x, h, c, W, b = _case(B, cx, C, H, B * 100 + C + H)
+    x, h, W = _bf16(x), _bf16(h), _bf16(W)
+    hr, cr, _ = _lstm_ref(x, h, c, W, b)
+    hg, cg = ops.convlstm_bf16(x, h, c, W, b, nch)
+    assert np.abs(hg - hr).max() < TOL and np.abs(cg - cr).max() < TOL
+
+
+@pytest.mark.parametrize('B,cx,C,H', SHAPES[:5])
+def test_convlstm_bf16_rounding_error(ops, B, cx, C, H):
+    # fp32 operands: the result is the oracle's on bf16-rounded operands; against the unrounded oracle the error is the
+    # operand rounding (2^-9 relative per operand, K = 25 (cx + C) random-sign terms) -- well under 1e-2 on O(1) gates
+    x, h, c, W, b = _case(B, cx, C, H, 7 + H)
+    hq, cq, _ = _lstm_ref(_bf16(x), _bf16(h), c, _bf16(W), b)
+    hr, cr, _ = _lstm_ref(x, h, c, W, b)
+    hg, cg = ops.convlstm_bf16(x, h, c, W, b)
+    assert np.abs(hg - hq).max() < TOL and np.abs(cg - cq).max() < TOL
+    err = max(np.abs(hg - hr).max(), np.abs(cg - cr).max())
+    print('bf16 ConvLSTM B=%d cx=%d C=%d H=%d: max |err| vs fp64 oracle %.2e' % (B, cx, C, H, err))
+    assert 1e-5 < err < 1e-2
+
+
+def test_convlstm_bf16_first_step_zero_h(ops):
+    x, h, c, W, b = _case(2, 64, 128, 8, 5)
+    x, W = _bf16(x), _bf16(W)
+    h = np.zeros_like(h); c = np.zeros_like(c)
+    hr, cr, _ = _lstm_ref(x, h, c, W, b)
+    hg, cg = ops.convlstm_bf16(x, h, c, W, b, h_is_zero=True)
+    hz, cz = ops.convlstm_bf16(x, h, c, W, b, h_is_zero=False)
+    assert np.abs(hg - hr).max() < TOL and np.abs(cg - cr).max() < TOL
+    assert np.abs(hg - hz).max() < 2e-6 and np.abs(cg - cz).max() < 2e-6
+
+
+@pytest.mark.parametrize('B,cx,C,H', [(2, 32, 32, 32), (2, 64, 128, 8), (2, 32, 64, 16)])
+def test_convlstm_bf16_gates_and_layernorm_partials(ops, B, cx, C, H):
+    x, h, c, W, b = _case(B, cx, C, H, 11 + C)
+    x, h, W = _bf16(x), _bf16(h), _bf16(W)
+    hr, cr, gr = _lstm_ref(x, h, c, W, b)
+    hg, cg, gates, (part, n) = ops.convlstm_bf16(x, h, c, W, b, want_gates=True, want_ln=True)
+    assert np.abs(hg - hr).max() < TOL
+    gn = gates.reshape(B, H, H, 4, C).transpose(3, 0, 4, 1, 2)      # [gate][B][C][H][W]
+    for k in range(4):
+        assert np.abs(gn[k] - gr[k]).max() < TOL
+    assert n > 0
+    for s in range(B):                                              # Chan merge of the (count, mean, M2) partials
+        cnt = part[s, :, 0].astype(np.float64); mean = part[s, :, 1].astype(np.float64); m2 = part[s, :, 2].astype(np.float64)
+        assert cnt.sum() == C * H * H
+        tot_mean = (cnt * mean).sum() / cnt.sum()
+        tot_m2 = m2.sum() + (cnt * (mean - tot_mean) ** 2).sum()
+        assert abs(tot_mean - hr[s].mean()) < 1e-5
+        assert abs(tot_m2 / cnt.sum() - hr[s].var()) < 1e-5
+
+
+def test_convlstm_bf16_rejects_bad_shapes(ops):
+    x, h, c, W, b = _case(1, 32, 32, 8, 1)                          # 8-wide map with odd batch
+    with pytest.raises(RuntimeError):
+        ops.convlstm_bf16(x, h, c, W, b)
+    x, h, c, W, b = _case(2, 32, 32, 12, 1)                         # H % 8 != 0
+    with pytest.raises(RuntimeError):
+        ops.convlstm_bf16(x, h, c, W, b)
