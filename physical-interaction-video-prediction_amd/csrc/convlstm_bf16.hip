@@ -30,6 +30,10 @@ constexpr int TH = 8, PH = TH + 4;     // anchor rows per tile, patch rows
 constexpr int MAXPIX = 2 * PH * 12;    // 288 patch pixels (two 8x8 images); one 8x16 tile has 12 * 20 = 240
 constexpr int PATCH_BYTES = MAXPIX * PP;
 constexpr int NSLOT = 4, DEPTH = 3;    // weight ring slots; taps of prefetch
+#ifndef PIVP_BF16_ABL
+#define PIVP_BF16_ABL 0             // timing-only ablations (scripts/bench_lstm_layers.py): 1 no weight DMAs in the loop, 2 no MFMAs,
+#endif                              // 3 no fragment reads in the loop, 4 no epilogue, 6 neither loop nor epilogue (prologue only)
+
 
 __device__ __forceinline__ float b_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float b_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
@@ -157,10 +161,16 @@ __global__ __launch_bounds__(256, 1) void convlstm_bf16_kernel(const IgemmDesc d
         wsrc[j] = reinterpret_cast<const unsigned char*>(wb) + ((size_t)(g * C + nblk * NCH + cl)) * 128 + piece * 16;
     }
     const size_t wstep = (size_t)N * 128;              // bytes between consecutive (group, tap) weight tiles
+    // Every block walks the 25 taps of a channel group in its own rotation (tap0, tap0 + 1, ... mod 25): blocks that run in
+    // step would otherwise all pull the same 16 KB of weights out of the same few L2 channels at the same time.
+    const int tap0 = (lid * 7) % 25;
     int issued = 0;                                    // taps whose DMAs have been issued
+    int i_tap = tap0, i_cg = 0;                        // ... the next one to issue
     auto issue_weights = [&]() {
         const int slot = issued & (NSLOT - 1);
-        const size_t goff = (size_t)issued * wstep;
+        const size_t goff = (size_t)(i_cg * 25 + i_tap) * wstep;
+        i_tap = i_tap == 24 ? 0 : i_tap + 1;
+        i_cg += i_tap == tap0 ? 1 : 0;
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             unsigned char* dst = ring + slot * SLOT + (j * 256 + wave * 64) * 16;    // wave-uniform; the DMA adds lane * 16
@@ -204,6 +214,7 @@ __global__ __launch_bounds__(256, 1) void convlstm_bf16_kernel(const IgemmDesc d
     };
     auto read_frags = [&](auto SET, auto KS, int tp, int slot) {   // fragments of k-step KS of tap tp (weights in ring slot `slot`)
         constexpr int st = decltype(SET)::value, ks = decltype(KS)::value;
+        if (PIVP_BF16_ABL == 3 && issued > DEPTH) return;
         const int ty = tp / 5, tx = tp - ty * 5;
         const unsigned ab = lds0 + (ty * PW + tx) * PP;
         const unsigned bb = lds0 + PATCH_BYTES + slot * SLOT + b_sw[ks];
@@ -214,6 +225,7 @@ __global__ __launch_bounds__(256, 1) void convlstm_bf16_kernel(const IgemmDesc d
     };
     auto mfmas = [&](auto SET) {
         constexpr int st = decltype(SET)::value;
+        if constexpr (PIVP_BF16_ABL == 2) return;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -226,6 +238,24 @@ __global__ __launch_bounds__(256, 1) void convlstm_bf16_kernel(const IgemmDesc d
 
     // ---- prologue: patch of channel group 0, weights of taps 0..2 -----------------------------------------------------------
     stage_patch(0);
+    // The epilogue's c_{t-1} values are requested here, behind the patch loads: read in the epilogue they cost one exposed HBM round
+    // trip per accumulator row (16-32 in a row), more than the whole tap loop.  Lane (grp, channel) owns rows r with r % GPT == grp.
+    const int chl = wn * CPW + (l31 % CPW);
+    const int ch = nblk * NCH + chl;
+    const int grp = l31 / CPW;
+    constexpr int OWN = 16 / GPT;
+    const float bj = d.bias[ch], bi = d.bias[C + ch], bf = d.bias[2 * C + ch] + 1.0f, bo = d.bias[3 * C + ch];
+    float cpre[2][OWN];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int k = 0; k < OWN; ++k) {
+            const int r = k * GPT + grp;
+            const int i = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int ti = tw == 16 ? 0 : i >> 6, ay = tw == 16 ? i >> 4 : (i >> 3) & 7, ax = tw == 16 ? i & 15 : i & 7;
+            const int m = ((b0 + ti) * H + y0 + ay) * W + x0 + ax;
+            cpre[mt][k] = d.cstate_in[(size_t)m * C + ch];
+        }
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i)
         if (i < nchunks) issue_weights();
@@ -236,14 +266,14 @@ __global__ __launch_bounds__(256, 1) void convlstm_bf16_kernel(const IgemmDesc d
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    read_frags(S0{}, K0{}, 0, 0);
+    read_frags(S0{}, K0{}, tap0, 0);
 
     // One tap = 4 k-steps of 16 channels; fragments of the next k-step are requested before the MFMAs of the current one.  The
     // barrier that publishes the NEXT tap's weights sits in the middle of the tap (its skew hides behind queued MFMAs), so the
     // first fragments of the next tap can be requested right after the last k-step: at that barrier every wave is past tap it - 1,
     // whose ring slot then takes the DMAs of tap it + 3.
-    int tap = 0, cg = 0;
-    for (int it = 0; it < nchunks; ++it) {
+    int tap = tap0, cg = 0;
+    for (int it = 0; it < (PIVP_BF16_ABL == 6 ? 0 : nchunks); ++it) {
         const int slot = it & (NSLOT - 1);
         wait_frags(S0{}); read_frags(S1{}, K1{}, tap, slot); mfmas(S0{});
         __builtin_amdgcn_sched_barrier(0);
@@ -256,12 +286,12 @@ __global__ __launch_bounds__(256, 1) void convlstm_bf16_kernel(const IgemmDesc d
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        if (it + DEPTH < nchunks) issue_weights();
+        if (PIVP_BF16_ABL != 1 && it + DEPTH < nchunks) issue_weights();
         __builtin_amdgcn_sched_barrier(0);
         wait_frags(S0{}); read_frags(S1{}, K3{}, tap, slot); mfmas(S0{});
         __builtin_amdgcn_sched_barrier(0);
-        const bool regroup = tap == 24;
-        tap = regroup ? 0 : tap + 1;
+        tap = tap == 24 ? 0 : tap + 1;
+        const bool regroup = tap == tap0;
         wait_frags(S1{});
         if (!regroup) read_frags(S0{}, K0{}, tap, (it + 1) & (NSLOT - 1));
         mfmas(S1{});
@@ -269,56 +299,71 @@ __global__ __launch_bounds__(256, 1) void convlstm_bf16_kernel(const IgemmDesc d
             __syncthreads();                           // every wave is done with the old patch
             stage_patch(cg);
             __syncthreads();
-            read_frags(S0{}, K0{}, 0, (it + 1) & (NSLOT - 1));
+            read_frags(S0{}, K0{}, tap, (it + 1) & (NSLOT - 1));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    if (PIVP_BF16_ABL == 6) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // it skipped the loop's own drain
+    if (PIVP_BF16_ABL == 4 || PIVP_BF16_ABL == 6) { if (acc[0][0][0] == 123.f) d.hout[0] = 0.f; return; }
     // ---- epilogue: gates, state update, optional gate activations and LayerNorm partial ----------------------------------
-    const int chl = wn * CPW + (l31 % CPW);
-    const int ch = nblk * NCH + chl;
-    const int grp = l31 / CPW;
-    const float bj = d.bias[ch], bi = d.bias[C + ch], bf = d.bias[2 * C + ch] + 1.0f, bo = d.bias[3 * C + ch];
-    float sv[2][16];
-    unsigned own = 0;
+    // Accumulator row r of a lane is one anchor; its column is (gate t * GPT + grp, channel): the 4 gates of an (anchor, channel)
+    // sit in the GPT lanes lane ^ (x * CPW) and the TPW tiles.  Lane grp takes rows r = k * GPT + grp: it keeps its own gate of
+    // that row and receives the others from its partners in GPT - 1 xor-shuffles per tile, each partner sending the row its
+    // receiver owns.  Every lane then updates one (anchor, channel) per k: no idle lanes, 2 (NCH 32) or 3 (NCH 16) shuffles per
+    // cell instead of 8 or 16.  Register arrays are only indexed statically; per-lane choices are select chains.
+    auto pick = [&](const float (&v)[GPT], int idx) -> float {
+        if constexpr (GPT == 2) {
+            return idx ? v[1] : v[0];
+        } else {
+            const float lo = (idx & 1) ? v[1] : v[0], hi = (idx & 1) ? v[3] : v[2];
+            return (idx & 2) ? hi : lo;
+        }
+    };
+    float sv[2][OWN];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sv[mt][r] = 0.f;
+        for (int k = 0; k < OWN; ++k) {
             float g4[4];
 #pragma unroll
-            for (int Gt = 0; Gt < 4; ++Gt)
-                g4[Gt] = __shfl(acc[mt][Gt / GPT][r], (l31 % CPW) + CPW * (Gt % GPT) + 32 * half, 64);
+            for (int t = 0; t < TPW; ++t) {
+                float rows[GPT], val[GPT];
+#pragma unroll
+                for (int g = 0; g < GPT; ++g) rows[g] = acc[mt][t][k * GPT + g];
+                val[0] = pick(rows, grp);
+#pragma unroll
+                for (int x = 1; x < GPT; ++x) val[x] = __shfl_xor(pick(rows, grp ^ x), x * CPW, 64);
+#pragma unroll
+                for (int g = 0; g < GPT; ++g) g4[t * GPT + g] = pick(val, g ^ grp);
+            }
+            const int r = k * GPT + grp;
             const int i = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;       // anchor within the block
             const int ti = tw == 16 ? 0 : i >> 6, ay = tw == 16 ? i >> 4 : (i >> 3) & 7, ax = tw == 16 ? i & 15 : i & 7;
             const int m = ((b0 + ti) * H + y0 + ay) * W + x0 + ax;
-            if (grp == (r % GPT)) {
-                const size_t o = (size_t)m * C + ch;
-                const float aj = b_tanh(g4[0] + bj), ai = b_sigmoid(g4[1] + bi);
-                const float af = b_sigmoid(g4[2] + bf), ao = b_sigmoid(g4[3] + bo);
-                const float cn = d.cstate_in[o] * af + ai * aj;
-                d.cstate_out[o] = cn;
-                const float hn = b_tanh(cn) * ao;
-                d.hout[o] = hn;
-                sv[mt][r] = hn;
-                if (mt == 0) own |= 1u << r;
-                if (d.gates_out) {
-                    float* gp = d.gates_out + (size_t)m * 4 * C + ch;
-                    gp[0] = aj; gp[C] = ai; gp[2 * C] = af; gp[3 * C] = ao;
-                }
+            const size_t o = (size_t)m * C + ch;
+            const float aj = b_tanh(g4[0] + bj), ai = b_sigmoid(g4[1] + bi);
+            const float af = b_sigmoid(g4[2] + bf), ao = b_sigmoid(g4[3] + bo);
+            const float cn = cpre[mt][k] * af + ai * aj;
+            d.cstate_out[o] = cn;
+            const float hn = b_tanh(cn) * ao;
+            d.hout[o] = hn;
+            sv[mt][k] = hn;
+            if (d.gates_out) {
+                float* gp = d.gates_out + (size_t)m * 4 * C + ch;
+                gp[0] = aj; gp[C] = ai; gp[2 * C] = af; gp[3 * C] = ao;
             }
         }
     if (d.ln_part) {
         // (count, mean, M2) of the h values of each image of the tile; with two images wave pair wm owns image wm.
         float* red = reinterpret_cast<float*>(lds);
-        float s1 = 0.f, c1 = 0.f;
+        float s1 = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if ((own >> r) & 1) { s1 += sv[mt][r]; c1 += 1.f; }
-        s1 = wave_sum(s1); c1 = wave_sum(c1);
+            for (int k = 0; k < OWN; ++k) s1 += sv[mt][k];
+        s1 = wave_sum(s1);
+        const float c1 = 64.f * 2 * OWN;
         __syncthreads();
         if (lane == 0) { red[wave] = s1; red[4 + wave] = c1; }
         __syncthreads();
@@ -334,8 +379,7 @@ __global__ __launch_bounds__(256, 1) void convlstm_bf16_kernel(const IgemmDesc d
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if ((own >> r) & 1) { const float dd = sv[mt][r] - mean; q = fmaf(dd, dd, q); }
+            for (int k = 0; k < OWN; ++k) { const float dd = sv[mt][k] - mean; q = fmaf(dd, dd, q); }
         q = wave_sum(q);
         if (lane == 0) red[8 + wave] = q;
         __syncthreads();

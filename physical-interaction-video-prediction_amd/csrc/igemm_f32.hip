@@ -307,6 +307,23 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
     };
     auto sync = [&]() { keep(); if (ABL != 3) __syncthreads(); };
 
+    // ConvLSTM: bias and c_{t-1} of the cells this lane will update are requested here, in front of the K loop.  Read in the
+    // epilogue they cost one exposed HBM round trip per accumulator row, 16 in a row (measured on the bf16 kernel, where the
+    // epilogue was longer than the tap loop).  Lane (grp, channel) updates rows r = k * WN + grp of its wave tile (see the epilogue).
+    constexpr int OWNR = LSTM ? 16 / WN : 1;
+    float cpre[OWNR];
+    float bj = 0.f, bi = 0.f, bf = 0.f, bo = 0.f;
+    if constexpr (LSTM) {
+        const int C = d.C, ch = nblk * 32 + wn * CPW + (l31 % CPW), grp = l31 / CPW;
+        bj = d.bias[ch]; bi = d.bias[C + ch]; bf = d.bias[2 * C + ch] + 1.0f; bo = d.bias[3 * C + ch];
+#pragma unroll
+        for (int k = 0; k < OWNR; ++k) {
+            const int r = k * WN + grp;
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            cpre[k] = d.cstate_in[(size_t)(m < d.M ? m : d.M - 1) * C + ch];
+        }
+    }
+
     // prologue: chunk 0 straight into buffer 0, chunk 1 into register set 1
     if (nchunks > 0) {
         stage_begin(); load_all(S0{}); store_all(S0{}, 0);
@@ -362,33 +379,53 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
             p[0] = cnt; p[1] = mean; p[2] = (lds[8] + lds[9]) + (lds[10] + lds[11]); p[3] = 0.f;
         }
     };
-    if (LSTM) {
+    if constexpr (LSTM) {
+        // Accumulator row r of a lane is one anchor, its column (gate t * WN + grp, channel): the 4 gates of a cell sit in the WN
+        // lanes lane ^ (x * CPW) and the 4 / WN tiles.  Lane grp takes rows r = k * WN + grp: it keeps its own gate of that row
+        // and receives the others from its partners in WN - 1 xor-shuffles per tile, each partner sending the row its receiver
+        // owns.  Every lane updates one cell per k (no idle lanes; WN = 1 needs no exchange).  Register arrays are indexed
+        // statically; per-lane choices are select chains.
         const int C = d.C;
-        const int chl = wn * CPW + (l31 % CPW);
-        const int ch = nblk * 32 + chl;
-        const int grp = l31 / CPW;  // which gate-group of the tile this lane's column belongs to
-        const float bj = d.bias[ch], bi = d.bias[C + ch], bf = d.bias[2 * C + ch] + 1.0f, bo = d.bias[3 * C + ch];
-        float sv[16];          // this lane's h values (0 where it owns none), for the fused LayerNorm statistics
+        const int ch = nblk * 32 + wn * CPW + (l31 % CPW);
+        const int grp = l31 / CPW;
+        auto pick = [&](const float (&v)[WN], int idx) -> float {
+            if constexpr (WN == 1) {
+                return v[0];
+            } else if constexpr (WN == 2) {
+                return idx ? v[1] : v[0];
+            } else {
+                const float lo = (idx & 1) ? v[1] : v[0], hi = (idx & 1) ? v[3] : v[2];
+                return (idx & 2) ? hi : lo;
+            }
+        };
+        float sv[OWNR];        // this lane's h values, for the fused LayerNorm statistics
         unsigned own = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sv[r] = 0.f;
+        for (int k = 0; k < OWNR; ++k) {
             float g4[4];
 #pragma unroll
-            for (int G = 0; G < 4; ++G) {
-                const float v = acc[G / WN][r];
-                g4[G] = (WN == 1) ? v : __shfl(v, (l31 % CPW) + CPW * (G % WN) + 32 * half, 64);
+            for (int t = 0; t < 4 / WN; ++t) {
+                float rows[WN], val[WN];
+#pragma unroll
+                for (int g = 0; g < WN; ++g) rows[g] = acc[t][k * WN + g];
+                val[0] = pick(rows, grp);
+#pragma unroll
+                for (int x = 1; x < WN; ++x) val[x] = __shfl_xor(pick(rows, grp ^ x), x * CPW, 64);
+#pragma unroll
+                for (int g = 0; g < WN; ++g) g4[t * WN + g] = pick(val, g ^ grp);
             }
+            const int r = k * WN + grp;
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m < d.M && grp == (r % WN)) {
+            sv[k] = 0.f;
+            if (m < d.M) {
                 const size_t o = (size_t)m * C + ch;
                 const float aj = fast_tanh(g4[0] + bj), ai = fast_sigmoid(g4[1] + bi);
                 const float af = fast_sigmoid(g4[2] + bf), ao = fast_sigmoid(g4[3] + bo);
-                const float cn = d.cstate_in[o] * af + ai * aj;
+                const float cn = cpre[k] * af + ai * aj;
                 d.cstate_out[o] = cn;
                 const float hn = fast_tanh(cn) * ao;
                 d.hout[o] = hn;
-                sv[r] = hn; own |= 1u << r;
+                sv[k] = hn; own |= 1u << k;
                 if (d.gates_out) {   // training: keep the gate activations for BPTT, [pixel][gate][C]
                     float* gp = d.gates_out + (size_t)m * 4 * C + ch;
                     gp[0] = aj; gp[C] = ai; gp[2 * C] = af; gp[3 * C] = ao;
@@ -397,7 +434,7 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
         }
         if (d.ln_part) {
             const int b = m0 / HWg;
-            tile_stats(sv, own, std::integral_constant<int, 16>{}, b, ((m0 - b * HWg) / BM) * n_nblk + nblk);
+            tile_stats(sv, own, std::integral_constant<int, OWNR>{}, b, ((m0 - b * HWg) / BM) * n_nblk + nblk);
         }
     } else {
         const int oy0 = deconv ? py : 0, ox0 = deconv ? px : 0;
