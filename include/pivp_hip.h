@@ -29,7 +29,11 @@ extern "C" {
 #define PIVP_MODEL_STP 1
 #define PIVP_MODEL_DNA 2
 
-int pivp_abi_version(void);   /* 4 (2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback) */
+#define PIVP_PRECISION_F32 0
+#define PIVP_PRECISION_BF16 1
+
+int pivp_abi_version(void);   /* 5 (2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+                                 5: + bf16 ConvLSTM, pivp_plan_set_precision) */
 
 /* ------------------------------------------------------------------------------------------
  * Plan = Model.__init__ (TM:484-602): layer table, op program, variant head.
@@ -58,6 +62,13 @@ int pivp_param_count(const pivp_plan_t* plan);
 const char* pivp_param_name(const pivp_plan_t* plan, int idx);      /* Chainer save_npz key        */
 long long pivp_param_numel(const pivp_plan_t* plan, int idx);       /* elements in internal layout */
 int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr);
+
+/* Precision of the seven ConvLSTM gate convolutions (BASELINE.json config 3 asks for bf16): PIVP_PRECISION_F32 (default, the
+ * parity path) or PIVP_PRECISION_BF16 = x, h and the weights rounded to bf16 on the way into the matrix pipe, fp32 accumulation,
+ * gates and state.  All other ops, and the whole backward pass, stay fp32 on the fp32 parameters (the bf16 weight pack is rebuilt
+ * at the start of every rollout).  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
+int pivp_plan_set_precision(pivp_plan_t* plan, int precision);
+int pivp_plan_get_precision(const pivp_plan_t* plan);
 
 long long pivp_plan_workspace_bytes(const pivp_plan_t* plan);
 int pivp_plan_set_workspace(pivp_plan_t* plan, void* dptr, long long bytes);

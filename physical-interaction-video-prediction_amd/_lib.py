@@ -45,6 +45,8 @@ SIGNATURES = {
     'pivp_plan_set_grad_callback': (_i, [_vp, _vp, _vp]),
     'pivp_convlstm_ln_scratch_floats': (_ll, [_i, _i, _i, _i]),
     'pivp_convlstm_ln': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
+    'pivp_plan_set_precision': (_i, [_vp, _i]),
+    'pivp_plan_get_precision': (_i, [_vp]),
     'pivp_lstm_bf16_weight_elems': (_ll, [_i, _i]),
     'pivp_pack_lstm_bf16': (_i, [_vp, _vp, _i, _i, _vp]),
     'pivp_convlstm_bf16': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),

@@ -180,7 +180,7 @@ int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w
 
 }  // namespace pivp
 
-extern "C" int pivp_abi_version(void) { return 4; }   // 4: + pivp_param_group, pivp_plan_set_grad_callback
+extern "C" int pivp_abi_version(void) { return 5; }   // 5: + bf16 ConvLSTM entry points, pivp_plan_set_precision
 
 extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                              const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream) {

@@ -72,6 +72,8 @@ struct pivp_plan {
     Grads g;
     bool has_grads;
     size_t o_zero, o_lnpart, o_linpart, o_masks, o_losspart;
+    size_t o_wbf16[7];                // bf16 packs of the ConvLSTM weights (pivp_plan_set_precision), rebuilt at the start of a rollout
+    int lstm_bf16 = 0;
     pivp_grad_group_cb grad_cb = nullptr; void* grad_cb_user = nullptr;   // gradient-group-final notifications (t = 0 sweep)
     int loss_nparts;
     int last_steps;
@@ -153,6 +155,8 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
     p->o_masks = carve((size_t)B * p->NP * HW);
     p->loss_nparts = loss_partials_count((int)(B * 3 * HW));
     p->o_losspart = carve((size_t)T * p->loss_nparts);
+    for (int i = 0; i < 7; ++i)       // 2-byte elements in a float-counted workspace
+        p->o_wbf16[i] = carve((lstm_bf16_weight_elems(kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C) + 1) / 2);
     p->nslabs = train ? T - 1 : 2;
     p->slabs.resize(p->nslabs);
     for (int s = 0; s < p->nslabs; ++s) {
@@ -226,6 +230,26 @@ extern "C" int pivp_plan_set_grad(pivp_plan_t* plan, int idx, float* dptr) {
     plan->params[idx].grad = dptr;
     return PIVP_OK;
 }
+// Precision of the ConvLSTM gate convolutions (95 % of the FLOPs): PIVP_PRECISION_F32 (default) or PIVP_PRECISION_BF16 = operands
+// rounded to bf16, fp32 accumulation / gates / state (csrc/convlstm_bf16.hip).  Everything else, and the whole backward pass,
+// stays fp32 on the fp32 parameters.  Refused when a layer's map does not fit the bf16 kernel's tiles (8-wide maps need an even batch).
+extern "C" int pivp_plan_set_precision(pivp_plan_t* plan, int precision) {
+    if (!plan || (precision != PIVP_PRECISION_F32 && precision != PIVP_PRECISION_BF16)) return PIVP_ERR_BADARG;
+    if (precision == PIVP_PRECISION_BF16) {
+        const int hs[7] = {plan->H2, plan->H2, plan->H4, plan->H4, plan->H8, plan->H4, plan->H2};
+        const int wsz[7] = {plan->W2, plan->W2, plan->W4, plan->W4, plan->W8, plan->W4, plan->W2};
+        for (int i = 0; i < 7; ++i) {
+            IgemmDesc d;
+            memset(&d, 0, sizeof(d));
+            d.ksize = 5; d.pad = 2; d.in_step = 1; d.C = kLstm[i].C; d.c0 = kLstm[i].cx; d.c1 = kLstm[i].C;
+            d.ld0 = 4; d.ld1 = 4; d.B = plan->cfg.batch; d.Hin = hs[i]; d.Win = wsz[i];
+            if (!convlstm_bf16_ok(d)) return PIVP_ERR_BADARG;
+        }
+    }
+    plan->lstm_bf16 = precision == PIVP_PRECISION_BF16;
+    return PIVP_OK;
+}
+extern "C" int pivp_plan_get_precision(const pivp_plan_t* plan) { return plan ? plan->lstm_bf16 : PIVP_ERR_BADARG; }
 extern "C" long long pivp_plan_workspace_bytes(const pivp_plan_t* plan) { return plan ? plan->ws_floats * 4 : PIVP_ERR_BADARG; }
 extern "C" int pivp_plan_set_workspace(pivp_plan_t* plan, void* dptr, long long bytes) {
     if (!plan || !dptr || bytes < plan->ws_floats * 4 || ((uintptr_t)dptr & 255)) return PIVP_ERR_BADARG;
@@ -264,7 +288,8 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
         // the LayerNorm behind every ConvLSTM gets its statistics from the ConvLSTM epilogue (np partials per sample)
         int rc = run_convlstm(x, kLstm[i].cx, ldx, hp(i), kLstm[i].C, P(p, p->i_lstm_w[i]), P(p, p->i_lstm_b[i]),
                               cp(i), ws + S.c[i], ws + S.h[i], B, hh, wwid, s, 0, train ? ws + S.gates[i] : nullptr,
-                              lnp, ln_cap, &np);
+                              lnp, ln_cap, &np,
+                              p->lstm_bf16 ? reinterpret_cast<const unsigned short*>(ws + p->o_wbf16[i]) : nullptr);
         if (prof) {
             (void)hipEventRecord(p->prof_ev[p->prof_used + 1], s);
             p->prof_layer[p->prof_used / 2] = i + (Sp ? 0 : 8);   // +8: first-step launch without the h half of K
@@ -356,6 +381,10 @@ extern "C" int pivp_rollout_forward(pivp_plan_t* plan, const float* images, cons
     const pivp_config_t& c = plan->cfg;
     const int B = c.batch, T = c.seq_len, ctx = c.context_frames;
     const size_t fr = (size_t)B * 3 * c.height * c.width;
+    if (plan->lstm_bf16)            // the parameters may have changed since the last call (optimizer step, checkpoint load)
+        for (int i = 0; i < 7; ++i)
+            RC(pack_lstm_bf16(P(plan, plan->i_lstm_w[i]), reinterpret_cast<unsigned short*>(plan->ws + plan->o_wbf16[i]),
+                              kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C, s));
     for (int t = 0; t < T - 1; ++t) {
         if (t >= ctx && gt_select)                                     // TM:667-670
             RC(run_select_frames(images + t * fr, gen_images + (t - 1) * fr, gt_select + (size_t)t * B,

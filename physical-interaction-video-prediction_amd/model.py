@@ -137,7 +137,7 @@ class Model(object):
 
     def __init__(self, num_masks, is_cdna=True, is_dna=False, is_stp=False, use_state=True,
                  scheduled_sampling_k=-1, num_frame_before_prediction=2, prefix=None,
-                 device='cuda:0', ln_eps=1e-6, stp_border='clamp', keep_activations=False):
+                 device='cuda:0', ln_eps=1e-6, stp_border='clamp', keep_activations=False, precision='fp32'):
         if is_cdna:                      # TM:531-542, precedence cdna > stp > dna
             self.model_type = 'CDNA'
         elif is_stp:
@@ -157,6 +157,12 @@ class Model(object):
             raise ValueError("stp_border must be 'clamp' or 'zeros'")
         self.stp_border = stp_border
         self.keep_activations = bool(keep_activations)
+        # 'fp32' is the parity path (per-pixel L2 < 1e-4 vs the reference).  'bf16' (BASELINE.json config 3) rounds the operands of
+        # the seven ConvLSTM gate convolutions to bf16 -- fp32 accumulation, gates, state, every other op and the whole backward
+        # pass stay fp32 -- and reports, not gates, its error.
+        if precision not in ('fp32', 'bf16'):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
         self._ref_pending = None       # reference-layout arrays loaded before the first call
         self._params = None            # name -> view into _flat_params (internal layout)
         self._flat_params = None
@@ -291,6 +297,8 @@ class Model(object):
                                   keep_activations=1 if self.keep_activations else 0,
                                   ln_eps=self.ln_eps, stp_zero_border=1 if self.stp_border == 'zeros' else 0)
             plan = _Plan(lib, cfg)
+            if self.precision == 'bf16':
+                _lib.check(lib.pivp_plan_set_precision(plan.h, 1), 'pivp_plan_set_precision(bf16)')
             nbytes = lib.pivp_plan_workspace_bytes(plan.h)
             plan.workspace = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.device)
             base = plan.workspace.data_ptr()

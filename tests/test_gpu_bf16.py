@@ -106,3 +106,80 @@ def test_convlstm_bf16_rejects_bad_shapes(ops):
     x, h, c, W, b = _case(2, 32, 32, 12, 1)                         # H % 8 != 0
     with pytest.raises(RuntimeError):
         ops.convlstm_bf16(x, h, c, W, b)
+
+
+# ---- whole rollout in the bf16 precision mode (BASELINE.json config 3) ---------------------------------------------------
+GOLD = __import__('os').path.join(__import__('os').path.dirname(__file__), 'golden')
+
+
+def _rollout(precision, mt='CDNA', nm=10, B=2, T=10, train=False, keep=False, smooth=False):
+    import pivp_amd
+    P = R.init_params(seed=1, dtype=np.float32, scale=1.0, num_masks=nm, model_type=mt)
+    imgs, acts, stas = R.synthetic_batch(B, T)
+    if smooth:                          # video-like frames (11x11 box blur of the noise), as tests/test_gpu_model.py's STP case
+        from numpy.lib.stride_tricks import sliding_window_view
+        pad = np.pad(imgs, ((0, 0), (0, 0), (0, 0), (5, 5), (5, 5)), mode='reflect')
+        imgs = np.ascontiguousarray(sliding_window_view(pad, (11, 11), axis=(3, 4)).mean(axis=(-1, -2))).astype(np.float32)
+    m = pivp_amd.Model(nm, is_cdna=mt == 'CDNA', is_stp=mt == 'STP', is_dna=mt == 'DNA', prefix='test', precision=precision,
+                       keep_activations=keep)
+    m.load_state_dict_reference(P)
+    with pivp_amd.using_config('train', train):
+        loss = m([imgs, acts, stas], 0)
+    return m, float(loss), torch.stack(m.gen_images).cpu().numpy()
+
+
+def test_rollout_bf16_reports_error_against_the_golden_fixture():
+    # config 1's golden rollout (float64 oracle): the bf16 mode is not held to the 1e-4 gate ("bf16 config
+    # reports its error"); the bound below only guards against a broken kernel, the printed numbers are the report
+    g = np.load(__import__('os').path.join(GOLD, 'cdna_b2_t10.npz'))
+    m32, loss32, gen32 = _rollout('fp32')
+    m16, loss16, gen16 = _rollout('bf16')
+    l2_32 = R.per_pixel_l2(gen32, g['gen_images']); l2_16 = R.per_pixel_l2(gen16, g['gen_images'])
+    print('per-pixel L2 vs float64 oracle: fp32 max %.2e rms %.2e | bf16 max %.2e rms %.2e | loss %.6f / %.6f / %.6f'
+          % (l2_32.max(), np.sqrt((l2_32 ** 2).mean()), l2_16.max(), np.sqrt((l2_16 ** 2).mean()), float(g['loss']), loss32, loss16))
+    assert l2_32.max() < 1e-4
+    assert 1e-6 < l2_16.max() < 5e-2            # bf16 really ran, and is a rounding-level perturbation
+    assert abs(loss16 - float(g['loss'])) < 1e-3
+    assert m16._active.lib.pivp_plan_get_precision(m16._active.h) == 1
+    assert m32._active.lib.pivp_plan_get_precision(m32._active.h) == 0
+
+
+@pytest.mark.parametrize('mt,nm', [('STP', 10), ('DNA', 1)])
+def test_rollout_bf16_other_heads(mt, nm):
+    # STP warps the previous frame bilinearly: on white-noise frames a 1e-3 change of the affine parameters moves O(1) pixel
+    # values (tests/test_gpu_model.py has the fp32 analysis), so the STP comparison uses smooth frames
+    _, l32, g32 = _rollout('fp32', mt, nm, T=4, smooth=mt == 'STP')
+    _, l16, g16 = _rollout('bf16', mt, nm, T=4, smooth=mt == 'STP')
+    l2 = R.per_pixel_l2(g16, g32)
+    rms = float(np.sqrt((l2 ** 2).mean()))
+    print('%s bf16 vs fp32 rollout: per-pixel L2 max %.2e rms %.2e' % (mt, l2.max(), rms))
+    # (measured: DNA max 2.5e-2; STP max 1.5e-1 at a few pixels where the warp crosses an edge, rms an order below)
+    assert 1e-7 < l2.max() < (5e-1 if mt == 'STP' else 5e-2) and rms < 2e-2 and abs(l16 - l32) < 1e-3
+
+
+def test_train_step_in_bf16_mode_tracks_fp32():
+    # forward gate convolutions in bf16, backward in fp32 on the fp32 parameters: gradients stay close to the fp32 path's
+    import pivp_amd
+    outs = {}
+    for prec in ('fp32', 'bf16'):
+        m, loss, _ = _rollout(prec, T=4, train=True, keep=True)
+        with pivp_amd.using_config('train', True):
+            m.backward()
+        outs[prec] = (loss, m._flat_grads.clone())
+    g32, g16 = outs['fp32'][1], outs['bf16'][1]
+    rel = float((g16 - g32).norm() / g32.norm())
+    print('bf16-forward train step: loss %.6f vs %.6f, relative gradient difference %.2e' % (outs['bf16'][0], outs['fp32'][0], rel))
+    assert abs(outs['bf16'][0] - outs['fp32'][0]) < 1e-3
+    assert 1e-6 < rel < 5e-2
+
+
+def test_bf16_precision_refused_for_unsupported_geometry():
+    import pivp_amd
+    P = R.init_params(seed=1, dtype=np.float32, scale=1.0, num_masks=10, model_type='CDNA')
+    imgs, acts, stas = R.synthetic_batch(1, 3)                      # 8-wide lstm5 map with an odd batch
+    m = pivp_amd.Model(10, precision='bf16', prefix='t')
+    m.load_state_dict_reference(P)
+    with pytest.raises(RuntimeError):
+        m([imgs, acts, stas], 0)
+    with pytest.raises(ValueError):
+        pivp_amd.Model(10, precision='fp16')
