@@ -27,13 +27,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int PP = 144;                // patch pixel pitch (bytes): 64 bf16 + 16
 constexpr int TH = 8, PH = TH + 4;     // anchor rows per tile, patch rows
-constexpr int MAXPIX = 2 * PH * 12;    // 288 patch pixels (two 8x8 images); one 8x16 tile has 12 * 20 = 240
+constexpr int NPJ = 5;                 // patch pixels per staging thread (512 threads = 64 pixels x 8 pieces per pass)
+constexpr int MAXPIX = NPJ * 64;       // 320 allocated; two 8x8 images need 2 * 12 * 12 = 288, one 8x16 tile 12 * 20 = 240
 constexpr int PATCH_BYTES = MAXPIX * PP;
 constexpr int NSLOT = 4, DEPTH = 3;    // weight ring slots; taps of prefetch
-#ifndef PIVP_BF16_ABL
-#define PIVP_BF16_ABL 0             // timing-only ablations (scripts/bench_lstm_layers.py): 1 no weight DMAs in the loop, 2 no MFMAs,
-#endif                              // 3 no fragment reads in the loop, 4 no epilogue, 6 neither loop nor epilogue (prologue only)
-
 
 __device__ __forceinline__ float b_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float b_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
@@ -75,18 +72,22 @@ __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned shor
 }
 
 template <int NCH>
-__global__ __launch_bounds__(256, 1) void convlstm_bf16_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int tw) {
+__global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int tw) {
     constexpr int BN = 4 * NCH;                 // block columns: [gate][channel]
     constexpr int SLOT = BN * 128;              // bytes of one ring slot: BN rows x 64 bf16
-    constexpr int G = BN / 32;                  // global_load_lds per thread and tap
+    constexpr int G = BN / 32;                  // global_load_lds per loader thread and tap
     constexpr int TPW = NCH / 16;               // MFMA column tiles per wave
     constexpr int CPW = NCH / 2;                // channels per wave (all 4 gates of a channel stay in one wave)
     constexpr int GPT = 32 / CPW;               // gates per MFMA tile
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // patch | ring
     unsigned char* const patch = lds;
-    unsigned char* const ring = lds + PATCH_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // waves 0..3 multiply (2 x 2 over the 128 x BN block tile), waves 4..7 only feed the weight ring: a global_load_lds costs
+    // 60-180 cycles of its wave's issue time, which in a multiplying wave is time the matrix pipe idles (4 per tap: a quarter
+    // of the tap); issued by a second wave of the same SIMD they overlap the MFMAs.
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave8 >= 4;
+    const int wave = wave8 & 3;
     const int wm = wave & 1, wn = wave >> 1;
     const int half = lane >> 5, l31 = lane & 31;
     const int C = d.C, N = d.N, n_nblk = C / NCH;
@@ -111,75 +112,115 @@ __global__ __launch_bounds__(256, 1) void convlstm_bf16_kernel(const IgemmDesc d
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.c1 ? d.x1 : d.x0), 0, d.c1 ? d.bytes1 : d.bytes0, 0x00020000);
     constexpr unsigned OOB = 0xC0000000u;
 
-    // ---- patch staging roles: thread = (pixel (tid >> 3) + 32 j, 8-channel piece tid & 7), j < 9 ------------------------
+    // ---- patch staging (all 8 waves): thread = (pixel (tid >> 3) + 64 j, 8-channel piece tid & 7), j < 5 -------------------
     const int cpiece = tid & 7;
-    int a_pix[9];                                      // global pixel index, or -1 outside the image / past the patch
+    int a_pix[NPJ];                                    // global pixel index, or -1 outside the image / past the patch
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        const int p = (tid >> 3) + 32 * j;
+    for (int j = 0; j < NPJ; ++j) {
+        const int p = (tid >> 3) + 64 * j;
         const int ti = p / (PH * PW), pr = p - ti * (PH * PW);
         const int py = pr / PW, px = pr - py * PW;
         const int iy = y0 - 2 + py, ix = x0 - 2 + px;
         const bool ok = p < npix && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
         a_pix[j] = ok ? ((b0 + ti) * H + iy) * W + ix : -1;
     }
-    auto stage_patch = [&](int cg) {
+    f32x4 plo[NPJ], phi[NPJ];                          // a patch in flight (live only between the two halves of a staging)
+    auto patch_load = [&](int cg) {
         const int ch = cg * 64 + cpiece * 8;           // first of this thread's 8 channels of concat(x, h)
         const bool s0 = ch < c0, s1 = !s0 && ch < cin;
         const int ld = s0 ? ld0 : ld1, co = s0 ? ch : ch - c0;
-        f32x4 lo[9], hi[9];
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
+        for (int j = 0; j < NPJ; ++j) {
             const unsigned off = (a_pix[j] >= 0 && (s0 || s1)) ? (unsigned)((a_pix[j] * ld + co) * 4) : OOB;
             if (s0) {
-                lo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
-                hi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 16, 0));
+                plo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
+                phi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 16, 0));
             } else {
-                lo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
-                hi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 16, 0));
+                plo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
+                phi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 16, 0));
             }
         }
+    };
+    auto patch_store = [&]() {
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            // unconditional (9 * 32 = MAXPIX pixels are allocated; pixels past npix receive zeros): a predicated write leaves the
-            // loads "pending" on the skipped path for hipcc's wait-count pass, which then drains vmcnt inside the tap loop
-            const int p = (tid >> 3) + 32 * j;
+        for (int j = 0; j < NPJ; ++j) {
+            // unconditional (NPJ * 64 = MAXPIX pixels are allocated; pixels past npix receive zeros): a predicated write leaves
+            // the loads "pending" on the skipped path for hipcc's wait-count pass, which then drains vmcnt inside the tap loop
+            const int p = (tid >> 3) + 64 * j;
             uint4 v;
-            v.x = pack2(lo[j][0], lo[j][1]); v.y = pack2(lo[j][2], lo[j][3]);
-            v.z = pack2(hi[j][0], hi[j][1]); v.w = pack2(hi[j][2], hi[j][3]);
+            v.x = pack2(plo[j][0], plo[j][1]); v.y = pack2(plo[j][2], plo[j][3]);
+            v.z = pack2(phi[j][0], phi[j][1]); v.w = pack2(phi[j][2], phi[j][3]);
             *reinterpret_cast<uint4*>(patch + p * PP + cpiece * 16) = v;
         }
     };
 
-    // ---- weight ring: DMA j of a tap writes ring bytes [(j * 256 + tid) * 16, +16): row (j * 32 + tid / 8), piece tid % 8,
-    // which holds SOURCE piece (tid % 8) ^ (row % 8) of that row ------------------------------------------------------------
-    const unsigned char* wsrc[G];
-#pragma unroll
-    for (int j = 0; j < G; ++j) {
-        const int row = j * 32 + (tid >> 3), g = row / NCH, cl = row - g * NCH;
-        const int piece = (tid & 7) ^ (row & 7);
-        wsrc[j] = reinterpret_cast<const unsigned char*>(wb) + ((size_t)(g * C + nblk * NCH + cl)) * 128 + piece * 16;
-    }
-    const size_t wstep = (size_t)N * 128;              // bytes between consecutive (group, tap) weight tiles
     // Every block walks the 25 taps of a channel group in its own rotation (tap0, tap0 + 1, ... mod 25): blocks that run in
     // step would otherwise all pull the same 16 KB of weights out of the same few L2 channels at the same time.
     const int tap0 = (lid * 7) % 25;
-    int issued = 0;                                    // taps whose DMAs have been issued
-    int i_tap = tap0, i_cg = 0;                        // ... the next one to issue
-    auto issue_weights = [&]() {
-        const int slot = issued & (NSLOT - 1);
-        const size_t goff = (size_t)(i_cg * 25 + i_tap) * wstep;
-        i_tap = i_tap == 24 ? 0 : i_tap + 1;
-        i_cg += i_tap == tap0 ? 1 : 0;
+
+    // =========================================================================================================================
+    // loader waves: DMA j of a tap writes ring bytes [(j * 256 + lt) * 16, +16): row (j * 32 + lt / 8), piece lt % 8, which holds
+    // SOURCE piece (lt % 8) ^ (row % 8) of that row (lt = thread index within the four loader waves)
+    // =========================================================================================================================
+    if (loader) {
+        const int lt = tid - 256;
+        unsigned char* const ring = lds + PATCH_BYTES;
+        const unsigned char* wsrc[G];
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-            unsigned char* dst = ring + slot * SLOT + (j * 256 + wave * 64) * 16;    // wave-uniform; the DMA adds lane * 16
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + goff),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            const int row = j * 32 + (lt >> 3), g = row / NCH, cl = row - g * NCH;
+            const int piece = (lt & 7) ^ (row & 7);
+            wsrc[j] = reinterpret_cast<const unsigned char*>(wb) + ((size_t)(g * C + nblk * NCH + cl)) * 128 + piece * 16;
         }
-        ++issued;
-    };
+        const size_t wstep = (size_t)N * 128;          // bytes between consecutive (group, tap) weight tiles
+        int issued = 0, i_tap = tap0, i_cg = 0;        // taps issued; the next one to issue
+        auto issue_weights = [&]() {
+            const int slot = issued & (NSLOT - 1);
+            const size_t goff = (size_t)(i_cg * 25 + i_tap) * wstep;
+            i_tap = i_tap == 24 ? 0 : i_tap + 1;
+            i_cg += i_tap == tap0 ? 1 : 0;
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                unsigned char* dst = ring + slot * SLOT + (j * 256 + wave * 64) * 16;    // wave-uniform; the DMA adds lane * 16
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + goff),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+            ++issued;
+        };
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i)
+            if (i < nchunks) issue_weights();
+        patch_load(0);
+        patch_store();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // taps 0..2 and this thread's part of the patch are in LDS
+        __builtin_amdgcn_s_barrier();
+        int tap = tap0, cg = 0;
+        for (int it = 0; it < nchunks; ++it) {
+            // the multiplying waves' mid-tap barrier publishes tap it + 1: this wave's share of it must have landed.  Outstanding
+            // here: taps it + 1 and it + 2 (when they exist).
+            if (it + 2 < nchunks) {
+                if constexpr (G == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            // every multiplying wave is past tap it - 1: its ring slot takes tap it + 3
+            if (it + DEPTH < nchunks) issue_weights();
+            tap = tap == 24 ? 0 : tap + 1;
+            if (tap == tap0 && ++cg < ncg) {           // next 64 input channels: all 8 waves restage the patch
+                __syncthreads();
+                patch_load(cg);
+                patch_store();
+                __syncthreads();
+            }
+        }
+        return;                                        // (the last iteration drained this wave's DMAs)
+    }
 
+    // =========================================================================================================================
+    // multiplying waves
+    // =========================================================================================================================
     f32x16 acc[2][TPW];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -204,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void convlstm_bf16_kernel(const IgemmDesc d
     for (int ks = 0; ks < 4; ++ks) b_sw[ks] = ((2 * ks + half) ^ (l31 & 7)) * 16;    // row % 8 == l31 % 8 (NCH, CPW multiples of 8)
 
     // LDS reads go through inline asm: hipcc knows that an LDS-DMA writes LDS and puts s_waitcnt vmcnt(0) in front of every
-    // ds_read it can see, which would drain the prefetch every tap.  The waits below are explicit instead.
+    // ds_read it can see.  The waits below are explicit instead.
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     bf16x8 fa[2][2], fb[2][TPW];                       // [register set][tile]
     auto wait_frags = [&](auto SET) {
@@ -214,7 +255,6 @@ __global__ __launch_bounds__(256, 1) void convlstm_bf16_kernel(const IgemmDesc d
     };
     auto read_frags = [&](auto SET, auto KS, int tp, int slot) {   // fragments of k-step KS of tap tp (weights in ring slot `slot`)
         constexpr int st = decltype(SET)::value, ks = decltype(KS)::value;
-        if (PIVP_BF16_ABL == 3 && issued > DEPTH) return;
         const int ty = tp / 5, tx = tp - ty * 5;
         const unsigned ab = lds0 + (ty * PW + tx) * PP;
         const unsigned bb = lds0 + PATCH_BYTES + slot * SLOT + b_sw[ks];
@@ -225,7 +265,6 @@ __global__ __launch_bounds__(256, 1) void convlstm_bf16_kernel(const IgemmDesc d
     };
     auto mfmas = [&](auto SET) {
         constexpr int st = decltype(SET)::value;
-        if constexpr (PIVP_BF16_ABL == 2) return;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -236,10 +275,10 @@ __global__ __launch_bounds__(256, 1) void convlstm_bf16_kernel(const IgemmDesc d
     using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
     using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
 
-    // ---- prologue: patch of channel group 0, weights of taps 0..2 -----------------------------------------------------------
-    stage_patch(0);
-    // The epilogue's c_{t-1} values are requested here, behind the patch loads: read in the epilogue they cost one exposed HBM round
-    // trip per accumulator row (16-32 in a row), more than the whole tap loop.  Lane (grp, channel) owns rows r with r % GPT == grp.
+    // ---- prologue: this thread's part of the patch, the epilogue's operands ---------------------------------------------------
+    // bias and c_{t-1} are requested here: read in the epilogue they cost one exposed HBM round trip per accumulator row
+    // (16-32 in a row), more than the whole tap loop.  Lane (grp, channel) owns accumulator rows r with r % GPT == grp.
+    patch_load(0);
     const int chl = wn * CPW + (l31 % CPW);
     const int ch = nblk * NCH + chl;
     const int grp = l31 / CPW;
@@ -256,37 +295,22 @@ __global__ __launch_bounds__(256, 1) void convlstm_bf16_kernel(const IgemmDesc d
             const int m = ((b0 + ti) * H + y0 + ay) * W + x0 + ax;
             cpre[mt][k] = d.cstate_in[(size_t)m * C + ch];
         }
-#pragma unroll
-    for (int i = 0; i < DEPTH; ++i)
-        if (i < nchunks) issue_weights();
-    if (nchunks >= DEPTH) {                            // taps 0 and 1 landed
-        if constexpr (G == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
+    patch_store();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // patch and taps 0..2 are in LDS
     read_frags(S0{}, K0{}, tap0, 0);
 
     // One tap = 4 k-steps of 16 channels; fragments of the next k-step are requested before the MFMAs of the current one.  The
     // barrier that publishes the NEXT tap's weights sits in the middle of the tap (its skew hides behind queued MFMAs), so the
-    // first fragments of the next tap can be requested right after the last k-step: at that barrier every wave is past tap it - 1,
-    // whose ring slot then takes the DMAs of tap it + 3.
+    // first fragments of the next tap can be requested right after the last k-step.  No VMEM instruction in this loop.
     int tap = tap0, cg = 0;
-    for (int it = 0; it < (PIVP_BF16_ABL == 6 ? 0 : nchunks); ++it) {
+    for (int it = 0; it < nchunks; ++it) {
         const int slot = it & (NSLOT - 1);
         wait_frags(S0{}); read_frags(S1{}, K1{}, tap, slot); mfmas(S0{});
         __builtin_amdgcn_sched_barrier(0);
         wait_frags(S1{}); read_frags(S0{}, K2{}, tap, slot); mfmas(S1{});
         __builtin_amdgcn_sched_barrier(0);
-        if (it + 2 < nchunks) {                        // DMAs of taps it + 1, it + 2 outstanding: it + 1 must have landed
-            if constexpr (G == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
         __builtin_amdgcn_s_barrier();
-        if (PIVP_BF16_ABL != 1 && it + DEPTH < nchunks) issue_weights();
         __builtin_amdgcn_sched_barrier(0);
         wait_frags(S0{}); read_frags(S1{}, K3{}, tap, slot); mfmas(S0{});
         __builtin_amdgcn_sched_barrier(0);
@@ -295,17 +319,16 @@ __global__ __launch_bounds__(256, 1) void convlstm_bf16_kernel(const IgemmDesc d
         wait_frags(S1{});
         if (!regroup) read_frags(S0{}, K0{}, tap, (it + 1) & (NSLOT - 1));
         mfmas(S1{});
-        if (regroup && ++cg < ncg) {                   // next 64 input channels: restage the patch
+        if (regroup && ++cg < ncg) {                   // next 64 input channels: all 8 waves restage the patch
             __syncthreads();                           // every wave is done with the old patch
-            stage_patch(cg);
+            patch_load(cg);
+            patch_store();
             __syncthreads();
             read_frags(S0{}, K0{}, tap, (it + 1) & (NSLOT - 1));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    if (PIVP_BF16_ABL == 6) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // it skipped the loop's own drain
-    if (PIVP_BF16_ABL == 4 || PIVP_BF16_ABL == 6) { if (acc[0][0][0] == 123.f) d.hout[0] = 0.f; return; }
     // ---- epilogue: gates, state update, optional gate activations and LayerNorm partial ----------------------------------
     // Accumulator row r of a lane is one anchor; its column is (gate t * GPT + grp, channel): the 4 gates of an (anchor, channel)
     // sit in the GPT lanes lane ^ (x * CPW) and the TPW tiles.  Lane grp takes rows r = k * GPT + grp: it keeps its own gate of
@@ -429,7 +452,7 @@ static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
     const int blocks = (d.B / ti_n) * tpi * nb;
-    hipLaunchKernelGGL(convlstm_bf16_kernel<NCH>, dim3(blocks), dim3(256), lds_bytes, stream, dd, wb, tw);
+    hipLaunchKernelGGL(convlstm_bf16_kernel<NCH>, dim3(blocks), dim3(512), lds_bytes, stream, dd, wb, tw);
     return PIVP_LAUNCH_STATUS();
 }
 
