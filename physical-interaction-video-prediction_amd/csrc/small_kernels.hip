@@ -213,6 +213,19 @@ __global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__
                                                        float* __restrict__ stat_out, int S) {
     __shared__ float stat[2];
     const int s = blockIdx.x, b = blockIdx.y;   // S partials per sample: ln_stats slices, or the tiles of a producer
+    // The slice's x, gamma and beta do not depend on the statistics: all twelve 16-B loads of a thread are requested first (clamped,
+    // unpredicated), so the merge of the partials below runs under their round trip instead of in front of four more.
+    const float* xb = x + (size_t)b * n;
+    const int base = s * LN_SLICE;
+    const int cnt = min(LN_SLICE, n - base);    // multiple of 4, >= 4
+    f32x4 v[4], g[4], be[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = base + min((j * 256 + (int)threadIdx.x) * 4, cnt - 4);
+        v[j] = *reinterpret_cast<const f32x4*>(xb + idx);
+        g[j] = *reinterpret_cast<const f32x4*>(gamma + idx);
+        be[j] = *reinterpret_cast<const f32x4*>(beta + idx);
+    }
     if (threadIdx.x < 64) {
         float mean, rstd;
         if (S > 0) ln_merge_partials(partials, b, S, eps, mean, rstd);
@@ -224,22 +237,16 @@ __global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__
     }
     __syncthreads();
     const float mean = stat[0], rstd = stat[1];
-    const float* xb = x + (size_t)b * n;
-    const int base = s * LN_SLICE;
-    const int cnt = min(LN_SLICE, n - base);
     const size_t pix0 = (size_t)b * (n / C);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int i = (j * 256 + threadIdx.x) * 4;
         if (i < cnt) {
             const int idx = base + i;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xb + idx);
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + idx);
-            const f32x4 be = *reinterpret_cast<const f32x4*>(beta + idx);
             f32x4 y;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float t = (v[e] - mean) * rstd * g[e] + be[e];
+                float t = (v[j][e] - mean) * rstd * g[j][e] + be[j][e];
                 y[e] = relu ? fmaxf(t, 0.f) : t;
             }
             const int pix = idx / C, ch = idx - pix * C;
