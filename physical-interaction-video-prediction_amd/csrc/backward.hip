@@ -6,7 +6,7 @@
 
 namespace pivp {
 
-__device__ __forceinline__ float fast_tanh_b(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+__device__ __forceinline__ float fast_tanh_b(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 // ------------------------------------------------------------------------------------------
 // ConvLSTM gate math backward (TM:269-272):  c' = c*f + i*j,  h = tanh(c')*o  with the stored activations

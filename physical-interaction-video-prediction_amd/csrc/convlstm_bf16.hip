@@ -32,8 +32,8 @@ constexpr int MAXPIX = NPJ * 64;       // 320 allocated; two 8x8 images need 2 *
 constexpr int PATCH_BYTES = MAXPIX * PP;
 constexpr int NSLOT = 4, DEPTH = 3;    // weight ring slots; taps of prefetch
 
-__device__ __forceinline__ float b_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float b_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+__device__ __forceinline__ float b_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float b_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {   // two fp32 -> packed bf16, round to nearest even
     f32x2 v = {a, b};
@@ -71,6 +71,13 @@ __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned shor
     wb[i] = __builtin_bit_cast(unsigned short, h);
 }
 
+#ifdef PIVP_BF16_STAMPS   // in-kernel phase stamps of one block's wave 0 (scripts/bf16_stamps.py)
+__device__ long long pivp_bf16_stamps[8];
+#define BF_STAMP(i) do { if (lid == 37 && tid == 0) pivp_bf16_stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define BF_STAMP(i)
+#endif
+
 template <int NCH>
 __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int tw) {
     constexpr int BN = 4 * NCH;                 // block columns: [gate][channel]
@@ -103,6 +110,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     const int nblk = lid / n_tiles, tile = lid - nblk * n_tiles;
     const int b0 = (tile / tpi) * ti_n, trem = tile - (tile / tpi) * tpi;
     const int y0 = (trem / tpr) * TH, x0 = (trem - (trem / tpr) * tpr) * tw;
+    BF_STAMP(0);
     const int c0 = d.c0, ld0 = d.ld0, ld1 = d.ld1;
     const int cin = c0 + d.c1;
     const int ncg = (cin + 63) >> 6;
@@ -297,7 +305,9 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         }
     patch_store();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    BF_STAMP(1);
     __builtin_amdgcn_s_barrier();                      // patch and taps 0..2 are in LDS
+    BF_STAMP(2);
     read_frags(S0{}, K0{}, tap0, 0);
 
     // One tap = 4 k-steps of 16 channels; fragments of the next k-step are requested before the MFMAs of the current one.  The
@@ -329,6 +339,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    BF_STAMP(3);
     // ---- epilogue: gates, state update, optional gate activations and LayerNorm partial ----------------------------------
     // Accumulator row r of a lane is one anchor; its column is (gate t * GPT + grp, channel): the 4 gates of an (anchor, channel)
     // sit in the GPT lanes lane ^ (x * CPW) and the TPW tiles.  Lane grp takes rows r = k * GPT + grp: it keeps its own gate of
@@ -377,6 +388,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
                 gp[0] = aj; gp[C] = ai; gp[2 * C] = af; gp[3 * C] = ao;
             }
         }
+    BF_STAMP(4);
     if (d.ln_part) {
         // (count, mean, M2) of the h values of each image of the tile; with two images wave pair wm owns image wm.
         float* red = reinterpret_cast<float*>(lds);
@@ -417,6 +429,14 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         }
     }
 }
+
+#ifdef PIVP_BF16_STAMPS
+}
+extern "C" int pivp_debug_bf16_stamps(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pivp::pivp_bf16_stamps), 8 * sizeof(long long)) == hipSuccess ? 0 : -2;
+}
+namespace pivp {
+#endif
 
 size_t lstm_bf16_weight_elems(int wcin, int N) { return (size_t)((wcin + 63) / 64) * 25 * N * 64; }
 

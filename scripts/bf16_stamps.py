@@ -1,0 +1,33 @@
+"""In-kernel cycle stamps of the bf16 ConvLSTM kernel's phases (build with PIVP_EXTRA_FLAGS=-DPIVP_BF16_STAMPS):
+entry | prologue done | first barrier passed | tap loop done | epilogue cells done, for wave 0 of block 37; the rest of the
+launch's duration (hipEvents) is stores draining + the end of the grid."""
+import sys, ctypes, glob, numpy as np, torch
+sys.path.insert(0, '.')
+import pivp_amd
+from pivp_amd import _lib
+lib = _lib.load()
+so = ctypes.CDLL(glob.glob('physical-interaction-video-prediction_amd/libpivp_hip.so')[0])
+dev = 'cuda:0'; B = 32
+st = torch.cuda.current_stream().cuda_stream
+rs = np.random.RandomState(0)
+for name, cx, C, H in [('lstm1', 32, 32, 32), ('lstm5', 64, 128, 8), ('lstm7', 96, 32, 32)]:
+    x = torch.randn(B, H, H, cx, device=dev); h = torch.randn(B, H, H, C, device=dev) * 0.5; c = torch.randn(B, H, H, C, device=dev)
+    w = torch.randn(25 * (cx + C) * 4 * C, device=dev) / np.sqrt(25 * (cx + C)); b = torch.randn(4 * C, device=dev) * 0.1
+    co = torch.empty_like(c); ho = torch.empty_like(h)
+    wb = torch.empty(lib.pivp_lstm_bf16_weight_elems(cx + C, C), dtype=torch.int16, device=dev)
+    assert lib.pivp_pack_lstm_bf16(w.data_ptr(), wb.data_ptr(), cx + C, C, st) == 0
+    def launch():
+        assert lib.pivp_convlstm_bf16(x.data_ptr(), cx, cx, h.data_ptr(), C, wb.data_ptr(), b.data_ptr(), c.data_ptr(), co.data_ptr(),
+                                      ho.data_ptr(), None, None, 0, None, B, H, H, 0, st) == 0
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        launch()
+    e1.record(); torch.cuda.synchronize()
+    buf = (ctypes.c_longlong * 8)()
+    assert so.pivp_debug_bf16_stamps(buf) == 0
+    v = list(buf)
+    print(name, 'launch %.1f us; stamps (counter ticks from entry):' % (e0.elapsed_time(e1) / 20 * 1e3), [v[i] - v[0] for i in range(1, 5)])
