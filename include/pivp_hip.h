@@ -157,6 +157,14 @@ int pivp_convlstm_bf16(const float* x, int cx, int ldx, const float* h_prev, int
                        const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
                        int* ln_nparts, int B, int H, int W, int nch, void* stream);
 
+/* Plain 5x5 stride-1 "same" convolution with bf16 operands and fp32 accumulation, out[b,y,x,n] (+)= sum x[b,y+dy,x+dx,k] w[tap][k][n]
+ * (the ConvLSTM data gradient of the bf16 mode: x = d gates, w = the flipped transposed weights).  x NHWC (cin channels, stride ldx);
+ * w fp32 K-inner packed [25][cin/32][cout][32]; w_bf16 scratch of pivp_conv5x5_bf16_weight_elems(cin, cout) 2-byte elements, rebuilt
+ * by the call; out NHWC with pixel stride ldo; accum != 0 adds into out.  Geometry as pivp_convlstm_bf16. */
+long long pivp_conv5x5_bf16_weight_elems(int cin, int cout);
+int pivp_conv5x5_bf16(const float* x, int cin, int ldx, const float* w, void* w_bf16, float* out, int cout, int ldo, int accum,
+                      int B, int H, int W, void* stream);
+
 /* --- training (what Chainer's autograd does under optimizer.update, TM:950) ---------------------------------- */
 /* pivp_convlstm with the gate activations kept for BPTT: gates_out [B*H*W][4C] = tanh(j), s(i), s(f+1), s(o). */
 int pivp_convlstm_train(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,

@@ -55,18 +55,18 @@ __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c) {
 }
 }  // namespace
 
-// fp32 K-inner packed weights [25][wcin/32][N][32] -> bf16 [ceil(wcin/64)][25][N][64], channels past wcin zero
-__global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int N, long total) {
+// fp32 K-inner packed weights [25][wcin/32][N][32] -> bf16 [ceil(wcin/64)][25][Np][64], channels past wcin and rows past N zero
+__global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int N, int Np, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int c64 = (int)(i & 63);
     long r = i >> 6;
-    const int n = (int)(r % N); r /= N;
+    const int n = (int)(r % Np); r /= Np;
     const int tap = (int)(r % 25);
     const int cg = (int)(r / 25);
     const int ch = cg * 64 + c64;
     float v = 0.f;
-    if (ch < wcin) v = w[(((long)tap * (wcin >> 5) + (ch >> 5)) * N + n) * 32 + (ch & 31)];
+    if (ch < wcin && n < N) v = w[(((long)tap * (wcin >> 5) + (ch >> 5)) * N + n) * 32 + (ch & 31)];
     const __bf16 h = (__bf16)v;
     wb[i] = __builtin_bit_cast(unsigned short, h);
 }
@@ -78,8 +78,11 @@ __device__ long long pivp_bf16_stamps[8];
 #define BF_STAMP(i)
 #endif
 
-template <int NCH>
-__global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int tw) {
+// LSTM = true: the ConvLSTM cell (block columns = 4 gates x NCH channels, gate epilogue).  LSTM = false: a plain 5x5 stride-1 "same"
+// convolution out[m][n] (+)= sum x[m + tap][k] w[tap][k][n] with block columns = 4 NCH consecutive n (the ConvLSTM DATA gradient: x = dG,
+// w = the flipped transposed weights); gridDim.y splits the channel groups, partial sums then meet in `out` by atomic adds.
+template <int NCH, bool LSTM>
+__global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int tw, int ncols) {
     constexpr int BN = 4 * NCH;                 // block columns: [gate][channel]
     constexpr int SLOT = BN * 128;              // bytes of one ring slot: BN rows x 64 bf16
     constexpr int G = BN / 32;                  // global_load_lds per loader thread and tap
@@ -97,7 +100,8 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     const int wave = wave8 & 3;
     const int wm = wave & 1, wn = wave >> 1;
     const int half = lane >> 5, l31 = lane & 31;
-    const int C = d.C, N = d.N, n_nblk = C / NCH;
+    const int C = d.C, N = d.N;                       // (plain conv: N = rows of the padded weight pack, a multiple of BN)
+    const int n_nblk = LSTM ? C / NCH : N / BN;
     const int H = d.Hin, W = d.Win;
     // tile geometry: tw = 16: one image, 8 x 16 anchors; tw = 8: two images, 8 x 8 anchors each
     const int ti_n = tw == 16 ? 1 : 2;
@@ -113,7 +117,9 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     BF_STAMP(0);
     const int c0 = d.c0, ld0 = d.ld0, ld1 = d.ld1;
     const int cin = c0 + d.c1;
-    const int ncg = (cin + 63) >> 6;
+    const int ncg_all = (cin + 63) >> 6;
+    const int cgbase = (int)blockIdx.y * ncg_all / (int)gridDim.y;                 // this block's channel groups: [cgbase, cgbase + ncg)
+    const int ncg = ((int)blockIdx.y + 1) * ncg_all / (int)gridDim.y - cgbase;
     const int nchunks = 25 * ncg;
 
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x0), 0, d.bytes0, 0x00020000);
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     }
     f32x4 plo[NPJ], phi[NPJ];                          // a patch in flight (live only between the two halves of a staging)
     auto patch_load = [&](int cg) {
-        const int ch = cg * 64 + cpiece * 8;           // first of this thread's 8 channels of concat(x, h)
+        const int ch = (cgbase + cg) * 64 + cpiece * 8;   // first of this thread's 8 channels of concat(x, h)
         const bool s0 = ch < c0, s1 = !s0 && ch < cin;
         const int ld = s0 ? ld0 : ld1, co = s0 ? ch : ch - c0;
 #pragma unroll
@@ -178,13 +184,14 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         for (int j = 0; j < G; ++j) {
             const int row = j * 32 + (lt >> 3), g = row / NCH, cl = row - g * NCH;
             const int piece = (lt & 7) ^ (row & 7);
-            wsrc[j] = reinterpret_cast<const unsigned char*>(wb) + ((size_t)(g * C + nblk * NCH + cl)) * 128 + piece * 16;
+            const int grow = LSTM ? g * C + nblk * NCH + cl : nblk * BN + row;
+            wsrc[j] = reinterpret_cast<const unsigned char*>(wb) + (size_t)grow * 128 + piece * 16;
         }
         const size_t wstep = (size_t)N * 128;          // bytes between consecutive (group, tap) weight tiles
         int issued = 0, i_tap = tap0, i_cg = 0;        // taps issued; the next one to issue
         auto issue_weights = [&]() {
             const int slot = issued & (NSLOT - 1);
-            const size_t goff = (size_t)(i_cg * 25 + i_tap) * wstep;
+            const size_t goff = (size_t)((cgbase + i_cg) * 25 + i_tap) * wstep;
             i_tap = i_tap == 24 ? 0 : i_tap + 1;
             i_cg += i_tap == tap0 ? 1 : 0;
 #pragma unroll
@@ -248,7 +255,8 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     // B: MFMA column l31 of tile t = gate t * GPT + l31 / CPW, channel wn * CPW + l31 % CPW; ring row = gate * NCH + channel
     int b_row[TPW], b_sw[4];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) b_row[t] = ((t * GPT + l31 / CPW) * NCH + wn * CPW + (l31 % CPW)) * 128;
+    for (int t = 0; t < TPW; ++t)
+        b_row[t] = (LSTM ? (t * GPT + l31 / CPW) * NCH + wn * CPW + (l31 % CPW) : (wn * TPW + t) * 32 + l31) * 128;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) b_sw[ks] = ((2 * ks + half) ^ (l31 & 7)) * 16;    // row % 8 == l31 % 8 (NCH, CPW multiples of 8)
 
@@ -291,18 +299,21 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     const int ch = nblk * NCH + chl;
     const int grp = l31 / CPW;
     constexpr int OWN = 16 / GPT;
-    const float bj = d.bias[ch], bi = d.bias[C + ch], bf = d.bias[2 * C + ch] + 1.0f, bo = d.bias[3 * C + ch];
+    float bj = 0.f, bi = 0.f, bf = 0.f, bo = 0.f;
     float cpre[2][OWN];
+    if constexpr (LSTM) {
+        bj = d.bias[ch]; bi = d.bias[C + ch]; bf = d.bias[2 * C + ch] + 1.0f; bo = d.bias[3 * C + ch];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int k = 0; k < OWN; ++k) {
-            const int r = k * GPT + grp;
-            const int i = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int ti = tw == 16 ? 0 : i >> 6, ay = tw == 16 ? i >> 4 : (i >> 3) & 7, ax = tw == 16 ? i & 15 : i & 7;
-            const int m = ((b0 + ti) * H + y0 + ay) * W + x0 + ax;
-            cpre[mt][k] = d.cstate_in[(size_t)m * C + ch];
-        }
+            for (int k = 0; k < OWN; ++k) {
+                const int r = k * GPT + grp;
+                const int i = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int ti = tw == 16 ? 0 : i >> 6, ay = tw == 16 ? i >> 4 : (i >> 3) & 7, ax = tw == 16 ? i & 15 : i & 7;
+                const int m = ((b0 + ti) * H + y0 + ay) * W + x0 + ax;
+                cpre[mt][k] = d.cstate_in[(size_t)m * C + ch];
+            }
+    }
     patch_store();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     BF_STAMP(1);
@@ -339,6 +350,28 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    if constexpr (!LSTM) {
+        // ---- plain epilogue: accumulator row = anchor, column = output channel; 32 lanes write 128 contiguous bytes ----------
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int ti = tw == 16 ? 0 : i >> 6, ay = tw == 16 ? i >> 4 : (i >> 3) & 7, ax = tw == 16 ? i & 15 : i & 7;
+                const size_t m = (size_t)(((b0 + ti) * H + y0 + ay) * W + x0 + ax);
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    const int col = nblk * BN + (wn * TPW + t) * 32 + l31;
+                    if (col < ncols) {                  // the pack's rows past the real column count are zero padding
+                        float* o = d.out + m * d.ldo + col;
+                        if (gridDim.y > 1) atomicAdd(o, acc[mt][t][r]);
+                        else if (d.accum) *o += acc[mt][t][r];
+                        else *o = acc[mt][t][r];
+                    }
+                }
+            }
+        return;
+    }
     BF_STAMP(3);
     // ---- epilogue: gates, state update, optional gate activations and LayerNorm partial ----------------------------------
     // Accumulator row r of a lane is one anchor; its column is (gate t * GPT + grp, channel): the 4 gates of an (anchor, channel)
@@ -439,40 +472,45 @@ namespace pivp {
 #endif
 
 size_t lstm_bf16_weight_elems(int wcin, int N) { return (size_t)((wcin + 63) / 64) * 25 * N * 64; }
+// rows of the bf16 pack of a plain 5x5 convolution with N output channels: whole 128- or 64-column blocks
+int conv5x5_bf16_rows(int N) { return N % 128 == 0 ? N : (N + 63) / 64 * 64; }
 
-int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s) {
-    PIVP_CHECK_ARG(w && wb && wcin > 0 && wcin % 32 == 0 && N > 0);
-    const long total = (long)lstm_bf16_weight_elems(wcin, N);
-    hipLaunchKernelGGL(pack_lstm_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, total);
+// w: fp32 K-inner packed [25][wcin/32][N][32]; wb: [ceil(wcin/64)][25][Np][64] bf16 (Np >= N rows, the extra ones zero; 0 = N)
+int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s, int Np) {
+    if (Np == 0) Np = N;
+    PIVP_CHECK_ARG(w && wb && wcin > 0 && wcin % 32 == 0 && N > 0 && Np >= N);
+    const long total = (long)lstm_bf16_weight_elems(wcin, Np);
+    hipLaunchKernelGGL(pack_lstm_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, total);
     return PIVP_LAUNCH_STATUS();
 }
 
-bool convlstm_bf16_ok(const IgemmDesc& d) {
-    if (d.ksize != 5 || d.pad != 2 || d.in_step != 1 || d.C % 16 || d.Hin % TH) return false;
+static bool bf16_geometry_ok(const IgemmDesc& d) {
+    if (d.ksize != 5 || d.pad != 2 || d.in_step != 1 || d.Hin % TH) return false;
     if (d.c0 % 8 || d.c1 % 8 || d.ld0 % 4 || d.ld1 % 4) return false;
     if (d.Win % 16 == 0) return true;
     return d.Win % 8 == 0 && d.B % 2 == 0;
 }
+bool convlstm_bf16_ok(const IgemmDesc& d) { return bf16_geometry_ok(d) && d.C > 0 && d.C % 16 == 0; }
 
-template <int NCH>
-static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts) {
+template <int NCH, bool LSTM>
+static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nb, int ksplit, int ncols) {
     constexpr int lds_bytes = PATCH_BYTES + NSLOT * 4 * NCH * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bf16_kernel<NCH>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds_bytes) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bf16_kernel<NCH, LSTM>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
             return PIVP_ERR_LAUNCH;
         attr_set = true;
     }
     IgemmDesc dd = d;
     const int tw = d.Win % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
-    const int tpi = (d.Hin / TH) * (d.Win / tw), nb = d.C / NCH;
+    const int tpi = (d.Hin / TH) * (d.Win / tw);
     const int np = tpi * nb;
-    dd.ln_nparts = (d.ln_part && np <= d.ln_cap) ? np : 0;
+    dd.ln_nparts = (LSTM && d.ln_part && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
     const int blocks = (d.B / ti_n) * tpi * nb;
-    hipLaunchKernelGGL(convlstm_bf16_kernel<NCH>, dim3(blocks), dim3(512), lds_bytes, stream, dd, wb, tw);
+    hipLaunchKernelGGL((convlstm_bf16_kernel<NCH, LSTM>), dim3(blocks, ksplit), dim3(512), lds_bytes, stream, dd, wb, tw, ncols);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -482,7 +520,29 @@ int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stre
     const int tw = d.Win % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
     const long blocks32 = (long)(d.B / ti_n) * (d.Hin / TH) * (d.Win / tw) * (d.C / 32);
     if (nch == 0) nch = (d.C % 32 || blocks32 < 256) ? 16 : 32;
-    return nch == 16 ? launch_bf16<16>(d, wb, stream, ln_nparts) : launch_bf16<32>(d, wb, stream, ln_nparts);
+    return nch == 16 ? launch_bf16<16, true>(d, wb, stream, ln_nparts, d.C / 16, 1, 0)
+                     : launch_bf16<32, true>(d, wb, stream, ln_nparts, d.C / 32, 1, 0);
+}
+
+// Plain 5x5 stride-1 "same" convolution with bf16 operands: out[m][n] (+)= sum_{tap, k} x[m + tap][k] w[tap][k][n], n < d.N, written
+// with pixel stride d.ldo.  x = d.x0 | d.x1 (fp32 NHWC, rounded to bf16 on the way into LDS); wb = pack_lstm_bf16(w, c0 + c1, d.N,
+// conv5x5_bf16_rows(d.N)).  d.accum adds into out; d.ksplit_ok (out pre-zeroed, no accum) lets grids that would leave CUs idle split
+// the channel groups over gridDim.y and meet in out by atomic adds.  This is the ConvLSTM data gradient (x = dG, 4C channels).
+int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream) {
+    PIVP_CHECK_ARG(wb && bf16_geometry_ok(d) && d.out && d.N > 0 && d.ldo >= d.N && d.x0 && d.c0 > 0);
+    const int Np = conv5x5_bf16_rows(d.N);
+    const int tw = d.Win % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
+    const int tiles = (d.B / ti_n) * (d.Hin / TH) * (d.Win / tw);
+    const int ncg = (d.c0 + d.c1 + 63) / 64;
+    IgemmDesc dd = d;
+    dd.N = Np;                                         // the kernel's weight-row count
+    const bool wide = Np % 128 == 0;
+    const int nb = Np / (wide ? 128 : 64);
+    int ks = 1;
+    if (d.ksplit_ok && !d.accum)
+        while (ks * 2 <= ncg && (long)tiles * nb * ks * 2 <= 512) ks *= 2;
+    return wide ? launch_bf16<32, false>(dd, wb, stream, nullptr, nb, ks, d.N)
+                : launch_bf16<16, false>(dd, wb, stream, nullptr, nb, ks, d.N);
 }
 
 }  // namespace pivp

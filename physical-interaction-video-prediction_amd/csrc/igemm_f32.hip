@@ -51,9 +51,15 @@ constexpr int ig_lds_bytes() { return 2 * (32 * WM + 32 * NTB) * IG_P * 4; }
 
 // sigmoid / tanh of the gate epilogue through v_exp_f32 / v_rcp_f32: |error| <= ~2e-7 absolute, an order
 // below the fp32 accumulation noise of the K = 1600..4800 dot products in front of them.
-// v_rcp_f32 (1 ulp) instead of an IEEE division: __frcp_rn expands to ~10 instructions (div_scale, rcp, 4 fma, div_fmas, div_fixup), 5 times per cell
-__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
+// 1 / d as v_rcp_f32 plus one Newton step (3 instructions, error well under 1 ulp) instead of an IEEE division: __frcp_rn expands to
+// ~10 instructions (div_scale x2, rcp, 4 fma, div_fmas, div_fixup), 5 times per cell.  The bare 1-ulp v_rcp_f32 is not enough for the
+// parity path: through 9 recurrent steps and the STP warp of white-noise frames it moved tests/test_gpu_model.py's STP case past its gate.
+__device__ __forceinline__ float fast_rcp(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * fast_rcp(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 // ABL: timing-only ablations for scripts/bench_lstm_layers.py (built with -DPIVP_ABLATE; outputs are wrong):
 //   1 = no global loads and no LDS stores, 2 = loads but no LDS stores, 3 = as 1 without the barrier,

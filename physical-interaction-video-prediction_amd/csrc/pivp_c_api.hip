@@ -92,6 +92,25 @@ int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, in
     return igemm_conv(d, s);
 }
 
+// 5x5 stride-1 "same" convolution with bf16 operands (csrc/convlstm_bf16.hip); wb = pack_lstm_bf16(w, cin, cout, conv5x5_bf16_rows(cout))
+int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb, float* out, int cout, int ldo, int accum,
+                     int B, int H, int W, hipStream_t s) {
+    IgemmDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x0 = x; d.c0 = cin; d.ld0 = ldx; d.wcin = cin;
+    d.B = B; d.Hin = H; d.Win = W; d.Hg = H; d.Wg = W; d.in_step = 1;
+    d.N = cout; d.M = B * H * W; d.nphase = 1; d.ksize = 5; d.pad = 2;
+    const long long b0 = view_bytes(B, H, W, ldx);
+    if (!fits31(b0)) return PIVP_ERR_BADARG;
+    d.bytes0 = (int)b0;
+    d.out_step = 1; d.Hout = H; d.Wout = W; d.out = out; d.ldo = ldo; d.accum = accum;
+    if (!accum && ldo == cout) {     // contiguous fresh output: allow the K-split path (needs a zeroed destination)
+        if (hipMemsetAsync(out, 0, (size_t)B * H * W * cout * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
+        d.ksplit_ok = 1;
+    }
+    return conv5x5_bf16(d, wb, s);
+}
+
 // weight gradient of: mode 0 = conv K x K stride `stride` pad `pad`; mode 1 = transposed 3x3 s2 p1
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
               float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s, float* db,
@@ -115,7 +134,7 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
 int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
                           const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                           float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
-                          int B, int H, int W, hipStream_t s, int wt_ready) {
+                          int B, int H, int W, hipStream_t s, int wt_ready, unsigned short* wt_bf16) {
     const int M = B * H * W, cin = cx + C, N = 4 * C;
     int rc = lstm_gates_bwd(gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc, dc_valid, dG, M, C, s);
     if (rc != PIVP_OK) return rc;
@@ -123,7 +142,15 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
         rc = repack_transpose(w, wt, 25, cin, N, 1, s);                   // [25][cin/32][4C][32] -> flipped [25][4C/32][cin][32]
         if (rc != PIVP_OK) return rc;
     }
-    rc = run_conv_s1(dG, N, N, wt, d_in, cin, cin, 5, B, H, W, s);        // d[x,h] = conv5x5(dG, W^T flipped)
+    if (wt_bf16) {   // bf16 precision mode: the data gradient with bf16 operands (wt_bf16 = bf16 pack of wt, built here unless wt_ready)
+        if (!wt_ready) {
+            rc = pack_lstm_bf16(wt, wt_bf16, N, cin, s, conv5x5_bf16_rows(cin));
+            if (rc != PIVP_OK) return rc;
+        }
+        rc = run_conv5x5_bf16(dG, N, N, wt_bf16, d_in, cin, cin, 0, B, H, W, s);
+    } else {
+        rc = run_conv_s1(dG, N, N, wt, d_in, cin, cin, 5, B, H, W, s);    // d[x,h] = conv5x5(dG, W^T flipped)
+    }
     if (rc != PIVP_OK) return rc;
     int bias_done = 0;   // the 5x5 weight-gradient kernel sums dG's columns on the side
     rc = run_wgrad(0, x, cx, ldx, h_prev, C, C, cin, dG, N, N, dW, B, H, W, H, W, 5, 2, 1, s, db, &bias_done);
@@ -234,6 +261,19 @@ extern "C" int pivp_convlstm_bf16(const float* x, int cx, int ldx, const float* 
     if (!x || !w_bf16 || !bias || !c_in || !c_out || !h_out) return PIVP_ERR_BADARG;
     return run_convlstm(x, cx, ldx, h_prev, C, nullptr, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, nch, gates_out,
                         ln_part, ln_cap, ln_nparts, (const unsigned short*)w_bf16);
+}
+// Plain 5x5 stride-1 "same" convolution with bf16 operands (the ConvLSTM data gradient of the bf16 mode): w fp32 K-inner packed
+// [25][cin/32][cout][32]; w_bf16: scratch of pivp_conv5x5_bf16_weight_elems(cin, cout) 2-byte elements, (re)built by this call.
+extern "C" long long pivp_conv5x5_bf16_weight_elems(int cin, int cout) {
+    if (cin <= 0 || cin % 32 || cout <= 0) return PIVP_ERR_BADARG;
+    return (long long)lstm_bf16_weight_elems(cin, conv5x5_bf16_rows(cout));
+}
+extern "C" int pivp_conv5x5_bf16(const float* x, int cin, int ldx, const float* w, void* w_bf16, float* out, int cout, int ldo, int accum,
+                                 int B, int H, int W, void* stream) {
+    if (!x || !w || !w_bf16 || !out || cin <= 0 || cout <= 0) return PIVP_ERR_BADARG;
+    int rc = pack_lstm_bf16(w, (unsigned short*)w_bf16, cin, cout, (hipStream_t)stream, conv5x5_bf16_rows(cout));
+    if (rc != PIVP_OK) return rc;
+    return run_conv5x5_bf16(x, cin, ldx, (const unsigned short*)w_bf16, out, cout, ldo, accum, B, H, W, (hipStream_t)stream);
 }
 static int convlstm_ln_cap(int H, int W, int C) {
     const int tiles = ((H * W + 31) / 32) * (C / 32), slices = ln_stats_slices(H * W * C);

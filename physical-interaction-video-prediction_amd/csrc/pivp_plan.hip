@@ -54,6 +54,7 @@ struct Grads {   // gradient workspace (single copy, reused by every timestep of
     size_t hln[7], din[7][2], dc[7];
     size_t dG, go[2], dmk, dz, dkpart, dv, dstate, lnpart;
     size_t wt_lstm[7], wt_enc[7];   // re-packed (transposed) weights for the data gradients, rebuilt once per backward
+    size_t wtb_lstm[7];             // ... and their bf16 packs (bf16 precision mode)
 };
 
 }  // namespace
@@ -186,6 +187,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
             g.din[i][0] = carve(M * (kLstm[i].cx + kLstm[i].C)); g.din[i][1] = carve(M * (kLstm[i].cx + kLstm[i].C));
             if (M * 4 * kLstm[i].C > maxdG) maxdG = M * 4 * kLstm[i].C;
             g.wt_lstm[i] = carve((size_t)25 * (kLstm[i].cx + kLstm[i].C) * 4 * kLstm[i].C);
+            g.wtb_lstm[i] = carve((lstm_bf16_weight_elems(4 * kLstm[i].C, conv5x5_bf16_rows(kLstm[i].cx + kLstm[i].C)) + 1) / 2);
             g.wt_enc[i] = (i == 0 || i == 3) ? 0 : carve((size_t)encw[i]);
         }
         g.dG = carve(maxdG);
@@ -439,7 +441,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                                      Sp ? ws + Sp->c[i] : ws + p->o_zero, ws + S.c[i], ws + g.hln[i], L.C,
                                      last_step ? nullptr : ws + g.din[i][npar] + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
                                      ws + g.dG, ws + g.wt_lstm[i], ws + g.din[i][par], G(p, p->i_lstm_w[i]), G(p, p->i_lstm_b[i]), B, hh, wwid,
-                                     s, 1);
+                                     s, 1, p->lstm_bf16 ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr);
     };
     const long px2 = (long)B * p->H2 * p->W2, px4 = (long)B * p->H4 * p->W4, px8 = (long)B * p->H8 * p->W8;
 
@@ -542,6 +544,12 @@ extern "C" int pivp_rollout_backward(pivp_plan_t* plan, const float* images, con
     // weights are constant during the sweep: build the transposed packs for the data gradients once
     for (int i = 0; i < 7; ++i)
         RC(repack_transpose(P(plan, plan->i_lstm_w[i]), ws + g.wt_lstm[i], 25, kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C, 1, s));
+    if (plan->lstm_bf16)        // bf16 mode: the ConvLSTM data gradients run with bf16 operands on these packs
+        for (int i = 0; i < 7; ++i) {
+            const int cin = kLstm[i].cx + kLstm[i].C;
+            RC(pack_lstm_bf16(ws + g.wt_lstm[i], reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]), 4 * kLstm[i].C, cin, s,
+                              conv5x5_bf16_rows(cin)));
+        }
     {
         const int ecin[7] = {0, 32, 64, 0, 128, 96, 64};
         for (int i : {1, 2, 4, 5, 6}) RC(repack_transpose(P(plan, plan->i_enc_w[i]), ws + g.wt_enc[i], 9, ecin[i], ecin[i], 0, s));

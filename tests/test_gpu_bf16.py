@@ -183,3 +183,23 @@ def test_bf16_precision_refused_for_unsupported_geometry():
         m([imgs, acts, stas], 0)
     with pytest.raises(ValueError):
         pivp_amd.Model(10, precision='fp16')
+
+
+# ---- plain 5x5 convolution of the same kernel (the ConvLSTM data gradient of the bf16 mode) -----------------------------
+@pytest.mark.parametrize('B,cin,cout,H', [(2, 128, 64, 32), (2, 256, 96, 16), (4, 512, 192, 8), (2, 256, 128, 16), (1, 128, 128, 32),
+                                          (32, 512, 192, 8)])
+def test_conv5x5_bf16_exact_on_bf16_operands(ops, B, cin, cout, H):
+    # shapes of the seven data gradients (cin = 4C gate channels, cout = Cx + C); cout = 96 exercises the padded column block,
+    # the 8x8 / B = 4 case the K-split over channel groups with atomic adds, B = 32 the unsplit 8x8 grid
+    rs = np.random.RandomState(cin + cout + H)
+    x = _bf16(rs.randn(B, cin, H, H)); W = _bf16(rs.randn(cout, cin, 5, 5) / np.sqrt(25 * cin))
+    ref = R.conv2d(x, W, np.zeros(cout), 1, 2)
+    got = ops.conv5x5_bf16(x, W)
+    assert np.abs(got - ref).max() < TOL
+
+
+def test_conv5x5_bf16_accumulates(ops):
+    rs = np.random.RandomState(3)
+    x = _bf16(rs.randn(2, 128, 16, 16)); W = _bf16(rs.randn(64, 128, 5, 5) / np.sqrt(3200)); base = rs.randn(2, 64, 16, 16)
+    ref = base + R.conv2d(x, W, np.zeros(64), 1, 2)
+    assert np.abs(ops.conv5x5_bf16(x, W, accum_into=base) - ref).max() < TOL
