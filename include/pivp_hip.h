@@ -165,6 +165,12 @@ long long pivp_conv5x5_bf16_weight_elems(int cin, int cout);
 int pivp_conv5x5_bf16(const float* x, int cin, int ldx, const float* w, void* w_bf16, float* out, int cout, int ldo, int accum,
                       int B, int H, int W, void* stream);
 
+/* ConvLSTM weight gradient with bf16 operands and fp32 accumulation (bf16 mode): dW[tap][ci][n] += sum_m concat(x, h_prev)[m + tap][ci]
+ * dG[m][n]; dW K-inner packed like the weight, ACCUMULATED; h_prev may be NULL (first timestep: only the x rows are touched);
+ * dG [B*H*W][4C].  Needs 4C % 128 == 0, cx % 32 == 0, C % 32 == 0 and the map geometry of pivp_convlstm_bf16. */
+int pivp_wgrad5x5_bf16(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW,
+                       int B, int H, int W, void* stream);
+
 /* --- training (what Chainer's autograd does under optimizer.update, TM:950) ---------------------------------- */
 /* pivp_convlstm with the gate activations kept for BPTT: gates_out [B*H*W][4C] = tanh(j), s(i), s(f+1), s(o). */
 int pivp_convlstm_train(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,

@@ -114,7 +114,7 @@ int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb,
 // weight gradient of: mode 0 = conv K x K stride `stride` pad `pad`; mode 1 = transposed 3x3 s2 p1
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
               float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s, float* db,
-              int* bias_done) {
+              int* bias_done, int bf16) {
     WgradDesc d;
     memset(&d, 0, sizeof(d));
     d.x0 = x0; d.c0 = c0; d.ld0 = ld0; d.x1 = x1; d.c1 = x1 ? c1 : 0; d.ld1 = ld1; d.cin = c0 + (x1 ? c1 : 0); d.wcin = wcin;
@@ -126,6 +126,10 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
     if (!fits31(b0) || (x1 && !fits31(b1)) || !fits31(by)) return PIVP_ERR_BADARG;
     d.bytes0 = (int)b0; d.bytes1 = (int)b1; d.bytesy = (int)by;
     d.db = db;
+    if (bf16) {   // bf16 precision mode (5x5 ConvLSTM case only): operands rounded to bf16, fp32 accumulation; bias left to the caller
+        if (bias_done) *bias_done = 0;
+        return wgrad5x5_bf16(d, s);
+    }
     return igemm_wgrad(d, s, bias_done);
 }
 
@@ -153,7 +157,7 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
     }
     if (rc != PIVP_OK) return rc;
     int bias_done = 0;   // the 5x5 weight-gradient kernel sums dG's columns on the side
-    rc = run_wgrad(0, x, cx, ldx, h_prev, C, C, cin, dG, N, N, dW, B, H, W, H, W, 5, 2, 1, s, db, &bias_done);
+    rc = run_wgrad(0, x, cx, ldx, h_prev, C, C, cin, dG, N, N, dW, B, H, W, H, W, 5, 2, 1, s, db, &bias_done, wt_bf16 != nullptr);
     if (rc != PIVP_OK) return rc;
     return bias_done ? PIVP_OK : bias_grad(dG, N, N, M, db, s);
 }
@@ -274,6 +278,13 @@ extern "C" int pivp_conv5x5_bf16(const float* x, int cin, int ldx, const float* 
     int rc = pack_lstm_bf16(w, (unsigned short*)w_bf16, cin, cout, (hipStream_t)stream, conv5x5_bf16_rows(cout));
     if (rc != PIVP_OK) return rc;
     return run_conv5x5_bf16(x, cin, ldx, (const unsigned short*)w_bf16, out, cout, ldo, accum, B, H, W, (hipStream_t)stream);
+}
+// ConvLSTM weight gradient with bf16 operands: dW (K-inner packed like the weight, [25][(cx+C)/32][4C][32]) += x|h^T . dG per tap.
+extern "C" int pivp_wgrad5x5_bf16(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW,
+                                  int B, int H, int W, void* stream) {
+    if (!x || !dG || !dW || C <= 0 || cx <= 0) return PIVP_ERR_BADARG;
+    return run_wgrad(0, x, cx, ldx, h_prev, C, C, cx + C, dG, 4 * C, 4 * C, dW, B, H, W, H, W, 5, 2, 1, (hipStream_t)stream, nullptr,
+                     nullptr, 1);
 }
 static int convlstm_ln_cap(int H, int W, int C) {
     const int tiles = ((H * W + 31) / 32) * (C / 32), slices = ln_stats_slices(H * W * C);

@@ -19,7 +19,7 @@ int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, in
                 hipStream_t s, int accum = 0);
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
               float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s,
-              float* db = nullptr, int* bias_done = nullptr);
+              float* db = nullptr, int* bias_done = nullptr, int bf16 = 0);
 int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
                           const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                           float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,

@@ -52,6 +52,9 @@ struct WgradDesc {
                                          // kernel that runs can do it on the side (*bias_done = 1), else left to bias_grad
 };
 int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done = nullptr);
+// bf16-operand form of the ConvLSTM weight gradient (csrc/wgrad_bf16.hip); the bias gradient is left to bias_grad
+bool wgrad5x5_bf16_ok(const WgradDesc& d);
+int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s);
 int repack_transpose(const float* w, float* wt, int taps, int cin, int N, int flip, hipStream_t s);
 
 // ln_nparts (optional): receives the number of LayerNorm partials per sample the launch writes to d.ln_part (0: none)

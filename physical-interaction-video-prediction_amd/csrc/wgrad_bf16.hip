@@ -1,0 +1,212 @@
+// ConvLSTM weight gradient with bf16 operands and fp32 accumulation (the bf16 precision mode's form of wgrad5x5_kernel,
+// igemm_wgrad.hip):   dW[tap][ci][n] += sum over pixels m of  X[m + tap][ci] * dG[m][n]      (5x5, stride 1, pad 2)
+// i.e. per tap a GEMM whose REDUCTION runs over pixels.  On v_mfma_f32_32x32x16_bf16 both operands then need 8 consecutive
+// k = 8 pixels per lane for one row (n) / column (ci), while the activations are pixel-major [pixel][channel].  gfx950's
+// transposing LDS read does that for free: ds_read_b64_tr_b16 takes, per group of 16 lanes, a block of 4 image rows (pixels)
+// x 16 columns (channels) and hands lane i column i of the 4 rows, so two of them deliver the 8 k values of an MFMA operand
+// straight from the pixel-major image -- and a tap only shifts the pixel (row) address, so no alignment case arises.
+//
+// A block owns one kernel row ky (5 taps kx), 32 input channels, 128 gate columns (wave w: columns 32 w .. 32 w + 31) and a
+// slice of the pixel tiles; MFMA rows = n, columns = ci, so that the epilogue's atomic adds into the K-inner packed gradient
+// [tap][ci / 32][n][32] are 128-B contiguous per half-wave.  Per tile of 128 pixels (8 x 16, or two 8 x 8 images) it stages
+// dG [128 px][128 n] and the X strip of kernel row ky [8 rows][16 + 4 columns][32 ci] as bf16 (fp32 in HBM, rounded on the way
+// in; out-of-image pixels = the zeros of an out-of-range buffer load) and runs 8 k-steps x 5 taps against the same dG
+// fragments.  The next tile's loads are in flight in registers while the current one is multiplied.
+// Slices meet in dW by fp32 atomic adds (gradients accumulate until the host clears them, as in the fp32 kernel).
+#include <type_traits>
+
+#include "pivp_kernels.h"
+
+namespace pivp {
+
+namespace {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int GP = 272;                // dG image row pitch (bytes): 128 bf16 + 16
+constexpr int XP = 80;                 // X strip pixel pitch (bytes): 32 bf16 + 16
+constexpr int G_BYTES = 128 * GP;      // 34,816
+constexpr int XPIX = 192;              // strip pixels allocated (8 x 20 = 160, or 2 x 8 x 12 = 192)
+constexpr int X_BYTES = XPIX * XP;     // 15,360
+
+__device__ __forceinline__ unsigned wpack2(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// 4 rows x 16 columns of 16-bit elements, transposed: this lane's column, the 4 rows (see the header)
+template <int OFF>
+__device__ __forceinline__ bf16x4 lds_read_tr(unsigned addr) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+}  // namespace
+
+template <int TW>   // tile = 8 x 16 pixels of one image (TW = 16) or 8 x 8 pixels of two images (TW = 8)
+__global__ __launch_bounds__(256, 2) void wgrad5x5_bf16_kernel(const WgradDesc d, int tiles_per_split) {
+    constexpr int tw = TW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // dG image | X strip
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = d.Hx, W = d.Wx, N = d.N;
+    const int ncb = d.cin >> 5;
+    // block -> (ky, channel block, column block); blockIdx.y = pixel slice
+    int bx = blockIdx.x;
+    const int ky = bx % 5; bx /= 5;
+    const int cb = bx % ncb, nb = bx / ncb;
+    constexpr int ti_n = tw == 16 ? 1 : 2;
+    constexpr int SWC = tw + 4;                               // strip columns
+    const int tpr = W / tw, tpi = (H / 8) * tpr;
+    const int n_tiles = (d.B / ti_n) * tpi;
+    const int t_begin = blockIdx.y * tiles_per_split;
+    const int t_end = min(n_tiles, t_begin + tiles_per_split);
+
+    const int ch0 = cb * 32;                                  // first of the block's 32 channels of concat(x0, x1)
+    const bool src0 = ch0 < d.c0;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src0 ? d.x0 : d.x1), 0, src0 ? d.bytes0 : d.bytes1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy), 0, d.bytesy, 0x00020000);
+    const int ldx = src0 ? d.ld0 : d.ld1, cho = src0 ? ch0 : ch0 - d.c0;
+    constexpr unsigned OOB = 0xC0000000u;
+
+    // ---- staging roles ----------------------------------------------------------------------------------------------------
+    // dG tile: 128 px x 128 n = 4096 float4: thread -> (px = tid / 32 + 8 j, n4 = tid % 32), j < 16
+    // X strip: XPIX px x 8 float4: thread -> (px = tid / 8 + 32 j, c4 = tid % 8), j < 6
+    f32x4 rg[16], rx[6];
+    auto tile_geom = [&](int t, int& b0, int& y0, int& x0) {
+        b0 = (t / tpi) * ti_n;
+        const int trem = t - (t / tpi) * tpi;
+        y0 = (trem / tpr) * 8; x0 = (trem - (trem / tpr) * tpr) * tw;
+    };
+    auto load_tile = [&](int t) {
+        int b0, y0, x0;
+        tile_geom(t, b0, y0, x0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int i = (tid >> 5) + 8 * j;                 // anchor of the tile
+            const int ti = tw == 16 ? 0 : i >> 6, ay = tw == 16 ? i >> 4 : (i >> 3) & 7, ax = tw == 16 ? i & 15 : i & 7;
+            const int m = ((b0 + ti) * H + y0 + ay) * W + x0 + ax;
+            rg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy, (unsigned)((m * d.ldy + nb * 128 + (tid & 31) * 4) * 4), 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int p = (tid >> 3) + 32 * j;                // strip pixel: [image][row][column]
+            const int ti = p / (8 * SWC), pr = p - ti * (8 * SWC);
+            const int py = pr / SWC, px = pr - py * SWC;
+            const int iy = y0 + py + ky - 2, ix = x0 + px - 2;
+            const bool ok = ti < ti_n && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const unsigned off = ok ? (unsigned)(((((b0 + ti) * H + iy) * W + ix) * ldx + cho + (tid & 7) * 4) * 4) : OOB;
+            rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            uint2 v;
+            v.x = wpack2(rg[j][0], rg[j][1]); v.y = wpack2(rg[j][2], rg[j][3]);
+            *reinterpret_cast<uint2*>(lds + ((tid >> 5) + 8 * j) * GP + (tid & 31) * 8) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            uint2 v;
+            v.x = wpack2(rx[j][0], rx[j][1]); v.y = wpack2(rx[j][2], rx[j][3]);
+            *reinterpret_cast<uint2*>(lds + G_BYTES + ((tid >> 3) + 32 * j) * XP + (tid & 7) * 8) = v;
+        }
+    };
+
+    // ---- fragment addresses ---------------------------------------------------------------------------------------------------
+    // transposing read j (0, 1) of k-step s: lane (group g = lane / 16, q = (lane % 16) / 4, p = lane % 4) supplies the address of
+    // pixel k = 16 s + 8 (g / 2) + 4 j + q, columns 16 (g % 2) + 4 p .. + 3 of the operand's 32.  The lane-dependent part goes into
+    // one base register per operand, (s, j) and the tap into the instruction's offset field.
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned a_base = lds0 + (8 * (g >> 1) + q) * GP + (wave * 32 + 16 * (g & 1) + 4 * p) * 2;     // dG: this wave's 32 columns
+    // X strip pixel of k, tap kx: TW 16: row s, column 8 (g / 2) + 4 j + q + kx; TW 8: image s / 4, row 2 (s % 4) + g / 2, column 4 j + q + kx
+    const unsigned b_base = lds0 + G_BYTES + (TW == 16 ? 8 * (g >> 1) + q : (g >> 1) * SWC + q) * XP + (16 * (g & 1) + 4 * p) * 2;
+    auto a_off = [](int s, int j) constexpr { return (16 * s + 4 * j) * GP; };
+    auto b_off = [](int s, int j, int kx) constexpr {
+        return (TW == 16 ? s * SWC + 4 * j + kx : ((s >> 2) * 8 + 2 * (s & 3)) * SWC + 4 * j + kx) * XP;
+    };
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[kx][r] = 0.f;
+
+    auto kstep = [&](auto S) {
+        constexpr int s = decltype(S)::value;
+        bf16x4 a0 = lds_read_tr<a_off(s, 0)>(a_base), a1 = lds_read_tr<a_off(s, 1)>(a_base);
+        bf16x4 b00 = lds_read_tr<b_off(s, 0, 0)>(b_base), b10 = lds_read_tr<b_off(s, 1, 0)>(b_base);
+        bf16x4 b01 = lds_read_tr<b_off(s, 0, 1)>(b_base), b11 = lds_read_tr<b_off(s, 1, 1)>(b_base);
+        bf16x4 b02 = lds_read_tr<b_off(s, 0, 2)>(b_base), b12 = lds_read_tr<b_off(s, 1, 2)>(b_base);
+        bf16x4 b03 = lds_read_tr<b_off(s, 0, 3)>(b_base), b13 = lds_read_tr<b_off(s, 1, 3)>(b_base);
+        bf16x4 b04 = lds_read_tr<b_off(s, 0, 4)>(b_base), b14 = lds_read_tr<b_off(s, 1, 4)>(b_base);
+        // (inline asm: the waits are explicit and tied to the fragments so that no MFMA moves above them)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b00), "+v"(b10), "+v"(b01), "+v"(b11),
+                     "+v"(b02), "+v"(b12), "+v"(b03), "+v"(b13), "+v"(b04), "+v"(b14));
+        const bf16x8 fa = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_shufflevector(b00, b10, 0, 1, 2, 3, 4, 5, 6, 7), acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_shufflevector(b01, b11, 0, 1, 2, 3, 4, 5, 6, 7), acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_shufflevector(b02, b12, 0, 1, 2, 3, 4, 5, 6, 7), acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_shufflevector(b03, b13, 0, 1, 2, 3, 4, 5, 6, 7), acc[3], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_shufflevector(b04, b14, 0, 1, 2, 3, 4, 5, 6, 7), acc[4], 0, 0, 0);
+    };
+    if (t_begin < t_end) load_tile(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();                                       // every wave is done with the previous tile's images
+        store_tile();
+        __syncthreads();
+        if (t + 1 < t_end) load_tile(t + 1);                   // in flight while this tile is multiplied
+        kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{});
+        kstep(std::integral_constant<int, 2>{}); kstep(std::integral_constant<int, 3>{});
+        kstep(std::integral_constant<int, 4>{}); kstep(std::integral_constant<int, 5>{});
+        kstep(std::integral_constant<int, 6>{}); kstep(std::integral_constant<int, 7>{});
+    }
+
+    // ---- epilogue: accumulator row = n (8 (r / 4) + 4 (lane / 32) + r % 4 of the wave's 32), column = ci (lane % 32) --------------------
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) {
+        float* base = d.dw + ((size_t)((ky * 5 + kx) * (d.wcin >> 5) + cb) * N + nb * 128 + wave * 32) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(base + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32, acc[kx][r]);
+    }
+}
+
+bool wgrad5x5_bf16_ok(const WgradDesc& d) {
+    if (d.deconv || d.ksize != 5 || d.pad != 2 || d.stride != 1 || d.Hx != d.Hy || d.Wx != d.Wy) return false;
+    if (d.N % 128 || d.cin % 32 || d.c0 % 32 || d.c1 % 32 || d.ld0 % 4 || d.ld1 % 4 || d.ldy % 4 || d.Hx % 8) return false;
+    if (d.Wx % 16 == 0) return true;
+    return d.Wx % 8 == 0 && d.B % 2 == 0;
+}
+
+// d as for igemm_wgrad (ConvLSTM case: 5x5, stride 1, pad 2); dW accumulated with atomics; the bias gradient is left to bias_grad.
+int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s) {
+    PIVP_CHECK_ARG(d.x0 && d.dy && d.dw && wgrad5x5_bf16_ok(d) && (d.c1 == 0 || d.x1) && d.wcin >= d.cin && d.wcin % 32 == 0);
+    constexpr int lds_bytes = G_BYTES + X_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad5x5_bf16_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad5x5_bf16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds_bytes) != hipSuccess)
+            return PIVP_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int tw = d.Wx % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
+    const int n_tiles = (d.B / ti_n) * (d.Hx / 8) * (d.Wx / tw);
+    const int gx = 5 * (d.cin / 32) * (d.N / 128);
+    // two blocks per CU are resident: aim at one full round of 512, at least 2 tiles per block
+    int ns = (512 + gx - 1) / gx;
+    if (ns > n_tiles / 2) ns = n_tiles / 2;
+    if (ns < 1) ns = 1;
+    const int tps = (n_tiles + ns - 1) / ns;
+    ns = (n_tiles + tps - 1) / tps;
+    if (tw == 16) hipLaunchKernelGGL(wgrad5x5_bf16_kernel<16>, dim3(gx, ns), dim3(256), lds_bytes, s, d, tps);
+    else hipLaunchKernelGGL(wgrad5x5_bf16_kernel<8>, dim3(gx, ns), dim3(256), lds_bytes, s, d, tps);
+    return PIVP_LAUNCH_STATUS();
+}
+
+}  // namespace pivp

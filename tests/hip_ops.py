@@ -231,3 +231,16 @@ def conv5x5_bf16(x, W, accum_into=None):
                                      1 if accum_into is not None else 0, B, H, Wd, stream()), 'conv5x5_bf16')
     torch.cuda.synchronize()
     return nchw(out, B, H, Wd, cout)
+
+
+def wgrad5x5_bf16(x, h, dG, h_is_zero=False):
+    """ConvLSTM weight gradient with bf16 operands: x (B,cx,H,W), h (B,C,H,W), dG (B,4C,H,W) -> dW in reference layout (4C, cx+C, 5, 5)."""
+    lib = _lib.load()
+    B, cx, H, Wd = x.shape
+    C = h.shape[1]
+    xd, hd, gd = nhwc(x), nhwc(h), nhwc(dG)
+    dW = torch.zeros(25 * (cx + C) * 4 * C, dtype=torch.float32, device=DEV)
+    _lib.check(lib.pivp_wgrad5x5_bf16(xd.data_ptr(), cx, cx, None if h_is_zero else hd.data_ptr(), C, gd.data_ptr(), dW.data_ptr(),
+                                      B, H, Wd, stream()), 'wgrad5x5_bf16')
+    torch.cuda.synchronize()
+    return pivp_amd.from_internal('lstm1/conv/W', dW.cpu().numpy(), (4 * C, cx + C, 5, 5))

@@ -203,3 +203,36 @@ def test_conv5x5_bf16_accumulates(ops):
     x = _bf16(rs.randn(2, 128, 16, 16)); W = _bf16(rs.randn(64, 128, 5, 5) / np.sqrt(3200)); base = rs.randn(2, 64, 16, 16)
     ref = base + R.conv2d(x, W, np.zeros(64), 1, 2)
     assert np.abs(ops.conv5x5_bf16(x, W, accum_into=base) - ref).max() < TOL
+
+
+# ---- ConvLSTM weight gradient with bf16 operands (transposing LDS reads) ----------------------------------------------------
+def _wgrad_ref(x, h, dG):
+    """dW[n, ci, ky, kx] = sum_{b,y,x} concat(x,h)[b, ci, y+ky-2, x+kx-2] * dG[b, n, y, x] (zero outside the image), float64."""
+    xin = np.concatenate([x, h], 1)
+    B, cin, H, W = xin.shape
+    pad = np.pad(xin, ((0, 0), (0, 0), (2, 2), (2, 2)))
+    dW = np.zeros((dG.shape[1], cin, 5, 5))
+    for ky in range(5):
+        for kx in range(5):
+            dW[:, :, ky, kx] = np.einsum('bnyx,bcyx->nc', dG, pad[:, :, ky:ky + H, kx:kx + W])
+    return dW
+
+
+@pytest.mark.parametrize('B,cx,C,H', [(2, 32, 32, 32), (2, 32, 64, 16), (4, 64, 128, 8), (2, 128, 64, 16), (1, 96, 32, 32), (3, 64, 64, 16)])
+def test_wgrad5x5_bf16_exact_on_bf16_operands(ops, B, cx, C, H):
+    rs = np.random.RandomState(B + cx + C + H)
+    x = _bf16(rs.randn(B, cx, H, H)); h = _bf16(rs.randn(B, C, H, H) * 0.5); dG = _bf16(rs.randn(B, 4 * C, H, H) * 0.1)
+    ref = _wgrad_ref(x, h, dG)
+    got = ops.wgrad5x5_bf16(x, h, dG)
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() < 2e-5 * max(1.0, scale)      # fp32 accumulation over B*H*W products per element
+
+
+def test_wgrad5x5_bf16_first_step_leaves_h_rows_alone(ops):
+    rs = np.random.RandomState(9)
+    B, cx, C, H = 2, 64, 128, 8
+    x = _bf16(rs.randn(B, cx, H, H)); h = np.zeros((B, C, H, H)); dG = _bf16(rs.randn(B, 4 * C, H, H) * 0.1)
+    ref = _wgrad_ref(x, h, dG)
+    got = ops.wgrad5x5_bf16(x, h, dG, h_is_zero=True)
+    assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+    assert np.all(got[:, cx:] == 0)
