@@ -167,8 +167,9 @@ int pivp_conv5x5_bf16(const float* x, int cin, int ldx, const float* w, void* w_
 
 /* ConvLSTM weight gradient with bf16 operands and fp32 accumulation (bf16 mode): dW[tap][ci][n] += sum_m concat(x, h_prev)[m + tap][ci]
  * dG[m][n]; dW K-inner packed like the weight, ACCUMULATED; h_prev may be NULL (first timestep: only the x rows are touched);
- * dG [B*H*W][4C].  Needs 4C % 128 == 0, cx % 32 == 0, C % 32 == 0 and the map geometry of pivp_convlstm_bf16. */
-int pivp_wgrad5x5_bf16(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW,
+ * dG [B*H*W][4C]; db (optional, [4C]) += the column sums of dG, taken in fp32.  Needs 4C % 128 == 0, cx % 32 == 0, C % 32 == 0 and
+ * the map geometry of pivp_convlstm_bf16. */
+int pivp_wgrad5x5_bf16(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW, float* db,
                        int B, int H, int W, void* stream);
 
 /* --- training (what Chainer's autograd does under optimizer.update, TM:950) ---------------------------------- */

@@ -126,8 +126,8 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
     if (!fits31(b0) || (x1 && !fits31(b1)) || !fits31(by)) return PIVP_ERR_BADARG;
     d.bytes0 = (int)b0; d.bytes1 = (int)b1; d.bytesy = (int)by;
     d.db = db;
-    if (bf16) {   // bf16 precision mode (5x5 ConvLSTM case only): operands rounded to bf16, fp32 accumulation; bias left to the caller
-        if (bias_done) *bias_done = 0;
+    if (bf16) {   // bf16 precision mode (5x5 ConvLSTM case only): operands rounded to bf16, fp32 accumulation; db summed on the side in fp32
+        if (bias_done) *bias_done = db != nullptr;
         return wgrad5x5_bf16(d, s);
     }
     return igemm_wgrad(d, s, bias_done);
@@ -280,10 +280,10 @@ extern "C" int pivp_conv5x5_bf16(const float* x, int cin, int ldx, const float* 
     return run_conv5x5_bf16(x, cin, ldx, (const unsigned short*)w_bf16, out, cout, ldo, accum, B, H, W, (hipStream_t)stream);
 }
 // ConvLSTM weight gradient with bf16 operands: dW (K-inner packed like the weight, [25][(cx+C)/32][4C][32]) += x|h^T . dG per tap.
-extern "C" int pivp_wgrad5x5_bf16(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW,
+extern "C" int pivp_wgrad5x5_bf16(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW, float* db,
                                   int B, int H, int W, void* stream) {
     if (!x || !dG || !dW || C <= 0 || cx <= 0) return PIVP_ERR_BADARG;
-    return run_wgrad(0, x, cx, ldx, h_prev, C, C, cx + C, dG, 4 * C, 4 * C, dW, B, H, W, H, W, 5, 2, 1, (hipStream_t)stream, nullptr,
+    return run_wgrad(0, x, cx, ldx, h_prev, C, C, cx + C, dG, 4 * C, 4 * C, dW, B, H, W, H, W, 5, 2, 1, (hipStream_t)stream, db,
                      nullptr, 1);
 }
 static int convlstm_ln_cap(int H, int W, int C) {

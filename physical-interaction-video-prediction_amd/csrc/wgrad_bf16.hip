@@ -100,7 +100,15 @@ __global__ __launch_bounds__(256, 2) void wgrad5x5_bf16_kernel(const WgradDesc d
             rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
         }
     };
+    // bias gradient = column sums of dG: the blocks of kernel row 2 / channel block 0 see every dG pixel of their slice exactly once, in
+    // fp32, on its way into LDS
+    const bool do_bias = d.db != nullptr && ky == 2 && cb == 0;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     auto store_tile = [&]() {
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) bsum += rg[j];
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             uint2 v;
@@ -173,6 +181,13 @@ __global__ __launch_bounds__(256, 2) void wgrad5x5_bf16_kernel(const WgradDesc d
 #pragma unroll
         for (int r = 0; r < 16; ++r) atomicAdd(base + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32, acc[kx][r]);
     }
+    if (do_bias) {   // thread (tid / 32, n4 = tid % 32) holds the sums of columns 4 n4 .. 4 n4 + 3 over its pixels: lanes l and l + 32 pair up
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = bsum[e] + __shfl_xor(bsum[e], 32, 64);
+            if (half == 0) atomicAdd(d.db + nb * 128 + l31 * 4 + e, v);
+        }
+    }
 }
 
 bool wgrad5x5_bf16_ok(const WgradDesc& d) {
@@ -182,7 +197,7 @@ bool wgrad5x5_bf16_ok(const WgradDesc& d) {
     return d.Wx % 8 == 0 && d.B % 2 == 0;
 }
 
-// d as for igemm_wgrad (ConvLSTM case: 5x5, stride 1, pad 2); dW accumulated with atomics; the bias gradient is left to bias_grad.
+// d as for igemm_wgrad (ConvLSTM case: 5x5, stride 1, pad 2); dW and, when d.db is set, the bias gradient accumulated with atomics.
 int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s) {
     PIVP_CHECK_ARG(d.x0 && d.dy && d.dw && wgrad5x5_bf16_ok(d) && (d.c1 == 0 || d.x1) && d.wcin >= d.cin && d.wcin % 32 == 0);
     constexpr int lds_bytes = G_BYTES + X_BYTES;

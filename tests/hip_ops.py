@@ -240,7 +240,8 @@ def wgrad5x5_bf16(x, h, dG, h_is_zero=False):
     C = h.shape[1]
     xd, hd, gd = nhwc(x), nhwc(h), nhwc(dG)
     dW = torch.zeros(25 * (cx + C) * 4 * C, dtype=torch.float32, device=DEV)
+    db = torch.zeros(4 * C, dtype=torch.float32, device=DEV)
     _lib.check(lib.pivp_wgrad5x5_bf16(xd.data_ptr(), cx, cx, None if h_is_zero else hd.data_ptr(), C, gd.data_ptr(), dW.data_ptr(),
-                                      B, H, Wd, stream()), 'wgrad5x5_bf16')
+                                      db.data_ptr(), B, H, Wd, stream()), 'wgrad5x5_bf16')
     torch.cuda.synchronize()
-    return pivp_amd.from_internal('lstm1/conv/W', dW.cpu().numpy(), (4 * C, cx + C, 5, 5))
+    return pivp_amd.from_internal('lstm1/conv/W', dW.cpu().numpy(), (4 * C, cx + C, 5, 5)), db.cpu().numpy()

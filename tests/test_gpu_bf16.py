@@ -223,9 +223,10 @@ def test_wgrad5x5_bf16_exact_on_bf16_operands(ops, B, cx, C, H):
     rs = np.random.RandomState(B + cx + C + H)
     x = _bf16(rs.randn(B, cx, H, H)); h = _bf16(rs.randn(B, C, H, H) * 0.5); dG = _bf16(rs.randn(B, 4 * C, H, H) * 0.1)
     ref = _wgrad_ref(x, h, dG)
-    got = ops.wgrad5x5_bf16(x, h, dG)
+    got, db = ops.wgrad5x5_bf16(x, h, dG)
     scale = np.abs(ref).max()
     assert np.abs(got - ref).max() < 2e-5 * max(1.0, scale)      # fp32 accumulation over B*H*W products per element
+    assert np.abs(db - dG.sum(axis=(0, 2, 3))).max() < 2e-4      # bias gradient: fp32 column sums of dG taken on the side
 
 
 def test_wgrad5x5_bf16_first_step_leaves_h_rows_alone(ops):
@@ -233,6 +234,6 @@ def test_wgrad5x5_bf16_first_step_leaves_h_rows_alone(ops):
     B, cx, C, H = 2, 64, 128, 8
     x = _bf16(rs.randn(B, cx, H, H)); h = np.zeros((B, C, H, H)); dG = _bf16(rs.randn(B, 4 * C, H, H) * 0.1)
     ref = _wgrad_ref(x, h, dG)
-    got = ops.wgrad5x5_bf16(x, h, dG, h_is_zero=True)
+    got, _ = ops.wgrad5x5_bf16(x, h, dG, h_is_zero=True)
     assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
     assert np.all(got[:, cx:] == 0)
