@@ -65,8 +65,9 @@ int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr);
 
 /* Precision of the seven ConvLSTM gate convolutions (BASELINE.json config 3 asks for bf16): PIVP_PRECISION_F32 (default, the
  * parity path) or PIVP_PRECISION_BF16 = x, h and the weights rounded to bf16 on the way into the matrix pipe, fp32 accumulation,
- * gates and state.  All other ops, and the whole backward pass, stay fp32 on the fp32 parameters (the bf16 weight pack is rebuilt
- * at the start of every rollout).  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
+ * gates and state; in the backward pass the ConvLSTM data and weight gradients likewise (operands rounded to bf16, fp32 accumulation
+ * into the fp32 gradients).  All other ops stay fp32, as do the parameters and Adam (the bf16 weight packs are rebuilt at the start of
+ * every rollout / backward sweep).  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
 int pivp_plan_set_precision(pivp_plan_t* plan, int precision);
 int pivp_plan_get_precision(const pivp_plan_t* plan);
 

@@ -233,8 +233,8 @@ extern "C" int pivp_plan_set_grad(pivp_plan_t* plan, int idx, float* dptr) {
     return PIVP_OK;
 }
 // Precision of the ConvLSTM gate convolutions (95 % of the FLOPs): PIVP_PRECISION_F32 (default) or PIVP_PRECISION_BF16 = operands
-// rounded to bf16, fp32 accumulation / gates / state (csrc/convlstm_bf16.hip).  Everything else, and the whole backward pass,
-// stays fp32 on the fp32 parameters.  Refused when a layer's map does not fit the bf16 kernel's tiles (8-wide maps need an even batch).
+// rounded to bf16, fp32 accumulation / gates / state (csrc/convlstm_bf16.hip), and in the backward sweep their data and weight gradients
+// (csrc/convlstm_bf16.hip <NCH, false>, csrc/wgrad_bf16.hip).  Everything else stays fp32, as do the parameters, the gradients and Adam.  Refused when a layer's map does not fit the bf16 kernel's tiles (8-wide maps need an even batch).
 extern "C" int pivp_plan_set_precision(pivp_plan_t* plan, int precision) {
     if (!plan || (precision != PIVP_PRECISION_F32 && precision != PIVP_PRECISION_BF16)) return PIVP_ERR_BADARG;
     if (precision == PIVP_PRECISION_BF16) {

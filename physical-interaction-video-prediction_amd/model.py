@@ -158,8 +158,8 @@ class Model(object):
         self.stp_border = stp_border
         self.keep_activations = bool(keep_activations)
         # 'fp32' is the parity path (per-pixel L2 < 1e-4 vs the reference).  'bf16' (BASELINE.json config 3) rounds the operands of
-        # the seven ConvLSTM gate convolutions to bf16 -- fp32 accumulation, gates, state, every other op and the whole backward
-        # pass stay fp32 -- and reports, not gates, its error.
+        # the seven ConvLSTM gate convolutions and of their data / weight gradients to bf16 -- fp32 accumulation, gates, state, every
+        # other op, the parameters, the gradients and Adam stay fp32 -- and reports, not gates, its error.
         if precision not in ('fp32', 'bf16'):
             raise ValueError("precision must be 'fp32' or 'bf16'")
         self.precision = precision
