@@ -31,8 +31,10 @@ int scaled_diff(const float* a, const float* b, float* out, long n, float scale,
 //   d prev[c](q) = mk[0](q) go[c](q) + sum_ij sum_k kern[k][ij] (mk[k+2] go[c])(q - (ij - 2))     (when dprev != null)
 // The softmax Jacobian couples 11 consecutive flat elements and is applied by mask_softmax_bwd_kernel afterwards.
 // ------------------------------------------------------------------------------------------
-constexpr int CB_TR = 8;
+// rows of the frame per block tile: 8 up to 64-wide frames, 4 for 128-wide ones (the tile's LDS images grow with W)
+constexpr int composite_bwd_rows(int W) { return W <= 64 ? 8 : 4; }
 
+template <int CB_TR>
 __global__ __launch_bounds__(256) void composite_bwd_cdna_kernel(const float* __restrict__ prev, const float* __restrict__ logits,
                                                                  const float* __restrict__ layer0, const float* __restrict__ kerns,
                                                                  const float* __restrict__ go, float* __restrict__ dmk,
@@ -223,18 +225,25 @@ __global__ __launch_bounds__(256) void composite_bwd_cdna_kernel(const float* __
     }
 }
 
-int composite_bwd_tiles(int H) { return (H + CB_TR - 1) / CB_TR; }
+int composite_bwd_tiles(int H, int W) { const int tr = composite_bwd_rows(W); return (H + tr - 1) / tr; }
 
 int composite_bwd_cdna(const float* prev, const float* logits, const float* layer0, const float* kerns, const float* go,
                        float* dmk, float* dz, float* dkpart, float* dprev, int dprev_accum, int B, int H, int W, int NM, hipStream_t s) {
     PIVP_CHECK_ARG(prev && logits && layer0 && kerns && go && dmk && dz && dkpart && B > 0 && H > 1 && W > 1 && NM >= 1 && NM <= 10);
+    const int CB_TR = composite_bwd_rows(W);
     const int NP = NM + 1, PR = CB_TR + 4;
     const int enp = PR * W, win = enp + 2 * (NP - 1), G = enp / NP + 2;
     const size_t lds = sizeof(float) * ((size_t)NP * win + 2 * NP * G + (size_t)NP * PR * W + 3 * PR * W + 3 * PR * (W + 4) + NM * 25);
     PIVP_CHECK_ARG(lds <= 160 * 1024 && W + 4 <= 256 && NM * 25 <= 256);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_cdna_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(composite_bwd_cdna_kernel, dim3(composite_bwd_tiles(H), B), dim3(256), lds, s, prev, logits, layer0, kerns, go, dmk,
-                       dz, dkpart, dprev, dprev_accum, H, W, NM);
+    if (CB_TR == 8) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_cdna_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(composite_bwd_cdna_kernel<8>, dim3(composite_bwd_tiles(H, W), B), dim3(256), lds, s, prev, logits, layer0, kerns, go,
+                           dmk, dz, dkpart, dprev, dprev_accum, H, W, NM);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_cdna_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(composite_bwd_cdna_kernel<4>, dim3(composite_bwd_tiles(H, W), B), dim3(256), lds, s, prev, logits, layer0, kerns, go,
+                           dmk, dz, dkpart, dprev, dprev_accum, H, W, NM);
+    }
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -246,6 +255,7 @@ int composite_bwd_cdna(const float* prev, const float* logits, const float* laye
 //   d e7_j = d kn_j [e7_j - 1e-12 > 0]  (e7 = relu(conv): same mask)  -> dz planar [25]
 //   d prev[c](q) = mk0 go + sum_i [q.y+2 < H and q.x+2 < W] (w_i mk1 go[c])(q - (xk-2, yk-2))
 // ------------------------------------------------------------------------------------------
+template <int CB_TR>
 __global__ __launch_bounds__(256) void composite_bwd_dna_kernel(const float* __restrict__ prev, const float* __restrict__ logits,
                                                                 const float* __restrict__ e7, const float* __restrict__ go,
                                                                 float* __restrict__ dmk, float* __restrict__ dz,
@@ -355,12 +365,19 @@ __global__ __launch_bounds__(256) void composite_bwd_dna_kernel(const float* __r
 int composite_bwd_dna(const float* prev, const float* logits, const float* e7, const float* go, float* dmk, float* dz,
                       float* dprev, int dprev_accum, int B, int H, int W, hipStream_t s) {
     PIVP_CHECK_ARG(prev && logits && e7 && go && dmk && dz && B > 0 && H > 1 && W > 1);
+    const int CB_TR = composite_bwd_rows(W);
     const int PR = CB_TR + 4;
     const size_t lds = sizeof(float) * ((size_t)29 * PR * W + 3 * PR * (W + 4));
     PIVP_CHECK_ARG(lds <= 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_dna_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(composite_bwd_dna_kernel, dim3(composite_bwd_tiles(H), B), dim3(256), lds, s, prev, logits, e7, go, dmk, dz, dprev,
-                       dprev_accum, H, W);
+    if (CB_TR == 8) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_dna_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(composite_bwd_dna_kernel<8>, dim3(composite_bwd_tiles(H, W), B), dim3(256), lds, s, prev, logits, e7, go, dmk, dz, dprev,
+                           dprev_accum, H, W);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_dna_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(composite_bwd_dna_kernel<4>, dim3(composite_bwd_tiles(H, W), B), dim3(256), lds, s, prev, logits, e7, go, dmk, dz, dprev,
+                           dprev_accum, H, W);
+    }
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -613,6 +630,7 @@ int cdna_kernels_bwd(const float* hidden5, const float* wt, const float* vpre, c
 //   d prev (feed-self): mk0*go plus the bilinear weights scattered to the 4 neighbours (atomics into a buffer the caller has
 //            initialised with the loss term)
 // ------------------------------------------------------------------------------------------
+template <int CB_TR>
 __global__ __launch_bounds__(256) void composite_bwd_stp_kernel(const float* __restrict__ prev, const float* __restrict__ logits,
                                                                 const float* __restrict__ layer0, const float* __restrict__ theta,
                                                                 const float* __restrict__ go, float* __restrict__ dmk, float* __restrict__ dz,
@@ -723,12 +741,19 @@ __global__ __launch_bounds__(256) void composite_bwd_stp_kernel(const float* __r
 int composite_bwd_stp(const float* prev, const float* logits, const float* layer0, const float* theta, const float* go,
                       float* dmk, float* dz, float* dthpart, float* dprev, int B, int H, int W, int NM, int stp_zero, hipStream_t s) {
     PIVP_CHECK_ARG(prev && logits && layer0 && theta && go && dmk && dz && dthpart && B > 0 && H > 1 && W > 1 && NM >= 2 && NM <= 10);
+    const int CB_TR = composite_bwd_rows(W);
     const int NP = NM + 1, np = CB_TR * W, win = np + 2 * (NP - 1), G = np / NP + 2;
     const size_t lds = sizeof(float) * ((size_t)NP * win + 2 * NP * G);
     PIVP_CHECK_ARG(lds <= 96 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_stp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(composite_bwd_stp_kernel, dim3(composite_bwd_tiles(H), B), dim3(256), lds, s, prev, logits, layer0, theta, go, dmk, dz,
-                       dthpart, dprev, H, W, NM, stp_zero);
+    if (CB_TR == 8) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_stp_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(composite_bwd_stp_kernel<8>, dim3(composite_bwd_tiles(H, W), B), dim3(256), lds, s, prev, logits, layer0, theta, go, dmk,
+                           dz, dthpart, dprev, H, W, NM, stp_zero);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_stp_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(composite_bwd_stp_kernel<4>, dim3(composite_bwd_tiles(H, W), B), dim3(256), lds, s, prev, logits, layer0, theta, go, dmk,
+                           dz, dthpart, dprev, H, W, NM, stp_zero);
+    }
     return PIVP_LAUNCH_STATUS();
 }
 

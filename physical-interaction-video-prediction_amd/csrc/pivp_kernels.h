@@ -131,7 +131,7 @@ int adam_step(float* p, const float* g, float* m, float* v, long n, double lr_t,
 
 // ---- backward of the heads / trunk ends (csrc/backward_heads.hip) ----
 int scaled_diff(const float* a, const float* b, float* out, long n, float scale, int accum, hipStream_t s);
-int composite_bwd_tiles(int H);
+int composite_bwd_tiles(int H, int W);
 int composite_bwd_cdna(const float* prev, const float* logits, const float* layer0, const float* kerns, const float* go,
                        float* dmk, float* dz, float* dkpart, float* dprev, int dprev_accum, int B, int H, int W, int NM, hipStream_t s);
 int composite_bwd_stp(const float* prev, const float* logits, const float* layer0, const float* theta, const float* go,

@@ -193,7 +193,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
         g.dG = carve(maxdG);
         g.go[0] = carve((size_t)B * 3 * HW); g.go[1] = carve((size_t)B * 3 * HW);
         g.dmk = carve((size_t)B * p->NP * HW); g.dz = carve((size_t)B * p->NE * HW);
-        g.dkpart = carve((size_t)B * composite_bwd_tiles(H) * 256); g.dv = carve((size_t)B * 256);
+        g.dkpart = carve((size_t)B * composite_bwd_tiles(H, W) * 256); g.dv = carve((size_t)B * 256);
         g.dstate = carve((size_t)T * B * 5);
         g.lnpart = carve((size_t)B * ln_bwd_slices((int)(64 * HW)) * 2);
     }
@@ -460,10 +460,10 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         RC(heads_bwd(ws + S.e6, P(p, p->i_masks_w), P(p, p->i_enc7_w), ws + g.dmk, ws + g.dz, ws + g.e6, G(p, p->i_masks_w),
                      G(p, p->i_masks_b), G(p, p->i_enc7_w), G(p, p->i_enc7_b), B, HW, p->NP, p->NE, s));
         if (c.model_type == PIVP_MODEL_CDNA)
-            RC(cdna_kernels_bwd(ws + S.n5, P(p, p->i_head_w), ws + S.vpre, ws + g.dkpart, composite_bwd_tiles(H), ws + g.dv, ws + g.n5, 0,
+            RC(cdna_kernels_bwd(ws + S.n5, P(p, p->i_head_w), ws + S.vpre, ws + g.dkpart, composite_bwd_tiles(H, W), ws + g.dv, ws + g.n5, 0,
                                 G(p, p->i_head_w), G(p, p->i_head_b), B, p->K5, c.num_masks, s));
         else if (c.model_type == PIVP_MODEL_STP)
-            RC(stp_params_bwd(ws + S.n5, P(p, p->i_head_w), ws + S.vpre, P(p, p->i_head2_w), ws + g.dkpart, composite_bwd_tiles(H),
+            RC(stp_params_bwd(ws + S.n5, P(p, p->i_head_w), ws + S.vpre, P(p, p->i_head2_w), ws + g.dkpart, composite_bwd_tiles(H, W),
                               ws + g.dv, ws + g.n5, G(p, p->i_head_w), G(p, p->i_head_b), G(p, p->i_head2_w), G(p, p->i_head2_b),
                               B, p->K5, s));
         else if (hipMemsetAsync(ws + g.n5, 0, (size_t)px8 * 128 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;   // DNA: no hidden5 head

@@ -33,7 +33,7 @@ def _rel(a, b):
     return np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max() / (np.abs(b).max() + 1e-30)
 
 
-@pytest.mark.parametrize('B,cx,C,H,first', [(2, 32, 32, 32, False), (2, 32, 64, 16, False), (3, 64, 128, 8, False),
+@pytest.mark.parametrize('B,cx,C,H,first', [(2, 32, 32, 64, False), (2, 32, 32, 32, False), (2, 32, 64, 16, False), (3, 64, 128, 8, False),
                                             (2, 96, 32, 32, False), (2, 128, 64, 16, True)])
 def test_convlstm_backward(env, B, cx, C, H, first):
     pivp, _lib, lib = env
@@ -85,7 +85,8 @@ def test_convlstm_backward(env, B, cx, C, H, first):
     assert _rel(db.cpu().numpy(), tb.grad.numpy()) < 2e-5
 
 
-@pytest.mark.parametrize('mode,B,cin,cout,H', [(0, 2, 32, 32, 32), (0, 3, 64, 64, 16), (1, 2, 128, 128, 8), (1, 2, 96, 96, 16), (1, 2, 64, 64, 32)])
+@pytest.mark.parametrize('mode,B,cin,cout,H', [(0, 2, 32, 32, 32), (0, 3, 64, 64, 16), (1, 2, 128, 128, 8), (1, 2, 96, 96, 16), (1, 2, 64, 64, 32), (1, 2, 64, 64, 64),
+                                               (0, 2, 32, 32, 64)])
 def test_conv_deconv_backward(env, mode, B, cin, cout, H):
     pivp, _lib, lib = env
     rs = np.random.RandomState(cin + mode)
@@ -114,7 +115,8 @@ def test_conv_deconv_backward(env, mode, B, cin, cout, H):
     assert _rel(db.cpu().numpy(), tb.grad.numpy()) < 2e-5
 
 
-@pytest.mark.parametrize('B,C,H,relu', [(2, 32, 32, True), (3, 64, 16, False), (2, 128, 8, False), (2, 64, 64, True)])
+@pytest.mark.parametrize('B,C,H,relu', [(2, 32, 32, True), (3, 64, 16, False), (2, 128, 8, False), (2, 64, 64, True), (2, 64, 128, True),
+                                       (2, 32, 64, False)])
 def test_layernorm_backward(env, B, C, H, relu):
     pivp, _lib, lib = env
     rs = np.random.RandomState(C)

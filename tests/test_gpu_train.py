@@ -26,7 +26,7 @@ def _autograd(P, imgs, acts, stas, k=-1, it=0, seed=None, **kw):
     return float(loss), {kk: v.grad.numpy() for kk, v in tm.p.items()}
 
 
-def _check_grads(got, ref, tol):
+def _check_grads(got, ref, tol, relu_flips=2):
     """max |got - ref| / max |ref| < tol per tensor.  The per-element LayerNorm parameters behind a ReLU (norm_enc0,
     norm_enc6: 32k / 262k elements, gradient = sum over the BATCH of dy * [y > 0]) get an allowance of 2 elements: an
     activation within fp32 rounding of zero has its mask decided differently in fp32 and in the float64 oracle, which
@@ -37,7 +37,7 @@ def _check_grads(got, ref, tol):
         scale = np.abs(g).max() + 1e-12
         e = np.abs(got[kname].astype(np.float64) - g).ravel() / scale
         if g.size >= 32768 and '/norm/' in kname:
-            e = np.sort(e)[:-2]
+            e = np.sort(e)[:-relu_flips]
         err = e.max()
         worst.append((err, kname))
         assert err < tol, '%s: relative gradient error %.3e (scale %.3e)' % (kname, err, scale)
@@ -226,3 +226,26 @@ def test_overlapped_allreduce_single_rank(pivp):
         assert torch.allclose(m._ensure_grads(), ref, rtol=1e-4, atol=1e-7)
     finally:
         dist.destroy_process_group()
+
+
+def test_bptt_gradients_128x128(pivp):
+    # BASELINE.json config 5 (128x128 frames) trains too: the head backward kernels tile 128-wide frames 4 rows at a time.
+    # norm_enc6 has 1M per-element parameters behind a ReLU here, so a few activations within fp32 rounding of zero get their mask
+    # decided differently than in the float64 oracle (scripts/debug_grad_errors.py 128: exactly 2 elements of norm_enc6/beta off, by one
+    # sample's dy, everything else at 1e-6), and with B = 2 that one-pixel difference is visible in every tensor below it
+    # (relative L2 4e-3, localised around the pixel).  The check is therefore on the relative L2 error and the median element error:
+    # an indexing bug in any kernel moves these to O(0.1 - 1).
+    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, height=128, width=128)
+    imgs, acts, stas = R.synthetic_batch(2, 3, 128, 128)
+    loss_ref, gref = _autograd(P, imgs, acts, stas)
+    m = pivp.Model(10, prefix='t', keep_activations=True)
+    m.load_state_dict_reference(P)
+    loss = float(m([imgs, acts, stas], 0))
+    m.cleargrads(); m.backward()
+    assert abs(loss - loss_ref) < 1e-6
+    got = m.grads_reference()
+    for kname, g in gref.items():
+        d = got[kname].astype(np.float64) - g
+        rel_l2 = np.linalg.norm(d) / (np.linalg.norm(g) + 1e-30)
+        med = np.median(np.abs(d)) / (np.abs(g).max() + 1e-12)
+        assert rel_l2 < 1e-2 and med < 1e-3, '%s: relative L2 %.2e, median %.2e' % (kname, rel_l2, med)
