@@ -405,6 +405,15 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
                 return (idx & 2) ? hi : lo;
             }
         };
+        // Stores go through buffer descriptors: the lane-dependent part of a cell's address (row mlane, channel) is ONE 32-bit offset,
+        // the cell-dependent part (row k * WN + grp -> srow(k) rows further) a scalar offset, and rows past M fall outside the
+        // descriptor and are dropped by the hardware -- no 64-bit address arithmetic and no exec-mask region per cell.
+        const int M = d.M;
+        const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(d.cstate_out, 0, M * C * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc(d.hout, 0, M * C * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(d.gates_out ? d.gates_out : d.hout, 0, d.gates_out ? M * C * 16 : 0, 0x00020000);
+        const int mlane = m0 + wm * 32 + 4 * half + (WN > 1 ? grp : 0);
+        const int vo = (mlane * C + ch) * 4, vog = (mlane * 4 * C + ch) * 4;
         float sv[OWNR];        // this lane's h values, for the fused LayerNorm statistics
         unsigned own = 0;
 #pragma unroll
@@ -421,22 +430,24 @@ __global__ __launch_bounds__(256, 1) void igemm_f32_kernel(const IgemmDesc d) {
 #pragma unroll
                 for (int g = 0; g < WN; ++g) g4[t * WN + g] = pick(val, g ^ grp);
             }
-            const int r = k * WN + grp;
-            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            sv[k] = 0.f;
-            if (m < d.M) {
-                const size_t o = (size_t)m * C + ch;
-                const float aj = fast_tanh(g4[0] + bj), ai = fast_sigmoid(g4[1] + bi);
-                const float af = fast_sigmoid(g4[2] + bf), ao = fast_sigmoid(g4[3] + bo);
-                const float cn = cpre[k] * af + ai * aj;
-                d.cstate_out[o] = cn;
-                const float hn = fast_tanh(cn) * ao;
-                d.hout[o] = hn;
-                sv[k] = hn; own |= 1u << k;
-                if (d.gates_out) {   // training: keep the gate activations for BPTT, [pixel][gate][C]
-                    float* gp = d.gates_out + (size_t)m * 4 * C + ch;
-                    gp[0] = aj; gp[C] = ai; gp[2 * C] = af; gp[3 * C] = ao;
-                }
+            // row r = k * WN + grp of the wave tile is anchor (r & 3) + 8 (r >> 2) (+ 4 half): srow = the part that does not depend on grp
+            const int srow = WN == 1 ? (k & 3) + 8 * (k >> 2) : WN == 2 ? 2 * (k & 1) + 8 * (k >> 1) : 8 * k;
+            const int so = srow * C * 4;                     // scalar
+            const float aj = fast_tanh(g4[0] + bj), ai = fast_sigmoid(g4[1] + bi);
+            const float af = fast_sigmoid(g4[2] + bf), ao = fast_sigmoid(g4[3] + bo);
+            const float cn = cpre[k] * af + ai * aj;
+            const float hn = fast_tanh(cn) * ao;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cn), rsc, vo, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hn), rsh, vo, so, 0);
+            const bool in = mlane + srow < M;
+            sv[k] = in ? hn : 0.f;
+            own |= in ? 1u << k : 0u;
+            if (d.gates_out) {   // training: keep the gate activations for BPTT, [pixel][gate][C]
+                const int sog = so * 4;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, aj), rsg, vog, sog, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ai), rsg, vog, sog + C * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, af), rsg, vog, sog + C * 8, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ao), rsg, vog, sog + C * 12, 0);
             }
         }
         if (d.ln_part) {

@@ -29,7 +29,7 @@ int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, co
     d.N = 4 * C; d.M = B * H * W;
     d.nphase = 1; d.deconv = 0; d.ksize = 5; d.pad = 2;
     const long long b0 = view_bytes(B, H, W, ldx), b1 = view_bytes(B, H, W, C), bw = 25LL * (cx + C) * 4 * C * 4;
-    if (!fits31(b0) || !fits31(b1) || !fits31(bw)) return PIVP_ERR_BADARG;
+    if (!fits31(b0) || !fits31(b1) || !fits31(bw) || (gates_out && !fits31(4 * b1))) return PIVP_ERR_BADARG;   // (epilogue: 32-bit buffer offsets)
     d.bytes0 = (int)b0; d.bytes1 = (int)b1; d.bytesw = (int)bw;
     d.out_step = 1; d.Hout = H; d.Wout = W;
     d.cstate_in = c_in; d.cstate_out = c_out; d.hout = h_out; d.C = C; d.gates_out = gates_out;
