@@ -1,0 +1,189 @@
+// Transposed 3x3 stride-2 convolution (pad 1, outsize = 2 x in: enc4 / enc5 / enc6, TM:505-507, and the data gradient of the 3x3 stride-2
+// convs), all four output parities in one block.
+//
+// igemm_small.hip runs the four sub-pixel phases (1 / 2 / 2 / 4 taps) as four grids of 32-anchor tiles: 16,384 blocks of a few
+// microseconds each for enc6, every one re-gathering its input rows, 40 % of the fp32 MFMA rate.  Here a block owns 8 x 16 INPUT
+// pixels of one image and 32 output columns, for ALL parities: the input patch with its one-pixel right / bottom halo (9 x 17 pixels x
+// 32 channels, zero outside the image = the hardware's out-of-range load result) is staged once per 32-channel chunk, the 9 taps run
+// against it -- tap (ky, kx) reads the patch shifted by (ky == 0, kx == 0) and accumulates into parity (ky != 1, kx != 1) -- and the
+// wave's four 32 x 32 accumulator tiles become a 2 x 2 output pixel block per input pixel.  Weights ([tap][Cin / 32][N][32]: nine 4 KB
+// tiles per channel chunk) and the patch travel global -> register -> LDS one channel chunk ahead, so the 9 taps run without a barrier.  Epilogue: bias, ReLU, optional accumulate, optional LayerNorm
+// partial of the block's 16,384 outputs (the norm behind enc6).  Results equal igemm_small's up to fp32 summation order.
+#include <type_traits>
+
+#include "pivp_kernels.h"
+
+namespace pivp {
+
+namespace {
+constexpr int DP = 36;                 // LDS row pitch (floats): conflict-free ds_read_b128
+constexpr int PR = 9, PC = 17;         // patch rows / columns (8 x 16 anchors + halo)
+constexpr int A_ROWS = 160;             // patch pixel rows allocated: the 5 x 32 staging slots (153 used)
+constexpr int A_FL = A_ROWS * DP;      // 5,760 floats
+constexpr int B_FL = 32 * DP;          // one weight tile [32 columns][36]
+}
+
+__global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDesc d) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // A patch | the 9 weight tiles
+    float* const At = lds;
+    float* const Bt = lds + A_FL;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int H = d.Hin, W = d.Win, N = d.N;
+    const int n_nblk = N >> 5, tpr = W >> 4, tpi = (H >> 3) * tpr;
+    const int n_tiles = d.B * tpi;
+    int lid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware, column-block major
+    const int nblk = lid / n_tiles, tile = lid - nblk * n_tiles;
+    const int b = tile / tpi, trem = tile - b * tpi;
+    const int y0 = (trem / tpr) * 8, x0 = (trem - (trem / tpr) * tpr) * 16;
+    const int ncc = d.c0 >> 5;
+
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x0), 0, d.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, d.bytesw, 0x00020000);
+    constexpr unsigned OOB = 0xC0000000u;
+
+    // ---- staging roles ----------------------------------------------------------------------------------------------------
+    // patch: 153 pixels x 8 float4: thread -> (pixel tid / 8 + 32 j, c4 = tid % 8), j < 5
+    const int c4 = tid & 7;
+    unsigned a_go[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int p = (tid >> 3) + 32 * j;
+        const int py = p / PC, px = p - py * PC;
+        const int iy = y0 + py, ix = x0 + px;
+        const bool ok = p < PR * PC && iy < H && ix < W;
+        a_go[j] = ok ? (unsigned)((((b * H + iy) * W + ix) * d.ld0 + c4 * 4) * 4) : OOB;
+    }
+    // Per 32-channel chunk the patch AND the weight tiles of all 9 taps ([9][32 columns][32 k], 41 KB) are staged together, so the 9 taps
+    // (144 MFMAs per wave) run without a barrier; the next chunk's 14 float4 per thread are in flight in registers meanwhile.
+    const int b_go = (((nblk * 32 + (tid >> 3)) * 32) + c4 * 4) * 4;
+    const int b_lw = (tid >> 3) * DP + c4 * 4;
+    f32x4 rp[5], rw[9];
+    auto load_chunk = [&](int cc) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) rp[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, a_go[j], cc * 128, 0));
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int sbase = __builtin_amdgcn_readfirstlane((t * (d.wcin >> 5) + cc) * N * 128);
+            rw[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, b_go, sbase, 0));
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < 5; ++j)      // unconditional: 160 pixel rows are allocated, rows past 153 receive zeros
+            *reinterpret_cast<f32x4*>(At + ((tid >> 3) + 32 * j) * DP + c4 * 4) = rp[j];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(Bt + t * B_FL + b_lw) = rw[t];
+    };
+
+    f32x16 acc[4];                     // output parity (py, px) -> acc[2 py + px]
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ph][r] = 0.f;
+
+    // A fragment: row l31 of the wave's 32 anchors = patch pixel (2 wave + l31 / 16, l31 % 16), shifted by the tap; B: column l31
+    const int a_lane = ((2 * wave + (l31 >> 4)) * PC + (l31 & 15)) * DP + 4 * half;
+    const int b_lane = l31 * DP + 4 * half;
+
+    // one tap of one 32-channel chunk: 16 MFMAs (k = 32) per wave
+    auto tap_mfmas = [&](auto TAP) {
+        constexpr int tap = decltype(TAP)::value, ky = tap / 3, kx = tap % 3;
+        constexpr int ph = 2 * (ky != 1) + (kx != 1);
+        constexpr int shift = ((ky == 0) * PC + (kx == 0)) * DP;
+        const float* As = At + a_lane + shift;
+        const float* Bs = Bt + tap * B_FL + b_lane;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const f32x4 fa = *reinterpret_cast<const f32x4*>(As + 8 * qd);
+            const f32x4 fb = *reinterpret_cast<const f32x4*>(Bs + 8 * qd);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[ph] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc[ph], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop over the 32-channel chunks ----------------------------------------------------------------------------------------
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int cc = 0; cc < ncc; ++cc) {
+        if (cc + 1 < ncc) load_chunk(cc + 1);
+        tap_mfmas(std::integral_constant<int, 0>{}); tap_mfmas(std::integral_constant<int, 1>{}); tap_mfmas(std::integral_constant<int, 2>{});
+        tap_mfmas(std::integral_constant<int, 3>{}); tap_mfmas(std::integral_constant<int, 4>{}); tap_mfmas(std::integral_constant<int, 5>{});
+        tap_mfmas(std::integral_constant<int, 6>{}); tap_mfmas(std::integral_constant<int, 7>{}); tap_mfmas(std::integral_constant<int, 8>{});
+        if (cc + 1 < ncc) {
+            __syncthreads();               // every wave is done with this chunk's images
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: accumulator row i -> anchor (2 wave + i / 16, i % 16), parity (py, px) -> output pixel (2 y + py, 2 x + px) ----------
+    const int col = nblk * 32 + l31;
+    const float bias = d.bias ? d.bias[col] : 0.f;
+    float s1 = 0.f;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int oy = 2 * (y0 + 2 * wave + (i >> 4)) + (ph >> 1), ox = 2 * (x0 + (i & 15)) + (ph & 1);
+            float* o = d.out + ((size_t)(b * d.Hout + oy) * d.Wout + ox) * d.ldo + col;
+            float v = acc[ph][r] + bias;
+            if (d.relu) v = fmaxf(v, 0.f);
+            if (d.accum) v += *o;
+            *o = v;
+            acc[ph][r] = v;
+            s1 += v;
+        }
+    if (d.ln_part) {   // (count, mean, M2) of the block's 128 x 4 x 32 outputs: two passes over registers, fixed order
+        float* red = lds;
+        s1 = wave_sum(s1);
+        __syncthreads();
+        if (lane == 0) red[wave] = s1;
+        __syncthreads();
+        const float cnt = 16384.f;
+        const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / cnt;
+        float q = 0.f;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float dd = acc[ph][r] - mean; q = fmaf(dd, dd, q); }
+        q = wave_sum(q);
+        if (lane == 0) red[4 + wave] = q;
+        __syncthreads();
+        if (tid == 0) {
+            float* p = d.ln_part + ((size_t)b * d.ln_nparts + (size_t)trem * n_nblk + nblk) * 4;
+            p[0] = cnt; p[1] = mean; p[2] = (red[4] + red[5]) + (red[6] + red[7]); p[3] = 0.f;
+        }
+    }
+}
+
+bool deconv_tile_ok(const IgemmDesc& d) {
+    return d.deconv && d.nphase == 4 && d.c1 == 0 && d.c0 % 32 == 0 && d.N % 32 == 0 && d.Hin % 8 == 0 && d.Win % 16 == 0 &&
+           d.Hout == 2 * d.Hin && d.Wout == 2 * d.Win && d.ld0 % 4 == 0 && d.out != nullptr;
+}
+
+// d as igemm_conv takes it for the transposed conv (validated by the caller); ln_nparts as there.
+int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
+    PIVP_CHECK_ARG(deconv_tile_ok(d));
+    constexpr int lds_bytes = (A_FL + 9 * B_FL) * 4;      // 64,512
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+            return PIVP_ERR_LAUNCH;
+        attr_set = true;
+    }
+    IgemmDesc dd = d;
+    const int tpi = (d.Hin / 8) * (d.Win / 16), nb = d.N / 32;
+    const int np = tpi * nb;
+    dd.ln_nparts = (d.ln_part && np <= d.ln_cap) ? np : 0;
+    if (!dd.ln_nparts) dd.ln_part = nullptr;
+    if (ln_nparts) *ln_nparts = dd.ln_nparts;
+    hipLaunchKernelGGL(deconv3x3s2_tile_kernel, dim3(d.B * tpi * nb), dim3(256), lds_bytes, stream, dd);
+    return PIVP_LAUNCH_STATUS();
+}
+
+}  // namespace pivp

@@ -61,6 +61,9 @@ int repack_transpose(const float* w, float* wt, int taps, int cin, int N, int fl
 int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant = 0, int* ln_nparts = nullptr);  // 0 auto, 1: 4x1 waves, 2: 2x2, 3: 1x4
 int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr);
 int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr);
+// transposed 3x3 s2 conv, all four output parities per block (csrc/deconv_tile.hip); d validated by igemm_validate
+bool deconv_tile_ok(const IgemmDesc& d);
+int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr);
 // bf16-operand ConvLSTM (csrc/convlstm_bf16.hip): wb = pack_lstm_bf16 of d.w; nch: 0 auto, 16 / 32 channels per block
 size_t lstm_bf16_weight_elems(int wcin, int N);
 int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s, int Np = 0);
