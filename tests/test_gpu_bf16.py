@@ -187,7 +187,7 @@ def test_bf16_precision_refused_for_unsupported_geometry():
 
 # ---- plain 5x5 convolution of the same kernel (the ConvLSTM data gradient of the bf16 mode) -----------------------------
 @pytest.mark.parametrize('B,cin,cout,H', [(2, 128, 64, 32), (2, 256, 96, 16), (4, 512, 192, 8), (2, 256, 128, 16), (1, 128, 128, 32),
-                                          (32, 512, 192, 8)])
+                                          (32, 512, 192, 8), (1, 128, 64, 64)])
 def test_conv5x5_bf16_exact_on_bf16_operands(ops, B, cin, cout, H):
     # shapes of the seven data gradients (cin = 4C gate channels, cout = Cx + C); cout = 96 exercises the padded column block,
     # the 8x8 / B = 4 case the K-split over channel groups with atomic adds, B = 32 the unsplit 8x8 grid
@@ -218,7 +218,8 @@ def _wgrad_ref(x, h, dG):
     return dW
 
 
-@pytest.mark.parametrize('B,cx,C,H', [(2, 32, 32, 32), (2, 32, 64, 16), (4, 64, 128, 8), (2, 128, 64, 16), (1, 96, 32, 32), (3, 64, 64, 16)])
+@pytest.mark.parametrize('B,cx,C,H', [(2, 32, 32, 32), (2, 32, 64, 16), (4, 64, 128, 8), (2, 128, 64, 16), (1, 96, 32, 32), (3, 64, 64, 16),
+                                      (1, 32, 32, 64)])
 def test_wgrad5x5_bf16_exact_on_bf16_operands(ops, B, cx, C, H):
     rs = np.random.RandomState(B + cx + C + H)
     x = _bf16(rs.randn(B, cx, H, H)); h = _bf16(rs.randn(B, C, H, H) * 0.5); dG = _bf16(rs.randn(B, 4 * C, H, H) * 0.1)
