@@ -528,19 +528,26 @@ int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stre
 // with pixel stride d.ldo.  x = d.x0 | d.x1 (fp32 NHWC, rounded to bf16 on the way into LDS); wb = pack_lstm_bf16(w, c0 + c1, d.N,
 // conv5x5_bf16_rows(d.N)).  d.accum adds into out; d.ksplit_ok (out pre-zeroed, no accum) lets grids that would leave CUs idle split
 // the channel groups over gridDim.y and meet in out by atomic adds.  This is the ConvLSTM data gradient (x = dG, 4C channels).
-int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream) {
-    PIVP_CHECK_ARG(wb && bf16_geometry_ok(d) && d.out && d.N > 0 && d.ldo >= d.N && d.x0 && d.c0 > 0);
+// ks > 1 (the K split conv5x5_bf16 will use) needs a zeroed destination: the caller asks first so that it only clears when needed
+int conv5x5_bf16_ksplit(const IgemmDesc& d) {
     const int Np = conv5x5_bf16_rows(d.N);
     const int tw = d.Win % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
     const int tiles = (d.B / ti_n) * (d.Hin / TH) * (d.Win / tw);
-    const int ncg = (d.c0 + d.c1 + 63) / 64;
+    const int ncg = (d.c0 + d.c1 + 63) / 64, nb = Np / (Np % 128 == 0 ? 128 : 64);
+    int ks = 1;
+    if (d.ksplit_ok && !d.accum)
+        while (ks * 2 <= ncg && (long)tiles * nb * ks * 2 <= 512) ks *= 2;
+    return ks;
+}
+
+int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream) {
+    PIVP_CHECK_ARG(wb && bf16_geometry_ok(d) && d.out && d.N > 0 && d.ldo >= d.N && d.x0 && d.c0 > 0);
+    const int Np = conv5x5_bf16_rows(d.N);
     IgemmDesc dd = d;
     dd.N = Np;                                         // the kernel's weight-row count
     const bool wide = Np % 128 == 0;
     const int nb = Np / (wide ? 128 : 64);
-    int ks = 1;
-    if (d.ksplit_ok && !d.accum)
-        while (ks * 2 <= ncg && (long)tiles * nb * ks * 2 <= 512) ks *= 2;
+    const int ks = conv5x5_bf16_ksplit(d);
     return wide ? launch_bf16<32, false>(dd, wb, stream, nullptr, nb, ks, d.N)
                 : launch_bf16<16, false>(dd, wb, stream, nullptr, nb, ks, d.N);
 }

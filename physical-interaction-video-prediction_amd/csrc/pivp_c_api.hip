@@ -104,9 +104,9 @@ int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb,
     if (!fits31(b0)) return PIVP_ERR_BADARG;
     d.bytes0 = (int)b0;
     d.out_step = 1; d.Hout = H; d.Wout = W; d.out = out; d.ldo = ldo; d.accum = accum;
-    if (!accum && ldo == cout) {     // contiguous fresh output: allow the K-split path (needs a zeroed destination)
-        if (hipMemsetAsync(out, 0, (size_t)B * H * W * cout * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
+    if (!accum && ldo == cout) {     // contiguous fresh output: the K-split path may be used; it needs a zeroed destination
         d.ksplit_ok = 1;
+        if (conv5x5_bf16_ksplit(d) > 1 && hipMemsetAsync(out, 0, (size_t)B * H * W * cout * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     }
     return conv5x5_bf16(d, wb, s);
 }
