@@ -10,10 +10,13 @@
 // the hardware zeros of an out-of-range buffer load) and runs the 25 taps against it: a tap only shifts the LDS address
 // of the A fragment.  The weights ([group][tap][4C][64] bf16, packed once per rollout by pack_lstm_bf16) stream through a
 // 4-slot LDS ring filled by global_load_lds_dwordx4 three taps ahead of their use: no VGPRs, no ds_writes, and the
-// loads stay in flight across the per-tap barrier (raw s_barrier + counted vmcnt).  A ring slot is lane-linear (the DMA
+// loads stay in flight across the per-tap barrier (raw s_barrier + counted vmcnt).  The DMAs are issued by four LOADER
+// waves (waves 4..7 of the 8-wave block) that do nothing else in the tap loop; waves 0..3 multiply (2 x 2 over the
+// 128 x 4 NCH block tile) and issue no VMEM instruction there.  A ring slot is lane-linear (the DMA
 // writes base + lane * 16), so bank conflicts of the B fragment reads are removed by an XOR swizzle of the 16-B pieces
 // of a 128-B weight row, applied to the per-lane SOURCE address of the DMA and to the read address alike.
 // Accumulators, gate math, cell state, h and the LayerNorm partial stay fp32; the epilogue is that of igemm_f32.hip.
+// The same kernel with a plain epilogue (LSTM = false) is a general 5x5 stride-1 convolution: the ConvLSTM data gradient.
 #include <type_traits>
 
 #include "pivp_kernels.h"
