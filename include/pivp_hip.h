@@ -63,7 +63,7 @@ const char* pivp_param_name(const pivp_plan_t* plan, int idx);      /* Chainer s
 long long pivp_param_numel(const pivp_plan_t* plan, int idx);       /* elements in internal layout */
 int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr);
 
-/* Precision of the seven ConvLSTM gate convolutions (BASELINE.json config 3 asks for bf16): PIVP_PRECISION_F32 (default, the
+/* Precision of the seven ConvLSTM gate convolutions and of the enc5 / enc6 transposed convs (BASELINE.json config 3 asks for bf16): PIVP_PRECISION_F32 (default, the
  * parity path) or PIVP_PRECISION_BF16 = x, h and the weights rounded to bf16 on the way into the matrix pipe, fp32 accumulation,
  * gates and state; in the backward pass the ConvLSTM data and weight gradients likewise (operands rounded to bf16, fp32 accumulation
  * into the fp32 gradients).  All other ops stay fp32, as do the parameters and Adam (the bf16 weight packs are rebuilt at the start of
@@ -157,6 +157,11 @@ int pivp_pack_lstm_bf16(const float* w, void* w_bf16, int cin_total, int C, void
 int pivp_convlstm_bf16(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
                        const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
                        int* ln_nparts, int B, int H, int W, int nch, void* stream);
+
+/* pivp_deconv3x3s2 with bf16 operands (precision mode bf16): x and w are rounded to bf16 on the way into the matrix pipe, accumulation, bias
+ * and ReLU stay fp32.  Only maps with Hin % 8 == 0 and Win % 16 == 0 (and at least 16 tiles x column blocks) run in bf16; the call is the fp32 op otherwise. */
+int pivp_deconv3x3s2_bf16(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
+                          int ldo, int relu, int B, int Hin, int Win, void* stream);
 
 /* Plain 5x5 stride-1 "same" convolution with bf16 operands and fp32 accumulation, out[b,y,x,n] (+)= sum x[b,y+dy,x+dx,k] w[tap][k][n]
  * (the ConvLSTM data gradient of the bf16 mode: x = d gates, w = the flipped transposed weights).  x NHWC (cin channels, stride ldx);

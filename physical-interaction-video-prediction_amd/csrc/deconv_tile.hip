@@ -21,12 +21,27 @@ constexpr int PR = 9, PC = 17;         // patch rows / columns (8 x 16 anchors +
 constexpr int A_ROWS = 160;             // patch pixel rows allocated: the 5 x 32 staging slots (153 used)
 constexpr int A_FL = A_ROWS * DP;      // 5,760 floats
 constexpr int B_FL = 32 * DP;          // one weight tile [32 columns][36]
+// bf16 form (precision mode bf16): the same images with 32 bf16 + 16 B of padding per row
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int HP = 80;                 // row pitch (bytes)
+constexpr int A_HB = A_ROWS * HP, B_HB = 32 * HP;
+__device__ __forceinline__ unsigned dpack2(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
 }
 
+// BF16: operands rounded to bf16 on their way into LDS (activations AND weights: both stay fp32 in HBM), v_mfma_f32_32x32x16_bf16, fp32
+// accumulation and epilogue.
+template <bool BF16>
 __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDesc d) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // A patch | the 9 weight tiles
     float* const At = lds;
     float* const Bt = lds + A_FL;
+    unsigned char* const Ah = reinterpret_cast<unsigned char*>(lds);       // BF16: byte-addressed images
+    unsigned char* const Bh = Ah + A_HB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -71,11 +86,24 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
         }
     };
     auto store_chunk = [&]() {
+        if constexpr (BF16) {
 #pragma unroll
-        for (int j = 0; j < 5; ++j)      // unconditional: 160 pixel rows are allocated, rows past 153 receive zeros
-            *reinterpret_cast<f32x4*>(At + ((tid >> 3) + 32 * j) * DP + c4 * 4) = rp[j];
+            for (int j = 0; j < 5; ++j) {
+                uint2 v; v.x = dpack2(rp[j][0], rp[j][1]); v.y = dpack2(rp[j][2], rp[j][3]);
+                *reinterpret_cast<uint2*>(Ah + ((tid >> 3) + 32 * j) * HP + c4 * 8) = v;
+            }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(Bt + t * B_FL + b_lw) = rw[t];
+            for (int t = 0; t < 9; ++t) {
+                uint2 v; v.x = dpack2(rw[t][0], rw[t][1]); v.y = dpack2(rw[t][2], rw[t][3]);
+                *reinterpret_cast<uint2*>(Bh + t * B_HB + (tid >> 3) * HP + c4 * 8) = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j)      // unconditional: 160 pixel rows are allocated, rows past 153 receive zeros
+                *reinterpret_cast<f32x4*>(At + ((tid >> 3) + 32 * j) * DP + c4 * 4) = rp[j];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(Bt + t * B_FL + b_lw) = rw[t];
+        }
     };
 
     f32x16 acc[4];                     // output parity (py, px) -> acc[2 py + px]
@@ -92,6 +120,16 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
     auto tap_mfmas = [&](auto TAP) {
         constexpr int tap = decltype(TAP)::value, ky = tap / 3, kx = tap % 3;
         constexpr int ph = 2 * (ky != 1) + (kx != 1);
+        if constexpr (BF16) {              // k = 32 in two MFMAs; lane: row l31, k = 16 ks + 8 half .. + 7
+            constexpr int prow = (ky == 0) * PC + (kx == 0);
+            const unsigned char* Ar = Ah + ((2 * wave + (l31 >> 4)) * PC + (l31 & 15) + prow) * HP + half * 16;
+            const unsigned char* Br = Bh + tap * B_HB + l31 * HP + half * 16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Ar + ks * 32),
+                                                                  *reinterpret_cast<const bf16x8*>(Br + ks * 32), acc[ph], 0, 0, 0);
+            return;
+        }
         constexpr int shift = ((ky == 0) * PC + (kx == 0)) * DP;
         const float* As = At + a_lane + shift;
         const float* Bs = Bt + tap * B_FL + b_lane;
@@ -167,12 +205,12 @@ bool deconv_tile_ok(const IgemmDesc& d) {
 }
 
 // d as igemm_conv takes it for the transposed conv (validated by the caller); ln_nparts as there.
-int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
+int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts, bool bf16) {
     PIVP_CHECK_ARG(deconv_tile_ok(d));
-    constexpr int lds_bytes = (A_FL + 9 * B_FL) * 4;      // 64,512
+    constexpr int lds_f32 = (A_FL + 9 * B_FL) * 4;        // 64,512 (the bf16 images fit inside)
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_f32) != hipSuccess)
             return PIVP_ERR_LAUNCH;
         attr_set = true;
     }
@@ -182,7 +220,8 @@ int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     dd.ln_nparts = (d.ln_part && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
-    hipLaunchKernelGGL(deconv3x3s2_tile_kernel, dim3(d.B * tpi * nb), dim3(256), lds_bytes, stream, dd);
+    if (bf16) hipLaunchKernelGGL(deconv3x3s2_tile_kernel<true>, dim3(d.B * tpi * nb), dim3(256), A_HB + 9 * B_HB, stream, dd);
+    else hipLaunchKernelGGL(deconv3x3s2_tile_kernel<false>, dim3(d.B * tpi * nb), dim3(256), lds_f32, stream, dd);
     return PIVP_LAUNCH_STATUS();
 }
 

@@ -57,9 +57,10 @@ int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float*
 
 int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                     int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum, float* ln_part, int ln_cap,
-                    int* ln_nparts) {
+                    int* ln_nparts, int bf16) {
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
+    d.bf16 = bf16;                   // precision mode bf16: honoured by the all-parities tile kernel (deconv_tile.hip), fp32 otherwise
     d.x0 = x; d.c0 = cin; d.ld0 = ldx; d.wcin = cin; d.w = w; d.bias = bias;
     d.B = B; d.Hin = Hin; d.Win = Win; d.Hg = Hin; d.Wg = Win; d.in_step = 1;
     d.N = cout; d.M = B * Hin * Win;
@@ -330,6 +331,13 @@ extern "C" int pivp_deconv3x3s2(const float* x, int cin, int ldx, const float* w
                                 int ldo, int relu, int B, int Hin, int Win, void* stream) {
     if (!x || !w || !out) return PIVP_ERR_BADARG;
     return run_deconv3x3s2(x, cin, ldx, w, bias, out, cout, ldo, relu, B, Hin, Win, (hipStream_t)stream);
+}
+// bf16-operand form (precision mode bf16): x and w rounded to bf16 on the way into LDS, fp32 accumulation / bias / ReLU.  Only maps that the
+// all-parities tile kernel takes (Hin % 8 == 0, Win % 16 == 0, at least 16 blocks) run in bf16; others fall to the fp32 kernels.
+extern "C" int pivp_deconv3x3s2_bf16(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
+                                     int ldo, int relu, int B, int Hin, int Win, void* stream) {
+    if (!x || !w || !out) return PIVP_ERR_BADARG;
+    return run_deconv3x3s2(x, cin, ldx, w, bias, out, cout, ldo, relu, B, Hin, Win, (hipStream_t)stream, 0, nullptr, 0, nullptr, 1);
 }
 extern "C" int pivp_conv_enc0(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, void* stream) {
     return conv_enc0(img, w, bias, out, B, H, W, (hipStream_t)stream);

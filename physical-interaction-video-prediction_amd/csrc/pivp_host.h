@@ -14,7 +14,7 @@ int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float*
                   int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0);
 int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                     int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0,
-                    float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr);
+                    float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr, int bf16 = 0);
 int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, int cout, int ldo, int ksize, int B, int H, int W,
                 hipStream_t s, int accum = 0);
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,

@@ -158,7 +158,7 @@ class Model(object):
         self.stp_border = stp_border
         self.keep_activations = bool(keep_activations)
         # 'fp32' is the parity path (per-pixel L2 < 1e-4 vs the reference).  'bf16' (BASELINE.json config 3) rounds the operands of
-        # the seven ConvLSTM gate convolutions and of their data / weight gradients to bf16 -- fp32 accumulation, gates, state, every
+        # the seven ConvLSTM gate convolutions, of their data / weight gradients and of the enc5 / enc6 transposed convs to bf16 -- fp32 accumulation, gates, state, every
         # other op, the parameters, the gradients and Adam stay fp32 -- and reports, not gates, its error.
         if precision not in ('fp32', 'bf16'):
             raise ValueError("precision must be 'fp32' or 'bf16'")

@@ -99,14 +99,15 @@ def conv3x3s2(x, W, b, relu):
     return nchw(out, B, H // 2, Wd // 2, cout)
 
 
-def deconv3x3s2(x, W, b, relu):
+def deconv3x3s2(x, W, b, relu, bf16=False):
     lib = _lib.load()
     B, cin, H, Wd = x.shape
     cout = W.shape[1]
     xd, wd, bd = nhwc(x), _t(pivp_amd.to_internal('enc4/W', W)), _t(b)
     out = torch.empty((B, 2 * H, 2 * Wd, cout), dtype=torch.float32, device=DEV)
-    _lib.check(lib.pivp_deconv3x3s2(xd.data_ptr(), cin, cin, wd.data_ptr(), bd.data_ptr(), out.data_ptr(), cout, cout,
-                                    int(relu), B, H, Wd, stream()), 'deconv3x3s2')
+    fn = lib.pivp_deconv3x3s2_bf16 if bf16 else lib.pivp_deconv3x3s2
+    _lib.check(fn(xd.data_ptr(), cin, cin, wd.data_ptr(), bd.data_ptr(), out.data_ptr(), cout, cout,
+                  int(relu), B, H, Wd, stream()), 'deconv3x3s2')
     torch.cuda.synchronize()
     return nchw(out, B, 2 * H, 2 * Wd, cout)
 

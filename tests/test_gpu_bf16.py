@@ -238,3 +238,19 @@ def test_wgrad5x5_bf16_first_step_leaves_h_rows_alone(ops):
     got, _ = ops.wgrad5x5_bf16(x, h, dG, h_is_zero=True)
     assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
     assert np.all(got[:, cx:] == 0)
+
+
+# ---- transposed 3x3 stride-2 conv with bf16 operands (enc5 / enc6 in the bf16 mode) ---------------------------------------------------
+@pytest.mark.parametrize('B,cin,cout,H,relu', [(2, 64, 64, 32, False), (4, 96, 96, 16, True), (2, 128, 128, 16, True)])
+def test_deconv3x3s2_bf16_exact_on_bf16_operands(ops, B, cin, cout, H, relu):
+    rs = np.random.RandomState(cin + H)
+    x = _bf16(rs.randn(B, cin, H, H)); W = _bf16(rs.randn(cin, cout, 3, 3) / np.sqrt(9 * cin)); b = rs.randn(cout) * 0.1
+    ref = R.deconv2d(x, W, b, 2, 1, (2 * H, 2 * H))
+    if relu:
+        ref = R.relu(ref)
+    got = ops.deconv3x3s2(x, W, b, relu, bf16=True)
+    assert np.abs(got - ref).max() < TOL
+    # and the unrounded operands differ from the fp32 op by the operand rounding only
+    x2 = rs.randn(B, cin, H, H); W2 = rs.randn(cin, cout, 3, 3) / np.sqrt(9 * cin)
+    d = np.abs(ops.deconv3x3s2(x2, W2, b, relu, bf16=True) - ops.deconv3x3s2(x2, W2, b, relu)).max()
+    assert 1e-5 < d < 2e-2
