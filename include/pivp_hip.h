@@ -31,6 +31,7 @@ extern "C" {
 
 #define PIVP_PRECISION_F32 0
 #define PIVP_PRECISION_BF16 1
+#define PIVP_PRECISION_BF16X3 2
 
 int pivp_abi_version(void);   /* 5 (2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
                                  5: + bf16 ConvLSTM, pivp_plan_set_precision) */
@@ -67,7 +68,10 @@ int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr);
  * parity path) or PIVP_PRECISION_BF16 = x, h and the weights rounded to bf16 on the way into the matrix pipe, fp32 accumulation,
  * gates and state; in the backward pass the ConvLSTM data and weight gradients likewise (operands rounded to bf16, fp32 accumulation
  * into the fp32 gradients).  All other ops stay fp32, as do the parameters and Adam (the bf16 weight packs are rebuilt at the start of
- * every rollout / backward sweep).  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
+ * every rollout / backward sweep).
+ * PIVP_PRECISION_BF16X3 = the split mode: only the FORWARD gate convolutions change -- each fp32 operand travels as two bf16 numbers (hi, lo)
+ * and a product is three bf16 MFMAs, 16 bits of product mantissa, fp32 accumulation -- and the result stays inside the 1e-4 per-pixel gate
+ * (3e-5 on the config 1 rollout; tests/test_gpu_bf16.py); the backward pass and every other op are the fp32 ones.  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
 int pivp_plan_set_precision(pivp_plan_t* plan, int precision);
 int pivp_plan_get_precision(const pivp_plan_t* plan);
 
@@ -157,6 +161,14 @@ int pivp_pack_lstm_bf16(const float* w, void* w_bf16, int cin_total, int C, void
 int pivp_convlstm_bf16(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
                        const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
                        int* ln_nparts, int B, int H, int W, int nch, void* stream);
+
+/* Split form of pivp_convlstm_bf16 (precision mode PIVP_PRECISION_BF16X3): every fp32 operand travels as two bf16 numbers, hi = bf16(v) and
+ * lo = bf16(v - hi), and a product is formed on three bf16 MFMAs (lo*hi + hi*lo + hi*hi, fp32 accumulation): 16 bits of product mantissa.
+ * w_bf16 = pivp_pack_lstm_bf16x3(w): 2 * pivp_lstm_bf16_weight_elems(cx + C, C) 2-byte elements.  Other arguments as pivp_convlstm_bf16. */
+int pivp_pack_lstm_bf16x3(const float* w, void* w_bf16, int cin_total, int C, void* stream);
+int pivp_convlstm_bf16x3(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
+                         const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
+                         int* ln_nparts, int B, int H, int W, void* stream);
 
 /* pivp_deconv3x3s2 with bf16 operands (precision mode bf16): x and w are rounded to bf16 on the way into the matrix pipe, accumulation, bias
  * and ReLU stay fp32.  Only maps with Hin % 8 == 0 and Win % 16 == 0 (and at least 16 tiles x column blocks) run in bf16; the call is the fp32 op otherwise. */

@@ -56,21 +56,27 @@ __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x
 __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
 }
+__device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& e, bf16x8& f, bf16x8& g) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e), "+v"(f), "+v"(g));
+}
 }  // namespace
 
-// fp32 K-inner packed weights [25][wcin/32][N][32] -> bf16 [ceil(wcin/64)][25][Np][64], channels past wcin and rows past N zero
-__global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int N, int Np, long total) {
+// fp32 K-inner packed weights [25][wcin/32][N][32] -> bf16 [ceil(wcin/64)][25][PL][Np][64], channels past wcin and rows past N zero.
+// PL = 1: plane 0 = bf16(w).  PL = 2 (split mode): plane 0 = hi = bf16(w), plane 1 = lo = bf16(w - hi).
+__global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int N, int Np, int PL, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int c64 = (int)(i & 63);
     long r = i >> 6;
     const int n = (int)(r % Np); r /= Np;
+    const int pl = (int)(r % PL); r /= PL;
     const int tap = (int)(r % 25);
     const int cg = (int)(r / 25);
     const int ch = cg * 64 + c64;
     float v = 0.f;
     if (ch < wcin && n < N) v = w[(((long)tap * (wcin >> 5) + (ch >> 5)) * N + n) * 32 + (ch & 31)];
-    const __bf16 h = (__bf16)v;
+    __bf16 h = (__bf16)v;
+    if (pl == 1) h = (__bf16)(v - (float)h);
     wb[i] = __builtin_bit_cast(unsigned short, h);
 }
 
@@ -84,16 +90,21 @@ __device__ long long pivp_bf16_stamps[8];
 // LSTM = true: the ConvLSTM cell (block columns = 4 gates x NCH channels, gate epilogue).  LSTM = false: a plain 5x5 stride-1 "same"
 // convolution out[m][n] (+)= sum x[m + tap][k] w[tap][k][n] with block columns = 4 NCH consecutive n (the ConvLSTM DATA gradient: x = dG,
 // w = the flipped transposed weights); gridDim.y splits the channel groups, partial sums then meet in `out` by atomic adds.
-template <int NCH, bool LSTM>
+// PL = 2: split mode.  Every fp32 operand travels as TWO bf16 numbers, hi = bf16(v) and lo = bf16(v - hi) (two patch planes, two weight
+// planes per ring slot), and a product a * b is formed as a_lo * b_hi + a_hi * b_lo + a_hi * b_hi on three MFMAs (each exact in fp32):
+// 16 bits of product mantissa instead of 8, 3e-5 instead of 2e-2 per-pixel on the config 1 rollout (scripts/split_bf16_study.py).
+template <int NCH, bool LSTM, int PL = 1>
 __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int tw, int ncols) {
     constexpr int BN = 4 * NCH;                 // block columns: [gate][channel]
-    constexpr int SLOT = BN * 128;              // bytes of one ring slot: BN rows x 64 bf16
+    constexpr int PLANE = BN * 128;             // one weight plane of a ring slot: BN rows x 64 bf16
+    constexpr int SLOT = PL * PLANE;            // bytes of one ring slot
+    static_assert(PL == 1 || (PL == 2 && NCH == 16 && LSTM), "the split mode runs the 16-channel LSTM blocks");
     constexpr int G = BN / 32;                  // global_load_lds per loader thread and tap
     constexpr int TPW = NCH / 16;               // MFMA column tiles per wave
     constexpr int CPW = NCH / 2;                // channels per wave (all 4 gates of a channel stay in one wave)
     constexpr int GPT = 32 / CPW;               // gates per MFMA tile
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // patch | ring
-    unsigned char* const patch = lds;
+    unsigned char* const patch = lds;                  // patch plane(s) | ring
     const int tid = threadIdx.x, lane = tid & 63;
     // waves 0..3 multiply (2 x 2 over the 128 x BN block tile), waves 4..7 only feed the weight ring: a global_load_lds costs
     // 60-180 cycles of its wave's issue time, which in a multiplying wave is time the matrix pipe idles (4 per tap: a quarter
@@ -168,6 +179,15 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
             v.x = pack2(plo[j][0], plo[j][1]); v.y = pack2(plo[j][2], plo[j][3]);
             v.z = pack2(phi[j][0], phi[j][1]); v.w = pack2(phi[j][2], phi[j][3]);
             *reinterpret_cast<uint4*>(patch + p * PP + cpiece * 16) = v;
+            if constexpr (PL == 2) {                   // lo plane: bf16(v - hi); hi as a float is its 16 bits shifted up
+                auto lo2 = [](unsigned hi2, float a, float b) {
+                    return pack2(a - __builtin_bit_cast(float, hi2 << 16), b - __builtin_bit_cast(float, hi2 & 0xffff0000u));
+                };
+                uint4 l;
+                l.x = lo2(v.x, plo[j][0], plo[j][1]); l.y = lo2(v.y, plo[j][2], plo[j][3]);
+                l.z = lo2(v.z, phi[j][0], phi[j][1]); l.w = lo2(v.w, phi[j][2], phi[j][3]);
+                *reinterpret_cast<uint4*>(patch + PATCH_BYTES + p * PP + cpiece * 16) = l;
+            }
         }
     };
 
@@ -181,7 +201,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     // =========================================================================================================================
     if (loader) {
         const int lt = tid - 256;
-        unsigned char* const ring = lds + PATCH_BYTES;
+        unsigned char* const ring = lds + PL * PATCH_BYTES;
         const unsigned char* wsrc[G];
 #pragma unroll
         for (int j = 0; j < G; ++j) {
@@ -190,7 +210,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
             const int grow = LSTM ? g * C + nblk * NCH + cl : nblk * BN + row;
             wsrc[j] = reinterpret_cast<const unsigned char*>(wb) + (size_t)grow * 128 + piece * 16;
         }
-        const size_t wstep = (size_t)N * 128;          // bytes between consecutive (group, tap) weight tiles
+        const size_t wstep = (size_t)PL * N * 128;     // bytes between consecutive (group, tap) weight tiles ([PL][N][64] bf16 each)
         int issued = 0, i_tap = tap0, i_cg = 0;        // taps issued; the next one to issue
         auto issue_weights = [&]() {
             const int slot = issued & (NSLOT - 1);
@@ -198,11 +218,13 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
             i_tap = i_tap == 24 ? 0 : i_tap + 1;
             i_cg += i_tap == tap0 ? 1 : 0;
 #pragma unroll
-            for (int j = 0; j < G; ++j) {
-                unsigned char* dst = ring + slot * SLOT + (j * 256 + wave * 64) * 16;    // wave-uniform; the DMA adds lane * 16
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + goff),
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            }
+            for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    unsigned char* dst = ring + slot * SLOT + pl * PLANE + (j * 256 + wave * 64) * 16;   // wave-uniform; the DMA adds lane * 16
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + goff + (size_t)pl * N * 128),
+                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                }
             ++issued;
         };
 #pragma unroll
@@ -217,7 +239,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
             // the multiplying waves' mid-tap barrier publishes tap it + 1: this wave's share of it must have landed.  Outstanding
             // here: taps it + 1 and it + 2 (when they exist).
             if (it + 2 < nchunks) {
-                if constexpr (G == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                if constexpr (G * PL == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -267,28 +289,41 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     // ds_read it can see.  The waits below are explicit instead.
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     bf16x8 fa[2][2], fb[2][TPW];                       // [register set][tile]
+    bf16x8 fal[2][2], fbl[2][TPW];                     // ... and their lo planes (split mode)
     auto wait_frags = [&](auto SET) {
         constexpr int st = decltype(SET)::value;
-        if constexpr (TPW == 2) wait_lgkm(fa[st][0], fa[st][1], fb[st][0], fb[st][1]);
+        if constexpr (PL == 2) wait_lgkm(fa[st][0], fa[st][1], fb[st][0], fal[st][0], fal[st][1], fbl[st][0]);
+        else if constexpr (TPW == 2) wait_lgkm(fa[st][0], fa[st][1], fb[st][0], fb[st][1]);
         else wait_lgkm(fa[st][0], fa[st][1], fb[st][0]);
     };
     auto read_frags = [&](auto SET, auto KS, int tp, int slot) {   // fragments of k-step KS of tap tp (weights in ring slot `slot`)
         constexpr int st = decltype(SET)::value, ks = decltype(KS)::value;
         const int ty = tp / 5, tx = tp - ty * 5;
         const unsigned ab = lds0 + (ty * PW + tx) * PP;
-        const unsigned bb = lds0 + PATCH_BYTES + slot * SLOT + b_sw[ks];
+        const unsigned bb = lds0 + PL * PATCH_BYTES + slot * SLOT + b_sw[ks];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) fa[st][mt] = lds_read_b128<ks * 32>(ab + a_off[mt]);
 #pragma unroll
         for (int t = 0; t < TPW; ++t) fb[st][t] = lds_read_b128<0>(bb + b_row[t]);
+        if constexpr (PL == 2) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) fal[st][mt] = lds_read_b128<ks * 32>(ab + PATCH_BYTES + a_off[mt]);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) fbl[st][t] = lds_read_b128<0>(bb + PLANE + b_row[t]);
+        }
     };
     auto mfmas = [&](auto SET) {
         constexpr int st = decltype(SET)::value;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int t = 0; t < TPW; ++t)
+            for (int t = 0; t < TPW; ++t) {
+                if constexpr (PL == 2) {               // the two cross terms first, the leading term last
+                    acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[st][mt], fb[st][t], acc[mt][t], 0, 0, 0);
+                    acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], fbl[st][t], acc[mt][t], 0, 0, 0);
+                }
                 acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], fb[st][t], acc[mt][t], 0, 0, 0);
+            }
     };
     using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
     using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
@@ -478,12 +513,13 @@ size_t lstm_bf16_weight_elems(int wcin, int N) { return (size_t)((wcin + 63) / 6
 // rows of the bf16 pack of a plain 5x5 convolution with N output channels: whole 128- or 64-column blocks
 int conv5x5_bf16_rows(int N) { return N % 128 == 0 ? N : (N + 63) / 64 * 64; }
 
-// w: fp32 K-inner packed [25][wcin/32][N][32]; wb: [ceil(wcin/64)][25][Np][64] bf16 (Np >= N rows, the extra ones zero; 0 = N)
-int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s, int Np) {
+// w: fp32 K-inner packed [25][wcin/32][N][32]; wb: [ceil(wcin/64)][25][planes][Np][64] bf16 (Np >= N rows, the extra ones zero; 0 = N;
+// planes = 2: the hi / lo split of the split mode, lstm_bf16_weight_elems(wcin, Np) * 2 elements)
+int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s, int Np, int planes) {
     if (Np == 0) Np = N;
-    PIVP_CHECK_ARG(w && wb && wcin > 0 && wcin % 32 == 0 && N > 0 && Np >= N);
-    const long total = (long)lstm_bf16_weight_elems(wcin, Np);
-    hipLaunchKernelGGL(pack_lstm_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, total);
+    PIVP_CHECK_ARG(w && wb && wcin > 0 && wcin % 32 == 0 && N > 0 && Np >= N && (planes == 1 || planes == 2));
+    const long total = (long)lstm_bf16_weight_elems(wcin, Np) * planes;
+    hipLaunchKernelGGL(pack_lstm_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, planes, total);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -495,12 +531,12 @@ static bool bf16_geometry_ok(const IgemmDesc& d) {
 }
 bool convlstm_bf16_ok(const IgemmDesc& d) { return bf16_geometry_ok(d) && d.C > 0 && d.C % 16 == 0; }
 
-template <int NCH, bool LSTM>
+template <int NCH, bool LSTM, int PL = 1>
 static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nb, int ksplit, int ncols) {
-    constexpr int lds_bytes = PATCH_BYTES + NSLOT * 4 * NCH * 128;
+    constexpr int lds_bytes = PL * (PATCH_BYTES + NSLOT * 4 * NCH * 128);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bf16_kernel<NCH, LSTM>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bf16_kernel<NCH, LSTM, PL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
             return PIVP_ERR_LAUNCH;
         attr_set = true;
@@ -513,13 +549,15 @@ static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
     const int blocks = (d.B / ti_n) * tpi * nb;
-    hipLaunchKernelGGL((convlstm_bf16_kernel<NCH, LSTM>), dim3(blocks, ksplit), dim3(512), lds_bytes, stream, dd, wb, tw, ncols);
+    hipLaunchKernelGGL((convlstm_bf16_kernel<NCH, LSTM, PL>), dim3(blocks, ksplit), dim3(512), lds_bytes, stream, dd, wb, tw, ncols);
     return PIVP_LAUNCH_STATUS();
 }
 
-// d as for igemm_lstm (validated by the caller's igemm_validate(d, true) equivalent); wb = pack_lstm_bf16(d.w).
-int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nch) {
-    PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0)));
+// d as for igemm_lstm (validated by the caller's igemm_validate(d, true) equivalent); wb = pack_lstm_bf16(d.w, ..., planes).
+int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nch, int planes) {
+    PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0)) && (planes == 1 || planes == 2));
+    if (planes == 2)     // split mode: hi / lo planes of the patch and of the weights leave room for the 16-channel blocks only
+        return launch_bf16<16, true, 2>(d, wb, stream, ln_nparts, d.C / 16, 1, 0);
     const int tw = d.Win % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
     const long blocks32 = (long)(d.B / ti_n) * (d.Hin / TH) * (d.Win / tw) * (d.C / 32);
     if (nch == 0) nch = (d.C % 32 || blocks32 < 256) ? 16 : 32;

@@ -18,7 +18,7 @@ bool fits31(long long v) { return v > 0 && v < (1LL << 31); }
 
 int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                  const float* c_in, float* c_out, float* h_out, int B, int H, int W, hipStream_t s, int variant,
-                 float* gates_out, float* ln_part, int ln_cap, int* ln_nparts, const unsigned short* w_bf16) {
+                 float* gates_out, float* ln_part, int ln_cap, int* ln_nparts, const unsigned short* w_bf16, int bf16_planes) {
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
     // h_prev == nullptr: the recurrent input is identically zero (first timestep after reset_state, TM:254-257);
@@ -35,7 +35,7 @@ int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, co
     d.cstate_in = c_in; d.cstate_out = c_out; d.hout = h_out; d.C = C; d.gates_out = gates_out;
     d.ln_part = ln_part; d.ln_cap = ln_cap;
     // w_bf16: the bf16 pack of w (pack_lstm_bf16) selects the bf16-operand kernel; variant then is its channels per block
-    if (w_bf16) return convlstm_bf16(d, w_bf16, s, ln_nparts, variant);
+    if (w_bf16) return convlstm_bf16(d, w_bf16, s, ln_nparts, variant, bf16_planes);
     return igemm_lstm(d, s, variant, ln_nparts);
 }
 
@@ -252,6 +252,18 @@ extern "C" int pivp_layernorm_train(const float* x, const float* gamma, const fl
 }
 // bf16-operand ConvLSTM (BASELINE.json config 3): weights re-packed to bf16 once, operands rounded to bf16 on the way into LDS,
 // fp32 accumulation / gates / state.  nch: 0 automatic, 16 or 32 channels per block.
+// Split mode (three bf16 MFMAs per product, 16 bits of product mantissa): weights packed as hi / lo planes, twice the elements.
+extern "C" int pivp_pack_lstm_bf16x3(const float* w, void* w_bf16, int cin_total, int C, void* stream) {
+    if (C <= 0) return PIVP_ERR_BADARG;
+    return pack_lstm_bf16(w, (unsigned short*)w_bf16, cin_total, 4 * C, (hipStream_t)stream, 0, 2);
+}
+extern "C" int pivp_convlstm_bf16x3(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
+                                    const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
+                                    int* ln_nparts, int B, int H, int W, void* stream) {
+    if (!x || !w_bf16 || !bias || !c_in || !c_out || !h_out) return PIVP_ERR_BADARG;
+    return run_convlstm(x, cx, ldx, h_prev, C, nullptr, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, 0, gates_out,
+                        ln_part, ln_cap, ln_nparts, (const unsigned short*)w_bf16, 2);
+}
 extern "C" long long pivp_lstm_bf16_weight_elems(int cin_total, int C) {
     if (cin_total <= 0 || cin_total % 32 || C <= 0) return PIVP_ERR_BADARG;
     return (long long)lstm_bf16_weight_elems(cin_total, 4 * C);

@@ -9,7 +9,7 @@ bool fits31(long long v);
 int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                  const float* c_in, float* c_out, float* h_out, int B, int H, int W, hipStream_t s, int variant = 0,
                  float* gates_out = nullptr, float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr,
-                 const unsigned short* w_bf16 = nullptr);
+                 const unsigned short* w_bf16 = nullptr, int bf16_planes = 1);
 int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                   int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0);
 int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,

@@ -67,12 +67,12 @@ bool deconv_tile_ok(const IgemmDesc& d);
 int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr, bool bf16 = false);   // bf16: operands rounded to bf16
 // bf16-operand ConvLSTM (csrc/convlstm_bf16.hip): wb = pack_lstm_bf16 of d.w; nch: 0 auto, 16 / 32 channels per block
 size_t lstm_bf16_weight_elems(int wcin, int N);
-int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s, int Np = 0);
+int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s, int Np = 0, int planes = 1);
 int conv5x5_bf16_rows(int N);
 int conv5x5_bf16_ksplit(const IgemmDesc& d);   // > 1: the launch will split K and needs d.out zeroed
 int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream);   // plain 5x5 s1 conv (ConvLSTM data gradient)
 bool convlstm_bf16_ok(const IgemmDesc& d);
-int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts = nullptr, int nch = 0);
+int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts = nullptr, int nch = 0, int planes = 1);
 
 // enc0: 5x5 stride-2 pad-2 conv on a planar 3-channel frame -> NHWC 32 channels (TM:500)
 // ln_part (optional): the launch also writes *ln_nparts LayerNorm partials per sample of its output (0 = not supported for the shape)

@@ -74,7 +74,10 @@ struct pivp_plan {
     bool has_grads;
     size_t o_zero, o_lnpart, o_linpart, o_masks, o_losspart;
     size_t o_wbf16[7];                // bf16 packs of the ConvLSTM weights (pivp_plan_set_precision), rebuilt at the start of a rollout
-    int lstm_bf16 = 0;
+    int lstm_bf16 = 0;                // 1: bf16 operands in the ConvLSTM forward (precision modes BF16 and BF16X3)
+    int precision = 0;                // PIVP_PRECISION_*
+    int lstm_planes = 1;              // 2: split mode (hi / lo planes, three MFMAs per product); the backward and the deconvs then stay fp32
+    int bf16_all = 0;                 // precision mode BF16: also the ConvLSTM gradients and the enc5 / enc6 transposed convs
     pivp_grad_group_cb grad_cb = nullptr; void* grad_cb_user = nullptr;   // gradient-group-final notifications (t = 0 sweep)
     int loss_nparts;
     int last_steps;
@@ -157,7 +160,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
     p->loss_nparts = loss_partials_count((int)(B * 3 * HW));
     p->o_losspart = carve((size_t)T * p->loss_nparts);
     for (int i = 0; i < 7; ++i)       // 2-byte elements in a float-counted workspace
-        p->o_wbf16[i] = carve((lstm_bf16_weight_elems(kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C) + 1) / 2);
+        p->o_wbf16[i] = carve(lstm_bf16_weight_elems(kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C));   // room for the two planes of the split mode
     p->nslabs = train ? T - 1 : 2;
     p->slabs.resize(p->nslabs);
     for (int s = 0; s < p->nslabs; ++s) {
@@ -232,12 +235,14 @@ extern "C" int pivp_plan_set_grad(pivp_plan_t* plan, int idx, float* dptr) {
     plan->params[idx].grad = dptr;
     return PIVP_OK;
 }
-// Precision of the ConvLSTM gate convolutions (95 % of the FLOPs): PIVP_PRECISION_F32 (default) or PIVP_PRECISION_BF16 = operands
+// Precision of the ConvLSTM gate convolutions (95 % of the FLOPs): PIVP_PRECISION_F32 (default), PIVP_PRECISION_BF16X3 = every fp32 operand of the
+// FORWARD gate convolutions as two bf16 pieces and three MFMAs per product (fp32-grade results, everything else and the backward in fp32), or
+// PIVP_PRECISION_BF16 = operands
 // rounded to bf16, fp32 accumulation / gates / state (csrc/convlstm_bf16.hip), and in the backward sweep their data and weight gradients
 // (csrc/convlstm_bf16.hip <NCH, false>, csrc/wgrad_bf16.hip).  Everything else stays fp32, as do the parameters, the gradients and Adam.  Refused when a layer's map does not fit the bf16 kernel's tiles (8-wide maps need an even batch).
 extern "C" int pivp_plan_set_precision(pivp_plan_t* plan, int precision) {
-    if (!plan || (precision != PIVP_PRECISION_F32 && precision != PIVP_PRECISION_BF16)) return PIVP_ERR_BADARG;
-    if (precision == PIVP_PRECISION_BF16) {
+    if (!plan || (precision != PIVP_PRECISION_F32 && precision != PIVP_PRECISION_BF16 && precision != PIVP_PRECISION_BF16X3)) return PIVP_ERR_BADARG;
+    if (precision != PIVP_PRECISION_F32) {
         const int hs[7] = {plan->H2, plan->H2, plan->H4, plan->H4, plan->H8, plan->H4, plan->H2};
         const int wsz[7] = {plan->W2, plan->W2, plan->W4, plan->W4, plan->W8, plan->W4, plan->W2};
         for (int i = 0; i < 7; ++i) {
@@ -248,10 +253,13 @@ extern "C" int pivp_plan_set_precision(pivp_plan_t* plan, int precision) {
             if (!convlstm_bf16_ok(d)) return PIVP_ERR_BADARG;
         }
     }
-    plan->lstm_bf16 = precision == PIVP_PRECISION_BF16;
+    plan->lstm_bf16 = precision != PIVP_PRECISION_F32;
+    plan->lstm_planes = precision == PIVP_PRECISION_BF16X3 ? 2 : 1;
+    plan->bf16_all = precision == PIVP_PRECISION_BF16;
+    plan->precision = precision;
     return PIVP_OK;
 }
-extern "C" int pivp_plan_get_precision(const pivp_plan_t* plan) { return plan ? plan->lstm_bf16 : PIVP_ERR_BADARG; }
+extern "C" int pivp_plan_get_precision(const pivp_plan_t* plan) { return plan ? plan->precision : PIVP_ERR_BADARG; }
 extern "C" long long pivp_plan_workspace_bytes(const pivp_plan_t* plan) { return plan ? plan->ws_floats * 4 : PIVP_ERR_BADARG; }
 extern "C" int pivp_plan_set_workspace(pivp_plan_t* plan, void* dptr, long long bytes) {
     if (!plan || !dptr || bytes < plan->ws_floats * 4 || ((uintptr_t)dptr & 255)) return PIVP_ERR_BADARG;
@@ -291,7 +299,7 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
         int rc = run_convlstm(x, kLstm[i].cx, ldx, hp(i), kLstm[i].C, P(p, p->i_lstm_w[i]), P(p, p->i_lstm_b[i]),
                               cp(i), ws + S.c[i], ws + S.h[i], B, hh, wwid, s, 0, train ? ws + S.gates[i] : nullptr,
                               lnp, ln_cap, &np,
-                              p->lstm_bf16 ? reinterpret_cast<const unsigned short*>(ws + p->o_wbf16[i]) : nullptr);
+                              p->lstm_bf16 ? reinterpret_cast<const unsigned short*>(ws + p->o_wbf16[i]) : nullptr, p->lstm_planes);
         if (prof) {
             (void)hipEventRecord(p->prof_ev[p->prof_used + 1], s);
             p->prof_layer[p->prof_used / 2] = i + (Sp ? 0 : 8);   // +8: first-step launch without the h half of K
@@ -327,17 +335,17 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     RC(lstm(4, ws + S.e3, 64, p->H8, p->W8));
     RC(ln(5, ws + S.h[4], ws + S.n5, n8, 128, 128, 0, np));
     RC(run_deconv3x3s2(ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), P(p, p->i_enc_b[4]), ws + S.e4, 128, 128, 1, B, p->H8, p->W8, s, 0,
-                       nullptr, 0, nullptr, p->lstm_bf16));
+                       nullptr, 0, nullptr, p->bf16_all));
     // group 5 (TM:600): lstm6 -> hidden6 -> concat(., enc1) -> enc5 -> relu
     RC(lstm(5, ws + S.e4, 128, p->H4, p->W4));
     RC(ln(6, ws + S.h[5], ws + S.cat6, n4, 64, 96, 0, np));
     RC(run_deconv3x3s2(ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), P(p, p->i_enc_b[5]), ws + S.e5, 96, 96, 1, B, p->H4, p->W4, s, 0,
-                       nullptr, 0, nullptr, p->lstm_bf16));
+                       nullptr, 0, nullptr, p->bf16_all));
     // group 6 (TM:601): lstm7 -> hidden7 -> concat(., enc0) -> enc6 -> norm_enc6 -> relu
     RC(lstm(6, ws + S.e5, 96, p->H2, p->W2));
     RC(ln(7, ws + S.h[6], ws + S.cat7, n2, 32, 64, 0, np));
     RC(run_deconv3x3s2(ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), P(p, p->i_enc_b[6]), ws + S.e6raw, 64, 64, 0, B, p->H2, p->W2, s, 0,
-                       lnp, ln_cap, &np, p->lstm_bf16));
+                       lnp, ln_cap, &np, p->bf16_all));
     // heads (TM:711-728).  norm_enc6 + relu is applied while the heads kernel stages its input: the normalised enc6 is only
     // written when the activations are kept for BPTT (pivp_get_tap recomputes it on request otherwise).
     if (np > 0 && (H * W) % 64 == 0) {
@@ -388,7 +396,7 @@ extern "C" int pivp_rollout_forward(pivp_plan_t* plan, const float* images, cons
     if (plan->lstm_bf16)            // the parameters may have changed since the last call (optimizer step, checkpoint load)
         for (int i = 0; i < 7; ++i)
             RC(pack_lstm_bf16(P(plan, plan->i_lstm_w[i]), reinterpret_cast<unsigned short*>(plan->ws + plan->o_wbf16[i]),
-                              kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C, s));
+                              kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C, s, 0, plan->lstm_planes));
     for (int t = 0; t < T - 1; ++t) {
         if (t >= ctx && gt_select)                                     // TM:667-670
             RC(run_select_frames(images + t * fr, gen_images + (t - 1) * fr, gt_select + (size_t)t * B,
@@ -443,7 +451,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                                      Sp ? ws + Sp->c[i] : ws + p->o_zero, ws + S.c[i], ws + g.hln[i], L.C,
                                      last_step ? nullptr : ws + g.din[i][npar] + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
                                      ws + g.dG, ws + g.wt_lstm[i], ws + g.din[i][par], G(p, p->i_lstm_w[i]), G(p, p->i_lstm_b[i]), B, hh, wwid,
-                                     s, 1, p->lstm_bf16 ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr);
+                                     s, 1, p->bf16_all ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr);
     };
     const long px2 = (long)B * p->H2 * p->W2, px4 = (long)B * p->H4 * p->W4, px8 = (long)B * p->H8 * p->W8;
 
@@ -546,7 +554,7 @@ extern "C" int pivp_rollout_backward(pivp_plan_t* plan, const float* images, con
     // weights are constant during the sweep: build the transposed packs for the data gradients once
     for (int i = 0; i < 7; ++i)
         RC(repack_transpose(P(plan, plan->i_lstm_w[i]), ws + g.wt_lstm[i], 25, kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C, 1, s));
-    if (plan->lstm_bf16)        // bf16 mode: the ConvLSTM data gradients run with bf16 operands on these packs
+    if (plan->bf16_all)         // bf16 mode: the ConvLSTM data gradients run with bf16 operands on these packs
         for (int i = 0; i < 7; ++i) {
             const int cin = kLstm[i].cx + kLstm[i].C;
             RC(pack_lstm_bf16(ws + g.wt_lstm[i], reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]), 4 * kLstm[i].C, cin, s,

@@ -160,8 +160,10 @@ class Model(object):
         # 'fp32' is the parity path (per-pixel L2 < 1e-4 vs the reference).  'bf16' (BASELINE.json config 3) rounds the operands of
         # the seven ConvLSTM gate convolutions, of their data / weight gradients and of the enc5 / enc6 transposed convs to bf16 -- fp32 accumulation, gates, state, every
         # other op, the parameters, the gradients and Adam stay fp32 -- and reports, not gates, its error.
-        if precision not in ('fp32', 'bf16'):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        # 'bf16x3' is the split mode: the forward gate convolutions take every fp32 operand as two bf16 pieces and form a product on
+        # three bf16 MFMAs (16 bits of product mantissa); the rollout stays inside the 1e-4 gate; backward and everything else fp32.
+        if precision not in ('fp32', 'bf16', 'bf16x3'):
+            raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x3'")
         self.precision = precision
         self._ref_pending = None       # reference-layout arrays loaded before the first call
         self._params = None            # name -> view into _flat_params (internal layout)
@@ -297,8 +299,9 @@ class Model(object):
                                   keep_activations=1 if self.keep_activations else 0,
                                   ln_eps=self.ln_eps, stp_zero_border=1 if self.stp_border == 'zeros' else 0)
             plan = _Plan(lib, cfg)
-            if self.precision == 'bf16':
-                _lib.check(lib.pivp_plan_set_precision(plan.h, 1), 'pivp_plan_set_precision(bf16)')
+            if self.precision != 'fp32':
+                _lib.check(lib.pivp_plan_set_precision(plan.h, {'bf16': 1, 'bf16x3': 2}[self.precision]),
+                           'pivp_plan_set_precision(%s)' % self.precision)
             nbytes = lib.pivp_plan_workspace_bytes(plan.h)
             plan.workspace = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.device)
             base = plan.workspace.data_ptr()

@@ -254,3 +254,52 @@ def test_deconv3x3s2_bf16_exact_on_bf16_operands(ops, B, cin, cout, H, relu):
     x2 = rs.randn(B, cin, H, H); W2 = rs.randn(cin, cout, 3, 3) / np.sqrt(9 * cin)
     d = np.abs(ops.deconv3x3s2(x2, W2, b, relu, bf16=True) - ops.deconv3x3s2(x2, W2, b, relu)).max()
     assert 1e-5 < d < 2e-2
+
+
+# ---- split mode: two bf16 pieces per fp32 operand, three MFMAs per product -------------------------------------------------------
+@pytest.mark.parametrize('B,cx,C,H', SHAPES[:6])
+def test_convlstm_bf16x3_on_fp32_operands(ops, B, cx, C, H):
+    # arbitrary fp32 operands: what is lost is the lo*lo product and the third piece of each operand, ~2^-16 relative per product
+    x, h, c, W, b = _case(B, cx, C, H, 31 + C + H)
+    hr, cr, _ = _lstm_ref(x, h, c, W, b)
+    hg, cg = ops.convlstm_bf16x3(x, h, c, W, b)
+    h1, c1 = ops.convlstm_bf16(x, h, c, W, b)
+    e3 = max(np.abs(hg - hr).max(), np.abs(cg - cr).max()); e1 = max(np.abs(h1 - hr).max(), np.abs(c1 - cr).max())
+    print('B=%d cx=%d C=%d H=%d: max |err| split %.2e, plain bf16 %.2e' % (B, cx, C, H, e3, e1))
+    assert e3 < 5e-5 and e3 < e1 / 50
+
+
+def test_convlstm_bf16x3_exact_when_operands_fit_two_pieces(ops):
+    # operands with 16 significant bits (hi + lo exactly): every kept product is exact, the dropped lo*lo terms are ~2^-16 of the result
+    x, h, c, W, b = _case(2, 32, 64, 16, 77)
+    def two(a):
+        hi = _bf16(a); return hi + _bf16(a - hi)
+    x, h, W = two(x), two(h), two(W)
+    hr, cr, _ = _lstm_ref(x, h, c, W, b)
+    hg, cg = ops.convlstm_bf16x3(x, h, c, W, b)
+    assert np.abs(hg - hr).max() < TOL and np.abs(cg - cr).max() < TOL
+
+
+def test_rollout_bf16x3_stays_inside_the_gate():
+    # the split mode on the config 1 golden rollout: the CPU study (scripts/split_bf16_study.py) predicts 3.2e-5 max per-pixel L2
+    g = np.load(__import__('os').path.join(GOLD, 'cdna_b2_t10.npz'))
+    m, loss, gen = _rollout('bf16x3')
+    l2 = R.per_pixel_l2(gen, g['gen_images'])
+    print('bf16x3 rollout: per-pixel L2 vs float64 oracle max %.2e rms %.2e; loss %.8f vs %.8f'
+          % (l2.max(), np.sqrt((l2 ** 2).mean()), loss, float(g['loss'])))
+    assert l2.max() < 1e-4 and abs(loss - float(g['loss'])) < 1e-5
+    assert m._active.lib.pivp_plan_get_precision(m._active.h) == 2
+
+
+def test_train_step_in_bf16x3_mode_matches_fp32_gradients():
+    # split forward + the fp32 backward: gradients agree with the fp32 path to the forward's 1e-5-level differences
+    import pivp_amd
+    outs = {}
+    for prec in ('fp32', 'bf16x3'):
+        m, loss, _ = _rollout(prec, T=4, train=True, keep=True)
+        with pivp_amd.using_config('train', True):
+            m.backward()
+        outs[prec] = (loss, m._flat_grads.clone())
+    rel = float((outs['bf16x3'][1] - outs['fp32'][1]).norm() / outs['fp32'][1].norm())
+    print('bf16x3 train step: loss %.8f vs %.8f, relative gradient difference %.2e' % (outs['bf16x3'][0], outs['fp32'][0], rel))
+    assert abs(outs['bf16x3'][0] - outs['fp32'][0]) < 1e-5 and rel < 1e-3
