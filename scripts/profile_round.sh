@@ -13,6 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/train -o train -- p
 python3 bench.py --precision bf16 --no-cpu-baseline > $out/bench_bf16.json 2> $out/bench_bf16.err
 python3 bench.py --precision bf16 --mode train --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $out/bench_bf16_train.json 2> $out/bench_bf16_train.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_bf16 -o rollout_bf16 -- python3 bench.py --precision bf16 --steps 7 --warmup 2 --no-cpu-baseline > $out/kt_bf16.log 2>&1
+python3 bench.py --precision bf16x3 --no-cpu-baseline > $out/bench_bf16x3.json 2> $out/bench_bf16x3.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $out/write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/mfma -o m -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $out/mfma.log 2>&1
@@ -21,4 +22,4 @@ python3 scripts/pmc_summary.py --mfma $out/mfma $out/pmc/pmc_mfma_busy_summary.c
 # keep the merge small: the raw per-dispatch traces are not needed back
 rm -f $out/kt/*kernel_trace.csv $out/train/*kernel_trace.csv $out/kt_bf16/*kernel_trace.csv
 find $out/fetch $out/write $out/mfma -name '*counter_collection.csv' -delete
-cat $out/bench.json; cat $out/bench_train.json; cat $out/bench_bf16.json; cat $out/bench_bf16_train.json
+cat $out/bench.json; cat $out/bench_train.json; cat $out/bench_bf16.json; cat $out/bench_bf16_train.json; cat $out/bench_bf16x3.json
