@@ -59,6 +59,9 @@ __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c) {
 __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& e, bf16x8& f, bf16x8& g) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e), "+v"(f), "+v"(g));
 }
+__device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& e, bf16x8& f, bf16x8& g, bf16x8& h, bf16x8& i) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i));
+}
 }  // namespace
 
 // fp32 K-inner packed weights [25][wcin/32][N][32] -> bf16 [ceil(wcin/64)][25][PL][Np][64], channels past wcin and rows past N zero.
@@ -98,7 +101,11 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     constexpr int BN = 4 * NCH;                 // block columns: [gate][channel]
     constexpr int PLANE = BN * 128;             // one weight plane of a ring slot: BN rows x 64 bf16
     constexpr int SLOT = PL * PLANE;            // bytes of one ring slot
-    static_assert(PL == 1 || (PL == 2 && NCH == 16 && LSTM), "the split mode runs the 16-channel LSTM blocks");
+    static_assert(PL == 1 || (PL == 2 && LSTM), "the split mode is built for the ConvLSTM forward");
+    // Split mode with 32-channel blocks: two patch planes (92 KB) leave room for TWO 32 KB ring slots only, so the schedule changes: the
+    // loaders bring tap it + 1 in during tap it (one tap of lookahead), and the block barrier sits at the END of a tap (LATE).
+    constexpr bool LATE = PL == 2 && NCH == 32;
+    constexpr int NSL = LATE ? 2 : NSLOT;
     constexpr int G = BN / 32;                  // global_load_lds per loader thread and tap
     constexpr int TPW = NCH / 16;               // MFMA column tiles per wave
     constexpr int CPW = NCH / 2;                // channels per wave (all 4 gates of a channel stay in one wave)
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         const size_t wstep = (size_t)PL * N * 128;     // bytes between consecutive (group, tap) weight tiles ([PL][N][64] bf16 each)
         int issued = 0, i_tap = tap0, i_cg = 0;        // taps issued; the next one to issue
         auto issue_weights = [&]() {
-            const int slot = issued & (NSLOT - 1);
+            const int slot = issued & (NSL - 1);
             const size_t goff = (size_t)((cgbase + i_cg) * 25 + i_tap) * wstep;
             i_tap = i_tap == 24 ? 0 : i_tap + 1;
             i_cg += i_tap == tap0 ? 1 : 0;
@@ -227,6 +234,26 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
                 }
             ++issued;
         };
+        if constexpr (LATE) {
+            issue_weights();                                   // tap 0
+            patch_load(0);
+            patch_store();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // tap 0 and the patch are published
+            int tap = tap0, cg = 0;
+            for (int it = 0; it < nchunks; ++it) {
+                if (it + 1 < nchunks) issue_weights();         // tap it + 1 into the slot tap it - 1 left at the last barrier
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                  // end of tap it: tap it + 1 is published
+                tap = tap == 24 ? 0 : tap + 1;
+                if (tap == tap0 && ++cg < ncg) {               // next 64 input channels: all 8 waves restage the patch
+                    patch_load(cg);
+                    patch_store();
+                    __syncthreads();
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i)
             if (i < nchunks) issue_weights();
@@ -292,7 +319,8 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     bf16x8 fal[2][2], fbl[2][TPW];                     // ... and their lo planes (split mode)
     auto wait_frags = [&](auto SET) {
         constexpr int st = decltype(SET)::value;
-        if constexpr (PL == 2) wait_lgkm(fa[st][0], fa[st][1], fb[st][0], fal[st][0], fal[st][1], fbl[st][0]);
+        if constexpr (PL == 2 && TPW == 2) wait_lgkm(fa[st][0], fa[st][1], fb[st][0], fb[st][1], fal[st][0], fal[st][1], fbl[st][0], fbl[st][1]);
+        else if constexpr (PL == 2) wait_lgkm(fa[st][0], fa[st][1], fb[st][0], fal[st][0], fal[st][1], fbl[st][0]);
         else if constexpr (TPW == 2) wait_lgkm(fa[st][0], fa[st][1], fb[st][0], fb[st][1]);
         else wait_lgkm(fa[st][0], fa[st][1], fb[st][0]);
     };
@@ -357,6 +385,29 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     BF_STAMP(1);
     __builtin_amdgcn_s_barrier();                      // patch and taps 0..2 are in LDS
     BF_STAMP(2);
+    if constexpr (LATE) {
+        // end-of-tap barrier schedule: the first fragments of a tap are requested right behind the barrier that published it
+        int tap = tap0, cg = 0;
+        for (int it = 0; it < nchunks; ++it) {
+            const int slot = it & 1;
+            read_frags(S0{}, K0{}, tap, slot);
+            wait_frags(S0{}); read_frags(S1{}, K1{}, tap, slot); mfmas(S0{});
+            __builtin_amdgcn_sched_barrier(0);
+            wait_frags(S1{}); read_frags(S0{}, K2{}, tap, slot); mfmas(S1{});
+            __builtin_amdgcn_sched_barrier(0);
+            wait_frags(S0{}); read_frags(S1{}, K3{}, tap, slot); mfmas(S0{});
+            __builtin_amdgcn_sched_barrier(0);
+            wait_frags(S1{}); mfmas(S1{});
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            tap = tap == 24 ? 0 : tap + 1;
+            if (tap == tap0 && ++cg < ncg) {
+                patch_load(cg);
+                patch_store();
+                __syncthreads();
+            }
+        }
+    } else {
     read_frags(S0{}, K0{}, tap0, 0);
 
     // One tap = 4 k-steps of 16 channels; fragments of the next k-step are requested before the MFMAs of the current one.  The
@@ -387,6 +438,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    }   // !LATE
 
     if constexpr (!LSTM) {
         // ---- plain epilogue: accumulator row = anchor, column = output channel; 32 lanes write 128 contiguous bytes ----------
@@ -533,7 +585,7 @@ bool convlstm_bf16_ok(const IgemmDesc& d) { return bf16_geometry_ok(d) && d.C > 
 
 template <int NCH, bool LSTM, int PL = 1>
 static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nb, int ksplit, int ncols) {
-    constexpr int lds_bytes = PL * (PATCH_BYTES + NSLOT * 4 * NCH * 128);
+    constexpr int lds_bytes = PL * PATCH_BYTES + ((PL == 2 && NCH == 32) ? 2 : NSLOT) * PL * 4 * NCH * 128;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bf16_kernel<NCH, LSTM, PL>),
@@ -556,8 +608,12 @@ static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t
 // d as for igemm_lstm (validated by the caller's igemm_validate(d, true) equivalent); wb = pack_lstm_bf16(d.w, ..., planes).
 int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nch, int planes) {
     PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0)) && (planes == 1 || planes == 2));
-    if (planes == 2)     // split mode: hi / lo planes of the patch and of the weights leave room for the 16-channel blocks only
+    if (planes == 2) {   // split mode: 32-channel blocks (two ring slots) when they still give every CU a block, else 16-channel ones
+        const int tw2 = d.Win % 16 == 0 ? 16 : 8, ti2 = tw2 == 16 ? 1 : 2;
+        const long b32 = d.C % 32 ? 0 : (long)(d.B / ti2) * (d.Hin / TH) * (d.Win / tw2) * (d.C / 32);
+        if (nch == 32 || (nch == 0 && b32 >= 256)) return launch_bf16<32, true, 2>(d, wb, stream, ln_nparts, d.C / 32, 1, 0);
         return launch_bf16<16, true, 2>(d, wb, stream, ln_nparts, d.C / 16, 1, 0);
+    }
     const int tw = d.Win % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
     const long blocks32 = (long)(d.B / ti_n) * (d.Hin / TH) * (d.Win / tw) * (d.C / 32);
     if (nch == 0) nch = (d.C % 32 || blocks32 < 256) ? 16 : 32;

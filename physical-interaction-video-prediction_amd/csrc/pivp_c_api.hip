@@ -259,9 +259,9 @@ extern "C" int pivp_pack_lstm_bf16x3(const float* w, void* w_bf16, int cin_total
 }
 extern "C" int pivp_convlstm_bf16x3(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
                                     const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
-                                    int* ln_nparts, int B, int H, int W, void* stream) {
+                                    int* ln_nparts, int B, int H, int W, int nch, void* stream) {
     if (!x || !w_bf16 || !bias || !c_in || !c_out || !h_out) return PIVP_ERR_BADARG;
-    return run_convlstm(x, cx, ldx, h_prev, C, nullptr, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, 0, gates_out,
+    return run_convlstm(x, cx, ldx, h_prev, C, nullptr, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, nch, gates_out,
                         ln_part, ln_cap, ln_nparts, (const unsigned short*)w_bf16, 2);
 }
 extern "C" long long pivp_lstm_bf16_weight_elems(int cin_total, int C) {

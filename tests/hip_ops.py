@@ -67,7 +67,7 @@ def convlstm_bf16(x, h, c, W, b, nch=0, h_is_zero=False, want_gates=False, want_
     return tuple(out)
 
 
-def convlstm_bf16x3(x, h, c, W, b, h_is_zero=False):
+def convlstm_bf16x3(x, h, c, W, b, h_is_zero=False, nch=0):
     """Split-bf16 ConvLSTM (three bf16 MFMAs per product); returns (h, c)."""
     lib = _lib.load()
     B, cx, H, Wd = x.shape
@@ -78,7 +78,7 @@ def convlstm_bf16x3(x, h, c, W, b, h_is_zero=False):
     _lib.check(lib.pivp_pack_lstm_bf16x3(wd.data_ptr(), wb.data_ptr(), cx + C, C, stream()), 'pack_lstm_bf16x3')
     c_out = torch.empty_like(cd); h_out = torch.empty_like(hd)
     _lib.check(lib.pivp_convlstm_bf16x3(xd.data_ptr(), cx, cx, None if h_is_zero else hd.data_ptr(), C, wb.data_ptr(), bd.data_ptr(),
-                                        cd.data_ptr(), c_out.data_ptr(), h_out.data_ptr(), None, None, 0, None, B, H, Wd, stream()),
+                                        cd.data_ptr(), c_out.data_ptr(), h_out.data_ptr(), None, None, 0, None, B, H, Wd, nch, stream()),
                'convlstm_bf16x3')
     torch.cuda.synchronize()
     return nchw(h_out, B, H, Wd, C), nchw(c_out, B, H, Wd, C)

@@ -257,12 +257,13 @@ def test_deconv3x3s2_bf16_exact_on_bf16_operands(ops, B, cin, cout, H, relu):
 
 
 # ---- split mode: two bf16 pieces per fp32 operand, three MFMAs per product -------------------------------------------------------
+@pytest.mark.parametrize('nch', [16, 32])
 @pytest.mark.parametrize('B,cx,C,H', SHAPES[:6])
-def test_convlstm_bf16x3_on_fp32_operands(ops, B, cx, C, H):
+def test_convlstm_bf16x3_on_fp32_operands(ops, B, cx, C, H, nch):
     # arbitrary fp32 operands: what is lost is the lo*lo product and the third piece of each operand, ~2^-16 relative per product
     x, h, c, W, b = _case(B, cx, C, H, 31 + C + H)
     hr, cr, _ = _lstm_ref(x, h, c, W, b)
-    hg, cg = ops.convlstm_bf16x3(x, h, c, W, b)
+    hg, cg = ops.convlstm_bf16x3(x, h, c, W, b, nch=nch)   # 16: four ring slots, mid-tap barrier; 32: two slots, end-of-tap barrier
     h1, c1 = ops.convlstm_bf16(x, h, c, W, b)
     e3 = max(np.abs(hg - hr).max(), np.abs(cg - cr).max()); e1 = max(np.abs(h1 - hr).max(), np.abs(c1 - cr).max())
     print('B=%d cx=%d C=%d H=%d: max |err| split %.2e, plain bf16 %.2e' % (B, cx, C, H, e3, e1))
@@ -276,8 +277,9 @@ def test_convlstm_bf16x3_exact_when_operands_fit_two_pieces(ops):
         hi = _bf16(a); return hi + _bf16(a - hi)
     x, h, W = two(x), two(h), two(W)
     hr, cr, _ = _lstm_ref(x, h, c, W, b)
-    hg, cg = ops.convlstm_bf16x3(x, h, c, W, b)
-    assert np.abs(hg - hr).max() < TOL and np.abs(cg - cr).max() < TOL
+    for nch in (16, 32):
+        hg, cg = ops.convlstm_bf16x3(x, h, c, W, b, nch=nch)
+        assert np.abs(hg - hr).max() < TOL and np.abs(cg - cr).max() < TOL
 
 
 def test_rollout_bf16x3_stays_inside_the_gate():
