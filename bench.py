@@ -132,6 +132,10 @@ def main():
         loss_val = float(loss)
 
         roofline = None
+        if not args.no_roofline and rank != 0 and train and world > 1:
+            for _ in range(args.steps):        # rank 0's instrumented pass below calls the gradient all-reduce: every rank must take part
+                step()
+            torch.cuda.synchronize()
         if not args.no_roofline and rank == 0:
             plan = model._active
             lib = plan.lib
