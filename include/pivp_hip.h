@@ -69,9 +69,9 @@ int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr);
  * gates and state; in the backward pass the ConvLSTM data and weight gradients likewise (operands rounded to bf16, fp32 accumulation
  * into the fp32 gradients).  All other ops stay fp32, as do the parameters and Adam (the bf16 weight packs are rebuilt at the start of
  * every rollout / backward sweep).
- * PIVP_PRECISION_BF16X3 = the split mode: only the FORWARD gate convolutions change -- each fp32 operand travels as two bf16 numbers (hi, lo)
+ * PIVP_PRECISION_BF16X3 = the split mode: only the FORWARD gate convolutions and the enc5 / enc6 transposed convs change -- each fp32 operand travels as two bf16 numbers (hi, lo)
  * and a product is three bf16 MFMAs, 16 bits of product mantissa, fp32 accumulation -- and the result stays inside the 1e-4 per-pixel gate
- * (3e-5 on the config 1 rollout; tests/test_gpu_bf16.py); the backward pass and every other op are the fp32 ones.  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
+ * (4.4e-5 on the config 1 rollout; tests/test_gpu_bf16.py); the backward pass and every other op are the fp32 ones.  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
 int pivp_plan_set_precision(pivp_plan_t* plan, int precision);
 int pivp_plan_get_precision(const pivp_plan_t* plan);
 
@@ -174,6 +174,9 @@ int pivp_convlstm_bf16x3(const float* x, int cx, int ldx, const float* h_prev, i
  * and ReLU stay fp32.  Only maps with Hin % 8 == 0 and Win % 16 == 0 (and at least 16 tiles x column blocks) run in bf16; the call is the fp32 op otherwise. */
 int pivp_deconv3x3s2_bf16(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                           int ldo, int relu, int B, int Hin, int Win, void* stream);
+/* ... and in the split mode (two bf16 pieces per operand, three MFMAs per product; PIVP_PRECISION_BF16X3) */
+int pivp_deconv3x3s2_bf16x3(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
+                            int ldo, int relu, int B, int Hin, int Win, void* stream);
 
 /* Plain 5x5 stride-1 "same" convolution with bf16 operands and fp32 accumulation, out[b,y,x,n] (+)= sum x[b,y+dy,x+dx,k] w[tap][k][n]
  * (the ConvLSTM data gradient of the bf16 mode: x = d gates, w = the flipped transposed weights).  x NHWC (cin channels, stride ldx);

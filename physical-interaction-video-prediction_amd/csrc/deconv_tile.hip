@@ -33,14 +33,17 @@ __device__ __forceinline__ unsigned dpack2(float a, float b) {
 }
 }
 
-// BF16: operands rounded to bf16 on their way into LDS (activations AND weights: both stay fp32 in HBM), v_mfma_f32_32x32x16_bf16, fp32
-// accumulation and epilogue.
-template <bool BF16>
+// PREC 1 (bf16): operands rounded to bf16 on their way into LDS (activations AND weights: both stay fp32 in HBM), v_mfma_f32_32x32x16_bf16, fp32
+// accumulation and epilogue.  PREC 2 (split): each operand as hi = bf16(v) and lo = bf16(v - hi) in two image planes, a product as
+// lo*hi + hi*lo + hi*hi on three MFMAs (the split mode of convlstm_bf16.hip).  PREC 0: fp32 MFMA.
+template <int PREC>
 __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDesc d) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // A patch | the 9 weight tiles
     float* const At = lds;
     float* const Bt = lds + A_FL;
-    unsigned char* const Ah = reinterpret_cast<unsigned char*>(lds);       // BF16: byte-addressed images
+    constexpr bool BF16 = PREC != 0;
+    constexpr int HPL = A_HB + 9 * B_HB;                                     // bytes of one plane of bf16 images (patch | 9 weight tiles)
+    unsigned char* const Ah = reinterpret_cast<unsigned char*>(lds);       // BF16: byte-addressed images; split mode: the lo plane at + HPL
     unsigned char* const Bh = Ah + A_HB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,15 +90,26 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
     };
     auto store_chunk = [&]() {
         if constexpr (BF16) {
+            auto lo2 = [](unsigned hi2, float a, float b) {     // bf16(v - hi): hi as a float is its 16 bits shifted up
+                return dpack2(a - __builtin_bit_cast(float, hi2 << 16), b - __builtin_bit_cast(float, hi2 & 0xffff0000u));
+            };
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
                 uint2 v; v.x = dpack2(rp[j][0], rp[j][1]); v.y = dpack2(rp[j][2], rp[j][3]);
                 *reinterpret_cast<uint2*>(Ah + ((tid >> 3) + 32 * j) * HP + c4 * 8) = v;
+                if constexpr (PREC == 2) {
+                    uint2 l; l.x = lo2(v.x, rp[j][0], rp[j][1]); l.y = lo2(v.y, rp[j][2], rp[j][3]);
+                    *reinterpret_cast<uint2*>(Ah + HPL + ((tid >> 3) + 32 * j) * HP + c4 * 8) = l;
+                }
             }
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 uint2 v; v.x = dpack2(rw[t][0], rw[t][1]); v.y = dpack2(rw[t][2], rw[t][3]);
                 *reinterpret_cast<uint2*>(Bh + t * B_HB + (tid >> 3) * HP + c4 * 8) = v;
+                if constexpr (PREC == 2) {
+                    uint2 l; l.x = lo2(v.x, rw[t][0], rw[t][1]); l.y = lo2(v.y, rw[t][2], rw[t][3]);
+                    *reinterpret_cast<uint2*>(Bh + HPL + t * B_HB + (tid >> 3) * HP + c4 * 8) = l;
+                }
             }
         } else {
 #pragma unroll
@@ -125,9 +139,15 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
             const unsigned char* Ar = Ah + ((2 * wave + (l31 >> 4)) * PC + (l31 & 15) + prow) * HP + half * 16;
             const unsigned char* Br = Bh + tap * B_HB + l31 * HP + half * 16;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Ar + ks * 32),
-                                                                  *reinterpret_cast<const bf16x8*>(Br + ks * 32), acc[ph], 0, 0, 0);
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ar + ks * 32), bh = *reinterpret_cast<const bf16x8*>(Br + ks * 32);
+                if constexpr (PREC == 2) {
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ar + HPL + ks * 32), bl = *reinterpret_cast<const bf16x8*>(Br + HPL + ks * 32);
+                    acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[ph], 0, 0, 0);
+                    acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[ph], 0, 0, 0);
+                }
+                acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[ph], 0, 0, 0);
+            }
             return;
         }
         constexpr int shift = ((ky == 0) * PC + (kx == 0)) * DP;
@@ -205,12 +225,13 @@ bool deconv_tile_ok(const IgemmDesc& d) {
 }
 
 // d as igemm_conv takes it for the transposed conv (validated by the caller); ln_nparts as there.
-int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts, bool bf16) {
+int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts, int prec) {
     PIVP_CHECK_ARG(deconv_tile_ok(d));
     constexpr int lds_f32 = (A_FL + 9 * B_FL) * 4;        // 64,512 (the bf16 images fit inside)
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_f32) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_f32) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_HB + 9 * B_HB)) != hipSuccess)
             return PIVP_ERR_LAUNCH;
         attr_set = true;
     }
@@ -220,8 +241,9 @@ int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts, bool bf1
     dd.ln_nparts = (d.ln_part && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
-    if (bf16) hipLaunchKernelGGL(deconv3x3s2_tile_kernel<true>, dim3(d.B * tpi * nb), dim3(256), A_HB + 9 * B_HB, stream, dd);
-    else hipLaunchKernelGGL(deconv3x3s2_tile_kernel<false>, dim3(d.B * tpi * nb), dim3(256), lds_f32, stream, dd);
+    if (prec == 2) hipLaunchKernelGGL(deconv3x3s2_tile_kernel<2>, dim3(d.B * tpi * nb), dim3(256), 2 * (A_HB + 9 * B_HB), stream, dd);
+    else if (prec == 1) hipLaunchKernelGGL(deconv3x3s2_tile_kernel<1>, dim3(d.B * tpi * nb), dim3(256), A_HB + 9 * B_HB, stream, dd);
+    else hipLaunchKernelGGL(deconv3x3s2_tile_kernel<0>, dim3(d.B * tpi * nb), dim3(256), lds_f32, stream, dd);
     return PIVP_LAUNCH_STATUS();
 }
 

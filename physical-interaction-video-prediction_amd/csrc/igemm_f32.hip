@@ -582,7 +582,7 @@ int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     // transposed conv on maps that tile into 8 x 16 input patches: all four parities per block (deconv_tile.hip), unless the grid would be tiny
     if (deconv_tile_ok(d) && !(getenv("PIVP_DECONV_TILE") && atoi(getenv("PIVP_DECONV_TILE")) == 0) &&
         (long)d.B * (d.Hin / 8) * (d.Win / 16) * nt >= 16)
-        return deconv_tile(d, stream, ln_nparts, d.bf16 != 0);
+        return deconv_tile(d, stream, ln_nparts, d.bf16);
     const long full = (long)((d.M + 127) / 128) * d.nphase;   // blocks with BM = 128 and the whole N in one block
     if (d.ksplit_ok && !d.deconv && !d.bias && !d.relu && !d.accum && d.ksize * d.ksize * ((d.c0 + d.c1) / 32) > 40) {
         // Long-K data gradients (the ConvLSTM's 5x5 over 4C channels).  The output is pre-zeroed and may be produced by K-split

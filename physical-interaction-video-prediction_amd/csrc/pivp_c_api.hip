@@ -351,6 +351,11 @@ extern "C" int pivp_deconv3x3s2_bf16(const float* x, int cin, int ldx, const flo
     if (!x || !w || !out) return PIVP_ERR_BADARG;
     return run_deconv3x3s2(x, cin, ldx, w, bias, out, cout, ldo, relu, B, Hin, Win, (hipStream_t)stream, 0, nullptr, 0, nullptr, 1);
 }
+extern "C" int pivp_deconv3x3s2_bf16x3(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
+                                       int ldo, int relu, int B, int Hin, int Win, void* stream) {   // split mode: two bf16 pieces per operand
+    if (!x || !w || !out) return PIVP_ERR_BADARG;
+    return run_deconv3x3s2(x, cin, ldx, w, bias, out, cout, ldo, relu, B, Hin, Win, (hipStream_t)stream, 0, nullptr, 0, nullptr, 2);
+}
 extern "C" int pivp_conv_enc0(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, void* stream) {
     return conv_enc0(img, w, bias, out, B, H, W, (hipStream_t)stream);
 }

@@ -36,7 +36,7 @@ struct IgemmDesc {
     // each block writes (count, mean, M2) of its tile to ln_part[(b * ln_nparts + slot) * 4]; ln_apply merges them.
     // The launcher fills ln_nparts (0 = tiles straddle samples or exceed ln_cap: not fused, run ln_stats instead).
     float* ln_part; int ln_cap; int ln_nparts;
-    int bf16;                            // transposed conv only: bf16 operands (precision mode bf16) when the tile kernel takes the call
+    int bf16;                            // transposed conv only, when the tile kernel takes the call: 1 = bf16 operands, 2 = split (two bf16 pieces)
 };
 
 // weight gradient of a conv / transposed conv (csrc/igemm_wgrad.hip)
@@ -64,7 +64,7 @@ int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr)
 int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr);
 // transposed 3x3 s2 conv, all four output parities per block (csrc/deconv_tile.hip); d validated by igemm_validate
 bool deconv_tile_ok(const IgemmDesc& d);
-int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr, bool bf16 = false);   // bf16: operands rounded to bf16
+int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr, int prec = 0);   // 0 fp32, 1 bf16 operands, 2 split (2 bf16 pieces)
 // bf16-operand ConvLSTM (csrc/convlstm_bf16.hip): wb = pack_lstm_bf16 of d.w; nch: 0 auto, 16 / 32 channels per block
 size_t lstm_bf16_weight_elems(int wcin, int N);
 int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s, int Np = 0, int planes = 1);

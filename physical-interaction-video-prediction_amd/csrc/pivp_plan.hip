@@ -335,17 +335,17 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     RC(lstm(4, ws + S.e3, 64, p->H8, p->W8));
     RC(ln(5, ws + S.h[4], ws + S.n5, n8, 128, 128, 0, np));
     RC(run_deconv3x3s2(ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), P(p, p->i_enc_b[4]), ws + S.e4, 128, 128, 1, B, p->H8, p->W8, s, 0,
-                       nullptr, 0, nullptr, p->bf16_all));
+                       nullptr, 0, nullptr, p->bf16_all ? 1 : p->lstm_planes == 2 ? 2 : 0));
     // group 5 (TM:600): lstm6 -> hidden6 -> concat(., enc1) -> enc5 -> relu
     RC(lstm(5, ws + S.e4, 128, p->H4, p->W4));
     RC(ln(6, ws + S.h[5], ws + S.cat6, n4, 64, 96, 0, np));
     RC(run_deconv3x3s2(ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), P(p, p->i_enc_b[5]), ws + S.e5, 96, 96, 1, B, p->H4, p->W4, s, 0,
-                       nullptr, 0, nullptr, p->bf16_all));
+                       nullptr, 0, nullptr, p->bf16_all ? 1 : p->lstm_planes == 2 ? 2 : 0));
     // group 6 (TM:601): lstm7 -> hidden7 -> concat(., enc0) -> enc6 -> norm_enc6 -> relu
     RC(lstm(6, ws + S.e5, 96, p->H2, p->W2));
     RC(ln(7, ws + S.h[6], ws + S.cat7, n2, 32, 64, 0, np));
     RC(run_deconv3x3s2(ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), P(p, p->i_enc_b[6]), ws + S.e6raw, 64, 64, 0, B, p->H2, p->W2, s, 0,
-                       lnp, ln_cap, &np, p->bf16_all));
+                       lnp, ln_cap, &np, p->bf16_all ? 1 : p->lstm_planes == 2 ? 2 : 0));
     // heads (TM:711-728).  norm_enc6 + relu is applied while the heads kernel stages its input: the normalised enc6 is only
     // written when the activations are kept for BPTT (pivp_get_tap recomputes it on request otherwise).
     if (np > 0 && (H * W) % 64 == 0) {

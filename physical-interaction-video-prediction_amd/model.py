@@ -160,7 +160,7 @@ class Model(object):
         # 'fp32' is the parity path (per-pixel L2 < 1e-4 vs the reference).  'bf16' (BASELINE.json config 3) rounds the operands of
         # the seven ConvLSTM gate convolutions, of their data / weight gradients and of the enc5 / enc6 transposed convs to bf16 -- fp32 accumulation, gates, state, every
         # other op, the parameters, the gradients and Adam stay fp32 -- and reports, not gates, its error.
-        # 'bf16x3' is the split mode: the forward gate convolutions take every fp32 operand as two bf16 pieces and form a product on
+        # 'bf16x3' is the split mode: the forward gate convolutions (and the enc5 / enc6 transposed convs) take every fp32 operand as two bf16 pieces and form a product on
         # three bf16 MFMAs (16 bits of product mantissa); the rollout stays inside the 1e-4 gate; backward and everything else fp32.
         if precision not in ('fp32', 'bf16', 'bf16x3'):
             raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x3'")

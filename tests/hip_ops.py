@@ -122,7 +122,7 @@ def deconv3x3s2(x, W, b, relu, bf16=False):
     cout = W.shape[1]
     xd, wd, bd = nhwc(x), _t(pivp_amd.to_internal('enc4/W', W)), _t(b)
     out = torch.empty((B, 2 * H, 2 * Wd, cout), dtype=torch.float32, device=DEV)
-    fn = lib.pivp_deconv3x3s2_bf16 if bf16 else lib.pivp_deconv3x3s2
+    fn = lib.pivp_deconv3x3s2_bf16x3 if bf16 == 3 else lib.pivp_deconv3x3s2_bf16 if bf16 else lib.pivp_deconv3x3s2
     _lib.check(fn(xd.data_ptr(), cin, cin, wd.data_ptr(), bd.data_ptr(), out.data_ptr(), cout, cout,
                   int(relu), B, H, Wd, stream()), 'deconv3x3s2')
     torch.cuda.synchronize()

@@ -305,3 +305,13 @@ def test_train_step_in_bf16x3_mode_matches_fp32_gradients():
     rel = float((outs['bf16x3'][1] - outs['fp32'][1]).norm() / outs['fp32'][1].norm())
     print('bf16x3 train step: loss %.8f vs %.8f, relative gradient difference %.2e' % (outs['bf16x3'][0], outs['fp32'][0], rel))
     assert abs(outs['bf16x3'][0] - outs['fp32'][0]) < 1e-5 and rel < 1e-3
+
+
+@pytest.mark.parametrize('B,cin,cout,H', [(2, 64, 64, 32), (4, 96, 96, 16)])
+def test_deconv3x3s2_bf16x3(ops, B, cin, cout, H):
+    rs = np.random.RandomState(cin + H + 1)
+    x = rs.randn(B, cin, H, H); W = rs.randn(cin, cout, 3, 3) / np.sqrt(9 * cin); b = rs.randn(cout) * 0.1
+    ref = R.relu(R.deconv2d(x, W, b, 2, 1, (2 * H, 2 * H)))
+    e3 = np.abs(ops.deconv3x3s2(x, W, b, True, bf16=3) - ref).max(); e1 = np.abs(ops.deconv3x3s2(x, W, b, True, bf16=True) - ref).max()
+    print('deconv %d->%d @%d: max |err| split %.2e, plain bf16 %.2e' % (cin, cout, H, e3, e1))
+    assert e3 < 3e-5 and e3 < e1 / 50
