@@ -185,6 +185,9 @@ int pivp_deconv3x3s2_bf16x3(const float* x, int cin, int ldx, const float* w, co
 long long pivp_conv5x5_bf16_weight_elems(int cin, int cout);
 int pivp_conv5x5_bf16(const float* x, int cin, int ldx, const float* w, void* w_bf16, float* out, int cout, int ldo, int accum,
                       int B, int H, int W, void* stream);
+/* ... in the split mode (two bf16 pieces per operand, three MFMAs per product); w_bf16: twice the elements */
+int pivp_conv5x5_bf16x3(const float* x, int cin, int ldx, const float* w, void* w_bf16, float* out, int cout, int ldo, int accum,
+                        int B, int H, int W, void* stream);
 
 /* ConvLSTM weight gradient with bf16 operands and fp32 accumulation (bf16 mode): dW[tap][ci][n] += sum_m concat(x, h_prev)[m + tap][ci]
  * dG[m][n]; dW K-inner packed like the weight, ACCUMULATED; h_prev may be NULL (first timestep: only the x rows are touched);

@@ -101,7 +101,6 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     constexpr int BN = 4 * NCH;                 // block columns: [gate][channel]
     constexpr int PLANE = BN * 128;             // one weight plane of a ring slot: BN rows x 64 bf16
     constexpr int SLOT = PL * PLANE;            // bytes of one ring slot
-    static_assert(PL == 1 || (PL == 2 && LSTM), "the split mode is built for the ConvLSTM forward");
     // Split mode with 32-channel blocks: two patch planes (92 KB) leave room for TWO 32 KB ring slots only, so the schedule changes: the
     // loaders bring tap it + 1 in during tap it (one tap of lookahead), and the block barrier sits at the END of a tap (LATE).
     constexpr bool LATE = PL == 2 && NCH == 32;
@@ -637,14 +636,17 @@ int conv5x5_bf16_ksplit(const IgemmDesc& d) {
     return ks;
 }
 
-int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream) {
-    PIVP_CHECK_ARG(wb && bf16_geometry_ok(d) && d.out && d.N > 0 && d.ldo >= d.N && d.x0 && d.c0 > 0);
+int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int planes) {
+    PIVP_CHECK_ARG(wb && bf16_geometry_ok(d) && d.out && d.N > 0 && d.ldo >= d.N && d.x0 && d.c0 > 0 && (planes == 1 || planes == 2));
     const int Np = conv5x5_bf16_rows(d.N);
     IgemmDesc dd = d;
     dd.N = Np;                                         // the kernel's weight-row count
     const bool wide = Np % 128 == 0;
     const int nb = Np / (wide ? 128 : 64);
     const int ks = conv5x5_bf16_ksplit(d);
+    if (planes == 2)     // split mode (wb packed with planes = 2): 128-column blocks run the two-slot schedule, 64-column ones the four-slot one
+        return wide ? launch_bf16<32, false, 2>(dd, wb, stream, nullptr, nb, ks, d.N)
+                    : launch_bf16<16, false, 2>(dd, wb, stream, nullptr, nb, ks, d.N);
     return wide ? launch_bf16<32, false>(dd, wb, stream, nullptr, nb, ks, d.N)
                 : launch_bf16<16, false>(dd, wb, stream, nullptr, nb, ks, d.N);
 }

@@ -95,7 +95,7 @@ int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, in
 
 // 5x5 stride-1 "same" convolution with bf16 operands (csrc/convlstm_bf16.hip); wb = pack_lstm_bf16(w, cin, cout, conv5x5_bf16_rows(cout))
 int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb, float* out, int cout, int ldo, int accum,
-                     int B, int H, int W, hipStream_t s) {
+                     int B, int H, int W, hipStream_t s, int planes) {
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
     d.x0 = x; d.c0 = cin; d.ld0 = ldx; d.wcin = cin;
@@ -109,7 +109,7 @@ int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb,
         d.ksplit_ok = 1;
         if (conv5x5_bf16_ksplit(d) > 1 && hipMemsetAsync(out, 0, (size_t)B * H * W * cout * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     }
-    return conv5x5_bf16(d, wb, s);
+    return conv5x5_bf16(d, wb, s, planes);
 }
 
 // weight gradient of: mode 0 = conv K x K stride `stride` pad `pad`; mode 1 = transposed 3x3 s2 p1
@@ -139,7 +139,7 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
 int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
                           const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                           float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
-                          int B, int H, int W, hipStream_t s, int wt_ready, unsigned short* wt_bf16) {
+                          int B, int H, int W, hipStream_t s, int wt_ready, unsigned short* wt_bf16, int bf16_planes) {
     const int M = B * H * W, cin = cx + C, N = 4 * C;
     int rc = lstm_gates_bwd(gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc, dc_valid, dG, M, C, s);
     if (rc != PIVP_OK) return rc;
@@ -149,16 +149,17 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
     }
     if (wt_bf16) {   // bf16 precision mode: the data gradient with bf16 operands (wt_bf16 = bf16 pack of wt, built here unless wt_ready)
         if (!wt_ready) {
-            rc = pack_lstm_bf16(wt, wt_bf16, N, cin, s, conv5x5_bf16_rows(cin));
+            rc = pack_lstm_bf16(wt, wt_bf16, N, cin, s, conv5x5_bf16_rows(cin), bf16_planes);
             if (rc != PIVP_OK) return rc;
         }
-        rc = run_conv5x5_bf16(dG, N, N, wt_bf16, d_in, cin, cin, 0, B, H, W, s);
+        rc = run_conv5x5_bf16(dG, N, N, wt_bf16, d_in, cin, cin, 0, B, H, W, s, bf16_planes);
     } else {
         rc = run_conv_s1(dG, N, N, wt, d_in, cin, cin, 5, B, H, W, s);    // d[x,h] = conv5x5(dG, W^T flipped)
     }
     if (rc != PIVP_OK) return rc;
     int bias_done = 0;   // the 5x5 weight-gradient kernel sums dG's columns on the side
-    rc = run_wgrad(0, x, cx, ldx, h_prev, C, C, cin, dG, N, N, dW, B, H, W, H, W, 5, 2, 1, s, db, &bias_done, wt_bf16 != nullptr);
+    // (the weight gradient has a bf16 form but no split form: in the split mode it stays the fp32 kernel)
+    rc = run_wgrad(0, x, cx, ldx, h_prev, C, C, cin, dG, N, N, dW, B, H, W, H, W, 5, 2, 1, s, db, &bias_done, wt_bf16 != nullptr && bf16_planes == 1);
     if (rc != PIVP_OK) return rc;
     return bias_done ? PIVP_OK : bias_grad(dG, N, N, M, db, s);
 }
@@ -291,6 +292,14 @@ extern "C" int pivp_conv5x5_bf16(const float* x, int cin, int ldx, const float* 
     int rc = pack_lstm_bf16(w, (unsigned short*)w_bf16, cin, cout, (hipStream_t)stream, conv5x5_bf16_rows(cout));
     if (rc != PIVP_OK) return rc;
     return run_conv5x5_bf16(x, cin, ldx, (const unsigned short*)w_bf16, out, cout, ldo, accum, B, H, W, (hipStream_t)stream);
+}
+// split form (two bf16 pieces per operand): w_bf16 holds 2 * pivp_conv5x5_bf16_weight_elems(cin, cout) elements
+extern "C" int pivp_conv5x5_bf16x3(const float* x, int cin, int ldx, const float* w, void* w_bf16, float* out, int cout, int ldo, int accum,
+                                   int B, int H, int W, void* stream) {
+    if (!x || !w || !w_bf16 || !out || cin <= 0 || cout <= 0) return PIVP_ERR_BADARG;
+    int rc = pack_lstm_bf16(w, (unsigned short*)w_bf16, cin, cout, (hipStream_t)stream, conv5x5_bf16_rows(cout), 2);
+    if (rc != PIVP_OK) return rc;
+    return run_conv5x5_bf16(x, cin, ldx, (const unsigned short*)w_bf16, out, cout, ldo, accum, B, H, W, (hipStream_t)stream, 2);
 }
 // ConvLSTM weight gradient with bf16 operands: dW (K-inner packed like the weight, [25][(cx+C)/32][4C][32]) += x|h^T . dG per tap.
 extern "C" int pivp_wgrad5x5_bf16(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW, float* db,

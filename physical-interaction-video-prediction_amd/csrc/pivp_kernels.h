@@ -70,7 +70,7 @@ size_t lstm_bf16_weight_elems(int wcin, int N);
 int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s, int Np = 0, int planes = 1);
 int conv5x5_bf16_rows(int N);
 int conv5x5_bf16_ksplit(const IgemmDesc& d);   // > 1: the launch will split K and needs d.out zeroed
-int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream);   // plain 5x5 s1 conv (ConvLSTM data gradient)
+int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int planes = 1);   // plain 5x5 s1 conv (ConvLSTM data gradient)
 bool convlstm_bf16_ok(const IgemmDesc& d);
 int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts = nullptr, int nch = 0, int planes = 1);
 

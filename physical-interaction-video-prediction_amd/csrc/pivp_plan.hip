@@ -190,7 +190,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
             g.din[i][0] = carve(M * (kLstm[i].cx + kLstm[i].C)); g.din[i][1] = carve(M * (kLstm[i].cx + kLstm[i].C));
             if (M * 4 * kLstm[i].C > maxdG) maxdG = M * 4 * kLstm[i].C;
             g.wt_lstm[i] = carve((size_t)25 * (kLstm[i].cx + kLstm[i].C) * 4 * kLstm[i].C);
-            g.wtb_lstm[i] = carve((lstm_bf16_weight_elems(4 * kLstm[i].C, conv5x5_bf16_rows(kLstm[i].cx + kLstm[i].C)) + 1) / 2);
+            g.wtb_lstm[i] = carve(lstm_bf16_weight_elems(4 * kLstm[i].C, conv5x5_bf16_rows(kLstm[i].cx + kLstm[i].C)));   // two planes
             g.wt_enc[i] = (i == 0 || i == 3) ? 0 : carve((size_t)encw[i]);
         }
         g.dG = carve(maxdG);
@@ -451,7 +451,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                                      Sp ? ws + Sp->c[i] : ws + p->o_zero, ws + S.c[i], ws + g.hln[i], L.C,
                                      last_step ? nullptr : ws + g.din[i][npar] + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
                                      ws + g.dG, ws + g.wt_lstm[i], ws + g.din[i][par], G(p, p->i_lstm_w[i]), G(p, p->i_lstm_b[i]), B, hh, wwid,
-                                     s, 1, p->bf16_all ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr);
+                                     s, 1, p->lstm_bf16 ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->lstm_planes);
     };
     const long px2 = (long)B * p->H2 * p->W2, px4 = (long)B * p->H4 * p->W4, px8 = (long)B * p->H8 * p->W8;
 
@@ -554,11 +554,11 @@ extern "C" int pivp_rollout_backward(pivp_plan_t* plan, const float* images, con
     // weights are constant during the sweep: build the transposed packs for the data gradients once
     for (int i = 0; i < 7; ++i)
         RC(repack_transpose(P(plan, plan->i_lstm_w[i]), ws + g.wt_lstm[i], 25, kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C, 1, s));
-    if (plan->bf16_all)         // bf16 mode: the ConvLSTM data gradients run with bf16 operands on these packs
+    if (plan->lstm_bf16)        // bf16 / split modes: the ConvLSTM data gradients run on these packs (one plane, or the hi / lo pair)
         for (int i = 0; i < 7; ++i) {
             const int cin = kLstm[i].cx + kLstm[i].C;
             RC(pack_lstm_bf16(ws + g.wt_lstm[i], reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]), 4 * kLstm[i].C, cin, s,
-                              conv5x5_bf16_rows(cin)));
+                              conv5x5_bf16_rows(cin), plan->lstm_planes));
         }
     {
         const int ecin[7] = {0, 32, 64, 0, 128, 96, 64};

@@ -315,3 +315,14 @@ def test_deconv3x3s2_bf16x3(ops, B, cin, cout, H):
     e3 = np.abs(ops.deconv3x3s2(x, W, b, True, bf16=3) - ref).max(); e1 = np.abs(ops.deconv3x3s2(x, W, b, True, bf16=True) - ref).max()
     print('deconv %d->%d @%d: max |err| split %.2e, plain bf16 %.2e' % (cin, cout, H, e3, e1))
     assert e3 < 3e-5 and e3 < e1 / 50
+
+
+@pytest.mark.parametrize('B,cin,cout,H', [(2, 128, 64, 32), (2, 256, 96, 16), (4, 512, 192, 8), (2, 256, 128, 16), (32, 512, 192, 8)])
+def test_conv5x5_bf16x3(ops, B, cin, cout, H):
+    # the data gradients of the split mode: 64-column blocks (four ring slots), 128-column blocks (two slots), padded columns, K split
+    rs = np.random.RandomState(cin + cout + H + 5)
+    x = rs.randn(B, cin, H, H); W = rs.randn(cout, cin, 5, 5) / np.sqrt(25 * cin)
+    ref = R.conv2d(x, W, np.zeros(cout), 1, 2)
+    e3 = np.abs(ops.conv5x5_bf16(x, W, split=True) - ref).max(); e1 = np.abs(ops.conv5x5_bf16(x, W) - ref).max()
+    print('conv5x5 %d->%d @%d: max |err| split %.2e, plain bf16 %.2e' % (cin, cout, H, e3, e1))
+    assert e3 < 5e-5 and e3 < e1 / 50
