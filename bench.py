@@ -183,7 +183,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import restatement as R
         from oracle.torch_restatement import TorchModel
-        cb, ct = 2, T
+        # The same workload as the GPU leg (batch, frame size, T).  16 threads: PyTorch-CPU on this model is fastest there on the GPU box's host
+        # (scripts/cpu_thread_scan.py: 65 / 307 / 59 frames/s at 1 / 16 / 64 threads for B = 2; 128 threads, the default, gave 23)
+        cpu_threads = min(16, torch.get_num_threads())
+        torch.set_num_threads(cpu_threads)
+        cb, ct = B, T
         P = R.init_params(seed=1, dtype=np.float32, scale=1.0, num_masks=nm, model_type=args.model, height=S, width=S)
         ci, ca, cs = R.synthetic_batch(cb, ct, S, S)
         tm = TorchModel(nm, is_cdna=args.model == 'CDNA', is_stp=args.model == 'STP', is_dna=args.model == 'DNA',
@@ -211,7 +215,7 @@ def main():
                 reps += 1
             cel = time.perf_counter() - c0
         cpu_baseline = {'value': round(cb * (ct - 1) * reps / cel, 2), 'unit': 'predicted frames/s',
-                        'cores': torch.get_num_threads(), 'kind': 'port',
+                        'cores': cpu_threads, 'kind': 'port',
                         'sample': '%d %s of B=%d T=%d %dx%d %s, fp32 PyTorch-CPU restatement of the reference path '
                                   '(oracle/torch_restatement.py), %.1f s' % (reps, 'train steps (fwd+bwd+Adam)' if train else 'rollouts',
                                                                               cb, ct, S, S, args.model, cel)}
