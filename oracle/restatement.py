@@ -268,6 +268,16 @@ def synthetic_batch(batch, seq_len=10, height=64, width=64, seed=0, dtype=np.flo
     return images, actions, states
 
 
+def smooth_batch(batch, seq_len=10, height=64, width=64, seed=0, dtype=np.float32, box=11):
+    """`synthetic_batch` with every frame box-blurred (box x box, reflect padding): frames with the smoothness of video instead of
+    white noise.  The STP warp multiplies a theta error by the image gradient, so white noise is its worst case."""
+    images, actions, states = synthetic_batch(batch, seq_len, height, width, seed, dtype)
+    r = box // 2
+    pad = np.pad(images, ((0, 0), (0, 0), (0, 0), (r, r), (r, r)), mode='reflect')
+    images = np.ascontiguousarray(sliding_window_view(pad, (box, box), axis=(3, 4)).mean(axis=(-1, -2))).astype(dtype)
+    return images, actions, states
+
+
 def concat_examples(batch):
     """TM:51-71: list of (imgs (T,H,W,3), act (T,5), sta (T,5)) -> time-major (T,B,3,H,W), (T,B,5), (T,B,5)."""
     img = np.array([b[0] for b in batch])
@@ -408,8 +418,8 @@ class Model(object):
             for yk in range(DNA_KERN_SIZE):
                 tmp = pad[:, :, xk:H, yk:W]                                      # TM:400 (the reference's slice quirk)
                 tmp = np.pad(tmp, ((0, 0), (0, 0), (0, xk), (0, yk)))            # TM:402
-                inputs.append(tmp[:, None])
-        kin = np.concatenate(inputs, axis=1)                                      # (B,25,C,H,W)
+                inputs.append(tmp[:, None])                                      # TM:404 appends tmp.data: DETACHED from the graph
+        kin = np.concatenate(inputs, axis=1)                                      # (B,25,C,H,W); constant w.r.t. prev in the backward
         kn = relu(enc7 - RELU_SHIFT) + RELU_SHIFT                                 # TM:408
         kn = kn / kn.sum(axis=1, keepdims=True)                                   # TM:409-410
         out = (kin * kn[:, :, None]).sum(axis=1)                                  # TM:411-414

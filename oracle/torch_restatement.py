@@ -80,7 +80,9 @@ class TorchModel(object):
     def _deconv(self, n, x):                                       # TM:505-507 (outsize = 2*in)
         return F.conv_transpose2d(x, self.p[n + '/W'], self.p[n + '/b'], stride=2, padding=1, output_padding=1)
 
-    def _step(self, prev, sa):
+    def _step(self, prev, sa, prev_head=None):
+        """One timestep (TM:676-731).  `prev_head` (tests only) lets a KAT hand the motion head / compositing a separate leaf
+        from the one the trunk reads, to isolate d out / d prev through the head; the model always passes one tensor."""
         p = self.p
         B, _, H, W = prev.shape
         enc0 = F.relu(self._ln('norm_enc0', F.conv2d(prev, p['enc0/W'], p['enc0/b'], stride=2, padding=2)))
@@ -100,6 +102,9 @@ class TorchModel(object):
         enc5 = F.relu(self._deconv('enc5', torch.cat((x, enc1), 1)))
         x = self._ln('hidden7', self._lstm('lstm7', enc5))
         enc6 = F.relu(self._ln('norm_enc6', self._deconv('enc6', torch.cat((x, enc0), 1))))
+
+        if prev_head is not None:
+            prev = prev_head
 
         # 1x1 deconvs == 1x1 convs with W^T (TM:288, TM:527)
         def conv1x1_t(w, b, xin):
@@ -139,7 +144,7 @@ class TorchModel(object):
                 for yk in range(5):
                     tmp = padded[:, :, xk:H, yk:W]                 # TM:400 quirk: slice ends at H, W
                     tmp = F.pad(tmp, (0, yk, 0, xk))               # TM:402
-                    shifted.append(tmp)
+                    shifted.append(tmp.detach())                   # TM:404 `kernel_inputs.append(tmp.data)`: graph cut, no gradient into prev
             kin = torch.stack(shifted, 1)                          # (B,25,3,H,W)
             kn = F.relu(enc7 - RELU_SHIFT) + RELU_SHIFT
             kn = kn / kn.sum(dim=1, keepdim=True)

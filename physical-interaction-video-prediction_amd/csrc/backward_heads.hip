@@ -337,22 +337,9 @@ __global__ __launch_bounds__(256) void composite_bwd_dna_kernel(const float* __r
         dm[0] = g0 * p0[2 * PW + 2] + g1 * p1[2 * PW + 2] + g2 * p2[2 * PW + 2];
         dm[(size_t)HW] = g0 * t0 + g1 * t1 + g2 * t2;
         if (dprev) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-            if (y + 2 < H && x + 2 < W) {
-#pragma unroll
-                for (int xk = 0; xk < 5; ++xk) {
-                    const int sy = y - (xk - 2);
-                    if (sy < ey0 || sy >= ey1) continue;
-#pragma unroll
-                    for (int yk = 0; yk < 5; ++yk) {
-                        const int sx = x - (yk - 2);
-                        if ((unsigned)sx >= (unsigned)W) continue;
-                        const int sp = (sy - ey0) * W + sx;
-                        const float w = wx[(xk * 5 + yk) * PR * W + sp];
-                        a0 = fmaf(w, dtx[sp], a0); a1 = fmaf(w, dtx[PR * W + sp], a1); a2 = fmaf(w, dtx[2 * PR * W + sp], a2);
-                    }
-                }
-            }
+            // TM:404 `kernel_inputs.append(tmp.data)`: the 25 shifted copies of the previous frame are DETACHED in the reference, so
+            // nothing flows into the frame through the per-pixel kernels; only the mask-0 term m0 * go does (TM:725).
+            const float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             const float m0 = m0x[toff + pp];
             float* dp = dprev + (size_t)b * 3 * HW + p;
             const float v0 = a0 + m0 * g0, v1 = a1 + m0 * g1, v2 = a2 + m0 * g2;

@@ -256,3 +256,25 @@ def test_dna_requires_single_mask():
     m.num_masks = 2
     with pytest.raises(ValueError):
         m._dna(np.zeros((1, 64, 64, 64)), None, np.zeros((1, 3, 64, 64)))
+
+
+def test_dna_shifted_stack_is_detached():
+    # TM:404 `kernel_inputs.append(tmp.data)`: the 25 shifted copies of the previous frame leave the graph, so through the
+    # DNA head d out / d prev is the mask-0 term alone: d out[b,c,p] / d prev[b,c,p] = m0[b,p] (TM:725), nothing via the kernels.
+    import torch
+    from oracle.torch_restatement import TorchModel
+    P = R.init_params(seed=3, dtype=np.float64, scale=1.0, model_type='DNA', num_masks=1)
+    tm = TorchModel(1, is_cdna=False, is_dna=True, params=P)
+    rs = np.random.RandomState(5)
+    prev = torch.tensor(rs.rand(2, 3, 64, 64))
+    sa = torch.tensor(rs.randn(2, 10) * 0.1)
+    head = prev.clone().requires_grad_(True)
+    out, _ = tm._step(prev, sa, prev_head=head)          # trunk reads the constant `prev`, the head reads the leaf
+    go = torch.tensor(rs.randn(2, 3, 64, 64))
+    (out * go).sum().backward()
+    m0 = tm.last['masks'][:, 0:1].detach()
+    assert torch.allclose(head.grad, m0 * go, rtol=0, atol=1e-14)
+    # and the term the reference drops is not small: with the stack attached the gradient would differ visibly
+    kn = torch.relu(tm.last['enc7'].detach() - 1e-12) + 1e-12
+    kn = kn / kn.sum(1, keepdim=True)
+    assert float((kn[:, 12:13] * tm.last['masks'][:, 1:2].detach() * go).abs().max()) > 1e-3
