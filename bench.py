@@ -2,9 +2,18 @@
 """Benchmark of the hot path: predicted frames/s of the 10-frame 64x64x3 CDNA rollout (BASELINE.json).
 
     python bench.py --gpus N --steps K --warmup W
-For N > 1 the driver launches one rank per GPU through torch.distributed.run; every rank runs the
-same per-GPU workload (weak scaling; the forward rollout shards over the batch with no data-path
-collective: SURVEY.md 8e "inference rollout: replicas only").
+One process per GPU.  When the driver launches the ranks itself (torch.distributed.run: WORLD_SIZE / RANK / LOCAL_RANK in the
+environment) this file is a rank.  Started plainly with --gpus N > 1 it is the LAUNCHER: before anything touches the GPU it starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` as a child
+process, relays rank 0's JSON line and exits with the child's code.  A world size different from --gpus is an error, never a
+silent 1-GPU run.  Every rank runs the same per-GPU workload (weak scaling).
+
+Two legs, both in the ONE JSON line rank 0 prints:
+  value / ms_per_step : the rollout, Model.__call__ forward, feed-self (predict_model.py:126-128).  It shards over the batch with
+                        no data-path collective (SURVEY.md 8e "inference rollout: replicas only").
+  train               : optimizer.update (train_model.py:950) = forward + BPTT backward + gradient all-reduce over RCCL, overlapped
+                        with the backward sweep + Adam: ms_per_step, frames_per_s (whole job), rccl_ranks, and
+                        allreduce_ms_exposed = that step time minus the time of the same step with the collective switched off.
 
 A "step" is one Model.__call__ (TM:620-764) over one synthetic batch already resident in HBM:
 B sequences x (T-1) predicted frames, feed-self after the context frames as predict_model.py:126-128.
@@ -30,14 +39,15 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32-i
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak of the same guide (the headline 5 PFLOP/s figure includes 2:1 sparsity)
 
 
-def _pmc_traffic():
+def _pmc_traffic(bf16=False):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), or None.
     PMC counters cannot be collected inside this process; the passes are re-run per round on the same command."""
     try:
         best = None
         pdir = os.path.join(ROOT, 'profiles')
+        name = 'pmc_traffic_bf16.json' if bf16 else 'pmc_traffic.json'
         for rnd in sorted(os.listdir(pdir)):
-            f = os.path.join(pdir, rnd, 'pmc_traffic.json')
+            f = os.path.join(pdir, rnd, name)
             if os.path.exists(f):
                 best = f
         if best is None:
@@ -48,7 +58,7 @@ def _pmc_traffic():
         return None
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -58,173 +68,225 @@ def main():
     ap.add_argument('--size', type=int, default=64)
     ap.add_argument('--model', default='CDNA', choices=['CDNA', 'STP', 'DNA'])
     ap.add_argument('--mode', default='rollout', choices=['rollout', 'train'],
-                    help='rollout: Model.__call__ forward (predict_model.py:126-128); train: optimizer.update = forward + '
-                         'BPTT backward + gradient all-reduce + Adam (train_model.py:950)')
+                    help='rollout (default): `value` is the rollout and the train step is reported in `train`; train: only the '
+                         'train step runs and `value` is its frames/s (profiling runs)')
+    ap.add_argument('--no-train', action='store_true', help='rollout mode: skip the train leg')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'bf16x3'],
                     help='fp32: the parity path and the headline metric (config 2). bf16: ConvLSTM gate convolutions with bf16 operands, '
                          'fp32 accumulation (config 3); reports its per-pixel error instead of meeting the 1e-4 gate')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
-    args = ap.parse_args()
+    ap.add_argument('--dry', action='store_true',
+                    help='host logic only: gloo on CPU, stub kernels (HostStubModel); exercises the launcher, the rank bookkeeping, the '
+                         'barrier / max-over-ranks timing and the overlapped all-reduce without a GPU.  Not a measurement.')
+    return ap
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a launcher around us: start the N ranks as a child process tree.  Nothing in this process has touched
+    the GPU (torch is not even imported yet), and the child is started with subprocess, never exec'd over us."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')    # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + '\n')
+    if proc.returncode != 0 or line is None:
+        sys.stderr.write('bench.py: the %d-rank run failed (exit code %d)\n' % (args.gpus, proc.returncode))
+        return proc.returncode or 1
+    got = json.loads(line).get('n_gpus')
+    if got != args.gpus:
+        sys.stderr.write('bench.py: asked for %d ranks, the run reports %r\n' % (args.gpus, got))
+        return 1
+    print(line)
+    return 0
+
+
+def timed(step, steps, warmup, sync, barrier):
+    """W untimed warm-up steps, then exactly K steps between barrier + device synchronisation on both sides."""
+    out = None
+    for _ in range(warmup):
+        out = step()
+    sync(); barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    sync(); barrier()
+    return time.perf_counter() - t0, out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = build_parser().parse_args(argv)
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args, argv))
+    world = int(env_world or '1')
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a run of a different size' % (args.gpus, world))
 
     import numpy as np
     import torch
     import pivp_amd
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
-    torch.cuda.set_device(local_rank)
-    dev = 'cuda:%d' % local_rank
+    dry = args.dry
+    if not dry:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+    dev = 'cpu' if dry else 'cuda:%d' % local_rank
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device(dev))
+        if dry:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device(dev))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit('bench.py: process group has %d ranks, --gpus %d' % (dist.get_world_size(), args.gpus))
 
-    B, T, S = args.batch, args.seq_len, args.size
-    nm = 1 if args.model == 'DNA' else 10
-    np.random.seed(1234 + rank)
-    train = args.mode == 'train'
-    model = pivp_amd.Model(nm, is_cdna=args.model == 'CDNA', is_stp=args.model == 'STP', is_dna=args.model == 'DNA',
-                           prefix='bench', device=dev, keep_activations=train, precision=args.precision)
-    rs = np.random.RandomState(rank)
-    images = torch.from_numpy(rs.random_sample((T, B, 3, S, S)).astype(np.float32)).to(dev)
-    actions = torch.from_numpy((0.1 * rs.standard_normal((T, B, 5))).astype(np.float32)).to(dev)
-    states = torch.from_numpy((0.1 * rs.standard_normal((T, B, 5))).astype(np.float32)).to(dev)
-
-    opt = None
-    if train:
-        dp = pivp_amd.GradAllReduce() if world > 1 else None
-        opt = pivp_amd.Adam(alpha=0.001).setup(model, data_parallel=dp)   # TM:860-861
-        if world > 1:                                                        # identical replicas: broadcast rank 0's init
-            with pivp_amd.using_config('train', False):
-                model([images, actions, states], 0)
-            dist.broadcast(model._flat_params, src=0)
-
-    def step():
-        model.reset_state()
-        if train:
-            return opt.update(model, [images, actions, states], 0)          # schedsamp_k = -1: feed-self, deterministic
-        return model([images, actions, states], 0)
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    with pivp_amd.using_config('train', False):
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
-        torch.cuda.synchronize()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        loss_val = float(loss)
-
-        roofline = None
-        if not args.no_roofline and rank != 0 and train and world > 1:
-            for _ in range(args.steps):        # rank 0's instrumented pass below calls the gradient all-reduce: every rank must take part
-                step()
-            torch.cuda.synchronize()
-        if not args.no_roofline and rank == 0:
-            plan = model._active
-            lib = plan.lib
-            lib.pivp_plan_set_profiling(plan.h, 1)
-            ms_tot = np.zeros(7); n_tot = np.zeros(7, dtype=np.int64); flops = np.zeros(7)
-            t_prof = 0.0
-            for _ in range(args.steps):
-                tp0 = time.perf_counter()
-                step()
-                torch.cuda.synchronize()
-                t_prof += time.perf_counter() - tp0
-                ms = (ctypes.c_double * 7)(); n = (ctypes.c_int * 7)(); fl = (ctypes.c_double * 7)()
-                rc = lib.pivp_plan_profile_read(plan.h, ms, n, fl)
-                assert rc == 0, rc
-                ms_tot += np.array(ms[:]); n_tot += np.array(n[:]); flops += np.array(fl[:])
-            lib.pivp_plan_set_profiling(plan.h, 0)
-            total_flops = float(flops.sum())
-            total_s = float(ms_tot.sum()) * 1e-3
-            achieved = total_flops / total_s / 1e12
-            bf16 = args.precision != 'fp32'
-            # bf16x3 executes three bf16 MFMAs per algorithmic product: its ceiling in algorithmic flops is a third of the bf16 peak
-            peak = (PEAK_BF16_MFMA_TFLOPS / (3.0 if args.precision == 'bf16x3' else 1.0)) if bf16 else PEAK_FP32_MFMA_TFLOPS
-            roofline = {
-                'bound': 'mfma',
-                'kernel': ('convlstm_bf16_kernel<NCH> (ConvLSTM 5x5 gate conv, %s, + fused gates)' %
-                           ('bf16 operands' if args.precision == 'bf16' else 'fp32 operands as 2 bf16 pieces, 3 MFMAs per product') if bf16 else
-                           'igemm_f32_kernel<WM,WN,4,true> (ConvLSTM 5x5 gate conv + fused gates)'),
-                'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                'frac': round(achieved / peak, 4),
-                'traffic': None if bf16 else _pmc_traffic(),
-                'launches': int(n_tot.sum()), 'avg_launch_us': round(total_s / max(1, int(n_tot.sum())) * 1e6, 2),
-                'algorithmic_gflop_per_launch': round(total_flops / max(1, int(n_tot.sum())) / 1e9, 3),
-                'per_layer_tflops': {('lstm%d' % (i + 1)): round(float(flops[i] / (ms_tot[i] * 1e-3) / 1e12), 2)
-                                     for i in range(7) if ms_tot[i] > 0},
-                'share_of_step_time': round(total_s / args.steps / (elapsed / args.steps), 3),
-                'ms_per_step_with_events': round(t_prof / args.steps * 1e3, 3),
-            }
-
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    B, T, S = args.batch, args.seq_len, args.size
+    nm = 1 if args.model == 'DNA' else 10
+    np.random.seed(1234 + rank)
+    kinds = dict(is_cdna=args.model == 'CDNA', is_stp=args.model == 'STP', is_dna=args.model == 'DNA')
+    rs = np.random.RandomState(rank)
+    if not dry:
+        images = torch.from_numpy(rs.random_sample((T, B, 3, S, S)).astype(np.float32)).to(dev)
+        actions = torch.from_numpy((0.1 * rs.standard_normal((T, B, 5))).astype(np.float32)).to(dev)
+        states = torch.from_numpy((0.1 * rs.standard_normal((T, B, 5))).astype(np.float32)).to(dev)
+    do_rollout = args.mode == 'rollout'
+    do_train = args.mode == 'train' or not args.no_train
+
+    elapsed = loss_val = None
+    roofline = None
+    model = None
+    with pivp_amd.using_config('train', False):
+        # ---- leg 1: the rollout (`value`) --------------------------------------------------------------------
+        if do_rollout and not dry:
+            model = pivp_amd.Model(nm, prefix='bench', device=dev, keep_activations=False, precision=args.precision, **kinds)
+
+            def rollout_step():
+                model.reset_state()
+                return model([images, actions, states], 0)
+            elapsed, loss = timed(rollout_step, args.steps, args.warmup, sync, barrier)
+            loss_val = float(loss)
+            elapsed = max_over_ranks(elapsed)
+        elif do_rollout:
+            elapsed, _ = timed(lambda: time.sleep(0.001), args.steps, args.warmup, sync, barrier)
+            elapsed = max_over_ranks(elapsed); loss_val = 0.0
+
+        # ---- leg 2: the data-parallel train step ----------------------------------------------------------------
+        train_obj = None
+        tmodel = None
+        if do_train:
+            dp = pivp_amd.GradAllReduce() if world > 1 else None
+            if dry:
+                tmodel = pivp_amd.HostStubModel(sizes=(1 << 16, 1 << 14, 1 << 15, 1 << 15, 1 << 16, 1 << 14), value=float(rank + 1))
+                ngrad = sum(tmodel.sizes)
+
+                def train_step():
+                    tmodel.cleargrads()
+                    if dp is not None and use_dp[0]:
+                        dp.backward_and_allreduce(tmodel)
+                    else:
+                        tmodel.backward()
+                    return 0.0
+            else:
+                tmodel = pivp_amd.Model(nm, prefix='bench', device=dev, keep_activations=True, precision=args.precision, **kinds)
+                opt = pivp_amd.Adam(alpha=0.001).setup(tmodel, data_parallel=dp)        # TM:860-861
+                tmodel([images, actions, states], 0)                                    # parameters are lazily sized: one forward first
+                if world > 1:                                                           # identical replicas: rank 0's initialisation
+                    dist.broadcast(tmodel._flat_params, src=0)
+                ngrad = int(tmodel._flat_params.numel())
+
+                def train_step():
+                    tmodel.reset_state()
+                    opt._dp = dp if use_dp[0] else None
+                    return opt.update(tmodel, [images, actions, states], 0)             # schedsamp_k = -1: feed-self, deterministic
+            use_dp = [True]
+            t_with, tloss = timed(train_step, args.steps, args.warmup, sync, barrier)
+            t_with = max_over_ranks(t_with)
+            t_without = None
+            if world > 1:       # the same step with the collective switched off (replicas drift apart: timing only, run last)
+                use_dp[0] = False
+                t_without, _ = timed(train_step, args.steps, max(1, args.warmup // 2), sync, barrier)
+                t_without = max_over_ranks(t_without)
+                use_dp[0] = True
+            train_obj = {
+                'ms_per_step': round(t_with / args.steps * 1e3, 3),
+                'frames_per_s': round(world * B * (T - 1) * args.steps / t_with, 1),
+                'rccl_ranks': dist.get_world_size() if dist is not None else 1,
+                'backend': (dist.get_backend() if dist is not None else None),
+                'ms_per_step_without_allreduce': None if t_without is None else round(t_without / args.steps * 1e3, 3),
+                'allreduce_ms_exposed': 0.0 if t_without is None else round(max(0.0, t_with - t_without) / args.steps * 1e3, 3),
+                'gradient_bytes_per_step': 4 * ngrad,
+                'allreduce': 'none (1 rank)' if world == 1 else '6 gradient groups, SUM, issued from inside the backward sweep of t = 0 on a side stream',
+                'workload': 'optimizer.update (TM:950): forward + BPTT backward + gradient all-reduce + Adam, schedsamp_k=-1, batch %d/GPU' % B,
+                'loss': float(tloss),
+            }
+            if args.mode == 'train':
+                elapsed, loss_val = t_with, float(tloss)
+
+        # ---- the dominant kernel against its roofline, HIP events on the launch stream, second pass over the same K steps ----------
+        pmodel = model if do_rollout else tmodel
+        if not args.no_roofline and not dry:
+            def prof_step():
+                pmodel.reset_state()
+                if do_rollout:
+                    return pmodel([images, actions, states], 0)
+                return opt.update(pmodel, [images, actions, states], 0)
+            if rank != 0 and not do_rollout and world > 1:
+                for _ in range(args.steps):        # rank 0's instrumented pass calls the gradient all-reduce: every rank must take part
+                    prof_step()
+                sync()
+            if rank == 0:
+                roofline = roofline_pass(args, pmodel, prof_step, elapsed, np, torch)
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import restatement as R
-        from oracle.torch_restatement import TorchModel
-        # The same workload as the GPU leg (batch, frame size, T).  16 threads: PyTorch-CPU on this model is fastest there on the GPU box's host
-        # (scripts/cpu_thread_scan.py: 65 / 307 / 59 frames/s at 1 / 16 / 64 threads for B = 2; 128 threads, the default, gave 23)
-        cpu_threads = min(16, torch.get_num_threads())
-        torch.set_num_threads(cpu_threads)
-        cb, ct = B, T
-        P = R.init_params(seed=1, dtype=np.float32, scale=1.0, num_masks=nm, model_type=args.model, height=S, width=S)
-        ci, ca, cs = R.synthetic_batch(cb, ct, S, S)
-        tm = TorchModel(nm, is_cdna=args.model == 'CDNA', is_stp=args.model == 'STP', is_dna=args.model == 'DNA',
-                        params=P, dtype=torch.float32)
-        tm.train = False
-        with torch.no_grad():
-            tm([ci, ca, cs], 0); tm.reset_state()      # warm-up
-            reps, c0 = 0, time.perf_counter()
-            while time.perf_counter() - c0 < args.cpu_seconds:
-                tm([ci, ca, cs], 0); tm.reset_state()
-                reps += 1
-            cel = time.perf_counter() - c0
-        if train:      # same bounded sample, but forward + autograd backward + Chainer-rule Adam
-            from oracle.torch_restatement import chainer_adam_step
-            tmt = TorchModel(nm, is_cdna=True, params=P, dtype=torch.float32, requires_grad=True)
-            Pm = {k: v.detach().numpy() for k, v in tmt.p.items()}
-            Mm = {k: np.zeros_like(v) for k, v in Pm.items()}; Vm = {k: np.zeros_like(v) for k, v in Pm.items()}
-            reps, c0 = 0, time.perf_counter()
-            while time.perf_counter() - c0 < args.cpu_seconds:
-                for v in tmt.p.values():
-                    v.grad = None
-                l = tmt([ci, ca, cs], 0); l.backward(); tmt.reset_state()
-                with torch.no_grad():
-                    chainer_adam_step(Pm, {k: v.grad.numpy() for k, v in tmt.p.items()}, Mm, Vm, reps + 1)
-                reps += 1
-            cel = time.perf_counter() - c0
-        cpu_baseline = {'value': round(cb * (ct - 1) * reps / cel, 2), 'unit': 'predicted frames/s',
-                        'cores': cpu_threads, 'kind': 'port',
-                        'sample': '%d %s of B=%d T=%d %dx%d %s, fp32 PyTorch-CPU restatement of the reference path '
-                                  '(oracle/torch_restatement.py), %.1f s' % (reps, 'train steps (fwd+bwd+Adam)' if train else 'rollouts',
-                                                                              cb, ct, S, S, args.model, cel)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
+        cpu_baseline = cpu_baseline_leg(args, B, T, S, nm, np, torch, train=args.mode == 'train')
 
     if rank == 0:
         frames = world * B * (T - 1) * args.steps
+        train_mode = args.mode == 'train'
         out = {
             'metric': 'predicted frames/sec (64x64x3, 10-step rollout)',
-            'value': round(frames / elapsed, 1),
+            'value': round(frames / elapsed, 1) if not dry else 0.0,
             'unit': 'frames/s',
             'n_gpus': world,
             'steps': args.steps,
@@ -235,20 +297,105 @@ def main():
             'vs_baseline': None,
             'dtype': {'fp32': 'f32', 'bf16': 'bf16 ConvLSTM operands, f32 accumulate and elsewhere',
                       'bf16x3': 'f32 operands of the ConvLSTM forward as 2 bf16 pieces (3 bf16 MFMAs per product), f32 accumulate and elsewhere'}[args.precision],
-            'data': 'synthetic',
+            'data': 'synthetic' if not dry else 'none: --dry run of the host logic on CPU (gloo, stub kernels); NOT a measurement',
             'config': {'workload': '%s %s, batch %d/GPU, %d-frame %dx%dx3 sequences, action-conditioned, num_masks=%d, '
                                    'random-init weights' % (args.model, 'train step (optimizer.update: forward + BPTT backward + grad '
-                                   'all-reduce + Adam, schedsamp_k=-1)' if train else 'rollout forward (Model.__call__, feed-self)',
+                                   'all-reduce + Adam, schedsamp_k=-1)' if train_mode else 'rollout forward (Model.__call__, feed-self)',
                                    B, T, S, S, nm),
                        'global_batch': world * B, 'frames_per_step': world * B * (T - 1),
-                       'parallelism': ('dp%d (RCCL all-reduce of the flat gradient)' if train else 'replicas x%d') % world,
+                       'parallelism': ('dp%d (RCCL all-reduce of the flat gradient)' if train_mode else 'replicas x%d') % world,
                        'loss': loss_val},
             'roofline': roofline,
             'cpu_baseline': cpu_baseline,
         }
+        if not train_mode:
+            out['train'] = train_obj
+        if dry:
+            out['dry'] = True
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def roofline_pass(args, model, step, elapsed, np, torch):
+    plan = model._active
+    lib = plan.lib
+    lib.pivp_plan_set_profiling(plan.h, 1)
+    ms_tot = np.zeros(7); n_tot = np.zeros(7, dtype=np.int64); flops = np.zeros(7)
+    t_prof = 0.0
+    for _ in range(args.steps):
+        tp0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        t_prof += time.perf_counter() - tp0
+        ms = (ctypes.c_double * 7)(); n = (ctypes.c_int * 7)(); fl = (ctypes.c_double * 7)()
+        rc = lib.pivp_plan_profile_read(plan.h, ms, n, fl)
+        assert rc == 0, rc
+        ms_tot += np.array(ms[:]); n_tot += np.array(n[:]); flops += np.array(fl[:])
+    lib.pivp_plan_set_profiling(plan.h, 0)
+    total_flops = float(flops.sum())
+    total_s = float(ms_tot.sum()) * 1e-3
+    achieved = total_flops / total_s / 1e12
+    bf16 = args.precision != 'fp32'
+    # bf16x3 executes three bf16 MFMAs per algorithmic product: its ceiling in algorithmic flops is a third of the bf16 peak
+    peak = (PEAK_BF16_MFMA_TFLOPS / (3.0 if args.precision == 'bf16x3' else 1.0)) if bf16 else PEAK_FP32_MFMA_TFLOPS
+    return {
+        'bound': 'mfma',
+        'kernel': ('convlstm_bf16_kernel<NCH> (ConvLSTM 5x5 gate conv, %s, + fused gates)' %
+                   ('bf16 operands' if args.precision == 'bf16' else 'fp32 operands as 2 bf16 pieces, 3 MFMAs per product') if bf16 else
+                   'igemm_f32_kernel<WM,WN,4,true> (ConvLSTM 5x5 gate conv + fused gates)'),
+        'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+        'frac': round(achieved / peak, 4),
+        'traffic': _pmc_traffic(bf16),
+        'launches': int(n_tot.sum()), 'avg_launch_us': round(total_s / max(1, int(n_tot.sum())) * 1e6, 2),
+        'algorithmic_gflop_per_launch': round(total_flops / max(1, int(n_tot.sum())) / 1e9, 3),
+        'per_layer_tflops': {('lstm%d' % (i + 1)): round(float(flops[i] / (ms_tot[i] * 1e-3) / 1e12), 2)
+                             for i in range(7) if ms_tot[i] > 0},
+        'share_of_step_time': round(total_s / args.steps / (elapsed / args.steps), 3),
+        'ms_per_step_with_events': round(t_prof / args.steps * 1e3, 3),
+    }
+
+
+def cpu_baseline_leg(args, B, T, S, nm, np, torch, train):
+    from oracle import restatement as R
+    from oracle.torch_restatement import TorchModel
+    # The same workload as the GPU leg (batch, frame size, T).  16 threads: PyTorch-CPU on this model is fastest there on the GPU box's host
+    # (scripts/cpu_thread_scan.py: 65 / 307 / 59 frames/s at 1 / 16 / 64 threads for B = 2; 128 threads, the default, gave 23)
+    cpu_threads = min(16, torch.get_num_threads())
+    torch.set_num_threads(cpu_threads)
+    cb, ct = B, T
+    P = R.init_params(seed=1, dtype=np.float32, scale=1.0, num_masks=nm, model_type=args.model, height=S, width=S)
+    ci, ca, cs = R.synthetic_batch(cb, ct, S, S)
+    tm = TorchModel(nm, is_cdna=args.model == 'CDNA', is_stp=args.model == 'STP', is_dna=args.model == 'DNA',
+                    params=P, dtype=torch.float32)
+    tm.train = False
+    with torch.no_grad():
+        tm([ci, ca, cs], 0); tm.reset_state()      # warm-up
+        reps, c0 = 0, time.perf_counter()
+        while time.perf_counter() - c0 < args.cpu_seconds:
+            tm([ci, ca, cs], 0); tm.reset_state()
+            reps += 1
+        cel = time.perf_counter() - c0
+    if train:      # same bounded sample, but forward + autograd backward + Chainer-rule Adam
+        from oracle.torch_restatement import chainer_adam_step
+        tmt = TorchModel(nm, is_cdna=True, params=P, dtype=torch.float32, requires_grad=True)
+        Pm = {k: v.detach().numpy() for k, v in tmt.p.items()}
+        Mm = {k: np.zeros_like(v) for k, v in Pm.items()}; Vm = {k: np.zeros_like(v) for k, v in Pm.items()}
+        reps, c0 = 0, time.perf_counter()
+        while time.perf_counter() - c0 < args.cpu_seconds:
+            for v in tmt.p.values():
+                v.grad = None
+            l = tmt([ci, ca, cs], 0); l.backward(); tmt.reset_state()
+            with torch.no_grad():
+                chainer_adam_step(Pm, {k: v.grad.numpy() for k, v in tmt.p.items()}, Mm, Vm, reps + 1)
+            reps += 1
+        cel = time.perf_counter() - c0
+    return {'value': round(cb * (ct - 1) * reps / cel, 2), 'unit': 'predicted frames/s',
+            'cores': cpu_threads, 'kind': 'port',
+            'sample': '%d %s of B=%d T=%d %dx%d %s, fp32 PyTorch-CPU restatement of the reference path '
+                      '(oracle/torch_restatement.py), %.1f s' % (reps, 'train steps (fwd+bwd+Adam)' if train else 'rollouts',
+                                                                  cb, ct, S, S, args.model, cel)}
 
 
 if __name__ == '__main__':

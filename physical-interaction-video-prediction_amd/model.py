@@ -149,6 +149,10 @@ class Model(object):
         self.num_masks = num_masks
         self.use_state = use_state
         self.scheduled_sampling_k = scheduled_sampling_k
+        # scheduled_sample draws from NumPy's GLOBAL RNG in the reference (TM:94); None keeps that.  Data-parallel training gives
+        # every rank its own stream here (train.py: RandomState(seed + 1 + rank)), or all ranks would draw the same shuffle
+        # for their shards.
+        self.sampling_rng = None
         self.num_frame_before_prediction = num_frame_before_prediction
         self.prefix = prefix
         self.device = torch.device(device)
@@ -367,7 +371,7 @@ class Model(object):
             gt_ptr = None
             self._gt_mask = None
             if config.train and self.scheduled_sampling_k != -1:
-                mask = scheduled_sampling_masks(B, T, ctx, self.scheduled_sampling_k, iter_num)
+                mask = scheduled_sampling_masks(B, T, ctx, self.scheduled_sampling_k, iter_num, rng=self.sampling_rng)
                 self._gt_mask = torch.from_numpy(mask).to(self.device)
                 gt_ptr = self._gt_mask.data_ptr()
             gen = torch.empty((T - 1, B, 3, H, W), dtype=torch.float32, device=self.device)

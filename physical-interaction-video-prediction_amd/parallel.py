@@ -1,8 +1,9 @@
 """Data parallelism over the batch axis: one process per GPU, replicated parameters, one sum all-reduce of the flat
-gradient buffer per step (the reference itself is single-device).
+gradient buffer per step (the reference itself is single-device: its `optimizer.update`, TM:950, is the
+call this wraps).
 
 On MI355X the backend is "nccl" (= RCCL over xGMI); the same code runs with "gloo" on CPU tensors, which is how the
-host logic is tested without a GPU (tests/test_parallel_gloo.py)."""
+host logic -- including the overlapped, per-group path -- is tested without a GPU (tests/test_parallel_gloo.py)."""
 import torch
 import torch.distributed as dist
 
@@ -22,6 +23,7 @@ class GradAllReduce(object):
         self.rank = dist.get_rank(group)
         self.nbuckets = max(1, int(nbuckets))
         self._stream = None
+        self.issued = []          # group indices in the order their collectives were issued by the last overlapped backward
 
     def bucket_bounds(self, n):
         """Split [0, n) into nbuckets slices with 64-float aligned edges."""
@@ -54,35 +56,127 @@ class GradAllReduce(object):
         return self.allreduce_flat(model._ensure_grads())
 
     def backward_and_allreduce(self, model, force_overlap=False):
-        """model.backward() with the all-reduce of each gradient group launched on the side stream as soon as the sweep
-        has finished that group at t = 0 (every parameter is shared by all timesteps, so nothing is final earlier): the
-        heads / enc6 slice travels while lstm7 .. enc0 of the last timestep are still being differentiated.  Six
-        contiguous slices of 1-11 MB (model.grad_group_ranges()); xGMI is point-to-point, a few large messages keep
-        its links busier than many small ones."""
-        flat = model._ensure_grads()
-        if (self.world_size == 1 and not force_overlap) or not flat.is_cuda:   # force_overlap: exercise the path on one rank (tests)
-            model.backward()
-            return self.allreduce_flat(flat)
-        if self._stream is None:
-            self._stream = torch.cuda.Stream(device=flat.device)
-        ranges = model.grad_group_ranges()
-        main = torch.cuda.current_stream(flat.device)
-        works = []
+        """model.backward() with the all-reduce of each gradient group launched as soon as the sweep has finished that group
+        at t = 0 (every parameter is shared by all timesteps, so nothing is final earlier): the heads / enc6 slice travels
+        while lstm7 .. enc0 of the last timestep are still being differentiated.  Six contiguous slices of 1-11 MB
+        (model.grad_group_ranges()); xGMI is point-to-point, a few large messages keep its links busier than many small ones.
 
-        def on_group(g):
+        `model` is anything with `_ensure_grads() -> flat tensor`, `grad_group_ranges() -> [(start, end)]` and
+        `backward(on_group=callable)`; device tensors run the collectives on a side stream behind an event, host tensors
+        (gloo) issue them asynchronously from the callback.
+
+        Every rank issues the SAME sequence of collectives whatever happens locally: groups go out in ascending order (a group
+        announced out of turn first sends the ones before it), and if `backward` raises -- a launch failure, or an exception in a
+        callback -- the groups not yet sent are still sent and every collective is waited for before the exception is re-raised.
+        Peers therefore leave their collectives (with this rank's unfinished gradients: the step is void) instead of blocking
+        in them; the launcher (torch.distributed.run) then ends the job because this rank exits."""
+        flat = model._ensure_grads()
+        if self.world_size == 1 and not force_overlap:   # force_overlap: exercise the path on one rank (tests)
+            model.backward()
+            return flat
+        ranges = model.grad_group_ranges()
+        cuda = flat.is_cuda
+        if cuda:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=flat.device)
+            main = torch.cuda.current_stream(flat.device)
+        works = []
+        self.issued = issued = []
+        out_of_turn = []
+
+        def issue(g):
             a, b = ranges[g]
-            ev = torch.cuda.Event()
-            ev.record(main)                      # everything that writes slice g is already enqueued on `main`
-            self._stream.wait_event(ev)
-            with torch.cuda.stream(self._stream):
+            issued.append(g)
+            if b <= a:
+                return
+            if cuda:
+                ev = torch.cuda.Event()
+                ev.record(main)                      # everything that writes slice g is already enqueued on `main`
+                self._stream.wait_event(ev)
+                with torch.cuda.stream(self._stream):
+                    works.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            else:
                 works.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-        model.backward(on_group=on_group)
-        with torch.cuda.stream(self._stream):
-            for w in works:
-                w.wait()
-        main.wait_stream(self._stream)
+        def on_group(g):
+            if g < len(issued):
+                out_of_turn.append(g)                # announced twice or late: its collective has already gone out
+                return
+            if g > len(issued):
+                out_of_turn.append(g)
+            while len(issued) <= g:
+                issue(len(issued))
+
+        error = None
+        try:
+            model.backward(on_group=on_group)
+        except BaseException as e:                   # noqa: B902 -- re-raised below, after the collectives are matched
+            error = e
+        try:
+            while len(issued) < len(ranges):         # groups the sweep never announced (only after an error)
+                if error is None:
+                    out_of_turn.append(len(issued))
+                issue(len(issued))
+        finally:
+            if cuda:
+                with torch.cuda.stream(self._stream):
+                    for w in works:
+                        w.wait()
+                main.wait_stream(self._stream)
+            else:
+                for w in works:
+                    w.wait()
+        if error is not None:
+            raise error
+        if out_of_turn:
+            raise RuntimeError('gradient groups were announced out of order or not at all: %r (collectives were still issued '
+                               'in ascending order; this step\'s gradients are not valid)' % (out_of_turn,))
         return flat
+
+
+class HostStubModel(object):
+    """CPU stand-in for `Model` with the same training protocol (`_ensure_grads`, `grad_group_ranges`, `cleargrads`,
+    `backward(on_group)`): the gradient of group g is `value * (g + 1)` everywhere.  It lets the data-parallel host logic run
+    under gloo with no GPU: tests/test_parallel_gloo.py and `bench.py --dry`.  `fail_in_group` makes the callback of that group
+    raise, as a failing rank would; `skip_groups` leaves groups unannounced."""
+
+    def __init__(self, sizes=(1000, 300, 70, 5000, 64, 1), value=1.0, fail_in_group=None, skip_groups=()):
+        self.sizes = list(sizes)
+        self.value = float(value)
+        self.fail_in_group = fail_in_group
+        self.skip_groups = set(skip_groups)
+        self._flat_params = torch.zeros(sum(self.sizes))
+        self._flat = torch.zeros(sum(self.sizes))
+        self.announced = []
+
+    def _ensure_grads(self):
+        return self._flat
+
+    def cleargrads(self):
+        self._flat.zero_()
+
+    def grad_group_ranges(self):
+        out, o = [], 0
+        for n in self.sizes:
+            out.append((o, o + n))
+            o += n
+        return out
+
+    def backward(self, on_group=None):
+        errors = []
+        for g, (a, b) in enumerate(self.grad_group_ranges()):
+            self._flat[a:b] += self.value * (g + 1)
+            if on_group is None or g in self.skip_groups:
+                continue
+            self.announced.append(g)
+            try:                                     # like Model.backward: the sweep continues, the first error is raised afterwards
+                if g == self.fail_in_group:
+                    raise RuntimeError('injected failure in group %d' % g)
+                on_group(g)
+            except BaseException as e:               # noqa: B902
+                errors.append(e)
+        if errors:
+            raise errors[0]
 
 
 def shard_batch(arrays, rank, world_size):

@@ -86,6 +86,8 @@ def main(argv=None):
     if per_rank * world != args.batch_size:
         raise SystemExit('--batch_size must be divisible by the number of ranks')
     np.random.seed(0 if world > 1 else None)      # identical shuffles on every rank; each takes its shard of the batch
+    if world > 1:                                 # ... but its own scheduled-sampling draws (rank-offset stream)
+        model.sampling_rng = np.random.RandomState(1 + rank)
     train_iter = ds.SerialIterator(ds.group_examples(tr_i, tr_a, tr_s), args.batch_size, repeat=True, shuffle=True)
     valid_iter = ds.SerialIterator(ds.group_examples(va_i, va_a, va_s), args.batch_size, repeat=False, shuffle=True)
     save_dir = os.path.join(args.output_dir, '%s-%s-%d' % (time.strftime('%Y%m%d-%H%M%S'), args.model_type, args.batch_size))

@@ -27,20 +27,27 @@ def _autograd(P, imgs, acts, stas, k=-1, it=0, seed=None, **kw):
 
 
 def _check_grads(got, ref, tol, relu_flips=2):
-    """max |got - ref| / max |ref| < tol per tensor.  The per-element LayerNorm parameters behind a ReLU (norm_enc0,
-    norm_enc6: 32k / 262k elements, gradient = sum over the BATCH of dy * [y > 0]) get an allowance of 2 elements: an
-    activation within fp32 rounding of zero has its mask decided differently in fp32 and in the float64 oracle, which
-    moves exactly that element's gradient by one sample's dy (scripts/debug_dna_grad.py: 1 element of 262144 at
-    7e-3, every other one at 3e-6)."""
+    """Per tensor, relative to max |ref|: the 99th percentile of the element errors < tol, the relative L2 error < tol, and
+    no element beyond 10 x tol.  Why not simply max < tol: an activation within fp32 rounding of zero has its ReLU mask decided
+    differently in fp32 and in the float64 oracle, which moves the gradient of everything in that unit's footprint by one sample's
+    dy -- e.g. one flipped enc5 unit shows up at ONE pixel position in all 64 channels of hidden6's gamma/beta (7e-3 there, 5e-7
+    median: scripts/debug_grad_errors_stp.py), one flipped enc6 unit in one element of norm_enc6 (scripts/debug_dna_grad.py).
+    Which unit flips changes with any rounding change in the forward pass; a wrong kernel moves the bulk, which the percentile and
+    the L2 norm see.  The per-element LayerNorm parameters directly behind a ReLU (norm_enc0, norm_enc6) additionally drop their
+    `relu_flips` largest elements from the 10 x tol bound."""
     worst = []
     for kname, g in ref.items():
         scale = np.abs(g).max() + 1e-12
-        e = np.abs(got[kname].astype(np.float64) - g).ravel() / scale
+        d = got[kname].astype(np.float64) - g
+        e = np.sort(np.abs(d).ravel() / scale)
         if g.size >= 32768 and '/norm/' in kname:
-            e = np.sort(e)[:-relu_flips]
-        err = e.max()
-        worst.append((err, kname))
-        assert err < tol, '%s: relative gradient error %.3e (scale %.3e)' % (kname, err, scale)
+            e = e[:-relu_flips]
+        p99 = e[int(0.99 * (e.size - 1))]
+        rel_l2 = np.linalg.norm(d) / (np.linalg.norm(g) + 1e-30)
+        worst.append((max(p99, rel_l2), kname))
+        assert p99 < tol, '%s: 99th-percentile relative gradient error %.3e (scale %.3e)' % (kname, p99, scale)
+        assert rel_l2 < tol, '%s: relative L2 gradient error %.3e' % (kname, rel_l2)
+        assert e[-1] < 10 * tol, '%s: largest relative gradient error %.3e (scale %.3e)' % (kname, e[-1], scale)
     return max(worst)
 
 

@@ -76,3 +76,91 @@ def test_shard_batch_rejects_ragged():
     import pivp_amd
     with pytest.raises(ValueError):
         pivp_amd.shard_batch([np.zeros((3, 7, 2))], 0, 2)
+
+
+# ---- the overlapped per-group path (GradAllReduce.backward_and_allreduce), two ranks, gloo ------------------------------------
+
+def _overlap_worker(rank, world, port, q, scenario):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import pivp_amd
+        dp = pivp_amd.GradAllReduce()
+        kw = {}
+        if scenario == 'callback_raises' and rank == 1:
+            kw['fail_in_group'] = 2                      # rank 1's callback for group 2 raises; rank 0 is healthy
+        if scenario == 'group_skipped' and rank == 1:
+            kw['skip_groups'] = (3,)                     # rank 1 never announces group 3
+        model = pivp_amd.HostStubModel(value=float(rank + 1), **kw)
+        model.cleargrads()
+        err = None
+        try:
+            dp.backward_and_allreduce(model)
+        except Exception as e:                           # the failing rank re-raises AFTER matching every collective
+            err = '%s: %s' % (type(e).__name__, e)
+        flat = model._ensure_grads().clone()
+        # a collective issued after the step proves that no rank is still stuck inside the step's collectives
+        after = torch.tensor([float(rank + 1)])
+        dist.all_reduce(after)
+        q.put((rank, err, list(dp.issued), list(model.announced), flat.numpy(), float(after.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_overlap(scenario):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q, scenario)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def _expected_sum(world=2):
+    sys.path.insert(0, ROOT)
+    import pivp_amd
+    m = pivp_amd.HostStubModel()
+    out = np.zeros(sum(m.sizes), dtype=np.float32)
+    for g, (a, b) in enumerate(m.grad_group_ranges()):
+        out[a:b] = (g + 1) * sum(r + 1 for r in range(world))
+    return out
+
+
+def test_overlapped_allreduce_two_ranks():
+    """Six gradient groups announced from inside backward(): summed over both ranks, same collective order on both."""
+    res = _run_overlap('ok')
+    expect = _expected_sum()
+    for rank, err, issued, announced, flat, after in res:
+        assert err is None
+        assert issued == [0, 1, 2, 3, 4, 5] and announced == [0, 1, 2, 3, 4, 5]
+        assert np.array_equal(flat, expect)
+        assert after == 3.0
+
+
+def test_overlapped_allreduce_survives_a_failing_callback():
+    """One rank's callback raises in group 2: that rank still issues all six collectives in order and re-raises afterwards; the
+    healthy rank returns from every collective (nobody blocks), and a later collective still works on both."""
+    res = _run_overlap('callback_raises')
+    (r0, err0, issued0, _, flat0, after0), (r1, err1, issued1, _, _, after1) = res
+    assert err0 is None and issued0 == [0, 1, 2, 3, 4, 5]
+    assert err1 is not None and 'injected failure in group 2' in err1
+    assert issued1 == [0, 1, 2, 3, 4, 5]                 # same sequence as the healthy rank
+    assert after0 == 3.0 and after1 == 3.0
+    assert np.array_equal(flat0, _expected_sum())        # the stub's gradients were complete when they were sent
+
+
+def test_overlapped_allreduce_flags_a_missing_group():
+    res = _run_overlap('group_skipped')
+    (r0, err0, issued0, _, _, after0), (r1, err1, issued1, _, _, after1) = res
+    assert err0 is None and issued0 == [0, 1, 2, 3, 4, 5]
+    assert issued1 == [0, 1, 2, 3, 4, 5]
+    assert err1 is not None and 'out of order' in err1
+    assert after0 == 3.0 and after1 == 3.0
