@@ -42,14 +42,14 @@ def run(model_type, num_masks, batch, seq_len, tap_steps):
 PIXEL_STRIDE = 37
 
 
-def run_full_batch(model_type, num_masks, batch, seq_len, smooth=False, fp32_error=False):
+def run_full_batch(model_type, num_masks, batch, seq_len, smooth=False, fp32_error=False, size=64):
     """Full-size batch (BASELINE.json config 2 / config 4: B = 32): the frames are 14 MB, so the fixture keeps every
     PIXEL_STRIDE-th pixel (all three colours, flat (t, b, y, x) order) plus loss, PSNR and all predicted states.
     `fp32_error`: also run the oracle in float32 (the reference's own arithmetic, NumPy/BLAS) and keep ITS per-(step, sample)
     max per-pixel L2 from the float64 result: on STP with white-noise frames that alone exceeds 1e-4, so the HIP path is held
     to "no less accurate than plain float32" there (tests/test_gpu_model.py)."""
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, num_masks=num_masks, model_type=model_type)
-    imgs, acts, stas = (R.smooth_batch if smooth else R.synthetic_batch)(batch, seq_len, seed=0)
+    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, num_masks=num_masks, model_type=model_type, height=size, width=size)
+    imgs, acts, stas = (R.smooth_batch if smooth else R.synthetic_batch)(batch, seq_len, size, size, seed=0)
     kw = dict(is_cdna=model_type == 'CDNA', is_stp=model_type == 'STP', is_dna=model_type == 'DNA')
     m = R.Model(num_masks, params=P, dtype=np.float64, prefix='golden', **kw)
     m.train = False
@@ -71,19 +71,20 @@ def run_full_batch(model_type, num_masks, batch, seq_len, smooth=False, fp32_err
     return out
 
 
-FULL_BATCH = {   # name: (model_type, smooth, fp32_error)
-    'cdna_b32_t10': ('CDNA', False, False),
-    'stp_b32_t10': ('STP', False, True),
-    'stp_b32_t10_smooth': ('STP', True, True),
+FULL_BATCH = {   # name: (model_type, batch, seq_len, frame size, smooth, fp32_error)
+    'cdna_b32_t10': ('CDNA', 32, 10, 64, False, False),            # BASELINE.json config 2
+    'stp_b32_t10': ('STP', 32, 10, 64, False, True),               # config 4, white-noise frames
+    'stp_b32_t10_smooth': ('STP', 32, 10, 64, True, True),         # config 4, video-like frames
+    'cdna_128_b2_t20': ('CDNA', 2, 20, 128, False, True),          # config 5's geometry (128x128, 20 frames) at B = 2
 }
 
 
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'b32':                 # 1-3 min of NumPy each
-        for name, (mt, smooth, f32e) in FULL_BATCH.items():
+        for name, (mt, nb, nt, size, smooth, f32e) in FULL_BATCH.items():
             if len(sys.argv) > 2 and sys.argv[2] != name:
                 continue
-            np.savez_compressed(os.path.join(OUT, name + '.npz'), **run_full_batch(mt, 10, 32, 10, smooth, f32e))
+            np.savez_compressed(os.path.join(OUT, name + '.npz'), **run_full_batch(mt, 10, nb, nt, smooth, f32e, size))
             print(name, os.path.getsize(os.path.join(OUT, name + '.npz')))
         sys.exit(0)
     np.savez_compressed(os.path.join(OUT, 'cdna_b2_t10.npz'), **run('CDNA', 10, 2, 10, (0, 8)))
