@@ -136,12 +136,28 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
 
 // ConvLSTM cell backward (TM:262-272): gate math, data gradient d[x,h_prev], weight and bias gradients.
 //   d_in [M][cx+C] receives d x (first cx channels) and d h_{t-1} (last C); dc is updated in place to d c_{t-1}.
+static int fork_begin(const SideFork* f, hipStream_t s, hipStream_t* sw) {
+    *sw = s;
+    if (!f || !f->side) return PIVP_OK;
+    if (hipEventRecord(f->ready, s) != hipSuccess || hipStreamWaitEvent(f->side, f->ready, 0) != hipSuccess) return PIVP_ERR_LAUNCH;
+    *sw = f->side;
+    return PIVP_OK;
+}
+static int fork_end(const SideFork* f) {
+    if (!f || !f->side) return PIVP_OK;
+    return hipEventRecord(f->done, f->side) == hipSuccess ? PIVP_OK : PIVP_ERR_LAUNCH;
+}
+
 int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
                           const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                           float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
-                          int B, int H, int W, hipStream_t s, int wt_ready, unsigned short* wt_bf16, int bf16_planes) {
+                          int B, int H, int W, hipStream_t s, int wt_ready, unsigned short* wt_bf16, int bf16_planes, const SideFork* fork) {
     const int M = B * H * W, cin = cx + C, N = 4 * C;
     int rc = lstm_gates_bwd(gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc, dc_valid, dG, M, C, s);
+    if (rc != PIVP_OK) return rc;
+    // dG is final: the weight gradient can start (on the side stream when forked), next to this layer's own data gradient
+    hipStream_t sw;
+    rc = fork_begin(fork, s, &sw);
     if (rc != PIVP_OK) return rc;
     if (!wt_ready) {
         rc = repack_transpose(w, wt, 25, cin, N, 1, s);                   // [25][cin/32][4C][32] -> flipped [25][4C/32][cin][32]
@@ -159,9 +175,10 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
     if (rc != PIVP_OK) return rc;
     int bias_done = 0;   // the 5x5 weight-gradient kernel sums dG's columns on the side
     // (the weight gradient has a bf16 form but no split form: in the split mode it stays the fp32 kernel)
-    rc = run_wgrad(0, x, cx, ldx, h_prev, C, C, cin, dG, N, N, dW, B, H, W, H, W, 5, 2, 1, s, db, &bias_done, wt_bf16 != nullptr && bf16_planes == 1);
+    rc = run_wgrad(0, x, cx, ldx, h_prev, C, C, cin, dG, N, N, dW, B, H, W, H, W, 5, 2, 1, sw, db, &bias_done, wt_bf16 != nullptr && bf16_planes == 1);
     if (rc != PIVP_OK) return rc;
-    return bias_done ? PIVP_OK : bias_grad(dG, N, N, M, db, s);
+    if (!bias_done) { rc = bias_grad(dG, N, N, M, db, sw); if (rc != PIVP_OK) return rc; }
+    return fork_end(fork);
 }
 
 int run_layernorm(const float* x, const float* g, const float* b, float* out, float* partials, int B, int n, int C,
@@ -193,10 +210,13 @@ int run_select_frames(const float* gt, const float* gen, const unsigned char* ta
 // conv3x3s2 (mode 0) / deconv3x3s2 (mode 1) backward.  dy is masked in place by (y > 0) when y != null (fused ReLU).
 int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w, float* dy, int cout, int ldy, const float* y, int ldyy,
                       float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, hipStream_t s,
-                      int wt_ready) {
+                      int wt_ready, const SideFork* fork) {
     const int Hout = mode ? 2 * Hin : Hin / 2, Wout = mode ? 2 * Win : Win / 2;
     int rc = PIVP_OK;
     if (y) { rc = relu_mask(dy, ldy, y, ldyy, cout, (long)B * Hout * Wout, s); if (rc != PIVP_OK) return rc; }
+    hipStream_t sw;
+    rc = fork_begin(fork, s, &sw);      // dy is final here
+    if (rc != PIVP_OK) return rc;
     if (dx) {
         if (!wt_ready) {
             rc = repack_transpose(w, wt, 9, cin, cout, 0, s);
@@ -206,9 +226,11 @@ int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w
                   : run_deconv3x3s2(dy, cout, ldy, wt, nullptr, dx, cin, lddx, 0, B, Hout, Wout, s, accum_dx);
         if (rc != PIVP_OK) return rc;
     }
-    rc = run_wgrad(mode, x, cin, ldx, nullptr, 0, 0, cin, dy, ldy, cout, dW, B, Hin, Win, Hout, Wout, 3, 1, 2, s);
+    rc = run_wgrad(mode, x, cin, ldx, nullptr, 0, 0, cin, dy, ldy, cout, dW, B, Hin, Win, Hout, Wout, 3, 1, 2, sw);
     if (rc != PIVP_OK) return rc;
-    return bias_grad(dy, ldy, cout, B * Hout * Wout, db, s);
+    rc = bias_grad(dy, ldy, cout, B * Hout * Wout, db, sw);
+    if (rc != PIVP_OK) return rc;
+    return fork_end(fork);
 }
 
 }  // namespace pivp

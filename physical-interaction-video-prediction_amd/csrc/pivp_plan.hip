@@ -1,5 +1,6 @@
 // The plan: Model.__init__ / reset_state / __call__ of the reference (TM:484-764) and the backward pass that
 // Chainer's autograd performs under optimizer.update (TM:950), sequenced in native code on one HIP stream.
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -52,7 +53,7 @@ struct Slab {
 struct Grads {   // gradient workspace (single copy, reused by every timestep of the backward sweep)
     size_t cat7, n2, cat6, n4, e2, n5, e6, e6raw, e0raw;
     size_t hln[7], din[7][2], dc[7];
-    size_t dG, go[2], dmk, dz, dkpart, dv, dstate, lnpart;
+    size_t dG[7], go[2], dmk, dz, dkpart, dv, dstate, lnpart;   // dG: gate pre-activation gradients, one buffer per ConvLSTM (its weight gradient reads it from the side stream)
     size_t wt_lstm[7], wt_enc[7];   // re-packed (transposed) weights for the data gradients, rebuilt once per backward
     size_t wtb_lstm[7];             // ... and their bf16 packs (bf16 precision mode)
 };
@@ -86,7 +87,18 @@ struct pivp_plan {
     std::vector<hipEvent_t> prof_ev;
     std::vector<int> prof_layer;
     size_t prof_used = 0;
-    ~pivp_plan() { for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e); }
+    // Weight gradients run on a second, lower-priority stream next to the backward sweep's critical path (SideFork, pivp_host.h):
+    // slots 0..6 = the ConvLSTMs, 7..11 = enc6, enc5, enc4, enc2, enc1.  Created on first use; PIVP_SIDE_STREAM=0 (read when
+    // the plan is created) keeps everything on the caller's stream.
+    static constexpr int NSLOT = 12;
+    bool use_side = true;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_ready[NSLOT] = {}, ev_done[NSLOT] = {};
+    ~pivp_plan() {
+        for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
+        for (int i = 0; i < NSLOT; ++i) { if (ev_ready[i]) (void)hipEventDestroy(ev_ready[i]); if (ev_done[i]) (void)hipEventDestroy(ev_done[i]); }
+        if (side) (void)hipStreamDestroy(side);
+    }
 };
 
 static const float* P(const pivp_plan* p, int idx) { return p->params[idx].ptr; }
@@ -108,6 +120,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
     p->NE = cfg->model_type == PIVP_MODEL_DNA ? 25 : 3;
     p->K5 = 128 * p->H8 * p->W8;
     p->ws = nullptr; p->ws_floats = 0; p->last_steps = 0; p->last_sched = false;
+    { const char* e = getenv("PIVP_SIDE_STREAM"); p->use_side = !(e && e[0] == '0'); }
 
     auto add = [&](const std::string& name, long long n) { p->params.push_back({name, n, nullptr, nullptr, grad_group_of(name)}); return (int)p->params.size() - 1; };
     const int cin3 = 64 + (cfg->use_state ? 10 : 0);
@@ -183,17 +196,15 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
         g.cat7 = carve(B * HW2 * 64); g.n2 = carve(B * HW2 * 32); g.cat6 = carve(B * HW4 * 96); g.n4 = carve(B * HW4 * 64);
         g.e2 = carve(B * HW8 * 64); g.n5 = carve(B * HW8 * 128); g.e6 = carve(B * HW * 64); g.e6raw = carve(B * HW * 64);
         g.e0raw = carve(B * HW2 * 32);
-        size_t maxdG = 0;
         for (int i = 0; i < 7; ++i) {
             const size_t M = hsz[i] / kLstm[i].C * B;
             g.hln[i] = carve(B * hsz[i]); g.dc[i] = carve(B * hsz[i]);
             g.din[i][0] = carve(M * (kLstm[i].cx + kLstm[i].C)); g.din[i][1] = carve(M * (kLstm[i].cx + kLstm[i].C));
-            if (M * 4 * kLstm[i].C > maxdG) maxdG = M * 4 * kLstm[i].C;
+            g.dG[i] = carve(M * 4 * kLstm[i].C);
             g.wt_lstm[i] = carve((size_t)25 * (kLstm[i].cx + kLstm[i].C) * 4 * kLstm[i].C);
             g.wtb_lstm[i] = carve(lstm_bf16_weight_elems(4 * kLstm[i].C, conv5x5_bf16_rows(kLstm[i].cx + kLstm[i].C)));   // two planes
             g.wt_enc[i] = (i == 0 || i == 3) ? 0 : carve((size_t)encw[i]);
         }
-        g.dG = carve(maxdG);
         g.go[0] = carve((size_t)B * 3 * HW); g.go[1] = carve((size_t)B * 3 * HW);
         g.dmk = carve((size_t)B * p->NP * HW); g.dz = carve((size_t)B * p->NE * HW);
         g.dkpart = carve((size_t)B * composite_bwd_tiles(H, W) * 256); g.dv = carve((size_t)B * 256);
@@ -274,6 +285,18 @@ extern "C" int pivp_reset_state(pivp_plan_t* plan, void* stream) {
 }
 
 #define RC(call) do { int rc_ = (call); if (rc_ != PIVP_OK) return rc_; } while (0)
+
+// the plan's second stream (lowest priority: the critical path wins the CUs it asks for) and its fork / join events
+static int ensure_side(pivp_plan* plan) {
+    if (!plan->use_side || plan->side) return PIVP_OK;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    if (hipStreamCreateWithPriority(&plan->side, hipStreamNonBlocking, least) != hipSuccess) { plan->side = nullptr; return PIVP_ERR_LAUNCH; }
+    for (int i = 0; i < pivp_plan::NSLOT; ++i)
+        if (hipEventCreateWithFlags(&plan->ev_ready[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&plan->ev_done[i], hipEventDisableTiming) != hipSuccess) return PIVP_ERR_LAUNCH;
+    return PIVP_OK;
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // forward, one timestep (TM:659-731)
@@ -358,6 +381,8 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
         RC(heads_1x1(ws + S.e6, P(p, p->i_masks_w), P(p, p->i_masks_b), P(p, p->i_enc7_w), P(p, p->i_enc7_b),
                      ws + S.logits, ws + S.enc7, ws + S.layer0, B, H * W, p->NP, p->NE, c.model_type, s));
     }
+    // (The motion head's generator needs hidden5 only and could run on the side stream under lstm6 .. heads: measured, the rollout got
+    // SLOWER, 8.68 -> 8.79 ms: the co-running kernels cost the ConvLSTMs more than the 16 us they hide.  It stays in line.)
     const float* aux = nullptr;
     if (c.model_type == PIVP_MODEL_CDNA) {
         RC(cdna_kernels(ws + S.n5, P(p, p->i_head_w), P(p, p->i_head_b), ws + p->o_linpart, ws + S.kerns, B, p->K5, c.num_masks, s,
@@ -444,17 +469,34 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         return ln_backward(dy, lddy, y, ldy, x, ws + S.lnstat + (size_t)j * B * 2, P(p, p->i_ln_g[j]), lnpart, dx,
                            G(p, p->i_ln_g[j]), G(p, p->i_ln_b[j]), B, n, C, relu, s);
     };
+    // weight-gradient slots (pivp_plan::NSLOT): join = the main stream waits for the slot's last weight-gradient kernels
+    auto fork_of = [&](int slot, SideFork& f) -> const SideFork* {
+        if (!p->side) return nullptr;
+        f.side = p->side; f.ready = p->ev_ready[slot]; f.done = p->ev_done[slot];
+        return &f;
+    };
+    auto join = [&](int slot) -> int {
+        if (!p->side) return PIVP_OK;
+        return hipStreamWaitEvent(s, p->ev_done[slot], 0) == hipSuccess ? PIVP_OK : PIVP_ERR_LAUNCH;   // never recorded: returns at once
+    };
     auto lstmb = [&](int i, const float* x, int ldx, int hh, int wwid) {
         const LstmSpec& L = kLstm[i];
         const int cin = L.cx + L.C;
+        SideFork f;
+        const SideFork* fk = fork_of(i, f);
+        int rcj = join(i);        // the previous timestep's weight gradient of this layer still reads dG[i]
+        if (rcj != PIVP_OK) return rcj;
         return run_convlstm_backward(x, L.cx, ldx, Sp ? ws + Sp->h[i] : nullptr, L.C, P(p, p->i_lstm_w[i]), ws + S.gates[i],
                                      Sp ? ws + Sp->c[i] : ws + p->o_zero, ws + S.c[i], ws + g.hln[i], L.C,
                                      last_step ? nullptr : ws + g.din[i][npar] + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
-                                     ws + g.dG, ws + g.wt_lstm[i], ws + g.din[i][par], G(p, p->i_lstm_w[i]), G(p, p->i_lstm_b[i]), B, hh, wwid,
-                                     s, 1, p->lstm_bf16 ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->lstm_planes);
+                                     ws + g.dG[i], ws + g.wt_lstm[i], ws + g.din[i][par], G(p, p->i_lstm_w[i]), G(p, p->i_lstm_b[i]), B, hh, wwid,
+                                     s, 1, p->lstm_bf16 ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->lstm_planes, fk);
     };
     const long px2 = (long)B * p->H2 * p->W2, px4 = (long)B * p->H4 * p->W4, px8 = (long)B * p->H8 * p->W8;
 
+    // the enc convs' weight gradients of the previous (later) timestep read dY buffers that this step is about to rewrite
+    for (int slot = 7; slot < pivp_plan::NSLOT; ++slot) RC(join(slot));
+    SideFork fe;
     // ---- heads (TM:711-728) ----
     if (has_go) {
         if (c.model_type == PIVP_MODEL_CDNA)
@@ -480,29 +522,36 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         // group 6 (TM:601), reversed: norm_enc6 (+relu) <- enc6 deconv <- [hidden7 | enc0]
         RC(lnb(8, ws + g.e6, 64, ws + S.e6, 64, ws + S.e6raw, ws + g.e6raw, 64 * HW, 64, 1));
         RC(run_conv_backward(1, ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), ws + g.e6raw, 64, 64, nullptr, 0, ws + g.wt_enc[6], ws + g.cat7, 64, 0,
-                             G(p, p->i_enc_w[6]), G(p, p->i_enc_b[6]), B, p->H2, p->W2, s, 1));
+                             G(p, p->i_enc_w[6]), G(p, p->i_enc_b[6]), B, p->H2, p->W2, s, 1, fork_of(7, fe)));
     } else {
         // no gradient reaches this step's frame: only the recurrent paths are live
         if (hipMemsetAsync(ws + g.cat7, 0, (size_t)px2 * 64 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
         if (hipMemsetAsync(ws + g.n5, 0, (size_t)px8 * 128 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     }
-    auto done = [&](int group) { if (t == 0 && p->grad_cb) p->grad_cb(p->grad_cb_user, group); };   // t = 0: the sweep's final timestep
-    done(0);
+    // t = 0 is the sweep's final timestep: a gradient group is final once the side stream's weight gradients of its layers are in too
+    auto done = [&](int group) -> int {
+        if (t != 0 || !p->grad_cb) return PIVP_OK;
+        static const int slots[6][3] = {{7, -1, -1}, {6, -1, -1}, {8, 5, -1}, {9, 4, -1}, {10, 3, 2}, {11, 1, 0}};
+        for (int k = 0; k < 3; ++k) if (slots[group][k] >= 0) RC(join(slots[group][k]));
+        p->grad_cb(p->grad_cb_user, group);
+        return PIVP_OK;
+    };
+    RC(done(0));
     RC(lnb(7, ws + g.cat7, 64, nullptr, 0, ws + S.h[6], ws + g.hln[6], n2, 32, 0));
     RC(lstmb(6, ws + S.e5, 96, p->H2, p->W2));
-    done(1);
+    RC(done(1));
     // group 5 (TM:600): d e5 = x-part of lstm7's d_in (ReLU fused in enc5) <- enc5 deconv <- [hidden6 | enc1]
     RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ws + S.e5, 96, ws + g.wt_enc[5], ws + g.cat6, 96, 0,
-                         G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1));
+                         G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1, fork_of(8, fe)));
     RC(lnb(6, ws + g.cat6, 96, nullptr, 0, ws + S.h[5], ws + g.hln[5], n4, 64, 0));
     RC(lstmb(5, ws + S.e4, 128, p->H4, p->W4));
-    done(2);
+    RC(done(2));
     // group 4 (TM:599): d e4 = x-part of lstm6's d_in <- enc4 deconv <- hidden5 (also read by the CDNA kernel generator)
     RC(run_conv_backward(1, ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), ws + g.din[5][par], 128, 192, ws + S.e4, 128, ws + g.wt_enc[4], ws + g.n5, 128, 1,
-                         G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s, 1));
+                         G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s, 1, fork_of(9, fe)));
     RC(lnb(5, ws + g.n5, 128, nullptr, 0, ws + S.h[4], ws + g.hln[4], n8, 128, 0));
     RC(lstmb(4, ws + S.e3, 64, p->H8, p->W8));
-    done(3);
+    RC(done(3));
     // group 3 (TM:598) + state predictor (TM:730): d e3 = x-part of lstm5's d_in (ld 192)
     RC(enc3_state_bwd(ws + S.e2, ws + S.e3, ws + g.din[4][par], 192, action, state_prev, P(p, p->i_enc_w[3]), P(p, p->i_cs_w),
                       ws + g.dstate + (size_t)t * B * 5, ws + g.e2, G(p, p->i_enc_w[3]), G(p, p->i_enc_b[3]), G(p, p->i_cs_w),
@@ -510,16 +559,16 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                       B, p->H8 * p->W8, c.use_state, s));
     // group 2 (TM:597): enc2 conv (ReLU) <- hidden4 <- lstm4 <- hidden3 <- lstm3 <- enc1
     RC(run_conv_backward(0, ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), ws + g.e2, 64, 64, ws + S.e2, 64, ws + g.wt_enc[2], ws + g.n4, 64, 0,
-                         G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s, 1));
+                         G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s, 1, fork_of(10, fe)));
     RC(lnb(4, ws + g.n4, 64, nullptr, 0, ws + S.h[3], ws + g.hln[3], n4, 64, 0));
     RC(lstmb(3, ws + S.n3, 64, p->H4, p->W4));
     RC(lnb(3, ws + g.din[3][par], 128, nullptr, 0, ws + S.h[2], ws + g.hln[2], n4, 64, 0));
     RC(lstmb(2, ws + S.cat6 + 64, 96, p->H4, p->W4));
-    done(4);
+    RC(done(4));
     RC(add_strided(ws + g.cat6 + 64, 96, ws + g.din[2][par], 96, 32, px4, s));          // d enc1: from enc5's concat + from lstm3
     // group 1 (TM:596): enc1 conv (ReLU) <- hidden2 <- lstm2 <- hidden1 <- lstm1 <- enc0
     RC(run_conv_backward(0, ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), ws + g.cat6 + 64, 32, 96, ws + S.cat6 + 64, 96, ws + g.wt_enc[1], ws + g.n2, 32, 0,
-                         G(p, p->i_enc_w[1]), G(p, p->i_enc_b[1]), B, p->H2, p->W2, s, 1));
+                         G(p, p->i_enc_w[1]), G(p, p->i_enc_b[1]), B, p->H2, p->W2, s, 1, fork_of(11, fe)));
     RC(lnb(2, ws + g.n2, 32, nullptr, 0, ws + S.h[1], ws + g.hln[1], n2, 32, 0));
     RC(lstmb(1, ws + S.n1, 32, p->H2, p->W2));
     RC(lnb(1, ws + g.din[1][par], 64, nullptr, 0, ws + S.h[0], ws + g.hln[0], n2, 32, 0));
@@ -529,7 +578,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(lnb(0, ws + g.cat7 + 32, 64, ws + S.cat7 + 32, 64, ws + S.e0raw, ws + g.e0raw, n2, 32, 1));
     RC(enc0_bwd(prev, P(p, p->i_enc_w[0]), ws + g.e0raw, G(p, p->i_enc_w[0]), G(p, p->i_enc_b[0]), prev_has_grad ? go_prev : nullptr, 1,
                 B, H, W, s));
-    done(5);
+    RC(done(5));
     return PIVP_OK;
 }
 
@@ -547,6 +596,7 @@ extern "C" int pivp_rollout_backward(pivp_plan_t* plan, const float* images, con
     const Grads& g = plan->g;
     const float fscale = 2.0f / ((float)fr * (float)(T - ctx));              // d/d gen of mean-squared error / (T - ctx)
     const float sscale = 2.0f * 1e-4f / ((float)(B * 5) * (float)(T - ctx));
+    RC(ensure_side(plan));
     // d loss / d gen_states[t] for every t (zero before ctx-1), later accumulated with the state recurrence
     if (hipMemsetAsync(ws + g.dstate, 0, (size_t)T * B * 5 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     for (int t = ctx - 1; t < T - 1; ++t)
@@ -583,6 +633,9 @@ extern "C" int pivp_rollout_backward(pivp_plan_t* plan, const float* images, con
         RC(backward_step(plan, t, prev, prev_has_grad && has_go, actions + (size_t)t * B * 5, st_prev, has_go, go, go_prev, last, s));
         has_go = next_loss || (prev_has_grad && has_go);
     }
+    if (plan->side)     // whatever the caller enqueues next on its stream (the all-reduce, Adam) sees every weight gradient
+        for (int i = 0; i < pivp_plan::NSLOT; ++i)
+            if (hipStreamWaitEvent(s, plan->ev_done[i], 0) != hipSuccess) return PIVP_ERR_LAUNCH;
     return PIVP_OK;
 }
 
