@@ -49,7 +49,9 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
     const int ky = tap / d.ksize, kx = tap - ky * d.ksize;
     const int ci0 = cb * WG_CI, n0 = nb * WG_N;
     const int nsplit = gridDim.y, split = blockIdx.y;
-    const int nchunks_total = (d.M + WG_PIX - 1) / WG_PIX;
+    const int cpt = (d.M + WG_PIX - 1) / WG_PIX;          // chunks per timestep
+    const int tcount = d.tcount > 1 ? d.tcount : 1;
+    const int nchunks_total = cpt * tcount;
     const int c_begin = (int)((long)nchunks_total * split / nsplit), c_end = (int)((long)nchunks_total * (split + 1) / nsplit);
     const int HWg = d.Hg * d.Wg;
     // offsets of the two operands relative to the anchor
@@ -57,9 +59,6 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
     const int bdy = d.deconv ? ky - 1 : 0, bdx = d.deconv ? kx - 1 : 0;                   // dY side (after anchor*sb)
     const int sa = d.deconv ? 1 : d.stride, sb = d.deconv ? 2 : 1;
     constexpr unsigned OOB = 0xC0000000u;
-    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x0), 0, d.bytes0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.c1 ? d.x1 : d.x0), 0, d.c1 ? d.bytes1 : d.bytes0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy), 0, d.bytesy, 0x00020000);
 
     // staging: X tile 32 pix x 64 ci = 512 float4 (2 per thread), dY tile 32 pix x 128 n = 1024 float4 (4 per thread)
     const int xr = tid >> 4, xc = (tid & 15) * 4;        // rows xr, xr+16
@@ -85,6 +84,16 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
     auto issue = [&](auto SET, int chunk) {
         f32x4 (&rx)[2] = rxs[decltype(SET)::value];
         f32x4 (&rY)[NYL] = rYs[decltype(SET)::value];
+        // (timestep of the batch, chunk inside it): block-uniform; that timestep's descriptors are rebuilt here (scalar work)
+        const int tj = __builtin_amdgcn_readfirstlane(tcount > 1 ? chunk / cpt : 0);
+        chunk -= tj * cpt;
+        const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(d.x0) + (long long)tj * d.ts_x0), 0, d.bytes0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(d.c1 ? d.x1 : d.x0) + (long long)tj * (d.c1 ? d.ts_x1 : d.ts_x0)), 0,
+            d.c1 ? d.bytes1 : d.bytes0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(d.dy) + (long long)tj * d.ts_dy), 0, d.bytesy, 0x00020000);
         const int m0 = __builtin_amdgcn_readfirstlane(chunk * WG_PIX);
         const int b0 = m0 / HWg, rem0 = m0 - b0 * HWg, ay0 = rem0 / d.Wg, ax0 = rem0 - ay0 * d.Wg;   // wave-uniform
 #pragma unroll
@@ -210,14 +219,16 @@ __global__ __launch_bounds__(256, 1) void wgrad5x5_kernel(const WgradDesc d) {
     const int ky = bid;                          // 0..4
     const int ci0 = cb * 32, n0 = nb * 32 * NTW;
     const int HWg = d.Hg * d.Wg, Wd = d.Wg, Hd = d.Hg;
-    const int nchunks_total = d.M / 32;
+    const int cpt = d.M / 32;                     // chunks per timestep
+    const int tcount = d.tcount > 1 ? d.tcount : 1;
+    const int nchunks_total = cpt * tcount;
     const int nsplit = gridDim.y, split = blockIdx.y;
     const int c_begin = (int)((long)nchunks_total * split / nsplit), c_end = (int)((long)nchunks_total * (split + 1) / nsplit);
     constexpr unsigned OOB = 0xC0000000u;
     const bool from0 = ci0 < d.c0;               // a 32-channel block never straddles the two sources (c0 % 32 == 0)
-    const __amdgpu_buffer_rsrc_t rx = from0 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x0), 0, d.bytes0, 0x00020000)
-                                            : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x1), 0, d.bytes1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy), 0, d.bytesy, 0x00020000);
+    const char* xbase = reinterpret_cast<const char*>(from0 ? d.x0 : d.x1);
+    const long long xts = from0 ? d.ts_x0 : d.ts_x1;
+    const int xbytes = from0 ? d.bytes0 : d.bytes1;
     const int xld = from0 ? d.ld0 : d.ld1;
     const int xc0 = from0 ? ci0 : ci0 - d.c0;
     float* wbase = sm + wave * 2 * WBUF;
@@ -235,7 +246,13 @@ __global__ __launch_bounds__(256, 1) void wgrad5x5_kernel(const WgradDesc d) {
     auto issue = [&](auto SET, int chunk) {
         f32x4 (&rx4)[NXP] = rxs[decltype(SET)::value];
         f32x4 (&ry4)[NYP] = rys[decltype(SET)::value];
-        const int p0 = chunk * 32;
+        // chunk -> (timestep of the batch, chunk inside it); wave-uniform.  The descriptors of that timestep's operands are rebuilt
+        // here (scalar work): byte strides between timesteps can exceed a descriptor's 32-bit offsets.
+        const int tj = __builtin_amdgcn_readfirstlane(tcount > 1 ? chunk / cpt : 0);
+        const int p0 = (chunk - tj * cpt) * 32;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase + (long long)tj * xts), 0, xbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(d.dy) + (long long)tj * d.ts_dy), 0, d.bytesy, 0x00020000);
         const int b = p0 / HWg, rem = p0 - b * HWg, y0 = rem / Wd, x0 = rem - y0 * Wd;
 #pragma unroll
         for (int j = 0; j < NXP; ++j) {
@@ -396,7 +413,7 @@ static int launch_wgrad5x5(const WgradDesc& d, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = 5 * (d.cin / 32) * (d.N / (32 * NTW));
-    const int chunks = d.M / 32;
+    const int chunks = d.M / 32 * (d.tcount > 1 ? d.tcount : 1);
     // One block per CU is resident (~100 KB of LDS), so the grid is sized to whole rounds of the chip's CUs: the first
     // version asked for "about 512" blocks and got 520-600, i.e. a third round that ran 8-88 blocks on 256 CUs (lstm7: 264 us
     // for 171 us of MFMA work).  Take the fewest rounds (1..3) whose last round is at least 90 % full.
@@ -436,7 +453,7 @@ int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done) {
     const int wg_n = d.N <= 64 ? 64 : 128;
     const int ncb = (d.cin + WG_CI - 1) / WG_CI, nnb = (d.N + wg_n - 1) / wg_n;
     const int tiles = d.ksize * d.ksize * ncb * nnb;
-    const int chunks = (d.M + WG_PIX - 1) / WG_PIX;
+    const int chunks = (d.M + WG_PIX - 1) / WG_PIX * (d.tcount > 1 ? d.tcount : 1);
     // every block ends with a tile of atomics (64 x 128), so no more pixel splits than fill the chip twice (3 blocks fit a CU)
     int nsplit = (512 + tiles - 1) / tiles;
     if (nsplit > chunks / 8) nsplit = chunks / 8;         // and >= 8 chunks (256 pixels) per block (enc4 with 4: 63 -> 94 us, atomics)

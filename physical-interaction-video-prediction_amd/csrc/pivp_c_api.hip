@@ -115,7 +115,7 @@ int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb,
 // weight gradient of: mode 0 = conv K x K stride `stride` pad `pad`; mode 1 = transposed 3x3 s2 p1
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
               float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s, float* db,
-              int* bias_done, int bf16) {
+              int* bias_done, int bf16, int tcount, long long ts_x0, long long ts_x1, long long ts_dy) {
     WgradDesc d;
     memset(&d, 0, sizeof(d));
     d.x0 = x0; d.c0 = c0; d.ld0 = ld0; d.x1 = x1; d.c1 = x1 ? c1 : 0; d.ld1 = ld1; d.cin = c0 + (x1 ? c1 : 0); d.wcin = wcin;
@@ -127,6 +127,7 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
     if (!fits31(b0) || (x1 && !fits31(b1)) || !fits31(by)) return PIVP_ERR_BADARG;
     d.bytes0 = (int)b0; d.bytes1 = (int)b1; d.bytesy = (int)by;
     d.db = db;
+    d.tcount = tcount; d.ts_x0 = ts_x0; d.ts_x1 = ts_x1; d.ts_dy = ts_dy;
     if (bf16) {   // bf16 precision mode (5x5 ConvLSTM case only): operands rounded to bf16, fp32 accumulation; db summed on the side in fp32
         if (bias_done) *bias_done = db != nullptr;
         return wgrad5x5_bf16(d, s);
@@ -173,6 +174,7 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
         rc = run_conv_s1(dG, N, N, wt, d_in, cin, cin, 5, B, H, W, s);    // d[x,h] = conv5x5(dG, W^T flipped)
     }
     if (rc != PIVP_OK) return rc;
+    if (!dW) return PIVP_OK;   // the caller batches this layer's weight gradient over several timesteps itself (pivp_plan.hip)
     int bias_done = 0;   // the 5x5 weight-gradient kernel sums dG's columns on the side
     // (the weight gradient has a bf16 form but no split form: in the split mode it stays the fp32 kernel)
     rc = run_wgrad(0, x, cx, ldx, h_prev, C, C, cin, dG, N, N, dW, B, H, W, H, W, 5, 2, 1, sw, db, &bias_done, wt_bf16 != nullptr && bf16_planes == 1);

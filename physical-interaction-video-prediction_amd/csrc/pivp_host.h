@@ -19,7 +19,8 @@ int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, in
                 hipStream_t s, int accum = 0);
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
               float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s,
-              float* db = nullptr, int* bias_done = nullptr, int bf16 = 0);
+              float* db = nullptr, int* bias_done = nullptr, int bf16 = 0,
+              int tcount = 1, long long ts_x0 = 0, long long ts_x1 = 0, long long ts_dy = 0);   // a batch of timesteps: WgradDesc
 // Where the WEIGHT-gradient half of a conv backward runs.  A weight gradient feeds nothing but the optimizer, while the data gradient
 // is on the backward sweep's critical path: with a fork the weight (and bias) gradient kernels are enqueued on `side` behind `ready`
 // (recorded on the main stream as soon as dY is final) and `done` is recorded behind them; the caller makes whoever next overwrites

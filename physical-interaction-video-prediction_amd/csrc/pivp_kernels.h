@@ -51,6 +51,11 @@ struct WgradDesc {
     int bytes0, bytes1, bytesy;
     float* db;                           // optional bias gradient [N] (column sums of dy), accumulated with atomics when the
                                          // kernel that runs can do it on the side (*bias_done = 1), else left to bias_grad
+    // A batch of timesteps in one launch (the reduction of a weight gradient runs over pixels AND timesteps): operand j = 0..tcount-1
+    // lives at x0 + j*ts_x0, x1 + j*ts_x1, dy + j*ts_dy (byte strides, may be negative); M, B, bytes* describe ONE timestep.
+    // 0 / 1 = a single timestep.  Fewer, longer launches: one block epilogue (LDS reduction + atomics) per batch instead of per step.
+    int tcount;
+    long long ts_x0, ts_x1, ts_dy;
 };
 int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done = nullptr);
 // bf16-operand form of the ConvLSTM weight gradient (csrc/wgrad_bf16.hip); the bias gradient is left to bias_grad

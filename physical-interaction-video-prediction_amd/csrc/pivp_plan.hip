@@ -40,6 +40,14 @@ static int ln_partial_cap(int HW) {
     return a > b ? a : b;
 }
 
+// ConvLSTM weight gradients can be taken over a batch of up to this many timesteps in ONE launch (the reduction runs over pixels and
+// timesteps alike; WgradDesc::tcount): a quarter of the block epilogues and grid ramps.  Measured at B = 32 it does not pay: alone
+// it is worth 0.4 ms of a 35.6 ms train step, and next to the side stream it LOSES 0.7 ms (34.1 vs 33.4 ms) because the weight
+// gradients then arrive in bursts instead of filling the gaps of every step.  So the default is one timestep per launch
+// (PIVP_WGRAD_BATCH=1), the dG rings then simply double-buffer; the batched path stays for larger per-GPU batches and is tested
+// (tests/test_gpu_train.py).  Timestep 0 is always its own batch (its h_{-1} = 0 half is skipped).
+constexpr int WG_BATCH = 4;
+
 struct Slab {
     size_t cat7, n1, n2, cat6, n3, n4, e2, e3, n5, e4, e5, e6;   // NHWC feature maps (cat7 = [hidden7|enc0], cat6 = [hidden6|enc1])
     size_t h[7], c[7];                                           // ConvLSTM states
@@ -53,7 +61,7 @@ struct Slab {
 struct Grads {   // gradient workspace (single copy, reused by every timestep of the backward sweep)
     size_t cat7, n2, cat6, n4, e2, n5, e6, e6raw, e0raw;
     size_t hln[7], din[7][2], dc[7];
-    size_t dG[7], go[2], dmk, dz, dkpart, dv, dstate, lnpart;   // dG: gate pre-activation gradients, one buffer per ConvLSTM (its weight gradient reads it from the side stream)
+    size_t dG[7], go[2], dmk, dz, dkpart, dv, dstate, lnpart;   // dG: gate pre-activation gradients per ConvLSTM: 2 rings x WG_BATCH timesteps (batched weight gradients)
     size_t wt_lstm[7], wt_enc[7];   // re-packed (transposed) weights for the data gradients, rebuilt once per backward
     size_t wtb_lstm[7];             // ... and their bf16 packs (bf16 precision mode)
 };
@@ -94,7 +102,11 @@ struct pivp_plan {
     bool use_side = true;
     hipStream_t side = nullptr;
     hipEvent_t ev_ready[NSLOT] = {}, ev_done[NSLOT] = {};
+    hipEvent_t ev_ring_done[7][2] = {};        // ConvLSTM slots: one `done` per dG ring (slots 0..6 of ev_done are unused)
+    int wg_batch = 1;                          // timesteps per weight-gradient launch (<= WG_BATCH; always 1 in the bf16 mode, whose kernel takes one)
+    const float* wg_x[7] = {}; const float* wg_h[7] = {};   // operands of the first timestep of the open batch
     ~pivp_plan() {
+        for (int i = 0; i < 7; ++i) for (int r = 0; r < 2; ++r) if (ev_ring_done[i][r]) (void)hipEventDestroy(ev_ring_done[i][r]);
         for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
         for (int i = 0; i < NSLOT; ++i) { if (ev_ready[i]) (void)hipEventDestroy(ev_ready[i]); if (ev_done[i]) (void)hipEventDestroy(ev_done[i]); }
         if (side) (void)hipStreamDestroy(side);
@@ -200,7 +212,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
             const size_t M = hsz[i] / kLstm[i].C * B;
             g.hln[i] = carve(B * hsz[i]); g.dc[i] = carve(B * hsz[i]);
             g.din[i][0] = carve(M * (kLstm[i].cx + kLstm[i].C)); g.din[i][1] = carve(M * (kLstm[i].cx + kLstm[i].C));
-            g.dG[i] = carve(M * 4 * kLstm[i].C);
+            g.dG[i] = carve(M * 4 * kLstm[i].C * 2 * WG_BATCH);
             g.wt_lstm[i] = carve((size_t)25 * (kLstm[i].cx + kLstm[i].C) * 4 * kLstm[i].C);
             g.wtb_lstm[i] = carve(lstm_bf16_weight_elems(4 * kLstm[i].C, conv5x5_bf16_rows(kLstm[i].cx + kLstm[i].C)));   // two planes
             g.wt_enc[i] = (i == 0 || i == 3) ? 0 : carve((size_t)encw[i]);
@@ -295,6 +307,9 @@ static int ensure_side(pivp_plan* plan) {
     for (int i = 0; i < pivp_plan::NSLOT; ++i)
         if (hipEventCreateWithFlags(&plan->ev_ready[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&plan->ev_done[i], hipEventDisableTiming) != hipSuccess) return PIVP_ERR_LAUNCH;
+    for (int i = 0; i < 7; ++i)
+        for (int r = 0; r < 2; ++r)
+            if (hipEventCreateWithFlags(&plan->ev_ring_done[i][r], hipEventDisableTiming) != hipSuccess) return PIVP_ERR_LAUNCH;
     return PIVP_OK;
 }
 
@@ -454,8 +469,9 @@ extern "C" int pivp_rollout_forward(pivp_plan_t* plan, const float* images, cons
 // backward through time (what loss.backward() does inside Chainer's optimizer.update, TM:950), all three heads.
 // Gradients are ACCUMULATED into the buffers registered with pivp_plan_set_grad (same layouts as the parameters).
 // ------------------------------------------------------------------------------------------------------------
+// wg_ring / wg_slot: where this step's gate gradients go in the ConvLSTMs' dG rings; wg_flush: this step closes its batch
 static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_grad, const float* action, const float* state_prev,
-                         bool has_go, float* go, float* go_prev, bool last_step, hipStream_t s) {
+                         bool has_go, float* go, float* go_prev, bool last_step, int wg_ring, int wg_slot, bool wg_flush, hipStream_t s) {
     const pivp_config_t& c = p->cfg;
     const int B = c.batch, H = c.height, W = c.width, HW = H * W;
     float* ws = p->ws;
@@ -479,18 +495,36 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         if (!p->side) return PIVP_OK;
         return hipStreamWaitEvent(s, p->ev_done[slot], 0) == hipSuccess ? PIVP_OK : PIVP_ERR_LAUNCH;   // never recorded: returns at once
     };
-    auto lstmb = [&](int i, const float* x, int ldx, int hh, int wwid) {
+    const long long slab_bytes = p->nslabs > 1 ? ((long long)p->slabs[1].cat7 - (long long)p->slabs[0].cat7) * 4 : 0;
+    auto lstmb = [&](int i, const float* x, int ldx, int hh, int wwid) -> int {
         const LstmSpec& L = kLstm[i];
-        const int cin = L.cx + L.C;
+        const int cin = L.cx + L.C, N = 4 * L.C;
+        const size_t dG1 = (size_t)B * hh * wwid * N;                      // floats of one timestep's dG
+        float* ring = ws + g.dG[i] + (size_t)wg_ring * WG_BATCH * dG1;
+        const float* h_prev = Sp ? ws + Sp->h[i] : nullptr;
         SideFork f;
-        const SideFork* fk = fork_of(i, f);
-        int rcj = join(i);        // the previous timestep's weight gradient of this layer still reads dG[i]
-        if (rcj != PIVP_OK) return rcj;
-        return run_convlstm_backward(x, L.cx, ldx, Sp ? ws + Sp->h[i] : nullptr, L.C, P(p, p->i_lstm_w[i]), ws + S.gates[i],
-                                     Sp ? ws + Sp->c[i] : ws + p->o_zero, ws + S.c[i], ws + g.hln[i], L.C,
-                                     last_step ? nullptr : ws + g.din[i][npar] + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
-                                     ws + g.dG[i], ws + g.wt_lstm[i], ws + g.din[i][par], G(p, p->i_lstm_w[i]), G(p, p->i_lstm_b[i]), B, hh, wwid,
-                                     s, 1, p->lstm_bf16 ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->lstm_planes, fk);
+        if (wg_slot == 0) {     // a new batch: the ring's previous weight-gradient launch (two batches ago) must have read it
+            if (p->side && hipStreamWaitEvent(s, p->ev_ring_done[i][wg_ring], 0) != hipSuccess) return PIVP_ERR_LAUNCH;
+            p->wg_x[i] = x; p->wg_h[i] = h_prev;
+        }
+        RC(run_convlstm_backward(x, L.cx, ldx, h_prev, L.C, P(p, p->i_lstm_w[i]), ws + S.gates[i],
+                                 Sp ? ws + Sp->c[i] : ws + p->o_zero, ws + S.c[i], ws + g.hln[i], L.C,
+                                 last_step ? nullptr : ws + g.din[i][npar] + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
+                                 ring + (size_t)wg_slot * dG1, ws + g.wt_lstm[i], ws + g.din[i][par], nullptr, nullptr, B, hh, wwid,
+                                 s, 1, p->lstm_bf16 ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->lstm_planes,
+                                 wg_flush ? fork_of(i, f) : nullptr));   // dW = null: only the fork's `ready` (behind the gate math) is used
+        if (!wg_flush) return PIVP_OK;
+        // weight + bias gradient of the whole batch: timestep j of it reads slab (first - j) and ring slot j; on the side stream it
+        // starts as soon as this step's dG exists, next to this step's own data gradient
+        hipStream_t sw = p->side ? p->side : s;
+        const int cnt = wg_slot + 1;
+        int bias_done = 0;
+        RC(run_wgrad(0, p->wg_x[i], L.cx, ldx, p->wg_h[i], L.C, L.C, cin, ring, N, N, G(p, p->i_lstm_w[i]), B, hh, wwid, hh, wwid, 5, 2, 1, sw,
+                     G(p, p->i_lstm_b[i]), &bias_done, p->bf16_all, cnt, -slab_bytes, -slab_bytes, (long long)dG1 * 4));
+        if (!bias_done)
+            for (int j = 0; j < cnt; ++j) RC(bias_grad(ring + (size_t)j * dG1, N, N, B * hh * wwid, G(p, p->i_lstm_b[i]), sw));
+        if (p->side && hipEventRecord(p->ev_ring_done[i][wg_ring], p->side) != hipSuccess) return PIVP_ERR_LAUNCH;
+        return PIVP_OK;
     };
     const long px2 = (long)B * p->H2 * p->W2, px4 = (long)B * p->H4 * p->W4, px8 = (long)B * p->H8 * p->W8;
 
@@ -532,7 +566,12 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     auto done = [&](int group) -> int {
         if (t != 0 || !p->grad_cb) return PIVP_OK;
         static const int slots[6][3] = {{7, -1, -1}, {6, -1, -1}, {8, 5, -1}, {9, 4, -1}, {10, 3, 2}, {11, 1, 0}};
-        for (int k = 0; k < 3; ++k) if (slots[group][k] >= 0) RC(join(slots[group][k]));
+        for (int k = 0; k < 3; ++k) {
+            const int sl = slots[group][k];
+            if (sl >= 7) RC(join(sl));
+            else if (sl >= 0 && p->side)
+                for (int r = 0; r < 2; ++r) if (hipStreamWaitEvent(s, p->ev_ring_done[sl][r], 0) != hipSuccess) return PIVP_ERR_LAUNCH;
+        }
         p->grad_cb(p->grad_cb_user, group);
         return PIVP_OK;
     };
@@ -597,6 +636,13 @@ extern "C" int pivp_rollout_backward(pivp_plan_t* plan, const float* images, con
     const float fscale = 2.0f / ((float)fr * (float)(T - ctx));              // d/d gen of mean-squared error / (T - ctx)
     const float sscale = 2.0f * 1e-4f / ((float)(B * 5) * (float)(T - ctx));
     RC(ensure_side(plan));
+    {   // PIVP_WGRAD_BATCH (1..WG_BATCH): experiment knob; the bf16 weight-gradient kernel takes one timestep per launch
+        const char* e = getenv("PIVP_WGRAD_BATCH");
+        int gb = e ? atoi(e) : 1;
+        if (gb < 1) gb = 1;
+        if (gb > WG_BATCH) gb = WG_BATCH;
+        plan->wg_batch = plan->bf16_all ? 1 : gb;
+    }
     // d loss / d gen_states[t] for every t (zero before ctx-1), later accumulated with the state recurrence
     if (hipMemsetAsync(ws + g.dstate, 0, (size_t)T * B * 5 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     for (int t = ctx - 1; t < T - 1; ++t)
@@ -630,12 +676,22 @@ extern "C" int pivp_rollout_backward(pivp_plan_t* plan, const float* images, con
         else if (prev_has_grad) { if (hipMemsetAsync(go_prev, 0, fr * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH; }
         const float* prev = step_input(plan, t, images, gt_select, gen_images, fr);
         const float* st_prev = t == 0 ? states : gen_states + (size_t)(t - 1) * B * 5;
-        RC(backward_step(plan, t, prev, prev_has_grad && has_go, actions + (size_t)t * B * 5, st_prev, has_go, go, go_prev, last, s));
+        // the ConvLSTM weight gradients: batches of wg_batch timesteps counted from the top of the sweep; t = 0 on its own
+        const int G = plan->wg_batch, k = T - 2 - t;
+        const int wg_b = t >= 1 ? k / G : (T - 2 + G - 1) / G, wg_slot = t >= 1 ? k % G : 0;
+        const bool wg_flush = t <= 1 || wg_slot == G - 1;
+        RC(backward_step(plan, t, prev, prev_has_grad && has_go, actions + (size_t)t * B * 5, st_prev, has_go, go, go_prev, last,
+                         wg_b & 1, wg_slot, wg_flush, s));
         has_go = next_loss || (prev_has_grad && has_go);
     }
     if (plan->side)     // whatever the caller enqueues next on its stream (the all-reduce, Adam) sees every weight gradient
-        for (int i = 0; i < pivp_plan::NSLOT; ++i)
+    {
+        for (int i = 7; i < pivp_plan::NSLOT; ++i)
             if (hipStreamWaitEvent(s, plan->ev_done[i], 0) != hipSuccess) return PIVP_ERR_LAUNCH;
+        for (int i = 0; i < 7; ++i)
+            for (int r = 0; r < 2; ++r)
+                if (hipStreamWaitEvent(s, plan->ev_ring_done[i][r], 0) != hipSuccess) return PIVP_ERR_LAUNCH;
+    }
     return PIVP_OK;
 }
 

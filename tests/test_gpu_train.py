@@ -256,3 +256,23 @@ def test_bptt_gradients_128x128(pivp):
         rel_l2 = np.linalg.norm(d) / (np.linalg.norm(g) + 1e-30)
         med = np.median(np.abs(d)) / (np.abs(g).max() + 1e-12)
         assert rel_l2 < 1e-2 and med < 1e-3, '%s: relative L2 %.2e, median %.2e' % (kname, rel_l2, med)
+
+
+def test_batched_weight_gradients_match_per_step(pivp, monkeypatch):
+    # WgradDesc::tcount: the ConvLSTM weight gradients of up to 4 timesteps in one launch (PIVP_WGRAD_BATCH) must give the gradients of
+    # one launch per timestep (same products, other summation order), with and without the side stream
+    P = R.init_params(seed=1, dtype=np.float64, scale=1.0)
+    imgs, acts, stas = R.synthetic_batch(2, 8)             # 7 steps: batches [6,5,4,3] [2,1] [0]
+    outs = {}
+    for batch, side in (('1', '1'), ('4', '1'), ('3', '0')):
+        monkeypatch.setenv('PIVP_WGRAD_BATCH', batch)
+        monkeypatch.setenv('PIVP_SIDE_STREAM', side)
+        m = pivp.Model(10, prefix='t', keep_activations=True)
+        m.load_state_dict_reference(P)
+        m([imgs, acts, stas], 0)
+        m.cleargrads(); m.backward()
+        outs[(batch, side)] = m._flat_grads.clone()
+    ref = outs[('1', '1')]
+    for key, g in outs.items():
+        rel = float((g - ref).norm() / ref.norm())
+        assert rel < 2e-5, (key, rel)
