@@ -2,6 +2,8 @@
 // autograd inside optimizer.update (train_model.py:950); each kernel cites the forward code it differentiates
 // ("TM" = src/models/train_model.py).  Heavy contractions (data / weight gradients of the convolutions) are in
 // igemm_f32.hip / igemm_wgrad.hip.  All gradient buffers ACCUMULATE (Chainer: cleargrads() then backward()).
+#include <string.h>
+
 #include "pivp_kernels.h"
 
 namespace pivp {
@@ -15,35 +17,80 @@ __device__ __forceinline__ float fast_tanh_b(float x) { return 2.0f * __builtin_
 // Writes the pre-activation gate gradients dG [M][4C] (column order j,i,f,o like the weights) and turns dc into
 // d c_{t-1} in place.
 // ------------------------------------------------------------------------------------------
+// Thread = 4 consecutive channels of one pixel, block = 1024 consecutive elements (NHWC) of one sample.  With `ln.dy` set, dh_a is not
+// read but formed on the fly as the LayerNorm backward of the norm behind this cell (TM:203-208; what ln_bwd_apply_kernel would
+// have written): dh_a = rstd * (dy*gamma - m1 - xhat*m2), xhat = (h - mean)*rstd, (m1, m2) = the sample's means of g and g*xhat
+// from ln_bwd_stats_kernel's partials -- one launch and one 4-byte-per-element round trip less per ConvLSTM and timestep.
 __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_old,
                                                              const float* __restrict__ c_new, const float* __restrict__ dh_a, int lda,
                                                              const float* __restrict__ dh_b, int ldb, float* __restrict__ dc,
-                                                             int dc_valid, float* __restrict__ dG, int M, int C) {
-    const long total = (long)M * C;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int m = (int)(idx / C), ch = (int)(idx - (long)m * C);
-        const float* g = gates + (size_t)m * 4 * C + ch;
-        const float aj = g[0], ai = g[C], af = g[2 * C], ao = g[3 * C];
-        float dh = dh_a ? dh_a[(size_t)m * lda + ch] : 0.f;
-        if (dh_b) dh += dh_b[(size_t)m * ldb + ch];
-        const float tc = fast_tanh_b(c_new[idx]);
-        const float dct = dh * ao * (1.f - tc * tc) + (dc_valid ? dc[idx] : 0.f);
-        float* o = dG + (size_t)m * 4 * C + ch;
-        o[0] = dct * ai * (1.f - aj * aj);
-        o[C] = dct * aj * ai * (1.f - ai);
-        o[2 * C] = dct * c_old[idx] * af * (1.f - af);
-        o[3 * C] = dh * tc * ao * (1.f - ao);
-        dc[idx] = dct * af;
+                                                             int dc_valid, float* __restrict__ dG, int npix, int C, const LnFuse ln) {
+    __shared__ float sums[2];
+    const int b = blockIdx.y;
+    const int n = npix * C;                                   // elements per sample
+    if (ln.dy) {
+        if (threadIdx.x < 64) {
+            float a = 0.f, c2 = 0.f;
+            for (int i = threadIdx.x; i < ln.S; i += 64) { a += ln.partials[((size_t)b * ln.S + i) * 2]; c2 += ln.partials[((size_t)b * ln.S + i) * 2 + 1]; }
+            a = wave_sum(a); c2 = wave_sum(c2);
+            if (threadIdx.x == 0) { sums[0] = a / (float)n; sums[1] = c2 / (float)n; }
+        }
+        __syncthreads();
     }
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;       // element of the sample
+    if (e >= n) return;
+    const int pix = e / C, ch = e - pix * C;
+    const size_t m = (size_t)b * npix + pix;                  // global pixel
+    const size_t idx = m * C + ch;
+    const float* g = gates + m * 4 * C + ch;
+    const f32x4 aj = *reinterpret_cast<const f32x4*>(g), ai = *reinterpret_cast<const f32x4*>(g + C);
+    const f32x4 af = *reinterpret_cast<const f32x4*>(g + 2 * C), ao = *reinterpret_cast<const f32x4*>(g + 3 * C);
+    const f32x4 cn = *reinterpret_cast<const f32x4*>(c_new + idx), co = *reinterpret_cast<const f32x4*>(c_old + idx);
+    f32x4 dh = {0.f, 0.f, 0.f, 0.f};
+    if (ln.dy) {
+        const f32x4 dy = *reinterpret_cast<const f32x4*>(ln.dy + m * ln.lddy + ch);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(ln.gamma + e);
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(ln.h + idx);
+        const float mean = ln.stat[b * 2], rstd = ln.stat[b * 2 + 1], m1 = sums[0], m2 = sums[1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dh[k] = rstd * (dy[k] * gm[k] - m1 - (hv[k] - mean) * rstd * m2);
+    } else if (dh_a) {
+        dh = *reinterpret_cast<const f32x4*>(dh_a + m * lda + ch);
+    }
+    if (dh_b) dh += *reinterpret_cast<const f32x4*>(dh_b + m * ldb + ch);
+    f32x4 dcv = {0.f, 0.f, 0.f, 0.f};
+    if (dc_valid) dcv = *reinterpret_cast<const f32x4*>(dc + idx);
+    f32x4 oj, oi, of, oo, dcn;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float tc = fast_tanh_b(cn[k]);
+        const float dct = dh[k] * ao[k] * (1.f - tc * tc) + dcv[k];
+        oj[k] = dct * ai[k] * (1.f - aj[k] * aj[k]);
+        oi[k] = dct * aj[k] * ai[k] * (1.f - ai[k]);
+        of[k] = dct * co[k] * af[k] * (1.f - af[k]);
+        oo[k] = dh[k] * tc * ao[k] * (1.f - ao[k]);
+        dcn[k] = dct * af[k];
+    }
+    float* o = dG + m * 4 * C + ch;
+    *reinterpret_cast<f32x4*>(o) = oj; *reinterpret_cast<f32x4*>(o + C) = oi;
+    *reinterpret_cast<f32x4*>(o + 2 * C) = of; *reinterpret_cast<f32x4*>(o + 3 * C) = oo;
+    *reinterpret_cast<f32x4*>(dc + idx) = dcn;
 }
 
 int lstm_gates_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_a, int lda,
-                   const float* dh_b, int ldb, float* dc, int dc_valid, float* dG, int M, int C, hipStream_t s) {
-    PIVP_CHECK_ARG(gates && c_old && c_new && dc && dG && M > 0 && C > 0 && (dh_a || dh_b));
-    const long total = (long)M * C;
-    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(blocks), dim3(256), 0, s, gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc,
-                       dc_valid, dG, M, C);
+                   const float* dh_b, int ldb, float* dc, int dc_valid, float* dG, int M, int C, hipStream_t s, int B, const LnFuse* ln) {
+    PIVP_CHECK_ARG(gates && c_old && c_new && dc && dG && M > 0 && C > 0 && C % 4 == 0 && (dh_a || dh_b || (ln && ln->dy)));
+    PIVP_CHECK_ARG(B > 0 && M % B == 0 && (!dh_a || lda % 4 == 0) && (!dh_b || ldb % 4 == 0));
+    LnFuse lf;
+    memset(&lf, 0, sizeof(lf));
+    if (ln && ln->dy) {
+        PIVP_CHECK_ARG(ln->gamma && ln->stat && ln->partials && ln->h && ln->S > 0 && ln->lddy % 4 == 0);
+        lf = *ln;
+    }
+    const int npix = M / B;
+    const int xb = (npix * C / 4 + 255) / 256;
+    hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(xb, B), dim3(256), 0, s, gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc,
+                       dc_valid, dG, npix, C, lf);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -214,11 +261,12 @@ int ln_bwd_slices(int n) { return (n + LNB_SLICE - 1) / LNB_SLICE; }
 
 int ln_backward(const float* dy, int lddy, const float* y, int ldy, const float* x, const float* stat, const float* gamma,
                 float* partials, float* dx, float* dgamma, float* dbeta, int B, int n, int C, int relu, hipStream_t s) {
-    PIVP_CHECK_ARG(dy && x && stat && gamma && partials && dx && dgamma && dbeta && B > 0 && n > 0 && C > 0 && C % 4 == 0 && n % C == 0);
+    // dx == nullptr: the consumer forms dx itself from the partials (lstm_gates_bwd with LnFuse); only the sums and the parameter gradients run here
+    PIVP_CHECK_ARG(dy && x && stat && gamma && partials && dgamma && dbeta && B > 0 && n > 0 && C > 0 && C % 4 == 0 && n % C == 0);
     PIVP_CHECK_ARG(lddy >= C && lddy % 4 == 0 && (!relu || (y && ldy >= C && ldy % 4 == 0)));
     const int S = ln_bwd_slices(n);
     hipLaunchKernelGGL(ln_bwd_stats_kernel, dim3(S, B), dim3(256), 0, s, dy, lddy, y, ldy, x, stat, gamma, partials, n, C, relu);
-    hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3(S, B), dim3(256), 0, s, dy, lddy, y, ldy, x, stat, gamma, partials, dx, n, C, relu);
+    if (dx) hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3(S, B), dim3(256), 0, s, dy, lddy, y, ldy, x, stat, gamma, partials, dx, n, C, relu);
     {
         const int xb = (n / 4 + 255) / 256;
         int yb = 512 / xb; if (yb < 1) yb = 1; if (yb > B) yb = B; if (yb > 8) yb = 8;

@@ -152,9 +152,10 @@ static int fork_end(const SideFork* f) {
 int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
                           const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                           float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
-                          int B, int H, int W, hipStream_t s, int wt_ready, unsigned short* wt_bf16, int bf16_planes, const SideFork* fork) {
+                          int B, int H, int W, hipStream_t s, int wt_ready, unsigned short* wt_bf16, int bf16_planes, const SideFork* fork,
+                          const LnFuse* ln) {
     const int M = B * H * W, cin = cx + C, N = 4 * C;
-    int rc = lstm_gates_bwd(gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc, dc_valid, dG, M, C, s);
+    int rc = lstm_gates_bwd(gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc, dc_valid, dG, M, C, s, B, ln);
     if (rc != PIVP_OK) return rc;
     // dG is final: the weight gradient can start (on the side stream when forked), next to this layer's own data gradient
     hipStream_t sw;

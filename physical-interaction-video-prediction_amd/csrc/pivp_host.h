@@ -33,7 +33,7 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
                           const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                           float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
                           int B, int H, int W, hipStream_t s, int wt_ready = 0, unsigned short* wt_bf16 = nullptr, int bf16_planes = 1,
-                          const SideFork* fork = nullptr);
+                          const SideFork* fork = nullptr, const LnFuse* ln = nullptr);   // ln: dh_a is formed from the LayerNorm behind the cell
 int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb, float* out, int cout, int ldo, int accum,
                      int B, int H, int W, hipStream_t s, int planes = 1);
 int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w, float* dy, int cout, int ldy, const float* y, int ldyy,

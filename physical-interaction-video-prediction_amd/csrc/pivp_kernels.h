@@ -129,8 +129,17 @@ int loss_finalize(const float* frame_partials, int nparts, int nframes, int fram
                   float denom, float* results, hipStream_t s);
 
 // ---- backward (csrc/backward.hip) ----
+// LayerNorm backward folded into the ConvLSTM gate backward: the cell's dh is the dx of the norm behind it (see lstm_gates_bwd_kernel)
+struct LnFuse {
+    const float* dy; int lddy;       // gradient arriving at the norm's OUTPUT (may be a channel slice of a concat buffer)
+    const float* gamma;              // [n] NHWC-flat
+    const float* stat;               // [B][2] mean, rstd of the forward pass
+    const float* partials; int S;    // [B][S][2] from ln_bwd_stats_kernel (S = ln_bwd_slices(n))
+    const float* h;                  // the norm's input = the cell's h_t, [M][C]
+};
 int lstm_gates_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_a, int lda,
-                   const float* dh_b, int ldb, float* dc, int dc_valid, float* dG, int M, int C, hipStream_t s);
+                   const float* dh_b, int ldb, float* dc, int dc_valid, float* dG, int M, int C, hipStream_t s, int B = 1,
+                   const LnFuse* ln = nullptr);
 int bias_grad(const float* dy, int ld, int N, int M, float* db, hipStream_t s);
 int relu_mask(float* dy, int lddy, const float* y, int ldy, int C, long npix, hipStream_t s);
 int ln_bwd_slices(int n);

@@ -496,6 +496,15 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         return hipStreamWaitEvent(s, p->ev_done[slot], 0) == hipSuccess ? PIVP_OK : PIVP_ERR_LAUNCH;   // never recorded: returns at once
     };
     const long long slab_bytes = p->nslabs > 1 ? ((long long)p->slabs[1].cat7 - (long long)p->slabs[0].cat7) * 4 : 0;
+    // LayerNorm behind ConvLSTM i (hidden<i+1>): partial sums and parameter gradients here, dx inside the cell's gate backward
+    LnFuse lf[7];
+    auto lnb_cell = [&](int i, const float* dy, int lddy, int n, int C) {
+        const int j = i + 1;
+        lf[i].dy = dy; lf[i].lddy = lddy; lf[i].gamma = P(p, p->i_ln_g[j]); lf[i].stat = ws + S.lnstat + (size_t)j * B * 2;
+        lf[i].partials = lnpart; lf[i].S = ln_bwd_slices(n); lf[i].h = ws + S.h[i];
+        return ln_backward(dy, lddy, nullptr, 0, ws + S.h[i], lf[i].stat, lf[i].gamma, lnpart, nullptr,
+                           G(p, p->i_ln_g[j]), G(p, p->i_ln_b[j]), B, n, C, 0, s);
+    };
     auto lstmb = [&](int i, const float* x, int ldx, int hh, int wwid) -> int {
         const LstmSpec& L = kLstm[i];
         const int cin = L.cx + L.C, N = 4 * L.C;
@@ -508,11 +517,11 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
             p->wg_x[i] = x; p->wg_h[i] = h_prev;
         }
         RC(run_convlstm_backward(x, L.cx, ldx, h_prev, L.C, P(p, p->i_lstm_w[i]), ws + S.gates[i],
-                                 Sp ? ws + Sp->c[i] : ws + p->o_zero, ws + S.c[i], ws + g.hln[i], L.C,
+                                 Sp ? ws + Sp->c[i] : ws + p->o_zero, ws + S.c[i], nullptr, L.C,
                                  last_step ? nullptr : ws + g.din[i][npar] + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
                                  ring + (size_t)wg_slot * dG1, ws + g.wt_lstm[i], ws + g.din[i][par], nullptr, nullptr, B, hh, wwid,
                                  s, 1, p->lstm_bf16 ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->lstm_planes,
-                                 wg_flush ? fork_of(i, f) : nullptr));   // dW = null: only the fork's `ready` (behind the gate math) is used
+                                 wg_flush ? fork_of(i, f) : nullptr, &lf[i]));   // dW = null: only the fork's `ready` (behind the gate math) is used
         if (!wg_flush) return PIVP_OK;
         // weight + bias gradient of the whole batch: timestep j of it reads slab (first - j) and ring slot j; on the side stream it
         // starts as soon as this step's dG exists, next to this step's own data gradient
@@ -576,19 +585,19 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         return PIVP_OK;
     };
     RC(done(0));
-    RC(lnb(7, ws + g.cat7, 64, nullptr, 0, ws + S.h[6], ws + g.hln[6], n2, 32, 0));
+    RC(lnb_cell(6, ws + g.cat7, 64, n2, 32));
     RC(lstmb(6, ws + S.e5, 96, p->H2, p->W2));
     RC(done(1));
     // group 5 (TM:600): d e5 = x-part of lstm7's d_in (ReLU fused in enc5) <- enc5 deconv <- [hidden6 | enc1]
     RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ws + S.e5, 96, ws + g.wt_enc[5], ws + g.cat6, 96, 0,
                          G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1, fork_of(8, fe)));
-    RC(lnb(6, ws + g.cat6, 96, nullptr, 0, ws + S.h[5], ws + g.hln[5], n4, 64, 0));
+    RC(lnb_cell(5, ws + g.cat6, 96, n4, 64));
     RC(lstmb(5, ws + S.e4, 128, p->H4, p->W4));
     RC(done(2));
     // group 4 (TM:599): d e4 = x-part of lstm6's d_in <- enc4 deconv <- hidden5 (also read by the CDNA kernel generator)
     RC(run_conv_backward(1, ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), ws + g.din[5][par], 128, 192, ws + S.e4, 128, ws + g.wt_enc[4], ws + g.n5, 128, 1,
                          G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s, 1, fork_of(9, fe)));
-    RC(lnb(5, ws + g.n5, 128, nullptr, 0, ws + S.h[4], ws + g.hln[4], n8, 128, 0));
+    RC(lnb_cell(4, ws + g.n5, 128, n8, 128));
     RC(lstmb(4, ws + S.e3, 64, p->H8, p->W8));
     RC(done(3));
     // group 3 (TM:598) + state predictor (TM:730): d e3 = x-part of lstm5's d_in (ld 192)
@@ -599,18 +608,18 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     // group 2 (TM:597): enc2 conv (ReLU) <- hidden4 <- lstm4 <- hidden3 <- lstm3 <- enc1
     RC(run_conv_backward(0, ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), ws + g.e2, 64, 64, ws + S.e2, 64, ws + g.wt_enc[2], ws + g.n4, 64, 0,
                          G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s, 1, fork_of(10, fe)));
-    RC(lnb(4, ws + g.n4, 64, nullptr, 0, ws + S.h[3], ws + g.hln[3], n4, 64, 0));
+    RC(lnb_cell(3, ws + g.n4, 64, n4, 64));
     RC(lstmb(3, ws + S.n3, 64, p->H4, p->W4));
-    RC(lnb(3, ws + g.din[3][par], 128, nullptr, 0, ws + S.h[2], ws + g.hln[2], n4, 64, 0));
+    RC(lnb_cell(2, ws + g.din[3][par], 128, n4, 64));
     RC(lstmb(2, ws + S.cat6 + 64, 96, p->H4, p->W4));
     RC(done(4));
     RC(add_strided(ws + g.cat6 + 64, 96, ws + g.din[2][par], 96, 32, px4, s));          // d enc1: from enc5's concat + from lstm3
     // group 1 (TM:596): enc1 conv (ReLU) <- hidden2 <- lstm2 <- hidden1 <- lstm1 <- enc0
     RC(run_conv_backward(0, ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), ws + g.cat6 + 64, 32, 96, ws + S.cat6 + 64, 96, ws + g.wt_enc[1], ws + g.n2, 32, 0,
                          G(p, p->i_enc_w[1]), G(p, p->i_enc_b[1]), B, p->H2, p->W2, s, 1, fork_of(11, fe)));
-    RC(lnb(2, ws + g.n2, 32, nullptr, 0, ws + S.h[1], ws + g.hln[1], n2, 32, 0));
+    RC(lnb_cell(1, ws + g.n2, 32, n2, 32));
     RC(lstmb(1, ws + S.n1, 32, p->H2, p->W2));
-    RC(lnb(1, ws + g.din[1][par], 64, nullptr, 0, ws + S.h[0], ws + g.hln[0], n2, 32, 0));
+    RC(lnb_cell(0, ws + g.din[1][par], 64, n2, 32));
     RC(lstmb(0, ws + S.cat7 + 32, 64, p->H2, p->W2));
     RC(add_strided(ws + g.cat7 + 32, 64, ws + g.din[0][par], 64, 32, px2, s));          // d enc0: from enc6's concat + from lstm1
     // group 0 (TM:595): norm_enc0 (+relu) <- enc0 conv <- frame
