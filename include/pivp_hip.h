@@ -9,7 +9,12 @@
  * Conventions
  *   - all pointers are DEVICE pointers to fp32 unless stated; the caller owns every buffer
  *   - return value: 0 = ok, <0 = error (PIVP_ERR_*); functions never throw and never synchronise
- *   - re-entrant per plan + stream; no global mutable state besides lazily set kernel attributes
+ *   - re-entrant per plan + stream.  Process-global state is limited to (a) write-once-per-DEVICE caches of kernel attributes and the
+ *     CU count (csrc/pivp_common.h: a process may drive several devices) and (b) PIVP_* tuning knobs read once with getenv(); both
+ *     are idempotent.  A plan that runs a backward sweep owns one internal low-priority stream and its events for the weight
+ *     gradients (created on the first pivp_rollout_backward, destroyed with the plan); everything it enqueues there is fenced
+ *     against the caller's stream with events, so the caller still only ever synchronises its own stream.  PIVP_SIDE_STREAM=0
+ *     (read at pivp_plan_create) keeps all work on the caller's stream.
  *   - feature maps are NHWC with an explicit pixel stride `ld` (floats); frames and mask planes are
  *     planar NCHW exactly as the reference holds them
  */

@@ -585,13 +585,8 @@ bool convlstm_bf16_ok(const IgemmDesc& d) { return bf16_geometry_ok(d) && d.C > 
 template <int NCH, bool LSTM, int PL = 1>
 static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nb, int ksplit, int ncols) {
     constexpr int lds_bytes = PL * PATCH_BYTES + ((PL == 2 && NCH == 32) ? 2 : NSLOT) * PL * 4 * NCH * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convlstm_bf16_kernel<NCH, LSTM, PL>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
-            return PIVP_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_bf16_kernel<NCH, LSTM, PL>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     IgemmDesc dd = d;
     const int tw = d.Win % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
     const int tpi = (d.Hin / TH) * (d.Win / tw);

@@ -228,13 +228,10 @@ bool deconv_tile_ok(const IgemmDesc& d) {
 int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts, int prec) {
     PIVP_CHECK_ARG(deconv_tile_ok(d));
     constexpr int lds_f32 = (A_FL + 9 * B_FL) * 4;        // 64,512 (the bf16 images fit inside)
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_f32) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_HB + 9 * B_HB)) != hipSuccess)
-            return PIVP_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static PerDeviceOnce once0, once2;
+    if (pivp_ensure_dyn_lds(once0, reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<0>), lds_f32) != PIVP_OK ||
+        pivp_ensure_dyn_lds(once2, reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<2>), 2 * (A_HB + 9 * B_HB)) != PIVP_OK)
+        return PIVP_ERR_LAUNCH;
     IgemmDesc dd = d;
     const int tpi = (d.Hin / 8) * (d.Win / 16), nb = d.N / 32;
     const int np = tpi * nb;

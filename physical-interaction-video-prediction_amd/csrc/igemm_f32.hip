@@ -528,12 +528,8 @@ static int launch_igemm(const IgemmDesc& d, hipStream_t stream, int ksplit = 1, 
     const int n_nblk = LSTM ? (d.C >> 5) : (d.N / BN);
     const int mblk = (d.M + BM - 1) / BM;
     constexpr int lds_bytes = ig_lds_bytes<WM, NTB>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_f32_kernel<WM, WN, NTB, LSTM, ABL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&igemm_f32_kernel<WM, WN, NTB, LSTM, ABL>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     dim3 grid(mblk * n_nblk, d.nphase, ksplit);
     IgemmDesc dd = d;
     // fused LayerNorm partials: only when no tile straddles two samples and the caller's buffer holds them
@@ -623,11 +619,7 @@ int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
         // because at M = 2048..8192 the block count, not the tile shape, decides: 384 blocks on 256 CUs run as 2 rounds.
         struct Tile { int wm, wn, ntb; double eff; };
         static const Tile tiles[] = {{2, 2, 2, 0.85}, {4, 1, 1, 0.70}, {4, 1, 2, 0.90}, {4, 1, 3, 0.95}, {4, 1, 4, 1.00}, {2, 2, 4, 0.95}, {1, 4, 4, 0.80}};
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        }
+        const int cus = pivp_cu_count();
         static const int force_t = [] { const char* e = getenv("PIVP_DGRAD_TILE"); return e ? atoi(e) : -1; }();   // tuning
         static const int force_k = [] { const char* e = getenv("PIVP_DGRAD_KS"); return e ? atoi(e) : 0; }();
         int bt = -1, bks = 1;

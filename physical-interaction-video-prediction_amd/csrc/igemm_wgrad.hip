@@ -407,21 +407,14 @@ static int launch_wgrad5x5(const WgradDesc& d, hipStream_t s) {
     constexpr int IMG = 5 * NTW * 32 * 33;
     constexpr int lds_floats = (4 * 2 * WBUF > 2 * IMG) ? 4 * 2 * WBUF : 2 * IMG;
     constexpr int lds_bytes = lds_floats * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad5x5_kernel<NTW, SW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&wgrad5x5_kernel<NTW, SW>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     const int tiles = 5 * (d.cin / 32) * (d.N / (32 * NTW));
     const int chunks = d.M / 32 * (d.tcount > 1 ? d.tcount : 1);
     // One block per CU is resident (~100 KB of LDS), so the grid is sized to whole rounds of the chip's CUs: the first
     // version asked for "about 512" blocks and got 520-600, i.e. a third round that ran 8-88 blocks on 256 CUs (lstm7: 264 us
     // for 171 us of MFMA work).  Take the fewest rounds (1..3) whose last round is at least 90 % full.
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    }
+    const int cus = pivp_cu_count();
     int nsplit = 1;
     double best = 0.0;
     for (int r = 1; r <= 3; ++r) {

@@ -12,6 +12,37 @@
 #define PIVP_CHECK_ARG(cond) do { if (!(cond)) return PIVP_ERR_BADARG; } while (0)
 #define PIVP_LAUNCH_STATUS() (hipGetLastError() == hipSuccess ? PIVP_OK : PIVP_ERR_LAUNCH)
 
+// ---- per-device host-side caches -----------------------------------------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize and the CU count belong to a DEVICE, and one process may drive several (Model(device=
+// 'cuda:1') after 'cuda:0'): both are remembered per hipGetDevice() index.  These tables and the PIVP_* tuning knobs read once with
+// getenv() are the library's only process-global state; they are write-once per device / per process and idempotent, so concurrent
+// first calls from several host threads are benign.  Everything else lives in the plan or in the caller's buffers.
+constexpr int PIVP_MAX_DEV = 64;
+inline int pivp_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PIVP_MAX_DEV) dev = 0;
+    return dev;
+}
+struct PerDeviceOnce { bool done[PIVP_MAX_DEV] = {}; };
+// raise a kernel's dynamic-LDS cap once per device; the return code is checked (a launch with the default 64 KB cap would fail later)
+inline int pivp_ensure_dyn_lds(PerDeviceOnce& once, const void* kernel, int bytes) {
+    const int dev = pivp_current_device();
+    if (once.done[dev]) return PIVP_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return PIVP_ERR_LAUNCH;
+    once.done[dev] = true;
+    return PIVP_OK;
+}
+inline int pivp_cu_count() {
+    static int cus[PIVP_MAX_DEV] = {};
+    const int dev = pivp_current_device();
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -201,15 +201,10 @@ bool wgrad5x5_bf16_ok(const WgradDesc& d) {
 int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s) {
     PIVP_CHECK_ARG(d.x0 && d.dy && d.dw && wgrad5x5_bf16_ok(d) && (d.c1 == 0 || d.x1) && d.wcin >= d.cin && d.wcin % 32 == 0);
     constexpr int lds_bytes = G_BYTES + X_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad5x5_bf16_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds_bytes) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad5x5_bf16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds_bytes) != hipSuccess)
-            return PIVP_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static PerDeviceOnce once16, once8;
+    if (pivp_ensure_dyn_lds(once16, reinterpret_cast<const void*>(&wgrad5x5_bf16_kernel<16>), lds_bytes) != PIVP_OK ||
+        pivp_ensure_dyn_lds(once8, reinterpret_cast<const void*>(&wgrad5x5_bf16_kernel<8>), lds_bytes) != PIVP_OK)
+        return PIVP_ERR_LAUNCH;
     const int tw = d.Wx % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
     const int n_tiles = (d.B / ti_n) * (d.Hx / 8) * (d.Wx / tw);
     const int gx = 5 * (d.cin / 32) * (d.N / 128);

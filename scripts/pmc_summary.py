@@ -64,18 +64,22 @@ def main():
         for r in mfma_busy(sys.argv[2], sys.argv[3])[:6]:
             print('%-60s launches %4d  MFMA busy fraction %.3f' % (r[0][:60], r[1], r[4]))
         return
+    bf16 = sys.argv[1] == '--bf16'       # python scripts/pmc_summary.py --bf16 <fetch_dir> <write_dir> <out_dir> [workload]
+    if bf16:
+        del sys.argv[1]
     fetch_dir, write_dir, out_dir = sys.argv[1:4]
     workload = sys.argv[4] if len(sys.argv) > 4 else ''
     fe = per_kernel(fetch_dir, 'FETCH_SIZE')
     wr = per_kernel(write_dir, 'WRITE_SIZE')
     os.makedirs(out_dir, exist_ok=True)
-    write_summary(os.path.join(out_dir, 'pmc_fetch_size_summary.csv'), fe, 'avg_FETCH_SIZE_KB')
-    write_summary(os.path.join(out_dir, 'pmc_write_size_summary.csv'), wr, 'avg_WRITE_SIZE_KB')
-    is_lstm = lambda k: 'igemm_f32_kernel' in k and 'true' in k
+    sfx = '_bf16' if bf16 else ''
+    write_summary(os.path.join(out_dir, 'pmc_fetch_size_summary%s.csv' % sfx), fe, 'avg_FETCH_SIZE_KB')
+    write_summary(os.path.join(out_dir, 'pmc_write_size_summary%s.csv' % sfx), wr, 'avg_WRITE_SIZE_KB')
+    is_lstm = (lambda k: 'convlstm_bf16_kernel' in k and 'true' in k) if bf16 else (lambda k: 'igemm_f32_kernel' in k and 'true' in k)
     nf = sum(n for k, (n, v) in fe.items() if is_lstm(k)); f_kb = sum(n * v for k, (n, v) in fe.items() if is_lstm(k)) / max(nf, 1)
     nw = sum(n for k, (n, v) in wr.items() if is_lstm(k)); w_kb = sum(n * v for k, (n, v) in wr.items() if is_lstm(k)) / max(nw, 1)
     out = {
-        'kernel': 'igemm_f32_kernel<*,*,4,true> (ConvLSTM)',
+        'kernel': 'convlstm_bf16_kernel<*,true,1> (ConvLSTM, bf16 operands)' if bf16 else 'igemm_f32_kernel<*,*,4,true> (ConvLSTM)',
         'workload': workload,
         'launches': nf,
         'fetch_size_KB_raw': f_kb,
@@ -84,7 +88,7 @@ def main():
         'note': 'separate --pmc passes (FETCH_SIZE, WRITE_SIZE); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of '
                 'wide coalesced reads; uncalibrated for this gather); Infinity-Cache hits are counted',
     }
-    json.dump(out, open(os.path.join(out_dir, 'pmc_traffic.json'), 'w'), indent=1)
+    json.dump(out, open(os.path.join(out_dir, 'pmc_traffic%s.json' % sfx), 'w'), indent=1)
     print(json.dumps(out))
 
 
