@@ -174,7 +174,19 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
         }
         if (c < c_end) mma(0);
     }
-    // acc[t][r]: row i = ci (= (r&3) + 8*(r>>2) + 4*half), column j = n (= l31); packed gradient [tap][ci/32][n][ci%32]
+    // acc[t][r]: row i = ci (= (r&3) + 8*(r>>2) + 4*half), column j = n (= l31)
+    if (d.part) {      // this block's own [64][WG_N] slot: plain read-modify-write, rows of 32 lanes are 128 contiguous bytes
+        float* pt = d.part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (64 * WG_N);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* q = pt + (wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * WG_N + wn * 32 * NT + t * 32 + l31;
+                *q += acc[t][r];
+            }
+        return;
+    }
+    // direct path: fp32 atomics into the packed gradient [tap][ci/32][n][ci%32]
     const int wtap = tap;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -187,6 +199,25 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
                 atomicAdd(g, acc[t][r]);
             }
         }
+    }
+}
+
+// dw += sum over the pixel splits of the per-block partial tiles (see WgradDesc::part).  One block per tile.
+__global__ __launch_bounds__(256) void igemm_wgrad_reduce_kernel(const WgradDesc d, int wg_n, int nsplit) {
+    const int tiles = gridDim.x;
+    const int ncb = (d.cin + WG_CI - 1) / WG_CI, nnb = (d.N + wg_n - 1) / wg_n;
+    int bid = blockIdx.x;
+    const int nb = bid % nnb; bid /= nnb;
+    const int cb = bid % ncb; bid /= ncb;
+    const int tap = bid;
+    const int tile_floats = 64 * wg_n;
+    for (int e = threadIdx.x; e < tile_floats; e += 256) {
+        const int row = e / wg_n, col = e - row * wg_n;
+        const int ci = cb * WG_CI + row, n = nb * wg_n + col;
+        if (ci >= d.cin || n >= d.N) continue;
+        float sum = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) sum += d.part[((size_t)sp * tiles + blockIdx.x) * tile_floats + e];
+        d.dw[(((size_t)tap * (d.wcin >> 5) + (ci >> 5)) * d.N + n) * 32 + (ci & 31)] += sum;
     }
 }
 
@@ -430,29 +461,55 @@ static int launch_wgrad5x5(const WgradDesc& d, hipStream_t s) {
     return PIVP_LAUNCH_STATUS();
 }
 
+static bool takes_fast_path(const WgradDesc& d) {
+    return !d.deconv && d.ksize == 5 && d.pad == 2 && d.stride == 1 && d.M % 32 == 0 && d.N % 64 == 0 &&
+           (d.Wg == 8 || d.Wg == 16 || d.Wg % 32 == 0) && d.Hx == d.Hy && d.Wx == d.Wy;
+}
+// grid of the generic kernel: a function of the descriptor alone, so a launch, its partial buffer and its reduction agree
+static void generic_grid(const WgradDesc& d, int& wg_n, int& tiles, int& nsplit) {
+    wg_n = d.N <= 64 ? 64 : 128;
+    const int ncb = (d.cin + WG_CI - 1) / WG_CI, nnb = (d.N + wg_n - 1) / wg_n;
+    tiles = d.ksize * d.ksize * ncb * nnb;
+    const int chunks = (d.M + WG_PIX - 1) / WG_PIX * (d.tcount > 1 ? d.tcount : 1);
+    // direct path: every block ends with a tile of atomics (64 x 128), so no more pixel splits than fill the chip twice (3 blocks fit a
+    // CU) and >= 8 chunks (256 pixels) per block (enc4 with 4: 63 -> 94 us, atomics); kept for the partial-sum path, where a split
+    // costs 16-32 KB of traffic instead
+    nsplit = (512 + tiles - 1) / tiles;
+    if (nsplit > chunks / 8) nsplit = chunks / 8;
+    if (nsplit < 1) nsplit = 1;
+}
+
 int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done) {
     if (bias_done) *bias_done = 0;
     PIVP_CHECK_ARG(d.x0 && d.dy && d.dw && d.c0 > 0 && d.c0 % 32 == 0 && d.c1 >= 0 && d.c1 % 32 == 0 && (d.c1 == 0 || d.x1));
     PIVP_CHECK_ARG(d.cin == d.c0 + d.c1 && d.wcin >= d.cin && d.wcin % 32 == 0 && d.N > 0 && d.N % 32 == 0);
     PIVP_CHECK_ARG(d.M == d.B * d.Hg * d.Wg && d.M > 0 && d.ksize >= 1 && d.ksize <= 7);
     PIVP_CHECK_ARG(d.bytes0 > 0 && d.bytesy > 0 && (d.c1 == 0 || d.bytes1 > 0));
-    if (!d.deconv && d.ksize == 5 && d.pad == 2 && d.stride == 1 && d.M % 32 == 0 && d.N % 64 == 0 &&
-        (d.Wg == 8 || d.Wg == 16 || d.Wg % 32 == 0) && d.Hx == d.Hy && d.Wx == d.Wy) {
+    if (takes_fast_path(d)) {
         if (bias_done) *bias_done = d.db ? 1 : 0;
         if (d.Wg == 8) return launch_wgrad5x5<2, 8>(d, s);
         if (d.Wg == 16) return launch_wgrad5x5<2, 16>(d, s);
         return launch_wgrad5x5<2, 32>(d, s);
     }
-    const int wg_n = d.N <= 64 ? 64 : 128;
-    const int ncb = (d.cin + WG_CI - 1) / WG_CI, nnb = (d.N + wg_n - 1) / wg_n;
-    const int tiles = d.ksize * d.ksize * ncb * nnb;
-    const int chunks = (d.M + WG_PIX - 1) / WG_PIX * (d.tcount > 1 ? d.tcount : 1);
-    // every block ends with a tile of atomics (64 x 128), so no more pixel splits than fill the chip twice (3 blocks fit a CU)
-    int nsplit = (512 + tiles - 1) / tiles;
-    if (nsplit > chunks / 8) nsplit = chunks / 8;         // and >= 8 chunks (256 pixels) per block (enc4 with 4: 63 -> 94 us, atomics)
-    if (nsplit < 1) nsplit = 1;
+    int wg_n, tiles, nsplit;
+    generic_grid(d, wg_n, tiles, nsplit);
     if (wg_n == 64) hipLaunchKernelGGL(igemm_wgrad_kernel<1>, dim3(tiles, nsplit), dim3(256), 0, s, d);
     else hipLaunchKernelGGL(igemm_wgrad_kernel<2>, dim3(tiles, nsplit), dim3(256), 0, s, d);
+    return PIVP_LAUNCH_STATUS();
+}
+
+long long igemm_wgrad_part_floats(const WgradDesc& d) {
+    if (takes_fast_path(d)) return 0;
+    int wg_n, tiles, nsplit;
+    generic_grid(d, wg_n, tiles, nsplit);
+    return (long long)tiles * nsplit * 64 * wg_n;
+}
+
+int igemm_wgrad_reduce(const WgradDesc& d, hipStream_t s) {
+    PIVP_CHECK_ARG(d.part && d.dw && !takes_fast_path(d));
+    int wg_n, tiles, nsplit;
+    generic_grid(d, wg_n, tiles, nsplit);
+    hipLaunchKernelGGL(igemm_wgrad_reduce_kernel, dim3(tiles), dim3(256), 0, s, d, wg_n, nsplit);
     return PIVP_LAUNCH_STATUS();
 }
 

@@ -115,7 +115,7 @@ int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb,
 // weight gradient of: mode 0 = conv K x K stride `stride` pad `pad`; mode 1 = transposed 3x3 s2 p1
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
               float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s, float* db,
-              int* bias_done, int bf16, int tcount, long long ts_x0, long long ts_x1, long long ts_dy) {
+              int* bias_done, int bf16, int tcount, long long ts_x0, long long ts_x1, long long ts_dy, float* part, WgradDesc* desc_out) {
     WgradDesc d;
     memset(&d, 0, sizeof(d));
     d.x0 = x0; d.c0 = c0; d.ld0 = ld0; d.x1 = x1; d.c1 = x1 ? c1 : 0; d.ld1 = ld1; d.cin = c0 + (x1 ? c1 : 0); d.wcin = wcin;
@@ -128,6 +128,8 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
     d.bytes0 = (int)b0; d.bytes1 = (int)b1; d.bytesy = (int)by;
     d.db = db;
     d.tcount = tcount; d.ts_x0 = ts_x0; d.ts_x1 = ts_x1; d.ts_dy = ts_dy;
+    d.part = part;
+    if (desc_out) *desc_out = d;
     if (bf16) {   // bf16 precision mode (5x5 ConvLSTM case only): operands rounded to bf16, fp32 accumulation; db summed on the side in fp32
         if (bias_done) *bias_done = db != nullptr;
         return wgrad5x5_bf16(d, s);
@@ -213,7 +215,7 @@ int run_select_frames(const float* gt, const float* gen, const unsigned char* ta
 // conv3x3s2 (mode 0) / deconv3x3s2 (mode 1) backward.  dy is masked in place by (y > 0) when y != null (fused ReLU).
 int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w, float* dy, int cout, int ldy, const float* y, int ldyy,
                       float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, hipStream_t s,
-                      int wt_ready, const SideFork* fork) {
+                      int wt_ready, const SideFork* fork, float* part, WgradDesc* desc_out) {
     const int Hout = mode ? 2 * Hin : Hin / 2, Wout = mode ? 2 * Win : Win / 2;
     int rc = PIVP_OK;
     if (y) { rc = relu_mask(dy, ldy, y, ldyy, cout, (long)B * Hout * Wout, s); if (rc != PIVP_OK) return rc; }
@@ -229,11 +231,22 @@ int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w
                   : run_deconv3x3s2(dy, cout, ldy, wt, nullptr, dx, cin, lddx, 0, B, Hout, Wout, s, accum_dx);
         if (rc != PIVP_OK) return rc;
     }
-    rc = run_wgrad(mode, x, cin, ldx, nullptr, 0, 0, cin, dy, ldy, cout, dW, B, Hin, Win, Hout, Wout, 3, 1, 2, sw);
+    rc = run_wgrad(mode, x, cin, ldx, nullptr, 0, 0, cin, dy, ldy, cout, dW, B, Hin, Win, Hout, Wout, 3, 1, 2, sw, nullptr, nullptr, 0,
+                   1, 0, 0, 0, part, desc_out);
     if (rc != PIVP_OK) return rc;
     rc = bias_grad(dy, ldy, cout, B * Hout * Wout, db, sw);
     if (rc != PIVP_OK) return rc;
     return fork_end(fork);
+}
+
+long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin, int Win) {
+    const int Hout = mode ? 2 * Hin : Hin / 2, Wout = mode ? 2 * Win : Win / 2;
+    WgradDesc d;
+    memset(&d, 0, sizeof(d));
+    d.c0 = cin; d.cin = cin; d.wcin = cin; d.N = cout; d.B = B; d.Hx = Hin; d.Wx = Win; d.Hy = Hout; d.Wy = Wout;
+    d.deconv = mode; d.ksize = 3; d.pad = 1; d.stride = 2;
+    d.Hg = mode ? Hin : Hout; d.Wg = mode ? Win : Wout; d.M = B * d.Hg * d.Wg;
+    return igemm_wgrad_part_floats(d);
 }
 
 }  // namespace pivp

@@ -20,7 +20,8 @@ int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, in
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
               float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s,
               float* db = nullptr, int* bias_done = nullptr, int bf16 = 0,
-              int tcount = 1, long long ts_x0 = 0, long long ts_x1 = 0, long long ts_dy = 0);   // a batch of timesteps: WgradDesc
+              int tcount = 1, long long ts_x0 = 0, long long ts_x1 = 0, long long ts_dy = 0,    // a batch of timesteps: WgradDesc
+              float* part = nullptr, WgradDesc* desc_out = nullptr);   // part: WgradDesc::part; desc_out: the descriptor that was launched
 // Where the WEIGHT-gradient half of a conv backward runs.  A weight gradient feeds nothing but the optimizer, while the data gradient
 // is on the backward sweep's critical path: with a fork the weight (and bias) gradient kernels are enqueued on `side` behind `ready`
 // (recorded on the main stream as soon as dY is final) and `done` is recorded behind them; the caller makes whoever next overwrites
@@ -38,7 +39,9 @@ int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb,
                      int B, int H, int W, hipStream_t s, int planes = 1);
 int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w, float* dy, int cout, int ldy, const float* y, int ldyy,
                       float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, hipStream_t s,
-                      int wt_ready = 0, const SideFork* fork = nullptr);
+                      int wt_ready = 0, const SideFork* fork = nullptr, float* part = nullptr, WgradDesc* desc_out = nullptr);
+// floats of WgradDesc::part a conv3x3s2 (mode 0) / deconv3x3s2 (mode 1) weight gradient of these sizes needs
+long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin, int Win);
 int run_layernorm(const float* x, const float* g, const float* b, float* out, float* partials, int B, int n, int C,
                   int ldo, float eps, int relu, hipStream_t s, float* stat_out = nullptr, int fused_nparts = 0);
 int run_select_frames(const float* gt, const float* gen, const unsigned char* take, float* out, int B, int frame_numel, hipStream_t s);

@@ -56,8 +56,15 @@ struct WgradDesc {
     // 0 / 1 = a single timestep.  Fewer, longer launches: one block epilogue (LDS reduction + atomics) per batch instead of per step.
     int tcount;
     long long ts_x0, ts_x1, ts_dy;
+    // Generic kernel only: per-block partial sums instead of atomics.  Every (tile, pixel-split) block owns one [64][64 or 128] slot of
+    // `part` (igemm_wgrad_part_floats(d) floats, zeroed by the caller before the first launch) and adds its tile into it with plain
+    // loads and stores; igemm_wgrad_reduce(d) then sums the splits into dw.  The scattered atomics of the direct path cost 54 of the
+    // 85 us of an enc5 / enc6 launch (64 adds per address from 500 blocks).  The launches that share a slot must be stream-ordered.
+    float* part;
 };
 int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done = nullptr);
+long long igemm_wgrad_part_floats(const WgradDesc& d);    // 0 when the ConvLSTM fast path would take this descriptor
+int igemm_wgrad_reduce(const WgradDesc& d, hipStream_t s);   // dw += sum over the splits of d.part
 // bf16-operand form of the ConvLSTM weight gradient (csrc/wgrad_bf16.hip); the bias gradient is left to bias_grad
 bool wgrad5x5_bf16_ok(const WgradDesc& d);
 int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s);

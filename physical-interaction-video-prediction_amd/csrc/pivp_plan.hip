@@ -63,6 +63,7 @@ struct Grads {   // gradient workspace (single copy, reused by every timestep of
     size_t hln[7], din[7][2], dc[7];
     size_t dG[7], go[2], dmk, dz, dkpart, dv, dstate, lnpart;   // dG: gate pre-activation gradients per ConvLSTM: 2 rings x WG_BATCH timesteps (batched weight gradients)
     size_t wt_lstm[7], wt_enc[7];   // re-packed (transposed) weights for the data gradients, rebuilt once per backward
+    size_t wg_part[5], wg_part_floats;   // per-block partial weight gradients of enc6, enc5, enc4, enc2, enc1 (WgradDesc::part), one contiguous region
     size_t wtb_lstm[7];             // ... and their bf16 packs (bf16 precision mode)
 };
 
@@ -105,6 +106,7 @@ struct pivp_plan {
     hipEvent_t ev_ring_done[7][2] = {};        // ConvLSTM slots: one `done` per dG ring (slots 0..6 of ev_done are unused)
     int wg_batch = 1;                          // timesteps per weight-gradient launch (<= WG_BATCH; always 1 in the bf16 mode, whose kernel takes one)
     const float* wg_x[7] = {}; const float* wg_h[7] = {};   // operands of the first timestep of the open batch
+    WgradDesc enc_desc[5]; bool enc_desc_valid[5] = {};     // enc6, enc5, enc4, enc2, enc1: what this sweep launched (for the reduction of the partial sums)
     ~pivp_plan() {
         for (int i = 0; i < 7; ++i) for (int r = 0; r < 2; ++r) if (ev_ring_done[i][r]) (void)hipEventDestroy(ev_ring_done[i][r]);
         for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
@@ -222,6 +224,16 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
         g.dkpart = carve((size_t)B * composite_bwd_tiles(H, W) * 256); g.dv = carve((size_t)B * 256);
         g.dstate = carve((size_t)T * B * 5);
         g.lnpart = carve((size_t)B * ln_bwd_slices((int)(64 * HW)) * 2);
+        {   // slots 7..11 = enc6, enc5, enc4 (transposed, anchors = their INPUT maps), enc2, enc1 (stride-2 convs)
+            const int mode[5] = {1, 1, 1, 0, 0}, ci[5] = {64, 96, 128, 64, 32};
+            const int hin[5] = {p->H2, p->H4, p->H8, p->H4, p->H2}, win[5] = {p->W2, p->W4, p->W8, p->W4, p->W2};
+            g.wg_part_floats = 0;
+            for (int k = 0; k < 5; ++k) {
+                const size_t n = (size_t)conv_backward_part_floats(mode[k], ci[k], ci[k], B, hin[k], win[k]);
+                g.wg_part[k] = carve(n);
+                g.wg_part_floats = g.wg_part[k] + n - g.wg_part[0];      // carve() aligns: measure the region, not the sum
+            }
+        }
     }
     p->ws_floats = (long long)off;
     *out = p;
@@ -565,19 +577,33 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         // group 6 (TM:601), reversed: norm_enc6 (+relu) <- enc6 deconv <- [hidden7 | enc0]
         RC(lnb(8, ws + g.e6, 64, ws + S.e6, 64, ws + S.e6raw, ws + g.e6raw, 64 * HW, 64, 1));
         RC(run_conv_backward(1, ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), ws + g.e6raw, 64, 64, nullptr, 0, ws + g.wt_enc[6], ws + g.cat7, 64, 0,
-                             G(p, p->i_enc_w[6]), G(p, p->i_enc_b[6]), B, p->H2, p->W2, s, 1, fork_of(7, fe)));
+                             G(p, p->i_enc_w[6]), G(p, p->i_enc_b[6]), B, p->H2, p->W2, s, 1, fork_of(7, fe), ws + g.wg_part[0], &p->enc_desc[0]));
+    p->enc_desc_valid[0] = true;
     } else {
         // no gradient reaches this step's frame: only the recurrent paths are live
         if (hipMemsetAsync(ws + g.cat7, 0, (size_t)px2 * 64 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
         if (hipMemsetAsync(ws + g.n5, 0, (size_t)px8 * 128 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     }
+    // enc conv k's partial weight-gradient sums -> its gradient (once per sweep, behind its last weight-gradient launch)
+    auto reduce_enc = [&](int k) -> int {
+        if (!p->enc_desc_valid[k]) return PIVP_OK;
+        p->enc_desc_valid[k] = false;
+        hipStream_t sw = p->side ? p->side : s;
+        RC(igemm_wgrad_reduce(p->enc_desc[k], sw));
+        if (p->side && hipEventRecord(p->ev_done[7 + k], p->side) != hipSuccess) return PIVP_ERR_LAUNCH;
+        return PIVP_OK;
+    };
     // t = 0 is the sweep's final timestep: a gradient group is final once the side stream's weight gradients of its layers are in too
     auto done = [&](int group) -> int {
+        if (t == 0 && !p->grad_cb) {       // no listener: still turn the group's partial sums into gradients
+            static const int encs[6][1] = {{0}, {-1}, {1}, {2}, {3}, {4}};
+            if (encs[group][0] >= 0) RC(reduce_enc(encs[group][0]));
+        }
         if (t != 0 || !p->grad_cb) return PIVP_OK;
         static const int slots[6][3] = {{7, -1, -1}, {6, -1, -1}, {8, 5, -1}, {9, 4, -1}, {10, 3, 2}, {11, 1, 0}};
         for (int k = 0; k < 3; ++k) {
             const int sl = slots[group][k];
-            if (sl >= 7) RC(join(sl));
+            if (sl >= 7) { RC(reduce_enc(sl - 7)); RC(join(sl)); }
             else if (sl >= 0 && p->side)
                 for (int r = 0; r < 2; ++r) if (hipStreamWaitEvent(s, p->ev_ring_done[sl][r], 0) != hipSuccess) return PIVP_ERR_LAUNCH;
         }
@@ -590,13 +616,15 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(done(1));
     // group 5 (TM:600): d e5 = x-part of lstm7's d_in (ReLU fused in enc5) <- enc5 deconv <- [hidden6 | enc1]
     RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ws + S.e5, 96, ws + g.wt_enc[5], ws + g.cat6, 96, 0,
-                         G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1, fork_of(8, fe)));
+                         G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1, fork_of(8, fe), ws + g.wg_part[1], &p->enc_desc[1]));
+    p->enc_desc_valid[1] = true;
     RC(lnb_cell(5, ws + g.cat6, 96, n4, 64));
     RC(lstmb(5, ws + S.e4, 128, p->H4, p->W4));
     RC(done(2));
     // group 4 (TM:599): d e4 = x-part of lstm6's d_in <- enc4 deconv <- hidden5 (also read by the CDNA kernel generator)
     RC(run_conv_backward(1, ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), ws + g.din[5][par], 128, 192, ws + S.e4, 128, ws + g.wt_enc[4], ws + g.n5, 128, 1,
-                         G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s, 1, fork_of(9, fe)));
+                         G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s, 1, fork_of(9, fe), ws + g.wg_part[2], &p->enc_desc[2]));
+    p->enc_desc_valid[2] = true;
     RC(lnb_cell(4, ws + g.n5, 128, n8, 128));
     RC(lstmb(4, ws + S.e3, 64, p->H8, p->W8));
     RC(done(3));
@@ -607,7 +635,8 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                       B, p->H8 * p->W8, c.use_state, s));
     // group 2 (TM:597): enc2 conv (ReLU) <- hidden4 <- lstm4 <- hidden3 <- lstm3 <- enc1
     RC(run_conv_backward(0, ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), ws + g.e2, 64, 64, ws + S.e2, 64, ws + g.wt_enc[2], ws + g.n4, 64, 0,
-                         G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s, 1, fork_of(10, fe)));
+                         G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s, 1, fork_of(10, fe), ws + g.wg_part[3], &p->enc_desc[3]));
+    p->enc_desc_valid[3] = true;
     RC(lnb_cell(3, ws + g.n4, 64, n4, 64));
     RC(lstmb(3, ws + S.n3, 64, p->H4, p->W4));
     RC(lnb_cell(2, ws + g.din[3][par], 128, n4, 64));
@@ -616,7 +645,8 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(add_strided(ws + g.cat6 + 64, 96, ws + g.din[2][par], 96, 32, px4, s));          // d enc1: from enc5's concat + from lstm3
     // group 1 (TM:596): enc1 conv (ReLU) <- hidden2 <- lstm2 <- hidden1 <- lstm1 <- enc0
     RC(run_conv_backward(0, ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), ws + g.cat6 + 64, 32, 96, ws + S.cat6 + 64, 96, ws + g.wt_enc[1], ws + g.n2, 32, 0,
-                         G(p, p->i_enc_w[1]), G(p, p->i_enc_b[1]), B, p->H2, p->W2, s, 1, fork_of(11, fe)));
+                         G(p, p->i_enc_w[1]), G(p, p->i_enc_b[1]), B, p->H2, p->W2, s, 1, fork_of(11, fe), ws + g.wg_part[4], &p->enc_desc[4]));
+    p->enc_desc_valid[4] = true;
     RC(lnb_cell(1, ws + g.n2, 32, n2, 32));
     RC(lstmb(1, ws + S.n1, 32, p->H2, p->W2));
     RC(lnb_cell(0, ws + g.din[1][par], 64, n2, 32));
@@ -652,6 +682,9 @@ extern "C" int pivp_rollout_backward(pivp_plan_t* plan, const float* images, con
         if (gb > WG_BATCH) gb = WG_BATCH;
         plan->wg_batch = plan->bf16_all ? 1 : gb;
     }
+    // the enc convs' per-block partial weight gradients start from zero every sweep
+    if (hipMemsetAsync(ws + g.wg_part[0], 0, g.wg_part_floats * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
+    for (int k = 0; k < 5; ++k) plan->enc_desc_valid[k] = false;
     // d loss / d gen_states[t] for every t (zero before ctx-1), later accumulated with the state recurrence
     if (hipMemsetAsync(ws + g.dstate, 0, (size_t)T * B * 5 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     for (int t = ctx - 1; t < T - 1; ++t)
