@@ -426,7 +426,12 @@ __global__ __launch_bounds__(256, 1) void wgrad5x5_kernel(const WgradDesc d) {
         const int kx = t / NTW, tt = t - kx * NTW;
         const int tap = ky * 5 + kx;
         float* g = d.dw + (((size_t)tap * (d.wcin >> 5) + cb) * d.N + n0 + tt * 32 + n) * 32 + ci;
+#ifdef PIVP_WG_NOATOMIC   // timing-only ablation (results wrong): these contiguous atomics cost 2 % of the kernel (160 -> 157 us on lstm7), unlike the
+                          // generic kernel's scattered ones (85 -> 31 us), which is why only that one got per-block partial sums
+        if (sm[t * IT + n * 33 + ci] == 12345.678f) *g = 1.f;
+#else
         atomicAdd(g, sm[t * IT + n * 33 + ci]);
+#endif
     }
     // bias gradient for free: the kernel-row 0 / channel-block 0 blocks have every dY pixel of their chunks in LDS... not kept; see bias_grad
 }
