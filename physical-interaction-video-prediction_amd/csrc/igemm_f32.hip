@@ -603,6 +603,44 @@ int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant, int* ln_npar
 }
 
 // Plain conv / transposed conv: pick the block tile that fills the 256 CUs.  Blocks = (M/BM) * (N/BN) * phases.
+// Long-K data gradients (the ConvLSTM's 5x5 over 4C channels).  The output may be produced by K-split blocks with atomic adds into a
+// pre-zeroed destination, so both the tile AND the split are free: pick the pair with the least modelled time
+//   rounds(blocks over the CUs) x rows-per-split x tile area / tile efficiency  (+ a per-block constant),
+// because at M = 2048..8192 the block count, not the tile shape, decides: 384 blocks on 256 CUs run as 2 rounds.
+// Returns false when the descriptor is not such a conv.  ks == 1: plain stores, the destination need not be zeroed.
+static bool dgrad_choice(const IgemmDesc& d, int& bt, int& bks) {
+    if (!(d.ksplit_ok && !d.deconv && !d.bias && !d.relu && !d.accum && d.ksize * d.ksize * ((d.c0 + d.c1) / 32) > 40)) return false;
+    const int nt = d.N / 32;
+    struct Tile { int wm, wn, ntb; double eff; };
+    static const Tile tiles[] = {{2, 2, 2, 0.85}, {4, 1, 1, 0.70}, {4, 1, 2, 0.90}, {4, 1, 3, 0.95}, {4, 1, 4, 1.00}, {2, 2, 4, 0.95}, {1, 4, 4, 0.80}};
+    const int cus = pivp_cu_count();
+    static const int force_t = [] { const char* e = getenv("PIVP_DGRAD_TILE"); return e ? atoi(e) : -1; }();   // tuning
+    static const int force_k = [] { const char* e = getenv("PIVP_DGRAD_KS"); return e ? atoi(e) : 0; }();
+    bt = -1; bks = 1;
+    double bcost = 1e300;
+    for (int t = 0; t < 7; ++t) {
+        if (nt % tiles[t].ntb) continue;
+        if (force_t >= 0 && t != force_t) continue;
+        const int bm = 32 * tiles[t].wm, bn = 32 * tiles[t].ntb;
+        const long mb = (d.M + bm - 1) / bm, nb = d.N / bn;
+        for (int ks = 1; ks <= d.ksize; ++ks) {
+            if (force_k > 0 && ks != force_k) continue;
+            const long blocks = mb * nb * ks;
+            const long rounds = (blocks + cus - 1) / cus;
+            const int rows = (d.ksize + ks - 1) / ks;                   // kernel rows of the largest split
+            const double work = (double)bm * bn * (rows * d.ksize + 1.5) / tiles[t].eff;   // +1.5 taps: prologue / epilogue
+            // one resident block per CU hides no latency (lstm4, 64x64 tiles: 256 blocks 151 us, 2 x 256 K-split blocks 139)
+            const double cost = rounds * work * (ks > 1 ? 1.03 : 1.0) / (rounds >= 2 ? 1.0 : 0.75);
+            if (cost < bcost) { bcost = cost; bt = t; bks = ks; }
+        }
+    }
+    return bt >= 0;
+}
+int igemm_conv_ksplit(const IgemmDesc& d) {
+    int bt, bks;
+    return dgrad_choice(d, bt, bks) ? bks : 1;
+}
+
 int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     int rc = igemm_validate(d, false);
     if (rc != PIVP_OK) return rc;
@@ -612,34 +650,8 @@ int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
         (long)d.B * (d.Hin / 8) * (d.Win / 16) * nt >= 16)
         return deconv_tile(d, stream, ln_nparts, d.bf16);
     const long full = (long)((d.M + 127) / 128) * d.nphase;   // blocks with BM = 128 and the whole N in one block
-    if (d.ksplit_ok && !d.deconv && !d.bias && !d.relu && !d.accum && d.ksize * d.ksize * ((d.c0 + d.c1) / 32) > 40) {
-        // Long-K data gradients (the ConvLSTM's 5x5 over 4C channels).  The output is pre-zeroed and may be produced by K-split
-        // blocks with atomic adds, so both the tile AND the split are free: pick the pair with the least modelled time
-        //   rounds(blocks over the CUs) x rows-per-split x tile area / tile efficiency  (+ a per-block constant),
-        // because at M = 2048..8192 the block count, not the tile shape, decides: 384 blocks on 256 CUs run as 2 rounds.
-        struct Tile { int wm, wn, ntb; double eff; };
-        static const Tile tiles[] = {{2, 2, 2, 0.85}, {4, 1, 1, 0.70}, {4, 1, 2, 0.90}, {4, 1, 3, 0.95}, {4, 1, 4, 1.00}, {2, 2, 4, 0.95}, {1, 4, 4, 0.80}};
-        const int cus = pivp_cu_count();
-        static const int force_t = [] { const char* e = getenv("PIVP_DGRAD_TILE"); return e ? atoi(e) : -1; }();   // tuning
-        static const int force_k = [] { const char* e = getenv("PIVP_DGRAD_KS"); return e ? atoi(e) : 0; }();
-        int bt = -1, bks = 1;
-        double bcost = 1e300;
-        for (int t = 0; t < 7; ++t) {
-            if (nt % tiles[t].ntb) continue;
-            if (force_t >= 0 && t != force_t) continue;
-            const int bm = 32 * tiles[t].wm, bn = 32 * tiles[t].ntb;
-            const long mb = (d.M + bm - 1) / bm, nb = d.N / bn;
-            for (int ks = 1; ks <= d.ksize; ++ks) {
-                if (force_k > 0 && ks != force_k) continue;
-                const long blocks = mb * nb * ks;
-                const long rounds = (blocks + cus - 1) / cus;
-                const int rows = (d.ksize + ks - 1) / ks;                   // kernel rows of the largest split
-                const double work = (double)bm * bn * (rows * d.ksize + 1.5) / tiles[t].eff;   // +1.5 taps: prologue / epilogue
-                // one resident block per CU hides no latency (lstm4, 64x64 tiles: 256 blocks 151 us, 2 x 256 K-split blocks 139)
-                const double cost = rounds * work * (ks > 1 ? 1.03 : 1.0) / (rounds >= 2 ? 1.0 : 0.75);
-                if (cost < bcost) { bcost = cost; bt = t; bks = ks; }
-            }
-        }
+    int bt = -1, bks = 1;
+    if (dgrad_choice(d, bt, bks)) {
         switch (bt) {
             case 0: return launch_igemm<2, 2, 2, false>(d, stream, bks, ln_nparts);
             case 1: return launch_igemm<4, 1, 1, false>(d, stream, bks, ln_nparts);

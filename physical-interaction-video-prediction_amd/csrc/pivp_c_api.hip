@@ -86,9 +86,9 @@ int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, in
     if (!fits31(b0) || !fits31(bw)) return PIVP_ERR_BADARG;
     d.bytes0 = (int)b0; d.bytesw = (int)bw;
     d.out_step = 1; d.Hout = H; d.Wout = W; d.out = out; d.ldo = ldo; d.relu = 0; d.accum = accum;
-    if (!accum && ldo == cout) {     // contiguous fresh output: allow the K-split path (needs a zeroed destination)
-        if (hipMemsetAsync(out, 0, (size_t)B * H * W * cout * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
+    if (!accum && ldo == cout) {     // contiguous fresh output: allow the K-split path, which needs a zeroed destination
         d.ksplit_ok = 1;
+        if (igemm_conv_ksplit(d) > 1 && hipMemsetAsync(out, 0, (size_t)B * H * W * cout * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     }
     return igemm_conv(d, s);
 }

@@ -73,6 +73,7 @@ int repack_transpose(const float* w, float* wt, int taps, int cin, int N, int fl
 // ln_nparts (optional): receives the number of LayerNorm partials per sample the launch writes to d.ln_part (0: none)
 int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant = 0, int* ln_nparts = nullptr);  // 0 auto, 1: 4x1 waves, 2: 2x2, 3: 1x4
 int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr);
+int igemm_conv_ksplit(const IgemmDesc& d);   // the K split igemm_conv will use for d (> 1: atomics into a destination the caller must zero)
 int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr);
 // transposed 3x3 s2 conv, all four output parities per block (csrc/deconv_tile.hip); d validated by igemm_validate
 bool deconv_tile_ok(const IgemmDesc& d);
