@@ -315,6 +315,7 @@ def main(argv=None):
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
+        barrier()                      # rank 0 was still measuring (roofline pass): every rank leaves the group together
         dist.destroy_process_group()
 
 

@@ -276,3 +276,39 @@ def test_batched_weight_gradients_match_per_step(pivp, monkeypatch):
     for key, g in outs.items():
         rel = float((g - ref).norm() / ref.norm())
         assert rel < 2e-5, (key, rel)
+
+
+def test_two_process_data_parallel_step(pivp, tmp_path):
+    """Two real ranks (processes) on the one GPU, gloo for the collective: after one optimizer.update with the overlapped per-group
+    all-reduce both replicas hold the same parameters, and they are the parameters of a single-process step on the global batch."""
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['OMP_NUM_THREADS'] = '4'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'tests', 'dp_worker.py'), str(tmp_path)]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:]
+    r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
+    assert list(r0['issued']) == [0, 1, 2, 3, 4, 5] and list(r1['issued']) == [0, 1, 2, 3, 4, 5]
+    assert np.array_equal(r0['grads'], r1['grads'])                 # the same summed gradient on both ranks, bit for bit
+    assert np.array_equal(r0['params'], r1['params'])
+    # single process, global batch: loss = mean of the shard losses, gradient = mean of the shard gradients
+    P = R.init_params(seed=1, dtype=np.float32, scale=1.0)
+    imgs, acts, stas = R.synthetic_batch(4, 5)
+    m = pivp.Model(10, prefix='dp', keep_activations=True)
+    m.load_state_dict_reference(P)
+    opt = pivp.Adam(alpha=0.001).setup(m)
+    with pivp.using_config('train', True):
+        loss = float(opt.update(m, [imgs, acts, stas], 0))
+    assert abs(loss - 0.5 * (float(r0['loss']) + float(r1['loss']))) < 1e-6
+    g = m._flat_grads.cpu().numpy()
+    rel = np.linalg.norm(0.5 * r0['grads'] - g) / np.linalg.norm(g)
+    print('2-process DP vs single-process global batch: relative gradient difference %.2e' % rel)
+    assert rel < 1e-4                                                # other batch size, other tiles and summation order
+    dpar = np.abs(r0['params'] - m._flat_params.cpu().numpy()).max()
+    assert dpar <= 2.001e-3                                          # Adam's first step is +-alpha per element: a sign flip of a ~0 gradient costs 2 alpha
+    frac = float(np.mean(np.abs(r0['params'] - m._flat_params.cpu().numpy()) > 1e-4))
+    assert frac < 2e-3
