@@ -77,6 +77,11 @@ def build_parser():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='collective backend of the ranks: nccl = RCCL over xGMI (the product); gloo stages device tensors through the host')
+    ap.add_argument('--share-gpu', action='store_true',
+                    help='rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo: RCCL refuses two ranks on one device). '
+                         'Real kernels and the real data-parallel step; the numbers are NOT a multi-GPU measurement.')
     ap.add_argument('--dry', action='store_true',
                     help='host logic only: gloo on CPU, stub kernels (HostStubModel); exercises the launcher, the rank bookkeeping, the '
                          'barrier / max-over-ranks timing and the overlapped all-reduce without a GPU.  Not a measurement.')
@@ -150,6 +155,10 @@ def main(argv=None):
     if not dry:
         if not torch.cuda.is_available():
             raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+        if args.share_gpu:
+            if args.backend != 'gloo' and world > 1:
+                raise SystemExit('bench.py: --share-gpu needs --backend gloo')
+            local_rank = 0
         if torch.cuda.device_count() <= local_rank:
             raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
@@ -158,7 +167,7 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if dry:
+        if dry or args.backend == 'gloo':
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=torch.device(dev))
@@ -297,7 +306,8 @@ def main(argv=None):
             'vs_baseline': None,
             'dtype': {'fp32': 'f32', 'bf16': 'bf16 ConvLSTM operands, f32 accumulate and elsewhere',
                       'bf16x3': 'f32 operands of the ConvLSTM forward as 2 bf16 pieces (3 bf16 MFMAs per product), f32 accumulate and elsewhere'}[args.precision],
-            'data': 'synthetic' if not dry else 'none: --dry run of the host logic on CPU (gloo, stub kernels); NOT a measurement',
+            'data': ('synthetic' if not args.share_gpu else 'synthetic; REHEARSAL: %d ranks share one GPU over gloo, not a multi-GPU measurement' % world)
+                    if not dry else 'none: --dry run of the host logic on CPU (gloo, stub kernels); NOT a measurement',
             'config': {'workload': '%s %s, batch %d/GPU, %d-frame %dx%dx3 sequences, action-conditioned, num_masks=%d, '
                                    'random-init weights' % (args.model, 'train step (optimizer.update: forward + BPTT backward + grad '
                                    'all-reduce + Adam, schedsamp_k=-1)' if train_mode else 'rollout forward (Model.__call__, feed-self)',

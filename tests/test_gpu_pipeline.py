@@ -78,3 +78,21 @@ def test_train_checkpoint_resume_predict(pivp, tmp_path):
     loss, frames = Pm.predict(args)
     assert frames.shape == (3, 3, 64, 64) and frames.dtype == np.uint8 and np.isfinite(loss)
     assert frames.reshape(3, -1).min(axis=1).tolist() == [0, 0, 0] and frames.reshape(3, -1).max(axis=1).tolist() == [255, 255, 255]
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu(pivp):
+    """`python bench.py --gpus 2` as the driver types it, except that both ranks share this box's one GPU (--share-gpu, gloo): the
+    launcher, the rank bookkeeping, both legs with real kernels and the data-parallel step with its overlapped all-reduce."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--share-gpu', '--batch', '4',
+                        '--steps', '2', '--warmup', '1', '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 8 and 'REHEARSAL' in out['data']
+    assert out['value'] > 0 and out['roofline']['frac'] > 0
+    tr = out['train']
+    assert tr['rccl_ranks'] == 2 and tr['backend'] == 'gloo' and tr['ms_per_step'] > 0 and tr['ms_per_step_without_allreduce'] > 0
+    assert np.isfinite(tr['loss']) and np.isfinite(out['config']['loss'])
