@@ -60,7 +60,7 @@ struct Slab {
 
 struct Grads {   // gradient workspace (single copy, reused by every timestep of the backward sweep)
     size_t cat7, n2, cat6, n4, e2, n5, e6, e6raw, e0raw;
-    size_t hln[7], din[7][2], dc[7];
+    size_t din[7][2], dc[7];
     size_t dG[7], go[2], dmk, dz, dkpart, dv, dstate, lnpart;   // dG: gate pre-activation gradients per ConvLSTM: 2 rings x WG_BATCH timesteps (batched weight gradients)
     size_t wt_lstm[7], wt_enc[7];   // re-packed (transposed) weights for the data gradients, rebuilt once per backward
     size_t wg_part[5], wg_part_floats;   // per-block partial weight gradients of enc6, enc5, enc4, enc2, enc1 (WgradDesc::part), one contiguous region
@@ -212,7 +212,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
         g.e0raw = carve(B * HW2 * 32);
         for (int i = 0; i < 7; ++i) {
             const size_t M = hsz[i] / kLstm[i].C * B;
-            g.hln[i] = carve(B * hsz[i]); g.dc[i] = carve(B * hsz[i]);
+            g.dc[i] = carve(B * hsz[i]);   // (d h of a cell is never materialised: the LayerNorm backward is folded into the gate backward)
             g.din[i][0] = carve(M * (kLstm[i].cx + kLstm[i].C)); g.din[i][1] = carve(M * (kLstm[i].cx + kLstm[i].C));
             g.dG[i] = carve(M * 4 * kLstm[i].C * 2 * WG_BATCH);
             g.wt_lstm[i] = carve((size_t)25 * (kLstm[i].cx + kLstm[i].C) * 4 * kLstm[i].C);

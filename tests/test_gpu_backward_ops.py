@@ -165,3 +165,25 @@ def test_adam_step_matches_chainer_rule(env):
     torch.cuda.synchronize()
     assert np.abs(pd.cpu().numpy() - P['w']).max() < 2e-6
     assert _rel(md.cpu().numpy(), M['w']) < 1e-5 and _rel(vd.cpu().numpy(), V['w']) < 1e-5
+
+
+def test_adam_epsilon_placement_kat(env):
+    """Chainer 2's AdamRule adds eps to the UNcorrected sqrt(v): p -= alpha * sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps).
+    PyTorch / the paper divide the corrected moments: p -= alpha * mhat / (sqrt(vhat) + eps).  They differ where sqrt(v) ~ eps, i.e. for
+    |g| ~ eps / sqrt(1 - b2) = 3e-7 at t = 1: there Chainer's first step is alpha / 2, the other placement's 0.97 alpha.  Gradients that
+    small pin the placement; the 0.01-sized gradients of test_adam_step_matches_chainer_rule cannot."""
+    pivp, _lib, lib = env
+    import math
+    g = np.array([1e-9, 1e-8, 1e-7, 3.1623e-7, 1e-6, 1e-5, 1e-3, -3.1623e-7, -1e-8, 0.0], dtype=np.float64)
+    alpha, b1, b2, eps = 0.001, 0.9, 0.999, 1e-8
+    m = (1 - b1) * g; v = (1 - b2) * g * g
+    lr_t = alpha * math.sqrt(1 - b2) / (1 - b1)
+    chainer = -lr_t * m / (np.sqrt(v) + eps)                       # AdamRule.update_core at t = 1 from zero moments
+    paper = -alpha * g / (np.abs(g) + eps)                         # mhat = g, vhat = g^2
+    assert abs(chainer[3] / -alpha - 0.5) < 1e-3 and abs(paper[3] / -alpha - 0.97) < 1e-2   # the two rules really differ here
+    pd = _t(np.zeros_like(g)); gd = _t(g); md = torch.zeros_like(pd); vd = torch.zeros_like(pd)
+    _lib.check(lib.pivp_adam_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), g.size, lr_t, b1, b2, eps, 1.0, _st()), 'adam')
+    torch.cuda.synchronize()
+    got = pd.cpu().numpy().astype(np.float64)
+    assert np.abs(got - chainer).max() < 2e-9, (got, chainer)
+    assert np.abs(got - paper).max() > 4e-4                        # and is NOT the other placement
