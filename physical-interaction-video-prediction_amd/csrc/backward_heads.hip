@@ -600,11 +600,18 @@ __global__ __launch_bounds__(256) void skinny_linear_bwd_w_kernel(const float* _
 }
 
 int cdna_kernels_bwd(const float* hidden5, const float* wt, const float* vpre, const float* dkpart, int ntiles, float* dv,
-                     float* dhidden5, int accum_dx, float* dwt, float* db, int B, int K, int NM, hipStream_t s) {
+                     float* dhidden5, int accum_dx, float* dwt, float* db, int B, int K, int NM, hipStream_t s, const SideFork* fork) {
     PIVP_CHECK_ARG(hidden5 && wt && vpre && dkpart && dv && dhidden5 && dwt && db && B > 0 && K > 0 && NM >= 1 && NM * 25 <= 256);
     hipLaunchKernelGGL(cdna_kernels_bwd_dv_kernel, dim3(B), dim3(256), 0, s, vpre, dkpart, ntiles, dv, db, NM);
     hipLaunchKernelGGL(skinny_linear_bwd_x_kernel, dim3((K + 31) / 32, (B + 31) / 32), dim3(256), 0, s, wt, dv, dhidden5, B, K, accum_dx);
-    hipLaunchKernelGGL(skinny_linear_bwd_w_kernel, dim3((K + 7) / 8), dim3(256), 0, s, hidden5, dv, dwt, B, K);
+    hipStream_t sw = s;      // the weight gradient needs dv only: on the fork's stream it runs beside the rest of the sweep
+    if (fork && fork->side) {
+        // `ready` sits behind skinny_linear_bwd_x too: one kernel later than strictly needed, and the side stream never reads dv early
+        if (hipEventRecord(fork->ready, s) != hipSuccess || hipStreamWaitEvent(fork->side, fork->ready, 0) != hipSuccess) return PIVP_ERR_LAUNCH;
+        sw = fork->side;
+    }
+    hipLaunchKernelGGL(skinny_linear_bwd_w_kernel, dim3((K + 7) / 8), dim3(256), 0, sw, hidden5, dv, dwt, B, K);
+    if (fork && fork->side && hipEventRecord(fork->done, fork->side) != hipSuccess) return PIVP_ERR_LAUNCH;
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -970,11 +977,17 @@ __global__ __launch_bounds__(256) void enc0_dgrad_kernel(const float* __restrict
 }
 
 int enc0_bwd(const float* img, const float* w, const float* d, float* dw, float* db, float* dimg, int dimg_accum, int B, int H, int W,
-             hipStream_t s) {
+             hipStream_t s, const SideFork* fork) {
     PIVP_CHECK_ARG(img && w && d && dw && db && B > 0 && H > 0 && W > 0);
+    hipStream_t sw = s;
+    if (fork && fork->side) {
+        if (hipEventRecord(fork->ready, s) != hipSuccess || hipStreamWaitEvent(fork->side, fork->ready, 0) != hipSuccess) return PIVP_ERR_LAUNCH;
+        sw = fork->side;
+    }
     const int total = B * (H / 2) * (W / 2);
     int blocks = (total + 63) / 64; if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(enc0_wgrad_kernel, dim3(blocks), dim3(256), 0, s, img, d, dw, db, B, H, W);
+    hipLaunchKernelGGL(enc0_wgrad_kernel, dim3(blocks), dim3(256), 0, sw, img, d, dw, db, B, H, W);
+    if (fork && fork->side && hipEventRecord(fork->done, fork->side) != hipSuccess) return PIVP_ERR_LAUNCH;
     if (dimg) {
         const long tp = (long)B * H * W;
         hipLaunchKernelGGL(enc0_dgrad_kernel, dim3((unsigned)((tp + 255) / 256 < 2048 ? (tp + 255) / 256 : 2048)), dim3(256), 0, s, d, w, dimg,

@@ -22,14 +22,6 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
               float* db = nullptr, int* bias_done = nullptr, int bf16 = 0,
               int tcount = 1, long long ts_x0 = 0, long long ts_x1 = 0, long long ts_dy = 0,    // a batch of timesteps: WgradDesc
               float* part = nullptr, WgradDesc* desc_out = nullptr);   // part: WgradDesc::part; desc_out: the descriptor that was launched
-// Where the WEIGHT-gradient half of a conv backward runs.  A weight gradient feeds nothing but the optimizer, while the data gradient
-// is on the backward sweep's critical path: with a fork the weight (and bias) gradient kernels are enqueued on `side` behind `ready`
-// (recorded on the main stream as soon as dY is final) and `done` is recorded behind them; the caller makes whoever next overwrites
-// dY, or reads dW, wait for `done`.
-struct SideFork {
-    hipStream_t side;
-    hipEvent_t ready, done;
-};
 int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
                           const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                           float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,

@@ -40,6 +40,15 @@ struct IgemmDesc {
 };
 
 // weight gradient of a conv / transposed conv (csrc/igemm_wgrad.hip)
+// Where the WEIGHT-gradient half of a conv backward runs.  A weight gradient feeds nothing but the optimizer, while the data gradient
+// is on the backward sweep's critical path: with a fork the weight (and bias) gradient kernels are enqueued on `side` behind `ready`
+// (recorded on the main stream as soon as dY is final) and `done` is recorded behind them; the caller makes whoever next overwrites
+// dY, or reads dW, wait for `done`.
+struct SideFork {
+    hipStream_t side;
+    hipEvent_t ready, done;
+};
+
 struct WgradDesc {
     const float* x0; const float* x1;    // forward input sources (channel-concatenated), NHWC
     int c0, ld0, c1, ld1, cin, wcin;     // cin = c0 + c1 channels differentiated; wcin = Cin of the packed weight
@@ -171,12 +180,12 @@ int mask_softmax_bwd(const float* logits, float* dmk, int B, int HW, int NP, hip
 int heads_bwd(const float* e6, const float* wm, const float* we, const float* dpm, const float* dpe, float* de6,
               float* dwm, float* dbm, float* dwe, float* dbe, int B, int HW, int NP, int NE, hipStream_t s);
 int cdna_kernels_bwd(const float* hidden5, const float* wt, const float* vpre, const float* dkpart, int ntiles, float* dv,
-                     float* dhidden5, int accum_dx, float* dwt, float* db, int B, int K, int NM, hipStream_t s);
+                     float* dhidden5, int accum_dx, float* dwt, float* db, int B, int K, int NM, hipStream_t s, const SideFork* fork = nullptr);   // fork: where the WEIGHT-gradient kernel runs (behind dv)
 int enc3_state_bwd(const float* e2, const float* e3, const float* de3, int ldd3, const float* action, const float* state, const float* w3,
                    const float* wcs, const float* dsnew, float* de2, float* dw3, float* db3, float* dwcs, float* dbcs,
                    float* dstate_prev, int B, int HW8, int use_state, hipStream_t s);
 int enc0_bwd(const float* img, const float* w, const float* d, float* dw, float* db, float* dimg, int dimg_accum, int B, int H, int W,
-             hipStream_t s);
+             hipStream_t s, const SideFork* fork = nullptr);   // fork: where the weight / bias gradient kernel runs
 int add_strided(float* dst, int ldd, const float* src, int lds_, int C, long npix, hipStream_t s);
 
 // planar NCHW <-> NHWC helpers for taps (conv_res) and tests

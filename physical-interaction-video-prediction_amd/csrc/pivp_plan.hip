@@ -99,7 +99,7 @@ struct pivp_plan {
     // Weight gradients run on a second, lower-priority stream next to the backward sweep's critical path (SideFork, pivp_host.h):
     // slots 0..6 = the ConvLSTMs, 7..11 = enc6, enc5, enc4, enc2, enc1.  Created on first use; PIVP_SIDE_STREAM=0 (read when
     // the plan is created) keeps everything on the caller's stream.
-    static constexpr int NSLOT = 12;
+    static constexpr int NSLOT = 14;      // 12: enc0's weight gradient, 13: the motion head's Linear (cdna_kernels / stp_input)
     bool use_side = true;
     hipStream_t side = nullptr;
     hipEvent_t ev_ready[NSLOT] = {}, ev_done[NSLOT] = {};
@@ -568,7 +568,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                      G(p, p->i_masks_b), G(p, p->i_enc7_w), G(p, p->i_enc7_b), B, HW, p->NP, p->NE, s));
         if (c.model_type == PIVP_MODEL_CDNA)
             RC(cdna_kernels_bwd(ws + S.n5, P(p, p->i_head_w), ws + S.vpre, ws + g.dkpart, composite_bwd_tiles(H, W), ws + g.dv, ws + g.n5, 0,
-                                G(p, p->i_head_w), G(p, p->i_head_b), B, p->K5, c.num_masks, s));
+                                G(p, p->i_head_w), G(p, p->i_head_b), B, p->K5, c.num_masks, s, fork_of(13, fe)));
         else if (c.model_type == PIVP_MODEL_STP)
             RC(stp_params_bwd(ws + S.n5, P(p, p->i_head_w), ws + S.vpre, P(p, p->i_head2_w), ws + g.dkpart, composite_bwd_tiles(H, W),
                               ws + g.dv, ws + g.n5, G(p, p->i_head_w), G(p, p->i_head_b), G(p, p->i_head2_w), G(p, p->i_head2_b),
@@ -600,10 +600,11 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
             if (encs[group][0] >= 0) RC(reduce_enc(encs[group][0]));
         }
         if (t != 0 || !p->grad_cb) return PIVP_OK;
-        static const int slots[6][3] = {{7, -1, -1}, {6, -1, -1}, {8, 5, -1}, {9, 4, -1}, {10, 3, 2}, {11, 1, 0}};
-        for (int k = 0; k < 3; ++k) {
+        static const int slots[6][4] = {{7, 13, -1, -1}, {6, -1, -1, -1}, {8, 5, -1, -1}, {9, 4, -1, -1}, {10, 3, 2, -1}, {11, 1, 0, 12}};
+        for (int k = 0; k < 4; ++k) {
             const int sl = slots[group][k];
-            if (sl >= 7) { RC(reduce_enc(sl - 7)); RC(join(sl)); }
+            if (sl >= 12) RC(join(sl));
+            else if (sl >= 7) { RC(reduce_enc(sl - 7)); RC(join(sl)); }
             else if (sl >= 0 && p->side)
                 for (int r = 0; r < 2; ++r) if (hipStreamWaitEvent(s, p->ev_ring_done[sl][r], 0) != hipSuccess) return PIVP_ERR_LAUNCH;
         }
@@ -655,7 +656,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     // group 0 (TM:595): norm_enc0 (+relu) <- enc0 conv <- frame
     RC(lnb(0, ws + g.cat7 + 32, 64, ws + S.cat7 + 32, 64, ws + S.e0raw, ws + g.e0raw, n2, 32, 1));
     RC(enc0_bwd(prev, P(p, p->i_enc_w[0]), ws + g.e0raw, G(p, p->i_enc_w[0]), G(p, p->i_enc_b[0]), prev_has_grad ? go_prev : nullptr, 1,
-                B, H, W, s));
+                B, H, W, s, fork_of(12, fe)));
     RC(done(5));
     return PIVP_OK;
 }
