@@ -82,3 +82,26 @@ def test_chainer_adam_step_kat():
     lr = 0.001 * np.sqrt(1 - 0.999) / (1 - 0.9)
     expect = np.array([1.0, -2.0]) - lr * (0.1 * g['w']) / (np.sqrt(0.001 * g['w'] ** 2) + 1e-8)
     assert np.allclose(p['w'], expect, rtol=1e-12)
+
+
+def test_float32_arithmetic_itself_misses_1e4_on_white_noise_stp():
+    """The reason the STP gate is statistical on white-noise frames (tests/test_gpu_model.py), checkable without a GPU: the
+    oracle evaluated in float32 -- the reference's own arithmetic -- is already more than 1e-4 from the float64 oracle on the FIRST
+    predicted frame of the B = 32 STP fixture (max over 32 samples), while on video-like frames it is two orders below the gate."""
+    g = np.load(os.path.join(GOLD, 'stp_b32_t10.npz'))
+    e = g['fp32_oracle_max_l2']                                   # (T-1, B): per step and sample, stored by make_golden.py
+    assert e.shape == (9, 32)
+    assert e[0].max() > 1e-4 and e[8].max() > 1e-3                # step 0: 1.1e-4; after eight fed-back steps: 2.3e-3
+    gs = np.load(os.path.join(GOLD, 'stp_b32_t10_smooth.npz'))
+    assert gs['fp32_oracle_max_l2'][:2].max() < 1e-5              # ground-truth-fed steps of video-like frames: 5e-6
+    # and the stored numbers are what the oracle gives: re-run the first step (T = 2: one prediction) in both precisions
+    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, num_masks=10, model_type='STP')
+    imgs, acts, stas = R.synthetic_batch(32, 10)
+    out = {}
+    for dt in (np.float64, np.float32):
+        m = R.Model(10, is_cdna=False, is_stp=True, params=P, dtype=dt, prefix='x'); m.train = False
+        with np.errstate(all='ignore'):
+            m([imgs[:2], acts[:2], stas[:2]], 0)                  # T = 2 has no loss frame (division by zero in the loss only)
+        out[dt] = np.stack(m.gen_images)
+    l2 = R.per_pixel_l2(out[np.float32], out[np.float64])[0].max(axis=(1, 2))
+    assert np.allclose(l2, e[0], rtol=1e-3, atol=1e-9)
