@@ -834,41 +834,37 @@ __global__ __launch_bounds__(256) void enc3_state_bwd_kernel(const float* __rest
         }
     }
     __syncthreads();
+    // blockIdx.z = quarter q: 16 of the tile's 64 pixels for d e2 and 16 of the 64 input channels for dW (every quarter stages the whole
+    // tile: 48 KB from L2).  One block per (tile, sample) ran 2 x 64 iterations of 16 FMAs on 32 of 256 CUs: 41 us for 17 MFLOP.
+    const int q = blockIdx.z;
     if (tid < 64) {
         float c = 0.f;
         for (int p = 0; p < 64; ++p) c += dt[p * 65 + tid];
         colsum[tid] = c;
-        atomicAdd(db3 + tid, c);
+        if (q == 0) atomicAdd(db3 + tid, c);
     }
-    {   // d e2[p][ci] = sum_co w3[ci][co] dpre[p][co]: thread (p = tid/4, 16 ci)
-        const int p = tid >> 2, cg = (tid & 3) * 16;
-        float acc[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    {   // d e2[p][ci] = sum_co w3[ci][co] dpre[p][co]: thread (p = 16 q + tid/16, 4 ci)
+        const int p = q * 16 + (tid >> 4), cg = (tid & 15) * 4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int co = 0; co < 64; ++co) {
             const float d = dt[p * 65 + co];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = fmaf(wl[(cg + i) * 64 + co], d, acc[i]);
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(wl[(cg + i) * 64 + co], d, acc[i]);
         }
-        if (p < npx) {
-            float* op = de2 + base + (size_t)p * 64 + cg;
-#pragma unroll
-            for (int i = 0; i < 16; i += 4) *reinterpret_cast<f32x4*>(op + i) = f32x4{acc[i], acc[i + 1], acc[i + 2], acc[i + 3]};
-        }
+        if (p < npx) *reinterpret_cast<f32x4*>(de2 + base + (size_t)p * 64 + cg) = f32x4{acc[0], acc[1], acc[2], acc[3]};
     }
-    {   // dW3x[ci][co] += sum_p e2[p][ci] dpre[p][co]: thread (ci = tid/4, co group of 16)
-        const int ci = tid >> 2, cg = (tid & 3) * 16;
-        float acc[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    {   // dW3x[ci][co] += sum_p e2[p][ci] dpre[p][co]: thread (ci = 16 q + tid/16, 4 co)
+        const int ci = q * 16 + (tid >> 4), cg = (tid & 15) * 4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int p = 0; p < 64; ++p) {
             const float xv = xt[p * 65 + ci];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = fmaf(xv, dt[p * 65 + cg + i], acc[i]);
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(xv, dt[p * 65 + cg + i], acc[i]);
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) atomicAdd(dw3 + ci * 64 + cg + i, acc[i]);
+        for (int i = 0; i < 4; ++i) atomicAdd(dw3 + ci * 64 + cg + i, acc[i]);
     }
+    if (q != 0) return;      // the state predictor and the smeared action/state rows: once per (tile, sample)
     __syncthreads();
     if (use_state && tid < 64) {
 #pragma unroll
@@ -890,7 +886,7 @@ int enc3_state_bwd(const float* e2, const float* e3, const float* de3, int ldd3,
                    const float* wcs, const float* dsnew, float* de2, float* dw3, float* db3, float* dwcs, float* dbcs,
                    float* dstate_prev, int B, int HW8, int use_state, hipStream_t s) {
     PIVP_CHECK_ARG(e2 && e3 && de3 && action && state && w3 && wcs && dsnew && de2 && dw3 && db3 && dwcs && dbcs && dstate_prev && B > 0 && HW8 > 0);
-    hipLaunchKernelGGL(enc3_state_bwd_kernel, dim3((HW8 + 63) / 64, B), dim3(256), 0, s, e2, e3, de3, ldd3, action, state, w3, wcs, dsnew, de2,
+    hipLaunchKernelGGL(enc3_state_bwd_kernel, dim3((HW8 + 63) / 64, B, 4), dim3(256), 0, s, e2, e3, de3, ldd3, action, state, w3, wcs, dsnew, de2,
                        dw3, db3, dwcs, dbcs, dstate_prev, HW8, use_state);
     return PIVP_LAUNCH_STATUS();
 }
@@ -942,7 +938,7 @@ __global__ __launch_bounds__(256) void enc0_wgrad_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void enc0_dgrad_kernel(const float* __restrict__ d, const float* __restrict__ w, float* __restrict__ dimg,
                                                          int accum, int B, int H, int W) {
-    __shared__ float wl[75 * 32];
+    __shared__ __attribute__((aligned(16))) float wl[75 * 32];
     for (int i = threadIdx.x; i < 75 * 32; i += 256) wl[i] = w[i];
     __syncthreads();
     const int H2 = H >> 1, W2 = W >> 1;
@@ -964,6 +960,8 @@ __global__ __launch_bounds__(256) void enc0_dgrad_kernel(const float* __restrict
                 if ((unsigned)ox >= (unsigned)W2) continue;
                 const float* dp = d + ((size_t)(b * H2 + oy) * W2 + ox) * 32;
                 const float* wr = wl + (ky * 5 + kx) * 3 * 32;
+                // (eight 16-B loads into a register array + float4 weight reads were tried here: 41 -> 202 us, the partially predicated,
+                // fully unrolled tap loop then lives in scratch; the scalar loop stays)
                 for (int co = 0; co < 32; ++co) {
                     const float dv = dp[co];
                     a0 = fmaf(wr[co], dv, a0); a1 = fmaf(wr[32 + co], dv, a1); a2 = fmaf(wr[64 + co], dv, a2);
