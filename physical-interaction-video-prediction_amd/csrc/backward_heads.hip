@@ -960,11 +960,15 @@ __global__ __launch_bounds__(256) void enc0_dgrad_kernel(const float* __restrict
                 if ((unsigned)ox >= (unsigned)W2) continue;
                 const float* dp = d + ((size_t)(b * H2 + oy) * W2 + ox) * 32;
                 const float* wr = wl + (ky * 5 + kx) * 3 * 32;
-                // (eight 16-B loads into a register array + float4 weight reads were tried here: 41 -> 202 us, the partially predicated,
-                // fully unrolled tap loop then lives in scratch; the scalar loop stays)
-                for (int co = 0; co < 32; ++co) {
-                    const float dv = dp[co];
-                    a0 = fmaf(wr[co], dv, a0); a1 = fmaf(wr[32 + co], dv, a1); a2 = fmaf(wr[64 + co], dv, a2);
+                // 16-B loads, two in flight (a register array of all eight per tap was tried: 41 -> 202 us, the fully unrolled, partially
+                // predicated tap loop then lives in scratch)
+#pragma unroll 2
+                for (int c4 = 0; c4 < 8; ++c4) {
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(dp + 4 * c4);
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + 4 * c4), w1 = *reinterpret_cast<const f32x4*>(wr + 32 + 4 * c4);
+                    const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 64 + 4 * c4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a0 = fmaf(w0[e], dv[e], a0); a1 = fmaf(w1[e], dv[e], a1); a2 = fmaf(w2[e], dv[e], a2); }
                 }
             }
         }
