@@ -405,29 +405,40 @@ int mask_softmax_bwd(const float* logits, float* dmk, int B, int HW, int NP, hip
 constexpr int HB_PX = 128;       // pixels per sub-tile
 constexpr int HB_SUB = 4;        // sub-tiles per block: dW / db are accumulated in registers over them, so each of the 910 gradient
                                  // addresses receives one atomic per 512 pixels (1024 blocks x 910 atomics on the same addresses made
-                                 // the first version an L2-atomic queue)
-constexpr int HB_MAXOUT = 36;
+                                 // the first version an L2-atomic queue).  (2, i.e. two blocks per CU at B = 32, measured slower.)
+constexpr int HB_MAXOUT = 32;    // outputs (mask planes + enc7 planes): one 32-wide MFMA tile
+constexpr int HB_DP = 129;       // pitch of the [output][pixel] tile: lanes that walk the outputs at one pixel hit 32 different banks
+// Both contractions run on the fp32 matrix cores (v_mfma_f32_32x32x2_f32): these 1x1 channel mixes are the dense contractions the
+// reference's heads consist of (TM:718, TM:315).  Wave w of the block owns pixels [32w, 32w + 32) of a 128-pixel sub-tile:
+//   d e6 [32 px][64 k]  = dp^T [32 px][NO] . W^T [NO][64]       K = NO (zero-padded to even): A = dpt, B = wl, two 32-channel tiles
+//   dW   [64 k][NO]    += e6^T [64 k][32 px] . dp [32 px][NO]    K = the wave's 32 pixels: A = xt, B = dpt (rows >= NO are zero)
+// The scalar version spent 63 us per launch in LDS reads (one per FMA); this one is bound by reading e6 and writing d e6 (67 MB).
 __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ e6, const float* __restrict__ wm, const float* __restrict__ we,
                                                         const float* __restrict__ dpm, const float* __restrict__ dpe,
                                                         float* __restrict__ de6, float* __restrict__ dwm, float* __restrict__ dbm,
                                                         float* __restrict__ dwe, float* __restrict__ dbe, int total_px, int HW, int NP, int NE) {
-    __shared__ __attribute__((aligned(16))) float xt[HB_PX * 68];        // [pixel][64 + 4]
-    __shared__ __attribute__((aligned(16))) float dpt[HB_MAXOUT * HB_PX];   // [output][pixel]
-    __shared__ __attribute__((aligned(16))) float wl[HB_MAXOUT * 64];    // [output][k]
-    const int tid = threadIdx.x, NO = NP + NE;
-    for (int i = tid; i < 64 * NO; i += 256) {
-        const int k = i / NO, o = i - k * NO;
-        wl[o * 64 + k] = o < NP ? wm[k * NP + o] : we[k * NE + (o - NP)];
+    __shared__ __attribute__((aligned(16))) float xt[HB_PX * 68];        // [pixel][64 + 4]; reused for the block reduction of dW
+    __shared__ float dpt[HB_MAXOUT * HB_DP];                              // [output][pixel]
+    __shared__ float wl[HB_MAXOUT * 64];                                  // [output][k]
+    const int tid = threadIdx.x, NO = NP + NE, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < HB_MAXOUT * 64; i += 256) {
+        const int o = i >> 6, k = i & 63;
+        wl[i] = o < NP ? wm[k * NP + o] : (o < NO ? we[k * NE + (o - NP)] : 0.f);
     }
-    const int kw = tid >> 2, og = tid & 3;          // dW role: input channel kw, outputs og, og+4, ...
-    float dwacc[HB_MAXOUT / 4], dbacc = 0.f;
+    for (int i = tid; i < HB_MAXOUT * HB_DP; i += 256) dpt[i] = 0.f;      // rows >= NO stay zero for the whole block
+    const int KO = (NO + 1) >> 1;                                         // k-steps of the d e6 contraction
+    f32x16 dwacc[2];
 #pragma unroll
-    for (int u = 0; u < HB_MAXOUT / 4; ++u) dwacc[u] = 0.f;
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dwacc[t][r] = 0.f;
+    float dbacc = 0.f;
     for (int sub = 0; sub < HB_SUB; ++sub) {
         const int px0 = (blockIdx.x * HB_SUB + sub) * HB_PX;
         if (px0 >= total_px) break;
         __syncthreads();
-        {   // staging: 8 + up to 18 independent loads per thread, then the LDS stores
+        {   // staging: 8 + up to 16 independent loads per thread, then the LDS stores
             f32x4 tx[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -450,56 +461,55 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
                 *reinterpret_cast<f32x4*>(xt + pp * 68 + cv) = tx[u];
             }
 #pragma unroll
-            for (int u = 0; u < HB_MAXOUT / 2; ++u) { const int o = oh + 2 * u; if (o < NO) dpt[o * HB_PX + p] = td[u]; }
+            for (int u = 0; u < HB_MAXOUT / 2; ++u) { const int o = oh + 2 * u; if (o < NO) dpt[o * HB_DP + p] = td[u]; }
         }
         __syncthreads();
-        {   // d e6: thread = (pixel, 32-channel half); an output's 32 weights are 8 wave-uniform ds_read_b128
-            const int p = tid >> 1, kh = (tid & 1) * 32;
-            if (px0 + p < total_px) {
-                float acc[32];
+        {   // d e6 of this wave's 32 pixels: row i of the MFMA tile = pixel, column j = channel
+            f32x16 c0, c1;
 #pragma unroll
-                for (int k = 0; k < 32; ++k) acc[k] = 0.f;
-                for (int o = 0; o < NO; ++o) {
-                    const float dd = dpt[o * HB_PX + p];
+            for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+            for (int ks = 0; ks < KO; ++ks) {
+                const int o = 2 * ks + half;
+                const float a = dpt[o * HB_DP + 32 * wave + l31];
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wl[o * 64 + l31], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wl[o * 64 + 32 + l31], c1, 0, 0, 0);
+            }
 #pragma unroll
-                    for (int k4 = 0; k4 < 8; ++k4) {
-                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + o * 64 + kh + k4 * 4);
-                        acc[k4 * 4] = fmaf(w4[0], dd, acc[k4 * 4]); acc[k4 * 4 + 1] = fmaf(w4[1], dd, acc[k4 * 4 + 1]);
-                        acc[k4 * 4 + 2] = fmaf(w4[2], dd, acc[k4 * 4 + 2]); acc[k4 * 4 + 3] = fmaf(w4[3], dd, acc[k4 * 4 + 3]);
-                    }
+            for (int r = 0; r < 16; ++r) {
+                const int px = px0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (px < total_px) {                       // a half-wave writes 128 contiguous bytes per tile
+                    de6[(size_t)px * 64 + l31] = c0[r];
+                    de6[(size_t)px * 64 + 32 + l31] = c1[r];
                 }
-                float* op = de6 + (size_t)(px0 + p) * 64 + kh;
-#pragma unroll
-                for (int k = 0; k < 32; k += 4) *reinterpret_cast<f32x4*>(op + k) = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
             }
         }
-        // dW partial: this thread's channel column of the tile against its outputs' pixel rows (ds_read_b128 on dpt)
-#pragma unroll
-        for (int u = 0; u < HB_MAXOUT / 4; ++u) {
-            const int o = og + 4 * u;
-            if (o < NO) {
-                float a = dwacc[u];
-                for (int p4 = 0; p4 < HB_PX; p4 += 4) {
-                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(dpt + o * HB_PX + p4);
-                    a = fmaf(xt[p4 * 68 + kw], d4[0], a); a = fmaf(xt[(p4 + 1) * 68 + kw], d4[1], a);
-                    a = fmaf(xt[(p4 + 2) * 68 + kw], d4[2], a); a = fmaf(xt[(p4 + 3) * 68 + kw], d4[3], a);
-                }
-                dwacc[u] = a;
-            }
+        // dW partial over this wave's 32 pixels: row i = input channel, column j = output (pixels past total_px were staged as zeros)
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+            const int p = 32 * wave + 2 * ks + half;
+            const float b = dpt[l31 * HB_DP + p];
+            dwacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xt[p * 68 + l31], b, dwacc[0], 0, 0, 0);
+            dwacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xt[p * 68 + 32 + l31], b, dwacc[1], 0, 0, 0);
         }
         if (tid < NO) {
             float a = dbacc;
-            for (int p4 = 0; p4 < HB_PX; p4 += 4) {
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dpt + tid * HB_PX + p4);
-                a += (d4[0] + d4[1]) + (d4[2] + d4[3]);
-            }
+            for (int p = 0; p < HB_PX; ++p) a += dpt[tid * HB_DP + p];
             dbacc = a;
         }
     }
+    // block reduction of the four waves' dW tiles through LDS ([wave][k tile][k][33]), then one atomic per (k, output)
+    __syncthreads();
+    float* red = xt;                                   // 4 * 2 * 32 * 33 floats = 33.8 KB <= 34.8 KB
 #pragma unroll
-    for (int u = 0; u < HB_MAXOUT / 4; ++u) {
-        const int o = og + 4 * u;
-        if (o < NO) { if (o < NP) atomicAdd(dwm + kw * NP + o, dwacc[u]); else atomicAdd(dwe + kw * NE + (o - NP), dwacc[u]); }
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * 2 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l31] = dwacc[t][r];
+    __syncthreads();
+    for (int e = tid; e < 64 * NO; e += 256) {
+        const int k = e / NO, o = e - k * NO;
+        const int idx = ((k >> 5) * 32 + (k & 31)) * 33 + o;
+        const float v = (red[idx] + red[2 * 32 * 33 + idx]) + (red[4 * 32 * 33 + idx] + red[6 * 32 * 33 + idx]);
+        if (o < NP) atomicAdd(dwm + k * NP + o, v); else atomicAdd(dwe + k * NE + (o - NP), v);
     }
     if (tid < NO) { if (tid < NP) atomicAdd(dbm + tid, dbacc); else atomicAdd(dbe + (tid - NP), dbacc); }
 }
@@ -550,10 +560,21 @@ __global__ __launch_bounds__(256) void skinny_linear_bwd_x_kernel(const float* _
     __shared__ float wl[32 * 257];
     __shared__ float dl[32 * 257];
     const int k0 = blockIdx.x * 32, b0 = blockIdx.y * 32, tid = threadIdx.x;
-    for (int i = tid; i < 32 * 256; i += 256) {
-        const int r = i >> 8, o = i & 255;
-        wl[r * 257 + o] = (k0 + r < K) ? wt[(size_t)(k0 + r) * 256 + o] : 0.f;
-        dl[r * 257 + o] = (b0 + r < B) ? dv[(size_t)(b0 + r) * 256 + o] : 0.f;
+    {   // 2 x 8 independent 16-B loads per thread, all issued before the first LDS store (the element loop was one L2 round trip per element)
+        f32x4 tw[8], td[8];
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int f = (tid + 256 * u) * 4, r = f >> 8, o = f & 255;
+            tw[u] = (k0 + r < K) ? *reinterpret_cast<const f32x4*>(wt + (size_t)(k0 + r) * 256 + o) : z4;
+            td[u] = (b0 + r < B) ? *reinterpret_cast<const f32x4*>(dv + (size_t)(b0 + r) * 256 + o) : z4;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int f = (tid + 256 * u) * 4, r = f >> 8, o = f & 255;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { wl[r * 257 + o + e] = tw[u][e]; dl[r * 257 + o + e] = td[u][e]; }
+        }
     }
     __syncthreads();
     const int kk = tid & 31, bg = tid >> 5;       // 8 groups of 4 samples
