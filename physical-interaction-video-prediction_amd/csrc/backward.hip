@@ -234,12 +234,15 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
 __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
                                                             const float* __restrict__ x, const float* __restrict__ stat,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int B, int n, int C, int relu) {
-    // thread = 4 consecutive elements x one group of samples (blockIdx.y); groups combine with atomics
+                                                            int B, int n, int C, int relu, float* __restrict__ part) {
+    // thread = 4 consecutive elements x one group of samples (blockIdx.y).  Groups combine with atomics, or -- with `part`, the
+    // plan's path -- every group adds into its own [2][n] plane of the partial buffer with plain loads and stores (launches of one
+    // norm are stream-ordered), and ln_bwd_params_reduce sums the planes once per sweep: 8 atomics per element per timestep less
     const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= n) return;
     const int pix = e / C, ch = e - pix * C;
     f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4      // the samples' loads are independent: keep four samples' worth in flight (the rolled loop waited for each sample's pair)
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
         const size_t pb = (size_t)b * (n / C) + pix;
         f32x4 g = *reinterpret_cast<const f32x4*>(dy + pb * lddy + ch);
@@ -253,14 +256,48 @@ __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < 4; ++k) { ag[k] = fmaf(g[k], (xv[k] - mean) * rstd, ag[k]); ab[k] += g[k]; }
     }
+    if (part) {
+        float* pg = part + (size_t)blockIdx.y * 2 * n + e;
+        f32x4 og = *reinterpret_cast<f32x4*>(pg), ob = *reinterpret_cast<f32x4*>(pg + n);
+        og += ag; ob += ab;
+        *reinterpret_cast<f32x4*>(pg) = og; *reinterpret_cast<f32x4*>(pg + n) = ob;
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { atomicAdd(dgamma + e + k, ag[k]); atomicAdd(dbeta + e + k, ab[k]); }
+}
+
+// dgamma, dbeta += the sum of the sample-group planes of ln_bwd_params_kernel's partial buffer ([groups][2][n])
+__global__ __launch_bounds__(256) void ln_bwd_params_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, int n, int groups) {
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= n) return;
+    f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
+    for (int y = 0; y < groups; ++y) {
+        ag += *reinterpret_cast<const f32x4*>(part + (size_t)y * 2 * n + e);
+        ab += *reinterpret_cast<const f32x4*>(part + (size_t)y * 2 * n + n + e);
+    }
+    f32x4 og = *reinterpret_cast<f32x4*>(dgamma + e), ob = *reinterpret_cast<f32x4*>(dbeta + e);
+    og += ag; ob += ab;
+    *reinterpret_cast<f32x4*>(dgamma + e) = og; *reinterpret_cast<f32x4*>(dbeta + e) = ob;
+}
+
+static int ln_bwd_param_groups(int B, int n) {
+    const int xb = (n / 4 + 255) / 256;
+    int yb = 512 / xb; if (yb < 1) yb = 1; if (yb > B) yb = B; if (yb > 8) yb = 8;
+    return yb;
+}
+long long ln_bwd_param_part_floats(int n) { return 8LL * 2 * n; }      // up to 8 sample groups
+int ln_bwd_params_reduce(const float* part, float* dgamma, float* dbeta, int B, int n, hipStream_t s) {
+    PIVP_CHECK_ARG(part && dgamma && dbeta && B > 0 && n > 0 && n % 4 == 0);
+    hipLaunchKernelGGL(ln_bwd_params_reduce_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, s, part, dgamma, dbeta, n, ln_bwd_param_groups(B, n));
+    return PIVP_LAUNCH_STATUS();
 }
 
 int ln_bwd_slices(int n) { return (n + LNB_SLICE - 1) / LNB_SLICE; }
 
 int ln_backward(const float* dy, int lddy, const float* y, int ldy, const float* x, const float* stat, const float* gamma,
-                float* partials, float* dx, float* dgamma, float* dbeta, int B, int n, int C, int relu, hipStream_t s) {
+                float* partials, float* dx, float* dgamma, float* dbeta, int B, int n, int C, int relu, hipStream_t s, float* param_part) {
     // dx == nullptr: the consumer forms dx itself from the partials (lstm_gates_bwd with LnFuse); only the sums and the parameter gradients run here
     PIVP_CHECK_ARG(dy && x && stat && gamma && partials && dgamma && dbeta && B > 0 && n > 0 && C > 0 && C % 4 == 0 && n % C == 0);
     PIVP_CHECK_ARG(lddy >= C && lddy % 4 == 0 && (!relu || (y && ldy >= C && ldy % 4 == 0)));
@@ -268,9 +305,8 @@ int ln_backward(const float* dy, int lddy, const float* y, int ldy, const float*
     hipLaunchKernelGGL(ln_bwd_stats_kernel, dim3(S, B), dim3(256), 0, s, dy, lddy, y, ldy, x, stat, gamma, partials, n, C, relu);
     if (dx) hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3(S, B), dim3(256), 0, s, dy, lddy, y, ldy, x, stat, gamma, partials, dx, n, C, relu);
     {
-        const int xb = (n / 4 + 255) / 256;
-        int yb = 512 / xb; if (yb < 1) yb = 1; if (yb > B) yb = B; if (yb > 8) yb = 8;
-        hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(xb, yb), dim3(256), 0, s, dy, lddy, y, ldy, x, stat, dgamma, dbeta, B, n, C, relu);
+        const int xb = (n / 4 + 255) / 256, yb = ln_bwd_param_groups(B, n);
+        hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(xb, yb), dim3(256), 0, s, dy, lddy, y, ldy, x, stat, dgamma, dbeta, B, n, C, relu, param_part);
     }
     return PIVP_LAUNCH_STATUS();
 }

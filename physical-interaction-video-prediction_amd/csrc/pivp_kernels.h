@@ -160,8 +160,13 @@ int lstm_gates_bwd(const float* gates, const float* c_old, const float* c_new, c
 int bias_grad(const float* dy, int ld, int N, int M, float* db, hipStream_t s);
 int relu_mask(float* dy, int lddy, const float* y, int ldy, int C, long npix, hipStream_t s);
 int ln_bwd_slices(int n);
+// param_part (optional, ln_bwd_param_part_floats(n) floats, zeroed before the first launch of a sweep): the parameter gradients are
+// accumulated there without atomics and reach dgamma / dbeta only through ln_bwd_params_reduce (once per sweep)
 int ln_backward(const float* dy, int lddy, const float* y, int ldy, const float* x, const float* stat, const float* gamma,
-                float* partials, float* dx, float* dgamma, float* dbeta, int B, int n, int C, int relu, hipStream_t s);
+                float* partials, float* dx, float* dgamma, float* dbeta, int B, int n, int C, int relu, hipStream_t s,
+                float* param_part = nullptr);
+long long ln_bwd_param_part_floats(int n);
+int ln_bwd_params_reduce(const float* part, float* dgamma, float* dbeta, int B, int n, hipStream_t s);
 int adam_step(float* p, const float* g, float* m, float* v, long n, double lr_t, double beta1, double beta2, double eps,
               double gscale, hipStream_t s);
 

@@ -63,6 +63,7 @@ struct Grads {   // gradient workspace (single copy, reused by every timestep of
     size_t din[7][2], dc[7];
     size_t dG[7], go[2], dmk, dz, dkpart, dv, dstate, lnpart;   // dG: gate pre-activation gradients per ConvLSTM: 2 rings x WG_BATCH timesteps (batched weight gradients)
     size_t wt_lstm[7], wt_enc[7];   // re-packed (transposed) weights for the data gradients, rebuilt once per backward
+    size_t ln_ppart[9], ln_ppart_floats;   // per-norm partial parameter gradients (ln_backward's param_part), one contiguous region
     size_t wg_part[5], wg_part_floats;   // per-block partial weight gradients of enc6, enc5, enc4, enc2, enc1 (WgradDesc::part), one contiguous region
     size_t wtb_lstm[7];             // ... and their bf16 packs (bf16 precision mode)
 };
@@ -106,6 +107,7 @@ struct pivp_plan {
     hipEvent_t ev_ring_done[7][2] = {};        // ConvLSTM slots: one `done` per dG ring (slots 0..6 of ev_done are unused)
     int wg_batch = 1;                          // timesteps per weight-gradient launch (<= WG_BATCH; always 1 in the bf16 mode, whose kernel takes one)
     const float* wg_x[7] = {}; const float* wg_h[7] = {};   // operands of the first timestep of the open batch
+    bool ln_touched[9] = {};                                // norms whose partial parameter gradients still await their reduction
     WgradDesc enc_desc[5]; bool enc_desc_valid[5] = {};     // enc6, enc5, enc4, enc2, enc1: what this sweep launched (for the reduction of the partial sums)
     ~pivp_plan() {
         for (int i = 0; i < 7; ++i) for (int r = 0; r < 2; ++r) if (ev_ring_done[i][r]) (void)hipEventDestroy(ev_ring_done[i][r]);
@@ -224,6 +226,12 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
         g.dkpart = carve((size_t)B * composite_bwd_tiles(H, W) * 256); g.dv = carve((size_t)B * 256);
         g.dstate = carve((size_t)T * B * 5);
         g.lnpart = carve((size_t)B * ln_bwd_slices((int)(64 * HW)) * 2);
+        g.ln_ppart_floats = 0;
+        for (int j = 0; j < 9; ++j) {
+            const size_t n = (size_t)ln_bwd_param_part_floats((int)lnsz[j]);
+            g.ln_ppart[j] = carve(n);
+            g.ln_ppart_floats = g.ln_ppart[j] + n - g.ln_ppart[0];
+        }
         {   // slots 7..11 = enc6, enc5, enc4 (transposed, anchors = their INPUT maps), enc2, enc1 (stride-2 convs)
             const int mode[5] = {1, 1, 1, 0, 0}, ci[5] = {64, 96, 128, 64, 32};
             const int hin[5] = {p->H2, p->H4, p->H8, p->H4, p->H2}, win[5] = {p->W2, p->W4, p->W8, p->W4, p->W2};
@@ -493,9 +501,18 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     const int par = t & 1, npar = par ^ 1;
     const int n2 = 32 * p->H2 * p->W2, n4 = 64 * p->H4 * p->W4, n8 = 128 * p->H8 * p->W8;
     float* lnpart = ws + g.lnpart;
-    auto lnb = [&](int j, const float* dy, int lddy, const float* y, int ldy, const float* x, float* dx, int n, int C, int relu) {
-        return ln_backward(dy, lddy, y, ldy, x, ws + S.lnstat + (size_t)j * B * 2, P(p, p->i_ln_g[j]), lnpart, dx,
-                           G(p, p->i_ln_g[j]), G(p, p->i_ln_b[j]), B, n, C, relu, s);
+    const long long ln_n[9] = {n2, n2, n2, n4, n4, n8, n4, n2, 64LL * HW};   // elements per sample of norm_enc0, hidden1..7, norm_enc6
+    auto ln_finish = [&](int j) -> int {
+        if (!p->ln_touched[j]) return PIVP_OK;
+        p->ln_touched[j] = false;
+        return ln_bwd_params_reduce(ws + g.ln_ppart[j], G(p, p->i_ln_g[j]), G(p, p->i_ln_b[j]), B, (int)ln_n[j], s);
+    };
+    auto lnb = [&](int j, const float* dy, int lddy, const float* y, int ldy, const float* x, float* dx, int n, int C, int relu) -> int {
+        RC(ln_backward(dy, lddy, y, ldy, x, ws + S.lnstat + (size_t)j * B * 2, P(p, p->i_ln_g[j]), lnpart, dx,
+                       G(p, p->i_ln_g[j]), G(p, p->i_ln_b[j]), B, n, C, relu, s, ws + g.ln_ppart[j]));
+        p->ln_touched[j] = true;
+        if (t == 0) RC(ln_finish(j));       // the sweep's last timestep: the partial planes become the gradient
+        return PIVP_OK;
     };
     // weight-gradient slots (pivp_plan::NSLOT): join = the main stream waits for the slot's last weight-gradient kernels
     auto fork_of = [&](int slot, SideFork& f) -> const SideFork* {
@@ -510,12 +527,15 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     const long long slab_bytes = p->nslabs > 1 ? ((long long)p->slabs[1].cat7 - (long long)p->slabs[0].cat7) * 4 : 0;
     // LayerNorm behind ConvLSTM i (hidden<i+1>): partial sums and parameter gradients here, dx inside the cell's gate backward
     LnFuse lf[7];
-    auto lnb_cell = [&](int i, const float* dy, int lddy, int n, int C) {
+    auto lnb_cell = [&](int i, const float* dy, int lddy, int n, int C) -> int {
         const int j = i + 1;
         lf[i].dy = dy; lf[i].lddy = lddy; lf[i].gamma = P(p, p->i_ln_g[j]); lf[i].stat = ws + S.lnstat + (size_t)j * B * 2;
         lf[i].partials = lnpart; lf[i].S = ln_bwd_slices(n); lf[i].h = ws + S.h[i];
-        return ln_backward(dy, lddy, nullptr, 0, ws + S.h[i], lf[i].stat, lf[i].gamma, lnpart, nullptr,
-                           G(p, p->i_ln_g[j]), G(p, p->i_ln_b[j]), B, n, C, 0, s);
+        RC(ln_backward(dy, lddy, nullptr, 0, ws + S.h[i], lf[i].stat, lf[i].gamma, lnpart, nullptr,
+                       G(p, p->i_ln_g[j]), G(p, p->i_ln_b[j]), B, n, C, 0, s, ws + g.ln_ppart[j]));
+        p->ln_touched[j] = true;
+        if (t == 0) RC(ln_finish(j));
+        return PIVP_OK;
     };
     auto lstmb = [&](int i, const float* x, int ldx, int hh, int wwid) -> int {
         const LstmSpec& L = kLstm[i];
@@ -584,6 +604,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         if (hipMemsetAsync(ws + g.cat7, 0, (size_t)px2 * 64 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
         if (hipMemsetAsync(ws + g.n5, 0, (size_t)px8 * 128 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     }
+    if (t == 0) RC(ln_finish(8));   // norm_enc6's backward does not run in a step no gradient reaches (the usual t = 0): finish it here
     // enc conv k's partial weight-gradient sums -> its gradient (once per sweep, behind its last weight-gradient launch)
     auto reduce_enc = [&](int k) -> int {
         if (!p->enc_desc_valid[k]) return PIVP_OK;
@@ -683,8 +704,10 @@ extern "C" int pivp_rollout_backward(pivp_plan_t* plan, const float* images, con
         if (gb > WG_BATCH) gb = WG_BATCH;
         plan->wg_batch = plan->bf16_all ? 1 : gb;
     }
-    // the enc convs' per-block partial weight gradients start from zero every sweep
+    // the enc convs' per-block partial weight gradients and the norms' partial parameter gradients start from zero every sweep
     if (hipMemsetAsync(ws + g.wg_part[0], 0, g.wg_part_floats * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
+    if (hipMemsetAsync(ws + g.ln_ppart[0], 0, g.ln_ppart_floats * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
+    for (int j = 0; j < 9; ++j) plan->ln_touched[j] = false;
     for (int k = 0; k < 5; ++k) plan->enc_desc_valid[k] = false;
     // d loss / d gen_states[t] for every t (zero before ctx-1), later accumulated with the state recurrence
     if (hipMemsetAsync(ws + g.dstate, 0, (size_t)T * B * 5 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
