@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, (LSTM && WM < 4) ? 2 : 1) void igemm_f32_kerne
         // (readfirstlane: carried from one chunk to the next these values lose their "uniform" proof, and a divergent
         // soffset turns every weight load into a waterfall loop)
         s_delta = __builtin_amdgcn_readfirstlane(((s_dy * d.Win + s_dx) * s_ld + cbase) * 4);   // bytes, relative to the anchor pixel
-        s_wbase = __builtin_amdgcn_readfirstlane((wi * (d.wcin >> 5) + l_cc) * d.N * 128);       // bytes; the weight keeps all its Cin chunks
+        s_wbase = __builtin_amdgcn_readfirstlane((wi * (d.wcin >> 5) + l_cc) * (d.wN ? d.wN : d.N) * 128);       // bytes; the weight keeps all its Cin chunks
         ++l_cc;
         const bool w0 = l_cc == ncc;
         l_cc = w0 ? 0 : l_cc;

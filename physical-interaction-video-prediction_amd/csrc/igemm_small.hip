@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
         const bool first = ch < d.c0;
         const int ld = first ? d.ld0 : d.ld1;
         const int delta = ((dy * d.Win + dx) * ld + (first ? ch : ch - d.c0)) * 4;
-        const int wbase = (wi * (d.wcin >> 5) + l_cc) * d.N * 128;
+        const int wbase = (wi * (d.wcin >> 5) + l_cc) * (d.wN ? d.wN : d.N) * 128;
         const int iy = a_iy0 + dy, ix = a_ix0 + dx;
         const bool ok = (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
         const unsigned off = ok ? (unsigned)((first ? a_off0 : a_off1) + delta) : OOB;

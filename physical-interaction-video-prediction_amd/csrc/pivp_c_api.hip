@@ -75,20 +75,20 @@ int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const floa
 
 // stride-1 K x K "same" convolution through the generic kernel (used as the ConvLSTM data gradient)
 int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, int cout, int ldo, int ksize, int B, int H, int W,
-                hipStream_t s, int accum) {
+                hipStream_t s, int accum, int wN) {
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
     d.x0 = x; d.c0 = cin; d.ld0 = ldx; d.wcin = cin; d.w = w; d.bias = nullptr;
     d.B = B; d.Hin = H; d.Win = W; d.Hg = H; d.Wg = W; d.in_step = 1;
-    d.N = cout; d.M = B * H * W;
+    d.N = cout; d.M = B * H * W; d.wN = wN > cout ? wN : 0;
     d.nphase = 1; d.deconv = 0; d.ksize = ksize; d.pad = ksize / 2;
-    const long long b0 = view_bytes(B, H, W, ldx), bw = (long long)ksize * ksize * cin * cout * 4;
+    const long long b0 = view_bytes(B, H, W, ldx), bw = (long long)ksize * ksize * cin * (wN > cout ? wN : cout) * 4;
     if (!fits31(b0) || !fits31(bw)) return PIVP_ERR_BADARG;
     d.bytes0 = (int)b0; d.bytesw = (int)bw;
     d.out_step = 1; d.Hout = H; d.Wout = W; d.out = out; d.ldo = ldo; d.relu = 0; d.accum = accum;
-    if (!accum && ldo == cout) {     // contiguous fresh output: allow the K-split path, which needs a zeroed destination
-        d.ksplit_ok = 1;
-        if (igemm_conv_ksplit(d) > 1 && hipMemsetAsync(out, 0, (size_t)B * H * W * cout * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
+    if (!accum && (ldo == cout || d.wN)) {   // fresh output (contiguous, or the leading columns of a buffer whose rest nobody reads): the K-split
+        d.ksplit_ok = 1;                     // path is allowed; it needs a zeroed destination
+        if (igemm_conv_ksplit(d) > 1 && hipMemsetAsync(out, 0, (size_t)B * H * W * ldo * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     }
     return igemm_conv(d, s);
 }
@@ -155,7 +155,7 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
                           const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                           float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
                           int B, int H, int W, hipStream_t s, int wt_ready, unsigned short* wt_bf16, int bf16_planes, const SideFork* fork,
-                          const LnFuse* ln) {
+                          const LnFuse* ln, int dx_only) {
     const int M = B * H * W, cin = cx + C, N = 4 * C;
     int rc = lstm_gates_bwd(gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc, dc_valid, dG, M, C, s, B, ln);
     if (rc != PIVP_OK) return rc;
@@ -174,7 +174,8 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
         }
         rc = run_conv5x5_bf16(dG, N, N, wt_bf16, d_in, cin, cin, 0, B, H, W, s, bf16_planes);
     } else {
-        rc = run_conv_s1(dG, N, N, wt, d_in, cin, cin, 5, B, H, W, s);    // d[x,h] = conv5x5(dG, W^T flipped)
+        // d[x,h] = conv5x5(dG, W^T flipped); dx_only: the x columns alone (the pack's first cx of cin; the h columns of d_in stay unwritten)
+        rc = dx_only ? run_conv_s1(dG, N, N, wt, d_in, cx, cin, 5, B, H, W, s, 0, cin) : run_conv_s1(dG, N, N, wt, d_in, cin, cin, 5, B, H, W, s);
     }
     if (rc != PIVP_OK) return rc;
     if (!dW) return PIVP_OK;   // the caller batches this layer's weight gradient over several timesteps itself (pivp_plan.hip)

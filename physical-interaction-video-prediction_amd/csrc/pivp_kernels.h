@@ -22,6 +22,7 @@ struct IgemmDesc {
     int B, Hin, Win;                     // input feature-map size
     int Hg, Wg, in_step;                 // anchor grid; input coord = anchor*in_step + (dy,dx)
     int N, M;                            // output columns; M = B*Hg*Wg
+    int wN;                              // columns the weight was packed with (0: N): N < wN computes the first N columns only
     int nphase;                          // 1 (conv) or 4 (sub-pixel phases of the stride-2 transposed conv)
     int deconv, ksize, pad;              // tap set: conv ksize x ksize with `pad`, or transposed 3x3 s2 p1
     int bytes0, bytes1, bytesw;          // extents of x0 / x1 / w for the buffer descriptors (< 2^31)

@@ -553,7 +553,8 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                                  last_step ? nullptr : ws + g.din[i][npar] + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
                                  ring + (size_t)wg_slot * dG1, ws + g.wt_lstm[i], ws + g.din[i][par], nullptr, nullptr, B, hh, wwid,
                                  s, 1, p->lstm_bf16 ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->lstm_planes,
-                                 wg_flush ? fork_of(i, f) : nullptr, &lf[i]));   // dW = null: only the fork's `ready` (behind the gate math) is used
+                                 wg_flush ? fork_of(i, f) : nullptr, &lf[i],    // dW = null: only the fork's `ready` (behind the gate math) is used
+                                 t == 0 ? 1 : 0));                              // t = 0: nobody reads d h_{-1}
         if (!wg_flush) return PIVP_OK;
         // weight + bias gradient of the whole batch: timestep j of it reads slab (first - j) and ring slot j; on the side stream it
         // starts as soon as this step's dG exists, next to this step's own data gradient
