@@ -46,8 +46,8 @@ constexpr int IG_P = 36;  // LDS row pitch in floats (A and B tiles)
 #endif
 constexpr bool XCD_MAP = PIVP_XCD_MAP != 0;
 
-template <int WM, int NTB>
-constexpr int ig_lds_bytes() { return 2 * (32 * WM + 32 * NTB) * IG_P * 4; }
+template <int WM, int NTB, int KG = 1>
+constexpr int ig_lds_bytes() { return KG * 2 * (32 * WM + 32 * NTB) * IG_P * 4; }
 
 // sigmoid / tanh of the gate epilogue through v_exp_f32 / v_rcp_f32: |error| <= ~2e-7 absolute, an order
 // below the fp32 accumulation noise of the K = 1600..4800 dot products in front of them.
@@ -78,18 +78,27 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // ABL: timing-only ablations for scripts/bench_lstm_layers.py (built with -DPIVP_ABLATE; outputs are wrong):
 //   1 = no global loads and no LDS stores, 2 = loads but no LDS stores, 3 = as 1 without the barrier,
 //   4 = as 2 with constant load addresses (no per-chunk address math), 5 = address math only.
-template <int WM, int WN, int NTB, bool LSTM, int ABL = 0>
-__global__ __launch_bounds__(256, (LSTM && WM < 4) ? 2 : 1) void igemm_f32_kernel(const IgemmDesc d) {
+// KG = 2 (ConvLSTM on small maps, lstm5's 8 x 8): the block is TWO groups of 4 waves that each run HALF of the K chunks of the same
+// output tile through their own LDS buffers, in lockstep (same barriers); group 1 then hands its accumulators to group 0 through LDS
+// and group 0 runs the epilogue.  With M = 2048 anchors there are only 256 tiles of 32 x 128: one block per CU, one wave per SIMD,
+// MFMA pipe busy 0.62.  Measured: lstm5 110.6 -> 117 TFLOP/s only (rollout 8.69 -> 8.66 ms): the tile is not short of waves but of L2
+// bandwidth -- 256 blocks x 150 chunks x (4 KB of A + 16 KB of B) = 614 MB per launch in ~80 us, 7.7 TB/s; a 32-row tile uses every
+// weight byte for 32 MACs.  A square 64 x 64 tile (16 channels x 4 gates) would move 20 % less; not built.
+template <int WM, int WN, int NTB, bool LSTM, int ABL = 0, int KG = 1>
+__global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void igemm_f32_kernel(const IgemmDesc d) {
     static_assert(WM * WN == 4, "4 waves");
+    static_assert(KG == 1 || (KG == 2 && LSTM), "the in-block K split serves the ConvLSTM tile only");
     static_assert(!LSTM || NTB == 4, "ConvLSTM blocks own 4 gates x 32 channels");
     constexpr int BM = 32 * WM;
     constexpr int BN = 32 * NTB;
     constexpr int TPW = LSTM ? 4 / WN : NTB / WN;
     constexpr int CPW = 32 / WN;  // LSTM: channels per wave
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
     constexpr int A_FLOATS = BM * IG_P, B_FLOATS = BN * IG_P;
+    const int gid = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;     // K group of this wave
+    float* const lds = lds_all + gid * 2 * (A_FLOATS + B_FLOATS);                           // the group's own A / B buffers
 
-    const int tid = threadIdx.x;
+    const int tid = KG > 1 ? (int)threadIdx.x & 255 : (int)threadIdx.x;                     // thread index inside the group
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
@@ -118,7 +127,9 @@ __global__ __launch_bounds__(256, (LSTM && WM < 4) ? 2 : 1) void igemm_f32_kerne
     const int ksplit = gridDim.z;
     const int ty_begin = (nty_all * (int)blockIdx.z) / ksplit, ty_end = (nty_all * ((int)blockIdx.z + 1)) / ksplit;
     const int nty = ty_end - ty_begin;
-    const int nchunks = nty * ntx * ncc;
+    const int nchunks_all = nty * ntx * ncc;
+    const int nchunks = nchunks_all / KG;               // (KG = 2: the launcher only takes this form for an even chunk count)
+    const int chunk0 = gid * nchunks;                   // this group's first chunk
     const int HWg = d.Hg * d.Wg;
 
     // ---- staging roles ---------------------------------------------------------------------
@@ -179,6 +190,7 @@ __global__ __launch_bounds__(256, (LSTM && WM < 4) ? 2 : 1) void igemm_f32_kerne
 
     // scalar state of the NEXT chunk to load: channel chunk l_cc of tap (l_ty, l_tx); no division, no branch
     int l_cc = 0, l_ty = ty_begin, l_tx = 0;
+    if constexpr (KG > 1) { const int tap = chunk0 / ncc; l_cc = chunk0 - tap * ncc; l_ty = ty_begin + tap / ntx; l_tx = tap - (tap / ntx) * ntx; }
     int s_delta = 0, s_ld = 0, s_wbase = 0;
     unsigned s_bit = 0;
     bool s_first = true;
@@ -389,6 +401,26 @@ __global__ __launch_bounds__(256, (LSTM && WM < 4) ? 2 : 1) void igemm_f32_kerne
             }
     }
 
+    if constexpr (KG > 1) {   // group 1 hands its half of the K sum to group 0: [register][thread] floats through the (dead) tile buffers
+        __syncthreads();
+        float* xch = lds_all;
+        if (gid == 1) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[(t * 16 + r) * 256 + tid] = accs[0][t][r];
+        }
+        __syncthreads();
+        if (gid == 1) {       // group 0 alone runs the epilogue; group 1 only keeps it company at the statistics' three barriers
+            if (LSTM && d.ln_part) { __syncthreads(); __syncthreads(); __syncthreads(); }
+            return;
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accs[0][t][r] += xch[(t * 16 + r) * 256 + tid];
+    }
+
     // ---- epilogue --------------------------------------------------------------------------
     // (count, mean, M2) of the block's output tile, two passes over the values held in registers, fixed summation
     // order (bitwise reproducible); written as one LayerNorm partial of sample b.
@@ -522,14 +554,14 @@ __global__ __launch_bounds__(256, (LSTM && WM < 4) ? 2 : 1) void igemm_f32_kerne
     }
 }
 
-template <int WM, int WN, int NTB, bool LSTM, int ABL = 0>
+template <int WM, int WN, int NTB, bool LSTM, int ABL = 0, int KG = 1>
 static int launch_igemm(const IgemmDesc& d, hipStream_t stream, int ksplit = 1, int* ln_nparts = nullptr) {
     constexpr int BM = 32 * WM, BN = 32 * NTB;
     const int n_nblk = LSTM ? (d.C >> 5) : (d.N / BN);
     const int mblk = (d.M + BM - 1) / BM;
-    constexpr int lds_bytes = ig_lds_bytes<WM, NTB>();
+    constexpr int lds_bytes = ig_lds_bytes<WM, NTB, KG>();
     static PerDeviceOnce once;
-    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&igemm_f32_kernel<WM, WN, NTB, LSTM, ABL>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&igemm_f32_kernel<WM, WN, NTB, LSTM, ABL, KG>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     dim3 grid(mblk * n_nblk, d.nphase, ksplit);
     IgemmDesc dd = d;
     // fused LayerNorm partials: only when no tile straddles two samples and the caller's buffer holds them
@@ -538,7 +570,7 @@ static int launch_igemm(const IgemmDesc& d, hipStream_t stream, int ksplit = 1, 
     dd.ln_nparts = (d.ln_part && ksplit == 1 && hwg % BM == 0 && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
-    hipLaunchKernelGGL((igemm_f32_kernel<WM, WN, NTB, LSTM, ABL>), grid, dim3(256), lds_bytes, stream, dd);
+    hipLaunchKernelGGL((igemm_f32_kernel<WM, WN, NTB, LSTM, ABL, KG>), grid, dim3(256 * KG), lds_bytes, stream, dd);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -597,7 +629,13 @@ int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant, int* ln_npar
     switch (variant) {
         case 1: return launch_igemm<4, 1, 4, true>(d, stream, 1, ln_nparts);
         case 2: return launch_igemm<2, 2, 4, true>(d, stream, 1, ln_nparts);
-        case 3: return launch_igemm<1, 4, 4, true>(d, stream, 1, ln_nparts);
+        case 3: {
+            // the in-block K split needs an even number of chunks (25 taps x (c0 + c1) / 32: always even when the channel count is a multiple of 64)
+            static const int kg = [] { const char* e = getenv("PIVP_LSTM_KG"); return e ? atoi(e) : 2; }();   // tuning: 1 = one group
+            const int ncc = (d.c0 + d.c1) >> 5;
+            if (kg == 2 && ((25 * ncc) & 1) == 0) return launch_igemm<1, 4, 4, true, 0, 2>(d, stream, 1, ln_nparts);
+            return launch_igemm<1, 4, 4, true>(d, stream, 1, ln_nparts);
+        }
     }
     return PIVP_ERR_BADARG;
 }

@@ -48,7 +48,10 @@ def test_convlstm_first_step_skips_zero_h(ops, variant):
     hg, cg = ops.convlstm(x, h, c, W, b, variant, h_is_zero=True)
     hz, cz = ops.convlstm(x, h, c, W, b, variant, h_is_zero=False)
     assert np.abs(hg - hr).max() < TOL and np.abs(cg - cr).max() < TOL
-    assert np.array_equal(hg, hz) and np.array_equal(cg, cz)      # skipping adds exact zeros: bit-identical
+    if variant in (0, 3):      # the 1x4 tile splits K over two wave groups: 25 + 25 chunks without h, 75 + 75 with it -- other partial sums
+        assert np.abs(hg - hz).max() < 1e-6 and np.abs(cg - cz).max() < 1e-6
+    else:
+        assert np.array_equal(hg, hz) and np.array_equal(cg, cz)      # skipping adds exact zeros: bit-identical
 
 
 @pytest.mark.parametrize('variant', [0, 1, 2, 3])
