@@ -320,7 +320,8 @@ class Model(object):
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def _reset_plan(self, plan):
-        _lib.check(plan.lib.pivp_reset_state(plan.h, self._stream()), 'pivp_reset_state')
+        with torch.cuda.device(self.device):
+            _lib.check(plan.lib.pivp_reset_state(plan.h, self._stream()), 'pivp_reset_state')
 
     # ---- reference surface ----------------------------------------------------------------
     def reset_state(self):
@@ -432,9 +433,11 @@ class Model(object):
             cb = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int)(_trampoline)
             _lib.check(plan.lib.pivp_plan_set_grad_callback(plan.h, ctypes.cast(cb, ctypes.c_void_p), None), 'pivp_plan_set_grad_callback')
         try:
-            _lib.check(plan.lib.pivp_rollout_backward(plan.h, images.data_ptr(), actions.data_ptr(), states.data_ptr(), gt_ptr,
-                                                      self._gen.data_ptr(), self._gen_states.data_ptr(), self._stream()),
-                       'pivp_rollout_backward')
+            # the model's device must be the CURRENT one for the launches (and for the plan's own side stream, created on first use)
+            with torch.cuda.device(self.device):
+                _lib.check(plan.lib.pivp_rollout_backward(plan.h, images.data_ptr(), actions.data_ptr(), states.data_ptr(), gt_ptr,
+                                                          self._gen.data_ptr(), self._gen_states.data_ptr(), self._stream()),
+                           'pivp_rollout_backward')
         finally:
             if cb is not None:
                 plan.lib.pivp_plan_set_grad_callback(plan.h, None, None)
@@ -497,7 +500,8 @@ class Model(object):
         else:
             raise KeyError(name)
         out = torch.empty(shape, dtype=torch.float32, device=self.device)
-        n = plan.lib.pivp_get_tap(plan.h, name.encode(), step, out.data_ptr(), self._stream())
+        with torch.cuda.device(self.device):
+            n = plan.lib.pivp_get_tap(plan.h, name.encode(), step, out.data_ptr(), self._stream())
         if n < 0:
             _lib.check(int(n), 'pivp_get_tap(%s, %d)' % (name, step))
         assert n == out.numel()

@@ -50,9 +50,10 @@ class Adam(object):
         if self._dp is not None:
             gscale = 1.0 / self._dp.world_size
         lib = _lib.load()
-        _lib.check(lib.pivp_adam_step(model._flat_params.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(),
-                                      model._flat_params.numel(), self.lr, self.beta1, self.beta2, self.eps, gscale,
-                                      model._stream()), 'pivp_adam_step')
+        with torch.cuda.device(model._flat_params.device):      # launches need the model's device to be the current one
+            _lib.check(lib.pivp_adam_step(model._flat_params.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                          model._flat_params.numel(), self.lr, self.beta1, self.beta2, self.eps, gscale,
+                                          model._stream()), 'pivp_adam_step')
 
     def update(self, lossfun, *args):
         """chainer.Optimizer.update(lossfun, *args): loss = lossfun(*args); cleargrads; backward; update."""

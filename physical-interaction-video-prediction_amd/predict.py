@@ -21,8 +21,9 @@ def resize_images(frames, out_hw, device='cuda:0', scale=1.0):
     x = torch.as_tensor(np.ascontiguousarray(frames, dtype=np.float32)).to(device)
     B, C, H, W = x.shape
     out = torch.empty((B, C, out_hw[0], out_hw[1]), dtype=torch.float32, device=device)
-    _lib.check(lib.pivp_resize_images(x.data_ptr(), out.data_ptr(), B * C, H, W, out_hw[0], out_hw[1], float(scale),
-                                      torch.cuda.current_stream(x.device).cuda_stream), 'pivp_resize_images')
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pivp_resize_images(x.data_ptr(), out.data_ptr(), B * C, H, W, out_hw[0], out_hw[1], float(scale),
+                                          torch.cuda.current_stream(x.device).cuda_stream), 'pivp_resize_images')
     return out
 
 
