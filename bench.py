@@ -14,6 +14,8 @@ Two legs, both in the ONE JSON line rank 0 prints:
   train               : optimizer.update (train_model.py:950) = forward + BPTT backward + gradient all-reduce over RCCL, overlapped
                         with the backward sweep + Adam: ms_per_step, frames_per_s (whole job), rccl_ranks, and
                         allreduce_ms_exposed = that step time minus the time of the same step with the collective switched off.
+  train_bf16          : the same leg in the bf16 precision mode (fp32 runs only): BASELINE.json's config 3 is bf16 data parallel, so at
+                        --gpus 8 (global batch 256) this object is config 3.
 
 A "step" is one Model.__call__ (TM:620-764) over one synthetic batch already resident in HBM:
 B sequences x (T-1) predicted frames, feed-self after the context frames as predict_model.py:126-128.
@@ -71,6 +73,7 @@ def build_parser():
                     help='rollout (default): `value` is the rollout and the train step is reported in `train`; train: only the '
                          'train step runs and `value` is its frames/s (profiling runs)')
     ap.add_argument('--no-train', action='store_true', help='rollout mode: skip the train leg')
+    ap.add_argument('--no-bf16-train', action='store_true', help='fp32 runs: skip the additional bf16 train leg (`train_bf16`, config 3\'s arithmetic)')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'bf16x3'],
                     help='fp32: the parity path and the headline metric (config 2). bf16: ConvLSTM gate convolutions with bf16 operands, '
                          'fp32 accumulation (config 3); reports its per-pixel error instead of meeting the 1e-4 gate')
@@ -219,35 +222,38 @@ def main(argv=None):
             elapsed, _ = timed(lambda: time.sleep(0.001), args.steps, args.warmup, sync, barrier)
             elapsed = max_over_ranks(elapsed); loss_val = 0.0
 
-        # ---- leg 2: the data-parallel train step ----------------------------------------------------------------
-        train_obj = None
-        tmodel = None
-        if do_train:
-            dp = pivp_amd.GradAllReduce() if world > 1 else None
+        # ---- leg 2: the data-parallel train step (the run's precision; in the default fp32 run also config 3's bf16 arithmetic) ----------
+        train_obj = train_bf16_obj = None
+        tmodel = opt = None
+        dp = pivp_amd.GradAllReduce() if (do_train and world > 1) else None
+
+        def train_leg(precision):
+            """-> (result object, model, optimizer, seconds for K steps with the collective, last loss)"""
+            use_dp = [True]
             if dry:
-                tmodel = pivp_amd.HostStubModel(sizes=(1 << 16, 1 << 14, 1 << 15, 1 << 15, 1 << 16, 1 << 14), value=float(rank + 1))
-                ngrad = sum(tmodel.sizes)
+                tm = pivp_amd.HostStubModel(sizes=(1 << 16, 1 << 14, 1 << 15, 1 << 15, 1 << 16, 1 << 14), value=float(rank + 1))
+                op = None
+                ngrad = sum(tm.sizes)
 
                 def train_step():
-                    tmodel.cleargrads()
+                    tm.cleargrads()
                     if dp is not None and use_dp[0]:
-                        dp.backward_and_allreduce(tmodel)
+                        dp.backward_and_allreduce(tm)
                     else:
-                        tmodel.backward()
+                        tm.backward()
                     return 0.0
             else:
-                tmodel = pivp_amd.Model(nm, prefix='bench', device=dev, keep_activations=True, precision=args.precision, **kinds)
-                opt = pivp_amd.Adam(alpha=0.001).setup(tmodel, data_parallel=dp)        # TM:860-861
-                tmodel([images, actions, states], 0)                                    # parameters are lazily sized: one forward first
+                tm = pivp_amd.Model(nm, prefix='bench', device=dev, keep_activations=True, precision=precision, **kinds)
+                op = pivp_amd.Adam(alpha=0.001).setup(tm, data_parallel=dp)             # TM:860-861
+                tm([images, actions, states], 0)                                        # parameters are lazily sized: one forward first
                 if world > 1:                                                           # identical replicas: rank 0's initialisation
-                    dist.broadcast(tmodel._flat_params, src=0)
-                ngrad = int(tmodel._flat_params.numel())
+                    dist.broadcast(tm._flat_params, src=0)
+                ngrad = int(tm._flat_params.numel())
 
                 def train_step():
-                    tmodel.reset_state()
-                    opt._dp = dp if use_dp[0] else None
-                    return opt.update(tmodel, [images, actions, states], 0)             # schedsamp_k = -1: feed-self, deterministic
-            use_dp = [True]
+                    tm.reset_state()
+                    op._dp = dp if use_dp[0] else None
+                    return op.update(tm, [images, actions, states], 0)                  # schedsamp_k = -1: feed-self, deterministic
             t_with, tloss = timed(train_step, args.steps, args.warmup, sync, barrier)
             t_with = max_over_ranks(t_with)
             t_without = None
@@ -256,7 +262,9 @@ def main(argv=None):
                 t_without, _ = timed(train_step, args.steps, max(1, args.warmup // 2), sync, barrier)
                 t_without = max_over_ranks(t_without)
                 use_dp[0] = True
-            train_obj = {
+                if op is not None:
+                    op._dp = dp
+            obj = {
                 'ms_per_step': round(t_with / args.steps * 1e3, 3),
                 'frames_per_s': round(world * B * (T - 1) * args.steps / t_with, 1),
                 'rccl_ranks': dist.get_world_size() if dist is not None else 1,
@@ -265,11 +273,21 @@ def main(argv=None):
                 'allreduce_ms_exposed': 0.0 if t_without is None else round(max(0.0, t_with - t_without) / args.steps * 1e3, 3),
                 'gradient_bytes_per_step': 4 * ngrad,
                 'allreduce': 'none (1 rank)' if world == 1 else '6 gradient groups, SUM, issued from inside the backward sweep of t = 0 on a side stream',
+                'dtype': {'fp32': 'f32', 'bf16': 'bf16 ConvLSTM / enc5 / enc6 operands, f32 accumulate, gradients and optimizer',
+                          'bf16x3': 'f32 as 2 bf16 pieces in the ConvLSTM forward and data gradients'}[precision],
                 'workload': 'optimizer.update (TM:950): forward + BPTT backward + gradient all-reduce + Adam, schedsamp_k=-1, batch %d/GPU' % B,
                 'loss': float(tloss),
             }
+            return obj, tm, op, t_with, float(tloss)
+
+        if do_train:
+            train_obj, tmodel, opt, t_with, tloss = train_leg(args.precision)
             if args.mode == 'train':
-                elapsed, loss_val = t_with, float(tloss)
+                elapsed, loss_val = t_with, tloss
+            elif args.precision == 'fp32' and not dry and not args.no_bf16_train:
+                # BASELINE.json config 3 names bf16 for the data-parallel configuration: at --gpus 8 this object IS config 3 (global batch 256)
+                train_bf16_obj, m16, _, _, _ = train_leg('bf16')
+                del m16
 
         # ---- the dominant kernel against its roofline, HIP events on the launch stream, second pass over the same K steps ----------
         pmodel = model if do_rollout else tmodel
@@ -320,6 +338,8 @@ def main(argv=None):
         }
         if not train_mode:
             out['train'] = train_obj
+            if train_bf16_obj is not None:
+                out['train_bf16'] = train_bf16_obj
         if dry:
             out['dry'] = True
         print(json.dumps(out))
