@@ -109,6 +109,20 @@ def test_scheduled_sampling_masks_match_reference_rng_use():
     assert mask[ctx:].sum(axis=1).tolist() == [ngt] * (T - 1 - ctx)
 
 
+def test_rank_offset_sampling_streams():
+    # data parallel: every rank draws its scheduled-sampling shuffles from its OWN stream (train.py: RandomState(1 + rank)),
+    # leaves the global RNG -- which orders the dataset identically on every rank -- untouched, and is reproducible per rank
+    B, T, ctx, k, it = 8, 6, 2, 4.0, 3.0
+    np.random.seed(5)
+    before = np.random.get_state()[1].copy()
+    masks = [pivp_amd.scheduled_sampling_masks(B, T, ctx, k, it, rng=np.random.RandomState(1 + rank)) for rank in range(4)]
+    assert np.array_equal(np.random.get_state()[1], before)               # the global stream was not consumed
+    assert all(m[ctx:].sum(axis=1).tolist() == masks[0][ctx:].sum(axis=1).tolist() for m in masks)   # same count per step (TM:654-656)
+    assert len({m.tobytes() for m in masks}) == 4                         # but different samples on every rank
+    again = pivp_amd.scheduled_sampling_masks(B, T, ctx, k, it, rng=np.random.RandomState(1 + 2))
+    assert np.array_equal(again, masks[2])
+
+
 def test_concat_examples_matches_reference_layout():
     rs = np.random.RandomState(0)
     batch = [(rs.rand(4, 8, 8, 3).astype(np.float32), rs.rand(4, 5).astype(np.float32), rs.rand(4, 5).astype(np.float32))
