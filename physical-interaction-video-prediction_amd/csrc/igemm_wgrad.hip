@@ -243,7 +243,8 @@ __global__ __launch_bounds__(256) void igemm_wgrad_reduce_kernel(const WgradDesc
 // ---------------------------------------------------------------------------------------------------------
 // (Round 2 also spread the staging over the chunk's 16 k-steps, one load and one ds_write per k-step in the shadow of its ten MFMAs, as
 // igemm_f32.hip does: 159.6 vs 159.8 us per launch, no gain -- and 213 us with a run-time `if (c + 8 < c_end)` around the pieces, which
-// makes hipcc drain vmcnt in front of every ds_write.  The block form of issue() / store() stays.)
+// makes hipcc drain vmcnt in front of every ds_write.  Interleaving at MFMA granularity (sched_group_barrier: 1 MFMA, 3 VALU, ten times) gave
+// 160.0 us.  The pipe's idle third (MFMA busy 0.65) is not the staging's issue slots.  The block form of issue() / store() stays.)
 // (Round 2 tried two blocks per CU: one LDS region and one staging register set per wave, 51 KB per block, launch_bounds(256, 2).  The 160
 // accumulator registers leave 96 for everything else: 76-97 VGPRs spill and the train step went 32.3 -> 35.0 ms.  One block per CU stays.)
 template <int NTW, int SW>   // NTW: 32-column tiles per wave (1 or 2); SW: pixels of one image row inside a chunk (min(W, 32))
