@@ -38,8 +38,8 @@ extern "C" {
 #define PIVP_PRECISION_BF16 1
 #define PIVP_PRECISION_BF16X3 2
 
-int pivp_abi_version(void);   /* 5 (2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
-                                 5: + bf16 ConvLSTM, pivp_plan_set_precision) */
+int pivp_abi_version(void);   /* 6 (2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+                                 5: + bf16 ConvLSTM, pivp_plan_set_precision, 6: + pivp_plan_set_group_join / pivp_plan_group_wait) */
 
 /* ------------------------------------------------------------------------------------------
  * Plan = Model.__init__ (TM:484-602): layer table, op program, variant head.
@@ -117,6 +117,15 @@ typedef void (*pivp_grad_group_cb)(void* user, int group);
 int pivp_param_group(const pivp_plan_t* plan, int idx);
 int pivp_param_group_by_name(const char* name);            /* same mapping, from the checkpoint key alone */
 int pivp_plan_set_grad_callback(pivp_plan_t* plan, pivp_grad_group_cb cb, void* user);
+/* The weight gradients of a group may still be running on the plan's internal side stream when the group's last kernel has been
+ * enqueued on the caller's.  Default (join = 1): before the callback the CALLER'S stream is made to wait for them, so "announced"
+ * means "final in stream order on the caller's stream" -- simple, and it stalls the sweep's last timestep by ~0.3 ms per step.
+ * join = 0: the caller's stream is not held up; the host must then call pivp_plan_group_wait(plan, g, comm_stream) from inside the
+ * callback, which makes ONLY that stream wait for the side stream's work of group g (in addition to the event the host records on
+ * the caller's stream).  pivp_rollout_backward still joins everything before it returns, so whatever the caller enqueues after the
+ * sweep (the optimizer step) is ordered behind every gradient either way. */
+int pivp_plan_set_group_join(pivp_plan_t* plan, int join);
+int pivp_plan_group_wait(pivp_plan_t* plan, int group, void* stream);
 int pivp_rollout_backward(pivp_plan_t* plan, const float* images, const float* actions, const float* states,
                           const unsigned char* gt_select, const float* gen_images, const float* gen_states, void* stream);
 

@@ -43,6 +43,8 @@ SIGNATURES = {
     'pivp_param_group': (_i, [_vp, _i]),
     'pivp_param_group_by_name': (_i, [_c.c_char_p]),
     'pivp_plan_set_grad_callback': (_i, [_vp, _vp, _vp]),
+    'pivp_plan_set_group_join': (_i, [_vp, _i]),
+    'pivp_plan_group_wait': (_i, [_vp, _i, _vp]),
     'pivp_convlstm_ln_scratch_floats': (_ll, [_i, _i, _i, _i]),
     'pivp_convlstm_ln': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
     'pivp_plan_set_precision': (_i, [_vp, _i]),

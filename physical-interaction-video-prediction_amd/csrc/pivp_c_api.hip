@@ -252,7 +252,7 @@ long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin,
 
 }  // namespace pivp
 
-extern "C" int pivp_abi_version(void) { return 5; }   // 5: + bf16 ConvLSTM entry points, pivp_plan_set_precision
+extern "C" int pivp_abi_version(void) { return 6; }   // 6: + pivp_plan_set_group_join / pivp_plan_group_wait
 
 extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                              const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream) {

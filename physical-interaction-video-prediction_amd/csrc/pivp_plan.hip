@@ -107,6 +107,7 @@ struct pivp_plan {
     hipEvent_t ev_ring_done[7][2] = {};        // ConvLSTM slots: one `done` per dG ring (slots 0..6 of ev_done are unused)
     int wg_batch = 1;                          // timesteps per weight-gradient launch (<= WG_BATCH; always 1 in the bf16 mode, whose kernel takes one)
     const float* wg_x[7] = {}; const float* wg_h[7] = {};   // operands of the first timestep of the open batch
+    bool group_join = true;                                 // pivp_plan_set_group_join
     bool ln_touched[9] = {};                                // norms whose partial parameter gradients still await their reduction
     WgradDesc enc_desc[5]; bool enc_desc_valid[5] = {};     // enc6, enc5, enc4, enc2, enc1: what this sweep launched (for the reduction of the partial sums)
     ~pivp_plan() {
@@ -489,6 +490,27 @@ extern "C" int pivp_rollout_forward(pivp_plan_t* plan, const float* images, cons
 // backward through time (what loss.backward() does inside Chainer's optimizer.update, TM:950), all three heads.
 // Gradients are ACCUMULATED into the buffers registered with pivp_plan_set_grad (same layouts as the parameters).
 // ------------------------------------------------------------------------------------------------------------
+// side-stream slots whose weight gradients belong to gradient group g (pivp_plan::NSLOT numbering)
+static const int kGroupSlots[6][4] = {{7, 13, -1, -1}, {6, -1, -1, -1}, {8, 5, -1, -1}, {9, 4, -1, -1}, {10, 3, 2, -1}, {11, 1, 0, 12}};
+// make `stream` wait for the side stream's latest work of one slot (no side stream: nothing to do).  NB: a null hipStream_t is the
+// legacy default stream, a perfectly good stream to wait on -- never a "no stream" marker.
+static int wait_slot(pivp_plan* p, int sl, hipStream_t stream) {
+    if (!p->side) return PIVP_OK;
+    if (sl >= 7) return hipStreamWaitEvent(stream, p->ev_done[sl], 0) == hipSuccess ? PIVP_OK : PIVP_ERR_LAUNCH;
+    for (int r = 0; r < 2; ++r) if (hipStreamWaitEvent(stream, p->ev_ring_done[sl][r], 0) != hipSuccess) return PIVP_ERR_LAUNCH;
+    return PIVP_OK;
+}
+extern "C" int pivp_plan_set_group_join(pivp_plan_t* plan, int join) {
+    if (!plan) return PIVP_ERR_BADARG;
+    plan->group_join = join != 0;
+    return PIVP_OK;
+}
+extern "C" int pivp_plan_group_wait(pivp_plan_t* plan, int group, void* stream) {
+    if (!plan || group < 0 || group >= 6) return PIVP_ERR_BADARG;
+    for (int k = 0; k < 4; ++k) if (kGroupSlots[group][k] >= 0) RC(wait_slot(plan, kGroupSlots[group][k], (hipStream_t)stream));
+    return PIVP_OK;
+}
+
 // wg_ring / wg_slot: where this step's gate gradients go in the ConvLSTMs' dG rings; wg_flush: this step closes its batch
 static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_grad, const float* action, const float* state_prev,
                          bool has_go, float* go, float* go_prev, bool last_step, int wg_ring, int wg_slot, bool wg_flush, hipStream_t s) {
@@ -622,13 +644,11 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
             if (encs[group][0] >= 0) RC(reduce_enc(encs[group][0]));
         }
         if (t != 0 || !p->grad_cb) return PIVP_OK;
-        static const int slots[6][4] = {{7, 13, -1, -1}, {6, -1, -1, -1}, {8, 5, -1, -1}, {9, 4, -1, -1}, {10, 3, 2, -1}, {11, 1, 0, 12}};
+        const int (&slots)[6][4] = kGroupSlots;
         for (int k = 0; k < 4; ++k) {
             const int sl = slots[group][k];
-            if (sl >= 12) RC(join(sl));
-            else if (sl >= 7) { RC(reduce_enc(sl - 7)); RC(join(sl)); }
-            else if (sl >= 0 && p->side)
-                for (int r = 0; r < 2; ++r) if (hipStreamWaitEvent(s, p->ev_ring_done[sl][r], 0) != hipSuccess) return PIVP_ERR_LAUNCH;
+            if (sl >= 7 && sl < 12) RC(reduce_enc(sl - 7));          // behind the conv's last weight-gradient launch, on the same stream
+            if (sl >= 0 && p->group_join) RC(wait_slot(p, sl, s));
         }
         p->grad_cb(p->grad_cb_user, group);
         return PIVP_OK;

@@ -444,6 +444,20 @@ class Model(object):
         if cb is not None and errors:
             raise errors[0]
 
+    def set_group_join(self, join):
+        """join=False: a gradient group's announcement no longer makes the model's stream wait for the group's weight gradients on the
+        plan's side stream; the listener must then call wait_group(g, its_stream) (include/pivp_hip.h: pivp_plan_set_group_join)."""
+        plan = self._active
+        if plan is None:
+            raise RuntimeError('call the model first')
+        _lib.check(plan.lib.pivp_plan_set_group_join(plan.h, 1 if join else 0), 'pivp_plan_set_group_join')
+
+    def wait_group(self, g, stream):
+        """Make `stream` (a torch.cuda.Stream) wait for the side-stream work of gradient group g."""
+        plan = self._active
+        with torch.cuda.device(self.device):
+            _lib.check(plan.lib.pivp_plan_group_wait(plan.h, int(g), stream.cuda_stream), 'pivp_plan_group_wait')
+
     def grads_reference(self):
         """Gradients in the reference's Chainer-npz layout (same permutations as the parameters)."""
         if self._grads is None:
