@@ -245,10 +245,14 @@ __global__ __launch_bounds__(256) void igemm_wgrad_reduce_kernel(const WgradDesc
 // igemm_f32.hip does: 159.6 vs 159.8 us per launch, no gain -- and 213 us with a run-time `if (c + 8 < c_end)` around the pieces, which
 // makes hipcc drain vmcnt in front of every ds_write.  Interleaving at MFMA granularity (sched_group_barrier: 1 MFMA, 3 VALU, ten times) gave
 // 160.0 us.  The pipe's idle third (MFMA busy 0.65) is not the staging's issue slots.  The block form of issue() / store() stays.)
-// (Round 2 tried two blocks per CU: one LDS region and one staging register set per wave, 51 KB per block, launch_bounds(256, 2).  The 160
-// accumulator registers leave 96 for everything else: 76-97 VGPRs spill and the train step went 32.3 -> 35.0 ms.  One block per CU stays.)
+// Two blocks per CU: with NTW = 2 a wave carries 160 accumulator registers (344 VGPRs in all) and a block ~100 KB of LDS, so every SIMD
+// holds ONE wave and each of its waits is exposed (MFMA busy 0.58-0.65).  NTW = 1 halves both (180 VGPRs, 70-80 KB): two blocks = two
+// waves per SIMD, for 1.36x the operand traffic per MFMA.  Per launch at B = 32 (us, NTW 2 -> 1): lstm1/2 130 -> 119, lstm3 99 -> 90,
+// lstm4 130 -> 118, lstm5 101 -> 92, lstm6 183 -> 169, lstm7 238 -> 224; train step 31.0 -> 30.7 ms.  (Keeping NTW = 2 and dropping to one
+// LDS buffer + one staging register set per wave instead spilled 76-97 VGPRs: 32.3 -> 35.0 ms.)  A second round of blocks costs 8-9 us
+// per launch (prologue + block reduction + atomics + the first loads' latency): the grid stays at one round of resident blocks.
 template <int NTW, int SW>   // NTW: 32-column tiles per wave (1 or 2); SW: pixels of one image row inside a chunk (min(W, 32))
-__global__ __launch_bounds__(256, 1) void wgrad5x5_kernel(const WgradDesc d) {
+__global__ __launch_bounds__(256, NTW == 1 ? 2 : 1) void wgrad5x5_kernel(const WgradDesc d) {
     constexpr int R = 32 / SW;                  // image rows per chunk
     constexpr int SP = R * (SW + 4);            // strip pixels
     constexpr int XP = 32, YP = 32 * NTW;       // LDS row lengths (floats): lane-contiguous reads, no padding needed
@@ -465,10 +469,11 @@ static int launch_wgrad5x5(const WgradDesc& d, hipStream_t s) {
     // One block per CU is resident (~100 KB of LDS), so the grid is sized to whole rounds of the chip's CUs: the first
     // version asked for "about 512" blocks and got 520-600, i.e. a third round that ran 8-88 blocks on 256 CUs (lstm7: 264 us
     // for 171 us of MFMA work).  Take the fewest rounds (1..3) whose last round is at least 90 % full.
-    const int cus = pivp_cu_count();
+    const int cus = pivp_cu_count() * (NTW == 1 ? 2 : 1);   // resident blocks (NTW = 1: two per CU)
     int nsplit = 1;
     double best = 0.0;
-    for (int r = 1; r <= 3; ++r) {
+    static const int rmin = [] { const char* e = getenv("PIVP_WGRAD_ROUNDS"); return e ? atoi(e) : 1; }();   // tuning
+    for (int r = rmin; r <= 3; ++r) {
         int ns = (cus * r) / tiles;
         if (ns > chunks / 16) ns = chunks / 16;          // >= 4 chunks per wave
         if (ns < 1) ns = 1;
@@ -507,7 +512,10 @@ int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done) {
     PIVP_CHECK_ARG(d.bytes0 > 0 && d.bytesy > 0 && (d.c1 == 0 || d.bytes1 > 0));
     if (takes_fast_path(d)) {
         if (bias_done) *bias_done = d.db ? 1 : 0;
-        if (d.Wg == 8) return launch_wgrad5x5<2, 8>(d, s);
+        static const int ntw = [] { const char* e = getenv("PIVP_WGRAD_NTW"); return e ? atoi(e) : 1; }();   // tuning
+        static const int ntw8 = [] { const char* e = getenv("PIVP_WGRAD_NTW8"); return e ? atoi(e) : 1; }();
+        if (d.Wg == 8) return ntw8 == 1 ? launch_wgrad5x5<1, 8>(d, s) : launch_wgrad5x5<2, 8>(d, s);
+        if (ntw == 1) return d.Wg == 16 ? launch_wgrad5x5<1, 16>(d, s) : launch_wgrad5x5<1, 32>(d, s);
         if (d.Wg == 16) return launch_wgrad5x5<2, 16>(d, s);
         return launch_wgrad5x5<2, 32>(d, s);
     }

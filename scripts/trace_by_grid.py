@@ -1,12 +1,26 @@
-"""Per-dispatch durations grouped by (kernel, grid) from a rocprofv3 kernel trace:
-python scripts/trace_by_grid.py <kernel_trace.csv> <substring of the kernel name> [...]"""
-import csv, sys, collections
-acc = collections.defaultdict(list)
-pats = sys.argv[2:]
-for r in csv.DictReader(open(sys.argv[1])):
-    n = r['Kernel_Name']
-    if any(p in n for p in pats):
-        grid = (int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])), int(r['Grid_Size_Y']), int(r['Grid_Size_Z']))
-        acc[(n[:48], grid)].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
-    print('%-50s blocks %-16s n %4d  avg %7.1f us  total %7.2f ms' % (k[0], k[1], len(v), sum(v) / len(v), sum(v) / 1e3))
+"""Kernel trace grouped by (kernel, grid): tells the layers of one templated kernel apart.
+python scripts/trace_by_grid.py <kernel_trace.csv> [steps]   -> name, grid, calls, avg us, total ms (per step when `steps` is given)"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def main():
+    rows = defaultdict(lambda: [0, 0.0])
+    with open(sys.argv[1]) as f:
+        for r in csv.DictReader(f):
+            name = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void pivp::', '').replace('pivp::', '')
+            grid = '%sx%sx%s' % (r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'])
+            k = (name, grid, r.get('LDS_Block_Size', ''))
+            rows[k][0] += 1
+            rows[k][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+    tot = sum(v[1] for v in rows.values())
+    print('total %.3f ms%s' % (tot / 1e3 / steps, ' per step' if steps != 1 else ''))
+    for k, v in sorted(rows.items(), key=lambda kv: -kv[1][1])[:70]:
+        print('%-52s %-16s lds %-7s calls %6.1f  avg %8.1f us  total %8.3f ms' % (k[0][:52], k[1], k[2], v[0] / steps, v[1] / v[0], v[1] / 1e3 / steps))
+
+
+if __name__ == '__main__':
+    main()
