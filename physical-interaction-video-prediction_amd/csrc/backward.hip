@@ -24,10 +24,16 @@ __device__ __forceinline__ float fast_tanh_b(float x) { return 2.0f * __builtin_
 __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_old,
                                                              const float* __restrict__ c_new, const float* __restrict__ dh_a, int lda,
                                                              const float* __restrict__ dh_b, int ldb, float* __restrict__ dc,
-                                                             int dc_valid, float* __restrict__ dG, int npix, int C, const LnFuse ln) {
+                                                             int dc_valid, float* __restrict__ dG, int npix, int C, const LnFuse ln,
+                                                             float* __restrict__ zero, long long zero_f4) {
     __shared__ float sums[2];
     const int b = blockIdx.y;
     const int n = npix * C;                                   // elements per sample
+    if (zero) {   // destination of the K-split data gradient that follows (atomic adds): cleared here instead of by a memset launch of its own
+        const long long nthr = (long long)gridDim.x * gridDim.y * 256;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (long long i = ((long long)b * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_f4; i += nthr) reinterpret_cast<f32x4*>(zero)[i] = z;
+    }
     if (ln.dy) {
         if (threadIdx.x < 64) {
             float a = 0.f, c2 = 0.f;
@@ -78,9 +84,11 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __rest
 }
 
 int lstm_gates_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_a, int lda,
-                   const float* dh_b, int ldb, float* dc, int dc_valid, float* dG, int M, int C, hipStream_t s, int B, const LnFuse* ln) {
+                   const float* dh_b, int ldb, float* dc, int dc_valid, float* dG, int M, int C, hipStream_t s, int B, const LnFuse* ln,
+                   float* zero, long long zero_floats) {
     PIVP_CHECK_ARG(gates && c_old && c_new && dc && dG && M > 0 && C > 0 && C % 4 == 0 && (dh_a || dh_b || (ln && ln->dy)));
     PIVP_CHECK_ARG(B > 0 && M % B == 0 && (!dh_a || lda % 4 == 0) && (!dh_b || ldb % 4 == 0));
+    PIVP_CHECK_ARG(!zero || (zero_floats > 0 && zero_floats % 4 == 0 && ((uintptr_t)zero & 15) == 0));
     LnFuse lf;
     memset(&lf, 0, sizeof(lf));
     if (ln && ln->dy) {
@@ -90,7 +98,7 @@ int lstm_gates_bwd(const float* gates, const float* c_old, const float* c_new, c
     const int npix = M / B;
     const int xb = (npix * C / 4 + 255) / 256;
     hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(xb, B), dim3(256), 0, s, gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc,
-                       dc_valid, dG, npix, C, lf);
+                       dc_valid, dG, npix, C, lf, zero, zero ? zero_floats / 4 : 0);
     return PIVP_LAUNCH_STATUS();
 }
 

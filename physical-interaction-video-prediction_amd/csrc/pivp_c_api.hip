@@ -74,9 +74,8 @@ int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const floa
 }
 
 // stride-1 K x K "same" convolution through the generic kernel (used as the ConvLSTM data gradient)
-int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, int cout, int ldo, int ksize, int B, int H, int W,
-                hipStream_t s, int accum, int wN) {
-    IgemmDesc d;
+static int conv_s1_desc(IgemmDesc& d, const float* x, int cin, int ldx, const float* w, float* out, int cout, int ldo, int ksize, int B, int H, int W,
+                        int accum, int wN) {
     memset(&d, 0, sizeof(d));
     d.x0 = x; d.c0 = cin; d.ld0 = ldx; d.wcin = cin; d.w = w; d.bias = nullptr;
     d.B = B; d.Hin = H; d.Win = W; d.Hg = H; d.Wg = W; d.in_step = 1;
@@ -86,17 +85,29 @@ int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, in
     if (!fits31(b0) || !fits31(bw)) return PIVP_ERR_BADARG;
     d.bytes0 = (int)b0; d.bytesw = (int)bw;
     d.out_step = 1; d.Hout = H; d.Wout = W; d.out = out; d.ldo = ldo; d.relu = 0; d.accum = accum;
-    if (!accum && (ldo == cout || d.wN)) {   // fresh output (contiguous, or the leading columns of a buffer whose rest nobody reads): the K-split
-        d.ksplit_ok = 1;                     // path is allowed; it needs a zeroed destination
-        if (igemm_conv_ksplit(d) > 1 && hipMemsetAsync(out, 0, (size_t)B * H * W * ldo * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
-    }
+    // fresh output (contiguous, or the leading columns of a buffer whose rest nobody reads): the K-split path is allowed; it needs a zeroed destination
+    if (!accum && (ldo == cout || d.wN)) d.ksplit_ok = 1;
+    return PIVP_OK;
+}
+// true when run_conv_s1 with these arguments adds K-split partial sums into `out` (B * H * W * ldo floats to be zeroed first)
+bool conv_s1_splits_k(int cin, int cout, int ldo, int ksize, int B, int H, int W, int wN) {
+    IgemmDesc d;
+    static float dummy;
+    if (conv_s1_desc(d, &dummy, cin, cin, &dummy, &dummy, cout, ldo, ksize, B, H, W, 0, wN) != PIVP_OK) return false;
+    return d.ksplit_ok && igemm_conv_ksplit(d) > 1;
+}
+int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, int cout, int ldo, int ksize, int B, int H, int W,
+                hipStream_t s, int accum, int wN, int dest_zeroed) {
+    IgemmDesc d;
+    int rc = conv_s1_desc(d, x, cin, ldx, w, out, cout, ldo, ksize, B, H, W, accum, wN);
+    if (rc != PIVP_OK) return rc;
+    if (d.ksplit_ok && !dest_zeroed && igemm_conv_ksplit(d) > 1 &&
+        hipMemsetAsync(out, 0, (size_t)B * H * W * ldo * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     return igemm_conv(d, s);
 }
 
 // 5x5 stride-1 "same" convolution with bf16 operands (csrc/convlstm_bf16.hip); wb = pack_lstm_bf16(w, cin, cout, conv5x5_bf16_rows(cout))
-int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb, float* out, int cout, int ldo, int accum,
-                     int B, int H, int W, hipStream_t s, int planes) {
-    IgemmDesc d;
+static int conv5x5_bf16_desc(IgemmDesc& d, const float* x, int cin, int ldx, float* out, int cout, int ldo, int accum, int B, int H, int W) {
     memset(&d, 0, sizeof(d));
     d.x0 = x; d.c0 = cin; d.ld0 = ldx; d.wcin = cin;
     d.B = B; d.Hin = H; d.Win = W; d.Hg = H; d.Wg = W; d.in_step = 1;
@@ -105,10 +116,22 @@ int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb,
     if (!fits31(b0)) return PIVP_ERR_BADARG;
     d.bytes0 = (int)b0;
     d.out_step = 1; d.Hout = H; d.Wout = W; d.out = out; d.ldo = ldo; d.accum = accum;
-    if (!accum && ldo == cout) {     // contiguous fresh output: the K-split path may be used; it needs a zeroed destination
-        d.ksplit_ok = 1;
-        if (conv5x5_bf16_ksplit(d) > 1 && hipMemsetAsync(out, 0, (size_t)B * H * W * cout * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
-    }
+    if (!accum && ldo == cout) d.ksplit_ok = 1;     // contiguous fresh output: the K-split path may be used; it needs a zeroed destination
+    return PIVP_OK;
+}
+bool conv5x5_bf16_splits_k(int cin, int cout, int ldo, int B, int H, int W) {
+    IgemmDesc d;
+    static float dummy;
+    if (conv5x5_bf16_desc(d, &dummy, cin, cin, &dummy, cout, ldo, 0, B, H, W) != PIVP_OK) return false;
+    return d.ksplit_ok && conv5x5_bf16_ksplit(d) > 1;
+}
+int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb, float* out, int cout, int ldo, int accum,
+                     int B, int H, int W, hipStream_t s, int planes, int dest_zeroed) {
+    IgemmDesc d;
+    int rc = conv5x5_bf16_desc(d, x, cin, ldx, out, cout, ldo, accum, B, H, W);
+    if (rc != PIVP_OK) return rc;
+    if (d.ksplit_ok && !dest_zeroed && conv5x5_bf16_ksplit(d) > 1 &&
+        hipMemsetAsync(out, 0, (size_t)B * H * W * cout * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     return conv5x5_bf16(d, wb, s, planes);
 }
 
@@ -157,7 +180,10 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
                           int B, int H, int W, hipStream_t s, int wt_ready, unsigned short* wt_bf16, int bf16_planes, const SideFork* fork,
                           const LnFuse* ln, int dx_only) {
     const int M = B * H * W, cin = cx + C, N = 4 * C;
-    int rc = lstm_gates_bwd(gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc, dc_valid, dG, M, C, s, B, ln);
+    // a K-split data gradient adds into d_in: the gate kernel clears it on the side (one launch less than a memset per cell and timestep)
+    const bool zero = wt_bf16 ? conv5x5_bf16_splits_k(N, cin, cin, B, H, W)
+                              : (dx_only ? conv_s1_splits_k(N, cx, cin, 5, B, H, W, cin) : conv_s1_splits_k(N, cin, cin, 5, B, H, W, 0));
+    int rc = lstm_gates_bwd(gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc, dc_valid, dG, M, C, s, B, ln, zero ? d_in : nullptr, (long long)M * cin);
     if (rc != PIVP_OK) return rc;
     // dG is final: the weight gradient can start (on the side stream when forked), next to this layer's own data gradient
     hipStream_t sw;
@@ -172,10 +198,10 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
             rc = pack_lstm_bf16(wt, wt_bf16, N, cin, s, conv5x5_bf16_rows(cin), bf16_planes);
             if (rc != PIVP_OK) return rc;
         }
-        rc = run_conv5x5_bf16(dG, N, N, wt_bf16, d_in, cin, cin, 0, B, H, W, s, bf16_planes);
+        rc = run_conv5x5_bf16(dG, N, N, wt_bf16, d_in, cin, cin, 0, B, H, W, s, bf16_planes, zero);
     } else {
         // d[x,h] = conv5x5(dG, W^T flipped); dx_only: the x columns alone (the pack's first cx of cin; the h columns of d_in stay unwritten)
-        rc = dx_only ? run_conv_s1(dG, N, N, wt, d_in, cx, cin, 5, B, H, W, s, 0, cin) : run_conv_s1(dG, N, N, wt, d_in, cin, cin, 5, B, H, W, s);
+        rc = dx_only ? run_conv_s1(dG, N, N, wt, d_in, cx, cin, 5, B, H, W, s, 0, cin, zero) : run_conv_s1(dG, N, N, wt, d_in, cin, cin, 5, B, H, W, s, 0, 0, zero);
     }
     if (rc != PIVP_OK) return rc;
     if (!dW) return PIVP_OK;   // the caller batches this layer's weight gradient over several timesteps itself (pivp_plan.hip)

@@ -16,7 +16,10 @@ int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const floa
                     int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0,
                     float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr, int bf16 = 0);
 int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, int cout, int ldo, int ksize, int B, int H, int W,
-                hipStream_t s, int accum = 0, int wN = 0);   // wN: columns of the weight pack when only its first `cout` are wanted
+                hipStream_t s, int accum = 0, int wN = 0,    // wN: columns of the weight pack when only its first `cout` are wanted
+                int dest_zeroed = 0);                        // 1: the caller has cleared `out` (see conv_s1_splits_k)
+bool conv_s1_splits_k(int cin, int cout, int ldo, int ksize, int B, int H, int W, int wN);
+bool conv5x5_bf16_splits_k(int cin, int cout, int ldo, int B, int H, int W);
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
               float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s,
               float* db = nullptr, int* bias_done = nullptr, int bf16 = 0,
@@ -29,7 +32,7 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
                           const SideFork* fork = nullptr, const LnFuse* ln = nullptr,    // ln: dh_a is formed from the LayerNorm behind the cell
                           int dx_only = 0);   // 1: d h_{t-1} is not needed (the sweep's last timestep): only the cx columns of d_in are computed
 int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb, float* out, int cout, int ldo, int accum,
-                     int B, int H, int W, hipStream_t s, int planes = 1);
+                     int B, int H, int W, hipStream_t s, int planes = 1, int dest_zeroed = 0);
 int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w, float* dy, int cout, int ldy, const float* y, int ldyy,
                       float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, hipStream_t s,
                       int wt_ready = 0, const SideFork* fork = nullptr, float* part = nullptr, WgradDesc* desc_out = nullptr);

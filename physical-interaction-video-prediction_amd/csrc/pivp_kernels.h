@@ -157,7 +157,8 @@ struct LnFuse {
 };
 int lstm_gates_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_a, int lda,
                    const float* dh_b, int ldb, float* dc, int dc_valid, float* dG, int M, int C, hipStream_t s, int B = 1,
-                   const LnFuse* ln = nullptr);
+                   const LnFuse* ln = nullptr,
+                   float* zero = nullptr, long long zero_floats = 0);
 int bias_grad(const float* dy, int ld, int N, int M, float* db, hipStream_t s);
 int relu_mask(float* dy, int lddy, const float* y, int ldy, int C, long npix, hipStream_t s);
 int ln_bwd_slices(int n);
