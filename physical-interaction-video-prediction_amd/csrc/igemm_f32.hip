@@ -34,6 +34,7 @@
 // 2 / 4 gates of 16 / 8 channels and the epilogue gathers the four gates of a channel with wave
 // shuffles.  The 4C-wide gate tensor is never written.
 #include <stdlib.h>
+#include <stdio.h>
 #include <type_traits>
 
 #include "pivp_kernels.h"
@@ -122,14 +123,15 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
     const bool deconv = LSTM ? false : d.deconv != 0;
     const int nty_all = deconv ? 1 + py : d.ksize;
     const int ntx = deconv ? 1 + px : d.ksize;
-    // optional split of K over blockIdx.z by kernel rows (data gradients of small-M layers); partial sums are atomically
-    // added into a pre-zeroed output
+    // optional split of K over blockIdx.z (data gradients of small-M layers): contiguous ranges of the chunk sequence
+    // (kernel row, kernel column, 32-channel chunk), equal to within one chunk; partial sums are atomically added into a pre-zeroed output
     const int ksplit = gridDim.z;
-    const int ty_begin = (nty_all * (int)blockIdx.z) / ksplit, ty_end = (nty_all * ((int)blockIdx.z + 1)) / ksplit;
-    const int nty = ty_end - ty_begin;
-    const int nchunks_all = nty * ntx * ncc;
+    const int nchunks_tot = nty_all * ntx * ncc;
+    const int z_begin = ksplit > 1 ? (int)(((long)nchunks_tot * (int)blockIdx.z) / ksplit) : 0;
+    const int z_end = ksplit > 1 ? (int)(((long)nchunks_tot * ((int)blockIdx.z + 1)) / ksplit) : nchunks_tot;
+    const int nchunks_all = z_end - z_begin;
     const int nchunks = nchunks_all / KG;               // (KG = 2: the launcher only takes this form for an even chunk count)
-    const int chunk0 = gid * nchunks;                   // this group's first chunk
+    const int chunk0 = z_begin + gid * nchunks;         // this block's / group's first chunk
     const int HWg = d.Hg * d.Wg;
 
     // ---- staging roles ---------------------------------------------------------------------
@@ -189,8 +191,8 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
     f32x4 rbs[2][NB];
 
     // scalar state of the NEXT chunk to load: channel chunk l_cc of tap (l_ty, l_tx); no division, no branch
-    int l_cc = 0, l_ty = ty_begin, l_tx = 0;
-    if constexpr (KG > 1) { const int tap = chunk0 / ncc; l_cc = chunk0 - tap * ncc; l_ty = ty_begin + tap / ntx; l_tx = tap - (tap / ntx) * ntx; }
+    int l_cc = 0, l_ty = 0, l_tx = 0;
+    if (KG > 1 || ksplit > 1) { const int tap = chunk0 / ncc; l_cc = chunk0 - tap * ncc; l_ty = tap / ntx; l_tx = tap - (tap / ntx) * ntx; }
     int s_delta = 0, s_ld = 0, s_wbase = 0;
     unsigned s_bit = 0;
     bool s_first = true;
@@ -645,32 +647,39 @@ int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant, int* ln_npar
 // Plain conv / transposed conv: pick the block tile that fills the 256 CUs.  Blocks = (M/BM) * (N/BN) * phases.
 // Long-K data gradients (the ConvLSTM's 5x5 over 4C channels).  The output may be produced by K-split blocks with atomic adds into a
 // pre-zeroed destination, so both the tile AND the split are free: pick the pair with the least modelled time
-//   rounds(blocks over the CUs) x rows-per-split x tile area / tile efficiency  (+ a per-block constant),
-// because at M = 2048..8192 the block count, not the tile shape, decides: 384 blocks on 256 CUs run as 2 rounds.
+//   blocks per CU x tile area x (taps per split + c) / tile efficiency,
+// c = the per-block prologue / epilogue in taps' worth of time: 3 when a block has its CU to itself (and its one wave per SIMD then
+// runs at 0.8), 1.5 with two resident blocks, 1 with three or more (their fixed phases hide under each other's MFMAs); resident
+// blocks per CU are bounded by the tile's registers and LDS.  At M = 2048..8192 the block count, not the tile shape, decides.  Splits are contiguous ranges of the chunk
+// sequence, so any split count is balanced.  Measured at B = 32 (scripts/dgrad_ks_scan.sh, us per launch, best of all forced splits
+// = the model's choice): lstm1/2 128x64 / 2 splits 113.7 (64x64 unsplit 117.8), lstm3 128x96 / 8 90.4, lstm4 64x128 / 4 109.3 (by kernel
+// rows, 5 splits: 123.6), lstm5 64x64 / 8 91.4 (5: 97.0), lstm6 128x96 / 4 159.7 (128x64 / 5: 182.1), lstm7 64x128 unsplit 210.6.
 // Returns false when the descriptor is not such a conv.  ks == 1: plain stores, the destination need not be zeroed.
 static bool dgrad_choice(const IgemmDesc& d, int& bt, int& bks) {
     if (!(d.ksplit_ok && !d.deconv && !d.bias && !d.relu && !d.accum && d.ksize * d.ksize * ((d.c0 + d.c1) / 32) > 40)) return false;
     const int nt = d.N / 32;
-    struct Tile { int wm, wn, ntb; double eff; };
-    static const Tile tiles[] = {{2, 2, 2, 0.85}, {4, 1, 1, 0.70}, {4, 1, 2, 0.90}, {4, 1, 3, 0.95}, {4, 1, 4, 1.00}, {2, 2, 4, 0.95}, {1, 4, 4, 0.80}};
+    struct Tile { int wm, wn, ntb; double eff; int resident; };
+    static const Tile tiles[] = {{2, 2, 2, 0.80, 4}, {4, 1, 1, 0.70, 3}, {4, 1, 2, 0.90, 2}, {4, 1, 3, 0.95, 2}, {4, 1, 4, 1.00, 1}, {2, 2, 4, 0.95, 2}, {1, 4, 4, 0.80, 3}};
+    static const double fixed_taps[] = {3.0, 1.5, 1.0, 1.0};
+    static const double alone[] = {0.80, 1.0, 1.0, 1.0};      // one wave per SIMD hides none of its own waits
     const int cus = pivp_cu_count();
     static const int force_t = [] { const char* e = getenv("PIVP_DGRAD_TILE"); return e ? atoi(e) : -1; }();   // tuning
     static const int force_k = [] { const char* e = getenv("PIVP_DGRAD_KS"); return e ? atoi(e) : 0; }();
     bt = -1; bks = 1;
     double bcost = 1e300;
+    const int nchunks = d.ksize * d.ksize * ((d.c0 + d.c1) / 32);
     for (int t = 0; t < 7; ++t) {
         if (nt % tiles[t].ntb) continue;
         if (force_t >= 0 && t != force_t) continue;
         const int bm = 32 * tiles[t].wm, bn = 32 * tiles[t].ntb;
         const long mb = (d.M + bm - 1) / bm, nb = d.N / bn;
-        for (int ks = 1; ks <= d.ksize; ++ks) {
+        for (int ks = 1; ks <= 10 && ks * 8 <= nchunks; ++ks) {          // >= 8 chunks per split
             if (force_k > 0 && ks != force_k) continue;
             const long blocks = mb * nb * ks;
-            const long rounds = (blocks + cus - 1) / cus;
-            const int rows = (d.ksize + ks - 1) / ks;                   // kernel rows of the largest split
-            const double work = (double)bm * bn * (rows * d.ksize + 1.5) / tiles[t].eff;   // +1.5 taps: prologue / epilogue
-            // one resident block per CU hides no latency (lstm4, 64x64 tiles: 256 blocks 151 us, 2 x 256 K-split blocks 139)
-            const double cost = rounds * work * (ks > 1 ? 1.03 : 1.0) / (rounds >= 2 ? 1.0 : 0.75);
+            const long per_cu = (blocks + cus - 1) / cus;
+            const int res = (int)(per_cu < tiles[t].resident ? per_cu : tiles[t].resident);
+            const double taps = (double)(d.ksize * d.ksize) / ks;       // taps of one split
+            const double cost = (double)per_cu * bm * bn * (taps + fixed_taps[res - 1]) / (tiles[t].eff * alone[res - 1]) * (ks > 1 ? 1.01 : 1.0);
             if (cost < bcost) { bcost = cost; bt = t; bks = ks; }
         }
     }
@@ -692,6 +701,8 @@ int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     const long full = (long)((d.M + 127) / 128) * d.nphase;   // blocks with BM = 128 and the whole N in one block
     int bt = -1, bks = 1;
     if (dgrad_choice(d, bt, bks)) {
+        static const bool dbg = getenv("PIVP_DGRAD_DEBUG") != nullptr;   // tuning: which tile / split a shape gets (scripts/dgrad_ks_scan.sh)
+        if (dbg) fprintf(stderr, "dgrad M=%d N=%d K=%d tile=%d ks=%d\n", d.M, d.N, d.ksize * d.ksize * (d.c0 + d.c1), bt, bks);
         switch (bt) {
             case 0: return launch_igemm<2, 2, 2, false>(d, stream, bks, ln_nparts);
             case 1: return launch_igemm<4, 1, 1, false>(d, stream, bks, ln_nparts);
