@@ -151,7 +151,7 @@ long long pivp_get_tap(pivp_plan_t* plan, const char* name, int step, float* out
 int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                   const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream);
 
-/* Same, with the block-tile variant forced (0 auto, 1: BM 128, 2: BM 64, 3: BM 32) -- tests and tuning. */
+/* Same, with the block-tile variant forced (0 auto, 1: BM 128, 2: BM 64, 3: BM 32 as two K groups of 4 waves, 4: BM 64 as two K groups) -- tests and tuning. */
 int pivp_convlstm_v(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                     const float* c_in, float* c_out, float* h_out, int B, int H, int W, int variant, void* stream);
 

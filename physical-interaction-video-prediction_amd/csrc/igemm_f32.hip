@@ -625,12 +625,17 @@ int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant, int* ln_npar
         // so take BM = 128 only when it still leaves >= 2 blocks per CU, BM = 64 while that fills the chip
         const long nb = d.C / 32;
         if ((long)(d.M / 128) * nb >= 512) variant = 1;
-        else if ((long)(d.M / 64) * nb >= 256) variant = 2;
+        else if ((long)(d.M / 64) * nb >= 512) variant = 2;
+        else if ((long)(d.M / 64) * nb >= 256) variant = 4;      // one 64-row block per CU: as two K groups (falls back to variant 2 on an odd chunk count)
         else variant = 3;
     }
     // (128-row tiles as ONE 8-wave block per CU, two K groups -- a third less L2 traffic, half the staging per MFMA -- were measured on the
     // layers that fill the chip: lstm1 126 -> 119.5 TF, lstm7 135.5 -> 132, rollout 8.67 -> 8.86 ms; 46 VGPRs spill under the 256 cap.  Not kept.)
     switch (variant) {
+        case 4:   // 64-row tile as two K groups of 4 waves (two waves per SIMD where the grid gives every CU one block): lstm4 106.6 -> 104.6 us,
+                  // lstm6 153.6 -> 150.2 at B = 32; needs an even chunk count (lstm3 has 75)
+            if (((25 * ((d.c0 + d.c1) >> 5)) & 1) == 0) return launch_igemm<2, 2, 4, true, 0, 2>(d, stream, 1, ln_nparts);
+            return launch_igemm<2, 2, 4, true>(d, stream, 1, ln_nparts);
         case 1: return launch_igemm<4, 1, 4, true>(d, stream, 1, ln_nparts);
         case 2: return launch_igemm<2, 2, 4, true>(d, stream, 1, ln_nparts);
         case 3: {

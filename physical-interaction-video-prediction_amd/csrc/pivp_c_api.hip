@@ -385,7 +385,7 @@ extern "C" int pivp_convlstm_ln(const float* x, int cx, int ldx, const float* h_
                                 const float* c_in, float* c_out, float* h_out, const float* gamma, const float* beta,
                                 float* ln_out, int ldo, float* partials, float eps, int B, int H, int W, int variant, int* fused,
                                 void* stream) {
-    if (!x || !w || !bias || !c_in || !c_out || !h_out || !gamma || !beta || !ln_out || !partials || variant < 0 || variant > 3)
+    if (!x || !w || !bias || !c_in || !c_out || !h_out || !gamma || !beta || !ln_out || !partials || variant < 0 || variant > 4)
         return PIVP_ERR_BADARG;
     if (C <= 0 || C % 32) return PIVP_ERR_BADARG;
     int np = 0;
