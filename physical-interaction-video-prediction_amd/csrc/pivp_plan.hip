@@ -593,7 +593,9 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     const long px2 = (long)B * p->H2 * p->W2, px4 = (long)B * p->H4 * p->W4, px8 = (long)B * p->H8 * p->W8;
 
     // the enc convs' weight gradients of the previous (later) timestep read dY buffers that this step is about to rewrite
-    for (int slot = 7; slot < pivp_plan::NSLOT; ++slot) RC(join(slot));
+    // The enc convs' weight gradients of the previous (later) timestep read dY buffers that this step rewrites: each is joined right in
+    // front of the first kernel that rewrites its buffer, not here -- at the top of a timestep the side stream still has the previous
+    // timestep's last launches (lstm1's and enc0's weight gradients) in front of it, and the main stream sat idle for ~40 us per timestep.
     SideFork fe;
     // ---- heads (TM:711-728) ----
     if (has_go) {
@@ -609,6 +611,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         RC(mask_softmax_bwd(ws + S.logits, ws + g.dmk, B, HW, p->NP, s));
         RC(heads_bwd(ws + S.e6, P(p, p->i_masks_w), P(p, p->i_enc7_w), ws + g.dmk, ws + g.dz, ws + g.e6, G(p, p->i_masks_w),
                      G(p, p->i_masks_b), G(p, p->i_enc7_w), G(p, p->i_enc7_b), B, HW, p->NP, p->NE, s));
+        RC(join(13));      // d v (the kernel generator's weight gradient reads it)
         if (c.model_type == PIVP_MODEL_CDNA)
             RC(cdna_kernels_bwd(ws + S.n5, P(p, p->i_head_w), ws + S.vpre, ws + g.dkpart, composite_bwd_tiles(H, W), ws + g.dv, ws + g.n5, 0,
                                 G(p, p->i_head_w), G(p, p->i_head_b), B, p->K5, c.num_masks, s, fork_of(13, fe)));
@@ -618,6 +621,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                               B, p->K5, s));
         else if (hipMemsetAsync(ws + g.n5, 0, (size_t)px8 * 128 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;   // DNA: no hidden5 head
         // group 6 (TM:601), reversed: norm_enc6 (+relu) <- enc6 deconv <- [hidden7 | enc0]
+        RC(join(7));       // d e6raw
         RC(lnb(8, ws + g.e6, 64, ws + S.e6, 64, ws + S.e6raw, ws + g.e6raw, 64 * HW, 64, 1));
         RC(run_conv_backward(1, ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), ws + g.e6raw, 64, 64, nullptr, 0, ws + g.wt_enc[6], ws + g.cat7, 64, 0,
                              G(p, p->i_enc_w[6]), G(p, p->i_enc_b[6]), B, p->H2, p->W2, s, 1, fork_of(7, fe), ws + g.wg_part[0], &p->enc_desc[0]));
@@ -655,13 +659,16 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     };
     RC(done(0));
     RC(lnb_cell(6, ws + g.cat7, 64, n2, 32));
+    RC(join(8));           // enc5's dY = the x part of lstm7's d_in of this parity (two timesteps ago)
     RC(lstmb(6, ws + S.e5, 96, p->H2, p->W2));
     RC(done(1));
+    RC(join(11));          // enc1's dY lives in d cat6, which enc5's data gradient rewrites
     // group 5 (TM:600): d e5 = x-part of lstm7's d_in (ReLU fused in enc5) <- enc5 deconv <- [hidden6 | enc1]
     RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ws + S.e5, 96, ws + g.wt_enc[5], ws + g.cat6, 96, 0,
                          G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1, fork_of(8, fe), ws + g.wg_part[1], &p->enc_desc[1]));
     p->enc_desc_valid[1] = true;
     RC(lnb_cell(5, ws + g.cat6, 96, n4, 64));
+    RC(join(9));           // enc4's dY = the x part of lstm6's d_in of this parity
     RC(lstmb(5, ws + S.e4, 128, p->H4, p->W4));
     RC(done(2));
     // group 4 (TM:599): d e4 = x-part of lstm6's d_in <- enc4 deconv <- hidden5 (also read by the CDNA kernel generator)
@@ -672,6 +679,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(lstmb(4, ws + S.e3, 64, p->H8, p->W8));
     RC(done(3));
     // group 3 (TM:598) + state predictor (TM:730): d e3 = x-part of lstm5's d_in (ld 192)
+    RC(join(10));          // d e2
     RC(enc3_state_bwd(ws + S.e2, ws + S.e3, ws + g.din[4][par], 192, action, state_prev, P(p, p->i_enc_w[3]), P(p, p->i_cs_w),
                       ws + g.dstate + (size_t)t * B * 5, ws + g.e2, G(p, p->i_enc_w[3]), G(p, p->i_enc_b[3]), G(p, p->i_cs_w),
                       G(p, p->i_cs_b), t > 0 ? ws + g.dstate + (size_t)(t - 1) * B * 5 : ws + g.dstate + (size_t)(c.seq_len - 1) * B * 5,
@@ -696,6 +704,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(lstmb(0, ws + S.cat7 + 32, 64, p->H2, p->W2));
     RC(add_strided(ws + g.cat7 + 32, 64, ws + g.din[0][par], 64, 32, px2, s));          // d enc0: from enc6's concat + from lstm1
     // group 0 (TM:595): norm_enc0 (+relu) <- enc0 conv <- frame
+    RC(join(12));          // d e0raw
     RC(lnb(0, ws + g.cat7 + 32, 64, ws + S.cat7 + 32, 64, ws + S.e0raw, ws + g.e0raw, n2, 32, 1));
     RC(enc0_bwd(prev, P(p, p->i_enc_w[0]), ws + g.e0raw, G(p, p->i_enc_w[0]), G(p, p->i_enc_b[0]), prev_has_grad ? go_prev : nullptr, 1,
                 B, H, W, s, fork_of(12, fe)));
