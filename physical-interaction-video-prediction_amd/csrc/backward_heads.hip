@@ -1,5 +1,7 @@
 // Backward of the output heads (CDNA variant) and of the small ops at both ends of the trunk.
 // Forward definitions: heads.hip / small_kernels.hip; reference code: train_model.py ("TM") lines cited per kernel.
+#include <stdlib.h>
+
 #include "pivp_kernels.h"
 
 namespace pivp {
@@ -32,7 +34,11 @@ int scaled_diff(const float* a, const float* b, float* out, long n, float scale,
 // The softmax Jacobian couples 11 consecutive flat elements and is applied by mask_softmax_bwd_kernel afterwards.
 // ------------------------------------------------------------------------------------------
 // rows of the frame per block tile: 8 up to 64-wide frames, 4 for 128-wide ones (the tile's LDS images grow with W)
-constexpr int composite_bwd_rows(int W) { return W <= 64 ? 8 : 4; }
+static int composite_bwd_rows(int W) {
+    static const int force = [] { const char* e = getenv("PIVP_CB_ROWS"); return e ? atoi(e) : 0; }();   // tuning: 4 or 8
+    if (force == 4 || force == 8) return W <= 64 ? force : 4;
+    return W <= 64 ? 8 : 4;
+}
 
 template <int CB_TR>
 __global__ __launch_bounds__(256) void composite_bwd_cdna_kernel(const float* __restrict__ prev, const float* __restrict__ logits,
