@@ -621,11 +621,11 @@ int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant, int* ln_npar
     }
 #endif
     if (variant == 0) {
-        // measured at B = 32 (scripts/bench_lstm_layers.py): two resident blocks per CU beat one larger tile,
-        // so take BM = 128 only when it still leaves >= 2 blocks per CU, BM = 64 while that fills the chip
+        // Two resident blocks per CU (64-row tile, 240 VGPRs) beat the 128-row tile (320 VGPRs: one block, one wave per SIMD) at every grid
+        // size: at M = 131072 / 32768 (config 5's maps, scripts/bench_lstm_layers.py 128) 139.9 against 132.3 TFLOP/s over the seven layers,
+        // so the 128-row tile is never picked (variant 1 stays for the tests)
         const long nb = d.C / 32;
-        if ((long)(d.M / 128) * nb >= 512) variant = 1;
-        else if ((long)(d.M / 64) * nb >= 512) variant = 2;
+        if ((long)(d.M / 64) * nb >= 512) variant = 2;
         else if ((long)(d.M / 64) * nb >= 256) variant = 4;      // one 64-row block per CU: as two K groups (falls back to variant 2 on an odd chunk count)
         else variant = 3;
     }
