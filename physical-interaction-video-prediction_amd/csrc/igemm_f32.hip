@@ -76,6 +76,13 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return copysignf(a < 0.55f ? small : big, x);
 }
 
+#ifdef PIVP_F32_STAMPS   // per-block phase stamps (constant-rate 100 MHz counter) of the kernel: scripts/f32_stamps.py
+__device__ long long pivp_f32_stamps[2048 * 4];
+#define F32_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048 && blockIdx.y == 0 && blockIdx.z == 0) pivp_f32_stamps[blockIdx.x * 4 + (i)] = (long long)wall_clock64(); } while (0)
+#else
+#define F32_STAMP(i)
+#endif
+
 // ABL: timing-only ablations for scripts/bench_lstm_layers.py (built with -DPIVP_ABLATE; outputs are wrong):
 //   1 = no global loads and no LDS stores, 2 = loads but no LDS stores, 3 = as 1 without the barrier,
 //   4 = as 2 with constant load addresses (no per-chunk address math), 5 = address math only.
@@ -87,6 +94,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // weight byte for 32 MACs.  A square 64 x 64 tile (16 channels x 4 gates) would move 20 % less; not built.
 template <int WM, int WN, int NTB, bool LSTM, int ABL = 0, int KG = 1>
 __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void igemm_f32_kernel(const IgemmDesc d) {
+    F32_STAMP(0);
     static_assert(WM * WN == 4, "4 waves");
     static_assert(KG == 1 || (KG == 2 && LSTM), "the in-block K split serves the ConvLSTM tile only");
     static_assert(!LSTM || NTB == 4, "ConvLSTM blocks own 4 gates x 32 channels");
@@ -374,6 +382,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
         if (nchunks > 1) { stage_begin(); load_all(S1{}); }
         if constexpr (PRE > 0) stage_begin();   // parameters of chunk 2, loaded while chunk 0 is consumed
         __syncthreads();
+        F32_STAMP(1);
         // two chunks per trip: the register sets alternate statically (a run-time parity branch makes hipcc wait vmcnt(0) in
         // front of every ds_write); `it` stays even
         int it = 0;
@@ -393,6 +402,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
             chunk(std::false_type{}, std::false_type{}, S0{}, S0{}, 0);
         }
     }
+    F32_STAMP(2);
     if constexpr (NACC > 1) {   // join the chains pairwise, fixed order
 #pragma unroll
         for (int t = 0; t < TPW; ++t)
@@ -554,6 +564,10 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
                        (((m0 - b * HWg) / BM) * n_nblk + nblk) * (int)gridDim.y + phase);
         }
     }
+#ifdef PIVP_F32_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the block's stores have left
+    F32_STAMP(3);
+#endif
 }
 
 template <int WM, int WN, int NTB, bool LSTM, int ABL = 0, int KG = 1>
@@ -753,3 +767,9 @@ int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
 }
 
 }  // namespace pivp
+
+#ifdef PIVP_F32_STAMPS
+extern "C" int pivp_debug_f32_stamps(long long* out, int n) {   // n <= 2048 * 4 values: [block][entry, loop start, loop end, stores done]
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pivp::pivp_f32_stamps), sizeof(long long) * n) == hipSuccess ? 0 : -2;
+}
+#endif
