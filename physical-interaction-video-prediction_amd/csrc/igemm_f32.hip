@@ -204,23 +204,31 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
     int s_delta = 0, s_ld = 0, s_wbase = 0;
     unsigned s_bit = 0;
     bool s_first = true;
-    auto stage_begin = [&]() {            // scalar prelude of one chunk's loads, then advance the counters
-        int wi, s_dy, s_dx;
+    // scalar prelude of one chunk's loads in three parts (tap decode; activation offset; weight offset + counters): inside the K loop they
+    // run in three consecutive micro-steps that carry no staging piece, so that no MFMA waits behind the whole ~25-instruction chain of
+    // dependent scalar multiplies.  (The timing-only build with the address math alone is 4.8 us slower on lstm1's 102; spreading the
+    // chain returned 0.3 % of the seven layers, same box: 798.7 / 801.0 -> 797.0 / 797.9 us -- the other wave of the SIMD already filled it.)
+    int t_dy = 0, t_dx = 0, t_wi = 0, t_cbase = 0;
+    auto stage_a = [&]() {
         if (deconv) {
             const int ky = py ? 2 * l_ty : 1, kx = px ? 2 * l_tx : 1;
-            s_dy = (py + 1 - ky) >> 1; s_dx = (px + 1 - kx) >> 1; wi = ky * 3 + kx;
+            t_dy = (py + 1 - ky) >> 1; t_dx = (px + 1 - kx) >> 1; t_wi = ky * 3 + kx;
         } else {
-            s_dy = l_ty - d.pad; s_dx = l_tx - d.pad; wi = l_ty * d.ksize + l_tx;
+            t_dy = l_ty - d.pad; t_dx = l_tx - d.pad; t_wi = l_ty * d.ksize + l_tx;
         }
         s_bit = __builtin_amdgcn_readfirstlane(1u << (l_ty * 5 + l_tx));
         const int ch = l_cc << 5;
         s_first = ch < d.c0;
         s_ld = s_first ? d.ld0 : d.ld1;
-        const int cbase = s_first ? ch : ch - d.c0;
+        t_cbase = s_first ? ch : ch - d.c0;
+    };
+    auto stage_b = [&]() {
         // (readfirstlane: carried from one chunk to the next these values lose their "uniform" proof, and a divergent
         // soffset turns every weight load into a waterfall loop)
-        s_delta = __builtin_amdgcn_readfirstlane(((s_dy * d.Win + s_dx) * s_ld + cbase) * 4);   // bytes, relative to the anchor pixel
-        s_wbase = __builtin_amdgcn_readfirstlane((wi * (d.wcin >> 5) + l_cc) * (d.wN ? d.wN : d.N) * 128);       // bytes; the weight keeps all its Cin chunks
+        s_delta = __builtin_amdgcn_readfirstlane(((t_dy * d.Win + t_dx) * s_ld + t_cbase) * 4);   // bytes, relative to the anchor pixel
+    };
+    auto stage_c = [&]() {
+        s_wbase = __builtin_amdgcn_readfirstlane((t_wi * (d.wcin >> 5) + l_cc) * (d.wN ? d.wN : d.N) * 128);       // bytes; the weight keeps all its Cin chunks
         ++l_cc;
         const bool w0 = l_cc == ncc;
         l_cc = w0 ? 0 : l_cc;
@@ -229,6 +237,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
         l_tx = w1 ? 0 : l_tx;
         l_ty += w1 ? 1 : 0;
     };
+    auto stage_begin = [&]() { stage_a(); stage_b(); stage_c(); };
     auto load_piece = [&](auto SET, auto J) {        // piece j < NA: A-tile load j; NA <= j < NA+NB: B-tile load j-NA
         constexpr int j = decltype(J)::value;
         f32x4 (&ra)[NA] = ras[decltype(SET)::value];
@@ -324,7 +333,10 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
 #pragma unroll
             for (int t = 0; t < TPW; ++t)
                 accs[ci][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s2], fb[cur][t][s2], accs[ci][t], 0, 0, 0);
-            if constexpr (do_load && step == PRE) stage_begin();
+            if constexpr (do_load && PRE == 0 && step == 0) stage_begin();
+            if constexpr (do_load && PRE > 0 && step == PRE) stage_a();
+            if constexpr (do_load && PRE > 0 && step == PRE + 1) stage_b();
+            if constexpr (do_load && PRE > 0 && step == PRE + 2) stage_c();
             if constexpr (do_load && step < NST) load_piece(SET, std::integral_constant<int, step>{});
             if constexpr (do_store && step >= 16 - NST) store_piece(OTHER{}, std::integral_constant<int, step - (16 - NST)>{}, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
