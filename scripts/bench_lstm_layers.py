@@ -61,14 +61,30 @@ for name in bufs:
     launch(name)
 torch.cuda.synchronize()
 res = {n: [] for n in bufs}
-for r in range(5):
-    for name in bufs:
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+if os.environ.get('PIVP_BENCH_INTERLEAVE', '0') == '1':
+    # the layers in program order, one launch each per pass (as in a rollout: every launch finds the caches as the other six left them)
+    for r in range(5):
+        evs = []
         for _ in range(iters):
-            launch(name)
-        e1.record(); torch.cuda.synchronize()
-        res[name].append(e0.elapsed_time(e1) / iters)
+            for name in bufs:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(); launch(name); e1.record()
+                evs.append((name, e0, e1))
+        torch.cuda.synchronize()
+        acc = {n: 0.0 for n in bufs}
+        for name, e0, e1 in evs:
+            acc[name] += e0.elapsed_time(e1)
+        for name in bufs:
+            res[name].append(acc[name] / iters)
+else:
+    for r in range(5):
+        for name in bufs:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                launch(name)
+            e1.record(); torch.cuda.synchronize()
+            res[name].append(e0.elapsed_time(e1) / iters)
 tot_f, tot_t = 0.0, 0.0
 for name in bufs:
     x, h, c, w, b, co, ho, cx, C, H, wb = bufs[name]

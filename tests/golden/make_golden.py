@@ -71,6 +71,34 @@ def run_full_batch(model_type, num_masks, batch, seq_len, smooth=False, fp32_err
     return out
 
 
+GRAD_SAMPLES = 512
+
+
+def run_full_batch_grads(model_type, num_masks, batch, seq_len, size=64):
+    """The TRAIN step's gradients at full size (config 2: B = 32, feed-self, TM:950 through optimizer.update): float64 autograd of the
+    independent PyTorch restatement.  54 tensors, 9.2 M values: the fixture keeps every tensor's L2 norm and sum and up to GRAD_SAMPLES
+    entries of each (flat reference layout, a fixed stride from entry 0), plus the loss."""
+    import torch
+    from oracle.torch_restatement import TorchModel
+    torch.set_num_threads(8)
+    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, num_masks=num_masks, model_type=model_type, height=size, width=size)
+    imgs, acts, stas = R.synthetic_batch(batch, seq_len, size, size, seed=0)
+    kw = dict(is_cdna=model_type == 'CDNA', is_stp=model_type == 'STP', is_dna=model_type == 'DNA')
+    tm = TorchModel(num_masks, params=P, requires_grad=True, **kw)
+    loss = tm([imgs, acts, stas], 0)
+    loss.backward()
+    out = dict(loss=np.float64(float(loss.detach())), batch=batch, seq_len=seq_len, num_masks=num_masks, samples=GRAD_SAMPLES,
+               param_checksum=np.float64(sum(float(np.abs(v).sum()) for v in P.values())))
+    for k, v in tm.p.items():
+        g = v.grad.numpy().ravel()
+        stride = max(1, g.size // GRAD_SAMPLES)
+        key = k.replace('/', '.')
+        out['norm:' + key] = np.float64(np.linalg.norm(g))
+        out['sum:' + key] = np.float64(g.sum())
+        out['val:' + key] = g[::stride][:GRAD_SAMPLES].astype(np.float64)
+    return out
+
+
 FULL_BATCH = {   # name: (model_type, batch, seq_len, frame size, smooth, fp32_error)
     'cdna_b32_t10': ('CDNA', 32, 10, 64, False, False),            # BASELINE.json config 2
     'stp_b32_t10': ('STP', 32, 10, 64, False, True),               # config 4, white-noise frames
@@ -80,6 +108,10 @@ FULL_BATCH = {   # name: (model_type, batch, seq_len, frame size, smooth, fp32_e
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'grads':               # a few minutes of PyTorch-CPU float64
+        np.savez_compressed(os.path.join(OUT, 'cdna_b32_t10_grads.npz'), **run_full_batch_grads('CDNA', 10, 32, 10))
+        print('cdna_b32_t10_grads', os.path.getsize(os.path.join(OUT, 'cdna_b32_t10_grads.npz')))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'b32':                 # 1-3 min of NumPy each
         for name, (mt, nb, nt, size, smooth, f32e) in FULL_BATCH.items():
             if len(sys.argv) > 2 and sys.argv[2] != name:

@@ -312,3 +312,35 @@ def test_two_process_data_parallel_step(pivp, tmp_path):
     assert dpar <= 2.001e-3                                          # Adam's first step is +-alpha per element: a sign flip of a ~0 gradient costs 2 alpha
     frac = float(np.mean(np.abs(r0['params'] - m._flat_params.cpu().numpy()) > 1e-4))
     assert frac < 2e-3
+
+
+def test_config2_batch32_gradients_match_golden(pivp):
+    """The train step's gradients at BASELINE.json config 2's full size (B = 32, T = 10, CDNA, feed-self) against the committed float64
+    autograd fixture (tests/golden/make_golden.py grads): per tensor its L2 norm and sum and up to 512 sampled entries.  This is the
+    sweep exactly as the bench times it: K-split data gradients, two-blocks-per-CU weight gradients, partial-sum planes, side stream."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cdna_b32_t10_grads.npz'))
+    P = R.init_params(seed=1, dtype=np.float32, scale=1.0)
+    imgs, acts, stas = R.synthetic_batch(32, 10)
+    m = pivp.Model(10, prefix='t', keep_activations=True)
+    m.load_state_dict_reference(P)
+    loss = float(m([imgs, acts, stas], 0))
+    m.cleargrads(); m.backward()
+    got = m.grads_reference()
+    assert abs(loss - float(g['loss'])) < 1e-5
+    ns = int(g['samples'])
+    keys = [k[4:] for k in g.files if k.startswith('val:')]
+    assert len(keys) == len(got) == 54
+    worst = (0.0, '')
+    for k, v in got.items():
+        key = k.replace('/', '.')
+        f = v.ravel().astype(np.float64)
+        ref = g['val:' + key]
+        val = f[::max(1, f.size // ns)][:ns]
+        rel = np.linalg.norm(val - ref) / (np.linalg.norm(ref) + 1e-30)
+        nrm = abs(np.linalg.norm(f) - float(g['norm:' + key])) / (float(g['norm:' + key]) + 1e-30)
+        worst = max(worst, (max(rel, nrm), k))
+        assert rel < 2e-3, '%s: relative L2 error of the sampled entries %.3e' % (k, rel)
+        assert nrm < 1e-3, '%s: gradient norm off by %.3e' % (k, nrm)
+        assert abs(f.sum() - float(g['sum:' + key])) < 2e-3 * float(g['norm:' + key]) * np.sqrt(f.size) + 1e-9, k
+    print('config 2 (B=32) gradients: worst tensor %s, relative error %.2e' % (worst[1], worst[0]))

@@ -105,3 +105,19 @@ def test_float32_arithmetic_itself_misses_1e4_on_white_noise_stp():
         out[dt] = np.stack(m.gen_images)
     l2 = R.per_pixel_l2(out[np.float32], out[np.float64])[0].max(axis=(1, 2))
     assert np.allclose(l2, e[0], rtol=1e-3, atol=1e-9)
+
+
+def test_full_size_gradient_fixture_is_consistent():
+    """tests/golden/cdna_b32_t10_grads.npz (float64 autograd of the PyTorch restatement at config 2's size, feed-self): same weights and
+    the same loss as the NumPy oracle's forward fixture of that config, 54 tensors, finite, non-trivial."""
+    gg = np.load(os.path.join(GOLD, 'cdna_b32_t10_grads.npz'))
+    gf = np.load(os.path.join(GOLD, 'cdna_b32_t10.npz'))
+    assert abs(float(gg['param_checksum']) - float(gf['param_checksum'])) < 1e-6
+    assert abs(float(gg['loss']) - float(gf['loss'])) < 1e-10          # two independent restatements, float64
+    vals = [k for k in gg.files if k.startswith('val:')]
+    assert len(vals) == 54                                             # the CDNA model's parameter tensors (SURVEY.md App. B)
+    P = R.init_params(seed=1, dtype=np.float64, scale=1.0)
+    assert sorted(k[4:] for k in vals) == sorted(k.replace('/', '.') for k in P)
+    for k in vals:
+        v = gg[k]
+        assert np.isfinite(v).all() and v.size <= int(gg['samples']) and float(gg['norm:' + k[4:]]) > 0
