@@ -469,7 +469,8 @@ static int launch_wgrad5x5(const WgradDesc& d, hipStream_t s) {
     // One block per CU is resident (~100 KB of LDS), so the grid is sized to whole rounds of the chip's CUs: the first
     // version asked for "about 512" blocks and got 520-600, i.e. a third round that ran 8-88 blocks on 256 CUs (lstm7: 264 us
     // for 171 us of MFMA work).  Take the fewest rounds (1..3) whose last round is at least 90 % full.
-    const int cus = pivp_cu_count() * (NTW == 1 ? 2 : 1);   // resident blocks (NTW = 1: two per CU)
+    static const int slots = [] { const char* e = getenv("PIVP_WGRAD_SLOTS"); return e ? atoi(e) : 0; }();   // tuning: blocks per round
+    const int cus = slots > 0 ? slots : pivp_cu_count() * (NTW == 1 ? 2 : 1);   // resident blocks (NTW = 1: two per CU)
     int nsplit = 1;
     double best = 0.0;
     static const int rmin = [] { const char* e = getenv("PIVP_WGRAD_ROUNDS"); return e ? atoi(e) : 1; }();   // tuning
@@ -499,7 +500,8 @@ static void generic_grid(const WgradDesc& d, int& wg_n, int& tiles, int& nsplit)
     // direct path: every block ends with a tile of atomics (64 x 128), so no more pixel splits than fill the chip twice (3 blocks fit a
     // CU) and >= 8 chunks (256 pixels) per block (enc4 with 4: 63 -> 94 us, atomics); kept for the partial-sum path, where a split
     // costs 16-32 KB of traffic instead
-    nsplit = (512 + tiles - 1) / tiles;
+    static const int gslots = [] { const char* e = getenv("PIVP_WGRAD_GEN_SLOTS"); return e ? atoi(e) : 512; }();   // tuning
+    nsplit = (gslots + tiles - 1) / tiles;
     if (nsplit > chunks / 8) nsplit = chunks / 8;
     if (nsplit < 1) nsplit = 1;
 }

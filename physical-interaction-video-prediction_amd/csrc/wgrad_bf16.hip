@@ -13,6 +13,7 @@
 // in; out-of-image pixels = the zeros of an out-of-range buffer load) and runs 8 k-steps x 5 taps against the same dG
 // fragments.  The next tile's loads are in flight in registers while the current one is multiplied.
 // Slices meet in dW by fp32 atomic adds (gradients accumulate until the host clears them, as in the fp32 kernel).
+#include <stdlib.h>
 #include <type_traits>
 
 #include "pivp_kernels.h"
@@ -179,7 +180,13 @@ __global__ __launch_bounds__(256, 2) void wgrad5x5_bf16_kernel(const WgradDesc d
     for (int kx = 0; kx < 5; ++kx) {
         float* base = d.dw + ((size_t)((ky * 5 + kx) * (d.wcin >> 5) + cb) * N + nb * 128 + wave * 32) * 32 + l31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(base + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32, acc[kx][r]);
+        for (int r = 0; r < 16; ++r) {
+#ifdef PIVP_WGB_NOATOMIC   // timing-only ablation (results wrong): what do the epilogue's atomics cost?
+            if (acc[kx][r] == 12345.678f) base[((r & 3) + 8 * (r >> 2) + 4 * half) * 32] = 1.f;
+#else
+            atomicAdd(base + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32, acc[kx][r]);
+#endif
+        }
     }
     if (do_bias) {   // thread (tid / 32, n4 = tid % 32) holds the sums of columns 4 n4 .. 4 n4 + 3 over its pixels: lanes l and l + 32 pair up
 #pragma unroll
@@ -208,8 +215,14 @@ int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s) {
     const int tw = d.Wx % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
     const int n_tiles = (d.B / ti_n) * (d.Hx / 8) * (d.Wx / tw);
     const int gx = 5 * (d.cin / 32) * (d.N / 128);
-    // two blocks per CU are resident: aim at one full round of 512, at least 2 tiles per block
-    int ns = (512 + gx - 1) / gx;
+    // Pixel splits: about one block per TWO CUs, at least 2 tiles per block.  Two blocks per CU could be resident, but the kernel is not
+    // short of parallelism: it is short of tiles per block -- every block ends with 20,480 atomic adds into the same 80 KB of dW as the
+    // other splits of its tile (timing-only build without them: 72 -> 43 us on lstm1 at 52 splits) -- and it runs on the side stream, where
+    // a grid that fills every CU's registers starves the main stream's small kernels (a 5 us add_strided took 34 us beside it).
+    // Train step in the bf16 mode against the block target: 512: 13.93 ms, 256: 13.00, 192: 12.73, 128: 12.54, 96: 13.08, 64: 14.57.
+    static const int slots = [] { const char* e = getenv("PIVP_WGB_SLOTS"); return e ? atoi(e) : 0; }();   // tuning
+    const int target = slots > 0 ? slots : pivp_cu_count() / 2;
+    int ns = (target + gx - 1) / gx;
     if (ns > n_tiles / 2) ns = n_tiles / 2;
     if (ns < 1) ns = 1;
     const int tps = (n_tiles + ns - 1) / ns;
