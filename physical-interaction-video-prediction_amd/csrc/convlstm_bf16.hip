@@ -17,6 +17,7 @@
 // of a 128-B weight row, applied to the per-lane SOURCE address of the DMA and to the read address alike.
 // Accumulators, gate math, cell state, h and the LayerNorm partial stay fp32; the epilogue is that of igemm_f32.hip.
 // The same kernel with a plain epilogue (LSTM = false) is a general 5x5 stride-1 convolution: the ConvLSTM data gradient.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "pivp_kernels.h"
@@ -625,9 +626,10 @@ int conv5x5_bf16_ksplit(const IgemmDesc& d) {
     const int tw = d.Win % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
     const int tiles = (d.B / ti_n) * (d.Hin / TH) * (d.Win / tw);
     const int ncg = (d.c0 + d.c1 + 63) / 64, nb = Np / (Np % 128 == 0 ? 128 : 64);
+    static const int target = [] { const char* e = getenv("PIVP_BF16_KS_BLOCKS"); return e ? atoi(e) : 512; }();   // tuning
     int ks = 1;
     if (d.ksplit_ok && !d.accum)
-        while (ks * 2 <= ncg && (long)tiles * nb * ks * 2 <= 512) ks *= 2;
+        while (ks * 2 <= ncg && (long)tiles * nb * ks * 2 <= target) ks *= 2;
     return ks;
 }
 
