@@ -626,7 +626,10 @@ int conv5x5_bf16_ksplit(const IgemmDesc& d) {
     const int tw = d.Win % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
     const int tiles = (d.B / ti_n) * (d.Hin / TH) * (d.Win / tw);
     const int ncg = (d.c0 + d.c1 + 63) / 64, nb = Np / (Np % 128 == 0 ? 128 : 64);
-    static const int target = [] { const char* e = getenv("PIVP_BF16_KS_BLOCKS"); return e ? atoi(e) : 512; }();   // tuning
+    // split only up to ONE round of blocks (the kernel is one 8-wave block per CU): 512 blocks = two rounds of half-length blocks with
+    // atomics and a zeroed destination were slower than 256 whole ones (bf16 train step 12.56 -> 12.36 ms)
+    static const int forced = [] { const char* e = getenv("PIVP_BF16_KS_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning
+    const int target = forced > 0 ? forced : pivp_cu_count();
     int ks = 1;
     if (d.ksplit_ok && !d.accum)
         while (ks * 2 <= ncg && (long)tiles * nb * ks * 2 <= target) ks *= 2;
