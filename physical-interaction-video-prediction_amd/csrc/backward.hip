@@ -145,11 +145,12 @@ int bias_grad(const float* dy, int ld, int N, int M, float* db, hipStream_t s) {
 
 // dy[pix][c] *= (y[pix][c] > 0)   (backward of the ReLU fused into a producer, TM:697-700)
 __global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
-                                                        int C, long npix) {
+                                                        int C, long npix, const float* __restrict__ add, int ldadd) {
     const long total = npix * (C / 4);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long p = i / (C / 4); const int c = (int)(i - p * (C / 4)) * 4;
         f32x4 g = *reinterpret_cast<f32x4*>(dy + p * lddy + c);
+        if (add) g += *reinterpret_cast<const f32x4*>(add + p * ldadd + c);
         const f32x4 v = *reinterpret_cast<const f32x4*>(y + p * ldy + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) g[e] = v[e] > 0.f ? g[e] : 0.f;
@@ -157,11 +158,11 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ dy, 
     }
 }
 
-int relu_mask(float* dy, int lddy, const float* y, int ldy, int C, long npix, hipStream_t s) {
-    PIVP_CHECK_ARG(dy && y && C > 0 && C % 4 == 0 && npix > 0 && lddy % 4 == 0 && ldy % 4 == 0);
+int relu_mask(float* dy, int lddy, const float* y, int ldy, int C, long npix, hipStream_t s, const float* add, int ldadd) {
+    PIVP_CHECK_ARG(dy && y && C > 0 && C % 4 == 0 && npix > 0 && lddy % 4 == 0 && ldy % 4 == 0 && (!add || ldadd % 4 == 0));
     const long total = npix * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(relu_mask_kernel, dim3(blocks), dim3(256), 0, s, dy, lddy, y, ldy, C, npix);
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(blocks), dim3(256), 0, s, dy, lddy, y, ldy, C, npix, add, ldadd);
     return PIVP_LAUNCH_STATUS();
 }
 

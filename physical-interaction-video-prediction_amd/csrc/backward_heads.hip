@@ -827,7 +827,7 @@ __global__ __launch_bounds__(256) void enc3_state_bwd_kernel(const float* __rest
                                                              const float* __restrict__ dsnew, float* __restrict__ de2,
                                                              float* __restrict__ dw3, float* __restrict__ db3, float* __restrict__ dwcs,
                                                              float* __restrict__ dbcs, float* __restrict__ dstate_prev,
-                                                             int HW8, int use_state) {
+                                                             int HW8, int use_state, int mask_e2) {
     __shared__ float xt[64 * 65];
     __shared__ float dt[64 * 65];
     __shared__ __attribute__((aligned(16))) float wl[64 * 64];
@@ -878,6 +878,10 @@ __global__ __launch_bounds__(256) void enc3_state_bwd_kernel(const float* __rest
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = fmaf(wl[(cg + i) * 64 + co], d, acc[i]);
         }
+        if (mask_e2) {   // e2 = relu(enc2's conv): hand enc2's backward the gradient of the PRE-activation (no relu_mask launch there)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = xt[p * 65 + cg + i] > 0.f ? acc[i] : 0.f;
+        }
         if (p < npx) *reinterpret_cast<f32x4*>(de2 + base + (size_t)p * 64 + cg) = f32x4{acc[0], acc[1], acc[2], acc[3]};
     }
     {   // dW3x[ci][co] += sum_p e2[p][ci] dpre[p][co]: thread (ci = 16 q + tid/16, 4 co)
@@ -911,10 +915,10 @@ __global__ __launch_bounds__(256) void enc3_state_bwd_kernel(const float* __rest
 }
 int enc3_state_bwd(const float* e2, const float* e3, const float* de3, int ldd3, const float* action, const float* state, const float* w3,
                    const float* wcs, const float* dsnew, float* de2, float* dw3, float* db3, float* dwcs, float* dbcs,
-                   float* dstate_prev, int B, int HW8, int use_state, hipStream_t s) {
+                   float* dstate_prev, int B, int HW8, int use_state, hipStream_t s, int mask_e2) {
     PIVP_CHECK_ARG(e2 && e3 && de3 && action && state && w3 && wcs && dsnew && de2 && dw3 && db3 && dwcs && dbcs && dstate_prev && B > 0 && HW8 > 0);
     hipLaunchKernelGGL(enc3_state_bwd_kernel, dim3((HW8 + 63) / 64, B, 4), dim3(256), 0, s, e2, e3, de3, ldd3, action, state, w3, wcs, dsnew, de2,
-                       dw3, db3, dwcs, dbcs, dstate_prev, HW8, use_state);
+                       dw3, db3, dwcs, dbcs, dstate_prev, HW8, use_state, mask_e2);
     return PIVP_LAUNCH_STATUS();
 }
 

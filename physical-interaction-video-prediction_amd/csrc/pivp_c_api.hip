@@ -242,10 +242,11 @@ int run_select_frames(const float* gt, const float* gen, const unsigned char* ta
 // conv3x3s2 (mode 0) / deconv3x3s2 (mode 1) backward.  dy is masked in place by (y > 0) when y != null (fused ReLU).
 int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w, float* dy, int cout, int ldy, const float* y, int ldyy,
                       float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, hipStream_t s,
-                      int wt_ready, const SideFork* fork, float* part, WgradDesc* desc_out) {
+                      int wt_ready, const SideFork* fork, float* part, WgradDesc* desc_out, const float* dy_add, int ld_add) {
     const int Hout = mode ? 2 * Hin : Hin / 2, Wout = mode ? 2 * Win : Win / 2;
     int rc = PIVP_OK;
-    if (y) { rc = relu_mask(dy, ldy, y, ldyy, cout, (long)B * Hout * Wout, s); if (rc != PIVP_OK) return rc; }
+    if (y) { rc = relu_mask(dy, ldy, y, ldyy, cout, (long)B * Hout * Wout, s, dy_add, ld_add); if (rc != PIVP_OK) return rc; }
+    else if (dy_add) { rc = add_strided(dy, ldy, dy_add, ld_add, cout, (long)B * Hout * Wout, s); if (rc != PIVP_OK) return rc; }
     hipStream_t sw;
     rc = fork_begin(fork, s, &sw);      // dy is final here
     if (rc != PIVP_OK) return rc;

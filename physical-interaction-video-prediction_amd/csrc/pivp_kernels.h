@@ -160,7 +160,8 @@ int lstm_gates_bwd(const float* gates, const float* c_old, const float* c_new, c
                    const LnFuse* ln = nullptr,
                    float* zero = nullptr, long long zero_floats = 0);
 int bias_grad(const float* dy, int ld, int N, int M, float* db, hipStream_t s);
-int relu_mask(float* dy, int lddy, const float* y, int ldy, int C, long npix, hipStream_t s);
+int relu_mask(float* dy, int lddy, const float* y, int ldy, int C, long npix, hipStream_t s,
+              const float* add = nullptr, int ldadd = 0);   // add: dy = (dy + add) masked -- a second gradient path into the same activation
 int ln_bwd_slices(int n);
 // param_part (optional, ln_bwd_param_part_floats(n) floats, zeroed before the first launch of a sweep): the parameter gradients are
 // accumulated there without atomics and reach dgamma / dbeta only through ln_bwd_params_reduce (once per sweep)
@@ -190,7 +191,8 @@ int cdna_kernels_bwd(const float* hidden5, const float* wt, const float* vpre, c
                      float* dhidden5, int accum_dx, float* dwt, float* db, int B, int K, int NM, hipStream_t s, const SideFork* fork = nullptr);   // fork: where the WEIGHT-gradient kernel runs (behind dv)
 int enc3_state_bwd(const float* e2, const float* e3, const float* de3, int ldd3, const float* action, const float* state, const float* w3,
                    const float* wcs, const float* dsnew, float* de2, float* dw3, float* db3, float* dwcs, float* dbcs,
-                   float* dstate_prev, int B, int HW8, int use_state, hipStream_t s);
+                   float* dstate_prev, int B, int HW8, int use_state, hipStream_t s,
+                   int mask_e2 = 0);   // 1: de2 is masked by (e2 > 0), i.e. it is the gradient in front of enc2's ReLU
 int enc0_bwd(const float* img, const float* w, const float* d, float* dw, float* db, float* dimg, int dimg_accum, int B, int H, int W,
              hipStream_t s, const SideFork* fork = nullptr);   // fork: where the weight / bias gradient kernel runs
 int add_strided(float* dst, int ldd, const float* src, int lds_, int C, long npix, hipStream_t s);

@@ -590,7 +590,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         if (p->side && hipEventRecord(p->ev_ring_done[i][wg_ring], p->side) != hipSuccess) return PIVP_ERR_LAUNCH;
         return PIVP_OK;
     };
-    const long px2 = (long)B * p->H2 * p->W2, px4 = (long)B * p->H4 * p->W4, px8 = (long)B * p->H8 * p->W8;
+    const long px2 = (long)B * p->H2 * p->W2, px8 = (long)B * p->H8 * p->W8;
 
     // the enc convs' weight gradients of the previous (later) timestep read dY buffers that this step is about to rewrite
     // The enc convs' weight gradients of the previous (later) timestep read dY buffers that this step rewrites: each is joined right in
@@ -683,9 +683,9 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(enc3_state_bwd(ws + S.e2, ws + S.e3, ws + g.din[4][par], 192, action, state_prev, P(p, p->i_enc_w[3]), P(p, p->i_cs_w),
                       ws + g.dstate + (size_t)t * B * 5, ws + g.e2, G(p, p->i_enc_w[3]), G(p, p->i_enc_b[3]), G(p, p->i_cs_w),
                       G(p, p->i_cs_b), t > 0 ? ws + g.dstate + (size_t)(t - 1) * B * 5 : ws + g.dstate + (size_t)(c.seq_len - 1) * B * 5,
-                      B, p->H8 * p->W8, c.use_state, s));
+                      B, p->H8 * p->W8, c.use_state, s, 1));      // d e2 comes out masked by enc2's ReLU
     // group 2 (TM:597): enc2 conv (ReLU) <- hidden4 <- lstm4 <- hidden3 <- lstm3 <- enc1
-    RC(run_conv_backward(0, ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), ws + g.e2, 64, 64, ws + S.e2, 64, ws + g.wt_enc[2], ws + g.n4, 64, 0,
+    RC(run_conv_backward(0, ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), ws + g.e2, 64, 64, nullptr, 0, ws + g.wt_enc[2], ws + g.n4, 64, 0,
                          G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s, 1, fork_of(10, fe), ws + g.wg_part[3], &p->enc_desc[3]));
     p->enc_desc_valid[3] = true;
     RC(lnb_cell(3, ws + g.n4, 64, n4, 64));
@@ -693,10 +693,10 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(lnb_cell(2, ws + g.din[3][par], 128, n4, 64));
     RC(lstmb(2, ws + S.cat6 + 64, 96, p->H4, p->W4));
     RC(done(4));
-    RC(add_strided(ws + g.cat6 + 64, 96, ws + g.din[2][par], 96, 32, px4, s));          // d enc1: from enc5's concat + from lstm3
     // group 1 (TM:596): enc1 conv (ReLU) <- hidden2 <- lstm2 <- hidden1 <- lstm1 <- enc0
     RC(run_conv_backward(0, ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), ws + g.cat6 + 64, 32, 96, ws + S.cat6 + 64, 96, ws + g.wt_enc[1], ws + g.n2, 32, 0,
-                         G(p, p->i_enc_w[1]), G(p, p->i_enc_b[1]), B, p->H2, p->W2, s, 1, fork_of(11, fe), ws + g.wg_part[4], &p->enc_desc[4]));
+                         G(p, p->i_enc_w[1]), G(p, p->i_enc_b[1]), B, p->H2, p->W2, s, 1, fork_of(11, fe), ws + g.wg_part[4], &p->enc_desc[4],
+                         ws + g.din[2][par], 96));      // d enc1 = enc5's concat part (in d cat6) + lstm3's x gradient, summed in the ReLU-mask pass
     p->enc_desc_valid[4] = true;
     RC(lnb_cell(1, ws + g.n2, 32, n2, 32));
     RC(lstmb(1, ws + S.n1, 32, p->H2, p->W2));
