@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __rest
                                                              const float* __restrict__ dh_b, int ldb, float* __restrict__ dc,
                                                              int dc_valid, float* __restrict__ dG, int npix, int C, const LnFuse ln,
                                                              float* __restrict__ zero, long long zero_f4) {
+    PIVP_SET_MAIN_PRIO();
     __shared__ float sums[2];
     const int b = blockIdx.y;
     const int n = npix * C;                                   // elements per sample
@@ -146,6 +147,7 @@ int bias_grad(const float* dy, int ld, int N, int M, float* db, hipStream_t s) {
 // dy[pix][c] *= (y[pix][c] > 0)   (backward of the ReLU fused into a producer, TM:697-700)
 __global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
                                                         int C, long npix, const float* __restrict__ add, int ldadd) {
+    PIVP_SET_MAIN_PRIO();
     const long total = npix * (C / 4);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long p = i / (C / 4); const int c = (int)(i - p * (C / 4)) * 4;
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const float* __restri
                                                            const float* __restrict__ x, const float* __restrict__ stat,
                                                            const float* __restrict__ gamma, float* __restrict__ partials,
                                                            int n, int C, int relu) {
+    PIVP_SET_MAIN_PRIO();
     __shared__ float red[4];
     const int sl = blockIdx.x, b = blockIdx.y, S = gridDim.x;
     const float mean = stat[b * 2], rstd = stat[b * 2 + 1];
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ x, const float* __restrict__ stat,
                                                            const float* __restrict__ gamma, const float* __restrict__ partials,
                                                            float* __restrict__ dx, int n, int C, int relu) {
+    PIVP_SET_MAIN_PRIO();
     __shared__ float sums[2];
     const int sl = blockIdx.x, b = blockIdx.y, S = gridDim.x;
     if (threadIdx.x < 64) {
@@ -285,6 +289,7 @@ __global__ __launch_bounds__(256) void ln_bwd_sums_params_kernel(const float* __
                                                                  const float* __restrict__ x, const float* __restrict__ stat,
                                                                  const float* __restrict__ gamma, float* __restrict__ partials,
                                                                  int B, int n, int C, int relu, float* __restrict__ part) {
+    PIVP_SET_MAIN_PRIO();
     __shared__ float red[4][8];
     const int e0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     const bool valid = e0 < n;

@@ -12,6 +12,7 @@ namespace pivp {
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void scaled_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
                                                           long n, float scale, int accum) {
+    PIVP_SET_MAIN_PRIO();
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float v = scale * (a[i] - b[i]);
         out[i] = accum ? out[i] + v : v;
@@ -46,6 +47,7 @@ __global__ __launch_bounds__(256) void composite_bwd_cdna_kernel(const float* __
                                                                  const float* __restrict__ go, float* __restrict__ dmk,
                                                                  float* __restrict__ dz, float* __restrict__ dkpart,
                                                                  float* __restrict__ dprev, int dprev_accum, int H, int W, int NM) {
+    PIVP_SET_MAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int NP = NM + 1, HW = H * W, NK = NM - 1;
     const int b = blockIdx.y, y0 = blockIdx.x * CB_TR;
@@ -266,6 +268,7 @@ __global__ __launch_bounds__(256) void composite_bwd_dna_kernel(const float* __r
                                                                 const float* __restrict__ e7, const float* __restrict__ go,
                                                                 float* __restrict__ dmk, float* __restrict__ dz,
                                                                 float* __restrict__ dprev, int dprev_accum, int H, int W) {
+    PIVP_SET_MAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int NP = 2;
     const int HW = H * W;
@@ -379,6 +382,7 @@ int composite_bwd_dna(const float* prev, const float* logits, const float* e7, c
 // elements, d r = mk * (d mk - sum_group mk * d mk), masked by r > 0 (r = relu(masks conv)).  In place on dmk.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mask_softmax_bwd_kernel(const float* __restrict__ logits, float* __restrict__ dmk, long ngroups, int NP) {
+    PIVP_SET_MAIN_PRIO();
     for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (long)gridDim.x * 256) {
         const float* r = logits + g * NP;
         float* d = dmk + g * NP;
@@ -423,6 +427,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ dpm, const float* __restrict__ dpe,
                                                         float* __restrict__ de6, float* __restrict__ dwm, float* __restrict__ dbm,
                                                         float* __restrict__ dwe, float* __restrict__ dbe, int total_px, int HW, int NP, int NE) {
+    PIVP_SET_MAIN_PRIO();
     __shared__ __attribute__((aligned(16))) float xt[HB_PX * 68];        // [pixel][64 + 4]; reused for the block reduction of dW
     __shared__ float dpt[HB_MAXOUT * HB_DP];                              // [output][pixel]
     __shared__ float wl[HB_MAXOUT * 64];                                  // [output][k]
@@ -536,6 +541,7 @@ int heads_bwd(const float* e6, const float* wm, const float* we, const float* dp
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cdna_kernels_bwd_dv_kernel(const float* __restrict__ vpre, const float* __restrict__ dkpart, int ntiles,
                                                                   float* __restrict__ dv, float* __restrict__ db, int NM) {
+    PIVP_SET_MAIN_PRIO();
     __shared__ float u[256], dk[256];
     const int b = blockIdx.x, o = threadIdx.x, nout = NM * 25, nused = (NM - 1) * 25;
     float uu = 0.f, d = 0.f;
@@ -563,6 +569,7 @@ __global__ __launch_bounds__(256) void cdna_kernels_bwd_dv_kernel(const float* _
 // d x[b][kk] = sum_o Wt[kk][o] dv[b][o]; block = 32 rows kk, all b (<= 32 per pass)
 __global__ __launch_bounds__(256) void skinny_linear_bwd_x_kernel(const float* __restrict__ wt, const float* __restrict__ dv,
                                                                   float* __restrict__ dx, int B, int K, int accum) {
+    PIVP_SET_MAIN_PRIO();
     __shared__ float wl[32 * 257];
     __shared__ float dl[32 * 257];
     const int k0 = blockIdx.x * 32, b0 = blockIdx.y * 32, tid = threadIdx.x;
@@ -657,6 +664,7 @@ __global__ __launch_bounds__(256) void composite_bwd_stp_kernel(const float* __r
                                                                 const float* __restrict__ go, float* __restrict__ dmk, float* __restrict__ dz,
                                                                 float* __restrict__ dthpart, float* __restrict__ dprev,
                                                                 int H, int W, int NM, int stp_zero) {
+    PIVP_SET_MAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float red[4][6];
     const int NP = NM + 1, HW = H * W;
@@ -783,6 +791,7 @@ int composite_bwd_stp(const float* prev, const float* logits, const float* layer
 __global__ __launch_bounds__(128) void stp_params_bwd_kernel(const float* __restrict__ dthpart, int ntiles, const float* __restrict__ s1,
                                                              const float* __restrict__ w2, float* __restrict__ dw2, float* __restrict__ db2,
                                                              float* __restrict__ db1, float* __restrict__ dv) {
+    PIVP_SET_MAIN_PRIO();
     __shared__ float dth[6];
     const int b = blockIdx.x, o = threadIdx.x;
     if (o < 6) {
@@ -828,6 +837,7 @@ __global__ __launch_bounds__(256) void enc3_state_bwd_kernel(const float* __rest
                                                              float* __restrict__ dw3, float* __restrict__ db3, float* __restrict__ dwcs,
                                                              float* __restrict__ dbcs, float* __restrict__ dstate_prev,
                                                              int HW8, int use_state, int mask_e2) {
+    PIVP_SET_MAIN_PRIO();
     __shared__ float xt[64 * 65];
     __shared__ float dt[64 * 65];
     __shared__ __attribute__((aligned(16))) float wl[64 * 64];
@@ -969,6 +979,7 @@ __global__ __launch_bounds__(256) void enc0_wgrad_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void enc0_dgrad_kernel(const float* __restrict__ d, const float* __restrict__ w, float* __restrict__ dimg,
                                                          int accum, int B, int H, int W) {
+    PIVP_SET_MAIN_PRIO();
     __shared__ __attribute__((aligned(16))) float wl[75 * 32];
     for (int i = threadIdx.x; i < 75 * 32; i += 256) wl[i] = w[i];
     __syncthreads();
@@ -1031,6 +1042,7 @@ int enc0_bwd(const float* img, const float* w, const float* d, float* dw, float*
 
 // out[i] = a[i] + b[i] over n floats with row strides (sum of two gradient contributions into one buffer)
 __global__ __launch_bounds__(256) void add_strided_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds_, int C, long npix) {
+    PIVP_SET_MAIN_PRIO();
     const long total = npix * (C / 4);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long p = i / (C / 4); const int c = (int)(i - p * (C / 4)) * 4;

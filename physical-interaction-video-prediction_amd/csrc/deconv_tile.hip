@@ -38,6 +38,7 @@ __device__ __forceinline__ unsigned dpack2(float a, float b) {
 // lo*hi + hi*lo + hi*hi on three MFMAs (the split mode of convlstm_bf16.hip).  PREC 0: fp32 MFMA.
 template <int PREC>
 __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDesc d) {
+    PIVP_SET_MAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float lds[];   // A patch | the 9 weight tiles
     float* const At = lds;
     float* const Bt = lds + A_FL;

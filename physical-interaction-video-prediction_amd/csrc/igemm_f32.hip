@@ -95,6 +95,7 @@ __device__ long long pivp_f32_stamps[2048 * 4];
 template <int WM, int WN, int NTB, bool LSTM, int ABL = 0, int KG = 1>
 __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void igemm_f32_kernel(const IgemmDesc d) {
     F32_STAMP(0);
+    PIVP_SET_MAIN_PRIO();
     static_assert(WM * WN == 4, "4 waves");
     static_assert(KG == 1 || (KG == 2 && LSTM), "the in-block K split serves the ConvLSTM tile only");
     static_assert(!LSTM || NTB == 4, "ConvLSTM blocks own 4 gates x 32 channels");

@@ -25,6 +25,7 @@ constexpr int TILE = 32 * SP;
 // NTB: 32-column tiles per block (the A fragment is reused NTB times; fewer, longer-running blocks).
 template <int NTB>
 __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
+    PIVP_SET_MAIN_PRIO();
     constexpr int BN = 32 * NTB;
     constexpr int RP = BN + 4;                                    // row pitch of the partial-sum image
     constexpr int A_OFF = 0, B_OFF = 2 * TILE;                    // A0 A1 | B0 B1 (NTB tiles each)

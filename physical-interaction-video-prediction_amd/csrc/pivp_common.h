@@ -111,3 +111,11 @@ __device__ __forceinline__ void ln_merge_partials(const float* __restrict__ part
 }
 
 }  // namespace pivp
+
+// Wave priority of the kernels on the backward sweep's critical path (the caller's stream).  Beside the side stream's weight-gradient
+// waves, which keep the matrix pipe of their SIMD busy, a co-resident wave at the default priority 0 gets a VALU issue slot every few
+// hundred cycles: a chain of 500 dependent FMAs takes 111 us instead of 3.6 (scripts/contention_probe.py), 45 us with s_setprio 3.
+#ifndef PIVP_MAIN_PRIO
+#define PIVP_MAIN_PRIO 3
+#endif
+#define PIVP_SET_MAIN_PRIO() do { if (PIVP_MAIN_PRIO > 0) __builtin_amdgcn_s_setprio(PIVP_MAIN_PRIO); } while (0)
