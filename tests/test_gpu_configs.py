@@ -151,3 +151,26 @@ def test_config5_rollout_and_train_step_at_rank_size(pivp):
     # B = 32, 128 x 128, plus gradients-of-activations scratch: 18.4 GiB measured.  288 GB of HBM holds it 15 times over.
     assert 10 * 2**30 < ws_train < 24 * 2**30
     assert ws_infer < 3 * 2**30
+
+
+def test_config2_and_3_training_trajectories(pivp):
+    """Thirty optimizer.update steps (TM:950) on one fixed video-like batch at the per-GPU size of configs 2 and 3 (B = 32, T = 10): the
+    loss falls steadily in fp32 and in the bf16 mode, and the two trajectories stay together -- the train step as the bench times it
+    (side stream, K-split data gradients, partial-sum planes, fused Adam) does what an optimizer step is for."""
+    P = R.init_params(seed=1, dtype=np.float32, scale=1.0)
+    imgs, acts, stas = R.smooth_batch(32, 10)
+    traj = {}
+    for prec in ('fp32', 'bf16'):
+        m = _model(pivp, P, precision=prec, keep=True)
+        opt = pivp.Adam(alpha=0.001); opt.setup(m)
+        losses = []
+        for it in range(30):
+            losses.append(float(opt.update(m, [imgs, acts, stas], it)))
+            m.reset_state()
+        traj[prec] = np.array(losses)
+        assert np.isfinite(traj[prec]).all()
+        assert traj[prec][-1] < 0.5 * traj[prec][0], (prec, traj[prec][0], traj[prec][-1])          # it learns the batch
+        assert (np.diff(traj[prec]) < 0.05 * traj[prec][:-1]).all(), (prec, traj[prec])           # no step blows the loss up
+    print('loss, 30 steps: fp32 %.5f -> %.5f, bf16 %.5f -> %.5f' % (traj['fp32'][0], traj['fp32'][-1], traj['bf16'][0], traj['bf16'][-1]))
+    assert abs(traj['bf16'][0] - traj['fp32'][0]) < 0.02 * traj['fp32'][0]
+    assert np.abs(traj['bf16'] - traj['fp32']).max() < 0.15 * traj['fp32'][0]
