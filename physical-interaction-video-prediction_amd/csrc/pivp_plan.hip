@@ -418,7 +418,8 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
                      ws + S.logits, ws + S.enc7, ws + S.layer0, B, H * W, p->NP, p->NE, c.model_type, s));
     }
     // (The motion head's generator needs hidden5 only and could run on the side stream under lstm6 .. heads: measured, the rollout got
-    // SLOWER, 8.68 -> 8.79 ms: the co-running kernels cost the ConvLSTMs more than the 16 us they hide.  It stays in line.)
+    // SLOWER, 8.68 -> 8.79 ms: the co-running kernels cost the ConvLSTMs more than the 16 us they hide; again with the ConvLSTM waves at
+    // priority 3 and the generator at 0: 8.57 -> 8.67 / 8.73 ms.  It stays in line.)
     const float* aux = nullptr;
     if (c.model_type == PIVP_MODEL_CDNA) {
         RC(cdna_kernels(ws + S.n5, P(p, p->i_head_w), P(p, p->i_head_b), ws + p->o_linpart, ws + S.kerns, B, p->K5, c.num_masks, s,
