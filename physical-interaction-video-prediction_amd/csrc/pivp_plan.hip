@@ -102,7 +102,7 @@ struct pivp_plan {
     // the plan is created) keeps everything on the caller's stream.
     static constexpr int NSLOT = 14;      // 12: enc0's weight gradient, 13: the motion head's Linear (cdna_kernels / stp_input)
     bool use_side = true;
-    hipStream_t side = nullptr, side2 = nullptr;   // side2 (bf16 mode, or PIVP_SIDE_STREAMS=2): the odd slots' weight gradients run on a second side stream
+    hipStream_t side = nullptr, side2 = nullptr;   // side2 (PIVP_SIDE_STREAMS=2 only): the odd slots' weight gradients run on a second side stream
     hipStream_t side_of(int slot) const { return (side2 && (slot & 1)) ? side2 : side; }
     hipEvent_t ev_ready[NSLOT] = {}, ev_done[NSLOT] = {};
     hipEvent_t ev_ring_done[7][2] = {};        // ConvLSTM slots: one `done` per dG ring (slots 0..6 of ev_done are unused)
@@ -327,10 +327,12 @@ static int ensure_side(pivp_plan* plan) {
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
     if (hipStreamCreateWithPriority(&plan->side, hipStreamNonBlocking, least) != hipSuccess) { plan->side = nullptr; return PIVP_ERR_LAUNCH; }
-    {   // a second side stream for the odd slots: two weight-gradient kernels in flight.  fp32: no change (28.33 / 28.42 vs 28.35 / 28.34 ms);
-        // bf16 mode, whose weight gradients are short launches with an atomics tail: 12.25 -> 12.05 ms.  Default: bf16 mode only.
+    {   // PIVP_SIDE_STREAMS=2: a second side stream for the odd slots (two weight-gradient kernels in flight).  fp32: no change (28.33 / 28.42
+        // vs 28.35 / 28.34 ms); bf16 mode: 12.25 -> 12.05 ms.  NOT the default: with two processes on one GPU (bench.py --share-gpu, gloo) the
+        // bf16 train step went from 65 ms to 78 SECONDS -- five streams per process oversubscribe the hardware queues -- and a data-parallel rank
+        // already adds the collective's stream to main + side.
         const char* e = getenv("PIVP_SIDE_STREAMS");
-        const bool two = e ? atoi(e) == 2 : plan->bf16_all != 0;
+        const bool two = e && atoi(e) == 2;
         if (two && hipStreamCreateWithPriority(&plan->side2, hipStreamNonBlocking, least) != hipSuccess) plan->side2 = nullptr;
     }
     for (int i = 0; i < pivp_plan::NSLOT; ++i)
