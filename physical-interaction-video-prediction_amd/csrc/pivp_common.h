@@ -115,7 +115,10 @@ __device__ __forceinline__ void ln_merge_partials(const float* __restrict__ part
 // Wave priority of the kernels on the backward sweep's critical path (the caller's stream).  Beside the side stream's weight-gradient
 // waves, which keep the matrix pipe of their SIMD busy, a co-resident wave at the default priority 0 gets a VALU issue slot every few
 // hundred cycles: a chain of 500 dependent FMAs takes 111 us instead of 3.6 (scripts/contention_probe.py), 45 us with s_setprio 3.
+// Built with -DPIVP_MAIN_PRIO=3 the sweep's small kernels run 2-4x faster beside the side stream (igemm_small 171 -> 43 us) but the
+// train step does not move (the sweep is bound by the matrix-pipe work of both streams together), and in a data-parallel job the
+// collective's long-lived waves, which win the oldest-first arbitration at equal priority, would lose it.  Default: 0 (no s_setprio).
 #ifndef PIVP_MAIN_PRIO
-#define PIVP_MAIN_PRIO 3
+#define PIVP_MAIN_PRIO 0
 #endif
 #define PIVP_SET_MAIN_PRIO() do { if (PIVP_MAIN_PRIO > 0) __builtin_amdgcn_s_setprio(PIVP_MAIN_PRIO); } while (0)
