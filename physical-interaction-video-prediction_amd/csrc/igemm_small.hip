@@ -23,7 +23,7 @@ constexpr int TILE = 32 * SP;
 }
 
 // NTB: 32-column tiles per block (the A fragment is reused NTB times; fewer, longer-running blocks).
-template <int NTB>
+template <int NTB, bool IN_LN = false>
 __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     PIVP_SET_MAIN_PRIO();
     constexpr int BN = 32 * NTB;
@@ -67,9 +67,22 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     for (int t = 0; t < NTB; ++t) b_goff[t] = ((nblk * BN + t * 32 + prow) * 32 + cvec * 4) * 4;
     const int lds_w = prow * SP + cvec * 4;
 
+    // LayerNorm-on-load (d.in_g): the tile's 32 anchors lie in ONE sample (the launcher checks Hg * Wg % 32 == 0); its statistics are merged
+    // from the producer's partials by wave 0 and every staged float4 becomes (v - mean) * rstd * gamma + beta, the expression of
+    // ln_apply_kernel (bit-identical to the two-launch form).  Out-of-image taps load 0 for v, gamma and beta alike: they stay 0.
+    constexpr bool in_ln = IN_LN;
+    __shared__ float in_stat[2];
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_ln ? d.in_g : d.x0), 0, in_ln ? d.Hin * d.Win * d.c0 * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_ln ? d.in_b : d.x0), 0, in_ln ? d.Hin * d.Win * d.c0 * 4 : 0, 0x00020000);
+    if (IN_LN && tid < 64) {
+        float mean, rstd;
+        ln_merge_partials(d.in_part, m0 / HWg, d.in_np, d.in_eps, mean, rstd);
+        if (tid == 0) { in_stat[0] = mean; in_stat[1] = rstd; }
+    }
     int l_cc = 0, l_ty = 0, l_tx = 0;
     // two register sets: chunk i+2 is loaded while chunk i is multiplied and written to LDS at the end of chunk i+1
     f32x4 ras[2], rbs[2][NTB];
+    f32x4 rgs[2], rbe[2];              // in_ln: gamma / beta of the staged float4
     auto load_next = [&](auto SET) {   // chunk (l_ty, l_tx, l_cc) -> register set SET, then advance
         f32x4& ra = ras[decltype(SET)::value];
         f32x4 (&rb)[NTB] = rbs[decltype(SET)::value];
@@ -90,13 +103,24 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
         const unsigned off = ok ? (unsigned)((first ? a_off0 : a_off1) + delta) : OOB;
         ra = __builtin_bit_cast(f32x4, first ? __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0)
                                              : __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
+        if constexpr (IN_LN) {         // element (iy, ix, channel) of the sample: [Hin*Win][c0]
+            const unsigned goff = ok ? (unsigned)(((iy * d.Win + ix) * d.c0 + ch + cvec * 4) * 4) : OOB;
+            rgs[decltype(SET)::value] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, goff, 0, 0));
+            rbe[decltype(SET)::value] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, goff, 0, 0));
+        }
 #pragma unroll
         for (int t = 0; t < NTB; ++t) rb[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, b_goff[t], wbase, 0));
         if (++l_cc == ncc) { l_cc = 0; if (++l_tx == ntx) { l_tx = 0; ++l_ty; } }
     };
     auto store_regs = [&](auto SET, int buf) {
-        const f32x4& ra = ras[decltype(SET)::value];
+        f32x4 ra = ras[decltype(SET)::value];
         const f32x4 (&rb)[NTB] = rbs[decltype(SET)::value];
+        if constexpr (IN_LN) {
+            const float mean = in_stat[0], rstd = in_stat[1];
+            const f32x4 g = rgs[decltype(SET)::value], be = rbe[decltype(SET)::value];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ra[e] = (ra[e] - mean) * rstd * g[e] + be[e];
+        }
         *reinterpret_cast<f32x4*>(lds + A_OFF + buf * TILE + lds_w) = ra;
 #pragma unroll
         for (int t = 0; t < NTB; ++t) *reinterpret_cast<f32x4*>(lds + B_OFF + (buf * NTB + t) * TILE + lds_w) = rb[t];
@@ -122,6 +146,7 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
                 for (int t = 0; t < NTB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s2], fb[t][s2], acc[t], 0, 0, 0);
         };
         load_next(S0{});
+        if constexpr (IN_LN) __syncthreads();   // in_stat
         store_regs(S0{}, 0);
         if (nchunks > 1) load_next(S1{});
         __syncthreads();
@@ -214,10 +239,24 @@ int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     dd.ln_nparts = (d.ln_part && hwg % 32 == 0 && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
+    if (d.in_g) {      // LayerNorm-on-load (see IgemmDesc::in_g): one sample per tile, one source, a plain conv
+        PIVP_CHECK_ARG(igemm_in_ln_ok(d) && d.in_b && d.in_part && d.in_np > 0);
+        if (ntb == 3) hipLaunchKernelGGL((igemm_small_kernel<3, true>), grid, dim3(256), 0, stream, dd);
+        else if (ntb == 2) hipLaunchKernelGGL((igemm_small_kernel<2, true>), grid, dim3(256), 0, stream, dd);
+        else hipLaunchKernelGGL((igemm_small_kernel<1, true>), grid, dim3(256), 0, stream, dd);
+        return PIVP_LAUNCH_STATUS();
+    }
     if (ntb == 3) hipLaunchKernelGGL(igemm_small_kernel<3>, grid, dim3(256), 0, stream, dd);
     else if (ntb == 2) hipLaunchKernelGGL(igemm_small_kernel<2>, grid, dim3(256), 0, stream, dd);
     else hipLaunchKernelGGL(igemm_small_kernel<1>, grid, dim3(256), 0, stream, dd);
     return PIVP_LAUNCH_STATUS();
+}
+
+// geometry the LayerNorm-on-load form serves: a conv (not the 4-phase transposed form) on one source whose rows are exactly the c0
+// channels, output tiles of 32 anchors inside one sample
+bool igemm_in_ln_ok(const IgemmDesc& d) {
+    return !d.deconv && d.nphase == 1 && d.c1 == 0 && d.ld0 == d.c0 && (d.Hg * d.Wg) % 32 == 0 && d.M == d.B * d.Hg * d.Wg &&
+           (long long)d.Hin * d.Win * d.c0 * 4 < (1LL << 31);
 }
 
 }  // namespace pivp

@@ -55,6 +55,35 @@ int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float*
     return igemm_conv(d, s);
 }
 
+// conv3x3s2 of LayerNorm(x_raw): the norm (per-element gamma / beta, statistics from the producer's partials) is applied while the
+// input is staged -- no launch of its own (inference rollouts).  x_raw [B][Hin*Win][cin] contiguous.
+static void conv3x3s2_ln_desc(IgemmDesc& d, const float* x_raw, int cin, const float* w, const float* bias, float* out, int cout, int ldo,
+                              int relu, int B, int Hin, int Win) {
+    memset(&d, 0, sizeof(d));
+    d.x0 = x_raw; d.c0 = cin; d.ld0 = cin; d.wcin = cin; d.w = w; d.bias = bias;
+    d.B = B; d.Hin = Hin; d.Win = Win; d.Hg = Hin / 2; d.Wg = Win / 2; d.in_step = 2;
+    d.N = cout; d.M = B * d.Hg * d.Wg;
+    d.nphase = 1; d.deconv = 0; d.ksize = 3; d.pad = 1;
+    d.out_step = 1; d.Hout = d.Hg; d.Wout = d.Wg; d.out = out; d.ldo = ldo; d.relu = relu;
+}
+bool conv3x3s2_ln_ok(int cin, int cout, int B, int Hin, int Win) {
+    if (Hin % 2 || Win % 2 || cin % 32 || cout % 32) return false;
+    IgemmDesc d;
+    conv3x3s2_ln_desc(d, nullptr, cin, nullptr, nullptr, nullptr, cout, cout, 0, B, Hin, Win);
+    return igemm_in_ln_ok(d) && fits31(view_bytes(B, Hin, Win, cin)) && fits31(9LL * cin * cout * 4);
+}
+int run_conv3x3s2_ln(const float* x_raw, int cin, const float* w, const float* bias, float* out, int cout, int ldo, int relu,
+                     int B, int Hin, int Win, hipStream_t s, const float* gamma, const float* beta, const float* partials, int nparts, float eps) {
+    if (!x_raw || !w || !out || !gamma || !beta || !partials || nparts <= 0 || !conv3x3s2_ln_ok(cin, cout, B, Hin, Win)) return PIVP_ERR_BADARG;
+    IgemmDesc d;
+    conv3x3s2_ln_desc(d, x_raw, cin, w, bias, out, cout, ldo, relu, B, Hin, Win);
+    d.bytes0 = (int)view_bytes(B, Hin, Win, cin); d.bytesw = (int)(9LL * cin * cout * 4);
+    d.in_g = gamma; d.in_b = beta; d.in_part = partials; d.in_np = nparts; d.in_eps = eps;
+    int rc = igemm_validate(d, false);
+    if (rc != PIVP_OK) return rc;
+    return igemm_small(d, s);
+}
+
 int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                     int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum, float* ln_part, int ln_cap,
                     int* ln_nparts, int bf16) {

@@ -12,6 +12,11 @@ int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, co
                  const unsigned short* w_bf16 = nullptr, int bf16_planes = 1);
 int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                   int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0);
+// conv3x3s2 of LayerNorm(x_raw) with the norm applied while the input is staged (IgemmDesc::in_g); conv3x3s2_ln_ok tells whether the
+// geometry qualifies (output tiles of 32 anchors inside one sample)
+bool conv3x3s2_ln_ok(int cin, int cout, int B, int Hin, int Win);
+int run_conv3x3s2_ln(const float* x_raw, int cin, const float* w, const float* bias, float* out, int cout, int ldo, int relu,
+                     int B, int Hin, int Win, hipStream_t s, const float* gamma, const float* beta, const float* partials, int nparts, float eps);
 int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                     int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0,
                     float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr, int bf16 = 0);

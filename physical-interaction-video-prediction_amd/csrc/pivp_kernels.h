@@ -38,6 +38,10 @@ struct IgemmDesc {
     // The launcher fills ln_nparts (0 = tiles straddle samples or exceed ln_cap: not fused, run ln_stats instead).
     float* ln_part; int ln_cap; int ln_nparts;
     int bf16;                            // transposed conv only, when the tile kernel takes the call: 1 = bf16 operands, 2 = split (two bf16 pieces)
+    // LayerNorm of the INPUT applied while it is staged (inference rollouts: the norm's own launch disappears).  x0 then is the RAW tensor
+    // [B][Hin*Win][c0] (all c0 channels are normalised), in_g / in_b the norm's per-element gamma / beta ([Hin*Win][c0], the checkpoint's
+    // flat order), in_part the producer's (count, mean, M2) partials [B][in_np][4].  Served by igemm_small only (igemm_in_ln_ok).
+    const float* in_g; const float* in_b; const float* in_part; int in_np; float in_eps;
 };
 
 // weight gradient of a conv / transposed conv (csrc/igemm_wgrad.hip)
@@ -84,7 +88,9 @@ int repack_transpose(const float* w, float* wt, int taps, int cin, int N, int fl
 int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant = 0, int* ln_nparts = nullptr);  // 0 auto, 1: 4x1 waves, 2: 2x2, 3: 1x4
 int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr);
 int igemm_conv_ksplit(const IgemmDesc& d);   // the K split igemm_conv will use for d (> 1: atomics into a destination the caller must zero)
+int igemm_validate(const IgemmDesc& d, bool lstm);   // argument checks shared by the igemm launchers (igemm_f32.hip)
 int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr);
+bool igemm_in_ln_ok(const IgemmDesc& d);   // can igemm_small apply d.in_g's LayerNorm while staging x0?
 // transposed 3x3 s2 conv, all four output parities per block (csrc/deconv_tile.hip); d validated by igemm_validate
 bool deconv_tile_ok(const IgemmDesc& d);
 int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr, int prec = 0);   // 0 fp32, 1 bf16 operands, 2 split (2 bf16 pieces)

@@ -389,14 +389,27 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     RC(lstm(0, ws + S.cat7 + 32, 64, p->H2, p->W2));
     RC(ln(1, ws + S.h[0], ws + S.n1, n2, 32, 32, 0, np));
     RC(lstm(1, ws + S.n1, 32, p->H2, p->W2));
-    RC(ln(2, ws + S.h[1], ws + S.n2, n2, 32, 32, 0, np));
-    RC(run_conv3x3s2(ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), P(p, p->i_enc_b[1]), ws + S.cat6 + 64, 32, 96, 1, B, p->H2, p->W2, s));
+    // Inference rollouts: hidden2 / hidden4 feed only enc1 / enc2, so their norms are applied while those convs stage their input
+    // (run_conv3x3s2_ln) instead of by a launch of their own; training keeps the materialised tensors (the backward sweep reads them).
+    static const int fold_ln = [] { const char* e = getenv("PIVP_LN_FOLD"); return e ? atoi(e) : 1; }();   // tuning: 0 = always a separate ln_apply
+    if (!train && fold_ln && np > 0 && conv3x3s2_ln_ok(32, 32, B, p->H2, p->W2)) {
+        RC(run_conv3x3s2_ln(ws + S.h[1], 32, P(p, p->i_enc_w[1]), P(p, p->i_enc_b[1]), ws + S.cat6 + 64, 32, 96, 1, B, p->H2, p->W2, s,
+                            P(p, p->i_ln_g[2]), P(p, p->i_ln_b[2]), lnp, np, eps));
+    } else {
+        RC(ln(2, ws + S.h[1], ws + S.n2, n2, 32, 32, 0, np));
+        RC(run_conv3x3s2(ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), P(p, p->i_enc_b[1]), ws + S.cat6 + 64, 32, 96, 1, B, p->H2, p->W2, s));
+    }
     // group 2 (TM:597)
     RC(lstm(2, ws + S.cat6 + 64, 96, p->H4, p->W4));
     RC(ln(3, ws + S.h[2], ws + S.n3, n4, 64, 64, 0, np));
     RC(lstm(3, ws + S.n3, 64, p->H4, p->W4));
-    RC(ln(4, ws + S.h[3], ws + S.n4, n4, 64, 64, 0, np));
-    RC(run_conv3x3s2(ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), P(p, p->i_enc_b[2]), ws + S.e2, 64, 64, 1, B, p->H4, p->W4, s));
+    if (!train && fold_ln && np > 0 && conv3x3s2_ln_ok(64, 64, B, p->H4, p->W4)) {
+        RC(run_conv3x3s2_ln(ws + S.h[3], 64, P(p, p->i_enc_w[2]), P(p, p->i_enc_b[2]), ws + S.e2, 64, 64, 1, B, p->H4, p->W4, s,
+                            P(p, p->i_ln_g[4]), P(p, p->i_ln_b[4]), lnp, np, eps));
+    } else {
+        RC(ln(4, ws + S.h[3], ws + S.n4, n4, 64, 64, 0, np));
+        RC(run_conv3x3s2(ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), P(p, p->i_enc_b[2]), ws + S.e2, 64, 64, 1, B, p->H4, p->W4, s));
+    }
     // group 3 (TM:598) + state predictor (TM:730)
     RC(enc3_state(ws + S.e2, action, state_prev, P(p, p->i_enc_w[3]), P(p, p->i_enc_b[3]), P(p, p->i_cs_w), P(p, p->i_cs_b),
                   ws + S.e3, state_out, B, p->H8 * p->W8, c.use_state, s));
