@@ -415,6 +415,8 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
                   ws + S.e3, state_out, B, p->H8 * p->W8, c.use_state, s));
     // group 4 (TM:599)
     RC(lstm(4, ws + S.e3, 64, p->H8, p->W8));
+    // (hidden5's norm was folded the same way into enc4's four-phase form and the motion head's Linear, which then has to run here, in front
+    // of lstm6: the two consumers lost more than the launch saves, rollout 8.52 -> 8.60 ms.  It keeps its own launch.)
     RC(ln(5, ws + S.h[4], ws + S.n5, n8, 128, 128, 0, np));
     RC(run_deconv3x3s2(ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), P(p, p->i_enc_b[4]), ws + S.e4, 128, 128, 1, B, p->H8, p->W8, s, 0,
                        nullptr, 0, nullptr, p->bf16_all ? 1 : p->lstm_planes == 2 ? 2 : 0));
@@ -884,6 +886,18 @@ extern "C" long long pivp_get_tap(pivp_plan_t* plan, const char* name, int step,
         int rc = ln_apply(ws + S.e6raw, ws + S.lnstat + (size_t)8 * B * 2, P(plan, plan->i_ln_g[8]), P(plan, plan->i_ln_b[8]),
                           ws + S.e6, B, 64 * HW, 64, 64, c.ln_eps, 1, s, nullptr, -1);
         if (rc != PIVP_OK) return rc;
+    }
+    if (!c.keep_activations) {
+        // inference applies the norms of hidden2 / hidden4 inside their consumers (run_step): rebuild the tensor on request from
+        // the raw ConvLSTM output (statistics recomputed by ln_stats: equal to the fused ones up to fp32 summation order)
+        struct F { const char* n; int layer, norm; size_t dst; int C, hw; };
+        const F folded[] = {{"hidden2", 1, 2, S.n2, 32, HW2}, {"hidden4", 3, 4, S.n4, 64, HW4}};
+        for (const F& f : folded)
+            if (strcmp(f.n, name) == 0) {
+                int rc = run_layernorm(ws + S.h[f.layer], P(plan, plan->i_ln_g[f.norm]), P(plan, plan->i_ln_b[f.norm]), ws + f.dst,
+                                       ws + plan->o_lnpart, B, f.C * f.hw, f.C, f.C, c.ln_eps, 0, s, nullptr, 0);
+                if (rc != PIVP_OK) return rc;
+            }
     }
     for (const T& t : taps) {
         if (strcmp(t.n, name) == 0) {

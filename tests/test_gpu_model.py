@@ -155,6 +155,20 @@ def test_use_state_false_and_keep_activations(pivp):
             assert np.abs(got - ref.taps[step][tap]).max() < 5e-4, (step, tap)
 
 
+def test_inference_taps_of_norms_applied_inside_their_consumers(pivp):
+    # an inference plan applies norm(hidden2) / norm(hidden4) while enc1 / enc2 stage their input (run_conv3x3s2_ln: no ln_apply launch,
+    # the normalised tensor is never written); enc1 / enc2 must equal the oracle's, and tap() rebuilds hidden2 / hidden4 on request
+    P = R.init_params(seed=3, dtype=np.float32, scale=1.0)
+    imgs, acts, stas = R.synthetic_batch(2, 4)
+    ref = R.Model(10, params=P, dtype=np.float64, prefix='x'); ref.train = False
+    ref([imgs, acts, stas], 0, tap_steps=(2,))
+    m, loss, gen = _run(pivp, 'CDNA', 10, imgs, acts, stas, P)              # keep_activations = False
+    assert R.per_pixel_l2(gen, np.stack(ref.gen_images)).max() < GATE
+    for tap in ('enc1', 'enc2', 'hidden2', 'hidden4', 'hidden5'):
+        got = m.tap(tap).cpu().numpy()
+        assert np.abs(got - ref.taps[2][tap]).max() < 5e-4, tap
+
+
 def test_batch32_properties(pivp):
     """Full-size batch (config 2: B=32, T=10): size-independent properties instead of the slow oracle.
     (a) samples are independent: rows of a B=32 run equal the same sequences run as B=2;
