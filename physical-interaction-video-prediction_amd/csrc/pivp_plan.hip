@@ -444,7 +444,8 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     }
     // (The motion head's generator needs hidden5 only and could run on the side stream under lstm6 .. heads: measured, the rollout got
     // SLOWER, 8.68 -> 8.79 ms: the co-running kernels cost the ConvLSTMs more than the 16 us they hide; again with the ConvLSTM waves at
-    // priority 3 and the generator at 0: 8.57 -> 8.67 / 8.73 ms.  It stays in line.)
+    // priority 3 and the generator at 0: 8.57 -> 8.67 / 8.73 ms; and forked only behind norm(hidden7), i.e. beside enc6 and the heads kernel,
+    // no ConvLSTM: 8.60 -> 8.68 / 8.69 ms -- a cross-stream event pair per timestep costs more than the 16 us.  It stays in line.)
     const float* aux = nullptr;
     if (c.model_type == PIVP_MODEL_CDNA) {
         RC(cdna_kernels(ws + S.n5, P(p, p->i_head_w), P(p, p->i_head_b), ws + p->o_linpart, ws + S.kerns, B, p->K5, c.num_masks, s,
