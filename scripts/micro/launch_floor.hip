@@ -30,5 +30,34 @@ int main() {
         printf("%s: graph launch     %.2f us per kernel\n", mode ? "small" : "empty", ms * 1e3 / N);
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     }
+    // what a fork costs the stream it forks FROM: the same chain of small kernels with (a) an event record after every kernel, (b) the
+    // record + a wait on a second stream + a kernel there (the side-stream pattern of the backward sweep), (c) additionally the main stream
+    // waiting for the side stream's `done` event of two launches ago
+    {
+        hipStream_t side; CK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        const int M = 500;
+        hipEvent_t ready[M], done[M];
+        for (int i = 0; i < M; ++i) { CK(hipEventCreateWithFlags(&ready[i], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming)); }
+        for (int mode = 0; mode < 4; ++mode) {
+            auto chain = [&]() {
+                for (int i = 0; i < M; ++i) {
+                    hipLaunchKernelGGL(small_kernel, dim3(32), dim3(256), 0, s, buf, i);
+                    if (mode >= 1) (void)hipEventRecord(ready[i], s);
+                    if (mode >= 2) {
+                        (void)hipStreamWaitEvent(side, ready[i], 0);
+                        hipLaunchKernelGGL(small_kernel, dim3(32), dim3(256), 0, side, buf + 65536, i);
+                        (void)hipEventRecord(done[i], side);
+                    }
+                    if (mode >= 3 && i >= 2) (void)hipStreamWaitEvent(s, done[i - 2], 0);
+                }
+            };
+            chain(); CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(side));
+            float ms = 0;
+            CK(hipEventRecord(e0, s)); chain(); CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(side));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const char* what[] = {"kernels only", "+ event record after each", "+ side stream waits, runs a kernel, records", "+ main waits for the side's event of two launches ago"};
+            printf("fork cost, main stream: %-55s %.2f us per kernel\n", what[mode], ms * 1e3 / M);
+        }
+    }
     return 0;
 }
