@@ -144,6 +144,15 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    // Bias gradient = column sums of dY, on the side: the dY values a wave feeds its MFMAs pass through its registers anyway.  A conv's
+    // dY tile is the same for all taps: the blocks of tap 0 / channel block 0 see every dY pixel of their slice once.  The transposed conv
+    // gathers dY at 2a - 1 + k: taps (1,1), (1,2), (2,1), (2,2) visit each of the four output parities exactly once and never leave the
+    // map.  (A bias_grad_kernel launch per conv and timestep before: 44 launches per train step.)
+    const bool do_bias = d.db != nullptr && cb == 0 && wm == 0 &&
+                         (d.deconv ? (tap == 4 || tap == 5 || tap == 7 || tap == 8) : tap == 0);
+    float bsum[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bsum[t] = 0.f;
     if (c_begin < c_end) {
         using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
         auto mma = [&](int buf) {
@@ -153,8 +162,11 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
             for (int k = 0; k < WG_PIX; k += 2) {
                 const float a = X[(k + half) * WG_XP];
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Y[(k + half) * WG_YP + 32 * t], acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) {
+                    const float yv = Y[(k + half) * WG_YP + 32 * t];
+                    bsum[t] += yv;
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, yv, acc[t], 0, 0, 0);
+                }
             }
         };
         issue(S0{}, c_begin);
@@ -173,6 +185,14 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
             __syncthreads();
         }
         if (c < c_end) mma(0);
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float v = bsum[t] + __shfl_xor(bsum[t], 32, 64);
+            const int n = n0 + wn * 32 * NT + t * 32 + l31;
+            if (half == 0 && n < d.N) atomicAdd(d.db + n, v);
+        }
     }
     // acc[t][r]: row i = ci (= (r&3) + 8*(r>>2) + 4*half), column j = n (= l31)
     if (d.part) {      // this block's own [64][WG_N] slot: plain read-modify-write, rows of 32 lanes are 128 contiguous bytes
@@ -523,8 +543,13 @@ int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done) {
     }
     int wg_n, tiles, nsplit;
     generic_grid(d, wg_n, tiles, nsplit);
-    if (wg_n == 64) hipLaunchKernelGGL(igemm_wgrad_kernel<1>, dim3(tiles, nsplit), dim3(256), 0, s, d);
-    else hipLaunchKernelGGL(igemm_wgrad_kernel<2>, dim3(tiles, nsplit), dim3(256), 0, s, d);
+    // the column sums ride along when the tap set qualifies: a 3x3 conv, or the transposed 3x3 s2 conv (see the kernel)
+    const bool bias_here = d.db && d.ksize == 3 && (!d.deconv || (d.Hy == 2 * d.Hx && d.Wy == 2 * d.Wx));
+    WgradDesc dd = d;
+    if (!bias_here) dd.db = nullptr;
+    if (bias_done) *bias_done = bias_here ? 1 : 0;
+    if (wg_n == 64) hipLaunchKernelGGL(igemm_wgrad_kernel<1>, dim3(tiles, nsplit), dim3(256), 0, s, dd);
+    else hipLaunchKernelGGL(igemm_wgrad_kernel<2>, dim3(tiles, nsplit), dim3(256), 0, s, dd);
     return PIVP_LAUNCH_STATUS();
 }
 

@@ -288,11 +288,11 @@ int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w
                   : run_deconv3x3s2(dy, cout, ldy, wt, nullptr, dx, cin, lddx, 0, B, Hout, Wout, s, accum_dx);
         if (rc != PIVP_OK) return rc;
     }
-    rc = run_wgrad(mode, x, cin, ldx, nullptr, 0, 0, cin, dy, ldy, cout, dW, B, Hin, Win, Hout, Wout, 3, 1, 2, sw, nullptr, nullptr, 0,
+    int bias_done = 0;     // the weight-gradient kernel sums dY's columns on the side when it can
+    rc = run_wgrad(mode, x, cin, ldx, nullptr, 0, 0, cin, dy, ldy, cout, dW, B, Hin, Win, Hout, Wout, 3, 1, 2, sw, db, &bias_done, 0,
                    1, 0, 0, 0, part, desc_out);
     if (rc != PIVP_OK) return rc;
-    rc = bias_grad(dy, ldy, cout, B * Hout * Wout, db, sw);
-    if (rc != PIVP_OK) return rc;
+    if (!bias_done) { rc = bias_grad(dy, ldy, cout, B * Hout * Wout, db, sw); if (rc != PIVP_OK) return rc; }
     return fork_end(fork);
 }
 
