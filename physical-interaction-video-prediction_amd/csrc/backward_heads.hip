@@ -41,8 +41,11 @@ static int composite_bwd_rows(int W) {
     return W <= 64 ? 8 : 4;
 }
 
+// threads per block: two waves per SIMD (the kernel is a chain of LDS-fed FMA loops; with 256 threads a CU's one block left every wait exposed)
+constexpr int CBC_NT = 512;
+
 template <int CB_TR>
-__global__ __launch_bounds__(256) void composite_bwd_cdna_kernel(const float* __restrict__ prev, const float* __restrict__ logits,
+__global__ __launch_bounds__(CBC_NT) void composite_bwd_cdna_kernel(const float* __restrict__ prev, const float* __restrict__ logits,
                                                                  const float* __restrict__ layer0, const float* __restrict__ kerns,
                                                                  const float* __restrict__ go, float* __restrict__ dmk,
                                                                  float* __restrict__ dz, float* __restrict__ dkpart,
@@ -70,6 +73,7 @@ __global__ __launch_bounds__(256) void composite_bwd_cdna_kernel(const float* __
     // independent loads in flight per thread (the flat-index loops of the first version made one L2 round trip per element)
     const unsigned magic = 0xFFFFFFFFu / (unsigned)NP + 1u;
     auto div_np = [&](int x) { return (int)__umulhi((unsigned)x, magic); };
+    if (tid < 256)
     for (int m = 0; m < NP; ++m) {
         const int F0 = m * HW + ep0 - (NP - 1);
         for (int j0 = tid; j0 < win; j0 += 1024) {
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(256) void composite_bwd_cdna_kernel(const float* __
             }
     }
     const float* gb = go + (size_t)b * 3 * HW;
+    if (tid < 256)
 #pragma unroll
     for (int c = 0; c < 3; ++c)
         for (int p0_ = tid; p0_ < enp; p0_ += 1024) {
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256) void composite_bwd_cdna_kernel(const float* __
         }
     if (tid < NM * 25) kl[tid] = kerns[(size_t)b * NM * 25 + tid];
     __syncthreads();
-    for (int i = tid; i < NP * G; i += 256) {
+    for (int i = tid; i < NP * G; i += CBC_NT) {
         const int m = i / G, gi = i - m * G;
         const int gfirst = div_np(m * HW + ep0), glast = div_np(m * HW + ep0 + enp - 1);
         if (gfirst + gi <= glast) {
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256) void composite_bwd_cdna_kernel(const float* __
     __syncthreads();
     for (int m = 0; m < NP; ++m) {
         const int gbase = div_np(m * HW + ep0);
-        for (int pp = tid; pp < enp; pp += 256) {
+        for (int pp = tid; pp < enp; pp += CBC_NT) {
             const int gi = div_np(m * HW + ep0 + pp) - gbase;
             mkx[m * PR * W + pp] = __expf(lg[m * win + pp + (NP - 1)] - gmx[m * G + gi]) * ginv[m * G + gi];
         }
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void composite_bwd_cdna_kernel(const float* __
     const int toff = (y0 - ey0) * W;             // tile offset inside the extended arrays
     const int np = rows * W;
     // ---- per-pixel gradients of the masks and of enc7 ----
-    for (int pp = tid; pp < np; pp += 256) {
+    for (int pp = tid; pp < np; pp += CBC_NT) {
         const int p = y0 * W + pp, y = p / W, x = p - y * W, ry = y - y0;
         const float g0 = gox[0 * PR * W + toff + pp], g1 = gox[1 * PR * W + toff + pp], g2 = gox[2 * PR * W + toff + pp];
         const float* p0 = prevt + (0 * PR + ry) * PW + x;
@@ -173,9 +178,11 @@ __global__ __launch_bounds__(256) void composite_bwd_cdna_kernel(const float* __
     // tap ij) forms the go*prev product ONCE per pixel and feeds all NK kernels (9 accumulators); the 8 rows are summed
     // through LDS.  (One thread per (k, ij) walking all 512 pixels redid the product per kernel: 3.6k LDS reads per thread.)
     __syncthreads();                                   // lg (the logits window) is dead: reuse it for the row partials
-    float* red = lg;                                   // [CB_TR][256]
-    if (tid < CB_TR * 25) {
-        const int ry = tid / 25, ij = tid - ry * 25, i = ij / 5, j = ij - i * 5;
+    float* red = lg;                                   // [CBC_NT / 256][CB_TR][256]: one image per half of the row (threads 256.. take x >= W / 2)
+    const int xh = tid >> 8, t8 = tid & 255;
+    const int xa = (W * xh) / (CBC_NT / 256), xb = (W * (xh + 1)) / (CBC_NT / 256);
+    if (t8 < CB_TR * 25) {
+        const int ry = t8 / 25, ij = t8 - ry * 25, i = ij / 5, j = ij - i * 5;
         float acc[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) acc[k] = 0.f;
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(256) void composite_bwd_cdna_kernel(const float* __
             const float* q2 = prevt + (2 * PR + ry + i) * PW + j;
             const float* mrow = mkx + 2 * PR * W + toff + ry * W;
 #pragma unroll 2
-            for (int x = 0; x < W; ++x) {
+            for (int x = xa; x < xb; ++x) {
                 const float v = g0r[x] * q0[x] + g0r[PR * W + x] * q1[x] + g0r[2 * PR * W + x] * q2[x];
 #pragma unroll
                 for (int k = 0; k < 9; ++k)
@@ -194,20 +201,20 @@ __global__ __launch_bounds__(256) void composite_bwd_cdna_kernel(const float* __
             }
         }
 #pragma unroll
-        for (int k = 0; k < 9; ++k) red[ry * 256 + k * 25 + ij] = acc[k];
+        for (int k = 0; k < 9; ++k) red[(xh * CB_TR + ry) * 256 + k * 25 + ij] = acc[k];
     }
     __syncthreads();
     {
         float acc = 0.f;
         if (tid < NK * 25) {
 #pragma unroll
-            for (int r = 0; r < CB_TR; ++r) acc += red[r * 256 + tid];
+            for (int r = 0; r < CB_TR * (CBC_NT / 256); ++r) acc += red[r * 256 + tid];
         }
-        dkpart[((size_t)b * gridDim.x + blockIdx.x) * 256 + tid] = acc;
+        if (tid < 256) dkpart[((size_t)b * gridDim.x + blockIdx.x) * 256 + tid] = acc;
     }
     // ---- gradient w.r.t. the previous frame (feed-self only) ----
     if (dprev) {
-        for (int pp = tid; pp < np; pp += 256) {
+        for (int pp = tid; pp < np; pp += CBC_NT) {
             const int p = y0 * W + pp, y = p / W, x = p - y * W;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
@@ -245,11 +252,11 @@ int composite_bwd_cdna(const float* prev, const float* logits, const float* laye
     PIVP_CHECK_ARG(lds <= 160 * 1024 && W + 4 <= 256 && NM * 25 <= 256);
     if (CB_TR == 8) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_cdna_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(composite_bwd_cdna_kernel<8>, dim3(composite_bwd_tiles(H, W), B), dim3(256), lds, s, prev, logits, layer0, kerns, go,
+        hipLaunchKernelGGL(composite_bwd_cdna_kernel<8>, dim3(composite_bwd_tiles(H, W), B), dim3(CBC_NT), lds, s, prev, logits, layer0, kerns, go,
                            dmk, dz, dkpart, dprev, dprev_accum, H, W, NM);
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_cdna_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(composite_bwd_cdna_kernel<4>, dim3(composite_bwd_tiles(H, W), B), dim3(256), lds, s, prev, logits, layer0, kerns, go,
+        hipLaunchKernelGGL(composite_bwd_cdna_kernel<4>, dim3(composite_bwd_tiles(H, W), B), dim3(CBC_NT), lds, s, prev, logits, layer0, kerns, go,
                            dmk, dz, dkpart, dprev, dprev_accum, H, W, NM);
     }
     return PIVP_LAUNCH_STATUS();
