@@ -178,8 +178,9 @@ __global__ __launch_bounds__(CBC_NT) void composite_bwd_cdna_kernel(const float*
     // ---- kernel gradient partials: dK[k][ij] = sum_pixels mk[k+2] * (sum_c go[c] * prev[c](+ij)).  Thread (row of the tile,
     // tap ij) forms the go*prev product ONCE per pixel and feeds all NK kernels (9 accumulators); the 8 rows are summed
     // through LDS.  (One thread per (k, ij) walking all 512 pixels redid the product per kernel: 3.6k LDS reads per thread.)
-    __syncthreads();                                   // lg (the logits window) is dead: reuse it for the row partials
-    float* red = lg;                                   // [CBC_NT / 256][CB_TR][256]: one image per half of the row (threads 256.. take x >= W / 2)
+    // [CBC_NT / 256][CB_TR][256]: one image per quarter of the row.  Its own LDS region: the logits window it used to overlay (lg) is only
+    // NP * win floats, smaller than this for num_masks < 10 (with 1024 threads the overlay ran into the masks: test_bptt_gradients_cdna_four_masks)
+    float* red = kl + ((NM * 25 + 3) & ~3);
     const int xh = tid >> 8, t8 = tid & 255;
     const int xa = (W * xh) / (CBC_NT / 256), xb = (W * (xh + 1)) / (CBC_NT / 256);
     if (t8 < CB_TR * 25) {
@@ -249,7 +250,8 @@ int composite_bwd_cdna(const float* prev, const float* logits, const float* laye
     const int CB_TR = composite_bwd_rows(W);
     const int NP = NM + 1, PR = CB_TR + 4;
     const int enp = PR * W, win = enp + 2 * (NP - 1), G = enp / NP + 2;
-    const size_t lds = sizeof(float) * ((size_t)NP * win + 2 * NP * G + (size_t)NP * PR * W + 3 * PR * W + 3 * PR * (W + 4) + NM * 25);
+    const size_t lds = sizeof(float) * ((size_t)NP * win + 2 * NP * G + (size_t)NP * PR * W + 3 * PR * W + 3 * PR * (W + 4) + ((NM * 25 + 3) & ~3) +
+                                        (size_t)CB_TR * CBC_NT);      // ... + the kernel-gradient row partials
     PIVP_CHECK_ARG(lds <= 160 * 1024 && W + 4 <= 256 && NM * 25 <= 256);
     if (CB_TR == 8) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_cdna_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

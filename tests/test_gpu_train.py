@@ -177,7 +177,21 @@ def test_bptt_gradients_cdna_four_masks(pivp):
     loss = float(m([imgs, acts, stas], 0))
     m.cleargrads(); m.backward()
     assert abs(loss - loss_ref) < 1e-6
-    _check_grads(m.grads_reference(), gref, 2e-3)
+    got = m.grads_reference()
+    _check_grads(got, gref, 2e-3)
+    # The state predictor's gradients are tiny (the state cost is weighted 1e-4) and sit behind the kernel-gradient partials of the composite
+    # backward: an LDS overlay that was too small for num_masks < 10 once made them wander 0.1-0.7 % from run to run, inside the bound above.
+    # They have no ReLU in front of them: hold them (and the run-to-run spread of every tensor) to fp32 accuracy.
+    for k in ('current_state/W', 'current_state/b', 'enc3/W'):
+        rel = np.linalg.norm(got[k].astype(np.float64) - gref[k]) / np.linalg.norm(gref[k])
+        assert rel < 2e-5, (k, rel)
+    m2 = pivp.Model(4, prefix='t', keep_activations=True)
+    m2.load_state_dict_reference(P)
+    m2([imgs, acts, stas], 0); m2.cleargrads(); m2.backward()
+    again = m2.grads_reference()
+    for k, v in got.items():
+        spread = np.linalg.norm(again[k].astype(np.float64) - v) / (np.linalg.norm(v) + 1e-30)
+        assert spread < 2e-5, (k, spread)
 
 
 def test_gradient_groups_are_final_when_announced(pivp):
