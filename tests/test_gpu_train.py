@@ -354,7 +354,7 @@ def test_config2_batch32_gradients_match_golden(pivp):
         rel = np.linalg.norm(val - ref) / (np.linalg.norm(ref) + 1e-30)
         nrm = abs(np.linalg.norm(f) - float(g['norm:' + key])) / (float(g['norm:' + key]) + 1e-30)
         worst = max(worst, (max(rel, nrm), k))
-        assert rel < 2e-3, '%s: relative L2 error of the sampled entries %.3e' % (k, rel)
-        assert nrm < 1e-3, '%s: gradient norm off by %.3e' % (k, nrm)
+        assert rel < 5e-4, '%s: relative L2 error of the sampled entries %.3e' % (k, rel)       # measured worst: 9.4e-5 (lstm3/conv/W)
+        assert nrm < 2e-4, '%s: gradient norm off by %.3e' % (k, nrm)
         assert abs(f.sum() - float(g['sum:' + key])) < 2e-3 * float(g['norm:' + key]) * np.sqrt(f.size) + 1e-9, k
     print('config 2 (B=32) gradients: worst tensor %s, relative error %.2e' % (worst[1], worst[0]))
