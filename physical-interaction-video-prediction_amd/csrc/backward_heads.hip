@@ -668,15 +668,19 @@ int cdna_kernels_bwd(const float* hidden5, const float* wt, const float* vpre, c
 //   d prev (feed-self): mk0*go plus the bilinear weights scattered to the 4 neighbours (atomics into a buffer the caller has
 //            initialised with the loss term)
 // ------------------------------------------------------------------------------------------
+// threads per block: one pixel per thread on 8 x 64 tiles, two waves per SIMD (256 threads: 224 us per launch at B = 32)
+constexpr int CBS_NT = 512;
+constexpr int CBS_R = 12;        // rows above / below the tile held in the LDS window of d prev
+
 template <int CB_TR>
-__global__ __launch_bounds__(256) void composite_bwd_stp_kernel(const float* __restrict__ prev, const float* __restrict__ logits,
+__global__ __launch_bounds__(CBS_NT) void composite_bwd_stp_kernel(const float* __restrict__ prev, const float* __restrict__ logits,
                                                                 const float* __restrict__ layer0, const float* __restrict__ theta,
                                                                 const float* __restrict__ go, float* __restrict__ dmk, float* __restrict__ dz,
                                                                 float* __restrict__ dthpart, float* __restrict__ dprev,
                                                                 int H, int W, int NM, int stp_zero) {
     PIVP_SET_MAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ float red[4][6];
+    __shared__ float red[CBS_NT / 64][6];
     const int NP = NM + 1, HW = H * W;
     const int b = blockIdx.y, y0 = blockIdx.x * CB_TR;
     const int rows = min(CB_TR, H - y0);
@@ -685,17 +689,24 @@ __global__ __launch_bounds__(256) void composite_bwd_stp_kernel(const float* __r
     float* lg = sm;                      // [NP][win]
     float* gmx = lg + NP * win;          // [NP][G]
     float* ginv = gmx + NP * G;          // [NP][G]
+    float* dwin = ginv + NP * G;         // [3][WR][W]  this block's window of d prev (feed-self only)
+    constexpr int WR = CB_TR + 2 * CBS_R;
+    const int wy0 = y0 - CBS_R;
     const int tid = threadIdx.x;
+    if (dprev)
+        for (int i = tid; i < 3 * WR * W; i += CBS_NT) dwin[i] = 0.f;
     const float* lgb = logits + (size_t)b * NP * HW;
-    for (int i = tid; i < NP * win; i += 256) {
+    const unsigned magic = 0xFFFFFFFFu / (unsigned)NP + 1u;        // exact x / NP for x * NP < 2^32 (as in composite_bwd_cdna_kernel)
+    auto div_np = [&](int x) { return (int)__umulhi((unsigned)x, magic); };
+    for (int i = tid; i < NP * win; i += CBS_NT) {
         const int m = i / win, j = i - m * win;
         const int F = m * HW + p0 - (NP - 1) + j;
         lg[i] = (F >= 0 && F < NP * HW) ? lgb[F] : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < NP * G; i += 256) {
+    for (int i = tid; i < NP * G; i += CBS_NT) {
         const int m = i / G, gi = i - m * G;
-        const int gfirst = (m * HW + p0) / NP, glast = (m * HW + p0 + np - 1) / NP;
+        const int gfirst = div_np(m * HW + p0), glast = div_np(m * HW + p0 + np - 1);
         if (gfirst + gi <= glast) {
             const float* e = lg + m * win + (gfirst + gi) * NP - (m * HW + p0 - (NP - 1));
             float mx = e[0];
@@ -709,11 +720,11 @@ __global__ __launch_bounds__(256) void composite_bwd_stp_kernel(const float* __r
     const float* th = theta + (size_t)b * 6;
     const float* pb = prev + (size_t)b * 3 * HW;
     float dth[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int pp = tid; pp < np; pp += 256) {
+    for (int pp = tid; pp < np; pp += CBS_NT) {
         const int p = p0 + pp, y = p / W, x = p - y * W;
         float mk0 = 0.f, mk1 = 0.f, msum = 0.f;
         for (int m = 0; m < NP; ++m) {
-            const int gi = (m * HW + p) / NP - (m * HW + p0) / NP;
+            const int gi = div_np(m * HW + p) - div_np(m * HW + p0);
             const float v = expf(lg[m * win + pp + (NP - 1)] - gmx[m * G + gi]) * ginv[m * G + gi];
             if (m == 0) mk0 = v; else if (m == 1) mk1 = v; else msum += v;
         }
@@ -751,15 +762,22 @@ __global__ __launch_bounds__(256) void composite_bwd_stp_kernel(const float* __r
             du = fmaf(dw, (1.f - wv1) * (nb[0][1] - nb[0][0]) + wv1 * (nb[1][1] - nb[1][0]), du);
             dvv = fmaf(dw, (1.f - wu1) * (nb[1][0] - nb[0][0]) + wu1 * (nb[1][1] - nb[0][1]), dvv);
             if (dprev) {
+                // scatter into the block's LDS window of d prev (rows wy0 .. wy0 + WR - 1: the tile's own rows +- CBS_R, where a near-identity
+                // warp lands); targets outside it go straight to memory.  Straight global atomics for everything cost 215 of this kernel's
+                // 231 us: neighbouring pixels' bilinear footprints overlap, so the lanes of one instruction hit the same addresses.
                 float* dp = dprev + ((size_t)b * 3 + c) * HW;
-                atomicAdd(dp + p, mk0 * g);
+                float* dwc = dwin + c * WR * W;
+                atomicAdd(dwc + (y - wy0) * W + x, mk0 * g);
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const int uu = iu + e, vv = iv + a;
-                        if ((unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H)
-                            atomicAdd(dp + vv * W + uu, dw * (a ? wv1 : 1.f - wv1) * (e ? wu1 : 1.f - wu1));
+                        if ((unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H) {
+                            const float val = dw * (a ? wv1 : 1.f - wv1) * (e ? wu1 : 1.f - wu1);
+                            if ((unsigned)(vv - wy0) < (unsigned)WR) atomicAdd(dwc + (vv - wy0) * W + uu, val);
+                            else atomicAdd(dp + vv * W + uu, val);
+                        }
                     }
             }
         }
@@ -774,7 +792,18 @@ __global__ __launch_bounds__(256) void composite_bwd_stp_kernel(const float* __r
     for (int j = 0; j < 6; ++j) dth[j] = wave_sum(dth[j]);
     if ((tid & 63) == 0) for (int j = 0; j < 6; ++j) red[tid >> 6][j] = dth[j];
     __syncthreads();
-    if (tid < 6) dthpart[((size_t)b * gridDim.x + blockIdx.x) * 8 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (dprev)          // the window's touched elements, one atomic each (other tiles' windows overlap this one)
+        for (int i = tid; i < 3 * WR * W; i += CBS_NT) {
+            const float v = dwin[i];
+            const int c = i / (WR * W), rem = i - c * (WR * W), r = rem / W, xx = rem - r * W, yy = wy0 + r;
+            if (v != 0.f && (unsigned)yy < (unsigned)H) atomicAdd(dprev + ((size_t)b * 3 + c) * HW + yy * W + xx, v);
+        }
+    if (tid < 6) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < CBS_NT / 64; ++w) v += red[w][tid];
+        dthpart[((size_t)b * gridDim.x + blockIdx.x) * 8 + tid] = v;
+    }
 }
 
 int composite_bwd_stp(const float* prev, const float* logits, const float* layer0, const float* theta, const float* go,
@@ -782,15 +811,15 @@ int composite_bwd_stp(const float* prev, const float* logits, const float* layer
     PIVP_CHECK_ARG(prev && logits && layer0 && theta && go && dmk && dz && dthpart && B > 0 && H > 1 && W > 1 && NM >= 2 && NM <= 10);
     const int CB_TR = composite_bwd_rows(W);
     const int NP = NM + 1, np = CB_TR * W, win = np + 2 * (NP - 1), G = np / NP + 2;
-    const size_t lds = sizeof(float) * ((size_t)NP * win + 2 * NP * G);
-    PIVP_CHECK_ARG(lds <= 96 * 1024);
+    const size_t lds = sizeof(float) * ((size_t)NP * win + 2 * NP * G + 3 * (size_t)(CB_TR + 2 * CBS_R) * W);
+    PIVP_CHECK_ARG(lds <= 150 * 1024);
     if (CB_TR == 8) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_stp_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(composite_bwd_stp_kernel<8>, dim3(composite_bwd_tiles(H, W), B), dim3(256), lds, s, prev, logits, layer0, theta, go, dmk,
+        hipLaunchKernelGGL(composite_bwd_stp_kernel<8>, dim3(composite_bwd_tiles(H, W), B), dim3(CBS_NT), lds, s, prev, logits, layer0, theta, go, dmk,
                            dz, dthpart, dprev, H, W, NM, stp_zero);
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_stp_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(composite_bwd_stp_kernel<4>, dim3(composite_bwd_tiles(H, W), B), dim3(256), lds, s, prev, logits, layer0, theta, go, dmk,
+        hipLaunchKernelGGL(composite_bwd_stp_kernel<4>, dim3(composite_bwd_tiles(H, W), B), dim3(CBS_NT), lds, s, prev, logits, layer0, theta, go, dmk,
                            dz, dthpart, dprev, H, W, NM, stp_zero);
     }
     return PIVP_LAUNCH_STATUS();
