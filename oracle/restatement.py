@@ -278,6 +278,43 @@ def smooth_batch(batch, seq_len=10, height=64, width=64, seed=0, dtype=np.float3
     return images, actions, states
 
 
+def moving_batch(batch, seq_len=10, height=64, width=64, seed=0, dtype=np.float32, box=9, margin=24):
+    """Synthetic VIDEO: per sequence one smooth random scene (box-blurred noise, stretched to [0, 1]) seen through a window that
+    drifts with a per-sequence velocity of up to 2 pixels a step (sub-pixel positions, bilinear crop) plus a little per-step jitter.
+    `actions[t] = [vx, vy, 0, 0, 0] / 4` is the displacement between frame t and t+1, `states[t] = [px, py, 0, 0, 0] / 16` the window
+    position: the roles the gripper command and pose play in the reference's data (make_dataset.py:111-124).  Unlike `smooth_batch`
+    the frames of a sequence are predictable from the past, so a model TRAINED on it predicts motion (tests/golden/train_weights.py:
+    the trained-weight fixtures)."""
+    rs = np.random.RandomState(seed)
+    Hs, Ws = height + 2 * margin, width + 2 * margin
+    r = box // 2
+    noise = rs.random_sample((batch, 3, Hs + 2 * r, Ws + 2 * r))
+    scene = sliding_window_view(noise, (box, box), axis=(2, 3)).mean(axis=(-1, -2))
+    lo = scene.min(axis=(1, 2, 3), keepdims=True); hi = scene.max(axis=(1, 2, 3), keepdims=True)
+    scene = (scene - lo) / (hi - lo)
+    vel = rs.uniform(-2.0, 2.0, size=(batch, 2))
+    jit = 0.15 * rs.standard_normal((seq_len, batch, 2))
+    pos = np.zeros((seq_len, batch, 2)); v = np.zeros((seq_len, batch, 2))
+    p = np.full((batch, 2), float(margin))
+    for t in range(seq_len):
+        pos[t] = p
+        v[t] = vel + jit[t]
+        p = np.clip(p + v[t], 1.0, 2.0 * margin - 2.0)
+    v[:-1] = pos[1:] - pos[:-1]                                    # the displacement actually applied (after clipping)
+    images = np.empty((seq_len, batch, 3, height, width))
+    for t in range(seq_len):
+        for b in range(batch):
+            x0, y0 = int(np.floor(pos[t, b, 0])), int(np.floor(pos[t, b, 1]))
+            fx, fy = pos[t, b, 0] - x0, pos[t, b, 1] - y0
+            s = scene[b]
+            images[t, b] = ((1 - fy) * (1 - fx) * s[:, y0:y0 + height, x0:x0 + width] + (1 - fy) * fx * s[:, y0:y0 + height, x0 + 1:x0 + 1 + width]
+                            + fy * (1 - fx) * s[:, y0 + 1:y0 + 1 + height, x0:x0 + width] + fy * fx * s[:, y0 + 1:y0 + 1 + height, x0 + 1:x0 + 1 + width])
+    actions = np.zeros((seq_len, batch, 5)); states = np.zeros((seq_len, batch, 5))
+    actions[:, :, :2] = v / 4.0
+    states[:, :, :2] = (pos - margin) / 16.0
+    return images.astype(dtype), actions.astype(dtype), states.astype(dtype)
+
+
 def concat_examples(batch):
     """TM:51-71: list of (imgs (T,H,W,3), act (T,5), sta (T,5)) -> time-major (T,B,3,H,W), (T,B,5), (T,B,5)."""
     img = np.array([b[0] for b in batch])
