@@ -91,31 +91,52 @@ def build_parser():
     return ap
 
 
-def _free_port():
-    import socket
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        return s.getsockname()[1]
+RENDEZVOUS_TIMEOUT_S = 120     # init_process_group / first collective: a hung RCCL bootstrap must end the run, not burn the box's lease
+
+
+def _launch_timeout(args):
+    """Wall-clock bound of the whole N-rank child (PIVP_BENCH_TIMEOUT overrides): imports + rendezvous + every leg of the run.
+    The default run is ~1 min per rank set on an MI355X; the bound is generous and only there so that a hang exits non-zero."""
+    env = os.environ.get('PIVP_BENCH_TIMEOUT')
+    if env:
+        return float(env)
+    return 600.0 + 4.0 * (args.steps + args.warmup) * max(1.0, (args.size / 64.0) ** 2 * args.seq_len / 10.0 * args.batch / 32.0)
 
 
 def launch_ranks(args, argv):
     """--gpus N > 1 without a launcher around us: start the N ranks as a child process tree.  Nothing in this process has touched
-    the GPU (torch is not even imported yet), and the child is started with subprocess, never exec'd over us."""
+    the GPU (torch is not even imported yet), and the child is started with subprocess, never exec'd over us.  torchrun picks the
+    rendezvous port itself (--standalone: a c10d store on a free port; no window in which another job can take a port we chose),
+    the child is bounded in time, and every failure ends in a non-zero exit code with a one-line reason."""
+    import signal
     import subprocess
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')    # the host driver only supports dmabuf IPC (RCCL needs it)
-    env.setdefault('OMP_NUM_THREADS', '8')
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))   # the ranks share the host's cores
+    limit = _launch_timeout(args)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        stdout, _ = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)          # the process group we started (torchrun + its ranks), nothing else
+        except OSError:
+            pass
+        stdout, _ = proc.communicate()
+        sys.stderr.write((stdout or '')[-4000:])
+        sys.stderr.write('bench.py: the %d-rank run did not finish within %.0f s (hung rendezvous or collective?); killed\n' % (args.gpus, limit))
+        return 124
     line = None
-    for ln in proc.stdout.splitlines():
+    for ln in stdout.splitlines():
         if ln.startswith('{') and '"metric"' in ln:
             line = ln
         else:
             sys.stderr.write(ln + '\n')
     if proc.returncode != 0 or line is None:
-        sys.stderr.write('bench.py: the %d-rank run failed (exit code %d)\n' % (args.gpus, proc.returncode))
+        sys.stderr.write('bench.py: the %d-rank run failed (exit code %d%s)\n' % (
+            args.gpus, proc.returncode, '' if line is not None or proc.returncode else ', no JSON line from rank 0'))
         return proc.returncode or 1
     got = json.loads(line).get('n_gpus')
     if got != args.gpus:
@@ -170,12 +191,25 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if dry or args.backend == 'gloo':
-            dist.init_process_group('gloo')
-        else:
-            dist.init_process_group('nccl', device_id=torch.device(dev))
-        if dist.get_world_size() != args.gpus:
-            raise SystemExit('bench.py: process group has %d ranks, --gpus %d' % (dist.get_world_size(), args.gpus))
+        import datetime
+        backend = 'gloo' if (dry or args.backend == 'gloo') else 'nccl'
+        try:
+            tmo = datetime.timedelta(seconds=RENDEZVOUS_TIMEOUT_S)
+            if backend == 'gloo':
+                dist.init_process_group('gloo', timeout=tmo)
+            else:
+                dist.init_process_group('nccl', device_id=torch.device(dev), timeout=tmo)
+            if dist.get_world_size() != args.gpus:
+                raise RuntimeError('process group has %d ranks, --gpus %d' % (dist.get_world_size(), args.gpus))
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)                         # the first collective builds the communicator: fail HERE, with the rank named
+            if int(probe.item()) != world:
+                raise RuntimeError('first all-reduce summed to %r over %d ranks' % (probe.item(), world))
+        except BaseException as e:                         # noqa: B902
+            sys.stderr.write('bench.py: rank %d/%d (local %d, device %s, backend %s, MASTER %s:%s) could not join the process group: %s: %s\n' % (
+                rank, world, local_rank, dev, backend, os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT'), type(e).__name__, e))
+            sys.stderr.flush()
+            os._exit(3)                                    # no destructor of a half-built communicator may block the exit
 
     def sync():
         if not dry:
@@ -271,7 +305,10 @@ def main(argv=None):
                 'backend': (dist.get_backend() if dist is not None else None),
                 'ms_per_step_without_allreduce': None if t_without is None else round(t_without / args.steps * 1e3, 3),
                 'allreduce_ms_exposed': 0.0 if t_without is None else round(max(0.0, t_with - t_without) / args.steps * 1e3, 3),
-                'gradient_bytes_per_step': 4 * ngrad,
+                # what one rank hands to the all-reduce per step: the fp32 flat gradient buffer, or its bf16 image in the bf16 precision
+                # mode (parallel.GradAllReduce(payload='auto'))
+                'gradient_bytes_per_step': (2 if precision == 'bf16' else 4) * ngrad,
+                'gradient_payload': 'bf16 (fp32 accumulation in the flat gradient buffer and Adam)' if precision == 'bf16' else 'fp32',
                 'allreduce': 'none (1 rank)' if world == 1 else '6 gradient groups, SUM, issued from inside the backward sweep of t = 0 on a side stream',
                 'dtype': {'fp32': 'f32', 'bf16': 'bf16 ConvLSTM / enc5 / enc6 operands, f32 accumulate, gradients and optimizer',
                           'bf16x3': 'f32 as 2 bf16 pieces in the ConvLSTM forward and data gradients'}[precision],
@@ -306,7 +343,10 @@ def main(argv=None):
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
-        cpu_baseline = cpu_baseline_leg(args, B, T, S, nm, np, torch, train=args.mode == 'train')
+        try:
+            cpu_baseline = cpu_baseline_leg(args, B, T, S, nm, np, torch, train=args.mode == 'train')
+        except Exception as e:                             # the GPU legs are measured: a failing CPU leg must not discard them
+            sys.stderr.write('bench.py: cpu_baseline leg failed (%s: %s); reporting cpu_baseline = null\n' % (type(e).__name__, e))
 
     if rank == 0:
         frames = world * B * (T - 1) * args.steps
@@ -379,6 +419,8 @@ def roofline_pass(args, model, step, elapsed, np, torch):
         'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
         'frac': round(achieved / peak, 4),
         'traffic': _pmc_traffic(bf16),
+        'traffic_source': 'HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (profiles/*/pmc_traffic%s.json: '
+                          'FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE); not measured in this run' % ('_bf16' if bf16 else ''),
         'launches': int(n_tot.sum()), 'avg_launch_us': round(total_s / max(1, int(n_tot.sum())) * 1e6, 2),
         'algorithmic_gflop_per_launch': round(total_flops / max(1, int(n_tot.sum())) / 1e9, 3),
         'per_layer_tflops': {('lstm%d' % (i + 1)): round(float(flops[i] / (ms_tot[i] * 1e-3) / 1e12), 2)
@@ -410,7 +452,8 @@ def cpu_baseline_leg(args, B, T, S, nm, np, torch, train):
         cel = time.perf_counter() - c0
     if train:      # same bounded sample, but forward + autograd backward + Chainer-rule Adam
         from oracle.torch_restatement import chainer_adam_step
-        tmt = TorchModel(nm, is_cdna=True, params=P, dtype=torch.float32, requires_grad=True)
+        tmt = TorchModel(nm, is_cdna=args.model == 'CDNA', is_stp=args.model == 'STP', is_dna=args.model == 'DNA',
+                         params=P, dtype=torch.float32, requires_grad=True)
         Pm = {k: v.detach().numpy() for k, v in tmt.p.items()}
         Mm = {k: np.zeros_like(v) for k, v in Pm.items()}; Vm = {k: np.zeros_like(v) for k, v in Pm.items()}
         reps, c0 = 0, time.perf_counter()

@@ -235,6 +235,11 @@ int pivp_layernorm_backward(const float* dy, int lddy, const float* y, int ldy, 
 /* Chainer 2 Adam over a flat buffer (TM:860): lr_t = alpha*sqrt(1-beta2^t)/(1-beta1^t) from the host; g is scaled by gscale. */
 int pivp_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr_t, double beta1, double beta2,
                    double eps, double gscale, void* stream);
+/* bf16 payload of the data-parallel gradient all-reduce (BASELINE.json config 3; the reference is single-device, so this wraps
+ * the gradients its optimizer.update(), TM:950, consumes): pack n fp32 gradients (16-B aligned) into a bf16 send buffer (round to
+ * nearest even), and unpack the summed bf16 buffer back into the fp32 gradient buffer that pivp_adam_step reads. */
+int pivp_grad_pack_bf16(const float* src, void* dst_bf16, long long n, void* stream);
+int pivp_grad_unpack_bf16(const void* src_bf16, float* dst, long long n, void* stream);
 
 /* L.Convolution2D(cout,(3,3),stride=2,pad=1) (TM:501-502) + optional ReLU; w [9][cin/32][cout][32]. */
 int pivp_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,

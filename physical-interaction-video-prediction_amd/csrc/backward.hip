@@ -434,4 +434,44 @@ int adam_step(float* p, const float* g, float* m, float* v, long n, double lr_t,
     return PIVP_LAUNCH_STATUS();
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16 payload of the data-parallel gradient all-reduce (BASELINE.json config 3; SURVEY.md 8e: 18.4 MB instead of 36.9 MB per
+// step).  pack: fp32 gradient slice -> bf16 send buffer (round to nearest even, NaN stays NaN: the hardware convert); unpack: the
+// summed bf16 slice back into the fp32 flat gradient buffer, which stays the optimizer's (fp32 "master") input.  HBM-bound
+// streaming kernels: 16 B per lane on the wide side.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void grad_pack_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long n) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 3 < n) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+            *reinterpret_cast<bf16x4_t*>(dst + i) = __builtin_convertvector(v, bf16x4_t);
+        } else {
+            for (long j = i; j < n; ++j) dst[j] = __builtin_bit_cast(unsigned short, (__bf16)src[j]);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void grad_unpack_bf16_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, long n) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 3 < n) {
+            const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(src + i);
+            *reinterpret_cast<f32x4*>(dst + i) = __builtin_convertvector(v, f32x4);
+        } else {
+            for (long j = i; j < n; ++j) dst[j] = (float)__builtin_bit_cast(__bf16, src[j]);
+        }
+    }
+}
+int grad_pack_bf16(const float* src, void* dst, long n, hipStream_t s) {
+    PIVP_CHECK_ARG(src && dst && n > 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0);
+    const long blocks = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(grad_pack_bf16_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, src, (unsigned short*)dst, n);
+    return PIVP_LAUNCH_STATUS();
+}
+int grad_unpack_bf16(const void* src, float* dst, long n, hipStream_t s) {
+    PIVP_CHECK_ARG(src && dst && n > 0 && ((uintptr_t)dst & 15) == 0 && ((uintptr_t)src & 7) == 0);
+    const long blocks = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(grad_unpack_bf16_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, (const unsigned short*)src, dst, n);
+    return PIVP_LAUNCH_STATUS();
+}
+
 }  // namespace pivp

@@ -438,6 +438,12 @@ extern "C" int pivp_adam_step(float* p, const float* g, float* m, float* v, long
                               double eps, double gscale, void* stream) {
     return adam_step(p, g, m, v, (long)n, lr_t, beta1, beta2, eps, gscale, (hipStream_t)stream);
 }
+extern "C" int pivp_grad_pack_bf16(const float* src, void* dst_bf16, long long n, void* stream) {
+    return grad_pack_bf16(src, dst_bf16, (long)n, (hipStream_t)stream);
+}
+extern "C" int pivp_grad_unpack_bf16(const void* src_bf16, float* dst, long long n, void* stream) {
+    return grad_unpack_bf16(src_bf16, dst, (long)n, (hipStream_t)stream);
+}
 extern "C" int pivp_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                               int ldo, int relu, int B, int Hin, int Win, void* stream) {
     if (!x || !w || !out) return PIVP_ERR_BADARG;

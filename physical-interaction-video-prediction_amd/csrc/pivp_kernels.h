@@ -178,6 +178,8 @@ long long ln_bwd_param_part_floats(int n);
 int ln_bwd_params_reduce(const float* part, float* dgamma, float* dbeta, int B, int n, hipStream_t s);
 int adam_step(float* p, const float* g, float* m, float* v, long n, double lr_t, double beta1, double beta2, double eps,
               double gscale, hipStream_t s);
+int grad_pack_bf16(const float* src, void* dst, long n, hipStream_t s);     // fp32 -> bf16 (RNE): the all-reduce payload of config 3
+int grad_unpack_bf16(const void* src, float* dst, long n, hipStream_t s);   // bf16 -> fp32, into the flat gradient buffer
 
 // ---- backward of the heads / trunk ends (csrc/backward_heads.hip) ----
 int scaled_diff(const float* a, const float* b, float* out, long n, float scale, int accum, hipStream_t s);

@@ -111,12 +111,21 @@ struct pivp_plan {
     bool group_join = true;                                 // pivp_plan_set_group_join
     bool ln_touched[9] = {};                                // norms whose partial parameter gradients still await their reduction
     WgradDesc enc_desc[5]; bool enc_desc_valid[5] = {};     // enc6, enc5, enc4, enc2, enc1: what this sweep launched (for the reduction of the partial sums)
+    // the side stream(s) and every fork / join event, back to "never created" (the destructor; ensure_side's partial-failure path)
+    void destroy_side() {
+        for (int i = 0; i < 7; ++i) for (int r = 0; r < 2; ++r) if (ev_ring_done[i][r]) { (void)hipEventDestroy(ev_ring_done[i][r]); ev_ring_done[i][r] = nullptr; }
+        for (int i = 0; i < NSLOT; ++i) {
+            if (ev_ready[i]) { (void)hipEventDestroy(ev_ready[i]); ev_ready[i] = nullptr; }
+            if (ev_done[i]) { (void)hipEventDestroy(ev_done[i]); ev_done[i] = nullptr; }
+        }
+        if (side) { (void)hipStreamDestroy(side); side = nullptr; }
+        if (side2) { (void)hipStreamDestroy(side2); side2 = nullptr; }
+    }
     ~pivp_plan() {
-        for (int i = 0; i < 7; ++i) for (int r = 0; r < 2; ++r) if (ev_ring_done[i][r]) (void)hipEventDestroy(ev_ring_done[i][r]);
+        if (side) (void)hipStreamSynchronize(side);      // a sweep that failed half-way may have left weight-gradient kernels in flight
+        if (side2) (void)hipStreamSynchronize(side2);
         for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
-        for (int i = 0; i < NSLOT; ++i) { if (ev_ready[i]) (void)hipEventDestroy(ev_ready[i]); if (ev_done[i]) (void)hipEventDestroy(ev_done[i]); }
-        if (side) (void)hipStreamDestroy(side);
-        if (side2) (void)hipStreamDestroy(side2);
+        destroy_side();
     }
 };
 
@@ -326,7 +335,10 @@ static int ensure_side(pivp_plan* plan) {
     if (!plan->use_side || plan->side) return PIVP_OK;
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-    if (hipStreamCreateWithPriority(&plan->side, hipStreamNonBlocking, least) != hipSuccess) { plan->side = nullptr; return PIVP_ERR_LAUNCH; }
+    if (hipStreamCreateWithPriority(&plan->side, hipStreamNonBlocking, least) != hipSuccess) {
+        plan->side = nullptr; plan->use_side = false; (void)hipGetLastError();      // single-stream sweeps from here on
+        return PIVP_OK;
+    }
     {   // PIVP_SIDE_STREAMS=2: a second side stream for the odd slots (two weight-gradient kernels in flight).  fp32: no change (28.33 / 28.42
         // vs 28.35 / 28.34 ms); bf16 mode: 12.25 -> 12.05 ms.  NOT the default: with two processes on one GPU (bench.py --share-gpu, gloo) the
         // bf16 train step went from 65 ms to 78 SECONDS -- five streams per process oversubscribe the hardware queues -- and a data-parallel rank
@@ -335,12 +347,18 @@ static int ensure_side(pivp_plan* plan) {
         const bool two = e && atoi(e) == 2;
         if (two && hipStreamCreateWithPriority(&plan->side2, hipStreamNonBlocking, least) != hipSuccess) plan->side2 = nullptr;
     }
-    for (int i = 0; i < pivp_plan::NSLOT; ++i)
-        if (hipEventCreateWithFlags(&plan->ev_ready[i], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&plan->ev_done[i], hipEventDisableTiming) != hipSuccess) return PIVP_ERR_LAUNCH;
-    for (int i = 0; i < 7; ++i)
-        for (int r = 0; r < 2; ++r)
-            if (hipEventCreateWithFlags(&plan->ev_ring_done[i][r], hipEventDisableTiming) != hipSuccess) return PIVP_ERR_LAUNCH;
+    bool ok = true;
+    for (int i = 0; i < pivp_plan::NSLOT && ok; ++i)
+        ok = hipEventCreateWithFlags(&plan->ev_ready[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&plan->ev_done[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 7 && ok; ++i)
+        for (int r = 0; r < 2 && ok; ++r)
+            ok = hipEventCreateWithFlags(&plan->ev_ring_done[i][r], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {      // never leave `side` set beside null events: back to "no side stream", and this plan runs its sweeps on one stream
+        plan->destroy_side();
+        plan->use_side = false;
+        (void)hipGetLastError();
+    }
     return PIVP_OK;
 }
 
@@ -739,8 +757,34 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     return PIVP_OK;
 }
 
+static int rollout_backward_sweep(pivp_plan_t* plan, const float* images, const float* actions, const float* states,
+                                  const unsigned char* gt_select, const float* gen_images, const float* gen_states, void* stream);
 extern "C" int pivp_rollout_backward(pivp_plan_t* plan, const float* images, const float* actions, const float* states,
                                      const unsigned char* gt_select, const float* gen_images, const float* gen_states, void* stream) {
+    if (!plan) return PIVP_ERR_BADARG;
+    const int rc = rollout_backward_sweep(plan, images, actions, states, gt_select, gen_images, gen_states, stream);
+    // The side stream's weight gradients are joined whatever the sweep returned: on success the caller's stream is made to wait for
+    // them (what it enqueues next -- the all-reduce, Adam -- sees every gradient); after a failure half-way the host waits for both
+    // streams, so nothing is still reading the workspace or writing gradients when the caller clears, reuses or frees them.
+    if (plan->side) {
+        hipStream_t s = (hipStream_t)stream;
+        bool joined = rc == PIVP_OK;
+        if (joined) {
+            for (int i = 7; i < pivp_plan::NSLOT && joined; ++i) joined = hipStreamWaitEvent(s, plan->ev_done[i], 0) == hipSuccess;
+            for (int i = 0; i < 7 && joined; ++i)
+                for (int r = 0; r < 2 && joined; ++r) joined = hipStreamWaitEvent(s, plan->ev_ring_done[i][r], 0) == hipSuccess;
+        }
+        if (!joined) {
+            (void)hipStreamSynchronize(plan->side);
+            if (plan->side2) (void)hipStreamSynchronize(plan->side2);
+            (void)hipStreamSynchronize(s);
+            return rc != PIVP_OK ? rc : PIVP_ERR_LAUNCH;
+        }
+    }
+    return rc;
+}
+static int rollout_backward_sweep(pivp_plan_t* plan, const float* images, const float* actions, const float* states,
+                                  const unsigned char* gt_select, const float* gen_images, const float* gen_states, void* stream) {
     if (!plan || !images || !actions || !states || !gen_images || !gen_states) return PIVP_ERR_BADARG;
     if (!plan->ws || !plan->has_grads || plan->last_steps != plan->cfg.seq_len - 1) return PIVP_ERR_STATE;
     if ((gt_select != nullptr) != plan->last_sched) return PIVP_ERR_STATE;
@@ -807,15 +851,7 @@ extern "C" int pivp_rollout_backward(pivp_plan_t* plan, const float* images, con
                          wg_b & 1, wg_slot, wg_flush, s));
         has_go = next_loss || (prev_has_grad && has_go);
     }
-    if (plan->side)     // whatever the caller enqueues next on its stream (the all-reduce, Adam) sees every weight gradient
-    {
-        for (int i = 7; i < pivp_plan::NSLOT; ++i)
-            if (hipStreamWaitEvent(s, plan->ev_done[i], 0) != hipSuccess) return PIVP_ERR_LAUNCH;
-        for (int i = 0; i < 7; ++i)
-            for (int r = 0; r < 2; ++r)
-                if (hipStreamWaitEvent(s, plan->ev_ring_done[i][r], 0) != hipSuccess) return PIVP_ERR_LAUNCH;
-    }
-    return PIVP_OK;
+    return PIVP_OK;      // the side stream is joined by the caller, pivp_rollout_backward, on every path
 }
 
 // ------------------------------------------------------------------------------------------------------------

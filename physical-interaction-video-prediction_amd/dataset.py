@@ -114,3 +114,101 @@ class SerialIterator(object):
         return batch
 
     next = __next__
+
+
+class DeviceFeeder(object):
+    """Overlapped host feed of the training loop (the reference's loop, train_model.py:937-950, is synchronous: `concat_examples`
+    and the host -> device copy of every batch sit between two `optimizer.update` calls).
+
+    Two slots, each a set of PINNED host buffers and a set of device buffers.  `get()` hands out batch t on the device (the caller's
+    stream is made to wait for its copy) together with the iterator's bookkeeping AS IT WAS when batch t was drawn; `prefetch()`,
+    called right after the step of batch t has been enqueued, draws batch t + 1 from the iterator, runs `concat_examples` and the
+    rank's shard slice into the other slot's pinned buffers and starts the copy on a second stream, so both run under the GPU's work
+    on batch t.  The iterator is advanced exactly as a plain `iterator.next()` loop would advance it, one batch early: order of the
+    batches, shards, `epoch` and `is_new_epoch` are unchanged (tests/test_dataset_host.py).  With device='cpu' (tests) the slots are
+    plain host tensors and the copy is a memcpy.
+
+    Slot reuse: the copy into a slot's DEVICE buffers waits for an event recorded on the caller's stream when the batch AFTER the
+    slot's previous occupant was handed out (its step is enqueued before that), the write into its PINNED buffers for the event of
+    its previous copy."""
+
+    def __init__(self, iterator, rank=0, world=1, device='cuda:0'):
+        import torch
+        self._torch = torch
+        self.iterator = iterator
+        self.rank, self.world = int(rank), int(world)
+        self.device = torch.device(device)
+        self.cuda = self.device.type == 'cuda'
+        self._slots = [None, None]
+        self._staged = None           # (slot index, epoch when drawn, is_new_epoch after the draw) of the batch waiting for get()
+        self._count = 0
+        self._copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self._exhausted = False
+
+    def _slot(self, k, arrays):
+        torch = self._torch
+        sl = self._slots[k]
+        if sl is None or any(tuple(h.shape) != a.shape for h, a in zip(sl['host'], arrays)):
+            host = [torch.empty(a.shape, dtype=torch.float32, pin_memory=self.cuda) for a in arrays]
+            dev = [torch.empty(a.shape, dtype=torch.float32, device=self.device) for a in arrays] if self.cuda else host
+            sl = self._slots[k] = dict(host=host, dev=dev, copied=None, consumed=None)
+        return sl
+
+    def prefetch(self):
+        """Draw the next batch and start its journey to the device.  No-op when one is already staged or the iterator has ended."""
+        if self._staged is not None or self._exhausted:
+            return
+        from .data import concat_examples
+        torch = self._torch
+        epoch = self.iterator.epoch
+        try:
+            batch = self.iterator.next()
+        except StopIteration:
+            self._exhausted = True
+            return
+        new_epoch = self.iterator.is_new_epoch
+        img, act, sta = concat_examples(batch)
+        B = img.shape[1]
+        if B % self.world:
+            raise ValueError('batch of %d sequences is not divisible by %d ranks' % (B, self.world))
+        per = B // self.world
+        lo = self.rank * per
+        arrays = [a[:, lo:lo + per] for a in (img, act, sta)]
+        k = self._count % 2
+        self._count += 1
+        sl = self._slot(k, arrays)
+        if sl['copied'] is not None:
+            sl['copied'].synchronize()              # the previous copy OUT of these pinned buffers has finished (two batches ago)
+        for h, a in zip(sl['host'], arrays):
+            np.copyto(h.numpy(), a)
+        if self.cuda:
+            with torch.cuda.stream(self._copy_stream):
+                if sl['consumed'] is not None:
+                    self._copy_stream.wait_event(sl['consumed'])
+                for h, d in zip(sl['host'], sl['dev']):
+                    d.copy_(h, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._copy_stream)
+            sl['copied'] = ev
+        self._staged = (k, epoch, new_epoch)
+
+    def get(self):
+        """-> ([images (T,B/world,3,H,W), actions, states] on the device, epoch at the draw, is_new_epoch after the draw)."""
+        torch = self._torch
+        if self._staged is None:
+            self.prefetch()
+        if self._staged is None:
+            raise StopIteration
+        k, epoch, new_epoch = self._staged
+        self._staged = None
+        sl = self._slots[k]
+        if self.cuda:
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(sl['copied'])
+            other = self._slots[1 - k]
+            if other is not None:                   # everything enqueued so far used the OTHER slot's batch at the latest
+                ev = torch.cuda.Event()
+                ev.record(main)
+                other['consumed'] = ev
+            return list(sl['dev']), epoch, new_epoch
+        return [t.clone() for t in sl['host']], epoch, new_epoch

@@ -15,9 +15,19 @@ class GradAllReduce(object):
     the default of 4 buckets of ~9 MB each lets the first slices travel while the tail of backward still runs when the
     caller invokes `allreduce_range` per finished region (the plan fills gradients back-to-front)."""
 
-    def __init__(self, group=None, nbuckets=4, defer_side_wait=True):
+    def __init__(self, group=None, nbuckets=4, defer_side_wait=True, payload='auto'):
+        """payload: what travels in the overlapped all-reduce (`backward_and_allreduce`).  'fp32' = the flat gradient buffer itself
+        (36.9 MB per step at 64x64).  'bf16' = every announced group slice is rounded to bf16 into a send buffer on the collective's
+        stream (one HIP launch), the bf16 buffer is all-reduced (18.4 MB) and the sum is written back into the fp32 flat buffer,
+        which stays the optimizer's input ("bf16 payload + fp32 master accumulation").  'auto' (default) = 'bf16'
+        for a model in the bf16 precision mode (BASELINE.json config 3), 'fp32' otherwise; pass 'fp32' to opt out."""
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
+        if payload not in ('auto', 'fp32', 'bf16'):
+            raise ValueError("payload must be 'auto', 'fp32' or 'bf16'")
+        self.payload = payload
+        self._send = None           # bf16 send buffer, as large as the flat gradient buffer
+        self.last_payload_bytes = 0
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -77,6 +87,13 @@ class GradAllReduce(object):
             return flat
         ranges = model.grad_group_ranges()
         cuda = flat.is_cuda
+        bf16 = self.payload == 'bf16' or (self.payload == 'auto' and getattr(model, 'precision', 'fp32') == 'bf16')
+        send = None
+        if bf16:
+            if self._send is None or self._send.numel() != flat.numel() or self._send.device != flat.device:
+                self._send = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+            send = self._send
+        self.last_payload_bytes = sum(max(0, b - a) for a, b in ranges) * (2 if bf16 else 4)
         if cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=flat.device)
@@ -102,9 +119,13 @@ class GradAllReduce(object):
                 if defer:
                     model.wait_group(g, self._stream)   # ... or on the model's side stream
                 with torch.cuda.stream(self._stream):
-                    works.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    if bf16:
+                        _pack_bf16(flat[a:b], send[a:b], self._stream)
+                    works.append((g, dist.all_reduce(send[a:b] if bf16 else flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
             else:
-                works.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if bf16:
+                    send[a:b].copy_(flat[a:b])       # host tensors (gloo tests): torch's round-to-nearest-even cast
+                works.append((g, dist.all_reduce(send[a:b] if bf16 else flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
         def on_group(g):
             if g < len(issued):
@@ -130,12 +151,18 @@ class GradAllReduce(object):
                 model.set_group_join(True)
             if cuda:
                 with torch.cuda.stream(self._stream):
-                    for w in works:
+                    for g, w in works:
                         w.wait()
+                        if bf16:                      # the summed bf16 slice back into the fp32 gradient buffer (the optimizer's input)
+                            a, b = ranges[g]
+                            _unpack_bf16(send[a:b], flat[a:b], self._stream)
                 main.wait_stream(self._stream)
             else:
-                for w in works:
+                for g, w in works:
                     w.wait()
+                    if bf16:
+                        a, b = ranges[g]
+                        flat[a:b].copy_(send[a:b])
         if error is not None:
             raise error
         if out_of_turn:
@@ -144,13 +171,27 @@ class GradAllReduce(object):
         return flat
 
 
+def _pack_bf16(src, dst, stream):
+    """fp32 device slice -> bf16 device slice on `stream` (csrc/backward.hip: grad_pack_bf16_kernel)."""
+    from . import _lib
+    lib = _lib.load()
+    _lib.check(lib.pivp_grad_pack_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), stream.cuda_stream), 'pivp_grad_pack_bf16')
+
+
+def _unpack_bf16(src, dst, stream):
+    from . import _lib
+    lib = _lib.load()
+    _lib.check(lib.pivp_grad_unpack_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), stream.cuda_stream), 'pivp_grad_unpack_bf16')
+
+
 class HostStubModel(object):
     """CPU stand-in for `Model` with the same training protocol (`_ensure_grads`, `grad_group_ranges`, `cleargrads`,
     `backward(on_group)`): the gradient of group g is `value * (g + 1)` everywhere.  It lets the data-parallel host logic run
     under gloo with no GPU: tests/test_parallel_gloo.py and `bench.py --dry`.  `fail_in_group` makes the callback of that group
     raise, as a failing rank would; `skip_groups` leaves groups unannounced."""
 
-    def __init__(self, sizes=(1000, 300, 70, 5000, 64, 1), value=1.0, fail_in_group=None, skip_groups=()):
+    def __init__(self, sizes=(1000, 300, 70, 5000, 64, 1), value=1.0, fail_in_group=None, skip_groups=(), precision='fp32'):
+        self.precision = precision
         self.sizes = list(sizes)
         self.value = float(value)
         self.fail_in_group = fail_in_group

@@ -95,12 +95,11 @@ def main(argv=None):
     stat = lambda a: [float(np.mean(a)), float(np.std(a)), float(np.min(a)), float(np.max(a)), float(np.median(a))]
     state_loaded = False
     itr, start = 0, None
+    # Host feed (TM:937-950 is synchronous): batch t + 1 is drawn, laid out (concat_examples), sharded and copied from pinned memory on a
+    # second stream while the GPU works on batch t; iterator order, shards and epoch bookkeeping are those of the plain loop
+    feeder = ds.DeviceFeeder(train_iter, rank=rank, world=world, device=device)
     while itr < args.num_iterations:
-        epoch = train_iter.epoch
-        batch = train_iter.next()
-        img, act, sta = concat_examples(batch)
-        sl = slice(rank * per_rank, (rank + 1) * per_rank)
-        x = [np.ascontiguousarray(img[:, sl]), np.ascontiguousarray(act[:, sl]), np.ascontiguousarray(sta[:, sl])]
+        x, epoch, is_new_epoch = feeder.get()
         start = start or time.time()
         if world > 1 and itr == 0:                  # replicas start identical: rank 0's lazily initialised weights
             with using_config('train', False):
@@ -111,12 +110,18 @@ def main(argv=None):
             with using_config('train', False):
                 model(x, 0)
             model.reset_state(); load_optimizer_npz(args.pretrained_state, optimizer); state_loaded = True
-        optimizer.update(model, x, itr)
-        local_losses.append(float(model.loss)); local_psnr.append(float(model.psnr_all))
+        optimizer.update(model, x, itr)             # enqueues the whole step; returns while the GPU is still working on it
+        if itr + 1 < args.num_iterations:
+            feeder.prefetch()                       # ... so the next batch's host work and copy run underneath it
+        stats = torch.stack([model.loss, model.psnr_all]).to(torch.float64)
+        if world > 1:                               # the logged statistics are those of the GLOBAL batch (mean over the ranks' shards)
+            dist.all_reduce(stats); stats /= world
+        lv, pv = stats.tolist()                     # the step's one host synchronisation
+        local_losses.append(lv); local_psnr.append(pv)
         model.reset_state()
         if rank == 0:
             logger.info('%d %s', epoch + 1, local_losses[-1])
-        if train_iter.is_new_epoch:
+        if is_new_epoch:
             g_loss.append(stat(local_losses)); g_psnr.append(stat(local_psnr))
             if rank == 0:
                 logger.info('[TRAIN] Epoch #: %d  elapsed %.2fs  loss %.6f  psnr %.3f', epoch + 1, time.time() - start, g_loss[-1][0], g_psnr[-1][0])

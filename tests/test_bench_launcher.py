@@ -45,3 +45,24 @@ def test_bench_single_rank_dry_reports_both_legs():
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][0])
     assert out['n_gpus'] == 1 and out['train']['rccl_ranks'] == 1 and out['train']['allreduce_ms_exposed'] == 0.0
+
+
+def test_eight_ranks_dry():
+    """The driver's largest run (--gpus 8): launcher, rendezvous on a port torchrun picks, 8 ranks' bookkeeping, the overlapped
+    all-reduce over 8 gloo ranks and the one JSON line.  Host logic only (stub kernels)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--dry', '--steps', '2', '--warmup', '1'],
+                       env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 8 and out['config']['global_batch'] == 256 and out['config']['frames_per_step'] == 8 * 32 * 9
+    assert out['train']['rccl_ranks'] == 8 and out['train']['backend'] == 'gloo'
+
+
+def test_launcher_times_out_with_a_reason():
+    # a child that cannot finish inside the bound is killed (its own process group only) and the launcher exits non-zero with one line
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry', '--steps', '2', '--warmup', '1'],
+                       env=_env(PIVP_BENCH_TIMEOUT='0.5'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 124
+    assert 'did not finish within' in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith('{')]

@@ -99,3 +99,46 @@ def test_cli_flag_surface_matches_reference():
         assert getattr(a, k) == v, k
     b = pred_parser().parse_args(['20170101-000000-CDNA-32', 'training-0', '3'])
     assert (b.time_step, b.schedsamp_k, b.context_frames, b.num_masks, b.image_height, b.image_width) == (8, -1, 2, 10, 64, 64)
+
+
+def test_device_feeder_keeps_iterator_order_shards_and_epochs():
+    """The overlapped host feed (dataset.DeviceFeeder, used by train.py) draws from the iterator one batch early; what the training
+    loop sees -- batches, their order, each rank's shard, `epoch` at the draw and `is_new_epoch` after it, and NumPy's global RNG
+    stream as interleaved with other draws between steps -- must equal the plain synchronous loop of train_model.py:937-950."""
+    rs = np.random.RandomState(0)
+    N, T, H = 11, 3, 8
+    data = ds.group_examples(rs.rand(N, T, H, H, 3).astype(np.float32), rs.randn(N, T, 5).astype(np.float32), rs.randn(N, T, 5).astype(np.float32))
+    steps, B, world = 9, 4, 2                                   # 11 sequences, batches of 4: an epoch boundary inside batches 2, 5, 8
+    # the plain loop; between two steps something else draws from the global RNG (scheduled sampling does, TM:94)
+    np.random.seed(5)
+    it = ds.SerialIterator(data, B, repeat=True, shuffle=True)
+    plain = []
+    for _ in range(steps):
+        epoch = it.epoch
+        img, act, sta = pivp_amd.concat_examples(it.next())
+        plain.append((img, act, sta, epoch, it.is_new_epoch, np.random.rand()))
+    for rank in range(world):
+        np.random.seed(5)
+        it = ds.SerialIterator(data, B, repeat=True, shuffle=True)
+        feeder = ds.DeviceFeeder(it, rank=rank, world=world, device='cpu')
+        per = B // world
+        for t in range(steps):
+            x, epoch, new_epoch = feeder.get()
+            draw = np.random.rand()                             # the step's own draws come after its batch was drawn ...
+            if t + 1 < steps:
+                feeder.prefetch()                               # ... and before the next batch is
+            img, act, sta, e0, n0, d0 = plain[t]
+            sl = slice(rank * per, (rank + 1) * per)
+            assert np.array_equal(x[0].numpy(), img[:, sl]) and np.array_equal(x[1].numpy(), act[:, sl]) and np.array_equal(x[2].numpy(), sta[:, sl])
+            assert (epoch, new_epoch, draw) == (e0, n0, d0), t
+            assert x[0].shape == (T, per, 3, H, H) and x[0].dtype.is_floating_point
+    assert [p[4] for p in plain].count(True) == 3
+    # a finite iterator ends with StopIteration from get(), after serving every batch
+    feeder = ds.DeviceFeeder(ds.SerialIterator(data, 4, repeat=False, shuffle=False), device='cpu')
+    n = 0
+    with pytest.raises(StopIteration):
+        while True:
+            x, _, _ = feeder.get(); n += x[0].shape[1]; feeder.prefetch()
+    assert n == N
+    with pytest.raises(ValueError):
+        ds.DeviceFeeder(ds.SerialIterator(data, 3, repeat=True, shuffle=False), rank=0, world=2, device='cpu').get()

@@ -22,6 +22,9 @@ GATE = 1e-4
 #    (test_config4_stp_batch32), which is a statement about the kernels rather than about one draw of a theta error.
 STP_VS_FP32_PER_STEP = 1.35     # rms over 32 samples of one step: HIP <= 1.35 x float32 oracle (32 draws: ~ +-15 % noise)
 STP_VS_FP32_OVERALL = 1.10      # geometric mean of the nine per-step ratios
+STP_VS_FP32_MAX = 3.0           # per step, the largest error over the sampled pixels: HIP <= 3 x the float32 oracle's largest on the same
+                                # pixels.  An rms over 32 samples barely sees a localised kernel error (a tile tail, an edge tap: a few
+                                # pixels at 1e-3); the maximum does.  3x: the step's maximum is ONE sample's draw of a theta error.
 
 
 @pytest.fixture(scope='module')
@@ -234,6 +237,7 @@ def test_config4_stp_batch32(pivp, name):
     assert np.isfinite(gen).all()
     assert (ratio < STP_VS_FP32_PER_STEP).all()
     assert np.exp(np.log(ratio).mean()) < STP_VS_FP32_OVERALL
+    assert (mx(l2) < STP_VS_FP32_MAX * mx(ref32)).all()
     if smooth:
         assert mx(l2)[:2].max() < GATE                           # ground-truth-fed steps of video-like frames
     assert abs(loss - float(g['loss'])) < 1e-5

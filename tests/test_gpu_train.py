@@ -26,6 +26,10 @@ def _autograd(P, imgs, acts, stas, k=-1, it=0, seed=None, **kw):
     return float(loss), {kk: v.grad.numpy() for kk, v in tm.p.items()}
 
 
+MAX_OVER_TOL_NORM = 4 * 128      # per-element LayerNorm parameters: up to four flipped units x 128 channels at their pixel
+MAX_OVER_TOL = 16                # every other tensor
+
+
 def _check_grads(got, ref, tol, relu_flips=2):
     """Per tensor, relative to max |ref|: the 99th percentile of the element errors < tol, the relative L2 error < tol, and
     no element beyond 10 x tol.  Why not simply max < tol: an activation within fp32 rounding of zero has its ReLU mask decided
@@ -36,6 +40,7 @@ def _check_grads(got, ref, tol, relu_flips=2):
     the L2 norm see.  The per-element LayerNorm parameters directly behind a ReLU (norm_enc0, norm_enc6) additionally drop their
     `relu_flips` largest elements from the 10 x tol bound."""
     worst = []
+    over_counts = []
     for kname, g in ref.items():
         scale = np.abs(g).max() + 1e-12
         d = got[kname].astype(np.float64) - g
@@ -48,6 +53,15 @@ def _check_grads(got, ref, tol, relu_flips=2):
         assert p99 < tol, '%s: 99th-percentile relative gradient error %.3e (scale %.3e)' % (kname, p99, scale)
         assert rel_l2 < tol, '%s: relative L2 gradient error %.3e' % (kname, rel_l2)
         assert e[-1] < 10 * tol, '%s: largest relative gradient error %.3e (scale %.3e)' % (kname, e[-1], scale)
+        # ... and HOW MANY elements may sit between tol and 10 x tol: the footprint of a few flipped units, not a flat 1 % of the tensor
+        # (a tile-edge bug in a partial-sum reduce or a column-limited data gradient is wrong on a stripe of the tensor: hundreds to
+        # thousands of elements).  A flipped unit moves ONE pixel position of the per-element LayerNorm parameters above it in all of its
+        # <= 128 channels, and nothing else by more than one sample's share of a sum over >= 2048 pixels.
+        n_over = int((e > tol).sum())
+        allowed = MAX_OVER_TOL_NORM if '/norm/' in kname else MAX_OVER_TOL
+        over_counts.append((n_over, kname))
+        assert n_over <= allowed, '%s: %d elements above tol %.1e (allowed %d)' % (kname, n_over, tol, allowed)
+    print('elements above tol, worst tensors:', sorted(over_counts, reverse=True)[:3])
     return max(worst)
 
 
@@ -244,6 +258,55 @@ def test_overlapped_allreduce_single_rank(pivp):
         dp.backward_and_allreduce(m, force_overlap=True)
         torch.cuda.synchronize()
         # fp32 atomics make the weight gradients differ in the last bits between two sweeps
+        assert torch.allclose(m._ensure_grads(), ref, rtol=1e-4, atol=1e-7)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_gradient_payload_kernels_and_single_rank_path(pivp):
+    """config 3's all-reduce payload: pivp_grad_pack_bf16 is the round-to-nearest-even cast bit for bit (odd length: scalar tail;
+    NaN stays NaN), unpack is exact, and the overlapped path with payload='bf16' on a 1-rank RCCL group leaves bf16(gradient) in
+    the fp32 flat buffer with half the bytes sent."""
+    import ctypes
+    from pivp_amd import _lib
+    lib = _lib.load()
+    n = 4 * 100000 + 3
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy((rs.standard_normal(n) * np.exp(rs.uniform(-30, 30, n))).astype(np.float32)).cuda()
+    x[17] = float('nan'); x[18] = float('inf'); x[19] = 0.0; x[20] = -0.0
+    y = torch.empty(n, dtype=torch.bfloat16, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.pivp_grad_pack_bf16(x.data_ptr(), y.data_ptr(), n, st) == 0
+    want = x.to(torch.bfloat16)
+    assert torch.equal(y.view(torch.int16)[~torch.isnan(x)], want.view(torch.int16)[~torch.isnan(x)])
+    assert bool(torch.isnan(y[17].float()))
+    z = torch.empty(n, dtype=torch.float32, device='cuda')
+    assert lib.pivp_grad_unpack_bf16(y.data_ptr(), z.data_ptr(), n, st) == 0
+    ok = ~torch.isnan(x)
+    assert torch.equal(z[ok], want.float()[ok])
+    assert lib.pivp_grad_pack_bf16(x.data_ptr() + 4, y.data_ptr(), 8, st) == -1      # misaligned source: refused, not launched
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29534', world_size=1, rank=0, device_id=torch.device('cuda:0'))
+    try:
+        P = R.init_params(seed=1, dtype=np.float64, scale=1.0)
+        imgs, acts, stas = R.synthetic_batch(2, 3)
+        m = pivp.Model(10, prefix='t', keep_activations=True)
+        m.load_state_dict_reference(P)
+        m([imgs, acts, stas], 0)
+        m.cleargrads(); m.backward()
+        ref = m._ensure_grads().clone()
+        m.cleargrads()
+        dp = pivp.GradAllReduce(payload='bf16')
+        dp.backward_and_allreduce(m, force_overlap=True)
+        torch.cuda.synchronize()
+        got = m._ensure_grads()
+        assert dp.last_payload_bytes == 2 * got.numel()
+        assert torch.equal(got, got.to(torch.bfloat16).float())                       # every value is a bf16 number
+        assert torch.allclose(got, ref, rtol=2.0 ** -7, atol=1e-7)                     # ... within bf16 rounding of the fp32 gradient
+        auto = pivp.GradAllReduce()                                                   # 'auto' on an fp32 model keeps the fp32 payload
+        m.cleargrads(); auto.backward_and_allreduce(m, force_overlap=True); torch.cuda.synchronize()
+        assert auto.last_payload_bytes == 4 * got.numel()
         assert torch.allclose(m._ensure_grads(), ref, rtol=1e-4, atol=1e-7)
     finally:
         dist.destroy_process_group()

@@ -87,13 +87,15 @@ def _overlap_worker(rank, world, port, q, scenario):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         import pivp_amd
-        dp = pivp_amd.GradAllReduce()
+        dp = pivp_amd.GradAllReduce(payload='fp32' if scenario == 'bf16_model_fp32_payload' else 'auto')
         kw = {}
+        if scenario in ('bf16_payload', 'bf16_model_fp32_payload'):
+            kw['precision'] = 'bf16'                     # a model in the bf16 precision mode (config 3): 'auto' sends bf16
         if scenario == 'callback_raises' and rank == 1:
             kw['fail_in_group'] = 2                      # rank 1's callback for group 2 raises; rank 0 is healthy
         if scenario == 'group_skipped' and rank == 1:
             kw['skip_groups'] = (3,)                     # rank 1 never announces group 3
-        model = pivp_amd.HostStubModel(value=float(rank + 1), **kw)
+        model = pivp_amd.HostStubModel(value=float(rank + 1) * (1.003 if 'bf16' in scenario else 1.0), **kw)
         model.cleargrads()
         err = None
         try:
@@ -104,7 +106,7 @@ def _overlap_worker(rank, world, port, q, scenario):
         # a collective issued after the step proves that no rank is still stuck inside the step's collectives
         after = torch.tensor([float(rank + 1)])
         dist.all_reduce(after)
-        q.put((rank, err, list(dp.issued), list(model.announced), flat.numpy(), float(after.item())))
+        q.put((rank, err, list(dp.issued), list(model.announced), flat.numpy(), float(after.item()) + 1000.0 * dp.last_payload_bytes))
     finally:
         dist.destroy_process_group()
 
@@ -121,7 +123,12 @@ def _run_overlap(scenario):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    return res
+    global _payload_bytes
+    _payload_bytes = [int(r[5] // 1000.0) for r in res]
+    return [r[:5] + (r[5] % 1000.0,) for r in res]
+
+
+_payload_bytes = None
 
 
 def _expected_sum(world=2):
@@ -164,3 +171,31 @@ def test_overlapped_allreduce_flags_a_missing_group():
     assert issued1 == [0, 1, 2, 3, 4, 5]
     assert err1 is not None and 'out of order' in err1
     assert after0 == 3.0 and after1 == 3.0
+
+
+def test_bf16_gradient_payload_two_ranks():
+    """BASELINE.json config 3: a model in the bf16 precision mode sends its gradient groups as bf16 (half the bytes); the sum comes
+    back into the fp32 flat buffer within bf16 rounding; both ranks hold the same bytes."""
+    res = _run_overlap('bf16_payload')
+    n = sum(__import__('pivp_amd').HostStubModel().sizes)
+    assert _payload_bytes == [2 * n, 2 * n]
+    exact = _expected_sum() * 1.003
+    for rank, err, issued, announced, flat, after in res:
+        assert err is None and issued == [0, 1, 2, 3, 4, 5]
+        rel = np.abs(flat - exact) / exact
+        assert rel.max() < 3 * 2.0 ** -8 and rel.max() > 0          # two roundings to bf16 and one bf16 add; NOT the exact fp32 sum
+        assert np.array_equal(flat, flat.astype(np.float32).view(np.uint32).__and__(0xFFFF0000).view(np.float32))   # bf16 numbers
+    assert np.array_equal(res[0][4], res[1][4])
+
+
+def test_bf16_model_can_opt_out_of_the_bf16_payload():
+    res = _run_overlap('bf16_model_fp32_payload')
+    n = sum(__import__('pivp_amd').HostStubModel().sizes)
+    assert _payload_bytes == [4 * n, 4 * n]
+    m = __import__('pivp_amd').HostStubModel()
+    exact = np.zeros(n, dtype=np.float32)
+    for g, (a, b) in enumerate(m.grad_group_ranges()):
+        exact[a:b] = np.float32(np.float32(1.003) * (g + 1)) + np.float32(np.float32(2.006) * (g + 1))
+    for rank, err, issued, announced, flat, after in res:
+        assert err is None
+        assert np.allclose(flat, exact, rtol=1e-6)
