@@ -289,7 +289,10 @@ def moving_batch(batch, seq_len=10, height=64, width=64, seed=0, dtype=np.float3
     Hs, Ws = height + 2 * margin, width + 2 * margin
     r = box // 2
     noise = rs.random_sample((batch, 3, Hs + 2 * r, Ws + 2 * r))
-    scene = sliding_window_view(noise, (box, box), axis=(2, 3)).mean(axis=(-1, -2))
+    c = np.cumsum(np.pad(noise, ((0, 0), (0, 0), (1, 0), (0, 0))), axis=2)          # box sums by running sums (sequential float64 adds)
+    rows = c[:, :, box:] - c[:, :, :-box]
+    c = np.cumsum(np.pad(rows, ((0, 0), (0, 0), (0, 0), (1, 0))), axis=3)
+    scene = (c[:, :, :, box:] - c[:, :, :, :-box]) / float(box * box)
     lo = scene.min(axis=(1, 2, 3), keepdims=True); hi = scene.max(axis=(1, 2, 3), keepdims=True)
     scene = (scene - lo) / (hi - lo)
     vel = rs.uniform(-2.0, 2.0, size=(batch, 2))

@@ -32,8 +32,28 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int PP = 144;                // patch pixel pitch (bytes): 64 bf16 + 16
 constexpr int TH = 8, PH = TH + 4;     // anchor rows per tile, patch rows
 constexpr int NPJ = 5;                 // patch pixels per staging thread (512 threads = 64 pixels x 8 pieces per pass)
-constexpr int MAXPIX = NPJ * 64;       // 320 allocated; two 8x8 images need 2 * 12 * 12 = 288, one 8x16 tile 12 * 20 = 240
-constexpr int PATCH_BYTES = MAXPIX * PP;
+// (NPJ * 64 = 320 pixels are staged per pass; two 8x8 images need 2 * 12 * 12 = 288, one 8x16 tile 12 * 20 = 240)
+// Patch ROW pitch.  A 16-lane phase of the A fragment's ds_read_b128 covers pixels of TWO (8 x 16 tile) or FOUR (8 x 8 tiles)
+// patch rows; with rows simply 20 / 12 pixels apart (2880 / 1728 B) half of its lanes landed on the banks of the other half
+// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.47, profiles/r03: every fragment read took two passes, and four multiplying waves
+// then keep the LDS busy for as long as their MFMAs run).  The 144-B pixel pitch puts 16 consecutive pixels on 16 distinct 16-B
+// bank slots; a row pitch that is a multiple of 256 B continues that sequence into the next row (8 x 16 tile: pixels 16..31 of a
+// 32-row M tile), one that is 128 (mod 256) gives the complementary slots to alternate rows (8 x 8 tiles: 8 pixels per row).
+constexpr int RP16 = 3072;             // 20 px * 144 B = 2880 -> 12 * 256
+constexpr int RP8 = 1920;              // 12 px * 144 B = 1728 -> 7 * 256 + 128
+constexpr int PATCH_BYTES = 2 * PH * RP8;   // 46,080 (= 320 * 144 as before); one 8 x 16 tile: 12 * 3072 = 36,864
+static_assert(PH * RP16 <= PATCH_BYTES && RP16 % 256 == 0 && RP8 % 256 == 128 && RP16 >= 21 * PP && RP8 >= 13 * PP, "patch rows");
+// swizzle of a weight row's eight 16-B pieces (ring slot = [row][64 bf16] = 128-B rows, so two consecutive rows span the 64 banks):
+// the 16 lanes of a ds_read_b128 phase read one piece each from 16 different rows and are conflict-free iff the 8 even and the 8
+// odd rows among them all use different pieces.  Rows of a phase: 32 consecutive MFMA columns are ring rows r0 + {0-3, 12-15, 20-27}
+// or r0 + {4-11, 16-19, 28-31} when a wave's columns are consecutive rows or 16-row runs 32 rows apart (plain conv; 32-channel
+// ConvLSTM blocks): (row >> 1) & 7 separates them.  16-channel ConvLSTM blocks take 8-row runs of the four gates (16 rows apart):
+// ((row >> 1) & 3) | (gate >> 1) << 2.  (The first version used row & 7: two passes per read, same counter.)
+template <int NCH, bool LSTM>
+__device__ __forceinline__ int ring_swizzle(int row) {
+    if constexpr (LSTM && NCH == 16) return ((row >> 1) & 3) | (((row >> 5) & 1) << 2);
+    else return (row >> 1) & 7;
+}
 constexpr int NSLOT = 4, DEPTH = 3;    // weight ring slots; taps of prefetch
 
 __device__ __forceinline__ float b_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -127,6 +147,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     // tile geometry: tw = 16: one image, 8 x 16 anchors; tw = 8: two images, 8 x 8 anchors each
     const int ti_n = tw == 16 ? 1 : 2;
     const int PW = tw + 4;
+    const int RP = tw == 16 ? RP16 : RP8;             // patch row pitch (bytes)
     const int npix = ti_n * PH * PW;
     const int tpr = W / tw, tpi = (H / TH) * tpr;          // tiles per row / per image
     const int n_tiles = (d.B / ti_n) * tpi;
@@ -150,6 +171,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     // ---- patch staging (all 8 waves): thread = (pixel (tid >> 3) + 64 j, 8-channel piece tid & 7), j < 5 -------------------
     const int cpiece = tid & 7;
     int a_pix[NPJ];                                    // global pixel index, or -1 outside the image / past the patch
+    int a_lds[NPJ];                                    // the pixel's byte offset in the patch (pixels past the patch: row 0's padding)
 #pragma unroll
     for (int j = 0; j < NPJ; ++j) {
         const int p = (tid >> 3) + 64 * j;
@@ -158,6 +180,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         const int iy = y0 - 2 + py, ix = x0 - 2 + px;
         const bool ok = p < npix && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
         a_pix[j] = ok ? ((b0 + ti) * H + iy) * W + ix : -1;
+        a_lds[j] = p < npix ? (ti * PH + py) * RP + px * PP : PW * PP;
     }
     f32x4 plo[NPJ], phi[NPJ];                          // a patch in flight (live only between the two halves of a staging)
     auto patch_load = [&](int cg) {
@@ -179,13 +202,12 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     auto patch_store = [&]() {
 #pragma unroll
         for (int j = 0; j < NPJ; ++j) {
-            // unconditional (NPJ * 64 = MAXPIX pixels are allocated; pixels past npix receive zeros): a predicated write leaves
-            // the loads "pending" on the skipped path for hipcc's wait-count pass, which then drains vmcnt inside the tap loop
-            const int p = (tid >> 3) + 64 * j;
+            // unconditional (pixels past npix write their zeros into the padding behind row 0, which nobody reads): a predicated write
+            // leaves the loads "pending" on the skipped path for hipcc's wait-count pass, which then drains vmcnt inside the tap loop
             uint4 v;
             v.x = pack2(plo[j][0], plo[j][1]); v.y = pack2(plo[j][2], plo[j][3]);
             v.z = pack2(phi[j][0], phi[j][1]); v.w = pack2(phi[j][2], phi[j][3]);
-            *reinterpret_cast<uint4*>(patch + p * PP + cpiece * 16) = v;
+            *reinterpret_cast<uint4*>(patch + a_lds[j] + cpiece * 16) = v;
             if constexpr (PL == 2) {                   // lo plane: bf16(v - hi); hi as a float is its 16 bits shifted up
                 auto lo2 = [](unsigned hi2, float a, float b) {
                     return pack2(a - __builtin_bit_cast(float, hi2 << 16), b - __builtin_bit_cast(float, hi2 & 0xffff0000u));
@@ -193,7 +215,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
                 uint4 l;
                 l.x = lo2(v.x, plo[j][0], plo[j][1]); l.y = lo2(v.y, plo[j][2], plo[j][3]);
                 l.z = lo2(v.z, phi[j][0], phi[j][1]); l.w = lo2(v.w, phi[j][2], phi[j][3]);
-                *reinterpret_cast<uint4*>(patch + PATCH_BYTES + p * PP + cpiece * 16) = l;
+                *reinterpret_cast<uint4*>(patch + PATCH_BYTES + a_lds[j] + cpiece * 16) = l;
             }
         }
     };
@@ -213,7 +235,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             const int row = j * 32 + (lt >> 3), g = row / NCH, cl = row - g * NCH;
-            const int piece = (lt & 7) ^ (row & 7);
+            const int piece = (lt & 7) ^ ring_swizzle<NCH, LSTM>(row);
             const int grow = LSTM ? g * C + nblk * NCH + cl : nblk * BN + row;
             wsrc[j] = reinterpret_cast<const unsigned char*>(wb) + (size_t)grow * 128 + piece * 16;
         }
@@ -302,7 +324,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     for (int mt = 0; mt < 2; ++mt) {
         const int i = 64 * wm + 32 * mt + l31;
         const int ti = tw == 16 ? 0 : i >> 6, ay = tw == 16 ? i >> 4 : (i >> 3) & 7, ax = tw == 16 ? i & 15 : i & 7;
-        a_off[mt] = ((ti * PH + ay) * PW + ax) * PP + half * 16;
+        a_off[mt] = (ti * PH + ay) * RP + ax * PP + half * 16;
     }
     // B: MFMA column l31 of tile t = gate t * GPT + l31 / CPW, channel wn * CPW + l31 % CPW; ring row = gate * NCH + channel
     int b_row[TPW], b_sw[4];
@@ -310,7 +332,8 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     for (int t = 0; t < TPW; ++t)
         b_row[t] = (LSTM ? (t * GPT + l31 / CPW) * NCH + wn * CPW + (l31 % CPW) : (wn * TPW + t) * 32 + l31) * 128;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) b_sw[ks] = ((2 * ks + half) ^ (l31 & 7)) * 16;    // row % 8 == l31 % 8 (NCH, CPW multiples of 8)
+    for (int ks = 0; ks < 4; ++ks)      // (the tiles of a wave are 32 or 64 ring rows apart: one swizzle value serves them all)
+        b_sw[ks] = ((2 * ks + half) ^ ring_swizzle<NCH, LSTM>(b_row[0] >> 7)) * 16;
 
     // LDS reads go through inline asm: hipcc knows that an LDS-DMA writes LDS and puts s_waitcnt vmcnt(0) in front of every
     // ds_read it can see.  The waits below are explicit instead.
@@ -327,7 +350,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     auto read_frags = [&](auto SET, auto KS, int tp, int slot) {   // fragments of k-step KS of tap tp (weights in ring slot `slot`)
         constexpr int st = decltype(SET)::value, ks = decltype(KS)::value;
         const int ty = tp / 5, tx = tp - ty * 5;
-        const unsigned ab = lds0 + (ty * PW + tx) * PP;
+        const unsigned ab = lds0 + ty * RP + tx * PP;
         const unsigned bb = lds0 + PL * PATCH_BYTES + slot * SLOT + b_sw[ks];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) fa[st][mt] = lds_read_b128<ks * 32>(ab + a_off[mt]);

@@ -26,11 +26,16 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int GP = 272;                // dG image row pitch (bytes): 128 bf16 + 16
-constexpr int XP = 80;                 // X strip pixel pitch (bytes): 32 bf16 + 16
-constexpr int G_BYTES = 128 * GP;      // 34,816
+// Row pitches for the transposing reads.  The 32 lanes of a ds_read_b64_tr_b16 phase (banks = dword address mod 64) cover 4 consecutive
+// image rows x 32 columns = 4 x 64 B, so they are conflict-free iff the row pitch is 16 dwords (mod 64): 256 + 64 B for the dG image, and
+// exactly the 64 B of a strip pixel's 32 channels (no padding) for the X strip.  The first version padded both by 16 B (pitches of 68
+// and 20 dwords): rows 4 dwords / 20 dwords apart overlap in the banks, two passes per read (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE =
+// 0.50, profiles/r03).  The staging writes (8 B per lane, a row's lanes contiguous) are conflict-free at any pitch.
+constexpr int GP = 320;                // dG image row pitch (bytes): 128 bf16 + 64
+constexpr int XP = 64;                 // X strip pixel pitch (bytes): 32 bf16
+constexpr int G_BYTES = 128 * GP;      // 40,960
 constexpr int XPIX = 192;              // strip pixels allocated (8 x 20 = 160, or 2 x 8 x 12 = 192)
-constexpr int X_BYTES = XPIX * XP;     // 15,360
+constexpr int X_BYTES = XPIX * XP;     // 12,288
 
 __device__ __forceinline__ unsigned wpack2(float a, float b) {
     f32x2 v = {a, b};

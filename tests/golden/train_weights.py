@@ -5,7 +5,8 @@
 
 Random-init weights amplify a rounding error ~1.5x per fed-back step, which is what made plain float32 miss 1e-4 on the STP and 20-step
 fixtures of round 2.  A trained model is the case the reference is used in: `optimizer.update` (TM:950) with Adam(1e-3) on
-`R.moving_batch` sequences (a fresh batch of 32 per step, feed-self), starting from the fixtures' usual `R.init_params(seed=1)`.
+`R.moving_batch` sequences (a fresh batch of 32 per step; scheduled sampling with the reference's default k = 900, TM:785, so the
+first thousands of steps are fed ground truth), starting from the fixtures' usual `R.init_params(seed=1)`.
 The result is stored as int8 deltas (tests/golden/trained_weights.py); the file is copied into tests/golden/ and committed, and
 `make_golden.py trained` runs the float64 and float32 oracles on it HERE (CPU).  The loss with the exact and with the stored weights
 is printed so that the quantisation is seen to keep the model trained."""
@@ -32,15 +33,24 @@ def main():
     ap.add_argument('--seq-len', type=int, default=10)
     ap.add_argument('--lr', type=float, default=1e-3)
     ap.add_argument('--freeze', default='', help='comma-separated parameter keys that keep their initial value (smaller file)')
+    ap.add_argument('--schedsamp-k', type=float, default=900.0, help='TM:785; -1 = feed-self from the first step')
+    ap.add_argument('--workers', type=int, default=12, help='host processes that generate the batches ahead of the GPU')
     ap.add_argument('--out', required=True)
     args = ap.parse_args()
+    # the batch generators are forked BEFORE anything initialises the GPU (a process that has must not be forked)
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    pool = cf.ProcessPoolExecutor(args.workers, mp_context=mp.get_context('fork'))
+    depth = 3 * args.workers
+    pending = [pool.submit(R.moving_batch, args.batch, args.seq_len, args.size, args.size, 1000 + i) for i in range(min(depth, args.steps))]
     import torch
     import pivp_amd
     assert torch.cuda.is_available()
     nm = 1 if args.model == 'DNA' else 10
     kinds = dict(is_cdna=args.model == 'CDNA', is_stp=args.model == 'STP', is_dna=args.model == 'DNA')
     P0 = R.init_params(seed=1, dtype=np.float32, scale=1.0, num_masks=nm, model_type=args.model, height=args.size, width=args.size)
-    m = pivp_amd.Model(nm, prefix='fixture', keep_activations=True, **kinds)
+    m = pivp_amd.Model(nm, prefix='fixture', keep_activations=True, scheduled_sampling_k=args.schedsamp_k, **kinds)
+    np.random.seed(11)                                                     # scheduled_sample draws from NumPy's global RNG (TM:94)
     m.load_state_dict_reference(P0)
     opt = pivp_amd.Adam(alpha=args.lr).setup(m)
     frozen = [k for k in args.freeze.split(',') if k]
@@ -62,15 +72,18 @@ def main():
     t0 = time.time()
     with pivp_amd.using_config('train', True):
         for it in range(args.steps):
-            x = R.moving_batch(args.batch, args.seq_len, S, S, seed=1000 + it)
+            x = pending.pop(0).result()
+            if it + depth < args.steps:
+                pending.append(pool.submit(R.moving_batch, args.batch, args.seq_len, S, S, 1000 + it + depth))
             m.reset_state()
-            loss = m(list(x), it)                                          # scheduled_sampling_k = -1: feed-self (TM:649-657)
+            loss = m(list(x), it)
             m.cleargrads(); m.backward()
             for k in frozen:
                 m._grads[k].zero_()
             opt.step(m)
             if it % 50 == 0 or it == args.steps - 1:
                 print('step %5d  loss %.6f  (%.0f s)' % (it, float(loss), time.time() - t0), flush=True)
+    pool.shutdown()
     evaluate('after %d steps' % args.steps)
     W = m.state_dict_reference()
     out = {}
