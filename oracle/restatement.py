@@ -304,14 +304,15 @@ def moving_batch(batch, seq_len=10, height=64, width=64, seed=0, dtype=np.float3
         v[t] = vel + jit[t]
         p = np.clip(p + v[t], 1.0, 2.0 * margin - 2.0)
     v[:-1] = pos[1:] - pos[:-1]                                    # the displacement actually applied (after clipping)
-    images = np.empty((seq_len, batch, 3, height, width))
+    # bilinear crop: the (H + 1) x (W + 1) scene window of every (t, b) at its integer position, then one vectorised blend
+    x0 = np.floor(pos[..., 0]).astype(np.int64); y0 = np.floor(pos[..., 1]).astype(np.int64)
+    fx = (pos[..., 0] - x0)[:, :, None, None, None]; fy = (pos[..., 1] - y0)[:, :, None, None, None]
+    g = np.empty((seq_len, batch, 3, height + 1, width + 1))
     for t in range(seq_len):
         for b in range(batch):
-            x0, y0 = int(np.floor(pos[t, b, 0])), int(np.floor(pos[t, b, 1]))
-            fx, fy = pos[t, b, 0] - x0, pos[t, b, 1] - y0
-            s = scene[b]
-            images[t, b] = ((1 - fy) * (1 - fx) * s[:, y0:y0 + height, x0:x0 + width] + (1 - fy) * fx * s[:, y0:y0 + height, x0 + 1:x0 + 1 + width]
-                            + fy * (1 - fx) * s[:, y0 + 1:y0 + 1 + height, x0:x0 + width] + fy * fx * s[:, y0 + 1:y0 + 1 + height, x0 + 1:x0 + 1 + width])
+            g[t, b] = scene[b, :, y0[t, b]:y0[t, b] + height + 1, x0[t, b]:x0[t, b] + width + 1]
+    images = ((1 - fy) * (1 - fx) * g[..., :-1, :-1] + (1 - fy) * fx * g[..., :-1, 1:]
+              + fy * (1 - fx) * g[..., 1:, :-1] + fy * fx * g[..., 1:, 1:])
     actions = np.zeros((seq_len, batch, 5)); states = np.zeros((seq_len, batch, 5))
     actions[:, :, :2] = v / 4.0
     states[:, :, :2] = (pos - margin) / 16.0

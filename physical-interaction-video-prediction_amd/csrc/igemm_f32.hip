@@ -77,8 +77,10 @@ __device__ __forceinline__ float fast_tanh(float x) {
 }
 
 #ifdef PIVP_F32_STAMPS   // per-block phase stamps (constant-rate 100 MHz counter) of the kernel: scripts/f32_stamps.py
-__device__ long long pivp_f32_stamps[2048 * 4];
-#define F32_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048 && blockIdx.y == 0 && blockIdx.z == 0) pivp_f32_stamps[blockIdx.x * 4 + (i)] = (long long)wall_clock64(); } while (0)
+// second half of the array: the shader-cycle counter (s_memtime) at the same points; cycles / wall = the clock the chip holds in that phase
+__device__ long long pivp_f32_stamps[2048 * 8];
+#define F32_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048 && blockIdx.y == 0 && blockIdx.z == 0) { \
+    pivp_f32_stamps[blockIdx.x * 4 + (i)] = (long long)wall_clock64(); pivp_f32_stamps[2048 * 4 + blockIdx.x * 4 + (i)] = (long long)clock64(); } } while (0)
 #else
 #define F32_STAMP(i)
 #endif
@@ -139,10 +141,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
     const int z_begin = ksplit > 1 ? (int)(((long)nchunks_tot * (int)blockIdx.z) / ksplit) : 0;
     const int z_end = ksplit > 1 ? (int)(((long)nchunks_tot * ((int)blockIdx.z + 1)) / ksplit) : nchunks_tot;
     const int nchunks_all = z_end - z_begin;
-    // KG = 2 with an odd chunk count (lstm3: 75): both groups run ceil(n / 2) chunks through the same barriers, and group 1's last one is
-    // chunk index n, one past the end: its tap bit (row ksize of the 5 x 5 mask) is in no anchor's mask, so its A tile is the hardware
-    // zero of out-of-range loads and it adds nothing (ConvLSTM launches never split K over z)
-    const int nchunks = (nchunks_all + KG - 1) / KG;
+    const int nchunks = nchunks_all / KG;               // (KG = 2: the launcher only takes this form for an even chunk count)
     const int chunk0 = z_begin + gid * nchunks;         // this block's / group's first chunk
     const int HWg = d.Hg * d.Wg;
 
@@ -232,10 +231,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
         s_delta = __builtin_amdgcn_readfirstlane(((t_dy * d.Win + t_dx) * s_ld + t_cbase) * 4);   // bytes, relative to the anchor pixel
     };
     auto stage_c = [&]() {
-        // (KG = 2, odd chunk count: group 1's one-past-the-end chunk multiplies its all-zero A tile with tap 0's weights -- the scalar
-        // offset of a buffer load is not range-checked, so it must stay inside the weight)
-        const int wi = (KG > 1 && t_wi >= d.ksize * d.ksize) ? 0 : t_wi;
-        s_wbase = __builtin_amdgcn_readfirstlane((wi * (d.wcin >> 5) + l_cc) * (d.wN ? d.wN : d.N) * 128);       // bytes; the weight keeps all its Cin chunks
+        s_wbase = __builtin_amdgcn_readfirstlane((t_wi * (d.wcin >> 5) + l_cc) * (d.wN ? d.wN : d.N) * 128);       // bytes; the weight keeps all its Cin chunks
         ++l_cc;
         const bool w0 = l_cc == ncc;
         l_cc = w0 ? 0 : l_cc;
@@ -402,24 +398,10 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
         if constexpr (PRE > 0) stage_begin();   // parameters of chunk 2, loaded while chunk 0 is consumed
         __syncthreads();
         F32_STAMP(1);
-        // Two blocks of this kernel share a CU (one wave of each per SIMD), and at equal priority the matrix pipe goes to the OLDER wave
-        // first: the block that was dispatched first leaves its loop at 91 us, the other at 116 us, so every CU spends its last fifth with
-        // one wave per SIMD and every wait exposed (scripts/f32_stamps.py, profiles/r02/NOTES.md).  Priority outranks age, so a block
-        // lowers its own priority as it advances (3 until half of its chunks are done, then 2, 1, 0 at 80 % and 95 %): whichever block is
-        // behind has the higher or equal priority, the lead a block can build is what the older one gains over ONE stage, and the stages
-        // shrink towards the end.  (KG = 2 blocks have their CU to themselves and run their two groups in lockstep: no stairs.)
-        const bool stairs = KG == 1 && d.prio_stairs != 0;
-        const int st1 = (nchunks >> 1) & ~1, st2 = (nchunks * 4 / 5) & ~1, st3 = (nchunks * 19 / 20) & ~1;
-        if (stairs) __builtin_amdgcn_s_setprio(3);
         // two chunks per trip: the register sets alternate statically (a run-time parity branch makes hipcc wait vmcnt(0) in
         // front of every ds_write); `it` stays even
         int it = 0;
         for (; it + 3 < nchunks; it += 2) {
-            if (stairs) {
-                if (it == st1) __builtin_amdgcn_s_setprio(2);
-                else if (it == st2) __builtin_amdgcn_s_setprio(1);
-                else if (it == st3) __builtin_amdgcn_s_setprio(0);
-            }
             chunk(std::true_type{}, std::true_type{}, S0{}, S0{}, 0); sync();
             chunk(std::true_type{}, std::true_type{}, S1{}, S1{}, 1); sync();
         }
@@ -436,7 +418,6 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
         }
     }
     F32_STAMP(2);
-    if constexpr (KG == 1) { if (d.prio_stairs) __builtin_amdgcn_s_setprio(0); }
     if constexpr (NACC > 1) {   // join the chains pairwise, fixed order
 #pragma unroll
         for (int t = 0; t < TPW; ++t)
@@ -620,10 +601,6 @@ static int launch_igemm(const IgemmDesc& d, hipStream_t stream, int ksplit = 1, 
     dd.ln_nparts = (d.ln_part && ksplit == 1 && hwg % BM == 0 && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
-    {   // PIVP_PRIO_STAIRS (default 1): the progress-priority staircase of co-resident blocks (see the kernel's main loop); 0 = off
-        static const int stairs = [] { const char* e = getenv("PIVP_PRIO_STAIRS"); return e ? atoi(e) : 1; }();
-        dd.prio_stairs = (KG == 1 && stairs) ? 1 : 0;
-    }
     hipLaunchKernelGGL((igemm_f32_kernel<WM, WN, NTB, LSTM, ABL, KG>), grid, dim3(256 * KG), lds_bytes, stream, dd);
     return PIVP_LAUNCH_STATUS();
 }
@@ -685,13 +662,16 @@ int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant, int* ln_npar
     // layers that fill the chip: lstm1 126 -> 119.5 TF, lstm7 135.5 -> 132, rollout 8.67 -> 8.86 ms; 46 VGPRs spill under the 256 cap.  Not kept.)
     switch (variant) {
         case 4:   // 64-row tile as two K groups of 4 waves (two waves per SIMD where the grid gives every CU one block): lstm4 106.6 -> 104.6 us,
-                  // lstm6 153.6 -> 150.2 at B = 32
-            return launch_igemm<2, 2, 4, true, 0, 2>(d, stream, 1, ln_nparts);   // (odd chunk counts: group 1 ends on an all-zero chunk)
+                  // lstm6 153.6 -> 150.2 at B = 32; needs an even chunk count (lstm3 has 75)
+            if (((25 * ((d.c0 + d.c1) >> 5)) & 1) == 0) return launch_igemm<2, 2, 4, true, 0, 2>(d, stream, 1, ln_nparts);
+            return launch_igemm<2, 2, 4, true>(d, stream, 1, ln_nparts);
         case 1: return launch_igemm<4, 1, 4, true>(d, stream, 1, ln_nparts);
         case 2: return launch_igemm<2, 2, 4, true>(d, stream, 1, ln_nparts);
         case 3: {
+            // the in-block K split needs an even number of chunks (25 taps x (c0 + c1) / 32: always even when the channel count is a multiple of 64)
             static const int kg = [] { const char* e = getenv("PIVP_LSTM_KG"); return e ? atoi(e) : 2; }();   // tuning: 1 = one group
-            if (kg == 2) return launch_igemm<1, 4, 4, true, 0, 2>(d, stream, 1, ln_nparts);
+            const int ncc = (d.c0 + d.c1) >> 5;
+            if (kg == 2 && ((25 * ncc) & 1) == 0) return launch_igemm<1, 4, 4, true, 0, 2>(d, stream, 1, ln_nparts);
             return launch_igemm<1, 4, 4, true>(d, stream, 1, ln_nparts);
         }
     }
@@ -804,7 +784,7 @@ int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
 }  // namespace pivp
 
 #ifdef PIVP_F32_STAMPS
-extern "C" int pivp_debug_f32_stamps(long long* out, int n) {   // n <= 2048 * 4 values: [block][entry, loop start, loop end, stores done]
+extern "C" int pivp_debug_f32_stamps(long long* out, int n) {   // n <= 2048 * 8 values: [block][entry, loop start, loop end, stores done] in 10 ns ticks, then the same in shader cycles
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(pivp::pivp_f32_stamps), sizeof(long long) * n) == hipSuccess ? 0 : -2;
 }
 #endif

@@ -42,7 +42,6 @@ struct IgemmDesc {
     // [B][Hin*Win][c0] (all c0 channels are normalised), in_g / in_b the norm's per-element gamma / beta ([Hin*Win][c0], the checkpoint's
     // flat order), in_part the producer's (count, mean, M2) partials [B][in_np][4].  Served by igemm_small only (igemm_in_ln_ok).
     const float* in_g; const float* in_b; const float* in_part; int in_np; float in_eps;
-    int prio_stairs;                     // igemm_f32_kernel: lower the wave priority as the block advances (set by the launcher)
 };
 
 // weight gradient of a conv / transposed conv (csrc/igemm_wgrad.hip)

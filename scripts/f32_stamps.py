@@ -24,9 +24,12 @@ for name, cx, C, H in [('lstm1', 32, 32, 32), ('lstm4', 64, 64, 16), ('lstm5', 6
     def launch():
         assert lib.pivp_convlstm_v(x.data_ptr(), cx, cx, h.data_ptr(), C, w.data_ptr(), b.data_ptr(), c.data_ptr(), co.data_ptr(),
                                    ho.data_ptr(), B, H, H, 0, st) == 0
-    for _ in range(3):
-        launch()
-    torch.cuda.synchronize()
+    import time
+    t_warm = time.time()                          # ~2 s of back-to-back launches first: the clock the chip HOLDS under this load, not a burst's
+    while time.time() - t_warm < float(__import__('os').environ.get('STAMP_WARM_S', '2')):
+        for _ in range(200):
+            launch()
+        torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
@@ -35,9 +38,13 @@ for name, cx, C, H in [('lstm1', 32, 32, 32), ('lstm4', 64, 64, 16), ('lstm5', 6
     nblk = min(2048, (B * H * H // 64) * (C // 32))
     if nblk < 256:
         nblk = min(2048, (B * H * H // 32) * (C // 32))
-    buf = (ctypes.c_longlong * (2048 * 4))()
-    assert so.pivp_debug_f32_stamps(buf, 2048 * 4) == 0
-    v = np.array(list(buf), dtype=np.int64).reshape(2048, 4)[:nblk] * 0.01     # us
+    buf = (ctypes.c_longlong * (2048 * 8))()
+    assert so.pivp_debug_f32_stamps(buf, 2048 * 8) == 0
+    raw = np.array(list(buf), dtype=np.int64).reshape(2, 2048, 4)
+    v = raw[0, :nblk] * 0.01     # us
+    cyc = raw[1, :nblk].astype(np.float64)
+    ghz = (cyc[:, 2] - cyc[:, 1]) / np.maximum(raw[0, :nblk, 2] - raw[0, :nblk, 1], 1) * 0.1      # cycles per 10 ns tick -> GHz
+    print('   shader clock held inside the K loop (s_memtime / s_memrealtime): median %.3f GHz, min %.3f, max %.3f' % (np.median(ghz), ghz.min(), ghz.max()))
     t0 = v[:, 0].min()
     ent, pro, loop, epi, end = v[:, 0] - t0, v[:, 1] - v[:, 0], v[:, 2] - v[:, 1], v[:, 3] - v[:, 2], v[:, 3] - t0
 

@@ -99,6 +99,52 @@ def run_full_batch_grads(model_type, num_masks, batch, seq_len, size=64):
     return out
 
 
+def run_trained(weights, model_type, num_masks, batch, seq_len, size, data_seed=7, weights_dir=None):
+    """TRAINED weights (tests/golden/<weights>.npz, made on the MI355X by train_weights.py, defined by trained_weights.load_trained) on a
+    held-out `R.moving_batch`: float64 oracle = the fixture's frames; float32 oracle (the reference's own arithmetic) = its distance from
+    them per (step, sample) and on the fixture's pixels.  VERDICT r02 item 1: is 1e-4 attainable in float32 on fed-back steps once the
+    recurrent map is the contractive one of a trained model?  Both distances are stored; tests/test_gpu_trained.py gates the HIP path."""
+    sys.path.insert(0, OUT)
+    import trained_weights as TW
+    if weights_dir:
+        TW.HERE = weights_dir
+    P32 = TW.load_trained(weights, R.init_params(seed=1, dtype=np.float32, scale=1.0, num_masks=num_masks, model_type=model_type, height=size, width=size))
+    P = type(P32)((k, v.astype(np.float64)) for k, v in P32.items())
+    imgs, acts, stas = R.moving_batch(batch, seq_len, size, size, seed=data_seed)
+    kw = dict(is_cdna=model_type == 'CDNA', is_stp=model_type == 'STP', is_dna=model_type == 'DNA')
+    m = R.Model(num_masks, params=P, dtype=np.float64, prefix='golden', **kw)
+    m.train = False
+    last = seq_len - 2
+    loss = m([imgs, acts, stas], 0, tap_steps=(last,))
+    gen = np.stack(m.gen_images)
+    pix = np.ascontiguousarray(gen.transpose(0, 1, 3, 4, 2)).reshape(-1, 3)[::PIXEL_STRIDE]
+    # what the composite is made of at the last (fed-back) step: mean weight of mask 0 (previous frame), mask 1 (generated pixels) and of
+    # the motion-transformed layers -- a trained model must actually USE the transforms for the fixture to exercise them
+    mk = m.taps[last]['masks'].mean(axis=(0, 2, 3))
+    print('  mean mask weights at step %d: prev %.3f, generated %.3f, transformed %.3f' % (last, mk[0], mk[1], mk[2:].sum()))
+    m32 = R.Model(num_masks, params=P32, dtype=np.float32, prefix='golden', **kw)
+    m32.train = False
+    loss32 = m32([imgs, acts, stas], 0)
+    l2 = R.per_pixel_l2(np.stack(m32.gen_images), gen)             # (T-1, B, H, W)
+    copy_mse = float(((imgs[1:] - imgs[:-1]) ** 2).mean()); pred_mse = float(((imgs[1:] - gen) ** 2).mean())
+    print('%s: loss %.6f  mse(pred, next) %.6f  mse(prev, next) %.6f' % (weights, float(loss), pred_mse, copy_mse))
+    print('  float32 oracle vs float64, max per-pixel L2 per step:', ['%.1e' % v for v in l2.max(axis=(1, 2, 3))])
+    return dict(loss=np.float64(loss), psnr_all=np.float64(m.psnr_all), gen_pixels=pix.astype(np.float32),
+                gen_states=np.stack(m.gen_states).astype(np.float32), pixel_stride=PIXEL_STRIDE,
+                frame_mean=gen.mean(axis=(2, 3, 4)).astype(np.float64), batch=batch, seq_len=seq_len, num_masks=num_masks, size=size,
+                data_seed=data_seed, weights=weights, model_type=model_type,
+                param_checksum=np.float64(sum(float(np.abs(v).sum()) for v in P.values())),
+                pred_mse=np.float64(pred_mse), copy_mse=np.float64(copy_mse), fp32_oracle_loss=np.float64(loss32), mask_means=mk.astype(np.float64),
+                fp32_oracle_max_l2=l2.max(axis=(2, 3)).astype(np.float64),
+                fp32_oracle_pixels_l2=l2.reshape(-1)[::PIXEL_STRIDE].astype(np.float32))
+
+
+TRAINED = {   # fixture name: (weights file stem, model_type, batch, seq_len, frame size)
+    'stp_b32_t10_trained': ('trained_stp64_q8', 'STP', 32, 10, 64),            # BASELINE.json config 4 with trained weights
+    'stp_b2_t20_trained': ('trained_stp64_q8', 'STP', 2, 20, 64),              # ... and a 20-step rollout of the same model
+    'cdna_128_b2_t20_trained': ('trained_cdna128_q8', 'CDNA', 2, 20, 128),     # config 5's geometry (128x128, 20 frames), trained
+}
+
 FULL_BATCH = {   # name: (model_type, batch, seq_len, frame size, smooth, fp32_error)
     'cdna_b32_t10': ('CDNA', 32, 10, 64, False, False),            # BASELINE.json config 2
     'stp_b32_t10': ('STP', 32, 10, 64, False, True),               # config 4, white-noise frames
@@ -111,6 +157,16 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'grads':               # a few minutes of PyTorch-CPU float64
         np.savez_compressed(os.path.join(OUT, 'cdna_b32_t10_grads.npz'), **run_full_batch_grads('CDNA', 10, 32, 10))
         print('cdna_b32_t10_grads', os.path.getsize(os.path.join(OUT, 'cdna_b32_t10_grads.npz')))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'trained':             # needs tests/golden/trained_*_q8.npz (train_weights.py on the GPU box)
+        wdir = os.environ.get('PIVP_TRAINED_DIR')                  # dry runs on weights that are not committed yet
+        for name, (wt, mt, nb, nt, size) in TRAINED.items():
+            if len(sys.argv) > 2 and sys.argv[2] != name:
+                continue
+            out = run_trained(wt, mt, 10, nb, nt, size, weights_dir=wdir)
+            if not wdir:
+                np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+                print(name, os.path.getsize(os.path.join(OUT, name + '.npz')))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'b32':                 # 1-3 min of NumPy each
         for name, (mt, nb, nt, size, smooth, f32e) in FULL_BATCH.items():
