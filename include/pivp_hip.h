@@ -209,6 +209,11 @@ int pivp_conv5x5_bf16x3(const float* x, int cin, int ldx, const float* w, void* 
  * the map geometry of pivp_convlstm_bf16. */
 int pivp_wgrad5x5_bf16(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW, float* db,
                        int B, int H, int W, void* stream);
+/* The same for a batch of `tcount` timesteps in one launch (the reduction of a weight gradient runs over pixels AND timesteps: the
+ * BPTT sweep of optimizer.update, TM:950, visits every cell T-1 times): timestep j reads x + j*ts_x, h_prev + j*ts_h, dG + j*ts_dG
+ * (byte strides, multiples of 16, may be negative). */
+int pivp_wgrad5x5_bf16_batch(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW, float* db,
+                             int B, int H, int W, int tcount, long long ts_x, long long ts_h, long long ts_dG, void* stream);
 
 /* --- training (what Chainer's autograd does under optimizer.update, TM:950) ---------------------------------- */
 /* pivp_convlstm with the gate activations kept for BPTT: gates_out [B*H*W][4C] = tanh(j), s(i), s(f+1), s(o). */

@@ -403,6 +403,14 @@ extern "C" int pivp_wgrad5x5_bf16(const float* x, int cx, int ldx, const float* 
     return run_wgrad(0, x, cx, ldx, h_prev, C, C, cx + C, dG, 4 * C, 4 * C, dW, B, H, W, H, W, 5, 2, 1, (hipStream_t)stream, db,
                      nullptr, 1);
 }
+// ... of a BATCH of timesteps in one launch (the sum over pixels runs over timesteps too): timestep j reads x + j * ts_x, h_prev + j * ts_h,
+// dG + j * ts_dG (byte strides, multiples of 16, may be negative: the backward sweep walks time downwards)
+extern "C" int pivp_wgrad5x5_bf16_batch(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW, float* db,
+                                        int B, int H, int W, int tcount, long long ts_x, long long ts_h, long long ts_dG, void* stream) {
+    if (!x || !dG || !dW || C <= 0 || cx <= 0 || tcount < 1) return PIVP_ERR_BADARG;
+    return run_wgrad(0, x, cx, ldx, h_prev, C, C, cx + C, dG, 4 * C, 4 * C, dW, B, H, W, H, W, 5, 2, 1, (hipStream_t)stream, db,
+                     nullptr, 1, tcount, ts_x, ts_h, ts_dG);
+}
 static int convlstm_ln_cap(int H, int W, int C) {
     const int tiles = ((H * W + 31) / 32) * (C / 32), slices = ln_stats_slices(H * W * C);
     return tiles > slices ? tiles : slices;

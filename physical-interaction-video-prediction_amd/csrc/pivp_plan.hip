@@ -46,7 +46,7 @@ static int ln_partial_cap(int HW) {
 // gradients then arrive in bursts instead of filling the gaps of every step.  So the default is one timestep per launch
 // (PIVP_WGRAD_BATCH=1), the dG rings then simply double-buffer; the batched path stays for larger per-GPU batches and is tested
 // (tests/test_gpu_train.py).  Timestep 0 is always its own batch (its h_{-1} = 0 half is skipped).
-constexpr int WG_BATCH = 4;
+constexpr int WG_BATCH_MAX = 8;   // most timesteps one ConvLSTM weight-gradient launch can take (dG ring slots per ring: pivp_plan::wg_cap <= this)
 
 struct Slab {
     size_t cat7, n1, n2, cat6, n3, n4, e2, e3, n5, e4, e5, e6;   // NHWC feature maps (cat7 = [hidden7|enc0], cat6 = [hidden6|enc1])
@@ -61,7 +61,7 @@ struct Slab {
 struct Grads {   // gradient workspace (single copy, reused by every timestep of the backward sweep)
     size_t cat7, n2, cat6, n4, e2, n5, e6, e6raw, e0raw;
     size_t din[7][2], dc[7];
-    size_t dG[7], go[2], dmk, dz, dkpart, dv, dstate, lnpart;   // dG: gate pre-activation gradients per ConvLSTM: 2 rings x WG_BATCH timesteps (batched weight gradients)
+    size_t dG[7], go[2], dmk, dz, dkpart, dv, dstate, lnpart;   // dG: gate pre-activation gradients per ConvLSTM: 2 rings x wg_cap timesteps (batched weight gradients)
     size_t wt_lstm[7], wt_enc[7];   // re-packed (transposed) weights for the data gradients, rebuilt once per backward
     size_t ln_ppart[9], ln_ppart_floats;   // per-norm partial parameter gradients (ln_backward's param_part), one contiguous region
     size_t wg_part[5], wg_part_floats;   // per-block partial weight gradients of enc6, enc5, enc4, enc2, enc1 (WgradDesc::part), one contiguous region
@@ -106,7 +106,8 @@ struct pivp_plan {
     hipStream_t side_of(int slot) const { return (side2 && (slot & 1)) ? side2 : side; }
     hipEvent_t ev_ready[NSLOT] = {}, ev_done[NSLOT] = {};
     hipEvent_t ev_ring_done[7][2] = {};        // ConvLSTM slots: one `done` per dG ring (slots 0..6 of ev_done are unused)
-    int wg_batch = 1;                          // timesteps per weight-gradient launch (<= WG_BATCH; always 1 in the bf16 mode, whose kernel takes one)
+    int wg_cap = 1;                            // dG ring slots per ring = min(T - 2, WG_BATCH_MAX), fixed when the workspace is laid out
+    int wg_batch = 1;                          // timesteps per weight-gradient launch (<= wg_cap)
     const float* wg_x[7] = {}; const float* wg_h[7] = {};   // operands of the first timestep of the open batch
     bool group_join = true;                                 // pivp_plan_set_group_join
     bool ln_touched[9] = {};                                // norms whose partial parameter gradients still await their reduction
@@ -203,6 +204,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
     for (int i = 0; i < 7; ++i)       // 2-byte elements in a float-counted workspace
         p->o_wbf16[i] = carve(lstm_bf16_weight_elems(kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C));   // room for the two planes of the split mode
     p->nslabs = train ? T - 1 : 2;
+    p->wg_cap = T - 2 < 1 ? 1 : (T - 2 > WG_BATCH_MAX ? WG_BATCH_MAX : T - 2);   // timesteps t = T-2 .. 1 batch; t = 0 (no h input) goes alone
     p->slabs.resize(p->nslabs);
     for (int s = 0; s < p->nslabs; ++s) {
         Slab& S = p->slabs[s];
@@ -228,7 +230,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
             const size_t M = hsz[i] / kLstm[i].C * B;
             g.dc[i] = carve(B * hsz[i]);   // (d h of a cell is never materialised: the LayerNorm backward is folded into the gate backward)
             g.din[i][0] = carve(M * (kLstm[i].cx + kLstm[i].C)); g.din[i][1] = carve(M * (kLstm[i].cx + kLstm[i].C));
-            g.dG[i] = carve(M * 4 * kLstm[i].C * 2 * WG_BATCH);
+            g.dG[i] = carve(M * 4 * kLstm[i].C * 2 * p->wg_cap);
             g.wt_lstm[i] = carve((size_t)25 * (kLstm[i].cx + kLstm[i].C) * 4 * kLstm[i].C);
             g.wtb_lstm[i] = carve(lstm_bf16_weight_elems(4 * kLstm[i].C, conv5x5_bf16_rows(kLstm[i].cx + kLstm[i].C)));   // two planes
             g.wt_enc[i] = (i == 0 || i == 3) ? 0 : carve((size_t)encw[i]);
@@ -608,7 +610,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         const LstmSpec& L = kLstm[i];
         const int cin = L.cx + L.C, N = 4 * L.C;
         const size_t dG1 = (size_t)B * hh * wwid * N;                      // floats of one timestep's dG
-        float* ring = ws + g.dG[i] + (size_t)wg_ring * WG_BATCH * dG1;
+        float* ring = ws + g.dG[i] + (size_t)wg_ring * p->wg_cap * dG1;
         const float* h_prev = Sp ? ws + Sp->h[i] : nullptr;
         SideFork f;
         if (wg_slot == 0) {     // a new batch: the ring's previous weight-gradient launch (two batches ago) must have read it
@@ -798,12 +800,15 @@ static int rollout_backward_sweep(pivp_plan_t* plan, const float* images, const 
     const float fscale = 2.0f / ((float)fr * (float)(T - ctx));              // d/d gen of mean-squared error / (T - ctx)
     const float sscale = 2.0f * 1e-4f / ((float)(B * 5) * (float)(T - ctx));
     RC(ensure_side(plan));
-    {   // PIVP_WGRAD_BATCH (1..WG_BATCH): experiment knob; the bf16 weight-gradient kernel takes one timestep per launch
+    {   // Timesteps per ConvLSTM weight-gradient launch (PIVP_WGRAD_BATCH overrides, 1..wg_cap).  fp32: 1 (batches arrive in bursts and
+        // overlap the sweep worse: 29.9 / 30.3 ms for 1 / 2, profiles/r02).  bf16 mode: as many as the rings hold -- its 25-tap kernel
+        // fetches every operand tile once per 32 x 64 output slice, and what a block pays per launch (205 KB of atomics, the first tile's
+        // latency) is amortised over the batch (csrc/wgrad_bf16.hip).
         const char* e = getenv("PIVP_WGRAD_BATCH");
-        int gb = e ? atoi(e) : 1;
+        int gb = e ? atoi(e) : (plan->bf16_all ? plan->wg_cap : 1);
         if (gb < 1) gb = 1;
-        if (gb > WG_BATCH) gb = WG_BATCH;
-        plan->wg_batch = plan->bf16_all ? 1 : gb;
+        if (gb > plan->wg_cap) gb = plan->wg_cap;
+        plan->wg_batch = gb;
     }
     // the enc convs' per-block partial weight gradients and the norms' partial parameter gradients start from zero every sweep
     if (hipMemsetAsync(ws + g.wg_part[0], 0, g.wg_part_floats * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;

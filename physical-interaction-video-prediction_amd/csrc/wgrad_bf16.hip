@@ -202,16 +202,218 @@ __global__ __launch_bounds__(256, 2) void wgrad5x5_bf16_kernel(const WgradDesc d
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// All 25 taps per block, timesteps batched (round 3).  The kernel above gives a block ONE kernel row (5 taps) of a 32-channel x 128-column
+// slice, so every 128-pixel tile of dG is fetched (fp32, 64 KB) and converted by 5 x cin/32 blocks: 215 MB of L2 traffic per lstm1 launch
+// for 13.4 GFLOP, 62 FLOP per byte -- it runs at the rate the operands arrive, not at the matrix cores' (profiles/r03: 75 us per launch,
+// 0.07 of the bf16 peak), and a third of each launch is the 20,480 atomics every block ends with.  Here a block of EIGHT waves owns all 25
+// taps of a 32-channel x 64-column slice (50 MFMA tiles of 32 n x 32 ci: wave w takes column half w & 1 and taps (w >> 1) + 4 i, 7 or 6
+// accumulator tiles = 112 registers), fed from one dG tile [128 px][64 n] and one X PATCH [8 + 4 rows][16 + 4 columns][32 ci] (two images of
+// 8 x 8 + halo on the 8-wide maps): 210 FLOP per fetched byte.  The weight gradient sums over pixels AND timesteps, so a launch takes a
+// batch of timesteps (WgradDesc::tcount, operands at signed byte strides): more tiles per block, and the partial sums of a block leave it
+// once per batch.  Pixel splits meet in dW by fp32 atomic adds in full-rate shape (two contiguous 128-B rows per wave-instruction).
+// LDS images are [px][32 columns] with 64-B rows: the 32 lanes of a transposing read's phase cover 4 consecutive rows = the 64 banks.
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int W25_GH = 128 * 64 + 64;     // bytes of one 32-column half of the dG tile (+64: the two halves' staging writes use different banks)
+constexpr int W25_G_BYTES = 2 * W25_GH;   // 16,512
+constexpr int W25_XPIX = 320;             // patch pixels staged (12 x 20 = 240, or 2 x 12 x 12 = 288; 5 passes of 64)
+constexpr int W25_X_BYTES = W25_XPIX * 64;
+}  // namespace
+
+template <int TW>
+__global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d, int tiles_per_split) {
+    constexpr int tw = TW;
+    constexpr int ti_n = tw == 16 ? 1 : 2;
+    constexpr int PWC = tw + 4;                               // patch columns
+    constexpr int NPIX = ti_n * 12 * PWC;                     // 240 / 288
+    constexpr int NXJ = (NPIX + 63) / 64;                     // staging passes of the patch (64 pixels x 8 float4 each)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // dG halves | X patch
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = d.Hx, W = d.Wx, N = d.N;
+    const int ncb = d.cin >> 5;
+    const int cb = blockIdx.x % ncb, nb = blockIdx.x / ncb;   // 32 input channels x 64 gate columns
+    const int tpr = W / tw, tpi = (H / 8) * tpr;
+    const int n_tiles = (d.B / ti_n) * tpi;                   // per timestep
+    const int tcount = d.tcount > 1 ? d.tcount : 1;
+    const int g_end_all = n_tiles * tcount;
+    const int g_begin = blockIdx.y * tiles_per_split;
+    const int g_end = min(g_end_all, g_begin + tiles_per_split);
+
+    const int ch0 = cb * 32;
+    const bool src0 = ch0 < d.c0;
+    const char* xbase = reinterpret_cast<const char*>(src0 ? d.x0 : d.x1);
+    const long long xts = src0 ? d.ts_x0 : d.ts_x1;
+    const int xbytes = src0 ? d.bytes0 : d.bytes1;
+    const int ldx = src0 ? d.ld0 : d.ld1, cho = src0 ? ch0 : ch0 - d.c0;
+    constexpr unsigned OOB = 0xC0000000u;
+
+    // ---- staging: dG tile 128 px x 64 n = 2048 float4: thread -> (px = tid / 16 + 32 j, n4 = tid % 16), j < 4;
+    //               X patch NPIX px x 8 float4: thread -> (px = tid / 8 + 64 j, c4 = tid % 8), j < NXJ
+    f32x4 rg[4], rx[NXJ];
+    auto load_tile = [&](int gt) {
+        const int tj = __builtin_amdgcn_readfirstlane(tcount > 1 ? gt / n_tiles : 0);      // timestep of the batch (block-uniform)
+        const int t = gt - tj * n_tiles;
+        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase + (long long)tj * xts), 0, xbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(d.dy) + (long long)tj * d.ts_dy), 0, d.bytesy, 0x00020000);
+        const int b0 = (t / tpi) * ti_n, trem = t - (t / tpi) * tpi;
+        const int y0 = (trem / tpr) * 8, x0 = (trem - (trem / tpr) * tpr) * tw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = (tid >> 4) + 32 * j;                // anchor of the tile
+            const int ti = tw == 16 ? 0 : i >> 6, ay = tw == 16 ? i >> 4 : (i >> 3) & 7, ax = tw == 16 ? i & 15 : i & 7;
+            const int m = ((b0 + ti) * H + y0 + ay) * W + x0 + ax;
+            rg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy, (unsigned)((m * d.ldy + nb * 64 + (tid & 15) * 4) * 4), 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < NXJ; ++j) {
+            const int p = (tid >> 3) + 64 * j;                // patch pixel: [image][row][column]
+            const int ti = p / (12 * PWC), pr = p - ti * (12 * PWC);
+            const int py = pr / PWC, px = pr - py * PWC;
+            const int iy = y0 + py - 2, ix = x0 + px - 2;
+            const bool ok = p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const unsigned off = ok ? (unsigned)(((((b0 + ti) * H + iy) * W + ix) * ldx + cho + (tid & 7) * 4) * 4) : OOB;
+            rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
+        }
+    };
+    // bias gradient = column sums of dG (fp32, on its way into LDS): the blocks of channel block 0 see every dG element of their columns once
+    const bool do_bias = d.db != nullptr && cb == 0;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    auto store_tile = [&]() {
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bsum += rg[j];
+        }
+        const int n4 = tid & 15;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint2 v;
+            v.x = wpack2(rg[j][0], rg[j][1]); v.y = wpack2(rg[j][2], rg[j][3]);
+            *reinterpret_cast<uint2*>(lds + (n4 >> 3) * W25_GH + ((tid >> 4) + 32 * j) * 64 + (n4 & 7) * 8) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NXJ; ++j) {
+            uint2 v;                                          // (pixels past the patch carry the zeros of their out-of-range loads)
+            v.x = wpack2(rx[j][0], rx[j][1]); v.y = wpack2(rx[j][2], rx[j][3]);
+            *reinterpret_cast<uint2*>(lds + W25_G_BYTES + ((tid >> 3) + 64 * j) * 64 + (tid & 7) * 8) = v;
+        }
+    };
+
+    // ---- fragments (transposing reads, see the kernel above): lane (g = lane / 16, q = (lane % 16) / 4, p = lane % 4) addresses pixel
+    // k = 16 s + 8 (g / 2) + 4 j + q of k-step s, columns 16 (g % 2) + 4 p .. + 3 of the operand's 32
+    const int g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int nt = wave & 1, tg = wave >> 1;                  // this wave's 32 columns; its taps are tg, tg + 4, ... (< 25)
+    const unsigned a_base = lds0 + nt * W25_GH + (8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * p4) * 2;
+    const unsigned b_lane = lds0 + W25_G_BYTES + (TW == 16 ? 8 * (g >> 1) + q : (g >> 1) * PWC + q) * 64 + (16 * (g & 1) + 4 * p4) * 2;
+    unsigned b_base[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int tap = min(tg + 4 * i, 24), ky = tap / 5, kx = tap - ky * 5;
+        b_base[i] = b_lane + (ky * PWC + kx) * 64;
+    }
+    const bool seven = tg == 0;                               // taps 0, 4, ..., 24; the other three groups have six
+    auto a_off = [](int s, int j) constexpr { return (16 * s + 4 * j) * 64; };
+    auto b_off = [](int s, int j) constexpr {                 // patch pixel of k-step s, read j (relative to the tap's origin)
+        return (TW == 16 ? s * PWC + 4 * j : ((s >> 2) * 12 + 2 * (s & 3)) * PWC + 4 * j) * 64;
+    };
+
+    f32x16 acc[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    auto kstep = [&](auto S) {
+        constexpr int s = decltype(S)::value;
+        bf16x4 a0 = lds_read_tr<a_off(s, 0)>(a_base), a1 = lds_read_tr<a_off(s, 1)>(a_base);
+        bf16x4 b0[7], b1[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { b0[i] = lds_read_tr<b_off(s, 0)>(b_base[i]); b1[i] = lds_read_tr<b_off(s, 1)>(b_base[i]); }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]), "+v"(b1[2]),
+                     "+v"(b0[3]), "+v"(b1[3]), "+v"(b0[4]), "+v"(b1[4]), "+v"(b0[5]), "+v"(b1[5]), "+v"(b0[6]), "+v"(b1[6]));
+        const bf16x8 fa = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_shufflevector(b0[i], b1[i], 0, 1, 2, 3, 4, 5, 6, 7), acc[i], 0, 0, 0);
+        if (seven) acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_shufflevector(b0[6], b1[6], 0, 1, 2, 3, 4, 5, 6, 7), acc[6], 0, 0, 0);
+    };
+    if (g_begin < g_end) load_tile(g_begin);
+    for (int gt = g_begin; gt < g_end; ++gt) {
+        __syncthreads();                                       // every wave is done with the previous tile's images
+        store_tile();
+        __syncthreads();
+        if (gt + 1 < g_end) load_tile(gt + 1);                 // in flight while this tile is multiplied
+        kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{});
+        kstep(std::integral_constant<int, 2>{}); kstep(std::integral_constant<int, 3>{});
+        kstep(std::integral_constant<int, 4>{}); kstep(std::integral_constant<int, 5>{});
+        kstep(std::integral_constant<int, 6>{}); kstep(std::integral_constant<int, 7>{});
+    }
+
+    // ---- epilogue: accumulator row = n (8 (r / 4) + 4 (lane / 32) + r % 4 of the wave's 32), column = ci (lane % 32): a wave-instruction
+    // adds two contiguous 128-B rows of the K-inner packed gradient [tap][ci / 32][n][32] -----------------------------------------------
+    const int half = lane >> 5, l31 = lane & 31;
+    if (g_begin < g_end) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int tap = tg + 4 * i;
+            if (tap < 25) {
+                float* base = d.dw + ((size_t)(tap * (d.wcin >> 5) + cb) * N + nb * 64 + nt * 32) * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) atomicAdd(base + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32, acc[i][r]);
+            }
+        }
+    }
+    if (do_bias) {   // thread (tid / 16, n4 = tid % 16) holds the sums of columns 4 n4 .. 4 n4 + 3 over its pixels: lanes l, l ^ 16, l ^ 32, l ^ 48 pair up
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = bsum[e];
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (lane < 16) atomicAdd(d.db + nb * 64 + lane * 4 + e, v);
+        }
+    }
+}
+
 bool wgrad5x5_bf16_ok(const WgradDesc& d) {
     if (d.deconv || d.ksize != 5 || d.pad != 2 || d.stride != 1 || d.Hx != d.Hy || d.Wx != d.Wy) return false;
     if (d.N % 128 || d.cin % 32 || d.c0 % 32 || d.c1 % 32 || d.ld0 % 4 || d.ld1 % 4 || d.ldy % 4 || d.Hx % 8) return false;
+    if (d.tcount > 1 && (d.ts_x0 % 16 || d.ts_x1 % 16 || d.ts_dy % 16)) return false;
     if (d.Wx % 16 == 0) return true;
     return d.Wx % 8 == 0 && d.B % 2 == 0;
+}
+
+// the 25-tap kernel: grid = (cin / 32) x (N / 64) output slices x pixel splits over the tiles of ALL timesteps of the batch
+static int launch_wgrad25(const WgradDesc& d, hipStream_t s) {
+    constexpr int lds_bytes = W25_G_BYTES + W25_X_BYTES;
+    static PerDeviceOnce once16, once8;
+    if (pivp_ensure_dyn_lds(once16, reinterpret_cast<const void*>(&wgrad25_bf16_kernel<16>), lds_bytes) != PIVP_OK ||
+        pivp_ensure_dyn_lds(once8, reinterpret_cast<const void*>(&wgrad25_bf16_kernel<8>), lds_bytes) != PIVP_OK)
+        return PIVP_ERR_LAUNCH;
+    const int tw = d.Wx % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
+    const int n_tiles = (d.B / ti_n) * (d.Hx / 8) * (d.Wx / tw) * (d.tcount > 1 ? d.tcount : 1);
+    const int gx = (d.cin / 32) * (d.N / 64);
+    // Pixel splits: one block per CU (8 waves, ~70 KB of LDS), at least 2 tiles per block; every split ends with 25 x 32 x 64 atomic adds
+    // (205 KB: the batch of timesteps is what amortises them).  PIVP_WGB_SLOTS: block target (tuning).
+    static const int slots = [] { const char* e = getenv("PIVP_WGB_SLOTS"); return e ? atoi(e) : 0; }();
+    const int target = slots > 0 ? slots : pivp_cu_count();
+    int ns = (target + gx - 1) / gx;
+    if (ns > n_tiles / 2) ns = n_tiles / 2;
+    if (ns < 1) ns = 1;
+    const int tps = (n_tiles + ns - 1) / ns;
+    ns = (n_tiles + tps - 1) / tps;
+    if (tw == 16) hipLaunchKernelGGL(wgrad25_bf16_kernel<16>, dim3(gx, ns), dim3(512), lds_bytes, s, d, tps);
+    else hipLaunchKernelGGL(wgrad25_bf16_kernel<8>, dim3(gx, ns), dim3(512), lds_bytes, s, d, tps);
+    return PIVP_LAUNCH_STATUS();
 }
 
 // d as for igemm_wgrad (ConvLSTM case: 5x5, stride 1, pad 2); dW and, when d.db is set, the bias gradient accumulated with atomics.
 int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s) {
     PIVP_CHECK_ARG(d.x0 && d.dy && d.dw && wgrad5x5_bf16_ok(d) && (d.c1 == 0 || d.x1) && d.wcin >= d.cin && d.wcin % 32 == 0);
+    static const int kernel = [] { const char* e = getenv("PIVP_WGB_KERNEL"); return e ? atoi(e) : 25; }();   // tuning: 5 = one kernel row per block
+    if (kernel != 5) return launch_wgrad25(d, s);
+    PIVP_CHECK_ARG(d.tcount <= 1);                                                      // (that kernel takes one timestep)
     constexpr int lds_bytes = G_BYTES + X_BYTES;
     static PerDeviceOnce once16, once8;
     if (pivp_ensure_dyn_lds(once16, reinterpret_cast<const void*>(&wgrad5x5_bf16_kernel<16>), lds_bytes) != PIVP_OK ||

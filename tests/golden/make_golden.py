@@ -118,10 +118,13 @@ def run_trained(weights, model_type, num_masks, batch, seq_len, size, data_seed=
     loss = m([imgs, acts, stas], 0, tap_steps=(last,))
     gen = np.stack(m.gen_images)
     pix = np.ascontiguousarray(gen.transpose(0, 1, 3, 4, 2)).reshape(-1, 3)[::PIXEL_STRIDE]
-    # what the composite is made of at the last (fed-back) step: mean weight of mask 0 (previous frame), mask 1 (generated pixels) and of
-    # the motion-transformed layers -- a trained model must actually USE the transforms for the fixture to exercise them
-    mk = m.taps[last]['masks'].mean(axis=(0, 2, 3))
-    print('  mean mask weights at step %d: prev %.3f, generated %.3f, transformed %.3f' % (last, mk[0], mk[1], mk[2:].sum()))
+    # what the composite is made of at the last (fed-back) step: the share of the output that comes through the motion-transformed layers
+    # (sum_k m_{k+2} T_k) -- the fixture must exercise the transforms.  (The MEAN of a mask plane says nothing: the flat-(NM+1) softmax,
+    # TM:720-722, normalises over 11 neighbouring pixels of ONE plane, so every plane averages 1/11 whatever the weights are.)
+    tp = m.taps[last]
+    moved = sum(layer * tp['masks'][:, k + 2:k + 3] for k, layer in enumerate(tp['transformed'][1:]) if k + 2 < num_masks + 1)
+    mk = np.float64(np.abs(moved).mean() / np.abs(tp['output']).mean())
+    print('  share of the step-%d output that comes through the transformed layers: %.3f' % (last, mk))
     m32 = R.Model(num_masks, params=P32, dtype=np.float32, prefix='golden', **kw)
     m32.train = False
     loss32 = m32([imgs, acts, stas], 0)
@@ -134,7 +137,7 @@ def run_trained(weights, model_type, num_masks, batch, seq_len, size, data_seed=
                 frame_mean=gen.mean(axis=(2, 3, 4)).astype(np.float64), batch=batch, seq_len=seq_len, num_masks=num_masks, size=size,
                 data_seed=data_seed, weights=weights, model_type=model_type,
                 param_checksum=np.float64(sum(float(np.abs(v).sum()) for v in P.values())),
-                pred_mse=np.float64(pred_mse), copy_mse=np.float64(copy_mse), fp32_oracle_loss=np.float64(loss32), mask_means=mk.astype(np.float64),
+                pred_mse=np.float64(pred_mse), copy_mse=np.float64(copy_mse), fp32_oracle_loss=np.float64(loss32), transformed_share=mk,
                 fp32_oracle_max_l2=l2.max(axis=(2, 3)).astype(np.float64),
                 fp32_oracle_pixels_l2=l2.reshape(-1)[::PIXEL_STRIDE].astype(np.float32))
 

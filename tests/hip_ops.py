@@ -263,3 +263,21 @@ def wgrad5x5_bf16(x, h, dG, h_is_zero=False):
                                       db.data_ptr(), B, H, Wd, stream()), 'wgrad5x5_bf16')
     torch.cuda.synchronize()
     return pivp_amd.from_internal('lstm1/conv/W', dW.cpu().numpy(), (4 * C, cx + C, 5, 5)), db.cpu().numpy()
+
+
+def wgrad5x5_bf16_batch(xs, hs, dGs):
+    """The batched form: lists of per-timestep x (B,cx,H,W), h (B,C,H,W), dG (B,4C,H,W); operands are laid out LAST timestep first with
+    negative strides for x / h (as the backward sweep's slabs are) and positive for dG (as its ring is)."""
+    lib = _lib.load()
+    T = len(xs)
+    B, cx, H, Wd = xs[0].shape
+    C = hs[0].shape[1]
+    xd = torch.stack([nhwc(x) for x in xs]); hd = torch.stack([nhwc(h) for h in hs])       # [t] ascending in memory
+    gd = torch.stack([nhwc(g) for g in dGs[::-1]])                                          # ring slot j = timestep T-1-j
+    dW = torch.zeros(25 * (cx + C) * 4 * C, dtype=torch.float32, device=DEV)
+    db = torch.zeros(4 * C, dtype=torch.float32, device=DEV)
+    sx, sh, sg = xd[0].numel() * 4, hd[0].numel() * 4, gd[0].numel() * 4
+    _lib.check(lib.pivp_wgrad5x5_bf16_batch(xd[T - 1].data_ptr(), cx, cx, hd[T - 1].data_ptr(), C, gd.data_ptr(), dW.data_ptr(), db.data_ptr(),
+                                            B, H, Wd, T, -sx, -sh, sg, stream()), 'wgrad5x5_bf16_batch')
+    torch.cuda.synchronize()
+    return pivp_amd.from_internal('lstm1/conv/W', dW.cpu().numpy(), (4 * C, cx + C, 5, 5)), db.cpu().numpy()

@@ -240,6 +240,41 @@ def test_wgrad5x5_bf16_first_step_leaves_h_rows_alone(ops):
     assert np.all(got[:, cx:] == 0)
 
 
+@pytest.mark.parametrize('B,cx,C,H,T', [(2, 32, 32, 32, 3), (2, 32, 64, 16, 4), (4, 64, 128, 8, 3), (1, 96, 32, 32, 2)])
+def test_wgrad5x5_bf16_batch_of_timesteps(ops, B, cx, C, H, T):
+    # one launch for T timesteps (operands at signed byte strides) = the sum of the per-timestep gradients
+    rs = np.random.RandomState(B + cx + C + H + T)
+    xs = [_bf16(rs.randn(B, cx, H, H)) for _ in range(T)]; hs = [_bf16(rs.randn(B, C, H, H) * 0.5) for _ in range(T)]
+    dGs = [_bf16(rs.randn(B, 4 * C, H, H) * 0.1) for _ in range(T)]
+    ref = sum(_wgrad_ref(x, h, g) for x, h, g in zip(xs, hs, dGs))
+    got, db = ops.wgrad5x5_bf16_batch(xs, hs, dGs)
+    assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(db - sum(g.sum(axis=(0, 2, 3)) for g in dGs)).max() < 4e-4
+
+
+def test_bf16_mode_batched_weight_gradients_match_per_step(monkeypatch):
+    # the bf16 mode's plan batches the ConvLSTM weight gradients of up to 8 timesteps per launch (default) -- same products as one launch
+    # per timestep, other summation order
+    import torch
+    from oracle import restatement as R
+    P = R.init_params(seed=1, dtype=np.float64, scale=1.0)
+    imgs, acts, stas = R.synthetic_batch(2, 7)
+    outs = {}
+    for batch in ('1', '3', None):
+        if batch is None:
+            monkeypatch.delenv('PIVP_WGRAD_BATCH', raising=False)
+        else:
+            monkeypatch.setenv('PIVP_WGRAD_BATCH', batch)
+        m = pivp_amd.Model(10, prefix='t', keep_activations=True, precision='bf16')
+        m.load_state_dict_reference(P)
+        m([imgs, acts, stas], 0)
+        m.cleargrads(); m.backward()
+        outs[batch] = m._flat_grads.clone()
+    for key, g in outs.items():
+        rel = float((g - outs['1']).norm() / outs['1'].norm())
+        assert rel < 2e-4, (key, rel)       # (the K-split data gradients' atomics make two bf16 sweeps differ by ~1.5e-4: soak_bf16_sweeps.py)
+
+
 # ---- transposed 3x3 stride-2 conv with bf16 operands (enc5 / enc6 in the bf16 mode) ---------------------------------------------------
 @pytest.mark.parametrize('B,cin,cout,H,relu', [(2, 64, 64, 32, False), (4, 96, 96, 16, True), (2, 128, 128, 16, True)])
 def test_deconv3x3s2_bf16_exact_on_bf16_operands(ops, B, cin, cout, H, relu):

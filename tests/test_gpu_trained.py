@@ -37,7 +37,7 @@ def test_trained_fixture_is_what_it_says(name):
     T, B = int(g['seq_len']), int(g['batch'])
     assert g['fp32_oracle_max_l2'].shape == (T - 1, B)
     assert g['fp32_oracle_max_l2'].max() < 0.1 * GATE                 # float32 on trained weights: two orders inside the gate on all steps
-    assert float(g['mask_means'][2:].sum()) > 0.25                    # the transformed layers carry real weight in the composite
+    assert float(g['transformed_share']) > 0.25                       # the motion-transformed layers carry real weight in the composite
     assert float(g['pred_mse']) < 0.03                                # far better than predicting a constant (the data's variance is ~0.03)
 
 
