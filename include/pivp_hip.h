@@ -38,7 +38,7 @@ extern "C" {
 #define PIVP_PRECISION_BF16 1
 #define PIVP_PRECISION_BF16X3 2
 
-int pivp_abi_version(void);   /* 6 (2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+int pivp_abi_version(void);   /* 7 (7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
                                  5: + bf16 ConvLSTM, pivp_plan_set_precision, 6: + pivp_plan_set_group_join / pivp_plan_group_wait) */
 
 /* ------------------------------------------------------------------------------------------
@@ -230,6 +230,18 @@ int pivp_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev,
  * accum_dx adds into it), dW and db accumulated.  wt (size of w) is scratch. */
 int pivp_conv_backward(int mode, const float* x, int cin, int ldx, const float* w, const float* dy, int cout, int ldy,
                        float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, void* stream);
+/* The weight-gradient half of pivp_conv_backward the way the BPTT sweep of optimizer.update (TM:950) runs it over the timesteps:
+ * `repeats` launches add their tiles into per-block partial planes (`part`: pivp_conv_backward_part_floats floats, zeroed by the caller;
+ * no atomics), then one reduction adds the sum into dW; db accumulated on the side.  dW += repeats * dW_1, db += repeats * db_1. */
+long long pivp_conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin, int Win);
+int pivp_conv_wgrad_partial(int mode, const float* x, int cin, int ldx, const float* dy, int cout, int ldy, float* part,
+                            float* dW, float* db, int B, int Hin, int Win, int repeats, void* stream);
+/* pivp_convlstm_backward for the sweep's last timestep (t = 0; TM:254-257: the state before it is zero and nothing reads its
+ * gradient): only the cx columns of d_in (d x) are computed, the C columns of d h_{-1} are left untouched. */
+int pivp_convlstm_backward_dx_only(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
+                                   const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
+                                   float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
+                                   int B, int H, int W, void* stream);
 /* LayerNorm forward keeping (mean, rstd) per sample in stat [B][2], and its backward (dgamma/dbeta accumulated). */
 int pivp_layernorm_train(const float* x, const float* gamma, const float* beta, float* out, float* partials, float* stat,
                          int B, int n, int C, int ldo, float eps, int relu, void* stream);

@@ -308,7 +308,7 @@ long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin,
 
 }  // namespace pivp
 
-extern "C" int pivp_abi_version(void) { return 6; }   // 6: + pivp_plan_set_group_join / pivp_plan_group_wait
+extern "C" int pivp_abi_version(void) { return 7; }   // 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
 
 extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                              const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream) {
@@ -340,6 +340,38 @@ extern "C" int pivp_conv_backward(int mode, const float* x, int cin, int ldx, co
     if (!x || !w || !dy || !wt || !dW || !db || mode < 0 || mode > 1) return PIVP_ERR_BADARG;
     return run_conv_backward(mode, x, cin, ldx, w, const_cast<float*>(dy), cout, ldy, nullptr, 0, wt, dx, lddx, accum_dx, dW, db, B, Hin, Win,
                              (hipStream_t)stream);
+}
+// The weight-gradient half of pivp_conv_backward as the BPTT sweep runs it: `repeats` launches (one per timestep there; here the same
+// operands every time) add their tiles into the per-block partial planes `part` (pivp_conv_backward_part_floats floats, zeroed by the
+// caller) with plain loads and stores, then ONE reduction sums the pixel splits into dW; db is accumulated on the side by the tap blocks
+// that see every dy element once.  Result: dW += repeats * (x^T . dy per tap), db += repeats * column sums of dy.
+extern "C" long long pivp_conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin, int Win) {
+    if (mode < 0 || mode > 1 || cin <= 0 || cout <= 0 || B <= 0 || Hin <= 0 || Win <= 0) return PIVP_ERR_BADARG;
+    return conv_backward_part_floats(mode, cin, cout, B, Hin, Win);
+}
+extern "C" int pivp_conv_wgrad_partial(int mode, const float* x, int cin, int ldx, const float* dy, int cout, int ldy, float* part,
+                                       float* dW, float* db, int B, int Hin, int Win, int repeats, void* stream) {
+    if (!x || !dy || !part || !dW || !db || mode < 0 || mode > 1 || repeats < 1) return PIVP_ERR_BADARG;
+    const int Hout = mode ? 2 * Hin : Hin / 2, Wout = mode ? 2 * Win : Win / 2;
+    WgradDesc desc;
+    for (int r = 0; r < repeats; ++r) {
+        int bias_done = 0;
+        int rc = run_wgrad(mode, x, cin, ldx, nullptr, 0, 0, cin, dy, ldy, cout, dW, B, Hin, Win, Hout, Wout, 3, 1, 2, (hipStream_t)stream, db,
+                           &bias_done, 0, 1, 0, 0, 0, part, &desc);
+        if (rc != PIVP_OK) return rc;
+        if (!bias_done) { rc = bias_grad(dy, ldy, cout, B * Hout * Wout, db, (hipStream_t)stream); if (rc != PIVP_OK) return rc; }
+    }
+    return igemm_wgrad_reduce(desc, (hipStream_t)stream);
+}
+// pivp_convlstm_backward for the sweep's LAST timestep (t = 0): nobody reads d h_{-1}, so only the cx columns of d_in are computed
+// (the data gradient runs on the first cx columns of the transposed weight pack) and the h columns of d_in are left untouched.
+extern "C" int pivp_convlstm_backward_dx_only(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
+                                              const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
+                                              float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
+                                              int B, int H, int W, void* stream) {
+    if (!x || !w || !gates || !c_old || !c_new || !dc || !dG || !wt || !d_in || !dW || !db) return PIVP_ERR_BADARG;
+    return run_convlstm_backward(x, cx, ldx, h_prev, C, w, gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc, dc_valid, dG, wt, d_in,
+                                 dW, db, B, H, W, (hipStream_t)stream, 0, nullptr, 1, nullptr, nullptr, 1);
 }
 extern "C" int pivp_layernorm_train(const float* x, const float* gamma, const float* beta, float* out, float* partials, float* stat,
                                     int B, int n, int C, int ldo, float eps, int relu, void* stream) {

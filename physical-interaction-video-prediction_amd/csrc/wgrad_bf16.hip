@@ -411,8 +411,11 @@ static int launch_wgrad25(const WgradDesc& d, hipStream_t s) {
 // d as for igemm_wgrad (ConvLSTM case: 5x5, stride 1, pad 2); dW and, when d.db is set, the bias gradient accumulated with atomics.
 int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s) {
     PIVP_CHECK_ARG(d.x0 && d.dy && d.dw && wgrad5x5_bf16_ok(d) && (d.c1 == 0 || d.x1) && d.wcin >= d.cin && d.wcin % 32 == 0);
-    static const int kernel = [] { const char* e = getenv("PIVP_WGB_KERNEL"); return e ? atoi(e) : 25; }();   // tuning: 5 = one kernel row per block
-    if (kernel != 5) return launch_wgrad25(d, s);
+    // A batch of timesteps goes to the 25-tap kernel (per timestep at B = 32, all seven layers: 168 us at 8 per launch, 225 us at 4); ONE
+    // timestep to the kernel-row kernel below, whose 5 x cin/32 blocks per tile are then the better use of the chip (389 us against 580:
+    // the sweep's t = 0 launches, sequences too short to batch).  PIVP_WGB_KERNEL = 5 / 25 forces one of them (tuning).
+    static const int kernel = [] { const char* e = getenv("PIVP_WGB_KERNEL"); return e ? atoi(e) : 0; }();
+    if (kernel == 25 || (kernel != 5 && d.tcount > 1)) return launch_wgrad25(d, s);
     PIVP_CHECK_ARG(d.tcount <= 1);                                                      // (that kernel takes one timestep)
     constexpr int lds_bytes = G_BYTES + X_BYTES;
     static PerDeviceOnce once16, once8;

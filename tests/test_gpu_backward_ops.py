@@ -187,3 +187,76 @@ def test_adam_epsilon_placement_kat(env):
     got = pd.cpu().numpy().astype(np.float64)
     assert np.abs(got - chainer).max() < 2e-9, (got, chainer)
     assert np.abs(got - paper).max() > 4e-4                        # and is NOT the other placement
+
+
+@pytest.mark.parametrize('mode,B,cin,cout,H,repeats', [(0, 3, 32, 32, 32, 2), (0, 5, 64, 64, 16, 3), (1, 3, 128, 128, 8, 2), (1, 5, 96, 96, 16, 3),
+                                                       (1, 1, 64, 64, 32, 1), (0, 1, 32, 32, 64, 2), (1, 7, 64, 64, 8, 2)])
+def test_conv_weight_gradient_through_partial_planes(env, mode, B, cin, cout, H, repeats):
+    """The enc convs' weight gradients as the BPTT sweep runs them (round 2): per-block partial planes accumulated over `repeats` launches
+    with plain loads and stores, ONE reduction into dW, bias gradient summed by the tap blocks that see every dY element once (conv:
+    tap 0; transposed conv: taps (1,1), (1,2), (2,1), (2,2)).  Odd batch sizes put tile tails into the pixel splits; exact to fp32."""
+    pivp, _lib, lib = env
+    rs = np.random.RandomState(cin + mode + B)
+    x = rs.randn(B, cin, H, H)
+    Ho = 2 * H if mode else H // 2
+    dy = rs.randn(B, cout, Ho, Ho)
+    if mode:
+        W = rs.randn(cin, cout, 3, 3) / np.sqrt(9 * cin); key = 'enc4/W'
+    else:
+        W = rs.randn(cout, cin, 3, 3) / np.sqrt(9 * cin); key = 'enc1/W'
+    tx = torch.tensor(x, dtype=torch.float64); tW = torch.tensor(W, dtype=torch.float64, requires_grad=True)
+    tb = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    y = F.conv_transpose2d(tx, tW, tb, stride=2, padding=1, output_padding=1) if mode else F.conv2d(tx, tW, tb, stride=2, padding=1)
+    (y * torch.tensor(dy)).sum().backward()
+    xd, dyd = _nhwc(x), _nhwc(dy)
+    n = lib.pivp_conv_backward_part_floats(mode, cin, cout, B, H, H)
+    assert n > 0
+    part = torch.zeros(n, dtype=torch.float32, device=DEV)
+    prior = rs.randn(W.size).astype(np.float32) * 0.01                      # dW is accumulated into, not overwritten
+    dW = _t(prior); db = torch.zeros(cout, dtype=torch.float32, device=DEV)
+    _lib.check(lib.pivp_conv_wgrad_partial(mode, xd.data_ptr(), cin, cin, dyd.data_ptr(), cout, cout, part.data_ptr(), dW.data_ptr(),
+                                           db.data_ptr(), B, H, H, repeats, _st()), 'conv_wgrad_partial')
+    torch.cuda.synchronize()
+    got = pivp.from_internal(key, dW.cpu().numpy() - prior, W.shape)
+    assert _rel(got, repeats * tW.grad.numpy()) < 2e-5
+    assert _rel(db.cpu().numpy(), repeats * tb.grad.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize('B,cx,C,H', [(3, 32, 32, 32), (5, 32, 64, 16), (3, 64, 128, 8), (1, 96, 32, 32), (2, 128, 64, 16)])
+def test_convlstm_backward_last_timestep_computes_dx_only(env, B, cx, C, H):
+    """t = 0 of the sweep: the data gradient runs on the first cx columns of the transposed weight pack (IgemmDesc::wN) and leaves the
+    d h_{-1} columns of d_in alone; d x, d c, dW, db are those of the full backward.  Odd batches: M tails of the column-limited tiles."""
+    pivp, _lib, lib = env
+    rs = np.random.RandomState(C + cx + B)
+    x = rs.randn(B, cx, H, H); h = rs.randn(B, C, H, H) * 0.5; c = rs.randn(B, C, H, H)
+    W = rs.randn(4 * C, cx + C, 5, 5) / np.sqrt(25 * (cx + C)); b = rs.randn(4 * C) * 0.1
+    dh = rs.randn(B, C, H, H); dcn = rs.randn(B, C, H, H)
+    tx, th, tc = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (x, h, c)]
+    tW = torch.tensor(W, dtype=torch.float64, requires_grad=True); tb = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    g = F.conv2d(torch.cat((tx, th), 1), tW, tb, padding=2)
+    j, i, f, o = torch.split(g, C, dim=1)
+    cn = tc * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
+    hn = torch.tanh(cn) * torch.sigmoid(o)
+    (hn * torch.tensor(dh) + cn * torch.tensor(dcn)).sum().backward()
+    xd, hd, cd = _nhwc(x), _nhwc(h), _nhwc(c)
+    wd, bd = _t(pivp.to_internal('lstm1/conv/W', W)), _t(b)
+    c_out = torch.empty_like(cd); h_out = torch.empty_like(hd)
+    M = B * H * H
+    gates = torch.empty((M, 4 * C), dtype=torch.float32, device=DEV)
+    _lib.check(lib.pivp_convlstm_train(xd.data_ptr(), cx, cx, hd.data_ptr(), C, wd.data_ptr(), bd.data_ptr(), cd.data_ptr(), c_out.data_ptr(),
+                                       h_out.data_ptr(), gates.data_ptr(), B, H, H, _st()), 'fwd')
+    dha = _nhwc(dh); dc = _nhwc(dcn).clone()
+    dG = torch.empty((M, 4 * C), dtype=torch.float32, device=DEV)
+    wt = torch.empty_like(wd)
+    d_in = torch.full((M, cx + C), 7.0, dtype=torch.float32, device=DEV)
+    dW = torch.zeros_like(wd); db = torch.zeros_like(bd)
+    _lib.check(lib.pivp_convlstm_backward_dx_only(xd.data_ptr(), cx, cx, hd.data_ptr(), C, wd.data_ptr(), gates.data_ptr(), cd.data_ptr(),
+                                                  c_out.data_ptr(), dha.data_ptr(), C, None, 0, dc.data_ptr(), 1, dG.data_ptr(), wt.data_ptr(),
+                                                  d_in.data_ptr(), dW.data_ptr(), db.data_ptr(), B, H, H, _st()), 'bwd')
+    torch.cuda.synchronize()
+    din = d_in.cpu().numpy().reshape(B, H, H, cx + C).transpose(0, 3, 1, 2)
+    assert _rel(din[:, :cx], tx.grad.numpy()) < 2e-5
+    assert np.all(din[:, cx:] == 7.0)                              # d h_{-1}: not computed, not touched
+    assert _rel(dc.cpu().numpy().reshape(B, H, H, C).transpose(0, 3, 1, 2), tc.grad.numpy()) < 2e-5
+    assert _rel(pivp.from_internal('lstm1/conv/W', dW.cpu().numpy(), W.shape), tW.grad.numpy()) < 2e-5
+    assert _rel(db.cpu().numpy(), tb.grad.numpy()) < 2e-5

@@ -256,7 +256,9 @@ def test_bf16_mode_batched_weight_gradients_match_per_step(monkeypatch):
     # the bf16 mode's plan batches the ConvLSTM weight gradients of up to 8 timesteps per launch (default) -- same products as one launch
     # per timestep, other summation order
     import torch
+    import pivp_amd
     from oracle import restatement as R
+    assert torch.cuda.is_available()
     P = R.init_params(seed=1, dtype=np.float64, scale=1.0)
     imgs, acts, stas = R.synthetic_batch(2, 7)
     outs = {}
