@@ -237,7 +237,7 @@ long long pivp_conv_backward_part_floats(int mode, int cin, int cout, int B, int
 int pivp_conv_wgrad_partial(int mode, const float* x, int cin, int ldx, const float* dy, int cout, int ldy, float* part,
                             float* dW, float* db, int B, int Hin, int Win, int repeats, void* stream);
 /* pivp_convlstm_backward for the sweep's last timestep (t = 0; TM:254-257: the state before it is zero and nothing reads its
- * gradient): only the cx columns of d_in (d x) are computed, the C columns of d h_{-1} are left untouched. */
+ * gradient): only the cx columns of d_in (d x) are computed, the C columns of d h_{-1} are not computed (left as they are, or cleared). */
 int pivp_convlstm_backward_dx_only(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
                                    const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                                    float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,

@@ -104,9 +104,9 @@ __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned shor
     wb[i] = __builtin_bit_cast(unsigned short, h);
 }
 
-#ifdef PIVP_BF16_STAMPS   // in-kernel phase stamps of one block's wave 0 (scripts/bf16_stamps.py)
-__device__ long long pivp_bf16_stamps[8];
-#define BF_STAMP(i) do { if (lid == 37 && tid == 0) pivp_bf16_stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#ifdef PIVP_BF16_STAMPS   // in-kernel phase stamps of every block's wave 0, constant-rate 100 MHz counter (scripts/bf16_stamps.py)
+__device__ long long pivp_bf16_stamps[2048 * 8];
+#define BF_STAMP(i) do { if (tid == 0 && blockIdx.x < 2048 && blockIdx.y == 0) pivp_bf16_stamps[blockIdx.x * 8 + (i)] = (long long)wall_clock64(); } while (0)
 #else
 #define BF_STAMP(i)
 #endif
@@ -535,6 +535,10 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
             }
         }
     BF_STAMP(4);
+#ifdef PIVP_BF16_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the block's stores have left
+    BF_STAMP(5);
+#endif
     if (d.ln_part) {
         // (count, mean, M2) of the h values of each image of the tile; with two images wave pair wm owns image wm.
         float* red = reinterpret_cast<float*>(lds);
@@ -578,8 +582,8 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
 
 #ifdef PIVP_BF16_STAMPS
 }
-extern "C" int pivp_debug_bf16_stamps(long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pivp::pivp_bf16_stamps), 8 * sizeof(long long)) == hipSuccess ? 0 : -2;
+extern "C" int pivp_debug_bf16_stamps(long long* out, int n) {   // n <= 2048 * 8: [block][entry, prologue done, first barrier passed, tap loop done, cells done]
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pivp::pivp_bf16_stamps), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : -2;
 }
 namespace pivp {
 #endif

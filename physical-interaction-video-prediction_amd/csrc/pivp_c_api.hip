@@ -364,7 +364,7 @@ extern "C" int pivp_conv_wgrad_partial(int mode, const float* x, int cin, int ld
     return igemm_wgrad_reduce(desc, (hipStream_t)stream);
 }
 // pivp_convlstm_backward for the sweep's LAST timestep (t = 0): nobody reads d h_{-1}, so only the cx columns of d_in are computed
-// (the data gradient runs on the first cx columns of the transposed weight pack) and the h columns of d_in are left untouched.
+// (the data gradient runs on the first cx columns of the transposed weight pack) and the h columns of d_in are not computed (left as they are, or cleared with the rest of d_in for a K-split data gradient).
 extern "C" int pivp_convlstm_backward_dx_only(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
                                               const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                                               float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,

@@ -27,7 +27,17 @@ for name, cx, C, H in [('lstm1', 32, 32, 32), ('lstm5', 64, 128, 8), ('lstm7', 9
     for _ in range(20):
         launch()
     e1.record(); torch.cuda.synchronize()
-    buf = (ctypes.c_longlong * 8)()
-    assert so.pivp_debug_bf16_stamps(buf) == 0
-    v = list(buf)
-    print(name, 'launch %.1f us; stamps (counter ticks from entry):' % (e0.elapsed_time(e1) / 20 * 1e3), [v[i] - v[0] for i in range(1, 5)])
+    nch = 16 if (B * H * H // 128) * (C // 32) < 256 or C % 32 else 32
+    nblk = min(2048, (B * H * H // 128) * (C // nch))
+    buf = (ctypes.c_longlong * (2048 * 8))()
+    assert so.pivp_debug_bf16_stamps(buf, 2048 * 8) == 0
+    v = np.array(list(buf), dtype=np.int64).reshape(2048, 8)[:nblk] * 0.01       # us (100 MHz counter)
+    t0 = v[:, 0].min()
+
+    def q(a):
+        return 'min %.1f  median %.1f  p90 %.1f  max %.1f' % (a.min(), np.median(a), np.percentile(a, 90), a.max())
+    print('%s: launch %.1f us by events, %d blocks' % (name, e0.elapsed_time(e1) / 20 * 1e3, nblk))
+    print('   entry            ', q(v[:, 0] - t0))
+    print('   prologue         ', q(v[:, 1] - v[:, 0])); print('   first barrier    ', q(v[:, 2] - v[:, 1]))
+    print('   tap loop         ', q(v[:, 3] - v[:, 2])); print('   gate cells       ', q(v[:, 4] - v[:, 3]))
+    print('   stores drained   ', q(v[:, 5] - v[:, 4])); print('   end (from launch)', q(v[:, 5] - t0))

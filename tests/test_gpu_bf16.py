@@ -274,7 +274,10 @@ def test_bf16_mode_batched_weight_gradients_match_per_step(monkeypatch):
         outs[batch] = m._flat_grads.clone()
     for key, g in outs.items():
         rel = float((g - outs['1']).norm() / outs['1'].norm())
-        assert rel < 2e-4, (key, rel)       # (the K-split data gradients' atomics make two bf16 sweeps differ by ~1.5e-4: soak_bf16_sweeps.py)
+        # Two bf16 sweeps of the SAME configuration already differ by 1.5e-4 .. 6e-4 (the K-split data gradients' atomics reorder fp32 sums
+        # whose results are then rounded to bf16 operands downstream: scripts/soak_bf16_sweeps.py); a batching bug (a timestep dropped,
+        # a wrong stride) is O(0.1 - 1).  The exact statement about the batched kernel is test_wgrad5x5_bf16_batch_of_timesteps.
+        assert rel < 3e-3, (key, rel)
 
 
 # ---- transposed 3x3 stride-2 conv with bf16 operands (enc5 / enc6 in the bf16 mode) ---------------------------------------------------
