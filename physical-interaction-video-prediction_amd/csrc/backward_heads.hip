@@ -391,11 +391,21 @@ int composite_bwd_dna(const float* prev, const float* logits, const float* e7, c
 // Backward of the flat softmax + ReLU of the mask head (TM:719-722): for each group of NP consecutive flat
 // elements, d r = mk * (d mk - sum_group mk * d mk), masked by r > 0 (r = relu(masks conv)).  In place on dmk.
 // ------------------------------------------------------------------------------------------
+// A thread owns one group; the block's 256 groups are 256 * NP CONSECUTIVE floats of each array, so they travel through LDS in whole
+// lines (the first version let every lane walk its own group in global memory: 44-B strides, 23 cache lines per wave-instruction, 30 us
+// per launch for 17 MB).  In LDS the groups are NP floats apart: NP odd (11 for num_masks = 10) makes the lanes' banks distinct.
 __global__ __launch_bounds__(256) void mask_softmax_bwd_kernel(const float* __restrict__ logits, float* __restrict__ dmk, long ngroups, int NP) {
     PIVP_SET_MAIN_PRIO();
-    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (long)gridDim.x * 256) {
-        const float* r = logits + g * NP;
-        float* d = dmk + g * NP;
+    __shared__ float lr[256 * 12], ld[256 * 12];
+    const long g0 = (long)blockIdx.x * 256;
+    const int ng = (int)min((long)256, ngroups - g0), n = ng * NP;
+    const float* rsrc = logits + g0 * NP;
+    float* dsrc = dmk + g0 * NP;
+    for (int i = threadIdx.x; i < n; i += 256) { lr[i] = rsrc[i]; ld[i] = dsrc[i]; }
+    __syncthreads();
+    if ((int)threadIdx.x < ng) {
+        const float* r = lr + threadIdx.x * NP;
+        float* d = ld + threadIdx.x * NP;
         float mx = r[0];
         for (int u = 1; u < NP; ++u) mx = fmaxf(mx, r[u]);
         float e[12], sum = 0.f;
@@ -408,11 +418,13 @@ __global__ __launch_bounds__(256) void mask_softmax_bwd_kernel(const float* __re
 #pragma unroll
         for (int u = 0; u < 12; ++u) if (u < NP) d[u] = r[u] > 0.f ? e[u] * (d[u] - dot) : 0.f;
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) dsrc[i] = ld[i];
 }
 int mask_softmax_bwd(const float* logits, float* dmk, int B, int HW, int NP, hipStream_t s) {
     PIVP_CHECK_ARG(logits && dmk && B > 0 && HW > 0 && NP >= 2 && NP <= 12);
     const long ng = (long)B * HW;          // B*NP*HW / NP groups
-    hipLaunchKernelGGL(mask_softmax_bwd_kernel, dim3((unsigned)((ng + 255) / 256 < 2048 ? (ng + 255) / 256 : 2048)), dim3(256), 0, s, logits, dmk, ng, NP);
+    hipLaunchKernelGGL(mask_softmax_bwd_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, logits, dmk, ng, NP);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -455,36 +467,42 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) dwacc[t][r] = 0.f;
     float dbacc = 0.f;
+    // Register double buffer: the loads of sub-tile s + 1 (8 x 16 B of e6 + up to 16 plane elements per thread) are issued before sub-tile
+    // s is multiplied and land under its MFMAs and stores.  (The first version loaded, stored to LDS, synchronised and multiplied each
+    // sub-tile in turn with four waves on the CU: four exposed round trips per sub-tile, 38 us per launch for 67 MB.)
+    f32x4 tx[8];
+    float td[HB_MAXOUT / 2];
+    const int sp = tid & (HB_PX - 1), oh = tid >> 7;                       // staging role for the planes: pixel sp, outputs oh, oh + 2, ...
+    auto load_sub = [&](int sub) {
+        const int px0 = (blockIdx.x * HB_SUB + sub) * HB_PX;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int f = tid + 256 * u, p = f >> 4, cv = (f & 15) * 4;
+            tx[u] = px0 + p < total_px ? *reinterpret_cast<const f32x4*>(e6 + (size_t)(px0 + p) * 64 + cv) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int px = px0 + sp;
+        const bool pok = px < total_px;
+        const int bb = pok ? px / HW : 0, q = px - bb * HW;
+#pragma unroll
+        for (int u = 0; u < HB_MAXOUT / 2; ++u) {
+            const int o = oh + 2 * u;
+            td[u] = (pok && o < NO) ? (o < NP ? dpm[((size_t)bb * NP + o) * HW + q] : dpe[((size_t)bb * NE + (o - NP)) * HW + q]) : 0.f;
+        }
+    };
+    load_sub(0);
     for (int sub = 0; sub < HB_SUB; ++sub) {
         const int px0 = (blockIdx.x * HB_SUB + sub) * HB_PX;
         if (px0 >= total_px) break;
         __syncthreads();
-        {   // staging: 8 + up to 16 independent loads per thread, then the LDS stores
-            f32x4 tx[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int f = tid + 256 * u, p = f >> 4, cv = (f & 15) * 4;
-                tx[u] = px0 + p < total_px ? *reinterpret_cast<const f32x4*>(e6 + (size_t)(px0 + p) * 64 + cv) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            const int p = tid & (HB_PX - 1), oh = tid >> 7;                 // pixel p, outputs oh, oh+2, ...
-            const int px = px0 + p;
-            const bool pok = px < total_px;
-            const int bb = pok ? px / HW : 0, q = px - bb * HW;
-            float td[HB_MAXOUT / 2];
-#pragma unroll
-            for (int u = 0; u < HB_MAXOUT / 2; ++u) {
-                const int o = oh + 2 * u;
-                td[u] = (pok && o < NO) ? (o < NP ? dpm[((size_t)bb * NP + o) * HW + q] : dpe[((size_t)bb * NE + (o - NP)) * HW + q]) : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int f = tid + 256 * u, pp = f >> 4, cv = (f & 15) * 4;
-                *reinterpret_cast<f32x4*>(xt + pp * 68 + cv) = tx[u];
-            }
-#pragma unroll
-            for (int u = 0; u < HB_MAXOUT / 2; ++u) { const int o = oh + 2 * u; if (o < NO) dpt[o * HB_DP + p] = td[u]; }
+        for (int u = 0; u < 8; ++u) {
+            const int f = tid + 256 * u, pp = f >> 4, cv = (f & 15) * 4;
+            *reinterpret_cast<f32x4*>(xt + pp * 68 + cv) = tx[u];
         }
+#pragma unroll
+        for (int u = 0; u < HB_MAXOUT / 2; ++u) { const int o = oh + 2 * u; if (o < NO) dpt[o * HB_DP + sp] = td[u]; }
         __syncthreads();
+        if (sub + 1 < HB_SUB) load_sub(sub + 1);                           // (past the end of the image: every load is predicated off)
         {   // d e6 of this wave's 32 pixels: row i of the MFMA tile = pixel, column j = channel
             f32x16 c0, c1;
 #pragma unroll
@@ -1016,6 +1034,12 @@ __global__ __launch_bounds__(256) void enc0_wgrad_kernel(const float* __restrict
     if (kg == 0) atomicAdd(db + co, bacc);
 }
 
+// d img[c](y, x) = sum over the taps (ky, kx) with y + 2 - ky and x + 2 - kx even of sum_co w[tap][c][co] d[(y + 2 - ky) / 2, (x + 2 - kx) / 2][co].
+// Which taps contribute depends on the PARITY of (y, x) only: 9 / 6 / 6 / 4 of the 25.  The first version gave a thread one pixel in raster
+// order, so the four parity classes of a wave each walked all 25 taps under their own exec mask and every lane fetched its own 128-B row of d
+// per tap (51 us per launch at B = 32, on the sweep's critical path).  Here blockIdx.y is the parity class (the tap set is block-uniform:
+// no divergence), and a pixel is shared by FOUR lanes that take 8 of the 32 channels each (a wave reads 16 whole 128-B rows per tap) and
+// meet in two xor-shuffles.
 __global__ __launch_bounds__(256) void enc0_dgrad_kernel(const float* __restrict__ d, const float* __restrict__ w, float* __restrict__ dimg,
                                                          int accum, int B, int H, int W) {
     PIVP_SET_MAIN_PRIO();
@@ -1023,37 +1047,41 @@ __global__ __launch_bounds__(256) void enc0_dgrad_kernel(const float* __restrict
     for (int i = threadIdx.x; i < 75 * 32; i += 256) wl[i] = w[i];
     __syncthreads();
     const int H2 = H >> 1, W2 = W >> 1;
-    const long total = (long)B * H * W;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int b = (int)(idx / (H * W)), rem = (int)(idx - (long)b * H * W), y = rem / W, x = rem - y * W;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const int py = blockIdx.y >> 1, px = blockIdx.y & 1;          // parity of (y, x): taps ky = py, py + 2, (py + 4), likewise kx
+    const int cg = threadIdx.x & 3;                               // channels 8 cg .. 8 cg + 7
+    const long total = (long)B * H2 * W2;                         // pixels of one parity class
+    const long q = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool live = q < total;
+    const long qq = live ? q : total - 1;
+    const int b = (int)(qq / (H2 * W2)), rem = (int)(qq - (long)b * H2 * W2), yy = rem / W2, xx = rem - yy * W2;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const int nky = py ? 2 : 3, nkx = px ? 2 : 3;
+    for (int iy = 0; iy < nky; ++iy) {
+        const int ky = py + 2 * iy, oy = yy + 1 - iy;             // (y + 2 - ky) / 2 with y = 2 yy + py
+        const bool rowok = (unsigned)oy < (unsigned)H2;
+        for (int ix = 0; ix < nkx; ++ix) {
+            const int kx = px + 2 * ix, ox = xx + 1 - ix;
+            const bool ok = rowok && (unsigned)ox < (unsigned)W2;
+            const float* dp = d + ((size_t)(b * H2 + (rowok ? oy : 0)) * W2 + (ok ? ox : 0)) * 32 + cg * 8;   // clamped: always in range
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(dp), d1 = *reinterpret_cast<const f32x4*>(dp + 4);
+            const float m = ok ? 1.f : 0.f;
+            const float* wr = wl + (ky * 5 + kx) * 3 * 32 + cg * 8;
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int ky = 0; ky < 5; ++ky) {
-            const int ty = y + 2 - ky;
-            if (ty & 1) continue;
-            const int oy = ty >> 1;
-            if ((unsigned)oy >= (unsigned)H2) continue;
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 dv = h ? d1 : d0;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + 4 * h), w1 = *reinterpret_cast<const f32x4*>(wr + 32 + 4 * h);
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 64 + 4 * h);
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx) {
-                const int tx = x + 2 - kx;
-                if (tx & 1) continue;
-                const int ox = tx >> 1;
-                if ((unsigned)ox >= (unsigned)W2) continue;
-                const float* dp = d + ((size_t)(b * H2 + oy) * W2 + ox) * 32;
-                const float* wr = wl + (ky * 5 + kx) * 3 * 32;
-                // 16-B loads, two in flight (a register array of all eight per tap was tried: 41 -> 202 us, the fully unrolled, partially
-                // predicated tap loop then lives in scratch)
-#pragma unroll 2
-                for (int c4 = 0; c4 < 8; ++c4) {
-                    const f32x4 dv = *reinterpret_cast<const f32x4*>(dp + 4 * c4);
-                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + 4 * c4), w1 = *reinterpret_cast<const f32x4*>(wr + 32 + 4 * c4);
-                    const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 64 + 4 * c4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { a0 = fmaf(w0[e], dv[e], a0); a1 = fmaf(w1[e], dv[e], a1); a2 = fmaf(w2[e], dv[e], a2); }
-                }
+                for (int e = 0; e < 4; ++e) { t0 = fmaf(w0[e], dv[e], t0); t1 = fmaf(w1[e], dv[e], t1); t2 = fmaf(w2[e], dv[e], t2); }
             }
+            a0 = fmaf(m, t0, a0); a1 = fmaf(m, t1, a1); a2 = fmaf(m, t2, a2);
         }
-        float* o = dimg + (size_t)b * 3 * H * W + rem;
+    }
+    a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64); a2 += __shfl_xor(a2, 1, 64);
+    a0 += __shfl_xor(a0, 2, 64); a1 += __shfl_xor(a1, 2, 64); a2 += __shfl_xor(a2, 2, 64);
+    if (live && cg == 0) {
+        float* o = dimg + (size_t)b * 3 * H * W + (size_t)(2 * yy + py) * W + 2 * xx + px;
         if (accum) { o[0] += a0; o[(size_t)H * W] += a1; o[2 * (size_t)H * W] += a2; }
         else { o[0] = a0; o[(size_t)H * W] = a1; o[2 * (size_t)H * W] = a2; }
     }
@@ -1072,9 +1100,9 @@ int enc0_bwd(const float* img, const float* w, const float* d, float* dw, float*
     hipLaunchKernelGGL(enc0_wgrad_kernel, dim3(blocks), dim3(256), 0, sw, img, d, dw, db, B, H, W);
     if (fork && fork->side && hipEventRecord(fork->done, fork->side) != hipSuccess) return PIVP_ERR_LAUNCH;
     if (dimg) {
-        const long tp = (long)B * H * W;
-        hipLaunchKernelGGL(enc0_dgrad_kernel, dim3((unsigned)((tp + 255) / 256 < 2048 ? (tp + 255) / 256 : 2048)), dim3(256), 0, s, d, w, dimg,
-                           dimg_accum, B, H, W);
+        PIVP_CHECK_ARG(H % 2 == 0 && W % 2 == 0);
+        const long tp = (long)B * (H / 2) * (W / 2);           // pixels per parity class, 64 per block
+        hipLaunchKernelGGL(enc0_dgrad_kernel, dim3((unsigned)((tp + 63) / 64), 4), dim3(256), 0, s, d, w, dimg, dimg_accum, B, H, W);
     }
     return PIVP_LAUNCH_STATUS();
 }
