@@ -449,7 +449,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     // The barrier that publishes the NEXT tap's weights sits in the middle of the tap (its skew hides behind queued MFMAs); the next
     // tap's first two k-steps are requested behind it.  No VMEM instruction in this loop.
     int tap = tap0, cg = 0;
-    auto tap_body = [&](auto PH, int it) {
+    auto tap_body = [&](auto PH, int it) -> bool {     // returns true when the channel group (or the block's work) ends with this tap
         constexpr int ph = decltype(PH)::value;
         using A = std::integral_constant<int, ph % 3>; using B = std::integral_constant<int, (ph + 1) % 3>;
         using C = std::integral_constant<int, (ph + 2) % 3>;
@@ -461,32 +461,29 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const int ntap = tap == 24 ? 0 : tap + 1;
-        // The next tap's first two k-steps are requested UNCONDITIONALLY, also behind the last tap of a channel group, where nobody will
-        // use them (valid LDS addresses, stale bytes; the group's restart re-reads into the same registers, and LDS reads return in order).
-        // A conditional request puts the fragment sets behind phi nodes: hipcc then shuffles them with dozens of v_mov_b64 per tap -- of
-        // registers whose asm ds_read may still be in flight (measured: tap loop 10.9 -> 17.5 us) -- and the waits stop being uniform.
-        read_frags(B{}, K0{}, ntap, nslot); wait_frags(C{}, W2{});                          // k-step 2; the next tap's k-step 0 goes to B
+        const bool regroup = ntap == tap0;
+        if (!regroup) { read_frags(B{}, K0{}, ntap, nslot); wait_frags(C{}, W2{}); }     // k-step 2; the next tap's k-step 0 goes to B
+        else wait_frags(C{}, W1{});
         mfmas(C{});
         __builtin_amdgcn_sched_barrier(0);
-        read_frags(C{}, K1{}, ntap, nslot); wait_frags(A{}, W2{});                          // k-step 3; the next tap's k-step 1 goes to C
+        if (!regroup) { read_frags(C{}, K1{}, ntap, nslot); wait_frags(A{}, W2{}); }     // k-step 3; the next tap's k-step 1 goes to C
+        else wait_frags(A{}, W0{});
         mfmas(A{});
         __builtin_amdgcn_sched_barrier(0);
         tap = ntap;
+        return regroup;
     };
-    // a channel group = 25 taps = 8 x (phases 0, 1, 2) + one more in phase 0: a counted loop with a single back edge (with data-dependent
-    // exits between the phases hipcc gave the accumulators different registers on the exit paths and copied all of them every trip)
-    for (int it = 0; cg < ncg; ++cg) {
-        // the group starts with an empty pipeline: its first two k-steps go to sets 0 and 1, i.e. phase 0
+    for (int it = 0; it < nchunks;) {
+        // a channel group starts with an empty pipeline: its first two k-steps go to sets 0 and 1, i.e. phase 0
         read_frags(S0{}, K0{}, tap, it & (NSLOT - 1)); read_frags(S1{}, K1{}, tap, it & (NSLOT - 1));
-        for (int r = 0; r < 8; ++r) {
-            tap_body(std::integral_constant<int, 0>{}, it++);
-            tap_body(std::integral_constant<int, 1>{}, it++);
-            tap_body(std::integral_constant<int, 2>{}, it++);
+        for (;;) {
+            if (tap_body(std::integral_constant<int, 0>{}, it++)) break;
+            if (tap_body(std::integral_constant<int, 1>{}, it++)) break;
+            if (tap_body(std::integral_constant<int, 2>{}, it++)) break;
         }
-        tap_body(std::integral_constant<int, 0>{}, it++);
-        if (cg + 1 < ncg) {                            // next 64 input channels: all 8 waves restage the patch
+        if (++cg < ncg) {                              // next 64 input channels: all 8 waves restage the patch
             __syncthreads();                           // every wave is done with the old patch
-            patch_load(cg + 1);
+            patch_load(cg);
             patch_store();
             __syncthreads();
         }
