@@ -70,24 +70,18 @@ __device__ __forceinline__ bf16x8 lds_read_b128(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
-// the in/out operands tie the fragments to the wait so that no MFMA that consumes them moves above it.  CNT = LDS reads issued AFTER
-// the ones waited for that may stay in flight (LDS reads return in order; the multiplying waves issue nothing else that counts on lgkmcnt
-// in the tap loop, and anything extra in flight only makes the wait longer)
-template <int CNT = 0>
+// the in/out operands tie the fragments to the wait so that no MFMA that consumes them moves above it
 __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& e) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e) : "n"(CNT));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e));
 }
-template <int CNT = 0>
 __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c) {
-    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(CNT));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
 }
-template <int CNT = 0>
 __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& e, bf16x8& f, bf16x8& g) {
-    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e), "+v"(f), "+v"(g) : "n"(CNT));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e), "+v"(f), "+v"(g));
 }
-template <int CNT = 0>
 __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& e, bf16x8& f, bf16x8& g, bf16x8& h, bf16x8& i) {
-    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i) : "n"(CNT));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i));
 }
 }  // namespace
 
@@ -344,17 +338,14 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     // LDS reads go through inline asm: hipcc knows that an LDS-DMA writes LDS and puts s_waitcnt vmcnt(0) in front of every
     // ds_read it can see.  The waits below are explicit instead.
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    constexpr int NSET = LATE ? 2 : 3;                 // register sets of fragments (the four-slot schedule reads two k-steps ahead)
-    constexpr int RPS = (2 + TPW) * PL;                // LDS reads per set
-    bf16x8 fa[NSET][2], fb[NSET][TPW];                 // [register set][tile]
-    bf16x8 fal[NSET][2], fbl[NSET][TPW];               // ... and their lo planes (split mode)
-    auto wait_frags = [&](auto SET, auto CNT) {        // CNT: reads issued after this set's that may stay in flight
-        constexpr int st = decltype(SET)::value, cnt = decltype(CNT)::value;
-        static_assert(cnt <= 15, "lgkmcnt is a 4-bit counter");
-        if constexpr (PL == 2 && TPW == 2) wait_lgkm<cnt>(fa[st][0], fa[st][1], fb[st][0], fb[st][1], fal[st][0], fal[st][1], fbl[st][0], fbl[st][1]);
-        else if constexpr (PL == 2) wait_lgkm<cnt>(fa[st][0], fa[st][1], fb[st][0], fal[st][0], fal[st][1], fbl[st][0]);
-        else if constexpr (TPW == 2) wait_lgkm<cnt>(fa[st][0], fa[st][1], fb[st][0], fb[st][1]);
-        else wait_lgkm<cnt>(fa[st][0], fa[st][1], fb[st][0]);
+    bf16x8 fa[2][2], fb[2][TPW];                       // [register set][tile]
+    bf16x8 fal[2][2], fbl[2][TPW];                     // ... and their lo planes (split mode)
+    auto wait_frags = [&](auto SET) {
+        constexpr int st = decltype(SET)::value;
+        if constexpr (PL == 2 && TPW == 2) wait_lgkm(fa[st][0], fa[st][1], fb[st][0], fb[st][1], fal[st][0], fal[st][1], fbl[st][0], fbl[st][1]);
+        else if constexpr (PL == 2) wait_lgkm(fa[st][0], fa[st][1], fb[st][0], fal[st][0], fal[st][1], fbl[st][0]);
+        else if constexpr (TPW == 2) wait_lgkm(fa[st][0], fa[st][1], fb[st][0], fb[st][1]);
+        else wait_lgkm(fa[st][0], fa[st][1], fb[st][0]);
     };
     auto read_frags = [&](auto SET, auto KS, int tp, int slot) {   // fragments of k-step KS of tap tp (weights in ring slot `slot`)
         constexpr int st = decltype(SET)::value, ks = decltype(KS)::value;
@@ -386,7 +377,6 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
             }
     };
     using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
-    using W0 = std::integral_constant<int, 0>; using W1 = std::integral_constant<int, RPS>; using W2 = std::integral_constant<int, 2 * RPS>;
     using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
     using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
 
@@ -424,13 +414,13 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         for (int it = 0; it < nchunks; ++it) {
             const int slot = it & 1;
             read_frags(S0{}, K0{}, tap, slot);
-            wait_frags(S0{}, W0{}); read_frags(S1{}, K1{}, tap, slot); mfmas(S0{});
+            wait_frags(S0{}); read_frags(S1{}, K1{}, tap, slot); mfmas(S0{});
             __builtin_amdgcn_sched_barrier(0);
-            wait_frags(S1{}, W0{}); read_frags(S0{}, K2{}, tap, slot); mfmas(S1{});
+            wait_frags(S1{}); read_frags(S0{}, K2{}, tap, slot); mfmas(S1{});
             __builtin_amdgcn_sched_barrier(0);
-            wait_frags(S0{}, W0{}); read_frags(S1{}, K3{}, tap, slot); mfmas(S0{});
+            wait_frags(S0{}); read_frags(S1{}, K3{}, tap, slot); mfmas(S0{});
             __builtin_amdgcn_sched_barrier(0);
-            wait_frags(S1{}, W0{}); mfmas(S1{});
+            wait_frags(S1{}); mfmas(S1{});
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             tap = tap == 24 ? 0 : tap + 1;
@@ -441,52 +431,35 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
             }
         }
     } else {
-    // One tap = 4 k-steps of 16 channels.  Fragments are requested TWO k-steps ahead of their MFMAs, into three register sets: with one
-    // k-step of lookahead (round 2) a set had the 128 cycles of the previous k-step's four MFMAs to arrive, less than an LDS round trip
-    // under four reading waves and the ring's DMA writes -- every k-step stalled, 803 cycles per tap for 512 of MFMA (profiles/r03).
-    // Waits are counted (lgkmcnt = the reads issued behind the set that is needed).  4 k-steps on 3 sets: the set of a k-step rotates
-    // from tap to tap, so the tap body is instantiated for the three phases and the loop walks them in turn.
-    // The barrier that publishes the NEXT tap's weights sits in the middle of the tap (its skew hides behind queued MFMAs); the next
-    // tap's first two k-steps are requested behind it.  No VMEM instruction in this loop.
+    read_frags(S0{}, K0{}, tap0, 0);
+
+    // One tap = 4 k-steps of 16 channels; fragments of the next k-step are requested before the MFMAs of the current one.  The
+    // barrier that publishes the NEXT tap's weights sits in the middle of the tap (its skew hides behind queued MFMAs), so the
+    // first fragments of the next tap can be requested right after the last k-step.  No VMEM instruction in this loop.
     int tap = tap0, cg = 0;
-    auto tap_body = [&](auto PH, int it) -> bool {     // returns true when the channel group (or the block's work) ends with this tap
-        constexpr int ph = decltype(PH)::value;
-        using A = std::integral_constant<int, ph % 3>; using B = std::integral_constant<int, (ph + 1) % 3>;
-        using C = std::integral_constant<int, (ph + 2) % 3>;
-        const int slot = it & (NSLOT - 1), nslot = (it + 1) & (NSLOT - 1);
-        read_frags(C{}, K2{}, tap, slot); wait_frags(A{}, W2{}); mfmas(A{});             // k-step 0 (set A), k-step 1 is in flight in B
+    for (int it = 0; it < nchunks; ++it) {
+        const int slot = it & (NSLOT - 1);
+        wait_frags(S0{}); read_frags(S1{}, K1{}, tap, slot); mfmas(S0{});
         __builtin_amdgcn_sched_barrier(0);
-        read_frags(A{}, K3{}, tap, slot); wait_frags(B{}, W2{}); mfmas(B{});             // k-step 1
+        wait_frags(S1{}); read_frags(S0{}, K2{}, tap, slot); mfmas(S1{});
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        const int ntap = tap == 24 ? 0 : tap + 1;
-        const bool regroup = ntap == tap0;
-        if (!regroup) { read_frags(B{}, K0{}, ntap, nslot); wait_frags(C{}, W2{}); }     // k-step 2; the next tap's k-step 0 goes to B
-        else wait_frags(C{}, W1{});
-        mfmas(C{});
+        wait_frags(S0{}); read_frags(S1{}, K3{}, tap, slot); mfmas(S0{});
         __builtin_amdgcn_sched_barrier(0);
-        if (!regroup) { read_frags(C{}, K1{}, ntap, nslot); wait_frags(A{}, W2{}); }     // k-step 3; the next tap's k-step 1 goes to C
-        else wait_frags(A{}, W0{});
-        mfmas(A{});
-        __builtin_amdgcn_sched_barrier(0);
-        tap = ntap;
-        return regroup;
-    };
-    for (int it = 0; it < nchunks;) {
-        // a channel group starts with an empty pipeline: its first two k-steps go to sets 0 and 1, i.e. phase 0
-        read_frags(S0{}, K0{}, tap, it & (NSLOT - 1)); read_frags(S1{}, K1{}, tap, it & (NSLOT - 1));
-        for (;;) {
-            if (tap_body(std::integral_constant<int, 0>{}, it++)) break;
-            if (tap_body(std::integral_constant<int, 1>{}, it++)) break;
-            if (tap_body(std::integral_constant<int, 2>{}, it++)) break;
-        }
-        if (++cg < ncg) {                              // next 64 input channels: all 8 waves restage the patch
+        tap = tap == 24 ? 0 : tap + 1;
+        const bool regroup = tap == tap0;
+        wait_frags(S1{});
+        if (!regroup) read_frags(S0{}, K0{}, tap, (it + 1) & (NSLOT - 1));
+        mfmas(S1{});
+        if (regroup && ++cg < ncg) {                   // next 64 input channels: all 8 waves restage the patch
             __syncthreads();                           // every wave is done with the old patch
             patch_load(cg);
             patch_store();
             __syncthreads();
+            read_frags(S0{}, K0{}, tap, (it + 1) & (NSLOT - 1));
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
     }   // !LATE
 
