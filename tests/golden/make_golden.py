@@ -74,7 +74,7 @@ def run_full_batch(model_type, num_masks, batch, seq_len, smooth=False, fp32_err
 GRAD_SAMPLES = 512
 
 
-def run_full_batch_grads(model_type, num_masks, batch, seq_len, size=64):
+def run_full_batch_grads(model_type, num_masks, batch, seq_len, size=64, trained=None, data_seed=7):
     """The TRAIN step's gradients at full size (config 2: B = 32, feed-self, TM:950 through optimizer.update): float64 autograd of the
     independent PyTorch restatement.  54 tensors, 9.2 M values: the fixture keeps every tensor's L2 norm and sum and up to GRAD_SAMPLES
     entries of each (flat reference layout, a fixed stride from entry 0), plus the loss."""
@@ -83,6 +83,12 @@ def run_full_batch_grads(model_type, num_masks, batch, seq_len, size=64):
     torch.set_num_threads(8)
     P = R.init_params(seed=1, dtype=np.float64, scale=1.0, num_masks=num_masks, model_type=model_type, height=size, width=size)
     imgs, acts, stas = R.synthetic_batch(batch, seq_len, size, size, seed=0)
+    if trained:                          # the TRAINED weights of tests/golden/<trained>.npz on held-out video (run_trained's inputs)
+        sys.path.insert(0, OUT)
+        import trained_weights as TW
+        P32 = TW.load_trained(trained, R.init_params(seed=1, dtype=np.float32, scale=1.0, num_masks=num_masks, model_type=model_type, height=size, width=size))
+        P = type(P32)((k, v.astype(np.float64)) for k, v in P32.items())
+        imgs, acts, stas = R.moving_batch(batch, seq_len, size, size, seed=data_seed)
     kw = dict(is_cdna=model_type == 'CDNA', is_stp=model_type == 'STP', is_dna=model_type == 'DNA')
     tm = TorchModel(num_masks, params=P, requires_grad=True, **kw)
     loss = tm([imgs, acts, stas], 0)
@@ -122,7 +128,10 @@ def run_trained(weights, model_type, num_masks, batch, seq_len, size, data_seed=
     # (sum_k m_{k+2} T_k) -- the fixture must exercise the transforms.  (The MEAN of a mask plane says nothing: the flat-(NM+1) softmax,
     # TM:720-722, normalises over 11 neighbouring pixels of ONE plane, so every plane averages 1/11 whatever the weights are.)
     tp = m.taps[last]
-    moved = sum(layer * tp['masks'][:, k + 2:k + 3] for k, layer in enumerate(tp['transformed'][1:]) if k + 2 < num_masks + 1)
+    if model_type == 'DNA':                # TM:392-415: ONE transformed layer, paired with mask 1 (no generated-pixels layer)
+        moved = tp['transformed'][0] * tp['masks'][:, 1:2]
+    else:
+        moved = sum(layer * tp['masks'][:, k + 2:k + 3] for k, layer in enumerate(tp['transformed'][1:]) if k + 2 < num_masks + 1)
     mk = np.float64(np.abs(moved).mean() / np.abs(tp['output']).mean())
     print('  share of the step-%d output that comes through the transformed layers: %.3f' % (last, mk))
     m32 = R.Model(num_masks, params=P32, dtype=np.float32, prefix='golden', **kw)
@@ -146,6 +155,8 @@ TRAINED = {   # fixture name: (weights file stem, model_type, batch, seq_len, fr
     'stp_b32_t10_trained': ('trained_stp64_q8', 'STP', 32, 10, 64),            # BASELINE.json config 4 with trained weights
     'stp_b2_t20_trained': ('trained_stp64_q8', 'STP', 2, 20, 64),              # ... and a 20-step rollout of the same model
     'cdna_128_b2_t20_trained': ('trained_cdna128_q8', 'CDNA', 2, 20, 128),     # config 5's geometry (128x128, 20 frames), trained
+    'cdna_b32_t10_trained': ('trained_cdna64_q8', 'CDNA', 32, 10, 64),         # config 2 itself (the headline workload), trained
+    'dna_b2_t10_trained': ('trained_dna64_q8', 'DNA', 2, 10, 64),              # the DNA variant, trained
 }
 
 FULL_BATCH = {   # name: (model_type, batch, seq_len, frame size, smooth, fp32_error)
@@ -157,6 +168,11 @@ FULL_BATCH = {   # name: (model_type, batch, seq_len, frame size, smooth, fp32_e
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'grads_trained':       # config 2's train-step gradients on the trained CDNA weights
+        np.savez_compressed(os.path.join(OUT, 'cdna_b32_t10_trained_grads.npz'),
+                            **run_full_batch_grads('CDNA', 10, 32, 10, trained='trained_cdna64_q8'), trained='trained_cdna64_q8', data_seed=7)
+        print('cdna_b32_t10_trained_grads', os.path.getsize(os.path.join(OUT, 'cdna_b32_t10_trained_grads.npz')))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'grads':               # a few minutes of PyTorch-CPU float64
         np.savez_compressed(os.path.join(OUT, 'cdna_b32_t10_grads.npz'), **run_full_batch_grads('CDNA', 10, 32, 10))
         print('cdna_b32_t10_grads', os.path.getsize(os.path.join(OUT, 'cdna_b32_t10_grads.npz')))
@@ -166,7 +182,7 @@ if __name__ == '__main__':
         for name, (wt, mt, nb, nt, size) in TRAINED.items():
             if len(sys.argv) > 2 and sys.argv[2] != name:
                 continue
-            out = run_trained(wt, mt, 10, nb, nt, size, weights_dir=wdir)
+            out = run_trained(wt, mt, 1 if mt == 'DNA' else 10, nb, nt, size, weights_dir=wdir)
             if not wdir:
                 np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
                 print(name, os.path.getsize(os.path.join(OUT, name + '.npz')))
