@@ -180,49 +180,23 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
     }
 
     // ---- epilogue: accumulator row i -> anchor (2 wave + i / 16, i % 16), parity (py, px) -> output pixel (2 y + py, 2 x + px) ----------
-    // A lane holds ONE column of 64 output pixels: stored from the accumulators that is 64 four-byte store instructions per wave (two 128-B
-    // segments each), and the kernel's tail was store-issue bound.  The wave's tile goes through LDS instead (the images are dead): for each
-    // output-row parity py the wave's 2 anchor rows x 16 anchors x 2 px are 2 output rows of 32 CONSECUTIVE pixels x 32 columns = 8 KB, read
-    // back as float4 per lane -- 16 store instructions of 8 pixels x 128 B per wave and parity pair instead of 32.
     const int col = nblk * 32 + l31;
     const float bias = d.bias ? d.bias[col] : 0.f;
     float s1 = 0.f;
-    __syncthreads();                               // every wave is done with the patch and weight images
-    float* stw = lds + wave * 2048;                // this wave's [2 output rows][32 pixels][32 columns]
 #pragma unroll
-    for (int py = 0; py < 2; ++py) {
+    for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
-        for (int px = 0; px < 2; ++px)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;            // anchor of the wave tile: row i / 16, column i % 16
-                float v = acc[2 * py + px][r] + bias;
-                if (d.relu) v = fmaxf(v, 0.f);
-                stw[((i >> 4) * 32 + 2 * (i & 15) + px) * 32 + l31] = v;
-            }
-        // (a wave reads back only what it wrote: no block barrier; the compiler orders its LDS writes and reads)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int pxl = (lane >> 3) + 8 * j, c4v = (lane & 7) * 4;      // pixel 0..63 of the two rows, 4 columns
-            f32x4 v = *reinterpret_cast<const f32x4*>(stw + pxl * 32 + c4v);
-            const int oy = 2 * (y0 + 2 * wave + (pxl >> 5)) + py, ox = 2 * x0 + (pxl & 31);
-            float* o = d.out + ((size_t)(b * d.Hout + oy) * d.Wout + ox) * d.ldo + nblk * 32 + c4v;
-            if (d.accum) v += *reinterpret_cast<const f32x4*>(o);
-            *reinterpret_cast<f32x4*>(o) = v;
-            if (d.ln_part || d.accum) *reinterpret_cast<f32x4*>(stw + pxl * 32 + c4v) = v;   // final values for the statistics below
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int oy = 2 * (y0 + 2 * wave + (i >> 4)) + (ph >> 1), ox = 2 * (x0 + (i & 15)) + (ph & 1);
+            float* o = d.out + ((size_t)(b * d.Hout + oy) * d.Wout + ox) * d.ldo + col;
+            float v = acc[ph][r] + bias;
+            if (d.relu) v = fmaxf(v, 0.f);
+            if (d.accum) v += *o;
+            *o = v;
+            acc[ph][r] = v;
+            s1 += v;
         }
-        if (d.ln_part) {                           // back into the accumulator registers (the LayerNorm partial's two passes run on them)
-#pragma unroll
-            for (int px = 0; px < 2; ++px)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const float v = stw[((i >> 4) * 32 + 2 * (i & 15) + px) * 32 + l31];
-                    acc[2 * py + px][r] = v;
-                    s1 += v;
-                }
-        }
-    }
     if (d.ln_part) {   // (count, mean, M2) of the block's 128 x 4 x 32 outputs: two passes over registers, fixed order
         float* red = lds;
         s1 = wave_sum(s1);
@@ -248,8 +222,7 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
 
 bool deconv_tile_ok(const IgemmDesc& d) {
     return d.deconv && d.nphase == 4 && d.c1 == 0 && d.c0 % 32 == 0 && d.N % 32 == 0 && d.Hin % 8 == 0 && d.Win % 16 == 0 &&
-           d.Hout == 2 * d.Hin && d.Wout == 2 * d.Win && d.ld0 % 4 == 0 && d.out != nullptr &&
-           d.ldo % 4 == 0 && ((uintptr_t)d.out & 15) == 0;      // float4 output rows
+           d.Hout == 2 * d.Hin && d.Wout == 2 * d.Win && d.ld0 % 4 == 0 && d.out != nullptr;
 }
 
 // d as igemm_conv takes it for the transposed conv (validated by the caller); ln_nparts as there.

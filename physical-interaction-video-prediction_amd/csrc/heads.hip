@@ -51,27 +51,28 @@ __global__ __launch_bounds__(256) void heads_1x1_kernel(const float* __restrict_
     }
     if (ln_part && px0 < total_px) {   // a wave's 64 pixels never straddle samples (HW % 64 == 0, checked by the launcher)
         const int bs = px0 / HW;
-        // gamma / beta of the whole tile are requested before the statistics are merged: 32 more 16-B loads in flight behind the tile's 16,
-        // one round trip for everything (round 2 fetched them in four batches of 8 behind the merge: four more exposed round trips per wave)
-        f32x4 g[16], bb[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int f = lane + 64 * j, p = f >> 4, cv = (f & 15) * 4;
-            const size_t gi = (size_t)(min(px0 + p, total_px - 1) - bs * HW) * 64 + cv;
-            g[j] = *reinterpret_cast<const f32x4*>(gamma + gi);
-            bb[j] = *reinterpret_cast<const f32x4*>(beta + gi);
-        }
         float mean, rstd;
         ln_merge_partials(ln_part, bs, ln_nparts, eps, mean, rstd);
         if (lane == 0 && stat_out && px0 == bs * HW) { stat_out[bs * 2] = mean; stat_out[bs * 2 + 1] = rstd; }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int f = lane + 64 * j, p = f >> 4, cv = (f & 15) * 4;
-            f32x4 v = rx[j];
+        for (int j4 = 0; j4 < 16; j4 += 4) {          // gamma / beta in batches of four rows: 8 more loads in flight
+            f32x4 g[4], bb[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf((v[e] - mean) * rstd * g[j][e] + bb[j][e], 0.f);
-            if (y_out && px0 + p < total_px) *reinterpret_cast<f32x4*>(y_out + (size_t)(px0 + p) * 64 + cv) = v;
-            rx[j] = v;
+            for (int u = 0; u < 4; ++u) {
+                const int f = lane + 64 * (j4 + u), p = f >> 4, cv = (f & 15) * 4;
+                const size_t gi = (size_t)(min(px0 + p, total_px - 1) - bs * HW) * 64 + cv;
+                g[u] = *reinterpret_cast<const f32x4*>(gamma + gi);
+                bb[u] = *reinterpret_cast<const f32x4*>(beta + gi);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = lane + 64 * (j4 + u), p = f >> 4, cv = (f & 15) * 4;
+                f32x4 v = rx[j4 + u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf((v[e] - mean) * rstd * g[u][e] + bb[u][e], 0.f);
+                if (y_out && px0 + p < total_px) *reinterpret_cast<f32x4*>(y_out + (size_t)(px0 + p) * 64 + cv) = v;
+                rx[j4 + u] = v;
+            }
         }
     }
     float* mt = xt[wave];
