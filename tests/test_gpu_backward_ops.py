@@ -262,3 +262,55 @@ def test_convlstm_backward_last_timestep_computes_dx_only(env, B, cx, C, H):
     assert _rel(dc.cpu().numpy().reshape(B, H, H, C).transpose(0, 3, 1, 2), tc.grad.numpy()) < 2e-5
     assert _rel(pivp.from_internal('lstm1/conv/W', dW.cpu().numpy(), W.shape), tW.grad.numpy()) < 2e-5
     assert _rel(db.cpu().numpy(), tb.grad.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize('fused', [0, 1])
+@pytest.mark.parametrize('B,C,H,lddy,recurrent', [(32, 32, 32, 64, True), (8, 64, 16, 96, True), (32, 128, 8, 128, True), (5, 32, 32, 32, False),
+                                                  (2, 64, 16, 64, True)])
+def test_layernorm_plus_gate_backward_pair(env, fused, B, C, H, lddy, recurrent):
+    """hidden<k>'s LayerNorm backward + lstm<k>'s gate backward as the sweep runs the pair (TM:203-208, TM:269-272): the two-launch form
+    (sums, then gates reading the partials) and the form with the sums inside the gate launch, both against float64 autograd."""
+    pivp, _lib, lib = env
+    rs = np.random.RandomState(100 * C + B)
+    npix, n = H * H, H * H * C
+    if fused and not lib.pivp_gates_backward_ln_fits(B, n, C):
+        pytest.skip('shape not taken by the in-launch sums')
+    # forward pieces in NHWC: pre-activation gates, c_{t-1}; h_t = tanh(c_t) s(o) goes through the norm, whose output meets dy
+    pre = rs.randn(B, npix, 4, C); c_old = rs.randn(B, npix, C)
+    gamma = 1.0 + 0.3 * rs.randn(npix, C); beta = 0.1 * rs.randn(npix, C)
+    dy = rs.randn(B, npix, C); dh_b = rs.randn(B, npix, C) * 0.5; dc_in = rs.randn(B, npix, C)
+    tp, tco = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (pre, c_old)]
+    tg, tb = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (gamma, beta)]
+    aj, ai, af, ao = torch.tanh(tp[:, :, 0]), torch.sigmoid(tp[:, :, 1]), torch.sigmoid(tp[:, :, 2] + 1.0), torch.sigmoid(tp[:, :, 3])
+    cn = tco * af + ai * aj
+    hn = torch.tanh(cn) * ao
+    mean = hn.reshape(B, -1).mean(1)[:, None, None]; var = hn.reshape(B, -1).var(1, unbiased=False)[:, None, None]
+    eps = 1e-6
+    y = (hn - mean) / torch.sqrt(var + eps) * tg + tb
+    loss = (y * torch.tensor(dy)).sum() + (cn * torch.tensor(dc_in)).sum()
+    if recurrent:
+        loss = loss + (hn * torch.tensor(dh_b)).sum()
+    loss.backward()
+    # HIP: stored activations j, i, f, o; stat = (mean, rstd)
+    gates = _t(torch.stack((aj, ai, af, ao), 2).detach().numpy().reshape(B * npix, 4 * C))
+    stat = _t(np.stack((mean.detach().numpy().reshape(B), 1.0 / np.sqrt(var.detach().numpy().reshape(B) + eps)), 1))
+    dyw = torch.full((B * npix, lddy), 7.0, dtype=torch.float32, device=DEV)
+    off = lddy - C                                                           # the slice sits at the end of a wider concat row
+    dyw[:, off:] = _t(dy.reshape(B * npix, C))
+    dc = _t(dc_in.reshape(B * npix, C)); dG = torch.empty((B * npix, 4 * C), dtype=torch.float32, device=DEV)
+    dgm = torch.full((n,), 0.5, dtype=torch.float32, device=DEV); dbt = torch.full((n,), -0.25, dtype=torch.float32, device=DEV)   # accumulated into
+    scratch = torch.empty(lib.pivp_gates_backward_ln_scratch_floats(B, n), dtype=torch.float32, device=DEV)
+    hb = _t(dh_b.reshape(B * npix, C)) if recurrent else None
+    cod, cnd, gmd, hd = _t(c_old.reshape(B * npix, C)), _t(cn.detach().numpy().reshape(B * npix, C)), _t(gamma.reshape(-1)), _t(hn.detach().numpy().reshape(B * npix, C))
+    _lib.check(lib.pivp_gates_backward_ln(gates.data_ptr(), cod.data_ptr(), cnd.data_ptr(),
+                                          dyw.data_ptr() + off * 4, lddy, gmd.data_ptr(), stat.data_ptr(),
+                                          hd.data_ptr(), hb.data_ptr() if recurrent else None, C,
+                                          dc.data_ptr(), 1, dG.data_ptr(), dgm.data_ptr(), dbt.data_ptr(), scratch.data_ptr(), B, npix, C, fused, _st()),
+               'pivp_gates_backward_ln')
+    torch.cuda.synchronize()
+    ref_dG = tp.grad.numpy().reshape(B * npix, 4 * C)
+    assert _rel(dG.cpu().numpy(), ref_dG) < 2e-5
+    assert _rel(dc.cpu().numpy(), tco.grad.numpy().reshape(B * npix, C)) < 2e-5
+    assert _rel(dgm.cpu().numpy() - 0.5, tg.grad.numpy().reshape(-1)) < 2e-5
+    assert _rel(dbt.cpu().numpy() + 0.25, tb.grad.numpy().reshape(-1)) < 2e-5
+    assert off == 0 or float(dyw[:, :off].min()) == 7.0
