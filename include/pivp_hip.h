@@ -250,16 +250,14 @@ int pivp_layernorm_backward(const float* dy, int lddy, const float* y, int ldy, 
                             const float* gamma, float* partials, float* dx, float* dgamma, float* dbeta,
                             int B, int n, int C, int relu, void* stream);
 /* The pair "LayerNorm backward of hidden<k> (TM:203-208) + gate backward of lstm<k> (TM:269-272)" as the BPTT sweep runs it: dy (stride
- * lddy) is the gradient at the norm's output, h the cell's h_t = the norm's input, stat its (mean, rstd); the cell's dh is the norm's dx
- * (+ dh_b, the recurrent part, may be NULL).  Writes dG [B*npix][4C], updates dc in place, ACCUMULATES dgamma / dbeta.  fused = 0: two
- * launches (sums, then gates); fused = 1: the gate kernel forms the norm's sums itself (shapes for which pivp_gates_backward_ln_fits
- * returns 1; PIVP_ERR_BADARG otherwise).  scratch: pivp_gates_backward_ln_scratch_floats floats. */
+ * lddy) is the gradient at the norm's output, h the cell's h_t = the norm's input, stat its (mean, rstd); the cell's dh is the norm's dx,
+ * formed inside the gate kernel from the sums of a first launch (+ dh_b, the recurrent part, may be NULL).  Writes dG [B*npix][4C],
+ * updates dc in place, ACCUMULATES dgamma / dbeta.  scratch: pivp_gates_backward_ln_scratch_floats floats. */
 long long pivp_gates_backward_ln_scratch_floats(int B, int n);
-int pivp_gates_backward_ln_fits(int B, int n, int C);
 int pivp_gates_backward_ln(const float* gates, const float* c_old, const float* c_new, const float* dy, int lddy,
                            const float* gamma, const float* stat, const float* h, const float* dh_b, int ldb, float* dc,
                            int dc_valid, float* dG, float* dgamma, float* dbeta, float* scratch, int B, int npix, int C,
-                           int fused, void* stream);
+                           void* stream);
 /* Chainer 2 Adam over a flat buffer (TM:860): lr_t = alpha*sqrt(1-beta2^t)/(1-beta1^t) from the host; g is scaled by gscale. */
 int pivp_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr_t, double beta1, double beta2,
                    double eps, double gscale, void* stream);

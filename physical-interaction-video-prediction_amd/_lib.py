@@ -73,8 +73,7 @@ SIGNATURES = {
     'pivp_layernorm_backward_scratch_floats': (_ll, [_i, _i]),
     'pivp_layernorm_backward': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'pivp_gates_backward_ln_scratch_floats': (_ll, [_i, _i]),
-    'pivp_gates_backward_ln_fits': (_i, [_i, _i, _i]),
-    'pivp_gates_backward_ln': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'pivp_gates_backward_ln': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pivp_adam_step': (_i, [_vp, _vp, _vp, _vp, _ll, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _vp]),
     'pivp_grad_pack_bf16': (_i, [_vp, _vp, _ll, _vp]),
     'pivp_grad_unpack_bf16': (_i, [_vp, _vp, _ll, _vp]),

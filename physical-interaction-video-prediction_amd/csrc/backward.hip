@@ -84,125 +84,6 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __rest
     *reinterpret_cast<f32x4*>(dc + idx) = dcn;
 }
 
-// The same with the LayerNorm-backward SUMS formed inside the launch (LnFuse::whole): ln_bwd_sums_params_kernel in front of every cell's gate
-// backward was a 6-7 us launch on the sweep's critical path for 2 x 128 KB of reading.  A sample's (sum g, sum g xhat) need the whole
-// sample, so a block (NT threads, blockIdx.x = sample, blockIdx.y = one of `parts` ranges of the sample's elements) first reads
-// dy, gamma and h of its WHOLE sample -- the `parts` blocks of a sample repeat each other's reads; they are blockIdx.x = b apart, i.e. on
-// the same XCD for B % 8 == 0, so all but the first come out of that XCD's L2 -- reduces them in a fixed order (every block of a sample
-// gets bit-identical sums) and then does the gate backward of its own range.  No cross-block communication, no atomics, no spin.
-// The gate backward's own operands (stored activations, c, d c: cold, from HBM) are requested BEFORE the sums, so that their round trip
-// runs under the sums' reads.  Needs C a power of two (log2 = lc), (n / 4) % (4 * NT) == 0 and (n / parts / 4) % NT == 0
-// (lstm_gates_bwd_whole_parts; else the two-launch path).  The norm's parameter gradients are no longer a by-product of the sums:
-// ln_bwd_params_only, off the critical path.
-struct GateOps { f32x4 aj, ai, af, ao, cn, co, dcv, dhb; };
-template <int NT>
-__global__ __launch_bounds__(NT) void lstm_gates_bwd_lnsum_kernel(const float* __restrict__ gates, const float* __restrict__ c_old,
-                                                                  const float* __restrict__ c_new, const float* __restrict__ dh_b, int ldb,
-                                                                  float* __restrict__ dc, int dc_valid, float* __restrict__ dG, int npix,
-                                                                  int C, int lc, const LnFuse ln, float* __restrict__ zero, long long zero_f4) {
-    PIVP_SET_MAIN_PRIO();
-    __shared__ float red[NT / 64][2];
-    const int b = blockIdx.x, part = blockIdx.y, parts = gridDim.y;
-    const int n = npix * C, n4 = n >> 2;
-    const int per4 = n4 / parts, qend = (part + 1) * per4;
-    int q = part * per4 + threadIdx.x;
-    auto load_ops = [&](int qq, GateOps& o) {
-        const int e = qq << 2, pix = e >> lc, ch = e & (C - 1);
-        const size_t m = (size_t)b * npix + pix;
-        const size_t idx = m * C + ch;
-        const float* g = gates + m * 4 * C + ch;
-        o.aj = *reinterpret_cast<const f32x4*>(g); o.ai = *reinterpret_cast<const f32x4*>(g + C);
-        o.af = *reinterpret_cast<const f32x4*>(g + 2 * C); o.ao = *reinterpret_cast<const f32x4*>(g + 3 * C);
-        o.cn = *reinterpret_cast<const f32x4*>(c_new + idx); o.co = *reinterpret_cast<const f32x4*>(c_old + idx);
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        o.dcv = dc_valid ? *reinterpret_cast<const f32x4*>(dc + idx) : z;
-        o.dhb = dh_b ? *reinterpret_cast<const f32x4*>(dh_b + m * ldb + ch) : z;
-    };
-    GateOps cur;
-    load_ops(q, cur);                                     // per4 % NT == 0: every thread has at least one
-    if (zero) {
-        const long long nthr = (long long)gridDim.x * gridDim.y * NT;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        for (long long i = ((long long)part * gridDim.x + b) * NT + threadIdx.x; i < zero_f4; i += nthr) reinterpret_cast<f32x4*>(zero)[i] = z;
-    }
-    const float mean = ln.stat[b * 2], rstd = ln.stat[b * 2 + 1];
-    const float* __restrict__ dyb = ln.dy + (size_t)b * npix * ln.lddy;
-    const float* __restrict__ hb = ln.h + (size_t)b * n;
-    // ---- the sample's sums: four float4 triples in flight per thread ----
-    float s1 = 0.f, s2 = 0.f;
-    for (int q0 = threadIdx.x; q0 < n4; q0 += 4 * NT) {
-        f32x4 dv[4], gv[4], hv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = (q0 + u * NT) << 2;
-            dv[u] = *reinterpret_cast<const f32x4*>(dyb + (size_t)(e >> lc) * ln.lddy + (e & (C - 1)));
-            gv[u] = *reinterpret_cast<const f32x4*>(ln.gamma + e);
-            hv[u] = *reinterpret_cast<const f32x4*>(hb + e);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float gg = dv[u][k] * gv[u][k];
-                s1 += gg; s2 = fmaf(gg, (hv[u][k] - mean) * rstd, s2);
-            }
-    }
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s1; red[threadIdx.x >> 6][1] = s2; }
-    __syncthreads();
-    float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-    for (int w = 0; w < NT / 64; ++w) { m1 += red[w][0]; m2 += red[w][1]; }
-    m1 /= (float)n; m2 /= (float)n;
-    // ---- gate backward of this block's range of the sample ----
-    while (true) {
-        const int e = q << 2, pix = e >> lc, ch = e & (C - 1);
-        const size_t m = (size_t)b * npix + pix;
-        const size_t idx = m * C + ch;
-        const f32x4 dy = *reinterpret_cast<const f32x4*>(ln.dy + m * ln.lddy + ch);
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(ln.gamma + e);
-        const f32x4 hv = *reinterpret_cast<const f32x4*>(ln.h + idx);
-        const GateOps o = cur;
-        const bool more = q + NT < qend;
-        if (more) load_ops(q + NT, cur);
-        f32x4 oj, oi, of, oo, dcn;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float dh = rstd * (dy[k] * gm[k] - m1 - (hv[k] - mean) * rstd * m2) + o.dhb[k];
-            const float tc = fast_tanh_b(o.cn[k]);
-            const float dct = dh * o.ao[k] * (1.f - tc * tc) + o.dcv[k];
-            oj[k] = dct * o.ai[k] * (1.f - o.aj[k] * o.aj[k]);
-            oi[k] = dct * o.aj[k] * o.ai[k] * (1.f - o.ai[k]);
-            of[k] = dct * o.co[k] * o.af[k] * (1.f - o.af[k]);
-            oo[k] = dh * tc * o.ao[k] * (1.f - o.ao[k]);
-            dcn[k] = dct * o.af[k];
-        }
-        float* og = dG + m * 4 * C + ch;
-        *reinterpret_cast<f32x4*>(og) = oj; *reinterpret_cast<f32x4*>(og + C) = oi;
-        *reinterpret_cast<f32x4*>(og + 2 * C) = of; *reinterpret_cast<f32x4*>(og + 3 * C) = oo;
-        *reinterpret_cast<f32x4*>(dc + idx) = dcn;
-        if (!more) break;
-        q += NT;
-    }
-}
-
-// threads per block of lstm_gates_bwd_lnsum_kernel for a norm of n elements per sample
-static int gates_lnsum_threads(int n) { return (n / 4) % 4096 == 0 ? 1024 : 512; }
-// parts per sample of lstm_gates_bwd_lnsum_kernel for a norm of n elements per sample over B samples; 0 = the shape does not fit it
-int lstm_gates_bwd_whole_parts(int B, int n, int C) {
-    static const int forced = [] { const char* e = getenv("PIVP_LNSUM_PARTS"); return e ? atoi(e) : -1; }();   // tuning: 0 = never, k = at most k parts
-    if (forced == 0 || B <= 0 || n <= 0 || C <= 0 || (C & (C - 1)) || n % C || n % 4) return 0;
-    const int n4 = n / 4;
-    if (n4 % 2048 || n > (1 << 15)) return 0;       // beyond 32 K elements the repeated whole-sample read costs more than a launch
-    const int nt = gates_lnsum_threads(n);
-    static const int cus = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256; (void)hipGetLastError(); return v > 0 ? v : 256; }();
-    int parts = n4 / nt;                              // one float4 of the gate backward per thread
-    if (forced > 0 && parts > forced) parts = forced;
-    while (parts > 1 && (parts * B > cus + cus / 4 || n4 % parts || (n4 / parts) % nt)) --parts;    // about one block per CU at most
-    if (n4 % parts || (n4 / parts) % nt) return 0;
-    return parts;
-}
-
 int lstm_gates_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_a, int lda,
                    const float* dh_b, int ldb, float* dc, int dc_valid, float* dG, int M, int C, hipStream_t s, int B, const LnFuse* ln,
                    float* zero, long long zero_floats) {
@@ -212,22 +93,10 @@ int lstm_gates_bwd(const float* gates, const float* c_old, const float* c_new, c
     LnFuse lf;
     memset(&lf, 0, sizeof(lf));
     if (ln && ln->dy) {
-        PIVP_CHECK_ARG(ln->gamma && ln->stat && ln->h && ln->lddy % 4 == 0 && (ln->whole > 0 || (ln->partials && ln->S > 0)));
+        PIVP_CHECK_ARG(ln->gamma && ln->stat && ln->partials && ln->h && ln->S > 0 && ln->lddy % 4 == 0);
         lf = *ln;
     }
     const int npix = M / B;
-    if (lf.dy && lf.whole > 0) {      // the norm's sums inside this launch
-        PIVP_CHECK_ARG(!dh_a && lf.whole == lstm_gates_bwd_whole_parts(B, npix * C, C));
-        int lc = 0;
-        while ((1 << lc) < C) ++lc;
-        if (gates_lnsum_threads(npix * C) == 1024)
-            hipLaunchKernelGGL(lstm_gates_bwd_lnsum_kernel<1024>, dim3(B, lf.whole), dim3(1024), 0, s, gates, c_old, c_new, dh_b, ldb, dc, dc_valid, dG,
-                               npix, C, lc, lf, zero, zero ? zero_floats / 4 : 0);
-        else
-            hipLaunchKernelGGL(lstm_gates_bwd_lnsum_kernel<512>, dim3(B, lf.whole), dim3(512), 0, s, gates, c_old, c_new, dh_b, ldb, dc, dc_valid, dG,
-                               npix, C, lc, lf, zero, zero ? zero_floats / 4 : 0);
-        return PIVP_LAUNCH_STATUS();
-    }
     const int xb = (npix * C / 4 + 255) / 256;
     hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(xb, B), dim3(256), 0, s, gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc,
                        dc_valid, dG, npix, C, lf, zero, zero ? zero_floats / 4 : 0);
@@ -502,15 +371,6 @@ int ln_bwd_params_reduce(const float* part, float* dgamma, float* dbeta, int B, 
 }
 
 int ln_bwd_slices(int n) { return (n + LNB_SLICE - 1) / LNB_SLICE; }
-
-// the parameter-gradient planes of one LayerNorm backward alone (no sums, no dx): what is left of the norm behind a ConvLSTM when the
-// gate backward forms the sums itself (LnFuse::whole); the plan runs it on its side stream.  `part` as in ln_backward.
-int ln_bwd_params_only(const float* dy, int lddy, const float* x, const float* stat, int B, int n, int C, float* part, hipStream_t s) {
-    PIVP_CHECK_ARG(dy && x && stat && part && B > 0 && n > 0 && C > 0 && C % 4 == 0 && n % C == 0 && lddy >= C && lddy % 4 == 0);
-    hipLaunchKernelGGL(ln_bwd_params_kernel, dim3((n / 4 + 255) / 256, ln_bwd_param_groups(B, n)), dim3(256), 0, s, dy, lddy, nullptr, 0, x, stat,
-                       nullptr, nullptr, B, n, C, 0, part);
-    return PIVP_LAUNCH_STATUS();
-}
 
 int ln_backward(const float* dy, int lddy, const float* y, int ldy, const float* x, const float* stat, const float* gamma,
                 float* partials, float* dx, float* dgamma, float* dbeta, int B, int n, int C, int relu, hipStream_t s, float* param_part) {

@@ -308,7 +308,7 @@ long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin,
 
 }  // namespace pivp
 
-extern "C" int pivp_abi_version(void) { return 8; }   // 8: + pivp_gates_backward_ln (LayerNorm sums inside the gate backward); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
+extern "C" int pivp_abi_version(void) { return 8; }   // 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
 
 extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                              const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream) {
@@ -475,17 +475,15 @@ extern "C" int pivp_layernorm_backward(const float* dy, int lddy, const float* y
     return ln_backward(dy, lddy, y, ldy, x, stat, gamma, partials, dx, dgamma, dbeta, B, n, C, relu, (hipStream_t)stream);
 }
 // LayerNorm backward of the norm behind a ConvLSTM + the cell's gate backward, the way the BPTT sweep runs the pair (pivp_plan.hip:
-// lnb_cell + lstmb).  fused = 0: sums + parameter planes in one launch, then the gate kernel reads the partials; fused = 1: the gate
-// kernel forms the sums itself, the parameter planes come from a launch of their own (the sweep puts it on its side stream).
+// lnb_cell + lstmb): sums + parameter planes in one launch, then the gate kernel forms the norm's dx from the partials on the fly.
 extern "C" long long pivp_gates_backward_ln_scratch_floats(int B, int n) {
     if (B <= 0 || n <= 0) return PIVP_ERR_BADARG;
     return (long long)B * ln_bwd_slices(n) * 2 + ln_bwd_param_part_floats(n);
 }
-extern "C" int pivp_gates_backward_ln_fits(int B, int n, int C) { return lstm_gates_bwd_whole_parts(B, n, C) > 0 ? 1 : 0; }
 extern "C" int pivp_gates_backward_ln(const float* gates, const float* c_old, const float* c_new, const float* dy, int lddy,
                                       const float* gamma, const float* stat, const float* h, const float* dh_b, int ldb, float* dc,
                                       int dc_valid, float* dG, float* dgamma, float* dbeta, float* scratch, int B, int npix, int C,
-                                      int fused, void* stream) {
+                                      void* stream) {
     if (!gates || !c_old || !c_new || !dy || !gamma || !stat || !h || !dc || !dG || !dgamma || !dbeta || !scratch) return PIVP_ERR_BADARG;
     if (B <= 0 || npix <= 0 || C <= 0 || C % 4 || lddy < C || lddy % 4) return PIVP_ERR_BADARG;
     hipStream_t s = (hipStream_t)stream;
@@ -496,15 +494,8 @@ extern "C" int pivp_gates_backward_ln(const float* gates, const float* c_old, co
     LnFuse lf;
     memset(&lf, 0, sizeof(lf));
     lf.dy = dy; lf.lddy = lddy; lf.gamma = gamma; lf.stat = stat; lf.h = h;
-    int rc;
-    if (fused) {
-        lf.whole = lstm_gates_bwd_whole_parts(B, n, C);
-        if (lf.whole <= 0) return PIVP_ERR_BADARG;
-        rc = ln_bwd_params_only(dy, lddy, h, stat, B, n, C, part, s);
-    } else {
-        lf.partials = partials; lf.S = ln_bwd_slices(n);
-        rc = ln_backward(dy, lddy, nullptr, 0, h, stat, gamma, partials, nullptr, dgamma, dbeta, B, n, C, 0, s, part);
-    }
+    lf.partials = partials; lf.S = ln_bwd_slices(n);
+    int rc = ln_backward(dy, lddy, nullptr, 0, h, stat, gamma, partials, nullptr, dgamma, dbeta, B, n, C, 0, s, part);
     if (rc != PIVP_OK) return rc;
     rc = lstm_gates_bwd(gates, c_old, c_new, nullptr, 0, dh_b, ldb, dc, dc_valid, dG, B * npix, C, s, B, &lf);
     if (rc != PIVP_OK) return rc;

@@ -160,10 +160,7 @@ struct LnFuse {
     const float* stat;               // [B][2] mean, rstd of the forward pass
     const float* partials; int S;    // [B][S][2] from ln_bwd_stats_kernel (S = ln_bwd_slices(n))
     const float* h;                  // the norm's input = the cell's h_t, [M][C]
-    int whole;                       // > 0: no partials -- the gate kernel forms the sums itself, `whole` blocks per sample
-                                     // (= lstm_gates_bwd_whole_parts(B, n, C), which is 0 for shapes the kernel does not take)
 };
-int lstm_gates_bwd_whole_parts(int B, int n, int C);
 int lstm_gates_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_a, int lda,
                    const float* dh_b, int ldb, float* dc, int dc_valid, float* dG, int M, int C, hipStream_t s, int B = 1,
                    const LnFuse* ln = nullptr,
@@ -172,7 +169,6 @@ int bias_grad(const float* dy, int ld, int N, int M, float* db, hipStream_t s);
 int relu_mask(float* dy, int lddy, const float* y, int ldy, int C, long npix, hipStream_t s,
               const float* add = nullptr, int ldadd = 0);   // add: dy = (dy + add) masked -- a second gradient path into the same activation
 int ln_bwd_slices(int n);
-int ln_bwd_params_only(const float* dy, int lddy, const float* x, const float* stat, int B, int n, int C, float* part, hipStream_t s);
 // param_part (optional, ln_bwd_param_part_floats(n) floats, zeroed before the first launch of a sweep): the parameter gradients are
 // accumulated there without atomics and reach dgamma / dbeta only through ln_bwd_params_reduce (once per sweep)
 int ln_backward(const float* dy, int lddy, const float* y, int ldy, const float* x, const float* stat, const float* gamma,

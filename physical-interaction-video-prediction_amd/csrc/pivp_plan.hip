@@ -59,9 +59,7 @@ struct Slab {
 };
 
 struct Grads {   // gradient workspace (single copy, reused by every timestep of the backward sweep)
-    size_t cat7[2], n2[2], cat6[2], n4[2], n5[2];   // gradients at the outputs of hidden7 / 2 / 6 / 4 / 5's norms (+ concat partners): one copy per timestep
-                                                    // parity, because the side stream's norm-parameter launches of step t read them during step t-1
-    size_t e2, e6, e6raw, e0raw;
+    size_t cat7, n2, cat6, n4, e2, n5, e6, e6raw, e0raw;
     size_t din[7][2], dc[7];
     size_t dG[7], go[2], dmk, dz, dkpart, dv, dstate, lnpart;   // dG: gate pre-activation gradients per ConvLSTM: 2 rings x wg_cap timesteps (batched weight gradients)
     size_t wt_lstm[7], wt_enc[7];   // re-packed (transposed) weights for the data gradients, rebuilt once per backward
@@ -225,11 +223,8 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
     p->has_grads = train;
     if (p->has_grads) {
         Grads& g = p->g;
-        for (int r = 0; r < 2; ++r) {
-            g.cat7[r] = carve(B * HW2 * 64); g.n2[r] = carve(B * HW2 * 32); g.cat6[r] = carve(B * HW4 * 96); g.n4[r] = carve(B * HW4 * 64);
-            g.n5[r] = carve(B * HW8 * 128);
-        }
-        g.e2 = carve(B * HW8 * 64); g.e6 = carve(B * HW * 64); g.e6raw = carve(B * HW * 64);
+        g.cat7 = carve(B * HW2 * 64); g.n2 = carve(B * HW2 * 32); g.cat6 = carve(B * HW4 * 96); g.n4 = carve(B * HW4 * 64);
+        g.e2 = carve(B * HW8 * 64); g.n5 = carve(B * HW8 * 128); g.e6 = carve(B * HW * 64); g.e6raw = carve(B * HW * 64);
         g.e0raw = carve(B * HW2 * 32);
         for (int i = 0; i < 7; ++i) {
             const size_t M = hsz[i] / kLstm[i].C * B;
@@ -573,7 +568,6 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     const Slab* Sp = t > 0 ? &p->slabs[t - 1] : nullptr;
     const Grads& g = p->g;
     const int par = t & 1, npar = par ^ 1;
-    const size_t d_cat7 = g.cat7[par], d_n2 = g.n2[par], d_cat6 = g.cat6[par], d_n4 = g.n4[par], d_n5 = g.n5[par];
     const int n2 = 32 * p->H2 * p->W2, n4 = 64 * p->H4 * p->W4, n8 = 128 * p->H8 * p->W8;
     float* lnpart = ws + g.lnpart;
     const long long ln_n[9] = {n2, n2, n2, n4, n4, n8, n4, n2, 64LL * HW};   // elements per sample of norm_enc0, hidden1..7, norm_enc6
@@ -601,34 +595,11 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     };
     const long long slab_bytes = p->nslabs > 1 ? ((long long)p->slabs[1].cat7 - (long long)p->slabs[0].cat7) * 4 : 0;
     // LayerNorm behind ConvLSTM i (hidden<i+1>): partial sums and parameter gradients here, dx inside the cell's gate backward
-    // With a side stream the norm's sums move INTO the cell's gate backward (LnFuse::whole, backward.hip) and its parameter gradients
-    // onto the side stream (`lnp_side`, enqueued behind the cell's weight gradient, or behind enc0's when the weight gradients are
-    // batched over timesteps): one launch less per cell and timestep on the critical path.  What the side launch reads -- dy, a d_* buffer
-    // of this timestep's parity, and the slab's h / stat -- stays valid until the main stream has passed join(12) of the NEXT step, which
-    // waits for everything this step put on the side stream; the parity's next writer is the step after that.
-    static const int ln_in_gates = [] { const char* e = getenv("PIVP_LN_IN_GATES"); return e ? atoi(e) : 1; }();   // tuning: 0 = always two launches
-    const bool whole_ok = ln_in_gates && p->side && !p->side2;
     LnFuse lf[7];
-    memset(lf, 0, sizeof(lf));
-    struct { const float* dy; int lddy, n, C; bool pending; } lnp[7];
-    memset(lnp, 0, sizeof(lnp));
-    auto lnp_side = [&](int i, hipStream_t sw) -> int {       // parameter-gradient planes of hidden<i+1>'s norm (+ their reduction at t = 0)
-        const int j = i + 1;
-        lnp[i].pending = false;
-        RC(ln_bwd_params_only(lnp[i].dy, lnp[i].lddy, ws + S.h[i], ws + S.lnstat + (size_t)j * B * 2, B, lnp[i].n, lnp[i].C, ws + g.ln_ppart[j], sw));
-        if (t == 0) RC(ln_bwd_params_reduce(ws + g.ln_ppart[j], G(p, p->i_ln_g[j]), G(p, p->i_ln_b[j]), B, lnp[i].n, sw));
-        return PIVP_OK;
-    };
     auto lnb_cell = [&](int i, const float* dy, int lddy, int n, int C) -> int {
         const int j = i + 1;
         lf[i].dy = dy; lf[i].lddy = lddy; lf[i].gamma = P(p, p->i_ln_g[j]); lf[i].stat = ws + S.lnstat + (size_t)j * B * 2;
-        lf[i].h = ws + S.h[i];
-        lf[i].whole = whole_ok ? lstm_gates_bwd_whole_parts(B, n, C) : 0;
-        if (lf[i].whole > 0) {
-            lnp[i].dy = dy; lnp[i].lddy = lddy; lnp[i].n = n; lnp[i].C = C; lnp[i].pending = true;
-            return PIVP_OK;
-        }
-        lf[i].partials = lnpart; lf[i].S = ln_bwd_slices(n);
+        lf[i].partials = lnpart; lf[i].S = ln_bwd_slices(n); lf[i].h = ws + S.h[i];
         RC(ln_backward(dy, lddy, nullptr, 0, ws + S.h[i], lf[i].stat, lf[i].gamma, lnpart, nullptr,
                        G(p, p->i_ln_g[j]), G(p, p->i_ln_b[j]), B, n, C, 0, s, ws + g.ln_ppart[j]));
         p->ln_touched[j] = true;
@@ -653,7 +624,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                                  s, 1, p->lstm_bf16 ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->lstm_planes,
                                  wg_flush ? fork_of(i, f) : nullptr, &lf[i],    // dW = null: only the fork's `ready` (behind the gate math) is used
                                  t == 0 ? 1 : 0));                              // t = 0: nobody reads d h_{-1}
-        if (!wg_flush) return PIVP_OK;      // (a pending norm-parameter launch then goes behind enc0's weight gradient, at the end of the step)
+        if (!wg_flush) return PIVP_OK;
         // weight + bias gradient of the whole batch: timestep j of it reads slab (first - j) and ring slot j; on the side stream it
         // starts as soon as this step's dG exists, next to this step's own data gradient
         hipStream_t sw = p->side ? p->side_of(i) : s;
@@ -663,7 +634,6 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                      G(p, p->i_lstm_b[i]), &bias_done, p->bf16_all, cnt, -slab_bytes, -slab_bytes, (long long)dG1 * 4));
         if (!bias_done)
             for (int j = 0; j < cnt; ++j) RC(bias_grad(ring + (size_t)j * dG1, N, N, B * hh * wwid, G(p, p->i_lstm_b[i]), sw));
-        if (lnp[i].pending) RC(lnp_side(i, sw));      // in front of the ring event: at t = 0 the cell's gradient group is final behind it
         if (p->side && hipEventRecord(p->ev_ring_done[i][wg_ring], p->side_of(i)) != hipSuccess) return PIVP_ERR_LAUNCH;
         return PIVP_OK;
     };
@@ -690,23 +660,23 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                      G(p, p->i_masks_b), G(p, p->i_enc7_w), G(p, p->i_enc7_b), B, HW, p->NP, p->NE, s));
         RC(join(13));      // d v (the kernel generator's weight gradient reads it)
         if (c.model_type == PIVP_MODEL_CDNA)
-            RC(cdna_kernels_bwd(ws + S.n5, P(p, p->i_head_w), ws + S.vpre, ws + g.dkpart, composite_bwd_tiles(H, W), ws + g.dv, ws + d_n5, 0,
+            RC(cdna_kernels_bwd(ws + S.n5, P(p, p->i_head_w), ws + S.vpre, ws + g.dkpart, composite_bwd_tiles(H, W), ws + g.dv, ws + g.n5, 0,
                                 G(p, p->i_head_w), G(p, p->i_head_b), B, p->K5, c.num_masks, s, fork_of(13, fe)));
         else if (c.model_type == PIVP_MODEL_STP)
             RC(stp_params_bwd(ws + S.n5, P(p, p->i_head_w), ws + S.vpre, P(p, p->i_head2_w), ws + g.dkpart, composite_bwd_tiles(H, W),
-                              ws + g.dv, ws + d_n5, G(p, p->i_head_w), G(p, p->i_head_b), G(p, p->i_head2_w), G(p, p->i_head2_b),
+                              ws + g.dv, ws + g.n5, G(p, p->i_head_w), G(p, p->i_head_b), G(p, p->i_head2_w), G(p, p->i_head2_b),
                               B, p->K5, s));
-        else if (hipMemsetAsync(ws + d_n5, 0, (size_t)px8 * 128 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;   // DNA: no hidden5 head
+        else if (hipMemsetAsync(ws + g.n5, 0, (size_t)px8 * 128 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;   // DNA: no hidden5 head
         // group 6 (TM:601), reversed: norm_enc6 (+relu) <- enc6 deconv <- [hidden7 | enc0]
         RC(join(7));       // d e6raw
         RC(lnb(8, ws + g.e6, 64, ws + S.e6, 64, ws + S.e6raw, ws + g.e6raw, 64 * HW, 64, 1));
-        RC(run_conv_backward(1, ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), ws + g.e6raw, 64, 64, nullptr, 0, ws + g.wt_enc[6], ws + d_cat7, 64, 0,
+        RC(run_conv_backward(1, ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), ws + g.e6raw, 64, 64, nullptr, 0, ws + g.wt_enc[6], ws + g.cat7, 64, 0,
                              G(p, p->i_enc_w[6]), G(p, p->i_enc_b[6]), B, p->H2, p->W2, s, 1, fork_of(7, fe), ws + g.wg_part[0], &p->enc_desc[0]));
     p->enc_desc_valid[0] = true;
     } else {
         // no gradient reaches this step's frame: only the recurrent paths are live
-        if (hipMemsetAsync(ws + d_cat7, 0, (size_t)px2 * 64 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
-        if (hipMemsetAsync(ws + d_n5, 0, (size_t)px8 * 128 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
+        if (hipMemsetAsync(ws + g.cat7, 0, (size_t)px2 * 64 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
+        if (hipMemsetAsync(ws + g.n5, 0, (size_t)px8 * 128 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     }
     if (t == 0) RC(ln_finish(8));   // norm_enc6's backward does not run in a step no gradient reaches (the usual t = 0): finish it here
     // enc conv k's partial weight-gradient sums -> its gradient (once per sweep, behind its last weight-gradient launch)
@@ -735,24 +705,24 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         return PIVP_OK;
     };
     RC(done(0));
-    RC(lnb_cell(6, ws + d_cat7, 64, n2, 32));
+    RC(lnb_cell(6, ws + g.cat7, 64, n2, 32));
     RC(join(8));           // enc5's dY = the x part of lstm7's d_in of this parity (two timesteps ago)
     RC(lstmb(6, ws + S.e5, 96, p->H2, p->W2));
     RC(done(1));
     RC(join(11));          // enc1's dY lives in d cat6, which enc5's data gradient rewrites
     // group 5 (TM:600): d e5 = x-part of lstm7's d_in (ReLU fused in enc5) <- enc5 deconv <- [hidden6 | enc1]
-    RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ws + S.e5, 96, ws + g.wt_enc[5], ws + d_cat6, 96, 0,
+    RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ws + S.e5, 96, ws + g.wt_enc[5], ws + g.cat6, 96, 0,
                          G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1, fork_of(8, fe), ws + g.wg_part[1], &p->enc_desc[1]));
     p->enc_desc_valid[1] = true;
-    RC(lnb_cell(5, ws + d_cat6, 96, n4, 64));
+    RC(lnb_cell(5, ws + g.cat6, 96, n4, 64));
     RC(join(9));           // enc4's dY = the x part of lstm6's d_in of this parity
     RC(lstmb(5, ws + S.e4, 128, p->H4, p->W4));
     RC(done(2));
     // group 4 (TM:599): d e4 = x-part of lstm6's d_in <- enc4 deconv <- hidden5 (also read by the CDNA kernel generator)
-    RC(run_conv_backward(1, ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), ws + g.din[5][par], 128, 192, ws + S.e4, 128, ws + g.wt_enc[4], ws + d_n5, 128, 1,
+    RC(run_conv_backward(1, ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), ws + g.din[5][par], 128, 192, ws + S.e4, 128, ws + g.wt_enc[4], ws + g.n5, 128, 1,
                          G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s, 1, fork_of(9, fe), ws + g.wg_part[2], &p->enc_desc[2]));
     p->enc_desc_valid[2] = true;
-    RC(lnb_cell(4, ws + d_n5, 128, n8, 128));
+    RC(lnb_cell(4, ws + g.n5, 128, n8, 128));
     RC(lstmb(4, ws + S.e3, 64, p->H8, p->W8));
     RC(done(3));
     // group 3 (TM:598) + state predictor (TM:730): d e3 = x-part of lstm5's d_in (ld 192)
@@ -762,36 +732,29 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                       G(p, p->i_cs_b), t > 0 ? ws + g.dstate + (size_t)(t - 1) * B * 5 : ws + g.dstate + (size_t)(c.seq_len - 1) * B * 5,
                       B, p->H8 * p->W8, c.use_state, s, 1));      // d e2 comes out masked by enc2's ReLU
     // group 2 (TM:597): enc2 conv (ReLU) <- hidden4 <- lstm4 <- hidden3 <- lstm3 <- enc1
-    RC(run_conv_backward(0, ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), ws + g.e2, 64, 64, nullptr, 0, ws + g.wt_enc[2], ws + d_n4, 64, 0,
+    RC(run_conv_backward(0, ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), ws + g.e2, 64, 64, nullptr, 0, ws + g.wt_enc[2], ws + g.n4, 64, 0,
                          G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s, 1, fork_of(10, fe), ws + g.wg_part[3], &p->enc_desc[3]));
     p->enc_desc_valid[3] = true;
-    RC(lnb_cell(3, ws + d_n4, 64, n4, 64));
+    RC(lnb_cell(3, ws + g.n4, 64, n4, 64));
     RC(lstmb(3, ws + S.n3, 64, p->H4, p->W4));
     RC(lnb_cell(2, ws + g.din[3][par], 128, n4, 64));
     RC(lstmb(2, ws + S.cat6 + 64, 96, p->H4, p->W4));
     RC(done(4));
     // group 1 (TM:596): enc1 conv (ReLU) <- hidden2 <- lstm2 <- hidden1 <- lstm1 <- enc0
-    RC(run_conv_backward(0, ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), ws + d_cat6 + 64, 32, 96, ws + S.cat6 + 64, 96, ws + g.wt_enc[1], ws + d_n2, 32, 0,
+    RC(run_conv_backward(0, ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), ws + g.cat6 + 64, 32, 96, ws + S.cat6 + 64, 96, ws + g.wt_enc[1], ws + g.n2, 32, 0,
                          G(p, p->i_enc_w[1]), G(p, p->i_enc_b[1]), B, p->H2, p->W2, s, 1, fork_of(11, fe), ws + g.wg_part[4], &p->enc_desc[4],
                          ws + g.din[2][par], 96));      // d enc1 = enc5's concat part (in d cat6) + lstm3's x gradient, summed in the ReLU-mask pass
     p->enc_desc_valid[4] = true;
-    RC(lnb_cell(1, ws + d_n2, 32, n2, 32));
+    RC(lnb_cell(1, ws + g.n2, 32, n2, 32));
     RC(lstmb(1, ws + S.n1, 32, p->H2, p->W2));
     RC(lnb_cell(0, ws + g.din[1][par], 64, n2, 32));
     RC(lstmb(0, ws + S.cat7 + 32, 64, p->H2, p->W2));
-    RC(add_strided(ws + d_cat7 + 32, 64, ws + g.din[0][par], 64, 32, px2, s));          // d enc0: from enc6's concat + from lstm1
+    RC(add_strided(ws + g.cat7 + 32, 64, ws + g.din[0][par], 64, 32, px2, s));          // d enc0: from enc6's concat + from lstm1
     // group 0 (TM:595): norm_enc0 (+relu) <- enc0 conv <- frame
     RC(join(12));          // d e0raw
-    RC(lnb(0, ws + d_cat7 + 32, 64, ws + S.cat7 + 32, 64, ws + S.e0raw, ws + g.e0raw, n2, 32, 1));
+    RC(lnb(0, ws + g.cat7 + 32, 64, ws + S.cat7 + 32, 64, ws + S.e0raw, ws + g.e0raw, n2, 32, 1));
     RC(enc0_bwd(prev, P(p, p->i_enc_w[0]), ws + g.e0raw, G(p, p->i_enc_w[0]), G(p, p->i_enc_b[0]), prev_has_grad ? go_prev : nullptr, 1,
                 B, H, W, s, fork_of(12, fe)));
-    {   // norm-parameter launches whose cell did not flush a weight-gradient batch in this step: behind enc0's weight gradient (the side
-        // stream has waited there for this step's main-stream work), and slot 12's event moves behind them
-        bool any = false;
-        for (int i = 0; i < 7; ++i)
-            if (lnp[i].pending) { RC(lnp_side(i, p->side_of(12))); any = true; }
-        if (any && hipEventRecord(p->ev_done[12], p->side_of(12)) != hipSuccess) return PIVP_ERR_LAUNCH;
-    }
     RC(done(5));
     return PIVP_OK;
 }

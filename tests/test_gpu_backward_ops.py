@@ -264,17 +264,14 @@ def test_convlstm_backward_last_timestep_computes_dx_only(env, B, cx, C, H):
     assert _rel(db.cpu().numpy(), tb.grad.numpy()) < 2e-5
 
 
-@pytest.mark.parametrize('fused', [0, 1])
 @pytest.mark.parametrize('B,C,H,lddy,recurrent', [(32, 32, 32, 64, True), (8, 64, 16, 96, True), (32, 128, 8, 128, True), (5, 32, 32, 32, False),
                                                   (2, 64, 16, 64, True)])
-def test_layernorm_plus_gate_backward_pair(env, fused, B, C, H, lddy, recurrent):
-    """hidden<k>'s LayerNorm backward + lstm<k>'s gate backward as the sweep runs the pair (TM:203-208, TM:269-272): the two-launch form
-    (sums, then gates reading the partials) and the form with the sums inside the gate launch, both against float64 autograd."""
+def test_layernorm_plus_gate_backward_pair(env, B, C, H, lddy, recurrent):
+    """hidden<k>'s LayerNorm backward + lstm<k>'s gate backward as the sweep runs the pair (TM:203-208, TM:269-272: sums and parameter
+    planes, then the gate kernel forming the norm's dx from the partials) against float64 autograd."""
     pivp, _lib, lib = env
     rs = np.random.RandomState(100 * C + B)
     npix, n = H * H, H * H * C
-    if fused and not lib.pivp_gates_backward_ln_fits(B, n, C):
-        pytest.skip('shape not taken by the in-launch sums')
     # forward pieces in NHWC: pre-activation gates, c_{t-1}; h_t = tanh(c_t) s(o) goes through the norm, whose output meets dy
     pre = rs.randn(B, npix, 4, C); c_old = rs.randn(B, npix, C)
     gamma = 1.0 + 0.3 * rs.randn(npix, C); beta = 0.1 * rs.randn(npix, C)
@@ -305,7 +302,7 @@ def test_layernorm_plus_gate_backward_pair(env, fused, B, C, H, lddy, recurrent)
     _lib.check(lib.pivp_gates_backward_ln(gates.data_ptr(), cod.data_ptr(), cnd.data_ptr(),
                                           dyw.data_ptr() + off * 4, lddy, gmd.data_ptr(), stat.data_ptr(),
                                           hd.data_ptr(), hb.data_ptr() if recurrent else None, C,
-                                          dc.data_ptr(), 1, dG.data_ptr(), dgm.data_ptr(), dbt.data_ptr(), scratch.data_ptr(), B, npix, C, fused, _st()),
+                                          dc.data_ptr(), 1, dG.data_ptr(), dgm.data_ptr(), dbt.data_ptr(), scratch.data_ptr(), B, npix, C, _st()),
                'pivp_gates_backward_ln')
     torch.cuda.synchronize()
     ref_dG = tp.grad.numpy().reshape(B * npix, 4 * C)
