@@ -116,11 +116,20 @@ def test_adam_update_matches_chainer_rule(pivp):
     m.load_state_dict_reference(P)
     opt = pivp.Adam(alpha=0.001); opt.setup(m)
     losses = []
+    # second reference: Chainer's rule fed with the HIP path's OWN gradients -- the optimizer alone, exact up to float32 rounding
+    Ph = {k: v.copy() for k, v in P.items()}
+    Mh = {k: np.zeros_like(v) for k, v in P.items()}; Vh = {k: np.zeros_like(v) for k, v in P.items()}
     for itr in (0, 1):
         losses.append(float(opt.update(m, [imgs, acts, stas], itr)))
+        chainer_adam_step(Ph, {k: v.astype(np.float64) for k, v in m.grads_reference().items()}, Mh, Vh, itr + 1)
         m.reset_state()
     assert abs(losses[0] - losses_ref[0]) < 1e-6 and abs(losses[1] - losses_ref[1]) < 2e-5
     got = m.state_dict_reference()
+    for k in P:
+        # |p| <= ~3 and two steps of alpha = 1e-3: float32 parameters carry ~2e-7 of rounding, the step itself ~1e-9; where a gradient
+        # is so small that sqrt(v) ~ eps the float32 m / (sqrt(v) + eps) is still within a few 1e-7 relative of the float64 one
+        err = np.abs(got[k].astype(np.float64) - Ph[k]).max()
+        assert err < 1e-6, '%s: update differs from the rule applied to the same gradients by %.2e' % (k, err)
     for k in P:
         # Adam's first steps move every weight by ~alpha; compare the UPDATE, which is sign-dominated early on
         du_ref = Pr[k] - P[k]; du = got[k].astype(np.float64) - P[k]
