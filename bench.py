@@ -91,7 +91,9 @@ def build_parser():
     return ap
 
 
-RENDEZVOUS_TIMEOUT_S = 120     # init_process_group / first collective: a hung RCCL bootstrap must end the run, not burn the box's lease
+# init_process_group / every collective: a hung RCCL bootstrap must end the run, not burn the box's lease.  240 s, not less: on a fresh box the
+# first `import torch` of N concurrent ranks takes 1-2 minutes, and the ranks reach the rendezvous that far apart at worst.
+RENDEZVOUS_TIMEOUT_S = int(os.environ.get('PIVP_RENDEZVOUS_TIMEOUT', '240'))
 
 
 def _launch_timeout(args):
