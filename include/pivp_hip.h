@@ -38,7 +38,7 @@ extern "C" {
 #define PIVP_PRECISION_BF16 1
 #define PIVP_PRECISION_BF16X3 2
 
-int pivp_abi_version(void);   /* 8 (8: + pivp_gates_backward_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+int pivp_abi_version(void);   /* 8 (8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
                                  5: + bf16 ConvLSTM, pivp_plan_set_precision, 6: + pivp_plan_set_group_join / pivp_plan_group_wait) */
 
 /* ------------------------------------------------------------------------------------------
@@ -274,6 +274,15 @@ int pivp_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float
 /* L.Deconvolution2D(cout,(3,3),stride=2,pad=1,outsize=2*in) (TM:505-507) + optional ReLU; w [9][cin/32][cout][32]. */
 int pivp_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                      int ldo, int relu, int B, int Hin, int Win, void* stream);
+/* L.Deconvolution2D(...) of concat(LayerNormalizationConv2D(h_raw), x1) (TM:565-566 / 574-575: [hidden6 | enc1] -> enc5, [hidden7 | enc0] ->
+ * enc6) with the norm applied while the conv stages its input: one launch, the normalised tensor is never written; bit-identical to
+ * pivp_layernorm + pivp_deconv3x3s2.  h_raw [B][Hin*Win][c_ln]; x1 (may be NULL) c1 channels at stride ld1; gamma / beta [Hin*Win][c_ln];
+ * partials: scratch of pivp_layernorm_scratch_floats(B, Hin*Win*c_ln) floats; precision 0 fp32, 1 bf16 operands, 2 split.  Only for
+ * geometries pivp_deconv3x3s2_ln_fits accepts (whole 32-channel chunks, Hin % 8 == 0, Win % 16 == 0, enough tiles). */
+int pivp_deconv3x3s2_ln_fits(int c_ln, int c1, int cout, int B, int Hin, int Win);
+int pivp_deconv3x3s2_ln(const float* h_raw, int c_ln, const float* x1, int c1, int ld1, const float* w, const float* bias,
+                        const float* gamma, const float* beta, float eps, float* partials, float* out, int cout, int ldo, int relu,
+                        int B, int Hin, int Win, int precision, void* stream);
 
 /* L.Convolution2D(32,(5,5),stride=2,pad=2) on a planar 3-channel frame (TM:500); w [75][32]. */
 int pivp_conv_enc0(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, void* stream);

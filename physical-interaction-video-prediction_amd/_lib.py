@@ -79,6 +79,8 @@ SIGNATURES = {
     'pivp_grad_unpack_bf16': (_i, [_vp, _vp, _ll, _vp]),
     'pivp_conv3x3s2': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'pivp_deconv3x3s2': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'pivp_deconv3x3s2_ln_fits': (_i, [_i, _i, _i, _i, _i, _i]),
+    'pivp_deconv3x3s2_ln': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'pivp_conv_enc0': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pivp_layernorm_scratch_floats': (_ll, [_i, _i]),
     'pivp_layernorm': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

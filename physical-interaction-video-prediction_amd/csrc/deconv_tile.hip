@@ -36,7 +36,11 @@ __device__ __forceinline__ unsigned dpack2(float a, float b) {
 // PREC 1 (bf16): operands rounded to bf16 on their way into LDS (activations AND weights: both stay fp32 in HBM), v_mfma_f32_32x32x16_bf16, fp32
 // accumulation and epilogue.  PREC 2 (split): each operand as hi = bf16(v) and lo = bf16(v - hi) in two image planes, a product as
 // lo*hi + hi*lo + hi*hi on three MFMAs (the split mode of convlstm_bf16.hip).  PREC 0: fp32 MFMA.
-template <int PREC>
+// The input may be a concat of two tensors (x0: c0 channels | x1: c1 channels, whole 32-channel chunks each: [hidden6 | enc1], [hidden7 | enc0]),
+// and with IN_LN the x0 part is a RAW ConvLSTM output whose LayerNorm (TM:203-208: per-element gamma / beta [Hin*Win][c0], statistics merged
+// from the producer's partials d.in_part) is applied while the patch is staged -- the expression of ln_apply_kernel, bit-identical to the
+// two-launch form; pixels outside the image load 0 for v, gamma and beta alike and stay 0.  Inference rollouts use it for enc5 / enc6.
+template <int PREC, bool IN_LN>
 __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDesc d) {
     PIVP_SET_MAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float lds[];   // A patch | the 9 weight tiles
@@ -57,16 +61,21 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
     const int nblk = lid / n_tiles, tile = lid - nblk * n_tiles;
     const int b = tile / tpi, trem = tile - b * tpi;
     const int y0 = (trem / tpr) * 8, x0 = (trem - (trem / tpr) * tpr) * 16;
-    const int ncc = d.c0 >> 5;
+    const int ncc0 = d.c0 >> 5, ncc = (d.c0 + d.c1) >> 5;
 
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x0), 0, d.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.c1 ? d.x1 : d.x0), 0, d.c1 ? d.bytes1 : d.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN_LN ? d.in_g : d.x0), 0, IN_LN ? H * W * d.c0 * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN_LN ? d.in_b : d.x0), 0, IN_LN ? H * W * d.c0 * 4 : 0, 0x00020000);
+    float ln_mean = 0.f, ln_rstd = 1.f;
+    if constexpr (IN_LN) ln_merge_partials(d.in_part, b, d.in_np, d.in_eps, ln_mean, ln_rstd);      // every wave for itself: a few partials per sample
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, d.bytesw, 0x00020000);
     constexpr unsigned OOB = 0xC0000000u;
 
     // ---- staging roles ----------------------------------------------------------------------------------------------------
     // patch: 153 pixels x 8 float4: thread -> (pixel tid / 8 + 32 j, c4 = tid % 8), j < 5
     const int c4 = tid & 7;
-    unsigned a_go[5];
+    unsigned a_go[5], a_g1[5], g_go[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int p = (tid >> 3) + 32 * j;
@@ -74,15 +83,32 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
         const int iy = y0 + py, ix = x0 + px;
         const bool ok = p < PR * PC && iy < H && ix < W;
         a_go[j] = ok ? (unsigned)((((b * H + iy) * W + ix) * d.ld0 + c4 * 4) * 4) : OOB;
+        a_g1[j] = ok ? (unsigned)((((b * H + iy) * W + ix) * d.ld1 + c4 * 4) * 4) : OOB;
+        g_go[j] = ok ? (unsigned)(((iy * W + ix) * d.c0 + c4 * 4) * 4) : OOB;
     }
     // Per 32-channel chunk the patch AND the weight tiles of all 9 taps ([9][32 columns][32 k], 41 KB) are staged together, so the 9 taps
     // (144 MFMAs per wave) run without a barrier; the next chunk's 14 float4 per thread are in flight in registers meanwhile.
     const int b_go = (((nblk * 32 + (tid >> 3)) * 32) + c4 * 4) * 4;
     const int b_lw = (tid >> 3) * DP + c4 * 4;
     f32x4 rp[5], rw[9];
+    f32x4 rgm[5], rbt[5];              // IN_LN: gamma / beta of the staged float4s
+    bool ln_chunk = false;             // the chunk in rp is part of the normalised tensor (block-uniform)
     auto load_chunk = [&](int cc) {
+        const bool first = cc < ncc0;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) rp[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, a_go[j], cc * 128, 0));
+        for (int j = 0; j < 5; ++j)
+            rp[j] = __builtin_bit_cast(f32x4, first ? __builtin_amdgcn_raw_buffer_load_b128(rsx, a_go[j], cc * 128, 0)
+                                                    : __builtin_amdgcn_raw_buffer_load_b128(rsx1, a_g1[j], (cc - ncc0) * 128, 0));
+        if constexpr (IN_LN) {
+            ln_chunk = first;
+            if (first) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    rgm[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, g_go[j], cc * 128, 0));
+                    rbt[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, g_go[j], cc * 128, 0));
+                }
+            }
+        }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int sbase = __builtin_amdgcn_readfirstlane((t * (d.wcin >> 5) + cc) * N * 128);
@@ -90,6 +116,14 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
         }
     };
     auto store_chunk = [&]() {
+        if constexpr (IN_LN) {
+            if (ln_chunk) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rp[j][e] = (rp[j][e] - ln_mean) * ln_rstd * rgm[j][e] + rbt[j][e];
+            }
+        }
         if constexpr (BF16) {
             auto lo2 = [](unsigned hi2, float a, float b) {     // bf16(v - hi): hi as a float is its 16 bits shifted up
                 return dpack2(a - __builtin_bit_cast(float, hi2 << 16), b - __builtin_bit_cast(float, hi2 & 0xffff0000u));
@@ -221,17 +255,20 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
 }
 
 bool deconv_tile_ok(const IgemmDesc& d) {
-    return d.deconv && d.nphase == 4 && d.c1 == 0 && d.c0 % 32 == 0 && d.N % 32 == 0 && d.Hin % 8 == 0 && d.Win % 16 == 0 &&
-           d.Hout == 2 * d.Hin && d.Wout == 2 * d.Win && d.ld0 % 4 == 0 && d.out != nullptr;
+    return d.deconv && d.nphase == 4 && d.c0 > 0 && d.c0 % 32 == 0 && d.c1 % 32 == 0 && (d.c1 == 0 || (d.x1 && d.ld1 % 4 == 0)) && d.N % 32 == 0 &&
+           d.Hin % 8 == 0 && d.Win % 16 == 0 && d.Hout == 2 * d.Hin && d.Wout == 2 * d.Win && d.ld0 % 4 == 0 && d.out != nullptr &&
+           (!d.in_g || (d.in_b && d.in_part && d.in_np > 0 && d.ld0 == d.c0));
 }
 
 // d as igemm_conv takes it for the transposed conv (validated by the caller); ln_nparts as there.
 int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts, int prec) {
     PIVP_CHECK_ARG(deconv_tile_ok(d));
     constexpr int lds_f32 = (A_FL + 9 * B_FL) * 4;        // 64,512 (the bf16 images fit inside)
-    static PerDeviceOnce once0, once2;
-    if (pivp_ensure_dyn_lds(once0, reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<0>), lds_f32) != PIVP_OK ||
-        pivp_ensure_dyn_lds(once2, reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<2>), 2 * (A_HB + 9 * B_HB)) != PIVP_OK)
+    static PerDeviceOnce once0, once2, once0n, once2n;
+    if (pivp_ensure_dyn_lds(once0, reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<0, false>), lds_f32) != PIVP_OK ||
+        pivp_ensure_dyn_lds(once2, reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<2, false>), 2 * (A_HB + 9 * B_HB)) != PIVP_OK ||
+        pivp_ensure_dyn_lds(once0n, reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<0, true>), lds_f32) != PIVP_OK ||
+        pivp_ensure_dyn_lds(once2n, reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<2, true>), 2 * (A_HB + 9 * B_HB)) != PIVP_OK)
         return PIVP_ERR_LAUNCH;
     IgemmDesc dd = d;
     const int tpi = (d.Hin / 8) * (d.Win / 16), nb = d.N / 32;
@@ -239,9 +276,14 @@ int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts, int prec
     dd.ln_nparts = (d.ln_part && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
-    if (prec == 2) hipLaunchKernelGGL(deconv3x3s2_tile_kernel<2>, dim3(d.B * tpi * nb), dim3(256), 2 * (A_HB + 9 * B_HB), stream, dd);
-    else if (prec == 1) hipLaunchKernelGGL(deconv3x3s2_tile_kernel<1>, dim3(d.B * tpi * nb), dim3(256), A_HB + 9 * B_HB, stream, dd);
-    else hipLaunchKernelGGL(deconv3x3s2_tile_kernel<0>, dim3(d.B * tpi * nb), dim3(256), lds_f32, stream, dd);
+    const dim3 grid(d.B * tpi * nb);
+    if (d.in_g) {
+        if (prec == 2) hipLaunchKernelGGL((deconv3x3s2_tile_kernel<2, true>), grid, dim3(256), 2 * (A_HB + 9 * B_HB), stream, dd);
+        else if (prec == 1) hipLaunchKernelGGL((deconv3x3s2_tile_kernel<1, true>), grid, dim3(256), A_HB + 9 * B_HB, stream, dd);
+        else hipLaunchKernelGGL((deconv3x3s2_tile_kernel<0, true>), grid, dim3(256), lds_f32, stream, dd);
+    } else if (prec == 2) hipLaunchKernelGGL((deconv3x3s2_tile_kernel<2, false>), grid, dim3(256), 2 * (A_HB + 9 * B_HB), stream, dd);
+    else if (prec == 1) hipLaunchKernelGGL((deconv3x3s2_tile_kernel<1, false>), grid, dim3(256), A_HB + 9 * B_HB, stream, dd);
+    else hipLaunchKernelGGL((deconv3x3s2_tile_kernel<0, false>), grid, dim3(256), lds_f32, stream, dd);
     return PIVP_LAUNCH_STATUS();
 }
 

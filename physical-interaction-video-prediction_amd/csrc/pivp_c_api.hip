@@ -102,6 +102,44 @@ int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const floa
     return igemm_conv(d, s, ln_nparts);
 }
 
+// deconv3x3s2 of concat(LayerNorm(h_raw), x1): the norm of the first c_ln channels (per-element gamma / beta, statistics from the
+// producer's partials) is applied while the all-parities tile kernel stages its patch -- no launch of its own, and the normalised tensor
+// is never written (inference rollouts: [hidden6 | enc1] -> enc5, [hidden7 | enc0] -> enc6).  h_raw [B][Hin*Win][c_ln] contiguous.
+static int deconv3x3s2_ln_desc(IgemmDesc& d, const float* h_raw, int c_ln, const float* x1, int c1, int ld1, const float* w, const float* bias,
+                               float* out, int cout, int ldo, int relu, int B, int Hin, int Win) {
+    memset(&d, 0, sizeof(d));
+    d.x0 = h_raw; d.c0 = c_ln; d.ld0 = c_ln; d.x1 = x1; d.c1 = x1 ? c1 : 0; d.ld1 = ld1; d.wcin = c_ln + d.c1; d.w = w; d.bias = bias;
+    d.B = B; d.Hin = Hin; d.Win = Win; d.Hg = Hin; d.Wg = Win; d.in_step = 1;
+    d.N = cout; d.M = B * Hin * Win;
+    d.nphase = 4; d.deconv = 1; d.ksize = 3; d.pad = 1;
+    const long long b0 = view_bytes(B, Hin, Win, c_ln), b1 = d.c1 ? view_bytes(B, Hin, Win, ld1) : 0, bw = 9LL * d.wcin * cout * 4;
+    if (!fits31(b0) || (d.c1 && !fits31(b1)) || !fits31(bw)) return PIVP_ERR_BADARG;
+    d.bytes0 = (int)b0; d.bytes1 = (int)b1; d.bytesw = (int)bw;
+    d.out_step = 2; d.Hout = 2 * Hin; d.Wout = 2 * Win; d.out = out; d.ldo = ldo; d.relu = relu;
+    return PIVP_OK;
+}
+bool deconv3x3s2_ln_ok(int c_ln, int c1, int cout, int B, int Hin, int Win) {
+    if (c_ln <= 0 || c_ln % 32 || c1 < 0 || c1 % 32 || cout % 32 || Hin % 8 || Win % 16) return false;
+    static const bool off = getenv("PIVP_DECONV_TILE") && atoi(getenv("PIVP_DECONV_TILE")) == 0;
+    return !off && (long)B * (Hin / 8) * (Win / 16) * (cout / 32) >= 16;
+}
+int run_deconv3x3s2_ln(const float* h_raw, int c_ln, const float* x1, int c1, int ld1, const float* w, const float* bias, float* out, int cout,
+                       int ldo, int relu, int B, int Hin, int Win, hipStream_t s, const float* gamma, const float* beta, const float* partials,
+                       int nparts, float eps, float* ln_part, int ln_cap, int* ln_nparts, int bf16) {
+    if (!h_raw || !w || !out || !gamma || !beta || !partials || nparts <= 0 || !deconv3x3s2_ln_ok(c_ln, x1 ? c1 : 0, cout, B, Hin, Win)) return PIVP_ERR_BADARG;
+    if (ln_part && ln_part == partials) return PIVP_ERR_BADARG;      // blocks finish (and write their output partial) while others still read the input's
+    IgemmDesc d;
+    int rc = deconv3x3s2_ln_desc(d, h_raw, c_ln, x1, c1, ld1, w, bias, out, cout, ldo, relu, B, Hin, Win);
+    if (rc != PIVP_OK) return rc;
+    d.bf16 = bf16;
+    d.in_g = gamma; d.in_b = beta; d.in_part = partials; d.in_np = nparts; d.in_eps = eps;
+    d.ln_part = ln_part; d.ln_cap = ln_cap;
+    rc = igemm_validate(d, false);
+    if (rc != PIVP_OK) return rc;
+    if (!deconv_tile_ok(d)) return PIVP_ERR_BADARG;
+    return deconv_tile(d, s, ln_nparts, bf16);
+}
+
 // stride-1 K x K "same" convolution through the generic kernel (used as the ConvLSTM data gradient)
 static int conv_s1_desc(IgemmDesc& d, const float* x, int cin, int ldx, const float* w, float* out, int cout, int ldo, int ksize, int B, int H, int W,
                         int accum, int wN) {
@@ -520,6 +558,24 @@ extern "C" int pivp_deconv3x3s2(const float* x, int cin, int ldx, const float* w
                                 int ldo, int relu, int B, int Hin, int Win, void* stream) {
     if (!x || !w || !out) return PIVP_ERR_BADARG;
     return run_deconv3x3s2(x, cin, ldx, w, bias, out, cout, ldo, relu, B, Hin, Win, (hipStream_t)stream);
+}
+// deconv3x3s2 of concat(LayerNorm(h_raw), x1) in ONE conv launch (the norm applied while the tile kernel stages its patch): what inference
+// rollouts run for enc5 / enc6.  The statistics are taken here by ln_stats into `partials` (pivp_layernorm_scratch_floats(B, Hin*Win*c_ln));
+// in the rollout they come from the ConvLSTM's epilogue.  precision: 0 fp32, 1 bf16 operands, 2 split.  PIVP_ERR_BADARG for geometries
+// the tile kernel does not take (pivp_deconv3x3s2_ln_fits).
+extern "C" int pivp_deconv3x3s2_ln_fits(int c_ln, int c1, int cout, int B, int Hin, int Win) {
+    return deconv3x3s2_ln_ok(c_ln, c1, cout, B, Hin, Win) ? 1 : 0;
+}
+extern "C" int pivp_deconv3x3s2_ln(const float* h_raw, int c_ln, const float* x1, int c1, int ld1, const float* w, const float* bias,
+                                   const float* gamma, const float* beta, float eps, float* partials, float* out, int cout, int ldo, int relu,
+                                   int B, int Hin, int Win, int precision, void* stream) {
+    if (!h_raw || !w || !out || !gamma || !beta || !partials || precision < 0 || precision > 2) return PIVP_ERR_BADARG;
+    if (!deconv3x3s2_ln_ok(c_ln, x1 ? c1 : 0, cout, B, Hin, Win)) return PIVP_ERR_BADARG;
+    const int n = Hin * Win * c_ln;
+    int rc = ln_stats(h_raw, partials, B, n, (hipStream_t)stream);
+    if (rc != PIVP_OK) return rc;
+    return run_deconv3x3s2_ln(h_raw, c_ln, x1, c1, ld1, w, bias, out, cout, ldo, relu, B, Hin, Win, (hipStream_t)stream, gamma, beta, partials,
+                              ln_stats_slices(n), eps, nullptr, 0, nullptr, precision);
 }
 // bf16-operand form (precision mode bf16): x and w rounded to bf16 on the way into LDS, fp32 accumulation / bias / ReLU.  Only maps that the
 // all-parities tile kernel takes (Hin % 8 == 0, Win % 16 == 0, at least 16 blocks) run in bf16; others fall to the fp32 kernels.

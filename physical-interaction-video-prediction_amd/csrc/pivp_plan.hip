@@ -83,7 +83,7 @@ struct pivp_plan {
     std::vector<Slab> slabs;
     Grads g;
     bool has_grads;
-    size_t o_zero, o_lnpart, o_linpart, o_masks, o_losspart;
+    size_t o_zero, o_lnpart, o_lnpart2, o_linpart, o_masks, o_losspart;   // o_lnpart2: enc6 reads hidden7's partials while writing its own
     size_t o_wbf16[7];                // bf16 packs of the ConvLSTM weights (pivp_plan_set_precision), rebuilt at the start of a rollout
     int lstm_bf16 = 0;                // 1: bf16 operands in the ConvLSTM forward (precision modes BF16 and BF16X3)
     int precision = 0;                // PIVP_PRECISION_*
@@ -197,6 +197,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
     const bool train = cfg->keep_activations != 0;
     p->o_zero = carve((size_t)B * HW2 * 32);
     p->o_lnpart = carve((size_t)B * ln_partial_cap((int)HW) * 4);
+    p->o_lnpart2 = carve((size_t)B * ln_partial_cap((int)HW) * 4);
     p->o_linpart = carve((size_t)cdna_kernel_partials_slices(p->K5) * B * 256);
     p->o_masks = carve((size_t)B * p->NP * HW);
     p->loss_nparts = loss_partials_count((int)(B * 3 * HW));
@@ -411,7 +412,7 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     RC(lstm(1, ws + S.n1, 32, p->H2, p->W2));
     // Inference rollouts: hidden2 / hidden4 feed only enc1 / enc2, so their norms are applied while those convs stage their input
     // (run_conv3x3s2_ln) instead of by a launch of their own; training keeps the materialised tensors (the backward sweep reads them).
-    static const int fold_ln = [] { const char* e = getenv("PIVP_LN_FOLD"); return e ? atoi(e) : 1; }();   // tuning: 0 = always a separate ln_apply
+    static const int fold_ln = [] { const char* e = getenv("PIVP_LN_FOLD"); return e ? atoi(e) : 2; }();   // tuning: 0 = always a separate ln_apply, 1 = only enc1 / enc2 fold theirs
     if (!train && fold_ln && np > 0 && conv3x3s2_ln_ok(32, 32, B, p->H2, p->W2)) {
         RC(run_conv3x3s2_ln(ws + S.h[1], 32, P(p, p->i_enc_w[1]), P(p, p->i_enc_b[1]), ws + S.cat6 + 64, 32, 96, 1, B, p->H2, p->W2, s,
                             P(p, p->i_ln_g[2]), P(p, p->i_ln_b[2]), lnp, np, eps));
@@ -442,14 +443,31 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
                        nullptr, 0, nullptr, p->bf16_all ? 1 : p->lstm_planes == 2 ? 2 : 0));
     // group 5 (TM:600): lstm6 -> hidden6 -> concat(., enc1) -> enc5 -> relu
     RC(lstm(5, ws + S.e4, 128, p->H4, p->W4));
-    RC(ln(6, ws + S.h[5], ws + S.cat6, n4, 64, 96, 0, np));
-    RC(run_deconv3x3s2(ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), P(p, p->i_enc_b[5]), ws + S.e5, 96, 96, 1, B, p->H4, p->W4, s, 0,
-                       nullptr, 0, nullptr, p->bf16_all ? 1 : p->lstm_planes == 2 ? 2 : 0));
+    const int dprec = p->bf16_all ? 1 : p->lstm_planes == 2 ? 2 : 0;
+    // Inference: the norms of hidden6 / hidden7 feed only enc5 / enc6, whose tile kernel applies them while it stages its patch
+    // ([hidden6 | enc1], [hidden7 | enc0] as two sources); training keeps the materialised concat buffers (the backward sweep reads them).
+    if (!train && fold_ln >= 2 && np > 0 && deconv3x3s2_ln_ok(64, 32, 96, B, p->H4, p->W4)) {
+        RC(run_deconv3x3s2_ln(ws + S.h[5], 64, ws + S.cat6 + 64, 32, 96, P(p, p->i_enc_w[5]), P(p, p->i_enc_b[5]), ws + S.e5, 96, 96, 1, B, p->H4, p->W4,
+                              s, P(p, p->i_ln_g[6]), P(p, p->i_ln_b[6]), lnp, np, eps, nullptr, 0, nullptr, dprec));
+    } else {
+        RC(ln(6, ws + S.h[5], ws + S.cat6, n4, 64, 96, 0, np));
+        RC(run_deconv3x3s2(ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), P(p, p->i_enc_b[5]), ws + S.e5, 96, 96, 1, B, p->H4, p->W4, s, 0,
+                           nullptr, 0, nullptr, dprec));
+    }
     // group 6 (TM:601): lstm7 -> hidden7 -> concat(., enc0) -> enc6 -> norm_enc6 -> relu
     RC(lstm(6, ws + S.e5, 96, p->H2, p->W2));
-    RC(ln(7, ws + S.h[6], ws + S.cat7, n2, 32, 64, 0, np));
-    RC(run_deconv3x3s2(ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), P(p, p->i_enc_b[6]), ws + S.e6raw, 64, 64, 0, B, p->H2, p->W2, s, 0,
-                       lnp, ln_cap, &np, p->bf16_all ? 1 : p->lstm_planes == 2 ? 2 : 0));
+    if (!train && fold_ln >= 2 && np > 0 && deconv3x3s2_ln_ok(32, 32, 64, B, p->H2, p->W2)) {
+        // enc6's blocks write the partials of norm_enc6 while others still read hidden7's: the second partial buffer
+        float* lnp2 = ws + p->o_lnpart2;
+        const int np_in = np;
+        RC(run_deconv3x3s2_ln(ws + S.h[6], 32, ws + S.cat7 + 32, 32, 64, P(p, p->i_enc_w[6]), P(p, p->i_enc_b[6]), ws + S.e6raw, 64, 64, 0, B, p->H2, p->W2,
+                              s, P(p, p->i_ln_g[7]), P(p, p->i_ln_b[7]), lnp, np_in, eps, lnp2, ln_cap, &np, dprec));
+        lnp = lnp2;
+    } else {
+        RC(ln(7, ws + S.h[6], ws + S.cat7, n2, 32, 64, 0, np));
+        RC(run_deconv3x3s2(ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), P(p, p->i_enc_b[6]), ws + S.e6raw, 64, 64, 0, B, p->H2, p->W2, s, 0,
+                           lnp, ln_cap, &np, dprec));
+    }
     // heads (TM:711-728).  norm_enc6 + relu is applied while the heads kernel stages its input: the normalised enc6 is only
     // written when the activations are kept for BPTT (pivp_get_tap recomputes it on request otherwise).
     if (np > 0 && (H * W) % 64 == 0) {
@@ -930,14 +948,15 @@ extern "C" long long pivp_get_tap(pivp_plan_t* plan, const char* name, int step,
         if (rc != PIVP_OK) return rc;
     }
     if (!c.keep_activations) {
-        // inference applies the norms of hidden2 / hidden4 inside their consumers (run_step): rebuild the tensor on request from
+        // inference applies the norms of hidden2 / hidden4 / hidden6 / hidden7 inside their consumers (run_step): rebuild the tensor on request from
         // the raw ConvLSTM output (statistics recomputed by ln_stats: equal to the fused ones up to fp32 summation order)
-        struct F { const char* n; int layer, norm; size_t dst; int C, hw; };
-        const F folded[] = {{"hidden2", 1, 2, S.n2, 32, HW2}, {"hidden4", 3, 4, S.n4, 64, HW4}};
+        struct F { const char* n; int layer, norm; size_t dst; int C, hw, ld; };
+        const F folded[] = {{"hidden2", 1, 2, S.n2, 32, HW2, 32}, {"hidden4", 3, 4, S.n4, 64, HW4, 64}, {"hidden6", 5, 6, S.cat6, 64, HW4, 96},
+                            {"hidden7", 6, 7, S.cat7, 32, HW2, 64}};
         for (const F& f : folded)
             if (strcmp(f.n, name) == 0) {
                 int rc = run_layernorm(ws + S.h[f.layer], P(plan, plan->i_ln_g[f.norm]), P(plan, plan->i_ln_b[f.norm]), ws + f.dst,
-                                       ws + plan->o_lnpart, B, f.C * f.hw, f.C, f.C, c.ln_eps, 0, s, nullptr, 0);
+                                       ws + plan->o_lnpart, B, f.C * f.hw, f.C, f.ld, c.ln_eps, 0, s, nullptr, 0);
                 if (rc != PIVP_OK) return rc;
             }
     }

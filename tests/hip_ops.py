@@ -281,3 +281,33 @@ def wgrad5x5_bf16_batch(xs, hs, dGs):
                                             B, H, Wd, T, -sx, -sh, sg, stream()), 'wgrad5x5_bf16_batch')
     torch.cuda.synchronize()
     return pivp_amd.from_internal('lstm1/conv/W', dW.cpu().numpy(), (4 * C, cx + C, 5, 5)), db.cpu().numpy()
+
+
+def deconv3x3s2_of_norm_concat(h, gamma, beta, x1, W, b, relu, eps=1e-6, precision=0, fused=True):
+    """deconv3x3s2(concat(LayerNorm(h), x1)) in NCHW in / out.  fused: pivp_deconv3x3s2_ln (the norm applied while the conv stages its
+    input); otherwise pivp_layernorm into the concat buffer + pivp_deconv3x3s2* on it (what a training plan runs)."""
+    lib = _lib.load()
+    B, c_ln, H, Wd = h.shape
+    c1 = 0 if x1 is None else x1.shape[1]
+    cin, cout = c_ln + c1, W.shape[1]
+    n = c_ln * H * Wd
+    hd = nhwc(h)
+    perm = lambda v: _t(np.asarray(v).reshape(c_ln, H * Wd).T)
+    gd, bed = perm(gamma), perm(beta)
+    wd, bd = _t(pivp_amd.to_internal('enc4/W', W)), _t(b)
+    cat = torch.zeros((B, H, Wd, cin), dtype=torch.float32, device=DEV)
+    if c1:
+        cat[..., c_ln:] = nhwc(x1)
+    out = torch.empty((B, 2 * H, 2 * Wd, cout), dtype=torch.float32, device=DEV)
+    scratch = torch.empty(lib.pivp_layernorm_scratch_floats(B, n), dtype=torch.float32, device=DEV)
+    if fused:
+        x1p = cat.data_ptr() + c_ln * 4 if c1 else None
+        _lib.check(lib.pivp_deconv3x3s2_ln(hd.data_ptr(), c_ln, x1p, c1, cin, wd.data_ptr(), bd.data_ptr(), gd.data_ptr(), bed.data_ptr(), eps,
+                                           scratch.data_ptr(), out.data_ptr(), cout, cout, int(relu), B, H, Wd, precision, stream()), 'deconv3x3s2_ln')
+    else:
+        _lib.check(lib.pivp_layernorm(hd.data_ptr(), gd.data_ptr(), bed.data_ptr(), cat.data_ptr(), scratch.data_ptr(),
+                                      B, n, c_ln, cin, eps, 0, stream()), 'layernorm')
+        fn = [lib.pivp_deconv3x3s2, lib.pivp_deconv3x3s2_bf16, lib.pivp_deconv3x3s2_bf16x3][precision]
+        _lib.check(fn(cat.data_ptr(), cin, cin, wd.data_ptr(), bd.data_ptr(), out.data_ptr(), cout, cout, int(relu), B, H, Wd, stream()), 'deconv3x3s2')
+    torch.cuda.synchronize()
+    return nchw(out, B, 2 * H, 2 * Wd, cout)

@@ -159,15 +159,16 @@ def test_use_state_false_and_keep_activations(pivp):
 
 
 def test_inference_taps_of_norms_applied_inside_their_consumers(pivp):
-    # an inference plan applies norm(hidden2) / norm(hidden4) while enc1 / enc2 stage their input (run_conv3x3s2_ln: no ln_apply launch,
-    # the normalised tensor is never written); enc1 / enc2 must equal the oracle's, and tap() rebuilds hidden2 / hidden4 on request
+    # an inference plan applies norm(hidden2) / norm(hidden4) while enc1 / enc2 stage their input and norm(hidden6) / norm(hidden7) while
+    # enc5 / enc6 stage theirs (run_conv3x3s2_ln, run_deconv3x3s2_ln: no ln_apply launch, the normalised tensor is never written); the
+    # consumers must equal the oracle's, and tap() rebuilds the four hidden tensors on request.  B = 4: enough tiles for enc5's tile kernel.
     P = R.init_params(seed=3, dtype=np.float32, scale=1.0)
-    imgs, acts, stas = R.synthetic_batch(2, 4)
+    imgs, acts, stas = R.synthetic_batch(4, 4)
     ref = R.Model(10, params=P, dtype=np.float64, prefix='x'); ref.train = False
     ref([imgs, acts, stas], 0, tap_steps=(2,))
     m, loss, gen = _run(pivp, 'CDNA', 10, imgs, acts, stas, P)              # keep_activations = False
     assert R.per_pixel_l2(gen, np.stack(ref.gen_images)).max() < GATE
-    for tap in ('enc1', 'enc2', 'hidden2', 'hidden4', 'hidden5'):
+    for tap in ('enc1', 'enc2', 'enc5', 'enc6', 'hidden2', 'hidden4', 'hidden5', 'hidden6', 'hidden7'):
         got = m.tap(tap).cpu().numpy()
         assert np.abs(got - ref.taps[2][tap]).max() < 5e-4, tap
 

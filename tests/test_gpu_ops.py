@@ -106,6 +106,28 @@ def test_deconv3x3s2_parity(ops, B, cin, cout, H, relu):
     assert np.abs(ops.deconv3x3s2(x, W, b, relu) - ref).max() < TOL
 
 
+@pytest.mark.parametrize('B,c_ln,c1,cout,H,relu', [(4, 64, 32, 96, 16, True), (2, 32, 32, 64, 32, False), (5, 64, 0, 64, 16, True)])
+def test_deconv3x3s2_of_norm_concat_in_one_launch(ops, B, c_ln, c1, cout, H, relu):
+    """enc5 / enc6 of an inference rollout (TM:565-566, 574-575): deconv(concat(LayerNorm(hidden), skip)) with the norm applied while the
+    conv stages its input: within TOL of the float64 oracle and BIT-identical to the two launches a training plan runs, in every precision."""
+    rs = np.random.RandomState(7 + c_ln)
+    h = rs.randn(B, c_ln, H, H) * 0.3 + 0.1
+    x1 = rs.randn(B, c1, H, H) if c1 else None
+    n = c_ln * H * H
+    g = 1 + 0.1 * rs.randn(n); be = 0.1 * rs.randn(n)
+    W = rs.randn(c_ln + c1, cout, 3, 3) / np.sqrt(9 * (c_ln + c1)); b = rs.randn(cout) * 0.1
+    hn = R.layer_norm_conv2d(h, g, be, 1e-6)
+    ref = R.deconv2d(np.concatenate((hn, x1), 1) if c1 else hn, W, b, 2, 1, (2 * H, 2 * H))
+    if relu:
+        ref = R.relu(ref)
+    one = ops.deconv3x3s2_of_norm_concat(h, g, be, x1, W, b, relu)
+    assert np.abs(one - ref).max() < TOL
+    for precision in (0, 1, 2):
+        a = one if precision == 0 else ops.deconv3x3s2_of_norm_concat(h, g, be, x1, W, b, relu, precision=precision)
+        two = ops.deconv3x3s2_of_norm_concat(h, g, be, x1, W, b, relu, precision=precision, fused=False)
+        assert np.array_equal(a, two), precision
+
+
 def test_enc0_parity(ops):
     rs = np.random.RandomState(3)
     img = rs.rand(3, 3, 64, 64); W = rs.randn(32, 3, 5, 5) / np.sqrt(75); b = rs.randn(32) * 0.1
