@@ -68,7 +68,10 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
     const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN_LN ? d.in_g : d.x0), 0, IN_LN ? H * W * d.c0 * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN_LN ? d.in_b : d.x0), 0, IN_LN ? H * W * d.c0 * 4 : 0, 0x00020000);
     float ln_mean = 0.f, ln_rstd = 1.f;
-    if constexpr (IN_LN) ln_merge_partials(d.in_part, b, d.in_np, d.in_eps, ln_mean, ln_rstd);      // every wave for itself: a few partials per sample
+    if constexpr (IN_LN) {
+        ln_merge_partials(d.in_part, b, d.in_np, d.in_eps, ln_mean, ln_rstd);      // every wave for itself: a few partials per sample
+        if (d.in_stat_out && nblk == 0 && trem == 0 && tid == 0) { d.in_stat_out[b * 2] = ln_mean; d.in_stat_out[b * 2 + 1] = ln_rstd; }
+    }
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, d.bytesw, 0x00020000);
     constexpr unsigned OOB = 0xC0000000u;
 
@@ -93,8 +96,10 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
     f32x4 rp[5], rw[9];
     f32x4 rgm[5], rbt[5];              // IN_LN: gamma / beta of the staged float4s
     bool ln_chunk = false;             // the chunk in rp is part of the normalised tensor (block-uniform)
+    int ln_cc = 0;                     // ... and which of its 32-channel chunks
     auto load_chunk = [&](int cc) {
         const bool first = cc < ncc0;
+        ln_cc = cc;
 #pragma unroll
         for (int j = 0; j < 5; ++j)
             rp[j] = __builtin_bit_cast(f32x4, first ? __builtin_amdgcn_raw_buffer_load_b128(rsx, a_go[j], cc * 128, 0)
@@ -122,6 +127,15 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
                 for (int j = 0; j < 5; ++j)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) rp[j][e] = (rp[j][e] - ln_mean) * ln_rstd * rgm[j][e] + rbt[j][e];
+                if (d.in_out && nblk == 0) {      // the tile's own 8 x 16 pixels (not the halo), by the first column block
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        const int p = (tid >> 3) + 32 * j;
+                        const int py = p / PC, px = p - py * PC;
+                        if (py < 8 && px < 16)
+                            *reinterpret_cast<f32x4*>(d.in_out + ((size_t)(b * H + y0 + py) * W + x0 + px) * d.in_out_ld + ln_cc * 32 + c4 * 4) = rp[j];
+                    }
+                }
             }
         }
         if constexpr (BF16) {

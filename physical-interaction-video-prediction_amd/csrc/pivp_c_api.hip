@@ -125,8 +125,9 @@ bool deconv3x3s2_ln_ok(int c_ln, int c1, int cout, int B, int Hin, int Win) {
 }
 int run_deconv3x3s2_ln(const float* h_raw, int c_ln, const float* x1, int c1, int ld1, const float* w, const float* bias, float* out, int cout,
                        int ldo, int relu, int B, int Hin, int Win, hipStream_t s, const float* gamma, const float* beta, const float* partials,
-                       int nparts, float eps, float* ln_part, int ln_cap, int* ln_nparts, int bf16) {
+                       int nparts, float eps, float* ln_part, int ln_cap, int* ln_nparts, int bf16, float* norm_out, int norm_ld, float* stat_out) {
     if (!h_raw || !w || !out || !gamma || !beta || !partials || nparts <= 0 || !deconv3x3s2_ln_ok(c_ln, x1 ? c1 : 0, cout, B, Hin, Win)) return PIVP_ERR_BADARG;
+    if (norm_out && (norm_ld < c_ln || norm_ld % 4 || ((uintptr_t)norm_out & 15))) return PIVP_ERR_BADARG;
     if (ln_part && ln_part == partials) return PIVP_ERR_BADARG;      // blocks finish (and write their output partial) while others still read the input's
     IgemmDesc d;
     int rc = deconv3x3s2_ln_desc(d, h_raw, c_ln, x1, c1, ld1, w, bias, out, cout, ldo, relu, B, Hin, Win);
@@ -134,6 +135,7 @@ int run_deconv3x3s2_ln(const float* h_raw, int c_ln, const float* x1, int c1, in
     d.bf16 = bf16;
     d.in_g = gamma; d.in_b = beta; d.in_part = partials; d.in_np = nparts; d.in_eps = eps;
     d.ln_part = ln_part; d.ln_cap = ln_cap;
+    d.in_out = norm_out; d.in_out_ld = norm_ld; d.in_stat_out = stat_out;
     rc = igemm_validate(d, false);
     if (rc != PIVP_OK) return rc;
     if (!deconv_tile_ok(d)) return PIVP_ERR_BADARG;

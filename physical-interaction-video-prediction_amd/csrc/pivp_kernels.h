@@ -42,6 +42,9 @@ struct IgemmDesc {
     // [B][Hin*Win][c0] (all c0 channels are normalised), in_g / in_b the norm's per-element gamma / beta ([Hin*Win][c0], the checkpoint's
     // flat order), in_part the producer's (count, mean, M2) partials [B][in_np][4].  Served by igemm_small only (igemm_in_ln_ok).
     const float* in_g; const float* in_b; const float* in_part; int in_np; float in_eps;
+    // deconv_tile only (training plans): also WRITE the normalised x0 ([B][Hin*Win] pixels at stride in_out_ld; each pixel by the one block
+    // that owns it) and the samples' (mean, rstd) ([B][2]) -- what ln_apply would have left behind for the backward sweep
+    float* in_out; int in_out_ld; float* in_stat_out;
 };
 
 // weight gradient of a conv / transposed conv (csrc/igemm_wgrad.hip)

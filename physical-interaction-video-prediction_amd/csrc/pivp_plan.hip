@@ -412,7 +412,7 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     RC(lstm(1, ws + S.n1, 32, p->H2, p->W2));
     // Inference rollouts: hidden2 / hidden4 feed only enc1 / enc2, so their norms are applied while those convs stage their input
     // (run_conv3x3s2_ln) instead of by a launch of their own; training keeps the materialised tensors (the backward sweep reads them).
-    static const int fold_ln = [] { const char* e = getenv("PIVP_LN_FOLD"); return e ? atoi(e) : 2; }();   // tuning: 0 = always a separate ln_apply, 1 = only enc1 / enc2 fold theirs
+    static const int fold_ln = [] { const char* e = getenv("PIVP_LN_FOLD"); return e ? atoi(e) : 3; }();   // tuning: 0 = always a separate ln_apply, 1 = only enc1 / enc2 fold theirs (inference), 2 = + enc5 / enc6 (inference), 3 = + enc5 / enc6 in training plans
     if (!train && fold_ln && np > 0 && conv3x3s2_ln_ok(32, 32, B, p->H2, p->W2)) {
         RC(run_conv3x3s2_ln(ws + S.h[1], 32, P(p, p->i_enc_w[1]), P(p, p->i_enc_b[1]), ws + S.cat6 + 64, 32, 96, 1, B, p->H2, p->W2, s,
                             P(p, p->i_ln_g[2]), P(p, p->i_ln_b[2]), lnp, np, eps));
@@ -444,11 +444,15 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     // group 5 (TM:600): lstm6 -> hidden6 -> concat(., enc1) -> enc5 -> relu
     RC(lstm(5, ws + S.e4, 128, p->H4, p->W4));
     const int dprec = p->bf16_all ? 1 : p->lstm_planes == 2 ? 2 : 0;
-    // Inference: the norms of hidden6 / hidden7 feed only enc5 / enc6, whose tile kernel applies them while it stages its patch
-    // ([hidden6 | enc1], [hidden7 | enc0] as two sources); training keeps the materialised concat buffers (the backward sweep reads them).
-    if (!train && fold_ln >= 2 && np > 0 && deconv3x3s2_ln_ok(64, 32, 96, B, p->H4, p->W4)) {
+    // The norms of hidden6 / hidden7 feed only enc5 / enc6, whose tile kernel applies them while it stages its patch ([hidden6 | enc1],
+    // [hidden7 | enc0] as two sources).
+    // Training plans take the same launch and have it WRITE the normalised hidden6 / hidden7 (each pixel by the block that owns it) and the
+    // samples' (mean, rstd) for the backward sweep: no ln_apply launch there either.
+    const bool fold_dec = (train ? fold_ln >= 3 : fold_ln >= 2) && np > 0;
+    if (fold_dec && deconv3x3s2_ln_ok(64, 32, 96, B, p->H4, p->W4)) {
         RC(run_deconv3x3s2_ln(ws + S.h[5], 64, ws + S.cat6 + 64, 32, 96, P(p, p->i_enc_w[5]), P(p, p->i_enc_b[5]), ws + S.e5, 96, 96, 1, B, p->H4, p->W4,
-                              s, P(p, p->i_ln_g[6]), P(p, p->i_ln_b[6]), lnp, np, eps, nullptr, 0, nullptr, dprec));
+                              s, P(p, p->i_ln_g[6]), P(p, p->i_ln_b[6]), lnp, np, eps, nullptr, 0, nullptr, dprec,
+                              train ? ws + S.cat6 : nullptr, 96, train ? ws + S.lnstat + (size_t)6 * B * 2 : nullptr));
     } else {
         RC(ln(6, ws + S.h[5], ws + S.cat6, n4, 64, 96, 0, np));
         RC(run_deconv3x3s2(ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), P(p, p->i_enc_b[5]), ws + S.e5, 96, 96, 1, B, p->H4, p->W4, s, 0,
@@ -456,12 +460,13 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     }
     // group 6 (TM:601): lstm7 -> hidden7 -> concat(., enc0) -> enc6 -> norm_enc6 -> relu
     RC(lstm(6, ws + S.e5, 96, p->H2, p->W2));
-    if (!train && fold_ln >= 2 && np > 0 && deconv3x3s2_ln_ok(32, 32, 64, B, p->H2, p->W2)) {
+    if (fold_dec && deconv3x3s2_ln_ok(32, 32, 64, B, p->H2, p->W2)) {
         // enc6's blocks write the partials of norm_enc6 while others still read hidden7's: the second partial buffer
         float* lnp2 = ws + p->o_lnpart2;
         const int np_in = np;
         RC(run_deconv3x3s2_ln(ws + S.h[6], 32, ws + S.cat7 + 32, 32, 64, P(p, p->i_enc_w[6]), P(p, p->i_enc_b[6]), ws + S.e6raw, 64, 64, 0, B, p->H2, p->W2,
-                              s, P(p, p->i_ln_g[7]), P(p, p->i_ln_b[7]), lnp, np_in, eps, lnp2, ln_cap, &np, dprec));
+                              s, P(p, p->i_ln_g[7]), P(p, p->i_ln_b[7]), lnp, np_in, eps, lnp2, ln_cap, &np, dprec,
+                              train ? ws + S.cat7 : nullptr, 64, train ? ws + S.lnstat + (size_t)7 * B * 2 : nullptr));
         lnp = lnp2;
     } else {
         RC(ln(7, ws + S.h[6], ws + S.cat7, n2, 32, 64, 0, np));
