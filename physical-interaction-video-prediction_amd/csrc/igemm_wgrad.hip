@@ -15,7 +15,8 @@
 
 // timing-only ablations of wgrad5x5_kernel (results wrong): 1 = no global loads / LDS stores in the loop, 2 = also no LDS reads,
 // 3 = loads without stores, 4 = stores without loads.  lstm7 (us): full 265, 1: 222, 2: 208, 3: 221, 4: 217 -- loads and stores
-// cost nothing on their own and 43 us together, i.e. what costs is LDS contents that CHANGE between chunks (not understood).
+// cost nothing on their own and 43 us together, i.e. what costs is LDS contents that CHANGE between chunks (not understood; round 3,
+// scripts/wgrad_data_dependence.py: the full kernel is 13 % faster whenever one of its operands is all zeros, at an unchanged 2.39 GHz).
 #ifndef PIVP_WG_ABL
 #define PIVP_WG_ABL 0
 #endif
