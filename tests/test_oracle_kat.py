@@ -278,3 +278,53 @@ def test_dna_shifted_stack_is_detached():
     kn = torch.relu(tm.last['enc7'].detach() - 1e-12) + 1e-12
     kn = kn / kn.sum(1, keepdim=True)
     assert float((kn[:, 12:13] * tm.last['masks'][:, 1:2].detach() * go).abs().max()) > 1e-3
+
+
+def test_dna_one_hot_kernel_is_a_shift_with_the_slice_quirk():
+    # TM:395-402, derived by hand: prev is padded by 2 on every side; tap (xk, yk) takes rows xk..H-1 and columns yk..W-1 of the PADDED
+    # image (the slice ends at the unpadded size: the quirk), i.e. prev shifted by (xk - 2, yk - 2) and cut to H - xk rows / W - yk
+    # columns, then zero-filled at the bottom / right.  With enc7 one-hot at k = xk * 5 + yk the DNA output is exactly that image.
+    m, P = _model('DNA', 1)
+    rs = np.random.RandomState(4)
+    B, H, W = 2, 64, 64
+    prev = rs.rand(B, 3, H, W)
+    enc6 = np.ones((B, 64, H, W))
+    for xk, yk in ((0, 0), (2, 2), (4, 1), (1, 3), (4, 4)):
+        P['model/enc7/W'][...] = 0; P['model/enc7/b'][...] = 0
+        P['model/enc7/b'][xk * 5 + yk] = 1.0
+        m.load_params(P)
+        (out,), enc7 = m._dna(enc6, None, prev)
+        exp = np.zeros_like(prev)
+        for y in range(H - xk):
+            sy = y + xk - 2
+            if not 0 <= sy < H:
+                continue
+            for x in range(W - yk):
+                sx = x + yk - 2
+                if 0 <= sx < W:
+                    exp[:, :, y, x] = prev[:, :, sy, sx]
+        assert np.abs(out - exp).max() < 1e-9, (xk, yk)     # the 24 other taps weigh RELU_SHIFT = 1e-12 each
+
+
+def test_smear_and_state_predictor():
+    # TM:556-567: state_action is tiled over the 8x8 map and concatenated BEHIND enc2's 64 channels in front of the 1x1 enc3;
+    # TM:676: state_action = concat(action, current_state) in that order; TM:730-731: the PREDICTED state is fed back.
+    P = R.init_params(seed=2, dtype=np.float64, scale=1.0)
+    P['enc3/W'][:, :64] = 0.0                                     # enc3 sees the smear only
+    m = R.Model(10, params=P, dtype=np.float64, prefix='kat'); m.train = False
+    imgs, acts, stas = R.synthetic_batch(2, 4)
+    m([imgs, acts, stas], 0, tap_steps=(0, 1))
+    W3, b3 = P['enc3/W'][:, 64:, 0, 0], P['enc3/b']              # (64, 10)
+    Wc, bc = P['current_state/W'], P['current_state/b']          # (5, 10)
+    cur = stas[0].astype(np.float64)                              # TM:646
+    for t in (0, 1):
+        sa = np.concatenate((acts[t].astype(np.float64), cur), axis=1)
+        e3 = np.maximum(sa @ W3.T + b3, 0.0)                      # constant over the map
+        assert np.abs(m.taps[t]['enc3'] - e3[:, :, None, None]).max() < 1e-12
+        cur = sa @ Wc.T + bc
+        assert np.abs(m.gen_states[t] - cur).max() < 1e-12
+    # the ground-truth state of step 1 is never read (TM:675 comment "Predicted state is always fed back in")
+    stas2 = stas.copy(); stas2[1:] += 7.0
+    m2 = R.Model(10, params=P, dtype=np.float64, prefix='kat'); m2.train = False
+    m2([imgs, acts, stas2], 0)
+    assert np.array_equal(np.stack(m2.gen_images), np.stack(m.gen_images))
