@@ -689,33 +689,42 @@ int cdna_kernels_bwd(const float* hidden5, const float* wt, const float* vpre, c
 // threads per block: one pixel per thread on 8 x 64 tiles, two waves per SIMD (256 threads: 224 us per launch at B = 32)
 constexpr int CBS_NT = 512;
 constexpr int CBS_R = 12;        // rows above / below the tile held in the LDS window of d prev
+// `whole` (feed-self sweeps on frames whose three planes fit in LDS: 48 KB at 64 x 64): a block's window of d prev is the WHOLE frame, so
+// every scattered bilinear weight is an LDS atomic whatever theta is (with the +-12-row window a random-init theta, far from the identity,
+// sent most of them to global atomics: 194 us per launch).  A sample's tiles are shared by gridDim.x blocks (tile, tile + gridDim.x, ...),
+// each of which adds its frame to d prev once at the end: one coalesced atomic per touched element (plain adds when gridDim.x == 1).
 
 template <int CB_TR>
 __global__ __launch_bounds__(CBS_NT) void composite_bwd_stp_kernel(const float* __restrict__ prev, const float* __restrict__ logits,
                                                                 const float* __restrict__ layer0, const float* __restrict__ theta,
                                                                 const float* __restrict__ go, float* __restrict__ dmk, float* __restrict__ dz,
                                                                 float* __restrict__ dthpart, float* __restrict__ dprev,
-                                                                int H, int W, int NM, int stp_zero) {
+                                                                int H, int W, int NM, int stp_zero, int whole) {
     PIVP_SET_MAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float red[CBS_NT / 64][6];
     const int NP = NM + 1, HW = H * W;
-    const int b = blockIdx.y, y0 = blockIdx.x * CB_TR;
-    const int rows = min(CB_TR, H - y0);
-    const int p0 = y0 * W, np = rows * W;
-    const int win = np + 2 * (NP - 1), G = np / NP + 2;
-    float* lg = sm;                      // [NP][win]
-    float* gmx = lg + NP * win;          // [NP][G]
-    float* ginv = gmx + NP * G;          // [NP][G]
-    float* dwin = ginv + NP * G;         // [3][WR][W]  this block's window of d prev (feed-self only)
-    constexpr int WR = CB_TR + 2 * CBS_R;
-    const int wy0 = y0 - CBS_R;
+    const int b = blockIdx.y;
+    const int ntiles = (H + CB_TR - 1) / CB_TR;
     const int tid = threadIdx.x;
+    const int WR = whole ? H : CB_TR + 2 * CBS_R;
+    const int np_max = CB_TR * W, win_max = np_max + 2 * (NP - 1), G_max = np_max / NP + 2;
+    float* lg = sm;                              // [NP][win]
+    float* gmx = lg + NP * win_max;              // [NP][G]
+    float* ginv = gmx + NP * G_max;              // [NP][G]
+    float* dwin = ginv + NP * G_max;             // [3][WR][W]  this block's window of d prev (feed-self only)
     if (dprev)
         for (int i = tid; i < 3 * WR * W; i += CBS_NT) dwin[i] = 0.f;
     const float* lgb = logits + (size_t)b * NP * HW;
     const unsigned magic = 0xFFFFFFFFu / (unsigned)NP + 1u;        // exact x / NP for x * NP < 2^32 (as in composite_bwd_cdna_kernel)
     auto div_np = [&](int x) { return (int)__umulhi((unsigned)x, magic); };
+  for (int tile = blockIdx.x; tile < (whole ? ntiles : (int)blockIdx.x + 1); tile += gridDim.x) {
+    const int y0 = tile * CB_TR;
+    const int rows = min(CB_TR, H - y0);
+    const int p0 = y0 * W, np = rows * W;
+    const int win = np + 2 * (NP - 1), G = np / NP + 2;
+    const int wy0 = whole ? 0 : y0 - CBS_R;
+    if (tile != (int)blockIdx.x) __syncthreads();      // the previous tile's readers of lg / gmx / red are done
     for (int i = tid; i < NP * win; i += CBS_NT) {
         const int m = i / win, j = i - m * win;
         const int F = m * HW + p0 - (NP - 1) + j;
@@ -810,7 +819,7 @@ __global__ __launch_bounds__(CBS_NT) void composite_bwd_stp_kernel(const float* 
     for (int j = 0; j < 6; ++j) dth[j] = wave_sum(dth[j]);
     if ((tid & 63) == 0) for (int j = 0; j < 6; ++j) red[tid >> 6][j] = dth[j];
     __syncthreads();
-    if (dprev)          // the window's touched elements, one atomic each (other tiles' windows overlap this one)
+    if (dprev && !whole)   // the window's touched elements, one atomic each (other tiles' windows overlap this one)
         for (int i = tid; i < 3 * WR * W; i += CBS_NT) {
             const float v = dwin[i];
             const int c = i / (WR * W), rem = i - c * (WR * W), r = rem / W, xx = rem - r * W, yy = wy0 + r;
@@ -820,7 +829,14 @@ __global__ __launch_bounds__(CBS_NT) void composite_bwd_stp_kernel(const float* 
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < CBS_NT / 64; ++w) v += red[w][tid];
-        dthpart[((size_t)b * gridDim.x + blockIdx.x) * 8 + tid] = v;
+        dthpart[((size_t)b * ntiles + tile) * 8 + tid] = v;
+    }
+  }   // tiles
+    if (dprev && whole) {   // the whole frame: plain adds when this block is the sample's only writer in the launch, else one atomic per element
+        __syncthreads();
+        float* dp = dprev + (size_t)b * 3 * HW;
+        if (gridDim.x == 1) { for (int i = tid; i < 3 * HW; i += CBS_NT) dp[i] += dwin[i]; }
+        else { for (int i = tid; i < 3 * HW; i += CBS_NT) { const float v = dwin[i]; if (v != 0.f) atomicAdd(dp + i, v); } }
     }
 }
 
@@ -829,16 +845,26 @@ int composite_bwd_stp(const float* prev, const float* logits, const float* layer
     PIVP_CHECK_ARG(prev && logits && layer0 && theta && go && dmk && dz && dthpart && B > 0 && H > 1 && W > 1 && NM >= 2 && NM <= 10);
     const int CB_TR = composite_bwd_rows(W);
     const int NP = NM + 1, np = CB_TR * W, win = np + 2 * (NP - 1), G = np / NP + 2;
-    const size_t lds = sizeof(float) * ((size_t)NP * win + 2 * NP * G + 3 * (size_t)(CB_TR + 2 * CBS_R) * W);
+    static const int whole_on = [] { const char* e = getenv("PIVP_STP_WHOLE"); return e ? atoi(e) : 8; }();   // tuning: 0 = one block per tile and a +-12-row window; k = at most k blocks per sample (B = 32: 29.3 / 29.3 / 28.6 / 28.2 / 28.0 ms per STP train step for 0 / 1 / 2 / 4 / 8)
+    const size_t lds_head = sizeof(float) * ((size_t)NP * win + 2 * NP * G);
+    const int whole = (whole_on > 0 && dprev && lds_head + sizeof(float) * 3 * (size_t)H * W <= 96 * 1024) ? 1 : 0;
+    const size_t lds = lds_head + sizeof(float) * 3 * (size_t)(whole ? H : CB_TR + 2 * CBS_R) * W;
     PIVP_CHECK_ARG(lds <= 150 * 1024);
+    const int ntiles = composite_bwd_tiles(H, W);
+    int per_sample = ntiles;
+    if (whole) {           // blocks per sample: enough to cover the chip about once (every block flushes a whole frame of atomics)
+        per_sample = whole_on < ntiles ? whole_on : ntiles;
+        while (per_sample > 1 && (long)per_sample * B > 1024) per_sample >>= 1;
+    }
+    const dim3 grid(per_sample, B);
     if (CB_TR == 8) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_stp_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(composite_bwd_stp_kernel<8>, dim3(composite_bwd_tiles(H, W), B), dim3(CBS_NT), lds, s, prev, logits, layer0, theta, go, dmk,
-                           dz, dthpart, dprev, H, W, NM, stp_zero);
+        hipLaunchKernelGGL(composite_bwd_stp_kernel<8>, grid, dim3(CBS_NT), lds, s, prev, logits, layer0, theta, go, dmk,
+                           dz, dthpart, dprev, H, W, NM, stp_zero, whole);
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_stp_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(composite_bwd_stp_kernel<4>, dim3(composite_bwd_tiles(H, W), B), dim3(CBS_NT), lds, s, prev, logits, layer0, theta, go, dmk,
-                           dz, dthpart, dprev, H, W, NM, stp_zero);
+        hipLaunchKernelGGL(composite_bwd_stp_kernel<4>, grid, dim3(CBS_NT), lds, s, prev, logits, layer0, theta, go, dmk,
+                           dz, dthpart, dprev, H, W, NM, stp_zero, whole);
     }
     return PIVP_LAUNCH_STATUS();
 }
