@@ -176,6 +176,21 @@ def test_bptt_gradients_stp(pivp):
     print('STP worst relative gradient error', worst)
 
 
+def test_bptt_gradients_stp_128(pivp):
+    """128 x 128 frames: d prev's three planes do not fit in LDS, so the STP composite backward keeps its +-12-row window and sends what
+    falls outside it to global atomics (64 x 64: the whole frame is the window); same check as above, fed-back step included."""
+    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, model_type='STP', height=128, width=128)
+    imgs, acts, stas = R.smooth_batch(2, 4, height=128, width=128, seed=3)
+    loss_ref, gref = _autograd(P, imgs, acts, stas, is_cdna=False, is_stp=True)
+    m = pivp.Model(10, is_cdna=False, is_stp=True, prefix='t', keep_activations=True)
+    m.load_state_dict_reference(P)
+    loss = float(m([imgs, acts, stas], 0))
+    m.cleargrads(); m.backward()
+    assert abs(loss - loss_ref) < 1e-6
+    worst = _check_grads(m.grads_reference(), gref, 5e-3)
+    print('STP 128 x 128 worst relative gradient error', worst)
+
+
 def test_bptt_gradients_dna(pivp):
     # DNA head (TM:368-417), num_masks = 1, with the reference's slice quirk in forward and backward
     P = R.init_params(seed=1, dtype=np.float64, scale=1.0, model_type='DNA', num_masks=1)
