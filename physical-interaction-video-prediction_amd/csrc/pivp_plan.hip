@@ -448,8 +448,12 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     // [hidden7 | enc0] as two sources).
     // Training plans take the same launch and have it WRITE the normalised hidden6 / hidden7 (each pixel by the block that owns it) and the
     // samples' (mean, rstd) for the backward sweep: no ln_apply launch there either.
+    // Only while the norm is a launch-bound 5-us kernel (<= 6 MB of hidden tensor: 64 x 64 frames at B = 32): the consumer's column blocks
+    // each stage the patch and its gamma / beta again, which at config 5's 128 x 128 costs more than one bandwidth-bound ln_apply pass
+    // (B = 32, T = 20: rollout 65.5 -> 65.9 ms with the fold, so it is not taken there).
     const bool fold_dec = train ? fold_ln >= 3 : fold_ln >= 2;
-    if (fold_dec && np > 0 && deconv3x3s2_ln_ok(64, 32, 96, B, p->H4, p->W4)) {
+    auto fold_small = [&](long long floats) { return fold_ln >= 4 || floats * 4 <= 6LL << 20; };      // 4 = whatever the size
+    if (fold_dec && np > 0 && fold_small((long long)B * n4) && deconv3x3s2_ln_ok(64, 32, 96, B, p->H4, p->W4)) {
         RC(run_deconv3x3s2_ln(ws + S.h[5], 64, ws + S.cat6 + 64, 32, 96, P(p, p->i_enc_w[5]), P(p, p->i_enc_b[5]), ws + S.e5, 96, 96, 1, B, p->H4, p->W4,
                               s, P(p, p->i_ln_g[6]), P(p, p->i_ln_b[6]), lnp, np, eps, nullptr, 0, nullptr, dprec,
                               train ? ws + S.cat6 : nullptr, 96, train ? ws + S.lnstat + (size_t)6 * B * 2 : nullptr));
@@ -460,7 +464,7 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     }
     // group 6 (TM:601): lstm7 -> hidden7 -> concat(., enc0) -> enc6 -> norm_enc6 -> relu
     RC(lstm(6, ws + S.e5, 96, p->H2, p->W2));
-    if (fold_dec && np > 0 && deconv3x3s2_ln_ok(32, 32, 64, B, p->H2, p->W2)) {
+    if (fold_dec && np > 0 && fold_small((long long)B * n2) && deconv3x3s2_ln_ok(32, 32, 64, B, p->H2, p->W2)) {
         // enc6's blocks write the partials of norm_enc6 while others still read hidden7's: the second partial buffer
         float* lnp2 = ws + p->o_lnpart2;
         const int np_in = np;
