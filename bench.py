@@ -63,6 +63,10 @@ def _pmc_traffic(bf16=False):
 def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--config', type=int, default=None, choices=[2, 3, 4, 5],
+                    help="preset of a BASELINE.json config (index into its `configs`; per-GPU batch 32 throughout): 2 = the default "
+                         "(CDNA 64x64 T=10 fp32 rollout), 3 = --precision bf16 --mode train (at --gpus 8: global batch 256), 4 = --model STP, "
+                         "5 = --size 128 --seq-len 20.  Explicit flags given after it still win.")
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32, help='sequences per GPU (config 2: 32)')
@@ -161,9 +165,27 @@ def timed(step, steps, warmup, sync, barrier):
     return time.perf_counter() - t0, out
 
 
+CONFIG_PRESETS = {      # BASELINE.json `configs[i]` -> the flags that select it (per-GPU batch 32; config 3 / 5 are quoted at 8 GPUs: --gpus 8)
+    2: ([], '1xMI355X: batch=32, 64x64x3, 10-frame CDNA, action-conditioned, fp32'),
+    3: (['--precision', 'bf16', '--mode', 'train'], '8xMI355X DP: global batch=256, 64x64x3, 10-frame CDNA, RCCL all-reduce over xGMI, bf16'),
+    4: (['--model', 'STP'], 'STP variant (spatial-transformer predictor) in place of CDNA kernels, batch=32, 1 GPU'),
+    5: (['--size', '128', '--seq-len', '20'], '128x128x3 frames, 20-step rollout, num_masks=10, 8xMI355X DP (bandwidth-bound stress)'),
+}
+
+
+def parse_args(argv):
+    """--config N expands to its preset flags IN FRONT of the command line, so explicit flags override the preset."""
+    ap = build_parser()
+    first = ap.parse_args(argv)
+    if first.config is None:
+        return first
+    args = ap.parse_args(CONFIG_PRESETS[first.config][0] + list(argv))
+    return args
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
-    args = build_parser().parse_args(argv)
+    args = parse_args(argv)
     env_world = os.environ.get('WORLD_SIZE')
     if env_world is None and args.gpus > 1:
         sys.exit(launch_ranks(args, argv))
@@ -267,7 +289,9 @@ def main(argv=None):
             """-> (result object, model, optimizer, seconds for K steps with the collective, last loss)"""
             use_dp = [True]
             if dry:
-                tm = pivp_amd.HostStubModel(sizes=(1 << 16, 1 << 14, 1 << 15, 1 << 15, 1 << 16, 1 << 14), value=float(rank + 1))
+                sys.path.insert(0, os.path.join(ROOT, 'tests'))
+                from host_stub import HostStubModel          # the test double lives with the tests, not in the product package
+                tm = HostStubModel(sizes=(1 << 16, 1 << 14, 1 << 15, 1 << 15, 1 << 16, 1 << 14), value=float(rank + 1))
                 op = None
                 ngrad = sum(tm.sizes)
 
@@ -292,8 +316,23 @@ def main(argv=None):
                     return op.update(tm, [images, actions, states], 0)                  # schedsamp_k = -1: feed-self, deterministic
             t_with, tloss = timed(train_step, args.steps, args.warmup, sync, barrier)
             t_with = max_over_ranks(t_with)
+            algo = dp.last_algo if dp is not None else None
+            payload_bytes = dp.last_payload_bytes if dp is not None else None
             t_without = None
-            if world > 1:       # the same step with the collective switched off (replicas drift apart: timing only, run last)
+            compare = None
+            if world > 1:
+                if precision == 'bf16' and dp.algo == 'auto' and not dry:
+                    # SURVEY.md 5's "measured comparison": the same step with the other schedule of the bf16 payload (the default, all-links
+                    # reduce-scatter + all-gather with an fp32 local sum, against one ring all-reduce that sums in bf16)
+                    compare = {algo: round(t_with / args.steps * 1e3, 3)}
+                    other = 'allreduce' if algo == 'rs_ag' else 'rs_ag'
+                    dp.algo = other
+                    try:
+                        t_other, _ = timed(train_step, args.steps, max(1, args.warmup // 2), sync, barrier)
+                        compare[other] = round(max_over_ranks(t_other) / args.steps * 1e3, 3)
+                    finally:
+                        dp.algo = 'auto'
+                # the same step with the collective switched off (replicas drift apart: timing only, run last)
                 use_dp[0] = False
                 t_without, _ = timed(train_step, args.steps, max(1, args.warmup // 2), sync, barrier)
                 t_without = max_over_ranks(t_without)
@@ -309,9 +348,13 @@ def main(argv=None):
                 'allreduce_ms_exposed': 0.0 if t_without is None else round(max(0.0, t_with - t_without) / args.steps * 1e3, 3),
                 # what one rank hands to the all-reduce per step: the fp32 flat gradient buffer, or its bf16 image in the bf16 precision
                 # mode (parallel.GradAllReduce(payload='auto'))
-                'gradient_bytes_per_step': (2 if precision == 'bf16' else 4) * ngrad,
-                'gradient_payload': 'bf16 (fp32 accumulation in the flat gradient buffer and Adam)' if precision == 'bf16' else 'fp32',
+                # what one rank hands to the collective per step (GradAllReduce.last_payload_bytes); with one rank nothing travels: the figure
+                # is what a data-parallel rank of this precision would send
+                'gradient_bytes_per_step': payload_bytes if payload_bytes else (2 if precision == 'bf16' else 4) * ngrad,
+                'gradient_payload': 'bf16 (summed over the ranks in fp32, one rounding; fp32 flat gradient buffer and Adam)' if precision == 'bf16' else 'fp32',
                 'allreduce': 'none (1 rank)' if world == 1 else '6 gradient groups, SUM, issued from inside the backward sweep of t = 0 on a side stream',
+                'allreduce_algo': algo if world > 1 else 'none (1 rank; a data-parallel run of this precision uses %s)' % ('rs_ag' if precision == 'bf16' else 'allreduce'),
+                'allreduce_algo_ms_per_step': compare,
                 'dtype': {'fp32': 'f32', 'bf16': 'bf16 ConvLSTM / enc5 / enc6 operands, f32 accumulate, gradients and optimizer',
                           'bf16x3': 'f32 as 2 bf16 pieces in the ConvLSTM forward and data gradients'}[precision],
                 'workload': 'optimizer.update (TM:950): forward + BPTT backward + gradient all-reduce + Adam, schedsamp_k=-1, batch %d/GPU' % B,
@@ -353,8 +396,12 @@ def main(argv=None):
     if rank == 0:
         frames = world * B * (T - 1) * args.steps
         train_mode = args.mode == 'train'
+        preset = ''
+        if args.config is not None:     # name the BASELINE.json config this run is (one rank's share of it when it is quoted at 8 GPUs)
+            share = '' if args.config not in (3, 5) or world == 8 else "; this run: %d of its 8 ranks' shares" % world
+            preset = 'BASELINE.json configs[%d] (%s%s): ' % (args.config, CONFIG_PRESETS[args.config][1], share)
         out = {
-            'metric': 'predicted frames/sec (64x64x3, 10-step rollout)',
+            'metric': 'predicted frames/sec (%dx%dx3, %d-step rollout)' % (S, S, T),
             'value': round(frames / elapsed, 1) if not dry else 0.0,
             'unit': 'frames/s',
             'n_gpus': world,
@@ -368,7 +415,7 @@ def main(argv=None):
                       'bf16x3': 'f32 operands of the ConvLSTM forward as 2 bf16 pieces (3 bf16 MFMAs per product), f32 accumulate and elsewhere'}[args.precision],
             'data': ('synthetic' if not args.share_gpu else 'synthetic; REHEARSAL: %d ranks share one GPU over gloo, not a multi-GPU measurement' % world)
                     if not dry else 'none: --dry run of the host logic on CPU (gloo, stub kernels); NOT a measurement',
-            'config': {'workload': '%s %s, batch %d/GPU, %d-frame %dx%dx3 sequences, action-conditioned, num_masks=%d, '
+            'config': {'workload': preset + '%s %s, batch %d/GPU, %d-frame %dx%dx3 sequences, action-conditioned, num_masks=%d, '
                                    'random-init weights' % (args.model, 'train step (optimizer.update: forward + BPTT backward + grad '
                                    'all-reduce + Adam, schedsamp_k=-1)' if train_mode else 'rollout forward (Model.__call__, feed-self)',
                                    B, T, S, S, nm),
@@ -452,6 +499,7 @@ def cpu_baseline_leg(args, B, T, S, nm, np, torch, train):
             tm([ci, ca, cs], 0); tm.reset_state()
             reps += 1
         cel = time.perf_counter() - c0
+    roll_per_rep = cel / max(1, reps)
     if train:      # same bounded sample, but forward + autograd backward + Chainer-rule Adam
         from oracle.torch_restatement import chainer_adam_step
         tmt = TorchModel(nm, is_cdna=args.model == 'CDNA', is_stp=args.model == 'STP', is_dna=args.model == 'DNA',
@@ -467,11 +515,28 @@ def cpu_baseline_leg(args, B, T, S, nm, np, torch, train):
                 chainer_adam_step(Pm, {k: v.grad.numpy() for k, v in tmt.p.items()}, Mm, Vm, reps + 1)
             reps += 1
         cel = time.perf_counter() - c0
-    return {'value': round(cb * (ct - 1) * reps / cel, 2), 'unit': 'predicted frames/s',
-            'cores': cpu_threads, 'kind': 'port',
+    value = round(cb * (ct - 1) * reps / cel, 2)
+    one_thread = None
+    try:        # "plus a 1-thread run" -- bounded (~8 s): the same workload when one rollout fits, else a B = 2 sample of it
+        ob = cb if roll_per_rep * cpu_threads * 0.4 < 8.0 else 2      # one thread is ~6x slower than 16 on this model (scripts/cpu_thread_scan.py)
+        oi, oa, os_ = (ci, ca, cs) if ob == cb else R.synthetic_batch(ob, ct, S, S)
+        torch.set_num_threads(1)
+        with torch.no_grad():
+            r1, c1 = 0, time.perf_counter()
+            while r1 == 0 or time.perf_counter() - c1 < 8.0:
+                tm([oi, oa, os_], 0); tm.reset_state()
+                r1 += 1
+            e1 = time.perf_counter() - c1
+        one_thread = {'value': round(ob * (ct - 1) * r1 / e1, 2), 'unit': 'predicted frames/s', 'cores': 1,
+                      'sample': '%d rollouts of B=%d T=%d %dx%d %s, %.1f s%s' % (r1, ob, ct, S, S, args.model, e1,
+                                                                                  ' (rollout forward only)' if train else '')}
+    finally:
+        torch.set_num_threads(cpu_threads)
+    return {'value': value, 'unit': 'predicted frames/s',
+            'cores': cpu_threads, 'host_cores': os.cpu_count(), 'one_thread': one_thread, 'kind': 'port',
             'sample': '%d %s of B=%d T=%d %dx%d %s, fp32 PyTorch-CPU restatement of the reference path '
-                      '(oracle/torch_restatement.py), %.1f s' % (reps, 'train steps (fwd+bwd+Adam)' if train else 'rollouts',
-                                                                  cb, ct, S, S, args.model, cel)}
+                      '(oracle/torch_restatement.py), %.1f s on %d threads (the measured optimum of PyTorch-CPU on this model; the host has %d)' % (reps, 'train steps (fwd+bwd+Adam)' if train else 'rollouts',
+                                                                  cb, ct, S, S, args.model, cel, cpu_threads, os.cpu_count() or 0)}
 
 
 if __name__ == '__main__':

@@ -38,8 +38,13 @@ extern "C" {
 #define PIVP_PRECISION_BF16 1
 #define PIVP_PRECISION_BF16X3 2
 
-int pivp_abi_version(void);   /* 8 (8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+int pivp_abi_version(void);   /* 9 (9: + pivp_build_digest, pivp_grad_sum_shards; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
                                  5: + bf16 ConvLSTM, pivp_plan_set_precision, 6: + pivp_plan_set_group_join / pivp_plan_group_wait) */
+
+/* sha256 (hex) of the sources this library was compiled from (every .hip and .h under csrc/, and this header), embedded by build.py.  The Python
+ * binding recomputes it from the sources shipped next to the library and refuses to load on a mismatch: a stale build can never stand
+ * in for the code under test.  "unstamped" for a build that bypassed build.py. */
+const char* pivp_build_digest(void);
 
 /* ------------------------------------------------------------------------------------------
  * Plan = Model.__init__ (TM:484-602): layer table, op program, variant head.
@@ -266,6 +271,11 @@ int pivp_adam_step(float* p, const float* g, float* m, float* v, long long n, do
  * nearest even), and unpack the summed bf16 buffer back into the fp32 gradient buffer that pivp_adam_step reads. */
 int pivp_grad_pack_bf16(const float* src, void* dst_bf16, long long n, void* stream);
 int pivp_grad_unpack_bf16(const void* src_bf16, float* dst, long long n, void* stream);
+/* The local half of a reduce-scatter over all links (parallel.py: GradAllReduce(algo='rs_ag'); SURVEY.md 5 / 8e, wraps TM:950 like
+ * the two above): src holds `nshards` shards of `shard_len` elements each, one per peer (bf16 if src_bf16, else fp32; 16-B aligned,
+ * shard_len % 8 == 0 for bf16 / % 4 for fp32); dst[i] = sum over shards in the fixed order 0 .. nshards-1, accumulated in fp32 and
+ * rounded once to bf16 (dst_bf16) or kept fp32.  An all-reduce of a bf16 buffer rounds its running sum at every hop instead. */
+int pivp_grad_sum_shards(const void* src, int src_bf16, int nshards, long long shard_len, void* dst, int dst_bf16, void* stream);
 
 /* L.Convolution2D(cout,(3,3),stride=2,pad=1) (TM:501-502) + optional ReLU; w [9][cin/32][cout][32]. */
 int pivp_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,

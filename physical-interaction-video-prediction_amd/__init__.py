@@ -14,8 +14,8 @@ from .checkpoint import save_npz, load_npz, to_internal, from_internal, save_opt
 from . import dataset
 from .data import concat_examples
 from .optimizer import Adam
-from .parallel import GradAllReduce, HostStubModel, shard_batch
+from .parallel import GradAllReduce, shard_batch
 
 __all__ = ['Model', 'config', 'using_config', 'reference_param_shapes', 'default_init',
            'scheduled_sampling_masks', 'save_npz', 'load_npz', 'to_internal', 'from_internal', 'concat_examples',
-           'Adam', 'GradAllReduce', 'HostStubModel', 'shard_batch', 'save_optimizer_npz', 'load_optimizer_npz', 'dataset']
+           'Adam', 'GradAllReduce', 'shard_batch', 'save_optimizer_npz', 'load_optimizer_npz', 'dataset']

@@ -23,6 +23,7 @@ class PivpConfig(ctypes.Structure):
 # name -> (restype, argtypes); every symbol include/pivp_hip.h declares
 SIGNATURES = {
     'pivp_abi_version': (_i, []),
+    'pivp_build_digest': (_c.c_char_p, []),
     'pivp_plan_create': (_i, [_c.POINTER(PivpConfig), _c.POINTER(_vp)]),
     'pivp_plan_destroy': (None, [_vp]),
     'pivp_param_count': (_i, [_vp]),
@@ -77,6 +78,7 @@ SIGNATURES = {
     'pivp_adam_step': (_i, [_vp, _vp, _vp, _vp, _ll, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _vp]),
     'pivp_grad_pack_bf16': (_i, [_vp, _vp, _ll, _vp]),
     'pivp_grad_unpack_bf16': (_i, [_vp, _vp, _ll, _vp]),
+    'pivp_grad_sum_shards': (_i, [_vp, _i, _i, _ll, _vp, _i, _vp]),
     'pivp_conv3x3s2': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'pivp_deconv3x3s2': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'pivp_deconv3x3s2_ln_fits': (_i, [_i, _i, _i, _i, _i, _i]),
@@ -111,6 +113,14 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the ABI and the header drift apart
         fn.restype = res
         fn.argtypes = args
+    # a library older (or newer) than the sources next to it must never stand in for them: a GPU test would then pass or fail on code
+    # other than the code it claims to test
+    from . import _digest
+    built, shipped = lib.pivp_build_digest().decode(), _digest.source_digest()
+    if built != shipped:
+        raise RuntimeError(
+            'libpivp_hip.so is stale: it was built from sources with digest %s..., the sources in %s have %s.... Rebuild it '
+            '(`python physical-interaction-video-prediction_amd/build.py`); there is no CPU fallback.' % (built[:12], _digest.CSRC, shipped[:12]))
     _lib = lib
     return lib
 

@@ -461,6 +461,34 @@ __global__ __launch_bounds__(256) void grad_unpack_bf16_kernel(const unsigned sh
         }
     }
 }
+// Data-parallel reduce-scatter, local half (parallel.py: GradAllReduce(algo='rs_ag')): `nsh` shards of `len` elements, one per peer
+// (bf16 as they travelled, or fp32), summed in fp32 in the fixed order 0 .. nsh-1 and rounded ONCE to the output type.  An all-reduce
+// of a bf16 buffer rounds the running sum at every hop instead (7 roundings at 8 ranks).
+template <bool IN_BF16, bool OUT_BF16>
+__global__ __launch_bounds__(256) void grad_sum_shards_kernel(const void* __restrict__ src_, void* __restrict__ dst_, int nsh, long len) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < len; i += (long)gridDim.x * 1024) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nsh; ++k) {
+            f32x4 v;
+            if (IN_BF16) v = __builtin_convertvector(*reinterpret_cast<const bf16x4_t*>((const unsigned short*)src_ + (long)k * len + i), f32x4);
+            else v = *reinterpret_cast<const f32x4*>((const float*)src_ + (long)k * len + i);
+            acc += v;
+        }
+        if (OUT_BF16) *reinterpret_cast<bf16x4_t*>((unsigned short*)dst_ + i) = __builtin_convertvector(acc, bf16x4_t);
+        else *reinterpret_cast<f32x4*>((float*)dst_ + i) = acc;
+    }
+}
+int grad_sum_shards(const void* src, int src_bf16, int nsh, long len, void* dst, int dst_bf16, hipStream_t s) {
+    PIVP_CHECK_ARG(src && dst && nsh > 0 && len > 0 && len % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0);
+    PIVP_CHECK_ARG(!src_bf16 || (len * 2) % 16 == 0);       // every shard starts 16-B aligned
+    const long blocks = (len / 4 + 255) / 256;
+    const dim3 grid((unsigned)(blocks < 2048 ? blocks : 2048));
+    if (src_bf16 && dst_bf16) hipLaunchKernelGGL((grad_sum_shards_kernel<true, true>), grid, dim3(256), 0, s, src, dst, nsh, len);
+    else if (src_bf16) hipLaunchKernelGGL((grad_sum_shards_kernel<true, false>), grid, dim3(256), 0, s, src, dst, nsh, len);
+    else if (dst_bf16) hipLaunchKernelGGL((grad_sum_shards_kernel<false, true>), grid, dim3(256), 0, s, src, dst, nsh, len);
+    else hipLaunchKernelGGL((grad_sum_shards_kernel<false, false>), grid, dim3(256), 0, s, src, dst, nsh, len);
+    return PIVP_LAUNCH_STATUS();
+}
 int grad_pack_bf16(const float* src, void* dst, long n, hipStream_t s) {
     PIVP_CHECK_ARG(src && dst && n > 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0);
     const long blocks = (n / 4 + 255) / 256;

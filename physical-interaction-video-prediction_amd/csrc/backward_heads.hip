@@ -1116,6 +1116,7 @@ __global__ __launch_bounds__(256) void enc0_dgrad_kernel(const float* __restrict
 int enc0_bwd(const float* img, const float* w, const float* d, float* dw, float* db, float* dimg, int dimg_accum, int B, int H, int W,
              hipStream_t s, const SideFork* fork) {
     PIVP_CHECK_ARG(img && w && d && dw && db && B > 0 && H > 0 && W > 0);
+    PIVP_CHECK_ARG(!dimg || (H % 2 == 0 && W % 2 == 0));       // the parity-class data gradient: checked before anything is enqueued
     hipStream_t sw = s;
     if (fork && fork->side) {
         if (hipEventRecord(fork->ready, s) != hipSuccess || hipStreamWaitEvent(fork->side, fork->ready, 0) != hipSuccess) return PIVP_ERR_LAUNCH;
@@ -1126,7 +1127,6 @@ int enc0_bwd(const float* img, const float* w, const float* d, float* dw, float*
     hipLaunchKernelGGL(enc0_wgrad_kernel, dim3(blocks), dim3(256), 0, sw, img, d, dw, db, B, H, W);
     if (fork && fork->side && hipEventRecord(fork->done, fork->side) != hipSuccess) return PIVP_ERR_LAUNCH;
     if (dimg) {
-        PIVP_CHECK_ARG(H % 2 == 0 && W % 2 == 0);
         const long tp = (long)B * (H / 2) * (W / 2);           // pixels per parity class, 64 per block
         hipLaunchKernelGGL(enc0_dgrad_kernel, dim3((unsigned)((tp + 63) / 64), 4), dim3(256), 0, s, d, w, dimg, dimg_accum, B, H, W);
     }

@@ -348,7 +348,11 @@ long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin,
 
 }  // namespace pivp
 
-extern "C" int pivp_abi_version(void) { return 8; }   // 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
+#ifndef PIVP_BUILD_DIGEST
+#define PIVP_BUILD_DIGEST "unstamped"      // a build that did not go through build.py: _lib.load() refuses it
+#endif
+extern "C" const char* pivp_build_digest(void) { return PIVP_BUILD_DIGEST; }
+extern "C" int pivp_abi_version(void) { return 9; }   // 9: + pivp_build_digest, pivp_grad_sum_shards; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
 
 extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                              const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream) {
@@ -547,6 +551,9 @@ extern "C" int pivp_adam_step(float* p, const float* g, float* m, float* v, long
 }
 extern "C" int pivp_grad_pack_bf16(const float* src, void* dst_bf16, long long n, void* stream) {
     return grad_pack_bf16(src, dst_bf16, (long)n, (hipStream_t)stream);
+}
+extern "C" int pivp_grad_sum_shards(const void* src, int src_bf16, int nshards, long long shard_len, void* dst, int dst_bf16, void* stream) {
+    return grad_sum_shards(src, src_bf16, nshards, (long)shard_len, dst, dst_bf16, (hipStream_t)stream);
 }
 extern "C" int pivp_grad_unpack_bf16(const void* src_bf16, float* dst, long long n, void* stream) {
     return grad_unpack_bf16(src_bf16, dst, (long)n, (hipStream_t)stream);

@@ -183,6 +183,7 @@ int adam_step(float* p, const float* g, float* m, float* v, long n, double lr_t,
               double gscale, hipStream_t s);
 int grad_pack_bf16(const float* src, void* dst, long n, hipStream_t s);     // fp32 -> bf16 (RNE): the all-reduce payload of config 3
 int grad_unpack_bf16(const void* src, float* dst, long n, hipStream_t s);   // bf16 -> fp32, into the flat gradient buffer
+int grad_sum_shards(const void* src, int src_bf16, int nsh, long len, void* dst, int dst_bf16, hipStream_t s);   // sum of nsh peer shards in fp32, rounded once
 
 // ---- backward of the heads / trunk ends (csrc/backward_heads.hip) ----
 int scaled_diff(const float* a, const float* b, float* out, long n, float scale, int accum, hipStream_t s);

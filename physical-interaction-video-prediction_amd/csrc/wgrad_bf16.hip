@@ -416,7 +416,18 @@ int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s) {
     // the sweep's t = 0 launches, sequences too short to batch).  PIVP_WGB_KERNEL = 5 / 25 forces one of them (tuning).
     static const int kernel = [] { const char* e = getenv("PIVP_WGB_KERNEL"); return e ? atoi(e) : 0; }();
     if (kernel == 25 || (kernel != 5 && d.tcount > 1)) return launch_wgrad25(d, s);
-    PIVP_CHECK_ARG(d.tcount <= 1);                                                      // (that kernel takes one timestep)
+    if (d.tcount > 1) {      // PIVP_WGB_KERNEL=5 with a batched descriptor: the kernel-row kernel takes one timestep, so one launch per timestep
+        for (int j = 0; j < d.tcount; ++j) {
+            WgradDesc dj = d;
+            dj.tcount = 1;
+            dj.x0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d.x0) + j * d.ts_x0);
+            if (d.x1) dj.x1 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d.x1) + j * d.ts_x1);
+            dj.dy = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d.dy) + j * d.ts_dy);
+            const int rc = wgrad5x5_bf16(dj, s);
+            if (rc != PIVP_OK) return rc;
+        }
+        return PIVP_OK;
+    }
     constexpr int lds_bytes = G_BYTES + X_BYTES;
     static PerDeviceOnce once16, once8;
     if (pivp_ensure_dyn_lds(once16, reinterpret_cast<const void*>(&wgrad5x5_bf16_kernel<16>), lds_bytes) != PIVP_OK ||

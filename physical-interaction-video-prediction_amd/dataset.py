@@ -130,7 +130,16 @@ class DeviceFeeder(object):
 
     Slot reuse: the copy into a slot's DEVICE buffers waits for an event recorded on the caller's stream when the batch AFTER the
     slot's previous occupant was handed out (its step is enqueued before that), the write into its PINNED buffers for the event of
-    its previous copy."""
+    its previous copy.
+
+    INVARIANT the caller keeps (train.py does): `get()` returns the slot's OWN device buffers -- `Model.__call__` keeps their addresses,
+    it does not copy -- and they are overwritten by the copy stream once the `get()` after next has run.  So every kernel that reads
+    a batch must have been enqueued on, or joined into, the stream that is current at the following `get()`: `Model.__call__` /
+    `Model.backward` / `Adam.update` satisfy that (the plan's side stream is joined into the caller's stream before
+    `pivp_rollout_backward` returns, the all-reduce's stream before `update` returns).  A caller that runs the model on ANOTHER stream
+    than the one current at `get()`, or that catches a failed `update()` and carries on, must `clone()` the batch (or synchronise the
+    device) before it asks for the next but one.  `tests/test_gpu_pipeline.py::test_device_feeder_matches_the_synchronous_loop` runs the
+    fed loop against the synchronous one."""
 
     def __init__(self, iterator, rank=0, world=1, device='cuda:0'):
         import torch

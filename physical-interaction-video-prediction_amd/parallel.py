@@ -4,6 +4,8 @@ call this wraps).
 
 On MI355X the backend is "nccl" (= RCCL over xGMI); the same code runs with "gloo" on CPU tensors, which is how the
 host logic -- including the overlapped, per-group path -- is tested without a GPU (tests/test_parallel_gloo.py)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -15,16 +17,40 @@ class GradAllReduce(object):
     the default of 4 buckets of ~9 MB each lets the first slices travel while the tail of backward still runs when the
     caller invokes `allreduce_range` per finished region (the plan fills gradients back-to-front)."""
 
-    def __init__(self, group=None, nbuckets=4, defer_side_wait=True, payload='auto'):
+    def __init__(self, group=None, nbuckets=4, defer_side_wait=True, payload='auto', algo='auto'):
         """payload: what travels in the overlapped all-reduce (`backward_and_allreduce`).  'fp32' = the flat gradient buffer itself
         (36.9 MB per step at 64x64).  'bf16' = every announced group slice is rounded to bf16 into a send buffer on the collective's
-        stream (one HIP launch), the bf16 buffer is all-reduced (18.4 MB) and the sum is written back into the fp32 flat buffer,
+        stream (one HIP launch), the bf16 image travels (18.4 MB) and the sum is written back into the fp32 flat buffer,
         which stays the optimizer's input ("bf16 payload + fp32 master accumulation").  'auto' (default) = 'bf16'
-        for a model in the bf16 precision mode (BASELINE.json config 3), 'fp32' otherwise; pass 'fp32' to opt out."""
+        for a model in the bf16 precision mode (BASELINE.json config 3), 'fp32' otherwise; pass 'fp32' to opt out.
+
+        algo: how a group slice is summed over the ranks.
+          'allreduce'  one `dist.all_reduce(SUM)` per slice.  With a bf16 payload the REDUCTION ITSELF then runs in bf16 inside RCCL /
+                       gloo: the running sum is rounded to 8 significant bits at every hop of the ring (N - 1 roundings, about 2^-9
+                       relative each), and "fp32 accumulation" holds only for the buffer the result is written into afterwards.
+          'rs_ag'      SURVEY.md 5's all-links schedule: `all_to_all_single` of the slice cut into N shards (rank r receives shard r of
+                       every peer, each over its own xGMI link -- the mesh is point-to-point, so all 7 links of a GPU carry 1/N of the
+                       slice at once instead of a ring's one neighbour), the N received shards summed locally IN FP32 in rank order and
+                       rounded ONCE to the payload type (one HIP launch, `pivp_grad_sum_shards`), then `all_gather_into_tensor` of the
+                       reduced shards.  Every shard is reduced by exactly one rank, so all ranks end with identical bytes, and a bf16
+                       payload carries one rounding of the exact-in-fp32 sum instead of N - 1.  Same bytes per link as a ring
+                       all-reduce: 2 (N - 1) / N of the slice.
+          'auto'       (default) 'rs_ag' for a bf16 payload, 'allreduce' for fp32 (RCCL's own fp32 sum has nothing to gain in
+                       accuracy); the environment variable PIVP_ALLREDUCE_ALGO overrides 'auto' only."""
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         if payload not in ('auto', 'fp32', 'bf16'):
             raise ValueError("payload must be 'auto', 'fp32' or 'bf16'")
+        if algo not in ('auto', 'allreduce', 'rs_ag'):
+            raise ValueError("algo must be 'auto', 'allreduce' or 'rs_ag'")
+        if algo == 'auto':
+            env = os.environ.get('PIVP_ALLREDUCE_ALGO', 'auto')
+            if env not in ('auto', 'allreduce', 'rs_ag'):
+                raise ValueError("PIVP_ALLREDUCE_ALGO must be 'auto', 'allreduce' or 'rs_ag', got %r" % env)
+            algo = env
+        self.algo = algo
+        self.last_algo = None       # what the last overlapped backward actually ran: 'allreduce' or 'rs_ag'
+        self._rsag = {}             # group index -> staging buffers of the rs_ag schedule
         self.payload = payload
         self._send = None           # bf16 send buffer, as large as the flat gradient buffer
         self.last_payload_bytes = 0
@@ -88,8 +114,11 @@ class GradAllReduce(object):
         ranges = model.grad_group_ranges()
         cuda = flat.is_cuda
         bf16 = self.payload == 'bf16' or (self.payload == 'auto' and getattr(model, 'precision', 'fp32') == 'bf16')
+        rs_ag = (self.algo == 'rs_ag') or (self.algo == 'auto' and bf16)
+        self.last_algo = 'rs_ag' if rs_ag else 'allreduce'
+        N = self.world_size
         send = None
-        if bf16:
+        if bf16 and not rs_ag:
             if self._send is None or self._send.numel() != flat.numel() or self._send.device != flat.device:
                 self._send = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
             send = self._send
@@ -107,6 +136,34 @@ class GradAllReduce(object):
         if defer:
             model.set_group_join(False)
 
+        def rsag_buffers(g, n):
+            """stage / recv: N shards of S elements in the payload type (the slice, zero-padded to N * S); red: this rank's reduced shard;
+            full: the gathered result.  S is a multiple of 64 elements, so every shard starts 128-B aligned."""
+            S = ((n + N - 1) // N + 63) // 64 * 64
+            dt = torch.bfloat16 if bf16 else torch.float32
+            buf = self._rsag.get(g)
+            if buf is None or buf['S'] != S or buf['stage'].dtype != dt or buf['stage'].device != flat.device:
+                buf = {'S': S, 'stage': torch.zeros(N * S, dtype=dt, device=flat.device), 'recv': torch.empty(N * S, dtype=dt, device=flat.device),
+                       'red': torch.empty(S, dtype=dt, device=flat.device), 'full': torch.empty(N * S, dtype=dt, device=flat.device)}
+                self._rsag[g] = buf
+            return buf
+
+        def reduce_scatter_gather(g, a, b):
+            """the rs_ag schedule for slice [a, b) on the current stream / thread; returns the all-gather's work handle"""
+            buf = rsag_buffers(g, b - a)
+            S = buf['S']
+            if cuda and bf16:
+                _pack_bf16(flat[a:b], buf['stage'][:b - a], self._stream)
+            else:
+                buf['stage'][:b - a].copy_(flat[a:b])    # fp32 payload: a copy; host tensors (gloo tests): torch's round-to-nearest-even cast
+            # NCCL work.wait() makes the CURRENT stream wait, not the host: the sum below is enqueued behind the exchange
+            dist.all_to_all_single(buf['recv'], buf['stage'], group=self.group, async_op=True).wait()
+            if cuda:
+                _sum_shards(buf['recv'], N, S, buf['red'], self._stream)
+            else:
+                buf['red'].copy_(buf['recv'].view(N, S).float().sum(0))   # host tensors (gloo tests) only: fp32 sum in rank order, one rounding
+            return dist.all_gather_into_tensor(buf['full'], buf['red'], group=self.group, async_op=True)
+
         def issue(g):
             a, b = ranges[g]
             issued.append(g)
@@ -119,10 +176,16 @@ class GradAllReduce(object):
                 if defer:
                     model.wait_group(g, self._stream)   # ... or on the model's side stream
                 with torch.cuda.stream(self._stream):
+                    if rs_ag:
+                        works.append((g, reduce_scatter_gather(g, a, b)))
+                        return
                     if bf16:
                         _pack_bf16(flat[a:b], send[a:b], self._stream)
                     works.append((g, dist.all_reduce(send[a:b] if bf16 else flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
             else:
+                if rs_ag:
+                    works.append((g, reduce_scatter_gather(g, a, b)))
+                    return
                 if bf16:
                     send[a:b].copy_(flat[a:b])       # host tensors (gloo tests): torch's round-to-nearest-even cast
                 works.append((g, dist.all_reduce(send[a:b] if bf16 else flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
@@ -153,15 +216,20 @@ class GradAllReduce(object):
                 with torch.cuda.stream(self._stream):
                     for g, w in works:
                         w.wait()
+                        a, b = ranges[g]
+                        summed = self._rsag[g]['full'][:b - a] if rs_ag else (send[a:b] if bf16 else None)
                         if bf16:                      # the summed bf16 slice back into the fp32 gradient buffer (the optimizer's input)
-                            a, b = ranges[g]
-                            _unpack_bf16(send[a:b], flat[a:b], self._stream)
+                            _unpack_bf16(summed, flat[a:b], self._stream)
+                        elif summed is not None:
+                            flat[a:b].copy_(summed)
                 main.wait_stream(self._stream)
             else:
                 for g, w in works:
                     w.wait()
-                    if bf16:
-                        a, b = ranges[g]
+                    a, b = ranges[g]
+                    if rs_ag:
+                        flat[a:b].copy_(self._rsag[g]['full'][:b - a])
+                    elif bf16:
                         flat[a:b].copy_(send[a:b])
         if error is not None:
             raise error
@@ -178,56 +246,19 @@ def _pack_bf16(src, dst, stream):
     _lib.check(lib.pivp_grad_pack_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), stream.cuda_stream), 'pivp_grad_pack_bf16')
 
 
+def _sum_shards(recv, nshards, shard_len, out, stream):
+    """out[i] = sum_k recv[k * shard_len + i] accumulated in fp32 in the order k = 0 .. nshards-1, rounded once to out's type
+    (csrc/backward.hip: grad_sum_shards_kernel)."""
+    from . import _lib
+    lib = _lib.load()
+    _lib.check(lib.pivp_grad_sum_shards(recv.data_ptr(), 1 if recv.dtype == torch.bfloat16 else 0, int(nshards), int(shard_len), out.data_ptr(),
+                                        1 if out.dtype == torch.bfloat16 else 0, stream.cuda_stream), 'pivp_grad_sum_shards')
+
+
 def _unpack_bf16(src, dst, stream):
     from . import _lib
     lib = _lib.load()
     _lib.check(lib.pivp_grad_unpack_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), stream.cuda_stream), 'pivp_grad_unpack_bf16')
-
-
-class HostStubModel(object):
-    """CPU stand-in for `Model` with the same training protocol (`_ensure_grads`, `grad_group_ranges`, `cleargrads`,
-    `backward(on_group)`): the gradient of group g is `value * (g + 1)` everywhere.  It lets the data-parallel host logic run
-    under gloo with no GPU: tests/test_parallel_gloo.py and `bench.py --dry`.  `fail_in_group` makes the callback of that group
-    raise, as a failing rank would; `skip_groups` leaves groups unannounced."""
-
-    def __init__(self, sizes=(1000, 300, 70, 5000, 64, 1), value=1.0, fail_in_group=None, skip_groups=(), precision='fp32'):
-        self.precision = precision
-        self.sizes = list(sizes)
-        self.value = float(value)
-        self.fail_in_group = fail_in_group
-        self.skip_groups = set(skip_groups)
-        self._flat_params = torch.zeros(sum(self.sizes))
-        self._flat = torch.zeros(sum(self.sizes))
-        self.announced = []
-
-    def _ensure_grads(self):
-        return self._flat
-
-    def cleargrads(self):
-        self._flat.zero_()
-
-    def grad_group_ranges(self):
-        out, o = [], 0
-        for n in self.sizes:
-            out.append((o, o + n))
-            o += n
-        return out
-
-    def backward(self, on_group=None):
-        errors = []
-        for g, (a, b) in enumerate(self.grad_group_ranges()):
-            self._flat[a:b] += self.value * (g + 1)
-            if on_group is None or g in self.skip_groups:
-                continue
-            self.announced.append(g)
-            try:                                     # like Model.backward: the sweep continues, the first error is raised afterwards
-                if g == self.fail_in_group:
-                    raise RuntimeError('injected failure in group %d' % g)
-                on_group(g)
-            except BaseException as e:               # noqa: B902
-                errors.append(e)
-        if errors:
-            raise errors[0]
 
 
 def shard_batch(arrays, rank, world_size):

@@ -80,6 +80,44 @@ def test_train_checkpoint_resume_predict(pivp, tmp_path):
     assert frames.reshape(3, -1).min(axis=1).tolist() == [0, 0, 0] and frames.reshape(3, -1).max(axis=1).tolist() == [255, 255, 255]
 
 
+def test_device_feeder_matches_the_synchronous_loop(pivp):
+    """dataset.DeviceFeeder hands the model its own reusable device buffers while the copy stream refills the other slot: five
+    optimizer steps fed through it give the losses and the parameters of the synchronous loop (concat_examples + blocking upload per step),
+    bit for bit in the forward (the loss of step k depends on every earlier batch having been read intact)."""
+    from pivp_amd import dataset as ds
+    rs = np.random.RandomState(3)
+    data = [(rs.rand(4, 64, 64, 3).astype(np.float32), (rs.randn(4, 5) * 0.1).astype(np.float32), (rs.randn(4, 5) * 0.1).astype(np.float32))
+            for _ in range(7)]
+    P = R.init_params(seed=1, dtype=np.float64, scale=1.0)
+
+    def run(fed):
+        m = pivp.Model(10, prefix='f', keep_activations=True)
+        m.load_state_dict_reference(P)
+        opt = pivp.Adam(alpha=1e-3).setup(m)
+        it = ds.SerialIterator(data, 2, repeat=True, shuffle=False)
+        feeder = ds.DeviceFeeder(it, device='cuda:0') if fed else None
+        losses = []
+        for k in range(5):
+            if fed:
+                x, _, _ = feeder.get()
+            else:
+                x = list(pivp.concat_examples(it.next()))
+            loss = opt.update(m, x, k)
+            if fed:
+                feeder.prefetch()                  # the refill of the OTHER slot runs under this step
+            losses.append(loss.clone())            # no host synchronisation inside the loop: the copy stream really overlaps the steps
+            m.reset_state()
+        torch.cuda.synchronize()
+        return [float(l) for l in losses], m._flat_params.clone()
+
+    l_sync, p_sync = run(False)
+    l_fed, p_fed = run(True)
+    assert l_fed[0] == l_sync[0]                                   # same first forward, bit for bit
+    assert np.allclose(l_fed, l_sync, rtol=1e-5, atol=0)           # later steps: weight-gradient atomics reorder fp32 sums
+    assert torch.allclose(p_fed, p_sync, rtol=0, atol=2e-5)
+    assert len(set(l_sync)) == 5
+
+
 def test_bench_two_ranks_rehearsal_on_one_gpu(pivp):
     """`python bench.py --gpus 2` as the driver types it, except that both ranks share this box's one GPU (--share-gpu, gloo): the
     launcher, the rank bookkeeping, both legs with real kernels and the data-parallel step with its overlapped all-reduce."""
@@ -96,3 +134,5 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(pivp):
     tr = out['train']
     assert tr['rccl_ranks'] == 2 and tr['backend'] == 'gloo' and tr['ms_per_step'] > 0 and tr['ms_per_step_without_allreduce'] > 0
     assert np.isfinite(tr['loss']) and np.isfinite(out['config']['loss'])
+    assert tr['allreduce_algo'] == 'allreduce' and out['train_bf16']['allreduce_algo'] == 'rs_ag'      # fp32 payload: ring; bf16 payload: all-links, fp32 local sum
+    assert set(out['train_bf16']['allreduce_algo_ms_per_step']) == {'allreduce', 'rs_ag'}

@@ -325,15 +325,46 @@ def test_bf16_gradient_payload_kernels_and_single_rank_path(pivp):
         dp.backward_and_allreduce(m, force_overlap=True)
         torch.cuda.synchronize()
         got = m._ensure_grads()
-        assert dp.last_payload_bytes == 2 * got.numel()
+        assert dp.last_payload_bytes == 2 * got.numel() and dp.last_algo == 'rs_ag'   # the all-links schedule is the bf16 payload's default
         assert torch.equal(got, got.to(torch.bfloat16).float())                       # every value is a bf16 number
         assert torch.allclose(got, ref, rtol=2.0 ** -7, atol=1e-7)                     # ... within bf16 rounding of the fp32 gradient
+        ring = pivp.GradAllReduce(payload='bf16', algo='allreduce')                   # the plain all-reduce of the bf16 image stays available
+        m.cleargrads(); ring.backward_and_allreduce(m, force_overlap=True); torch.cuda.synchronize()
+        assert ring.last_algo == 'allreduce' and torch.allclose(m._ensure_grads(), ref, rtol=2.0 ** -7, atol=1e-7)
+        rs32 = pivp.GradAllReduce(payload='fp32', algo='rs_ag')                        # ... and rs_ag takes an fp32 payload too
+        m.cleargrads(); rs32.backward_and_allreduce(m, force_overlap=True); torch.cuda.synchronize()
+        assert rs32.last_algo == 'rs_ag' and rs32.last_payload_bytes == 4 * got.numel()
+        assert torch.allclose(m._ensure_grads(), ref, rtol=1e-4, atol=1e-7)
         auto = pivp.GradAllReduce()                                                   # 'auto' on an fp32 model keeps the fp32 payload
         m.cleargrads(); auto.backward_and_allreduce(m, force_overlap=True); torch.cuda.synchronize()
         assert auto.last_payload_bytes == 4 * got.numel()
         assert torch.allclose(m._ensure_grads(), ref, rtol=1e-4, atol=1e-7)
     finally:
         dist.destroy_process_group()
+
+
+def test_grad_sum_shards_kernel_is_one_rounding_of_the_fp32_sum(pivp):
+    """pivp_grad_sum_shards (the local half of GradAllReduce(algo='rs_ag')): N peer shards summed in fp32 in shard order, rounded once;
+    all four input / output type pairs, bit for bit against torch."""
+    from pivp_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    rs = np.random.RandomState(11)
+    for nsh, S in ((8, 64 * 37), (2, 64), (5, 64 * 1001), (1, 128)):
+        src32 = torch.from_numpy((rs.standard_normal(nsh * S) * np.exp(rs.uniform(-6, 6, nsh * S))).astype(np.float32)).cuda()
+        for in_bf16 in (1, 0):
+            src = src32.to(torch.bfloat16) if in_bf16 else src32
+            acc = torch.zeros(S, dtype=torch.float32, device='cuda')
+            for k in range(nsh):                                   # fixed order, fp32 accumulate
+                acc = acc + src[k * S:(k + 1) * S].float()
+            for out_bf16 in (1, 0):
+                out = torch.empty(S, dtype=torch.bfloat16 if out_bf16 else torch.float32, device='cuda')
+                assert lib.pivp_grad_sum_shards(src.data_ptr(), in_bf16, nsh, S, out.data_ptr(), out_bf16, st) == 0
+                want = acc.to(torch.bfloat16) if out_bf16 else acc
+                assert torch.equal(out, want), (nsh, S, in_bf16, out_bf16)
+    x = torch.zeros(64, device='cuda')
+    assert lib.pivp_grad_sum_shards(x.data_ptr(), 0, 2, 30, x.data_ptr(), 0, st) == -1      # shard length not a multiple of 4: refused
+    assert lib.pivp_grad_sum_shards(x.data_ptr(), 1, 2, 4, x.data_ptr(), 1, st) == -1       # bf16 shards must start 16-B aligned
 
 
 def test_bptt_gradients_128x128(pivp):

@@ -24,7 +24,25 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), 'libpivp_hip.so does not export %s' % name
     assert declared == set(_lib.SIGNATURES), 'ctypes table and header disagree: %s' % (declared ^ set(_lib.SIGNATURES))
-    assert _lib.load().pivp_abi_version() == 8
+    assert _lib.load().pivp_abi_version() == 9
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """_lib.load() compares the digest embedded in libpivp_hip.so (pivp_build_digest) with the digest of the sources shipped next to it:
+    a library built from other sources must raise, never run (a forgotten rebuild would have tested stale code)."""
+    import __graft_entry__ as g
+    g.build()
+    from pivp_amd import _digest
+    lib = _lib.load()
+    assert lib.pivp_build_digest().decode() == _digest.source_digest() and len(_digest.source_digest()) == 64
+    files = [os.path.basename(f) for f in _digest.source_files()]
+    assert 'pivp_hip.h' in files and 'igemm_f32.hip' in files and not [f for f in files if f.endswith('.o') or f.endswith('.so')]
+    monkeypatch.setattr(_lib, '_lib', None)                         # force a fresh load ...
+    monkeypatch.setattr(_digest, 'source_digest', lambda: 'f' * 64)  # ... against sources that differ from what was compiled
+    with pytest.raises(RuntimeError, match='stale'):
+        _lib.load()
+    monkeypatch.undo()
+    assert _lib.load().pivp_abi_version() == 9
 
 
 def test_plan_param_table_matches_reference_keys():
