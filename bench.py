@@ -64,7 +64,7 @@ def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--config', type=int, default=None, choices=[2, 3, 4, 5],
-                    help="preset of a BASELINE.json config (index into its `configs`; per-GPU batch 32 throughout): 2 = the default "
+                    help="preset of a BASELINE.json config, numbered from 1 as VERDICT / DESIGN do (config N = `configs[N-1]`; per-GPU batch 32 throughout): 2 = the default "
                          "(CDNA 64x64 T=10 fp32 rollout), 3 = --precision bf16 --mode train (at --gpus 8: global batch 256), 4 = --model STP, "
                          "5 = --size 128 --seq-len 20.  Explicit flags given after it still win.")
     ap.add_argument('--steps', type=int, default=20)
@@ -399,7 +399,7 @@ def main(argv=None):
         preset = ''
         if args.config is not None:     # name the BASELINE.json config this run is (one rank's share of it when it is quoted at 8 GPUs)
             share = '' if args.config not in (3, 5) or world == 8 else "; this run: %d of its 8 ranks' shares" % world
-            preset = 'BASELINE.json configs[%d] (%s%s): ' % (args.config, CONFIG_PRESETS[args.config][1], share)
+            preset = 'BASELINE.json config %d = configs[%d] (%s%s): ' % (args.config, args.config - 1, CONFIG_PRESETS[args.config][1], share)
         out = {
             'metric': 'predicted frames/sec (%dx%dx3, %d-step rollout)' % (S, S, T),
             'value': round(frames / elapsed, 1) if not dry else 0.0,
