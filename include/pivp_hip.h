@@ -38,7 +38,7 @@ extern "C" {
 #define PIVP_PRECISION_BF16 1
 #define PIVP_PRECISION_BF16X3 2
 
-int pivp_abi_version(void);   /* 9 (9: + pivp_build_digest, pivp_grad_sum_shards; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+int pivp_abi_version(void);   /* 9 (9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
                                  5: + bf16 ConvLSTM, pivp_plan_set_precision, 6: + pivp_plan_set_group_join / pivp_plan_group_wait) */
 
 /* sha256 (hex) of the sources this library was compiled from (every .hip and .h under csrc/, and this header), embedded by build.py.  The Python
@@ -326,6 +326,33 @@ int pivp_stp_params(const float* hidden5, const float* wt1, const float* b1, con
 int pivp_composite(const float* prev, const float* mask_logits, const float* layer0, const float* aux, float* out,
                    float* masks_out, int B, int H, int W, int num_masks, int model_type, int stp_zero_border,
                    void* stream);
+
+/* The output side of one timestep in ONE launch: relu(norm_enc6(raw enc6)) (TM:601) -> mask logits + enc7 (TM:718-719, TM:315-317 /
+ * 454-455 / 387-388) -> the motion head's finisher on the K-slice partial sums of its Linear (TM:321-329 CDNA kernels / TM:458-468 STP
+ * parameters) -> flat softmax + transform + compositing (TM:720-728).  Bit-identical to pivp_heads + pivp_cdna_kernels / pivp_stp_params +
+ * pivp_composite, without the logit / enc7 / layer0 round trip through HBM and two launches fewer; the plan's forward step uses it whenever
+ * pivp_frame_head_fits.  Optional outputs may be null.  partials == null: `aux` holds finished kernels [B][num_masks][25] / theta [B][6]. */
+typedef struct pivp_frame_head_args {
+    const float* e6raw;            /* [B][H*W][64] NHWC, raw output of enc6                                             */
+    const float* ln_part; int ln_nparts;   /* its (count, mean, M2, -) LayerNorm partials, ln_nparts per sample           */
+    const float* gamma; const float* beta; float ln_eps;   /* norm_enc6, NHWC-flat                                        */
+    const float* masks_w; const float* masks_b;            /* [64][num_masks+1], [num_masks+1]                            */
+    const float* enc7_w; const float* enc7_b;              /* [64][3 | 25], [3 | 25]                                      */
+    const float* prev;             /* previous frame, planar [B][3][H*W]                                                  */
+    const float* partials; int kslices; const float* head_bias;   /* pivp_motion_partials output [B][kslices][256], Linear bias */
+    const float* w2; const float* b2;      /* STP: identity_params/W (6,100), /b (6)                                      */
+    const float* aux;
+    float* out;                    /* next frame, planar [B][3][H*W]                                                      */
+    float* masks_out;              /* optional softmaxed masks [B][num_masks+1][H*W]                                      */
+    float* enc7;                   /* [B][3 | 25][H*W]                                                                    */
+    float* logits_out; float* layer0_out; float* enc6_out; float* stat_out;   /* optional: what a training plan keeps for BPTT */
+    float* kerns_out; float* vpre_out;     /* optional: finished kernels / theta; the Linear's pre-activation [B][256]    */
+    int B, H, W, num_masks, model_type, stp_zero_border;
+} pivp_frame_head_args_t;
+int pivp_frame_head_fits(int model_type, int B, int H, int W, int num_masks, int K);   /* 1: supported, finisher included; 2: supported with
+                                                                                          finished kernels in `aux`; 0: not supported */
+int pivp_motion_partials(const float* hidden5, const float* wt, float* partials, int B, int K, int fp64_accumulate, void* stream);
+int pivp_frame_head(const pivp_frame_head_args_t* args, void* stream);
 
 /* F.resize_images(frame, (Hout, Wout)) of the predict path (predict_model.py:119-122): bilinear, align-corners sample grid,
  * planar [planes][Hin][Win] -> [planes][Hout][Wout], result multiplied by `scale` (1/255 there). */

@@ -20,6 +20,15 @@ class PivpConfig(ctypes.Structure):
                 ('ln_eps', _f), ('stp_zero_border', _i)]
 
 
+class PivpFrameHeadArgs(ctypes.Structure):
+    _fields_ = [('e6raw', _vp), ('ln_part', _vp), ('ln_nparts', _i), ('gamma', _vp), ('beta', _vp), ('ln_eps', _f),
+                ('masks_w', _vp), ('masks_b', _vp), ('enc7_w', _vp), ('enc7_b', _vp), ('prev', _vp),
+                ('partials', _vp), ('kslices', _i), ('head_bias', _vp), ('w2', _vp), ('b2', _vp), ('aux', _vp),
+                ('out', _vp), ('masks_out', _vp), ('enc7', _vp),
+                ('logits_out', _vp), ('layer0_out', _vp), ('enc6_out', _vp), ('stat_out', _vp), ('kerns_out', _vp), ('vpre_out', _vp),
+                ('B', _i), ('H', _i), ('W', _i), ('num_masks', _i), ('model_type', _i), ('stp_zero_border', _i)]
+
+
 # name -> (restype, argtypes); every symbol include/pivp_hip.h declares
 SIGNATURES = {
     'pivp_abi_version': (_i, []),
@@ -91,6 +100,9 @@ SIGNATURES = {
     'pivp_linear_scratch_floats': (_ll, [_i, _i]),
     'pivp_cdna_kernels': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pivp_stp_params': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'pivp_frame_head_fits': (_i, [_i, _i, _i, _i, _i, _i]),
+    'pivp_motion_partials': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pivp_frame_head': (_i, [_c.POINTER(PivpFrameHeadArgs), _vp]),
     'pivp_composite': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'pivp_resize_images': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'pivp_select_frames': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),

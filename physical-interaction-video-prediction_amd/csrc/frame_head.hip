@@ -1,0 +1,500 @@
+// frame_head: the output side of one timestep in ONE launch (round 4).
+//   masks = relu(Deconv1x1(enc6)) and enc7 = Deconv1x1(enc6) with the variant's activation     (TM:718-719, TM:315-317 / 454-455 / 387-388)
+//   on enc6 = relu(LayerNorm(raw enc6)) (norm_enc6, TM:601), applied while the tile is staged,
+//   the motion head's finisher: CDNA kernels = normalise(relu(Linear(hidden5) - eps) + eps) (TM:326-329) or the STP parameters
+//   (TM:458-468), from the K-slice partial sums of skinny_linear_partials_kernel (heads.hip),
+//   and the flat-(num_masks+1) softmax + transform + compositing of the next frame              (TM:720-728 with TM:341-349 / 469-470 / 392-415).
+// Before: heads_1x1_kernel -> skinny_linear_partials_kernel -> *_finish_kernel -> composite_kernel, four launches and a round trip of the
+// 14 logit / enc7 / layer0 planes through HBM per timestep (425 us of a config-2 rollout).  Now the partial sums are the only launch in
+// front of this one.
+//
+// Block = one sample x FH_TR image rows.  The flat softmax groups of a band reach NP - 1 elements past either end of the band IN THE
+// FLAT [plane][pixel] ORDER (TM:720-722 reshapes the NCHW tensor to (-1, NP)): for plane m these are the NP - 1 pixels in front of /
+// behind the band, and at the first / last band of a sample the last pixels of plane m - 1 / the first pixels of plane m + 1.  So the
+// block computes the 1x1 mixes for its band plus a "halo tile" of 2 (NP - 1) wrapped pixels (<= 22 pixels of 64-channel recompute per
+// 256-pixel band) and files each halo logit under the plane whose window it belongs to.  The arithmetic of every output is that of the
+// separate kernels, in the same order: the fused frame is BIT-IDENTICAL to heads_1x1 + cdna_kernels / stp_params + composite
+// (tests/test_gpu_ops.py::test_frame_head_matches_the_separate_kernels).
+//
+// Each WAVE owns 64 consecutive pixels per tile, loads them with coalesced 16-B loads, applies the LayerNorm, and turns "lane = 4
+// channels of a pixel" into "lane = pixel" through a private LDS tile -- 32 channels at a time (two passes), so that the wave tiles
+// are 37 KB instead of 70 and two blocks share a CU.  The group maxima of the compositing phase reuse that space.
+#include "pivp_kernels.h"
+
+namespace pivp {
+
+constexpr int FH_TR = 4;              // image rows per block (composite_kernel: 4 rows 12.2 us, 8 rows 14.3, 2 rows 14.2 at 64 x 64)
+constexpr int FH_XP = 36;             // floats per pixel row of the transposition tile (144 B: conflict-free per-lane ds_read_b128)
+constexpr int FH_TILE = 64 * FH_XP;   // floats per wave tile
+constexpr int FH_KL = 11 * 28;        // CDNA kernel table [11][28]
+constexpr int FH_MAXKS = 128;         // most K slices the in-kernel finisher takes (every block of a sample re-reads its KS x 1 KB of partial sums)
+constexpr int FH_HW = 4;              // waves per block: at 64-wide frames a band is four 64-pixel tiles + the halo tile (wave 0 takes it second)
+constexpr int FH_NT = 64 * FH_HW;     // 256 threads x 256 registers: two blocks per CU wherever the dispatcher puts their waves
+
+#ifdef PIVP_FH_STAMPS   // phase stamps (constant-rate 100 MHz counter) of block (3, 5): [wave][slot]; scripts/r04/fh_stamps.py
+__device__ long long pivp_fh_stamps[8 * 16];
+#define FH_STAMP(i) do { if (blockIdx.x == 3 && blockIdx.y == 5 && (threadIdx.x & 63) == 0) pivp_fh_stamps[(threadIdx.x >> 6) * 16 + (i)] = (long long)wall_clock64(); } while (0)
+#else
+#define FH_STAMP(i)
+#endif
+
+// Block shape, as measured (scripts/r04/fh_stamps.py, profiles/r04/NOTES.md): the first versions ran five heads waves + a side wave for the
+// finisher at 168 registers (three waves per SIMD): ONE such block was resident per CU -- 62 us per launch for 30 us per block -- and
+// every spill reload inside the multiply loop waited, through its vmcnt(0), for the whole prefetch in flight (pass 0: 6.3 us, pass 1
+// with no prefetch behind it: 2.1).  Four waves with 256 registers each: no spills, and two blocks fit a CU whatever SIMDs their waves get.
+template <int MODE>   // 0 CDNA, 1 STP, 2 DNA
+__global__ __launch_bounds__(FH_NT, 2) void frame_head_kernel(const FrameHeadArgs a) {
+    constexpr int NE = MODE == 2 ? 25 : 3;
+    constexpr int MAXO = MODE == 2 ? 2 + 25 : 12 + 3;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.H, W = a.W, HW = H * W, NM = a.NM, NP = NM + 1, NO = NP + NE;
+    const int b = blockIdx.y, y0 = blockIdx.x * FH_TR;
+    const int p0 = y0 * W, np = FH_TR * W;
+    const int hn = NP - 1;
+    const int win = np + 2 * hn;
+    const int G = np / NP + 2;
+    const int PW = W + 4;
+    // ---- LDS carve -----------------------------------------------------------------------------------------------------------
+    float* wl = sm;                              // [MAXO][64] + [MAXO] bias (padded to 16)
+    float* bl = wl + MAXO * 64;
+    float* lg = bl + 16 * ((MAXO + 15) / 16);    // [NP][win] mask logits of the band's windows
+    float* l0t = lg + ((NP * win + 3) & ~3);     // [3][np] sigmoid(enc7) (CDNA / STP)
+    float* kl = l0t + (MODE == 2 ? 0 : 3 * np);  // [11][28] CDNA kernels
+    float* vs = kl + FH_KL;                      // [256] finisher scratch
+    float* th = vs + 256;                        // [8] STP theta
+    float* prevt = th + 8;                       // [3][FH_TR + 4][PW] previous-frame tile with its 2-pixel halo
+    float* un = prevt + ((3 * (FH_TR + 4) * PW + 3) & ~3);   // union: FH_HW transposition tiles | (gmx, ginv)
+    float* gmx = un;
+    float* ginv = gmx + NP * G;
+    const unsigned magic = 0xFFFFFFFFu / (unsigned)NP + 1u;     // exact x / NP for x * NP < 2^32
+    auto div_np = [&](int x) { return (int)__umulhi((unsigned)x, magic); };
+    const float* pb = a.prev + (size_t)b * 3 * HW;
+    const int ntile = np / 64 + 1;               // band tiles + the halo tile
+    FH_STAMP(0);
+
+    // ---- heads: the first pass's loads (e6, gamma, beta: 24 float4 per lane) go out first of all --------------------------------------
+    const float* eb = a.e6raw + (size_t)b * HW * 64;
+    float* yb = a.y_out ? a.y_out + (size_t)b * HW * 64 : nullptr;
+    float* mt = un + wave * FH_TILE;
+    // pixel (inside the sample) of slot pl of tile t; halo slots: [0, hn) = the hn pixels in front of the band, [hn, 2 hn) = behind it, wrapped
+    auto pix_of = [&](int t, int pl) -> int {
+        if (t != ntile - 1) return p0 + t * 64 + pl;
+        int raw = pl < hn ? p0 - hn + pl : p0 + np + (pl - hn);
+        if (pl >= 2 * hn) raw = p0;
+        return raw < 0 ? raw + HW : raw >= HW ? raw - HW : raw;
+    };
+    f32x4 rx[8], rg[8], rb[8];
+    auto issue = [&](int t, int hh) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int f = lane + 64 * j;
+            const size_t gi = (size_t)pix_of(t, f >> 3) * 64 + hh * 32 + (f & 7) * 4;
+            rx[j] = *reinterpret_cast<const f32x4*>(eb + gi);
+            rg[j] = *reinterpret_cast<const f32x4*>(a.gamma + gi);
+            rb[j] = *reinterpret_cast<const f32x4*>(a.beta + gi);
+        }
+    };
+    issue(wave, 0);                              // (wave < ntile always: ntile >= 2, and a band of one tile still has its halo tile)
+
+    // ---- weights of the 1x1 mixes and the previous-frame tile: every thread's loads go out before its first LDS store (a loop of
+    // lds[i] = g[i] compiles to one L2 round trip per element: an early version of this kernel spent 26 of them on the frame tile) ----
+    {
+        constexpr int WIT = (64 * MAXO + FH_NT - 1) / FH_NT;
+        float wv[WIT];
+#pragma unroll
+        for (int u = 0; u < WIT; ++u) {
+            const int i = min(tid + FH_NT * u, 64 * NO - 1);
+            const int k = i / NO, o = i - k * NO;
+            wv[u] = o < NP ? a.wm[k * NP + o] : a.we[k * NE + (o - NP)];
+        }
+        const float bv = tid < NO ? (tid < NP ? a.bm[tid] : a.be[tid - NP]) : 0.f;
+        const int ptot = MODE != 1 ? 3 * (FH_TR + 4) * PW : 0, prow_n = (FH_TR + 4) * PW;
+        for (int base = 0; base < ptot; base += 8 * FH_NT) {
+            float pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(base + tid + FH_NT * u, ptot - 1);
+                const int c = i / prow_n, rem = i - c * prow_n;
+                const int r = rem / PW, x = rem - r * PW;
+                const int iy = min(max(y0 + r - 2, 0), H - 1), ix = min(max(x - 2, 0), W - 1);
+                pv[u] = pb[(size_t)c * HW + iy * W + ix];          // clamped address, zeroed below: no predicate around the load
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + tid + FH_NT * u;
+                if (i < ptot) {
+                    const int c = i / prow_n, rem = i - c * prow_n;
+                    const int r = rem / PW, x = rem - r * PW;
+                    const int iy = y0 + r - 2, ix = x - 2;
+                    prevt[i] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? pv[u] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < WIT; ++u) {
+            const int i = tid + FH_NT * u;
+            if (i < 64 * NO) { const int k = i / NO, o = i - k * NO; wl[o * 64 + k] = wv[u]; }
+        }
+        if (tid < NO) bl[tid] = bv;
+    }
+    FH_STAMP(1);
+    float mean, rstd;
+    ln_merge_partials(a.ln_part, b, a.ln_nparts, a.eps, mean, rstd);
+    if (a.stat_out && blockIdx.x == 0 && tid == 0) { a.stat_out[b * 2] = mean; a.stat_out[b * 2 + 1] = rstd; }
+    FH_STAMP(2);
+    __syncthreads();          // (1) weight table in place
+    FH_STAMP(3);
+
+    // ---- heads: one 64-pixel tile per wave and turn, 32 channels per pass; the loads of pass i + 1 are in flight while pass i is multiplied ----
+    {
+        float acc[MAXO];
+        for (int t = wave; t < ntile; t += FH_HW) {
+            const bool halo = t == ntile - 1;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                // LayerNorm + ReLU of the pass in registers, into the wave's transposition tile
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int f = lane + 64 * j;
+                    f32x4 v = rx[j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf((v[e] - mean) * rstd * rg[j][e] + rb[j][e], 0.f);
+                    if (yb && !halo) *reinterpret_cast<f32x4*>(yb + (size_t)pix_of(t, f >> 3) * 64 + hh * 32 + (f & 7) * 4) = v;
+                    *reinterpret_cast<f32x4*>(mt + (f >> 3) * FH_XP + (f & 7) * 4) = v;
+                }
+                FH_STAMP(4 + 2 * hh);
+                // the next pass's loads: the other half of this tile, or the first half of the wave's next tile
+                if (hh == 0) issue(t, 1);
+                else if (t + FH_HW < ntile) issue(t + FH_HW, 0);
+                float xr[32];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(mt + lane * FH_XP + q * 4);
+                    xr[q * 4] = v[0]; xr[q * 4 + 1] = v[1]; xr[q * 4 + 2] = v[2]; xr[q * 4 + 3] = v[3];
+                }
+#pragma unroll
+                for (int o = 0; o < MAXO; ++o) {
+                    if (o < NO) {
+                        const float* wo = wl + o * 64 + hh * 32;
+                        float s = hh == 0 ? bl[o] : acc[o];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wo + q * 4);
+                            s = fmaf(xr[q * 4], w4[0], s); s = fmaf(xr[q * 4 + 1], w4[1], s);
+                            s = fmaf(xr[q * 4 + 2], w4[2], s); s = fmaf(xr[q * 4 + 3], w4[3], s);
+                        }
+                        acc[o] = s;
+                    }
+                }
+                FH_STAMP(5 + 2 * hh);
+            }
+            if (!halo) {
+                const int pp = t * 64 + lane, p = p0 + pp;
+#pragma unroll
+                for (int o = 0; o < MAXO; ++o) {
+                    if (o < NP) {
+                        const float v = fmaxf(acc[o], 0.f);
+                        lg[o * win + pp + hn] = v;
+                        if (a.logits_out) a.logits_out[((size_t)b * NP + o) * HW + p] = v;
+                    } else if (o < NO) {
+                        const int oe = o - NP;
+                        float v = acc[o];
+                        if (MODE != 1) v = fmaxf(v, 0.f);
+                        a.enc7[((size_t)b * NE + oe) * HW + p] = v;
+                        if (MODE != 2) {
+                            const float sg = sigmoidf_(v);
+                            l0t[oe * np + pp] = sg;
+                            if (a.layer0_out) a.layer0_out[((size_t)b * NE + oe) * HW + p] = sg;
+                        }
+                    }
+                }
+            } else if (lane < 2 * hn) {
+                // a halo logit of plane o at window position jx belongs to the window of plane o - carry, carry = -1 / +1 where the
+                // flat index wrapped into the previous / next plane
+                const int raw = lane < hn ? p0 - hn + lane : p0 + np + (lane - hn);
+                const int shift = raw < 0 ? 1 : raw >= HW ? -1 : 0;
+                const int jx = lane < hn ? lane : np + lane;
+#pragma unroll
+                for (int o = 0; o < MAXO; ++o) {
+                    if (o < NP) {
+                        const int row = o + shift;
+                        if ((unsigned)row < (unsigned)NP) lg[row * win + jx] = fmaxf(acc[o], 0.f);
+                    }
+                }
+            }
+        }
+    }
+    FH_STAMP(8);
+
+    // ---- the motion head's finisher (fixed summation order: that of sum_partials in heads.hip), by the last wave -- the one with the
+    // fewest tiles -- while wave 0 works on the halo tile.  A lane owns 4 consecutive outputs: its loads are whole 16-B pieces of the 1-KB
+    // partial rows, 32 slices in flight. ------------------------------------------------------------------------------------------------
+    if (MODE != 2 && wave == FH_HW - 1) {
+        if (a.partials) {
+            const int KS = a.KS;
+            const float* prow = a.partials + (size_t)b * KS * 256 + lane * 4;
+            double ch[4][4];                 // [output][chain]: chain c takes slices c, c + 4, ... in increasing order
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ch[e][c] = 0.0;
+            for (int k0 = 0; k0 < KS; k0 += 32) {
+                f32x4 v[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) v[u] = *reinterpret_cast<const f32x4*>(prow + (size_t)(k0 + u) * 256);   // slices past KS: the
+#pragma unroll                                                                                                 // buffer's tail padding, not summed
+                for (int u = 0; u < 32; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ch[e][u & 3] += k0 + u < KS ? (double)v[u][e] : 0.0;
+            }
+            double sum4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum4[e] = (ch[e][0] + ch[e][1]) + (ch[e][2] + ch[e][3]);
+            if (MODE == 0) {
+                const int nout = 25 * NM;
+                float accv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = lane * 4 + e;
+                    accv[e] = 0.f;
+                    if (o < nout) {
+                        const double t = (double)a.hbias[o] + sum4[e];
+                        if (a.vpre_out && blockIdx.x == 0) a.vpre_out[(size_t)b * 256 + o] = (float)t;
+                        accv[e] = fmaxf((float)t - 1e-12f, 0.f) + 1e-12f;
+                    }
+                    vs[o] = accv[e];
+                }
+                // (one wave: its LDS operations complete in order, no barrier needed between the stores above and the loads below)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = lane * 4 + e;
+                    if (o < nout) {
+                        const int g = (o / 25) * 25;
+                        float sum = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 25; ++i) sum += vs[g + i];
+                        const float kv = accv[e] / sum;
+                        kl[(o / 25) * 28 + (o - g)] = kv;
+                        if (a.kerns_out && blockIdx.x == 0) a.kerns_out[(size_t)b * nout + o] = kv;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = lane * 4 + e;
+                    if (o < 100) {
+                        const double t = (double)a.hbias[o] + sum4[e];
+                        vs[o] = fmaxf((float)t, 0.f);
+                        if (a.vpre_out && blockIdx.x == 0) a.vpre_out[(size_t)b * 256 + o] = vs[o];
+                    }
+                }
+                if (lane < 6) {
+                    double t = a.b2[lane];
+                    for (int i = 0; i < 100; ++i) t = fma((double)a.w2[lane * 100 + i], (double)vs[i], t);
+                    const float tv = (float)(t + ((lane == 0 || lane == 4) ? 1.0 : 0.0));
+                    th[lane] = tv;
+                    if (a.kerns_out && blockIdx.x == 0) a.kerns_out[b * 6 + lane] = tv;
+                }
+            }
+        } else if (MODE == 0) {
+            float kv[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {            // 308 table entries: five per lane, all requested before the first store
+                const int i2 = min(lane + 64 * u, FH_KL - 1), k = i2 / 28, e = i2 - k * 28;
+                kv[u] = a.aux[((size_t)b * NM + min(k, NM - 1)) * 25 + min(e, 24)];
+            }
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int i2 = lane + 64 * u, k = i2 / 28, e = i2 - k * 28;
+                if (i2 < FH_KL) kl[i2] = (k < NM && e < 25) ? kv[u] : 0.f;
+            }
+        } else {
+            if (lane < 6) th[lane] = a.aux[(size_t)b * 6 + lane];
+        }
+    }
+    __syncthreads();          // (2) logits, layer0, frame tile, kernels / theta (LDS) and, for DNA, enc7 (global, this block's own stores) complete
+    FH_STAMP(9);
+
+    // ---- per-group max and 1 / sum (groups of NP consecutive flat elements, TM:720-722); the transposition tiles are dead -------------
+    for (int i = tid; i < NP * G; i += FH_NT) {
+        const int m = i / G, gi = i - m * G;
+        const int gfirst = div_np(m * HW + p0);
+        const int glast = div_np(m * HW + p0 + np - 1);
+        if (gfirst + gi <= glast) {
+            const int j0 = (gfirst + gi) * NP - (m * HW + p0 - hn);
+            const float* e = lg + m * win + j0;
+            float ev[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) ev[u] = u < NP ? e[u] : -3.0e38f;
+            float mx = ev[0];
+#pragma unroll
+            for (int u = 1; u < 12; ++u) mx = fmaxf(mx, ev[u]);
+            float sum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 12; ++u) sum += u < NP ? __expf(ev[u] - mx) : 0.f;
+            gmx[i] = mx;
+            ginv[i] = 1.0f / sum;
+        }
+    }
+    __syncthreads();
+    FH_STAMP(10);
+
+    // ---- softmaxed masks, motion transform, blend (the body of composite_kernel, operands from LDS) --------------------------------------
+    for (int pp = tid; pp < np; pp += FH_NT) {
+        const int p = p0 + pp;
+        const int y = p / W, x = p - y * W;
+        const int ry = y - y0;
+        float l0v[3] = {0.f, 0.f, 0.f};
+        if (MODE != 2) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) l0v[c] = l0t[c * np + pp];
+        }
+        float mk[12];
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+            if (m < NP) {
+                const int F = m * HW + p;
+                const int gi = div_np(F) - div_np(m * HW + p0);
+                const float v = lg[m * win + pp + hn];
+                mk[m] = __expf(v - gmx[m * G + gi]) * ginv[m * G + gi];
+                if (a.masks_out) a.masks_out[((size_t)b * NP + m) * HW + p] = mk[m];
+            } else {
+                mk[m] = 0.f;
+            }
+        }
+        float o3[3];
+        if (MODE == 0) {
+            float keff[25];
+#pragma unroll
+            for (int i = 0; i < 25; ++i) keff[i] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                if (k < NM - 1) {
+                    const float mq = mk[k + 2];
+                    float kv[28];
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) {
+                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(kl + k * 28 + q * 4);
+                        kv[q * 4] = t4[0]; kv[q * 4 + 1] = t4[1]; kv[q * 4 + 2] = t4[2]; kv[q * 4 + 3] = t4[3];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 25; ++i) keff[i] = fmaf(mq, kv[i], keff[i]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* pt = prevt + (c * (FH_TR + 4) + ry) * PW + x;
+                float t = 0.f;
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) t = fmaf(keff[i * 5 + j], pt[i * PW + j], t);
+                const float pc = pt[2 * PW + 2];
+                o3[c] = mk[0] * pc + mk[1] * l0v[c] + t;
+            }
+        } else if (MODE == 1) {
+            const double xs = -1.0 + 2.0 * (double)x / (double)(W - 1);
+            const double ys = -1.0 + 2.0 * (double)y / (double)(H - 1);
+            double gu = (double)th[0] * xs + (double)th[1] * ys + (double)th[2];
+            double gv = (double)th[3] * xs + (double)th[4] * ys + (double)th[5];
+            if (!a.stp_zero) { gu = fmin(fmax(gu, -1.0), 1.0); gv = fmin(fmax(gv, -1.0), 1.0); }
+            const double u = (gu + 1.0) * (double)(W - 1) * 0.5;
+            const double v = (gv + 1.0) * (double)(H - 1) * 0.5;
+            double u0 = floor(u), v0 = floor(v);
+            if (!a.stp_zero) { u0 = fmin(fmax(u0, 0.0), (double)(W - 2)); v0 = fmin(fmax(v0, 0.0), (double)(H - 2)); }
+            const float wu1 = (float)(u - u0), wv1 = (float)(v - v0);
+            const int iu = (int)u0, iv = (int)v0;
+            float msum = 0.f;
+#pragma unroll
+            for (int q = 2; q < 12; ++q) msum += mk[q];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float t = 0.f;
+#pragma unroll
+                for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+                    for (int du = 0; du < 2; ++du) {
+                        const int uu = iu + du, vv = iv + dv;
+                        const float wgt = (dv ? wv1 : 1.f - wv1) * (du ? wu1 : 1.f - wu1);
+                        if ((unsigned)uu < (unsigned)W && (unsigned)vv < (unsigned)H) t = fmaf(wgt, pb[(size_t)c * HW + vv * W + uu], t);
+                    }
+                o3[c] = mk[0] * pb[(size_t)c * HW + p] + mk[1] * l0v[c] + msum * t;
+            }
+        } else {
+            const float* e7 = a.enc7 + (size_t)b * 25 * HW;
+            float kn[25];
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 25; ++i) {
+                kn[i] = fmaxf(e7[(size_t)i * HW + p] - 1e-12f, 0.f) + 1e-12f;
+                sum += kn[i];
+            }
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* pt = prevt + (c * (FH_TR + 4) + ry) * PW + x;
+                float t = 0.f;
+#pragma unroll
+                for (int xk = 0; xk < 5; ++xk)
+#pragma unroll
+                    for (int yk = 0; yk < 5; ++yk) {
+                        const bool ok = (y + xk < H) && (x + yk < W);   // TM:400 slice quirk
+                        t = fmaf(kn[xk * 5 + yk] * inv, ok ? pt[xk * PW + yk] : 0.f, t);
+                    }
+                o3[c] = mk[0] * pt[2 * PW + 2] + mk[1] * t;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.out[((size_t)b * 3 + c) * HW + p] = o3[c];
+    }
+    FH_STAMP(11);
+}
+
+static size_t frame_head_lds_floats(int mode, int W, int NM) {
+    const int NE = mode == 2 ? 25 : 3, MAXO = mode == 2 ? 27 : 15;
+    (void)NE;
+    const int NP = NM + 1, np = FH_TR * W, win = np + 2 * (NP - 1), G = np / NP + 2, PW = W + 4;
+    size_t f = (size_t)MAXO * 64 + 16 * ((MAXO + 15) / 16) + ((NP * win + 3) & ~3) + (mode == 2 ? 0 : 3 * np) + FH_KL + 256 + 8;
+    f += (3 * (FH_TR + 4) * PW + 3) & ~3;
+    const size_t un_tiles = (size_t)FH_HW * FH_TILE, un_comp = (size_t)2 * NP * G;
+    return f + (un_tiles > un_comp ? un_tiles : un_comp);
+}
+
+// can the fused launch serve this geometry?  (else: heads_1x1 + cdna_kernels / stp_params + composite)
+bool frame_head_ok(int mode, int B, int H, int W, int num_masks) {
+    if (mode < 0 || mode > 2 || B <= 0 || H <= 1 || W <= 1 || num_masks < 1 || num_masks > 11) return false;
+    if (mode == 2 && num_masks != 1) return false;
+    if (H % FH_TR || (FH_TR * W) % 64 || W + 4 > 256 || num_masks + 1 < 2) return false;
+    return frame_head_lds_floats(mode, W, num_masks) * sizeof(float) <= 160 * 1024;
+}
+// floats of a partial-sum buffer for B samples and K inputs: [B][KS][256] plus the tail the finisher's unclamped loads may touch
+long long motion_partials_floats(int B, int K) { return ((long long)B * cdna_kernel_partials_slices(K) + FH_MAXKS) * 256; }
+bool frame_head_finishes(int K) { return cdna_kernel_partials_slices(K) <= FH_MAXKS; }   // the in-kernel finisher takes this many K slices
+
+int frame_head(const FrameHeadArgs& a, int mode, hipStream_t s) {
+    PIVP_CHECK_ARG(frame_head_ok(mode, a.B, a.H, a.W, a.NM));
+    PIVP_CHECK_ARG(a.e6raw && a.ln_part && a.ln_nparts > 0 && a.gamma && a.beta && a.wm && a.bm && a.we && a.be && a.prev && a.out && a.enc7);
+    PIVP_CHECK_ARG(mode == 2 || a.partials || a.aux);
+    PIVP_CHECK_ARG(!a.partials || mode == 2 || (a.KS >= 1 && a.KS <= FH_MAXKS && a.hbias && (mode != 1 || (a.w2 && a.b2))));
+    const int lds = (int)(frame_head_lds_floats(mode, a.W, a.NM) * sizeof(float));
+    static PerDeviceOnce once[3];
+    const void* fn = mode == 0 ? reinterpret_cast<const void*>(&frame_head_kernel<0>)
+                   : mode == 1 ? reinterpret_cast<const void*>(&frame_head_kernel<1>) : reinterpret_cast<const void*>(&frame_head_kernel<2>);
+    // the cap is raised once per device to the most any geometry asks for (160 KB); the launch passes the bytes this one needs
+    if (pivp_ensure_dyn_lds(once[mode], fn, 160 * 1024) != PIVP_OK) return PIVP_ERR_LAUNCH;
+    const dim3 grid(a.H / FH_TR, a.B);
+    if (mode == 0) hipLaunchKernelGGL(frame_head_kernel<0>, grid, dim3(FH_NT), lds, s, a);
+    else if (mode == 1) hipLaunchKernelGGL(frame_head_kernel<1>, grid, dim3(FH_NT), lds, s, a);
+    else hipLaunchKernelGGL(frame_head_kernel<2>, grid, dim3(FH_NT), lds, s, a);
+    return PIVP_LAUNCH_STATUS();
+}
+
+}  // namespace pivp
+
+#ifdef PIVP_FH_STAMPS
+extern "C" int pivp_debug_fh_stamps(long long* out) {   // 8 x 16 values of block (3, 5), 10 ns ticks
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pivp::pivp_fh_stamps), sizeof(long long) * 128) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -230,6 +230,15 @@ int cdna_kernels(const float* hidden5, const float* wt, const float* bias, float
     return PIVP_LAUNCH_STATUS();
 }
 
+// the K-slice partial sums alone (the finisher then runs inside frame_head_kernel, csrc/frame_head.hip); dbl: accumulate in fp64 (STP)
+int motion_partials(const float* hidden5, const float* wt, float* partials, int B, int K, int dbl, hipStream_t s) {
+    PIVP_CHECK_ARG(hidden5 && wt && partials && B > 0 && K > 0);
+    const int KS = cdna_kernel_partials_slices(K);
+    if (dbl) hipLaunchKernelGGL(skinny_linear_partials_kernel<double>, dim3(KS, (B + LIN_BG - 1) / LIN_BG), dim3(256), 0, s, hidden5, wt, partials, B, K);
+    else hipLaunchKernelGGL(skinny_linear_partials_kernel<float>, dim3(KS, (B + LIN_BG - 1) / LIN_BG), dim3(256), 0, s, hidden5, wt, partials, B, K);
+    return PIVP_LAUNCH_STATUS();
+}
+
 // STP finisher (TM:458-468): relu(Linear(100)) -> shared Linear(6) + identity.  w2 reference layout (6,100).
 __global__ __launch_bounds__(128) void stp_params_finish_kernel(const float* __restrict__ partials, const float* __restrict__ b1,
                                                                 const float* __restrict__ w2, const float* __restrict__ b2,

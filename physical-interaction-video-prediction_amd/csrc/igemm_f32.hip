@@ -32,7 +32,8 @@
 // ConvLSTM: the block's 128 columns are the 4 gates (j,i,f,o) of 32 channels.  With WN = 1 a wave's
 // four accumulators are the four gates of the same channels; with WN = 2 / 4 a 32-column tile holds
 // 2 / 4 gates of 16 / 8 channels and the epilogue gathers the four gates of a channel with wave
-// shuffles.  The 4C-wide gate tensor is never written.
+// shuffles.  The 4C-wide gate tensor is never written.  NTB = 2 is the square 64 x 64 tile: 4 gates of 16
+// channels per block, 2 x 2 waves, each wave tile the 4 gates of 8 channels (GPT = gates per wave tile = 4).
 #include <stdlib.h>
 #include <stdio.h>
 #include <type_traits>
@@ -100,11 +101,13 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
     PIVP_SET_MAIN_PRIO();
     static_assert(WM * WN == 4, "4 waves");
     static_assert(KG == 1 || (KG == 2 && LSTM), "the in-block K split serves the ConvLSTM tile only");
-    static_assert(!LSTM || NTB == 4, "ConvLSTM blocks own 4 gates x 32 channels");
+    static_assert(!LSTM || NTB == 4 || (NTB == 2 && WN == 2), "ConvLSTM blocks own 4 gates x 32 channels, or 4 gates x 16 channels as 2 x 2 waves");
     constexpr int BM = 32 * WM;
     constexpr int BN = 32 * NTB;
-    constexpr int TPW = LSTM ? 4 / WN : NTB / WN;
-    constexpr int CPW = 32 / WN;  // LSTM: channels per wave
+    constexpr int CB = 8 * NTB;   // LSTM: channels per block (its BN columns are the 4 gates of CB channels): 32, or 16 for the square 64 x 64 tile
+    constexpr int CPW = LSTM ? CB / WN : 32 / WN;  // LSTM: channels per wave
+    constexpr int GPT = 32 / CPW; // LSTM: gates inside one 32-column MFMA tile of a wave (1, 2 or 4); with CB = 32 this is WN
+    constexpr int TPW = LSTM ? 4 / GPT : NTB / WN;
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     constexpr int A_FLOATS = BM * IG_P, B_FLOATS = BN * IG_P;
     const int gid = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;     // K group of this wave
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int phase = (int)gridDim.y - 1 - (int)blockIdx.y;   // transposed conv: the 4-tap phase is dispatched first, the 1-tap phase fills the tail
-    const int n_nblk = LSTM ? (d.C >> 5) : (d.N / BN);
+    const int n_nblk = LSTM ? (d.C / CB) : (d.N / BN);
     // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so block b runs
     // on XCD b % 8.  Give XCD k the k-th CONTIGUOUS eighth of the logical tile list, ordered column-block-major: its L2
     // then holds one column block's weights (<= 2.5 MB for every layer here) and a contiguous band of anchors whose
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int r = prow + 32 * j;
-        const int col = LSTM ? (r >> 5) * d.C + nblk * 32 + (r & 31) : nblk * BN + r;
+        const int col = LSTM ? (r / CB) * d.C + nblk * CB + (r % CB) : nblk * BN + r;
         b_goff[j] = (col * 32 + cvec * 4) * 4;
     }
     const int lds_wa = (prow * IG_P + cvec * 4);          // this thread's write slot inside the A / B tile (floats)
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         int row;
-        if (LSTM) row = (t * WN + l31 / CPW) * 32 + wn * CPW + (l31 % CPW);   // gate-major rows of the block tile
+        if (LSTM) row = (t * GPT + l31 / CPW) * CB + wn * CPW + (l31 % CPW);   // gate-major rows of the block tile
         else      row = (wn * TPW + t) * 32 + l31;
         b_off[t] = 2 * A_FLOATS + row * IG_P + 4 * half;
     }
@@ -376,16 +379,16 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
 
     // ConvLSTM: bias and c_{t-1} of the cells this lane will update are requested here, in front of the K loop.  Read in the
     // epilogue they cost one exposed HBM round trip per accumulator row, 16 in a row (measured on the bf16 kernel, where the
-    // epilogue was longer than the tap loop).  Lane (grp, channel) updates rows r = k * WN + grp of its wave tile (see the epilogue).
-    constexpr int OWNR = LSTM ? 16 / WN : 1;
+    // epilogue was longer than the tap loop).  Lane (grp, channel) updates rows r = k * GPT + grp of its wave tile (see the epilogue).
+    constexpr int OWNR = LSTM ? 16 / GPT : 1;
     float cpre[OWNR];
     float bj = 0.f, bi = 0.f, bf = 0.f, bo = 0.f;
     if constexpr (LSTM) {
-        const int C = d.C, ch = nblk * 32 + wn * CPW + (l31 % CPW), grp = l31 / CPW;
+        const int C = d.C, ch = nblk * CB + wn * CPW + (l31 % CPW), grp = l31 / CPW;
         bj = d.bias[ch]; bi = d.bias[C + ch]; bf = d.bias[2 * C + ch] + 1.0f; bo = d.bias[3 * C + ch];
 #pragma unroll
         for (int k = 0; k < OWNR; ++k) {
-            const int r = k * WN + grp;
+            const int r = k * GPT + grp;
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             cpre[k] = d.cstate_in[(size_t)(m < d.M ? m : d.M - 1) * C + ch];
         }
@@ -478,18 +481,18 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
         }
     };
     if constexpr (LSTM) {
-        // Accumulator row r of a lane is one anchor, its column (gate t * WN + grp, channel): the 4 gates of a cell sit in the WN
-        // lanes lane ^ (x * CPW) and the 4 / WN tiles.  Lane grp takes rows r = k * WN + grp: it keeps its own gate of that row
-        // and receives the others from its partners in WN - 1 xor-shuffles per tile, each partner sending the row its receiver
-        // owns.  Every lane updates one cell per k (no idle lanes; WN = 1 needs no exchange).  Register arrays are indexed
+        // Accumulator row r of a lane is one anchor, its column (gate t * GPT + grp, channel): the 4 gates of a cell sit in the GPT
+        // lanes lane ^ (x * CPW) and the 4 / GPT tiles.  Lane grp takes rows r = k * GPT + grp: it keeps its own gate of that row
+        // and receives the others from its partners in GPT - 1 xor-shuffles per tile, each partner sending the row its receiver
+        // owns.  Every lane updates one cell per k (no idle lanes; GPT = 1 needs no exchange).  Register arrays are indexed
         // statically; per-lane choices are select chains.
         const int C = d.C;
-        const int ch = nblk * 32 + wn * CPW + (l31 % CPW);
+        const int ch = nblk * CB + wn * CPW + (l31 % CPW);
         const int grp = l31 / CPW;
-        auto pick = [&](const float (&v)[WN], int idx) -> float {
-            if constexpr (WN == 1) {
+        auto pick = [&](const float (&v)[GPT], int idx) -> float {
+            if constexpr (GPT == 1) {
                 return v[0];
-            } else if constexpr (WN == 2) {
+            } else if constexpr (GPT == 2) {
                 return idx ? v[1] : v[0];
             } else {
                 const float lo = (idx & 1) ? v[1] : v[0], hi = (idx & 1) ? v[3] : v[2];
@@ -497,13 +500,13 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
             }
         };
         // Stores go through buffer descriptors: the lane-dependent part of a cell's address (row mlane, channel) is ONE 32-bit offset,
-        // the cell-dependent part (row k * WN + grp -> srow(k) rows further) a scalar offset, and rows past M fall outside the
+        // the cell-dependent part (row k * GPT + grp -> srow(k) rows further) a scalar offset, and rows past M fall outside the
         // descriptor and are dropped by the hardware -- no 64-bit address arithmetic and no exec-mask region per cell.
         const int M = d.M;
         const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(d.cstate_out, 0, M * C * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc(d.hout, 0, M * C * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(d.gates_out ? d.gates_out : d.hout, 0, d.gates_out ? M * C * 16 : 0, 0x00020000);
-        const int mlane = m0 + wm * 32 + 4 * half + (WN > 1 ? grp : 0);
+        const int mlane = m0 + wm * 32 + 4 * half + (GPT > 1 ? grp : 0);
         const int vo = (mlane * C + ch) * 4, vog = (mlane * 4 * C + ch) * 4;
         float sv[OWNR];        // this lane's h values, for the fused LayerNorm statistics
         unsigned own = 0;
@@ -511,18 +514,18 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
         for (int k = 0; k < OWNR; ++k) {
             float g4[4];
 #pragma unroll
-            for (int t = 0; t < 4 / WN; ++t) {
-                float rows[WN], val[WN];
+            for (int t = 0; t < 4 / GPT; ++t) {
+                float rows[GPT], val[GPT];
 #pragma unroll
-                for (int g = 0; g < WN; ++g) rows[g] = acc[t][k * WN + g];
+                for (int g = 0; g < GPT; ++g) rows[g] = acc[t][k * GPT + g];
                 val[0] = pick(rows, grp);
 #pragma unroll
-                for (int x = 1; x < WN; ++x) val[x] = __shfl_xor(pick(rows, grp ^ x), x * CPW, 64);
+                for (int x = 1; x < GPT; ++x) val[x] = __shfl_xor(pick(rows, grp ^ x), x * CPW, 64);
 #pragma unroll
-                for (int g = 0; g < WN; ++g) g4[t * WN + g] = pick(val, g ^ grp);
+                for (int g = 0; g < GPT; ++g) g4[t * GPT + g] = pick(val, g ^ grp);
             }
-            // row r = k * WN + grp of the wave tile is anchor (r & 3) + 8 (r >> 2) (+ 4 half): srow = the part that does not depend on grp
-            const int srow = WN == 1 ? (k & 3) + 8 * (k >> 2) : WN == 2 ? 2 * (k & 1) + 8 * (k >> 1) : 8 * k;
+            // row r = k * GPT + grp of the wave tile is anchor (r & 3) + 8 (r >> 2) (+ 4 half): srow = the part that does not depend on grp
+            const int srow = GPT == 1 ? (k & 3) + 8 * (k >> 2) : GPT == 2 ? 2 * (k & 1) + 8 * (k >> 1) : 8 * k;
             const int so = srow * C * 4;                     // scalar
             const float aj = fast_tanh(g4[0] + bj), ai = fast_sigmoid(g4[1] + bi);
             const float af = fast_sigmoid(g4[2] + bf), ao = fast_sigmoid(g4[3] + bo);
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
 template <int WM, int WN, int NTB, bool LSTM, int ABL = 0, int KG = 1>
 static int launch_igemm(const IgemmDesc& d, hipStream_t stream, int ksplit = 1, int* ln_nparts = nullptr) {
     constexpr int BM = 32 * WM, BN = 32 * NTB;
-    const int n_nblk = LSTM ? (d.C >> 5) : (d.N / BN);
+    const int n_nblk = LSTM ? (d.C / (8 * NTB)) : (d.N / BN);
     const int mblk = (d.M + BM - 1) / BM;
     constexpr int lds_bytes = ig_lds_bytes<WM, NTB, KG>();
     static PerDeviceOnce once;
@@ -649,6 +652,10 @@ int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant, int* ln_npar
         return launch_igemm<1, 4, 4, true, 3>(d, stream, 1, ln_nparts);
     }
 #endif
+    // PIVP_LSTM_SQ (tuning): the square 64 x 64 tile (16 channels x 4 gates per block; variants 5 / 6) where the automatic choice would take
+    // the 32-row tile (1: small maps, lstm5's 8 x 8 at B = 32) and also where exactly one 64 x 128 block per CU cannot split its odd chunk
+    // count over two K groups (2: lstm3).  A 32 x 128 tile streams 20 KB of operands per chunk, the square one 16 KB for the same MACs.
+    static const int sq = [] { const char* e = getenv("PIVP_LSTM_SQ"); return e ? atoi(e) : 0; }();
     if (variant == 0) {
         // Two resident blocks per CU (64-row tile, 240 VGPRs) beat the 128-row tile (320 VGPRs: one block, one wave per SIMD) at every grid
         // size: at M = 131072 / 32768 (config 5's maps, scripts/bench_lstm_layers.py 128) 139.9 against 132.3 TFLOP/s over the seven layers,
@@ -657,6 +664,9 @@ int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant, int* ln_npar
         if ((long)(d.M / 64) * nb >= 512) variant = 2;
         else if ((long)(d.M / 64) * nb >= 256) variant = 4;      // one 64-row block per CU: as two K groups (falls back to variant 2 on an odd chunk count)
         else variant = 3;
+        const bool even = ((25 * ((d.c0 + d.c1) >> 5)) & 1) == 0;
+        if (variant == 3 && sq >= 1 && d.C % 16 == 0 && d.M % 64 == 0) variant = even ? 6 : 5;
+        else if (variant == 4 && !even && sq >= 2) variant = 5;
     }
     // (128-row tiles as ONE 8-wave block per CU, two K groups -- a third less L2 traffic, half the staging per MFMA -- were measured on the
     // layers that fill the chip: lstm1 126 -> 119.5 TF, lstm7 135.5 -> 132, rollout 8.67 -> 8.86 ms; 46 VGPRs spill under the 256 cap.  Not kept.)
@@ -665,6 +675,10 @@ int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant, int* ln_npar
                   // lstm6 153.6 -> 150.2 at B = 32; needs an even chunk count (lstm3 has 75)
             if (((25 * ((d.c0 + d.c1) >> 5)) & 1) == 0) return launch_igemm<2, 2, 4, true, 0, 2>(d, stream, 1, ln_nparts);
             return launch_igemm<2, 2, 4, true>(d, stream, 1, ln_nparts);
+        case 5: return launch_igemm<2, 2, 2, true>(d, stream, 1, ln_nparts);          // 64 x 64 (16 channels x 4 gates)
+        case 6:                                                                         // ... as two K groups of 4 waves
+            if (((25 * ((d.c0 + d.c1) >> 5)) & 1) == 0) return launch_igemm<2, 2, 2, true, 0, 2>(d, stream, 1, ln_nparts);
+            return launch_igemm<2, 2, 2, true>(d, stream, 1, ln_nparts);
         case 1: return launch_igemm<4, 1, 4, true>(d, stream, 1, ln_nparts);
         case 2: return launch_igemm<2, 2, 4, true>(d, stream, 1, ln_nparts);
         case 3: {

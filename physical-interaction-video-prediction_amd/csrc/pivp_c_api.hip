@@ -352,7 +352,7 @@ long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin,
 #define PIVP_BUILD_DIGEST "unstamped"      // a build that did not go through build.py: _lib.load() refuses it
 #endif
 extern "C" const char* pivp_build_digest(void) { return PIVP_BUILD_DIGEST; }
-extern "C" int pivp_abi_version(void) { return 9; }   // 9: + pivp_build_digest, pivp_grad_sum_shards; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
+extern "C" int pivp_abi_version(void) { return 9; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
 
 extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                              const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream) {
@@ -499,7 +499,7 @@ extern "C" int pivp_convlstm_ln(const float* x, int cx, int ldx, const float* h_
                                 const float* c_in, float* c_out, float* h_out, const float* gamma, const float* beta,
                                 float* ln_out, int ldo, float* partials, float eps, int B, int H, int W, int variant, int* fused,
                                 void* stream) {
-    if (!x || !w || !bias || !c_in || !c_out || !h_out || !gamma || !beta || !ln_out || !partials || variant < 0 || variant > 4)
+    if (!x || !w || !bias || !c_in || !c_out || !h_out || !gamma || !beta || !ln_out || !partials || variant < 0 || variant > 6)
         return PIVP_ERR_BADARG;
     if (C <= 0 || C % 32) return PIVP_ERR_BADARG;
     int np = 0;
@@ -623,7 +623,7 @@ extern "C" int pivp_heads(const float* e6, const float* wm, const float* bm, con
 }
 extern "C" long long pivp_linear_scratch_floats(int B, int K) {
     if (B <= 0 || K <= 0) return PIVP_ERR_BADARG;
-    return (long long)cdna_kernel_partials_slices(K) * B * 256;
+    return motion_partials_floats(B, K);      // [B][K slices][256] + the tail pivp_frame_head's finisher may read (never summed)
 }
 extern "C" int pivp_cdna_kernels(const float* hidden5, const float* wt, const float* bias, float* partials, float* kerns,
                                  int B, int K, int num_masks, void* stream) {
@@ -632,6 +632,25 @@ extern "C" int pivp_cdna_kernels(const float* hidden5, const float* wt, const fl
 extern "C" int pivp_stp_params(const float* hidden5, const float* wt1, const float* b1, const float* w2, const float* b2,
                                float* partials, float* theta, int B, int K, void* stream) {
     return stp_params(hidden5, wt1, b1, w2, b2, partials, theta, B, K, (hipStream_t)stream);
+}
+extern "C" int pivp_frame_head_fits(int model_type, int B, int H, int W, int num_masks, int K) {
+    if (!frame_head_ok(model_type, B, H, W, num_masks)) return 0;
+    return (model_type == PIVP_MODEL_DNA || frame_head_finishes(K)) ? 1 : 2;
+}
+extern "C" int pivp_motion_partials(const float* hidden5, const float* wt, float* partials, int B, int K, int fp64_accumulate, void* stream) {
+    return motion_partials(hidden5, wt, partials, B, K, fp64_accumulate, (hipStream_t)stream);
+}
+extern "C" int pivp_frame_head(const pivp_frame_head_args_t* g, void* stream) {
+    if (!g) return PIVP_ERR_BADARG;
+    FrameHeadArgs a;
+    a.e6raw = g->e6raw; a.ln_part = g->ln_part; a.ln_nparts = g->ln_nparts; a.gamma = g->gamma; a.beta = g->beta; a.eps = g->ln_eps;
+    a.wm = g->masks_w; a.bm = g->masks_b; a.we = g->enc7_w; a.be = g->enc7_b; a.prev = g->prev;
+    a.partials = g->partials; a.KS = g->kslices; a.hbias = g->head_bias; a.w2 = g->w2; a.b2 = g->b2; a.aux = g->aux;
+    a.out = g->out; a.masks_out = g->masks_out; a.enc7 = g->enc7;
+    a.logits_out = g->logits_out; a.layer0_out = g->layer0_out; a.y_out = g->enc6_out; a.stat_out = g->stat_out;
+    a.kerns_out = g->kerns_out; a.vpre_out = g->vpre_out;
+    a.B = g->B; a.H = g->H; a.W = g->W; a.NM = g->num_masks; a.stp_zero = g->stp_zero_border;
+    return frame_head(a, g->model_type, (hipStream_t)stream);
 }
 extern "C" int pivp_composite(const float* prev, const float* mask_logits, const float* layer0, const float* aux, float* out,
                               float* masks_out, int B, int H, int W, int num_masks, int model_type, int stp_zero_border,

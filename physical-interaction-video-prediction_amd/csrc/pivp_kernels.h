@@ -148,6 +148,27 @@ int composite(const float* prev, const float* mask_logits, const float* layer0, 
               float* out, float* masks_out, int B, int H, int W, int num_masks, int mode, int stp_zero_border,
               hipStream_t s);
 
+// One launch for the output side of a timestep (csrc/frame_head.hip): norm_enc6 + ReLU + the 1x1 heads + the motion head's finisher +
+// flat softmax + transform + compositing; bit-identical to heads_1x1 + cdna_kernels / stp_params + composite.
+struct FrameHeadArgs {
+    const float* e6raw; const float* ln_part; int ln_nparts; const float* gamma; const float* beta; float eps;
+    const float* wm; const float* bm; const float* we; const float* be;
+    const float* prev;
+    const float* partials; int KS; const float* hbias;   // K-slice partial sums [B][KS][256] of the motion head's Linear + its bias; null: `aux` is final
+    const float* w2; const float* b2;                    // STP: identity_params (6,100), (6)
+    const float* aux;                                    // partials == null: kernels [B][NM][25] (CDNA) / theta [B][6] (STP)
+    float* out; float* masks_out;
+    float* enc7;
+    float* logits_out; float* layer0_out; float* y_out; float* stat_out;   // optional (training keeps them)
+    float* kerns_out; float* vpre_out;                   // optional: finished kernels / theta, and the Linear's pre-activation [B][256]
+    int B, H, W, NM, stp_zero;
+};
+bool frame_head_ok(int mode, int B, int H, int W, int num_masks);   // can the fused launch serve this geometry?
+long long motion_partials_floats(int B, int K);                     // floats of the partial-sum buffer (tail padding included)
+bool frame_head_finishes(int K);                                    // does its in-kernel finisher take a Linear over K inputs?
+int frame_head(const FrameHeadArgs& a, int mode, hipStream_t s);
+int motion_partials(const float* hidden5, const float* wt, float* partials, int B, int K, int dbl, hipStream_t s);   // skinny Linear, partial sums only
+
 // loss / PSNR (TM:737-759)
 int loss_partials_count(int n);
 int frame_sqerr_partials(const float* a, const float* b, float* partials, int n, hipStream_t s);

@@ -198,7 +198,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
     p->o_zero = carve((size_t)B * HW2 * 32);
     p->o_lnpart = carve((size_t)B * ln_partial_cap((int)HW) * 4);
     p->o_lnpart2 = carve((size_t)B * ln_partial_cap((int)HW) * 4);
-    p->o_linpart = carve((size_t)cdna_kernel_partials_slices(p->K5) * B * 256);
+    p->o_linpart = carve((size_t)motion_partials_floats(B, p->K5));      // [B][K slices][256] + the tail frame_head_kernel's finisher may read
     p->o_masks = carve((size_t)B * p->NP * HW);
     p->loss_nparts = loss_partials_count((int)(B * 3 * HW));
     p->o_losspart = carve((size_t)T * p->loss_nparts);
@@ -477,8 +477,39 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
         RC(run_deconv3x3s2(ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), P(p, p->i_enc_b[6]), ws + S.e6raw, 64, 64, 0, B, p->H2, p->W2, s, 0,
                            lnp, ln_cap, &np, dprec));
     }
-    // heads (TM:711-728).  norm_enc6 + relu is applied while the heads kernel stages its input: the normalised enc6 is only
-    // written when the activations are kept for BPTT (pivp_get_tap recomputes it on request otherwise).
+    // heads (TM:711-728).  One launch (csrc/frame_head.hip) for norm_enc6 + relu + the 1x1 heads + the motion head's finisher + flat softmax +
+    // transform + compositing, behind the Linear's partial sums: bit-identical to the four launches below it, which remain for geometries
+    // it does not take (PIVP_FRAME_HEAD=0 forces them).  The softmaxed masks are kept for the rollout's last step only (pivp_get_tap).
+    static const int use_fh = [] { const char* e = getenv("PIVP_FRAME_HEAD"); return e ? atoi(e) : 1; }();
+    if (use_fh && np > 0 && frame_head_ok(c.model_type, B, H, W, c.num_masks)) {
+        const bool fin = c.model_type == PIVP_MODEL_DNA || frame_head_finishes(p->K5);
+        FrameHeadArgs a;
+        memset(&a, 0, sizeof(a));
+        if (c.model_type == PIVP_MODEL_CDNA) {
+            if (fin) RC(motion_partials(ws + S.n5, P(p, p->i_head_w), ws + p->o_linpart, B, p->K5, 0, s));
+            else RC(cdna_kernels(ws + S.n5, P(p, p->i_head_w), P(p, p->i_head_b), ws + p->o_linpart, ws + S.kerns, B, p->K5, c.num_masks, s, ws + S.vpre));
+            a.aux = ws + S.kerns; a.kerns_out = ws + S.kerns;
+        } else if (c.model_type == PIVP_MODEL_STP) {
+            if (fin) RC(motion_partials(ws + S.n5, P(p, p->i_head_w), ws + p->o_linpart, B, p->K5, 1, s));
+            else RC(stp_params(ws + S.n5, P(p, p->i_head_w), P(p, p->i_head_b), P(p, p->i_head2_w), P(p, p->i_head2_b), ws + p->o_linpart,
+                               ws + S.theta, B, p->K5, s, ws + S.vpre));
+            a.aux = ws + S.theta; a.kerns_out = ws + S.theta; a.w2 = P(p, p->i_head2_w); a.b2 = P(p, p->i_head2_b);
+        }
+        if (fin && c.model_type != PIVP_MODEL_DNA) {
+            a.partials = ws + p->o_linpart; a.KS = cdna_kernel_partials_slices(p->K5); a.hbias = P(p, p->i_head_b); a.aux = nullptr;
+            a.vpre_out = ws + S.vpre;
+        } else {
+            a.kerns_out = nullptr;      // already written by the separate finisher
+        }
+        a.e6raw = ws + S.e6raw; a.ln_part = lnp; a.ln_nparts = np; a.gamma = P(p, p->i_ln_g[8]); a.beta = P(p, p->i_ln_b[8]); a.eps = eps;
+        a.wm = P(p, p->i_masks_w); a.bm = P(p, p->i_masks_b); a.we = P(p, p->i_enc7_w); a.be = P(p, p->i_enc7_b);
+        a.prev = prev; a.out = gen_out; a.enc7 = ws + S.enc7;
+        a.masks_out = t == c.seq_len - 2 ? ws + p->o_masks : nullptr;
+        a.stat_out = ws + S.lnstat + (size_t)8 * B * 2;
+        if (train) { a.logits_out = ws + S.logits; a.layer0_out = ws + S.layer0; a.y_out = ws + S.e6; }
+        a.B = B; a.H = H; a.W = W; a.NM = c.num_masks; a.stp_zero = c.stp_zero_border;
+        return frame_head(a, c.model_type, s);
+    }
     if (np > 0 && (H * W) % 64 == 0) {
         RC(heads_1x1(ws + S.e6raw, P(p, p->i_masks_w), P(p, p->i_masks_b), P(p, p->i_enc7_w), P(p, p->i_enc7_b),
                      ws + S.logits, ws + S.enc7, ws + S.layer0, B, H * W, p->NP, p->NE, c.model_type, s,

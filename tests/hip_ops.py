@@ -224,6 +224,83 @@ def composite(prev, logits, layer0, aux, num_masks, model_type, stp_zero=0):
     return out.cpu().numpy(), masks.cpu().numpy()
 
 
+def frame_head_pair(e6raw, gamma, beta, eps, Wm, bm, We, be, prev, hidden5, Wh, bh, W2, b2, num_masks, model_type, stp_zero=0, finisher=True,
+                    train=False):
+    """The output side of a timestep twice from the same device buffers: (1) pivp_layernorm(+relu) -> pivp_heads -> pivp_cdna_kernels /
+    pivp_stp_params -> pivp_composite, (2) pivp_motion_partials -> pivp_frame_head (finisher=False: the separate finisher's kernels / theta
+    through `aux`).  Returns two dicts of numpy arrays (out, masks, enc7, and for train=True logits, layer0, enc6, kerns, vpre)."""
+    import ctypes
+    lib = _lib.load()
+    B, _, H, Wd = prev.shape
+    HW = H * Wd
+    NP, NE = num_masks + 1, We.shape[1]
+    n = 64 * HW
+    e6d = nhwc(e6raw)
+    perm = lambda v: _t(np.asarray(v).reshape(64, HW).T)
+    gd, bd = perm(gamma), perm(beta)
+    wmd, bmd = _t(pivp_amd.to_internal('masks/W', Wm)), _t(bm)
+    wed, bed = _t(pivp_amd.to_internal('model/enc7/W', We)), _t(be)
+    pd = _t(prev)
+    new = lambda *shape: torch.full(shape, 7.0, dtype=torch.float32, device=DEV)
+    # ---- (1) the separate kernels -------------------------------------------------------------------------------------------------
+    e6n = torch.empty_like(e6d)
+    lnscr = torch.empty(lib.pivp_layernorm_scratch_floats(B, n), dtype=torch.float32, device=DEV)
+    _lib.check(lib.pivp_layernorm(e6d.data_ptr(), gd.data_ptr(), bd.data_ptr(), e6n.data_ptr(), lnscr.data_ptr(), B, n, 64, 64, eps, 1, stream()), 'layernorm')
+    nparts = lib.pivp_layernorm_scratch_floats(1, n) // 4          # (count, mean, M2, -) per ln_stats slice, left in the scratch
+    logits, enc7, layer0 = new(B, NP, H, Wd), new(B, NE, H, Wd), new(B, 3, H, Wd)
+    _lib.check(lib.pivp_heads(e6n.data_ptr(), wmd.data_ptr(), bmd.data_ptr(), wed.data_ptr(), bed.data_ptr(), logits.data_ptr(), enc7.data_ptr(),
+                              layer0.data_ptr(), B, HW, num_masks, model_type, stream()), 'heads')
+    aux = None
+    if model_type != 2:
+        K = int(np.prod(hidden5.shape[1:]))
+        hd = nhwc(hidden5)
+        lin = torch.empty(lib.pivp_linear_scratch_floats(B, K), dtype=torch.float32, device=DEV)
+        if model_type == 0:
+            whd, bhd = _t(pivp_amd.to_internal('model/cdna_kerns/W', Wh)), _t(bh)
+            aux = new(B, num_masks, 5, 5)
+            _lib.check(lib.pivp_cdna_kernels(hd.data_ptr(), whd.data_ptr(), bhd.data_ptr(), lin.data_ptr(), aux.data_ptr(), B, K, num_masks, stream()), 'cdna_kernels')
+        else:
+            whd, bhd, w2d, b2d = _t(pivp_amd.to_internal('model/stp_input/W', Wh)), _t(bh), _t(W2), _t(b2)
+            aux = new(B, 6)
+            _lib.check(lib.pivp_stp_params(hd.data_ptr(), whd.data_ptr(), bhd.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), lin.data_ptr(), aux.data_ptr(), B, K, stream()), 'stp_params')
+    out, masks = new(B, 3, H, Wd), new(B, NP, H, Wd)
+    _lib.check(lib.pivp_composite(pd.data_ptr(), logits.data_ptr(), layer0.data_ptr() if model_type != 2 else None, (aux if aux is not None else enc7).data_ptr(),
+                                  out.data_ptr(), masks.data_ptr(), B, H, Wd, num_masks, model_type, stp_zero, stream()), 'composite')
+    torch.cuda.synchronize()
+    sep = dict(out=out.cpu().numpy(), masks=masks.cpu().numpy(), enc7=enc7.cpu().numpy(), logits=logits.cpu().numpy(), layer0=layer0.cpu().numpy(),
+               enc6=nchw(e6n, B, H, Wd, 64), kerns=None if aux is None else aux.cpu().numpy())
+    # ---- (2) the fused launch ------------------------------------------------------------------------------------------------------------
+    fits = lib.pivp_frame_head_fits(model_type, B, H, Wd, num_masks, 0 if model_type == 2 else int(np.prod(hidden5.shape[1:])))
+    assert fits in (1, 2), 'pivp_frame_head_fits says no'
+    a = _lib.PivpFrameHeadArgs()
+    a.e6raw = e6d.data_ptr(); a.ln_part = lnscr.data_ptr(); a.ln_nparts = nparts; a.gamma = gd.data_ptr(); a.beta = bd.data_ptr(); a.ln_eps = eps
+    a.masks_w = wmd.data_ptr(); a.masks_b = bmd.data_ptr(); a.enc7_w = wed.data_ptr(); a.enc7_b = bed.data_ptr(); a.prev = pd.data_ptr()
+    out2, masks2, enc72 = new(B, 3, H, Wd), new(B, NP, H, Wd), new(B, NE, H, Wd)
+    logits2, layer02, e6n2, stat2 = new(B, NP, H, Wd), new(B, 3, H, Wd), torch.full_like(e6d, 7.0), new(B, 2)
+    kerns2 = new(B, num_masks, 5, 5) if model_type == 0 else new(B, 6)
+    vpre2 = new(B, 256)
+    a.out = out2.data_ptr(); a.masks_out = masks2.data_ptr(); a.enc7 = enc72.data_ptr()
+    if train:
+        a.logits_out = logits2.data_ptr(); a.layer0_out = layer02.data_ptr(); a.enc6_out = e6n2.data_ptr(); a.stat_out = stat2.data_ptr()
+    if model_type != 2:
+        if finisher and fits == 1:
+            lin.fill_(float('nan'))                                   # the tail padding is read but never summed: NaNs there must not matter
+            _lib.check(lib.pivp_motion_partials(hd.data_ptr(), whd.data_ptr(), lin.data_ptr(), B, K, 1 if model_type == 1 else 0, stream()), 'motion_partials')
+            a.partials = lin.data_ptr(); a.kslices = (K + 63) // 64; a.head_bias = bhd.data_ptr()
+            a.kerns_out = kerns2.data_ptr(); a.vpre_out = vpre2.data_ptr()
+            if model_type == 1:
+                a.w2 = w2d.data_ptr(); a.b2 = b2d.data_ptr()
+        else:
+            a.aux = aux.data_ptr()
+    a.B, a.H, a.W, a.num_masks, a.model_type, a.stp_zero_border = B, H, Wd, num_masks, model_type, stp_zero
+    _lib.check(lib.pivp_frame_head(ctypes.byref(a), stream()), 'frame_head')
+    torch.cuda.synchronize()
+    fused = dict(out=out2.cpu().numpy(), masks=masks2.cpu().numpy(), enc7=enc72.cpu().numpy(), logits=logits2.cpu().numpy(), layer0=layer02.cpu().numpy(),
+                 enc6=nchw(e6n2, B, H, Wd, 64), kerns=kerns2.cpu().numpy() if (model_type != 2 and finisher and fits == 1) else None,
+                 stat=stat2.cpu().numpy(), vpre=vpre2.cpu().numpy())
+    return sep, fused
+
+
 def select_frames(gt, gen, take):
     lib = _lib.load()
     B = gt.shape[0]

@@ -26,7 +26,7 @@ def _lstm_ref(x, h, c, W, b):
     return np.tanh(cn) * R.sigmoid(o), cn
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])      # 5 / 6: the square 64 x 64 tile (16 channels x 4 gates), one / two K groups
 @pytest.mark.parametrize('B,cx,C,H', [(2, 32, 32, 32), (2, 32, 64, 16), (3, 64, 128, 8), (2, 128, 64, 16), (1, 96, 32, 32), (5, 64, 64, 16)])
 def test_convlstm_parity(ops, B, cx, C, H, variant):
     rs = np.random.RandomState(B * 100 + C)
@@ -37,7 +37,7 @@ def test_convlstm_parity(ops, B, cx, C, H, variant):
     assert np.abs(hg - hr).max() < TOL and np.abs(cg - cr).max() < TOL
 
 
-@pytest.mark.parametrize('variant', [1, 2, 3, 4])
+@pytest.mark.parametrize('variant', [1, 2, 3, 4, 5, 6])
 def test_convlstm_first_step_skips_zero_h(ops, variant):
     # h_prev = NULL (all zeros after reset_state, TM:254-257): the h half of K is skipped, result identical
     rs = np.random.RandomState(77)
@@ -48,13 +48,13 @@ def test_convlstm_first_step_skips_zero_h(ops, variant):
     hg, cg = ops.convlstm(x, h, c, W, b, variant, h_is_zero=True)
     hz, cz = ops.convlstm(x, h, c, W, b, variant, h_is_zero=False)
     assert np.abs(hg - hr).max() < TOL and np.abs(cg - cr).max() < TOL
-    if variant in (0, 3, 4):   # tiles that split K over two wave groups: 25 + 25 chunks without h, 75 + 75 with it -- other partial sums
+    if variant in (0, 3, 4, 6):   # tiles that split K over two wave groups: 25 + 25 chunks without h, 75 + 75 with it -- other partial sums
         assert np.abs(hg - hz).max() < 1e-6 and np.abs(cg - cz).max() < 1e-6
     else:
         assert np.array_equal(hg, hz) and np.array_equal(cg, cz)      # skipping adds exact zeros: bit-identical
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize('B,cx,C,H,expect_fused', [(2, 32, 32, 32, True), (3, 64, 128, 8, None), (2, 32, 64, 16, True),
                                                    (2, 32, 32, 6, False)])
 def test_convlstm_layernorm_fused_stats(ops, B, cx, C, H, variant, expect_fused):
@@ -69,7 +69,7 @@ def test_convlstm_layernorm_fused_stats(ops, B, cx, C, H, variant, expect_fused)
     lg, hg, cg, fused = ops.convlstm_ln(x, h, c, W, b, gamma, beta, 1e-6, variant)
     assert np.abs(hg - hr).max() < TOL and np.abs(cg - cr).max() < TOL
     assert np.abs(lg - lr).max() < 1e-4      # LayerNorm divides by std(h) ~ 0.3: 3x the error of h
-    bm = {1: 128, 2: 64, 3: 32, 4: 64}.get(variant)
+    bm = {1: 128, 2: 64, 3: 32, 4: 64, 5: 64, 6: 64}.get(variant)
     if bm is not None:
         assert fused == int((H * H) % bm == 0)
     elif expect_fused is not None:
@@ -187,6 +187,49 @@ def test_heads_parity(ops, mt, nm, ne):
     assert np.abs(logits - rl).max() < TOL and np.abs(enc7 - r7).max() < TOL
     if mt != 2:
         assert np.abs(layer0 - R.sigmoid(r7)).max() < TOL
+
+
+@pytest.mark.parametrize('mt,nm,ne,H,W,finisher,train', [
+    (0, 10, 3, 64, 64, True, False), (0, 10, 3, 64, 64, True, True), (0, 10, 3, 64, 64, False, False), (0, 4, 3, 64, 64, True, True),
+    (1, 10, 3, 64, 64, True, True), (1, 10, 3, 64, 64, False, False), (2, 1, 25, 64, 64, True, True),
+    (0, 10, 3, 128, 128, True, False), (0, 10, 3, 32, 48, True, True), (1, 3, 3, 16, 64, True, False)])
+def test_frame_head_matches_the_separate_kernels(ops, mt, nm, ne, H, W, finisher, train):
+    """pivp_frame_head (norm_enc6 + relu + 1x1 heads + the motion head's finisher + flat softmax + transform + compositing in one launch)
+    against pivp_layernorm -> pivp_heads -> pivp_cdna_kernels / pivp_stp_params -> pivp_composite on the same device buffers: every
+    output BIT-identical.  The halo logic is what this pins: the flat-(num_masks+1) softmax groups of a 4-row band reach into the
+    neighbouring rows and, at the top / bottom band, into the neighbouring mask PLANE (TM:720-722); random logits would make any
+    misfiled halo element visible in the band's first / last groups.  128 x 128: the Linear has 512 K slices, so the finisher stays a
+    launch of its own (fits == 2) and the kernels arrive through aux."""
+    rs = np.random.RandomState(100 * mt + nm + H)
+    B = 3
+    e6raw = rs.randn(B, 64, H, W) * 1.5 + 0.3
+    gamma = 1.0 + 0.1 * rs.randn(64, H, W); beta = 0.1 * rs.randn(64, H, W)
+    Wm = rs.randn(64, nm + 1, 1, 1) / 4; bm = rs.randn(nm + 1) * 0.1
+    We = rs.randn(64, ne, 1, 1) / 8; be = rs.randn(ne) * 0.1
+    prev = rs.rand(B, 3, H, W)
+    h5 = rs.randn(B, 128, H // 8, W // 8)
+    K = 128 * (H // 8) * (W // 8)
+    nout = 25 * nm if mt == 0 else 100
+    Wh = rs.randn(nout, K) / np.sqrt(K); bh = rs.randn(nout) * 0.1
+    W2 = rs.randn(6, 100) * 0.02; b2 = rs.randn(6) * 0.01
+    sep, fused = ops.frame_head_pair(e6raw, gamma, beta, 1e-6, Wm, bm, We, be, prev, h5, Wh, bh, W2, b2, nm, mt, 0, finisher, train)
+    assert np.array_equal(sep['out'], fused['out']), np.abs(sep['out'] - fused['out']).max()
+    assert np.array_equal(sep['masks'], fused['masks'])
+    assert np.array_equal(sep['enc7'], fused['enc7'])
+    if train:
+        assert np.array_equal(sep['logits'], fused['logits']) and np.array_equal(sep['enc6'], fused['enc6'])
+        if mt != 2:
+            assert np.array_equal(sep['layer0'], fused['layer0'])
+        assert np.all(np.isfinite(fused['stat'])) and np.all(fused['stat'][:, 1] > 0)
+    else:
+        assert np.all(fused['logits'] == 7.0) and np.all(fused['enc6'] == 7.0)       # optional outputs: untouched when not asked for
+    if fused['kerns'] is not None:
+        assert np.array_equal(sep['kerns'].reshape(B, -1), fused['kerns'].reshape(B, -1))
+    # and against the float64 oracle, end to end
+    e6 = R.relu(R.layer_norm_conv2d(e6raw, gamma.reshape(-1), beta.reshape(-1), 1e-6))
+    rl = R.relu(R.deconv2d(e6, Wm, bm))
+    masks = _masks_ref(rl)
+    assert np.abs(fused['masks'] - masks).max() < 2e-5
 
 
 def test_cdna_kernels_parity_and_kat(ops):
