@@ -28,6 +28,7 @@ constexpr int FH_XP = 36;             // floats per pixel row of the transpositi
 constexpr int FH_TILE = 64 * FH_XP;   // floats per wave tile
 constexpr int FH_KL = 11 * 28;        // CDNA kernel table [11][28]
 constexpr int FH_MAXKS = 128;         // most K slices the in-kernel finisher takes (every block of a sample re-reads its KS x 1 KB of partial sums)
+constexpr int FH_HP = 68;             // floats per halo row (272 B)
 constexpr int FH_HW = 4;              // waves per block: at 64-wide frames a band is four 64-pixel tiles + the halo tile (wave 0 takes it second)
 constexpr int FH_NT = 64 * FH_HW;     // 256 threads x 256 registers: two blocks per CU wherever the dispatcher puts their waves
 
@@ -65,26 +66,21 @@ __global__ __launch_bounds__(FH_NT, 2) void frame_head_kernel(const FrameHeadArg
     float* vs = kl + FH_KL;                      // [256] finisher scratch
     float* th = vs + 256;                        // [8] STP theta
     float* prevt = th + 8;                       // [3][FH_TR + 4][PW] previous-frame tile with its 2-pixel halo
-    float* un = prevt + ((3 * (FH_TR + 4) * PW + 3) & ~3);   // union: FH_HW transposition tiles | (gmx, ginv)
+    float* hal = prevt + ((3 * (FH_TR + 4) * PW + 3) & ~3);   // [2 (NP - 1)][FH_HP] normalised enc6 rows of the halo pixels
+    float* un = hal + 24 * FH_HP;                // union: FH_HW transposition tiles | (gmx, ginv) | the finisher's chain sums
     float* gmx = un;
     float* ginv = gmx + NP * G;
     const unsigned magic = 0xFFFFFFFFu / (unsigned)NP + 1u;     // exact x / NP for x * NP < 2^32
     auto div_np = [&](int x) { return (int)__umulhi((unsigned)x, magic); };
     const float* pb = a.prev + (size_t)b * 3 * HW;
-    const int ntile = np / 64 + 1;               // band tiles + the halo tile
+    const int ntile = np / 64;                   // band tiles (the halo pixels are handled by all threads, below)
     FH_STAMP(0);
 
     // ---- heads: the first pass's loads (e6, gamma, beta: 24 float4 per lane) go out first of all --------------------------------------
     const float* eb = a.e6raw + (size_t)b * HW * 64;
     float* yb = a.y_out ? a.y_out + (size_t)b * HW * 64 : nullptr;
     float* mt = un + wave * FH_TILE;
-    // pixel (inside the sample) of slot pl of tile t; halo slots: [0, hn) = the hn pixels in front of the band, [hn, 2 hn) = behind it, wrapped
-    auto pix_of = [&](int t, int pl) -> int {
-        if (t != ntile - 1) return p0 + t * 64 + pl;
-        int raw = pl < hn ? p0 - hn + pl : p0 + np + (pl - hn);
-        if (pl >= 2 * hn) raw = p0;
-        return raw < 0 ? raw + HW : raw >= HW ? raw - HW : raw;
-    };
+    auto pix_of = [&](int t, int pl) -> int { return p0 + t * 64 + pl; };       // pixel (inside the sample) of slot pl of band tile t
     f32x4 rx[8], rg[8], rb[8];
     auto issue = [&](int t, int hh) {
 #pragma unroll
@@ -96,62 +92,107 @@ __global__ __launch_bounds__(FH_NT, 2) void frame_head_kernel(const FrameHeadArg
             rb[j] = *reinterpret_cast<const f32x4*>(a.beta + gi);
         }
     };
-    issue(wave, 0);                              // (wave < ntile always: ntile >= 2, and a band of one tile still has its halo tile)
-
-    // ---- weights of the 1x1 mixes and the previous-frame tile: every thread's loads go out before its first LDS store (a loop of
-    // lds[i] = g[i] compiles to one L2 round trip per element: an early version of this kernel spent 26 of them on the frame tile) ----
-    {
-        constexpr int WIT = (64 * MAXO + FH_NT - 1) / FH_NT;
-        float wv[WIT];
+    // ---- weights of the 1x1 mixes, the previous-frame tile and the halo pixels' rows: every thread's loads go out before its first LDS store
+    // (a loop of lds[i] = g[i] compiles to one L2 round trip per element: an early version of this kernel spent 26 of them on the frame
+    // tile), and in front of the first pass's 24 loads per lane (loads return in order: behind them the table waited for HBM) ----------
+    // halo slot hs: [0, hn) = the hn pixels in front of the band, [hn, 2 hn) = behind it, wrapped into the neighbouring plane's rows
+    auto halo_pix = [&](int hs) -> int {
+        const int raw = hs < hn ? p0 - hn + hs : p0 + np + (hs - hn);
+        return raw < 0 ? raw + HW : raw >= HW ? raw - HW : raw;
+    };
+    constexpr int WIT = (MAXO + FH_HW - 1) / FH_HW;      // thread = (k = lane, outputs wave, wave + 4, ...): no run-time division
+    float wv[WIT];
 #pragma unroll
-        for (int u = 0; u < WIT; ++u) {
-            const int i = min(tid + FH_NT * u, 64 * NO - 1);
-            const int k = i / NO, o = i - k * NO;
-            wv[u] = o < NP ? a.wm[k * NP + o] : a.we[k * NE + (o - NP)];
-        }
-        const float bv = tid < NO ? (tid < NP ? a.bm[tid] : a.be[tid - NP]) : 0.f;
-        const int ptot = MODE != 1 ? 3 * (FH_TR + 4) * PW : 0, prow_n = (FH_TR + 4) * PW;
-        for (int base = 0; base < ptot; base += 8 * FH_NT) {
-            float pv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = min(base + tid + FH_NT * u, ptot - 1);
-                const int c = i / prow_n, rem = i - c * prow_n;
-                const int r = rem / PW, x = rem - r * PW;
-                const int iy = min(max(y0 + r - 2, 0), H - 1), ix = min(max(x - 2, 0), W - 1);
-                pv[u] = pb[(size_t)c * HW + iy * W + ix];          // clamped address, zeroed below: no predicate around the load
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + tid + FH_NT * u;
-                if (i < ptot) {
-                    const int c = i / prow_n, rem = i - c * prow_n;
-                    const int r = rem / PW, x = rem - r * PW;
-                    const int iy = y0 + r - 2, ix = x - 2;
-                    prevt[i] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? pv[u] : 0.f;
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < WIT; ++u) {
-            const int i = tid + FH_NT * u;
-            if (i < 64 * NO) { const int k = i / NO, o = i - k * NO; wl[o * 64 + k] = wv[u]; }
-        }
-        if (tid < NO) bl[tid] = bv;
+    for (int u = 0; u < WIT; ++u) {
+        const int o = min(wave + FH_HW * u, NO - 1);
+        wv[u] = o < NP ? a.wm[lane * NP + o] : a.we[lane * NE + (o - NP)];
     }
+    const float bv = tid < NO ? (tid < NP ? a.bm[tid] : a.be[tid - NP]) : 0.f;
+    f32x4 hx[2], hg[2], hb[2];                   // halo rows: 2 hn pixels x 16 float4 <= 352 pieces, two per thread
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = min(tid + FH_NT * u, 2 * hn * 16 - 1);
+        const size_t gi = (size_t)halo_pix(i >> 4) * 64 + (i & 15) * 4;
+        hx[u] = *reinterpret_cast<const f32x4*>(eb + gi);
+        hg[u] = *reinterpret_cast<const f32x4*>(a.gamma + gi);
+        hb[u] = *reinterpret_cast<const f32x4*>(a.beta + gi);
+    }
+    constexpr int PR = (FH_TR + 4 + 2) / 3;      // frame-tile rows per thread when 256 / PW >= 3 (W <= 81), the rest looped below
+    float tp[3][PR];
+    const int tx = tid % PW, tr0 = tid / PW, rstep = FH_NT / PW;
+    const bool prow = MODE != 1 && tid < rstep * PW;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int u = 0; u < PR; ++u) {
+            const int r = tr0 + u * rstep;
+            const int iy = min(max(y0 + r - 2, 0), H - 1), ix = min(max(tx - 2, 0), W - 1);
+            tp[c][u] = pb[(size_t)c * HW + iy * W + ix];           // clamped address, zeroed below: no predicate around the load
+        }
+    if (wave < ntile) issue(wave, 0);
+    if (prow) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int u = 0; u < PR; ++u) {
+                const int r = tr0 + u * rstep, iy = y0 + r - 2, ix = tx - 2;
+                if (r < FH_TR + 4) prevt[(c * (FH_TR + 4) + r) * PW + tx] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? tp[c][u] : 0.f;
+            }
+        for (int r = tr0 + PR * rstep; r < FH_TR + 4; r += rstep) {   // wide frames: remaining rows
+            const int iy = y0 + r - 2, ix = tx - 2;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                prevt[(c * (FH_TR + 4) + r) * PW + tx] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? pb[(size_t)c * HW + iy * W + ix] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < WIT; ++u) {
+        const int o = wave + FH_HW * u;
+        if (o < NO) wl[o * 64 + lane] = wv[u];
+    }
+    if (tid < NO) bl[tid] = bv;
     FH_STAMP(1);
     float mean, rstd;
     ln_merge_partials(a.ln_part, b, a.ln_nparts, a.eps, mean, rstd);
     if (a.stat_out && blockIdx.x == 0 && tid == 0) { a.stat_out[b * 2] = mean; a.stat_out[b * 2 + 1] = rstd; }
     FH_STAMP(2);
-    __syncthreads();          // (1) weight table in place
+    // the halo pixels' rows, normalised, into LDS: relu((v - mean) rstd gamma + beta), the band tiles' expression
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + FH_NT * u;
+        if (i < 2 * hn * 16) {
+            f32x4 v = hx[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf((v[e] - mean) * rstd * hg[u][e] + hb[u][e], 0.f);
+            *reinterpret_cast<f32x4*>(hal + (i >> 4) * FH_HP + (i & 15) * 4) = v;
+        }
+    }
+    __syncthreads();          // (1) weight table and halo rows in place
     FH_STAMP(3);
+    // halo logits: thread = (halo pixel, mask plane), a 64-long dot product in the band tiles' order (bias first, k ascending).  A halo logit
+    // of plane o at window position jx belongs to the window of plane o - carry, carry = -1 / +1 where the flat index wrapped into the
+    // previous / next plane.  (Done here, while the first pass's e6 is still on its way from HBM.)
+    for (int i = tid; i < 2 * hn * NP; i += FH_NT) {
+        const int hs = i / NP, o = i - hs * NP;
+        const float* xrow = hal + hs * FH_HP;
+        const float* wo = wl + o * 64;
+        float sacc = bl[o];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + q * 4);
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wo + q * 4);
+            sacc = fmaf(xv[0], w4[0], sacc); sacc = fmaf(xv[1], w4[1], sacc); sacc = fmaf(xv[2], w4[2], sacc); sacc = fmaf(xv[3], w4[3], sacc);
+        }
+        const int raw = hs < hn ? p0 - hn + hs : p0 + np + (hs - hn);
+        const int row = o + (raw < 0 ? 1 : raw >= HW ? -1 : 0);
+        const int jx = hs < hn ? hs : np + hs;
+        if ((unsigned)row < (unsigned)NP) lg[row * win + jx] = fmaxf(sacc, 0.f);
+    }
 
     // ---- heads: one 64-pixel tile per wave and turn, 32 channels per pass; the loads of pass i + 1 are in flight while pass i is multiplied ----
     {
         float acc[MAXO];
         for (int t = wave; t < ntile; t += FH_HW) {
-            const bool halo = t == ntile - 1;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 // LayerNorm + ReLU of the pass in registers, into the wave's transposition tile
@@ -161,7 +202,7 @@ __global__ __launch_bounds__(FH_NT, 2) void frame_head_kernel(const FrameHeadArg
                     f32x4 v = rx[j];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf((v[e] - mean) * rstd * rg[j][e] + rb[j][e], 0.f);
-                    if (yb && !halo) *reinterpret_cast<f32x4*>(yb + (size_t)pix_of(t, f >> 3) * 64 + hh * 32 + (f & 7) * 4) = v;
+                    if (yb) *reinterpret_cast<f32x4*>(yb + (size_t)pix_of(t, f >> 3) * 64 + hh * 32 + (f & 7) * 4) = v;
                     *reinterpret_cast<f32x4*>(mt + (f >> 3) * FH_XP + (f & 7) * 4) = v;
                 }
                 FH_STAMP(4 + 2 * hh);
@@ -190,7 +231,7 @@ __global__ __launch_bounds__(FH_NT, 2) void frame_head_kernel(const FrameHeadArg
                 }
                 FH_STAMP(5 + 2 * hh);
             }
-            if (!halo) {
+            {
                 const int pp = t * 64 + lane, p = p0 + pp;
 #pragma unroll
                 for (int o = 0; o < MAXO; ++o) {
@@ -210,111 +251,32 @@ __global__ __launch_bounds__(FH_NT, 2) void frame_head_kernel(const FrameHeadArg
                         }
                     }
                 }
-            } else if (lane < 2 * hn) {
-                // a halo logit of plane o at window position jx belongs to the window of plane o - carry, carry = -1 / +1 where the
-                // flat index wrapped into the previous / next plane
-                const int raw = lane < hn ? p0 - hn + lane : p0 + np + (lane - hn);
-                const int shift = raw < 0 ? 1 : raw >= HW ? -1 : 0;
-                const int jx = lane < hn ? lane : np + lane;
-#pragma unroll
-                for (int o = 0; o < MAXO; ++o) {
-                    if (o < NP) {
-                        const int row = o + shift;
-                        if ((unsigned)row < (unsigned)NP) lg[row * win + jx] = fmaxf(acc[o], 0.f);
-                    }
-                }
             }
         }
     }
     FH_STAMP(8);
 
-    // ---- the motion head's finisher (fixed summation order: that of sum_partials in heads.hip), by the last wave -- the one with the
-    // fewest tiles -- while wave 0 works on the halo tile.  A lane owns 4 consecutive outputs: its loads are whole 16-B pieces of the 1-KB
-    // partial rows, 32 slices in flight. ------------------------------------------------------------------------------------------------
-    if (MODE != 2 && wave == FH_HW - 1) {
-        if (a.partials) {
-            const int KS = a.KS;
-            const float* prow = a.partials + (size_t)b * KS * 256 + lane * 4;
-            double ch[4][4];                 // [output][chain]: chain c takes slices c, c + 4, ... in increasing order
+    // ---- the motion head's finisher, part 1 (fixed summation order: that of sum_partials in heads.hip: four chains, chain c = slices c,
+    // c + 4, ... in increasing order, joined as (c0 + c1) + (c2 + c3)).  Wave c sums chain c for all 256 outputs -- a lane owns 4
+    // consecutive ones, its loads are whole 16-B pieces of the 1-KB partial rows, the chain's 32 slices in flight at once -- and leaves the
+    // sums at the end of its own (dead) transposition tile.  (One wave for all four chains: 8 us behind its tile; scripts/r04/fh_stamps.py.)
+    double* chd = reinterpret_cast<double*>(un + wave * FH_TILE + (FH_TILE - 512));
+    // (Requested in front of the wave's last multiplies instead, the 128 registers stayed allocated across the whole tile loop: 337 spills.)
+    if (MODE != 2 && a.partials) {
+        const int KS = a.KS;
+        const float* crow = a.partials + ((size_t)b * KS + wave) * 256 + lane * 4;
+        f32x4 cv[32];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+        for (int u = 0; u < 32; ++u) cv[u] = *reinterpret_cast<const f32x4*>(crow + (size_t)u * 1024);   // slices past KS: the buffer's tail padding, not summed
+        double c4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) ch[e][c] = 0.0;
-            for (int k0 = 0; k0 < KS; k0 += 32) {
-                f32x4 v[32];
+        for (int u = 0; u < 32; ++u)
 #pragma unroll
-                for (int u = 0; u < 32; ++u) v[u] = *reinterpret_cast<const f32x4*>(prow + (size_t)(k0 + u) * 256);   // slices past KS: the
-#pragma unroll                                                                                                 // buffer's tail padding, not summed
-                for (int u = 0; u < 32; ++u)
+            for (int e = 0; e < 4; ++e) c4[e] += wave + 4 * u < KS ? (double)cv[u][e] : 0.0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ch[e][u & 3] += k0 + u < KS ? (double)v[u][e] : 0.0;
-            }
-            double sum4[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sum4[e] = (ch[e][0] + ch[e][1]) + (ch[e][2] + ch[e][3]);
-            if (MODE == 0) {
-                const int nout = 25 * NM;
-                float accv[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int o = lane * 4 + e;
-                    accv[e] = 0.f;
-                    if (o < nout) {
-                        const double t = (double)a.hbias[o] + sum4[e];
-                        if (a.vpre_out && blockIdx.x == 0) a.vpre_out[(size_t)b * 256 + o] = (float)t;
-                        accv[e] = fmaxf((float)t - 1e-12f, 0.f) + 1e-12f;
-                    }
-                    vs[o] = accv[e];
-                }
-                // (one wave: its LDS operations complete in order, no barrier needed between the stores above and the loads below)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int o = lane * 4 + e;
-                    if (o < nout) {
-                        const int g = (o / 25) * 25;
-                        float sum = 0.f;
-#pragma unroll
-                        for (int i = 0; i < 25; ++i) sum += vs[g + i];
-                        const float kv = accv[e] / sum;
-                        kl[(o / 25) * 28 + (o - g)] = kv;
-                        if (a.kerns_out && blockIdx.x == 0) a.kerns_out[(size_t)b * nout + o] = kv;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int o = lane * 4 + e;
-                    if (o < 100) {
-                        const double t = (double)a.hbias[o] + sum4[e];
-                        vs[o] = fmaxf((float)t, 0.f);
-                        if (a.vpre_out && blockIdx.x == 0) a.vpre_out[(size_t)b * 256 + o] = vs[o];
-                    }
-                }
-                if (lane < 6) {
-                    double t = a.b2[lane];
-                    for (int i = 0; i < 100; ++i) t = fma((double)a.w2[lane * 100 + i], (double)vs[i], t);
-                    const float tv = (float)(t + ((lane == 0 || lane == 4) ? 1.0 : 0.0));
-                    th[lane] = tv;
-                    if (a.kerns_out && blockIdx.x == 0) a.kerns_out[b * 6 + lane] = tv;
-                }
-            }
-        } else if (MODE == 0) {
-            float kv[5];
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {            // 308 table entries: five per lane, all requested before the first store
-                const int i2 = min(lane + 64 * u, FH_KL - 1), k = i2 / 28, e = i2 - k * 28;
-                kv[u] = a.aux[((size_t)b * NM + min(k, NM - 1)) * 25 + min(e, 24)];
-            }
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                const int i2 = lane + 64 * u, k = i2 / 28, e = i2 - k * 28;
-                if (i2 < FH_KL) kl[i2] = (k < NM && e < 25) ? kv[u] : 0.f;
-            }
-        } else {
-            if (lane < 6) th[lane] = a.aux[(size_t)b * 6 + lane];
-        }
+        for (int e = 0; e < 4; ++e) chd[lane * 4 + e] = c4[e];
     }
-    __syncthreads();          // (2) logits, layer0, frame tile, kernels / theta (LDS) and, for DNA, enc7 (global, this block's own stores) complete
+    __syncthreads();          // (2) logits, layer0, chain sums (LDS) and, for DNA, enc7 (global, this block's own stores) complete; the tiles are dead
     FH_STAMP(9);
 
     // ---- per-group max and 1 / sum (groups of NP consecutive flat elements, TM:720-722); the transposition tiles are dead -------------
@@ -338,7 +300,65 @@ __global__ __launch_bounds__(FH_NT, 2) void frame_head_kernel(const FrameHeadArg
             ginv[i] = 1.0f / sum;
         }
     }
+    // finisher, part 2: thread = output; join the four chains, bias, activation
+    if (MODE != 2) {
+        const int o = tid;
+        if (a.partials) {
+            const double* c0 = reinterpret_cast<const double*>(un + (FH_TILE - 512));
+            constexpr int CS = FH_TILE / 2;                  // doubles between two waves' chain sums
+            const double sv = (c0[o] + c0[CS + o]) + (c0[2 * CS + o] + c0[3 * CS + o]);
+            if (MODE == 0) {
+                float accv = 0.f;
+                if (o < 25 * NM) {
+                    const double t = (double)a.hbias[o] + sv;
+                    if (a.vpre_out && blockIdx.x == 0) a.vpre_out[(size_t)b * 256 + o] = (float)t;
+                    accv = fmaxf((float)t - 1e-12f, 0.f) + 1e-12f;
+                }
+                vs[o] = accv;
+            } else if (o < 100) {
+                const double t = (double)a.hbias[o] + sv;
+                vs[o] = fmaxf((float)t, 0.f);
+                if (a.vpre_out && blockIdx.x == 0) a.vpre_out[(size_t)b * 256 + o] = vs[o];
+            }
+        } else if (MODE == 0) {
+            float kv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {                    // 308 table entries, both requested before the first store
+                const int i2 = min(tid + FH_NT * u, FH_KL - 1), k = i2 / 28, e = i2 - k * 28;
+                kv[u] = a.aux[((size_t)b * NM + min(k, NM - 1)) * 25 + min(e, 24)];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i2 = tid + FH_NT * u, k = i2 / 28, e = i2 - k * 28;
+                if (i2 < FH_KL) kl[i2] = (k < NM && e < 25) ? kv[u] : 0.f;
+            }
+        } else if (tid < 6) {
+            th[tid] = a.aux[(size_t)b * 6 + tid];
+        }
+    }
     __syncthreads();
+    // finisher, part 3: per-kernel normalisation (TM:327-329) / the shared Linear(100 -> 6) + identity (TM:462-468)
+    if (MODE != 2 && a.partials) {
+        const int o = tid;
+        if (MODE == 0) {
+            if (o < 25 * NM) {
+                const int g = (o / 25) * 25;
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 25; ++i) sum += vs[g + i];
+                const float kv = vs[o] / sum;
+                kl[(o / 25) * 28 + (o - g)] = kv;
+                if (a.kerns_out && blockIdx.x == 0) a.kerns_out[(size_t)b * 25 * NM + o] = kv;
+            }
+        } else if (o < 6) {
+            double t = a.b2[o];
+            for (int i = 0; i < 100; ++i) t = fma((double)a.w2[o * 100 + i], (double)vs[i], t);
+            const float tv = (float)(t + ((o == 0 || o == 4) ? 1.0 : 0.0));
+            th[o] = tv;
+            if (a.kerns_out && blockIdx.x == 0) a.kerns_out[b * 6 + o] = tv;
+        }
+        __syncthreads();      // (block-uniform condition)
+    }
     FH_STAMP(10);
 
     // ---- softmaxed masks, motion transform, blend (the body of composite_kernel, operands from LDS) --------------------------------------
@@ -457,7 +477,7 @@ static size_t frame_head_lds_floats(int mode, int W, int NM) {
     (void)NE;
     const int NP = NM + 1, np = FH_TR * W, win = np + 2 * (NP - 1), G = np / NP + 2, PW = W + 4;
     size_t f = (size_t)MAXO * 64 + 16 * ((MAXO + 15) / 16) + ((NP * win + 3) & ~3) + (mode == 2 ? 0 : 3 * np) + FH_KL + 256 + 8;
-    f += (3 * (FH_TR + 4) * PW + 3) & ~3;
+    f += ((3 * (FH_TR + 4) * PW + 3) & ~3) + 24 * FH_HP;
     const size_t un_tiles = (size_t)FH_HW * FH_TILE, un_comp = (size_t)2 * NP * G;
     return f + (un_tiles > un_comp ? un_tiles : un_comp);
 }
