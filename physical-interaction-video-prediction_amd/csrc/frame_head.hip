@@ -489,6 +489,11 @@ bool frame_head_ok(int mode, int B, int H, int W, int num_masks) {
     if (H % FH_TR || (FH_TR * W) % 64 || W + 4 > 256 || num_masks + 1 < 2) return false;
     return frame_head_lds_floats(mode, W, num_masks) * sizeof(float) <= 160 * 1024;
 }
+// ... and is it the faster form?  Only while two blocks share a CU (<= 80 KB of LDS each: frames up to 64 wide).  At 128 x 128 a block needs
+// 92 KB, the 1,024 blocks of B = 32 run in four rounds, and the separate kernels win: rollout 65.7 against 66.5 ms (T = 20, profiles/r04).
+bool frame_head_pays(int mode, int B, int H, int W, int num_masks) {
+    return frame_head_ok(mode, B, H, W, num_masks) && frame_head_lds_floats(mode, W, num_masks) * sizeof(float) * 2 <= 160 * 1024;
+}
 // floats of a partial-sum buffer for B samples and K inputs: [B][KS][256] plus the tail the finisher's unclamped loads may touch
 long long motion_partials_floats(int B, int K) { return ((long long)B * cdna_kernel_partials_slices(K) + FH_MAXKS) * 256; }
 bool frame_head_finishes(int K) { return cdna_kernel_partials_slices(K) <= FH_MAXKS; }   // the in-kernel finisher takes this many K slices

@@ -552,6 +552,11 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
         const int oy0 = deconv ? py : 0, ox0 = deconv ? px : 0;
         float sv[16 * TPW];
         unsigned long long own = 0;
+        // LayerNorm-backward sums of the output (data gradients, IgemmDesc::lnb_part; tiles lie inside one sample): block-uniform switch.
+        // K-split blocks add the sums of their own partial tile (the sums are linear in the output).
+        const bool lnb = d.lnb_part && nblk * BN < d.lnb_C;
+        float lb1 = 0.f, lb2 = 0.f, lmean = 0.f, lrstd = 0.f;
+        if (lnb) { const int bb = m0 / HWg; lmean = d.lnb_stat[bb * 2]; lrstd = d.lnb_stat[bb * 2 + 1]; }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -560,20 +565,36 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
                 const int rem = m - b * HWg;
                 const int ay = rem / d.Wg;
                 const int ax = rem - ay * d.Wg;
-                const size_t o = ((size_t)(b * d.Hout + ay * d.out_step + oy0) * d.Wout + ax * d.out_step + ox0) * d.ldo;
+                const int opix = (ay * d.out_step + oy0) * d.Wout + ax * d.out_step + ox0;
+                const size_t o = ((size_t)b * d.Hout * d.Wout + opix) * d.ldo;
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) {
                     const int col = nblk * BN + (wn * TPW + t) * 32 + l31;
                     if (ksplit > 1) {
-                        if (nchunks > 0) atomicAdd(d.out + o + col, acc[t][r]);
+                        if (nchunks > 0) {
+                            atomicAdd(d.out + o + col, acc[t][r]);
+                            if (lnb && col < d.lnb_C) PIVP_LNB_ACC(d, acc[t][r], b, opix, col, d.Hout * d.Wout, lmean, lrstd, lb1, lb2);
+                        }
                     } else {
                         float v = acc[t][r] + (d.bias ? d.bias[col] : 0.f);
                         if (d.relu) v = fmaxf(v, 0.f);
                         if (d.accum) v += d.out[o + col];
                         d.out[o + col] = v;
                         sv[t * 16 + r] = v; own |= 1ull << (t * 16 + r);
+                        if (lnb && col < d.lnb_C) PIVP_LNB_ACC(d, v, b, opix, col, d.Hout * d.Wout, lmean, lrstd, lb1, lb2);
                     }
                 }
+            }
+        }
+        if (lnb) {           // fixed order: xor tree inside a wave, the four waves left to right
+            lb1 = wave_sum(lb1); lb2 = wave_sum(lb2);
+            __syncthreads();   // every wave is past its last LDS tile read
+            if (lane == 0) { lds[16 + wave] = lb1; lds[20 + wave] = lb2; }
+            __syncthreads();
+            if (tid == 0) {
+                const int bb = m0 / HWg, nb_ln = (d.lnb_C + BN - 1) / BN;
+                float* pp = d.lnb_part + ((size_t)bb * d.lnb_np + ((size_t)((m0 - bb * HWg) / BM) * nb_ln + nblk) * ksplit + (int)blockIdx.z) * 2;
+                pp[0] = (lds[16] + lds[17]) + (lds[18] + lds[19]); pp[1] = (lds[20] + lds[21]) + (lds[22] + lds[23]);
             }
         }
         if (d.ln_part) {
@@ -604,6 +625,15 @@ static int launch_igemm(const IgemmDesc& d, hipStream_t stream, int ksplit = 1, 
     dd.ln_nparts = (d.ln_part && ksplit == 1 && hwg % BM == 0 && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
+    if (!LSTM) {   // LayerNorm-backward sums of the output (data gradients): one part per (tile, K split) that owns norm columns
+        const int nb_ln = d.lnb_part ? (d.lnb_C + BN - 1) / BN : 0;
+        const int lnp = (hwg / BM) * nb_ln * ksplit;
+        const bool ok = d.lnb_part && d.lnb_gamma && d.lnb_x && d.lnb_stat && d.lnb_C > 0 && d.lnb_C <= d.N && hwg % BM == 0 && d.nphase == 1 &&
+                        KG == 1 && lnp <= d.lnb_cap && !d.ln_part;
+        dd.lnb_np = ok ? lnp : 0;
+        if (!ok) dd.lnb_part = nullptr;
+        if (d.lnb_np_out) *d.lnb_np_out = dd.lnb_np;
+    }
     hipLaunchKernelGGL((igemm_f32_kernel<WM, WN, NTB, LSTM, ABL, KG>), grid, dim3(256 * KG), lds_bytes, stream, dd);
     return PIVP_LAUNCH_STATUS();
 }

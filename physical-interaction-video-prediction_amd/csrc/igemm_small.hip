@@ -181,6 +181,12 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     const int oy0 = deconv ? py : 0, ox0 = deconv ? px : 0;
     float* orow = d.out + ((size_t)(b * d.Hout + ay * d.out_step + oy0) * d.Wout + ax * d.out_step + ox0) * d.ldo + nblk * BN;
     float sv[4 * NTB];   // this thread's outputs, for the fused LayerNorm partial
+    // LayerNorm-backward sums of the output (data gradients, IgemmDesc::lnb_part): block-uniform switch
+    const int nb_ln = d.lnb_part ? (d.lnb_C + BN - 1) / BN : 0;
+    const bool lnb = nblk < nb_ln;
+    float lb1 = 0.f, lb2 = 0.f, lmean = 0.f, lrstd = 0.f;
+    const int opix = (ay * d.out_step + oy0) * d.Wout + ax * d.out_step + ox0;
+    if (lnb) { lmean = d.lnb_stat[b * 2]; lrstd = d.lnb_stat[b * 2 + 1]; }
 #pragma unroll
     for (int t = 0; t < NTB; ++t) {
         const int cl = t * 32 + cvec * 4;   // column within the block tile
@@ -195,6 +201,23 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) sv[t * 4 + e] = v[e];
+        if (lnb && valid && nblk * BN + cl < d.lnb_C) {       // (lnb_C is a multiple of 4: a float4 is inside or outside)
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(d.lnb_gamma + (size_t)opix * d.lnb_C + nblk * BN + cl);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(d.lnb_x + ((size_t)b * d.Hout * d.Wout + opix) * d.lnb_C + nblk * BN + cl);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float gg = v[e] * gv[e]; lb1 += gg; lb2 = fmaf(gg, (xv[e] - lmean) * lrstd, lb2); }
+        }
+    }
+    if (lnb) {           // fixed order: xor tree inside a wave, the four waves left to right
+        __syncthreads();   // the partial-sum image is dead
+        lb1 = wave_sum(lb1); lb2 = wave_sum(lb2);
+        if (lane == 0) { lds[16 + wave] = lb1; lds[20 + wave] = lb2; }
+        __syncthreads();
+        if (tid == 0) {
+            const int bb = m0 / HWg;
+            float* pp = d.lnb_part + ((size_t)bb * d.lnb_np + (((m0 - bb * HWg) >> 5) * nb_ln + nblk) * (int)gridDim.y + phase) * 2;
+            pp[0] = (lds[16] + lds[17]) + (lds[18] + lds[19]); pp[1] = (lds[20] + lds[21]) + (lds[22] + lds[23]);
+        }
     }
     if (d.ln_part) {   // (count, mean, M2) of the block's outputs, two passes over registers, fixed summation order
         __syncthreads();   // the partial-sum image is dead
@@ -239,6 +262,15 @@ int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     dd.ln_nparts = (d.ln_part && hwg % 32 == 0 && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
+    {   // LayerNorm-backward sums of the output (data gradients): one part per block that owns norm columns
+        const int bn = 32 * ntb, nb_ln = d.lnb_part ? (d.lnb_C + bn - 1) / bn : 0;
+        const int lnp = (hwg / 32) * nb_ln * d.nphase;
+        const bool ok = d.lnb_part && d.lnb_gamma && d.lnb_x && d.lnb_stat && d.lnb_C > 0 && d.lnb_C % 4 == 0 && d.lnb_C <= d.N &&
+                        hwg % 32 == 0 && lnp <= d.lnb_cap && !d.ln_part;
+        dd.lnb_np = ok ? lnp : 0;
+        if (!ok) dd.lnb_part = nullptr;
+        if (d.lnb_np_out) *d.lnb_np_out = dd.lnb_np;
+    }
     if (d.in_g) {      // LayerNorm-on-load (see IgemmDesc::in_g): one sample per tile, one source, a plain conv
         PIVP_CHECK_ARG(igemm_in_ln_ok(d) && d.in_b && d.in_part && d.in_np > 0);
         if (ntb == 3) hipLaunchKernelGGL((igemm_small_kernel<3, true>), grid, dim3(256), 0, stream, dd);

@@ -15,6 +15,11 @@ namespace pivp {
 // extent in bytes of an NHWC view with pixel stride ld (for the kernels' buffer descriptors)
 long long view_bytes(int B, int H, int W, int ld) { return (long long)B * H * W * ld * 4; }
 bool fits31(long long v) { return v > 0 && v < (1LL << 31); }
+void lnb_apply(IgemmDesc& d, const LnbSpec* l) {
+    if (!l) return;
+    if (l->np) *l->np = 0;
+    d.lnb_gamma = l->gamma; d.lnb_x = l->x; d.lnb_stat = l->stat; d.lnb_part = l->part; d.lnb_C = l->C; d.lnb_cap = l->cap; d.lnb_np_out = l->np;
+}
 
 int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                  const float* c_in, float* c_out, float* h_out, int B, int H, int W, hipStream_t s, int variant,
@@ -40,7 +45,7 @@ int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, co
 }
 
 int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
-                  int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum) {
+                  int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum, const LnbSpec* lnb) {
     if (Hin % 2 || Win % 2) return PIVP_ERR_BADARG;
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
@@ -52,6 +57,7 @@ int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float*
     if (!fits31(b0) || !fits31(bw)) return PIVP_ERR_BADARG;
     d.bytes0 = (int)b0; d.bytesw = (int)bw;
     d.out_step = 1; d.Hout = d.Hg; d.Wout = d.Wg; d.out = out; d.ldo = ldo; d.relu = relu; d.accum = accum;
+    lnb_apply(d, lnb);
     return igemm_conv(d, s);
 }
 
@@ -86,7 +92,7 @@ int run_conv3x3s2_ln(const float* x_raw, int cin, const float* w, const float* b
 
 int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                     int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum, float* ln_part, int ln_cap,
-                    int* ln_nparts, int bf16) {
+                    int* ln_nparts, int bf16, const LnbSpec* lnb) {
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
     d.bf16 = bf16;                   // precision mode bf16: honoured by the all-parities tile kernel (deconv_tile.hip), fp32 otherwise
@@ -99,6 +105,7 @@ int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const floa
     d.bytes0 = (int)b0; d.bytesw = (int)bw;
     d.out_step = 2; d.Hout = 2 * Hin; d.Wout = 2 * Win; d.out = out; d.ldo = ldo; d.relu = relu; d.accum = accum;
     d.ln_part = ln_part; d.ln_cap = ln_cap;
+    lnb_apply(d, lnb);
     return igemm_conv(d, s, ln_nparts);
 }
 
@@ -166,10 +173,11 @@ bool conv_s1_splits_k(int cin, int cout, int ldo, int ksize, int B, int H, int W
     return d.ksplit_ok && igemm_conv_ksplit(d) > 1;
 }
 int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, int cout, int ldo, int ksize, int B, int H, int W,
-                hipStream_t s, int accum, int wN, int dest_zeroed) {
+                hipStream_t s, int accum, int wN, int dest_zeroed, const LnbSpec* lnb) {
     IgemmDesc d;
     int rc = conv_s1_desc(d, x, cin, ldx, w, out, cout, ldo, ksize, B, H, W, accum, wN);
     if (rc != PIVP_OK) return rc;
+    lnb_apply(d, lnb);
     if (d.ksplit_ok && !dest_zeroed && igemm_conv_ksplit(d) > 1 &&
         hipMemsetAsync(out, 0, (size_t)B * H * W * ldo * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     return igemm_conv(d, s);
@@ -247,7 +255,7 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
                           const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                           float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
                           int B, int H, int W, hipStream_t s, int wt_ready, unsigned short* wt_bf16, int bf16_planes, const SideFork* fork,
-                          const LnFuse* ln, int dx_only) {
+                          const LnFuse* ln, int dx_only, const LnbSpec* dx_lnb) {
     const int M = B * H * W, cin = cx + C, N = 4 * C;
     // a K-split data gradient adds into d_in: the gate kernel clears it on the side (one launch less than a memset per cell and timestep)
     const bool zero = wt_bf16 ? conv5x5_bf16_splits_k(N, cin, cin, B, H, W)
@@ -267,10 +275,12 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
             rc = pack_lstm_bf16(wt, wt_bf16, N, cin, s, conv5x5_bf16_rows(cin), bf16_planes);
             if (rc != PIVP_OK) return rc;
         }
+        if (dx_lnb && dx_lnb->np) *dx_lnb->np = 0;      // (the bf16 data-gradient kernel has no LayerNorm-backward epilogue: the caller runs ln_bwd_sums)
         rc = run_conv5x5_bf16(dG, N, N, wt_bf16, d_in, cin, cin, 0, B, H, W, s, bf16_planes, zero);
     } else {
         // d[x,h] = conv5x5(dG, W^T flipped); dx_only: the x columns alone (the pack's first cx of cin; the h columns of d_in stay unwritten)
-        rc = dx_only ? run_conv_s1(dG, N, N, wt, d_in, cx, cin, 5, B, H, W, s, 0, cin, zero) : run_conv_s1(dG, N, N, wt, d_in, cin, cin, 5, B, H, W, s, 0, 0, zero);
+        rc = dx_only ? run_conv_s1(dG, N, N, wt, d_in, cx, cin, 5, B, H, W, s, 0, cin, zero, dx_lnb)
+                     : run_conv_s1(dG, N, N, wt, d_in, cin, cin, 5, B, H, W, s, 0, 0, zero, dx_lnb);
     }
     if (rc != PIVP_OK) return rc;
     if (!dW) return PIVP_OK;   // the caller batches this layer's weight gradient over several timesteps itself (pivp_plan.hip)
@@ -311,7 +321,7 @@ int run_select_frames(const float* gt, const float* gen, const unsigned char* ta
 // conv3x3s2 (mode 0) / deconv3x3s2 (mode 1) backward.  dy is masked in place by (y > 0) when y != null (fused ReLU).
 int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w, float* dy, int cout, int ldy, const float* y, int ldyy,
                       float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, hipStream_t s,
-                      int wt_ready, const SideFork* fork, float* part, WgradDesc* desc_out, const float* dy_add, int ld_add) {
+                      int wt_ready, const SideFork* fork, float* part, WgradDesc* desc_out, const float* dy_add, int ld_add, const LnbSpec* dx_lnb) {
     const int Hout = mode ? 2 * Hin : Hin / 2, Wout = mode ? 2 * Win : Win / 2;
     int rc = PIVP_OK;
     if (y) { rc = relu_mask(dy, ldy, y, ldyy, cout, (long)B * Hout * Wout, s, dy_add, ld_add); if (rc != PIVP_OK) return rc; }
@@ -324,8 +334,8 @@ int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w
             rc = repack_transpose(w, wt, 9, cin, cout, 0, s);
             if (rc != PIVP_OK) return rc;
         }
-        rc = mode ? run_conv3x3s2(dy, cout, ldy, wt, nullptr, dx, cin, lddx, 0, B, Hout, Wout, s, accum_dx)
-                  : run_deconv3x3s2(dy, cout, ldy, wt, nullptr, dx, cin, lddx, 0, B, Hout, Wout, s, accum_dx);
+        rc = mode ? run_conv3x3s2(dy, cout, ldy, wt, nullptr, dx, cin, lddx, 0, B, Hout, Wout, s, accum_dx, dx_lnb)
+                  : run_deconv3x3s2(dy, cout, ldy, wt, nullptr, dx, cin, lddx, 0, B, Hout, Wout, s, accum_dx, nullptr, 0, nullptr, 0, dx_lnb);
         if (rc != PIVP_OK) return rc;
     }
     int bias_done = 0;     // the weight-gradient kernel sums dY's columns on the side when it can
@@ -538,8 +548,8 @@ extern "C" int pivp_gates_backward_ln(const float* gates, const float* c_old, co
     LnFuse lf;
     memset(&lf, 0, sizeof(lf));
     lf.dy = dy; lf.lddy = lddy; lf.gamma = gamma; lf.stat = stat; lf.h = h;
-    lf.partials = partials; lf.S = ln_bwd_slices(n);
-    int rc = ln_backward(dy, lddy, nullptr, 0, h, stat, gamma, partials, nullptr, dgamma, dbeta, B, n, C, 0, s, part);
+    lf.partials = partials; lf.S = ln_bwd_slices(n); lf.param_part = part;      // the gate kernel accumulates dgamma / dbeta itself
+    int rc = ln_bwd_sums(dy, lddy, h, stat, gamma, partials, B, n, C, s);
     if (rc != PIVP_OK) return rc;
     rc = lstm_gates_bwd(gates, c_old, c_new, nullptr, 0, dh_b, ldb, dc, dc_valid, dG, B * npix, C, s, B, &lf);
     if (rc != PIVP_OK) return rc;

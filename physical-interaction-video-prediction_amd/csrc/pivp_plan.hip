@@ -479,9 +479,9 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     }
     // heads (TM:711-728).  One launch (csrc/frame_head.hip) for norm_enc6 + relu + the 1x1 heads + the motion head's finisher + flat softmax +
     // transform + compositing, behind the Linear's partial sums: bit-identical to the four launches below it, which remain for geometries
-    // it does not take (PIVP_FRAME_HEAD=0 forces them).  The softmaxed masks are kept for the rollout's last step only (pivp_get_tap).
+    // it does not take or where it is slower (frames wider than 64: frame_head_pays; PIVP_FRAME_HEAD=0 forces them, 2 forces the fused launch).  The softmaxed masks are kept for the rollout's last step only (pivp_get_tap).
     static const int use_fh = [] { const char* e = getenv("PIVP_FRAME_HEAD"); return e ? atoi(e) : 1; }();
-    if (use_fh && np > 0 && frame_head_ok(c.model_type, B, H, W, c.num_masks)) {
+    if (use_fh && np > 0 && (use_fh >= 2 ? frame_head_ok(c.model_type, B, H, W, c.num_masks) : frame_head_pays(c.model_type, B, H, W, c.num_masks))) {
         const bool fin = c.model_type == PIVP_MODEL_DNA || frame_head_finishes(p->K5);
         FrameHeadArgs a;
         memset(&a, 0, sizeof(a));
@@ -652,19 +652,43 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         return hipStreamWaitEvent(s, p->ev_done[slot], 0) == hipSuccess ? PIVP_OK : PIVP_ERR_LAUNCH;   // never recorded: returns at once
     };
     const long long slab_bytes = p->nslabs > 1 ? ((long long)p->slabs[1].cat7 - (long long)p->slabs[0].cat7) * 4 : 0;
-    // LayerNorm behind ConvLSTM i (hidden<i+1>): partial sums and parameter gradients here, dx inside the cell's gate backward
+    // LayerNorm behind ConvLSTM i (hidden<i+1>).  Its dx AND its parameter gradients are formed inside the cell's gate backward
+    // (lstm_gates_bwd_grp_kernel); the two sums per sample that needs come from the epilogue of the kernel that produced dy (pnp[i] parts:
+    // IgemmDesc::lnb_part), or from a sums-only launch when that kernel has no such epilogue (the bf16 mode's 5x5 data gradients; steps no
+    // gradient reaches).  Round 3 ran ln_bwd_sums_params_kernel here, 63 launches per train step on the main stream.
+    // PIVP_LN_BWD: 2 as described, 1 = always the sums-only launch, 0 (DEFAULT) = round 3's pair of kernels.  Measured (one box, A/B/A/B,
+    // profiles/r04/NOTES.md): fp32 train step 28.21 / 28.26 (0), 28.28 / 28.38 (1), 28.48 / 28.58 ms (2); bf16 11.85 / 11.79, 11.85 / 11.78,
+    // 11.89 / 11.93.  63 launches fewer per step and the step got SLOWER: the two loads per output element that the epilogues add to the
+    // data gradients (K-split ones pay them once per split) cost more than the 6-us launches they replace, and those launches were not
+    // what bounds the sweep (the matrix-pipe work of both streams is).  All gradient fixtures pass in all three modes.
+    static const int ln_bwd_mode = [] { const char* e = getenv("PIVP_LN_BWD"); return e ? atoi(e) : 0; }();
     LnFuse lf[7];
+    int pnp[7] = {0, 0, 0, 0, 0, 0, 0};
+    const int lnb_cap = ln_bwd_slices((int)(64 * HW));       // parts per sample g.lnpart holds
+    LnbSpec lsp[7];
+    auto lnb_spec = [&](int i, int C) -> const LnbSpec* {  // for the launch that produces the dy of the norm behind cell i
+        if (ln_bwd_mode < 2) return nullptr;
+        const int j = i + 1;
+        lsp[i] = LnbSpec{P(p, p->i_ln_g[j]), ws + S.h[i], ws + S.lnstat + (size_t)j * B * 2, lnpart, C, lnb_cap, &pnp[i]};
+        return &lsp[i];
+    };
     auto lnb_cell = [&](int i, const float* dy, int lddy, int n, int C) -> int {
         const int j = i + 1;
+        memset(&lf[i], 0, sizeof(lf[i]));
         lf[i].dy = dy; lf[i].lddy = lddy; lf[i].gamma = P(p, p->i_ln_g[j]); lf[i].stat = ws + S.lnstat + (size_t)j * B * 2;
         lf[i].partials = lnpart; lf[i].S = ln_bwd_slices(n); lf[i].h = ws + S.h[i];
-        RC(ln_backward(dy, lddy, nullptr, 0, ws + S.h[i], lf[i].stat, lf[i].gamma, lnpart, nullptr,
-                       G(p, p->i_ln_g[j]), G(p, p->i_ln_b[j]), B, n, C, 0, s, ws + g.ln_ppart[j]));
         p->ln_touched[j] = true;
-        if (t == 0) RC(ln_finish(j));
+        if (ln_bwd_mode == 0) {
+            RC(ln_backward(dy, lddy, nullptr, 0, ws + S.h[i], lf[i].stat, lf[i].gamma, lnpart, nullptr,
+                           G(p, p->i_ln_g[j]), G(p, p->i_ln_b[j]), B, n, C, 0, s, ws + g.ln_ppart[j]));
+            return PIVP_OK;
+        }
+        lf[i].param_part = ws + g.ln_ppart[j];
+        if (pnp[i] > 0) lf[i].S = pnp[i];          // the producer's epilogue left the sums
+        else RC(ln_bwd_sums(dy, lddy, ws + S.h[i], lf[i].stat, lf[i].gamma, lnpart, B, n, C, s));
         return PIVP_OK;
     };
-    auto lstmb = [&](int i, const float* x, int ldx, int hh, int wwid) -> int {
+    auto lstmb = [&](int i, const float* x, int ldx, int hh, int wwid, const LnbSpec* dx_lnb = nullptr) -> int {
         const LstmSpec& L = kLstm[i];
         const int cin = L.cx + L.C, N = 4 * L.C;
         const size_t dG1 = (size_t)B * hh * wwid * N;                      // floats of one timestep's dG
@@ -681,7 +705,8 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                                  ring + (size_t)wg_slot * dG1, ws + g.wt_lstm[i], ws + g.din[i][par], nullptr, nullptr, B, hh, wwid,
                                  s, 1, p->lstm_bf16 ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->lstm_planes,
                                  wg_flush ? fork_of(i, f) : nullptr, &lf[i],    // dW = null: only the fork's `ready` (behind the gate math) is used
-                                 t == 0 ? 1 : 0));                              // t = 0: nobody reads d h_{-1}
+                                 t == 0 ? 1 : 0, dx_lnb));                      // t = 0: nobody reads d h_{-1}
+        if (t == 0) RC(ln_finish(i + 1));       // the sweep's last timestep: the norm's partial parameter planes (written by the gate kernel) become its gradient
         if (!wg_flush) return PIVP_OK;
         // weight + bias gradient of the whole batch: timestep j of it reads slab (first - j) and ring slot j; on the side stream it
         // starts as soon as this step's dG exists, next to this step's own data gradient
@@ -729,7 +754,8 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         RC(join(7));       // d e6raw
         RC(lnb(8, ws + g.e6, 64, ws + S.e6, 64, ws + S.e6raw, ws + g.e6raw, 64 * HW, 64, 1));
         RC(run_conv_backward(1, ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), ws + g.e6raw, 64, 64, nullptr, 0, ws + g.wt_enc[6], ws + g.cat7, 64, 0,
-                             G(p, p->i_enc_w[6]), G(p, p->i_enc_b[6]), B, p->H2, p->W2, s, 1, fork_of(7, fe), ws + g.wg_part[0], &p->enc_desc[0]));
+                             G(p, p->i_enc_w[6]), G(p, p->i_enc_b[6]), B, p->H2, p->W2, s, 1, fork_of(7, fe), ws + g.wg_part[0], &p->enc_desc[0],
+                             nullptr, 0, lnb_spec(6, 32)));
     p->enc_desc_valid[0] = true;
     } else {
         // no gradient reaches this step's frame: only the recurrent paths are live
@@ -770,7 +796,8 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(join(11));          // enc1's dY lives in d cat6, which enc5's data gradient rewrites
     // group 5 (TM:600): d e5 = x-part of lstm7's d_in (ReLU fused in enc5) <- enc5 deconv <- [hidden6 | enc1]
     RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ws + S.e5, 96, ws + g.wt_enc[5], ws + g.cat6, 96, 0,
-                         G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1, fork_of(8, fe), ws + g.wg_part[1], &p->enc_desc[1]));
+                         G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1, fork_of(8, fe), ws + g.wg_part[1], &p->enc_desc[1],
+                         nullptr, 0, lnb_spec(5, 64)));
     p->enc_desc_valid[1] = true;
     RC(lnb_cell(5, ws + g.cat6, 96, n4, 64));
     RC(join(9));           // enc4's dY = the x part of lstm6's d_in of this parity
@@ -778,7 +805,8 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(done(2));
     // group 4 (TM:599): d e4 = x-part of lstm6's d_in <- enc4 deconv <- hidden5 (also read by the CDNA kernel generator)
     RC(run_conv_backward(1, ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), ws + g.din[5][par], 128, 192, ws + S.e4, 128, ws + g.wt_enc[4], ws + g.n5, 128, 1,
-                         G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s, 1, fork_of(9, fe), ws + g.wg_part[2], &p->enc_desc[2]));
+                         G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s, 1, fork_of(9, fe), ws + g.wg_part[2], &p->enc_desc[2],
+                         nullptr, 0, lnb_spec(4, 128)));
     p->enc_desc_valid[2] = true;
     RC(lnb_cell(4, ws + g.n5, 128, n8, 128));
     RC(lstmb(4, ws + S.e3, 64, p->H8, p->W8));
@@ -791,20 +819,21 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                       B, p->H8 * p->W8, c.use_state, s, 1));      // d e2 comes out masked by enc2's ReLU
     // group 2 (TM:597): enc2 conv (ReLU) <- hidden4 <- lstm4 <- hidden3 <- lstm3 <- enc1
     RC(run_conv_backward(0, ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), ws + g.e2, 64, 64, nullptr, 0, ws + g.wt_enc[2], ws + g.n4, 64, 0,
-                         G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s, 1, fork_of(10, fe), ws + g.wg_part[3], &p->enc_desc[3]));
+                         G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s, 1, fork_of(10, fe), ws + g.wg_part[3], &p->enc_desc[3],
+                         nullptr, 0, lnb_spec(3, 64)));
     p->enc_desc_valid[3] = true;
     RC(lnb_cell(3, ws + g.n4, 64, n4, 64));
-    RC(lstmb(3, ws + S.n3, 64, p->H4, p->W4));
+    RC(lstmb(3, ws + S.n3, 64, p->H4, p->W4, lnb_spec(2, 64)));      // its data gradient's x columns = the dy of hidden3
     RC(lnb_cell(2, ws + g.din[3][par], 128, n4, 64));
     RC(lstmb(2, ws + S.cat6 + 64, 96, p->H4, p->W4));
     RC(done(4));
     // group 1 (TM:596): enc1 conv (ReLU) <- hidden2 <- lstm2 <- hidden1 <- lstm1 <- enc0
     RC(run_conv_backward(0, ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), ws + g.cat6 + 64, 32, 96, ws + S.cat6 + 64, 96, ws + g.wt_enc[1], ws + g.n2, 32, 0,
                          G(p, p->i_enc_w[1]), G(p, p->i_enc_b[1]), B, p->H2, p->W2, s, 1, fork_of(11, fe), ws + g.wg_part[4], &p->enc_desc[4],
-                         ws + g.din[2][par], 96));      // d enc1 = enc5's concat part (in d cat6) + lstm3's x gradient, summed in the ReLU-mask pass
+                         ws + g.din[2][par], 96, lnb_spec(1, 32)));      // d enc1 = enc5's concat part (in d cat6) + lstm3's x gradient, summed in the ReLU-mask pass
     p->enc_desc_valid[4] = true;
     RC(lnb_cell(1, ws + g.n2, 32, n2, 32));
-    RC(lstmb(1, ws + S.n1, 32, p->H2, p->W2));
+    RC(lstmb(1, ws + S.n1, 32, p->H2, p->W2, lnb_spec(0, 32)));      // ... of hidden1
     RC(lnb_cell(0, ws + g.din[1][par], 64, n2, 32));
     RC(lstmb(0, ws + S.cat7 + 32, 64, p->H2, p->W2));
     RC(add_strided(ws + g.cat7 + 32, 64, ws + g.din[0][par], 64, 32, px2, s));          // d enc0: from enc6's concat + from lstm1
