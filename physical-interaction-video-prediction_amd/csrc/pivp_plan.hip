@@ -133,63 +133,17 @@ struct pivp_plan {
 static const float* P(const pivp_plan* p, int idx) { return p->params[idx].ptr; }
 static float* G(const pivp_plan* p, int idx) { return p->params[idx].grad; }
 
-extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
-    if (!cfg || !out) return PIVP_ERR_BADARG;
-    if (cfg->batch <= 0 || cfg->seq_len < 2 || cfg->height < 16 || cfg->width < 16) return PIVP_ERR_BADARG;
-    if (cfg->height % 8 || cfg->width % 8) return PIVP_ERR_BADARG;
-    if (cfg->model_type < 0 || cfg->model_type > 2) return PIVP_ERR_BADARG;
-    if (cfg->num_masks < 1 || cfg->num_masks > 11) return PIVP_ERR_BADARG;
-    if (cfg->model_type == PIVP_MODEL_DNA && cfg->num_masks != 1) return PIVP_ERR_BADARG;  // TM:389-390
-    if (cfg->context_frames < 1 || cfg->context_frames >= cfg->seq_len) return PIVP_ERR_BADARG;
-    pivp_plan* p = new pivp_plan();
-    p->cfg = *cfg;
+// ---- workspace carve (offsets in floats, 256-B aligned).  Runs at pivp_plan_create and again from pivp_plan_set_precision while no
+// workspace is bound: the ConvLSTM dG rings hold wg_cap timesteps per ring, and only the bf16 mode (or PIVP_WGRAD_BATCH) batches its weight
+// gradients -- an fp32 plan double-buffers with ONE slot per ring instead of 8 (2.5 GB less at 128 x 128, B = 32, T = 20). ----
+static void plan_layout(pivp_plan* p) {
+    const pivp_config_t* cfg = &p->cfg;
     const int H = cfg->height, W = cfg->width, B = cfg->batch, T = cfg->seq_len;
-    p->H2 = H / 2; p->W2 = W / 2; p->H4 = H / 4; p->W4 = W / 4; p->H8 = H / 8; p->W8 = W / 8;
-    p->NP = cfg->num_masks + 1;
-    p->NE = cfg->model_type == PIVP_MODEL_DNA ? 25 : 3;
-    p->K5 = 128 * p->H8 * p->W8;
-    p->ws = nullptr; p->ws_floats = 0; p->last_steps = 0; p->last_sched = false;
-    { const char* e = getenv("PIVP_SIDE_STREAM"); p->use_side = !(e && e[0] == '0'); }
-
-    auto add = [&](const std::string& name, long long n) { p->params.push_back({name, n, nullptr, nullptr, grad_group_of(name)}); return (int)p->params.size() - 1; };
     const int cin3 = 64 + (cfg->use_state ? 10 : 0);
     const long long encw[7] = {75 * 32, 9 * 32 * 32, 9 * 64 * 64, (long long)cin3 * 64, 9 * 128 * 128, 9 * 96 * 96, 9 * 64 * 64};
-    const int encb[7] = {32, 32, 64, 64, 128, 96, 64};
-    for (int i = 0; i < 7; ++i) {
-        p->i_enc_w[i] = add("enc" + std::to_string(i) + "/W", encw[i]);
-        p->i_enc_b[i] = add("enc" + std::to_string(i) + "/b", encb[i]);
-    }
-    for (int i = 0; i < 7; ++i) {
-        const LstmSpec& L = kLstm[i];
-        p->i_lstm_w[i] = add(std::string(L.name) + "/conv/W", 25LL * (L.cx + L.C) * 4 * L.C);
-        p->i_lstm_b[i] = add(std::string(L.name) + "/conv/b", 4 * L.C);
-    }
-    const char* lnn[9] = {"norm_enc0", "hidden1", "hidden2", "hidden3", "hidden4", "hidden5", "hidden6", "hidden7", "norm_enc6"};
     const long long lnsz[9] = {32LL * p->H2 * p->W2, 32LL * p->H2 * p->W2, 32LL * p->H2 * p->W2, 64LL * p->H4 * p->W4,
                                64LL * p->H4 * p->W4, 128LL * p->H8 * p->W8, 64LL * p->H4 * p->W4, 32LL * p->H2 * p->W2,
                                64LL * H * W};
-    for (int i = 0; i < 9; ++i) {
-        p->i_ln_g[i] = add(std::string(lnn[i]) + "/norm/gamma", lnsz[i]);
-        p->i_ln_b[i] = add(std::string(lnn[i]) + "/norm/beta", lnsz[i]);
-    }
-    p->i_masks_w = add("masks/W", 64LL * p->NP);
-    p->i_masks_b = add("masks/b", p->NP);
-    p->i_cs_w = add("current_state/W", 50);
-    p->i_cs_b = add("current_state/b", 5);
-    p->i_enc7_w = add("model/enc7/W", 64LL * p->NE);
-    p->i_enc7_b = add("model/enc7/b", p->NE);
-    p->i_head_w = p->i_head_b = p->i_head2_w = p->i_head2_b = -1;
-    if (cfg->model_type == PIVP_MODEL_CDNA) {
-        p->i_head_w = add("model/cdna_kerns/W", (long long)p->K5 * 256);
-        p->i_head_b = add("model/cdna_kerns/b", 25LL * cfg->num_masks);
-    } else if (cfg->model_type == PIVP_MODEL_STP) {
-        p->i_head_w = add("model/stp_input/W", (long long)p->K5 * 256);
-        p->i_head_b = add("model/stp_input/b", 100);
-        p->i_head2_w = add("model/identity_params/W", 600);
-        p->i_head2_b = add("model/identity_params/b", 6);
-    }
-
-    // ---- workspace carve (offsets in floats, 256-B aligned) ----
     size_t off = 0;
     auto carve = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };
     const size_t HW = (size_t)H * W, HW2 = (size_t)p->H2 * p->W2, HW4 = (size_t)p->H4 * p->W4, HW8 = (size_t)p->H8 * p->W8;
@@ -205,7 +159,13 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
     for (int i = 0; i < 7; ++i)       // 2-byte elements in a float-counted workspace
         p->o_wbf16[i] = carve(lstm_bf16_weight_elems(kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C));   // room for the two planes of the split mode
     p->nslabs = train ? T - 1 : 2;
-    p->wg_cap = T - 2 < 1 ? 1 : (T - 2 > WG_BATCH_MAX ? WG_BATCH_MAX : T - 2);   // timesteps t = T-2 .. 1 batch; t = 0 (no h input) goes alone
+    {   // timesteps t = T-2 .. 1 batch (t = 0, no h input, goes alone): as many ring slots as a launch may take timesteps
+        const char* e = getenv("PIVP_WGRAD_BATCH");
+        const int want = e ? atoi(e) : (p->bf16_all ? WG_BATCH_MAX : 1);
+        int cap = T - 2 < 1 ? 1 : (T - 2 > WG_BATCH_MAX ? WG_BATCH_MAX : T - 2);
+        if (want < cap) cap = want < 1 ? 1 : want;
+        p->wg_cap = cap;
+    }
     p->slabs.resize(p->nslabs);
     for (int s = 0; s < p->nslabs; ++s) {
         Slab& S = p->slabs[s];
@@ -259,6 +219,65 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
         }
     }
     p->ws_floats = (long long)off;
+}
+
+extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
+    if (!cfg || !out) return PIVP_ERR_BADARG;
+    if (cfg->batch <= 0 || cfg->seq_len < 2 || cfg->height < 16 || cfg->width < 16) return PIVP_ERR_BADARG;
+    if (cfg->height % 8 || cfg->width % 8) return PIVP_ERR_BADARG;
+    if (cfg->model_type < 0 || cfg->model_type > 2) return PIVP_ERR_BADARG;
+    if (cfg->num_masks < 1 || cfg->num_masks > 11) return PIVP_ERR_BADARG;
+    if (cfg->model_type == PIVP_MODEL_DNA && cfg->num_masks != 1) return PIVP_ERR_BADARG;  // TM:389-390
+    if (cfg->context_frames < 1 || cfg->context_frames >= cfg->seq_len) return PIVP_ERR_BADARG;
+    pivp_plan* p = new pivp_plan();
+    p->cfg = *cfg;
+    const int H = cfg->height, W = cfg->width;
+    p->H2 = H / 2; p->W2 = W / 2; p->H4 = H / 4; p->W4 = W / 4; p->H8 = H / 8; p->W8 = W / 8;
+    p->NP = cfg->num_masks + 1;
+    p->NE = cfg->model_type == PIVP_MODEL_DNA ? 25 : 3;
+    p->K5 = 128 * p->H8 * p->W8;
+    p->ws = nullptr; p->ws_floats = 0; p->last_steps = 0; p->last_sched = false;
+    { const char* e = getenv("PIVP_SIDE_STREAM"); p->use_side = !(e && e[0] == '0'); }
+
+    auto add = [&](const std::string& name, long long n) { p->params.push_back({name, n, nullptr, nullptr, grad_group_of(name)}); return (int)p->params.size() - 1; };
+    const int cin3 = 64 + (cfg->use_state ? 10 : 0);
+    const long long encw[7] = {75 * 32, 9 * 32 * 32, 9 * 64 * 64, (long long)cin3 * 64, 9 * 128 * 128, 9 * 96 * 96, 9 * 64 * 64};
+    const int encb[7] = {32, 32, 64, 64, 128, 96, 64};
+    for (int i = 0; i < 7; ++i) {
+        p->i_enc_w[i] = add("enc" + std::to_string(i) + "/W", encw[i]);
+        p->i_enc_b[i] = add("enc" + std::to_string(i) + "/b", encb[i]);
+    }
+    for (int i = 0; i < 7; ++i) {
+        const LstmSpec& L = kLstm[i];
+        p->i_lstm_w[i] = add(std::string(L.name) + "/conv/W", 25LL * (L.cx + L.C) * 4 * L.C);
+        p->i_lstm_b[i] = add(std::string(L.name) + "/conv/b", 4 * L.C);
+    }
+    const char* lnn[9] = {"norm_enc0", "hidden1", "hidden2", "hidden3", "hidden4", "hidden5", "hidden6", "hidden7", "norm_enc6"};
+    const long long lnsz[9] = {32LL * p->H2 * p->W2, 32LL * p->H2 * p->W2, 32LL * p->H2 * p->W2, 64LL * p->H4 * p->W4,
+                               64LL * p->H4 * p->W4, 128LL * p->H8 * p->W8, 64LL * p->H4 * p->W4, 32LL * p->H2 * p->W2,
+                               64LL * H * W};
+    for (int i = 0; i < 9; ++i) {
+        p->i_ln_g[i] = add(std::string(lnn[i]) + "/norm/gamma", lnsz[i]);
+        p->i_ln_b[i] = add(std::string(lnn[i]) + "/norm/beta", lnsz[i]);
+    }
+    p->i_masks_w = add("masks/W", 64LL * p->NP);
+    p->i_masks_b = add("masks/b", p->NP);
+    p->i_cs_w = add("current_state/W", 50);
+    p->i_cs_b = add("current_state/b", 5);
+    p->i_enc7_w = add("model/enc7/W", 64LL * p->NE);
+    p->i_enc7_b = add("model/enc7/b", p->NE);
+    p->i_head_w = p->i_head_b = p->i_head2_w = p->i_head2_b = -1;
+    if (cfg->model_type == PIVP_MODEL_CDNA) {
+        p->i_head_w = add("model/cdna_kerns/W", (long long)p->K5 * 256);
+        p->i_head_b = add("model/cdna_kerns/b", 25LL * cfg->num_masks);
+    } else if (cfg->model_type == PIVP_MODEL_STP) {
+        p->i_head_w = add("model/stp_input/W", (long long)p->K5 * 256);
+        p->i_head_b = add("model/stp_input/b", 100);
+        p->i_head2_w = add("model/identity_params/W", 600);
+        p->i_head2_b = add("model/identity_params/b", 6);
+    }
+
+    plan_layout(p);
     *out = p;
     return PIVP_OK;
 }
@@ -315,6 +334,7 @@ extern "C" int pivp_plan_set_precision(pivp_plan_t* plan, int precision) {
     plan->lstm_planes = precision == PIVP_PRECISION_BF16X3 ? 2 : 1;
     plan->bf16_all = precision == PIVP_PRECISION_BF16;
     plan->precision = precision;
+    if (!plan->ws) plan_layout(plan);      // the dG rings' depth follows the precision; a bound workspace keeps the layout it was sized for
     return PIVP_OK;
 }
 extern "C" int pivp_plan_get_precision(const pivp_plan_t* plan) { return plan ? plan->precision : PIVP_ERR_BADARG; }
