@@ -54,7 +54,25 @@ __device__ __forceinline__ int ring_swizzle(int row) {
     if constexpr (LSTM && NCH == 16) return ((row >> 1) & 3) | (((row >> 5) & 1) << 2);
     else return (row >> 1) & 7;
 }
-constexpr int NSLOT = 4, DEPTH = 3;    // weight ring slots; taps of prefetch
+// Weight ring: DEP taps of LDS-DMA prefetch in NSL = DEP + 1 slots.  Round 3 ran 3 taps ahead and measured the tap loop at 38 GB/s of weight
+// stream per CU, 800 cycles per tap for 512 of MFMA; a DMA takes ~1.1 us from issue to landing, so three 16-KB taps in flight ARE 38-43 GB/s
+// (Little's law), not the CU's fill rate (the guide's ring GEMM takes in 68 GB/s with 84 KB in flight).  Round 4: as many slots as the
+// 160 KB of LDS hold beside the patch -- 7 of 16 KB for 32-channel blocks (6 taps = 96 KB in flight), 8 of 8 KB for 16-channel ones;
+// the split mode's two patch planes leave the old 4 (16-channel blocks) or 2 (32-channel blocks, LATE schedule).
+// MEASURED (one box, full rebuilds, profiles/r04/NOTES.md): the deep ring is SLOWER -- seven layers at B = 32 188.7 us against 179.9 with 3 taps
+// ahead, at B = 256 994.8 against 970.3, bf16 rollout 2.97 against 2.88 ms, train step 11.93 against 11.72 -- so the in-flight depth was not
+// what held the stream at 38 GB/s per CU; the default stays 3.  The general ring (any depth, counted vmcnt tail) stays, tested at both depths.
+#ifndef PIVP_BF16_DEPTH
+#define PIVP_BF16_DEPTH 3              // taps ahead at most; 0 = the deepest ring that fits
+#endif
+template <int NCH, int PL>
+constexpr int ring_depth() {
+    if (PL == 2 && NCH == 32) return 1;                                          // LATE schedule
+    const int fit = (160 * 1024 - PL * PATCH_BYTES) / (PL * 4 * NCH * 128) - 1;     // slots that fit, minus one = taps ahead
+    const int cap = fit > 7 ? 7 : fit;
+    return (PIVP_BF16_DEPTH > 0 && PIVP_BF16_DEPTH < cap) ? PIVP_BF16_DEPTH : cap;
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 __device__ __forceinline__ float b_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float b_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
@@ -125,7 +143,9 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     // Split mode with 32-channel blocks: two patch planes (92 KB) leave room for TWO 32 KB ring slots only, so the schedule changes: the
     // loaders bring tap it + 1 in during tap it (one tap of lookahead), and the block barrier sits at the END of a tap (LATE).
     constexpr bool LATE = PL == 2 && NCH == 32;
-    constexpr int NSL = LATE ? 2 : NSLOT;
+    constexpr int DEP = ring_depth<NCH, PL>();      // taps of weight prefetch
+    constexpr int NSL = DEP + 1;                    // ring slots
+    static_assert(PL * PATCH_BYTES + NSL * PL * BN * 128 <= 160 * 1024 && DEP >= 1, "the ring must fit beside the patch");
     constexpr int G = BN / 32;                  // global_load_lds per loader thread and tap
     constexpr int TPW = NCH / 16;               // MFMA column tiles per wave
     constexpr int CPW = NCH / 2;                // channels per wave (all 4 gates of a channel stay in one wave)
@@ -240,9 +260,10 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
             wsrc[j] = reinterpret_cast<const unsigned char*>(wb) + (size_t)grow * 128 + piece * 16;
         }
         const size_t wstep = (size_t)PL * N * 128;     // bytes between consecutive (group, tap) weight tiles ([PL][N][64] bf16 each)
-        int issued = 0, i_tap = tap0, i_cg = 0;        // taps issued; the next one to issue
+        int i_slot = 0, i_tap = tap0, i_cg = 0;        // the ring slot of the next tap to issue, and which tap that is
         auto issue_weights = [&]() {
-            const int slot = issued & (NSL - 1);
+            const int slot = i_slot;
+            i_slot = i_slot + 1 == NSL ? 0 : i_slot + 1;
             const size_t goff = (size_t)((cgbase + i_cg) * 25 + i_tap) * wstep;
             i_tap = i_tap == 24 ? 0 : i_tap + 1;
             i_cg += i_tap == tap0 ? 1 : 0;
@@ -254,7 +275,6 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + goff + (size_t)pl * N * 128),
                                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
                 }
-            ++issued;
         };
         if constexpr (LATE) {
             issue_weights();                                   // tap 0
@@ -276,26 +296,36 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
             }
             return;
         }
+        constexpr int DEP0 = DEP < 3 ? DEP : 3;      // taps requested in front of the patch (the patch's loads return behind them)
 #pragma unroll
-        for (int i = 0; i < DEPTH; ++i)
+        for (int i = 0; i < DEP0; ++i)
             if (i < nchunks) issue_weights();
         patch_load(0);
         patch_store();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // taps 0..2 and this thread's part of the patch are in LDS
+#pragma unroll
+        for (int i = DEP0; i < DEP; ++i)             // the rest of the ring: in flight across the barrier
+            if (i < nchunks) issue_weights();
         __builtin_amdgcn_s_barrier();
         int tap = tap0, cg = 0;
         for (int it = 0; it < nchunks; ++it) {
-            // the multiplying waves' mid-tap barrier publishes tap it + 1: this wave's share of it must have landed.  Outstanding
-            // here: taps it + 1 and it + 2 (when they exist).
-            if (it + 2 < nchunks) {
-                if constexpr (G * PL == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // the multiplying waves' mid-tap barrier publishes tap it + 1: this wave's share of it must have landed.  Issued so far:
+            // taps up to it + DEP - 1; the `newer` ones behind tap it + 1 may stay in flight (G * PL DMAs per thread and tap).
+            {
+                int newer = nchunks - it - 2;
+                newer = newer < 0 ? 0 : newer > DEP - 2 ? DEP - 2 : newer;
+                constexpr int Q = G * PL;
+                if (newer <= 0) wait_vmcnt<0>();
+                else if (newer == 1) wait_vmcnt<Q>();
+                else if (newer == 2) wait_vmcnt<2 * Q>();
+                else if (newer == 3) wait_vmcnt<3 * Q>();
+                else if (newer == 4) wait_vmcnt<4 * Q>();
+                else wait_vmcnt<5 * Q>();
+                static_assert(DEP - 2 <= 5 && 5 * Q <= 63, "vmcnt immediates");
             }
             __builtin_amdgcn_s_barrier();
-            // every multiplying wave is past tap it - 1: its ring slot takes tap it + 3
-            if (it + DEPTH < nchunks) issue_weights();
+            // every multiplying wave is past tap it - 1: its ring slot takes tap it + DEP
+            if (it + DEP < nchunks) issue_weights();
             tap = tap == 24 ? 0 : tap + 1;
             if (tap == tap0 && ++cg < ncg) {           // next 64 input channels: all 8 waves restage the patch
                 __syncthreads();
@@ -436,9 +466,9 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     // One tap = 4 k-steps of 16 channels; fragments of the next k-step are requested before the MFMAs of the current one.  The
     // barrier that publishes the NEXT tap's weights sits in the middle of the tap (its skew hides behind queued MFMAs), so the
     // first fragments of the next tap can be requested right after the last k-step.  No VMEM instruction in this loop.
-    int tap = tap0, cg = 0;
+    int tap = tap0, cg = 0, slot = 0;
     for (int it = 0; it < nchunks; ++it) {
-        const int slot = it & (NSLOT - 1);
+        const int nslot = slot + 1 == NSL ? 0 : slot + 1;
         wait_frags(S0{}); read_frags(S1{}, K1{}, tap, slot); mfmas(S0{});
         __builtin_amdgcn_sched_barrier(0);
         wait_frags(S1{}); read_frags(S0{}, K2{}, tap, slot); mfmas(S1{});
@@ -450,15 +480,16 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         tap = tap == 24 ? 0 : tap + 1;
         const bool regroup = tap == tap0;
         wait_frags(S1{});
-        if (!regroup) read_frags(S0{}, K0{}, tap, (it + 1) & (NSLOT - 1));
+        if (!regroup) read_frags(S0{}, K0{}, tap, nslot);
         mfmas(S1{});
         if (regroup && ++cg < ncg) {                   // next 64 input channels: all 8 waves restage the patch
             __syncthreads();                           // every wave is done with the old patch
             patch_load(cg);
             patch_store();
             __syncthreads();
-            read_frags(S0{}, K0{}, tap, (it + 1) & (NSLOT - 1));
+            read_frags(S0{}, K0{}, tap, nslot);
         }
+        slot = nslot;
         __builtin_amdgcn_sched_barrier(0);
     }
     }   // !LATE
@@ -612,7 +643,7 @@ bool convlstm_bf16_ok(const IgemmDesc& d) { return bf16_geometry_ok(d) && d.C > 
 
 template <int NCH, bool LSTM, int PL = 1>
 static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nb, int ksplit, int ncols) {
-    constexpr int lds_bytes = PL * PATCH_BYTES + ((PL == 2 && NCH == 32) ? 2 : NSLOT) * PL * 4 * NCH * 128;
+    constexpr int lds_bytes = PL * PATCH_BYTES + (ring_depth<NCH, PL>() + 1) * PL * 4 * NCH * 128;
     static PerDeviceOnce once;
     if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_bf16_kernel<NCH, LSTM, PL>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     IgemmDesc dd = d;
