@@ -2,6 +2,7 @@
 // generator, the STP parameter regressor, and the fused flat-softmax + transform + compositing
 // kernel that produces the next frame.  "TM" = src/models/train_model.py of the reference.
 #include "pivp_kernels.h"
+#include "skinny_linear.h"
 
 namespace pivp {
 
@@ -135,54 +136,12 @@ int heads_1x1(const float* e6, const float* wm, const float* bm, const float* we
 // wt is K-major with 256 padded columns; x is the NHWC-flat hidden5 (the checkpoint permutes
 // cdna_kerns/W's in-feature axis from c*64+y*8+x to (y*8+x)*128+c at load time).
 // ------------------------------------------------------------------------------------------
-constexpr int LIN_KS = 64;    // K per slice
-#ifndef PIVP_LIN_BG
-#define PIVP_LIN_BG 16
-#endif
-constexpr int LIN_BG = PIVP_LIN_BG;    // batch rows per block
 int cdna_kernel_partials_slices(int K) { return (K + LIN_KS - 1) / LIN_KS; }
-
-// grid (K/64 slices, B/16 groups): 256 blocks at B = 32, K = 8192, so the 8 MB weight matrix streams across the
-// whole chip (twice: once per batch group).  A block's 64 weight loads per thread are all issued before the first FMA.  ACC = float for the CDNA kernels, double for the STP regressor (its output steers a bilinear warp
-// that amplifies a 1e-6 error in theta to ~3e-5 pixels).
-__device__ __forceinline__ float fma_acc(float x, float w, float a) { return fmaf(x, w, a); }
-__device__ __forceinline__ double fma_acc(float x, float w, double a) { return fma((double)x, (double)w, a); }
 
 template <typename ACC>
 __global__ __launch_bounds__(256) void skinny_linear_partials_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                                      float* __restrict__ partials, int B, int K) {
-    __shared__ __attribute__((aligned(16))) float xs[LIN_BG * LIN_KS];
-    const int ks = blockIdx.x, b0 = blockIdx.y * LIN_BG, o = threadIdx.x;
-    const int k0 = ks * LIN_KS;
-    const int nb = min(LIN_BG, B - b0);
-    // the weight loads go out first so that their round trip overlaps the x tile's (they do not depend on it)
-    float wv[LIN_KS];
-#pragma unroll
-    for (int k = 0; k < LIN_KS; ++k) {   // index clamped (x is zero there), not predicated: keeps the 64 loads branch-free
-        const float w = wt[(size_t)min(k0 + k, K - 1) * 256 + o];
-        wv[k] = k0 + k < K ? w : 0.f;
-    }
-    for (int i = threadIdx.x; i < LIN_BG * LIN_KS; i += 256) {
-        const int bb = i / LIN_KS, k = i - bb * LIN_KS;
-        xs[i] = (bb < nb && k0 + k < K) ? x[(size_t)(b0 + bb) * K + k0 + k] : 0.f;
-    }
-    __syncthreads();
-    ACC acc[LIN_BG];
-#pragma unroll
-    for (int bb = 0; bb < LIN_BG; ++bb) acc[bb] = (ACC)0;
-#pragma unroll
-    for (int k = 0; k < LIN_KS; k += 4) {
-#pragma unroll
-        for (int bb = 0; bb < LIN_BG; ++bb) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + bb * LIN_KS + k);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[bb] = fma_acc(xv[e], wv[k + e], acc[bb]);
-        }
-    }
-    // [B][KS][256]: a sample's partials are one contiguous run (a [KS][B][256] image made the finisher's loads a 32-KB
-    // stride, i.e. one L2 channel)
-    const int KS = gridDim.x;
-    for (int bb = 0; bb < nb; ++bb) partials[((size_t)(b0 + bb) * KS + ks) * 256 + o] = (float)acc[bb];
+    skinny_linear_partials_body<ACC>(x, wt, partials, B, K, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 // sum of the K-slice partials of output o of sample b, fixed order (bitwise reproducible), 4 independent chains

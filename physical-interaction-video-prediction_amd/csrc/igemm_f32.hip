@@ -768,6 +768,21 @@ int igemm_conv_ksplit(const IgemmDesc& d) {
     return dgrad_choice(d, bt, bks) ? bks : 1;
 }
 
+// does igemm_conv hand d to igemm_small?  (the same decisions, in the same order, as igemm_conv below)
+bool igemm_conv_takes_small(const IgemmDesc& d) {
+    if (igemm_validate(d, false) != PIVP_OK) return false;
+    const int nt = d.N / 32;
+    if (deconv_tile_ok(d) && !(getenv("PIVP_DECONV_TILE") && atoi(getenv("PIVP_DECONV_TILE")) == 0) &&
+        (long)d.B * (d.Hin / 8) * (d.Win / 16) * nt >= 16) return false;
+    int bt, bks;
+    if (dgrad_choice(d, bt, bks)) return false;
+    static const int mode = [] { const char* e = getenv("PIVP_IGEMM_SMALL"); return e ? atoi(e) : -1; }();
+    const bool can = d.ldo % 4 == 0 && ((uintptr_t)d.out & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0);
+    const long full = (long)((d.M + 127) / 128) * d.nphase, big = full * ((nt + 3) / 4);
+    const int chunks = (d.deconv ? 4 : d.ksize * d.ksize) * ((d.c0 + d.c1) / 32);
+    return can && (mode == 1 || (mode != 0 && (big < 128 || chunks <= 40)));
+}
+
 int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     int rc = igemm_validate(d, false);
     if (rc != PIVP_OK) return rc;

@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "pivp_kernels.h"
+#include "skinny_linear.h"
 
 namespace pivp {
 
@@ -24,7 +25,7 @@ constexpr int TILE = 32 * SP;
 
 // NTB: 32-column tiles per block (the A fragment is reused NTB times; fewer, longer-running blocks).
 template <int NTB, bool IN_LN = false>
-__global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
+__device__ __forceinline__ void igemm_small_body(const IgemmDesc& d, const int bx, const int by, const int gdy) {   // (bx, by) of a grid (., gdy)
     PIVP_SET_MAIN_PRIO();
     constexpr int BN = 32 * NTB;
     constexpr int RP = BN + 4;                                    // row pitch of the partial-sum image
@@ -35,9 +36,9 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int n_nblk = d.N / BN;
-    const int nblk = blockIdx.x % n_nblk, mblk = blockIdx.x / n_nblk;
+    const int nblk = bx % n_nblk, mblk = bx / n_nblk;
     const int m0 = mblk * 32;
-    const int phase = blockIdx.y, py = phase >> 1, px = phase & 1;
+    const int phase = by, py = phase >> 1, px = phase & 1;
     const bool deconv = d.deconv != 0;
     const int nty = deconv ? 1 + py : d.ksize, ntx = deconv ? 1 + px : d.ksize;
     const int ncc = (d.c0 + d.c1) >> 5;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
         __syncthreads();
         if (tid == 0) {
             const int bb = m0 / HWg;
-            float* pp = d.lnb_part + ((size_t)bb * d.lnb_np + (((m0 - bb * HWg) >> 5) * nb_ln + nblk) * (int)gridDim.y + phase) * 2;
+            float* pp = d.lnb_part + ((size_t)bb * d.lnb_np + (((m0 - bb * HWg) >> 5) * nb_ln + nblk) * gdy + phase) * 2;
             pp[0] = (lds[16] + lds[17]) + (lds[18] + lds[19]); pp[1] = (lds[20] + lds[21]) + (lds[22] + lds[23]);
         }
     }
@@ -238,8 +239,34 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
         __syncthreads();
         if (tid == 0) {
             const int bb = m0 / HWg;
-            float* pp = d.ln_part + ((size_t)bb * d.ln_nparts + (((m0 - bb * HWg) >> 5) * n_nblk + nblk) * (int)gridDim.y + phase) * 4;
+            float* pp = d.ln_part + ((size_t)bb * d.ln_nparts + (((m0 - bb * HWg) >> 5) * n_nblk + nblk) * gdy + phase) * 4;
             pp[0] = cnt; pp[1] = mean; pp[2] = (lds[8] + lds[9]) + (lds[10] + lds[11]); pp[3] = 0.f;
+        }
+    }
+}
+
+template <int NTB, bool IN_LN = false>
+__global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
+    igemm_small_body<NTB, IN_LN>(d, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// Two independent, latency-bound launches of the rollout in ONE grid (round 4): the conv `d` (enc4: the 4-phase transposed conv on the 8-wide
+// map, 1,024 blocks of 32 x 32) and the K-slice partial sums of the motion head's Linear (256 blocks).  Both read only hidden5, neither
+// fills the chip, and on one stream they ran back to back: 12.7 + 9.2 us and a launch boundary.  The first gridDim.x - conv_bx block columns,
+// taken phase-major, are the Linear's (K slice, batch group); the rest are the conv's.  Same arithmetic, same order: results are those of the two launches.
+template <bool DBL>
+__global__ __launch_bounds__(256) void igemm_small_partials_kernel(const IgemmDesc d, int conv_bx, const float* __restrict__ x,
+                                                                    const float* __restrict__ wt, float* __restrict__ partials, int B, int K, int KS, int ngrp) {
+    // the Linear's blocks FIRST: workgroups are dispatched in index order, and behind the conv's 1,024 blocks they only started when those had
+    // drained (21.4 us for the grid = the two launches back to back); in front, one per CU, the conv's blocks fill the CUs around them
+    const int part_bx = (int)gridDim.x - conv_bx;
+    if ((int)blockIdx.x >= part_bx) {
+        igemm_small_body<1, false>(d, (int)blockIdx.x - part_bx, blockIdx.y, gridDim.y);
+    } else {
+        const int pi = (int)blockIdx.x * (int)gridDim.y + (int)blockIdx.y;
+        if (pi < KS * ngrp) {
+            if (DBL) skinny_linear_partials_body<double>(x, wt, partials, B, K, pi % KS, pi / KS, KS);
+            else skinny_linear_partials_body<float>(x, wt, partials, B, K, pi % KS, pi / KS, KS);
         }
     }
 }
@@ -281,6 +308,24 @@ int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     if (ntb == 3) hipLaunchKernelGGL(igemm_small_kernel<3>, grid, dim3(256), 0, stream, dd);
     else if (ntb == 2) hipLaunchKernelGGL(igemm_small_kernel<2>, grid, dim3(256), 0, stream, dd);
     else hipLaunchKernelGGL(igemm_small_kernel<1>, grid, dim3(256), 0, stream, dd);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// the conv d (which must be one igemm_small would run with 32-column blocks, no fused epilogues) and the motion head's partial sums in one
+// launch; PIVP_ERR_BADARG when d does not qualify (the caller then launches the two separately)
+int igemm_small_with_partials(const IgemmDesc& d, hipStream_t stream, const float* hidden5, const float* wt, float* partials, int B, int K, int dbl) {
+    PIVP_CHECK_ARG(d.ldo % 4 == 0 && ((uintptr_t)d.out & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0));
+    PIVP_CHECK_ARG(hidden5 && wt && partials && B > 0 && K > 0 && !d.in_g && !d.ln_part && !d.lnb_part);
+    const int mblk = (d.M + 31) / 32, nt = d.N / 32;
+    static const int force = [] { const char* e = getenv("PIVP_SMALL_NTB"); return e ? atoi(e) : 0; }();
+    PIVP_CHECK_ARG(force <= 1 && !(nt % 3 == 0 && (long)mblk * (nt / 3) * d.nphase >= 1024) && !(nt % 2 == 0 && (long)mblk * (nt / 2) * d.nphase >= 1024));
+    const int KS = cdna_kernel_partials_slices(K), ngrp = (B + LIN_BG - 1) / LIN_BG;
+    const int conv_bx = mblk * nt, part_bx = (KS * ngrp + d.nphase - 1) / d.nphase;
+    IgemmDesc dd = d;
+    dd.ln_nparts = 0; dd.lnb_np = 0;
+    const dim3 grid(conv_bx + part_bx, d.nphase);
+    if (dbl) hipLaunchKernelGGL(igemm_small_partials_kernel<true>, grid, dim3(256), 0, stream, dd, conv_bx, hidden5, wt, partials, B, K, KS, ngrp);
+    else hipLaunchKernelGGL(igemm_small_partials_kernel<false>, grid, dim3(256), 0, stream, dd, conv_bx, hidden5, wt, partials, B, K, KS, ngrp);
     return PIVP_LAUNCH_STATUS();
 }
 

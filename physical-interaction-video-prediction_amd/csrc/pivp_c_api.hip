@@ -109,6 +109,34 @@ int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const floa
     return igemm_conv(d, s, ln_nparts);
 }
 
+// run_deconv3x3s2(x, ...) AND motion_partials(x, wt, partials, ...) -- two independent launches that read the same tensor and fill a
+// fraction of the chip each (enc4 and the motion head's Linear on hidden5) -- as ONE grid when the conv is igemm_small's (else the two
+// launches, in that order).  x [B][Hin*Win][cin] contiguous = the Linear's [B][K] input, K = Hin * Win * cin.
+int run_deconv3x3s2_and_partials(const float* x, int cin, const float* w, const float* bias, float* out, int cout, int ldo, int relu,
+                                 int B, int Hin, int Win, hipStream_t s, const float* wt, float* partials, int dbl) {
+    IgemmDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x0 = x; d.c0 = cin; d.ld0 = cin; d.wcin = cin; d.w = w; d.bias = bias;
+    d.B = B; d.Hin = Hin; d.Win = Win; d.Hg = Hin; d.Wg = Win; d.in_step = 1;
+    d.N = cout; d.M = B * Hin * Win;
+    d.nphase = 4; d.deconv = 1; d.ksize = 3; d.pad = 1;
+    const long long b0 = view_bytes(B, Hin, Win, cin), bw = 9LL * cin * cout * 4;
+    if (!fits31(b0) || !fits31(bw)) return PIVP_ERR_BADARG;
+    d.bytes0 = (int)b0; d.bytesw = (int)bw;
+    d.out_step = 2; d.Hout = 2 * Hin; d.Wout = 2 * Win; d.out = out; d.ldo = ldo; d.relu = relu;
+    const int K = Hin * Win * cin;
+    // PIVP_ENC4_PARTIALS=1: one grid.  MEASURED (profiles/r04/NOTES.md): the grid takes 21.4-22.0 us, the two launches 12.7 + 9.2, whichever
+    // kind of block is dispatched first, and the rollout does not move (8.46 against 8.46 ms): they do not overlap.  Default: two launches.
+    static const int fuse = [] { const char* e = getenv("PIVP_ENC4_PARTIALS"); return e ? atoi(e) : 0; }();
+    if (fuse && igemm_conv_takes_small(d)) {
+        const int rc = igemm_small_with_partials(d, s, x, wt, partials, B, K, dbl);
+        if (rc != PIVP_ERR_BADARG) return rc;
+    }
+    int rc = igemm_conv(d, s);
+    if (rc != PIVP_OK) return rc;
+    return motion_partials(x, wt, partials, B, K, dbl, s);
+}
+
 // deconv3x3s2 of concat(LayerNorm(h_raw), x1): the norm of the first c_ln channels (per-element gamma / beta, statistics from the
 // producer's partials) is applied while the all-parities tile kernel stages its patch -- no launch of its own, and the normalised tensor
 // is never written (inference rollouts: [hidden6 | enc1] -> enc5, [hidden7 | enc0] -> enc6).  h_raw [B][Hin*Win][c_ln] contiguous.

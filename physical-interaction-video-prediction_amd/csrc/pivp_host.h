@@ -24,6 +24,8 @@ int run_conv3x3s2_ln(const float* x_raw, int cin, const float* w, const float* b
 int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                     int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0,
                     float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr, int bf16 = 0, const LnbSpec* lnb = nullptr);
+int run_deconv3x3s2_and_partials(const float* x, int cin, const float* w, const float* bias, float* out, int cout, int ldo, int relu,
+                                 int B, int Hin, int Win, hipStream_t s, const float* wt, float* partials, int dbl);   // + motion_partials(x, wt, ...) in the same grid
 // deconv3x3s2 of concat(LayerNorm(h_raw) [c_ln channels], x1 [c1 channels, stride ld1]) with the norm applied while the tile kernel stages its
 // patch (IgemmDesc::in_g); `partials` = the producer's (count, mean, M2) partials of h_raw, never the same buffer as ln_part (the output's)
 bool deconv3x3s2_ln_ok(int c_ln, int c1, int cout, int B, int Hin, int Win);

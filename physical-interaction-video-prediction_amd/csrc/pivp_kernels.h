@@ -109,6 +109,10 @@ int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr)
 int igemm_conv_ksplit(const IgemmDesc& d);   // the K split igemm_conv will use for d (> 1: atomics into a destination the caller must zero)
 int igemm_validate(const IgemmDesc& d, bool lstm);   // argument checks shared by the igemm launchers (igemm_f32.hip)
 int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr);
+bool igemm_conv_takes_small(const IgemmDesc& d);   // would igemm_conv hand d to igemm_small?
+// the conv d and the K-slice partial sums of the motion head's Linear (motion_partials) in ONE grid; PIVP_ERR_BADARG (nothing launched)
+// when d is not a conv igemm_small runs with 32-column blocks and no fused epilogue
+int igemm_small_with_partials(const IgemmDesc& d, hipStream_t stream, const float* hidden5, const float* wt, float* partials, int B, int K, int dbl);
 bool igemm_in_ln_ok(const IgemmDesc& d);   // can igemm_small apply d.in_g's LayerNorm while staging x0?
 // transposed 3x3 s2 conv, all four output parities per block (csrc/deconv_tile.hip); d validated by igemm_validate
 bool deconv_tile_ok(const IgemmDesc& d);

@@ -459,6 +459,17 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     // (hidden5's norm was folded the same way into enc4's four-phase form and the motion head's Linear, which then has to run here, in front
     // of lstm6: the two consumers lost more than the launch saves, rollout 8.52 -> 8.60 ms.  It keeps its own launch.)
     RC(ln(5, ws + S.h[4], ws + S.n5, n8, 128, 128, 0, np));
+    // enc4 and the motion head's Linear both read hidden5 and nothing else: when the output side runs as frame_head (which finishes the
+    // Linear's partial sums itself), the two share ONE grid here -- 1,024 + 256 blocks that each filled a fraction of the chip
+    static const int use_fh = [] { const char* e = getenv("PIVP_FRAME_HEAD"); return e ? atoi(e) : 1; }();
+    const bool fh = use_fh && (use_fh >= 2 ? frame_head_ok(c.model_type, B, H, W, c.num_masks) : frame_head_pays(c.model_type, B, H, W, c.num_masks));
+    const bool fh_fin = fh && c.model_type != PIVP_MODEL_DNA && frame_head_finishes(p->K5);
+    bool partials_done = false;
+    if (fh_fin && !p->bf16_all && p->lstm_planes != 2) {
+        RC(run_deconv3x3s2_and_partials(ws + S.n5, 128, P(p, p->i_enc_w[4]), P(p, p->i_enc_b[4]), ws + S.e4, 128, 128, 1, B, p->H8, p->W8, s,
+                                        P(p, p->i_head_w), ws + p->o_linpart, c.model_type == PIVP_MODEL_STP ? 1 : 0));
+        partials_done = true;
+    } else
     RC(run_deconv3x3s2(ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), P(p, p->i_enc_b[4]), ws + S.e4, 128, 128, 1, B, p->H8, p->W8, s, 0,
                        nullptr, 0, nullptr, p->bf16_all ? 1 : p->lstm_planes == 2 ? 2 : 0));
     // group 5 (TM:600): lstm6 -> hidden6 -> concat(., enc1) -> enc5 -> relu
@@ -500,17 +511,16 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     // heads (TM:711-728).  One launch (csrc/frame_head.hip) for norm_enc6 + relu + the 1x1 heads + the motion head's finisher + flat softmax +
     // transform + compositing, behind the Linear's partial sums: bit-identical to the four launches below it, which remain for geometries
     // it does not take or where it is slower (frames wider than 64: frame_head_pays; PIVP_FRAME_HEAD=0 forces them, 2 forces the fused launch).  The softmaxed masks are kept for the rollout's last step only (pivp_get_tap).
-    static const int use_fh = [] { const char* e = getenv("PIVP_FRAME_HEAD"); return e ? atoi(e) : 1; }();
-    if (use_fh && np > 0 && (use_fh >= 2 ? frame_head_ok(c.model_type, B, H, W, c.num_masks) : frame_head_pays(c.model_type, B, H, W, c.num_masks))) {
+    if (fh && np > 0) {
         const bool fin = c.model_type == PIVP_MODEL_DNA || frame_head_finishes(p->K5);
         FrameHeadArgs a;
         memset(&a, 0, sizeof(a));
         if (c.model_type == PIVP_MODEL_CDNA) {
-            if (fin) RC(motion_partials(ws + S.n5, P(p, p->i_head_w), ws + p->o_linpart, B, p->K5, 0, s));
+            if (fin) { if (!partials_done) RC(motion_partials(ws + S.n5, P(p, p->i_head_w), ws + p->o_linpart, B, p->K5, 0, s)); }
             else RC(cdna_kernels(ws + S.n5, P(p, p->i_head_w), P(p, p->i_head_b), ws + p->o_linpart, ws + S.kerns, B, p->K5, c.num_masks, s, ws + S.vpre));
             a.aux = ws + S.kerns; a.kerns_out = ws + S.kerns;
         } else if (c.model_type == PIVP_MODEL_STP) {
-            if (fin) RC(motion_partials(ws + S.n5, P(p, p->i_head_w), ws + p->o_linpart, B, p->K5, 1, s));
+            if (fin) { if (!partials_done) RC(motion_partials(ws + S.n5, P(p, p->i_head_w), ws + p->o_linpart, B, p->K5, 1, s)); }
             else RC(stp_params(ws + S.n5, P(p, p->i_head_w), P(p, p->i_head_b), P(p, p->i_head2_w), P(p, p->i_head2_b), ws + p->o_linpart,
                                ws + S.theta, B, p->K5, s, ws + S.vpre));
             a.aux = ws + S.theta; a.kerns_out = ws + S.theta; a.w2 = P(p, p->i_head2_w); a.b2 = P(p, p->i_head2_b);
