@@ -29,6 +29,7 @@ constexpr int FH_TILE = 64 * FH_XP;   // floats per wave tile
 constexpr int FH_KL = 11 * 28;        // CDNA kernel table [11][28]
 constexpr int FH_MAXKS = 128;         // most K slices the in-kernel finisher takes (every block of a sample re-reads its KS x 1 KB of partial sums)
 constexpr int FH_HP = 68;             // floats per halo row (272 B)
+constexpr int FH_WP = 68;             // floats per row of the weight table [32 outputs][64 k]: per-lane rows (MFMA B operand, halo dots) read conflict-free
 constexpr int FH_HW = 4;              // waves per block: at 64-wide frames a band is four 64-pixel tiles + the halo tile (wave 0 takes it second)
 constexpr int FH_NT = 64 * FH_HW;     // 256 threads x 256 registers: two blocks per CU wherever the dispatcher puts their waves
 
@@ -58,9 +59,9 @@ __global__ __launch_bounds__(FH_NT, 2) void frame_head_kernel(const FrameHeadArg
     const int G = np / NP + 2;
     const int PW = W + 4;
     // ---- LDS carve -----------------------------------------------------------------------------------------------------------
-    float* wl = sm;                              // [MAXO][64] + [MAXO] bias (padded to 16)
-    float* bl = wl + MAXO * 64;
-    float* lg = bl + 16 * ((MAXO + 15) / 16);    // [NP][win] mask logits of the band's windows
+    float* wl = sm;                              // [32][FH_WP] weights (rows past NO: zeros) + [32] bias
+    float* bl = wl + 32 * FH_WP;
+    float* lg = bl + 32;                         // [NP][win] mask logits of the band's windows
     float* l0t = lg + ((NP * win + 3) & ~3);     // [3][np] sigmoid(enc7) (CDNA / STP)
     float* kl = l0t + (MODE == 2 ? 0 : 3 * np);  // [11][28] CDNA kernels
     float* vs = kl + FH_KL;                      // [256] finisher scratch
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(FH_NT, 2) void frame_head_kernel(const FrameHeadArg
         const int raw = hs < hn ? p0 - hn + hs : p0 + np + (hs - hn);
         return raw < 0 ? raw + HW : raw >= HW ? raw - HW : raw;
     };
-    constexpr int WIT = (MAXO + FH_HW - 1) / FH_HW;      // thread = (k = lane, outputs wave, wave + 4, ...): no run-time division
+    constexpr int WIT = 32 / FH_HW;              // thread = (k = lane, outputs wave, wave + 4, ...): no run-time division
     float wv[WIT];
 #pragma unroll
     for (int u = 0; u < WIT; ++u) {
@@ -148,9 +149,9 @@ __global__ __launch_bounds__(FH_NT, 2) void frame_head_kernel(const FrameHeadArg
 #pragma unroll
     for (int u = 0; u < WIT; ++u) {
         const int o = wave + FH_HW * u;
-        if (o < NO) wl[o * 64 + lane] = wv[u];
+        wl[o * FH_WP + lane] = o < NO ? wv[u] : 0.f;       // rows NO .. 31: the unused columns of the 32-wide MFMA tile
     }
-    if (tid < NO) bl[tid] = bv;
+    if (tid < 32) bl[tid] = bv;
     FH_STAMP(1);
     float mean, rstd;
     ln_merge_partials(a.ln_part, b, a.ln_nparts, a.eps, mean, rstd);
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(FH_NT, 2) void frame_head_kernel(const FrameHeadArg
     for (int i = tid; i < 2 * hn * NP; i += FH_NT) {
         const int hs = i / NP, o = i - hs * NP;
         const float* xrow = hal + hs * FH_HP;
-        const float* wo = wl + o * 64;
+        const float* wo = wl + o * FH_WP;
         float sacc = bl[o];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -190,8 +191,15 @@ __global__ __launch_bounds__(FH_NT, 2) void frame_head_kernel(const FrameHeadArg
     }
 
     // ---- heads: one 64-pixel tile per wave and turn, 32 channels per pass; the loads of pass i + 1 are in flight while pass i is multiplied ----
+    // The 1x1 mixes are the dense contractions of this model's heads (BASELINE.json north_star): they run on the fp32 matrix cores.
+    // v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain (C first, then the k of lanes 0-31, then that of lanes 32-63), so with the bias as
+    // C and instruction s fed channels 2s (lanes 0-31) and 2s + 1 (lanes 32-63) an output is BIT-identical to heads_1x1_kernel's scalar
+    // chain.  Tile: 32 pixels x 32 outputs (NO of them real), two per wave; a lane's ds_read_b128 of its pixel / output row brings four
+    // consecutive k of which its half of the wave uses two.  (Scalar form: 480 FMAs + 120 wave-uniform LDS reads per pass, 3.2 us.)
     {
-        float acc[MAXO];
+        f32x16 macc[2];
+        const float* brow = wl + (lane & 31) * FH_WP;
+        const int half = lane >> 5;
         for (int t = wave; t < ntile; t += FH_HW) {
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
@@ -209,27 +217,38 @@ __global__ __launch_bounds__(FH_NT, 2) void frame_head_kernel(const FrameHeadArg
                 // the next pass's loads: the other half of this tile, or the first half of the wave's next tile
                 if (hh == 0) issue(t, 1);
                 else if (t + FH_HW < ntile) issue(t + FH_HW, 0);
-                float xr[32];
+                if (hh == 0) {
+                    const float bias = bl[lane & 31];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(mt + lane * FH_XP + q * 4);
-                    xr[q * 4] = v[0]; xr[q * 4 + 1] = v[1]; xr[q * 4 + 2] = v[2]; xr[q * 4 + 3] = v[3];
+                    for (int r = 0; r < 16; ++r) { macc[0][r] = bias; macc[1][r] = bias; }
                 }
 #pragma unroll
-                for (int o = 0; o < MAXO; ++o) {
-                    if (o < NO) {
-                        const float* wo = wl + o * 64 + hh * 32;
-                        float s = hh == 0 ? bl[o] : acc[o];
+                for (int q = 0; q < 8; ++q) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(mt + (lane & 31) * FH_XP + q * 4);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(mt + (32 + (lane & 31)) * FH_XP + q * 4);
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(brow + hh * 32 + q * 4);
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wo + q * 4);
-                            s = fmaf(xr[q * 4], w4[0], s); s = fmaf(xr[q * 4 + 1], w4[1], s);
-                            s = fmaf(xr[q * 4 + 2], w4[2], s); s = fmaf(xr[q * 4 + 3], w4[3], s);
-                        }
-                        acc[o] = s;
+                    for (int u = 0; u < 2; ++u) {            // instruction 2q + u: channels 4q + 2u (lanes 0-31) and 4q + 2u + 1 (lanes 32-63)
+                        const float bv2 = half ? bq[2 * u + 1] : bq[2 * u];
+                        macc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? a0[2 * u + 1] : a0[2 * u], bv2, macc[0], 0, 0, 0);
+                        macc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? a1[2 * u + 1] : a1[2 * u], bv2, macc[1], 0, 0, 0);
                     }
                 }
                 FH_STAMP(5 + 2 * hh);
+            }
+            // accumulator register r of M tile m2 = pixel 32 m2 + (r & 3) + 8 (r >> 2) + 4 half of the tile, output column = lane & 31: back
+            // through the wave's (dead) transposition tile to "lane = pixel", so that every lane finishes one pixel's outputs (with the
+            // outputs left on their columns, 3 lanes did all of enc7's sigmoids and scattered stores: 4.3 us against 1.3)
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mt[(m2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * FH_XP + (lane & 31)] = macc[m2][r];
+            float acc[MAXO];
+#pragma unroll
+            for (int q = 0; q < (MAXO + 3) / 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(mt + lane * FH_XP + q * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (q * 4 + e < MAXO) acc[q * 4 + e] = v[e];
             }
             {
                 const int pp = t * 64 + lane, p = p0 + pp;
@@ -473,10 +492,8 @@ __global__ __launch_bounds__(FH_NT, 2) void frame_head_kernel(const FrameHeadArg
 }
 
 static size_t frame_head_lds_floats(int mode, int W, int NM) {
-    const int NE = mode == 2 ? 25 : 3, MAXO = mode == 2 ? 27 : 15;
-    (void)NE;
     const int NP = NM + 1, np = FH_TR * W, win = np + 2 * (NP - 1), G = np / NP + 2, PW = W + 4;
-    size_t f = (size_t)MAXO * 64 + 16 * ((MAXO + 15) / 16) + ((NP * win + 3) & ~3) + (mode == 2 ? 0 : 3 * np) + FH_KL + 256 + 8;
+    size_t f = (size_t)32 * FH_WP + 32 + ((NP * win + 3) & ~3) + (mode == 2 ? 0 : 3 * np) + FH_KL + 256 + 8;
     f += ((3 * (FH_TR + 4) * PW + 3) & ~3) + 24 * FH_HP;
     const size_t un_tiles = (size_t)FH_HW * FH_TILE, un_comp = (size_t)2 * NP * G;
     return f + (un_tiles > un_comp ? un_tiles : un_comp);
