@@ -24,7 +24,8 @@ Chainer 2.0.1 semantics relied upon:
   * L.LayerNormalization: eps=1e-6 (link default), biased variance over axis 1, gamma/beta per element
   * F.depthwise_convolution_2d(x (N,C,H,W), W (D,C,kh,kw)) -> (N, C*D, H, W), out channel c*D+d
   * F.softmax axis=1, F.mean_squared_error = mean over all elements
-  * F.spatial_transformer_grid / _sampler: align-corners bilinear, zero outside
+  * F.spatial_transformer_grid / _sampler: align-corners bilinear; out-of-range samples follow `stp_border`: 'clamp' (the default here:
+    2.0.x clips the sample coordinates to the image, as recollected: SURVEY App. C) or 'zeros' (Chainer >= 3 reads zero outside)
 """
 from __future__ import annotations
 
