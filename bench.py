@@ -77,8 +77,9 @@ def build_parser():
                     help='rollout (default): `value` is the rollout and the train step is reported in `train`; train: only the '
                          'train step runs and `value` is its frames/s (profiling runs)')
     ap.add_argument('--no-train', action='store_true', help='rollout mode: skip the train leg')
+    ap.add_argument('--no-bf16x6', action='store_true', help='fp32 rollout runs: skip the additional three-piece rollout leg (`rollout_bf16x6`)')
     ap.add_argument('--no-bf16-train', action='store_true', help='fp32 runs: skip the additional bf16 train leg (`train_bf16`, config 3\'s arithmetic)')
-    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'bf16x3'],
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'bf16x3', 'bf16x6'],
                     help='fp32: the parity path and the headline metric (config 2). bf16: ConvLSTM gate convolutions with bf16 operands, '
                          'fp32 accumulation (config 3); reports its per-pixel error instead of meeting the 1e-4 gate')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -280,6 +281,36 @@ def main(argv=None):
             elapsed, _ = timed(lambda: time.sleep(0.001), args.steps, args.warmup, sync, barrier)
             elapsed = max_over_ranks(elapsed); loss_val = 0.0
 
+        # ---- leg 1b (fp32 rollout runs): the same rollout with the gate convolutions as six bf16 MFMAs per product (three pieces per fp32 operand:
+        # fp32-grade products at a 417 TFLOP/s ceiling).  An ADDITIONAL object, never `value`; `max_l2_vs_f32_rollout` is the largest per-pixel L2
+        # between its frames and the fp32 rollout's on this run's input (the gate against the float64 oracle is tests/test_gpu_trained.py's).
+        x6_obj = None
+        if do_rollout and not dry and args.precision == 'fp32' and not args.no_bf16x6:
+            try:
+                m6 = pivp_amd.Model(nm, prefix='bench', device=dev, keep_activations=False, precision='bf16x6', **kinds)
+
+                def x6_step():
+                    m6.reset_state()
+                    return m6([images, actions, states], 0)
+                x6_step()
+                m6._flat_params.copy_(model._flat_params)            # the fp32 leg's weights (parameters are lazily sized: after one call)
+                t6, _ = timed(x6_step, args.steps, args.warmup, sync, barrier)
+                t6 = max_over_ranks(t6)
+                rollout_step()
+                d = torch.stack(m6.gen_images).double() - torch.stack(model.gen_images).double()
+                l2 = float(d.pow(2).sum(dim=2).sqrt().max())
+                x6_obj = {'ms_per_step': round(t6 / args.steps * 1e3, 3), 'frames_per_s': round(world * B * (T - 1) * args.steps / t6, 1),
+                          'max_l2_vs_f32_rollout': l2,
+                          'dtype': 'f32 operands of the ConvLSTM forward as 3 bf16 pieces, 6 bf16 MFMAs per product (layers on 8-wide maps: the f32 kernel)'}
+                if rank == 0 and not args.no_roofline:
+                    r6 = roofline_pass(args, m6, x6_step, t6, np, torch, precision='bf16x6')
+                    x6_obj.update({'achieved_tflops': r6['achieved'], 'peak_tflops': r6['peak'], 'frac': r6['frac'], 'per_layer_tflops': r6['per_layer_tflops'],
+                                   'layers_in_this_arithmetic': r6['layers']})
+                del m6
+            except Exception as e:
+                sys.stderr.write('bench.py: rollout_bf16x6 leg failed (%s: %s)\n' % (type(e).__name__, e))
+                x6_obj = None
+
         # ---- leg 2: the data-parallel train step (the run's precision; in the default fp32 run also config 3's bf16 arithmetic) ----------
         train_obj = train_bf16_obj = None
         tmodel = opt = None
@@ -356,7 +387,8 @@ def main(argv=None):
                 'allreduce_algo': algo if world > 1 else 'none (1 rank; a data-parallel run of this precision uses %s)' % ('rs_ag' if precision == 'bf16' else 'allreduce'),
                 'allreduce_algo_ms_per_step': compare,
                 'dtype': {'fp32': 'f32', 'bf16': 'bf16 ConvLSTM / enc5 / enc6 operands, f32 accumulate, gradients and optimizer',
-                          'bf16x3': 'f32 as 2 bf16 pieces in the ConvLSTM forward and data gradients'}[precision],
+                          'bf16x3': 'f32 as 2 bf16 pieces in the ConvLSTM forward and data gradients',
+                          'bf16x6': 'f32 as 3 bf16 pieces in the ConvLSTM forward (6 MFMAs per product), f32 backward'}[precision],
                 'workload': 'optimizer.update (TM:950): forward + BPTT backward + gradient all-reduce + Adam, schedsamp_k=-1, batch %d/GPU' % B,
                 'loss': float(tloss),
             }
@@ -412,7 +444,8 @@ def main(argv=None):
             'scaling': 'weak',
             'vs_baseline': None,
             'dtype': {'fp32': 'f32', 'bf16': 'bf16 ConvLSTM operands, f32 accumulate and elsewhere',
-                      'bf16x3': 'f32 operands of the ConvLSTM forward as 2 bf16 pieces (3 bf16 MFMAs per product), f32 accumulate and elsewhere'}[args.precision],
+                      'bf16x3': 'f32 operands of the ConvLSTM forward as 2 bf16 pieces (3 bf16 MFMAs per product), f32 accumulate and elsewhere',
+                      'bf16x6': 'f32 operands of the ConvLSTM forward as 3 bf16 pieces (6 bf16 MFMAs per product: fp32-grade products), f32 accumulate and elsewhere'}[args.precision],
             'data': ('synthetic' if not args.share_gpu else 'synthetic; REHEARSAL: %d ranks share one GPU over gloo, not a multi-GPU measurement' % world)
                     if not dry else 'none: --dry run of the host logic on CPU (gloo, stub kernels); NOT a measurement',
             'config': {'workload': preset + '%s %s, batch %d/GPU, %d-frame %dx%dx3 sequences, action-conditioned, num_masks=%d, '
@@ -425,6 +458,8 @@ def main(argv=None):
             'roofline': roofline,
             'cpu_baseline': cpu_baseline,
         }
+        if x6_obj is not None:
+            out['rollout_bf16x6'] = x6_obj
         if not train_mode:
             out['train'] = train_obj
             if train_bf16_obj is not None:
@@ -438,7 +473,8 @@ def main(argv=None):
         dist.destroy_process_group()
 
 
-def roofline_pass(args, model, step, elapsed, np, torch):
+def roofline_pass(args, model, step, elapsed, np, torch, precision=None):
+    precision = precision or args.precision
     plan = model._active
     lib = plan.lib
     lib.pivp_plan_set_profiling(plan.h, 1)
@@ -454,26 +490,32 @@ def roofline_pass(args, model, step, elapsed, np, torch):
         assert rc == 0, rc
         ms_tot += np.array(ms[:]); n_tot += np.array(n[:]); flops += np.array(fl[:])
     lib.pivp_plan_set_profiling(plan.h, 0)
-    total_flops = float(flops.sum())
-    total_s = float(ms_tot.sum()) * 1e-3
+    layers = list(range(7))
+    if precision == 'bf16x6':      # layers on maps that are not a multiple of 16 wide run the fp32 kernel in this mode: not part of its fraction
+        widths = [args.size // 2, args.size // 2, args.size // 4, args.size // 4, args.size // 8, args.size // 4, args.size // 2]
+        layers = [i for i in range(7) if widths[i] % 16 == 0]
+    total_flops = float(flops[layers].sum())
+    total_s = float(ms_tot[layers].sum()) * 1e-3
     achieved = total_flops / total_s / 1e12
-    bf16 = args.precision != 'fp32'
-    # bf16x3 executes three bf16 MFMAs per algorithmic product: its ceiling in algorithmic flops is a third of the bf16 peak
-    peak = (PEAK_BF16_MFMA_TFLOPS / (3.0 if args.precision == 'bf16x3' else 1.0)) if bf16 else PEAK_FP32_MFMA_TFLOPS
+    bf16 = precision != 'fp32'
+    # bf16x3 / bf16x6 execute three / six bf16 MFMAs per algorithmic product: their ceiling in algorithmic flops is a third / a sixth of the bf16 peak
+    peak = (PEAK_BF16_MFMA_TFLOPS / {'bf16x3': 3.0, 'bf16x6': 6.0}.get(precision, 1.0)) if bf16 else PEAK_FP32_MFMA_TFLOPS
     return {
+        'layers': ['lstm%d' % (i + 1) for i in layers],
         'bound': 'mfma',
         'kernel': ('convlstm_bf16_kernel<NCH> (ConvLSTM 5x5 gate conv, %s, + fused gates)' %
-                   ('bf16 operands' if args.precision == 'bf16' else 'fp32 operands as 2 bf16 pieces, 3 MFMAs per product') if bf16 else
+                   {'bf16': 'bf16 operands', 'bf16x3': 'fp32 operands as 2 bf16 pieces, 3 MFMAs per product',
+                    'bf16x6': 'fp32 operands as 3 bf16 pieces, 6 MFMAs per product'}[precision] if bf16 else
                    'igemm_f32_kernel<WM,WN,4,true> (ConvLSTM 5x5 gate conv + fused gates)'),
         'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
         'frac': round(achieved / peak, 4),
         'traffic': _pmc_traffic(bf16),
         'traffic_source': 'HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (profiles/*/pmc_traffic%s.json: '
                           'FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE); not measured in this run' % ('_bf16' if bf16 else ''),
-        'launches': int(n_tot.sum()), 'avg_launch_us': round(total_s / max(1, int(n_tot.sum())) * 1e6, 2),
-        'algorithmic_gflop_per_launch': round(total_flops / max(1, int(n_tot.sum())) / 1e9, 3),
+        'launches': int(n_tot[layers].sum()), 'avg_launch_us': round(total_s / max(1, int(n_tot[layers].sum())) * 1e6, 2),
+        'algorithmic_gflop_per_launch': round(total_flops / max(1, int(n_tot[layers].sum())) / 1e9, 3),
         'per_layer_tflops': {('lstm%d' % (i + 1)): round(float(flops[i] / (ms_tot[i] * 1e-3) / 1e12), 2)
-                             for i in range(7) if ms_tot[i] > 0},
+                             for i in layers if ms_tot[i] > 0},
         'share_of_step_time': round(total_s / args.steps / (elapsed / args.steps), 3),
         'ms_per_step_with_events': round(t_prof / args.steps * 1e3, 3),
     }

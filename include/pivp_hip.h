@@ -37,8 +37,9 @@ extern "C" {
 #define PIVP_PRECISION_F32 0
 #define PIVP_PRECISION_BF16 1
 #define PIVP_PRECISION_BF16X3 2
+#define PIVP_PRECISION_BF16X6 3
 
-int pivp_abi_version(void);   /* 9 (9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+int pivp_abi_version(void);   /* 10 (10: + PIVP_PRECISION_BF16X6, pivp_convlstm_bf16x6; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
                                  5: + bf16 ConvLSTM, pivp_plan_set_precision, 6: + pivp_plan_set_group_join / pivp_plan_group_wait) */
 
 /* sha256 (hex) of the sources this library was compiled from (every .hip and .h under csrc/, and this header), embedded by build.py.  The Python
@@ -81,7 +82,10 @@ int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr);
  * every rollout / backward sweep).
  * PIVP_PRECISION_BF16X3 = the split mode: only the FORWARD gate convolutions and the enc5 / enc6 transposed convs change -- each fp32 operand travels as two bf16 numbers (hi, lo)
  * and a product is three bf16 MFMAs, 16 bits of product mantissa, fp32 accumulation -- and the result stays inside the 1e-4 per-pixel gate
- * (4.4e-5 on the config 1 rollout; tests/test_gpu_bf16.py); the backward pass and every other op are the fp32 ones.  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
+ * (4.4e-5 on the config 1 rollout; tests/test_gpu_bf16.py); the backward pass and every other op are the fp32 ones.
+ * PIVP_PRECISION_BF16X6 = three bf16 pieces per fp32 operand (hi + mid + lo = v exactly) and the six products of weight >= 2^-16, i.e. fp32-grade
+ * gate pre-activations computed on the bf16 matrix cores: only the FORWARD gate convolutions of layers whose map is a multiple of 16 wide change (8-wide
+ * maps -- lstm5 on 64 x 64 frames -- run the fp32 kernel); every other op and the whole backward pass are the fp32 ones.  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
 int pivp_plan_set_precision(pivp_plan_t* plan, int precision);
 int pivp_plan_get_precision(const pivp_plan_t* plan);
 
@@ -188,6 +192,14 @@ int pivp_pack_lstm_bf16x3(const float* w, void* w_bf16, int cin_total, int C, vo
 int pivp_convlstm_bf16x3(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
                          const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
                          int* ln_nparts, int B, int H, int W, int nch, void* stream);
+
+/* Three-piece form (precision mode PIVP_PRECISION_BF16X6): hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid); a product is hi*hi on the main
+ * accumulator plus lo*hi + hi*lo + mid*mid + mid*hi + hi*mid on a second one (six bf16 MFMAs, fp32 accumulation): what is dropped is below 2^-24 of the
+ * product.  W % 16 == 0 and C % 16 == 0 only.  w_bf16 = pivp_pack_lstm_bf16x6(w): 3 * pivp_lstm_bf16_weight_elems(cx + C, C) 2-byte elements. */
+int pivp_pack_lstm_bf16x6(const float* w, void* w_bf16, int cin_total, int C, void* stream);
+int pivp_convlstm_bf16x6(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
+                         const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
+                         int* ln_nparts, int B, int H, int W, void* stream);
 
 /* pivp_deconv3x3s2 with bf16 operands (precision mode bf16): x and w are rounded to bf16 on the way into the matrix pipe, accumulation, bias
  * and ReLU stay fp32.  Only maps with Hin % 8 == 0 and Win % 16 == 0 (and at least 16 tiles x column blocks) run in bf16; the call is the fp32 op otherwise. */

@@ -43,6 +43,9 @@ constexpr int RP16 = 3072;             // 20 px * 144 B = 2880 -> 12 * 256
 constexpr int RP8 = 1920;              // 12 px * 144 B = 1728 -> 7 * 256 + 128
 constexpr int PATCH_BYTES = 2 * PH * RP8;   // 46,080 (= 320 * 144 as before); one 8 x 16 tile: 12 * 3072 = 36,864
 static_assert(PH * RP16 <= PATCH_BYTES && RP16 % 256 == 0 && RP8 % 256 == 128 && RP16 >= 21 * PP && RP8 >= 13 * PP, "patch rows");
+// bytes of one patch plane: the three-piece mode (PL = 3) serves 16-wide tiles only, whose 12 rows need 36,864 B: three planes then leave
+// room for two 24-KB ring slots (16-channel blocks), which the two-image 8 x 8 layout's 46,080 would not
+template <int PL> constexpr int patch_plane_bytes() { return PL == 3 ? PH * RP16 : PATCH_BYTES; }
 // swizzle of a weight row's eight 16-B pieces (ring slot = [row][64 bf16] = 128-B rows, so two consecutive rows span the 64 banks):
 // the 16 lanes of a ds_read_b128 phase read one piece each from 16 different rows and are conflict-free iff the 8 even and the 8
 // odd rows among them all use different pieces.  Rows of a phase: 32 consecutive MFMA columns are ring rows r0 + {0-3, 12-15, 20-27}
@@ -67,8 +70,8 @@ __device__ __forceinline__ int ring_swizzle(int row) {
 #endif
 template <int NCH, int PL>
 constexpr int ring_depth() {
-    if (PL == 2 && NCH == 32) return 1;                                          // LATE schedule
-    const int fit = (160 * 1024 - PL * PATCH_BYTES) / (PL * 4 * NCH * 128) - 1;     // slots that fit, minus one = taps ahead
+    if ((PL == 2 && NCH == 32) || PL == 3) return 1;                             // LATE schedule
+    const int fit = (160 * 1024 - PL * patch_plane_bytes<PL>()) / (PL * 4 * NCH * 128) - 1;     // slots that fit, minus one = taps ahead
     const int cap = fit > 7 ? 7 : fit;
     return (PIVP_BF16_DEPTH > 0 && PIVP_BF16_DEPTH < cap) ? PIVP_BF16_DEPTH : cap;
 }
@@ -101,10 +104,14 @@ __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x
 __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& e, bf16x8& f, bf16x8& g, bf16x8& h, bf16x8& i) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i));
 }
+__device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& e, bf16x8& f, bf16x8& g, bf16x8& h, bf16x8& i, bf16x8& j) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i), "+v"(j));
+}
 }  // namespace
 
 // fp32 K-inner packed weights [25][wcin/32][N][32] -> bf16 [ceil(wcin/64)][25][PL][Np][64], channels past wcin and rows past N zero.
-// PL = 1: plane 0 = bf16(w).  PL = 2 (split mode): plane 0 = hi = bf16(w), plane 1 = lo = bf16(w - hi).
+// PL = 1: plane 0 = bf16(w).  PL = 2 (split mode): plane 0 = hi = bf16(w), plane 1 = lo = bf16(w - hi).  PL = 3 (three pieces): plane 1 =
+// mid = bf16(w - hi), plane 2 = lo = bf16((w - hi) - mid); both differences are exact in fp32, so hi + mid + lo = w.
 __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int N, int Np, int PL, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -118,7 +125,8 @@ __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned shor
     float v = 0.f;
     if (ch < wcin && n < N) v = w[(((long)tap * (wcin >> 5) + (ch >> 5)) * N + n) * 32 + (ch & 31)];
     __bf16 h = (__bf16)v;
-    if (pl == 1) h = (__bf16)(v - (float)h);
+    if (pl >= 1) { v -= (float)h; h = (__bf16)v; }
+    if (pl == 2) { v -= (float)h; h = (__bf16)v; }
     wb[i] = __builtin_bit_cast(unsigned short, h);
 }
 
@@ -135,6 +143,11 @@ __device__ long long pivp_bf16_stamps[2048 * 8];
 // PL = 2: split mode.  Every fp32 operand travels as TWO bf16 numbers, hi = bf16(v) and lo = bf16(v - hi) (two patch planes, two weight
 // planes per ring slot), and a product a * b is formed as a_lo * b_hi + a_hi * b_lo + a_hi * b_hi on three MFMAs (each exact in fp32):
 // 16 bits of product mantissa instead of 8, 3e-5 instead of 2e-2 per-pixel on the config 1 rollout (scripts/split_bf16_study.py).
+// PL = 3: THREE pieces per operand (hi + mid + lo = v exactly) and the six products whose weight is >= 2^-16 of the leading one:
+// hi*hi into the main accumulator, lo*hi + hi*lo + mid*mid + mid*hi + hi*mid into a second one that joins it in front of the epilogue (the
+// main accumulator then rounds once per 16 exact products, the corrections' own rounding is 2^-8 of that): fp32-grade gate pre-activations on
+// the bf16 matrix cores, six MFMAs per product = a 417 TFLOP/s ceiling (the fp32 MFMA's is 157).  16-wide tiles, 16-channel blocks, two ring
+// slots (LATE schedule).
 template <int NCH, bool LSTM, int PL = 1>
 __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int tw, int ncols) {
     constexpr int BN = 4 * NCH;                 // block columns: [gate][channel]
@@ -142,10 +155,12 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     constexpr int SLOT = PL * PLANE;            // bytes of one ring slot
     // Split mode with 32-channel blocks: two patch planes (92 KB) leave room for TWO 32 KB ring slots only, so the schedule changes: the
     // loaders bring tap it + 1 in during tap it (one tap of lookahead), and the block barrier sits at the END of a tap (LATE).
-    constexpr bool LATE = PL == 2 && NCH == 32;
+    constexpr bool LATE = (PL == 2 && NCH == 32) || PL == 3;
+    constexpr int PB = patch_plane_bytes<PL>();     // bytes of one patch plane
+    static_assert(PL != 3 || NCH == 16, "three pieces: 16-channel blocks only");
     constexpr int DEP = ring_depth<NCH, PL>();      // taps of weight prefetch
     constexpr int NSL = DEP + 1;                    // ring slots
-    static_assert(PL * PATCH_BYTES + NSL * PL * BN * 128 <= 160 * 1024 && DEP >= 1, "the ring must fit beside the patch");
+    static_assert(PL * PB + NSL * PL * BN * 128 <= 160 * 1024 && DEP >= 1, "the ring must fit beside the patch");
     constexpr int G = BN / 32;                  // global_load_lds per loader thread and tap
     constexpr int TPW = NCH / 16;               // MFMA column tiles per wave
     constexpr int CPW = NCH / 2;                // channels per wave (all 4 gates of a channel stay in one wave)
@@ -228,14 +243,20 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
             v.x = pack2(plo[j][0], plo[j][1]); v.y = pack2(plo[j][2], plo[j][3]);
             v.z = pack2(phi[j][0], phi[j][1]); v.w = pack2(phi[j][2], phi[j][3]);
             *reinterpret_cast<uint4*>(patch + a_lds[j] + cpiece * 16) = v;
-            if constexpr (PL == 2) {                   // lo plane: bf16(v - hi); hi as a float is its 16 bits shifted up
-                auto lo2 = [](unsigned hi2, float a, float b) {
-                    return pack2(a - __builtin_bit_cast(float, hi2 << 16), b - __builtin_bit_cast(float, hi2 & 0xffff0000u));
+            if constexpr (PL >= 2) {                   // second plane: bf16(v - hi); hi as a float is its 16 bits shifted up
+                float r[8] = {plo[j][0], plo[j][1], plo[j][2], plo[j][3], phi[j][0], phi[j][1], phi[j][2], phi[j][3]};
+                auto rest = [&](unsigned p2, int i) {      // r[i], r[i + 1] become the remainders (exact in fp32); returns them as bf16
+                    r[i] -= __builtin_bit_cast(float, p2 << 16); r[i + 1] -= __builtin_bit_cast(float, p2 & 0xffff0000u);
+                    return pack2(r[i], r[i + 1]);
                 };
                 uint4 l;
-                l.x = lo2(v.x, plo[j][0], plo[j][1]); l.y = lo2(v.y, plo[j][2], plo[j][3]);
-                l.z = lo2(v.z, phi[j][0], phi[j][1]); l.w = lo2(v.w, phi[j][2], phi[j][3]);
-                *reinterpret_cast<uint4*>(patch + PATCH_BYTES + a_lds[j] + cpiece * 16) = l;
+                l.x = rest(v.x, 0); l.y = rest(v.y, 2); l.z = rest(v.z, 4); l.w = rest(v.w, 6);
+                *reinterpret_cast<uint4*>(patch + PB + a_lds[j] + cpiece * 16) = l;
+                if constexpr (PL == 3) {               // third plane: bf16((v - hi) - mid)
+                    uint4 q;
+                    q.x = rest(l.x, 0); q.y = rest(l.y, 2); q.z = rest(l.z, 4); q.w = rest(l.w, 6);
+                    *reinterpret_cast<uint4*>(patch + 2 * PB + a_lds[j] + cpiece * 16) = q;
+                }
             }
         }
     };
@@ -250,7 +271,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     // =========================================================================================================================
     if (loader) {
         const int lt = tid - 256;
-        unsigned char* const ring = lds + PL * PATCH_BYTES;
+        unsigned char* const ring = lds + PL * PB;
         const unsigned char* wsrc[G];
 #pragma unroll
         for (int j = 0; j < G; ++j) {
@@ -369,10 +390,21 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     // ds_read it can see.  The waits below are explicit instead.
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     bf16x8 fa[2][2], fb[2][TPW];                       // [register set][tile]
-    bf16x8 fal[2][2], fbl[2][TPW];                     // ... and their lo planes (split mode)
+    bf16x8 fal[2][2], fbl[2][TPW];                     // ... and their second planes (split modes)
+    bf16x8 fa3[2][2], fb3[2][TPW];                     // ... and their third planes (PL = 3)
+    f32x16 accl[2][TPW];                               // PL = 3: the five correction products' accumulator
+    if constexpr (PL == 3) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accl[mt][t][r] = 0.f;
+    }
     auto wait_frags = [&](auto SET) {
         constexpr int st = decltype(SET)::value;
-        if constexpr (PL == 2 && TPW == 2) wait_lgkm(fa[st][0], fa[st][1], fb[st][0], fb[st][1], fal[st][0], fal[st][1], fbl[st][0], fbl[st][1]);
+        if constexpr (PL == 3) wait_lgkm(fa[st][0], fa[st][1], fb[st][0], fal[st][0], fal[st][1], fbl[st][0], fa3[st][0], fa3[st][1], fb3[st][0]);
+        else if constexpr (PL == 2 && TPW == 2) wait_lgkm(fa[st][0], fa[st][1], fb[st][0], fb[st][1], fal[st][0], fal[st][1], fbl[st][0], fbl[st][1]);
         else if constexpr (PL == 2) wait_lgkm(fa[st][0], fa[st][1], fb[st][0], fal[st][0], fal[st][1], fbl[st][0]);
         else if constexpr (TPW == 2) wait_lgkm(fa[st][0], fa[st][1], fb[st][0], fb[st][1]);
         else wait_lgkm(fa[st][0], fa[st][1], fb[st][0]);
@@ -381,20 +413,42 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         constexpr int st = decltype(SET)::value, ks = decltype(KS)::value;
         const int ty = tp / 5, tx = tp - ty * 5;
         const unsigned ab = lds0 + ty * RP + tx * PP;
-        const unsigned bb = lds0 + PL * PATCH_BYTES + slot * SLOT + b_sw[ks];
+        const unsigned bb = lds0 + PL * PB + slot * SLOT + b_sw[ks];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) fa[st][mt] = lds_read_b128<ks * 32>(ab + a_off[mt]);
 #pragma unroll
         for (int t = 0; t < TPW; ++t) fb[st][t] = lds_read_b128<0>(bb + b_row[t]);
-        if constexpr (PL == 2) {
+        if constexpr (PL >= 2) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) fal[st][mt] = lds_read_b128<ks * 32>(ab + PATCH_BYTES + a_off[mt]);
+            for (int mt = 0; mt < 2; ++mt) fal[st][mt] = lds_read_b128<ks * 32>(ab + PB + a_off[mt]);
 #pragma unroll
             for (int t = 0; t < TPW; ++t) fbl[st][t] = lds_read_b128<0>(bb + PLANE + b_row[t]);
+        }
+        if constexpr (PL == 3) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) fa3[st][mt] = lds_read_b128<ks * 32>(ab + 2 * PB + a_off[mt]);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) fb3[st][t] = lds_read_b128<0>(bb + 2 * PLANE + b_row[t]);
         }
     };
     auto mfmas = [&](auto SET) {
         constexpr int st = decltype(SET)::value;
+        if constexpr (PL == 3) {       // term-major, so that consecutive MFMAs write different accumulators; corrections smallest first
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) {
+                        if (term == 0) accl[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa3[st][mt], fb[st][t], accl[mt][t], 0, 0, 0);        // lo * hi
+                        else if (term == 1) accl[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], fb3[st][t], accl[mt][t], 0, 0, 0);   // hi * lo
+                        else if (term == 2) accl[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[st][mt], fbl[st][t], accl[mt][t], 0, 0, 0);  // mid * mid
+                        else if (term == 3) accl[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[st][mt], fb[st][t], accl[mt][t], 0, 0, 0);   // mid * hi
+                        else if (term == 4) accl[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], fbl[st][t], accl[mt][t], 0, 0, 0);   // hi * mid
+                        else acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], fb[st][t], acc[mt][t], 0, 0, 0);                      // hi * hi
+                    }
+            return;
+        }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -493,6 +547,14 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         __builtin_amdgcn_sched_barrier(0);
     }
     }   // !LATE
+    if constexpr (PL == 3) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][t][r] += accl[mt][t][r];
+    }
 
     if constexpr (!LSTM) {
         // ---- plain epilogue: accumulator row = anchor, column = output channel; 32 lanes write 128 contiguous bytes ----------
@@ -627,7 +689,7 @@ int conv5x5_bf16_rows(int N) { return N % 128 == 0 ? N : (N + 63) / 64 * 64; }
 // planes = 2: the hi / lo split of the split mode, lstm_bf16_weight_elems(wcin, Np) * 2 elements)
 int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s, int Np, int planes) {
     if (Np == 0) Np = N;
-    PIVP_CHECK_ARG(w && wb && wcin > 0 && wcin % 32 == 0 && N > 0 && Np >= N && (planes == 1 || planes == 2));
+    PIVP_CHECK_ARG(w && wb && wcin > 0 && wcin % 32 == 0 && N > 0 && Np >= N && planes >= 1 && planes <= 3);
     const long total = (long)lstm_bf16_weight_elems(wcin, Np) * planes;
     hipLaunchKernelGGL(pack_lstm_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, planes, total);
     return PIVP_LAUNCH_STATUS();
@@ -640,10 +702,11 @@ static bool bf16_geometry_ok(const IgemmDesc& d) {
     return d.Win % 8 == 0 && d.B % 2 == 0;
 }
 bool convlstm_bf16_ok(const IgemmDesc& d) { return bf16_geometry_ok(d) && d.C > 0 && d.C % 16 == 0; }
+bool convlstm_bf16x6_ok(const IgemmDesc& d) { return convlstm_bf16_ok(d) && d.Win % 16 == 0; }
 
 template <int NCH, bool LSTM, int PL = 1>
 static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nb, int ksplit, int ncols) {
-    constexpr int lds_bytes = PL * PATCH_BYTES + (ring_depth<NCH, PL>() + 1) * PL * 4 * NCH * 128;
+    constexpr int lds_bytes = PL * patch_plane_bytes<PL>() + (ring_depth<NCH, PL>() + 1) * PL * 4 * NCH * 128;
     static PerDeviceOnce once;
     if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_bf16_kernel<NCH, LSTM, PL>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     IgemmDesc dd = d;
@@ -660,7 +723,11 @@ static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t
 
 // d as for igemm_lstm (validated by the caller's igemm_validate(d, true) equivalent); wb = pack_lstm_bf16(d.w, ..., planes).
 int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nch, int planes) {
-    PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0)) && (planes == 1 || planes == 2));
+    PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0)) && planes >= 1 && planes <= 3);
+    if (planes == 3) {   // three pieces: 16-wide tiles and 16-channel blocks only (convlstm_bf16x6_ok); 8-wide maps are the caller's to route elsewhere
+        PIVP_CHECK_ARG(convlstm_bf16x6_ok(d) && nch != 32);
+        return launch_bf16<16, true, 3>(d, wb, stream, ln_nparts, d.C / 16, 1, 0);
+    }
     if (planes == 2) {   // split mode: 32-channel blocks (two ring slots) when they still give every CU a block, else 16-channel ones
         const int tw2 = d.Win % 16 == 0 ? 16 : 8, ti2 = tw2 == 16 ? 1 : 2;
         const long b32 = d.C % 32 ? 0 : (long)(d.B / ti2) * (d.Hin / TH) * (d.Win / tw2) * (d.C / 32);

@@ -40,7 +40,9 @@ int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, co
     d.cstate_in = c_in; d.cstate_out = c_out; d.hout = h_out; d.C = C; d.gates_out = gates_out;
     d.ln_part = ln_part; d.ln_cap = ln_cap;
     // w_bf16: the bf16 pack of w (pack_lstm_bf16) selects the bf16-operand kernel; variant then is its channels per block
-    if (w_bf16) return convlstm_bf16(d, w_bf16, s, ln_nparts, variant, bf16_planes);
+    // (three pieces: maps the three-plane tile does not serve -- 8 wide -- take the fp32 kernel, which is what that mode stands in for)
+    if (w_bf16 && bf16_planes == 3 && !convlstm_bf16x6_ok(d)) return w ? igemm_lstm(d, s, 0, ln_nparts) : PIVP_ERR_BADARG;
+    if (w_bf16) return convlstm_bf16(d, w_bf16, s, ln_nparts, bf16_planes == 3 ? 0 : variant, bf16_planes);
     return igemm_lstm(d, s, variant, ln_nparts);
 }
 
@@ -390,7 +392,7 @@ long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin,
 #define PIVP_BUILD_DIGEST "unstamped"      // a build that did not go through build.py: _lib.load() refuses it
 #endif
 extern "C" const char* pivp_build_digest(void) { return PIVP_BUILD_DIGEST; }
-extern "C" int pivp_abi_version(void) { return 9; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
+extern "C" int pivp_abi_version(void) { return 10; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
 
 extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                              const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream) {
@@ -473,6 +475,17 @@ extern "C" int pivp_convlstm_bf16x3(const float* x, int cx, int ldx, const float
     if (!x || !w_bf16 || !bias || !c_in || !c_out || !h_out) return PIVP_ERR_BADARG;
     return run_convlstm(x, cx, ldx, h_prev, C, nullptr, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, nch, gates_out,
                         ln_part, ln_cap, ln_nparts, (const unsigned short*)w_bf16, 2);
+}
+extern "C" int pivp_pack_lstm_bf16x6(const float* w, void* w_bf16, int cin_total, int C, void* stream) {
+    if (C <= 0) return PIVP_ERR_BADARG;
+    return pack_lstm_bf16(w, (unsigned short*)w_bf16, cin_total, 4 * C, (hipStream_t)stream, 0, 3);
+}
+extern "C" int pivp_convlstm_bf16x6(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
+                                    const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
+                                    int* ln_nparts, int B, int H, int W, void* stream) {
+    if (!x || !w_bf16 || !bias || !c_in || !c_out || !h_out) return PIVP_ERR_BADARG;
+    return run_convlstm(x, cx, ldx, h_prev, C, nullptr, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, 0, gates_out,
+                        ln_part, ln_cap, ln_nparts, (const unsigned short*)w_bf16, 3);
 }
 extern "C" long long pivp_lstm_bf16_weight_elems(int cin_total, int C) {
     if (cin_total <= 0 || cin_total % 32 || C <= 0) return PIVP_ERR_BADARG;

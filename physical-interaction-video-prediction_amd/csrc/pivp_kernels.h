@@ -124,6 +124,7 @@ int conv5x5_bf16_rows(int N);
 int conv5x5_bf16_ksplit(const IgemmDesc& d);   // > 1: the launch will split K and needs d.out zeroed
 int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int planes = 1);   // plain 5x5 s1 conv (ConvLSTM data gradient)
 bool convlstm_bf16_ok(const IgemmDesc& d);
+bool convlstm_bf16x6_ok(const IgemmDesc& d);   // the three-piece form: 16-wide tiles only
 int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts = nullptr, int nch = 0, int planes = 1);
 
 // enc0: 5x5 stride-2 pad-2 conv on a planar 3-channel frame -> NHWC 32 channels (TM:500)

@@ -87,7 +87,8 @@ struct pivp_plan {
     size_t o_wbf16[7];                // bf16 packs of the ConvLSTM weights (pivp_plan_set_precision), rebuilt at the start of a rollout
     int lstm_bf16 = 0;                // 1: bf16 operands in the ConvLSTM forward (precision modes BF16 and BF16X3)
     int precision = 0;                // PIVP_PRECISION_*
-    int lstm_planes = 1;              // 2: split mode (hi / lo planes, three MFMAs per product); the backward and the deconvs then stay fp32
+    int lstm_planes = 1;              // 2: split mode (hi / lo planes, three MFMAs per product); 3: three pieces, six MFMAs (forward gate convs only: the
+                                      // backward sweep and every other op of that mode are the fp32 ones)
     int bf16_all = 0;                 // precision mode BF16: also the ConvLSTM gradients and the enc5 / enc6 transposed convs
     pivp_grad_group_cb grad_cb = nullptr; void* grad_cb_user = nullptr;   // gradient-group-final notifications (t = 0 sweep)
     int loss_nparts;
@@ -157,7 +158,7 @@ static void plan_layout(pivp_plan* p) {
     p->loss_nparts = loss_partials_count((int)(B * 3 * HW));
     p->o_losspart = carve((size_t)T * p->loss_nparts);
     for (int i = 0; i < 7; ++i)       // 2-byte elements in a float-counted workspace
-        p->o_wbf16[i] = carve(lstm_bf16_weight_elems(kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C));   // room for the two planes of the split mode
+        p->o_wbf16[i] = carve(lstm_bf16_weight_elems(kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C) * 3 / 2 + 64);   // room for the three planes of PIVP_PRECISION_BF16X6
     p->nslabs = train ? T - 1 : 2;
     {   // timesteps t = T-2 .. 1 batch (t = 0, no h input, goes alone): as many ring slots as a launch may take timesteps
         const char* e = getenv("PIVP_WGRAD_BATCH");
@@ -318,8 +319,8 @@ extern "C" int pivp_plan_set_grad(pivp_plan_t* plan, int idx, float* dptr) {
 // rounded to bf16, fp32 accumulation / gates / state (csrc/convlstm_bf16.hip), and in the backward sweep their data and weight gradients
 // (csrc/convlstm_bf16.hip <NCH, false>, csrc/wgrad_bf16.hip).  Everything else stays fp32, as do the parameters, the gradients and Adam.  Refused when a layer's map does not fit the bf16 kernel's tiles (8-wide maps need an even batch).
 extern "C" int pivp_plan_set_precision(pivp_plan_t* plan, int precision) {
-    if (!plan || (precision != PIVP_PRECISION_F32 && precision != PIVP_PRECISION_BF16 && precision != PIVP_PRECISION_BF16X3)) return PIVP_ERR_BADARG;
-    if (precision != PIVP_PRECISION_F32) {
+    if (!plan || precision < PIVP_PRECISION_F32 || precision > PIVP_PRECISION_BF16X6) return PIVP_ERR_BADARG;
+    if (precision != PIVP_PRECISION_F32 && precision != PIVP_PRECISION_BF16X6) {   // (BF16X6: a layer its tile does not serve runs the fp32 kernel)
         const int hs[7] = {plan->H2, plan->H2, plan->H4, plan->H4, plan->H8, plan->H4, plan->H2};
         const int wsz[7] = {plan->W2, plan->W2, plan->W4, plan->W4, plan->W8, plan->W4, plan->W2};
         for (int i = 0; i < 7; ++i) {
@@ -331,7 +332,7 @@ extern "C" int pivp_plan_set_precision(pivp_plan_t* plan, int precision) {
         }
     }
     plan->lstm_bf16 = precision != PIVP_PRECISION_F32;
-    plan->lstm_planes = precision == PIVP_PRECISION_BF16X3 ? 2 : 1;
+    plan->lstm_planes = precision == PIVP_PRECISION_BF16X3 ? 2 : precision == PIVP_PRECISION_BF16X6 ? 3 : 1;
     plan->bf16_all = precision == PIVP_PRECISION_BF16;
     plan->precision = precision;
     if (!plan->ws) plan_layout(plan);      // the dG rings' depth follows the precision; a bound workspace keeps the layout it was sized for
@@ -733,7 +734,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                                  Sp ? ws + Sp->c[i] : ws + p->o_zero, ws + S.c[i], nullptr, L.C,
                                  last_step ? nullptr : ws + g.din[i][npar] + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
                                  ring + (size_t)wg_slot * dG1, ws + g.wt_lstm[i], ws + g.din[i][par], nullptr, nullptr, B, hh, wwid,
-                                 s, 1, p->lstm_bf16 ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->lstm_planes,
+                                 s, 1, (p->lstm_bf16 && p->lstm_planes != 3) ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->lstm_planes,
                                  wg_flush ? fork_of(i, f) : nullptr, &lf[i],    // dW = null: only the fork's `ready` (behind the gate math) is used
                                  t == 0 ? 1 : 0, dx_lnb));                      // t = 0: nobody reads d h_{-1}
         if (t == 0) RC(ln_finish(i + 1));       // the sweep's last timestep: the norm's partial parameter planes (written by the gate kernel) become its gradient
@@ -939,7 +940,7 @@ static int rollout_backward_sweep(pivp_plan_t* plan, const float* images, const 
     // weights are constant during the sweep: build the transposed packs for the data gradients once
     for (int i = 0; i < 7; ++i)
         RC(repack_transpose(P(plan, plan->i_lstm_w[i]), ws + g.wt_lstm[i], 25, kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C, 1, s));
-    if (plan->lstm_bf16)        // bf16 / split modes: the ConvLSTM data gradients run on these packs (one plane, or the hi / lo pair)
+    if (plan->lstm_bf16 && plan->lstm_planes != 3)        // bf16 / split modes: the ConvLSTM data gradients run on these packs (one plane, or the hi / lo pair)
         for (int i = 0; i < 7; ++i) {
             const int cin = kLstm[i].cx + kLstm[i].C;
             RC(pack_lstm_bf16(ws + g.wt_lstm[i], reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]), 4 * kLstm[i].C, cin, s,

@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 4, call 21: the three-piece mode (bf16x6: six bf16 MFMAs per product in the forward gate convs): op tests, model tests, trained fixtures,
+# per-layer times against the fp32 kernel, rollout A/B
+set -o pipefail
+o=gpurun_out/r04/c21
+mkdir -p $o
+timeout -k 10 600 python -m pytest tests/test_gpu_bf16.py -x -q -s -k "x6 or bf16x3" > $o/tests_bf16.txt 2>&1 || { tail -40 $o/tests_bf16.txt; exit 1; }
+grep -a "three-piece\|bf16x6\|passed\|failed" $o/tests_bf16.txt | cut -c1-220
+timeout -k 10 600 python -m pytest tests/test_gpu_trained.py -x -q -s -k "bf16x6" > $o/tests_trained.txt 2>&1 || { tail -40 $o/tests_trained.txt; exit 1; }
+grep -a "three-piece\|fp32 path\|rms ratio\|passed\|failed" $o/tests_trained.txt | cut -c1-260
+PIVP_BENCH_INTERLEAVE=1 PIVP_BENCH_BF16=6 timeout -k 10 120 python scripts/bench_lstm_layers.py 32 20 2>&1 | grep -v amdgpu.ids | tee $o/layers_x6.txt && \
+PIVP_BENCH_INTERLEAVE=1 timeout -k 10 120 python scripts/bench_lstm_layers.py 32 20 2>&1 | grep -v amdgpu.ids | tee $o/layers_f32.txt && \
+PIVP_BENCH_INTERLEAVE=1 PIVP_BENCH_BF16=3 timeout -k 10 120 python scripts/bench_lstm_layers.py 32 20 2>&1 | grep -v amdgpu.ids | tee $o/layers_x3.txt && \
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-train > $o/bench.json 2> $o/bench.err && python - <<'EOF2'
+import json
+d = json.loads(open('gpurun_out/r04/c21/bench.json').read().strip().splitlines()[-1])
+print(d['ms_per_step'], d['value'], json.dumps(d.get('rollout_bf16x6')))
+EOF2
+timeout -k 10 300 python bench.py --precision bf16x6 --no-cpu-baseline --no-train > $o/bench_x6.json 2> $o/bench_x6.err && tail -1 $o/bench_x6.json | cut -c1-1500

@@ -322,6 +322,63 @@ def test_convlstm_bf16x3_exact_when_operands_fit_two_pieces(ops):
         assert np.abs(hg - hr).max() < TOL and np.abs(cg - cr).max() < TOL
 
 
+# ---- three pieces per operand, six MFMAs per product: fp32-grade results on the bf16 matrix cores ----------------------
+X6_SHAPES = [(2, 32, 32, 32), (2, 32, 64, 16), (2, 128, 64, 16), (1, 96, 32, 32), (3, 64, 64, 16), (1, 32, 32, 64), (2, 64, 128, 16)]
+
+
+@pytest.mark.parametrize('B,cx,C,H', X6_SHAPES)
+def test_convlstm_bf16x6_is_fp32_grade(ops, B, cx, C, H):
+    # fp32-representable operands, so that neither kernel is charged for the rounding of its inputs: hi + mid + lo is every operand exactly,
+    # the dropped products are < 2^-24 of a product, and the main accumulator rounds once per 16 products (the fp32 kernel: once per product)
+    x, h, c, W, b = [np.asarray(a, dtype=np.float32).astype(np.float64) for a in _case(B, cx, C, H, 131 + C + H)]
+    hr, cr, _ = _lstm_ref(x, h, c, W, b)
+    h6, c6 = ops.convlstm_bf16x6(x, h, c, W, b)
+    hf, cf = ops.convlstm(x, h, c, W, b)
+    e6 = max(np.abs(h6 - hr).max(), np.abs(c6 - cr).max()); ef = max(np.abs(hf - hr).max(), np.abs(cf - cr).max())
+    r6 = np.sqrt(((c6 - cr) ** 2).mean()); rf = np.sqrt(((cf - cr) ** 2).mean())
+    print('B=%d cx=%d C=%d H=%d: max |err| three-piece %.2e, fp32 kernel %.2e; rms of c %.2e vs %.2e' % (B, cx, C, H, e6, ef, r6, rf))
+    assert e6 < 2e-6 and e6 < 1.5 * ef and r6 < 1.5 * rf
+
+
+def test_convlstm_bf16x6_first_step_and_narrow_maps(ops):
+    # t = 0 (no h operand: its K range is skipped) on a 16-wide map; an 8-wide map is not the three-piece kernel's: the call is the fp32 kernel's then
+    x, h, c, W, b = [np.asarray(a, dtype=np.float32).astype(np.float64) for a in _case(2, 32, 32, 16, 5)]
+    hr, cr, _ = _lstm_ref(x, h * 0, c, W, b)
+    h6, c6 = ops.convlstm_bf16x6(x, h, c, W, b, h_is_zero=True)
+    assert np.abs(h6 - hr).max() < 2e-6 and np.abs(c6 - cr).max() < 2e-6
+    lib = __import__('pivp_amd')._lib.load()
+    import torch
+    z = torch.zeros(1 << 20, device='cuda')
+    rc = lib.pivp_convlstm_bf16x6(z.data_ptr(), 64, 64, z.data_ptr(), 128, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(),
+                                  None, None, 0, None, 2, 8, 8, None)
+    assert rc == -1            # PIVP_ERR_BADARG: the per-op entry has no fp32 weights to fall back on (the plan does)
+
+
+def test_rollout_bf16x6_is_as_close_to_float64_as_the_fp32_path():
+    g = np.load(__import__('os').path.join(GOLD, 'cdna_b2_t10.npz'))
+    m6, loss6, gen6 = _rollout('bf16x6')
+    mf, lossf, genf = _rollout('fp32')
+    l6 = R.per_pixel_l2(gen6, g['gen_images']); lf = R.per_pixel_l2(genf, g['gen_images'])
+    print('bf16x6 rollout: per-pixel L2 vs float64 oracle max %.2e rms %.2e (fp32 path: max %.2e rms %.2e); loss %.8f vs %.8f'
+          % (l6.max(), np.sqrt((l6 ** 2).mean()), lf.max(), np.sqrt((lf ** 2).mean()), loss6, float(g['loss'])))
+    per6 = l6.reshape(l6.shape[0], -1).max(axis=1); perf = lf.reshape(lf.shape[0], -1).max(axis=1)
+    assert (per6 < 2.0 * np.maximum(perf, 1e-6)).all() and abs(loss6 - float(g['loss'])) < 1e-6
+    assert m6._active.lib.pivp_plan_get_precision(m6._active.h) == 3
+
+
+def test_train_step_in_bf16x6_mode_runs_the_fp32_backward():
+    import pivp_amd
+    outs = {}
+    for prec in ('fp32', 'bf16x6'):
+        m, loss, _ = _rollout(prec, T=4, train=True, keep=True)
+        with pivp_amd.using_config('train', True):
+            m.backward()
+        outs[prec] = (loss, m._flat_grads.clone())
+    rel = float((outs['bf16x6'][1] - outs['fp32'][1]).norm() / outs['fp32'][1].norm())
+    print('bf16x6 train step: loss %.8f vs %.8f, relative gradient difference %.2e' % (outs['bf16x6'][0], outs['fp32'][0], rel))
+    assert abs(outs['bf16x6'][0] - outs['fp32'][0]) < 1e-6 and rel < 1e-4
+
+
 def test_rollout_bf16x3_stays_inside_the_gate():
     # the split mode on the config 1 golden rollout: the CPU study (scripts/split_bf16_study.py) predicts 3.2e-5 max per-pixel L2
     g = np.load(__import__('os').path.join(GOLD, 'cdna_b2_t10.npz'))

@@ -136,3 +136,33 @@ def test_bf16_mode_error_on_trained_weights_is_reported():
           'rms', ['%.1e' % v for v in np.sqrt((per_step ** 2).mean(axis=1))], 'loss %.6f vs %.6f' % (loss, float(g['loss'])))
     assert np.isfinite(gen).all() and 1e-6 < l2.max() < 5e-2
     assert abs(loss - float(g['loss'])) < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['cdna_b32_t10_trained', 'stp_b32_t10_trained', 'cdna_128_b2_t20_trained'])
+def test_bf16x6_mode_is_fp32_grade_on_trained_weights(name):
+    """the three-piece mode (six bf16 MFMAs per product in the forward gate convolutions) is gated at 1.5 x the fp32 path's OWN
+    distance from the float64 oracle on every step of the trained fixtures (and at the north star's 1e-4, which that implies)."""
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need the MI355X'
+    import pivp_amd
+    g, mt, nm, size, P = _load(name)
+    T, B = int(g['seq_len']), int(g['batch'])
+    imgs, acts, stas = R.moving_batch(B, T, size, size, seed=int(g['data_seed']))
+    stride = int(g['pixel_stride'])
+    per = {}
+    for prec in ('fp32', 'bf16x6'):
+        m = pivp_amd.Model(nm, is_cdna=mt == 'CDNA', is_stp=mt == 'STP', is_dna=mt == 'DNA', prefix='test', precision=prec)
+        m.load_state_dict_reference(P)
+        with pivp_amd.using_config('train', False):
+            loss = float(m([imgs, acts, stas], 0))
+        gen = torch.stack(m.gen_images).cpu().numpy()
+        pix = np.ascontiguousarray(gen.transpose(0, 1, 3, 4, 2)).reshape(-1, 3)[::stride]
+        l2 = np.sqrt(((pix.astype(np.float64) - g['gen_pixels']) ** 2).sum(axis=1))
+        n = (l2.size // (T - 1)) * (T - 1)
+        per[prec] = (l2[:n].reshape(T - 1, -1).max(axis=1), np.sqrt((l2 ** 2).mean()), loss)
+    print(name, 'per-step max per-pixel L2 vs float64: three-piece', ['%.1e' % v for v in per['bf16x6'][0]])
+    print(name, '                                      fp32 path ', ['%.1e' % v for v in per['fp32'][0]])
+    print(name, 'rms ratio three-piece / fp32 path: %.2f' % (per['bf16x6'][1] / per['fp32'][1]))
+    assert (per['bf16x6'][0] <= 1.5 * np.maximum(per['fp32'][0], 5e-7)).all()
+    assert per['bf16x6'][0].max() < GATE and abs(per['bf16x6'][2] - float(g['loss'])) < 1e-6
