@@ -70,7 +70,7 @@ __device__ __forceinline__ int ring_swizzle(int row) {
 #endif
 template <int NCH, int PL>
 constexpr int ring_depth() {
-    if ((PL == 2 && NCH == 32) || PL == 3) return 1;                             // LATE schedule
+    if ((PL == 2 && NCH == 32) || PL == 3) return 1;                             // LATE schedule (PL = 3: not used, its ring is per k-step)
     const int fit = (160 * 1024 - PL * patch_plane_bytes<PL>()) / (PL * 4 * NCH * 128) - 1;     // slots that fit, minus one = taps ahead
     const int cap = fit > 7 ? 7 : fit;
     return (PIVP_BF16_DEPTH > 0 && PIVP_BF16_DEPTH < cap) ? PIVP_BF16_DEPTH : cap;
@@ -130,9 +130,41 @@ __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned shor
     wb[i] = __builtin_bit_cast(unsigned short, h);
 }
 
+// PL = 3 pack, FRAGMENT-MAJOR: [group][tap][16-channel column block][k-step][plane][wave column wn][lane][8 bf16] -- one B fragment of
+// v_mfma_f32_32x32x16_bf16 (lane (half, l31): column l31 of the wave's tile = gate l31 / 8, channel wn * 8 + l31 % 8 of the block; k = the
+// k-step's channels half * 8 .. + 8) is 1 KB in lane order, so one global_load_lds_dwordx4 of a wave moves exactly one fragment into a
+// lane-linear (conflict-free) kilobyte of the ring, and the 6 KB of a (block, tap, k-step) are contiguous.
+#ifndef PIVP_X6_ABL
+#define PIVP_X6_ABL 0       // timing-only ablations of the three-piece kernel (results are then wrong): 1 no per-k-step barriers, 2 no B fragment
+#endif                      // reads, 4 no reads of the A mid / lo planes, 8 no weight DMAs, 16 one MFMA per product instead of six
+constexpr int X6_CHUNK = 3 * 2 * 1024;      // bytes of one k-step of weights of a 16-channel block: 3 planes x 2 wave columns x 1 KB
+__global__ void pack_lstm_x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int C, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), wn = (int)((i >> 9) & 1);
+    long r = i >> 10;
+    const int pl = (int)(r % 3); r /= 3;
+    const int ks = (int)(r & 3); r >>= 2;
+    const int nb = C / 16;
+    const int nblk = (int)(r % nb); r /= nb;
+    const int tap = (int)(r % 25);
+    const int cg = (int)(r / 25);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int n = (l31 >> 3) * C + nblk * 16 + wn * 8 + (l31 & 7);
+    const int ch = cg * 64 + ks * 16 + half * 8 + e;
+    float v = 0.f;
+    if (ch < wcin) v = w[(((long)tap * (wcin >> 5) + (ch >> 5)) * (4 * C) + n) * 32 + (ch & 31)];
+    __bf16 h = (__bf16)v;
+    if (pl >= 1) { v -= (float)h; h = (__bf16)v; }
+    if (pl == 2) { v -= (float)h; h = (__bf16)v; }
+    wb[i] = __builtin_bit_cast(unsigned short, h);
+}
+
 #ifdef PIVP_BF16_STAMPS   // in-kernel phase stamps of every block's wave 0, constant-rate 100 MHz counter (scripts/bf16_stamps.py)
 __device__ long long pivp_bf16_stamps[2048 * 8];
-#define BF_STAMP(i) do { if (tid == 0 && blockIdx.x < 2048 && blockIdx.y == 0) pivp_bf16_stamps[blockIdx.x * 8 + (i)] = (long long)wall_clock64(); } while (0)
+// entries 6, 7: the shader-cycle counter (s_memtime) at stamps 2 and 3: cycles / wall time = the clock the chip holds inside the tap loop
+#define BF_STAMP(i) do { if (tid == 0 && blockIdx.x < 2048 && blockIdx.y == 0) { pivp_bf16_stamps[blockIdx.x * 8 + (i)] = (long long)wall_clock64(); \
+    if ((i) == 2 || (i) == 3) pivp_bf16_stamps[blockIdx.x * 8 + 4 + (i)] = (long long)clock64(); } } while (0)
 #else
 #define BF_STAMP(i)
 #endif
@@ -147,7 +179,9 @@ __device__ long long pivp_bf16_stamps[2048 * 8];
 // hi*hi into the main accumulator, lo*hi + hi*lo + mid*mid + mid*hi + hi*mid into a second one that joins it in front of the epilogue (the
 // main accumulator then rounds once per 16 exact products, the corrections' own rounding is 2^-8 of that): fp32-grade gate pre-activations on
 // the bf16 matrix cores, six MFMAs per product = a 417 TFLOP/s ceiling (the fp32 MFMA's is 157).  16-wide tiles, 16-channel blocks, two ring
-// slots (LATE schedule).
+// slots' worth of LDS, organised as EIGHT 6-KB slots of one k-step each (KST schedule below): with whole taps in two slots the loop ran at
+// the latency of one LDS-DMA per tap (1.2 us for 0.64 of MFMA); a barrier per k-step frees a slot four times per tap, so the DMAs run seven
+// k-steps = 1.1 us of MFMA time ahead in the same 48 KB.
 template <int NCH, bool LSTM, int PL = 1>
 __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int tw, int ncols) {
     constexpr int BN = 4 * NCH;                 // block columns: [gate][channel]
@@ -155,12 +189,13 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     constexpr int SLOT = PL * PLANE;            // bytes of one ring slot
     // Split mode with 32-channel blocks: two patch planes (92 KB) leave room for TWO 32 KB ring slots only, so the schedule changes: the
     // loaders bring tap it + 1 in during tap it (one tap of lookahead), and the block barrier sits at the END of a tap (LATE).
-    constexpr bool LATE = (PL == 2 && NCH == 32) || PL == 3;
+    constexpr bool LATE = PL == 2 && NCH == 32;
+    constexpr bool KST = PL == 3;                   // ring of eight one-k-step slots, a block barrier per k-step
     constexpr int PB = patch_plane_bytes<PL>();     // bytes of one patch plane
     static_assert(PL != 3 || NCH == 16, "three pieces: 16-channel blocks only");
     constexpr int DEP = ring_depth<NCH, PL>();      // taps of weight prefetch
     constexpr int NSL = DEP + 1;                    // ring slots
-    static_assert(PL * PB + NSL * PL * BN * 128 <= 160 * 1024 && DEP >= 1, "the ring must fit beside the patch");
+    static_assert(PL * PB + (KST ? 8 * X6_CHUNK : NSL * PL * BN * 128) <= 160 * 1024 && DEP >= 1, "the ring must fit beside the patch");
     constexpr int G = BN / 32;                  // global_load_lds per loader thread and tap
     constexpr int TPW = NCH / 16;               // MFMA column tiles per wave
     constexpr int CPW = NCH / 2;                // channels per wave (all 4 gates of a channel stay in one wave)
@@ -297,6 +332,60 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
                                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
                 }
         };
+        if constexpr (KST) {
+            // chunk q = (tap index it = q / 4 in this block's rotation, k-step q % 4) lives in slot q % 8.  Loader wave 4 + p moves plane p (two
+            // fragments, wn = 0 / 1, per chunk); the fourth loader wave only stages the patch and keeps the barriers.
+            const bool mover = wave < 3;
+            const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(wb) + (size_t)wave * 2048 + (size_t)lane * 16;
+            const size_t tapstep = (size_t)(C / 16) * 4 * X6_CHUNK;     // bytes of one (group, tap): every 16-channel block's four k-steps
+            const int NQ = nchunks * 4;
+            int i_q = 0, i_tap = tap0, i_cg = 0;
+            auto issue_chunk = [&]() {
+                const int slot = i_q & 7, ks = i_q & 3;
+                const size_t goff = (size_t)((cgbase + i_cg) * 25 + i_tap) * tapstep + (size_t)(nblk * 4 + ks) * X6_CHUNK;
+                ++i_q;
+                if (ks == 3) { i_tap = i_tap == 24 ? 0 : i_tap + 1; i_cg += i_tap == tap0 ? 1 : 0; }
+                if (mover && !(PIVP_X6_ABL & 8)) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        unsigned char* dst = ring + slot * X6_CHUNK + wave * 2048 + j * 1024;      // wave-uniform; the DMA adds lane * 16
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + goff + j * 1024),
+                                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                    }
+                }
+            };
+            issue_chunk(); issue_chunk(); issue_chunk();           // chunks 0..2 in front of the patch's loads
+            patch_load(0);
+            patch_store();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            issue_chunk(); issue_chunk(); issue_chunk(); issue_chunk(); issue_chunk();     // chunks 3..7 (all eight slots): in flight across the barrier
+            __builtin_amdgcn_s_barrier();                          // the patch and chunk 0 are published
+            int tap = tap0, cg = 0;
+            for (int q = 0; q < NQ; ++q) {
+                // barrier q publishes chunk q + 1 (issued so far: chunks up to q + 7; the `newer` ones behind q + 1 may stay in flight, 2 DMAs each)
+                int newer = NQ - q - 2;
+                newer = newer < 0 ? 0 : newer > 6 ? 6 : newer;
+                if (newer >= 6) wait_vmcnt<12>();
+                else if (newer == 5) wait_vmcnt<10>();
+                else if (newer == 4) wait_vmcnt<8>();
+                else if (newer == 3) wait_vmcnt<6>();
+                else if (newer == 2) wait_vmcnt<4>();
+                else if (newer == 1) wait_vmcnt<2>();
+                else wait_vmcnt<0>();
+                if (!(PIVP_X6_ABL & 1)) __builtin_amdgcn_s_barrier();
+                if (q + 8 < NQ) issue_chunk();                     // every multiplying wave holds chunk q in registers: its slot takes chunk q + 8
+                if ((q & 3) == 3) {
+                    tap = tap == 24 ? 0 : tap + 1;
+                    if (tap == tap0 && ++cg < ncg) {               // next 64 input channels: all 8 waves restage the patch
+                        __syncthreads();
+                        patch_load(cg);
+                        patch_store();
+                        __syncthreads();
+                    }
+                }
+            }
+            return;
+        }
         if constexpr (LATE) {
             issue_weights();                                   // tap 0
             patch_load(0);
@@ -416,6 +505,22 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         const unsigned bb = lds0 + PL * PB + slot * SLOT + b_sw[ks];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) fa[st][mt] = lds_read_b128<ks * 32>(ab + a_off[mt]);
+        if constexpr (KST) {      // `slot` = 0 / 4: the tap's first slot; k-step ks is slot + ks, a plane 2 KB, this wave's fragment wn, lane-linear
+            const unsigned kb = lds0 + PL * PB + slot * X6_CHUNK + wn * 1024 + lane * 16;
+            if (!(PIVP_X6_ABL & 2)) {
+                fb[st][0] = lds_read_b128<ks * X6_CHUNK>(kb);
+                fbl[st][0] = lds_read_b128<ks * X6_CHUNK + 2048>(kb);
+                fb3[st][0] = lds_read_b128<ks * X6_CHUNK + 4096>(kb);
+            }
+            if (!(PIVP_X6_ABL & 4)) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    fal[st][mt] = lds_read_b128<ks * 32>(ab + PB + a_off[mt]);
+                    fa3[st][mt] = lds_read_b128<ks * 32>(ab + 2 * PB + a_off[mt]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < TPW; ++t) fb[st][t] = lds_read_b128<0>(bb + b_row[t]);
         if constexpr (PL >= 2) {
@@ -435,7 +540,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         constexpr int st = decltype(SET)::value;
         if constexpr (PL == 3) {       // term-major, so that consecutive MFMAs write different accumulators; corrections smallest first
 #pragma unroll
-            for (int term = 0; term < 6; ++term)
+            for (int term = (PIVP_X6_ABL & 16) ? 5 : 0; term < 6; ++term)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -492,7 +597,85 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     BF_STAMP(1);
     __builtin_amdgcn_s_barrier();                      // patch and taps 0..2 are in LDS
     BF_STAMP(2);
-    if constexpr (LATE) {
+    if constexpr (KST) {
+        // a block barrier per k-step: barrier q (behind the wait for chunk q's fragments, so its slot is free) publishes chunk q + 1, whose
+        // fragments are requested right behind it and fly during chunk q's twelve MFMAs
+        int tap = tap0, cg = 0;
+        auto kbar = [&]() { if (!(PIVP_X6_ABL & 1)) __builtin_amdgcn_s_barrier(); };
+        // One k-step: the twelve MFMAs of register set CUR with the nine fragment reads of the NEXT k-step (set NXT) issued one behind each of
+        // the first nine.  (Reads first, MFMAs after -- the first version -- made all four waves, in step behind the barrier, queue 36 KB of LDS
+        // reads and only then start multiplying: the LDS phase and the matrix phase of a k-step alternated, 660 cycles for 384 of MFMA.)
+        auto one_mfma = [&](auto CUR, auto I) {
+            constexpr int st = decltype(CUR)::value, i = decltype(I)::value, term = i >> 1, mt = i & 1;
+            if constexpr ((PIVP_X6_ABL & 16) && term != 5) return;
+            if constexpr (term == 0) accl[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa3[st][mt], fb[st][0], accl[mt][0], 0, 0, 0);        // lo * hi
+            else if constexpr (term == 1) accl[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], fb3[st][0], accl[mt][0], 0, 0, 0);   // hi * lo
+            else if constexpr (term == 2) accl[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[st][mt], fbl[st][0], accl[mt][0], 0, 0, 0);  // mid * mid
+            else if constexpr (term == 3) accl[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[st][mt], fb[st][0], accl[mt][0], 0, 0, 0);   // mid * hi
+            else if constexpr (term == 4) accl[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], fbl[st][0], accl[mt][0], 0, 0, 0);   // hi * mid
+            else acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], fb[st][0], acc[mt][0], 0, 0, 0);                                // hi * hi
+        };
+        auto one_read = [&](auto NXT, auto KS, auto I, unsigned ab, unsigned kb) {
+            constexpr int st = decltype(NXT)::value, ks = decltype(KS)::value, i = decltype(I)::value;
+            if constexpr (i < 3) {                         // B: plane i of the k-step's slot (published by the barrier just passed)
+                if constexpr (PIVP_X6_ABL & 2) return;
+                bf16x8 v = lds_read_b128<ks * X6_CHUNK + i * 2048>(kb);
+                if constexpr (i == 0) fb[st][0] = v; else if constexpr (i == 1) fbl[st][0] = v; else fb3[st][0] = v;
+            } else {                                       // A: plane (i - 3) / 2, M tile (i - 3) % 2
+                constexpr int pl = (i - 3) >> 1, mt = (i - 3) & 1;
+                if constexpr ((PIVP_X6_ABL & 4) && pl > 0) return;
+                bf16x8 v = lds_read_b128<ks * 32>(ab + pl * PB + a_off[mt]);
+                if constexpr (pl == 0) fa[st][mt] = v; else if constexpr (pl == 1) fal[st][mt] = v; else fa3[st][mt] = v;
+            }
+        };
+        // A k-step of register set CUR (its fragments have landed): four MFMAs with the six A reads of the next k-step behind them (the patch does
+        // not depend on the barrier), the block barrier -- behind queued MFMAs, so the matrix pipe keeps working while the waves meet --, four MFMAs
+        // with the three B reads the barrier has just published, four more MFMAs.  (With the barrier and then all nine reads IN FRONT of the
+        // MFMAs the pipe drained at every k-step: ~170 idle cycles per 384.)
+        auto kstep = [&](auto CUR, auto NXT, auto KS, int tp, int slot, auto RD) {
+            constexpr bool rd = decltype(RD)::value;
+            const int ty = tp / 5, tx = tp - ty * 5;
+            const unsigned ab = lds0 + ty * RP + tx * PP;
+            const unsigned kb = lds0 + PL * PB + slot * X6_CHUNK + wn * 1024 + lane * 16;
+#define PIVP_X6_M(I) one_mfma(CUR, std::integral_constant<int, I>{});
+#define PIVP_X6_R(I) if constexpr (rd) one_read(NXT, KS, std::integral_constant<int, I>{}, ab, kb);
+#define PIVP_X6_S __builtin_amdgcn_sched_barrier(0);
+            PIVP_X6_M(0) PIVP_X6_R(3) PIVP_X6_R(4) PIVP_X6_S
+            PIVP_X6_M(1) PIVP_X6_R(5) PIVP_X6_R(6) PIVP_X6_S
+            PIVP_X6_M(2) PIVP_X6_R(7) PIVP_X6_S
+            PIVP_X6_M(3) PIVP_X6_R(8) PIVP_X6_S
+            kbar();
+            PIVP_X6_S
+            PIVP_X6_M(4) PIVP_X6_R(0) PIVP_X6_S
+            PIVP_X6_M(5) PIVP_X6_R(1) PIVP_X6_S
+            PIVP_X6_M(6) PIVP_X6_R(2) PIVP_X6_S
+            PIVP_X6_M(7) PIVP_X6_M(8) PIVP_X6_M(9) PIVP_X6_M(10) PIVP_X6_M(11)
+            PIVP_X6_S
+#undef PIVP_X6_M
+#undef PIVP_X6_R
+#undef PIVP_X6_S
+        };
+        read_frags(S0{}, K0{}, tap, 0);
+        for (int it = 0; it < nchunks; ++it) {
+            const int sb = (it & 1) * 4;
+            wait_frags(S0{}); kstep(S0{}, S1{}, K1{}, tap, sb, std::true_type{});
+            wait_frags(S1{}); kstep(S1{}, S0{}, K2{}, tap, sb, std::true_type{});
+            wait_frags(S0{}); kstep(S0{}, S1{}, K3{}, tap, sb, std::true_type{});
+            tap = tap == 24 ? 0 : tap + 1;
+            const bool regroup = tap == tap0;
+            wait_frags(S1{});
+            if (!regroup) kstep(S1{}, S0{}, K0{}, tap, sb ^ 4, std::true_type{});
+            else kstep(S1{}, S0{}, K0{}, tap, sb ^ 4, std::false_type{});
+            if (regroup && ++cg < ncg) {
+                __syncthreads();
+                patch_load(cg);
+                patch_store();
+                __syncthreads();
+                read_frags(S0{}, K0{}, tap, sb ^ 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if constexpr (LATE) {
         // end-of-tap barrier schedule: the first fragments of a tap are requested right behind the barrier that published it
         int tap = tap0, cg = 0;
         for (int it = 0; it < nchunks; ++it) {
@@ -691,6 +874,11 @@ int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStrea
     if (Np == 0) Np = N;
     PIVP_CHECK_ARG(w && wb && wcin > 0 && wcin % 32 == 0 && N > 0 && Np >= N && planes >= 1 && planes <= 3);
     const long total = (long)lstm_bf16_weight_elems(wcin, Np) * planes;
+    if (planes == 3) {       // the three-piece kernel's fragment-major pack (ConvLSTM weights only: N = 4 C, no row padding)
+        PIVP_CHECK_ARG(Np == N && N % 64 == 0);
+        hipLaunchKernelGGL(pack_lstm_x6_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N / 4, total);
+        return PIVP_LAUNCH_STATUS();
+    }
     hipLaunchKernelGGL(pack_lstm_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, planes, total);
     return PIVP_LAUNCH_STATUS();
 }
@@ -706,7 +894,7 @@ bool convlstm_bf16x6_ok(const IgemmDesc& d) { return convlstm_bf16_ok(d) && d.Wi
 
 template <int NCH, bool LSTM, int PL = 1>
 static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nb, int ksplit, int ncols) {
-    constexpr int lds_bytes = PL * patch_plane_bytes<PL>() + (ring_depth<NCH, PL>() + 1) * PL * 4 * NCH * 128;
+    constexpr int lds_bytes = PL * patch_plane_bytes<PL>() + (PL == 3 ? 8 * X6_CHUNK : (ring_depth<NCH, PL>() + 1) * PL * 4 * NCH * 128);
     static PerDeviceOnce once;
     if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_bf16_kernel<NCH, LSTM, PL>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     IgemmDesc dd = d;

@@ -18,6 +18,8 @@ BF16 = os.environ.get('PIVP_BENCH_BF16', '0') in ('1', '3', '6')   # bf16-operan
 X3 = os.environ.get('PIVP_BENCH_BF16', '0') == '3'
 X6 = os.environ.get('PIVP_BENCH_BF16', '0') == '6'
 DATA = os.environ.get('PIVP_BENCH_DATA', 'random')   # random | zero | const: does the MFMA rate depend on the operand values?
+if os.environ.get('PIVP_BENCH_LIB'):      # a variant build of the library (scripts/r04/build_x6_variants.sh): timing experiments only
+    _lib.LIB_PATH = os.path.abspath(os.environ['PIVP_BENCH_LIB'])
 lib = _lib.load()
 dev = 'cuda:0'
 st = torch.cuda.current_stream().cuda_stream
