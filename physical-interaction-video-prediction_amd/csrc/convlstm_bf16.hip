@@ -130,27 +130,27 @@ __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned shor
     wb[i] = __builtin_bit_cast(unsigned short, h);
 }
 
-// PL = 3 pack, FRAGMENT-MAJOR: [group][tap][16-channel column block][k-step][plane][wave column wn][lane][8 bf16] -- one B fragment of
-// v_mfma_f32_32x32x16_bf16 (lane (half, l31): column l31 of the wave's tile = gate l31 / 8, channel wn * 8 + l31 % 8 of the block; k = the
-// k-step's channels half * 8 .. + 8) is 1 KB in lane order, so one global_load_lds_dwordx4 of a wave moves exactly one fragment into a
-// lane-linear (conflict-free) kilobyte of the ring, and the 6 KB of a (block, tap, k-step) are contiguous.
+// PL = 3 pack, FRAGMENT-MAJOR: [group][tap][k-step][plane][8-channel group c8][lane][8 bf16] -- one B fragment of
+// v_mfma_f32_32x32x16_bf16 whose 32 columns are the four gates of eight channels (lane (half, l31): gate l31 / 8, channel c8 * 8 + l31 % 8;
+// k = the k-step's channels half * 8 .. + 8) is 1 KB in lane order: one global_load_lds_dwordx4 of a wave moves exactly one fragment into
+// a lane-linear (conflict-free) kilobyte of the ring, one global_load_dwordx4 of a wave loads it straight into the MFMA's operand registers.
 #ifndef PIVP_X6_ABL
 #define PIVP_X6_ABL 0       // timing-only ablations of the three-piece kernel (results are then wrong): 1 no per-k-step barriers, 2 no B fragment
 #endif                      // reads, 4 no reads of the A mid / lo planes, 8 no weight DMAs, 16 one MFMA per product instead of six
-constexpr int X6_CHUNK = 3 * 2 * 1024;      // bytes of one k-step of weights of a 16-channel block: 3 planes x 2 wave columns x 1 KB
+constexpr int X6_CHUNK = 3 * 2 * 1024;      // ring slot of the 16-channel-block kernel: one k-step = 3 planes x 2 wave columns x 1 KB
 __global__ void pack_lstm_x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int C, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), wn = (int)((i >> 9) & 1);
-    long r = i >> 10;
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    long r = i >> 9;
+    const int n8 = C / 8;
+    const int c8 = (int)(r % n8); r /= n8;
     const int pl = (int)(r % 3); r /= 3;
     const int ks = (int)(r & 3); r >>= 2;
-    const int nb = C / 16;
-    const int nblk = (int)(r % nb); r /= nb;
     const int tap = (int)(r % 25);
     const int cg = (int)(r / 25);
     const int half = lane >> 5, l31 = lane & 31;
-    const int n = (l31 >> 3) * C + nblk * 16 + wn * 8 + (l31 & 7);
+    const int n = (l31 >> 3) * C + c8 * 8 + (l31 & 7);
     const int ch = cg * 64 + ks * 16 + half * 8 + e;
     float v = 0.f;
     if (ch < wcin) v = w[(((long)tap * (wcin >> 5) + (ch >> 5)) * (4 * C) + n) * 32 + (ch & 31)];
@@ -336,13 +336,13 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
             // chunk q = (tap index it = q / 4 in this block's rotation, k-step q % 4) lives in slot q % 8.  Loader wave 4 + p moves plane p (two
             // fragments, wn = 0 / 1, per chunk); the fourth loader wave only stages the patch and keeps the barriers.
             const bool mover = wave < 3;
-            const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(wb) + (size_t)wave * 2048 + (size_t)lane * 16;
-            const size_t tapstep = (size_t)(C / 16) * 4 * X6_CHUNK;     // bytes of one (group, tap): every 16-channel block's four k-steps
+            const size_t pls = (size_t)(C / 8) * 1024;                  // bytes between the planes of a k-step in the pack
+            const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(wb) + (size_t)wave * pls + (size_t)(nblk * 2) * 1024 + (size_t)lane * 16;
             const int NQ = nchunks * 4;
             int i_q = 0, i_tap = tap0, i_cg = 0;
             auto issue_chunk = [&]() {
                 const int slot = i_q & 7, ks = i_q & 3;
-                const size_t goff = (size_t)((cgbase + i_cg) * 25 + i_tap) * tapstep + (size_t)(nblk * 4 + ks) * X6_CHUNK;
+                const size_t goff = (size_t)(((cgbase + i_cg) * 25 + i_tap) * 4 + ks) * 3 * pls;
                 ++i_q;
                 if (ks == 3) { i_tap = i_tap == 24 ? 0 : i_tap + 1; i_cg += i_tap == tap0 ? 1 : 0; }
                 if (mover && !(PIVP_X6_ABL & 8)) {
@@ -856,6 +856,301 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     }
 }
 
+// =================================================================================================================================
+// Three-piece ConvLSTM with the weights read STRAIGHT FROM L2 into the MFMA's operand registers: no weight ring, no loader waves, no block
+// barrier in the tap loop.  The ring form above (16-channel blocks) spends a fifth of its k-step on the LDS-DMAs and the per-k-step barrier,
+// and its 16-channel blocks need two rounds on 32 x 32 maps.  Here a block is 128 anchors x 32 channels x 4 gates and all eight waves
+// multiply (2 x 4: wave tile = 64 anchors x the four gates of 8 channels, two waves per SIMD); the LDS holds only the three patch planes.
+// A wave's B fragment of a (tap, k-step, plane) is 1 KB of the fragment-major pack: one coalesced global_load_dwordx4 per wave, requested
+// FOUR k-steps (one tap) ahead into a register ring of 4 x 3 fragments: with two waves per SIMD a wave's k-step lasts ~0.45 us, so a tap of
+// lookahead covers an L2 round trip of 1-2 us; the two waves that share a fragment (wm = 0 / 1) ask for the same lines at about the same time.  Same arithmetic, term for term, as the ring form.
+// =================================================================================================================================
+__global__ __launch_bounds__(512, 1) void convlstm_x6g_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int wbytes) {
+    constexpr int PB = PH * RP16;                      // one patch plane: 36,864 B
+    constexpr int PW = 20;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* const patch = lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave8 & 1, wn = wave8 >> 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int C = d.C;
+    const int n_nblk = C / 32;
+    const int H = d.Hin, W = d.Win;
+    const int tpr = W / 16, tpi = (H / TH) * tpr;
+    const int n_tiles = d.B * tpi;
+    int lid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware, column-block major
+    const int nblk = lid / n_tiles, tile = lid - nblk * n_tiles;
+    const int b0 = tile / tpi, trem = tile - b0 * tpi;
+    const int y0 = (trem / tpr) * TH, x0 = (trem - (trem / tpr) * tpr) * 16;
+    BF_STAMP(0);
+    const int c0 = d.c0, ld0 = d.ld0, ld1 = d.ld1;
+    const int cin = c0 + d.c1;
+    const int ncg = (cin + 63) >> 6;
+    const int nchunks = 25 * ncg;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x0), 0, d.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.c1 ? d.x1 : d.x0), 0, d.c1 ? d.bytes1 : d.bytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(wb), 0, wbytes, 0x00020000);
+    constexpr unsigned OOB = 0xC0000000u;
+
+    // ---- patch staging (all 8 waves), as in convlstm_bf16_kernel: thread = (pixel (tid >> 3) + 64 j, 8-channel piece tid & 7), three planes ----
+    const int cpiece = tid & 7;
+    // (pixel -> image / patch offsets are recomputed where they are used: ten index registers held across the tap loop cost more than the divisions)
+    auto pix_of = [&](int j, int& a_pix, int& a_lds) {
+        const int p = (tid >> 3) + 64 * j;
+        const int py = p / PW, px = p - py * PW;
+        const int iy = y0 - 2 + py, ix = x0 - 2 + px;
+        const bool ok = p < PH * PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        a_pix = ok ? (b0 * H + iy) * W + ix : -1;
+        a_lds = p < PH * PW ? py * RP16 + px * PP : PW * PP;
+    };
+    f32x4 plo[NPJ], phi[NPJ];
+    auto patch_load = [&](int cg) {
+        const int ch = cg * 64 + cpiece * 8;
+        const bool s0 = ch < c0, s1 = !s0 && ch < cin;
+        const int ld = s0 ? ld0 : ld1, co = s0 ? ch : ch - c0;
+#pragma unroll
+        for (int j = 0; j < NPJ; ++j) {
+            int a_pix, a_lds;
+            pix_of(j, a_pix, a_lds);
+            const unsigned off = (a_pix >= 0 && (s0 || s1)) ? (unsigned)((a_pix * ld + co) * 4) : OOB;
+            if (s0) {
+                plo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
+                phi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 16, 0));
+            } else {
+                plo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
+                phi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 16, 0));
+            }
+        }
+    };
+    auto patch_store = [&]() {
+#pragma unroll
+        for (int j = 0; j < NPJ; ++j) {
+            int a_pix, a_lds;
+            pix_of(j, a_pix, a_lds);
+            float r[8] = {plo[j][0], plo[j][1], plo[j][2], plo[j][3], phi[j][0], phi[j][1], phi[j][2], phi[j][3]};
+            uint4 v;
+            v.x = pack2(r[0], r[1]); v.y = pack2(r[2], r[3]); v.z = pack2(r[4], r[5]); v.w = pack2(r[6], r[7]);
+            *reinterpret_cast<uint4*>(patch + a_lds + cpiece * 16) = v;
+            auto rest = [&](unsigned p2, int i) {          // r[i], r[i + 1] become the remainders (exact in fp32); returns them as bf16
+                r[i] -= __builtin_bit_cast(float, p2 << 16); r[i + 1] -= __builtin_bit_cast(float, p2 & 0xffff0000u);
+                return pack2(r[i], r[i + 1]);
+            };
+            uint4 l, q;
+            l.x = rest(v.x, 0); l.y = rest(v.y, 2); l.z = rest(v.z, 4); l.w = rest(v.w, 6);
+            *reinterpret_cast<uint4*>(patch + PB + a_lds + cpiece * 16) = l;
+            q.x = rest(l.x, 0); q.y = rest(l.y, 2); q.z = rest(l.z, 4); q.w = rest(l.w, 6);
+            *reinterpret_cast<uint4*>(patch + 2 * PB + a_lds + cpiece * 16) = q;
+        }
+    };
+    const int tap0 = (lid * 7) % 25;
+
+    f32x16 acc[2], accl[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[mt][r] = 0.f; accl[mt][r] = 0.f; }
+    int a_off[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int i = 64 * wm + 32 * mt + l31;
+        a_off[mt] = (i >> 4) * RP16 + (i & 15) * PP + half * 16;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+
+    // ---- the weights: fragment (group, tap, k-step, plane, c8 = nblk * 4 + wn) of the pack, 1 KB in lane order ------------------------
+    const unsigned pls = (unsigned)(C / 8) * 1024u;    // bytes between the planes of a k-step
+    const unsigned kss = 3u * pls, tps = 4u * kss;     // ... between k-steps, between taps
+    const unsigned voff = (unsigned)((nblk * 4 + wn) * 1024 + lane * 16);
+    bf16x8 Bf[4][3];                                   // [k-step][plane]: the current tap's fragments; behind each k-step its registers take the next tap's
+    auto bload = [&](bf16x8 (&dst)[3], unsigned soff) {
+        if constexpr (PIVP_X6_ABL & 8) return;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            dst[pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, voff, (int)(soff + pl * pls), 0));
+    };
+    auto adv = [&](int& tp, int& cg) { tp = tp == 24 ? 0 : tp + 1; cg += tp == tap0 ? 1 : 0; };
+
+    // ---- prologue ---------------------------------------------------------------------------------------------------------------------
+    patch_load(0);
+    int tap = tap0, cg = 0, tap1 = tap0, cg1 = 0;
+    adv(tap1, cg1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bload(Bf[ks], (unsigned)(cg * 25 + tap) * tps + ks * kss);
+    const int chl = wn * 8 + (l31 & 7);
+    const int ch = nblk * 32 + chl;
+    const int grp = l31 >> 3;
+    float bj = 0.f, bi = 0.f, bf = 0.f, bo = 0.f;
+    float cpre[2][4];
+    patch_store();
+    BF_STAMP(1);
+    __syncthreads();
+    BF_STAMP(2);
+
+    bf16x8 fa[2][2], fal[2][2], fa3[2][2];             // [register set][M tile]: the A fragments of a k-step, hi / mid / lo planes
+    auto wait_a = [&](auto SET) {
+        constexpr int st = decltype(SET)::value;
+        wait_lgkm(fa[st][0], fa[st][1], fal[st][0], fal[st][1], fa3[st][0], fa3[st][1]);
+    };
+    auto read_a = [&](auto SET, auto KS, auto I, unsigned ab) {       // read I of the six: plane I / 2, M tile I % 2
+        constexpr int st = decltype(SET)::value, ks = decltype(KS)::value, i = decltype(I)::value, pl = i >> 1, mt = i & 1;
+        if constexpr ((PIVP_X6_ABL & 4) && pl > 0) return;
+        bf16x8 v = lds_read_b128<ks * 32>(ab + pl * PB + a_off[mt]);
+        if constexpr (pl == 0) fa[st][mt] = v; else if constexpr (pl == 1) fal[st][mt] = v; else fa3[st][mt] = v;
+    };
+    // twelve MFMAs of register set CUR against the fragments b[3] (hi, mid, lo); corrections into accl, the leading term into acc
+    auto mfma = [&](auto CUR, auto I, const bf16x8 (&b)[3]) {
+        constexpr int st = decltype(CUR)::value, i = decltype(I)::value, term = i >> 1, mt = i & 1;
+        if constexpr ((PIVP_X6_ABL & 16) && term != 5) return;
+        if constexpr (term == 0) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa3[st][mt], b[0], accl[mt], 0, 0, 0);        // lo * hi
+        else if constexpr (term == 1) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], b[2], accl[mt], 0, 0, 0);    // hi * lo
+        else if constexpr (term == 2) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[st][mt], b[1], accl[mt], 0, 0, 0);   // mid * mid
+        else if constexpr (term == 3) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[st][mt], b[0], accl[mt], 0, 0, 0);   // mid * hi
+        else if constexpr (term == 4) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], b[1], accl[mt], 0, 0, 0);    // hi * mid
+        else acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], b[0], acc[mt], 0, 0, 0);                               // hi * hi
+    };
+    // one k-step: wait for its A fragments, then the MFMAs with the six A reads of the NEXT k-step (set NXT, k-step KSN at patch offset abn)
+    // behind the first three
+    auto kstep = [&](auto CUR, auto NXT, auto KSN, unsigned abn, const bf16x8 (&b)[3], auto RD) {
+        constexpr bool rd = decltype(RD)::value;
+        wait_a(CUR);
+#define PIVP_X6_M(I) mfma(CUR, std::integral_constant<int, I>{}, b);
+#define PIVP_X6_R(I) if constexpr (rd) read_a(NXT, KSN, std::integral_constant<int, I>{}, abn);
+#define PIVP_X6_S __builtin_amdgcn_sched_barrier(0);
+        PIVP_X6_S
+        PIVP_X6_M(0) PIVP_X6_R(0) PIVP_X6_R(1) PIVP_X6_S
+        PIVP_X6_M(1) PIVP_X6_R(2) PIVP_X6_R(3) PIVP_X6_S
+        PIVP_X6_M(2) PIVP_X6_R(4) PIVP_X6_R(5) PIVP_X6_S
+        PIVP_X6_M(3) PIVP_X6_M(4) PIVP_X6_M(5) PIVP_X6_M(6) PIVP_X6_M(7) PIVP_X6_M(8) PIVP_X6_M(9) PIVP_X6_M(10) PIVP_X6_M(11)
+        PIVP_X6_S
+#undef PIVP_X6_M
+#undef PIVP_X6_R
+#undef PIVP_X6_S
+    };
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+    auto read_a_all = [&](unsigned ab) {               // the first k-step of a tap into set 0 (prologue, and behind a restaged patch)
+        read_a(S0{}, K0{}, I0{}, ab); read_a(S0{}, K0{}, I1{}, ab); read_a(S0{}, K0{}, I2{}, ab);
+        read_a(S0{}, K0{}, I3{}, ab); read_a(S0{}, K0{}, I4{}, ab); read_a(S0{}, K0{}, I5{}, ab);
+    };
+    auto a_base = [&](int tp) { const int ty = tp / 5; return lds0 + ty * RP16 + (tp - ty * 5) * PP; };
+
+    for (int g = 0; g < ncg; ++g) {                    // 64 input channels of concat(x, h) at a time
+        if (g > 0) {                                   // every wave is done with the old patch
+            __syncthreads();
+            patch_load(g);
+            patch_store();
+            __syncthreads();
+        }
+        if (g == ncg - 1) {
+            // the epilogue's operands, requested in front of the last 25 taps (read in the epilogue they cost an exposed HBM round trip per row;
+            // requested in the prologue they hold 12 registers through every tap loop)
+            bj = d.bias[ch]; bi = d.bias[C + ch]; bf = d.bias[2 * C + ch] + 1.0f; bo = d.bias[3 * C + ch];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = k * 4 + grp;
+                    const int i = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int m = (b0 * H + y0 + (i >> 4)) * W + x0 + (i & 15);
+                    cpre[mt][k] = d.cstate_in[(size_t)m * C + ch];
+                }
+        }
+        read_a_all(a_base(tap));
+        for (int t = 0; t < 25; ++t) {                 // one tap = four k-steps; behind each k-step its registers take the next tap's fragments
+            const unsigned ab = a_base(tap), ab1 = a_base(tap1);
+            const bool has1 = t < 24 || g + 1 < ncg;
+            const unsigned so1 = (unsigned)(cg1 * 25 + tap1) * tps;
+            kstep(S0{}, S1{}, K1{}, ab, Bf[0], std::true_type{});
+            if (has1) bload(Bf[0], so1);
+            kstep(S1{}, S0{}, K2{}, ab, Bf[1], std::true_type{});
+            if (has1) bload(Bf[1], so1 + kss);
+            kstep(S0{}, S1{}, K3{}, ab, Bf[2], std::true_type{});
+            if (has1) bload(Bf[2], so1 + 2 * kss);
+            if (t < 24) kstep(S1{}, S0{}, K0{}, ab1, Bf[3], std::true_type{});
+            else kstep(S1{}, S0{}, K0{}, ab1, Bf[3], std::false_type{});      // (the next tap's A fragments come from the next patch)
+            if (has1) bload(Bf[3], so1 + 3 * kss);
+            tap = tap1; cg = cg1;
+            adv(tap1, cg1);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] += accl[mt][r];
+    BF_STAMP(3);
+
+    // ---- epilogue: the gate math of convlstm_bf16_kernel's 16-channel blocks (a wave's 32 columns = 4 gates x 8 channels) -------------
+    auto pick = [&](const float (&v)[4], int idx) -> float {
+        const float lo = (idx & 1) ? v[1] : v[0], hi = (idx & 1) ? v[3] : v[2];
+        return (idx & 2) ? hi : lo;
+    };
+    float sv[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float rows[4], val[4], g4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rows[g] = acc[mt][k * 4 + g];
+            val[0] = pick(rows, grp);
+#pragma unroll
+            for (int x = 1; x < 4; ++x) val[x] = __shfl_xor(pick(rows, grp ^ x), x * 8, 64);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) g4[g] = pick(val, g ^ grp);
+            const int r = k * 4 + grp;
+            const int i = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int m = (b0 * H + y0 + (i >> 4)) * W + x0 + (i & 15);
+            const size_t o = (size_t)m * C + ch;
+            const float aj = b_tanh(g4[0] + bj), ai = b_sigmoid(g4[1] + bi);
+            const float af = b_sigmoid(g4[2] + bf), ao = b_sigmoid(g4[3] + bo);
+            const float cn = cpre[mt][k] * af + ai * aj;
+            d.cstate_out[o] = cn;
+            const float hn = b_tanh(cn) * ao;
+            d.hout[o] = hn;
+            sv[mt][k] = hn;
+            if (d.gates_out) {
+                float* gp = d.gates_out + (size_t)m * 4 * C + ch;
+                gp[0] = aj; gp[C] = ai; gp[2 * C] = af; gp[3 * C] = ao;
+            }
+        }
+    BF_STAMP(4);
+#ifdef PIVP_BF16_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BF_STAMP(5);
+#endif
+    if (d.ln_part) {                                   // (count, mean, M2) of the block's h tile, two passes, fixed order over the eight waves
+        float* red = reinterpret_cast<float*>(lds);
+        float s1 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s1 += sv[mt][k];
+        s1 = wave_sum(s1);
+        __syncthreads();
+        if (lane == 0) red[wave8] = s1;
+        __syncthreads();
+        const float cnt = 8.f * 64.f * 8.f;
+        const float mean = (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) / cnt;
+        float q = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float dd = sv[mt][k] - mean; q = fmaf(dd, dd, q); }
+        q = wave_sum(q);
+        if (lane == 0) red[8 + wave8] = q;
+        __syncthreads();
+        if (tid == 0) {
+            float* p = d.ln_part + ((size_t)b0 * d.ln_nparts + (size_t)trem * n_nblk + nblk) * 4;
+            p[0] = cnt; p[1] = mean; p[2] = ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15])); p[3] = 0.f;
+        }
+    }
+}
+
 #ifdef PIVP_BF16_STAMPS
 }
 extern "C" int pivp_debug_bf16_stamps(long long* out, int n) {   // n <= 2048 * 8: [block][entry, prologue done, first barrier passed, tap loop done, cells done]
@@ -909,11 +1204,32 @@ static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t
     return PIVP_LAUNCH_STATUS();
 }
 
+static int launch_x6g(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts) {
+    constexpr int lds_bytes = 3 * PH * RP16;
+    static PerDeviceOnce once;
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
+    IgemmDesc dd = d;
+    const int tpi = (d.Hin / TH) * (d.Win / 16), nb = d.C / 32;
+    const int np = tpi * nb;
+    dd.ln_nparts = (d.ln_part && np <= d.ln_cap) ? np : 0;
+    if (!dd.ln_nparts) dd.ln_part = nullptr;
+    if (ln_nparts) *ln_nparts = dd.ln_nparts;
+    const long long wbytes = (long long)lstm_bf16_weight_elems(d.c0 + (d.c1 ? d.c1 : d.C), 4 * d.C) * 3 * 2;
+    if (wbytes >= (1LL << 31)) return PIVP_ERR_BADARG;
+    hipLaunchKernelGGL(convlstm_x6g_kernel, dim3(d.B * tpi * nb), dim3(512), lds_bytes, stream, dd, wb, (int)wbytes);
+    return PIVP_LAUNCH_STATUS();
+}
+
 // d as for igemm_lstm (validated by the caller's igemm_validate(d, true) equivalent); wb = pack_lstm_bf16(d.w, ..., planes).
 int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nch, int planes) {
     PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0)) && planes >= 1 && planes <= 3);
     if (planes == 3) {   // three pieces: 16-wide tiles and 16-channel blocks only (convlstm_bf16x6_ok); 8-wide maps are the caller's to route elsewhere
-        PIVP_CHECK_ARG(convlstm_bf16x6_ok(d) && nch != 32);
+        PIVP_CHECK_ARG(convlstm_bf16x6_ok(d));
+        // 32-channel blocks with the weights straight from L2 where they give every CU a block (one round); else 16-channel blocks on the ring
+        static const int forced = [] { const char* e = getenv("PIVP_X6_KERNEL"); return e ? atoi(e) : 0; }();     // tuning: 16 / 32
+        const long b32 = d.C % 32 ? 0 : (long)d.B * (d.Hin / TH) * (d.Win / 16) * (d.C / 32);
+        const int pick = nch ? nch : forced;
+        if ((pick == 32 && b32 > 0) || (pick == 0 && b32 >= pivp_cu_count())) return launch_x6g(d, wb, stream, ln_nparts);
         return launch_bf16<16, true, 3>(d, wb, stream, ln_nparts, d.C / 16, 1, 0);
     }
     if (planes == 2) {   // split mode: 32-channel blocks (two ring slots) when they still give every CU a block, else 16-channel ones

@@ -50,7 +50,7 @@ def launch(name):
     x, h, c, w, b, co, ho, cx, C, H, wb = bufs[name]
     if X6:
         rc = lib.pivp_convlstm_bf16x6(x.data_ptr(), cx, cx, h.data_ptr(), C, wb.data_ptr(), b.data_ptr(), c.data_ptr(), co.data_ptr(),
-                                      ho.data_ptr(), None, None, 0, None, B, H, H, st)
+                                      ho.data_ptr(), None, None, 0, None, B, H, H, VARIANT, st)
         assert rc == 0, rc
         return
     if X3:

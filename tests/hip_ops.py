@@ -84,7 +84,7 @@ def convlstm_bf16x3(x, h, c, W, b, h_is_zero=False, nch=0):
     return nchw(h_out, B, H, Wd, C), nchw(c_out, B, H, Wd, C)
 
 
-def convlstm_bf16x6(x, h, c, W, b, h_is_zero=False):
+def convlstm_bf16x6(x, h, c, W, b, h_is_zero=False, nch=0, want_ln=False):
     """Three-piece ConvLSTM (six bf16 MFMAs per product, fp32-grade); returns (h, c)."""
     lib = _lib.load()
     B, cx, H, Wd = x.shape
@@ -94,10 +94,18 @@ def convlstm_bf16x6(x, h, c, W, b, h_is_zero=False):
     wb = torch.empty(3 * lib.pivp_lstm_bf16_weight_elems(cx + C, C), dtype=torch.int16, device=DEV)
     _lib.check(lib.pivp_pack_lstm_bf16x6(wd.data_ptr(), wb.data_ptr(), cx + C, C, stream()), 'pack_lstm_bf16x6')
     c_out = torch.empty_like(cd); h_out = torch.empty_like(hd)
+    import ctypes
+    cap = 4096
+    part = torch.zeros(B * cap * 4, dtype=torch.float32, device=DEV)
+    npart = ctypes.c_int(-1)
     _lib.check(lib.pivp_convlstm_bf16x6(xd.data_ptr(), cx, cx, None if h_is_zero else hd.data_ptr(), C, wb.data_ptr(), bd.data_ptr(),
-                                        cd.data_ptr(), c_out.data_ptr(), h_out.data_ptr(), None, None, 0, None, B, H, Wd, stream()),
+                                        cd.data_ptr(), c_out.data_ptr(), h_out.data_ptr(), None, part.data_ptr() if want_ln else None, cap,
+                                        ctypes.addressof(npart) if want_ln else None, B, H, Wd, nch, stream()),
                'convlstm_bf16x6')
     torch.cuda.synchronize()
+    if want_ln:
+        n = npart.value
+        return nchw(h_out, B, H, Wd, C), nchw(c_out, B, H, Wd, C), (part.cpu().numpy().reshape(-1)[:B * n * 4].reshape(B, n, 4) if n > 0 else None, n)
     return nchw(h_out, B, H, Wd, C), nchw(c_out, B, H, Wd, C)
 
 
