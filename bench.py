@@ -298,9 +298,14 @@ def main(argv=None):
                 t6 = max_over_ranks(t6)
                 rollout_step()
                 d = torch.stack(m6.gen_images).double() - torch.stack(model.gen_images).double()
-                l2 = float(d.pow(2).sum(dim=2).sqrt().max())
+                l2_steps = [float(v) for v in d.pow(2).sum(dim=2).sqrt().flatten(1).max(dim=1).values]
+                l2 = max(l2_steps)
                 x6_obj = {'ms_per_step': round(t6 / args.steps * 1e3, 3), 'frames_per_s': round(world * B * (T - 1) * args.steps / t6, 1),
                           'max_l2_vs_f32_rollout': l2,
+                          # per predicted frame: the first is one pass through the network; with RANDOM-INIT weights (this run's) any two fp32-grade
+                          # evaluations then drift apart by a factor per fed-back step -- the gate against float64 on trained weights is
+                          # tests/test_gpu_trained.py::test_bf16x6_mode_is_fp32_grade_on_trained_weights
+                          'max_l2_vs_f32_rollout_per_step': [float('%.3g' % v) for v in l2_steps],
                           'dtype': 'f32 operands of the ConvLSTM forward as 3 bf16 pieces, 6 bf16 MFMAs per product (layers on 8-wide maps: the f32 kernel)'}
                 if rank == 0 and not args.no_roofline:
                     r6 = roofline_pass(args, m6, x6_step, t6, np, torch, precision='bf16x6')

@@ -199,8 +199,8 @@ int pivp_convlstm_bf16x3(const float* x, int cx, int ldx, const float* h_prev, i
 int pivp_pack_lstm_bf16x6(const float* w, void* w_bf16, int cin_total, int C, void* stream);
 int pivp_convlstm_bf16x6(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
                          const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
-                         int* ln_nparts, int B, int H, int W, int nch, void* stream);   /* nch: 0 automatic; 16 = 16-channel blocks, weights through
-                         an LDS ring; 32 = 32-channel blocks (C % 32 == 0), weights from L2 straight into the operand registers */
+                         int* ln_nparts, int B, int H, int W, int nch, void* stream);   /* nch: 0 automatic; 1 = 16-channel blocks, weights through
+                         an LDS ring; 16 / 32 = 16- / 32-channel blocks (C % 32 == 0 for 32), weights from L2 straight into the operand registers */
 
 /* pivp_deconv3x3s2 with bf16 operands (precision mode bf16): x and w are rounded to bf16 on the way into the matrix pipe, accumulation, bias
  * and ReLU stay fp32.  Only maps with Hin % 8 == 0 and Win % 16 == 0 (and at least 16 tiles x column blocks) run in bf16; the call is the fp32 op otherwise. */

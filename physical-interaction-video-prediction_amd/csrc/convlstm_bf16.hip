@@ -602,9 +602,6 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         // fragments are requested right behind it and fly during chunk q's twelve MFMAs
         int tap = tap0, cg = 0;
         auto kbar = [&]() { if (!(PIVP_X6_ABL & 1)) __builtin_amdgcn_s_barrier(); };
-        // One k-step: the twelve MFMAs of register set CUR with the nine fragment reads of the NEXT k-step (set NXT) issued one behind each of
-        // the first nine.  (Reads first, MFMAs after -- the first version -- made all four waves, in step behind the barrier, queue 36 KB of LDS
-        // reads and only then start multiplying: the LDS phase and the matrix phase of a k-step alternated, 660 cycles for 384 of MFMA.)
         auto one_mfma = [&](auto CUR, auto I) {
             constexpr int st = decltype(CUR)::value, i = decltype(I)::value, term = i >> 1, mt = i & 1;
             if constexpr ((PIVP_X6_ABL & 16) && term != 5) return;
@@ -630,8 +627,9 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         };
         // A k-step of register set CUR (its fragments have landed): four MFMAs with the six A reads of the next k-step behind them (the patch does
         // not depend on the barrier), the block barrier -- behind queued MFMAs, so the matrix pipe keeps working while the waves meet --, four MFMAs
-        // with the three B reads the barrier has just published, four more MFMAs.  (With the barrier and then all nine reads IN FRONT of the
-        // MFMAs the pipe drained at every k-step: ~170 idle cycles per 384.)
+        // with the three B reads the barrier has just published, four more MFMAs.  (Measured, profiles/r04/NOTES.md 9: this order, reads one per
+        // MFMA gap, and barrier + all reads in front of the MFMAs run within 2 % of each other: ~610 cycles per k-step at the 2.03 GHz the chip holds
+        // here, for 12 MFMAs of 37 = 445; what is left is one wave per SIMD's exposed waits, which the 32-channel form below hides with a second wave.)
         auto kstep = [&](auto CUR, auto NXT, auto KS, int tp, int slot, auto RD) {
             constexpr bool rd = decltype(RD)::value;
             const int ty = tp / 5, tx = tp - ty * 5;
@@ -865,9 +863,17 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
 // FOUR k-steps (one tap) ahead into a register ring of 4 x 3 fragments: with two waves per SIMD a wave's k-step lasts ~0.45 us, so a tap of
 // lookahead covers an L2 round trip of 1-2 us; the two waves that share a fragment (wm = 0 / 1) ask for the same lines at about the same time.  Same arithmetic, term for term, as the ring form.
 // =================================================================================================================================
-__global__ __launch_bounds__(512, 1) void convlstm_x6g_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int wbytes) {
+// NWN = 2: the same with four waves (2 x 2), 16 channels per block, for layers whose 32-channel blocks would leave CUs idle: one wave per
+// SIMD (up to 512 registers), so the fragment ring is EIGHT k-steps (two taps) deep -- a lone wave's k-step lasts ~0.22 us.
+template <int NWN>
+__global__ __launch_bounds__(128 * NWN, 1) void convlstm_x6g_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int wbytes) {
     constexpr int PB = PH * RP16;                      // one patch plane: 36,864 B
     constexpr int PW = 20;
+    constexpr int NT = 128 * NWN;                      // threads
+    constexpr int PPP = NT / 8;                        // patch pixels per staging pass
+    constexpr int NPJX = 4;                            // staging passes per round: 4 x 64 pixels cover the patch's 240 with 512 threads;
+    constexpr int NRND = (PH * PW + NPJX * PPP - 1) / (NPJX * PPP);     // 256 threads take two rounds of 4 x 32 (eight passes in one round put the staged pixels in scratch)
+    constexpr int RD = NWN == 4 ? 4 : 8;               // k-steps of B fragments in registers
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* const patch = lds;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -875,7 +881,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_x6g_kernel(const IgemmDesc d,
     const int wm = wave8 & 1, wn = wave8 >> 1;
     const int half = lane >> 5, l31 = lane & 31;
     const int C = d.C;
-    const int n_nblk = C / 32;
+    const int n_nblk = C / (8 * NWN);
     const int H = d.Hin, W = d.Win;
     const int tpr = W / 16, tpi = (H / TH) * tpr;
     const int n_tiles = d.B * tpi;
@@ -897,23 +903,23 @@ __global__ __launch_bounds__(512, 1) void convlstm_x6g_kernel(const IgemmDesc d,
     // ---- patch staging (all 8 waves), as in convlstm_bf16_kernel: thread = (pixel (tid >> 3) + 64 j, 8-channel piece tid & 7), three planes ----
     const int cpiece = tid & 7;
     // (pixel -> image / patch offsets are recomputed where they are used: ten index registers held across the tap loop cost more than the divisions)
-    auto pix_of = [&](int j, int& a_pix, int& a_lds) {
-        const int p = (tid >> 3) + 64 * j;
+    auto pix_of = [&](int j, int& a_pix, int& a_lds) {      // j: pass index over all rounds
+        const int p = (tid >> 3) + PPP * j;
         const int py = p / PW, px = p - py * PW;
         const int iy = y0 - 2 + py, ix = x0 - 2 + px;
         const bool ok = p < PH * PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
         a_pix = ok ? (b0 * H + iy) * W + ix : -1;
         a_lds = p < PH * PW ? py * RP16 + px * PP : PW * PP;
     };
-    f32x4 plo[NPJ], phi[NPJ];
-    auto patch_load = [&](int cg) {
+    f32x4 plo[NPJX], phi[NPJX];
+    auto patch_load = [&](int cg, int rnd) {
         const int ch = cg * 64 + cpiece * 8;
         const bool s0 = ch < c0, s1 = !s0 && ch < cin;
         const int ld = s0 ? ld0 : ld1, co = s0 ? ch : ch - c0;
 #pragma unroll
-        for (int j = 0; j < NPJ; ++j) {
+        for (int j = 0; j < NPJX; ++j) {
             int a_pix, a_lds;
-            pix_of(j, a_pix, a_lds);
+            pix_of(rnd * NPJX + j, a_pix, a_lds);
             const unsigned off = (a_pix >= 0 && (s0 || s1)) ? (unsigned)((a_pix * ld + co) * 4) : OOB;
             if (s0) {
                 plo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
@@ -924,11 +930,11 @@ __global__ __launch_bounds__(512, 1) void convlstm_x6g_kernel(const IgemmDesc d,
             }
         }
     };
-    auto patch_store = [&]() {
+    auto patch_store = [&](int rnd) {
 #pragma unroll
-        for (int j = 0; j < NPJ; ++j) {
+        for (int j = 0; j < NPJX; ++j) {
             int a_pix, a_lds;
-            pix_of(j, a_pix, a_lds);
+            pix_of(rnd * NPJX + j, a_pix, a_lds);
             float r[8] = {plo[j][0], plo[j][1], plo[j][2], plo[j][3], phi[j][0], phi[j][1], phi[j][2], phi[j][3]};
             uint4 v;
             v.x = pack2(r[0], r[1]); v.y = pack2(r[2], r[3]); v.z = pack2(r[4], r[5]); v.w = pack2(r[6], r[7]);
@@ -962,8 +968,8 @@ __global__ __launch_bounds__(512, 1) void convlstm_x6g_kernel(const IgemmDesc d,
     // ---- the weights: fragment (group, tap, k-step, plane, c8 = nblk * 4 + wn) of the pack, 1 KB in lane order ------------------------
     const unsigned pls = (unsigned)(C / 8) * 1024u;    // bytes between the planes of a k-step
     const unsigned kss = 3u * pls, tps = 4u * kss;     // ... between k-steps, between taps
-    const unsigned voff = (unsigned)((nblk * 4 + wn) * 1024 + lane * 16);
-    bf16x8 Bf[4][3];                                   // [k-step][plane]: the current tap's fragments; behind each k-step its registers take the next tap's
+    const unsigned voff = (unsigned)((nblk * NWN + wn) * 1024 + lane * 16);
+    bf16x8 Bf[RD][3];                                  // [k-step (of the even / odd tap when RD = 8)][plane]: behind each k-step its registers take the fragments RD k-steps on
     auto bload = [&](bf16x8 (&dst)[3], unsigned soff) {
         if constexpr (PIVP_X6_ABL & 8) return;
 #pragma unroll
@@ -973,17 +979,22 @@ __global__ __launch_bounds__(512, 1) void convlstm_x6g_kernel(const IgemmDesc d,
     auto adv = [&](int& tp, int& cg) { tp = tp == 24 ? 0 : tp + 1; cg += tp == tap0 ? 1 : 0; };
 
     // ---- prologue ---------------------------------------------------------------------------------------------------------------------
-    patch_load(0);
+    patch_load(0, 0);
     int tap = tap0, cg = 0, tap1 = tap0, cg1 = 0;
     adv(tap1, cg1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) bload(Bf[ks], (unsigned)(cg * 25 + tap) * tps + ks * kss);
+    if constexpr (RD == 8) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bload(Bf[4 + ks], (unsigned)(cg1 * 25 + tap1) * tps + ks * kss);
+    }
     const int chl = wn * 8 + (l31 & 7);
-    const int ch = nblk * 32 + chl;
+    const int ch = nblk * 8 * NWN + chl;
     const int grp = l31 >> 3;
     float bj = 0.f, bi = 0.f, bf = 0.f, bo = 0.f;
     float cpre[2][4];
-    patch_store();
+    patch_store(0);
+    if constexpr (NRND == 2) { patch_load(0, 1); patch_store(1); }
     BF_STAMP(1);
     __syncthreads();
     BF_STAMP(2);
@@ -1039,11 +1050,60 @@ __global__ __launch_bounds__(512, 1) void convlstm_x6g_kernel(const IgemmDesc d,
     };
     auto a_base = [&](int tp) { const int ty = tp / 5; return lds0 + ty * RP16 + (tp - ty * 5) * PP; };
 
+    if constexpr (RD == 8) {
+        // one wave per SIMD: the taps of all groups as one sequence, two per iteration (the ring's halves), fragments requested two taps ahead
+        int tap2 = tap1, cg2 = cg1;
+        adv(tap2, cg2);
+        auto tap_body = [&](auto P, int it) __attribute__((always_inline)) {
+            constexpr int p = decltype(P)::value;
+            if (it == nchunks - 25) {                  // in front of the last group's taps: the epilogue's operands
+                bj = d.bias[ch]; bi = d.bias[C + ch]; bf = d.bias[2 * C + ch] + 1.0f; bo = d.bias[3 * C + ch];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = k * 4 + grp;
+                        const int i = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const int m = (b0 * H + y0 + (i >> 4)) * W + x0 + (i & 15);
+                        cpre[mt][k] = d.cstate_in[(size_t)m * C + ch];
+                    }
+            }
+            const unsigned ab = a_base(tap), ab1 = a_base(tap1);
+            const bool has1 = it + 1 < nchunks, has2 = it + 2 < nchunks;
+            const bool regroup = has1 && cg1 != cg;
+            const unsigned so2 = (unsigned)(cg2 * 25 + tap2) * tps;
+            kstep(S0{}, S1{}, K1{}, ab, Bf[4 * p + 0], std::true_type{});
+            if (has2) bload(Bf[4 * p + 0], so2);
+            kstep(S1{}, S0{}, K2{}, ab, Bf[4 * p + 1], std::true_type{});
+            if (has2) bload(Bf[4 * p + 1], so2 + kss);
+            kstep(S0{}, S1{}, K3{}, ab, Bf[4 * p + 2], std::true_type{});
+            if (has2) bload(Bf[4 * p + 2], so2 + 2 * kss);
+            if (has1 && !regroup) kstep(S1{}, S0{}, K0{}, ab1, Bf[4 * p + 3], std::true_type{});
+            else kstep(S1{}, S0{}, K0{}, ab1, Bf[4 * p + 3], std::false_type{});
+            if (has2) bload(Bf[4 * p + 3], so2 + 3 * kss);
+            if (regroup) {                             // next 64 input channels: every wave is done with the old patch
+                __syncthreads();
+                patch_load(cg1, 0);
+                patch_store(0);
+                if constexpr (NRND == 2) { patch_load(cg1, 1); patch_store(1); }
+                __syncthreads();
+                read_a_all(ab1);
+            }
+            tap = tap1; cg = cg1; tap1 = tap2; cg1 = cg2;
+            adv(tap2, cg2);
+        };
+        read_a_all(a_base(tap));
+        for (int it = 0; it < nchunks; it += 2) {
+            tap_body(std::integral_constant<int, 0>{}, it);
+            if (it + 1 < nchunks) tap_body(std::integral_constant<int, 1>{}, it + 1);
+        }
+    } else {
     for (int g = 0; g < ncg; ++g) {                    // 64 input channels of concat(x, h) at a time
         if (g > 0) {                                   // every wave is done with the old patch
             __syncthreads();
-            patch_load(g);
-            patch_store();
+            patch_load(g, 0);
+            patch_store(0);
+            if constexpr (NRND == 2) { patch_load(g, 1); patch_store(1); }
             __syncthreads();
         }
         if (g == ncg - 1) {
@@ -1077,6 +1137,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_x6g_kernel(const IgemmDesc d,
             tap = tap1; cg = cg1;
             adv(tap1, cg1);
         }
+    }
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -1134,8 +1195,10 @@ __global__ __launch_bounds__(512, 1) void convlstm_x6g_kernel(const IgemmDesc d,
         __syncthreads();
         if (lane == 0) red[wave8] = s1;
         __syncthreads();
-        const float cnt = 8.f * 64.f * 8.f;
-        const float mean = (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) / cnt;
+        const float cnt = (float)(2 * NWN) * 64.f * 8.f;
+        float ssum = (red[0] + red[1]) + (red[2] + red[3]);
+        if constexpr (NWN == 4) ssum += (red[4] + red[5]) + (red[6] + red[7]);
+        const float mean = ssum / cnt;
         float q = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -1146,7 +1209,9 @@ __global__ __launch_bounds__(512, 1) void convlstm_x6g_kernel(const IgemmDesc d,
         __syncthreads();
         if (tid == 0) {
             float* p = d.ln_part + ((size_t)b0 * d.ln_nparts + (size_t)trem * n_nblk + nblk) * 4;
-            p[0] = cnt; p[1] = mean; p[2] = ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15])); p[3] = 0.f;
+            float qs = (red[8] + red[9]) + (red[10] + red[11]);
+            if constexpr (NWN == 4) qs += (red[12] + red[13]) + (red[14] + red[15]);
+            p[0] = cnt; p[1] = mean; p[2] = qs; p[3] = 0.f;
         }
     }
 }
@@ -1204,33 +1269,35 @@ static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t
     return PIVP_LAUNCH_STATUS();
 }
 
+template <int NWN>
 static int launch_x6g(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts) {
     constexpr int lds_bytes = 3 * PH * RP16;
     static PerDeviceOnce once;
-    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<NWN>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     IgemmDesc dd = d;
-    const int tpi = (d.Hin / TH) * (d.Win / 16), nb = d.C / 32;
+    const int tpi = (d.Hin / TH) * (d.Win / 16), nb = d.C / (8 * NWN);
     const int np = tpi * nb;
     dd.ln_nparts = (d.ln_part && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
     const long long wbytes = (long long)lstm_bf16_weight_elems(d.c0 + (d.c1 ? d.c1 : d.C), 4 * d.C) * 3 * 2;
     if (wbytes >= (1LL << 31)) return PIVP_ERR_BADARG;
-    hipLaunchKernelGGL(convlstm_x6g_kernel, dim3(d.B * tpi * nb), dim3(512), lds_bytes, stream, dd, wb, (int)wbytes);
+    hipLaunchKernelGGL(convlstm_x6g_kernel<NWN>, dim3(d.B * tpi * nb), dim3(128 * NWN), lds_bytes, stream, dd, wb, (int)wbytes);
     return PIVP_LAUNCH_STATUS();
 }
 
 // d as for igemm_lstm (validated by the caller's igemm_validate(d, true) equivalent); wb = pack_lstm_bf16(d.w, ..., planes).
 int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nch, int planes) {
-    PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0)) && planes >= 1 && planes <= 3);
+    PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0) || (nch == 1 && planes == 3)) && planes >= 1 && planes <= 3);
     if (planes == 3) {   // three pieces: 16-wide tiles and 16-channel blocks only (convlstm_bf16x6_ok); 8-wide maps are the caller's to route elsewhere
         PIVP_CHECK_ARG(convlstm_bf16x6_ok(d));
-        // 32-channel blocks with the weights straight from L2 where they give every CU a block (one round); else 16-channel blocks on the ring
-        static const int forced = [] { const char* e = getenv("PIVP_X6_KERNEL"); return e ? atoi(e) : 0; }();     // tuning: 16 / 32
+        // weights straight from L2: 32-channel blocks (eight waves) where they give every CU a block, else 16-channel blocks (four waves).
+        // PIVP_X6_RING=1 (tuning / tests): the 16-channel blocks take the LDS-ring kernel instead
+        static const int ring = [] { const char* e = getenv("PIVP_X6_RING"); return e ? atoi(e) : 0; }();
         const long b32 = d.C % 32 ? 0 : (long)d.B * (d.Hin / TH) * (d.Win / 16) * (d.C / 32);
-        const int pick = nch ? nch : forced;
-        if ((pick == 32 && b32 > 0) || (pick == 0 && b32 >= pivp_cu_count())) return launch_x6g(d, wb, stream, ln_nparts);
-        return launch_bf16<16, true, 3>(d, wb, stream, ln_nparts, d.C / 16, 1, 0);
+        if ((nch == 32 && b32 > 0) || (nch == 0 && b32 >= pivp_cu_count())) return launch_x6g<4>(d, wb, stream, ln_nparts);
+        if (ring || nch == 1) return launch_bf16<16, true, 3>(d, wb, stream, ln_nparts, d.C / 16, 1, 0);
+        return launch_x6g<2>(d, wb, stream, ln_nparts);
     }
     if (planes == 2) {   // split mode: 32-channel blocks (two ring slots) when they still give every CU a block, else 16-channel ones
         const int tw2 = d.Win % 16 == 0 ? 16 : 8, ti2 = tw2 == 16 ? 1 : 2;

@@ -7,7 +7,7 @@ timeout -k 10 600 python -m pytest tests/test_gpu_bf16.py -x -q -s -k "x6" > $o/
 grep -a "three-piece\|bf16x6\|passed\|failed" $o/tests_bf16.txt | cut -c1-220
 timeout -k 10 600 python -m pytest tests/test_gpu_trained.py -x -q -s -k "bf16x6" > $o/tests_trained.txt 2>&1 || { tail -40 $o/tests_trained.txt; exit 1; }
 grep -a "rms ratio\|passed\|failed" $o/tests_trained.txt | cut -c1-260
-for v in 16 32 0; do
+for v in 1 16 32 0; do
   echo "== nch $v" | tee -a $o/layers_x6.txt
   PIVP_LSTM_VARIANT=$v PIVP_BENCH_INTERLEAVE=1 PIVP_BENCH_BF16=6 timeout -k 10 120 python scripts/bench_lstm_layers.py 32 20 2>&1 | grep -v amdgpu.ids | tee -a $o/layers_x6.txt || exit 1
 done

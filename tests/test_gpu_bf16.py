@@ -326,14 +326,14 @@ def test_convlstm_bf16x3_exact_when_operands_fit_two_pieces(ops):
 X6_SHAPES = [(2, 32, 32, 32), (2, 32, 64, 16), (2, 128, 64, 16), (1, 96, 32, 32), (3, 64, 64, 16), (1, 32, 32, 64), (2, 64, 128, 16)]
 
 
-@pytest.mark.parametrize('nch', [16, 32])
+@pytest.mark.parametrize('nch', [1, 16, 32])       # 1: 16-channel blocks, weights through the LDS ring; 16 / 32: weights from L2 into the operand registers
 @pytest.mark.parametrize('B,cx,C,H', X6_SHAPES)
 def test_convlstm_bf16x6_is_fp32_grade(ops, B, cx, C, H, nch):
     # fp32-representable operands, so that neither kernel is charged for the rounding of its inputs: hi + mid + lo is every operand exactly,
     # the dropped products are < 2^-24 of a product, and the main accumulator rounds once per 16 products (the fp32 kernel: once per product)
     x, h, c, W, b = [np.asarray(a, dtype=np.float32).astype(np.float64) for a in _case(B, cx, C, H, 131 + C + H)]
     hr, cr, _ = _lstm_ref(x, h, c, W, b)
-    h6, c6 = ops.convlstm_bf16x6(x, h, c, W, b, nch=nch)      # 16: weights through the LDS ring; 32: weights from L2 into the operand registers
+    h6, c6 = ops.convlstm_bf16x6(x, h, c, W, b, nch=nch)
     hf, cf = ops.convlstm(x, h, c, W, b)
     e6 = max(np.abs(h6 - hr).max(), np.abs(c6 - cr).max()); ef = max(np.abs(hf - hr).max(), np.abs(cf - cr).max())
     r6 = np.sqrt(((c6 - cr) ** 2).mean()); rf = np.sqrt(((cf - cr) ** 2).mean())
@@ -345,16 +345,18 @@ def test_convlstm_bf16x6_first_step_and_narrow_maps(ops):
     # t = 0 (no h operand: its K range is skipped) on a 16-wide map; an 8-wide map is not the three-piece kernel's: the call is the fp32 kernel's then
     x, h, c, W, b = [np.asarray(a, dtype=np.float32).astype(np.float64) for a in _case(2, 32, 32, 16, 5)]
     hr, cr, _ = _lstm_ref(x, h * 0, c, W, b)
-    for nch in (16, 32):
+    for nch in (1, 16, 32):
         h6, c6 = ops.convlstm_bf16x6(x, h, c, W, b, h_is_zero=True, nch=nch)
         assert np.abs(h6 - hr).max() < 2e-6 and np.abs(c6 - cr).max() < 2e-6
     # both forms against each other, and the LayerNorm partial statistics of their epilogues
     xa, ha, ca, Wa, ba = [np.asarray(a, dtype=np.float32).astype(np.float64) for a in _case(2, 96, 32, 32, 9)]
     h16, c16, (p16, n16) = ops.convlstm_bf16x6(xa, ha, ca, Wa, ba, nch=16, want_ln=True)
     h32, c32, (p32, n32) = ops.convlstm_bf16x6(xa, ha, ca, Wa, ba, nch=32, want_ln=True)
+    h1, c1, (p1, n1) = ops.convlstm_bf16x6(xa, ha, ca, Wa, ba, nch=1, want_ln=True)
     assert np.abs(h16 - h32).max() < 2e-6 and np.abs(c16 - c32).max() < 2e-6      # (same terms; the blocks walk the taps in different rotations)
-    assert n16 == 2 * n32 and n32 == 8
-    for pp, hh in ((p16, h16), (p32, h32)):
+    assert np.array_equal(h16, h1) and np.array_equal(c16, c1)                      # same blocks, same rotations, same order: identical bits
+    assert n16 == 2 * n32 and n32 == 8 and n1 == n16
+    for pp, hh in ((p16, h16), (p32, h32), (p1, h1)):
         cnt = pp[:, :, 0].sum(axis=1)
         mean = (pp[:, :, 0] * pp[:, :, 1]).sum(axis=1) / cnt
         assert np.allclose(cnt, 32 * 32 * 32) and np.allclose(mean, hh.reshape(2, -1).mean(axis=1), atol=1e-6)
