@@ -317,7 +317,7 @@ def main(argv=None):
                 x6_obj = None
 
         # ---- leg 2: the data-parallel train step (the run's precision; in the default fp32 run also config 3's bf16 arithmetic) ----------
-        train_obj = train_bf16_obj = None
+        train_obj = train_bf16_obj = train_x6_obj = None
         tmodel = opt = None
         dp = pivp_amd.GradAllReduce() if (do_train and world > 1) else None
 
@@ -393,7 +393,7 @@ def main(argv=None):
                 'allreduce_algo_ms_per_step': compare,
                 'dtype': {'fp32': 'f32', 'bf16': 'bf16 ConvLSTM / enc5 / enc6 operands, f32 accumulate, gradients and optimizer',
                           'bf16x3': 'f32 as 2 bf16 pieces in the ConvLSTM forward and data gradients',
-                          'bf16x6': 'f32 as 3 bf16 pieces in the ConvLSTM forward (6 MFMAs per product), f32 backward'}[precision],
+                          'bf16x6': 'f32 as 3 bf16 pieces in the ConvLSTM gate convolutions and their data gradients (6 bf16 MFMAs per product: fp32-grade), f32 weight gradients and elsewhere'}[precision],
                 'workload': 'optimizer.update (TM:950): forward + BPTT backward + gradient all-reduce + Adam, schedsamp_k=-1, batch %d/GPU' % B,
                 'loss': float(tloss),
             }
@@ -407,6 +407,15 @@ def main(argv=None):
                 # BASELINE.json config 3 names bf16 for the data-parallel configuration: at --gpus 8 this object IS config 3 (global batch 256)
                 train_bf16_obj, m16, _, _, _ = train_leg('bf16')
                 del m16
+            if args.mode != 'train' and args.precision == 'fp32' and not dry and not args.no_bf16x6:
+                # the fp32-grade train step on the bf16 matrix cores: gate convolutions and their data gradients as six bf16 MFMAs per product
+                # (three pieces per fp32 operand), weight gradients and everything else fp32.  An additional object: `train` stays the fp32 kernels'.
+                try:
+                    train_x6_obj, m6t, _, _, _ = train_leg('bf16x6')
+                    del m6t
+                except Exception as e:
+                    sys.stderr.write('bench.py: train_bf16x6 leg failed (%s: %s)\n' % (type(e).__name__, e))
+                    train_x6_obj = None
 
         # ---- the dominant kernel against its roofline, HIP events on the launch stream, second pass over the same K steps ----------
         pmodel = model if do_rollout else tmodel
@@ -469,6 +478,8 @@ def main(argv=None):
             out['train'] = train_obj
             if train_bf16_obj is not None:
                 out['train_bf16'] = train_bf16_obj
+            if train_x6_obj is not None:
+                out['train_bf16x6'] = train_x6_obj
         if dry:
             out['dry'] = True
         print(json.dumps(out))

@@ -39,7 +39,7 @@ extern "C" {
 #define PIVP_PRECISION_BF16X3 2
 #define PIVP_PRECISION_BF16X6 3
 
-int pivp_abi_version(void);   /* 10 (10: + PIVP_PRECISION_BF16X6, pivp_convlstm_bf16x6; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+int pivp_abi_version(void);   /* 10 (10: + PIVP_PRECISION_BF16X6, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
                                  5: + bf16 ConvLSTM, pivp_plan_set_precision, 6: + pivp_plan_set_group_join / pivp_plan_group_wait) */
 
 /* sha256 (hex) of the sources this library was compiled from (every .hip and .h under csrc/, and this header), embedded by build.py.  The Python
@@ -84,8 +84,8 @@ int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr);
  * and a product is three bf16 MFMAs, 16 bits of product mantissa, fp32 accumulation -- and the result stays inside the 1e-4 per-pixel gate
  * (4.4e-5 on the config 1 rollout; tests/test_gpu_bf16.py); the backward pass and every other op are the fp32 ones.
  * PIVP_PRECISION_BF16X6 = three bf16 pieces per fp32 operand (hi + mid + lo = v exactly) and the six products of weight >= 2^-16, i.e. fp32-grade
- * gate pre-activations computed on the bf16 matrix cores: only the FORWARD gate convolutions of layers whose map is a multiple of 16 wide change (8-wide
- * maps -- lstm5 on 64 x 64 frames -- run the fp32 kernel); every other op and the whole backward pass are the fp32 ones.  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
+ * gate pre-activations computed on the bf16 matrix cores: the gate convolutions and, in the backward sweep, their DATA gradients, of layers whose map is a
+ * multiple of 16 wide (8-wide maps -- lstm5 on 64 x 64 frames -- run the fp32 kernels); the weight gradients and every other op are the fp32 ones.  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
 int pivp_plan_set_precision(pivp_plan_t* plan, int precision);
 int pivp_plan_get_precision(const pivp_plan_t* plan);
 
@@ -219,6 +219,10 @@ int pivp_conv5x5_bf16(const float* x, int cin, int ldx, const float* w, void* w_
                       int B, int H, int W, void* stream);
 /* ... in the split mode (two bf16 pieces per operand, three MFMAs per product); w_bf16: twice the elements */
 int pivp_conv5x5_bf16x3(const float* x, int cin, int ldx, const float* w, void* w_bf16, float* out, int cout, int ldo, int accum,
+                        int B, int H, int W, void* stream);
+/* ... and as three pieces per operand, six MFMAs per product (fp32-grade; PIVP_PRECISION_BF16X6's data gradient): W % 16 == 0; w_bf16 holds
+ * 3 * pivp_conv5x5_bf16_weight_elems(cin, cout) 2-byte elements */
+int pivp_conv5x5_bf16x6(const float* x, int cin, int ldx, const float* w, void* w_bf16, float* out, int cout, int ldo, int accum,
                         int B, int H, int W, void* stream);
 
 /* ConvLSTM weight gradient with bf16 operands and fp32 accumulation (bf16 mode): dW[tap][ci][n] += sum_m concat(x, h_prev)[m + tap][ci]

@@ -138,22 +138,24 @@ __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned shor
 #define PIVP_X6_ABL 0       // timing-only ablations of the three-piece kernel (results are then wrong): 1 no per-k-step barriers, 2 no B fragment
 #endif                      // reads, 4 no reads of the A mid / lo planes, 8 no weight DMAs, 16 one MFMA per product instead of six
 constexpr int X6_CHUNK = 3 * 2 * 1024;      // ring slot of the 16-channel-block kernel: one k-step = 3 planes x 2 wave columns x 1 KB
-__global__ void pack_lstm_x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int C, long total) {
+// plain = 1: the same pack for a plain 5x5 convolution (the data gradient): fragment c8 = the 32 consecutive output columns c8 * 32 .. + 32 of the
+// Np padded ones (rows past N zero)
+__global__ void pack_lstm_x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int N, int Np, int plain, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
     long r = i >> 9;
-    const int n8 = C / 8;
+    const int n8 = Np / 32, C = N / 4;
     const int c8 = (int)(r % n8); r /= n8;
     const int pl = (int)(r % 3); r /= 3;
     const int ks = (int)(r & 3); r >>= 2;
     const int tap = (int)(r % 25);
     const int cg = (int)(r / 25);
     const int half = lane >> 5, l31 = lane & 31;
-    const int n = (l31 >> 3) * C + c8 * 8 + (l31 & 7);
+    const int n = plain ? c8 * 32 + l31 : (l31 >> 3) * C + c8 * 8 + (l31 & 7);
     const int ch = cg * 64 + ks * 16 + half * 8 + e;
     float v = 0.f;
-    if (ch < wcin) v = w[(((long)tap * (wcin >> 5) + (ch >> 5)) * (4 * C) + n) * 32 + (ch & 31)];
+    if (ch < wcin && n < N) v = w[(((long)tap * (wcin >> 5) + (ch >> 5)) * N + n) * 32 + (ch & 31)];
     __bf16 h = (__bf16)v;
     if (pl >= 1) { v -= (float)h; h = (__bf16)v; }
     if (pl == 2) { v -= (float)h; h = (__bf16)v; }
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
             // chunk q = (tap index it = q / 4 in this block's rotation, k-step q % 4) lives in slot q % 8.  Loader wave 4 + p moves plane p (two
             // fragments, wn = 0 / 1, per chunk); the fourth loader wave only stages the patch and keeps the barriers.
             const bool mover = wave < 3;
-            const size_t pls = (size_t)(C / 8) * 1024;                  // bytes between the planes of a k-step in the pack
+            const size_t pls = (size_t)(N / 32) * 1024;                 // bytes between the planes of a k-step in the pack (N: its rows, 4 C for the cell)
             const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(wb) + (size_t)wave * pls + (size_t)(nblk * 2) * 1024 + (size_t)lane * 16;
             const int NQ = nchunks * 4;
             int i_q = 0, i_tap = tap0, i_cg = 0;
@@ -1230,13 +1232,13 @@ int conv5x5_bf16_rows(int N) { return N % 128 == 0 ? N : (N + 63) / 64 * 64; }
 
 // w: fp32 K-inner packed [25][wcin/32][N][32]; wb: [ceil(wcin/64)][25][planes][Np][64] bf16 (Np >= N rows, the extra ones zero; 0 = N;
 // planes = 2: the hi / lo split of the split mode, lstm_bf16_weight_elems(wcin, Np) * 2 elements)
-int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s, int Np, int planes) {
+int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s, int Np, int planes, int plain) {
     if (Np == 0) Np = N;
     PIVP_CHECK_ARG(w && wb && wcin > 0 && wcin % 32 == 0 && N > 0 && Np >= N && planes >= 1 && planes <= 3);
     const long total = (long)lstm_bf16_weight_elems(wcin, Np) * planes;
-    if (planes == 3) {       // the three-piece kernel's fragment-major pack (ConvLSTM weights only: N = 4 C, no row padding)
-        PIVP_CHECK_ARG(Np == N && N % 64 == 0);
-        hipLaunchKernelGGL(pack_lstm_x6_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N / 4, total);
+    if (planes == 3) {       // the three-piece kernels' fragment-major pack: the cell's (N = 4 C, gate-interleaved fragments) or a plain conv's
+        PIVP_CHECK_ARG(Np % 64 == 0 && (plain || (Np == N && N % 32 == 0)));
+        hipLaunchKernelGGL(pack_lstm_x6_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, plain, total);
         return PIVP_LAUNCH_STATUS();
     }
     hipLaunchKernelGGL(pack_lstm_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, planes, total);
@@ -1317,11 +1319,11 @@ int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stre
 // conv5x5_bf16_rows(d.N)).  d.accum adds into out; d.ksplit_ok (out pre-zeroed, no accum) lets grids that would leave CUs idle split
 // the channel groups over gridDim.y and meet in out by atomic adds.  This is the ConvLSTM data gradient (x = dG, 4C channels).
 // ks > 1 (the K split conv5x5_bf16 will use) needs a zeroed destination: the caller asks first so that it only clears when needed
-int conv5x5_bf16_ksplit(const IgemmDesc& d) {
+int conv5x5_bf16_ksplit(const IgemmDesc& d, int planes) {
     const int Np = conv5x5_bf16_rows(d.N);
     const int tw = d.Win % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
     const int tiles = (d.B / ti_n) * (d.Hin / TH) * (d.Win / tw);
-    const int ncg = (d.c0 + d.c1 + 63) / 64, nb = Np / (Np % 128 == 0 ? 128 : 64);
+    const int ncg = (d.c0 + d.c1 + 63) / 64, nb = Np / ((Np % 128 == 0 && planes != 3) ? 128 : 64);     // (three pieces: 64-column blocks only)
     // split only up to ONE round of blocks (the kernel is one 8-wave block per CU): 512 blocks = two rounds of half-length blocks with
     // atomics and a zeroed destination were slower than 256 whole ones (bf16 train step 12.56 -> 12.36 ms)
     static const int forced = [] { const char* e = getenv("PIVP_BF16_KS_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning
@@ -1333,13 +1335,15 @@ int conv5x5_bf16_ksplit(const IgemmDesc& d) {
 }
 
 int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int planes) {
-    PIVP_CHECK_ARG(wb && bf16_geometry_ok(d) && d.out && d.N > 0 && d.ldo >= d.N && d.x0 && d.c0 > 0 && (planes == 1 || planes == 2));
+    PIVP_CHECK_ARG(wb && bf16_geometry_ok(d) && d.out && d.N > 0 && d.ldo >= d.N && d.x0 && d.c0 > 0 && planes >= 1 && planes <= 3 && (planes != 3 || d.Win % 16 == 0));
     const int Np = conv5x5_bf16_rows(d.N);
     IgemmDesc dd = d;
     dd.N = Np;                                         // the kernel's weight-row count
     const bool wide = Np % 128 == 0;
     const int nb = Np / (wide ? 128 : 64);
-    const int ks = conv5x5_bf16_ksplit(d);
+    const int ks = conv5x5_bf16_ksplit(d, planes);
+    if (planes == 3)     // three pieces (wb packed with planes = 3, plain = 1): 64-column blocks on the k-step ring
+        return launch_bf16<16, false, 3>(dd, wb, stream, nullptr, Np / 64, ks, d.N);
     if (planes == 2)     // split mode (wb packed with planes = 2): 128-column blocks run the two-slot schedule, 64-column ones the four-slot one
         return wide ? launch_bf16<32, false, 2>(dd, wb, stream, nullptr, nb, ks, d.N)
                     : launch_bf16<16, false, 2>(dd, wb, stream, nullptr, nb, ks, d.N);

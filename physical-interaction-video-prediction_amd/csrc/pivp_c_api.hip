@@ -226,18 +226,18 @@ static int conv5x5_bf16_desc(IgemmDesc& d, const float* x, int cin, int ldx, flo
     if (!accum && ldo == cout) d.ksplit_ok = 1;     // contiguous fresh output: the K-split path may be used; it needs a zeroed destination
     return PIVP_OK;
 }
-bool conv5x5_bf16_splits_k(int cin, int cout, int ldo, int B, int H, int W) {
+bool conv5x5_bf16_splits_k(int cin, int cout, int ldo, int B, int H, int W, int planes) {
     IgemmDesc d;
     static float dummy;
     if (conv5x5_bf16_desc(d, &dummy, cin, cin, &dummy, cout, ldo, 0, B, H, W) != PIVP_OK) return false;
-    return d.ksplit_ok && conv5x5_bf16_ksplit(d) > 1;
+    return d.ksplit_ok && conv5x5_bf16_ksplit(d, planes) > 1;
 }
 int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb, float* out, int cout, int ldo, int accum,
                      int B, int H, int W, hipStream_t s, int planes, int dest_zeroed) {
     IgemmDesc d;
     int rc = conv5x5_bf16_desc(d, x, cin, ldx, out, cout, ldo, accum, B, H, W);
     if (rc != PIVP_OK) return rc;
-    if (d.ksplit_ok && !dest_zeroed && conv5x5_bf16_ksplit(d) > 1 &&
+    if (d.ksplit_ok && !dest_zeroed && conv5x5_bf16_ksplit(d, planes) > 1 &&
         hipMemsetAsync(out, 0, (size_t)B * H * W * cout * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     return conv5x5_bf16(d, wb, s, planes);
 }
@@ -288,7 +288,7 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
                           const LnFuse* ln, int dx_only, const LnbSpec* dx_lnb) {
     const int M = B * H * W, cin = cx + C, N = 4 * C;
     // a K-split data gradient adds into d_in: the gate kernel clears it on the side (one launch less than a memset per cell and timestep)
-    const bool zero = wt_bf16 ? conv5x5_bf16_splits_k(N, cin, cin, B, H, W)
+    const bool zero = wt_bf16 ? conv5x5_bf16_splits_k(N, cin, cin, B, H, W, bf16_planes)
                               : (dx_only ? conv_s1_splits_k(N, cx, cin, 5, B, H, W, cin) : conv_s1_splits_k(N, cin, cin, 5, B, H, W, 0));
     int rc = lstm_gates_bwd(gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc, dc_valid, dG, M, C, s, B, ln, zero ? d_in : nullptr, (long long)M * cin);
     if (rc != PIVP_OK) return rc;
@@ -302,7 +302,7 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
     }
     if (wt_bf16) {   // bf16 precision mode: the data gradient with bf16 operands (wt_bf16 = bf16 pack of wt, built here unless wt_ready)
         if (!wt_ready) {
-            rc = pack_lstm_bf16(wt, wt_bf16, N, cin, s, conv5x5_bf16_rows(cin), bf16_planes);
+            rc = pack_lstm_bf16(wt, wt_bf16, N, cin, s, conv5x5_bf16_rows(cin), bf16_planes, 1);
             if (rc != PIVP_OK) return rc;
         }
         if (dx_lnb && dx_lnb->np) *dx_lnb->np = 0;      // (the bf16 data-gradient kernel has no LayerNorm-backward epilogue: the caller runs ln_bwd_sums)
@@ -522,6 +522,14 @@ extern "C" int pivp_conv5x5_bf16x3(const float* x, int cin, int ldx, const float
     int rc = pack_lstm_bf16(w, (unsigned short*)w_bf16, cin, cout, (hipStream_t)stream, conv5x5_bf16_rows(cout), 2);
     if (rc != PIVP_OK) return rc;
     return run_conv5x5_bf16(x, cin, ldx, (const unsigned short*)w_bf16, out, cout, ldo, accum, B, H, W, (hipStream_t)stream, 2);
+}
+// three-piece form (six MFMAs per product, fp32-grade): w_bf16 holds 3 * pivp_conv5x5_bf16_weight_elems(cin, cout) elements; W % 16 == 0
+extern "C" int pivp_conv5x5_bf16x6(const float* x, int cin, int ldx, const float* w, void* w_bf16, float* out, int cout, int ldo, int accum,
+                                   int B, int H, int W, void* stream) {
+    if (!x || !w || !w_bf16 || !out || cin <= 0 || cout <= 0 || W % 16) return PIVP_ERR_BADARG;
+    int rc = pack_lstm_bf16(w, (unsigned short*)w_bf16, cin, cout, (hipStream_t)stream, conv5x5_bf16_rows(cout), 3, 1);
+    if (rc != PIVP_OK) return rc;
+    return run_conv5x5_bf16(x, cin, ldx, (const unsigned short*)w_bf16, out, cout, ldo, accum, B, H, W, (hipStream_t)stream, 3);
 }
 // ConvLSTM weight gradient with bf16 operands: dW (K-inner packed like the weight, [25][(cx+C)/32][4C][32]) += x|h^T . dG per tap.
 extern "C" int pivp_wgrad5x5_bf16(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW, float* db,

@@ -38,7 +38,7 @@ int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, in
                 int dest_zeroed = 0,                         // 1: the caller has cleared `out` (see conv_s1_splits_k)
                 const LnbSpec* lnb = nullptr);
 bool conv_s1_splits_k(int cin, int cout, int ldo, int ksize, int B, int H, int W, int wN);
-bool conv5x5_bf16_splits_k(int cin, int cout, int ldo, int B, int H, int W);
+bool conv5x5_bf16_splits_k(int cin, int cout, int ldo, int B, int H, int W, int planes = 1);
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
               float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s,
               float* db = nullptr, int* bias_done = nullptr, int bf16 = 0,

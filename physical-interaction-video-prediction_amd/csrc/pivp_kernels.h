@@ -119,9 +119,9 @@ bool deconv_tile_ok(const IgemmDesc& d);
 int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr, int prec = 0);   // 0 fp32, 1 bf16 operands, 2 split (2 bf16 pieces)
 // bf16-operand ConvLSTM (csrc/convlstm_bf16.hip): wb = pack_lstm_bf16 of d.w; nch: 0 auto, 16 / 32 channels per block
 size_t lstm_bf16_weight_elems(int wcin, int N);
-int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s, int Np = 0, int planes = 1);
+int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s, int Np = 0, int planes = 1, int plain = 0);   // plain: planes = 3 only (a plain conv's columns)
 int conv5x5_bf16_rows(int N);
-int conv5x5_bf16_ksplit(const IgemmDesc& d);   // > 1: the launch will split K and needs d.out zeroed
+int conv5x5_bf16_ksplit(const IgemmDesc& d, int planes = 1);   // > 1: the launch will split K and needs d.out zeroed
 int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int planes = 1);   // plain 5x5 s1 conv (ConvLSTM data gradient)
 bool convlstm_bf16_ok(const IgemmDesc& d);
 bool convlstm_bf16x6_ok(const IgemmDesc& d);   // the three-piece form: 16-wide tiles only

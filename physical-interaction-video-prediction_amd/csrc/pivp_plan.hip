@@ -194,7 +194,7 @@ static void plan_layout(pivp_plan* p) {
             g.din[i][0] = carve(M * (kLstm[i].cx + kLstm[i].C)); g.din[i][1] = carve(M * (kLstm[i].cx + kLstm[i].C));
             g.dG[i] = carve(M * 4 * kLstm[i].C * 2 * p->wg_cap);
             g.wt_lstm[i] = carve((size_t)25 * (kLstm[i].cx + kLstm[i].C) * 4 * kLstm[i].C);
-            g.wtb_lstm[i] = carve(lstm_bf16_weight_elems(4 * kLstm[i].C, conv5x5_bf16_rows(kLstm[i].cx + kLstm[i].C)));   // two planes
+            g.wtb_lstm[i] = carve(lstm_bf16_weight_elems(4 * kLstm[i].C, conv5x5_bf16_rows(kLstm[i].cx + kLstm[i].C)) * 3 / 2 + 64);   // up to three planes
             g.wt_enc[i] = (i == 0 || i == 3) ? 0 : carve((size_t)encw[i]);
         }
         g.go[0] = carve((size_t)B * 3 * HW); g.go[1] = carve((size_t)B * 3 * HW);
@@ -734,7 +734,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                                  Sp ? ws + Sp->c[i] : ws + p->o_zero, ws + S.c[i], nullptr, L.C,
                                  last_step ? nullptr : ws + g.din[i][npar] + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
                                  ring + (size_t)wg_slot * dG1, ws + g.wt_lstm[i], ws + g.din[i][par], nullptr, nullptr, B, hh, wwid,
-                                 s, 1, (p->lstm_bf16 && p->lstm_planes != 3) ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->lstm_planes,
+                                 s, 1, (p->lstm_bf16 && (p->lstm_planes != 3 || wwid % 16 == 0)) ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->lstm_planes,
                                  wg_flush ? fork_of(i, f) : nullptr, &lf[i],    // dW = null: only the fork's `ready` (behind the gate math) is used
                                  t == 0 ? 1 : 0, dx_lnb));                      // t = 0: nobody reads d h_{-1}
         if (t == 0) RC(ln_finish(i + 1));       // the sweep's last timestep: the norm's partial parameter planes (written by the gate kernel) become its gradient
@@ -940,11 +940,11 @@ static int rollout_backward_sweep(pivp_plan_t* plan, const float* images, const 
     // weights are constant during the sweep: build the transposed packs for the data gradients once
     for (int i = 0; i < 7; ++i)
         RC(repack_transpose(P(plan, plan->i_lstm_w[i]), ws + g.wt_lstm[i], 25, kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C, 1, s));
-    if (plan->lstm_bf16 && plan->lstm_planes != 3)        // bf16 / split modes: the ConvLSTM data gradients run on these packs (one plane, or the hi / lo pair)
+    if (plan->lstm_bf16)        // bf16 / split modes: the ConvLSTM data gradients run on these packs (one plane, the hi / lo pair, or the three pieces)
         for (int i = 0; i < 7; ++i) {
             const int cin = kLstm[i].cx + kLstm[i].C;
             RC(pack_lstm_bf16(ws + g.wt_lstm[i], reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]), 4 * kLstm[i].C, cin, s,
-                              conv5x5_bf16_rows(cin), plan->lstm_planes));
+                              conv5x5_bf16_rows(cin), plan->lstm_planes, 1));
         }
     {
         const int ecin[7] = {0, 32, 64, 0, 128, 96, 64};

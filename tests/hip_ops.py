@@ -338,16 +338,16 @@ def select_frames(gt, gen, take):
     return out.cpu().numpy()
 
 
-def conv5x5_bf16(x, W, accum_into=None, split=False):
+def conv5x5_bf16(x, W, accum_into=None, split=False, pieces=0):
     """Plain 5x5 stride-1 'same' convolution with bf16 operands: x NCHW, W (Cout, Cin, 5, 5) -> NCHW."""
     lib = _lib.load()
     B, cin, H, Wd = x.shape
     cout = W.shape[0]
     xd = nhwc(x)
     wd = _t(pivp_amd.to_internal('lstm1/conv/W', W))          # [25][cin/32][cout][32]
-    wb = torch.empty((2 if split else 1) * lib.pivp_conv5x5_bf16_weight_elems(cin, cout), dtype=torch.int16, device=DEV)
+    wb = torch.empty((3 if pieces == 3 else 2 if split else 1) * lib.pivp_conv5x5_bf16_weight_elems(cin, cout), dtype=torch.int16, device=DEV)
     out = nhwc(accum_into) if accum_into is not None else torch.full((B, H, Wd, cout), 7.0, dtype=torch.float32, device=DEV)
-    _lib.check((lib.pivp_conv5x5_bf16x3 if split else lib.pivp_conv5x5_bf16)(xd.data_ptr(), cin, cin, wd.data_ptr(), wb.data_ptr(), out.data_ptr(), cout, cout,
+    _lib.check((lib.pivp_conv5x5_bf16x6 if pieces == 3 else lib.pivp_conv5x5_bf16x3 if split else lib.pivp_conv5x5_bf16)(xd.data_ptr(), cin, cin, wd.data_ptr(), wb.data_ptr(), out.data_ptr(), cout, cout,
                                      1 if accum_into is not None else 0, B, H, Wd, stream()), 'conv5x5_bf16')
     torch.cuda.synchronize()
     return nchw(out, B, H, Wd, cout)

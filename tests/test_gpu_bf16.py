@@ -368,6 +368,27 @@ def test_convlstm_bf16x6_first_step_and_narrow_maps(ops):
     assert rc == -1            # PIVP_ERR_BADARG: the per-op entry has no fp32 weights to fall back on (the plan does)
 
 
+@pytest.mark.parametrize('B,cin,cout,H', [(2, 128, 64, 32), (2, 256, 96, 16), (2, 256, 128, 16), (32, 256, 192, 16), (1, 128, 128, 32)])
+def test_conv5x5_bf16x6(ops, B, cin, cout, H):
+    # the data gradients of the three-piece mode: 64-column blocks on the k-step ring, padded columns (96), K split over the channel groups (B = 32
+    # on a 16 x 16 map: 64 tiles x 3 column blocks), against the float64 convolution and the fp32 kernel
+    rs = np.random.RandomState(cin + cout + H + 6)
+    x = rs.randn(B, cin, H, H).astype(np.float32).astype(np.float64); W = (rs.randn(cout, cin, 5, 5) / np.sqrt(25 * cin)).astype(np.float32).astype(np.float64)
+    ref = R.conv2d(x, W, np.zeros(cout), 1, 2)
+    e6 = ops.conv5x5_bf16(x, W, pieces=3) - ref
+    ef = ops.conv_s1(x, W, 5) - ref if hasattr(ops, 'conv_s1') else None
+    print('conv5x5 %d->%d @%d: three-piece max |err| %.2e rms %.2e' % (cin, cout, H, np.abs(e6).max(), np.sqrt((e6 ** 2).mean()))
+          + ('' if ef is None else '; fp32 kernel max %.2e rms %.2e' % (np.abs(ef).max(), np.sqrt((ef ** 2).mean()))))
+    # (one accumulation chain per output over K = 25 cin: 2.1e-7 rms at K = 3200-6400 with the channel groups split over blocks, 4.4e-7 for the unsplit 6400)
+    assert np.abs(e6).max() < 1e-5 and np.sqrt((e6 ** 2).mean()) < 6e-7
+    if ef is not None:
+        assert np.sqrt((e6 ** 2).mean()) < 1.2 * np.sqrt((ef ** 2).mean())
+    acc = rs.randn(B, cout, H, H).astype(np.float32)
+    if B < 32:                                       # accumulate form
+        out = ops.conv5x5_bf16(x, W, accum_into=acc.astype(np.float64), pieces=3)
+        assert np.abs(out - (ref + acc)).max() < 6e-6       # (+ the rounding of the final add at |values| up to 5)
+
+
 def test_rollout_bf16x6_is_as_close_to_float64_as_the_fp32_path():
     g = np.load(__import__('os').path.join(GOLD, 'cdna_b2_t10.npz'))
     m6, loss6, gen6 = _rollout('bf16x6')
@@ -380,7 +401,7 @@ def test_rollout_bf16x6_is_as_close_to_float64_as_the_fp32_path():
     assert m6._active.lib.pivp_plan_get_precision(m6._active.h) == 3
 
 
-def test_train_step_in_bf16x6_mode_runs_the_fp32_backward():
+def test_train_step_in_bf16x6_mode_matches_the_fp32_gradients():
     import pivp_amd
     outs = {}
     for prec in ('fp32', 'bf16x6'):

@@ -77,9 +77,11 @@ def test_trained_weights_hold_the_gate_on_every_step(name):
 
 
 @pytest.mark.gpu
-def test_config2_gradients_on_trained_weights():
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x6'])
+def test_config2_gradients_on_trained_weights(precision):
     """optimizer.update's gradients (TM:950) at config 2's full size on the TRAINED CDNA weights and held-out video, against float64
-    autograd of the PyTorch restatement (tests/golden/make_golden.py grads_trained): per tensor the L2 norm, the sum and 512 sampled entries."""
+    autograd of the PyTorch restatement (tests/golden/make_golden.py grads_trained): per tensor the L2 norm, the sum and 512 sampled entries.
+    'bf16x6': the gate convolutions and their data gradients as six bf16 MFMAs per product (fp32-grade): the same gates."""
     import torch
     assert torch.cuda.is_available(), 'GPU tests need the MI355X'
     import pivp_amd
@@ -87,7 +89,7 @@ def test_config2_gradients_on_trained_weights():
     P0 = R.init_params(seed=1, dtype=np.float32, scale=1.0)
     P = TW.load_trained(str(g['trained']), P0)
     imgs, acts, stas = R.moving_batch(32, 10, 64, 64, seed=int(g['data_seed']))
-    m = pivp_amd.Model(10, prefix='t', keep_activations=True)
+    m = pivp_amd.Model(10, prefix='t', keep_activations=True, precision=precision)
     m.load_state_dict_reference(P)
     loss = float(m([imgs, acts, stas], 0))
     m.cleargrads(); m.backward()
@@ -110,7 +112,7 @@ def test_config2_gradients_on_trained_weights():
         worst = max(worst, (max(rel, nrm), k))
         assert rel < 2e-3, '%s: relative L2 error of the sampled entries %.3e' % (k, rel)
         assert nrm < 1e-3, '%s: gradient norm off by %.3e' % (k, nrm)
-    print('config 2 on trained weights (B=32) gradients: worst tensor %s, relative error %.2e' % (worst[1], worst[0]))
+    print('config 2 on trained weights (B=32, %s) gradients: worst tensor %s, relative error %.2e' % (precision, worst[1], worst[0]))
 
 
 @pytest.mark.gpu
