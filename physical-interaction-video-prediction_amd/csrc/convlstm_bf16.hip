@@ -867,20 +867,24 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
 // =================================================================================================================================
 // NWN = 2: the same with four waves (2 x 2), 16 channels per block, for layers whose 32-channel blocks would leave CUs idle: one wave per
 // SIMD (up to 512 registers), so the fragment ring is EIGHT k-steps (two taps) deep -- a lone wave's k-step lasts ~0.22 us.
-template <int NWN>
-__global__ __launch_bounds__(128 * NWN, 1) void convlstm_x6g_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int wbytes) {
+// NWM x NWN waves over the 128 anchors x (8 NWN channels x 4 gates) of a block: 2 x 4 (32 channels), 4 x 2 (16 channels, still two waves per
+// SIMD: a wave's tile is 32 anchors), 2 x 2 (16 channels, four waves).
+template <int NWM, int NWN>
+__global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int wbytes) {
     constexpr int PB = PH * RP16;                      // one patch plane: 36,864 B
     constexpr int PW = 20;
-    constexpr int NT = 128 * NWN;                      // threads
+    constexpr int NW = NWM * NWN;                      // waves
+    constexpr int MT = 4 / NWM;                        // 32-anchor M tiles per wave
+    constexpr int NT = 64 * NW;                        // threads
     constexpr int PPP = NT / 8;                        // patch pixels per staging pass
     constexpr int NPJX = 4;                            // staging passes per round: 4 x 64 pixels cover the patch's 240 with 512 threads;
     constexpr int NRND = (PH * PW + NPJX * PPP - 1) / (NPJX * PPP);     // 256 threads take two rounds of 4 x 32 (eight passes in one round put the staged pixels in scratch)
-    constexpr int RD = NWN == 4 ? 4 : 8;               // k-steps of B fragments in registers
+    constexpr int RD = NW == 8 ? 4 : 8;                // k-steps of B fragments in registers
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* const patch = lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave8 & 1, wn = wave8 >> 1;
+    const int wm = wave8 % NWM, wn = wave8 / NWM;
     const int half = lane >> 5, l31 = lane & 31;
     const int C = d.C;
     const int n_nblk = C / (8 * NWN);
@@ -954,15 +958,15 @@ __global__ __launch_bounds__(128 * NWN, 1) void convlstm_x6g_kernel(const IgemmD
     };
     const int tap0 = (lid * 7) % 25;
 
-    f32x16 acc[2], accl[2];
+    f32x16 acc[MT], accl[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[mt][r] = 0.f; accl[mt][r] = 0.f; }
-    int a_off[2];
+    int a_off[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int i = 64 * wm + 32 * mt + l31;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int i = 32 * MT * wm + 32 * mt + l31;
         a_off[mt] = (i >> 4) * RP16 + (i & 15) * PP + half * 16;
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
@@ -994,27 +998,28 @@ __global__ __launch_bounds__(128 * NWN, 1) void convlstm_x6g_kernel(const IgemmD
     const int ch = nblk * 8 * NWN + chl;
     const int grp = l31 >> 3;
     float bj = 0.f, bi = 0.f, bf = 0.f, bo = 0.f;
-    float cpre[2][4];
+    float cpre[MT][4];
     patch_store(0);
     if constexpr (NRND == 2) { patch_load(0, 1); patch_store(1); }
     BF_STAMP(1);
     __syncthreads();
     BF_STAMP(2);
 
-    bf16x8 fa[2][2], fal[2][2], fa3[2][2];             // [register set][M tile]: the A fragments of a k-step, hi / mid / lo planes
+    bf16x8 fa[2][MT], fal[2][MT], fa3[2][MT];          // [register set][M tile]: the A fragments of a k-step, hi / mid / lo planes
     auto wait_a = [&](auto SET) {
         constexpr int st = decltype(SET)::value;
-        wait_lgkm(fa[st][0], fa[st][1], fal[st][0], fal[st][1], fa3[st][0], fa3[st][1]);
+        if constexpr (MT == 2) wait_lgkm(fa[st][0], fa[st][1], fal[st][0], fal[st][1], fa3[st][0], fa3[st][1]);
+        else wait_lgkm(fa[st][0], fal[st][0], fa3[st][0]);
     };
-    auto read_a = [&](auto SET, auto KS, auto I, unsigned ab) {       // read I of the six: plane I / 2, M tile I % 2
-        constexpr int st = decltype(SET)::value, ks = decltype(KS)::value, i = decltype(I)::value, pl = i >> 1, mt = i & 1;
+    auto read_a = [&](auto SET, auto KS, auto I, unsigned ab) {       // read I of the 3 MT: plane I / MT, M tile I % MT
+        constexpr int st = decltype(SET)::value, ks = decltype(KS)::value, i = decltype(I)::value, pl = i / MT, mt = i % MT;
         if constexpr ((PIVP_X6_ABL & 4) && pl > 0) return;
         bf16x8 v = lds_read_b128<ks * 32>(ab + pl * PB + a_off[mt]);
         if constexpr (pl == 0) fa[st][mt] = v; else if constexpr (pl == 1) fal[st][mt] = v; else fa3[st][mt] = v;
     };
     // twelve MFMAs of register set CUR against the fragments b[3] (hi, mid, lo); corrections into accl, the leading term into acc
     auto mfma = [&](auto CUR, auto I, const bf16x8 (&b)[3]) {
-        constexpr int st = decltype(CUR)::value, i = decltype(I)::value, term = i >> 1, mt = i & 1;
+        constexpr int st = decltype(CUR)::value, i = decltype(I)::value, term = i / MT, mt = i % MT;
         if constexpr ((PIVP_X6_ABL & 16) && term != 5) return;
         if constexpr (term == 0) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa3[st][mt], b[0], accl[mt], 0, 0, 0);        // lo * hi
         else if constexpr (term == 1) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], b[2], accl[mt], 0, 0, 0);    // hi * lo
@@ -1032,10 +1037,16 @@ __global__ __launch_bounds__(128 * NWN, 1) void convlstm_x6g_kernel(const IgemmD
 #define PIVP_X6_R(I) if constexpr (rd) read_a(NXT, KSN, std::integral_constant<int, I>{}, abn);
 #define PIVP_X6_S __builtin_amdgcn_sched_barrier(0);
         PIVP_X6_S
-        PIVP_X6_M(0) PIVP_X6_R(0) PIVP_X6_R(1) PIVP_X6_S
-        PIVP_X6_M(1) PIVP_X6_R(2) PIVP_X6_R(3) PIVP_X6_S
-        PIVP_X6_M(2) PIVP_X6_R(4) PIVP_X6_R(5) PIVP_X6_S
-        PIVP_X6_M(3) PIVP_X6_M(4) PIVP_X6_M(5) PIVP_X6_M(6) PIVP_X6_M(7) PIVP_X6_M(8) PIVP_X6_M(9) PIVP_X6_M(10) PIVP_X6_M(11)
+        if constexpr (MT == 2) {
+            PIVP_X6_M(0) PIVP_X6_R(0) PIVP_X6_R(1) PIVP_X6_S
+            PIVP_X6_M(1) PIVP_X6_R(2) PIVP_X6_R(3) PIVP_X6_S
+            PIVP_X6_M(2) PIVP_X6_R(4) PIVP_X6_R(5) PIVP_X6_S
+            PIVP_X6_M(3) PIVP_X6_M(4) PIVP_X6_M(5) PIVP_X6_M(6) PIVP_X6_M(7) PIVP_X6_M(8) PIVP_X6_M(9) PIVP_X6_M(10) PIVP_X6_M(11)
+        } else {
+            PIVP_X6_M(0) PIVP_X6_R(0) PIVP_X6_R(1) PIVP_X6_S
+            PIVP_X6_M(1) PIVP_X6_R(2) PIVP_X6_S
+            PIVP_X6_M(2) PIVP_X6_M(3) PIVP_X6_M(4) PIVP_X6_M(5)
+        }
         PIVP_X6_S
 #undef PIVP_X6_M
 #undef PIVP_X6_R
@@ -1048,7 +1059,7 @@ __global__ __launch_bounds__(128 * NWN, 1) void convlstm_x6g_kernel(const IgemmD
     using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
     auto read_a_all = [&](unsigned ab) {               // the first k-step of a tap into set 0 (prologue, and behind a restaged patch)
         read_a(S0{}, K0{}, I0{}, ab); read_a(S0{}, K0{}, I1{}, ab); read_a(S0{}, K0{}, I2{}, ab);
-        read_a(S0{}, K0{}, I3{}, ab); read_a(S0{}, K0{}, I4{}, ab); read_a(S0{}, K0{}, I5{}, ab);
+        if constexpr (MT == 2) { read_a(S0{}, K0{}, I3{}, ab); read_a(S0{}, K0{}, I4{}, ab); read_a(S0{}, K0{}, I5{}, ab); }
     };
     auto a_base = [&](int tp) { const int ty = tp / 5; return lds0 + ty * RP16 + (tp - ty * 5) * PP; };
 
@@ -1061,11 +1072,11 @@ __global__ __launch_bounds__(128 * NWN, 1) void convlstm_x6g_kernel(const IgemmD
             if (it == nchunks - 25) {                  // in front of the last group's taps: the epilogue's operands
                 bj = d.bias[ch]; bi = d.bias[C + ch]; bf = d.bias[2 * C + ch] + 1.0f; bo = d.bias[3 * C + ch];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int r = k * 4 + grp;
-                        const int i = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const int i = 32 * MT * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
                         const int m = (b0 * H + y0 + (i >> 4)) * W + x0 + (i & 15);
                         cpre[mt][k] = d.cstate_in[(size_t)m * C + ch];
                     }
@@ -1113,11 +1124,11 @@ __global__ __launch_bounds__(128 * NWN, 1) void convlstm_x6g_kernel(const IgemmD
             // requested in the prologue they hold 12 registers through every tap loop)
             bj = d.bias[ch]; bi = d.bias[C + ch]; bf = d.bias[2 * C + ch] + 1.0f; bo = d.bias[3 * C + ch];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int r = k * 4 + grp;
-                    const int i = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int i = 32 * MT * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
                     const int m = (b0 * H + y0 + (i >> 4)) * W + x0 + (i & 15);
                     cpre[mt][k] = d.cstate_in[(size_t)m * C + ch];
                 }
@@ -1142,7 +1153,7 @@ __global__ __launch_bounds__(128 * NWN, 1) void convlstm_x6g_kernel(const IgemmD
     }
     }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] += accl[mt][r];
     BF_STAMP(3);
@@ -1152,9 +1163,9 @@ __global__ __launch_bounds__(128 * NWN, 1) void convlstm_x6g_kernel(const IgemmD
         const float lo = (idx & 1) ? v[1] : v[0], hi = (idx & 1) ? v[3] : v[2];
         return (idx & 2) ? hi : lo;
     };
-    float sv[2][4];
+    float sv[MT][4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float rows[4], val[4], g4[4];
@@ -1166,7 +1177,7 @@ __global__ __launch_bounds__(128 * NWN, 1) void convlstm_x6g_kernel(const IgemmD
 #pragma unroll
             for (int g = 0; g < 4; ++g) g4[g] = pick(val, g ^ grp);
             const int r = k * 4 + grp;
-            const int i = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int i = 32 * MT * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
             const int m = (b0 * H + y0 + (i >> 4)) * W + x0 + (i & 15);
             const size_t o = (size_t)m * C + ch;
             const float aj = b_tanh(g4[0] + bj), ai = b_sigmoid(g4[1] + bi);
@@ -1190,20 +1201,20 @@ __global__ __launch_bounds__(128 * NWN, 1) void convlstm_x6g_kernel(const IgemmD
         float* red = reinterpret_cast<float*>(lds);
         float s1 = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int k = 0; k < 4; ++k) s1 += sv[mt][k];
         s1 = wave_sum(s1);
         __syncthreads();
         if (lane == 0) red[wave8] = s1;
         __syncthreads();
-        const float cnt = (float)(2 * NWN) * 64.f * 8.f;
+        const float cnt = (float)NW * 64.f * 4.f * MT;
         float ssum = (red[0] + red[1]) + (red[2] + red[3]);
-        if constexpr (NWN == 4) ssum += (red[4] + red[5]) + (red[6] + red[7]);
+        if constexpr (NW == 8) ssum += (red[4] + red[5]) + (red[6] + red[7]);
         const float mean = ssum / cnt;
         float q = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const float dd = sv[mt][k] - mean; q = fmaf(dd, dd, q); }
         q = wave_sum(q);
@@ -1212,7 +1223,7 @@ __global__ __launch_bounds__(128 * NWN, 1) void convlstm_x6g_kernel(const IgemmD
         if (tid == 0) {
             float* p = d.ln_part + ((size_t)b0 * d.ln_nparts + (size_t)trem * n_nblk + nblk) * 4;
             float qs = (red[8] + red[9]) + (red[10] + red[11]);
-            if constexpr (NWN == 4) qs += (red[12] + red[13]) + (red[14] + red[15]);
+            if constexpr (NW == 8) qs += (red[12] + red[13]) + (red[14] + red[15]);
             p[0] = cnt; p[1] = mean; p[2] = qs; p[3] = 0.f;
         }
     }
@@ -1271,11 +1282,11 @@ static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t
     return PIVP_LAUNCH_STATUS();
 }
 
-template <int NWN>
+template <int NWM, int NWN>
 static int launch_x6g(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts) {
     constexpr int lds_bytes = 3 * PH * RP16;
     static PerDeviceOnce once;
-    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<NWN>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<NWM, NWN>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     IgemmDesc dd = d;
     const int tpi = (d.Hin / TH) * (d.Win / 16), nb = d.C / (8 * NWN);
     const int np = tpi * nb;
@@ -1284,22 +1295,23 @@ static int launch_x6g(const IgemmDesc& d, const unsigned short* wb, hipStream_t 
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
     const long long wbytes = (long long)lstm_bf16_weight_elems(d.c0 + (d.c1 ? d.c1 : d.C), 4 * d.C) * 3 * 2;
     if (wbytes >= (1LL << 31)) return PIVP_ERR_BADARG;
-    hipLaunchKernelGGL(convlstm_x6g_kernel<NWN>, dim3(d.B * tpi * nb), dim3(128 * NWN), lds_bytes, stream, dd, wb, (int)wbytes);
+    hipLaunchKernelGGL((convlstm_x6g_kernel<NWM, NWN>), dim3(d.B * tpi * nb), dim3(64 * NWM * NWN), lds_bytes, stream, dd, wb, (int)wbytes);
     return PIVP_LAUNCH_STATUS();
 }
 
 // d as for igemm_lstm (validated by the caller's igemm_validate(d, true) equivalent); wb = pack_lstm_bf16(d.w, ..., planes).
 int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nch, int planes) {
-    PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0) || (nch == 1 && planes == 3)) && planes >= 1 && planes <= 3);
+    PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0) || ((nch == 1 || nch == 2) && planes == 3)) && planes >= 1 && planes <= 3);
     if (planes == 3) {   // three pieces: 16-wide tiles and 16-channel blocks only (convlstm_bf16x6_ok); 8-wide maps are the caller's to route elsewhere
         PIVP_CHECK_ARG(convlstm_bf16x6_ok(d));
         // weights straight from L2: 32-channel blocks (eight waves) where they give every CU a block, else 16-channel blocks (four waves).
         // PIVP_X6_RING=1 (tuning / tests): the 16-channel blocks take the LDS-ring kernel instead
         static const int ring = [] { const char* e = getenv("PIVP_X6_RING"); return e ? atoi(e) : 0; }();
         const long b32 = d.C % 32 ? 0 : (long)d.B * (d.Hin / TH) * (d.Win / 16) * (d.C / 32);
-        if ((nch == 32 && b32 > 0) || (nch == 0 && b32 >= pivp_cu_count())) return launch_x6g<4>(d, wb, stream, ln_nparts);
+        if ((nch == 32 && b32 > 0) || (nch == 0 && b32 >= pivp_cu_count())) return launch_x6g<2, 4>(d, wb, stream, ln_nparts);
         if (ring || nch == 1) return launch_bf16<16, true, 3>(d, wb, stream, ln_nparts, d.C / 16, 1, 0);
-        return launch_x6g<2>(d, wb, stream, ln_nparts);
+        if (nch == 2) return launch_x6g<2, 2>(d, wb, stream, ln_nparts);      // (four waves, one per SIMD: measured against the eight-wave form)
+        return launch_x6g<4, 2>(d, wb, stream, ln_nparts);
     }
     if (planes == 2) {   // split mode: 32-channel blocks (two ring slots) when they still give every CU a block, else 16-channel ones
         const int tw2 = d.Win % 16 == 0 ? 16 : 8, ti2 = tw2 == 16 ? 1 : 2;

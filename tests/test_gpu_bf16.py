@@ -326,7 +326,7 @@ def test_convlstm_bf16x3_exact_when_operands_fit_two_pieces(ops):
 X6_SHAPES = [(2, 32, 32, 32), (2, 32, 64, 16), (2, 128, 64, 16), (1, 96, 32, 32), (3, 64, 64, 16), (1, 32, 32, 64), (2, 64, 128, 16)]
 
 
-@pytest.mark.parametrize('nch', [1, 16, 32])       # 1: 16-channel blocks, weights through the LDS ring; 16 / 32: weights from L2 into the operand registers
+@pytest.mark.parametrize('nch', [1, 2, 16, 32])    # 1: 16-channel blocks, weights through the LDS ring; weights from L2 into the operand registers: 2 = 16 channels, four waves; 16 / 32 = 16 / 32 channels, eight waves
 @pytest.mark.parametrize('B,cx,C,H', X6_SHAPES)
 def test_convlstm_bf16x6_is_fp32_grade(ops, B, cx, C, H, nch):
     # fp32-representable operands, so that neither kernel is charged for the rounding of its inputs: hi + mid + lo is every operand exactly,
@@ -345,7 +345,7 @@ def test_convlstm_bf16x6_first_step_and_narrow_maps(ops):
     # t = 0 (no h operand: its K range is skipped) on a 16-wide map; an 8-wide map is not the three-piece kernel's: the call is the fp32 kernel's then
     x, h, c, W, b = [np.asarray(a, dtype=np.float32).astype(np.float64) for a in _case(2, 32, 32, 16, 5)]
     hr, cr, _ = _lstm_ref(x, h * 0, c, W, b)
-    for nch in (1, 16, 32):
+    for nch in (1, 2, 16, 32):
         h6, c6 = ops.convlstm_bf16x6(x, h, c, W, b, h_is_zero=True, nch=nch)
         assert np.abs(h6 - hr).max() < 2e-6 and np.abs(c6 - cr).max() < 2e-6
     # both forms against each other, and the LayerNorm partial statistics of their epilogues
@@ -355,6 +355,8 @@ def test_convlstm_bf16x6_first_step_and_narrow_maps(ops):
     h1, c1, (p1, n1) = ops.convlstm_bf16x6(xa, ha, ca, Wa, ba, nch=1, want_ln=True)
     assert np.abs(h16 - h32).max() < 2e-6 and np.abs(c16 - c32).max() < 2e-6      # (same terms; the blocks walk the taps in different rotations)
     assert np.array_equal(h16, h1) and np.array_equal(c16, c1)                      # same blocks, same rotations, same order: identical bits
+    h2, c2 = ops.convlstm_bf16x6(xa, ha, ca, Wa, ba, nch=2)
+    assert np.array_equal(h2, h1) and np.array_equal(c2, c1)
     assert n16 == 2 * n32 and n32 == 8 and n1 == n16
     for pp, hh in ((p16, h16), (p32, h32), (p1, h1)):
         cnt = pp[:, :, 0].sum(axis=1)
