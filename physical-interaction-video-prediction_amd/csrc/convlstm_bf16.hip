@@ -869,8 +869,10 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
 // SIMD (up to 512 registers), so the fragment ring is EIGHT k-steps (two taps) deep -- a lone wave's k-step lasts ~0.22 us.
 // NWM x NWN waves over the 128 anchors x (8 NWN channels x 4 gates) of a block: 2 x 4 (32 channels), 4 x 2 (16 channels, still two waves per
 // SIMD: a wave's tile is 32 anchors), 2 x 2 (16 channels, four waves).
-template <int NWM, int NWN>
-__global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int wbytes) {
+// LSTM = false: the plain 5x5 convolution with the same loop (the data gradient): a wave's 32 columns are consecutive output columns, the channel
+// groups may be split over gridDim.y (partial sums then meet in `out` by atomic adds), the epilogue stores / adds the accumulators.
+template <int NWM, int NWN, bool LSTM = true>
+__global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int wbytes, int ncols) {
     constexpr int PB = PH * RP16;                      // one patch plane: 36,864 B
     constexpr int PW = 20;
     constexpr int NW = NWM * NWN;                      // waves
@@ -887,7 +889,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     const int wm = wave8 % NWM, wn = wave8 / NWM;
     const int half = lane >> 5, l31 = lane & 31;
     const int C = d.C;
-    const int n_nblk = C / (8 * NWN);
+    const int n_nblk = LSTM ? C / (8 * NWN) : d.N / (32 * NWN);      // (plain: d.N = rows of the padded pack, a multiple of 64)
     const int H = d.Hin, W = d.Win;
     const int tpr = W / 16, tpi = (H / TH) * tpr;
     const int n_tiles = d.B * tpi;
@@ -899,7 +901,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     BF_STAMP(0);
     const int c0 = d.c0, ld0 = d.ld0, ld1 = d.ld1;
     const int cin = c0 + d.c1;
-    const int ncg = (cin + 63) >> 6;
+    const int ncg_all = (cin + 63) >> 6;
+    const int cgbase = (int)blockIdx.y * ncg_all / (int)gridDim.y;                 // this block's channel groups: [cgbase, cgbase + ncg)
+    const int ncg = ((int)blockIdx.y + 1) * ncg_all / (int)gridDim.y - cgbase;
     const int nchunks = 25 * ncg;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x0), 0, d.bytes0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.c1 ? d.x1 : d.x0), 0, d.c1 ? d.bytes1 : d.bytes0, 0x00020000);
@@ -972,7 +976,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
 
     // ---- the weights: fragment (group, tap, k-step, plane, c8 = nblk * 4 + wn) of the pack, 1 KB in lane order ------------------------
-    const unsigned pls = (unsigned)(C / 8) * 1024u;    // bytes between the planes of a k-step
+    const unsigned pls = (unsigned)(LSTM ? C / 8 : d.N / 32) * 1024u;    // bytes between the planes of a k-step (one KB per 32-column fragment)
     const unsigned kss = 3u * pls, tps = 4u * kss;     // ... between k-steps, between taps
     const unsigned voff = (unsigned)((nblk * NWN + wn) * 1024 + lane * 16);
     bf16x8 Bf[RD][3];                                  // [k-step (of the even / odd tap when RD = 8)][plane]: behind each k-step its registers take the fragments RD k-steps on
@@ -985,8 +989,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     auto adv = [&](int& tp, int& cg) { tp = tp == 24 ? 0 : tp + 1; cg += tp == tap0 ? 1 : 0; };
 
     // ---- prologue ---------------------------------------------------------------------------------------------------------------------
-    patch_load(0, 0);
-    int tap = tap0, cg = 0, tap1 = tap0, cg1 = 0;
+    patch_load(cgbase, 0);
+    int tap = tap0, cg = cgbase, tap1 = tap0, cg1 = cgbase;
     adv(tap1, cg1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) bload(Bf[ks], (unsigned)(cg * 25 + tap) * tps + ks * kss);
@@ -1000,7 +1004,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     float bj = 0.f, bi = 0.f, bf = 0.f, bo = 0.f;
     float cpre[MT][4];
     patch_store(0);
-    if constexpr (NRND == 2) { patch_load(0, 1); patch_store(1); }
+    if constexpr (NRND == 2) { patch_load(cgbase, 1); patch_store(1); }
     BF_STAMP(1);
     __syncthreads();
     BF_STAMP(2);
@@ -1069,7 +1073,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
         adv(tap2, cg2);
         auto tap_body = [&](auto P, int it) __attribute__((always_inline)) {
             constexpr int p = decltype(P)::value;
-            if (it == nchunks - 25) {                  // in front of the last group's taps: the epilogue's operands
+            if (LSTM && it == nchunks - 25) {          // in front of the last group's taps: the epilogue's operands
                 bj = d.bias[ch]; bi = d.bias[C + ch]; bf = d.bias[2 * C + ch] + 1.0f; bo = d.bias[3 * C + ch];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
@@ -1114,12 +1118,12 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     for (int g = 0; g < ncg; ++g) {                    // 64 input channels of concat(x, h) at a time
         if (g > 0) {                                   // every wave is done with the old patch
             __syncthreads();
-            patch_load(g, 0);
+            patch_load(cgbase + g, 0);
             patch_store(0);
-            if constexpr (NRND == 2) { patch_load(g, 1); patch_store(1); }
+            if constexpr (NRND == 2) { patch_load(cgbase + g, 1); patch_store(1); }
             __syncthreads();
         }
-        if (g == ncg - 1) {
+        if (LSTM && g == ncg - 1) {
             // the epilogue's operands, requested in front of the last 25 taps (read in the epilogue they cost an exposed HBM round trip per row;
             // requested in the prologue they hold 12 registers through every tap loop)
             bj = d.bias[ch]; bi = d.bias[C + ch]; bf = d.bias[2 * C + ch] + 1.0f; bo = d.bias[3 * C + ch];
@@ -1158,6 +1162,24 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
         for (int r = 0; r < 16; ++r) acc[mt][r] += accl[mt][r];
     BF_STAMP(3);
 
+    if constexpr (!LSTM) {
+        // ---- plain epilogue: accumulator row = anchor, column = output channel; 32 lanes write 128 contiguous bytes -------------------
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = 32 * MT * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const size_t m = (size_t)((b0 * H + y0 + (i >> 4)) * W + x0 + (i & 15));
+                const int col = (nblk * NWN + wn) * 32 + l31;
+                if (col < ncols) {                      // the pack's rows past the real column count are zero padding
+                    float* o = d.out + m * d.ldo + col;
+                    if (gridDim.y > 1) atomicAdd(o, acc[mt][r]);
+                    else if (d.accum) *o += acc[mt][r];
+                    else *o = acc[mt][r];
+                }
+            }
+        return;
+    }
     // ---- epilogue: the gate math of convlstm_bf16_kernel's 16-channel blocks (a wave's 32 columns = 4 gates x 8 channels) -------------
     auto pick = [&](const float (&v)[4], int idx) -> float {
         const float lo = (idx & 1) ? v[1] : v[0], hi = (idx & 1) ? v[3] : v[2];
@@ -1295,7 +1317,19 @@ static int launch_x6g(const IgemmDesc& d, const unsigned short* wb, hipStream_t 
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
     const long long wbytes = (long long)lstm_bf16_weight_elems(d.c0 + (d.c1 ? d.c1 : d.C), 4 * d.C) * 3 * 2;
     if (wbytes >= (1LL << 31)) return PIVP_ERR_BADARG;
-    hipLaunchKernelGGL((convlstm_x6g_kernel<NWM, NWN>), dim3(d.B * tpi * nb), dim3(64 * NWM * NWN), lds_bytes, stream, dd, wb, (int)wbytes);
+    hipLaunchKernelGGL((convlstm_x6g_kernel<NWM, NWN>), dim3(d.B * tpi * nb), dim3(64 * NWM * NWN), lds_bytes, stream, dd, wb, (int)wbytes, 0);
+    return PIVP_LAUNCH_STATUS();
+}
+
+// the plain 5x5 convolution on the same kernel: dd.N = rows of the padded pack, nb = its 64-column blocks, ks = split of the channel groups
+static int launch_x6g_plain(const IgemmDesc& dd, const unsigned short* wb, hipStream_t stream, int nb, int ks, int ncols) {
+    constexpr int lds_bytes = 3 * PH * RP16;
+    static PerDeviceOnce once;
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<4, 2, false>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
+    const int tpi = (dd.Hin / TH) * (dd.Win / 16);
+    const long long wbytes = (long long)lstm_bf16_weight_elems(dd.c0 + dd.c1, dd.N) * 3 * 2;
+    if (wbytes >= (1LL << 31)) return PIVP_ERR_BADARG;
+    hipLaunchKernelGGL((convlstm_x6g_kernel<4, 2, false>), dim3(dd.B * tpi * nb, ks), dim3(512), lds_bytes, stream, dd, wb, (int)wbytes, ncols);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -1354,8 +1388,8 @@ int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t strea
     const bool wide = Np % 128 == 0;
     const int nb = Np / (wide ? 128 : 64);
     const int ks = conv5x5_bf16_ksplit(d, planes);
-    if (planes == 3)     // three pieces (wb packed with planes = 3, plain = 1): 64-column blocks on the k-step ring
-        return launch_bf16<16, false, 3>(dd, wb, stream, nullptr, Np / 64, ks, d.N);
+    if (planes == 3)     // three pieces (wb packed with planes = 3, plain = 1): 64-column blocks, weights from L2 into the operand registers, eight
+        return launch_x6g_plain(dd, wb, stream, Np / 64, ks, d.N);      // waves (the k-step-ring form of it measured 118 us per launch in the sweep against 100)
     if (planes == 2)     // split mode (wb packed with planes = 2): 128-column blocks run the two-slot schedule, 64-column ones the four-slot one
         return wide ? launch_bf16<32, false, 2>(dd, wb, stream, nullptr, nb, ks, d.N)
                     : launch_bf16<16, false, 2>(dd, wb, stream, nullptr, nb, ks, d.N);

@@ -17,6 +17,13 @@ python3 bench.py --precision bf16 $NB > $out/bench_bf16.json 2> $out/bench_bf16.
 python3 bench.py --precision bf16 --mode train --steps 10 --warmup 3 $NB --no-roofline > $out/bench_bf16_train.json 2> $out/bench_bf16_train.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_bf16 -o rollout_bf16 -- python3 bench.py --precision bf16 --steps 7 --warmup 2 $NB --no-train > $out/kt_bf16.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/train_bf16 -o train_bf16 -- python3 bench.py --precision bf16 --mode train --steps 4 --warmup 1 $NB --no-roofline > $out/train_bf16.log 2>&1
+# the three-piece mode (fp32-grade on the bf16 matrix cores): rollout and train step, kernel statistics, two-queue overlap of the train step
+python3 bench.py --precision bf16x6 $NB --no-train > $out/bench_x6.json 2> $out/bench_x6.err
+python3 bench.py --precision bf16x6 --mode train --steps 10 --warmup 3 $NB --no-roofline > $out/bench_x6_train.json 2> $out/bench_x6_train.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_x6 -o rollout_x6 -- python3 bench.py --precision bf16x6 --steps 7 --warmup 2 $NB --no-train > $out/kt_x6.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/train_x6 -o train_x6 -- python3 bench.py --precision bf16x6 --mode train --steps 4 --warmup 1 $NB --no-roofline > $out/train_x6.log 2>&1
+python3 scripts/overlap_report.py $out/train_x6/train_x6_kernel_trace.csv > $out/train_x6_overlap.txt 2>&1 || true
+python3 scripts/queue_breakdown.py $out/train_x6/train_x6_kernel_trace.csv > $out/train_x6_queues.txt 2>&1 || true
 R="--steps 2 --warmup 1 $NB --no-roofline --no-train"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 bench.py $R > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python3 bench.py $R > $out/write.log 2>&1
@@ -27,6 +34,6 @@ python3 scripts/pmc_summary.py $out/fetch $out/write $out/pmc "bench.py --steps 
 python3 scripts/pmc_summary.py --bf16 $out/fetch_bf16 $out/write_bf16 $out/pmc "bench.py --precision bf16 --steps 2 --warmup 1 (CDNA B=32 T=10 64x64)"
 python3 scripts/pmc_summary.py --mfma $out/mfma $out/pmc/pmc_mfma_busy_summary.csv
 # keep the merge small: the raw per-dispatch traces are not needed back
-rm -f $out/kt/*kernel_trace.csv $out/train/*kernel_trace.csv $out/kt_bf16/*kernel_trace.csv $out/train_bf16/*kernel_trace.csv
+rm -f $out/kt/*kernel_trace.csv $out/train/*kernel_trace.csv $out/kt_bf16/*kernel_trace.csv $out/train_bf16/*kernel_trace.csv $out/kt_x6/*kernel_trace.csv $out/train_x6/*kernel_trace.csv
 find $out/fetch $out/write $out/mfma $out/fetch_bf16 $out/write_bf16 -name '*counter_collection.csv' -delete
-cat $out/bench.json; cat $out/bench_train.json; cat $out/bench_bf16.json; cat $out/bench_bf16_train.json
+cat $out/bench.json; cat $out/bench_train.json; cat $out/bench_bf16.json; cat $out/bench_bf16_train.json; cat $out/bench_x6.json; cat $out/bench_x6_train.json
