@@ -882,6 +882,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     constexpr int NPJX = 4;                            // staging passes per round: 4 x 64 pixels cover the patch's 240 with 512 threads;
     constexpr int NRND = (PH * PW + NPJX * PPP - 1) / (NPJX * PPP);     // 256 threads take two rounds of 4 x 32 (eight passes in one round put the staged pixels in scratch)
     constexpr int RD = NW == 8 ? 4 : 8;                // k-steps of B fragments in registers
+    PIVP_SET_MAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* const patch = lds;
     const int tid = threadIdx.x, lane = tid & 63;
