@@ -79,7 +79,7 @@ def build_parser():
     ap.add_argument('--no-train', action='store_true', help='rollout mode: skip the train leg')
     ap.add_argument('--no-bf16x6', action='store_true', help='fp32 rollout runs: skip the additional three-piece rollout leg (`rollout_bf16x6`)')
     ap.add_argument('--no-bf16-train', action='store_true', help='fp32 runs: skip the additional bf16 train leg (`train_bf16`, config 3\'s arithmetic)')
-    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'bf16x3', 'bf16x6'],
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'bf16x3', 'bf16x6', 'fp16x3'],
                     help='fp32: the parity path and the headline metric (config 2). bf16: ConvLSTM gate convolutions with bf16 operands, '
                          'fp32 accumulation (config 3); reports its per-pixel error instead of meeting the 1e-4 gate')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -281,40 +281,41 @@ def main(argv=None):
             elapsed, _ = timed(lambda: time.sleep(0.001), args.steps, args.warmup, sync, barrier)
             elapsed = max_over_ranks(elapsed); loss_val = 0.0
 
-        # ---- leg 1b (fp32 rollout runs): the same rollout with the gate convolutions as six bf16 MFMAs per product (three pieces per fp32 operand:
-        # fp32-grade products at a 417 TFLOP/s ceiling).  An ADDITIONAL object, never `value`; `max_l2_vs_f32_rollout` is the largest per-pixel L2
-        # between its frames and the fp32 rollout's on this run's input (the gate against the float64 oracle is tests/test_gpu_trained.py's).
-        x6_obj = None
+        # ---- leg 1b (fp32 rollout runs): the same rollout with the gate convolutions on the bf16 / fp16 matrix cores at fp32 grade: every fp32 operand
+        # as three bf16 pieces and six MFMAs per product (417 TFLOP/s ceiling), or as two fp16 pieces and three MFMAs (833).  ADDITIONAL objects, never
+        # `value`; `max_l2_vs_f32_rollout` is the largest per-pixel L2 between their frames and the fp32 rollout's on this run's input (the gates against
+        # the float64 oracle are tests/test_gpu_trained.py's).
+        split_objs = {}
         if do_rollout and not dry and args.precision == 'fp32' and not args.no_bf16x6:
-            try:
-                m6 = pivp_amd.Model(nm, prefix='bench', device=dev, keep_activations=False, precision='bf16x6', **kinds)
+            for mode, what in (('bf16x6', '3 bf16 pieces, 6 bf16 MFMAs per product'), ('fp16x3', '2 fp16 pieces (weights packed times 2^8), 3 fp16 MFMAs per product')):
+                try:
+                    m6 = pivp_amd.Model(nm, prefix='bench', device=dev, keep_activations=False, precision=mode, **kinds)
 
-                def x6_step():
-                    m6.reset_state()
-                    return m6([images, actions, states], 0)
-                x6_step()
-                m6._flat_params.copy_(model._flat_params)            # the fp32 leg's weights (parameters are lazily sized: after one call)
-                t6, _ = timed(x6_step, args.steps, args.warmup, sync, barrier)
-                t6 = max_over_ranks(t6)
-                rollout_step()
-                d = torch.stack(m6.gen_images).double() - torch.stack(model.gen_images).double()
-                l2_steps = [float(v) for v in d.pow(2).sum(dim=2).sqrt().flatten(1).max(dim=1).values]
-                l2 = max(l2_steps)
-                x6_obj = {'ms_per_step': round(t6 / args.steps * 1e3, 3), 'frames_per_s': round(world * B * (T - 1) * args.steps / t6, 1),
-                          'max_l2_vs_f32_rollout': l2,
-                          # per predicted frame: the first is one pass through the network; with RANDOM-INIT weights (this run's) any two fp32-grade
-                          # evaluations then drift apart by a factor per fed-back step -- the gate against float64 on trained weights is
-                          # tests/test_gpu_trained.py::test_bf16x6_mode_is_fp32_grade_on_trained_weights
-                          'max_l2_vs_f32_rollout_per_step': [float('%.3g' % v) for v in l2_steps],
-                          'dtype': 'f32 operands of the ConvLSTM forward as 3 bf16 pieces, 6 bf16 MFMAs per product (layers on 8-wide maps: the f32 kernel)'}
-                if rank == 0 and not args.no_roofline:
-                    r6 = roofline_pass(args, m6, x6_step, t6, np, torch, precision='bf16x6')
-                    x6_obj.update({'achieved_tflops': r6['achieved'], 'peak_tflops': r6['peak'], 'frac': r6['frac'], 'per_layer_tflops': r6['per_layer_tflops'],
-                                   'layers_in_this_arithmetic': r6['layers']})
-                del m6
-            except Exception as e:
-                sys.stderr.write('bench.py: rollout_bf16x6 leg failed (%s: %s)\n' % (type(e).__name__, e))
-                x6_obj = None
+                    def x6_step():
+                        m6.reset_state()
+                        return m6([images, actions, states], 0)
+                    x6_step()
+                    m6._flat_params.copy_(model._flat_params)            # the fp32 leg's weights (parameters are lazily sized: after one call)
+                    t6, _ = timed(x6_step, args.steps, args.warmup, sync, barrier)
+                    t6 = max_over_ranks(t6)
+                    rollout_step()
+                    d = torch.stack(m6.gen_images).double() - torch.stack(model.gen_images).double()
+                    l2_steps = [float(v) for v in d.pow(2).sum(dim=2).sqrt().flatten(1).max(dim=1).values]
+                    obj = {'ms_per_step': round(t6 / args.steps * 1e3, 3), 'frames_per_s': round(world * B * (T - 1) * args.steps / t6, 1),
+                           'max_l2_vs_f32_rollout': max(l2_steps),
+                           # per predicted frame: the first is one pass through the network; with RANDOM-INIT weights (this run's) any two fp32-grade
+                           # evaluations then drift apart by a factor per fed-back step -- the gate against float64 on trained weights
+                           # is tests/test_gpu_trained.py::test_bf16x6_mode_is_fp32_grade_on_trained_weights
+                           'max_l2_vs_f32_rollout_per_step': [float('%.3g' % v) for v in l2_steps],
+                           'dtype': 'f32 operands of the ConvLSTM forward as %s (layers on 8-wide maps: the f32 kernel)' % what}
+                    if rank == 0 and not args.no_roofline:
+                        r6 = roofline_pass(args, m6, x6_step, t6, np, torch, precision=mode)
+                        obj.update({'achieved_tflops': r6['achieved'], 'peak_tflops': r6['peak'], 'frac': r6['frac'], 'per_layer_tflops': r6['per_layer_tflops'],
+                                    'layers_in_this_arithmetic': r6['layers']})
+                    split_objs[mode] = obj
+                    del m6
+                except Exception as e:
+                    sys.stderr.write('bench.py: rollout_%s leg failed (%s: %s)\n' % (mode, type(e).__name__, e))
 
         # ---- leg 2: the data-parallel train step (the run's precision; in the default fp32 run also config 3's bf16 arithmetic) ----------
         train_obj = train_bf16_obj = train_x6_obj = None
@@ -393,7 +394,8 @@ def main(argv=None):
                 'allreduce_algo_ms_per_step': compare,
                 'dtype': {'fp32': 'f32', 'bf16': 'bf16 ConvLSTM / enc5 / enc6 operands, f32 accumulate, gradients and optimizer',
                           'bf16x3': 'f32 as 2 bf16 pieces in the ConvLSTM forward and data gradients',
-                          'bf16x6': 'f32 as 3 bf16 pieces in the ConvLSTM gate convolutions and their data gradients (6 bf16 MFMAs per product: fp32-grade), f32 weight gradients and elsewhere'}[precision],
+                          'bf16x6': 'f32 as 3 bf16 pieces in the ConvLSTM gate convolutions and their data gradients (6 bf16 MFMAs per product: fp32-grade), f32 weight gradients and elsewhere',
+                          'fp16x3': 'f32 as 2 fp16 pieces in the ConvLSTM gate convolutions (3 fp16 MFMAs per product), data gradients as 3 bf16 pieces, f32 weight gradients and elsewhere'}[precision],
                 'workload': 'optimizer.update (TM:950): forward + BPTT backward + gradient all-reduce + Adam, schedsamp_k=-1, batch %d/GPU' % B,
                 'loss': float(tloss),
             }
@@ -410,12 +412,13 @@ def main(argv=None):
             if args.mode != 'train' and args.precision == 'fp32' and not dry and not args.no_bf16x6:
                 # the fp32-grade train step on the bf16 matrix cores: gate convolutions and their data gradients as six bf16 MFMAs per product
                 # (three pieces per fp32 operand), weight gradients and everything else fp32.  An additional object: `train` stays the fp32 kernels'.
-                try:
-                    train_x6_obj, m6t, _, _, _ = train_leg('bf16x6')
-                    del m6t
-                except Exception as e:
-                    sys.stderr.write('bench.py: train_bf16x6 leg failed (%s: %s)\n' % (type(e).__name__, e))
-                    train_x6_obj = None
+                train_x6_obj = {}
+                for mode in ('bf16x6', 'fp16x3'):       # (fp16x3: its forward; the sweep is bf16x6's)
+                    try:
+                        train_x6_obj[mode], m6t, _, _, _ = train_leg(mode)
+                        del m6t
+                    except Exception as e:
+                        sys.stderr.write('bench.py: train_%s leg failed (%s: %s)\n' % (mode, type(e).__name__, e))
 
         # ---- the dominant kernel against its roofline, HIP events on the launch stream, second pass over the same K steps ----------
         pmodel = model if do_rollout else tmodel
@@ -459,7 +462,8 @@ def main(argv=None):
             'vs_baseline': None,
             'dtype': {'fp32': 'f32', 'bf16': 'bf16 ConvLSTM operands, f32 accumulate and elsewhere',
                       'bf16x3': 'f32 operands of the ConvLSTM forward as 2 bf16 pieces (3 bf16 MFMAs per product), f32 accumulate and elsewhere',
-                      'bf16x6': 'f32 operands of the ConvLSTM forward as 3 bf16 pieces (6 bf16 MFMAs per product: fp32-grade products), f32 accumulate and elsewhere'}[args.precision],
+                      'bf16x6': 'f32 operands of the ConvLSTM forward as 3 bf16 pieces (6 bf16 MFMAs per product: fp32-grade products), f32 accumulate and elsewhere',
+                      'fp16x3': 'f32 operands of the ConvLSTM forward as 2 fp16 pieces (3 fp16 MFMAs per product: 22-bit operands), f32 accumulate and elsewhere'}[args.precision],
             'data': ('synthetic' if not args.share_gpu else 'synthetic; REHEARSAL: %d ranks share one GPU over gloo, not a multi-GPU measurement' % world)
                     if not dry else 'none: --dry run of the host logic on CPU (gloo, stub kernels); NOT a measurement',
             'config': {'workload': preset + '%s %s, batch %d/GPU, %d-frame %dx%dx3 sequences, action-conditioned, num_masks=%d, '
@@ -472,14 +476,14 @@ def main(argv=None):
             'roofline': roofline,
             'cpu_baseline': cpu_baseline,
         }
-        if x6_obj is not None:
-            out['rollout_bf16x6'] = x6_obj
+        for mode, obj in split_objs.items():
+            out['rollout_' + mode] = obj
         if not train_mode:
             out['train'] = train_obj
             if train_bf16_obj is not None:
                 out['train_bf16'] = train_bf16_obj
-            if train_x6_obj is not None:
-                out['train_bf16x6'] = train_x6_obj
+            for mode, obj in (train_x6_obj or {}).items():
+                out['train_' + mode] = obj
         if dry:
             out['dry'] = True
         print(json.dumps(out))
@@ -507,7 +511,7 @@ def roofline_pass(args, model, step, elapsed, np, torch, precision=None):
         ms_tot += np.array(ms[:]); n_tot += np.array(n[:]); flops += np.array(fl[:])
     lib.pivp_plan_set_profiling(plan.h, 0)
     layers = list(range(7))
-    if precision == 'bf16x6':      # layers on maps that are not a multiple of 16 wide run the fp32 kernel in this mode: not part of its fraction
+    if precision in ('bf16x6', 'fp16x3'):      # layers on maps that are not a multiple of 16 wide run the fp32 kernel in this mode: not part of its fraction
         widths = [args.size // 2, args.size // 2, args.size // 4, args.size // 4, args.size // 8, args.size // 4, args.size // 2]
         layers = [i for i in range(7) if widths[i] % 16 == 0]
     total_flops = float(flops[layers].sum())
@@ -515,13 +519,13 @@ def roofline_pass(args, model, step, elapsed, np, torch, precision=None):
     achieved = total_flops / total_s / 1e12
     bf16 = precision != 'fp32'
     # bf16x3 / bf16x6 execute three / six bf16 MFMAs per algorithmic product: their ceiling in algorithmic flops is a third / a sixth of the bf16 peak
-    peak = (PEAK_BF16_MFMA_TFLOPS / {'bf16x3': 3.0, 'bf16x6': 6.0}.get(precision, 1.0)) if bf16 else PEAK_FP32_MFMA_TFLOPS
+    peak = (PEAK_BF16_MFMA_TFLOPS / {'bf16x3': 3.0, 'bf16x6': 6.0, 'fp16x3': 3.0}.get(precision, 1.0)) if bf16 else PEAK_FP32_MFMA_TFLOPS
     return {
         'layers': ['lstm%d' % (i + 1) for i in layers],
         'bound': 'mfma',
         'kernel': ('convlstm_bf16_kernel<NCH> (ConvLSTM 5x5 gate conv, %s, + fused gates)' %
                    {'bf16': 'bf16 operands', 'bf16x3': 'fp32 operands as 2 bf16 pieces, 3 MFMAs per product',
-                    'bf16x6': 'fp32 operands as 3 bf16 pieces, 6 MFMAs per product'}[precision] if bf16 else
+                    'bf16x6': 'fp32 operands as 3 bf16 pieces, 6 MFMAs per product', 'fp16x3': 'fp32 operands as 2 fp16 pieces, 3 MFMAs per product'}[precision] if bf16 else
                    'igemm_f32_kernel<WM,WN,4,true> (ConvLSTM 5x5 gate conv + fused gates)'),
         'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
         'frac': round(achieved / peak, 4),

@@ -38,8 +38,9 @@ extern "C" {
 #define PIVP_PRECISION_BF16 1
 #define PIVP_PRECISION_BF16X3 2
 #define PIVP_PRECISION_BF16X6 3
+#define PIVP_PRECISION_FP16X3 4
 
-int pivp_abi_version(void);   /* 10 (10: + PIVP_PRECISION_BF16X6, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+int pivp_abi_version(void);   /* 10 (10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
                                  5: + bf16 ConvLSTM, pivp_plan_set_precision, 6: + pivp_plan_set_group_join / pivp_plan_group_wait) */
 
 /* sha256 (hex) of the sources this library was compiled from (every .hip and .h under csrc/, and this header), embedded by build.py.  The Python
@@ -85,7 +86,11 @@ int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr);
  * (4.4e-5 on the config 1 rollout; tests/test_gpu_bf16.py); the backward pass and every other op are the fp32 ones.
  * PIVP_PRECISION_BF16X6 = three bf16 pieces per fp32 operand (hi + mid + lo = v exactly) and the six products of weight >= 2^-16, i.e. fp32-grade
  * gate pre-activations computed on the bf16 matrix cores: the gate convolutions and, in the backward sweep, their DATA gradients, of layers whose map is a
- * multiple of 16 wide (8-wide maps -- lstm5 on 64 x 64 frames -- run the fp32 kernels); the weight gradients and every other op are the fp32 ones.  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
+ * multiple of 16 wide (8-wide maps -- lstm5 on 64 x 64 frames -- run the fp32 kernels); the weight gradients and every other op are the fp32 ones.
+ * PIVP_PRECISION_FP16X3 = the forward gate convolutions with every fp32 operand as TWO FP16 pieces (22 bits of mantissa; a layer's weights are packed times the
+ * power of two that puts the largest in [2^14, 2^15), so that the second piece of any weight down to 2^-18 of it stays a normal fp16 number; the sum is scaled
+ * back exactly) and three MFMAs per product; activations beyond +-65504 saturate, activations below 0.06 carry up to 3e-8 of absolute error.  Its truncation error is a quarter of the fp32 path's own rounding error (scripts/split_fp16_study.py); the backward sweep is
+ * PIVP_PRECISION_BF16X6's (gradients do not fit fp16's exponent range).  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
 int pivp_plan_set_precision(pivp_plan_t* plan, int precision);
 int pivp_plan_get_precision(const pivp_plan_t* plan);
 
@@ -201,6 +206,14 @@ int pivp_convlstm_bf16x6(const float* x, int cx, int ldx, const float* h_prev, i
                          const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
                          int* ln_nparts, int B, int H, int W, int nch, void* stream);   /* nch: 0 automatic; 1 = 16-channel blocks, weights through
                          an LDS ring; 16 / 32 = 16- / 32-channel blocks (C % 32 == 0 for 32), weights from L2 straight into the operand registers */
+
+/* Two-fp16-piece form (precision mode PIVP_PRECISION_FP16X3): hi = fp16(v), lo = fp16(v - hi); hi*hi on the main accumulator, lo*hi + hi*lo on a second one
+ * (three fp16 MFMAs, fp32 accumulation).  W % 16 == 0, C % 16 == 0.  w_bf16 = pivp_pack_lstm_fp16x3(w): 2 * pivp_lstm_bf16_weight_elems(cx + C, C) + 256 2-byte
+ * elements (s w as two fp16 pieces, fragment-major; s and the maxima it was taken from in the 512-byte tail).  nch: 0 automatic, 16 / 32 channels per block. */
+int pivp_pack_lstm_fp16x3(const float* w, void* w_bf16, int cin_total, int C, void* stream);
+int pivp_convlstm_fp16x3(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
+                         const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
+                         int* ln_nparts, int B, int H, int W, int nch, void* stream);
 
 /* pivp_deconv3x3s2 with bf16 operands (precision mode bf16): x and w are rounded to bf16 on the way into the matrix pipe, accumulation, bias
  * and ReLU stay fp32.  Only maps with Hin % 8 == 0 and Win % 16 == 0 (and at least 16 tiles x column blocks) run in bf16; the call is the fp32 op otherwise. */

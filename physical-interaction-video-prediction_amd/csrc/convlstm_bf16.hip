@@ -104,6 +104,43 @@ __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x
 __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& e, bf16x8& f, bf16x8& g, bf16x8& h, bf16x8& i) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i));
 }
+__device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
+}
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> packed fp16 (round to nearest even, saturating at the largest finite fp16); a, b become the remainders v - fp16(v), exact in fp32
+__device__ __forceinline__ unsigned pack2h_rest(float& a, float& b) {
+    const float ca = __builtin_fminf(__builtin_fmaxf(a, -65504.f), 65504.f), cb = __builtin_fminf(__builtin_fmaxf(b, -65504.f), 65504.f);
+    f32x2 v = {ca, cb};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    a -= (float)h[0]; b -= (float)h[1];
+    return __builtin_bit_cast(unsigned, h);
+}
+// fp16 pieces: the weights are packed times a power of two chosen per tensor so that the largest lands in [2^14, 2^15) -- the second piece of any
+// weight down to 2^-18 of the largest is then a normal fp16 number.  The pack's tail (X3_TAIL 2-byte elements behind the fragments) holds the scale
+// (float 0) and the 64 partial maxima it was taken from (floats 2..65).
+constexpr int X3_TAIL = 256;
+__global__ __launch_bounds__(256) void absmax_partials_kernel(const float* __restrict__ w, long n, float* __restrict__ tail) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += 64L * 256) m = __builtin_fmaxf(m, __builtin_fabsf(w[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) tail[2 + blockIdx.x] = __builtin_fmaxf(__builtin_fmaxf(red[0], red[1]), __builtin_fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float x3_scale_of(const float* tail) {      // every caller computes the same power of two from the 64 partial maxima
+    float m = 0.f;
+    for (int i = 0; i < 64; ++i) m = __builtin_fmaxf(m, tail[2 + i]);
+    if (!(m > 0.f) || !(m < 3.0e38f)) return 1.0f;
+    int e;
+    (void)__builtin_frexpf(m, &e);                  // m = f * 2^e, f in [0.5, 1)
+    int k = 15 - e;                                 // m * 2^k in [2^14, 2^15)
+    k = k < -60 ? -60 : k > 60 ? 60 : k;
+    return __builtin_ldexpf(1.0f, k);
+}
 __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& e, bf16x8& f, bf16x8& g, bf16x8& h, bf16x8& i, bf16x8& j) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i), "+v"(j));
 }
@@ -140,14 +177,25 @@ __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned shor
 constexpr int X6_CHUNK = 3 * 2 * 1024;      // ring slot of the 16-channel-block kernel: one k-step = 3 planes x 2 wave columns x 1 KB
 // plain = 1: the same pack for a plain 5x5 convolution (the data gradient): fragment c8 = the 32 consecutive output columns c8 * 32 .. + 32 of the
 // Np padded ones (rows past N zero)
-__global__ void pack_lstm_x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int N, int Np, int plain, long total) {
+// pieces = 2: TWO FP16 pieces of s w (hi = fp16, lo = fp16(s w - hi)), s = the tensor's power-of-two scale (absmax_partials_kernel ran before)
+__global__ void pack_lstm_x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int N, int Np, int plain, int pieces, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float wscale = 1.0f;
+    if (pieces == 2) {
+        __shared__ float sc;
+        if (threadIdx.x == 0) {
+            sc = x3_scale_of(reinterpret_cast<const float*>(wb + total));
+            if (blockIdx.x == 0) reinterpret_cast<float*>(wb + total)[0] = sc;      // what the convolution's epilogue divides by
+        }
+        __syncthreads();
+        wscale = sc;
+    }
     if (i >= total) return;
     const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
     long r = i >> 9;
     const int n8 = Np / 32, C = N / 4;
     const int c8 = (int)(r % n8); r /= n8;
-    const int pl = (int)(r % 3); r /= 3;
+    const int pl = (int)(r % pieces); r /= pieces;
     const int ks = (int)(r & 3); r >>= 2;
     const int tap = (int)(r % 25);
     const int cg = (int)(r / 25);
@@ -156,6 +204,13 @@ __global__ void pack_lstm_x6_kernel(const float* __restrict__ w, unsigned short*
     const int ch = cg * 64 + ks * 16 + half * 8 + e;
     float v = 0.f;
     if (ch < wcin && n < N) v = w[(((long)tap * (wcin >> 5) + (ch >> 5)) * N + n) * 32 + (ch & 31)];
+    if (pieces == 2) {
+        v = __builtin_fminf(__builtin_fmaxf(v * wscale, -65504.f), 65504.f);
+        _Float16 hh = (_Float16)v;
+        if (pl == 1) { v -= (float)hh; hh = (_Float16)v; }
+        wb[i] = __builtin_bit_cast(unsigned short, hh);
+        return;
+    }
     __bf16 h = (__bf16)v;
     if (pl >= 1) { v -= (float)h; h = (__bf16)v; }
     if (pl == 2) { v -= (float)h; h = (__bf16)v; }
@@ -871,9 +926,13 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
 // SIMD: a wave's tile is 32 anchors), 2 x 2 (16 channels, four waves).
 // LSTM = false: the plain 5x5 convolution with the same loop (the data gradient): a wave's 32 columns are consecutive output columns, the channel
 // groups may be split over gridDim.y (partial sums then meet in `out` by atomic adds), the epilogue stores / adds the accumulators.
-template <int NWM, int NWN, bool LSTM = true>
+// PCS = 2: TWO FP16 pieces per operand instead of three bf16 ones (22 bits of operand mantissa; the weights arrive times 2^8 and the sum is scaled
+// back) and three MFMAs per product: hi*hi on the main accumulator, lo*hi + hi*lo on the second.  scripts/split_fp16_study.py: the truncation is a
+// quarter of the fp32 path's own error.  Forward gate convolutions only (gradients are too small for fp16's exponent range).
+template <int NWM, int NWN, bool LSTM = true, int PCS = 3>
 __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int wbytes, int ncols) {
     constexpr int PB = PH * RP16;                      // one patch plane: 36,864 B
+    static_assert(PCS == 3 || (PCS == 2 && LSTM), "pieces");
     constexpr int PW = 20;
     constexpr int NW = NWM * NWN;                      // waves
     constexpr int MT = 4 / NWM;                        // 32-anchor M tiles per wave
@@ -947,6 +1006,14 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
             int a_pix, a_lds;
             pix_of(rnd * NPJX + j, a_pix, a_lds);
             float r[8] = {plo[j][0], plo[j][1], plo[j][2], plo[j][3], phi[j][0], phi[j][1], phi[j][2], phi[j][3]};
+            if constexpr (PCS == 2) {
+                uint4 hh, ll;
+                hh.x = pack2h_rest(r[0], r[1]); hh.y = pack2h_rest(r[2], r[3]); hh.z = pack2h_rest(r[4], r[5]); hh.w = pack2h_rest(r[6], r[7]);
+                ll.x = pack2h_rest(r[0], r[1]); ll.y = pack2h_rest(r[2], r[3]); ll.z = pack2h_rest(r[4], r[5]); ll.w = pack2h_rest(r[6], r[7]);
+                *reinterpret_cast<uint4*>(patch + a_lds + cpiece * 16) = hh;
+                *reinterpret_cast<uint4*>(patch + PB + a_lds + cpiece * 16) = ll;
+                continue;
+            }
             uint4 v;
             v.x = pack2(r[0], r[1]); v.y = pack2(r[2], r[3]); v.z = pack2(r[4], r[5]); v.w = pack2(r[6], r[7]);
             *reinterpret_cast<uint4*>(patch + a_lds + cpiece * 16) = v;
@@ -962,6 +1029,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
         }
     };
     const int tap0 = (lid * 7) % 25;
+    float inv_wscale = 1.0f;
+    if constexpr (PCS == 2) inv_wscale = 1.0f / *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(wb) + wbytes);   // the pack's tail
 
     f32x16 acc[MT], accl[MT];
 #pragma unroll
@@ -978,13 +1047,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
 
     // ---- the weights: fragment (group, tap, k-step, plane, c8 = nblk * 4 + wn) of the pack, 1 KB in lane order ------------------------
     const unsigned pls = (unsigned)(LSTM ? C / 8 : d.N / 32) * 1024u;    // bytes between the planes of a k-step (one KB per 32-column fragment)
-    const unsigned kss = 3u * pls, tps = 4u * kss;     // ... between k-steps, between taps
+    const unsigned kss = (unsigned)PCS * pls, tps = 4u * kss;     // ... between k-steps, between taps
     const unsigned voff = (unsigned)((nblk * NWN + wn) * 1024 + lane * 16);
-    bf16x8 Bf[RD][3];                                  // [k-step (of the even / odd tap when RD = 8)][plane]: behind each k-step its registers take the fragments RD k-steps on
-    auto bload = [&](bf16x8 (&dst)[3], unsigned soff) {
+    bf16x8 Bf[RD][PCS];                                  // [k-step (of the even / odd tap when RD = 8)][plane]: behind each k-step its registers take the fragments RD k-steps on
+    auto bload = [&](bf16x8 (&dst)[PCS], unsigned soff) {
         if constexpr (PIVP_X6_ABL & 8) return;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < PCS; ++pl)
             dst[pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, voff, (int)(soff + pl * pls), 0));
     };
     auto adv = [&](int& tp, int& cg) { tp = tp == 24 ? 0 : tp + 1; cg += tp == tap0 ? 1 : 0; };
@@ -1013,7 +1082,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     bf16x8 fa[2][MT], fal[2][MT], fa3[2][MT];          // [register set][M tile]: the A fragments of a k-step, hi / mid / lo planes
     auto wait_a = [&](auto SET) {
         constexpr int st = decltype(SET)::value;
-        if constexpr (MT == 2) wait_lgkm(fa[st][0], fa[st][1], fal[st][0], fal[st][1], fa3[st][0], fa3[st][1]);
+        if constexpr (PCS == 2 && MT == 2) wait_lgkm(fa[st][0], fa[st][1], fal[st][0], fal[st][1]);
+        else if constexpr (PCS == 2) wait_lgkm(fa[st][0], fal[st][0]);
+        else if constexpr (MT == 2) wait_lgkm(fa[st][0], fa[st][1], fal[st][0], fal[st][1], fa3[st][0], fa3[st][1]);
         else wait_lgkm(fa[st][0], fal[st][0], fa3[st][0]);
     };
     auto read_a = [&](auto SET, auto KS, auto I, unsigned ab) {       // read I of the 3 MT: plane I / MT, M tile I % MT
@@ -1023,8 +1094,15 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
         if constexpr (pl == 0) fa[st][mt] = v; else if constexpr (pl == 1) fal[st][mt] = v; else fa3[st][mt] = v;
     };
     // twelve MFMAs of register set CUR against the fragments b[3] (hi, mid, lo); corrections into accl, the leading term into acc
-    auto mfma = [&](auto CUR, auto I, const bf16x8 (&b)[3]) {
+    auto mfma = [&](auto CUR, auto I, const bf16x8 (&b)[PCS]) {
         constexpr int st = decltype(CUR)::value, i = decltype(I)::value, term = i / MT, mt = i % MT;
+        if constexpr (PCS == 2) {      // fp16 pieces: lo * hi, hi * lo into the corrections, hi * hi into the main accumulator
+            auto h = [](const bf16x8& v) { return __builtin_bit_cast(f16x8, v); };
+            if constexpr (term == 0) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fal[st][mt]), h(b[0]), accl[mt], 0, 0, 0);
+            else if constexpr (term == 1) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[st][mt]), h(b[1]), accl[mt], 0, 0, 0);
+            else acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[st][mt]), h(b[0]), acc[mt], 0, 0, 0);
+            return;
+        } else {
         if constexpr ((PIVP_X6_ABL & 16) && term != 5) return;
         if constexpr (term == 0) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa3[st][mt], b[0], accl[mt], 0, 0, 0);        // lo * hi
         else if constexpr (term == 1) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], b[2], accl[mt], 0, 0, 0);    // hi * lo
@@ -1032,17 +1110,25 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
         else if constexpr (term == 3) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[st][mt], b[0], accl[mt], 0, 0, 0);   // mid * hi
         else if constexpr (term == 4) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], b[1], accl[mt], 0, 0, 0);    // hi * mid
         else acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], b[0], acc[mt], 0, 0, 0);                               // hi * hi
+        }
     };
     // one k-step: wait for its A fragments, then the MFMAs with the six A reads of the NEXT k-step (set NXT, k-step KSN at patch offset abn)
     // behind the first three
-    auto kstep = [&](auto CUR, auto NXT, auto KSN, unsigned abn, const bf16x8 (&b)[3], auto RD) {
+    auto kstep = [&](auto CUR, auto NXT, auto KSN, unsigned abn, const bf16x8 (&b)[PCS], auto RD) {
         constexpr bool rd = decltype(RD)::value;
         wait_a(CUR);
 #define PIVP_X6_M(I) mfma(CUR, std::integral_constant<int, I>{}, b);
 #define PIVP_X6_R(I) if constexpr (rd) read_a(NXT, KSN, std::integral_constant<int, I>{}, abn);
 #define PIVP_X6_S __builtin_amdgcn_sched_barrier(0);
         PIVP_X6_S
-        if constexpr (MT == 2) {
+        if constexpr (PCS == 2 && MT == 2) {
+            PIVP_X6_M(0) PIVP_X6_R(0) PIVP_X6_R(1) PIVP_X6_S
+            PIVP_X6_M(1) PIVP_X6_R(2) PIVP_X6_R(3) PIVP_X6_S
+            PIVP_X6_M(2) PIVP_X6_M(3) PIVP_X6_M(4) PIVP_X6_M(5)
+        } else if constexpr (PCS == 2) {
+            PIVP_X6_M(0) PIVP_X6_R(0) PIVP_X6_R(1) PIVP_X6_S
+            PIVP_X6_M(1) PIVP_X6_M(2)
+        } else if constexpr (MT == 2) {
             PIVP_X6_M(0) PIVP_X6_R(0) PIVP_X6_R(1) PIVP_X6_S
             PIVP_X6_M(1) PIVP_X6_R(2) PIVP_X6_R(3) PIVP_X6_S
             PIVP_X6_M(2) PIVP_X6_R(4) PIVP_X6_R(5) PIVP_X6_S
@@ -1063,8 +1149,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
     auto read_a_all = [&](unsigned ab) {               // the first k-step of a tap into set 0 (prologue, and behind a restaged patch)
-        read_a(S0{}, K0{}, I0{}, ab); read_a(S0{}, K0{}, I1{}, ab); read_a(S0{}, K0{}, I2{}, ab);
-        if constexpr (MT == 2) { read_a(S0{}, K0{}, I3{}, ab); read_a(S0{}, K0{}, I4{}, ab); read_a(S0{}, K0{}, I5{}, ab); }
+        read_a(S0{}, K0{}, I0{}, ab); read_a(S0{}, K0{}, I1{}, ab);
+        if constexpr (PCS * MT > 2) read_a(S0{}, K0{}, I2{}, ab);
+        if constexpr (PCS * MT > 3) read_a(S0{}, K0{}, I3{}, ab);
+        if constexpr (PCS * MT > 4) { read_a(S0{}, K0{}, I4{}, ab); read_a(S0{}, K0{}, I5{}, ab); }
     };
     auto a_base = [&](int tp) { const int ty = tp / 5; return lds0 + ty * RP16 + (tp - ty * 5) * PP; };
 
@@ -1160,7 +1248,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] += accl[mt][r];
+        for (int r = 0; r < 16; ++r) {
+            acc[mt][r] += accl[mt][r];
+            if constexpr (PCS == 2) acc[mt][r] *= inv_wscale;            // (the weights were packed times a power of two)
+        }
     BF_STAMP(3);
 
     if constexpr (!LSTM) {
@@ -1266,13 +1357,17 @@ int conv5x5_bf16_rows(int N) { return N % 128 == 0 ? N : (N + 63) / 64 * 64; }
 
 // w: fp32 K-inner packed [25][wcin/32][N][32]; wb: [ceil(wcin/64)][25][planes][Np][64] bf16 (Np >= N rows, the extra ones zero; 0 = N;
 // planes = 2: the hi / lo split of the split mode, lstm_bf16_weight_elems(wcin, Np) * 2 elements)
+// planes = 3: three bf16 pieces, fragment-major; planes = -2: two fp16 pieces of 256 w, fragment-major (lstm_bf16_weight_elems * 2 elements)
 int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s, int Np, int planes, int plain) {
     if (Np == 0) Np = N;
-    PIVP_CHECK_ARG(w && wb && wcin > 0 && wcin % 32 == 0 && N > 0 && Np >= N && planes >= 1 && planes <= 3);
-    const long total = (long)lstm_bf16_weight_elems(wcin, Np) * planes;
-    if (planes == 3) {       // the three-piece kernels' fragment-major pack: the cell's (N = 4 C, gate-interleaved fragments) or a plain conv's
+    PIVP_CHECK_ARG(w && wb && wcin > 0 && wcin % 32 == 0 && N > 0 && Np >= N && ((planes >= 1 && planes <= 3) || planes == -2));
+    const int pieces = planes == -2 ? 2 : planes;
+    const long total = (long)lstm_bf16_weight_elems(wcin, Np) * pieces;
+    if (planes == -2)        // the tensor's scale first: 64 partial maxima into the pack's tail
+        hipLaunchKernelGGL(absmax_partials_kernel, dim3(64), dim3(256), 0, s, w, (long)25 * wcin * N, reinterpret_cast<float*>(wb + total));
+    if (planes == 3 || planes == -2) {       // the three-piece kernels' fragment-major pack: the cell's (N = 4 C, gate-interleaved fragments) or a plain conv's
         PIVP_CHECK_ARG(Np % 64 == 0 && (plain || (Np == N && N % 32 == 0)));
-        hipLaunchKernelGGL(pack_lstm_x6_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, plain, total);
+        hipLaunchKernelGGL(pack_lstm_x6_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, plain, pieces, total);
         return PIVP_LAUNCH_STATUS();
     }
     hipLaunchKernelGGL(pack_lstm_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, planes, total);
@@ -1305,20 +1400,20 @@ static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t
     return PIVP_LAUNCH_STATUS();
 }
 
-template <int NWM, int NWN>
+template <int NWM, int NWN, int PCS = 3>
 static int launch_x6g(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts) {
-    constexpr int lds_bytes = 3 * PH * RP16;
+    constexpr int lds_bytes = PCS * PH * RP16;
     static PerDeviceOnce once;
-    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<NWM, NWN>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<NWM, NWN, true, PCS>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     IgemmDesc dd = d;
     const int tpi = (d.Hin / TH) * (d.Win / 16), nb = d.C / (8 * NWN);
     const int np = tpi * nb;
     dd.ln_nparts = (d.ln_part && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
-    const long long wbytes = (long long)lstm_bf16_weight_elems(d.c0 + (d.c1 ? d.c1 : d.C), 4 * d.C) * 3 * 2;
+    const long long wbytes = (long long)lstm_bf16_weight_elems(d.c0 + (d.c1 ? d.c1 : d.C), 4 * d.C) * PCS * 2;
     if (wbytes >= (1LL << 31)) return PIVP_ERR_BADARG;
-    hipLaunchKernelGGL((convlstm_x6g_kernel<NWM, NWN>), dim3(d.B * tpi * nb), dim3(64 * NWM * NWN), lds_bytes, stream, dd, wb, (int)wbytes, 0);
+    hipLaunchKernelGGL((convlstm_x6g_kernel<NWM, NWN, true, PCS>), dim3(d.B * tpi * nb), dim3(64 * NWM * NWN), lds_bytes, stream, dd, wb, (int)wbytes, 0);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -1336,7 +1431,14 @@ static int launch_x6g_plain(const IgemmDesc& dd, const unsigned short* wb, hipSt
 
 // d as for igemm_lstm (validated by the caller's igemm_validate(d, true) equivalent); wb = pack_lstm_bf16(d.w, ..., planes).
 int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nch, int planes) {
-    PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0) || ((nch == 1 || nch == 2) && planes == 3)) && planes >= 1 && planes <= 3);
+    PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0) || ((nch == 1 || nch == 2) && planes == 3)) &&
+                   ((planes >= 1 && planes <= 3) || planes == -2));
+    if (planes == -2) {   // two fp16 pieces, three MFMAs per product (wb = pack_lstm_bf16(..., planes = -2)): the L2-direct kernel, 16-wide tiles
+        PIVP_CHECK_ARG(convlstm_bf16x6_ok(d));
+        const long b32 = d.C % 32 ? 0 : (long)d.B * (d.Hin / TH) * (d.Win / 16) * (d.C / 32);
+        if ((nch == 32 && b32 > 0) || (nch == 0 && b32 >= pivp_cu_count())) return launch_x6g<2, 4, 2>(d, wb, stream, ln_nparts);
+        return launch_x6g<4, 2, 2>(d, wb, stream, ln_nparts);
+    }
     if (planes == 3) {   // three pieces: 16-wide tiles and 16-channel blocks only (convlstm_bf16x6_ok); 8-wide maps are the caller's to route elsewhere
         PIVP_CHECK_ARG(convlstm_bf16x6_ok(d));
         // weights straight from L2: 32-channel blocks (eight waves) where they give every CU a block, else 16-channel blocks (four waves).

@@ -60,7 +60,9 @@ __device__ __forceinline__ float fast_rcp(float d) {
     const float r = __builtin_amdgcn_rcpf(d);
     return fmaf(fmaf(-d, r, 1.0f), r, r);
 }
-__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + __expf(-x)); }
+// (x is clamped at -87: below that exp(-x) is +inf, v_rcp_f32 returns 0 and the Newton step's inf * 0 is a NaN -- found in round 4 by a range test
+// of the split-precision kernels with pre-activations of -150, where this kernel wrote NaN cells; sigmoid(-87) = 1.6e-38)
+__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + __expf(-fmaxf(x, -87.0f))); }
 // tanh: 2 / (1 + exp(-2x)) - 1 carries ~1.2e-7 of ABSOLUTE error at every x (the rounding of a value near 1), i.e. many ulps of a small
 // tanh; behind a LayerNorm that divides by the ~0.2 spread of h this was a third of the whole path's error against the float64 oracle
 // (scripts/gate_math_study.py: hidden1 3.7e-7 rms with libm's tanh, 4.7e-7 with that formula) and what put the STP fixture over 1e-4.

@@ -41,8 +41,9 @@ int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, co
     d.ln_part = ln_part; d.ln_cap = ln_cap;
     // w_bf16: the bf16 pack of w (pack_lstm_bf16) selects the bf16-operand kernel; variant then is its channels per block
     // (three pieces: maps the three-plane tile does not serve -- 8 wide -- take the fp32 kernel, which is what that mode stands in for)
-    if (w_bf16 && bf16_planes == 3 && !convlstm_bf16x6_ok(d)) return w ? igemm_lstm(d, s, 0, ln_nparts) : PIVP_ERR_BADARG;
-    if (w_bf16) return convlstm_bf16(d, w_bf16, s, ln_nparts, (bf16_planes == 3 && variant != 1 && variant != 2 && variant != 16 && variant != 32) ? 0 : variant, bf16_planes);
+    if (w_bf16 && (bf16_planes == 3 || bf16_planes == -2) && !convlstm_bf16x6_ok(d)) return w ? igemm_lstm(d, s, 0, ln_nparts) : PIVP_ERR_BADARG;
+    if (w_bf16) return convlstm_bf16(d, w_bf16, s, ln_nparts, ((bf16_planes == 3 && variant != 1 && variant != 2 && variant != 16 && variant != 32) ||
+                                                        (bf16_planes == -2 && variant != 16 && variant != 32)) ? 0 : variant, bf16_planes);
     return igemm_lstm(d, s, variant, ln_nparts);
 }
 
@@ -486,6 +487,17 @@ extern "C" int pivp_convlstm_bf16x6(const float* x, int cx, int ldx, const float
     if (!x || !w_bf16 || !bias || !c_in || !c_out || !h_out || (nch != 0 && nch != 1 && nch != 2 && nch != 16 && nch != 32)) return PIVP_ERR_BADARG;
     return run_convlstm(x, cx, ldx, h_prev, C, nullptr, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, nch, gates_out,
                         ln_part, ln_cap, ln_nparts, (const unsigned short*)w_bf16, 3);
+}
+extern "C" int pivp_pack_lstm_fp16x3(const float* w, void* w_bf16, int cin_total, int C, void* stream) {
+    if (C <= 0) return PIVP_ERR_BADARG;
+    return pack_lstm_bf16(w, (unsigned short*)w_bf16, cin_total, 4 * C, (hipStream_t)stream, 0, -2);
+}
+extern "C" int pivp_convlstm_fp16x3(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
+                                    const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
+                                    int* ln_nparts, int B, int H, int W, int nch, void* stream) {
+    if (!x || !w_bf16 || !bias || !c_in || !c_out || !h_out || (nch != 0 && nch != 16 && nch != 32)) return PIVP_ERR_BADARG;
+    return run_convlstm(x, cx, ldx, h_prev, C, nullptr, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, nch, gates_out,
+                        ln_part, ln_cap, ln_nparts, (const unsigned short*)w_bf16, -2);
 }
 extern "C" long long pivp_lstm_bf16_weight_elems(int cin_total, int C) {
     if (cin_total <= 0 || cin_total % 32 || C <= 0) return PIVP_ERR_BADARG;

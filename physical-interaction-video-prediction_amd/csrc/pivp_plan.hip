@@ -87,6 +87,7 @@ struct pivp_plan {
     size_t o_wbf16[7];                // bf16 packs of the ConvLSTM weights (pivp_plan_set_precision), rebuilt at the start of a rollout
     int lstm_bf16 = 0;                // 1: bf16 operands in the ConvLSTM forward (precision modes BF16 and BF16X3)
     int precision = 0;                // PIVP_PRECISION_*
+    int bwd_planes = 1;               // the data gradients' form of lstm_planes
     int lstm_planes = 1;              // 2: split mode (hi / lo planes, three MFMAs per product); 3: three pieces, six MFMAs (forward gate convs only: the
                                       // backward sweep and every other op of that mode are the fp32 ones)
     int bf16_all = 0;                 // precision mode BF16: also the ConvLSTM gradients and the enc5 / enc6 transposed convs
@@ -319,8 +320,8 @@ extern "C" int pivp_plan_set_grad(pivp_plan_t* plan, int idx, float* dptr) {
 // rounded to bf16, fp32 accumulation / gates / state (csrc/convlstm_bf16.hip), and in the backward sweep their data and weight gradients
 // (csrc/convlstm_bf16.hip <NCH, false>, csrc/wgrad_bf16.hip).  Everything else stays fp32, as do the parameters, the gradients and Adam.  Refused when a layer's map does not fit the bf16 kernel's tiles (8-wide maps need an even batch).
 extern "C" int pivp_plan_set_precision(pivp_plan_t* plan, int precision) {
-    if (!plan || precision < PIVP_PRECISION_F32 || precision > PIVP_PRECISION_BF16X6) return PIVP_ERR_BADARG;
-    if (precision != PIVP_PRECISION_F32 && precision != PIVP_PRECISION_BF16X6) {   // (BF16X6: a layer its tile does not serve runs the fp32 kernel)
+    if (!plan || precision < PIVP_PRECISION_F32 || precision > PIVP_PRECISION_FP16X3) return PIVP_ERR_BADARG;
+    if (precision == PIVP_PRECISION_BF16 || precision == PIVP_PRECISION_BF16X3) {   // (BF16X6: a layer its tile does not serve runs the fp32 kernel)
         const int hs[7] = {plan->H2, plan->H2, plan->H4, plan->H4, plan->H8, plan->H4, plan->H2};
         const int wsz[7] = {plan->W2, plan->W2, plan->W4, plan->W4, plan->W8, plan->W4, plan->W2};
         for (int i = 0; i < 7; ++i) {
@@ -332,7 +333,8 @@ extern "C" int pivp_plan_set_precision(pivp_plan_t* plan, int precision) {
         }
     }
     plan->lstm_bf16 = precision != PIVP_PRECISION_F32;
-    plan->lstm_planes = precision == PIVP_PRECISION_BF16X3 ? 2 : precision == PIVP_PRECISION_BF16X6 ? 3 : 1;
+    plan->lstm_planes = precision == PIVP_PRECISION_BF16X3 ? 2 : precision == PIVP_PRECISION_BF16X6 ? 3 : precision == PIVP_PRECISION_FP16X3 ? -2 : 1;
+    plan->bwd_planes = plan->lstm_planes == -2 ? 3 : plan->lstm_planes;      // (fp16 pieces: forward only; its sweep is the three-bf16-piece one)
     plan->bf16_all = precision == PIVP_PRECISION_BF16;
     plan->precision = precision;
     if (!plan->ws) plan_layout(plan);      // the dG rings' depth follows the precision; a bound workspace keeps the layout it was sized for
@@ -734,7 +736,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                                  Sp ? ws + Sp->c[i] : ws + p->o_zero, ws + S.c[i], nullptr, L.C,
                                  last_step ? nullptr : ws + g.din[i][npar] + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
                                  ring + (size_t)wg_slot * dG1, ws + g.wt_lstm[i], ws + g.din[i][par], nullptr, nullptr, B, hh, wwid,
-                                 s, 1, (p->lstm_bf16 && (p->lstm_planes != 3 || wwid % 16 == 0)) ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->lstm_planes,
+                                 s, 1, (p->lstm_bf16 && (p->bwd_planes != 3 || wwid % 16 == 0)) ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->bwd_planes,
                                  wg_flush ? fork_of(i, f) : nullptr, &lf[i],    // dW = null: only the fork's `ready` (behind the gate math) is used
                                  t == 0 ? 1 : 0, dx_lnb));                      // t = 0: nobody reads d h_{-1}
         if (t == 0) RC(ln_finish(i + 1));       // the sweep's last timestep: the norm's partial parameter planes (written by the gate kernel) become its gradient
@@ -944,7 +946,7 @@ static int rollout_backward_sweep(pivp_plan_t* plan, const float* images, const 
         for (int i = 0; i < 7; ++i) {
             const int cin = kLstm[i].cx + kLstm[i].C;
             RC(pack_lstm_bf16(ws + g.wt_lstm[i], reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]), 4 * kLstm[i].C, cin, s,
-                              conv5x5_bf16_rows(cin), plan->lstm_planes, 1));
+                              conv5x5_bf16_rows(cin), plan->bwd_planes, 1));
         }
     {
         const int ecin[7] = {0, 32, 64, 0, 128, 96, 64};

@@ -168,8 +168,10 @@ class Model(object):
         # three bf16 MFMAs (16 bits of product mantissa); the rollout stays inside the 1e-4 gate; backward and everything else fp32.
         # 'bf16x6': three bf16 pieces per operand and the six significant products (fp32-grade results on the bf16 matrix cores) in the forward gate
         # convolutions of every layer whose map is a multiple of 16 wide; everything else, and the whole backward pass, fp32.
-        if precision not in ('fp32', 'bf16', 'bf16x3', 'bf16x6'):
-            raise ValueError("precision must be 'fp32', 'bf16', 'bf16x3' or 'bf16x6'")
+        # 'fp16x3': the forward gate convolutions with every operand as two fp16 pieces (weights pre-scaled by 2^8), three MFMAs per product: 22-bit operands,
+        # still fp32-grade (its truncation is a quarter of fp32's own rounding error); the backward sweep is 'bf16x6''s.
+        if precision not in ('fp32', 'bf16', 'bf16x3', 'bf16x6', 'fp16x3'):
+            raise ValueError("precision must be 'fp32', 'bf16', 'bf16x3', 'bf16x6' or 'fp16x3'")
         self.precision = precision
         self._ref_pending = None       # reference-layout arrays loaded before the first call
         self._params = None            # name -> view into _flat_params (internal layout)
@@ -306,7 +308,7 @@ class Model(object):
                                   ln_eps=self.ln_eps, stp_zero_border=1 if self.stp_border == 'zeros' else 0)
             plan = _Plan(lib, cfg)
             if self.precision != 'fp32':
-                _lib.check(lib.pivp_plan_set_precision(plan.h, {'bf16': 1, 'bf16x3': 2, 'bf16x6': 3}[self.precision]),
+                _lib.check(lib.pivp_plan_set_precision(plan.h, {'bf16': 1, 'bf16x3': 2, 'bf16x6': 3, 'fp16x3': 4}[self.precision]),
                            'pivp_plan_set_precision(%s)' % self.precision)
             nbytes = lib.pivp_plan_workspace_bytes(plan.h)
             plan.workspace = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.device)

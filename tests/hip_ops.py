@@ -109,6 +109,23 @@ def convlstm_bf16x6(x, h, c, W, b, h_is_zero=False, nch=0, want_ln=False):
     return nchw(h_out, B, H, Wd, C), nchw(c_out, B, H, Wd, C)
 
 
+def convlstm_fp16x3(x, h, c, W, b, h_is_zero=False, nch=0):
+    """Two-fp16-piece ConvLSTM (three fp16 MFMAs per product, weights packed times a power of two); returns (h, c)."""
+    lib = _lib.load()
+    B, cx, H, Wd = x.shape
+    C = h.shape[1]
+    xd, hd, cd = nhwc(x), nhwc(h), nhwc(c)
+    wd, bd = _t(pivp_amd.to_internal('lstm1/conv/W', W)), _t(b)
+    wb = torch.empty(2 * lib.pivp_lstm_bf16_weight_elems(cx + C, C) + 256, dtype=torch.int16, device=DEV)     # + the scale's tail
+    _lib.check(lib.pivp_pack_lstm_fp16x3(wd.data_ptr(), wb.data_ptr(), cx + C, C, stream()), 'pack_lstm_fp16x3')
+    c_out = torch.empty_like(cd); h_out = torch.empty_like(hd)
+    _lib.check(lib.pivp_convlstm_fp16x3(xd.data_ptr(), cx, cx, None if h_is_zero else hd.data_ptr(), C, wb.data_ptr(), bd.data_ptr(),
+                                        cd.data_ptr(), c_out.data_ptr(), h_out.data_ptr(), None, None, 0, None, B, H, Wd, nch, stream()),
+               'convlstm_fp16x3')
+    torch.cuda.synchronize()
+    return nchw(h_out, B, H, Wd, C), nchw(c_out, B, H, Wd, C)
+
+
 def convlstm_ln(x, h, c, W, b, gamma, beta, eps, variant=0):
     """hidden = norm(lstm(x)) with the LayerNorm statistics from the ConvLSTM epilogue; returns (ln(h), h, c, fused)."""
     import ctypes

@@ -391,6 +391,64 @@ def test_conv5x5_bf16x6(ops, B, cin, cout, H):
         assert np.abs(out - (ref + acc)).max() < 6e-6       # (+ the rounding of the final add at |values| up to 5)
 
 
+# ---- two fp16 pieces per operand, three MFMAs per product (weights packed times 2^8): 22-bit operands, forward only ---------------------------
+@pytest.mark.parametrize('nch', [16, 32])
+@pytest.mark.parametrize('B,cx,C,H', X6_SHAPES)
+def test_convlstm_fp16x3_is_fp32_grade(ops, B, cx, C, H, nch):
+    x, h, c, W, b = [np.asarray(a, dtype=np.float32).astype(np.float64) for a in _case(B, cx, C, H, 231 + C + H)]
+    hr, cr, _ = _lstm_ref(x, h, c, W, b)
+    h3, c3 = ops.convlstm_fp16x3(x, h, c, W, b, nch=nch)
+    hf, cf = ops.convlstm(x, h, c, W, b)
+    e3 = max(np.abs(h3 - hr).max(), np.abs(c3 - cr).max()); ef = max(np.abs(hf - hr).max(), np.abs(cf - cr).max())
+    r3 = np.sqrt(((c3 - cr) ** 2).mean()); rf = np.sqrt(((cf - cr) ** 2).mean())
+    print('B=%d cx=%d C=%d H=%d nch=%d: max |err| two fp16 pieces %.2e, fp32 kernel %.2e; rms of c %.2e vs %.2e' % (B, cx, C, H, nch, e3, ef, r3, rf))
+    assert e3 < 3e-6 and e3 < 2.5 * ef and r3 < 1.5 * rf
+
+
+def test_convlstm_fp16x3_ranges(ops):
+    # the weights' scale is chosen per tensor (largest weight into [2^14, 2^15)): tiny and huge weights alike keep 22 bits; activations of 1e3 do not overflow
+    x, h, c, W, b = [np.asarray(a, dtype=np.float32).astype(np.float64) for a in _case(2, 32, 32, 16, 77)]
+    for xs, ws in ((1e3, 1e-3), (0.25, 4.0), (1e-2, 1e2), (1e-4, 1e4)):      # the last two: pre-activations up to +-150 / +-15,000 (saturated gates)
+        xx = np.asarray(x * xs, dtype=np.float32).astype(np.float64); WW = np.asarray(W * ws, dtype=np.float32).astype(np.float64)
+        with np.errstate(over='ignore'):
+            hr, cr, _ = _lstm_ref(xx, h, c, WW, b)
+        h3, c3 = ops.convlstm_fp16x3(xx, h, c, WW, b)
+        h6, c6 = ops.convlstm_bf16x6(xx, h, c, WW, b)
+        hf, cf = ops.convlstm(xx, h, c, WW, b)
+        # (the fp32 kernel wrote NaN cells here until round 4: its sigmoid's Newton step met exp = inf below -88)
+        assert np.isfinite(h3).all() and np.isfinite(h6).all() and np.isfinite(hf).all() and np.isfinite(cf).all()
+        ef = max(np.abs(cf - cr).max(), 1e-6)
+        assert np.abs(c3 - cr).max() < 3 * ef and np.abs(c6 - cr).max() < 3 * ef
+    h3, c3 = ops.convlstm_fp16x3(x, h, c, W, b, h_is_zero=True)
+    hr, cr, _ = _lstm_ref(x, h * 0, c, W, b)
+    assert np.abs(h3 - hr).max() < 3e-6 and np.abs(c3 - cr).max() < 3e-6
+
+
+def test_rollout_fp16x3_is_as_close_to_float64_as_the_fp32_path():
+    g = np.load(__import__('os').path.join(GOLD, 'cdna_b2_t10.npz'))
+    m3, loss3, gen3 = _rollout('fp16x3')
+    mf, lossf, genf = _rollout('fp32')
+    l3 = R.per_pixel_l2(gen3, g['gen_images']); lf = R.per_pixel_l2(genf, g['gen_images'])
+    print('fp16x3 rollout: per-pixel L2 vs float64 oracle max %.2e rms %.2e (fp32 path: max %.2e rms %.2e); loss %.8f vs %.8f'
+          % (l3.max(), np.sqrt((l3 ** 2).mean()), lf.max(), np.sqrt((lf ** 2).mean()), loss3, float(g['loss'])))
+    per3 = l3.reshape(l3.shape[0], -1).max(axis=1); perf = lf.reshape(lf.shape[0], -1).max(axis=1)
+    assert (per3 < 2.0 * np.maximum(perf, 1e-6)).all() and abs(loss3 - float(g['loss'])) < 1e-6
+    assert m3._active.lib.pivp_plan_get_precision(m3._active.h) == 4
+
+
+def test_train_step_in_fp16x3_mode_matches_the_fp32_gradients():
+    import pivp_amd
+    outs = {}
+    for prec in ('fp32', 'fp16x3'):
+        m, loss, _ = _rollout(prec, T=4, train=True, keep=True)
+        with pivp_amd.using_config('train', True):
+            m.backward()
+        outs[prec] = (loss, m._flat_grads.clone())
+    rel = float((outs['fp16x3'][1] - outs['fp32'][1]).norm() / outs['fp32'][1].norm())
+    print('fp16x3 train step: loss %.8f vs %.8f, relative gradient difference %.2e' % (outs['fp16x3'][0], outs['fp32'][0], rel))
+    assert abs(outs['fp16x3'][0] - outs['fp32'][0]) < 1e-6 and rel < 1e-4
+
+
 def test_rollout_bf16x6_is_as_close_to_float64_as_the_fp32_path():
     g = np.load(__import__('os').path.join(GOLD, 'cdna_b2_t10.npz'))
     m6, loss6, gen6 = _rollout('bf16x6')
