@@ -171,6 +171,10 @@ __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned shor
 // v_mfma_f32_32x32x16_bf16 whose 32 columns are the four gates of eight channels (lane (half, l31): gate l31 / 8, channel c8 * 8 + l31 % 8;
 // k = the k-step's channels half * 8 .. + 8) is 1 KB in lane order: one global_load_lds_dwordx4 of a wave moves exactly one fragment into
 // a lane-linear (conflict-free) kilobyte of the ring, one global_load_dwordx4 of a wave loads it straight into the MFMA's operand registers.
+#ifndef PIVP_X6_MIDLOAD
+#define PIVP_X6_MIDLOAD 0   // 1: the eight-wave L2-direct kernels issue their fragment loads in the middle of a k-step's MFMAs instead of behind them
+                            // (measured: three pieces 466.4 against 465.9 us per six layers, two fp16 pieces 308.8 against 298.6: off)
+#endif
 #ifndef PIVP_X6_ABL
 #define PIVP_X6_ABL 0       // timing-only ablations of the three-piece kernel (results are then wrong): 1 no per-k-step barriers, 2 no B fragment
 #endif                      // reads, 4 no reads of the A mid / lo planes, 8 no weight DMAs, 16 one MFMA per product instead of six
@@ -1063,7 +1067,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     int tap = tap0, cg = cgbase, tap1 = tap0, cg1 = cgbase;
     adv(tap1, cg1);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) bload(Bf[ks], (unsigned)(cg * 25 + tap) * tps + ks * kss);
+    for (int ks = 0; ks < ((PIVP_X6_MIDLOAD && RD == 4) ? 3 : 4); ++ks) bload(Bf[ks], (unsigned)(cg * 25 + tap) * tps + ks * kss);
     if constexpr (RD == 8) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) bload(Bf[4 + ks], (unsigned)(cg1 * 25 + tap1) * tps + ks * kss);
@@ -1114,7 +1118,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     };
     // one k-step: wait for its A fragments, then the MFMAs with the six A reads of the NEXT k-step (set NXT, k-step KSN at patch offset abn)
     // behind the first three
-    auto kstep = [&](auto CUR, auto NXT, auto KSN, unsigned abn, const bf16x8 (&b)[PCS], auto RD) {
+    auto kstep = [&](auto CUR, auto NXT, auto KSN, unsigned abn, const bf16x8 (&b)[PCS], auto RD, auto mid) {     // mid(): issued behind the first MFMA
         constexpr bool rd = decltype(RD)::value;
         wait_a(CUR);
 #define PIVP_X6_M(I) mfma(CUR, std::integral_constant<int, I>{}, b);
@@ -1124,19 +1128,23 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
         if constexpr (PCS == 2 && MT == 2) {
             PIVP_X6_M(0) PIVP_X6_R(0) PIVP_X6_R(1) PIVP_X6_S
             PIVP_X6_M(1) PIVP_X6_R(2) PIVP_X6_R(3) PIVP_X6_S
-            PIVP_X6_M(2) PIVP_X6_M(3) PIVP_X6_M(4) PIVP_X6_M(5)
+            PIVP_X6_M(2) mid(); PIVP_X6_S
+            PIVP_X6_M(3) PIVP_X6_M(4) PIVP_X6_M(5)
         } else if constexpr (PCS == 2) {
             PIVP_X6_M(0) PIVP_X6_R(0) PIVP_X6_R(1) PIVP_X6_S
-            PIVP_X6_M(1) PIVP_X6_M(2)
+            PIVP_X6_M(1) mid(); PIVP_X6_S
+            PIVP_X6_M(2)
         } else if constexpr (MT == 2) {
             PIVP_X6_M(0) PIVP_X6_R(0) PIVP_X6_R(1) PIVP_X6_S
             PIVP_X6_M(1) PIVP_X6_R(2) PIVP_X6_R(3) PIVP_X6_S
             PIVP_X6_M(2) PIVP_X6_R(4) PIVP_X6_R(5) PIVP_X6_S
-            PIVP_X6_M(3) PIVP_X6_M(4) PIVP_X6_M(5) PIVP_X6_M(6) PIVP_X6_M(7) PIVP_X6_M(8) PIVP_X6_M(9) PIVP_X6_M(10) PIVP_X6_M(11)
+            PIVP_X6_M(3) mid(); PIVP_X6_S
+            PIVP_X6_M(4) PIVP_X6_M(5) PIVP_X6_M(6) PIVP_X6_M(7) PIVP_X6_M(8) PIVP_X6_M(9) PIVP_X6_M(10) PIVP_X6_M(11)
         } else {
             PIVP_X6_M(0) PIVP_X6_R(0) PIVP_X6_R(1) PIVP_X6_S
             PIVP_X6_M(1) PIVP_X6_R(2) PIVP_X6_S
-            PIVP_X6_M(2) PIVP_X6_M(3) PIVP_X6_M(4) PIVP_X6_M(5)
+            PIVP_X6_M(2) mid(); PIVP_X6_S
+            PIVP_X6_M(3) PIVP_X6_M(4) PIVP_X6_M(5)
         }
         PIVP_X6_S
 #undef PIVP_X6_M
@@ -1178,14 +1186,14 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
             const bool has1 = it + 1 < nchunks, has2 = it + 2 < nchunks;
             const bool regroup = has1 && cg1 != cg;
             const unsigned so2 = (unsigned)(cg2 * 25 + tap2) * tps;
-            kstep(S0{}, S1{}, K1{}, ab, Bf[4 * p + 0], std::true_type{});
+            kstep(S0{}, S1{}, K1{}, ab, Bf[4 * p + 0], std::true_type{}, []{});
             if (has2) bload(Bf[4 * p + 0], so2);
-            kstep(S1{}, S0{}, K2{}, ab, Bf[4 * p + 1], std::true_type{});
+            kstep(S1{}, S0{}, K2{}, ab, Bf[4 * p + 1], std::true_type{}, []{});
             if (has2) bload(Bf[4 * p + 1], so2 + kss);
-            kstep(S0{}, S1{}, K3{}, ab, Bf[4 * p + 2], std::true_type{});
+            kstep(S0{}, S1{}, K3{}, ab, Bf[4 * p + 2], std::true_type{}, []{});
             if (has2) bload(Bf[4 * p + 2], so2 + 2 * kss);
-            if (has1 && !regroup) kstep(S1{}, S0{}, K0{}, ab1, Bf[4 * p + 3], std::true_type{});
-            else kstep(S1{}, S0{}, K0{}, ab1, Bf[4 * p + 3], std::false_type{});
+            if (has1 && !regroup) kstep(S1{}, S0{}, K0{}, ab1, Bf[4 * p + 3], std::true_type{}, []{});
+            else kstep(S1{}, S0{}, K0{}, ab1, Bf[4 * p + 3], std::false_type{}, []{});
             if (has2) bload(Bf[4 * p + 3], so2 + 3 * kss);
             if (regroup) {                             // next 64 input channels: every wave is done with the old patch
                 __syncthreads();
@@ -1231,15 +1239,26 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
             const unsigned ab = a_base(tap), ab1 = a_base(tap1);
             const bool has1 = t < 24 || g + 1 < ncg;
             const unsigned so1 = (unsigned)(cg1 * 25 + tap1) * tps;
-            kstep(S0{}, S1{}, K1{}, ab, Bf[0], std::true_type{});
+#if PIVP_X6_MIDLOAD
+            // the fragment loads go out in the MIDDLE of a k-step's MFMAs (their issue then overlaps the wave's own matrix work), into the registers
+            // of the k-step before: three k-steps ahead of their use
+            const unsigned soc = (unsigned)(cg * 25 + tap) * tps;
+            kstep(S0{}, S1{}, K1{}, ab, Bf[0], std::true_type{}, [&] { bload(Bf[3], soc + 3 * kss); });
+            kstep(S1{}, S0{}, K2{}, ab, Bf[1], std::true_type{}, [&] { if (has1) bload(Bf[0], so1); });
+            kstep(S0{}, S1{}, K3{}, ab, Bf[2], std::true_type{}, [&] { if (has1) bload(Bf[1], so1 + kss); });
+            if (t < 24) kstep(S1{}, S0{}, K0{}, ab1, Bf[3], std::true_type{}, [&] { if (has1) bload(Bf[2], so1 + 2 * kss); });
+            else kstep(S1{}, S0{}, K0{}, ab1, Bf[3], std::false_type{}, [&] { if (has1) bload(Bf[2], so1 + 2 * kss); });
+#else
+            kstep(S0{}, S1{}, K1{}, ab, Bf[0], std::true_type{}, []{});
             if (has1) bload(Bf[0], so1);
-            kstep(S1{}, S0{}, K2{}, ab, Bf[1], std::true_type{});
+            kstep(S1{}, S0{}, K2{}, ab, Bf[1], std::true_type{}, []{});
             if (has1) bload(Bf[1], so1 + kss);
-            kstep(S0{}, S1{}, K3{}, ab, Bf[2], std::true_type{});
+            kstep(S0{}, S1{}, K3{}, ab, Bf[2], std::true_type{}, []{});
             if (has1) bload(Bf[2], so1 + 2 * kss);
-            if (t < 24) kstep(S1{}, S0{}, K0{}, ab1, Bf[3], std::true_type{});
-            else kstep(S1{}, S0{}, K0{}, ab1, Bf[3], std::false_type{});      // (the next tap's A fragments come from the next patch)
+            if (t < 24) kstep(S1{}, S0{}, K0{}, ab1, Bf[3], std::true_type{}, []{});
+            else kstep(S1{}, S0{}, K0{}, ab1, Bf[3], std::false_type{}, []{});      // (the next tap's A fragments come from the next patch)
             if (has1) bload(Bf[3], so1 + 3 * kss);
+#endif
             tap = tap1; cg = cg1;
             adv(tap1, cg1);
         }

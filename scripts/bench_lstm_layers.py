@@ -14,9 +14,10 @@ LAYERS = [('lstm1', 32, 32, 32), ('lstm2', 32, 32, 32), ('lstm3', 32, 64, 16), (
           ('lstm5', 64, 128, 8), ('lstm6', 128, 64, 16), ('lstm7', 96, 32, 32)]
 import os
 VARIANT = int(os.environ.get('PIVP_LSTM_VARIANT', '0'))
-BF16 = os.environ.get('PIVP_BENCH_BF16', '0') in ('1', '3', '6')   # bf16-operand kernel (VARIANT = channels per block: 0 / 16 / 32); 3 = split mode; 6 = three pieces
+BF16 = os.environ.get('PIVP_BENCH_BF16', '0') in ('1', '3', '6', 'h3')   # bf16-operand kernel (VARIANT = channels per block: 0 / 16 / 32); 3 = split mode; 6 = three pieces
 X3 = os.environ.get('PIVP_BENCH_BF16', '0') == '3'
 X6 = os.environ.get('PIVP_BENCH_BF16', '0') == '6'
+H3 = os.environ.get('PIVP_BENCH_BF16', '0') == 'h3'      # two fp16 pieces, three MFMAs per product
 DATA = os.environ.get('PIVP_BENCH_DATA', 'random')   # random | zero | const: does the MFMA rate depend on the operand values?
 if os.environ.get('PIVP_BENCH_LIB'):      # a variant build of the library (scripts/r04/build_x6_variants.sh): timing experiments only
     _lib.LIB_PATH = os.path.abspath(os.environ['PIVP_BENCH_LIB'])
@@ -40,16 +41,16 @@ for name, cx, C, H in LAYERS:
     co = torch.empty_like(c); ho = torch.empty_like(h)
     wb = None
     if BF16:
-        if X6 and H % 16:
+        if (X6 or H3) and H % 16:
             continue                      # (8-wide maps are not the three-piece kernel's)
-        wb = torch.empty((3 if X6 else 2 if X3 else 1) * lib.pivp_lstm_bf16_weight_elems(cx + C, C), dtype=torch.int16, device=dev)
-        assert (lib.pivp_pack_lstm_bf16x6 if X6 else lib.pivp_pack_lstm_bf16x3 if X3 else lib.pivp_pack_lstm_bf16)(w.data_ptr(), wb.data_ptr(), cx + C, C, st) == 0
+        wb = torch.empty((3 if X6 else 2 if (X3 or H3) else 1) * lib.pivp_lstm_bf16_weight_elems(cx + C, C) + 256, dtype=torch.int16, device=dev)
+        assert (lib.pivp_pack_lstm_fp16x3 if H3 else lib.pivp_pack_lstm_bf16x6 if X6 else lib.pivp_pack_lstm_bf16x3 if X3 else lib.pivp_pack_lstm_bf16)(w.data_ptr(), wb.data_ptr(), cx + C, C, st) == 0
     bufs[name] = (x, h, c, w, b, co, ho, cx, C, H, wb)
 
 def launch(name):
     x, h, c, w, b, co, ho, cx, C, H, wb = bufs[name]
-    if X6:
-        rc = lib.pivp_convlstm_bf16x6(x.data_ptr(), cx, cx, h.data_ptr(), C, wb.data_ptr(), b.data_ptr(), c.data_ptr(), co.data_ptr(),
+    if X6 or H3:
+        rc = (lib.pivp_convlstm_fp16x3 if H3 else lib.pivp_convlstm_bf16x6)(x.data_ptr(), cx, cx, h.data_ptr(), C, wb.data_ptr(), b.data_ptr(), c.data_ptr(), co.data_ptr(),
                                       ho.data_ptr(), None, None, 0, None, B, H, H, VARIANT, st)
         assert rc == 0, rc
         return
