@@ -40,7 +40,7 @@ extern "C" {
 #define PIVP_PRECISION_BF16X6 3
 #define PIVP_PRECISION_FP16X3 4
 
-int pivp_abi_version(void);   /* 10 (10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+int pivp_abi_version(void);   /* 10 (10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3, pivp_deconv3x3s2_fp16x3; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
                                  5: + bf16 ConvLSTM, pivp_plan_set_precision, 6: + pivp_plan_set_group_join / pivp_plan_group_wait) */
 
 /* sha256 (hex) of the sources this library was compiled from (every .hip and .h under csrc/, and this header), embedded by build.py.  The Python
@@ -87,7 +87,7 @@ int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr);
  * PIVP_PRECISION_BF16X6 = three bf16 pieces per fp32 operand (hi + mid + lo = v exactly) and the six products of weight >= 2^-16, i.e. fp32-grade
  * gate pre-activations computed on the bf16 matrix cores: the gate convolutions and, in the backward sweep, their DATA gradients, of layers whose map is a
  * multiple of 16 wide (8-wide maps -- lstm5 on 64 x 64 frames -- run the fp32 kernels); the weight gradients and every other op are the fp32 ones.
- * PIVP_PRECISION_FP16X3 = the forward gate convolutions with every fp32 operand as TWO FP16 pieces (22 bits of mantissa; a layer's weights are packed times the
+ * PIVP_PRECISION_FP16X3 = the forward gate convolutions (and the enc5 / enc6 transposed convs) with every fp32 operand as TWO FP16 pieces (22 bits of mantissa; a layer's weights are packed times the
  * power of two that puts the largest in [2^14, 2^15), so that the second piece of any weight down to 2^-18 of it stays a normal fp16 number; the sum is scaled
  * back exactly) and three MFMAs per product; activations beyond +-65504 saturate, activations below 0.06 carry up to 3e-8 of absolute error.  Its truncation error is a quarter of the fp32 path's own rounding error (scripts/split_fp16_study.py); the backward sweep is
  * PIVP_PRECISION_BF16X6's (gradients do not fit fp16's exponent range).  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
@@ -222,6 +222,10 @@ int pivp_deconv3x3s2_bf16(const float* x, int cin, int ldx, const float* w, cons
 /* ... and in the split mode (two bf16 pieces per operand, three MFMAs per product; PIVP_PRECISION_BF16X3) */
 int pivp_deconv3x3s2_bf16x3(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                             int ldo, int relu, int B, int Hin, int Win, void* stream);
+/* ... and as two FP16 pieces per operand, three MFMAs per product (fp32-grade; PIVP_PRECISION_FP16X3): the weights' power-of-two scale is taken from their
+ * absolute maximum first; scratch: 66 floats */
+int pivp_deconv3x3s2_fp16x3(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
+                            int ldo, int relu, int B, int Hin, int Win, float* scratch, void* stream);
 
 /* Plain 5x5 stride-1 "same" convolution with bf16 operands and fp32 accumulation, out[b,y,x,n] (+)= sum x[b,y+dy,x+dx,k] w[tap][k][n]
  * (the ConvLSTM data gradient of the bf16 mode: x = d gates, w = the flipped transposed weights).  x NHWC (cin channels, stride ldx);

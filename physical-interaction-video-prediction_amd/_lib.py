@@ -73,6 +73,7 @@ SIGNATURES = {
     'pivp_convlstm_fp16x3': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'pivp_convlstm_bf16x6': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'pivp_deconv3x3s2_bf16x3': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'pivp_deconv3x3s2_fp16x3': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'pivp_deconv3x3s2_bf16': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'pivp_wgrad5x5_bf16': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pivp_wgrad5x5_bf16_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _vp]),

@@ -1370,6 +1370,12 @@ extern "C" int pivp_debug_bf16_stamps(long long* out, int n) {   // n <= 2048 * 
 namespace pivp {
 #endif
 
+int absmax_partials(const float* w, long n, float* tail, hipStream_t stream) {
+    PIVP_CHECK_ARG(w && tail && n > 0);
+    hipLaunchKernelGGL(absmax_partials_kernel, dim3(64), dim3(256), 0, stream, w, n, tail);
+    return PIVP_LAUNCH_STATUS();
+}
+
 size_t lstm_bf16_weight_elems(int wcin, int N) { return (size_t)((wcin + 63) / 64) * 25 * N * 64; }
 // rows of the bf16 pack of a plain 5x5 convolution with N output channels: whole 128- or 64-column blocks
 int conv5x5_bf16_rows(int N) { return N % 128 == 0 ? N : (N + 63) / 64 * 64; }

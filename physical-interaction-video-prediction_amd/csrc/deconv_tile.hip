@@ -36,6 +36,8 @@ __device__ __forceinline__ unsigned dpack2(float a, float b) {
 // PREC 1 (bf16): operands rounded to bf16 on their way into LDS (activations AND weights: both stay fp32 in HBM), v_mfma_f32_32x32x16_bf16, fp32
 // accumulation and epilogue.  PREC 2 (split): each operand as hi = bf16(v) and lo = bf16(v - hi) in two image planes, a product as
 // lo*hi + hi*lo + hi*hi on three MFMAs (the split mode of convlstm_bf16.hip).  PREC 0: fp32 MFMA.
+// PREC 3: two FP16 pieces (22 bits of operand; the weights times the power of two of d.wscale_part, the sum scaled back), lo*hi + hi*lo + hi*hi on
+// three fp16 MFMAs: fp32-grade (precision mode PIVP_PRECISION_FP16X3).
 // The input may be a concat of two tensors (x0: c0 channels | x1: c1 channels, whole 32-channel chunks each: [hidden6 | enc1], [hidden7 | enc0]),
 // and with IN_LN the x0 part is a RAW ConvLSTM output whose LayerNorm (TM:203-208: per-element gamma / beta [Hin*Win][c0], statistics merged
 // from the producer's partials d.in_part) is applied while the patch is staged -- the expression of ln_apply_kernel, bit-identical to the
@@ -73,6 +75,8 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
         if (d.in_stat_out && nblk == 0 && trem == 0 && tid == 0) { d.in_stat_out[b * 2] = ln_mean; d.in_stat_out[b * 2 + 1] = ln_rstd; }
     }
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, d.bytesw, 0x00020000);
+    float wscale = 1.0f;
+    if constexpr (PREC == 3) wscale = d.wscale_part ? pivp_x3_scale_wave(d.wscale_part) : 1.0f;
     constexpr unsigned OOB = 0xC0000000u;
 
     // ---- staging roles ----------------------------------------------------------------------------------------------------
@@ -138,7 +142,26 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
                 }
             }
         }
-        if constexpr (BF16) {
+        if constexpr (PREC == 3) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                float r[4] = {rp[j][0], rp[j][1], rp[j][2], rp[j][3]};
+                uint2 v, l;
+                v.x = pivp_pack2h_rest(r[0], r[1]); v.y = pivp_pack2h_rest(r[2], r[3]);
+                l.x = pivp_pack2h_rest(r[0], r[1]); l.y = pivp_pack2h_rest(r[2], r[3]);
+                *reinterpret_cast<uint2*>(Ah + ((tid >> 3) + 32 * j) * HP + c4 * 8) = v;
+                *reinterpret_cast<uint2*>(Ah + HPL + ((tid >> 3) + 32 * j) * HP + c4 * 8) = l;
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float r[4] = {rw[t][0] * wscale, rw[t][1] * wscale, rw[t][2] * wscale, rw[t][3] * wscale};
+                uint2 v, l;
+                v.x = pivp_pack2h_rest(r[0], r[1]); v.y = pivp_pack2h_rest(r[2], r[3]);
+                l.x = pivp_pack2h_rest(r[0], r[1]); l.y = pivp_pack2h_rest(r[2], r[3]);
+                *reinterpret_cast<uint2*>(Bh + t * B_HB + (tid >> 3) * HP + c4 * 8) = v;
+                *reinterpret_cast<uint2*>(Bh + HPL + t * B_HB + (tid >> 3) * HP + c4 * 8) = l;
+            }
+        } else if constexpr (BF16) {
             auto lo2 = [](unsigned hi2, float a, float b) {     // bf16(v - hi): hi as a float is its 16 bits shifted up
                 return dpack2(a - __builtin_bit_cast(float, hi2 << 16), b - __builtin_bit_cast(float, hi2 & 0xffff0000u));
             };
@@ -190,6 +213,16 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ar + ks * 32), bh = *reinterpret_cast<const bf16x8*>(Br + ks * 32);
+                if constexpr (PREC == 3) {
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ar + HPL + ks * 32), bl = *reinterpret_cast<const bf16x8*>(Br + HPL + ks * 32);
+                    auto h = [](const bf16x8& v) { return __builtin_bit_cast(pivp_f16x8, v); };
+                    // (one accumulator: K is 36-54 k-steps here, three roundings per k-step stay below the fp32 MFMA's one per product; a second
+                    // set of four accumulators spilled 109 registers in the form that applies the LayerNorm while staging)
+                    acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(al), h(bh), acc[ph], 0, 0, 0);
+                    acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(ah), h(bl), acc[ph], 0, 0, 0);
+                    acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(ah), h(bh), acc[ph], 0, 0, 0);
+                    continue;
+                }
                 if constexpr (PREC == 2) {
                     const bf16x8 al = *reinterpret_cast<const bf16x8*>(Ar + HPL + ks * 32), bl = *reinterpret_cast<const bf16x8*>(Br + HPL + ks * 32);
                     acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[ph], 0, 0, 0);
@@ -230,6 +263,7 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
     // ---- epilogue: accumulator row i -> anchor (2 wave + i / 16, i % 16), parity (py, px) -> output pixel (2 y + py, 2 x + px) ----------
     const int col = nblk * 32 + l31;
     const float bias = d.bias ? d.bias[col] : 0.f;
+    const float inv_wscale = 1.0f / wscale;
     float s1 = 0.f;
     // LayerNorm-backward sums of the output (data gradients, IgemmDesc::lnb_part): block-uniform switch
     const bool lnb = d.lnb_part && nblk * 32 < d.lnb_C;
@@ -242,7 +276,9 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
             const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
             const int oy = 2 * (y0 + 2 * wave + (i >> 4)) + (ph >> 1), ox = 2 * (x0 + (i & 15)) + (ph & 1);
             float* o = d.out + ((size_t)(b * d.Hout + oy) * d.Wout + ox) * d.ldo + col;
-            float v = acc[ph][r] + bias;
+            float v = acc[ph][r];
+            if constexpr (PREC == 3) v *= inv_wscale;
+            v += bias;
             if (d.relu) v = fmaxf(v, 0.f);
             if (d.accum) v += *o;
             *o = v;
@@ -294,7 +330,10 @@ bool deconv_tile_ok(const IgemmDesc& d) {
 int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts, int prec) {
     PIVP_CHECK_ARG(deconv_tile_ok(d));
     constexpr int lds_f32 = (A_FL + 9 * B_FL) * 4;        // 64,512 (the bf16 images fit inside)
-    static PerDeviceOnce once0, once2, once0n, once2n;
+    static PerDeviceOnce once0, once2, once0n, once2n, once3, once3n;
+    if (prec == 3 && (pivp_ensure_dyn_lds(once3, reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<3, false>), 2 * (A_HB + 9 * B_HB)) != PIVP_OK ||
+                      pivp_ensure_dyn_lds(once3n, reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<3, true>), 2 * (A_HB + 9 * B_HB)) != PIVP_OK))
+        return PIVP_ERR_LAUNCH;
     if (pivp_ensure_dyn_lds(once0, reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<0, false>), lds_f32) != PIVP_OK ||
         pivp_ensure_dyn_lds(once2, reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<2, false>), 2 * (A_HB + 9 * B_HB)) != PIVP_OK ||
         pivp_ensure_dyn_lds(once0n, reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<0, true>), lds_f32) != PIVP_OK ||
@@ -314,7 +353,10 @@ int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts, int prec
         if (d.lnb_np_out) *d.lnb_np_out = dd.lnb_np;
     }
     const dim3 grid(d.B * tpi * nb);
-    if (d.in_g) {
+    if (prec == 3) {
+        if (d.in_g) hipLaunchKernelGGL((deconv3x3s2_tile_kernel<3, true>), grid, dim3(256), 2 * (A_HB + 9 * B_HB), stream, dd);
+        else hipLaunchKernelGGL((deconv3x3s2_tile_kernel<3, false>), grid, dim3(256), 2 * (A_HB + 9 * B_HB), stream, dd);
+    } else if (d.in_g) {
         if (prec == 2) hipLaunchKernelGGL((deconv3x3s2_tile_kernel<2, true>), grid, dim3(256), 2 * (A_HB + 9 * B_HB), stream, dd);
         else if (prec == 1) hipLaunchKernelGGL((deconv3x3s2_tile_kernel<1, true>), grid, dim3(256), A_HB + 9 * B_HB, stream, dd);
         else hipLaunchKernelGGL((deconv3x3s2_tile_kernel<0, true>), grid, dim3(256), lds_f32, stream, dd);

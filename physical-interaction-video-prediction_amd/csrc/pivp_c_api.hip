@@ -95,9 +95,11 @@ int run_conv3x3s2_ln(const float* x_raw, int cin, const float* w, const float* b
 
 int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                     int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum, float* ln_part, int ln_cap,
-                    int* ln_nparts, int bf16, const LnbSpec* lnb) {
+                    int* ln_nparts, int bf16, const LnbSpec* lnb, const float* wscale_part) {
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
+    if (bf16 == 3 && !wscale_part) return PIVP_ERR_BADARG;
+    d.wscale_part = wscale_part;
     d.bf16 = bf16;                   // precision mode bf16: honoured by the all-parities tile kernel (deconv_tile.hip), fp32 otherwise
     d.x0 = x; d.c0 = cin; d.ld0 = ldx; d.wcin = cin; d.w = w; d.bias = bias;
     d.B = B; d.Hin = Hin; d.Win = Win; d.Hg = Hin; d.Wg = Win; d.in_step = 1;
@@ -163,14 +165,16 @@ bool deconv3x3s2_ln_ok(int c_ln, int c1, int cout, int B, int Hin, int Win) {
 }
 int run_deconv3x3s2_ln(const float* h_raw, int c_ln, const float* x1, int c1, int ld1, const float* w, const float* bias, float* out, int cout,
                        int ldo, int relu, int B, int Hin, int Win, hipStream_t s, const float* gamma, const float* beta, const float* partials,
-                       int nparts, float eps, float* ln_part, int ln_cap, int* ln_nparts, int bf16, float* norm_out, int norm_ld, float* stat_out) {
+                       int nparts, float eps, float* ln_part, int ln_cap, int* ln_nparts, int bf16, float* norm_out, int norm_ld, float* stat_out,
+                       const float* wscale_part) {
     if (!h_raw || !w || !out || !gamma || !beta || !partials || nparts <= 0 || !deconv3x3s2_ln_ok(c_ln, x1 ? c1 : 0, cout, B, Hin, Win)) return PIVP_ERR_BADARG;
     if (norm_out && (norm_ld < c_ln || norm_ld % 4 || ((uintptr_t)norm_out & 15))) return PIVP_ERR_BADARG;
     if (ln_part && ln_part == partials) return PIVP_ERR_BADARG;      // blocks finish (and write their output partial) while others still read the input's
     IgemmDesc d;
     int rc = deconv3x3s2_ln_desc(d, h_raw, c_ln, x1, c1, ld1, w, bias, out, cout, ldo, relu, B, Hin, Win);
     if (rc != PIVP_OK) return rc;
-    d.bf16 = bf16;
+    if (bf16 == 3 && !wscale_part) return PIVP_ERR_BADARG;
+    d.bf16 = bf16; d.wscale_part = wscale_part;
     d.in_g = gamma; d.in_b = beta; d.in_part = partials; d.in_np = nparts; d.in_eps = eps;
     d.ln_part = ln_part; d.ln_cap = ln_cap;
     d.in_out = norm_out; d.in_out_ld = norm_ld; d.in_stat_out = stat_out;
@@ -668,6 +672,14 @@ extern "C" int pivp_deconv3x3s2_bf16x3(const float* x, int cin, int ldx, const f
                                        int ldo, int relu, int B, int Hin, int Win, void* stream) {   // split mode: two bf16 pieces per operand
     if (!x || !w || !out) return PIVP_ERR_BADARG;
     return run_deconv3x3s2(x, cin, ldx, w, bias, out, cout, ldo, relu, B, Hin, Win, (hipStream_t)stream, 0, nullptr, 0, nullptr, 2);
+}
+// two fp16 pieces per operand, three MFMAs per product (precision mode PIVP_PRECISION_FP16X3): scratch = 66 floats (the weights' partial maxima)
+extern "C" int pivp_deconv3x3s2_fp16x3(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
+                                       int ldo, int relu, int B, int Hin, int Win, float* scratch, void* stream) {
+    if (!x || !w || !out || !scratch || cin <= 0 || cout <= 0) return PIVP_ERR_BADARG;
+    int rc = absmax_partials(w, 9L * cin * cout, scratch, (hipStream_t)stream);
+    if (rc != PIVP_OK) return rc;
+    return run_deconv3x3s2(x, cin, ldx, w, bias, out, cout, ldo, relu, B, Hin, Win, (hipStream_t)stream, 0, nullptr, 0, nullptr, 3, nullptr, scratch);
 }
 extern "C" int pivp_conv_enc0(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, void* stream) {
     return conv_enc0(img, w, bias, out, B, H, W, (hipStream_t)stream);

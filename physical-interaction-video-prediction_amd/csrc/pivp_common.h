@@ -50,6 +50,34 @@ namespace pivp {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---- two fp16 pieces per fp32 operand (the fp16x3 forms of the ConvLSTM gate conv and of the enc5 / enc6 transposed convs) -----------------------
+typedef _Float16 pivp_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pivp_f16x2 __attribute__((ext_vector_type(2)));
+typedef float pivp_f32x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> packed fp16 (round to nearest even, saturating at the largest finite fp16); a, b become the remainders v - fp16(v), exact in fp32
+__device__ __forceinline__ unsigned pivp_pack2h_rest(float& a, float& b) {
+    const float ca = __builtin_fminf(__builtin_fmaxf(a, -65504.f), 65504.f), cb = __builtin_fminf(__builtin_fmaxf(b, -65504.f), 65504.f);
+    pivp_f32x2 v = {ca, cb};
+    const pivp_f16x2 h = __builtin_convertvector(v, pivp_f16x2);
+    a -= (float)h[0]; b -= (float)h[1];
+    return __builtin_bit_cast(unsigned, h);
+}
+// the power of two that puts a tensor's largest |value| (the maximum of the 64 partial maxima at tail[2..65]: absmax_partials) into [2^14, 2^15)
+__device__ __forceinline__ float pivp_x3_scale_of_max(float m) {
+    if (!(m > 0.f) || !(m < 3.0e38f)) return 1.0f;
+    int e;
+    (void)__builtin_frexpf(m, &e);                  // m = f * 2^e, f in [0.5, 1)
+    int k = 15 - e;
+    k = k < -60 ? -60 : k > 60 ? 60 : k;
+    return __builtin_ldexpf(1.0f, k);
+}
+__device__ __forceinline__ float pivp_x3_scale_wave(const float* tail) {       // one partial per lane, xor-tree maximum: every lane returns the scale
+    float m = tail[2 + (threadIdx.x & 63)];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+    return pivp_x3_scale_of_max(m);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

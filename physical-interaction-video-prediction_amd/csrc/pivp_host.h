@@ -23,7 +23,8 @@ int run_conv3x3s2_ln(const float* x_raw, int cin, const float* w, const float* b
                      int B, int Hin, int Win, hipStream_t s, const float* gamma, const float* beta, const float* partials, int nparts, float eps);
 int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                     int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0,
-                    float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr, int bf16 = 0, const LnbSpec* lnb = nullptr);
+                    float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr, int bf16 = 0, const LnbSpec* lnb = nullptr,
+                    const float* wscale_part = nullptr);   // bf16 == 3 (two fp16 pieces): absmax_partials(w)
 int run_deconv3x3s2_and_partials(const float* x, int cin, const float* w, const float* bias, float* out, int cout, int ldo, int relu,
                                  int B, int Hin, int Win, hipStream_t s, const float* wt, float* partials, int dbl);   // + motion_partials(x, wt, ...) in the same grid
 // deconv3x3s2 of concat(LayerNorm(h_raw) [c_ln channels], x1 [c1 channels, stride ld1]) with the norm applied while the tile kernel stages its
@@ -32,7 +33,8 @@ bool deconv3x3s2_ln_ok(int c_ln, int c1, int cout, int B, int Hin, int Win);
 int run_deconv3x3s2_ln(const float* h_raw, int c_ln, const float* x1, int c1, int ld1, const float* w, const float* bias, float* out, int cout,
                        int ldo, int relu, int B, int Hin, int Win, hipStream_t s, const float* gamma, const float* beta, const float* partials,
                        int nparts, float eps, float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr, int bf16 = 0,
-                       float* norm_out = nullptr, int norm_ld = 0, float* stat_out = nullptr);   // training plans: the normalised tensor and (mean, rstd) are kept
+                       float* norm_out = nullptr, int norm_ld = 0, float* stat_out = nullptr,    // training plans: the normalised tensor and (mean, rstd) are kept
+                       const float* wscale_part = nullptr);
 int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, int cout, int ldo, int ksize, int B, int H, int W,
                 hipStream_t s, int accum = 0, int wN = 0,    // wN: columns of the weight pack when only its first `cout` are wanted
                 int dest_zeroed = 0,                         // 1: the caller has cleared `out` (see conv_s1_splits_k)

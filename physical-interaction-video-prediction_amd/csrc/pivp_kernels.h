@@ -37,7 +37,9 @@ struct IgemmDesc {
     // each block writes (count, mean, M2) of its tile to ln_part[(b * ln_nparts + slot) * 4]; ln_apply merges them.
     // The launcher fills ln_nparts (0 = tiles straddle samples or exceed ln_cap: not fused, run ln_stats instead).
     float* ln_part; int ln_cap; int ln_nparts;
-    int bf16;                            // transposed conv only, when the tile kernel takes the call: 1 = bf16 operands, 2 = split (two bf16 pieces)
+    int bf16;                            // transposed conv only, when the tile kernel takes the call: 1 = bf16 operands, 2 = split (two bf16 pieces),
+                                         // 3 = two FP16 pieces (fp32-grade), the weights times the power of two of wscale_part
+    const float* wscale_part;            // bf16 == 3: absmax_partials(w) (64 partial maxima at [2..65])
     // LayerNorm of the INPUT applied while it is staged (inference rollouts: the norm's own launch disappears).  x0 then is the RAW tensor
     // [B][Hin*Win][c0] (all c0 channels are normalised), in_g / in_b the norm's per-element gamma / beta ([Hin*Win][c0], the checkpoint's
     // flat order), in_part the producer's (count, mean, M2) partials [B][in_np][4].  Served by igemm_small only (igemm_in_ln_ok).
@@ -116,7 +118,8 @@ int igemm_small_with_partials(const IgemmDesc& d, hipStream_t stream, const floa
 bool igemm_in_ln_ok(const IgemmDesc& d);   // can igemm_small apply d.in_g's LayerNorm while staging x0?
 // transposed 3x3 s2 conv, all four output parities per block (csrc/deconv_tile.hip); d validated by igemm_validate
 bool deconv_tile_ok(const IgemmDesc& d);
-int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr, int prec = 0);   // 0 fp32, 1 bf16 operands, 2 split (2 bf16 pieces)
+int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr, int prec = 0);   // 0 fp32, 1 bf16 operands, 2 split (2 bf16 pieces), 3 two fp16 pieces
+int absmax_partials(const float* w, long n, float* tail, hipStream_t stream);   // 64 partial maxima of |w| into tail[2..65] (tail: 66 floats)
 // bf16-operand ConvLSTM (csrc/convlstm_bf16.hip): wb = pack_lstm_bf16 of d.w; nch: 0 auto, 16 / 32 channels per block
 size_t lstm_bf16_weight_elems(int wcin, int N);
 int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s, int Np = 0, int planes = 1, int plain = 0);   // plain: planes = 3 only (a plain conv's columns)

@@ -84,6 +84,7 @@ struct pivp_plan {
     Grads g;
     bool has_grads;
     size_t o_zero, o_lnpart, o_lnpart2, o_linpart, o_masks, o_losspart;   // o_lnpart2: enc6 reads hidden7's partials while writing its own
+    size_t o_wabs[2];                 // precision mode FP16X3: absmax_partials of the enc5 / enc6 weights (rebuilt at the start of a rollout)
     size_t o_wbf16[7];                // bf16 packs of the ConvLSTM weights (pivp_plan_set_precision), rebuilt at the start of a rollout
     int lstm_bf16 = 0;                // 1: bf16 operands in the ConvLSTM forward (precision modes BF16 and BF16X3)
     int precision = 0;                // PIVP_PRECISION_*
@@ -158,6 +159,7 @@ static void plan_layout(pivp_plan* p) {
     p->o_masks = carve((size_t)B * p->NP * HW);
     p->loss_nparts = loss_partials_count((int)(B * 3 * HW));
     p->o_losspart = carve((size_t)T * p->loss_nparts);
+    p->o_wabs[0] = carve(128); p->o_wabs[1] = carve(128);
     for (int i = 0; i < 7; ++i)       // 2-byte elements in a float-counted workspace
         p->o_wbf16[i] = carve(lstm_bf16_weight_elems(kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C) * 3 / 2 + 64);   // room for the three planes of PIVP_PRECISION_BF16X6
     p->nslabs = train ? T - 1 : 2;
@@ -477,7 +479,7 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
                        nullptr, 0, nullptr, p->bf16_all ? 1 : p->lstm_planes == 2 ? 2 : 0));
     // group 5 (TM:600): lstm6 -> hidden6 -> concat(., enc1) -> enc5 -> relu
     RC(lstm(5, ws + S.e4, 128, p->H4, p->W4));
-    const int dprec = p->bf16_all ? 1 : p->lstm_planes == 2 ? 2 : 0;
+    const int dprec = p->bf16_all ? 1 : p->lstm_planes == 2 ? 2 : p->lstm_planes == -2 ? 3 : 0;      // (-2: two fp16 pieces, fp32-grade)
     // The norms of hidden6 / hidden7 feed only enc5 / enc6, whose tile kernel applies them while it stages its patch ([hidden6 | enc1],
     // [hidden7 | enc0] as two sources).
     // Training plans take the same launch and have it WRITE the normalised hidden6 / hidden7 (each pixel by the block that owns it) and the
@@ -490,11 +492,11 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     if (fold_dec && np > 0 && fold_small((long long)B * n4) && deconv3x3s2_ln_ok(64, 32, 96, B, p->H4, p->W4)) {
         RC(run_deconv3x3s2_ln(ws + S.h[5], 64, ws + S.cat6 + 64, 32, 96, P(p, p->i_enc_w[5]), P(p, p->i_enc_b[5]), ws + S.e5, 96, 96, 1, B, p->H4, p->W4,
                               s, P(p, p->i_ln_g[6]), P(p, p->i_ln_b[6]), lnp, np, eps, nullptr, 0, nullptr, dprec,
-                              train ? ws + S.cat6 : nullptr, 96, train ? ws + S.lnstat + (size_t)6 * B * 2 : nullptr));
+                              train ? ws + S.cat6 : nullptr, 96, train ? ws + S.lnstat + (size_t)6 * B * 2 : nullptr, ws + p->o_wabs[0]));
     } else {
         RC(ln(6, ws + S.h[5], ws + S.cat6, n4, 64, 96, 0, np));
         RC(run_deconv3x3s2(ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), P(p, p->i_enc_b[5]), ws + S.e5, 96, 96, 1, B, p->H4, p->W4, s, 0,
-                           nullptr, 0, nullptr, dprec));
+                           nullptr, 0, nullptr, dprec, nullptr, ws + p->o_wabs[0]));
     }
     // group 6 (TM:601): lstm7 -> hidden7 -> concat(., enc0) -> enc6 -> norm_enc6 -> relu
     RC(lstm(6, ws + S.e5, 96, p->H2, p->W2));
@@ -504,12 +506,12 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
         const int np_in = np;
         RC(run_deconv3x3s2_ln(ws + S.h[6], 32, ws + S.cat7 + 32, 32, 64, P(p, p->i_enc_w[6]), P(p, p->i_enc_b[6]), ws + S.e6raw, 64, 64, 0, B, p->H2, p->W2,
                               s, P(p, p->i_ln_g[7]), P(p, p->i_ln_b[7]), lnp, np_in, eps, lnp2, ln_cap, &np, dprec,
-                              train ? ws + S.cat7 : nullptr, 64, train ? ws + S.lnstat + (size_t)7 * B * 2 : nullptr));
+                              train ? ws + S.cat7 : nullptr, 64, train ? ws + S.lnstat + (size_t)7 * B * 2 : nullptr, ws + p->o_wabs[1]));
         lnp = lnp2;
     } else {
         RC(ln(7, ws + S.h[6], ws + S.cat7, n2, 32, 64, 0, np));
         RC(run_deconv3x3s2(ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), P(p, p->i_enc_b[6]), ws + S.e6raw, 64, 64, 0, B, p->H2, p->W2, s, 0,
-                           lnp, ln_cap, &np, dprec));
+                           lnp, ln_cap, &np, dprec, nullptr, ws + p->o_wabs[1]));
     }
     // heads (TM:711-728).  One launch (csrc/frame_head.hip) for norm_enc6 + relu + the 1x1 heads + the motion head's finisher + flat softmax +
     // transform + compositing, behind the Linear's partial sums: bit-identical to the four launches below it, which remain for geometries
@@ -592,6 +594,10 @@ extern "C" int pivp_rollout_forward(pivp_plan_t* plan, const float* images, cons
     const pivp_config_t& c = plan->cfg;
     const int B = c.batch, T = c.seq_len, ctx = c.context_frames;
     const size_t fr = (size_t)B * 3 * c.height * c.width;
+    if (plan->lstm_planes == -2) {  // two fp16 pieces: the enc5 / enc6 weights' scales (their tile kernel splits the fp32 weights while it stages them)
+        RC(absmax_partials(P(plan, plan->i_enc_w[5]), 9L * 96 * 96, plan->ws + plan->o_wabs[0], s));
+        RC(absmax_partials(P(plan, plan->i_enc_w[6]), 9L * 64 * 64, plan->ws + plan->o_wabs[1], s));
+    }
     if (plan->lstm_bf16)            // the parameters may have changed since the last call (optimizer step, checkpoint load)
         for (int i = 0; i < 7; ++i)
             RC(pack_lstm_bf16(P(plan, plan->i_lstm_w[i]), reinterpret_cast<unsigned short*>(plan->ws + plan->o_wbf16[i]),

@@ -164,6 +164,12 @@ def deconv3x3s2(x, W, b, relu, bf16=False):
     cout = W.shape[1]
     xd, wd, bd = nhwc(x), _t(pivp_amd.to_internal('enc4/W', W)), _t(b)
     out = torch.empty((B, 2 * H, 2 * Wd, cout), dtype=torch.float32, device=DEV)
+    if bf16 == 'fp16x3':            # two fp16 pieces per operand (fp32-grade)
+        scratch = torch.zeros(128, dtype=torch.float32, device=DEV)
+        _lib.check(lib.pivp_deconv3x3s2_fp16x3(xd.data_ptr(), cin, cin, wd.data_ptr(), bd.data_ptr(), out.data_ptr(), cout, cout,
+                                               int(relu), B, H, Wd, scratch.data_ptr(), stream()), 'deconv3x3s2_fp16x3')
+        torch.cuda.synchronize()
+        return nchw(out, B, 2 * H, 2 * Wd, cout)
     fn = lib.pivp_deconv3x3s2_bf16x3 if bf16 == 3 else lib.pivp_deconv3x3s2_bf16 if bf16 else lib.pivp_deconv3x3s2
     _lib.check(fn(xd.data_ptr(), cin, cin, wd.data_ptr(), bd.data_ptr(), out.data_ptr(), cout, cout,
                   int(relu), B, H, Wd, stream()), 'deconv3x3s2')

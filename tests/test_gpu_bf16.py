@@ -499,6 +499,20 @@ def test_train_step_in_bf16x3_mode_matches_fp32_gradients():
     assert abs(outs['bf16x3'][0] - outs['fp32'][0]) < 1e-5 and rel < 1e-3
 
 
+@pytest.mark.parametrize('wscale', [1.0, 1e-3, 300.0])
+@pytest.mark.parametrize('B,cin,cout,H', [(2, 64, 64, 32), (4, 96, 96, 16), (1, 32, 32, 64)])
+def test_deconv3x3s2_fp16x3_is_fp32_grade(ops, B, cin, cout, H, wscale):
+    # enc5 / enc6 in the fp16x3 mode: two fp16 pieces per operand, the weights' scale from their absolute maximum (tiny and large weights alike)
+    rs = np.random.RandomState(cin + H + 3)
+    x = rs.randn(B, cin, H, H).astype(np.float32).astype(np.float64)
+    W = (wscale * rs.randn(cin, cout, 3, 3) / np.sqrt(9 * cin)).astype(np.float32).astype(np.float64); b = (rs.randn(cout) * 0.1).astype(np.float32).astype(np.float64)
+    ref = R.relu(R.deconv2d(x, W, b, 2, 1, (2 * H, 2 * H)))
+    e3 = ops.deconv3x3s2(x, W, b, True, bf16='fp16x3') - ref; ef = ops.deconv3x3s2(x, W, b, True) - ref
+    print('deconv %d->%d @%d (weights x %g): two fp16 pieces max |err| %.2e rms %.2e; fp32 kernel %.2e / %.2e'
+          % (cin, cout, H, wscale, np.abs(e3).max(), np.sqrt((e3 ** 2).mean()), np.abs(ef).max(), np.sqrt((ef ** 2).mean())))
+    assert np.sqrt((e3 ** 2).mean()) < 1.5 * np.sqrt((ef ** 2).mean()) and np.abs(e3).max() < 2.5 * np.abs(ef).max()
+
+
 @pytest.mark.parametrize('B,cin,cout,H', [(2, 64, 64, 32), (4, 96, 96, 16)])
 def test_deconv3x3s2_bf16x3(ops, B, cin, cout, H):
     rs = np.random.RandomState(cin + H + 1)
