@@ -118,12 +118,15 @@ __device__ __forceinline__ unsigned pack2h_rest(float& a, float& b) {
     return __builtin_bit_cast(unsigned, h);
 }
 // fp16 pieces: the weights are packed times a power of two chosen per tensor so that the largest lands in [2^14, 2^15) -- the second piece of any
-// weight down to 2^-18 of the largest is then a normal fp16 number.  The pack's tail (X3_TAIL 2-byte elements behind the fragments) holds the scale
+// weight down to 2^-18 of the largest is then a normal fp16 number.  The pack's tail (256 2-byte elements behind the fragments) holds the scale
 // (float 0) and the 64 partial maxima it was taken from (floats 2..65).
-constexpr int X3_TAIL = 256;
 __global__ __launch_bounds__(256) void absmax_partials_kernel(const float* __restrict__ w, long n, float* __restrict__ tail) {
     float m = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += 64L * 256) m = __builtin_fmaxf(m, __builtin_fabsf(w[i]));
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(w);               // (n is a multiple of 32: K-inner packed weights)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (n >> 2); i += 64L * 256) {
+        const f32x4 v = w4[i];
+        m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
     __shared__ float red[4];
@@ -182,8 +185,12 @@ constexpr int X6_CHUNK = 3 * 2 * 1024;      // ring slot of the 16-channel-block
 // plain = 1: the same pack for a plain 5x5 convolution (the data gradient): fragment c8 = the 32 consecutive output columns c8 * 32 .. + 32 of the
 // Np padded ones (rows past N zero)
 // pieces = 2: TWO FP16 pieces of s w (hi = fp16, lo = fp16(s w - hi)), s = the tensor's power-of-two scale (absmax_partials_kernel ran before)
-__global__ void pack_lstm_x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int N, int Np, int plain, int pieces, long total) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// One thread = the 8 consecutive input channels of one (fragment, lane) -- 32 contiguous bytes of the fp32 pack -- and ALL the pieces' planes of
+// them: two 16-B loads, `pieces` 16-B stores, one index decode per 8 * pieces output elements (the first version decoded per element: 20 us per
+// layer and rollout, 3 % of an fp16x3 rollout).  nthreads = lstm_bf16_weight_elems / 8.
+__global__ void pack_lstm_x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int N, int Np, int plain, int pieces, long nthreads) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = nthreads * 8 * pieces;
     float wscale = 1.0f;
     if (pieces == 2) {
         __shared__ float sc;
@@ -194,31 +201,47 @@ __global__ void pack_lstm_x6_kernel(const float* __restrict__ w, unsigned short*
         __syncthreads();
         wscale = sc;
     }
-    if (i >= total) return;
-    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
-    long r = i >> 9;
+    if (j >= nthreads) return;
+    const int lane = (int)(j & 63);
+    long r = j >> 6;
     const int n8 = Np / 32, C = N / 4;
     const int c8 = (int)(r % n8); r /= n8;
-    const int pl = (int)(r % pieces); r /= pieces;
     const int ks = (int)(r & 3); r >>= 2;
     const int tap = (int)(r % 25);
     const int cg = (int)(r / 25);
     const int half = lane >> 5, l31 = lane & 31;
     const int n = plain ? c8 * 32 + l31 : (l31 >> 3) * C + c8 * 8 + (l31 & 7);
-    const int ch = cg * 64 + ks * 16 + half * 8 + e;
-    float v = 0.f;
-    if (ch < wcin && n < N) v = w[(((long)tap * (wcin >> 5) + (ch >> 5)) * N + n) * 32 + (ch & 31)];
+    const int ch = cg * 64 + ks * 16 + half * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (ch < wcin && n < N) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(w + (((long)tap * (wcin >> 5) + (ch >> 5)) * N + n) * 32 + (ch & 31));
+        const f32x4 a = src[0], b = src[1];
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
+    const long frag0 = (((long)(cg * 25 + tap) * 4 + ks) * pieces) * n8 + c8;       // plane pl: + pl * n8
+    unsigned short* dst = wb + frag0 * 512 + lane * 8;
     if (pieces == 2) {
-        v = __builtin_fminf(__builtin_fmaxf(v * wscale, -65504.f), 65504.f);
-        _Float16 hh = (_Float16)v;
-        if (pl == 1) { v -= (float)hh; hh = (_Float16)v; }
-        wb[i] = __builtin_bit_cast(unsigned short, hh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= wscale;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            uint4 o;
+            o.x = pivp_pack2h_rest(v[0], v[1]); o.y = pivp_pack2h_rest(v[2], v[3]); o.z = pivp_pack2h_rest(v[4], v[5]); o.w = pivp_pack2h_rest(v[6], v[7]);
+            *reinterpret_cast<uint4*>(dst + (long)pl * n8 * 512) = o;
+        }
         return;
     }
-    __bf16 h = (__bf16)v;
-    if (pl >= 1) { v -= (float)h; h = (__bf16)v; }
-    if (pl == 2) { v -= (float)h; h = (__bf16)v; }
-    wb[i] = __builtin_bit_cast(unsigned short, h);
+    for (int pl = 0; pl < pieces; ++pl) {
+        uint4 o;
+        unsigned* ow = reinterpret_cast<unsigned*>(&o);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned p2 = pack2(v[2 * q], v[2 * q + 1]);
+            ow[q] = p2;
+            v[2 * q] -= __builtin_bit_cast(float, p2 << 16); v[2 * q + 1] -= __builtin_bit_cast(float, p2 & 0xffff0000u);
+        }
+        *reinterpret_cast<uint4*>(dst + (long)pl * n8 * 512) = o;
+    }
 }
 
 #ifdef PIVP_BF16_STAMPS   // in-kernel phase stamps of every block's wave 0, constant-rate 100 MHz counter (scripts/bf16_stamps.py)
@@ -1392,7 +1415,8 @@ int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStrea
         hipLaunchKernelGGL(absmax_partials_kernel, dim3(64), dim3(256), 0, s, w, (long)25 * wcin * N, reinterpret_cast<float*>(wb + total));
     if (planes == 3 || planes == -2) {       // the three-piece kernels' fragment-major pack: the cell's (N = 4 C, gate-interleaved fragments) or a plain conv's
         PIVP_CHECK_ARG(Np % 64 == 0 && (plain || (Np == N && N % 32 == 0)));
-        hipLaunchKernelGGL(pack_lstm_x6_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, plain, pieces, total);
+        const long nthreads = (long)lstm_bf16_weight_elems(wcin, Np) / 8;
+        hipLaunchKernelGGL(pack_lstm_x6_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, plain, pieces, nthreads);
         return PIVP_LAUNCH_STATUS();
     }
     hipLaunchKernelGGL(pack_lstm_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, planes, total);
