@@ -513,7 +513,7 @@ def roofline_pass(args, model, step, elapsed, np, torch, precision=None):
     layers = list(range(7))
     if precision in ('bf16x6', 'fp16x3'):      # layers on maps that are not a multiple of 16 wide run the fp32 kernel in this mode: not part of its fraction
         widths = [args.size // 2, args.size // 2, args.size // 4, args.size // 4, args.size // 8, args.size // 4, args.size // 2]
-        layers = [i for i in range(7) if widths[i] % 16 == 0]
+        layers = [i for i in range(7) if widths[i] % 16 == 0 or (precision == 'fp16x3' and widths[i] % 8 == 0 and args.batch % 2 == 0)]     # (fp16 pieces: 8-wide maps too)
     total_flops = float(flops[layers].sum())
     total_s = float(ms_tot[layers].sum()) * 1e-3
     achieved = total_flops / total_s / 1e12

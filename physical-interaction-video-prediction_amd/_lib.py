@@ -69,7 +69,7 @@ SIGNATURES = {
     'pivp_pack_lstm_bf16x3': (_i, [_vp, _vp, _i, _i, _vp]),
     'pivp_convlstm_bf16x3': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'pivp_pack_lstm_bf16x6': (_i, [_vp, _vp, _i, _i, _vp]),
-    'pivp_pack_lstm_fp16x3': (_i, [_vp, _vp, _i, _i, _vp]),
+    'pivp_pack_lstm_fp16x3': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'pivp_convlstm_fp16x3': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'pivp_convlstm_bf16x6': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'pivp_deconv3x3s2_bf16x3': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

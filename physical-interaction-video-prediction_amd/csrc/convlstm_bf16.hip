@@ -152,8 +152,20 @@ __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x
 // fp32 K-inner packed weights [25][wcin/32][N][32] -> bf16 [ceil(wcin/64)][25][PL][Np][64], channels past wcin and rows past N zero.
 // PL = 1: plane 0 = bf16(w).  PL = 2 (split mode): plane 0 = hi = bf16(w), plane 1 = lo = bf16(w - hi).  PL = 3 (three pieces): plane 1 =
 // mid = bf16(w - hi), plane 2 = lo = bf16((w - hi) - mid); both differences are exact in fp32, so hi + mid + lo = w.
-__global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int N, int Np, int PL, long total) {
+// fp16 = 1 (PL = 2): the two planes are FP16 pieces of s w, s = the tensor's power-of-two scale from the partial maxima absmax_partials_kernel left
+// in the pack's tail (the ring kernel's form of the fp16x3 mode: the layers on 8-wide maps)
+__global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int N, int Np, int PL, long total, int fp16) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float wscale = 1.0f;
+    if (fp16) {
+        __shared__ float sc;
+        if (threadIdx.x == 0) {
+            sc = x3_scale_of(reinterpret_cast<const float*>(wb + total));
+            if (blockIdx.x == 0) reinterpret_cast<float*>(wb + total)[0] = sc;
+        }
+        __syncthreads();
+        wscale = sc;
+    }
     if (i >= total) return;
     const int c64 = (int)(i & 63);
     long r = i >> 6;
@@ -164,6 +176,13 @@ __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned shor
     const int ch = cg * 64 + c64;
     float v = 0.f;
     if (ch < wcin && n < N) v = w[(((long)tap * (wcin >> 5) + (ch >> 5)) * N + n) * 32 + (ch & 31)];
+    if (fp16) {
+        v = __builtin_fminf(__builtin_fmaxf(v * wscale, -65504.f), 65504.f);
+        _Float16 hh = (_Float16)v;
+        if (pl == 1) { v -= (float)hh; hh = (_Float16)v; }
+        wb[i] = __builtin_bit_cast(unsigned short, hh);
+        return;
+    }
     __bf16 h = (__bf16)v;
     if (pl >= 1) { v -= (float)h; h = (__bf16)v; }
     if (pl == 2) { v -= (float)h; h = (__bf16)v; }
@@ -266,8 +285,11 @@ __device__ long long pivp_bf16_stamps[2048 * 8];
 // slots' worth of LDS, organised as EIGHT 6-KB slots of one k-step each (KST schedule below): with whole taps in two slots the loop ran at
 // the latency of one LDS-DMA per tap (1.2 us for 0.64 of MFMA); a barrier per k-step frees a slot four times per tap, so the DMAs run seven
 // k-steps = 1.1 us of MFMA time ahead in the same 48 KB.
-template <int NCH, bool LSTM, int PL = 1>
+// F16 (PL = 2, LSTM): the two planes are FP16 pieces (the weights times the power of two in the pack's tail, the sums scaled back): the fp16x3
+// mode's cell on maps this kernel's 8 x 8 tiles serve and the L2-direct kernel's 16-wide ones do not.
+template <int NCH, bool LSTM, int PL = 1, bool F16 = false>
 __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int tw, int ncols) {
+    static_assert(!F16 || (PL == 2 && LSTM), "fp16 pieces: the split form of the cell");
     constexpr int BN = 4 * NCH;                 // block columns: [gate][channel]
     constexpr int PLANE = BN * 128;             // one weight plane of a ring slot: BN rows x 64 bf16
     constexpr int SLOT = PL * PLANE;            // bytes of one ring slot
@@ -358,6 +380,15 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         for (int j = 0; j < NPJ; ++j) {
             // unconditional (pixels past npix write their zeros into the padding behind row 0, which nobody reads): a predicated write
             // leaves the loads "pending" on the skipped path for hipcc's wait-count pass, which then drains vmcnt inside the tap loop
+            if constexpr (F16) {
+                float r[8] = {plo[j][0], plo[j][1], plo[j][2], plo[j][3], phi[j][0], phi[j][1], phi[j][2], phi[j][3]};
+                uint4 hh, ll;
+                hh.x = pivp_pack2h_rest(r[0], r[1]); hh.y = pivp_pack2h_rest(r[2], r[3]); hh.z = pivp_pack2h_rest(r[4], r[5]); hh.w = pivp_pack2h_rest(r[6], r[7]);
+                ll.x = pivp_pack2h_rest(r[0], r[1]); ll.y = pivp_pack2h_rest(r[2], r[3]); ll.z = pivp_pack2h_rest(r[4], r[5]); ll.w = pivp_pack2h_rest(r[6], r[7]);
+                *reinterpret_cast<uint4*>(patch + a_lds[j] + cpiece * 16) = hh;
+                *reinterpret_cast<uint4*>(patch + PB + a_lds[j] + cpiece * 16) = ll;
+                continue;
+            }
             uint4 v;
             v.x = pack2(plo[j][0], plo[j][1]); v.y = pack2(plo[j][2], plo[j][3]);
             v.z = pack2(phi[j][0], phi[j][1]); v.w = pack2(phi[j][2], phi[j][3]);
@@ -565,8 +596,8 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     bf16x8 fa[2][2], fb[2][TPW];                       // [register set][tile]
     bf16x8 fal[2][2], fbl[2][TPW];                     // ... and their second planes (split modes)
     bf16x8 fa3[2][2], fb3[2][TPW];                     // ... and their third planes (PL = 3)
-    f32x16 accl[2][TPW];                               // PL = 3: the five correction products' accumulator
-    if constexpr (PL == 3) {
+    f32x16 accl[2][TPW];                               // PL = 3: the five correction products' accumulator; F16: the two cross terms'
+    if constexpr (PL == 3 || F16) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -642,6 +673,15 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
+                if constexpr (F16) {
+                    auto h = [](const bf16x8& v) { return __builtin_bit_cast(pivp_f16x8, v); };
+                    // (the cross terms on their own accumulator: on ONE the three roundings per k-step over K = 4800 measured 1.56 x the fp32
+                    // kernel's rms error, with two it is at the L2-direct form's 0.95 x)
+                    accl[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fal[st][mt]), h(fb[st][t]), accl[mt][t], 0, 0, 0);
+                    accl[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[st][mt]), h(fbl[st][t]), accl[mt][t], 0, 0, 0);
+                    acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[st][mt]), h(fb[st][t]), acc[mt][t], 0, 0, 0);
+                    continue;
+                }
                 if constexpr (PL == 2) {               // the two cross terms first, the leading term last
                     acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[st][mt], fb[st][t], acc[mt][t], 0, 0, 0);
                     acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], fbl[st][t], acc[mt][t], 0, 0, 0);
@@ -819,6 +859,15 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
             for (int t = 0; t < TPW; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][t][r] += accl[mt][t][r];
+    }
+    if constexpr (F16) {           // the weights were packed times a power of two (the pack's tail, behind its [groups][25][2][N][64] elements)
+        const float inv = 1.0f / *reinterpret_cast<const float*>(wb + (size_t)((d.wcin + 63) >> 6) * 25 * 2 * N * 64);      // (d.wcin: the pack's channels, also at t = 0)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][t][r] = (acc[mt][t][r] + accl[mt][t][r]) * inv;
     }
 
     if constexpr (!LSTM) {
@@ -1411,6 +1460,11 @@ int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStrea
     PIVP_CHECK_ARG(w && wb && wcin > 0 && wcin % 32 == 0 && N > 0 && Np >= N && ((planes >= 1 && planes <= 3) || planes == -2));
     const int pieces = planes == -2 ? 2 : planes;
     const long total = (long)lstm_bf16_weight_elems(wcin, Np) * pieces;
+    if (planes == -2 && plain == 2) {     // two fp16 pieces in the RING kernel's layout (layers on 8-wide maps: convlstm_bf16_kernel<NCH, true, 2, true>)
+        hipLaunchKernelGGL(absmax_partials_kernel, dim3(64), dim3(256), 0, s, w, (long)25 * wcin * N, reinterpret_cast<float*>(wb + total));
+        hipLaunchKernelGGL(pack_lstm_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, 2, total, 1);
+        return PIVP_LAUNCH_STATUS();
+    }
     if (planes == -2)        // the tensor's scale first: 64 partial maxima into the pack's tail
         hipLaunchKernelGGL(absmax_partials_kernel, dim3(64), dim3(256), 0, s, w, (long)25 * wcin * N, reinterpret_cast<float*>(wb + total));
     if (planes == 3 || planes == -2) {       // the three-piece kernels' fragment-major pack: the cell's (N = 4 C, gate-interleaved fragments) or a plain conv's
@@ -1419,7 +1473,7 @@ int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStrea
         hipLaunchKernelGGL(pack_lstm_x6_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, plain, pieces, nthreads);
         return PIVP_LAUNCH_STATUS();
     }
-    hipLaunchKernelGGL(pack_lstm_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, planes, total);
+    hipLaunchKernelGGL(pack_lstm_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, planes, total, 0);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -1432,11 +1486,11 @@ static bool bf16_geometry_ok(const IgemmDesc& d) {
 bool convlstm_bf16_ok(const IgemmDesc& d) { return bf16_geometry_ok(d) && d.C > 0 && d.C % 16 == 0; }
 bool convlstm_bf16x6_ok(const IgemmDesc& d) { return convlstm_bf16_ok(d) && d.Win % 16 == 0; }
 
-template <int NCH, bool LSTM, int PL = 1>
+template <int NCH, bool LSTM, int PL = 1, bool F16 = false>
 static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nb, int ksplit, int ncols) {
     constexpr int lds_bytes = PL * patch_plane_bytes<PL>() + (PL == 3 ? 8 * X6_CHUNK : (ring_depth<NCH, PL>() + 1) * PL * 4 * NCH * 128);
     static PerDeviceOnce once;
-    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_bf16_kernel<NCH, LSTM, PL>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_bf16_kernel<NCH, LSTM, PL, F16>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     IgemmDesc dd = d;
     const int tw = d.Win % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
     const int tpi = (d.Hin / TH) * (d.Win / tw);
@@ -1445,7 +1499,7 @@ static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
     const int blocks = (d.B / ti_n) * tpi * nb;
-    hipLaunchKernelGGL((convlstm_bf16_kernel<NCH, LSTM, PL>), dim3(blocks, ksplit), dim3(512), lds_bytes, stream, dd, wb, tw, ncols);
+    hipLaunchKernelGGL((convlstm_bf16_kernel<NCH, LSTM, PL, F16>), dim3(blocks, ksplit), dim3(512), lds_bytes, stream, dd, wb, tw, ncols);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -1482,6 +1536,12 @@ static int launch_x6g_plain(const IgemmDesc& dd, const unsigned short* wb, hipSt
 int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nch, int planes) {
     PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0) || ((nch == 1 || nch == 2) && planes == 3)) &&
                    ((planes >= 1 && planes <= 3) || planes == -2));
+    if (planes == -2 && !convlstm_bf16x6_ok(d)) {   // 8-wide maps: the ring kernel with fp16 pieces (wb = pack_lstm_bf16(..., planes = -2, plain = 2))
+        const int tw2 = 8, ti2 = 2;
+        const long b32 = d.C % 32 ? 0 : (long)(d.B / ti2) * (d.Hin / TH) * (d.Win / tw2) * (d.C / 32);
+        (void)tw2; (void)ti2; (void)b32;      // 16-channel blocks only: with the second accumulator a 32-channel block would need 286 registers
+        return launch_bf16<16, true, 2, true>(d, wb, stream, ln_nparts, d.C / 16, 1, 0);
+    }
     if (planes == -2) {   // two fp16 pieces, three MFMAs per product (wb = pack_lstm_bf16(..., planes = -2)): the L2-direct kernel, 16-wide tiles
         PIVP_CHECK_ARG(convlstm_bf16x6_ok(d));
         const long b32 = d.C % 32 ? 0 : (long)d.B * (d.Hin / TH) * (d.Win / 16) * (d.C / 32);

@@ -41,7 +41,8 @@ int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, co
     d.ln_part = ln_part; d.ln_cap = ln_cap;
     // w_bf16: the bf16 pack of w (pack_lstm_bf16) selects the bf16-operand kernel; variant then is its channels per block
     // (three pieces: maps the three-plane tile does not serve -- 8 wide -- take the fp32 kernel, which is what that mode stands in for)
-    if (w_bf16 && (bf16_planes == 3 || bf16_planes == -2) && !convlstm_bf16x6_ok(d)) return w ? igemm_lstm(d, s, 0, ln_nparts) : PIVP_ERR_BADARG;
+    // (two fp16 pieces: 8-wide maps take the ring kernel's fp16 form when its tiles fit -- an even batch --, whose pack is laid out differently: the caller's)
+    if (w_bf16 && !convlstm_bf16x6_ok(d) && (bf16_planes == 3 || (bf16_planes == -2 && !convlstm_bf16_ok(d)))) return w ? igemm_lstm(d, s, 0, ln_nparts) : PIVP_ERR_BADARG;
     if (w_bf16) return convlstm_bf16(d, w_bf16, s, ln_nparts, ((bf16_planes == 3 && variant != 1 && variant != 2 && variant != 16 && variant != 32) ||
                                                         (bf16_planes == -2 && variant != 16 && variant != 32)) ? 0 : variant, bf16_planes);
     return igemm_lstm(d, s, variant, ln_nparts);
@@ -492,9 +493,10 @@ extern "C" int pivp_convlstm_bf16x6(const float* x, int cx, int ldx, const float
     return run_convlstm(x, cx, ldx, h_prev, C, nullptr, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, nch, gates_out,
                         ln_part, ln_cap, ln_nparts, (const unsigned short*)w_bf16, 3);
 }
-extern "C" int pivp_pack_lstm_fp16x3(const float* w, void* w_bf16, int cin_total, int C, void* stream) {
-    if (C <= 0) return PIVP_ERR_BADARG;
-    return pack_lstm_bf16(w, (unsigned short*)w_bf16, cin_total, 4 * C, (hipStream_t)stream, 0, -2);
+extern "C" int pivp_pack_lstm_fp16x3(const float* w, void* w_bf16, int cin_total, int C, int map_width, void* stream) {
+    if (C <= 0 || map_width <= 0) return PIVP_ERR_BADARG;
+    // (maps that are a multiple of 16 wide: fragment-major, for the L2-direct kernel; 8-wide ones: the ring kernel's layout)
+    return pack_lstm_bf16(w, (unsigned short*)w_bf16, cin_total, 4 * C, (hipStream_t)stream, 0, -2, map_width % 16 ? 2 : 0);
 }
 extern "C" int pivp_convlstm_fp16x3(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
                                     const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,

@@ -342,6 +342,7 @@ extern "C" int pivp_plan_set_precision(pivp_plan_t* plan, int precision) {
     if (!plan->ws) plan_layout(plan);      // the dG rings' depth follows the precision; a bound workspace keeps the layout it was sized for
     return PIVP_OK;
 }
+static int lstm_w_of(const pivp_plan_t* p, int i) { const int ws[7] = {p->W2, p->W2, p->W4, p->W4, p->W8, p->W4, p->W2}; return ws[i]; }
 extern "C" int pivp_plan_get_precision(const pivp_plan_t* plan) { return plan ? plan->precision : PIVP_ERR_BADARG; }
 extern "C" long long pivp_plan_workspace_bytes(const pivp_plan_t* plan) { return plan ? plan->ws_floats * 4 : PIVP_ERR_BADARG; }
 extern "C" int pivp_plan_set_workspace(pivp_plan_t* plan, void* dptr, long long bytes) {
@@ -601,7 +602,8 @@ extern "C" int pivp_rollout_forward(pivp_plan_t* plan, const float* images, cons
     if (plan->lstm_bf16)            // the parameters may have changed since the last call (optimizer step, checkpoint load)
         for (int i = 0; i < 7; ++i)
             RC(pack_lstm_bf16(P(plan, plan->i_lstm_w[i]), reinterpret_cast<unsigned short*>(plan->ws + plan->o_wbf16[i]),
-                              kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C, s, 0, plan->lstm_planes));
+                              kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C, s, 0, plan->lstm_planes,
+                              (plan->lstm_planes == -2 && lstm_w_of(plan, i) % 16) ? 2 : 0));      // (fp16 pieces on an 8-wide map: the ring kernel's layout)
     for (int t = 0; t < T - 1; ++t) {
         if (t >= ctx && gt_select)                                     // TM:667-670
             RC(run_select_frames(images + t * fr, gen_images + (t - 1) * fr, gt_select + (size_t)t * B,

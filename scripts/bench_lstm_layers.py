@@ -41,10 +41,13 @@ for name, cx, C, H in LAYERS:
     co = torch.empty_like(c); ho = torch.empty_like(h)
     wb = None
     if BF16:
-        if (X6 or H3) and H % 16:
+        if X6 and H % 16:
             continue                      # (8-wide maps are not the three-piece kernel's)
         wb = torch.empty((3 if X6 else 2 if (X3 or H3) else 1) * lib.pivp_lstm_bf16_weight_elems(cx + C, C) + 256, dtype=torch.int16, device=dev)
-        assert (lib.pivp_pack_lstm_fp16x3 if H3 else lib.pivp_pack_lstm_bf16x6 if X6 else lib.pivp_pack_lstm_bf16x3 if X3 else lib.pivp_pack_lstm_bf16)(w.data_ptr(), wb.data_ptr(), cx + C, C, st) == 0
+        if H3:
+            assert lib.pivp_pack_lstm_fp16x3(w.data_ptr(), wb.data_ptr(), cx + C, C, H, st) == 0
+        else:
+            assert (lib.pivp_pack_lstm_bf16x6 if X6 else lib.pivp_pack_lstm_bf16x3 if X3 else lib.pivp_pack_lstm_bf16)(w.data_ptr(), wb.data_ptr(), cx + C, C, st) == 0
     bufs[name] = (x, h, c, w, b, co, ho, cx, C, H, wb)
 
 def launch(name):

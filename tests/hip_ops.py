@@ -117,7 +117,7 @@ def convlstm_fp16x3(x, h, c, W, b, h_is_zero=False, nch=0):
     xd, hd, cd = nhwc(x), nhwc(h), nhwc(c)
     wd, bd = _t(pivp_amd.to_internal('lstm1/conv/W', W)), _t(b)
     wb = torch.empty(2 * lib.pivp_lstm_bf16_weight_elems(cx + C, C) + 256, dtype=torch.int16, device=DEV)     # + the scale's tail
-    _lib.check(lib.pivp_pack_lstm_fp16x3(wd.data_ptr(), wb.data_ptr(), cx + C, C, stream()), 'pack_lstm_fp16x3')
+    _lib.check(lib.pivp_pack_lstm_fp16x3(wd.data_ptr(), wb.data_ptr(), cx + C, C, Wd, stream()), 'pack_lstm_fp16x3')
     c_out = torch.empty_like(cd); h_out = torch.empty_like(hd)
     _lib.check(lib.pivp_convlstm_fp16x3(xd.data_ptr(), cx, cx, None if h_is_zero else hd.data_ptr(), C, wb.data_ptr(), bd.data_ptr(),
                                         cd.data_ptr(), c_out.data_ptr(), h_out.data_ptr(), None, None, 0, None, B, H, Wd, nch, stream()),
