@@ -40,7 +40,7 @@ extern "C" {
 #define PIVP_PRECISION_BF16X6 3
 #define PIVP_PRECISION_FP16X3 4
 
-int pivp_abi_version(void);   /* 10 (10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3, pivp_deconv3x3s2_fp16x3; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+int pivp_abi_version(void);   /* 10 (10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3, pivp_deconv3x3s2_fp16x3, pivp_plan_set_pack_cache, pivp_plan_params_changed; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
                                  5: + bf16 ConvLSTM, pivp_plan_set_precision, 6: + pivp_plan_set_group_join / pivp_plan_group_wait) */
 
 /* sha256 (hex) of the sources this library was compiled from (every .hip and .h under csrc/, and this header), embedded by build.py.  The Python
@@ -93,6 +93,11 @@ int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr);
  * PIVP_PRECISION_BF16X6's (gradients do not fit fp16's exponent range).  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
 int pivp_plan_set_precision(pivp_plan_t* plan, int precision);
 int pivp_plan_get_precision(const pivp_plan_t* plan);
+/* The precision modes re-pack the ConvLSTM weights (bf16 / split pieces) at the start of every rollout, because the parameters may have changed.  With
+ * constant weights (serving) pivp_plan_set_pack_cache(plan, 1) keeps the packs; the caller then calls pivp_plan_params_changed after EVERY modification of a
+ * parameter tensor.  The Python Model does both by itself (torch's in-place version counter + its own optimizer steps). */
+int pivp_plan_set_pack_cache(pivp_plan_t* plan, int on);
+int pivp_plan_params_changed(pivp_plan_t* plan);
 
 long long pivp_plan_workspace_bytes(const pivp_plan_t* plan);
 int pivp_plan_set_workspace(pivp_plan_t* plan, void* dptr, long long bytes);

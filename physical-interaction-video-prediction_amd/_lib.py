@@ -59,6 +59,8 @@ SIGNATURES = {
     'pivp_convlstm_ln': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
     'pivp_plan_set_precision': (_i, [_vp, _i]),
     'pivp_plan_get_precision': (_i, [_vp]),
+    'pivp_plan_set_pack_cache': (_i, [_vp, _i]),
+    'pivp_plan_params_changed': (_i, [_vp]),
     'pivp_lstm_bf16_weight_elems': (_ll, [_i, _i]),
     'pivp_pack_lstm_bf16': (_i, [_vp, _vp, _i, _i, _vp]),
     'pivp_convlstm_bf16': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),

@@ -88,6 +88,7 @@ struct pivp_plan {
     size_t o_wbf16[7];                // bf16 packs of the ConvLSTM weights (pivp_plan_set_precision), rebuilt at the start of a rollout
     int lstm_bf16 = 0;                // 1: bf16 operands in the ConvLSTM forward (precision modes BF16 and BF16X3)
     int precision = 0;                // PIVP_PRECISION_*
+    int pack_cache = 0, packs_valid = 0;   // pivp_plan_set_pack_cache: keep the precision modes' weight packs across rollouts until pivp_plan_params_changed
     int bwd_planes = 1;               // the data gradients' form of lstm_planes
     int lstm_planes = 1;              // 2: split mode (hi / lo planes, three MFMAs per product); 3: three pieces, six MFMAs (forward gate convs only: the
                                       // backward sweep and every other op of that mode are the fp32 ones)
@@ -299,6 +300,7 @@ extern "C" long long pivp_param_numel(const pivp_plan_t* plan, int idx) {
 extern "C" int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr) {
     if (!plan || idx < 0 || idx >= (int)plan->params.size() || !dptr) return PIVP_ERR_BADARG;
     plan->params[idx].ptr = dptr;
+    plan->packs_valid = 0;
     return PIVP_OK;
 }
 extern "C" int pivp_param_group(const pivp_plan_t* plan, int idx) {
@@ -339,7 +341,21 @@ extern "C" int pivp_plan_set_precision(pivp_plan_t* plan, int precision) {
     plan->bwd_planes = plan->lstm_planes == -2 ? 3 : plan->lstm_planes;      // (fp16 pieces: forward only; its sweep is the three-bf16-piece one)
     plan->bf16_all = precision == PIVP_PRECISION_BF16;
     plan->precision = precision;
+    plan->packs_valid = 0;
     if (!plan->ws) plan_layout(plan);      // the dG rings' depth follows the precision; a bound workspace keeps the layout it was sized for
+    return PIVP_OK;
+}
+// Inference with constant weights: keep the bf16 / fp16 weight packs across rollouts (on = 1) instead of rebuilding them at the start of each.  The
+// caller then owes pivp_plan_params_changed after EVERY modification of a parameter tensor (optimizer step, checkpoint load, host write); set_param,
+// set_precision and set_workspace invalidate by themselves.  Default off.
+extern "C" int pivp_plan_set_pack_cache(pivp_plan_t* plan, int on) {
+    if (!plan) return PIVP_ERR_BADARG;
+    plan->pack_cache = on ? 1 : 0; plan->packs_valid = 0;
+    return PIVP_OK;
+}
+extern "C" int pivp_plan_params_changed(pivp_plan_t* plan) {
+    if (!plan) return PIVP_ERR_BADARG;
+    plan->packs_valid = 0;
     return PIVP_OK;
 }
 static int lstm_w_of(const pivp_plan_t* p, int i) { const int ws[7] = {p->W2, p->W2, p->W4, p->W4, p->W8, p->W4, p->W2}; return ws[i]; }
@@ -348,6 +364,7 @@ extern "C" long long pivp_plan_workspace_bytes(const pivp_plan_t* plan) { return
 extern "C" int pivp_plan_set_workspace(pivp_plan_t* plan, void* dptr, long long bytes) {
     if (!plan || !dptr || bytes < plan->ws_floats * 4 || ((uintptr_t)dptr & 255)) return PIVP_ERR_BADARG;
     plan->ws = (float*)dptr;
+    plan->packs_valid = 0;
     return PIVP_OK;
 }
 extern "C" int pivp_reset_state(pivp_plan_t* plan, void* stream) {
@@ -595,15 +612,19 @@ extern "C" int pivp_rollout_forward(pivp_plan_t* plan, const float* images, cons
     const pivp_config_t& c = plan->cfg;
     const int B = c.batch, T = c.seq_len, ctx = c.context_frames;
     const size_t fr = (size_t)B * 3 * c.height * c.width;
-    if (plan->lstm_planes == -2) {  // two fp16 pieces: the enc5 / enc6 weights' scales (their tile kernel splits the fp32 weights while it stages them)
+    // The precision modes' weight packs: rebuilt at the start of every rollout (the parameters may have changed since the last call: optimizer step,
+    // checkpoint load) unless the caller keeps them -- pivp_plan_set_pack_cache(plan, 1) -- and reports every change with pivp_plan_params_changed.
+    const bool repack = !(plan->pack_cache && plan->packs_valid);
+    if (repack && plan->lstm_planes == -2) {  // two fp16 pieces: the enc5 / enc6 weights' scales (their tile kernel splits the fp32 weights while it stages them)
         RC(absmax_partials(P(plan, plan->i_enc_w[5]), 9L * 96 * 96, plan->ws + plan->o_wabs[0], s));
         RC(absmax_partials(P(plan, plan->i_enc_w[6]), 9L * 64 * 64, plan->ws + plan->o_wabs[1], s));
     }
-    if (plan->lstm_bf16)            // the parameters may have changed since the last call (optimizer step, checkpoint load)
+    if (repack && plan->lstm_bf16)
         for (int i = 0; i < 7; ++i)
             RC(pack_lstm_bf16(P(plan, plan->i_lstm_w[i]), reinterpret_cast<unsigned short*>(plan->ws + plan->o_wbf16[i]),
                               kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C, s, 0, plan->lstm_planes,
                               (plan->lstm_planes == -2 && lstm_w_of(plan, i) % 16) ? 2 : 0));      // (fp16 pieces on an 8-wide map: the ring kernel's layout)
+    plan->packs_valid = 1;
     for (int t = 0; t < T - 1; ++t) {
         if (t >= ctx && gt_select)                                     // TM:667-670
             RC(run_select_frames(images + t * fr, gen_images + (t - 1) * fr, gt_select + (size_t)t * B,

@@ -307,6 +307,7 @@ class Model(object):
                                   keep_activations=1 if self.keep_activations else 0,
                                   ln_eps=self.ln_eps, stp_zero_border=1 if self.stp_border == 'zeros' else 0)
             plan = _Plan(lib, cfg)
+            _lib.check(lib.pivp_plan_set_pack_cache(plan.h, 1), 'pivp_plan_set_pack_cache')
             if self.precision != 'fp32':
                 _lib.check(lib.pivp_plan_set_precision(plan.h, {'bf16': 1, 'bf16x3': 2, 'bf16x6': 3, 'fp16x3': 4}[self.precision]),
                            'pivp_plan_set_precision(%s)' % self.precision)
@@ -383,6 +384,12 @@ class Model(object):
             gen_states = torch.empty((T - 1, B, 5), dtype=torch.float32, device=self.device)
             nf = T - ctx
             results = torch.empty(2 + 3 * nf, dtype=torch.float32, device=self.device)
+            # the precision modes' weight packs are kept across calls while the parameters are untouched: torch counts in-place writes to the flat
+            # buffer and its views (_version), the optimizer's own kernel reports itself (_params_epoch)
+            pkey = (self._flat_params.data_ptr(), self._flat_params._version, getattr(self, '_params_epoch', 0))
+            if getattr(plan, 'packed_key', None) != pkey:
+                _lib.check(plan.lib.pivp_plan_params_changed(plan.h), 'pivp_plan_params_changed')
+                plan.packed_key = pkey
             _lib.check(plan.lib.pivp_rollout_forward(plan.h, images.data_ptr(), actions.data_ptr(), states.data_ptr(),
                                                      gt_ptr, gen.data_ptr(), gen_states.data_ptr(), results.data_ptr(),
                                                      self._stream()), 'pivp_rollout_forward')

@@ -438,6 +438,33 @@ def test_rollout_fp16x3_is_as_close_to_float64_as_the_fp32_path():
     assert m3._active.lib.pivp_plan_get_precision(m3._active.h) == 4
 
 
+def test_weight_packs_are_rebuilt_when_the_parameters_change():
+    """The precision modes keep their weight packs across calls (pivp_plan_set_pack_cache) while the parameters are untouched; an in-place write through
+    torch (its version counter) and the optimizer's own kernel (Model._params_epoch) must both invalidate them."""
+    import pivp_amd
+    imgs, acts, stas = R.synthetic_batch(2, 4)
+    for prec in ('fp16x3', 'bf16x6', 'bf16'):
+        P = R.init_params(seed=1, dtype=np.float32, scale=1.0)
+        m = pivp_amd.Model(10, prefix='t', precision=prec, keep_activations=True)
+        m.load_state_dict_reference(P)
+        with pivp_amd.using_config('train', False):
+            l0 = float(m([imgs, acts, stas], 0)); l0b = float(m([imgs, acts, stas], 0))
+            assert l0 == l0b                                              # (second call: cached packs)
+            m._params['lstm1/conv/W'].mul_(1.5)                           # an in-place write through a view of the flat buffer
+            l1 = float(m([imgs, acts, stas], 0))
+        assert abs(l1 - l0) > 1e-7, (prec, l0, l1)
+        opt = pivp_amd.Adam(alpha=0.01).setup(m)
+        opt.update(m, [imgs, acts, stas], 0)                              # the optimizer's kernel writes through raw pointers
+        with pivp_amd.using_config('train', False):
+            l2 = float(m([imgs, acts, stas], 0))
+        fresh = pivp_amd.Model(10, prefix='t', precision=prec)
+        with pivp_amd.using_config('train', False):
+            fresh([imgs, acts, stas], 0)
+            fresh._flat_params.copy_(m._flat_params)
+            l2f = float(fresh([imgs, acts, stas], 0))
+        assert l2 == l2f and abs(l2 - l1) > 1e-7, (prec, l1, l2, l2f)
+
+
 def test_train_step_in_fp16x3_mode_matches_the_fp32_gradients():
     import pivp_amd
     outs = {}
