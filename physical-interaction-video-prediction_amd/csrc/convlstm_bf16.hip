@@ -193,6 +193,11 @@ __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned shor
 // v_mfma_f32_32x32x16_bf16 whose 32 columns are the four gates of eight channels (lane (half, l31): gate l31 / 8, channel c8 * 8 + l31 % 8;
 // k = the k-step's channels half * 8 .. + 8) is 1 KB in lane order: one global_load_lds_dwordx4 of a wave moves exactly one fragment into
 // a lane-linear (conflict-free) kilobyte of the ring, one global_load_dwordx4 of a wave loads it straight into the MFMA's operand registers.
+#ifndef PIVP_X3_DOUBLE
+#define PIVP_X3_DOUBLE 0    // 1: the eight-wave two-fp16-piece kernels take TWO k-steps (32 channels) per wait.  Built on the guess that their short k-step
+#endif                      // (3 MT MFMAs) pays a per-wait cost twice as often as the three-piece form; measured: 349.0 against 346.2 us per seven layers: off
+template <class F, size_t... I> __device__ __forceinline__ void static_for_impl(F&& f, std::index_sequence<I...>) { (f(std::integral_constant<int, (int)I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_index_sequence<N>{}); }
 #ifndef PIVP_X6_MIDLOAD
 #define PIVP_X6_MIDLOAD 0   // 1: the eight-wave L2-direct kernels issue their fragment loads in the middle of a k-step's MFMAs instead of behind them
                             // (measured: three pieces 466.4 against 465.9 us per six layers, two fp16 pieces 308.8 against 298.6: off)
@@ -1236,6 +1241,44 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     };
     auto a_base = [&](int tp) { const int ty = tp / 5; return lds0 + ty * RP16 + (tp - ty * 5) * PP; };
 
+    // ---- two fp16 pieces, eight waves: two k-steps per wait -------------------------------------------------------------------------------------
+    constexpr bool DBL = PCS == 2 && NW == 8 && PIVP_X3_DOUBLE;
+    constexpr int NRD = 2 * 2 * MT;                    // A reads of a k-step pair: [k-step][plane][M tile]
+    constexpr int NMD = 2 * 3 * MT;                    // MFMAs of a k-step pair: [k-step][term][M tile]
+    bf16x8 ga[2][2][2][MT];                            // [register set][k-step of the pair][plane][M tile]
+    auto wait_d = [&](auto SET) {
+        constexpr int st = decltype(SET)::value;
+        if constexpr (MT == 2) wait_lgkm(ga[st][0][0][0], ga[st][0][0][1], ga[st][0][1][0], ga[st][0][1][1], ga[st][1][0][0], ga[st][1][0][1], ga[st][1][1][0], ga[st][1][1][1]);
+        else wait_lgkm(ga[st][0][0][0], ga[st][0][1][0], ga[st][1][0][0], ga[st][1][1][0]);
+    };
+    auto read_d = [&](auto SET, auto PAIR, auto I, unsigned ab) {      // PAIR: which half of the tap (k-steps 2 PAIR, 2 PAIR + 1)
+        constexpr int st = decltype(SET)::value, pair = decltype(PAIR)::value, i = decltype(I)::value;
+        constexpr int kk = i / (2 * MT), pl = (i / MT) % 2, mt = i % MT, ks = 2 * pair + kk;
+        ga[st][kk][pl][mt] = lds_read_b128<ks * 32>(ab + pl * PB + a_off[mt]);
+    };
+    auto mfma_d = [&](auto CUR, auto I, const bf16x8 (&b0)[PCS], const bf16x8 (&b1)[PCS]) {
+        constexpr int st = decltype(CUR)::value, i = decltype(I)::value, kk = i / (3 * MT), term = (i / MT) % 3, mt = i % MT;
+        auto h = [](const bf16x8& v) { return __builtin_bit_cast(f16x8, v); };
+        const bf16x8& bh = kk ? b1[0] : b0[0];
+        const bf16x8& bl = kk ? b1[PCS - 1] : b0[PCS - 1];
+        if constexpr (term == 0) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(ga[st][kk][1][mt]), h(bh), accl[mt], 0, 0, 0);       // lo * hi
+        else if constexpr (term == 1) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(ga[st][kk][0][mt]), h(bl), accl[mt], 0, 0, 0);  // hi * lo
+        else acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(ga[st][kk][0][mt]), h(bh), acc[mt], 0, 0, 0);                             // hi * hi
+    };
+    auto dstep = [&](auto CUR, auto NXT, auto PAIRN, unsigned abn, const bf16x8 (&b0)[PCS], const bf16x8 (&b1)[PCS], auto RD) {
+        constexpr bool rd = decltype(RD)::value;
+        wait_d(CUR);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NMD>([&](auto I) {                  // two reads of the next pair behind each of the first MFMAs
+            constexpr int i = decltype(I)::value;
+            mfma_d(CUR, I, b0, b1);
+            if constexpr (rd && 2 * i < NRD) read_d(NXT, PAIRN, std::integral_constant<int, 2 * i>{}, abn);
+            if constexpr (rd && 2 * i + 1 < NRD) read_d(NXT, PAIRN, std::integral_constant<int, 2 * i + 1>{}, abn);
+            if constexpr (2 * i < NRD + 2) __builtin_amdgcn_sched_barrier(0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
     if constexpr (RD == 8) {
         // one wave per SIMD: the taps of all groups as one sequence, two per iteration (the ring's halves), fragments requested two taps ahead
         int tap2 = tap1, cg2 = cg1;
@@ -1305,6 +1348,23 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
                     const int m = (b0 * H + y0 + (i >> 4)) * W + x0 + (i & 15);
                     cpre[mt][k] = d.cstate_in[(size_t)m * C + ch];
                 }
+        }
+        if constexpr (DBL) {
+            // two k-steps per wait: set 0 = k-steps 0, 1 of a tap, set 1 = k-steps 2, 3
+            static_for<NRD>([&](auto I) { read_d(S0{}, K0{}, I, a_base(tap)); });
+            for (int t = 0; t < 25; ++t) {
+                const unsigned ab = a_base(tap), ab1 = a_base(tap1);
+                const bool has1 = t < 24 || g + 1 < ncg;
+                const unsigned so1 = (unsigned)(cg1 * 25 + tap1) * tps;
+                dstep(S0{}, S1{}, K1{}, ab, Bf[0], Bf[1], std::true_type{});
+                if (has1) { bload(Bf[0], so1); bload(Bf[1], so1 + kss); }
+                if (t < 24) dstep(S1{}, S0{}, K0{}, ab1, Bf[2], Bf[3], std::true_type{});
+                else dstep(S1{}, S0{}, K0{}, ab1, Bf[2], Bf[3], std::false_type{});
+                if (has1) { bload(Bf[2], so1 + 2 * kss); bload(Bf[3], so1 + 3 * kss); }
+                tap = tap1; cg = cg1;
+                adv(tap1, cg1);
+            }
+            continue;
         }
         read_a_all(a_base(tap));
         for (int t = 0; t < 25; ++t) {                 // one tap = four k-steps; behind each k-step its registers take the next tap's fragments
