@@ -286,7 +286,8 @@ def main(argv=None):
         # `value`; `max_l2_vs_f32_rollout` is the largest per-pixel L2 between their frames and the fp32 rollout's on this run's input (the gates against
         # the float64 oracle are tests/test_gpu_trained.py's).
         split_objs = {}
-        if do_rollout and not dry and args.precision == 'fp32' and not args.no_bf16x6:
+        if do_rollout and not dry and args.precision == 'fp32' and not args.no_bf16x6 and world == 1:       # (one rank only: a leg that fails on one
+            # rank alone would leave the others in a barrier; the multi-GPU runs measure `value` and the data-parallel train steps)
             for mode, what in (('bf16x6', '3 bf16 pieces, 6 bf16 MFMAs per product'), ('fp16x3', '2 fp16 pieces (weights packed times 2^8), 3 fp16 MFMAs per product')):
                 try:
                     m6 = pivp_amd.Model(nm, prefix='bench', device=dev, keep_activations=False, precision=mode, **kinds)
@@ -409,7 +410,7 @@ def main(argv=None):
                 # BASELINE.json config 3 names bf16 for the data-parallel configuration: at --gpus 8 this object IS config 3 (global batch 256)
                 train_bf16_obj, m16, _, _, _ = train_leg('bf16')
                 del m16
-            if args.mode != 'train' and args.precision == 'fp32' and not dry and not args.no_bf16x6:
+            if args.mode != 'train' and args.precision == 'fp32' and not dry and not args.no_bf16x6 and world == 1:
                 # the fp32-grade train step on the bf16 matrix cores: gate convolutions and their data gradients as six bf16 MFMAs per product
                 # (three pieces per fp32 operand), weight gradients and everything else fp32.  An additional object: `train` stays the fp32 kernels'.
                 train_x6_obj = {}
