@@ -45,15 +45,16 @@ def _run(pivp, mt, nm, imgs, acts, stas, P, train=False, k=-1, it=0, **kw):
     return m, float(loss), torch.stack(m.gen_images).cpu().numpy()
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x6', 'fp16x3'])      # the two split modes are held to the SAME gates as the fp32 kernels
 @pytest.mark.parametrize('name,mt,nm', [('cdna_b2_t10', 'CDNA', 10), ('stp_b2_t4', 'STP', 10), ('dna_b2_t4', 'DNA', 1)])
-def test_rollout_matches_golden(pivp, name, mt, nm):
+def test_rollout_matches_golden(pivp, name, mt, nm, precision):
     g = np.load(os.path.join(GOLD, name + '.npz'))
     B, T = int(g['batch']), int(g['seq_len'])
     P = R.init_params(seed=1, dtype=np.float32, scale=1.0, num_masks=nm, model_type=mt)
     imgs, acts, stas = R.synthetic_batch(B, T)
-    m, loss, gen = _run(pivp, mt, nm, imgs, acts, stas, P)
+    m, loss, gen = _run(pivp, mt, nm, imgs, acts, stas, P, precision=precision)
     l2 = R.per_pixel_l2(gen, g['gen_images'])
-    print('%s: max per-pixel L2 %.3e, rms %.3e, loss %.8f vs %.8f' % (name, l2.max(), np.sqrt((l2 ** 2).mean()), loss, float(g['loss'])))
+    print('%s (%s): max per-pixel L2 %.3e, rms %.3e, loss %.8f vs %.8f' % (name, precision, l2.max(), np.sqrt((l2 ** 2).mean()), loss, float(g['loss'])))
     ctx = 2                                                     # frames 0, 1 are ground truth; later ones are fed back
     assert l2[:ctx].max() < GATE
     if mt != 'STP':                                             # STP fed-back steps: see the note at the top and test_config4_stp_batch32
@@ -198,16 +199,18 @@ def _sampled_pixels(gen, stride):
     return np.ascontiguousarray(gen.transpose(0, 1, 3, 4, 2)).reshape(-1, 3)[::stride]
 
 
-def test_config2_batch32_matches_golden(pivp):
-    """BASELINE.json config 2 at full size (B = 32, T = 10, CDNA, fp32) against the float64 oracle's committed fixture."""
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x6', 'fp16x3'])
+def test_config2_batch32_matches_golden(pivp, precision):
+    """BASELINE.json config 2 at full size (B = 32, T = 10, CDNA) against the float64 oracle's committed fixture: the fp32 kernels, and the two split
+    modes (fp32 operands as three bf16 / two fp16 pieces on the matrix cores) at the same 1e-4 gate."""
     import torch
     g = np.load(os.path.join(GOLD, 'cdna_b32_t10.npz'))
     P = R.init_params(seed=1, dtype=np.float32, scale=1.0)
     imgs, acts, stas = R.synthetic_batch(32, 10)
-    m, loss, gen = _run(pivp, 'CDNA', 10, imgs, acts, stas, P)
+    m, loss, gen = _run(pivp, 'CDNA', 10, imgs, acts, stas, P, precision=precision)
     pix = _sampled_pixels(gen, int(g['pixel_stride']))
     l2 = np.sqrt(((pix.astype(np.float64) - g['gen_pixels']) ** 2).sum(axis=1))
-    print('config 2 (B=32): max per-pixel L2 %.3e over %d sampled pixels, loss %.8f vs %.8f' % (l2.max(), l2.size, loss, float(g['loss'])))
+    print('config 2 (B=32, %s): max per-pixel L2 %.3e over %d sampled pixels, loss %.8f vs %.8f' % (precision, l2.max(), l2.size, loss, float(g['loss'])))
     assert l2.max() < GATE
     assert abs(loss - float(g['loss'])) < 1e-5
     assert abs(float(m.psnr_all) - float(g['psnr_all'])) < 1e-2
