@@ -438,6 +438,26 @@ def test_rollout_fp16x3_is_as_close_to_float64_as_the_fp32_path():
     assert m3._active.lib.pivp_plan_get_precision(m3._active.h) == 4
 
 
+@pytest.mark.parametrize('B', [1, 3])
+def test_split_modes_with_odd_batches(B):
+    """An odd batch: the 8 x 8 map of lstm5 cannot be paired into the ring kernel's two-image tiles and takes the fp32 kernel inside the plan; every other
+    layer stays on the split kernels (any batch).  Both modes against the fp32 path on the same input."""
+    import pivp_amd
+    P = R.init_params(seed=1, dtype=np.float32, scale=1.0)
+    imgs, acts, stas = R.synthetic_batch(B, 4)
+    gens = {}
+    for prec in ('fp32', 'bf16x6', 'fp16x3'):
+        m = pivp_amd.Model(10, prefix='t', precision=prec)
+        m.load_state_dict_reference(P)
+        with pivp_amd.using_config('train', False):
+            m([imgs, acts, stas], 0)
+        gens[prec] = torch.stack(m.gen_images).cpu().numpy()
+    for prec in ('bf16x6', 'fp16x3'):
+        l2 = R.per_pixel_l2(gens[prec], gens['fp32'])
+        print('B = %d, %s against the fp32 kernels: max per-pixel L2 %.2e' % (B, prec, l2.max()))
+        assert np.isfinite(gens[prec]).all() and l2.max() < 2e-5
+
+
 def test_weight_packs_are_rebuilt_when_the_parameters_change():
     """The precision modes keep their weight packs across calls (pivp_plan_set_pack_cache) while the parameters are untouched; an in-place write through
     torch (its version counter) and the optimizer's own kernel (Model._params_epoch) must both invalidate them."""
