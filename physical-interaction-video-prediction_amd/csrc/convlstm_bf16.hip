@@ -107,16 +107,7 @@ __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x
 __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
 }
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-// two fp32 -> packed fp16 (round to nearest even, saturating at the largest finite fp16); a, b become the remainders v - fp16(v), exact in fp32
-__device__ __forceinline__ unsigned pack2h_rest(float& a, float& b) {
-    const float ca = __builtin_fminf(__builtin_fmaxf(a, -65504.f), 65504.f), cb = __builtin_fminf(__builtin_fmaxf(b, -65504.f), 65504.f);
-    f32x2 v = {ca, cb};
-    const f16x2 h = __builtin_convertvector(v, f16x2);
-    a -= (float)h[0]; b -= (float)h[1];
-    return __builtin_bit_cast(unsigned, h);
-}
+typedef pivp_f16x8 f16x8;                  // (two fp16 pieces per operand: pivp_pack2h_rest, pivp_x3_scale_of_max in pivp_common.h)
 // fp16 pieces: the weights are packed times a power of two chosen per tensor so that the largest lands in [2^14, 2^15) -- the second piece of any
 // weight down to 2^-18 of the largest is then a normal fp16 number.  The pack's tail (256 2-byte elements behind the fragments) holds the scale
 // (float 0) and the 64 partial maxima it was taken from (floats 2..65).
@@ -137,12 +128,7 @@ __global__ __launch_bounds__(256) void absmax_partials_kernel(const float* __res
 __device__ __forceinline__ float x3_scale_of(const float* tail) {      // every caller computes the same power of two from the 64 partial maxima
     float m = 0.f;
     for (int i = 0; i < 64; ++i) m = __builtin_fmaxf(m, tail[2 + i]);
-    if (!(m > 0.f) || !(m < 3.0e38f)) return 1.0f;
-    int e;
-    (void)__builtin_frexpf(m, &e);                  // m = f * 2^e, f in [0.5, 1)
-    int k = 15 - e;                                 // m * 2^k in [2^14, 2^15)
-    k = k < -60 ? -60 : k > 60 ? 60 : k;
-    return __builtin_ldexpf(1.0f, k);
+    return pivp_x3_scale_of_max(m);
 }
 __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& e, bf16x8& f, bf16x8& g, bf16x8& h, bf16x8& i, bf16x8& j) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i), "+v"(j));
@@ -1089,8 +1075,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
             float r[8] = {plo[j][0], plo[j][1], plo[j][2], plo[j][3], phi[j][0], phi[j][1], phi[j][2], phi[j][3]};
             if constexpr (PCS == 2) {
                 uint4 hh, ll;
-                hh.x = pack2h_rest(r[0], r[1]); hh.y = pack2h_rest(r[2], r[3]); hh.z = pack2h_rest(r[4], r[5]); hh.w = pack2h_rest(r[6], r[7]);
-                ll.x = pack2h_rest(r[0], r[1]); ll.y = pack2h_rest(r[2], r[3]); ll.z = pack2h_rest(r[4], r[5]); ll.w = pack2h_rest(r[6], r[7]);
+                hh.x = pivp_pack2h_rest(r[0], r[1]); hh.y = pivp_pack2h_rest(r[2], r[3]); hh.z = pivp_pack2h_rest(r[4], r[5]); hh.w = pivp_pack2h_rest(r[6], r[7]);
+                ll.x = pivp_pack2h_rest(r[0], r[1]); ll.y = pivp_pack2h_rest(r[2], r[3]); ll.z = pivp_pack2h_rest(r[4], r[5]); ll.w = pivp_pack2h_rest(r[6], r[7]);
                 *reinterpret_cast<uint4*>(patch + a_lds + cpiece * 16) = hh;
                 *reinterpret_cast<uint4*>(patch + PB + a_lds + cpiece * 16) = ll;
                 continue;
