@@ -996,7 +996,10 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
 // PCS = 2: TWO FP16 pieces per operand instead of three bf16 ones (22 bits of operand mantissa; the weights arrive times 2^8 and the sum is scaled
 // back) and three MFMAs per product: hi*hi on the main accumulator, lo*hi + hi*lo on the second.  scripts/split_fp16_study.py: the truncation is a
 // quarter of the fp32 path's own error.  Forward gate convolutions only (gradients are too small for fp16's exponent range).
-template <int NWM, int NWN, bool LSTM = true, int PCS = 3>
+// IN_LN: the x operand (d.x0, c0 <= 64 channels) is a RAW ConvLSTM output whose LayerNorm (per-element gamma / beta d.in_g / d.in_b [H W][c0], statistics
+// merged from the producer's partials d.in_part) is applied while the patch is staged -- the expression of ln_apply_kernel; out-of-image pixels load 0
+// for v, gamma and beta alike and stay 0.  Inference rollouts: hidden1 -> lstm2 and hidden3 -> lstm4 lose their ln_apply launch.
+template <int NWM, int NWN, bool LSTM = true, int PCS = 3, bool IN_LN = false>
 __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int wbytes, int ncols) {
     constexpr int PB = PH * RP16;                      // one patch plane: 36,864 B
     static_assert(PCS == 3 || (PCS == 2 && LSTM), "pieces");
@@ -1005,7 +1008,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     constexpr int MT = 4 / NWM;                        // 32-anchor M tiles per wave
     constexpr int NT = 64 * NW;                        // threads
     constexpr int PPP = NT / 8;                        // patch pixels per staging pass
-    constexpr int NPJX = 4;                            // staging passes per round: 4 x 64 pixels cover the patch's 240 with 512 threads;
+    constexpr int NPJX = IN_LN ? 2 : 4;                // staging passes per round: 4 x 64 pixels cover the patch's 240 with 512 threads (IN_LN: gamma and beta
+                                                       // travel with the pixels: two rounds of 2, or the prologue spills);
     constexpr int NRND = (PH * PW + NPJX * PPP - 1) / (NPJX * PPP);     // 256 threads take two rounds of 4 x 32 (eight passes in one round put the staged pixels in scratch)
     constexpr int RD = NW == 8 ? 4 : 8;                // k-steps of B fragments in registers
     PIVP_SET_MAIN_PRIO();
@@ -1049,6 +1053,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
         a_lds = p < PH * PW ? py * RP16 + px * PP : PW * PP;
     };
     f32x4 plo[NPJX], phi[NPJX];
+    f32x4 glo[IN_LN ? NPJX : 1], ghi[IN_LN ? NPJX : 1], blo[IN_LN ? NPJX : 1], bhi[IN_LN ? NPJX : 1];      // IN_LN: gamma / beta of the staged pieces
+    float ln_mean = 0.f, ln_rstd = 1.f;
+    if constexpr (IN_LN) ln_merge_partials(d.in_part, b0, d.in_np, d.in_eps, ln_mean, ln_rstd);      // every wave for itself: a few partials per sample
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN_LN ? d.in_g : d.x0), 0, IN_LN ? H * W * c0 * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN_LN ? d.in_b : d.x0), 0, IN_LN ? H * W * c0 * 4 : 0, 0x00020000);
     auto patch_load = [&](int cg, int rnd) {
         const int ch = cg * 64 + cpiece * 8;
         const bool s0 = ch < c0, s1 = !s0 && ch < cin;
@@ -1058,6 +1067,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
             int a_pix, a_lds;
             pix_of(rnd * NPJX + j, a_pix, a_lds);
             const unsigned off = (a_pix >= 0 && (s0 || s1)) ? (unsigned)((a_pix * ld + co) * 4) : OOB;
+            if constexpr (IN_LN) {          // (pieces of h channels and pixels outside the image: the zeros of an out-of-range load)
+                const unsigned go = (a_pix >= 0 && s0) ? (unsigned)(((a_pix - b0 * H * W) * c0 + co) * 4) : OOB;
+                glo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, go, 0, 0));
+                ghi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, go, 16, 0));
+                blo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, go, 0, 0));
+                bhi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, go, 16, 0));
+            }
             if (s0) {
                 plo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
                 phi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 16, 0));
@@ -1067,12 +1083,20 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
             }
         }
     };
-    auto patch_store = [&](int rnd) {
+    auto patch_store = [&](int rnd, int cg = 0) {      // cg: which 64-channel group was loaded (IN_LN: its x pieces are normalised)
 #pragma unroll
         for (int j = 0; j < NPJX; ++j) {
             int a_pix, a_lds;
             pix_of(rnd * NPJX + j, a_pix, a_lds);
             float r[8] = {plo[j][0], plo[j][1], plo[j][2], plo[j][3], phi[j][0], phi[j][1], phi[j][2], phi[j][3]};
+            if constexpr (IN_LN) {
+                if (cg * 64 + cpiece * 8 < c0) {
+                    const float gm[8] = {glo[j][0], glo[j][1], glo[j][2], glo[j][3], ghi[j][0], ghi[j][1], ghi[j][2], ghi[j][3]};
+                    const float bt[8] = {blo[j][0], blo[j][1], blo[j][2], blo[j][3], bhi[j][0], bhi[j][1], bhi[j][2], bhi[j][3]};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) r[e] = (r[e] - ln_mean) * ln_rstd * gm[e] + bt[e];
+                }
+            }
             if constexpr (PCS == 2) {
                 uint4 hh, ll;
                 hh.x = pivp_pack2h_rest(r[0], r[1]); hh.y = pivp_pack2h_rest(r[2], r[3]); hh.z = pivp_pack2h_rest(r[4], r[5]); hh.w = pivp_pack2h_rest(r[6], r[7]);
@@ -1140,8 +1164,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     const int grp = l31 >> 3;
     float bj = 0.f, bi = 0.f, bf = 0.f, bo = 0.f;
     float cpre[MT][4];
-    patch_store(0);
-    if constexpr (NRND == 2) { patch_load(cgbase, 1); patch_store(1); }
+    patch_store(0, cgbase);
+    if constexpr (NRND == 2) { patch_load(cgbase, 1); patch_store(1, cgbase); }
     BF_STAMP(1);
     __syncthreads();
     BF_STAMP(2);
@@ -1299,8 +1323,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
             if (regroup) {                             // next 64 input channels: every wave is done with the old patch
                 __syncthreads();
                 patch_load(cg1, 0);
-                patch_store(0);
-                if constexpr (NRND == 2) { patch_load(cg1, 1); patch_store(1); }
+                patch_store(0, cg1);
+                if constexpr (NRND == 2) { patch_load(cg1, 1); patch_store(1, cg1); }
                 __syncthreads();
                 read_a_all(ab1);
             }
@@ -1317,8 +1341,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
         if (g > 0) {                                   // every wave is done with the old patch
             __syncthreads();
             patch_load(cgbase + g, 0);
-            patch_store(0);
-            if constexpr (NRND == 2) { patch_load(cgbase + g, 1); patch_store(1); }
+            patch_store(0, cgbase + g);
+            if constexpr (NRND == 2) { patch_load(cgbase + g, 1); patch_store(1, cgbase + g); }
             __syncthreads();
         }
         if (LSTM && g == ncg - 1) {
@@ -1549,11 +1573,11 @@ static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t
     return PIVP_LAUNCH_STATUS();
 }
 
-template <int NWM, int NWN, int PCS = 3>
-static int launch_x6g(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts) {
+template <int NWM, int NWN, int PCS, bool IN_LN>
+static int launch_x6g_impl(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts) {
     constexpr int lds_bytes = PCS * PH * RP16;
     static PerDeviceOnce once;
-    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<NWM, NWN, true, PCS>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<NWM, NWN, true, PCS, IN_LN>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     IgemmDesc dd = d;
     const int tpi = (d.Hin / TH) * (d.Win / 16), nb = d.C / (8 * NWN);
     const int np = tpi * nb;
@@ -1562,8 +1586,18 @@ static int launch_x6g(const IgemmDesc& d, const unsigned short* wb, hipStream_t 
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
     const long long wbytes = (long long)lstm_bf16_weight_elems(d.c0 + (d.c1 ? d.c1 : d.C), 4 * d.C) * PCS * 2;
     if (wbytes >= (1LL << 31)) return PIVP_ERR_BADARG;
-    hipLaunchKernelGGL((convlstm_x6g_kernel<NWM, NWN, true, PCS>), dim3(d.B * tpi * nb), dim3(64 * NWM * NWN), lds_bytes, stream, dd, wb, (int)wbytes, 0);
+    hipLaunchKernelGGL((convlstm_x6g_kernel<NWM, NWN, true, PCS, IN_LN>), dim3(d.B * tpi * nb), dim3(64 * NWM * NWN), lds_bytes, stream, dd, wb, (int)wbytes, 0);
     return PIVP_LAUNCH_STATUS();
+}
+template <int NWM, int NWN, int PCS = 3>
+static int launch_x6g(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts) {
+    if (d.in_g) {       // the x operand's LayerNorm applied while staging (eight-wave forms only; x in one 64-channel group)
+        if constexpr (NWM * NWN == 8) {
+            PIVP_CHECK_ARG(d.in_b && d.in_part && d.in_np > 0 && d.c0 <= 64 && d.ld0 == d.c0 && d.in_part != d.ln_part);
+            return launch_x6g_impl<NWM, NWN, PCS, true>(d, wb, stream, ln_nparts);
+        } else return PIVP_ERR_BADARG;
+    }
+    return launch_x6g_impl<NWM, NWN, PCS, false>(d, wb, stream, ln_nparts);
 }
 
 // the plain 5x5 convolution on the same kernel: dd.N = rows of the padded pack, nb = its 64-column blocks, ks = split of the channel groups

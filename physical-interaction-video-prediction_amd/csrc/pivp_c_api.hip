@@ -23,9 +23,14 @@ void lnb_apply(IgemmDesc& d, const LnbSpec* l) {
 
 int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                  const float* c_in, float* c_out, float* h_out, int B, int H, int W, hipStream_t s, int variant,
-                 float* gates_out, float* ln_part, int ln_cap, int* ln_nparts, const unsigned short* w_bf16, int bf16_planes) {
+                 float* gates_out, float* ln_part, int ln_cap, int* ln_nparts, const unsigned short* w_bf16, int bf16_planes, const LnIn* ln_in) {
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
+    if (ln_in) {
+        if (!w_bf16 || !convlstm_ln_in_ok(bf16_planes, cx, ldx, C, B, H, W) || !ln_in->gamma || !ln_in->beta || !ln_in->part || ln_in->np <= 0 || ln_in->part == ln_part)
+            return PIVP_ERR_BADARG;
+        d.in_g = ln_in->gamma; d.in_b = ln_in->beta; d.in_part = ln_in->part; d.in_np = ln_in->np; d.in_eps = ln_in->eps;
+    }
     // h_prev == nullptr: the recurrent input is identically zero (first timestep after reset_state, TM:254-257);
     // its K range contributes exactly 0 and is skipped
     d.x0 = x; d.c0 = cx; d.ld0 = ldx; d.x1 = h_prev; d.c1 = h_prev ? C : 0; d.ld1 = C; d.wcin = cx + C;
@@ -48,6 +53,10 @@ int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, co
     return igemm_lstm(d, s, variant, ln_nparts);
 }
 
+// the eight-wave L2-direct kernels of the split modes take it: a 16-wide map, x contiguous in one 64-channel group, and a grid that picks those kernels
+bool convlstm_ln_in_ok(int planes, int cx, int ldx, int C, int B, int H, int W) {
+    return (planes == 3 || planes == -2) && cx <= 64 && ldx == cx && cx % 8 == 0 && C % 16 == 0 && H % 8 == 0 && W % 16 == 0;
+}
 int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                   int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum, const LnbSpec* lnb) {
     if (Hin % 2 || Win % 2) return PIVP_ERR_BADARG;

@@ -10,10 +10,13 @@ struct LnbSpec { const float* gamma; const float* x; const float* stat; float* p
 void lnb_apply(IgemmDesc& d, const LnbSpec* l);
 long long view_bytes(int B, int H, int W, int ld);
 bool fits31(long long v);
+// the x operand of a ConvLSTM launch as a RAW tensor whose LayerNorm is applied while it is staged (split precision modes' eight-wave kernels)
+struct LnIn { const float* gamma; const float* beta; const float* part; int np; float eps; };
+bool convlstm_ln_in_ok(int planes, int cx, int ldx, int C, int B, int H, int W);
 int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                  const float* c_in, float* c_out, float* h_out, int B, int H, int W, hipStream_t s, int variant = 0,
                  float* gates_out = nullptr, float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr,
-                 const unsigned short* w_bf16 = nullptr, int bf16_planes = 1);
+                 const unsigned short* w_bf16 = nullptr, int bf16_planes = 1, const LnIn* ln_in = nullptr);
 int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                   int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0, const LnbSpec* lnb = nullptr);
 // conv3x3s2 of LayerNorm(x_raw) with the norm applied while the input is staged (IgemmDesc::in_g); conv3x3s2_ln_ok tells whether the

@@ -425,14 +425,14 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     auto cp = [&](int i) { return Sp ? ws + Sp->c[i] : ws + p->o_zero; };
     const int ln_cap = ln_partial_cap(H * W);   // partial slots per sample in lnp (see the workspace carve)
     int np = 0;
-    auto lstm = [&](int i, const float* x, int ldx, int hh, int wwid) {
+    auto lstm = [&](int i, const float* x, int ldx, int hh, int wwid, const LnIn* ln_in = nullptr, float* part_out = nullptr) {
         const bool prof = p->prof_on && p->prof_used + 2 <= p->prof_ev.size();
         if (prof) (void)hipEventRecord(p->prof_ev[p->prof_used], s);
         // the LayerNorm behind every ConvLSTM gets its statistics from the ConvLSTM epilogue (np partials per sample)
         int rc = run_convlstm(x, kLstm[i].cx, ldx, hp(i), kLstm[i].C, P(p, p->i_lstm_w[i]), P(p, p->i_lstm_b[i]),
                               cp(i), ws + S.c[i], ws + S.h[i], B, hh, wwid, s, 0, train ? ws + S.gates[i] : nullptr,
-                              lnp, ln_cap, &np,
-                              p->lstm_bf16 ? reinterpret_cast<const unsigned short*>(ws + p->o_wbf16[i]) : nullptr, p->lstm_planes);
+                              part_out ? part_out : lnp, ln_cap, &np,
+                              p->lstm_bf16 ? reinterpret_cast<const unsigned short*>(ws + p->o_wbf16[i]) : nullptr, p->lstm_planes, ln_in);
         if (prof) {
             (void)hipEventRecord(p->prof_ev[p->prof_used + 1], s);
             p->prof_layer[p->prof_used / 2] = i + (Sp ? 0 : 8);   // +8: first-step launch without the h half of K
@@ -451,8 +451,22 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     RC(ln(0, ws + S.e0raw, ws + S.cat7 + 32, n2, 32, 64, 1, np));
     // group 1 (TM:596): lstm1 -> hidden1 -> lstm2 -> hidden2 -> enc1 -> relu  => cat6[:, 64:96]
     RC(lstm(0, ws + S.cat7 + 32, 64, p->H2, p->W2));
-    RC(ln(1, ws + S.h[0], ws + S.n1, n2, 32, 32, 0, np));
-    RC(lstm(1, ws + S.n1, 32, p->H2, p->W2));
+    // Inference rollouts in the split precision modes: hidden1 / hidden3 feed only lstm2 / lstm4, whose eight-wave kernels apply the norm while
+    // they stage their patch (the partials of their own output go to the second buffer: their blocks finish while others still read the input's).
+    static const int fold_lstm = [] { const char* e = getenv("PIVP_LN_FOLD_LSTM"); return e ? atoi(e) : 1; }();
+    float* const lnpA = ws + p->o_lnpart, * const lnpB = ws + p->o_lnpart2;
+    auto other = [&](float* q) { return q == lnpA ? lnpB : lnpA; };
+    const bool fold_l2 = !train && fold_lstm && p->lstm_bf16 && np > 0 && convlstm_ln_in_ok(p->lstm_planes, 32, 32, 32, B, p->H2, p->W2) &&
+                         (long)B * (p->H2 / 8) * (p->W2 / 16) >= 128;
+    if (fold_l2) {
+        const LnIn li{P(p, p->i_ln_g[1]), P(p, p->i_ln_b[1]), lnp, np, eps};
+        float* q = other(lnp);
+        RC(lstm(1, ws + S.h[0], 32, p->H2, p->W2, &li, q));
+        lnp = q;
+    } else {
+        RC(ln(1, ws + S.h[0], ws + S.n1, n2, 32, 32, 0, np));
+        RC(lstm(1, ws + S.n1, 32, p->H2, p->W2));
+    }
     // Inference rollouts: hidden2 / hidden4 feed only enc1 / enc2, so their norms are applied while those convs stage their input
     // (run_conv3x3s2_ln) instead of by a launch of their own; training keeps the materialised tensors (the backward sweep reads them).
     static const int fold_ln = [] { const char* e = getenv("PIVP_LN_FOLD"); return e ? atoi(e) : 3; }();   // tuning: 0 = always a separate ln_apply, 1 = only enc1 / enc2 fold theirs (inference), 2 = + enc5 / enc6 (inference), 3 = + enc5 / enc6 in training plans
@@ -465,8 +479,17 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     }
     // group 2 (TM:597)
     RC(lstm(2, ws + S.cat6 + 64, 96, p->H4, p->W4));
-    RC(ln(3, ws + S.h[2], ws + S.n3, n4, 64, 64, 0, np));
-    RC(lstm(3, ws + S.n3, 64, p->H4, p->W4));
+    const bool fold_l4 = !train && fold_lstm && p->lstm_bf16 && np > 0 && convlstm_ln_in_ok(p->lstm_planes, 64, 64, 64, B, p->H4, p->W4) &&
+                         (long)B * (p->H4 / 8) * (p->W4 / 16) >= 64;
+    if (fold_l4) {
+        const LnIn li{P(p, p->i_ln_g[3]), P(p, p->i_ln_b[3]), lnp, np, eps};
+        float* q = other(lnp);
+        RC(lstm(3, ws + S.h[2], 64, p->H4, p->W4, &li, q));
+        lnp = q;
+    } else {
+        RC(ln(3, ws + S.h[2], ws + S.n3, n4, 64, 64, 0, np));
+        RC(lstm(3, ws + S.n3, 64, p->H4, p->W4));
+    }
     if (!train && fold_ln && np > 0 && conv3x3s2_ln_ok(64, 64, B, p->H4, p->W4)) {
         RC(run_conv3x3s2_ln(ws + S.h[3], 64, P(p, p->i_enc_w[2]), P(p, p->i_enc_b[2]), ws + S.e2, 64, 64, 1, B, p->H4, p->W4, s,
                             P(p, p->i_ln_g[4]), P(p, p->i_ln_b[4]), lnp, np, eps));
@@ -520,7 +543,7 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     RC(lstm(6, ws + S.e5, 96, p->H2, p->W2));
     if (fold_dec && np > 0 && fold_small((long long)B * n2) && deconv3x3s2_ln_ok(32, 32, 64, B, p->H2, p->W2)) {
         // enc6's blocks write the partials of norm_enc6 while others still read hidden7's: the second partial buffer
-        float* lnp2 = ws + p->o_lnpart2;
+        float* lnp2 = other(lnp);
         const int np_in = np;
         RC(run_deconv3x3s2_ln(ws + S.h[6], 32, ws + S.cat7 + 32, 32, 64, P(p, p->i_enc_w[6]), P(p, p->i_enc_b[6]), ws + S.e6raw, 64, 64, 0, B, p->H2, p->W2,
                               s, P(p, p->i_ln_g[7]), P(p, p->i_ln_b[7]), lnp, np_in, eps, lnp2, ln_cap, &np, dprec,
@@ -1081,11 +1104,13 @@ extern "C" long long pivp_get_tap(pivp_plan_t* plan, const char* name, int step,
     if (!c.keep_activations) {
         // inference applies the norms of hidden2 / hidden4 / hidden6 / hidden7 inside their consumers (run_step): rebuild the tensor on request from
         // the raw ConvLSTM output (statistics recomputed by ln_stats: equal to the fused ones up to fp32 summation order)
-        struct F { const char* n; int layer, norm; size_t dst; int C, hw, ld; };
+        struct F { const char* n; int layer, norm; size_t dst; int C, hw, ld; int split_only = 0; };
         const F folded[] = {{"hidden2", 1, 2, S.n2, 32, HW2, 32}, {"hidden4", 3, 4, S.n4, 64, HW4, 64}, {"hidden6", 5, 6, S.cat6, 64, HW4, 96},
-                            {"hidden7", 6, 7, S.cat7, 32, HW2, 64}};
+                            {"hidden7", 6, 7, S.cat7, 32, HW2, 64},
+                            {"hidden1", 0, 1, S.n1, 32, HW2, 32, 1}, {"hidden3", 2, 3, S.n3, 64, HW4, 64, 1}};      // (the split modes: inside lstm2 / lstm4)
+        const bool split = plan->lstm_planes == 3 || plan->lstm_planes == -2;
         for (const F& f : folded)
-            if (strcmp(f.n, name) == 0) {
+            if (strcmp(f.n, name) == 0 && (!f.split_only || split)) {
                 int rc = run_layernorm(ws + S.h[f.layer], P(plan, plan->i_ln_g[f.norm]), P(plan, plan->i_ln_b[f.norm]), ws + f.dst,
                                        ws + plan->o_lnpart, B, f.C * f.hw, f.C, f.ld, c.ln_eps, 0, s, nullptr, 0);
                 if (rc != PIVP_OK) return rc;

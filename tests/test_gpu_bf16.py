@@ -458,6 +458,26 @@ def test_split_modes_with_odd_batches(B):
         assert np.isfinite(gens[prec]).all() and l2.max() < 2e-5
 
 
+def test_split_modes_apply_hidden1_and_hidden3_inside_lstm2_and_lstm4():
+    """Inference rollouts of the split modes have no ln_apply launch for hidden1 / hidden3 (the norm is applied while lstm2 / lstm4 stage their patch);
+    Model.tap rebuilds the tensors on request, and the frames agree with a plan that keeps the separate launches (PIVP_LN_FOLD_LSTM is read once per
+    process, so the comparison is against the fp32 kernels' taps)."""
+    import pivp_amd
+    P = R.init_params(seed=1, dtype=np.float32, scale=1.0)
+    imgs, acts, stas = R.synthetic_batch(2, 4)
+    taps = {}
+    for prec in ('fp32', 'bf16x6', 'fp16x3'):
+        m = pivp_amd.Model(10, prefix='t', precision=prec)
+        m.load_state_dict_reference(P)
+        with pivp_amd.using_config('train', False):
+            m([imgs, acts, stas], 0)
+        taps[prec] = {k: m.tap(k).cpu().numpy() for k in ('hidden1', 'hidden2', 'hidden3', 'hidden4', 'hidden5')}
+    for prec in ('bf16x6', 'fp16x3'):
+        for k, v in taps[prec].items():
+            d = np.abs(v - taps['fp32'][k]).max()
+            assert d < 2e-5, (prec, k, d)
+
+
 def test_weight_packs_are_rebuilt_when_the_parameters_change():
     """The precision modes keep their weight packs across calls (pivp_plan_set_pack_cache) while the parameters are untouched; an in-place write through
     torch (its version counter) and the optimizer's own kernel (Model._params_epoch) must both invalidate them."""
