@@ -179,6 +179,10 @@ __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned shor
 // v_mfma_f32_32x32x16_bf16 whose 32 columns are the four gates of eight channels (lane (half, l31): gate l31 / 8, channel c8 * 8 + l31 % 8;
 // k = the k-step's channels half * 8 .. + 8) is 1 KB in lane order: one global_load_lds_dwordx4 of a wave moves exactly one fragment into
 // a lane-linear (conflict-free) kilobyte of the ring, one global_load_dwordx4 of a wave loads it straight into the MFMA's operand registers.
+#ifndef PIVP_X3_RD8
+#define PIVP_X3_RD8 0       // 1: the 4 x 2 two-fp16-piece kernel keeps EIGHT k-steps (two taps) of B fragments in flight instead of four (the counters show 30 % of
+                            // its wave cycles in s_waitcnt, almost none of it on LDS): measured 159.4 against 147.2 us for lstm3 / 4 / 6: slower, off
+#endif
 #ifndef PIVP_X3_DOUBLE
 #define PIVP_X3_DOUBLE 0    // 1: the eight-wave two-fp16-piece kernels take TWO k-steps (32 channels) per wait.  Built on the guess that their short k-step
 #endif                      // (3 MT MFMAs) pays a per-wait cost twice as often as the three-piece form; measured: 349.0 against 346.2 us per seven layers: off
@@ -1011,7 +1015,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     constexpr int NPJX = IN_LN ? 2 : 4;                // staging passes per round: 4 x 64 pixels cover the patch's 240 with 512 threads (IN_LN: gamma and beta
                                                        // travel with the pixels: two rounds of 2, or the prologue spills);
     constexpr int NRND = (PH * PW + NPJX * PPP - 1) / (NPJX * PPP);     // 256 threads take two rounds of 4 x 32 (eight passes in one round put the staged pixels in scratch)
-    constexpr int RD = NW == 8 ? 4 : 8;                // k-steps of B fragments in registers
+    constexpr int RD = (NW == 8 && !(PCS == 2 && NWM == 4 && PIVP_X3_RD8)) ? 4 : 8;      // k-steps of B fragments in registers
     PIVP_SET_MAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* const patch = lds;
