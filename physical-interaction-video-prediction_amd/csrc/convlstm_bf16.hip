@@ -179,6 +179,9 @@ __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned shor
 // v_mfma_f32_32x32x16_bf16 whose 32 columns are the four gates of eight channels (lane (half, l31): gate l31 / 8, channel c8 * 8 + l31 % 8;
 // k = the k-step's channels half * 8 .. + 8) is 1 KB in lane order: one global_load_lds_dwordx4 of a wave moves exactly one fragment into
 // a lane-linear (conflict-free) kilobyte of the ring, one global_load_dwordx4 of a wave loads it straight into the MFMA's operand registers.
+#ifndef PIVP_X6_READS_FIRST
+#define PIVP_X6_READS_FIRST 0      // 1: the fp16 kernels issue all A reads of the next k-step in front of a k-step's MFMAs (measured: 349.0 against 347.7 us: no change)
+#endif
 #ifndef PIVP_X3_RD8
 #define PIVP_X3_RD8 0       // 1: the 4 x 2 two-fp16-piece kernel keeps EIGHT k-steps (two taps) of B fragments in flight instead of four (the counters show 30 % of
                             // its wave cycles in s_waitcnt, almost none of it on LDS): measured 159.4 against 147.2 us for lstm3 / 4 / 6: slower, off
@@ -1216,7 +1219,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
 #define PIVP_X6_R(I) if constexpr (rd) read_a(NXT, KSN, std::integral_constant<int, I>{}, abn);
 #define PIVP_X6_S __builtin_amdgcn_sched_barrier(0);
         PIVP_X6_S
-        if constexpr (PCS == 2 && MT == 2) {
+        if constexpr (PIVP_X6_READS_FIRST && PCS == 2) {          // all reads of the next k-step in front of this one's MFMAs
+            PIVP_X6_R(0) PIVP_X6_R(1)
+            if constexpr (MT == 2) { PIVP_X6_R(2) PIVP_X6_R(3) }
+            PIVP_X6_S
+            PIVP_X6_M(0) PIVP_X6_M(1) mid(); PIVP_X6_M(2)
+            if constexpr (MT == 2) { PIVP_X6_M(3) PIVP_X6_M(4) PIVP_X6_M(5) }
+        } else if constexpr (PCS == 2 && MT == 2) {
             PIVP_X6_M(0) PIVP_X6_R(0) PIVP_X6_R(1) PIVP_X6_S
             PIVP_X6_M(1) PIVP_X6_R(2) PIVP_X6_R(3) PIVP_X6_S
             PIVP_X6_M(2) mid(); PIVP_X6_S
