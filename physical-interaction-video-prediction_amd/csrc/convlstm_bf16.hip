@@ -179,6 +179,11 @@ __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned shor
 // v_mfma_f32_32x32x16_bf16 whose 32 columns are the four gates of eight channels (lane (half, l31): gate l31 / 8, channel c8 * 8 + l31 % 8;
 // k = the k-step's channels half * 8 .. + 8) is 1 KB in lane order: one global_load_lds_dwordx4 of a wave moves exactly one fragment into
 // a lane-linear (conflict-free) kilobyte of the ring, one global_load_dwordx4 of a wave loads it straight into the MFMA's operand registers.
+#ifndef PIVP_X3_SHARE_B
+#define PIVP_X3_SHARE_B 0   // 1: the eight-wave two-fp16-piece kernels load every B fragment ONCE per block (one wave each) and hand it to the waves that share
+#endif                      // it through a two-slot LDS buffer with one block barrier per k-step, instead of every wave loading its own copy from L2.
+                            // Built because the timing-only variant WITHOUT the B loads runs 26-31 % faster (the MFMA-bound time); correct (tests, soak),
+                            // and 11 % SLOWER (388.3 against 348.8 us per seven layers): the duplicated L2 traffic was not what the loads cost
 #ifndef PIVP_X6_READS_FIRST
 #define PIVP_X6_READS_FIRST 0      // 1: the fp16 kernels issue all A reads of the next k-step in front of a k-step's MFMAs (measured: 349.0 against 347.7 us: no change)
 #endif
@@ -1160,8 +1165,17 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     patch_load(cgbase, 0);
     int tap = tap0, cg = cgbase, tap1 = tap0, cg1 = cgbase;
     adv(tap1, cg1);
+    constexpr bool SHB = PCS == 2 && NW == 8 && LSTM && PIVP_X3_SHARE_B && !PIVP_X3_DOUBLE && !PIVP_X3_RD8;
+    constexpr int NF = PCS * NWN;                      // fragments of a k-step of this block: [plane][wave column]
+    unsigned char* const bslot = lds + PCS * PB;       // SHB: two slots of NF KB behind the patch
+    const bool floader = wave8 < NF;                   // SHB: this wave fetches fragment wave8 = (plane wave8 / NWN, column wave8 % NWN) of every k-step
+    const unsigned fvoff = (unsigned)((wave8 / NWN) * pls + (nblk * NWN + (wave8 % NWN)) * 1024 + lane * 16);
+    bf16x8 Of[4];                                      // SHB: the own fragment of chunks c (register c & 3), four k-steps of lookahead
+    auto oload = [&](bf16x8& dst, unsigned soff) {
+        dst = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, fvoff, (int)soff, 0));
+    };
 #pragma unroll
-    for (int ks = 0; ks < ((PIVP_X6_MIDLOAD && RD == 4) ? 3 : 4); ++ks) bload(Bf[ks], (unsigned)(cg * 25 + tap) * tps + ks * kss);
+    for (int ks = 0; ks < (SHB ? 0 : ((PIVP_X6_MIDLOAD && RD == 4) ? 3 : 4)); ++ks) bload(Bf[ks], (unsigned)(cg * 25 + tap) * tps + ks * kss);
     if constexpr (RD == 8) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) bload(Bf[4 + ks], (unsigned)(cg1 * 25 + tap1) * tps + ks * kss);
@@ -1250,6 +1264,19 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
 #undef PIVP_X6_M
 #undef PIVP_X6_R
 #undef PIVP_X6_S
+    };
+    // (the shared-B loop waits for its fragments itself, in front of its barrier)
+    auto kstep_nowait = [&](auto CUR, auto NXT, auto KSN, unsigned abn, const bf16x8 (&b)[PCS], auto RD) {
+        constexpr bool rd = decltype(RD)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<3 * MT>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            mfma(CUR, I, b);
+            if constexpr (rd && 2 * i < PCS * MT) read_a(NXT, KSN, std::integral_constant<int, 2 * i>{}, abn);
+            if constexpr (rd && 2 * i + 1 < PCS * MT) read_a(NXT, KSN, std::integral_constant<int, 2 * i + 1>{}, abn);
+            if constexpr (2 * i < PCS * MT + 2) __builtin_amdgcn_sched_barrier(0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
     };
     using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
     using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
@@ -1371,6 +1398,65 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
                     const int m = (b0 * H + y0 + (i >> 4)) * W + x0 + (i & 15);
                     cpre[mt][k] = d.cstate_in[(size_t)m * C + ch];
                 }
+        }
+        if constexpr (SHB) {
+            // Chunk c = (tap, k-step) of this block's sequence.  Its NF fragments are fetched by NF waves (one each, four k-steps ahead, register
+            // Of[c & 3]), written to LDS slot c & 1 during k-step c - 2, read by every wave during k-step c - 1 and multiplied in k-step c.
+            // One barrier per k-step: behind it slot (c + 1) & 1 holds chunk c + 1 complete and slot c & 1 (chunk c, in registers by now) is free.
+            const int NQ = nchunks * 4;
+            bf16x8 bq[2][PCS];                          // [register set][plane]: the B fragments of the k-step in flight / in use
+            auto chunk_off = [&](int c) {               // byte offset of chunk c of this block's sequence (group, rotated tap, k-step)
+                const int tq = c >> 2, gg = tq / 25, tt = tq - gg * 25;
+                int tp = tap0 + tt; tp -= tp >= 25 ? 25 : 0;
+                return (unsigned)((cgbase + gg) * 25 + tp) * tps + (unsigned)(c & 3) * kss;
+            };
+            auto bread = [&](auto SET, int c) {          // fragments of chunk c from its slot (this wave's column, both planes)
+                constexpr int st = decltype(SET)::value;
+                const unsigned sb = lds0 + PCS * PB + (c & 1) * (NF * 1024) + wn * 1024 + lane * 16;
+#pragma unroll
+                for (int pl = 0; pl < PCS; ++pl) bq[st][pl] = lds_read_b128<0>(sb + pl * NWN * 1024);
+            };
+            auto bwrite = [&](const bf16x8& v, int c) {
+                *reinterpret_cast<bf16x8*>(bslot + (c & 1) * (NF * 1024) + wave8 * 1024 + lane * 16) = v;
+            };
+            if (g == 0) {
+                // prologue of the pipeline: chunks 0 and 1 into their slots, chunks 2..5 into the register ring
+                bf16x8 t0 = {}, t1 = {};
+                if (floader) {
+                    oload(t0, chunk_off(0)); oload(t1, chunk_off(1));
+                    oload(Of[2], chunk_off(2)); oload(Of[3], chunk_off(3)); oload(Of[0], chunk_off(4)); oload(Of[1], chunk_off(5));
+                    bwrite(t0, 0); bwrite(t1, 1);
+                }
+                __syncthreads();
+                bread(S0{}, 0);
+            }
+            read_a_all(a_base(tap));
+            for (int t = 0; t < 25; ++t) {
+                const unsigned ab = a_base(tap), ab1 = a_base(tap1);
+                const int c0q = (g * 25 + t) * 4;      // chunk index of this tap's k-step 0
+                auto step = [&](auto CUR, auto NXT, auto KSN, auto KS, unsigned abn, auto RD) {
+                    constexpr int st = decltype(CUR)::value, ks = decltype(KS)::value;
+                    const int c = c0q + ks;
+                    // this k-step's A and B fragments have landed; every LDS write of the previous k-step is done
+                    if constexpr (MT == 2) wait_lgkm(fa[st][0], fa[st][1], fal[st][0], fal[st][1], bq[st][0], bq[st][1]);
+                    else wait_lgkm(fa[st][0], fal[st][0], bq[st][0], bq[st][1]);
+                    __builtin_amdgcn_s_barrier();
+                    if (c + 1 < NQ) bread(NXT, c + 1);
+                    if (floader && c + 2 < NQ) {
+                        bwrite(Of[(ks + 2) & 3], c + 2);
+                        if (c + 6 < NQ) oload(Of[(ks + 2) & 3], chunk_off(c + 6));
+                    }
+                    kstep_nowait(CUR, NXT, KSN, abn, bq[st], RD);
+                };
+                step(S0{}, S1{}, K1{}, K0{}, ab, std::true_type{});
+                step(S1{}, S0{}, K2{}, K1{}, ab, std::true_type{});
+                step(S0{}, S1{}, K3{}, K2{}, ab, std::true_type{});
+                if (t < 24) step(S1{}, S0{}, K0{}, K3{}, ab1, std::true_type{});
+                else step(S1{}, S0{}, K0{}, K3{}, ab1, std::false_type{});
+                tap = tap1; cg = cg1;
+                adv(tap1, cg1);
+            }
+            continue;
         }
         if constexpr (DBL) {
             // two k-steps per wait: set 0 = k-steps 0, 1 of a tap, set 1 = k-steps 2, 3
@@ -1588,7 +1674,7 @@ static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t
 
 template <int NWM, int NWN, int PCS, bool IN_LN>
 static int launch_x6g_impl(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts) {
-    constexpr int lds_bytes = PCS * PH * RP16;
+    constexpr int lds_bytes = PCS * PH * RP16 + ((PCS == 2 && NWM * NWN == 8) ? 2 * PCS * NWN * 1024 : 0);       // (+ the shared-B slots of the fp16 forms)
     static PerDeviceOnce once;
     if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<NWM, NWN, true, PCS, IN_LN>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     IgemmDesc dd = d;
