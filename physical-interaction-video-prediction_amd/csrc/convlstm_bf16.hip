@@ -180,10 +180,11 @@ __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned shor
 // k = the k-step's channels half * 8 .. + 8) is 1 KB in lane order: one global_load_lds_dwordx4 of a wave moves exactly one fragment into
 // a lane-linear (conflict-free) kilobyte of the ring, one global_load_dwordx4 of a wave loads it straight into the MFMA's operand registers.
 #ifndef PIVP_X3_SHARE_B
-#define PIVP_X3_SHARE_B 0   // 1: the eight-wave two-fp16-piece kernels load every B fragment ONCE per block (one wave each) and hand it to the waves that share
-#endif                      // it through a two-slot LDS buffer with one block barrier per k-step, instead of every wave loading its own copy from L2.
-                            // Built because the timing-only variant WITHOUT the B loads runs 26-31 % faster (the MFMA-bound time); correct (tests, soak),
-                            // and 11 % SLOWER (388.3 against 348.8 us per seven layers): the duplicated L2 traffic was not what the loads cost
+#define PIVP_X3_SHARE_B 0   // 1: the eight-wave two-fp16-piece kernels load every B fragment ONCE per block (one wave each, a tap ahead) and hand it to the waves
+#endif                      // that share it through two LDS slots of a tap's fragments, one block barrier per tap, instead of every wave loading its own copy
+                            // from L2.  Built because the timing-only variant WITHOUT the B loads runs 26-31 % faster (the MFMA-bound time).  Correct (tests,
+                            // 60 bit-identical rollouts) and SLOWER: 389.3 against 360.3 us per seven layers with the barrier per tap, 388.3 against 348.8
+                            // with one per k-step (the first form): neither the duplicated L2 traffic nor the barrier count is what the loads cost
 #ifndef PIVP_X6_READS_FIRST
 #define PIVP_X6_READS_FIRST 0      // 1: the fp16 kernels issue all A reads of the next k-step in front of a k-step's MFMAs (measured: 349.0 against 347.7 us: no change)
 #endif
@@ -1167,7 +1168,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     adv(tap1, cg1);
     constexpr bool SHB = PCS == 2 && NW == 8 && LSTM && PIVP_X3_SHARE_B && !PIVP_X3_DOUBLE && !PIVP_X3_RD8;
     constexpr int NF = PCS * NWN;                      // fragments of a k-step of this block: [plane][wave column]
-    unsigned char* const bslot = lds + PCS * PB;       // SHB: two slots of NF KB behind the patch
+    unsigned char* const bslot = lds + PCS * PB;       // SHB: two slots of a tap's fragments (4 NF KB each) behind the patch
     const bool floader = wave8 < NF;                   // SHB: this wave fetches fragment wave8 = (plane wave8 / NWN, column wave8 % NWN) of every k-step
     const unsigned fvoff = (unsigned)((wave8 / NWN) * pls + (nblk * NWN + (wave8 % NWN)) * 1024 + lane * 16);
     bf16x8 Of[4];                                      // SHB: the own fragment of chunks c (register c & 3), four k-steps of lookahead
@@ -1210,6 +1211,15 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
         constexpr int st = decltype(CUR)::value, i = decltype(I)::value, term = i / MT, mt = i % MT;
         if constexpr (PCS == 2) {      // fp16 pieces: lo * hi, hi * lo into the corrections, hi * hi into the main accumulator
             auto h = [](const bf16x8& v) { return __builtin_bit_cast(f16x8, v); };
+            if constexpr (PIVP_X6_ABL & 32) {   // timing only: the loads are issued and kept alive (sink below), the MFMAs take the A fragments for B too
+                if constexpr (term == 0) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fal[st][mt]), h(fa[st][0]), accl[mt], 0, 0, 0);
+                else if constexpr (term == 1) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[st][mt]), h(fal[st][0]), accl[mt], 0, 0, 0);
+                else acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[st][mt]), h(fa[st][0]), acc[mt], 0, 0, 0);
+                // 32: the loaded registers are consumed (an empty asm: the compiler waits for the load as it would for an MFMA); 32 | 64: never consumed (loads
+                // issued, nobody waits -- the compiler still has to keep the ring registers, so the loads are not removed: they feed the next reload's WAW order)
+                if constexpr (i == 0 && !(PIVP_X6_ABL & 64)) asm volatile("" :: "v"(b[0]), "v"(b[1]));
+                return;
+            }
             if constexpr (term == 0) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fal[st][mt]), h(b[0]), accl[mt], 0, 0, 0);
             else if constexpr (term == 1) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[st][mt]), h(b[1]), accl[mt], 0, 0, 0);
             else acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[st][mt]), h(b[0]), acc[mt], 0, 0, 0);
@@ -1400,59 +1410,76 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
                 }
         }
         if constexpr (SHB) {
-            // Chunk c = (tap, k-step) of this block's sequence.  Its NF fragments are fetched by NF waves (one each, four k-steps ahead, register
-            // Of[c & 3]), written to LDS slot c & 1 during k-step c - 2, read by every wave during k-step c - 1 and multiplied in k-step c.
-            // One barrier per k-step: behind it slot (c + 1) & 1 holds chunk c + 1 complete and slot c & 1 (chunk c, in registers by now) is free.
-            const int NQ = nchunks * 4;
+            // Tap T of this block's sequence (all groups) has NF fragments per k-step.  NF waves fetch one each (a tap ahead, registers Of[k-step]) and
+            // write tap T + 1's into LDS slot (T + 1) & 1 during the first three k-steps of tap T; every wave reads its two planes from slot T & 1.
+            // ONE barrier per tap, at the top of its last k-step: behind it slot (T + 1) & 1 is complete (so the first fragments of tap T + 1 can be
+            // requested) and slot T & 1, whose last fragments are in registers by then, is free for tap T + 2.
+            const int NT25 = nchunks;
             bf16x8 bq[2][PCS];                          // [register set][plane]: the B fragments of the k-step in flight / in use
-            auto chunk_off = [&](int c) {               // byte offset of chunk c of this block's sequence (group, rotated tap, k-step)
-                const int tq = c >> 2, gg = tq / 25, tt = tq - gg * 25;
+            constexpr int SLOT = 4 * NF * 1024;         // bytes of a tap's fragments
+            auto tap_off = [&](int T) {                 // byte offset of tap T's weights (group, rotated tap)
+                const int gg = T / 25, tt = T - gg * 25;
                 int tp = tap0 + tt; tp -= tp >= 25 ? 25 : 0;
-                return (unsigned)((cgbase + gg) * 25 + tp) * tps + (unsigned)(c & 3) * kss;
+                return (unsigned)((cgbase + gg) * 25 + tp) * tps;
             };
-            auto bread = [&](auto SET, int c) {          // fragments of chunk c from its slot (this wave's column, both planes)
+            auto bread = [&](auto SET, int T, int ks) {  // fragments of (tap T, k-step ks): this wave's column, both planes
                 constexpr int st = decltype(SET)::value;
-                const unsigned sb = lds0 + PCS * PB + (c & 1) * (NF * 1024) + wn * 1024 + lane * 16;
+                const unsigned sb = lds0 + PCS * PB + (T & 1) * SLOT + ks * (NF * 1024) + wn * 1024 + lane * 16;
 #pragma unroll
                 for (int pl = 0; pl < PCS; ++pl) bq[st][pl] = lds_read_b128<0>(sb + pl * NWN * 1024);
             };
-            auto bwrite = [&](const bf16x8& v, int c) {
-                *reinterpret_cast<bf16x8*>(bslot + (c & 1) * (NF * 1024) + wave8 * 1024 + lane * 16) = v;
+            auto bwrite = [&](const bf16x8& v, int T, int ks) {
+                *reinterpret_cast<bf16x8*>(bslot + (T & 1) * SLOT + ks * (NF * 1024) + wave8 * 1024 + lane * 16) = v;
             };
-            if (g == 0) {
-                // prologue of the pipeline: chunks 0 and 1 into their slots, chunks 2..5 into the register ring
-                bf16x8 t0 = {}, t1 = {};
+            if (g == 0) {                                // tap 0 into slot 0, tap 1 into the registers
                 if (floader) {
-                    oload(t0, chunk_off(0)); oload(t1, chunk_off(1));
-                    oload(Of[2], chunk_off(2)); oload(Of[3], chunk_off(3)); oload(Of[0], chunk_off(4)); oload(Of[1], chunk_off(5));
-                    bwrite(t0, 0); bwrite(t1, 1);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) oload(Of[ks], tap_off(0) + ks * kss);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) bwrite(Of[ks], 0, ks);
+                    if (NT25 > 1) {
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) oload(Of[ks], tap_off(1) + ks * kss);
+                    }
                 }
                 __syncthreads();
-                bread(S0{}, 0);
+                bread(S0{}, 0, 0);
             }
             read_a_all(a_base(tap));
             for (int t = 0; t < 25; ++t) {
                 const unsigned ab = a_base(tap), ab1 = a_base(tap1);
-                const int c0q = (g * 25 + t) * 4;      // chunk index of this tap's k-step 0
-                auto step = [&](auto CUR, auto NXT, auto KSN, auto KS, unsigned abn, auto RD) {
-                    constexpr int st = decltype(CUR)::value, ks = decltype(KS)::value;
-                    const int c = c0q + ks;
-                    // this k-step's A and B fragments have landed; every LDS write of the previous k-step is done
+                const int T = g * 25 + t;
+                const bool w1 = floader && T + 1 < NT25, l2 = floader && T + 2 < NT25;
+                const unsigned o2 = l2 ? tap_off(T + 2) : 0u;
+                auto waitf = [&](auto CUR) {
+                    constexpr int st = decltype(CUR)::value;
                     if constexpr (MT == 2) wait_lgkm(fa[st][0], fa[st][1], fal[st][0], fal[st][1], bq[st][0], bq[st][1]);
                     else wait_lgkm(fa[st][0], fal[st][0], bq[st][0], bq[st][1]);
-                    __builtin_amdgcn_s_barrier();
-                    if (c + 1 < NQ) bread(NXT, c + 1);
-                    if (floader && c + 2 < NQ) {
-                        bwrite(Of[(ks + 2) & 3], c + 2);
-                        if (c + 6 < NQ) oload(Of[(ks + 2) & 3], chunk_off(c + 6));
-                    }
-                    kstep_nowait(CUR, NXT, KSN, abn, bq[st], RD);
                 };
-                step(S0{}, S1{}, K1{}, K0{}, ab, std::true_type{});
-                step(S1{}, S0{}, K2{}, K1{}, ab, std::true_type{});
-                step(S0{}, S1{}, K3{}, K2{}, ab, std::true_type{});
-                if (t < 24) step(S1{}, S0{}, K0{}, K3{}, ab1, std::true_type{});
-                else step(S1{}, S0{}, K0{}, K3{}, ab1, std::false_type{});
+                // k-step 0: tap T + 1's fragments of k-steps 0, 1 go to their slot
+                waitf(S0{});
+                bread(S1{}, T, 1);
+                if (w1) { bwrite(Of[0], T + 1, 0); bwrite(Of[1], T + 1, 1); }
+                if (l2) { oload(Of[0], o2); oload(Of[1], o2 + kss); }
+                kstep_nowait(S0{}, S1{}, K1{}, ab, bq[0], std::true_type{});
+                // k-step 1
+                waitf(S1{});
+                bread(S0{}, T, 2);
+                if (w1) bwrite(Of[2], T + 1, 2);
+                if (l2) oload(Of[2], o2 + 2 * kss);
+                kstep_nowait(S1{}, S0{}, K2{}, ab, bq[1], std::true_type{});
+                // k-step 2
+                waitf(S0{});
+                bread(S1{}, T, 3);
+                if (w1) bwrite(Of[3], T + 1, 3);
+                if (l2) oload(Of[3], o2 + 3 * kss);
+                kstep_nowait(S0{}, S1{}, K3{}, ab, bq[0], std::true_type{});
+                // k-step 3: the tap's barrier (every LDS write above is complete: lgkmcnt(0) in waitf)
+                waitf(S1{});
+                __builtin_amdgcn_s_barrier();
+                if (T + 1 < NT25) bread(S0{}, T + 1, 0);
+                if (t < 24) kstep_nowait(S1{}, S0{}, K0{}, ab1, bq[1], std::true_type{});
+                else kstep_nowait(S1{}, S0{}, K0{}, ab1, bq[1], std::false_type{});
                 tap = tap1; cg = cg1;
                 adv(tap1, cg1);
             }
@@ -1674,7 +1701,7 @@ static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t
 
 template <int NWM, int NWN, int PCS, bool IN_LN>
 static int launch_x6g_impl(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts) {
-    constexpr int lds_bytes = PCS * PH * RP16 + ((PCS == 2 && NWM * NWN == 8) ? 2 * PCS * NWN * 1024 : 0);       // (+ the shared-B slots of the fp16 forms)
+    constexpr int lds_bytes = PCS * PH * RP16 + ((PCS == 2 && NWM * NWN == 8 && PIVP_X3_SHARE_B) ? 2 * 4 * PCS * NWN * 1024 : 0);       // (+ the shared-B tap slots of the fp16 forms)
     static PerDeviceOnce once;
     if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<NWM, NWN, true, PCS, IN_LN>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     IgemmDesc dd = d;
