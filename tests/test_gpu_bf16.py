@@ -478,6 +478,25 @@ def test_split_modes_apply_hidden1_and_hidden3_inside_lstm2_and_lstm4():
             assert d < 2e-5, (prec, k, d)
 
 
+def test_split_entry_points_refuse_what_they_cannot_serve():
+    """The new C entry points return PIVP_ERR_BADARG (-1) for shapes their kernels do not take, before any launch."""
+    lib = __import__('pivp_amd')._lib.load()
+    z = torch.zeros(1 << 22, device='cuda')
+    p = z.data_ptr()
+    # three bf16 pieces: 8-wide map (no fp32 weights to fall back on in the per-op call), channels not a multiple of 16, bad block code
+    assert lib.pivp_convlstm_bf16x6(p, 64, 64, p, 128, p, p, p, p, p, None, None, 0, None, 2, 8, 8, 0, None) == -1
+    assert lib.pivp_convlstm_bf16x6(p, 32, 32, p, 24, p, p, p, p, p, None, None, 0, None, 2, 16, 16, 0, None) == -1
+    assert lib.pivp_convlstm_bf16x6(p, 32, 32, p, 32, p, p, p, p, p, None, None, 0, None, 2, 16, 16, 7, None) == -1
+    # two fp16 pieces: odd batch on an 8-wide map, map height not a multiple of 8, missing buffers
+    assert lib.pivp_convlstm_fp16x3(p, 64, 64, p, 128, p, p, p, p, p, None, None, 0, None, 3, 8, 8, 0, None) == -1
+    assert lib.pivp_convlstm_fp16x3(p, 32, 32, p, 32, p, p, p, p, p, None, None, 0, None, 2, 12, 16, 0, None) == -1
+    assert lib.pivp_convlstm_fp16x3(p, 32, 32, p, 32, None, p, p, p, p, None, None, 0, None, 2, 16, 16, 0, None) == -1
+    assert lib.pivp_pack_lstm_fp16x3(p, p, 64, 32, 0, None) == -1
+    assert lib.pivp_conv5x5_bf16x6(p, 128, 128, p, p, p, 64, 64, 0, 2, 8, 8, None) == -1            # 8-wide map
+    assert lib.pivp_deconv3x3s2_fp16x3(p, 64, 64, p, p, p, 64, 64, 1, 2, 32, 32, None, None) == -1   # no scratch for the weights' scale
+    torch.cuda.synchronize()
+
+
 def test_weight_packs_are_rebuilt_when_the_parameters_change():
     """The precision modes keep their weight packs across calls (pivp_plan_set_pack_cache) while the parameters are untouched; an in-place write through
     torch (its version counter) and the optimizer's own kernel (Model._params_epoch) must both invalidate them."""
