@@ -1012,18 +1012,23 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
 // IN_LN: the x operand (d.x0, c0 <= 64 channels) is a RAW ConvLSTM output whose LayerNorm (per-element gamma / beta d.in_g / d.in_b [H W][c0], statistics
 // merged from the producer's partials d.in_part) is applied while the patch is staged -- the expression of ln_apply_kernel; out-of-image pixels load 0
 // for v, gamma and beta alike and stay 0.  Inference rollouts: hidden1 -> lstm2 and hidden3 -> lstm4 lose their ln_apply launch.
-template <int NWM, int NWN, bool LSTM = true, int PCS = 3, bool IN_LN = false>
+// THX = 16 (two fp16 pieces, 4 x 2 waves): tiles of 16 x 16 anchors -- 256 anchors x 16 channels per block, a wave tile of 64 anchors.  The weight bytes a
+// block pulls from L2 per multiply-add halve (the 8-row forms pull ~6.0-6.6 TB/s of unique fragment bytes out of L2 in every layer); the two 20 x 20
+// patch planes take 120 KB.  Correct and tested (nch = 256), and not faster: see convlstm_bf16()'s note.  An option, off.
+template <int NWM, int NWN, bool LSTM = true, int PCS = 3, bool IN_LN = false, int THX = TH>
 __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int wbytes, int ncols) {
-    constexpr int PB = PH * RP16;                      // one patch plane: 36,864 B
+    constexpr int PHX = THX + 4;                       // patch rows
+    constexpr int PB = PHX * RP16;                     // one patch plane: 36,864 B (61,440 B with 16 anchor rows)
     static_assert(PCS == 3 || (PCS == 2 && LSTM), "pieces");
+    static_assert(THX == TH || (THX == 16 && PCS == 2 && NWM == 4 && NWN == 2), "16-row tiles: the fp16 form with 4 x 2 waves");
     constexpr int PW = 20;
     constexpr int NW = NWM * NWN;                      // waves
-    constexpr int MT = 4 / NWM;                        // 32-anchor M tiles per wave
+    constexpr int MT = THX / 2 / NWM;                  // 32-anchor M tiles per wave
     constexpr int NT = 64 * NW;                        // threads
     constexpr int PPP = NT / 8;                        // patch pixels per staging pass
     constexpr int NPJX = IN_LN ? 2 : 4;                // staging passes per round: 4 x 64 pixels cover the patch's 240 with 512 threads (IN_LN: gamma and beta
                                                        // travel with the pixels: two rounds of 2, or the prologue spills);
-    constexpr int NRND = (PH * PW + NPJX * PPP - 1) / (NPJX * PPP);     // 256 threads take two rounds of 4 x 32 (eight passes in one round put the staged pixels in scratch)
+    constexpr int NRND = (PHX * PW + NPJX * PPP - 1) / (NPJX * PPP);     // 256 threads take two rounds of 4 x 32 (eight passes in one round put the staged pixels in scratch)
     constexpr int RD = (NW == 8 && !(PCS == 2 && NWM == 4 && PIVP_X3_RD8)) ? 4 : 8;      // k-steps of B fragments in registers
     PIVP_SET_MAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1035,13 +1040,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     const int C = d.C;
     const int n_nblk = LSTM ? C / (8 * NWN) : d.N / (32 * NWN);      // (plain: d.N = rows of the padded pack, a multiple of 64)
     const int H = d.Hin, W = d.Win;
-    const int tpr = W / 16, tpi = (H / TH) * tpr;
+    const int tpr = W / 16, tpi = (H / THX) * tpr;
     const int n_tiles = d.B * tpi;
     int lid = blockIdx.x;
     if ((gridDim.x & 7) == 0) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware, column-block major
     const int nblk = lid / n_tiles, tile = lid - nblk * n_tiles;
     const int b0 = tile / tpi, trem = tile - b0 * tpi;
-    const int y0 = (trem / tpr) * TH, x0 = (trem - (trem / tpr) * tpr) * 16;
+    const int y0 = (trem / tpr) * THX, x0 = (trem - (trem / tpr) * tpr) * 16;
     BF_STAMP(0);
     const int c0 = d.c0, ld0 = d.ld0, ld1 = d.ld1;
     const int cin = c0 + d.c1;
@@ -1061,9 +1066,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
         const int p = (tid >> 3) + PPP * j;
         const int py = p / PW, px = p - py * PW;
         const int iy = y0 - 2 + py, ix = x0 - 2 + px;
-        const bool ok = p < PH * PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const bool ok = p < PHX * PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
         a_pix = ok ? (b0 * H + iy) * W + ix : -1;
-        a_lds = p < PH * PW ? py * RP16 + px * PP : PW * PP;
+        a_lds = p < PHX * PW ? py * RP16 + px * PP : PW * PP;
     };
     f32x4 plo[NPJX], phi[NPJX];
     f32x4 glo[IN_LN ? NPJX : 1], ghi[IN_LN ? NPJX : 1], blo[IN_LN ? NPJX : 1], bhi[IN_LN ? NPJX : 1];      // IN_LN: gamma / beta of the staged pieces
@@ -1187,7 +1192,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     float bj = 0.f, bi = 0.f, bf = 0.f, bo = 0.f;
     float cpre[MT][4];
     patch_store(0, cgbase);
-    if constexpr (NRND == 2) { patch_load(cgbase, 1); patch_store(1, cgbase); }
+#pragma unroll
+    for (int rnd = 1; rnd < NRND; ++rnd) { patch_load(cgbase, rnd); patch_store(rnd, cgbase); }
     BF_STAMP(1);
     __syncthreads();
     BF_STAMP(2);
@@ -1372,9 +1378,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
             if (has2) bload(Bf[4 * p + 3], so2 + 3 * kss);
             if (regroup) {                             // next 64 input channels: every wave is done with the old patch
                 __syncthreads();
-                patch_load(cg1, 0);
-                patch_store(0, cg1);
-                if constexpr (NRND == 2) { patch_load(cg1, 1); patch_store(1, cg1); }
+#pragma unroll
+                for (int rnd = 0; rnd < NRND; ++rnd) { patch_load(cg1, rnd); patch_store(rnd, cg1); }
                 __syncthreads();
                 read_a_all(ab1);
             }
@@ -1390,9 +1395,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     for (int g = 0; g < ncg; ++g) {                    // 64 input channels of concat(x, h) at a time
         if (g > 0) {                                   // every wave is done with the old patch
             __syncthreads();
-            patch_load(cgbase + g, 0);
-            patch_store(0, cgbase + g);
-            if constexpr (NRND == 2) { patch_load(cgbase + g, 1); patch_store(1, cgbase + g); }
+#pragma unroll
+            for (int rnd = 0; rnd < NRND; ++rnd) { patch_load(cgbase + g, rnd); patch_store(rnd, cgbase + g); }
             __syncthreads();
         }
         if (LSTM && g == ncg - 1) {
@@ -1699,31 +1703,33 @@ static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t
     return PIVP_LAUNCH_STATUS();
 }
 
-template <int NWM, int NWN, int PCS, bool IN_LN>
+template <int NWM, int NWN, int PCS, bool IN_LN, int THX = TH>
 static int launch_x6g_impl(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts) {
-    constexpr int lds_bytes = PCS * PH * RP16 + ((PCS == 2 && NWM * NWN == 8 && PIVP_X3_SHARE_B) ? 2 * 4 * PCS * NWN * 1024 : 0);       // (+ the shared-B tap slots of the fp16 forms)
+    constexpr int lds_bytes = PCS * (THX + 4) * RP16 + ((PCS == 2 && NWM * NWN == 8 && THX == TH && PIVP_X3_SHARE_B) ? 2 * 4 * PCS * NWN * 1024 : 0);       // (+ the shared-B tap slots of the fp16 forms)
+    static_assert(lds_bytes <= 160 * 1024, "LDS");
     static PerDeviceOnce once;
-    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<NWM, NWN, true, PCS, IN_LN>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<NWM, NWN, true, PCS, IN_LN, THX>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
+    PIVP_CHECK_ARG(d.Hin % THX == 0);
     IgemmDesc dd = d;
-    const int tpi = (d.Hin / TH) * (d.Win / 16), nb = d.C / (8 * NWN);
+    const int tpi = (d.Hin / THX) * (d.Win / 16), nb = d.C / (8 * NWN);
     const int np = tpi * nb;
     dd.ln_nparts = (d.ln_part && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
     const long long wbytes = (long long)lstm_bf16_weight_elems(d.c0 + (d.c1 ? d.c1 : d.C), 4 * d.C) * PCS * 2;
     if (wbytes >= (1LL << 31)) return PIVP_ERR_BADARG;
-    hipLaunchKernelGGL((convlstm_x6g_kernel<NWM, NWN, true, PCS, IN_LN>), dim3(d.B * tpi * nb), dim3(64 * NWM * NWN), lds_bytes, stream, dd, wb, (int)wbytes, 0);
+    hipLaunchKernelGGL((convlstm_x6g_kernel<NWM, NWN, true, PCS, IN_LN, THX>), dim3(d.B * tpi * nb), dim3(64 * NWM * NWN), lds_bytes, stream, dd, wb, (int)wbytes, 0);
     return PIVP_LAUNCH_STATUS();
 }
-template <int NWM, int NWN, int PCS = 3>
+template <int NWM, int NWN, int PCS = 3, int THX = TH>
 static int launch_x6g(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts) {
     if (d.in_g) {       // the x operand's LayerNorm applied while staging (eight-wave forms only; x in one 64-channel group)
         if constexpr (NWM * NWN == 8) {
             PIVP_CHECK_ARG(d.in_b && d.in_part && d.in_np > 0 && d.c0 <= 64 && d.ld0 == d.c0 && d.in_part != d.ln_part);
-            return launch_x6g_impl<NWM, NWN, PCS, true>(d, wb, stream, ln_nparts);
+            return launch_x6g_impl<NWM, NWN, PCS, true, THX>(d, wb, stream, ln_nparts);
         } else return PIVP_ERR_BADARG;
     }
-    return launch_x6g_impl<NWM, NWN, PCS, false>(d, wb, stream, ln_nparts);
+    return launch_x6g_impl<NWM, NWN, PCS, false, THX>(d, wb, stream, ln_nparts);
 }
 
 // the plain 5x5 convolution on the same kernel: dd.N = rows of the padded pack, nb = its 64-column blocks, ks = split of the channel groups
@@ -1740,7 +1746,8 @@ static int launch_x6g_plain(const IgemmDesc& dd, const unsigned short* wb, hipSt
 
 // d as for igemm_lstm (validated by the caller's igemm_validate(d, true) equivalent); wb = pack_lstm_bf16(d.w, ..., planes).
 int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nch, int planes) {
-    PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0) || ((nch == 1 || nch == 2) && planes == 3)) &&
+    PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0) || ((nch == 1 || nch == 2) && planes == 3) ||
+                                                 (nch == 256 && planes == -2 && d.Hin % 16 == 0 && d.Win % 16 == 0)) &&
                    ((planes >= 1 && planes <= 3) || planes == -2));
     if (planes == -2 && !convlstm_bf16x6_ok(d)) {   // 8-wide maps: the ring kernel with fp16 pieces (wb = pack_lstm_bf16(..., planes = -2, plain = 2))
         const int tw2 = 8, ti2 = 2;
@@ -1750,6 +1757,12 @@ int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stre
     }
     if (planes == -2) {   // two fp16 pieces, three MFMAs per product (wb = pack_lstm_bf16(..., planes = -2)): the L2-direct kernel, 16-wide tiles
         PIVP_CHECK_ARG(convlstm_bf16x6_ok(d));
+        // 16 x 16 tiles (256 anchors x 16 channels per block: half the weight bytes out of L2 per multiply-add) where they still give every CU a block:
+        // PIVP_X3_TH16=1 or nch = 256.  MEASURED (profiles/r04/fp16x3_layers_tile16_ab.txt): lstm1 / 2 / 7 41.8 / 41.7 / 72.9 us against 40.5 / 40.7 / 71.1 with
+        // 8-row tiles -- the weight stream was never the bound (clock_power_operand_values.txt: these loops run power-limited at 1.82 GHz).  Off.
+        static const int th16 = [] { const char* e = getenv("PIVP_X3_TH16"); return e ? atoi(e) : 0; }();
+        const long b256 = d.Hin % 16 ? 0 : (long)d.B * (d.Hin / 16) * (d.Win / 16) * (d.C / 16);
+        if (nch == 256 || (nch == 0 && th16 && b256 >= pivp_cu_count())) return launch_x6g<4, 2, 2, 16>(d, wb, stream, ln_nparts);
         const long b32 = d.C % 32 ? 0 : (long)d.B * (d.Hin / TH) * (d.Win / 16) * (d.C / 32);
         if ((nch == 32 && b32 > 0) || (nch == 0 && b32 >= pivp_cu_count())) return launch_x6g<2, 4, 2>(d, wb, stream, ln_nparts);
         return launch_x6g<4, 2, 2>(d, wb, stream, ln_nparts);

@@ -49,7 +49,7 @@ int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, co
     // (two fp16 pieces: 8-wide maps take the ring kernel's fp16 form when its tiles fit -- an even batch --, whose pack is laid out differently: the caller's)
     if (w_bf16 && !convlstm_bf16x6_ok(d) && (bf16_planes == 3 || (bf16_planes == -2 && !convlstm_bf16_ok(d)))) return w ? igemm_lstm(d, s, 0, ln_nparts) : PIVP_ERR_BADARG;
     if (w_bf16) return convlstm_bf16(d, w_bf16, s, ln_nparts, ((bf16_planes == 3 && variant != 1 && variant != 2 && variant != 16 && variant != 32) ||
-                                                        (bf16_planes == -2 && variant != 16 && variant != 32)) ? 0 : variant, bf16_planes);
+                                                        (bf16_planes == -2 && variant != 16 && variant != 32 && variant != 256)) ? 0 : variant, bf16_planes);
     return igemm_lstm(d, s, variant, ln_nparts);
 }
 
@@ -510,7 +510,7 @@ extern "C" int pivp_pack_lstm_fp16x3(const float* w, void* w_bf16, int cin_total
 extern "C" int pivp_convlstm_fp16x3(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
                                     const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
                                     int* ln_nparts, int B, int H, int W, int nch, void* stream) {
-    if (!x || !w_bf16 || !bias || !c_in || !c_out || !h_out || (nch != 0 && nch != 16 && nch != 32)) return PIVP_ERR_BADARG;
+    if (!x || !w_bf16 || !bias || !c_in || !c_out || !h_out || (nch != 0 && nch != 16 && nch != 32 && nch != 256)) return PIVP_ERR_BADARG;
     return run_convlstm(x, cx, ldx, h_prev, C, nullptr, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, nch, gates_out,
                         ln_part, ln_cap, ln_nparts, (const unsigned short*)w_bf16, -2);
 }

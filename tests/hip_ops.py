@@ -109,8 +109,9 @@ def convlstm_bf16x6(x, h, c, W, b, h_is_zero=False, nch=0, want_ln=False):
     return nchw(h_out, B, H, Wd, C), nchw(c_out, B, H, Wd, C)
 
 
-def convlstm_fp16x3(x, h, c, W, b, h_is_zero=False, nch=0):
+def convlstm_fp16x3(x, h, c, W, b, h_is_zero=False, nch=0, want_ln=False):
     """Two-fp16-piece ConvLSTM (three fp16 MFMAs per product, weights packed times a power of two); returns (h, c)."""
+    import ctypes
     lib = _lib.load()
     B, cx, H, Wd = x.shape
     C = h.shape[1]
@@ -119,10 +120,17 @@ def convlstm_fp16x3(x, h, c, W, b, h_is_zero=False, nch=0):
     wb = torch.empty(2 * lib.pivp_lstm_bf16_weight_elems(cx + C, C) + 256, dtype=torch.int16, device=DEV)     # + the scale's tail
     _lib.check(lib.pivp_pack_lstm_fp16x3(wd.data_ptr(), wb.data_ptr(), cx + C, C, Wd, stream()), 'pack_lstm_fp16x3')
     c_out = torch.empty_like(cd); h_out = torch.empty_like(hd)
+    cap = 4096
+    part = torch.zeros(B * cap * 4, dtype=torch.float32, device=DEV)
+    npart = ctypes.c_int(-1)
     _lib.check(lib.pivp_convlstm_fp16x3(xd.data_ptr(), cx, cx, None if h_is_zero else hd.data_ptr(), C, wb.data_ptr(), bd.data_ptr(),
-                                        cd.data_ptr(), c_out.data_ptr(), h_out.data_ptr(), None, None, 0, None, B, H, Wd, nch, stream()),
+                                        cd.data_ptr(), c_out.data_ptr(), h_out.data_ptr(), None, part.data_ptr() if want_ln else None, cap,
+                                        ctypes.addressof(npart) if want_ln else None, B, H, Wd, nch, stream()),
                'convlstm_fp16x3')
     torch.cuda.synchronize()
+    if want_ln:
+        n = npart.value
+        return nchw(h_out, B, H, Wd, C), nchw(c_out, B, H, Wd, C), (part.cpu().numpy().reshape(-1)[:B * n * 4].reshape(B, n, 4) if n > 0 else None, n)
     return nchw(h_out, B, H, Wd, C), nchw(c_out, B, H, Wd, C)
 
 

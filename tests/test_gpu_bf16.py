@@ -392,9 +392,11 @@ def test_conv5x5_bf16x6(ops, B, cin, cout, H):
 
 
 # ---- two fp16 pieces per operand, three MFMAs per product (weights packed times 2^8): 22-bit operands, forward only ---------------------------
-@pytest.mark.parametrize('nch', [16, 32])
+@pytest.mark.parametrize('nch', [16, 32, 256])   # 256: 16 channels on tiles of 16 x 16 anchors
 @pytest.mark.parametrize('B,cx,C,H', X6_SHAPES + [(4, 64, 128, 8), (2, 32, 32, 8), (32, 64, 128, 8)])       # 8-wide maps: the ring kernel's fp16 form
 def test_convlstm_fp16x3_is_fp32_grade(ops, B, cx, C, H, nch):
+    if nch == 256 and H % 16:
+        pytest.skip('16-row tiles need H % 16 == 0')
     x, h, c, W, b = [np.asarray(a, dtype=np.float32).astype(np.float64) for a in _case(B, cx, C, H, 231 + C + H)]
     hr, cr, _ = _lstm_ref(x, h, c, W, b)
     if nch == 32 and C % 32:
@@ -424,6 +426,26 @@ def test_convlstm_fp16x3_ranges(ops):
     h3, c3 = ops.convlstm_fp16x3(x, h, c, W, b, h_is_zero=True)
     hr, cr, _ = _lstm_ref(x, h * 0, c, W, b)
     assert np.abs(h3 - hr).max() < 3e-6 and np.abs(c3 - cr).max() < 3e-6
+
+
+def test_convlstm_fp16x3_tile_forms_agree(ops):
+    # 8 x 16 tiles (16- and 32-channel blocks) against 16 x 16 tiles: the same terms in another tap rotation; the LayerNorm partials of each epilogue;
+    # t = 0 (no h operand) on the 16-row tiles
+    xa, ha, ca, Wa, ba = [np.asarray(a, dtype=np.float32).astype(np.float64) for a in _case(2, 96, 32, 32, 9)]
+    h16, c16, (p16, n16) = ops.convlstm_fp16x3(xa, ha, ca, Wa, ba, nch=16, want_ln=True)
+    h32, c32, (p32, n32) = ops.convlstm_fp16x3(xa, ha, ca, Wa, ba, nch=32, want_ln=True)
+    h256, c256, (p256, n256) = ops.convlstm_fp16x3(xa, ha, ca, Wa, ba, nch=256, want_ln=True)
+    assert np.abs(h16 - h256).max() < 2e-6 and np.abs(c16 - c256).max() < 2e-6 and np.abs(h32 - h256).max() < 2e-6
+    assert n16 == 16 and n32 == 8 and n256 == 8       # tiles per image x channel blocks: 8 x 2, 8 x 1, 4 x 2
+    for pp, hh in ((p16, h16), (p32, h32), (p256, h256)):
+        cnt = pp[:, :, 0].sum(axis=1)
+        mean = (pp[:, :, 0] * pp[:, :, 1]).sum(axis=1) / cnt
+        var = (pp[:, :, 2] + pp[:, :, 0] * (pp[:, :, 1] - mean[:, None]) ** 2).sum(axis=1) / cnt
+        assert np.allclose(cnt, 32 * 32 * 32) and np.allclose(mean, hh.reshape(2, -1).mean(axis=1), atol=1e-6)
+        assert np.allclose(var, hh.reshape(2, -1).var(axis=1), rtol=1e-4)
+    hr, cr, _ = _lstm_ref(xa, ha * 0, ca, Wa, ba)
+    h0, c0 = ops.convlstm_fp16x3(xa, ha, ca, Wa, ba, h_is_zero=True, nch=256)
+    assert np.abs(h0 - hr).max() < 3e-6 and np.abs(c0 - cr).max() < 3e-6
 
 
 def test_rollout_fp16x3_is_as_close_to_float64_as_the_fp32_path():
@@ -458,13 +480,14 @@ def test_split_modes_with_odd_batches(B):
         assert np.isfinite(gens[prec]).all() and l2.max() < 2e-5
 
 
-def test_split_modes_apply_hidden1_and_hidden3_inside_lstm2_and_lstm4():
+@pytest.mark.parametrize('B', [2, 32])      # 32: the 32 x 32 layers take the 32-channel blocks (a block per CU), lstm2 with the norm folded in
+def test_split_modes_apply_hidden1_and_hidden3_inside_lstm2_and_lstm4(B):
     """Inference rollouts of the split modes have no ln_apply launch for hidden1 / hidden3 (the norm is applied while lstm2 / lstm4 stage their patch);
     Model.tap rebuilds the tensors on request, and the frames agree with a plan that keeps the separate launches (PIVP_LN_FOLD_LSTM is read once per
     process, so the comparison is against the fp32 kernels' taps)."""
     import pivp_amd
     P = R.init_params(seed=1, dtype=np.float32, scale=1.0)
-    imgs, acts, stas = R.synthetic_batch(2, 4)
+    imgs, acts, stas = R.synthetic_batch(B, 4)
     taps = {}
     for prec in ('fp32', 'bf16x6', 'fp16x3'):
         m = pivp_amd.Model(10, prefix='t', precision=prec)
