@@ -288,7 +288,7 @@ def main(argv=None):
         split_objs = {}
         if do_rollout and not dry and args.precision == 'fp32' and not args.no_bf16x6 and world == 1:       # (one rank only: a leg that fails on one
             # rank alone would leave the others in a barrier; the multi-GPU runs measure `value` and the data-parallel train steps)
-            for mode, what in (('bf16x6', '3 bf16 pieces, 6 bf16 MFMAs per product'), ('fp16x3', '2 fp16 pieces (weights packed times 2^8), 3 fp16 MFMAs per product')):
+            for mode, what in (('bf16x6', '3 bf16 pieces, 6 bf16 MFMAs per product'), ('fp16x3', '2 fp16 pieces (weights packed times a per-tensor power of two), 3 fp16 MFMAs per product')):
                 try:
                     m6 = pivp_amd.Model(nm, prefix='bench', device=dev, keep_activations=False, precision=mode, **kinds)
 
@@ -312,7 +312,9 @@ def main(argv=None):
                     if rank == 0 and not args.no_roofline:
                         r6 = roofline_pass(args, m6, x6_step, t6, np, torch, precision=mode)
                         obj.update({'achieved_tflops': r6['achieved'], 'peak_tflops': r6['peak'], 'frac': r6['frac'], 'per_layer_tflops': r6['per_layer_tflops'],
-                                    'layers_in_this_arithmetic': r6['layers']})
+                                    'layers_in_this_arithmetic': r6['layers'],
+                                    # (nominal peak at 2.4 GHz; measured: on real operands 16-bit MFMA loops hold 1.81-1.85 GHz at ~1270 W)
+                                    'peak_note': 'nominal (2.4 GHz); these loops are power-limited at ~0.76 of it on real operands: profiles/r04/clock_power_operand_values.txt'})
                     split_objs[mode] = obj
                     del m6
                 except Exception as e:

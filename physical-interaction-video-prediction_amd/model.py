@@ -168,7 +168,7 @@ class Model(object):
         # three bf16 MFMAs (16 bits of product mantissa); the rollout stays inside the 1e-4 gate; backward and everything else fp32.
         # 'bf16x6': three bf16 pieces per operand and the six significant products (fp32-grade results on the bf16 matrix cores) in the forward gate
         # convolutions of every layer whose map is a multiple of 16 wide; everything else, and the whole backward pass, fp32.
-        # 'fp16x3': the forward gate convolutions with every operand as two fp16 pieces (weights pre-scaled by 2^8), three MFMAs per product: 22-bit operands,
+        # 'fp16x3': the forward gate convolutions with every operand as two fp16 pieces (weights pre-scaled by a per-tensor power of two), three MFMAs per product: 22-bit operands,
         # still fp32-grade (its truncation is a quarter of fp32's own rounding error); the backward sweep is 'bf16x6''s.
         if precision not in ('fp32', 'bf16', 'bf16x3', 'bf16x6', 'fp16x3'):
             raise ValueError("precision must be 'fp32', 'bf16', 'bf16x3', 'bf16x6' or 'fp16x3'")
