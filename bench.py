@@ -416,7 +416,7 @@ def main(argv=None):
                 # the fp32-grade train step on the bf16 matrix cores: gate convolutions and their data gradients as six bf16 MFMAs per product
                 # (three pieces per fp32 operand), weight gradients and everything else fp32.  An additional object: `train` stays the fp32 kernels'.
                 train_x6_obj = {}
-                for mode in ('bf16x6', 'fp16x3'):       # (fp16x3: its forward; the sweep is bf16x6's)
+                for mode in ('bf16x6', 'fp16x3'):       # (fp16x3: its forward, and its data gradients with dG scaled by a power of two)
                     try:
                         train_x6_obj[mode], m6t, _, _, _ = train_leg(mode)
                         del m6t

@@ -68,6 +68,7 @@ SIGNATURES = {
     'pivp_conv5x5_bf16': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'pivp_conv5x5_bf16x3': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'pivp_conv5x5_bf16x6': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'pivp_conv5x5_fp16x3': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'pivp_pack_lstm_bf16x3': (_i, [_vp, _vp, _i, _i, _vp]),
     'pivp_convlstm_bf16x3': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'pivp_pack_lstm_bf16x6': (_i, [_vp, _vp, _i, _i, _vp]),

@@ -111,19 +111,37 @@ typedef pivp_f16x8 f16x8;                  // (two fp16 pieces per operand: pivp
 // fp16 pieces: the weights are packed times a power of two chosen per tensor so that the largest lands in [2^14, 2^15) -- the second piece of any
 // weight down to 2^-18 of the largest is then a normal fp16 number.  The pack's tail (256 2-byte elements behind the fragments) holds the scale
 // (float 0) and the 64 partial maxima it was taken from (floats 2..65).
-__global__ __launch_bounds__(256) void absmax_partials_kernel(const float* __restrict__ w, long n, float* __restrict__ tail) {
+// 64 blocks (one partial per lane of the consumers' wave) x 512 threads with EIGHT 16-byte loads in flight per thread: the data gradients of the fp16x3 mode
+// call it once per cell and timestep on a dG of up to 17 MB, beside the side stream's weight gradients (the first form, 256 threads and one load per trip,
+// took 32 us per launch there: 2.2 ms of a train step)
+__global__ __launch_bounds__(512) void absmax_partials_kernel(const float* __restrict__ w, long n, float* __restrict__ tail) {
     float m = 0.f;
-    const f32x4* w4 = reinterpret_cast<const f32x4*>(w);               // (n is a multiple of 32: K-inner packed weights)
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (n >> 2); i += 64L * 256) {
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(w);               // (n is a multiple of 32: K-inner packed weights, NHWC tensors of >= 8 channels)
+    const long n4 = n >> 2, stride = 64L * 512;
+    long i = (long)blockIdx.x * 512 + threadIdx.x;
+    for (; i + 7 * stride < n4; i += 8 * stride) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = w4[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v[u][0]), __builtin_fabsf(v[u][1]))), __builtin_fmaxf(__builtin_fabsf(v[u][2]), __builtin_fabsf(v[u][3])));
+    }
+    for (; i < n4; i += stride) {
         const f32x4 v = w4[i];
         m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
-    __shared__ float red[4];
+    __shared__ float red[8];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) tail[2 + blockIdx.x] = __builtin_fmaxf(__builtin_fmaxf(red[0], red[1]), __builtin_fmaxf(red[2], red[3]));
+    if (threadIdx.x == 0) {
+        float r = red[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) r = __builtin_fmaxf(r, red[k]);
+        tail[2 + blockIdx.x] = r;
+    }
 }
 __device__ __forceinline__ float x3_scale_of(const float* tail) {      // every caller computes the same power of two from the 64 partial maxima
     float m = 0.f;
@@ -1019,7 +1037,7 @@ template <int NWM, int NWN, bool LSTM = true, int PCS = 3, bool IN_LN = false, i
 __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int wbytes, int ncols) {
     constexpr int PHX = THX + 4;                       // patch rows
     constexpr int PB = PHX * RP16;                     // one patch plane: 36,864 B (61,440 B with 16 anchor rows)
-    static_assert(PCS == 3 || (PCS == 2 && LSTM), "pieces");
+    static_assert(PCS == 3 || PCS == 2, "pieces");
     static_assert(THX == TH || (THX == 16 && PCS == 2 && NWM == 4 && NWN == 2), "16-row tiles: the fp16 form with 4 x 2 waves");
     constexpr int PW = 20;
     constexpr int NW = NWM * NWN;                      // waves
@@ -1070,6 +1088,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
         a_pix = ok ? (b0 * H + iy) * W + ix : -1;
         a_lds = p < PHX * PW ? py * RP16 + px * PP : PW * PP;
     };
+    float a_scale = 1.0f;                              // (plain form with fp16 pieces: see inv_wscale below)
+    if constexpr (PCS == 2 && !LSTM) a_scale = pivp_x3_scale_wave(d.wscale_part);
     f32x4 plo[NPJX], phi[NPJX];
     f32x4 glo[IN_LN ? NPJX : 1], ghi[IN_LN ? NPJX : 1], blo[IN_LN ? NPJX : 1], bhi[IN_LN ? NPJX : 1];      // IN_LN: gamma / beta of the staged pieces
     float ln_mean = 0.f, ln_rstd = 1.f;
@@ -1116,6 +1136,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
                 }
             }
             if constexpr (PCS == 2) {
+                if constexpr (!LSTM) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) r[e] *= a_scale;
+                }
                 uint4 hh, ll;
                 hh.x = pivp_pack2h_rest(r[0], r[1]); hh.y = pivp_pack2h_rest(r[2], r[3]); hh.z = pivp_pack2h_rest(r[4], r[5]); hh.w = pivp_pack2h_rest(r[6], r[7]);
                 ll.x = pivp_pack2h_rest(r[0], r[1]); ll.y = pivp_pack2h_rest(r[2], r[3]); ll.z = pivp_pack2h_rest(r[4], r[5]); ll.w = pivp_pack2h_rest(r[6], r[7]);
@@ -1140,6 +1164,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     const int tap0 = (lid * 7) % 25;
     float inv_wscale = 1.0f;
     if constexpr (PCS == 2) inv_wscale = 1.0f / *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(wb) + wbytes);   // the pack's tail
+    // plain form with fp16 pieces (the data gradient): the activations are gradients, far below fp16's normal range -- they are staged times the power of
+    // two that puts the tensor's largest |value| into [2^14, 2^15) (d.wscale_part = absmax_partials of d.x0, one partial per lane), and the sums scaled back
+    if constexpr (PCS == 2 && !LSTM) inv_wscale *= 1.0f / a_scale;
 
     f32x16 acc[MT], accl[MT];
 #pragma unroll
@@ -1644,7 +1671,7 @@ namespace pivp {
 
 int absmax_partials(const float* w, long n, float* tail, hipStream_t stream) {
     PIVP_CHECK_ARG(w && tail && n > 0);
-    hipLaunchKernelGGL(absmax_partials_kernel, dim3(64), dim3(256), 0, stream, w, n, tail);
+    hipLaunchKernelGGL(absmax_partials_kernel, dim3(64), dim3(512), 0, stream, w, n, tail);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -1661,12 +1688,12 @@ int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStrea
     const int pieces = planes == -2 ? 2 : planes;
     const long total = (long)lstm_bf16_weight_elems(wcin, Np) * pieces;
     if (planes == -2 && plain == 2) {     // two fp16 pieces in the RING kernel's layout (layers on 8-wide maps: convlstm_bf16_kernel<NCH, true, 2, true>)
-        hipLaunchKernelGGL(absmax_partials_kernel, dim3(64), dim3(256), 0, s, w, (long)25 * wcin * N, reinterpret_cast<float*>(wb + total));
+        hipLaunchKernelGGL(absmax_partials_kernel, dim3(64), dim3(512), 0, s, w, (long)25 * wcin * N, reinterpret_cast<float*>(wb + total));
         hipLaunchKernelGGL(pack_lstm_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, 2, total, 1);
         return PIVP_LAUNCH_STATUS();
     }
     if (planes == -2)        // the tensor's scale first: 64 partial maxima into the pack's tail
-        hipLaunchKernelGGL(absmax_partials_kernel, dim3(64), dim3(256), 0, s, w, (long)25 * wcin * N, reinterpret_cast<float*>(wb + total));
+        hipLaunchKernelGGL(absmax_partials_kernel, dim3(64), dim3(512), 0, s, w, (long)25 * wcin * N, reinterpret_cast<float*>(wb + total));
     if (planes == 3 || planes == -2) {       // the three-piece kernels' fragment-major pack: the cell's (N = 4 C, gate-interleaved fragments) or a plain conv's
         PIVP_CHECK_ARG(Np % 64 == 0 && (plain || (Np == N && N % 32 == 0)));
         const long nthreads = (long)lstm_bf16_weight_elems(wcin, Np) / 8;
@@ -1733,14 +1760,15 @@ static int launch_x6g(const IgemmDesc& d, const unsigned short* wb, hipStream_t 
 }
 
 // the plain 5x5 convolution on the same kernel: dd.N = rows of the padded pack, nb = its 64-column blocks, ks = split of the channel groups
+template <int PCS>
 static int launch_x6g_plain(const IgemmDesc& dd, const unsigned short* wb, hipStream_t stream, int nb, int ks, int ncols) {
-    constexpr int lds_bytes = 3 * PH * RP16;
+    constexpr int lds_bytes = PCS * PH * RP16;
     static PerDeviceOnce once;
-    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<4, 2, false>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<4, 2, false, PCS>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     const int tpi = (dd.Hin / TH) * (dd.Win / 16);
-    const long long wbytes = (long long)lstm_bf16_weight_elems(dd.c0 + dd.c1, dd.N) * 3 * 2;
+    const long long wbytes = (long long)lstm_bf16_weight_elems(dd.c0 + dd.c1, dd.N) * PCS * 2;
     if (wbytes >= (1LL << 31)) return PIVP_ERR_BADARG;
-    hipLaunchKernelGGL((convlstm_x6g_kernel<4, 2, false>), dim3(dd.B * tpi * nb, ks), dim3(512), lds_bytes, stream, dd, wb, (int)wbytes, ncols);
+    hipLaunchKernelGGL((convlstm_x6g_kernel<4, 2, false, PCS>), dim3(dd.B * tpi * nb, ks), dim3(512), lds_bytes, stream, dd, wb, (int)wbytes, ncols);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -1800,7 +1828,7 @@ int conv5x5_bf16_ksplit(const IgemmDesc& d, int planes) {
     const int Np = conv5x5_bf16_rows(d.N);
     const int tw = d.Win % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
     const int tiles = (d.B / ti_n) * (d.Hin / TH) * (d.Win / tw);
-    const int ncg = (d.c0 + d.c1 + 63) / 64, nb = Np / ((Np % 128 == 0 && planes != 3) ? 128 : 64);     // (three pieces: 64-column blocks only)
+    const int ncg = (d.c0 + d.c1 + 63) / 64, nb = Np / ((Np % 128 == 0 && planes != 3 && planes != -2) ? 128 : 64);     // (three pieces / fp16 pieces: 64-column blocks only)
     // split only up to ONE round of blocks (the kernel is one 8-wave block per CU): 512 blocks = two rounds of half-length blocks with
     // atomics and a zeroed destination were slower than 256 whole ones (bf16 train step 12.56 -> 12.36 ms)
     static const int forced = [] { const char* e = getenv("PIVP_BF16_KS_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning
@@ -1812,7 +1840,8 @@ int conv5x5_bf16_ksplit(const IgemmDesc& d, int planes) {
 }
 
 int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int planes) {
-    PIVP_CHECK_ARG(wb && bf16_geometry_ok(d) && d.out && d.N > 0 && d.ldo >= d.N && d.x0 && d.c0 > 0 && planes >= 1 && planes <= 3 && (planes != 3 || d.Win % 16 == 0));
+    PIVP_CHECK_ARG(wb && bf16_geometry_ok(d) && d.out && d.N > 0 && d.ldo >= d.N && d.x0 && d.c0 > 0 && ((planes >= 1 && planes <= 3) || planes == -2) &&
+                   ((planes != 3 && planes != -2) || d.Win % 16 == 0) && (planes != -2 || (d.wscale_part && d.c1 == 0)));
     const int Np = conv5x5_bf16_rows(d.N);
     IgemmDesc dd = d;
     dd.N = Np;                                         // the kernel's weight-row count
@@ -1820,7 +1849,9 @@ int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t strea
     const int nb = Np / (wide ? 128 : 64);
     const int ks = conv5x5_bf16_ksplit(d, planes);
     if (planes == 3)     // three pieces (wb packed with planes = 3, plain = 1): 64-column blocks, weights from L2 into the operand registers, eight
-        return launch_x6g_plain(dd, wb, stream, Np / 64, ks, d.N);      // waves (the k-step-ring form of it measured 118 us per launch in the sweep against 100)
+        return launch_x6g_plain<3>(dd, wb, stream, Np / 64, ks, d.N);      // waves (the k-step-ring form of it measured 118 us per launch in the sweep against 100)
+    if (planes == -2)    // two fp16 pieces (wb packed with planes = -2, plain = 1; d.wscale_part = absmax_partials(d.x0): the activations' scale)
+        return launch_x6g_plain<2>(dd, wb, stream, Np / 64, ks, d.N);
     if (planes == 2)     // split mode (wb packed with planes = 2): 128-column blocks run the two-slot schedule, 64-column ones the four-slot one
         return wide ? launch_bf16<32, false, 2>(dd, wb, stream, nullptr, nb, ks, d.N)
                     : launch_bf16<16, false, 2>(dd, wb, stream, nullptr, nb, ks, d.N);

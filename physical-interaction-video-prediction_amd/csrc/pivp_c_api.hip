@@ -248,10 +248,11 @@ bool conv5x5_bf16_splits_k(int cin, int cout, int ldo, int B, int H, int W, int 
     return d.ksplit_ok && conv5x5_bf16_ksplit(d, planes) > 1;
 }
 int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb, float* out, int cout, int ldo, int accum,
-                     int B, int H, int W, hipStream_t s, int planes, int dest_zeroed) {
+                     int B, int H, int W, hipStream_t s, int planes, int dest_zeroed, const float* ascale_part) {
     IgemmDesc d;
     int rc = conv5x5_bf16_desc(d, x, cin, ldx, out, cout, ldo, accum, B, H, W);
     if (rc != PIVP_OK) return rc;
+    d.wscale_part = ascale_part;
     if (d.ksplit_ok && !dest_zeroed && conv5x5_bf16_ksplit(d, planes) > 1 &&
         hipMemsetAsync(out, 0, (size_t)B * H * W * cout * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     return conv5x5_bf16(d, wb, s, planes);
@@ -300,8 +301,9 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
                           const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                           float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
                           int B, int H, int W, hipStream_t s, int wt_ready, unsigned short* wt_bf16, int bf16_planes, const SideFork* fork,
-                          const LnFuse* ln, int dx_only, const LnbSpec* dx_lnb) {
+                          const LnFuse* ln, int dx_only, const LnbSpec* dx_lnb, float* dg_absmax) {
     const int M = B * H * W, cin = cx + C, N = 4 * C;
+    if (wt_bf16 && bf16_planes == -2 && !dg_absmax) return PIVP_ERR_BADARG;
     // a K-split data gradient adds into d_in: the gate kernel clears it on the side (one launch less than a memset per cell and timestep)
     const bool zero = wt_bf16 ? conv5x5_bf16_splits_k(N, cin, cin, B, H, W, bf16_planes)
                               : (dx_only ? conv_s1_splits_k(N, cx, cin, 5, B, H, W, cin) : conv_s1_splits_k(N, cin, cin, 5, B, H, W, 0));
@@ -321,7 +323,13 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
             if (rc != PIVP_OK) return rc;
         }
         if (dx_lnb && dx_lnb->np) *dx_lnb->np = 0;      // (the bf16 data-gradient kernel has no LayerNorm-backward epilogue: the caller runs ln_bwd_sums)
-        rc = run_conv5x5_bf16(dG, N, N, wt_bf16, d_in, cin, cin, 0, B, H, W, s, bf16_planes, zero);
+        if (bf16_planes == -2) {      // fp16 pieces: dG's power-of-two scale from its largest |value| (gradients lie far below fp16's normal range).
+            // (The maximum taken by the gate backward itself -- an atomic maximum of float bits per wave, behind a "can I raise it" load -- instead of this
+            // launch was built and measured: the train step 21.5 ms against 21.1 with the launch, 22.5 with three bf16 pieces.  Removed.)
+            rc = absmax_partials(dG, (long)M * N, dg_absmax, s);
+            if (rc != PIVP_OK) return rc;
+        }
+        rc = run_conv5x5_bf16(dG, N, N, wt_bf16, d_in, cin, cin, 0, B, H, W, s, bf16_planes, zero, dg_absmax);
     } else {
         // d[x,h] = conv5x5(dG, W^T flipped); dx_only: the x columns alone (the pack's first cx of cin; the h columns of d_in stay unwritten)
         rc = dx_only ? run_conv_s1(dG, N, N, wt, d_in, cx, cin, 5, B, H, W, s, 0, cin, zero, dx_lnb)
@@ -407,7 +415,7 @@ long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin,
 #define PIVP_BUILD_DIGEST "unstamped"      // a build that did not go through build.py: _lib.load() refuses it
 #endif
 extern "C" const char* pivp_build_digest(void) { return PIVP_BUILD_DIGEST; }
-extern "C" int pivp_abi_version(void) { return 10; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
+extern "C" int pivp_abi_version(void) { return 11; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
 
 extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                              const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream) {
@@ -557,6 +565,18 @@ extern "C" int pivp_conv5x5_bf16x6(const float* x, int cin, int ldx, const float
     int rc = pack_lstm_bf16(w, (unsigned short*)w_bf16, cin, cout, (hipStream_t)stream, conv5x5_bf16_rows(cout), 3, 1);
     if (rc != PIVP_OK) return rc;
     return run_conv5x5_bf16(x, cin, ldx, (const unsigned short*)w_bf16, out, cout, ldo, accum, B, H, W, (hipStream_t)stream, 3);
+}
+// two-fp16-piece form (three MFMAs per product, fp32-grade; the fp16x3 mode's data gradients): x is staged times the power of two that puts its largest
+// |value| into [2^14, 2^15) (gradients lie far below fp16's normal range), w as in pivp_pack_lstm_fp16x3; w_bf16 holds 2 * pivp_conv5x5_bf16_weight_elems
+// + 256 elements, scratch 66 floats (x's partial maxima); x contiguous (ldx == cin), W % 16 == 0
+extern "C" int pivp_conv5x5_fp16x3(const float* x, int cin, int ldx, const float* w, void* w_bf16, float* out, int cout, int ldo, int accum,
+                                   int B, int H, int W, float* scratch, void* stream) {
+    if (!x || !w || !w_bf16 || !out || !scratch || cin <= 0 || cout <= 0 || W % 16 || ldx != cin || B <= 0 || H <= 0) return PIVP_ERR_BADARG;
+    int rc = pack_lstm_bf16(w, (unsigned short*)w_bf16, cin, cout, (hipStream_t)stream, conv5x5_bf16_rows(cout), -2, 1);
+    if (rc != PIVP_OK) return rc;
+    rc = absmax_partials(x, (long)B * H * W * cin, scratch, (hipStream_t)stream);
+    if (rc != PIVP_OK) return rc;
+    return run_conv5x5_bf16(x, cin, ldx, (const unsigned short*)w_bf16, out, cout, ldo, accum, B, H, W, (hipStream_t)stream, -2, 0, scratch);
 }
 // ConvLSTM weight gradient with bf16 operands: dW (K-inner packed like the weight, [25][(cx+C)/32][4C][32]) += x|h^T . dG per tap.
 extern "C" int pivp_wgrad5x5_bf16(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW, float* db,

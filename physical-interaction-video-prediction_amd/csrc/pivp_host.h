@@ -55,9 +55,11 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
                           int B, int H, int W, hipStream_t s, int wt_ready = 0, unsigned short* wt_bf16 = nullptr, int bf16_planes = 1,
                           const SideFork* fork = nullptr, const LnFuse* ln = nullptr,    // ln: dh_a is formed from the LayerNorm behind the cell
                           int dx_only = 0,    // 1: d h_{t-1} is not needed (the sweep's last timestep): only the cx columns of d_in are computed
-                          const LnbSpec* dx_lnb = nullptr);   // the x columns of d_in are the dy of the norm in front of this cell
+                          const LnbSpec* dx_lnb = nullptr,    // the x columns of d_in are the dy of the norm in front of this cell
+                          float* dg_absmax = nullptr);        // bf16_planes == -2 (data gradient with two fp16 pieces): 66 floats of scratch for dG's partial maxima
 int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb, float* out, int cout, int ldo, int accum,
-                     int B, int H, int W, hipStream_t s, int planes = 1, int dest_zeroed = 0);
+                     int B, int H, int W, hipStream_t s, int planes = 1, int dest_zeroed = 0,
+                     const float* ascale_part = nullptr);     // planes == -2: absmax_partials(x) (the activations' power-of-two scale)
 int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w, float* dy, int cout, int ldy, const float* y, int ldyy,
                       float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, hipStream_t s,
                       int wt_ready = 0, const SideFork* fork = nullptr, float* part = nullptr, WgradDesc* desc_out = nullptr,

@@ -39,7 +39,8 @@ struct IgemmDesc {
     float* ln_part; int ln_cap; int ln_nparts;
     int bf16;                            // transposed conv only, when the tile kernel takes the call: 1 = bf16 operands, 2 = split (two bf16 pieces),
                                          // 3 = two FP16 pieces (fp32-grade), the weights times the power of two of wscale_part
-    const float* wscale_part;            // bf16 == 3: absmax_partials(w) (64 partial maxima at [2..65])
+    const float* wscale_part;            // bf16 == 3: absmax_partials(w) (64 partial maxima at [2..65]); conv5x5_bf16 with planes = -2: absmax_partials(x0),
+                                         // the ACTIVATIONS' scale (the weights' one travels in the pack's tail)
     // LayerNorm of the INPUT applied while it is staged (inference rollouts: the norm's own launch disappears).  x0 then is the RAW tensor
     // [B][Hin*Win][c0] (all c0 channels are normalised), in_g / in_b the norm's per-element gamma / beta ([Hin*Win][c0], the checkpoint's
     // flat order), in_part the producer's (count, mean, M2) partials [B][in_np][4].  Served by igemm_small only (igemm_in_ln_ok).

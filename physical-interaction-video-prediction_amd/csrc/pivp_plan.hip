@@ -66,6 +66,7 @@ struct Grads {   // gradient workspace (single copy, reused by every timestep of
     size_t ln_ppart[9], ln_ppart_floats;   // per-norm partial parameter gradients (ln_backward's param_part), one contiguous region
     size_t wg_part[5], wg_part_floats;   // per-block partial weight gradients of enc6, enc5, enc4, enc2, enc1 (WgradDesc::part), one contiguous region
     size_t wtb_lstm[7];             // ... and their bf16 packs (bf16 precision mode)
+    size_t dg_absmax;               // fp16-piece data gradients: the partial maxima of the dG in front of the launch (absmax_partials; stream-ordered, one buffer)
 };
 
 }  // namespace
@@ -201,6 +202,7 @@ static void plan_layout(pivp_plan* p) {
             g.wtb_lstm[i] = carve(lstm_bf16_weight_elems(4 * kLstm[i].C, conv5x5_bf16_rows(kLstm[i].cx + kLstm[i].C)) * 3 / 2 + 64);   // up to three planes
             g.wt_enc[i] = (i == 0 || i == 3) ? 0 : carve((size_t)encw[i]);
         }
+        g.dg_absmax = carve(128);
         g.go[0] = carve((size_t)B * 3 * HW); g.go[1] = carve((size_t)B * 3 * HW);
         g.dmk = carve((size_t)B * p->NP * HW); g.dz = carve((size_t)B * p->NE * HW);
         g.dkpart = carve((size_t)B * composite_bwd_tiles(H, W) * 256); g.dv = carve((size_t)B * 256);
@@ -338,7 +340,9 @@ extern "C" int pivp_plan_set_precision(pivp_plan_t* plan, int precision) {
     }
     plan->lstm_bf16 = precision != PIVP_PRECISION_F32;
     plan->lstm_planes = precision == PIVP_PRECISION_BF16X3 ? 2 : precision == PIVP_PRECISION_BF16X6 ? 3 : precision == PIVP_PRECISION_FP16X3 ? -2 : 1;
-    plan->bwd_planes = plan->lstm_planes == -2 ? 3 : plan->lstm_planes;      // (fp16 pieces: forward only; its sweep is the three-bf16-piece one)
+    // fp16 pieces in the sweep: the data gradients take dG times a power of two from its largest |value| (PIVP_X3_DGRAD=0: the three-bf16-piece form)
+    static const int x3_dgrad = [] { const char* e = getenv("PIVP_X3_DGRAD"); return e ? atoi(e) : 1; }();
+    plan->bwd_planes = plan->lstm_planes == -2 ? (x3_dgrad ? -2 : 3) : plan->lstm_planes;
     plan->bf16_all = precision == PIVP_PRECISION_BF16;
     plan->precision = precision;
     plan->packs_valid = 0;
@@ -788,9 +792,9 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                                  Sp ? ws + Sp->c[i] : ws + p->o_zero, ws + S.c[i], nullptr, L.C,
                                  last_step ? nullptr : ws + g.din[i][npar] + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
                                  ring + (size_t)wg_slot * dG1, ws + g.wt_lstm[i], ws + g.din[i][par], nullptr, nullptr, B, hh, wwid,
-                                 s, 1, (p->lstm_bf16 && (p->bwd_planes != 3 || wwid % 16 == 0)) ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->bwd_planes,
+                                 s, 1, (p->lstm_bf16 && ((p->bwd_planes != 3 && p->bwd_planes != -2) || wwid % 16 == 0)) ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->bwd_planes,
                                  wg_flush ? fork_of(i, f) : nullptr, &lf[i],    // dW = null: only the fork's `ready` (behind the gate math) is used
-                                 t == 0 ? 1 : 0, dx_lnb));                      // t = 0: nobody reads d h_{-1}
+                                 t == 0 ? 1 : 0, dx_lnb, ws + g.dg_absmax));    // t = 0: nobody reads d h_{-1}
         if (t == 0) RC(ln_finish(i + 1));       // the sweep's last timestep: the norm's partial parameter planes (written by the gate kernel) become its gradient
         if (!wg_flush) return PIVP_OK;
         // weight + bias gradient of the whole batch: timestep j of it reads slab (first - j) and ring slot j; on the side stream it

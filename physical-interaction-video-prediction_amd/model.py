@@ -169,7 +169,7 @@ class Model(object):
         # 'bf16x6': three bf16 pieces per operand and the six significant products (fp32-grade results on the bf16 matrix cores) in the forward gate
         # convolutions of every layer whose map is a multiple of 16 wide; everything else, and the whole backward pass, fp32.
         # 'fp16x3': the forward gate convolutions with every operand as two fp16 pieces (weights pre-scaled by a per-tensor power of two), three MFMAs per product: 22-bit operands,
-        # still fp32-grade (its truncation is a quarter of fp32's own rounding error); the backward sweep is 'bf16x6''s.
+        # still fp32-grade (its truncation is a quarter of fp32's own rounding error); the data gradients of the sweep take the same form with dG staged times a power of two from its largest value (gradients lie below fp16's normal range).
         if precision not in ('fp32', 'bf16', 'bf16x3', 'bf16x6', 'fp16x3'):
             raise ValueError("precision must be 'fp32', 'bf16', 'bf16x3', 'bf16x6' or 'fp16x3'")
         self.precision = precision

@@ -376,8 +376,14 @@ def conv5x5_bf16(x, W, accum_into=None, split=False, pieces=0):
     cout = W.shape[0]
     xd = nhwc(x)
     wd = _t(pivp_amd.to_internal('lstm1/conv/W', W))          # [25][cin/32][cout][32]
-    wb = torch.empty((3 if pieces == 3 else 2 if split else 1) * lib.pivp_conv5x5_bf16_weight_elems(cin, cout), dtype=torch.int16, device=DEV)
+    wb = torch.empty((3 if pieces == 3 else 2 if (split or pieces == 'fp16x3') else 1) * lib.pivp_conv5x5_bf16_weight_elems(cin, cout) + 256, dtype=torch.int16, device=DEV)
     out = nhwc(accum_into) if accum_into is not None else torch.full((B, H, Wd, cout), 7.0, dtype=torch.float32, device=DEV)
+    if pieces == 'fp16x3':       # two fp16 pieces per operand, the activations' scale from their largest |value|
+        scratch = torch.zeros(128, dtype=torch.float32, device=DEV)
+        _lib.check(lib.pivp_conv5x5_fp16x3(xd.data_ptr(), cin, cin, wd.data_ptr(), wb.data_ptr(), out.data_ptr(), cout, cout,
+                                           1 if accum_into is not None else 0, B, H, Wd, scratch.data_ptr(), stream()), 'conv5x5_fp16x3')
+        torch.cuda.synchronize()
+        return nchw(out, B, H, Wd, cout)
     _lib.check((lib.pivp_conv5x5_bf16x6 if pieces == 3 else lib.pivp_conv5x5_bf16x3 if split else lib.pivp_conv5x5_bf16)(xd.data_ptr(), cin, cin, wd.data_ptr(), wb.data_ptr(), out.data_ptr(), cout, cout,
                                      1 if accum_into is not None else 0, B, H, Wd, stream()), 'conv5x5_bf16')
     torch.cuda.synchronize()
