@@ -261,7 +261,8 @@ int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb,
 // weight gradient of: mode 0 = conv K x K stride `stride` pad `pad`; mode 1 = transposed 3x3 s2 p1
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
               float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s, float* db,
-              int* bias_done, int bf16, int tcount, long long ts_x0, long long ts_x1, long long ts_dy, float* part, WgradDesc* desc_out) {
+              int* bias_done, int bf16, int tcount, long long ts_x0, long long ts_x1, long long ts_dy, float* part, WgradDesc* desc_out,
+              const float* dy_absmax, int dy_absmax_stride) {
     WgradDesc d;
     memset(&d, 0, sizeof(d));
     d.x0 = x0; d.c0 = c0; d.ld0 = ld0; d.x1 = x1; d.c1 = x1 ? c1 : 0; d.ld1 = ld1; d.cin = c0 + (x1 ? c1 : 0); d.wcin = wcin;
@@ -275,8 +276,9 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
     d.db = db;
     d.tcount = tcount; d.ts_x0 = ts_x0; d.ts_x1 = ts_x1; d.ts_dy = ts_dy;
     d.part = part;
+    d.dy_absmax = dy_absmax; d.dy_absmax_stride = dy_absmax_stride;
     if (desc_out) *desc_out = d;
-    if (bf16) {   // bf16 precision mode (5x5 ConvLSTM case only): operands rounded to bf16, fp32 accumulation; db summed on the side in fp32
+    if (bf16 || dy_absmax) {   // bf16 precision mode (5x5 ConvLSTM case only): operands rounded to bf16, fp32 accumulation; db summed on the side in fp32
         if (bias_done) *bias_done = db != nullptr;
         return wgrad5x5_bf16(d, s);
     }
@@ -309,6 +311,13 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
                               : (dx_only ? conv_s1_splits_k(N, cx, cin, 5, B, H, W, cin) : conv_s1_splits_k(N, cin, cin, 5, B, H, W, 0));
     int rc = lstm_gates_bwd(gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc, dc_valid, dG, M, C, s, B, ln, zero ? d_in : nullptr, (long long)M * cin);
     if (rc != PIVP_OK) return rc;
+    if (dg_absmax) {      // fp16 pieces: dG's power-of-two scale from its largest |value| (gradients lie far below fp16's normal range); in front of the
+        // fork, because the weight gradient on the side stream reads it too.
+        // (The maximum taken by the gate backward itself -- an atomic maximum of float bits per wave, behind a "can I raise it" load -- instead of this
+        // launch was built and measured: the train step 21.5 ms against 21.1 with the launch, 22.5 with three bf16 pieces.  Removed.)
+        rc = absmax_partials(dG, (long)M * N, dg_absmax, s);
+        if (rc != PIVP_OK) return rc;
+    }
     // dG is final: the weight gradient can start (on the side stream when forked), next to this layer's own data gradient
     hipStream_t sw;
     rc = fork_begin(fork, s, &sw);
@@ -323,12 +332,6 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
             if (rc != PIVP_OK) return rc;
         }
         if (dx_lnb && dx_lnb->np) *dx_lnb->np = 0;      // (the bf16 data-gradient kernel has no LayerNorm-backward epilogue: the caller runs ln_bwd_sums)
-        if (bf16_planes == -2) {      // fp16 pieces: dG's power-of-two scale from its largest |value| (gradients lie far below fp16's normal range).
-            // (The maximum taken by the gate backward itself -- an atomic maximum of float bits per wave, behind a "can I raise it" load -- instead of this
-            // launch was built and measured: the train step 21.5 ms against 21.1 with the launch, 22.5 with three bf16 pieces.  Removed.)
-            rc = absmax_partials(dG, (long)M * N, dg_absmax, s);
-            if (rc != PIVP_OK) return rc;
-        }
         rc = run_conv5x5_bf16(dG, N, N, wt_bf16, d_in, cin, cin, 0, B, H, W, s, bf16_planes, zero, dg_absmax);
     } else {
         // d[x,h] = conv5x5(dG, W^T flipped); dx_only: the x columns alone (the pack's first cx of cin; the h columns of d_in stay unwritten)
@@ -415,7 +418,7 @@ long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin,
 #define PIVP_BUILD_DIGEST "unstamped"      // a build that did not go through build.py: _lib.load() refuses it
 #endif
 extern "C" const char* pivp_build_digest(void) { return PIVP_BUILD_DIGEST; }
-extern "C" int pivp_abi_version(void) { return 11; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
+extern "C" int pivp_abi_version(void) { return 12; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
 
 extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                              const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream) {
@@ -584,6 +587,19 @@ extern "C" int pivp_wgrad5x5_bf16(const float* x, int cx, int ldx, const float* 
     if (!x || !dG || !dW || C <= 0 || cx <= 0) return PIVP_ERR_BADARG;
     return run_wgrad(0, x, cx, ldx, h_prev, C, C, cx + C, dG, 4 * C, 4 * C, dW, B, H, W, H, W, 5, 2, 1, (hipStream_t)stream, db,
                      nullptr, 1);
+}
+// ... with two fp16 pieces per operand and three MFMAs per product (fp32-grade; the fp16x3 mode's weight gradient), a batch of timesteps as below:
+// scratch: 72 * tcount floats (the partial maxima of every timestep's dG: it is staged times a power of two from the largest of the batch)
+extern "C" int pivp_wgrad5x5_fp16x3_batch(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW, float* db,
+                                          int B, int H, int W, int tcount, long long ts_x, long long ts_h, long long ts_dG, float* scratch, void* stream) {
+    if (!x || !dG || !dW || !scratch || C <= 0 || cx <= 0 || tcount < 1 || B <= 0 || H <= 0 || W <= 0) return PIVP_ERR_BADARG;
+    for (int j = 0; j < tcount; ++j) {
+        const int rc = absmax_partials(reinterpret_cast<const float*>(reinterpret_cast<const char*>(dG) + j * ts_dG), (long)B * H * W * 4 * C,
+                                       scratch + (size_t)j * 72, (hipStream_t)stream);
+        if (rc != PIVP_OK) return rc;
+    }
+    return run_wgrad(0, x, cx, ldx, h_prev, C, C, cx + C, dG, 4 * C, 4 * C, dW, B, H, W, H, W, 5, 2, 1, (hipStream_t)stream, db,
+                     nullptr, 0, tcount, ts_x, ts_h, ts_dG, nullptr, nullptr, scratch, 72);
 }
 // ... of a BATCH of timesteps in one launch (the sum over pixels runs over timesteps too): timestep j reads x + j * ts_x, h_prev + j * ts_h,
 // dG + j * ts_dG (byte strides, multiples of 16, may be negative: the backward sweep walks time downwards)

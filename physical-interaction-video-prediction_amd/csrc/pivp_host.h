@@ -48,7 +48,8 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
               float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s,
               float* db = nullptr, int* bias_done = nullptr, int bf16 = 0,
               int tcount = 1, long long ts_x0 = 0, long long ts_x1 = 0, long long ts_dy = 0,    // a batch of timesteps: WgradDesc
-              float* part = nullptr, WgradDesc* desc_out = nullptr);   // part: WgradDesc::part; desc_out: the descriptor that was launched
+              float* part = nullptr, WgradDesc* desc_out = nullptr,    // part: WgradDesc::part; desc_out: the descriptor that was launched
+              const float* dy_absmax = nullptr, int dy_absmax_stride = 0);   // two fp16 pieces per operand (WgradDesc::dy_absmax; 5x5 ConvLSTM case only)
 int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
                           const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                           float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
@@ -56,7 +57,8 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
                           const SideFork* fork = nullptr, const LnFuse* ln = nullptr,    // ln: dh_a is formed from the LayerNorm behind the cell
                           int dx_only = 0,    // 1: d h_{t-1} is not needed (the sweep's last timestep): only the cx columns of d_in are computed
                           const LnbSpec* dx_lnb = nullptr,    // the x columns of d_in are the dy of the norm in front of this cell
-                          float* dg_absmax = nullptr);        // bf16_planes == -2 (data gradient with two fp16 pieces): 66 floats of scratch for dG's partial maxima
+                          float* dg_absmax = nullptr);        // 66 floats: receives dG's partial maxima (absmax_partials), the scale of the fp16-piece data gradient
+                                                              // (bf16_planes == -2 needs it) and of the fp16-piece weight gradient (WgradDesc::dy_absmax)
 int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb, float* out, int cout, int ldo, int accum,
                      int B, int H, int W, hipStream_t s, int planes = 1, int dest_zeroed = 0,
                      const float* ascale_part = nullptr);     // planes == -2: absmax_partials(x) (the activations' power-of-two scale)

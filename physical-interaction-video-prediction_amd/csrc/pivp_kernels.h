@@ -97,6 +97,10 @@ struct WgradDesc {
     // loads and stores; igemm_wgrad_reduce(d) then sums the splits into dw.  The scattered atomics of the direct path cost 54 of the
     // 85 us of an enc5 / enc6 launch (64 adds per address from 500 blocks).  The launches that share a slot must be stream-ordered.
     float* part;
+    // wgrad5x5_bf16 only: two FP16 pieces per operand, three MFMAs per product (the fp16x3 mode's weight gradient).  dy_absmax = the absmax_partials tail of
+    // timestep j's dy at dy_absmax + j * dy_absmax_stride floats (64 partial maxima at [2..65]): dy is staged times the power of two that puts the largest
+    // |value| of the whole batch into [2^14, 2^15) -- gradients lie far below fp16's normal range -- and the sums are scaled back exactly.  null: bf16 operands.
+    const float* dy_absmax; int dy_absmax_stride;
 };
 int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done = nullptr);
 long long igemm_wgrad_part_floats(const WgradDesc& d);    // 0 when the ConvLSTM fast path would take this descriptor

@@ -91,6 +91,7 @@ struct pivp_plan {
     int precision = 0;                // PIVP_PRECISION_*
     int pack_cache = 0, packs_valid = 0;   // pivp_plan_set_pack_cache: keep the precision modes' weight packs across rollouts until pivp_plan_params_changed
     int bwd_planes = 1;               // the data gradients' form of lstm_planes
+    bool x3_wgrad = false;            // fp16x3 mode: the ConvLSTM weight gradients with two fp16 pieces too (wgrad25_bf16_kernel<.., 2>, batched like the bf16 mode's)
     int lstm_planes = 1;              // 2: split mode (hi / lo planes, three MFMAs per product); 3: three pieces, six MFMAs (forward gate convs only: the
                                       // backward sweep and every other op of that mode are the fp32 ones)
     int bf16_all = 0;                 // precision mode BF16: also the ConvLSTM gradients and the enc5 / enc6 transposed convs
@@ -167,7 +168,9 @@ static void plan_layout(pivp_plan* p) {
     p->nslabs = train ? T - 1 : 2;
     {   // timesteps t = T-2 .. 1 batch (t = 0, no h input, goes alone): as many ring slots as a launch may take timesteps
         const char* e = getenv("PIVP_WGRAD_BATCH");
-        const int want = e ? atoi(e) : (p->bf16_all ? WG_BATCH_MAX : 1);
+        // (fp16-piece weight gradients: TWO timesteps per launch on half the CUs -- measured grid, profiles/r04/fp16x3_train_wgrad_batch_slots.txt: 8 per
+        // launch on every CU, what the bf16 mode does, leaves all of that work to the end of the sweep: 16.85 ms against 16.34)
+        const int want = e ? atoi(e) : (p->bf16_all ? WG_BATCH_MAX : p->x3_wgrad ? 2 : 1);
         int cap = T - 2 < 1 ? 1 : (T - 2 > WG_BATCH_MAX ? WG_BATCH_MAX : T - 2);
         if (want < cap) cap = want < 1 ? 1 : want;
         p->wg_cap = cap;
@@ -202,7 +205,7 @@ static void plan_layout(pivp_plan* p) {
             g.wtb_lstm[i] = carve(lstm_bf16_weight_elems(4 * kLstm[i].C, conv5x5_bf16_rows(kLstm[i].cx + kLstm[i].C)) * 3 / 2 + 64);   // up to three planes
             g.wt_enc[i] = (i == 0 || i == 3) ? 0 : carve((size_t)encw[i]);
         }
-        g.dg_absmax = carve(128);
+        g.dg_absmax = carve((size_t)7 * 2 * p->wg_cap * 72);     // dG's partial maxima per (cell, ring, slot): the fp16-piece gradients' scales
         g.go[0] = carve((size_t)B * 3 * HW); g.go[1] = carve((size_t)B * 3 * HW);
         g.dmk = carve((size_t)B * p->NP * HW); g.dz = carve((size_t)B * p->NE * HW);
         g.dkpart = carve((size_t)B * composite_bwd_tiles(H, W) * 256); g.dv = carve((size_t)B * 256);
@@ -343,6 +346,9 @@ extern "C" int pivp_plan_set_precision(pivp_plan_t* plan, int precision) {
     // fp16 pieces in the sweep: the data gradients take dG times a power of two from its largest |value| (PIVP_X3_DGRAD=0: the three-bf16-piece form)
     static const int x3_dgrad = [] { const char* e = getenv("PIVP_X3_DGRAD"); return e ? atoi(e) : 1; }();
     plan->bwd_planes = plan->lstm_planes == -2 ? (x3_dgrad ? -2 : 3) : plan->lstm_planes;
+    // ... and the weight gradients (PIVP_X3_WGRAD=0: the fp32 kernel, one launch per cell and timestep)
+    static const int x3_wgrad = [] { const char* e = getenv("PIVP_X3_WGRAD"); return e ? atoi(e) : 1; }();
+    plan->x3_wgrad = plan->lstm_planes == -2 && x3_wgrad != 0;
     plan->bf16_all = precision == PIVP_PRECISION_BF16;
     plan->precision = precision;
     plan->packs_valid = 0;
@@ -794,7 +800,8 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                                  ring + (size_t)wg_slot * dG1, ws + g.wt_lstm[i], ws + g.din[i][par], nullptr, nullptr, B, hh, wwid,
                                  s, 1, (p->lstm_bf16 && ((p->bwd_planes != 3 && p->bwd_planes != -2) || wwid % 16 == 0)) ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->bwd_planes,
                                  wg_flush ? fork_of(i, f) : nullptr, &lf[i],    // dW = null: only the fork's `ready` (behind the gate math) is used
-                                 t == 0 ? 1 : 0, dx_lnb, ws + g.dg_absmax));    // t = 0: nobody reads d h_{-1}
+                                 t == 0 ? 1 : 0, dx_lnb,
+                                 (p->bwd_planes == -2 || p->x3_wgrad) ? ws + g.dg_absmax + ((size_t)(i * 2 + wg_ring) * p->wg_cap + wg_slot) * 72 : nullptr));    // t = 0: nobody reads d h_{-1}
         if (t == 0) RC(ln_finish(i + 1));       // the sweep's last timestep: the norm's partial parameter planes (written by the gate kernel) become its gradient
         if (!wg_flush) return PIVP_OK;
         // weight + bias gradient of the whole batch: timestep j of it reads slab (first - j) and ring slot j; on the side stream it
@@ -803,7 +810,8 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         const int cnt = wg_slot + 1;
         int bias_done = 0;
         RC(run_wgrad(0, p->wg_x[i], L.cx, ldx, p->wg_h[i], L.C, L.C, cin, ring, N, N, G(p, p->i_lstm_w[i]), B, hh, wwid, hh, wwid, 5, 2, 1, sw,
-                     G(p, p->i_lstm_b[i]), &bias_done, p->bf16_all, cnt, -slab_bytes, -slab_bytes, (long long)dG1 * 4));
+                     G(p, p->i_lstm_b[i]), &bias_done, p->bf16_all, cnt, -slab_bytes, -slab_bytes, (long long)dG1 * 4, nullptr, nullptr,
+                     p->x3_wgrad ? ws + g.dg_absmax + (size_t)(i * 2 + wg_ring) * p->wg_cap * 72 : nullptr, 72));
         if (!bias_done)
             for (int j = 0; j < cnt; ++j) RC(bias_grad(ring + (size_t)j * dG1, N, N, B * hh * wwid, G(p, p->i_lstm_b[i]), sw));
         if (p->side && hipEventRecord(p->ev_ring_done[i][wg_ring], p->side_of(i)) != hipSuccess) return PIVP_ERR_LAUNCH;
@@ -981,7 +989,7 @@ static int rollout_backward_sweep(pivp_plan_t* plan, const float* images, const 
         // fetches every operand tile once per 32 x 64 output slice, and what a block pays per launch (205 KB of atomics, the first tile's
         // latency) is amortised over the batch (csrc/wgrad_bf16.hip).
         const char* e = getenv("PIVP_WGRAD_BATCH");
-        int gb = e ? atoi(e) : (plan->bf16_all ? plan->wg_cap : 1);
+        int gb = e ? atoi(e) : ((plan->bf16_all || plan->x3_wgrad) ? plan->wg_cap : 1);
         if (gb < 1) gb = 1;
         if (gb > plan->wg_cap) gb = plan->wg_cap;
         plan->wg_batch = gb;

@@ -221,9 +221,15 @@ constexpr int W25_XPIX = 320;             // patch pixels staged (12 x 20 = 240,
 constexpr int W25_X_BYTES = W25_XPIX * 64;
 }  // namespace
 
-template <int TW>
+// PCS = 2: every operand as TWO FP16 pieces (hi = fp16(v), lo = fp16(v - hi): 22 bits) and three MFMAs per product (lo * hi, hi * lo, hi * hi), the form of
+// the fp16x3 precision mode: fp32-grade sums at a sixth of the matrix-pipe time of the fp32 kernel (wgrad5x5_kernel), which matters beyond this kernel's own
+// duration because the sweep is bound by the matrix-pipe work of BOTH streams.  dG is staged times a power of two taken from the largest |value| of the
+// batch (WgradDesc::dy_absmax), the activations as they are (LayerNorm outputs, h, ReLU outputs: fp16's range); one accumulator per tile -- three
+// roundings per 16 products, where the fp32 MFMA rounds eight times.  LDS: two planes of each image, 74 KB.
+template <int TW, int PCS = 1>
 __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d, int tiles_per_split) {
     constexpr int tw = TW;
+    constexpr int GB = W25_G_BYTES, XB = W25_X_BYTES;         // bytes of one plane of the dG tile / of the X patch
     constexpr int ti_n = tw == 16 ? 1 : 2;
     constexpr int PWC = tw + 4;                               // patch columns
     constexpr int NPIX = ti_n * 12 * PWC;                     // 240 / 288
@@ -281,6 +287,14 @@ __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d,
     // bias gradient = column sums of dG (fp32, on its way into LDS): the blocks of channel block 0 see every dG element of their columns once
     const bool do_bias = d.db != nullptr && cb == 0;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    float gscale = 1.0f;                                      // PCS = 2: dG's power-of-two scale (the largest |value| of the batch's timesteps)
+    if constexpr (PCS == 2) {
+        float m = 0.f;
+        for (int j = 0; j < tcount; ++j) m = __builtin_fmaxf(m, d.dy_absmax[(size_t)j * d.dy_absmax_stride + 2 + lane]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+        gscale = pivp_x3_scale_of_max(m);
+    }
     auto store_tile = [&]() {
         if (do_bias) {
 #pragma unroll
@@ -289,15 +303,35 @@ __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d,
         const int n4 = tid & 15;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            uint2 v;
-            v.x = wpack2(rg[j][0], rg[j][1]); v.y = wpack2(rg[j][2], rg[j][3]);
-            *reinterpret_cast<uint2*>(lds + (n4 >> 3) * W25_GH + ((tid >> 4) + 32 * j) * 64 + (n4 & 7) * 8) = v;
+            unsigned char* dst = lds + (n4 >> 3) * W25_GH + ((tid >> 4) + 32 * j) * 64 + (n4 & 7) * 8;
+            if constexpr (PCS == 2) {
+                float r0 = rg[j][0] * gscale, r1 = rg[j][1] * gscale, r2 = rg[j][2] * gscale, r3 = rg[j][3] * gscale;
+                uint2 h, l;
+                h.x = pivp_pack2h_rest(r0, r1); h.y = pivp_pack2h_rest(r2, r3);
+                l.x = pivp_pack2h_rest(r0, r1); l.y = pivp_pack2h_rest(r2, r3);
+                *reinterpret_cast<uint2*>(dst) = h;
+                *reinterpret_cast<uint2*>(dst + GB) = l;
+            } else {
+                uint2 v;
+                v.x = wpack2(rg[j][0], rg[j][1]); v.y = wpack2(rg[j][2], rg[j][3]);
+                *reinterpret_cast<uint2*>(dst) = v;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NXJ; ++j) {
-            uint2 v;                                          // (pixels past the patch carry the zeros of their out-of-range loads)
-            v.x = wpack2(rx[j][0], rx[j][1]); v.y = wpack2(rx[j][2], rx[j][3]);
-            *reinterpret_cast<uint2*>(lds + W25_G_BYTES + ((tid >> 3) + 64 * j) * 64 + (tid & 7) * 8) = v;
+            unsigned char* dst = lds + PCS * GB + ((tid >> 3) + 64 * j) * 64 + (tid & 7) * 8;
+            if constexpr (PCS == 2) {
+                float r0 = rx[j][0], r1 = rx[j][1], r2 = rx[j][2], r3 = rx[j][3];
+                uint2 h, l;
+                h.x = pivp_pack2h_rest(r0, r1); h.y = pivp_pack2h_rest(r2, r3);
+                l.x = pivp_pack2h_rest(r0, r1); l.y = pivp_pack2h_rest(r2, r3);
+                *reinterpret_cast<uint2*>(dst) = h;
+                *reinterpret_cast<uint2*>(dst + XB) = l;
+            } else {
+                uint2 v;                                      // (pixels past the patch carry the zeros of their out-of-range loads)
+                v.x = wpack2(rx[j][0], rx[j][1]); v.y = wpack2(rx[j][2], rx[j][3]);
+                *reinterpret_cast<uint2*>(dst) = v;
+            }
         }
     };
 
@@ -307,7 +341,7 @@ __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d,
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const int nt = wave & 1, tg = wave >> 1;                  // this wave's 32 columns; its taps are tg, tg + 4, ... (< 25)
     const unsigned a_base = lds0 + nt * W25_GH + (8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * p4) * 2;
-    const unsigned b_lane = lds0 + W25_G_BYTES + (TW == 16 ? 8 * (g >> 1) + q : (g >> 1) * PWC + q) * 64 + (16 * (g & 1) + 4 * p4) * 2;
+    const unsigned b_lane = lds0 + PCS * GB + (TW == 16 ? 8 * (g >> 1) + q : (g >> 1) * PWC + q) * 64 + (16 * (g & 1) + 4 * p4) * 2;
     unsigned b_base[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
@@ -332,6 +366,28 @@ __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d,
         bf16x4 b0[7], b1[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) { b0[i] = lds_read_tr<b_off(s, 0)>(b_base[i]); b1[i] = lds_read_tr<b_off(s, 1)>(b_base[i]); }
+        if constexpr (PCS == 2) {
+            // the second pieces: the same addresses one plane further (in the instruction's offset field)
+            bf16x4 a0l = lds_read_tr<a_off(s, 0) + GB>(a_base), a1l = lds_read_tr<a_off(s, 1) + GB>(a_base);
+            bf16x4 c0[7], c1[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { c0[i] = lds_read_tr<b_off(s, 0) + XB>(b_base[i]); c1[i] = lds_read_tr<b_off(s, 1) + XB>(b_base[i]); }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]), "+v"(b1[2]),
+                         "+v"(b0[3]), "+v"(b1[3]), "+v"(b0[4]), "+v"(b1[4]), "+v"(b0[5]), "+v"(b1[5]), "+v"(b0[6]), "+v"(b1[6]));
+            asm volatile("" : "+v"(a0l), "+v"(a1l), "+v"(c0[0]), "+v"(c1[0]), "+v"(c0[1]), "+v"(c1[1]), "+v"(c0[2]), "+v"(c1[2]),
+                         "+v"(c0[3]), "+v"(c1[3]), "+v"(c0[4]), "+v"(c1[4]), "+v"(c0[5]), "+v"(c1[5]), "+v"(c0[6]), "+v"(c1[6]));
+            auto h8 = [](const bf16x4& u, const bf16x4& v) { return __builtin_bit_cast(pivp_f16x8, __builtin_shufflevector(u, v, 0, 1, 2, 3, 4, 5, 6, 7)); };
+            const pivp_f16x8 fa = h8(a0, a1), fal = h8(a0l, a1l);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                if (i < 6 || seven) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, h8(b0[i], b1[i]), acc[i], 0, 0, 0);       // lo * hi
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, h8(c0[i], c1[i]), acc[i], 0, 0, 0);        // hi * lo
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, h8(b0[i], b1[i]), acc[i], 0, 0, 0);        // hi * hi
+                }
+            }
+            return;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]), "+v"(b1[2]),
                      "+v"(b0[3]), "+v"(b1[3]), "+v"(b0[4]), "+v"(b1[4]), "+v"(b0[5]), "+v"(b1[5]), "+v"(b0[6]), "+v"(b1[6]));
         const bf16x8 fa = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -361,8 +417,9 @@ __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d,
             const int tap = tg + 4 * i;
             if (tap < 25) {
                 float* base = d.dw + ((size_t)(tap * (d.wcin >> 5) + cb) * N + nb * 64 + nt * 32) * 32 + l31;
+                const float inv = 1.0f / gscale;                 // (1 without pieces; a power of two with them: exact)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) atomicAdd(base + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32, acc[i][r]);
+                for (int r = 0; r < 16; ++r) atomicAdd(base + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32, acc[i][r] * inv);
             }
         }
     }
@@ -385,11 +442,12 @@ bool wgrad5x5_bf16_ok(const WgradDesc& d) {
 }
 
 // the 25-tap kernel: grid = (cin / 32) x (N / 64) output slices x pixel splits over the tiles of ALL timesteps of the batch
+template <int PCS>
 static int launch_wgrad25(const WgradDesc& d, hipStream_t s) {
-    constexpr int lds_bytes = W25_G_BYTES + W25_X_BYTES;
+    constexpr int lds_bytes = PCS * (W25_G_BYTES + W25_X_BYTES);
     static PerDeviceOnce once16, once8;
-    if (pivp_ensure_dyn_lds(once16, reinterpret_cast<const void*>(&wgrad25_bf16_kernel<16>), lds_bytes) != PIVP_OK ||
-        pivp_ensure_dyn_lds(once8, reinterpret_cast<const void*>(&wgrad25_bf16_kernel<8>), lds_bytes) != PIVP_OK)
+    if (pivp_ensure_dyn_lds(once16, reinterpret_cast<const void*>(&wgrad25_bf16_kernel<16, PCS>), lds_bytes) != PIVP_OK ||
+        pivp_ensure_dyn_lds(once8, reinterpret_cast<const void*>(&wgrad25_bf16_kernel<8, PCS>), lds_bytes) != PIVP_OK)
         return PIVP_ERR_LAUNCH;
     const int tw = d.Wx % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
     const int n_tiles = (d.B / ti_n) * (d.Hx / 8) * (d.Wx / tw) * (d.tcount > 1 ? d.tcount : 1);
@@ -397,14 +455,15 @@ static int launch_wgrad25(const WgradDesc& d, hipStream_t s) {
     // Pixel splits: one block per CU (8 waves, ~70 KB of LDS), at least 2 tiles per block; every split ends with 25 x 32 x 64 atomic adds
     // (205 KB: the batch of timesteps is what amortises them).  PIVP_WGB_SLOTS: block target (tuning).
     static const int slots = [] { const char* e = getenv("PIVP_WGB_SLOTS"); return e ? atoi(e) : 0; }();
-    const int target = slots > 0 ? slots : pivp_cu_count();
+    // (fp16 pieces: its 8-wave blocks hold a CU's whole register file, and the sweep's small kernels need CUs without one: half the CUs)
+    const int target = slots > 0 ? slots : (PCS == 2 ? pivp_cu_count() / 2 : pivp_cu_count());
     int ns = (target + gx - 1) / gx;
     if (ns > n_tiles / 2) ns = n_tiles / 2;
     if (ns < 1) ns = 1;
     const int tps = (n_tiles + ns - 1) / ns;
     ns = (n_tiles + tps - 1) / tps;
-    if (tw == 16) hipLaunchKernelGGL(wgrad25_bf16_kernel<16>, dim3(gx, ns), dim3(512), lds_bytes, s, d, tps);
-    else hipLaunchKernelGGL(wgrad25_bf16_kernel<8>, dim3(gx, ns), dim3(512), lds_bytes, s, d, tps);
+    if (tw == 16) hipLaunchKernelGGL((wgrad25_bf16_kernel<16, PCS>), dim3(gx, ns), dim3(512), lds_bytes, s, d, tps);
+    else hipLaunchKernelGGL((wgrad25_bf16_kernel<8, PCS>), dim3(gx, ns), dim3(512), lds_bytes, s, d, tps);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -415,7 +474,11 @@ int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s) {
     // timestep to the kernel-row kernel below, whose 5 x cin/32 blocks per tile are then the better use of the chip (389 us against 580:
     // the sweep's t = 0 launches, sequences too short to batch).  PIVP_WGB_KERNEL = 5 / 25 forces one of them (tuning).
     static const int kernel = [] { const char* e = getenv("PIVP_WGB_KERNEL"); return e ? atoi(e) : 0; }();
-    if (kernel == 25 || (kernel != 5 && d.tcount > 1)) return launch_wgrad25(d, s);
+    if (d.dy_absmax) {       // two fp16 pieces per operand: the 25-tap kernel, whatever the batch
+        PIVP_CHECK_ARG(d.dy_absmax_stride >= 66 || d.tcount <= 1);
+        return launch_wgrad25<2>(d, s);
+    }
+    if (kernel == 25 || (kernel != 5 && d.tcount > 1)) return launch_wgrad25<1>(d, s);
     if (d.tcount > 1) {      // PIVP_WGB_KERNEL=5 with a batched descriptor: the kernel-row kernel takes one timestep, so one launch per timestep
         for (int j = 0; j < d.tcount; ++j) {
             WgradDesc dj = d;
