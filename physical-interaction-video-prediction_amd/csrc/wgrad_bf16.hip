@@ -456,7 +456,8 @@ static int launch_wgrad25(const WgradDesc& d, hipStream_t s) {
     // (205 KB: the batch of timesteps is what amortises them).  PIVP_WGB_SLOTS: block target (tuning).
     static const int slots = [] { const char* e = getenv("PIVP_WGB_SLOTS"); return e ? atoi(e) : 0; }();
     // (fp16 pieces: its 8-wave blocks hold a CU's whole register file, and the sweep's small kernels need CUs without one: half the CUs)
-    const int target = slots > 0 ? slots : (PCS == 2 ? pivp_cu_count() / 2 : pivp_cu_count());
+    // bf16: three quarters (train step 11.86 -> 11.66 ms, profiles/r04/bf16_train_wgrad_batch_slots.txt)
+    const int target = slots > 0 ? slots : (PCS == 2 ? pivp_cu_count() / 2 : pivp_cu_count() * 3 / 4);
     int ns = (target + gx - 1) / gx;
     if (ns > n_tiles / 2) ns = n_tiles / 2;
     if (ns < 1) ns = 1;
