@@ -249,7 +249,7 @@ int pivp_conv5x5_bf16x6(const float* x, int cin, int ldx, const float* w, void* 
                         int B, int H, int W, void* stream);
 /* ... and as two fp16 pieces per operand, three MFMAs per product (fp32-grade; PIVP_PRECISION_FP16X3's data gradient): x is staged times the power of two
  * that puts its largest |value| into [2^14, 2^15) -- gradients lie far below fp16's normal range --, w as in pivp_pack_lstm_fp16x3, the sums scaled back
- * exactly.  x contiguous (ldx == cin), W % 16 == 0; w_bf16 holds 2 * pivp_conv5x5_bf16_weight_elems(cin, cout) + 256 2-byte elements; scratch: 66 floats */
+ * exactly.  x contiguous (ldx == cin), W % 16 == 0 (or W % 8 == 0 with an even batch); w_bf16 holds 2 * pivp_conv5x5_bf16_weight_elems(cin, cout) + 256 2-byte elements; scratch: 66 floats */
 int pivp_conv5x5_fp16x3(const float* x, int cin, int ldx, const float* w, void* w_bf16, float* out, int cout, int ldo, int accum,
                         int B, int H, int W, float* scratch, void* stream);
 

@@ -311,7 +311,8 @@ __device__ long long pivp_bf16_stamps[2048 * 8];
 // mode's cell on maps this kernel's 8 x 8 tiles serve and the L2-direct kernel's 16-wide ones do not.
 template <int NCH, bool LSTM, int PL = 1, bool F16 = false>
 __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int tw, int ncols) {
-    static_assert(!F16 || (PL == 2 && LSTM), "fp16 pieces: the split form of the cell");
+    static_assert(!F16 || (PL == 2 && NCH == 16), "fp16 pieces: the split form, 16-channel / 64-column blocks");
+    // (F16 without LSTM: the data gradient on 8-wide maps; the activations -- gradients -- are staged times d.wscale_part's power of two, as in convlstm_x6g_kernel)
     constexpr int BN = 4 * NCH;                 // block columns: [gate][channel]
     constexpr int PLANE = BN * 128;             // one weight plane of a ring slot: BN rows x 64 bf16
     constexpr int SLOT = PL * PLANE;            // bytes of one ring slot
@@ -397,6 +398,8 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
             }
         }
     };
+    float a_scale = 1.0f;
+    if constexpr (F16 && !LSTM) a_scale = pivp_x3_scale_wave(d.wscale_part);
     auto patch_store = [&]() {
 #pragma unroll
         for (int j = 0; j < NPJ; ++j) {
@@ -404,6 +407,10 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
             // leaves the loads "pending" on the skipped path for hipcc's wait-count pass, which then drains vmcnt inside the tap loop
             if constexpr (F16) {
                 float r[8] = {plo[j][0], plo[j][1], plo[j][2], plo[j][3], phi[j][0], phi[j][1], phi[j][2], phi[j][3]};
+                if constexpr (!LSTM) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) r[e] *= a_scale;
+                }
                 uint4 hh, ll;
                 hh.x = pivp_pack2h_rest(r[0], r[1]); hh.y = pivp_pack2h_rest(r[2], r[3]); hh.z = pivp_pack2h_rest(r[4], r[5]); hh.w = pivp_pack2h_rest(r[6], r[7]);
                 ll.x = pivp_pack2h_rest(r[0], r[1]); ll.y = pivp_pack2h_rest(r[2], r[3]); ll.z = pivp_pack2h_rest(r[4], r[5]); ll.w = pivp_pack2h_rest(r[6], r[7]);
@@ -883,7 +890,8 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
                 for (int r = 0; r < 16; ++r) acc[mt][t][r] += accl[mt][t][r];
     }
     if constexpr (F16) {           // the weights were packed times a power of two (the pack's tail, behind its [groups][25][2][N][64] elements)
-        const float inv = 1.0f / *reinterpret_cast<const float*>(wb + (size_t)((d.wcin + 63) >> 6) * 25 * 2 * N * 64);      // (d.wcin: the pack's channels, also at t = 0)
+        float inv = 1.0f / *reinterpret_cast<const float*>(wb + (size_t)((d.wcin + 63) >> 6) * 25 * 2 * N * 64);      // (d.wcin: the pack's channels, also at t = 0)
+        if constexpr (!LSTM) inv *= 1.0f / a_scale;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1841,7 +1849,7 @@ int conv5x5_bf16_ksplit(const IgemmDesc& d, int planes) {
 
 int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int planes) {
     PIVP_CHECK_ARG(wb && bf16_geometry_ok(d) && d.out && d.N > 0 && d.ldo >= d.N && d.x0 && d.c0 > 0 && ((planes >= 1 && planes <= 3) || planes == -2) &&
-                   ((planes != 3 && planes != -2) || d.Win % 16 == 0) && (planes != -2 || (d.wscale_part && d.c1 == 0)));
+                   (planes != 3 || d.Win % 16 == 0) && (planes != -2 || (d.wscale_part && d.c1 == 0)));
     const int Np = conv5x5_bf16_rows(d.N);
     IgemmDesc dd = d;
     dd.N = Np;                                         // the kernel's weight-row count
@@ -1850,6 +1858,8 @@ int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t strea
     const int ks = conv5x5_bf16_ksplit(d, planes);
     if (planes == 3)     // three pieces (wb packed with planes = 3, plain = 1): 64-column blocks, weights from L2 into the operand registers, eight
         return launch_x6g_plain<3>(dd, wb, stream, Np / 64, ks, d.N);      // waves (the k-step-ring form of it measured 118 us per launch in the sweep against 100)
+    if (planes == -2 && d.Win % 16)     // ... on an 8-wide map (an even batch): the ring kernel's two-image tiles, wb packed with plain = 2
+        return launch_bf16<16, false, 2, true>(dd, wb, stream, nullptr, Np / 64, ks, d.N);
     if (planes == -2)    // two fp16 pieces (wb packed with planes = -2, plain = 1; d.wscale_part = absmax_partials(d.x0): the activations' scale)
         return launch_x6g_plain<2>(dd, wb, stream, Np / 64, ks, d.N);
     if (planes == 2)     // split mode (wb packed with planes = 2): 128-column blocks run the two-slot schedule, 64-column ones the four-slot one

@@ -328,7 +328,7 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
     }
     if (wt_bf16) {   // bf16 precision mode: the data gradient with bf16 operands (wt_bf16 = bf16 pack of wt, built here unless wt_ready)
         if (!wt_ready) {
-            rc = pack_lstm_bf16(wt, wt_bf16, N, cin, s, conv5x5_bf16_rows(cin), bf16_planes, 1);
+            rc = pack_lstm_bf16(wt, wt_bf16, N, cin, s, conv5x5_bf16_rows(cin), bf16_planes, (bf16_planes == -2 && W % 16) ? 2 : 1);
             if (rc != PIVP_OK) return rc;
         }
         if (dx_lnb && dx_lnb->np) *dx_lnb->np = 0;      // (the bf16 data-gradient kernel has no LayerNorm-backward epilogue: the caller runs ln_bwd_sums)
@@ -571,11 +571,11 @@ extern "C" int pivp_conv5x5_bf16x6(const float* x, int cin, int ldx, const float
 }
 // two-fp16-piece form (three MFMAs per product, fp32-grade; the fp16x3 mode's data gradients): x is staged times the power of two that puts its largest
 // |value| into [2^14, 2^15) (gradients lie far below fp16's normal range), w as in pivp_pack_lstm_fp16x3; w_bf16 holds 2 * pivp_conv5x5_bf16_weight_elems
-// + 256 elements, scratch 66 floats (x's partial maxima); x contiguous (ldx == cin), W % 16 == 0
+// + 256 elements, scratch 66 floats (x's partial maxima); x contiguous (ldx == cin), W % 16 == 0 or W % 8 == 0 with an even batch
 extern "C" int pivp_conv5x5_fp16x3(const float* x, int cin, int ldx, const float* w, void* w_bf16, float* out, int cout, int ldo, int accum,
                                    int B, int H, int W, float* scratch, void* stream) {
-    if (!x || !w || !w_bf16 || !out || !scratch || cin <= 0 || cout <= 0 || W % 16 || ldx != cin || B <= 0 || H <= 0) return PIVP_ERR_BADARG;
-    int rc = pack_lstm_bf16(w, (unsigned short*)w_bf16, cin, cout, (hipStream_t)stream, conv5x5_bf16_rows(cout), -2, 1);
+    if (!x || !w || !w_bf16 || !out || !scratch || cin <= 0 || cout <= 0 || (W % 16 && (W % 8 || B % 2)) || ldx != cin || B <= 0 || H <= 0) return PIVP_ERR_BADARG;
+    int rc = pack_lstm_bf16(w, (unsigned short*)w_bf16, cin, cout, (hipStream_t)stream, conv5x5_bf16_rows(cout), -2, W % 16 ? 2 : 1);      // (8-wide maps: the ring kernel's pack)
     if (rc != PIVP_OK) return rc;
     rc = absmax_partials(x, (long)B * H * W * cin, scratch, (hipStream_t)stream);
     if (rc != PIVP_OK) return rc;

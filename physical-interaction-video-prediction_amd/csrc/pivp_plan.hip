@@ -798,7 +798,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                                  Sp ? ws + Sp->c[i] : ws + p->o_zero, ws + S.c[i], nullptr, L.C,
                                  last_step ? nullptr : ws + g.din[i][npar] + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
                                  ring + (size_t)wg_slot * dG1, ws + g.wt_lstm[i], ws + g.din[i][par], nullptr, nullptr, B, hh, wwid,
-                                 s, 1, (p->lstm_bf16 && ((p->bwd_planes != 3 && p->bwd_planes != -2) || wwid % 16 == 0)) ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->bwd_planes,
+                                 s, 1, (p->lstm_bf16 && (p->bwd_planes != 3 || wwid % 16 == 0) && (p->bwd_planes != -2 || wwid % 16 == 0 || B % 2 == 0)) ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->bwd_planes,
                                  wg_flush ? fork_of(i, f) : nullptr, &lf[i],    // dW = null: only the fork's `ready` (behind the gate math) is used
                                  t == 0 ? 1 : 0, dx_lnb,
                                  (p->bwd_planes == -2 || p->x3_wgrad) ? ws + g.dg_absmax + ((size_t)(i * 2 + wg_ring) * p->wg_cap + wg_slot) * 72 : nullptr));    // t = 0: nobody reads d h_{-1}
@@ -1010,7 +1010,8 @@ static int rollout_backward_sweep(pivp_plan_t* plan, const float* images, const 
         for (int i = 0; i < 7; ++i) {
             const int cin = kLstm[i].cx + kLstm[i].C;
             RC(pack_lstm_bf16(ws + g.wt_lstm[i], reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]), 4 * kLstm[i].C, cin, s,
-                              conv5x5_bf16_rows(cin), plan->bwd_planes, 1));
+                              conv5x5_bf16_rows(cin), plan->bwd_planes,
+                              (plan->bwd_planes == -2 && lstm_w_of(plan, i) % 16) ? 2 : 1));      // (fp16 pieces on an 8-wide map: the ring kernel's layout)
         }
     {
         const int ecin[7] = {0, 32, 64, 0, 128, 96, 64};
