@@ -398,7 +398,7 @@ def main(argv=None):
                 'dtype': {'fp32': 'f32', 'bf16': 'bf16 ConvLSTM / enc5 / enc6 operands, f32 accumulate, gradients and optimizer',
                           'bf16x3': 'f32 as 2 bf16 pieces in the ConvLSTM forward and data gradients',
                           'bf16x6': 'f32 as 3 bf16 pieces in the ConvLSTM gate convolutions and their data gradients (6 bf16 MFMAs per product: fp32-grade), f32 weight gradients and elsewhere',
-                          'fp16x3': 'f32 as 2 fp16 pieces in the ConvLSTM gate convolutions (3 fp16 MFMAs per product), data gradients as 3 bf16 pieces, f32 weight gradients and elsewhere'}[precision],
+                          'fp16x3': 'f32 as 2 fp16 pieces (3 fp16 MFMAs per product, f32 accumulate) in the ConvLSTM gate convolutions, their data and weight gradients (dG scaled by a power of two) and enc5 / enc6; f32 elsewhere'}[precision],
                 'workload': 'optimizer.update (TM:950): forward + BPTT backward + gradient all-reduce + Adam, schedsamp_k=-1, batch %d/GPU' % B,
                 'loss': float(tloss),
             }
@@ -466,7 +466,7 @@ def main(argv=None):
             'dtype': {'fp32': 'f32', 'bf16': 'bf16 ConvLSTM operands, f32 accumulate and elsewhere',
                       'bf16x3': 'f32 operands of the ConvLSTM forward as 2 bf16 pieces (3 bf16 MFMAs per product), f32 accumulate and elsewhere',
                       'bf16x6': 'f32 operands of the ConvLSTM forward as 3 bf16 pieces (6 bf16 MFMAs per product: fp32-grade products), f32 accumulate and elsewhere',
-                      'fp16x3': 'f32 operands of the ConvLSTM forward as 2 fp16 pieces (3 fp16 MFMAs per product: 22-bit operands), f32 accumulate and elsewhere'}[args.precision],
+                      'fp16x3': 'f32 operands of the ConvLSTM forward (train mode: and of its data / weight gradients) as 2 fp16 pieces (3 fp16 MFMAs per product: 22-bit operands), f32 accumulate and elsewhere'}[args.precision],
             'data': ('synthetic' if not args.share_gpu else 'synthetic; REHEARSAL: %d ranks share one GPU over gloo, not a multi-GPU measurement' % world)
                     if not dry else 'none: --dry run of the host logic on CPU (gloo, stub kernels); NOT a measurement',
             'config': {'workload': preset + '%s %s, batch %d/GPU, %d-frame %dx%dx3 sequences, action-conditioned, num_masks=%d, '
