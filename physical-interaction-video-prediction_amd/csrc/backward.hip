@@ -374,12 +374,17 @@ __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restr
 // block reduces each sample's (sum g, sum g xhat) over the slice.  71 launches per train step less than the two kernels (the sweep is
 // made of 5-6 us launches here).  Loads are unconditional (indices clamped, contributions weighted by 0) so that four samples' loads stay
 // in flight.
+#ifndef LNB_SP_NJ
+#define LNB_SP_NJ 4                  // samples in flight per trip (2: 64 registers instead of 88 -- a wave then fits on a SIMD beside two waves of the bf16 mode's
+                                     // weight gradient; measured, profiles/r04/NOTES.md: no difference in any mode's train step)
+#endif
 __global__ __launch_bounds__(256) void ln_bwd_sums_params_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
                                                                  const float* __restrict__ x, const float* __restrict__ stat,
                                                                  const float* __restrict__ gamma, float* __restrict__ partials,
                                                                  int B, int n, int C, int relu, float* __restrict__ part) {
     PIVP_SET_MAIN_PRIO();
-    __shared__ float red[4][8];
+    constexpr int NJ = LNB_SP_NJ;
+    __shared__ float red[4][2 * NJ];
     const int e0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     const bool valid = e0 < n;
     const int e = valid ? e0 : 0;
@@ -388,10 +393,10 @@ __global__ __launch_bounds__(256) void ln_bwd_sums_params_kernel(const float* __
     const int S = gridDim.x, G = gridDim.y, npix = n / C;
     const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + e);
     f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
-    for (int b0 = blockIdx.y; b0 < B; b0 += 4 * G) {
-        float sm[8];
+    for (int b0 = blockIdx.y; b0 < B; b0 += NJ * G) {
+        float sm[2 * NJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int bj = b0 + j * G;
             const int b = bj < B ? bj : B - 1;
             const float wgt = (bj < B && valid) ? 1.f : 0.f;
@@ -415,10 +420,10 @@ __global__ __launch_bounds__(256) void ln_bwd_sums_params_kernel(const float* __
         }
         if (lane == 0) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) red[wave][q] = sm[q];
+            for (int q = 0; q < 2 * NJ; ++q) red[wave][q] = sm[q];
         }
         __syncthreads();
-        if (threadIdx.x < 8) {
+        if (threadIdx.x < 2 * NJ) {
             const int b = b0 + (threadIdx.x >> 1) * G;
             if (b < B) partials[((size_t)b * S + blockIdx.x) * 2 + (threadIdx.x & 1)] =
                 (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
