@@ -24,11 +24,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_x6 -o rollout_x6
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/train_x6 -o train_x6 -- python3 bench.py --precision bf16x6 --mode train --steps 4 --warmup 1 $NB --no-roofline > $out/train_x6.log 2>&1
 python3 scripts/overlap_report.py $out/train_x6/train_x6_kernel_trace.csv > $out/train_x6_overlap.txt 2>&1 || true
 python3 scripts/queue_breakdown.py $out/train_x6/train_x6_kernel_trace.csv > $out/train_x6_queues.txt 2>&1 || true
-# two fp16 pieces per operand (forward gate convolutions; the sweep is the three-piece one)
+# two fp16 pieces per operand (forward gate convolutions, their data and weight gradients)
 python3 bench.py --precision fp16x3 $NB --no-train > $out/bench_fp16x3.json 2> $out/bench_fp16x3.err
 python3 bench.py --precision fp16x3 --mode train --steps 10 --warmup 3 $NB --no-roofline > $out/bench_fp16x3_train.json 2> $out/bench_fp16x3_train.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_fp16x3 -o rollout_fp16x3 -- python3 bench.py --precision fp16x3 --steps 7 --warmup 2 $NB --no-train > $out/kt_fp16x3.log 2>&1
 rm -f $out/kt_fp16x3/*kernel_trace.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/train_fp16x3 -o train_fp16x3 -- python3 bench.py --precision fp16x3 --mode train --steps 4 --warmup 1 $NB --no-roofline > $out/train_fp16x3.log 2>&1
+python3 scripts/overlap_report.py $out/train_fp16x3/train_fp16x3_kernel_trace.csv > $out/train_fp16x3_overlap.txt 2>&1 || true
+python3 scripts/queue_breakdown.py $out/train_fp16x3/train_fp16x3_kernel_trace.csv > $out/train_fp16x3_queues.txt 2>&1 || true
+rm -f $out/train_fp16x3/*kernel_trace.csv
 R="--steps 2 --warmup 1 $NB --no-roofline --no-train --no-bf16x6"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 bench.py $R > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python3 bench.py $R > $out/write.log 2>&1
