@@ -419,7 +419,13 @@ __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d,
                 float* base = d.dw + ((size_t)(tap * (d.wcin >> 5) + cb) * N + nb * 64 + nt * 32) * 32 + l31;
                 const float inv = 1.0f / gscale;                 // (1 without pieces; a power of two with them: exact)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) atomicAdd(base + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32, acc[i][r] * inv);
+                for (int r = 0; r < 16; ++r) {
+#ifdef PIVP_WGB_NOATOMIC   // timing-only ablation (results wrong): what do the epilogue's atomics cost?
+                    if (acc[i][r] == 12345.678f) base[((r & 3) + 8 * (r >> 2) + 4 * half) * 32] = inv;
+#else
+                    atomicAdd(base + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32, acc[i][r] * inv);
+#endif
+                }
             }
         }
     }
