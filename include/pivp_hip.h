@@ -89,8 +89,10 @@ int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr);
  * multiple of 16 wide (8-wide maps -- lstm5 on 64 x 64 frames -- run the fp32 kernels); the weight gradients and every other op are the fp32 ones.
  * PIVP_PRECISION_FP16X3 = the forward gate convolutions (and the enc5 / enc6 transposed convs) with every fp32 operand as TWO FP16 pieces (22 bits of mantissa; a layer's weights are packed times the
  * power of two that puts the largest in [2^14, 2^15), so that the second piece of any weight down to 2^-18 of it stays a normal fp16 number; the sum is scaled
- * back exactly) and three MFMAs per product; activations beyond +-65504 saturate, activations below 0.06 carry up to 3e-8 of absolute error.  Its truncation error is a quarter of the fp32 path's own rounding error (scripts/split_fp16_study.py); the backward sweep is
- * PIVP_PRECISION_BF16X6's (gradients do not fit fp16's exponent range).  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
+ * back exactly) and three MFMAs per product; activations beyond +-65504 saturate, activations below 0.06 carry up to 3e-8 of absolute error.  Its truncation error is a quarter of the fp32 path's own rounding error (scripts/split_fp16_study.py).  The backward sweep's
+ * ConvLSTM data and weight gradients take the same form: gradients do not fit fp16's exponent range as they are, so dG is staged times the power of two that puts
+ * its largest |value| (per cell and timestep / batch of timesteps: one absmax launch) into [2^14, 2^15) and the sums are scaled back exactly; an 8-wide map with
+ * an odd batch keeps the fp32 kernels.  PIVP_X3_DGRAD=0 / PIVP_X3_WGRAD=0: PIVP_PRECISION_BF16X6's data gradients / the fp32 weight gradients.  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
 int pivp_plan_set_precision(pivp_plan_t* plan, int precision);
 int pivp_plan_get_precision(const pivp_plan_t* plan);
 /* The precision modes re-pack the ConvLSTM weights (bf16 / split pieces) at the start of every rollout, because the parameters may have changed.  With
