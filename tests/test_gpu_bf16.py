@@ -411,7 +411,7 @@ def test_conv5x5_bf16x6(ops, B, cin, cout, H):
     print('conv5x5 %d->%d @%d: three-piece max |err| %.2e rms %.2e' % (cin, cout, H, np.abs(e6).max(), np.sqrt((e6 ** 2).mean()))
           + ('' if ef is None else '; fp32 kernel max %.2e rms %.2e' % (np.abs(ef).max(), np.sqrt((ef ** 2).mean()))))
     # (one accumulation chain per output over K = 25 cin: 2.1e-7 rms at K = 3200-6400 with the channel groups split over blocks, 4.4e-7 for the unsplit 6400)
-    assert np.abs(e6).max() < 1e-5 and np.sqrt((e6 ** 2).mean()) < 6e-7
+    assert np.abs(e6).max() < 2e-5 and np.sqrt((e6 ** 2).mean()) < 7e-7      # (observed up to 6.7e-6 / 5.2e-7; the K-split sums meet by atomic adds in any order)
     if ef is not None:
         assert np.sqrt((e6 ** 2).mean()) < 1.2 * np.sqrt((ef ** 2).mean())
     acc = rs.randn(B, cout, H, H).astype(np.float32)
@@ -439,7 +439,7 @@ def test_conv5x5_fp16x3(ops, B, cin, cout, H, scale):
     ef = ((ops.conv5x5_bf16(x, W, pieces=3) if H % 16 == 0 else ops.conv5x5_bf16(x, W, pieces='fp16x3')) - ref) / unit        # the three-bf16-piece form it replaces in the fp16x3 mode's sweep (16-wide maps)
     print('conv5x5 %d->%d @%d, x scale %s: two fp16 pieces max |err| %.2e rms %.2e of the output rms; three bf16 pieces max %.2e rms %.2e'
           % (cin, cout, H, scale, np.abs(e3).max(), np.sqrt((e3 ** 2).mean()), np.abs(ef).max(), np.sqrt((ef ** 2).mean())))
-    assert np.abs(e3).max() < 1e-5 and np.sqrt((e3 ** 2).mean()) < 6e-7
+    assert np.abs(e3).max() < 2e-5 and np.sqrt((e3 ** 2).mean()) < 7e-7      # (observed up to 7.8e-6 / 5.3e-7; the K-split sums meet by atomic adds in any order)
     assert np.sqrt((e3 ** 2).mean()) < 1.5 * np.sqrt((ef ** 2).mean())
     if B < 32 and scale == 1.0:                      # accumulate form
         acc = rs.randn(B, cout, H, H).astype(np.float32)
