@@ -397,7 +397,7 @@ def main(argv=None):
                 'allreduce_algo_ms_per_step': compare,
                 'dtype': {'fp32': 'f32', 'bf16': 'bf16 ConvLSTM / enc5 / enc6 operands, f32 accumulate, gradients and optimizer',
                           'bf16x3': 'f32 as 2 bf16 pieces in the ConvLSTM forward and data gradients',
-                          'bf16x6': 'f32 as 3 bf16 pieces in the ConvLSTM gate convolutions and their data gradients (6 bf16 MFMAs per product: fp32-grade), f32 weight gradients and elsewhere',
+                          'bf16x6': 'f32 as 3 bf16 pieces in the ConvLSTM gate convolutions, their data and weight gradients (6 bf16 MFMAs per product: fp32-grade), f32 elsewhere',
                           'fp16x3': 'f32 as 2 fp16 pieces (3 fp16 MFMAs per product, f32 accumulate) in the ConvLSTM gate convolutions, their data and weight gradients (dG scaled by a power of two) and enc5 / enc6; f32 elsewhere'}[precision],
                 'workload': 'optimizer.update (TM:950): forward + BPTT backward + gradient all-reduce + Adam, schedsamp_k=-1, batch %d/GPU' % B,
                 'loss': float(tloss),

@@ -40,7 +40,7 @@ extern "C" {
 #define PIVP_PRECISION_BF16X6 3
 #define PIVP_PRECISION_FP16X3 4
 
-int pivp_abi_version(void);   /* 12 (12: + pivp_wgrad5x5_fp16x3_batch; 11: + pivp_conv5x5_fp16x3; 10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3, pivp_deconv3x3s2_fp16x3, pivp_plan_set_pack_cache, pivp_plan_params_changed; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+int pivp_abi_version(void);   /* 13 (13: + pivp_wgrad5x5_bf16x6_batch; 12: + pivp_wgrad5x5_fp16x3_batch; 11: + pivp_conv5x5_fp16x3; 10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3, pivp_deconv3x3s2_fp16x3, pivp_plan_set_pack_cache, pivp_plan_params_changed; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
                                  5: + bf16 ConvLSTM, pivp_plan_set_precision, 6: + pivp_plan_set_group_join / pivp_plan_group_wait) */
 
 /* sha256 (hex) of the sources this library was compiled from (every .hip and .h under csrc/, and this header), embedded by build.py.  The Python
@@ -86,7 +86,8 @@ int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr);
  * (4.4e-5 on the config 1 rollout; tests/test_gpu_bf16.py); the backward pass and every other op are the fp32 ones.
  * PIVP_PRECISION_BF16X6 = three bf16 pieces per fp32 operand (hi + mid + lo = v exactly) and the six products of weight >= 2^-16, i.e. fp32-grade
  * gate pre-activations computed on the bf16 matrix cores: the gate convolutions and, in the backward sweep, their DATA gradients, of layers whose map is a
- * multiple of 16 wide (8-wide maps -- lstm5 on 64 x 64 frames -- run the fp32 kernels); the weight gradients and every other op are the fp32 ones.
+ * multiple of 16 wide (8-wide maps -- lstm5 on 64 x 64 frames -- run the fp32 kernels), and their WEIGHT gradients (two timesteps per launch; PIVP_X6_WGRAD=0: the
+ * fp32 kernel); every other op is the fp32 one.
  * PIVP_PRECISION_FP16X3 = the forward gate convolutions (and the enc5 / enc6 transposed convs) with every fp32 operand as TWO FP16 pieces (22 bits of mantissa; a layer's weights are packed times the
  * power of two that puts the largest in [2^14, 2^15), so that the second piece of any weight down to 2^-18 of it stays a normal fp16 number; the sum is scaled
  * back exactly) and three MFMAs per product; activations beyond +-65504 saturate, activations below 0.06 carry up to 3e-8 of absolute error.  Its truncation error is a quarter of the fp32 path's own rounding error (scripts/split_fp16_study.py).  The backward sweep's
@@ -266,6 +267,9 @@ int pivp_wgrad5x5_bf16(const float* x, int cx, int ldx, const float* h_prev, int
  * (byte strides, multiples of 16, may be negative). */
 int pivp_wgrad5x5_bf16_batch(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW, float* db,
                              int B, int H, int W, int tcount, long long ts_x, long long ts_h, long long ts_dG, void* stream);
+/* ... with every operand as three bf16 pieces and six MFMAs per product (fp32-grade, fp32's exponent range; PIVP_PRECISION_BF16X6's weight gradient) */
+int pivp_wgrad5x5_bf16x6_batch(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW, float* db,
+                               int B, int H, int W, int tcount, long long ts_x, long long ts_h, long long ts_dG, void* stream);
 /* ... with every operand as two fp16 pieces and three MFMAs per product (fp32-grade; PIVP_PRECISION_FP16X3's weight gradient): dG is staged times the
  * power of two that puts the largest |value| of the batch into [2^14, 2^15), x and h_prev as they are (|values| < 65504), the sums scaled back exactly.
  * scratch: 72 * tcount floats (every timestep's partial maxima). */

@@ -277,6 +277,7 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
     d.tcount = tcount; d.ts_x0 = ts_x0; d.ts_x1 = ts_x1; d.ts_dy = ts_dy;
     d.part = part;
     d.dy_absmax = dy_absmax; d.dy_absmax_stride = dy_absmax_stride;
+    d.pieces = bf16 == 3 ? 3 : 0;       // (bf16: 1 = operands rounded to bf16; 3 = three bf16 pieces per operand, fp32-grade)
     if (desc_out) *desc_out = d;
     if (bf16 || dy_absmax) {   // bf16 precision mode (5x5 ConvLSTM case only): operands rounded to bf16, fp32 accumulation; db summed on the side in fp32
         if (bias_done) *bias_done = db != nullptr;
@@ -418,7 +419,7 @@ long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin,
 #define PIVP_BUILD_DIGEST "unstamped"      // a build that did not go through build.py: _lib.load() refuses it
 #endif
 extern "C" const char* pivp_build_digest(void) { return PIVP_BUILD_DIGEST; }
-extern "C" int pivp_abi_version(void) { return 12; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
+extern "C" int pivp_abi_version(void) { return 13; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
 
 extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                              const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream) {
@@ -600,6 +601,13 @@ extern "C" int pivp_wgrad5x5_fp16x3_batch(const float* x, int cx, int ldx, const
     }
     return run_wgrad(0, x, cx, ldx, h_prev, C, C, cx + C, dG, 4 * C, 4 * C, dW, B, H, W, H, W, 5, 2, 1, (hipStream_t)stream, db,
                      nullptr, 0, tcount, ts_x, ts_h, ts_dG, nullptr, nullptr, scratch, 72);
+}
+// ... with three bf16 pieces per operand and six MFMAs per product (fp32-grade, fp32's exponent range; the bf16x6 mode's weight gradient)
+extern "C" int pivp_wgrad5x5_bf16x6_batch(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW, float* db,
+                                          int B, int H, int W, int tcount, long long ts_x, long long ts_h, long long ts_dG, void* stream) {
+    if (!x || !dG || !dW || C <= 0 || cx <= 0 || tcount < 1) return PIVP_ERR_BADARG;
+    return run_wgrad(0, x, cx, ldx, h_prev, C, C, cx + C, dG, 4 * C, 4 * C, dW, B, H, W, H, W, 5, 2, 1, (hipStream_t)stream, db,
+                     nullptr, 3, tcount, ts_x, ts_h, ts_dG);
 }
 // ... of a BATCH of timesteps in one launch (the sum over pixels runs over timesteps too): timestep j reads x + j * ts_x, h_prev + j * ts_h,
 // dG + j * ts_dG (byte strides, multiples of 16, may be negative: the backward sweep walks time downwards)

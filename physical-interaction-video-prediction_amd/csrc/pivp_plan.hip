@@ -92,6 +92,7 @@ struct pivp_plan {
     int pack_cache = 0, packs_valid = 0;   // pivp_plan_set_pack_cache: keep the precision modes' weight packs across rollouts until pivp_plan_params_changed
     int bwd_planes = 1;               // the data gradients' form of lstm_planes
     bool x3_wgrad = false;            // fp16x3 mode: the ConvLSTM weight gradients with two fp16 pieces too (wgrad25_bf16_kernel<.., 2>, batched like the bf16 mode's)
+    bool x6_wgrad = false;            // bf16x6 mode: ... with three bf16 pieces (wgrad25_bf16_kernel<.., 3>), same schedule
     int lstm_planes = 1;              // 2: split mode (hi / lo planes, three MFMAs per product); 3: three pieces, six MFMAs (forward gate convs only: the
                                       // backward sweep and every other op of that mode are the fp32 ones)
     int bf16_all = 0;                 // precision mode BF16: also the ConvLSTM gradients and the enc5 / enc6 transposed convs
@@ -170,7 +171,7 @@ static void plan_layout(pivp_plan* p) {
         const char* e = getenv("PIVP_WGRAD_BATCH");
         // (fp16-piece weight gradients: TWO timesteps per launch on half the CUs -- measured grid, profiles/r04/fp16x3_train_wgrad_batch_slots.txt: 8 per
         // launch on every CU, what the bf16 mode does, leaves all of that work to the end of the sweep: 16.85 ms against 16.34)
-        const int want = e ? atoi(e) : (p->bf16_all ? WG_BATCH_MAX : p->x3_wgrad ? 2 : 1);
+        const int want = e ? atoi(e) : (p->bf16_all ? WG_BATCH_MAX : (p->x3_wgrad || p->x6_wgrad) ? 2 : 1);
         int cap = T - 2 < 1 ? 1 : (T - 2 > WG_BATCH_MAX ? WG_BATCH_MAX : T - 2);
         if (want < cap) cap = want < 1 ? 1 : want;
         p->wg_cap = cap;
@@ -349,6 +350,8 @@ extern "C" int pivp_plan_set_precision(pivp_plan_t* plan, int precision) {
     // ... and the weight gradients (PIVP_X3_WGRAD=0: the fp32 kernel, one launch per cell and timestep)
     static const int x3_wgrad = [] { const char* e = getenv("PIVP_X3_WGRAD"); return e ? atoi(e) : 1; }();
     plan->x3_wgrad = plan->lstm_planes == -2 && x3_wgrad != 0;
+    static const int x6_wgrad = [] { const char* e = getenv("PIVP_X6_WGRAD"); return e ? atoi(e) : 1; }();      // 0: the fp32 kernel per cell and timestep
+    plan->x6_wgrad = plan->lstm_planes == 3 && x6_wgrad != 0;
     plan->bf16_all = precision == PIVP_PRECISION_BF16;
     plan->precision = precision;
     plan->packs_valid = 0;
@@ -810,7 +813,8 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         const int cnt = wg_slot + 1;
         int bias_done = 0;
         RC(run_wgrad(0, p->wg_x[i], L.cx, ldx, p->wg_h[i], L.C, L.C, cin, ring, N, N, G(p, p->i_lstm_w[i]), B, hh, wwid, hh, wwid, 5, 2, 1, sw,
-                     G(p, p->i_lstm_b[i]), &bias_done, p->bf16_all, cnt, -slab_bytes, -slab_bytes, (long long)dG1 * 4, nullptr, nullptr,
+                     G(p, p->i_lstm_b[i]), &bias_done, p->bf16_all ? 1 : (p->x6_wgrad && (wwid % 16 == 0 || B % 2 == 0)) ? 3 : 0, cnt, -slab_bytes, -slab_bytes,
+                     (long long)dG1 * 4, nullptr, nullptr,
                      // (fp16 pieces; an 8-wide map with an odd batch does not fit that kernel's two-image tiles: the fp32 kernel takes the batch)
                      (p->x3_wgrad && (wwid % 16 == 0 || B % 2 == 0)) ? ws + g.dg_absmax + (size_t)(i * 2 + wg_ring) * p->wg_cap * 72 : nullptr, 72));
         if (!bias_done)
@@ -990,7 +994,7 @@ static int rollout_backward_sweep(pivp_plan_t* plan, const float* images, const 
         // fetches every operand tile once per 32 x 64 output slice, and what a block pays per launch (205 KB of atomics, the first tile's
         // latency) is amortised over the batch (csrc/wgrad_bf16.hip).
         const char* e = getenv("PIVP_WGRAD_BATCH");
-        int gb = e ? atoi(e) : ((plan->bf16_all || plan->x3_wgrad) ? plan->wg_cap : 1);
+        int gb = e ? atoi(e) : ((plan->bf16_all || plan->x3_wgrad || plan->x6_wgrad) ? plan->wg_cap : 1);
         if (gb < 1) gb = 1;
         if (gb > plan->wg_cap) gb = plan->wg_cap;
         plan->wg_batch = gb;

@@ -41,6 +41,12 @@ __device__ __forceinline__ unsigned wpack2(float a, float b) {
     f32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
+// two fp32 -> packed bf16 (round to nearest even); a, b become the remainders v - bf16(v), exact in fp32 (the pieces of the three-piece form)
+__device__ __forceinline__ unsigned wpack2_rest(float& a, float& b) {
+    const unsigned p2 = wpack2(a, b);
+    a -= __builtin_bit_cast(float, p2 << 16); b -= __builtin_bit_cast(float, p2 & 0xffff0000u);
+    return p2;
+}
 // 4 rows x 16 columns of 16-bit elements, transposed: this lane's column, the 4 rows (see the header)
 template <int OFF>
 __device__ __forceinline__ bf16x4 lds_read_tr(unsigned addr) {
@@ -226,6 +232,8 @@ constexpr int W25_X_BYTES = W25_XPIX * 64;
 // duration because the sweep is bound by the matrix-pipe work of BOTH streams.  dG is staged times a power of two taken from the largest |value| of the
 // batch (WgradDesc::dy_absmax), the activations as they are (LayerNorm outputs, h, ReLU outputs: fp16's range); one accumulator per tile -- three
 // roundings per 16 products, where the fp32 MFMA rounds eight times.  LDS: two planes of each image, 74 KB.
+// PCS = 3: THREE BF16 pieces (hi + mid + lo = v exactly, fp32's exponent range: no scale) and the six products of weight >= 2^-16 (the bf16x6 mode's form):
+// three planes of each image (111 KB), the taps of a k-step in two passes so that their fragments fit the registers.
 template <int TW, int PCS = 1>
 __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d, int tiles_per_split) {
     constexpr int tw = TW;
@@ -311,6 +319,14 @@ __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d,
                 l.x = pivp_pack2h_rest(r0, r1); l.y = pivp_pack2h_rest(r2, r3);
                 *reinterpret_cast<uint2*>(dst) = h;
                 *reinterpret_cast<uint2*>(dst + GB) = l;
+            } else if constexpr (PCS == 3) {
+                float r0 = rg[j][0], r1 = rg[j][1], r2 = rg[j][2], r3 = rg[j][3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    uint2 v;
+                    v.x = wpack2_rest(r0, r1); v.y = wpack2_rest(r2, r3);
+                    *reinterpret_cast<uint2*>(dst + pl * GB) = v;
+                }
             } else {
                 uint2 v;
                 v.x = wpack2(rg[j][0], rg[j][1]); v.y = wpack2(rg[j][2], rg[j][3]);
@@ -327,6 +343,14 @@ __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d,
                 l.x = pivp_pack2h_rest(r0, r1); l.y = pivp_pack2h_rest(r2, r3);
                 *reinterpret_cast<uint2*>(dst) = h;
                 *reinterpret_cast<uint2*>(dst + XB) = l;
+            } else if constexpr (PCS == 3) {
+                float r0 = rx[j][0], r1 = rx[j][1], r2 = rx[j][2], r3 = rx[j][3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    uint2 v;
+                    v.x = wpack2_rest(r0, r1); v.y = wpack2_rest(r2, r3);
+                    *reinterpret_cast<uint2*>(dst + pl * XB) = v;
+                }
             } else {
                 uint2 v;                                      // (pixels past the patch carry the zeros of their out-of-range loads)
                 v.x = wpack2(rx[j][0], rx[j][1]); v.y = wpack2(rx[j][2], rx[j][3]);
@@ -362,6 +386,47 @@ __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d,
 
     auto kstep = [&](auto S) {
         constexpr int s = decltype(S)::value;
+        if constexpr (PCS == 3) {
+            auto j8 = [](const bf16x4& u, const bf16x4& v) { return __builtin_shufflevector(u, v, 0, 1, 2, 3, 4, 5, 6, 7); };
+            bf16x4 ah0 = lds_read_tr<a_off(s, 0)>(a_base), ah1 = lds_read_tr<a_off(s, 1)>(a_base);
+            bf16x4 am0 = lds_read_tr<a_off(s, 0) + GB>(a_base), am1 = lds_read_tr<a_off(s, 1) + GB>(a_base);
+            bf16x4 al0 = lds_read_tr<a_off(s, 0) + 2 * GB>(a_base), al1 = lds_read_tr<a_off(s, 1) + 2 * GB>(a_base);
+            bf16x8 fh, fm, fl;
+            auto pass = [&](auto I0, auto N) {       // taps i0 .. i0 + n - 1 of this wave's seven
+                constexpr int i0 = decltype(I0)::value, n = decltype(N)::value;
+                bf16x4 h0[n], h1[n], m0[n], m1[n], l0[n], l1[n];
+#pragma unroll
+                for (int i = 0; i < n; ++i) {
+                    h0[i] = lds_read_tr<b_off(s, 0)>(b_base[i0 + i]); h1[i] = lds_read_tr<b_off(s, 1)>(b_base[i0 + i]);
+                    m0[i] = lds_read_tr<b_off(s, 0) + XB>(b_base[i0 + i]); m1[i] = lds_read_tr<b_off(s, 1) + XB>(b_base[i0 + i]);
+                    l0[i] = lds_read_tr<b_off(s, 0) + 2 * XB>(b_base[i0 + i]); l1[i] = lds_read_tr<b_off(s, 1) + 2 * XB>(b_base[i0 + i]);
+                }
+                if constexpr (i0 == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah0), "+v"(ah1), "+v"(am0), "+v"(am1), "+v"(al0), "+v"(al1));
+                    fh = j8(ah0, ah1); fm = j8(am0, am1); fl = j8(al0, al1);
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+#pragma unroll
+                for (int i = 0; i < n; ++i) {
+                    asm volatile("" : "+v"(h0[i]), "+v"(h1[i]), "+v"(m0[i]), "+v"(m1[i]), "+v"(l0[i]), "+v"(l1[i]));      // (behind the wait above)
+                    if (i0 + i < 6 || seven) {
+                        const bf16x8 bh = j8(h0[i], h1[i]), bm = j8(m0[i], m1[i]), bl = j8(l0[i], l1[i]);
+                        f32x16 c = acc[i0 + i];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bh, c, 0, 0, 0);       // lo * hi
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bl, c, 0, 0, 0);       // hi * lo
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm, bm, c, 0, 0, 0);       // mid * mid
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm, bh, c, 0, 0, 0);       // mid * hi
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bm, c, 0, 0, 0);       // hi * mid
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bh, c, 0, 0, 0);       // hi * hi
+                        acc[i0 + i] = c;
+                    }
+                }
+            };
+            pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+            pass(std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{});
+            return;
+        }
         bf16x4 a0 = lds_read_tr<a_off(s, 0)>(a_base), a1 = lds_read_tr<a_off(s, 1)>(a_base);
         bf16x4 b0[7], b1[7];
 #pragma unroll
@@ -463,7 +528,7 @@ static int launch_wgrad25(const WgradDesc& d, hipStream_t s) {
     static const int slots = [] { const char* e = getenv("PIVP_WGB_SLOTS"); return e ? atoi(e) : 0; }();
     // (fp16 pieces: its 8-wave blocks hold a CU's whole register file, and the sweep's small kernels need CUs without one: half the CUs)
     // bf16: three quarters (train step 11.86 -> 11.66 ms, profiles/r04/bf16_train_wgrad_batch_slots.txt)
-    const int target = slots > 0 ? slots : (PCS == 2 ? pivp_cu_count() / 2 : pivp_cu_count() * 3 / 4);
+    const int target = slots > 0 ? slots : (PCS >= 2 ? pivp_cu_count() / 2 : pivp_cu_count() * 3 / 4);
     int ns = (target + gx - 1) / gx;
     if (ns > n_tiles / 2) ns = n_tiles / 2;
     if (ns < 1) ns = 1;
@@ -485,6 +550,7 @@ int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s) {
         PIVP_CHECK_ARG(d.dy_absmax_stride >= 66 || d.tcount <= 1);
         return launch_wgrad25<2>(d, s);
     }
+    if (d.pieces == 3) return launch_wgrad25<3>(d, s);      // three bf16 pieces per operand, likewise
     if (kernel == 25 || (kernel != 5 && d.tcount > 1)) return launch_wgrad25<1>(d, s);
     if (d.tcount > 1) {      // PIVP_WGB_KERNEL=5 with a batched descriptor: the kernel-row kernel takes one timestep, so one launch per timestep
         for (int j = 0; j < d.tcount; ++j) {

@@ -404,7 +404,7 @@ def wgrad5x5_bf16(x, h, dG, h_is_zero=False):
     return pivp_amd.from_internal('lstm1/conv/W', dW.cpu().numpy(), (4 * C, cx + C, 5, 5)), db.cpu().numpy()
 
 
-def wgrad5x5_bf16_batch(xs, hs, dGs, fp16x3=False, h_is_zero=False):
+def wgrad5x5_bf16_batch(xs, hs, dGs, fp16x3=False, h_is_zero=False, bf16x6=False):
     """The batched form: lists of per-timestep x (B,cx,H,W), h (B,C,H,W), dG (B,4C,H,W); operands are laid out LAST timestep first with
     negative strides for x / h (as the backward sweep's slabs are) and positive for dG (as its ring is)."""
     lib = _lib.load()
@@ -416,6 +416,11 @@ def wgrad5x5_bf16_batch(xs, hs, dGs, fp16x3=False, h_is_zero=False):
     dW = torch.zeros(25 * (cx + C) * 4 * C, dtype=torch.float32, device=DEV)
     db = torch.zeros(4 * C, dtype=torch.float32, device=DEV)
     sx, sh, sg = xd[0].numel() * 4, hd[0].numel() * 4, gd[0].numel() * 4
+    if bf16x6:       # three bf16 pieces per operand, six MFMAs per product
+        _lib.check(lib.pivp_wgrad5x5_bf16x6_batch(xd[T - 1].data_ptr(), cx, cx, None if h_is_zero else hd[T - 1].data_ptr(), C, gd.data_ptr(), dW.data_ptr(),
+                                                  db.data_ptr(), B, H, Wd, T, -sx, -sh, sg, stream()), 'wgrad5x5_bf16x6_batch')
+        torch.cuda.synchronize()
+        return pivp_amd.from_internal('lstm1/conv/W', dW.cpu().numpy(), (4 * C, cx + C, 5, 5)), db.cpu().numpy()
     if fp16x3:       # two fp16 pieces per operand, dG scaled by a power of two from the batch's largest value
         scratch = torch.zeros(72 * T, dtype=torch.float32, device=DEV)
         _lib.check(lib.pivp_wgrad5x5_fp16x3_batch(xd[T - 1].data_ptr(), cx, cx, None if h_is_zero else hd[T - 1].data_ptr(), C, gd.data_ptr(), dW.data_ptr(),

@@ -252,9 +252,10 @@ def test_wgrad5x5_bf16_batch_of_timesteps(ops, B, cx, C, H, T):
     assert np.abs(db - sum(g.sum(axis=(0, 2, 3)) for g in dGs)).max() < 4e-4
 
 
+@pytest.mark.parametrize('mode', ['fp16x3', 'bf16x6'])
 @pytest.mark.parametrize('gscale', [0.1, 1e-7, 'ragged'])
 @pytest.mark.parametrize('B,cx,C,H,T', [(2, 32, 32, 32, 3), (2, 32, 64, 16, 4), (4, 64, 128, 8, 3), (1, 96, 32, 32, 1)])
-def test_wgrad5x5_fp16x3_batch_of_timesteps(ops, B, cx, C, H, T, gscale):
+def test_wgrad5x5_fp16x3_batch_of_timesteps(ops, B, cx, C, H, T, gscale, mode):
     # the fp16x3 mode's weight gradient: two fp16 pieces per operand, dG scaled by a power of two from the batch's largest value.  fp32-representable
     # operands against the float64 sums and against the fp32 kernel; dG of gradient size (1e-7) and timesteps / gates whose sizes differ by 1e4
     rs = np.random.RandomState(B + cx + C + H + T + 5)
@@ -265,11 +266,12 @@ def test_wgrad5x5_fp16x3_batch_of_timesteps(ops, B, cx, C, H, T, gscale):
     else:
         dGs = [f32(rs.randn(B, 4 * C, H, H) * gscale) for _ in range(T)]
     ref = sum(_wgrad_ref(x, h, g) for x, h, g in zip(xs, hs, dGs))
-    got, db = ops.wgrad5x5_bf16_batch(xs, hs, dGs, fp16x3=True)
+    kw = {'fp16x3': True} if mode == 'fp16x3' else {'bf16x6': True}     # (three bf16 pieces: the bf16x6 mode's form, no scale)
+    got, db = ops.wgrad5x5_bf16_batch(xs, hs, dGs, **kw)
     unit = np.sqrt((ref ** 2).mean())
     e3 = (got - ref) / unit
     ef = (sum(ops.convlstm_wgrad(x, h, g)[0] for x, h, g in zip(xs, hs, dGs)) - ref) / unit if hasattr(ops, 'convlstm_wgrad') else None
-    print('wgrad %d+%d @%d x %d steps, dG %s: two fp16 pieces max |err| %.2e rms %.2e of the gradient rms' % (cx, C, H, T, gscale, np.abs(e3).max(), np.sqrt((e3 ** 2).mean()))
+    print('wgrad %d+%d @%d x %d steps, dG %s: %s max |err| %.2e rms %.2e of the gradient rms' % (cx, C, H, T, gscale, mode, np.abs(e3).max(), np.sqrt((e3 ** 2).mean()))
           + ('' if ef is None else '; fp32 kernel max %.2e rms %.2e' % (np.abs(ef).max(), np.sqrt((ef ** 2).mean()))))
     assert np.abs(e3).max() < 2e-5 and np.sqrt((e3 ** 2).mean()) < 2e-6
     if ef is not None:
@@ -277,7 +279,7 @@ def test_wgrad5x5_fp16x3_batch_of_timesteps(ops, B, cx, C, H, T, gscale):
     dbr = sum(g.sum(axis=(0, 2, 3)) for g in dGs)
     assert np.abs(db - dbr).max() < 1e-4 * np.abs(dbr).max() + 1e-12
     if T == 1:       # the sweep's t = 0: no h operand, only the x rows are touched
-        got0, _ = ops.wgrad5x5_bf16_batch(xs, hs, dGs, fp16x3=True, h_is_zero=True)
+        got0, _ = ops.wgrad5x5_bf16_batch(xs, hs, dGs, h_is_zero=True, **kw)
         assert np.abs(got0[:, :cx] - ref[:, :cx]).max() < 2e-5 * unit and np.all(got0[:, cx:] == 0)
 
 
