@@ -46,7 +46,7 @@ bool conv_s1_splits_k(int cin, int cout, int ldo, int ksize, int B, int H, int W
 bool conv5x5_bf16_splits_k(int cin, int cout, int ldo, int B, int H, int W, int planes = 1);
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
               float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s,
-              float* db = nullptr, int* bias_done = nullptr, int bf16 = 0,
+              float* db = nullptr, int* bias_done = nullptr, int bf16 = 0,    // 5x5 ConvLSTM case: 1 = operands rounded to bf16, 3 = three bf16 pieces each (fp32-grade)
               int tcount = 1, long long ts_x0 = 0, long long ts_x1 = 0, long long ts_dy = 0,    // a batch of timesteps: WgradDesc
               float* part = nullptr, WgradDesc* desc_out = nullptr,    // part: WgradDesc::part; desc_out: the descriptor that was launched
               const float* dy_absmax = nullptr, int dy_absmax_stride = 0);   // two fp16 pieces per operand (WgradDesc::dy_absmax; 5x5 ConvLSTM case only)
