@@ -284,6 +284,22 @@ class Model(object):
     def count_params(self):
         return sum(int(np.prod(s)) for s in self._shapes().values())
 
+    def params_changed(self):
+        """Tell the model that its parameters were written behind torch's back: a collective (`dist.broadcast` / `all_reduce` leave
+        `Tensor._version` untouched), a ctypes kernel, a raw-pointer copy.  The precision modes keep bf16 / fp16 packs of the weights
+        across calls (pivp_plan_set_pack_cache); they are keyed by torch's in-place version counter and this epoch, so every writer
+        torch cannot see must call this (include/pivp_hip.h: pivp_plan_params_changed).  `Adam.step` and `broadcast_params` do."""
+        self._params_epoch = getattr(self, '_params_epoch', 0) + 1
+
+    def broadcast_params(self, src=0, group=None):
+        """Data-parallel replicas start identical: rank `src`'s parameters to every rank, and the weight packs of the
+        precision modes invalidated (the collective writes through the raw pointer).  Parameters are lazily sized: call the model once first."""
+        import torch.distributed as dist
+        if self._flat_params is None:
+            raise RuntimeError('call the model first (parameters are lazily sized)')
+        dist.broadcast(self._flat_params, src=src, group=group)
+        self.params_changed()
+
     # ---- plans --------------------------------------------------------------------------
     def _bind(self, plan):
         lib = plan.lib

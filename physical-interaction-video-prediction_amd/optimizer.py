@@ -54,7 +54,8 @@ class Adam(object):
             _lib.check(lib.pivp_adam_step(model._flat_params.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(),
                                           model._flat_params.numel(), self.lr, self.beta1, self.beta2, self.eps, gscale,
                                           model._stream()), 'pivp_adam_step')
-        model._params_epoch = getattr(model, '_params_epoch', 0) + 1      # (a raw-pointer write: torch's version counter does not see it)
+        if hasattr(model, 'params_changed'):
+            model.params_changed()      # (a raw-pointer write: torch's version counter does not see it)
 
     def update(self, lossfun, *args):
         """chainer.Optimizer.update(lossfun, *args): loss = lossfun(*args); cleargrads; backward; update."""

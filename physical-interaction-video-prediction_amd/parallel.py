@@ -62,6 +62,77 @@ class GradAllReduce(object):
         self.defer_side_wait = bool(defer_side_wait)   # let only the collective's stream wait for the model's side-stream weight gradients
         self.issued = []          # group indices in the order their collectives were issued by the last overlapped backward
 
+    def _schedule(self, model):
+        """-> (bf16 payload?, rs_ag schedule?) for this model under the constructor's `payload` / `algo`"""
+        bf16 = self.payload == 'bf16' or (self.payload == 'auto' and getattr(model, 'precision', 'fp32') == 'bf16')
+        rs_ag = (self.algo == 'rs_ag') or (self.algo == 'auto' and bf16)
+        return bf16, rs_ag
+
+    def _send_buffer(self, flat):
+        if self._send is None or self._send.numel() != flat.numel() or self._send.device != flat.device:
+            self._send = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+        return self._send
+
+    def _rsag_buffers(self, g, n, bf16, device):
+        """stage / recv: N shards of S elements in the payload type (the slice, zero-padded to N * S); red: this rank's reduced shard;
+        full: the gathered result.  S is a multiple of 64 elements, so every shard starts 128-B aligned."""
+        N = self.world_size
+        S = ((n + N - 1) // N + 63) // 64 * 64
+        dt = torch.bfloat16 if bf16 else torch.float32
+        buf = self._rsag.get(g)
+        if buf is None or buf['S'] != S or buf['stage'].dtype != dt or buf['stage'].device != device:
+            buf = {'S': S, 'stage': torch.zeros(N * S, dtype=dt, device=device), 'recv': torch.empty(N * S, dtype=dt, device=device),
+                   'red': torch.empty(S, dtype=dt, device=device), 'full': torch.empty(N * S, dtype=dt, device=device)}
+            self._rsag[g] = buf
+        return buf
+
+    def prepare(self, model, probe=True):
+        """Everything the overlapped path would otherwise do lazily INSIDE the first backward sweep, on the collective stream's critical path:
+        the collective stream, the bf16 send buffer or the rs_ag staging buffers of every gradient group (4 tensors x 6 groups), and -- `probe` --
+        one untimed collective of each kind the schedule uses on the payload's dtype, so that RCCL builds its all-reduce or all-to-all /
+        all-gather channels here and not in a timed step.  Every rank must call it at the same point (the probes are collectives).
+        Returns the kinds probed."""
+        flat = model._ensure_grads()
+        ranges = model.grad_group_ranges()
+        bf16, rs_ag = self._schedule(model)
+        cuda = flat.is_cuda
+        if cuda and self._stream is None:
+            self._stream = torch.cuda.Stream(device=flat.device)
+        if rs_ag:
+            for g, (a, b) in enumerate(ranges):
+                if b > a:
+                    self._rsag_buffers(g, b - a, bf16, flat.device)
+        elif bf16:
+            self._send_buffer(flat)
+        probed = []
+        if not probe or self.world_size == 1:
+            return probed
+        N = self.world_size
+        dt = torch.bfloat16 if bf16 else torch.float32
+        ctx = torch.cuda.stream(self._stream) if cuda else _NullContext()
+        if cuda:
+            self._stream.wait_stream(torch.cuda.current_stream(flat.device))
+        with ctx:
+            if rs_ag:
+                stage = torch.full((N * 64,), float(self.rank + 1), dtype=dt, device=flat.device)
+                recv = torch.empty_like(stage)
+                dist.all_to_all_single(recv, stage, group=self.group)
+                want = torch.arange(1, N + 1, dtype=torch.float32, device=flat.device).repeat_interleave(64)
+                full = torch.empty(N * 64, dtype=dt, device=flat.device)
+                dist.all_gather_into_tensor(full, recv[:64].contiguous(), group=self.group)
+                ok = bool(torch.equal(recv.float(), want)) and bool((full.float() == 1.0).all())
+                probed += ['all_to_all_single', 'all_gather_into_tensor']
+            else:
+                t = torch.full((64,), 1.0, dtype=dt, device=flat.device)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                ok = bool((t.float() == float(N)).all())
+                probed += ['all_reduce']
+        if cuda:
+            torch.cuda.current_stream(flat.device).wait_stream(self._stream)
+        if not ok:
+            raise RuntimeError('collective probe (%s, %s) returned wrong data on rank %d of %d' % (', '.join(probed), dt, self.rank, N))
+        return probed
+
     def bucket_bounds(self, n):
         """Split [0, n) into nbuckets slices with 64-float aligned edges."""
         edges = [0]
@@ -113,15 +184,10 @@ class GradAllReduce(object):
             return flat
         ranges = model.grad_group_ranges()
         cuda = flat.is_cuda
-        bf16 = self.payload == 'bf16' or (self.payload == 'auto' and getattr(model, 'precision', 'fp32') == 'bf16')
-        rs_ag = (self.algo == 'rs_ag') or (self.algo == 'auto' and bf16)
+        bf16, rs_ag = self._schedule(model)
         self.last_algo = 'rs_ag' if rs_ag else 'allreduce'
         N = self.world_size
-        send = None
-        if bf16 and not rs_ag:
-            if self._send is None or self._send.numel() != flat.numel() or self._send.device != flat.device:
-                self._send = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
-            send = self._send
+        send = self._send_buffer(flat) if (bf16 and not rs_ag) else None
         self.last_payload_bytes = sum(max(0, b - a) for a, b in ranges) * (2 if bf16 else 4)
         if cuda:
             if self._stream is None:
@@ -136,21 +202,9 @@ class GradAllReduce(object):
         if defer:
             model.set_group_join(False)
 
-        def rsag_buffers(g, n):
-            """stage / recv: N shards of S elements in the payload type (the slice, zero-padded to N * S); red: this rank's reduced shard;
-            full: the gathered result.  S is a multiple of 64 elements, so every shard starts 128-B aligned."""
-            S = ((n + N - 1) // N + 63) // 64 * 64
-            dt = torch.bfloat16 if bf16 else torch.float32
-            buf = self._rsag.get(g)
-            if buf is None or buf['S'] != S or buf['stage'].dtype != dt or buf['stage'].device != flat.device:
-                buf = {'S': S, 'stage': torch.zeros(N * S, dtype=dt, device=flat.device), 'recv': torch.empty(N * S, dtype=dt, device=flat.device),
-                       'red': torch.empty(S, dtype=dt, device=flat.device), 'full': torch.empty(N * S, dtype=dt, device=flat.device)}
-                self._rsag[g] = buf
-            return buf
-
         def reduce_scatter_gather(g, a, b):
             """the rs_ag schedule for slice [a, b) on the current stream / thread; returns the all-gather's work handle"""
-            buf = rsag_buffers(g, b - a)
+            buf = self._rsag_buffers(g, b - a, bf16, flat.device)
             S = buf['S']
             if cuda and bf16:
                 _pack_bf16(flat[a:b], buf['stage'][:b - a], self._stream)
@@ -237,6 +291,14 @@ class GradAllReduce(object):
             raise RuntimeError('gradient groups were announced out of order or not at all: %r (collectives were still issued '
                                'in ascending order; this step\'s gradients are not valid)' % (out_of_turn,))
         return flat
+
+
+class _NullContext(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 def _pack_bf16(src, dst, stream):

@@ -15,6 +15,8 @@ import os
 import subprocess
 import time
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')    # before torch: this pool's host driver only supports dmabuf IPC (RCCL across processes needs it)
+
 import numpy as np
 import torch
 
@@ -105,7 +107,7 @@ def main(argv=None):
             with using_config('train', False):
                 model(x, 0)
             import torch.distributed as dist
-            dist.broadcast(model._flat_params, src=0); model.reset_state()
+            model.broadcast_params(src=0); model.reset_state()      # (also invalidates the precision modes' weight packs)
         if args.pretrained_state and not state_loaded:
             with using_config('train', False):
                 model(x, 0)

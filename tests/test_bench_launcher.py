@@ -29,6 +29,11 @@ def test_bench_launches_its_own_ranks():
     assert tr['ms_per_step'] > 0 and tr['ms_per_step_without_allreduce'] > 0 and tr['allreduce_ms_exposed'] >= 0
     for key in ('metric', 'unit', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'vs_baseline', 'dtype', 'data', 'roofline', 'cpu_baseline'):
         assert key in out
+    # legs in the order least risky first, all finished; the collectives of each schedule were probed before the timed steps
+    assert out['incomplete'] == [] and 'incomplete_reason' not in out
+    assert tr['collectives_probed_before_timing'] == ['all_reduce']
+    tb = out['train_bf16']                               # config 3's payload and schedule over gloo: all-to-all + fp32 local sum + all-gather
+    assert tb['rccl_ranks'] == 2 and tb['allreduce_algo'] == 'rs_ag' and tb['collectives_probed_before_timing'] == ['all_to_all_single', 'all_gather_into_tensor']
 
 
 def test_bench_refuses_a_world_of_the_wrong_size():
@@ -66,3 +71,78 @@ def test_launcher_times_out_with_a_reason():
                        env=_env(PIVP_BENCH_TIMEOUT='0.5'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode == 124
     assert 'did not finish within' in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+
+
+def test_default_limits_sit_inside_the_drivers():
+    """The driver gives `bench.py` 600 s.  With the default arguments the ranks' own budget and the launcher's limit are below it."""
+    sys.path.insert(0, ROOT)
+    import bench
+    args = bench.parse_args(['--gpus', '8'])
+    assert bench.BUDGET_S <= 450.0 and bench._launch_timeout(args) <= 480.0
+    assert bench._launch_timeout(args) > bench.BUDGET_S          # the ranks speak first, the launcher's kill is the backstop
+
+
+def _line(p):
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    return json.loads(lines[0])
+
+
+def _run(extra_env, launcher='own', timeout=300):
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry', '--steps', '2', '--warmup', '1']
+    if launcher == 'outer':          # the driver's way: bench.py is a rank under somebody else's torchrun
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', '29641'] + cmd[1:]
+    return subprocess.run(cmd, env=_env(**extra_env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_a_failing_train_leg_on_one_rank_keeps_the_measured_legs():
+    """an exception in train_leg('bf16') on rank 1 must not discard rank 0's rollout `value` nor the fp32 train leg.  The failure
+    is agreed on by all ranks (one MIN all-reduce of an ok flag) BEFORE anybody enters the leg's collectives; the leg is dropped everywhere, the
+    line says which and why, exit code 0."""
+    p = _run({'PIVP_BENCH_INJECT': 'train_bf16:1:raise:setup'})
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = _line(p)
+    assert out['n_gpus'] == 2 and out['incomplete'] == ['train_bf16'] and 'train_bf16' not in out
+    assert 'rank 1' in out['incomplete_reason']['train_bf16'] and 'injected failure' in out['incomplete_reason']['train_bf16']
+    assert out['train']['rccl_ranks'] == 2 and out['ms_per_step'] > 0
+
+
+def test_a_hung_leg_ends_with_the_line_and_a_reason_inside_the_budget():
+    """rank 1 never returns from the bf16 train leg: rank 0 blocks in its collective.  At the leg's deadline every rank's watchdog thread ends its
+    process; rank 0 first prints the line of the finished legs with the reason.  Exit code 0: `value` was measured on all ranks."""
+    import time
+    t0 = time.time()
+    p = _run({'PIVP_BENCH_INJECT': 'train_bf16:1:hang:run', 'PIVP_BENCH_LEG_BUDGET': '6'})
+    assert time.time() - t0 < 120
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = _line(p)
+    assert out['incomplete'] == ['train_bf16'] and 'train' in out and out['n_gpus'] == 2
+    assert 'did not finish within its time' in out['incomplete_reason']['run'] and "'train_bf16'" in out['incomplete_reason']['run']
+
+
+def test_the_whole_budget_bounds_the_run():
+    p = _run({'PIVP_BENCH_INJECT': 'train:0:hang:setup', 'PIVP_BENCH_BUDGET': '25'})
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = _line(p)
+    assert out['incomplete'] == ['train', 'train_bf16'] and 'budget of 25 s' in out['incomplete_reason']['run']
+
+
+def test_a_rank_that_dies_does_not_take_the_line_with_it():
+    """A rank gone without a word (segfault, OOM kill): torchrun ends the others with SIGTERM.  Rank 0 takes the signal in its watchdog thread
+    (the main thread sits in a collective) and prints what it has -- under our launcher AND under the driver's own torchrun."""
+    for launcher in ('own', 'outer'):
+        p = _run({'PIVP_BENCH_INJECT': 'train_bf16:1:die:run'}, launcher=launcher)
+        out = _line(p)
+        assert out['incomplete'] == ['train_bf16'] and 'train' in out and out['value'] == 0.0 and out['n_gpus'] == 2, launcher
+        assert 'SIGTERM' in out['incomplete_reason']['run']
+        if launcher == 'own':
+            assert p.returncode == 0, p.stderr[-2000:]      # `value` (the rollout leg) finished on all ranks
+
+
+def test_no_value_no_line():
+    """Nothing is fabricated: when the leg that carries `value` fails there is no line and the exit code is not 0."""
+    p = _run({'PIVP_BENCH_INJECT': 'rollout:1:raise:setup'})
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert 'injected failure' in p.stderr

@@ -608,6 +608,19 @@ def test_weight_packs_are_rebuilt_when_the_parameters_change():
             fresh._flat_params.copy_(m._flat_params)
             l2f = float(fresh([imgs, acts, stas], 0))
         assert l2 == l2f and abs(l2 - l1) > 1e-7, (prec, l1, l2, l2f)
+        # a writer torch cannot see (dist.broadcast / all_reduce leave Tensor._version alone; here a ctypes kernel through raw pointers):
+        # the caller owes Model.params_changed() (Model.broadcast_params does it), and then the next forward equals a fresh model's on those weights
+        lib = m._active.lib
+        v0 = m._flat_params._version
+        src = (m._flat_params * 0.75).to(torch.bfloat16)
+        assert lib.pivp_grad_unpack_bf16(src.data_ptr(), m._flat_params.data_ptr(), src.numel(), None) == 0
+        assert m._flat_params._version == v0
+        m.params_changed()
+        with pivp_amd.using_config('train', False):
+            l3 = float(m([imgs, acts, stas], 0))
+            fresh._flat_params.copy_(m._flat_params)
+            l3f = float(fresh([imgs, acts, stas], 0))
+        assert l3 == l3f and abs(l3 - l2) > 1e-7, (prec, l2, l3, l3f)
 
 
 @pytest.mark.parametrize('B', [2, 3])       # 3: lstm5's 8-wide map cannot be paired into two-image tiles: its three kernels of the sweep are the fp32 ones
