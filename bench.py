@@ -572,6 +572,8 @@ def main(argv=None):
         })
         if dry:
             run.line['dry'] = True
+        elif pivp_amd._lib.build_flags():       # an instrumented / timing-only build of the library (PIVP_EXTRA_FLAGS): say so in the line
+            run.line['library_build_flags'] = pivp_amd._lib.build_flags()
 
     st = {'model': None, 'elapsed': None, 'tmodel': None, 'opt': None, 't_ref': 1.0}     # what later legs need from earlier ones
     with pivp_amd.using_config('train', False):

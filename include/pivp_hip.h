@@ -40,13 +40,16 @@ extern "C" {
 #define PIVP_PRECISION_BF16X6 3
 #define PIVP_PRECISION_FP16X3 4
 
-int pivp_abi_version(void);   /* 13 (13: + pivp_wgrad5x5_bf16x6_batch; 12: + pivp_wgrad5x5_fp16x3_batch; 11: + pivp_conv5x5_fp16x3; 10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3, pivp_deconv3x3s2_fp16x3, pivp_plan_set_pack_cache, pivp_plan_params_changed; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+int pivp_abi_version(void);   /* 14 (14: + pivp_build_flags, pivp_plan_set_main_priority; 13: + pivp_wgrad5x5_bf16x6_batch; 12: + pivp_wgrad5x5_fp16x3_batch; 11: + pivp_conv5x5_fp16x3; 10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3, pivp_deconv3x3s2_fp16x3, pivp_plan_set_pack_cache, pivp_plan_params_changed; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
                                  5: + bf16 ConvLSTM, pivp_plan_set_precision, 6: + pivp_plan_set_group_join / pivp_plan_group_wait) */
 
 /* sha256 (hex) of the sources this library was compiled from (every .hip and .h under csrc/, and this header), embedded by build.py.  The Python
  * binding recomputes it from the sources shipped next to the library and refuses to load on a mismatch: a stale build can never stand
  * in for the code under test.  "unstamped" for a build that bypassed build.py. */
 const char* pivp_build_digest(void);
+/* The compile flags this library was built with beyond build.py's standard set (PIVP_EXTRA_FLAGS: instrumented / timing-only variants); "" for the
+ * product build.  A variant has the same source digest as the product: bench.py reports this string, the GPU tests refuse a non-empty one. */
+const char* pivp_build_flags(void);
 
 /* ------------------------------------------------------------------------------------------
  * Plan = Model.__init__ (TM:484-602): layer table, op program, variant head.
@@ -86,14 +89,16 @@ int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr);
  * (4.4e-5 on the config 1 rollout; tests/test_gpu_bf16.py); the backward pass and every other op are the fp32 ones.
  * PIVP_PRECISION_BF16X6 = three bf16 pieces per fp32 operand (hi + mid + lo = v exactly) and the six products of weight >= 2^-16, i.e. fp32-grade
  * gate pre-activations computed on the bf16 matrix cores: the gate convolutions and, in the backward sweep, their DATA gradients, of layers whose map is a
- * multiple of 16 wide (8-wide maps -- lstm5 on 64 x 64 frames -- run the fp32 kernels), and their WEIGHT gradients (two timesteps per launch; PIVP_X6_WGRAD=0: the
- * fp32 kernel); every other op is the fp32 one.
+ * multiple of 16 wide (8-wide maps -- lstm5 on 64 x 64 frames -- run the fp32 kernels), and their WEIGHT gradients (two timesteps per launch); every other op is the fp32 one.
  * PIVP_PRECISION_FP16X3 = the forward gate convolutions (and the enc5 / enc6 transposed convs) with every fp32 operand as TWO FP16 pieces (22 bits of mantissa; a layer's weights are packed times the
  * power of two that puts the largest in [2^14, 2^15), so that the second piece of any weight down to 2^-18 of it stays a normal fp16 number; the sum is scaled
  * back exactly) and three MFMAs per product; activations beyond +-65504 saturate, activations below 0.06 carry up to 3e-8 of absolute error.  Its truncation error is a quarter of the fp32 path's own rounding error (scripts/split_fp16_study.py).  The backward sweep's
  * ConvLSTM data and weight gradients take the same form: gradients do not fit fp16's exponent range as they are, so dG is staged times the power of two that puts
  * its largest |value| (per cell and timestep / batch of timesteps: one absmax launch) into [2^14, 2^15) and the sums are scaled back exactly; an 8-wide map with
- * an odd batch keeps the fp32 kernels.  PIVP_X3_DGRAD=0 / PIVP_X3_WGRAD=0: PIVP_PRECISION_BF16X6's data gradients / the fp32 weight gradients.  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch). */
+ * an odd batch keeps the fp32 kernels.  PIVP_ERR_BADARG when a layer's map does not fit the bf16 kernel (8-wide maps need an even batch).
+ * ORDER: pivp_plan_set_precision -> pivp_plan_workspace_bytes -> pivp_plan_set_workspace.  The workspace size depends on the precision (the modes that batch
+ * their ConvLSTM weight gradients keep deeper gate-gradient rings), so pivp_plan_workspace_bytes changes with this call while no workspace is bound.  With a
+ * workspace bound, a mode that needs deeper rings than the bound layout holds is refused with PIVP_ERR_STATE (nothing changes); modes that fit switch in place. */
 int pivp_plan_set_precision(pivp_plan_t* plan, int precision);
 int pivp_plan_get_precision(const pivp_plan_t* plan);
 /* The precision modes re-pack the ConvLSTM weights (bf16 / split pieces) at the start of every rollout, because the parameters may have changed.  With
@@ -119,6 +124,12 @@ int pivp_reset_state(pivp_plan_t* plan, void* stream);
 int pivp_rollout_forward(pivp_plan_t* plan, const float* images, const float* actions, const float* states,
                          const unsigned char* gt_select, float* gen_images, float* gen_states, float* results,
                          void* stream);
+
+/* Wave priority of the caller-stream kernels of pivp_rollout_backward (s_setprio 3 against the side stream's weight-gradient waves: the single-GPU train
+ * step gains 1.5 %).  mode -1 (default): on unless a gradient listener is registered (pivp_plan_set_grad_callback: a data-parallel rank, whose collective's
+ * waves must not be starved); 0 / 1: off / on.  The switch is one word per device and process, rewritten on the call's stream when the wanted value
+ * changes; it never changes results. */
+int pivp_plan_set_main_priority(pivp_plan_t* plan, int mode);
 
 /* Backward through time of the last pivp_rollout_forward (same arguments; the plan must have keep_activations = 1):
  * what loss.backward() does inside Chainer's optimizer.update (TM:950).  Gradients are ACCUMULATED into the buffers

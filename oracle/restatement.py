@@ -260,6 +260,13 @@ def init_params(seed=1, dtype=np.float32, scale=1.0, **kw):
     return p
 
 
+def init_params_widened(seed=1, scale=1.0, **kw):
+    """`init_params(dtype=np.float32)` -- the weights every GPU test loads -- widened to float64, so that the float64 oracle and the HIP path run on
+    IDENTICAL parameters (the fixtures of tests/golden since round 5; before, the oracle ran on the unrounded float64 draw of the same stream)."""
+    p32 = init_params(seed=seed, dtype=np.float32, scale=scale, **kw)
+    return OrderedDict((k, v.astype(np.float64)) for k, v in p32.items())
+
+
 def synthetic_batch(batch, seq_len=10, height=64, width=64, seed=0, dtype=np.float32):
     """Seed-0 synthetic inputs: images U[0,1) (T,B,3,H,W); actions, states 0.1*N(0,1) (T,B,5)."""
     rs = np.random.RandomState(seed)

@@ -33,6 +33,7 @@ class PivpFrameHeadArgs(ctypes.Structure):
 SIGNATURES = {
     'pivp_abi_version': (_i, []),
     'pivp_build_digest': (_c.c_char_p, []),
+    'pivp_build_flags': (_c.c_char_p, []),
     'pivp_plan_create': (_i, [_c.POINTER(PivpConfig), _c.POINTER(_vp)]),
     'pivp_plan_destroy': (None, [_vp]),
     'pivp_param_count': (_i, [_vp]),
@@ -53,6 +54,7 @@ SIGNATURES = {
     'pivp_param_group': (_i, [_vp, _i]),
     'pivp_param_group_by_name': (_i, [_c.c_char_p]),
     'pivp_plan_set_grad_callback': (_i, [_vp, _vp, _vp]),
+    'pivp_plan_set_main_priority': (_i, [_vp, _i]),
     'pivp_plan_set_group_join': (_i, [_vp, _i]),
     'pivp_plan_group_wait': (_i, [_vp, _i, _vp]),
     'pivp_convlstm_ln_scratch_floats': (_ll, [_i, _i, _i, _i]),
@@ -139,13 +141,23 @@ def load():
     # a library older (or newer) than the sources next to it must never stand in for them: a GPU test would then pass or fail on code
     # other than the code it claims to test
     from . import _digest
-    built, shipped = lib.pivp_build_digest().decode(), _digest.source_digest()
+    try:
+        shipped = _digest.source_digest()
+    except OSError as e:      # a copied / installed package without csrc/ or the repo's include/: say what is missing instead of a bare open() error
+        raise RuntimeError('cannot check libpivp_hip.so against its sources: %s is missing (the package needs csrc/*.hip, csrc/*.h and '
+                           '../include/pivp_hip.h next to it; there is no CPU fallback)' % e.filename) from e
+    built = lib.pivp_build_digest().decode()
     if built != shipped:
         raise RuntimeError(
             'libpivp_hip.so is stale: it was built from sources with digest %s..., the sources in %s have %s.... Rebuild it '
             '(`python physical-interaction-video-prediction_amd/build.py`); there is no CPU fallback.' % (built[:12], _digest.CSRC, shipped[:12]))
     _lib = lib
     return lib
+
+
+def build_flags():
+    """Extra compile flags of the loaded library ('' = the product build; anything else is an instrumented or timing-only variant)."""
+    return load().pivp_build_flags().decode()
 
 
 class PivpError(RuntimeError):

@@ -13,9 +13,10 @@ SOURCES = ['igemm_f32.hip', 'igemm_small.hip', 'deconv_tile.hip', 'convlstm_bf16
 LIB = os.path.join(HERE, 'libpivp_hip.so')
 STAMP = os.path.join(HERE, '.libpivp_hip.stamp')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
-if os.environ.get('PIVP_ABLATE'):   # timing-only diagnostic variants of the igemm kernel (scripts/bench_lstm_layers.py)
-    FLAGS.append('-DPIVP_ABLATE')
-FLAGS += os.environ.get('PIVP_EXTRA_FLAGS', '').split()   # experiments, e.g. -DPIVP_XCD_MAP=0
+EXTRA = os.environ.get('PIVP_EXTRA_FLAGS', '').split()     # instrumented builds, e.g. -DPIVP_F32_STAMPS: recorded in the library (pivp_build_flags)
+if os.environ.get('PIVP_ABLATE'):
+    EXTRA = ['-DPIVP_ABLATE'] + EXTRA
+FLAGS += EXTRA
 
 
 def _load_digest_module():
@@ -52,6 +53,7 @@ def build(force=False, verbose=False):
         cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
         if src == 'pivp_c_api.hip':      # pivp_build_digest(): the digest of the sources this library is built from
             cmd.insert(-4, '-DPIVP_BUILD_DIGEST="%s"' % src_dig)
+            cmd.insert(-4, '-DPIVP_BUILD_FLAGS="%s"' % ' '.join(EXTRA).replace('"', "'"))
         objs.append(obj)
         with open(os.path.join(CSRC, src), 'rb') as f:
             key = hashlib.sha256(hdr.digest() + f.read() + ' '.join(cmd).encode()).hexdigest()

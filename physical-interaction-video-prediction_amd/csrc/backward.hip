@@ -605,3 +605,5 @@ int grad_unpack_bf16(const void* src, float* dst, long n, hipStream_t s) {
 }
 
 }  // namespace pivp
+
+PIVP_DEFINE_MAIN_PRIO_SETTER(backward)

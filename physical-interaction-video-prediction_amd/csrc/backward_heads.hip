@@ -1152,3 +1152,5 @@ int add_strided(float* dst, int ldd, const float* src, int lds_, int C, long npi
 }
 
 }  // namespace pivp
+
+PIVP_DEFINE_MAIN_PRIO_SETTER(backward_heads)

@@ -1677,8 +1677,10 @@ extern "C" int pivp_debug_bf16_stamps(long long* out, int n) {   // n <= 2048 * 
 namespace pivp {
 #endif
 
+// (the kernel reads whole float4s: n a multiple of 4 and w 16-byte aligned -- every tensor it is used on is; anything else is refused, a tail
+// left out of the maximum would let the fp16 hi piece saturate)
 int absmax_partials(const float* w, long n, float* tail, hipStream_t stream) {
-    PIVP_CHECK_ARG(w && tail && n > 0);
+    PIVP_CHECK_ARG(w && tail && n > 0 && n % 4 == 0 && ((uintptr_t)w & 15) == 0);
     hipLaunchKernelGGL(absmax_partials_kernel, dim3(64), dim3(512), 0, stream, w, n, tail);
     return PIVP_LAUNCH_STATUS();
 }
@@ -1785,6 +1787,8 @@ int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stre
     PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0) || ((nch == 1 || nch == 2) && planes == 3) ||
                                                  (nch == 256 && planes == -2 && d.Hin % 16 == 0 && d.Win % 16 == 0)) &&
                    ((planes >= 1 && planes <= 3) || planes == -2));
+    // LayerNorm-on-load (d.in_g) exists in the eight-wave L2-direct kernels only (launch_x6g): every other form would consume the raw tensor
+    PIVP_CHECK_ARG(!d.in_g || ((planes == 3 || planes == -2) && convlstm_bf16x6_ok(d) && nch != 1));
     if (planes == -2 && !convlstm_bf16x6_ok(d)) {   // 8-wide maps: the ring kernel with fp16 pieces (wb = pack_lstm_bf16(..., planes = -2, plain = 2))
         const int tw2 = 8, ti2 = 2;
         const long b32 = d.C % 32 ? 0 : (long)(d.B / ti2) * (d.Hin / TH) * (d.Win / tw2) * (d.C / 32);
@@ -1805,12 +1809,11 @@ int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stre
     }
     if (planes == 3) {   // three pieces: 16-wide tiles and 16-channel blocks only (convlstm_bf16x6_ok); 8-wide maps are the caller's to route elsewhere
         PIVP_CHECK_ARG(convlstm_bf16x6_ok(d));
-        // weights straight from L2: 32-channel blocks (eight waves) where they give every CU a block, else 16-channel blocks (four waves).
-        // PIVP_X6_RING=1 (tuning / tests): the 16-channel blocks take the LDS-ring kernel instead
-        static const int ring = [] { const char* e = getenv("PIVP_X6_RING"); return e ? atoi(e) : 0; }();
+        // weights straight from L2: 32-channel blocks (eight waves) where they give every CU a block, else 16-channel blocks (four waves);
+        // nch = 1 (op tests): the 16-channel blocks on the LDS-ring kernel instead
         const long b32 = d.C % 32 ? 0 : (long)d.B * (d.Hin / TH) * (d.Win / 16) * (d.C / 32);
         if ((nch == 32 && b32 > 0) || (nch == 0 && b32 >= pivp_cu_count())) return launch_x6g<2, 4>(d, wb, stream, ln_nparts);
-        if (ring || nch == 1) return launch_bf16<16, true, 3>(d, wb, stream, ln_nparts, d.C / 16, 1, 0);
+        if (nch == 1) return launch_bf16<16, true, 3>(d, wb, stream, ln_nparts, d.C / 16, 1, 0);
         if (nch == 2) return launch_x6g<2, 2>(d, wb, stream, ln_nparts);      // (four waves, one per SIMD: measured against the eight-wave form)
         return launch_x6g<4, 2>(d, wb, stream, ln_nparts);
     }
@@ -1870,3 +1873,5 @@ int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t strea
 }
 
 }  // namespace pivp
+
+PIVP_DEFINE_MAIN_PRIO_SETTER(convlstm_bf16)

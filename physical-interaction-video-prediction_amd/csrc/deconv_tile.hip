@@ -367,3 +367,5 @@ int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts, int prec
 }
 
 }  // namespace pivp
+
+PIVP_DEFINE_MAIN_PRIO_SETTER(deconv_tile)

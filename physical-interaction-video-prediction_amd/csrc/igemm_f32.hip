@@ -849,3 +849,5 @@ extern "C" int pivp_debug_f32_stamps(long long* out, int n) {   // n <= 2048 * 8
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(pivp::pivp_f32_stamps), sizeof(long long) * n) == hipSuccess ? 0 : -2;
 }
 #endif
+
+PIVP_DEFINE_MAIN_PRIO_SETTER(igemm_f32)

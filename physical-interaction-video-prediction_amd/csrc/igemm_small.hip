@@ -337,3 +337,5 @@ bool igemm_in_ln_ok(const IgemmDesc& d) {
 }
 
 }  // namespace pivp
+
+PIVP_DEFINE_MAIN_PRIO_SETTER(igemm_small)

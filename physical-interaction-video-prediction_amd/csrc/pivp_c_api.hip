@@ -419,7 +419,11 @@ long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin,
 #define PIVP_BUILD_DIGEST "unstamped"      // a build that did not go through build.py: _lib.load() refuses it
 #endif
 extern "C" const char* pivp_build_digest(void) { return PIVP_BUILD_DIGEST; }
-extern "C" int pivp_abi_version(void) { return 13; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
+#ifndef PIVP_BUILD_FLAGS
+#define PIVP_BUILD_FLAGS ""                // the compile flags beyond build.py's standard set (PIVP_EXTRA_FLAGS): "" = the product build
+#endif
+extern "C" const char* pivp_build_flags(void) { return PIVP_BUILD_FLAGS; }
+extern "C" int pivp_abi_version(void) { return 14; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
 
 extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                              const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream) {

@@ -143,10 +143,21 @@ __device__ __forceinline__ void ln_merge_partials(const float* __restrict__ part
 // Wave priority of the kernels on the backward sweep's critical path (the caller's stream).  Beside the side stream's weight-gradient
 // waves, which keep the matrix pipe of their SIMD busy, a co-resident wave at the default priority 0 gets a VALU issue slot every few
 // hundred cycles: a chain of 500 dependent FMAs takes 111 us instead of 3.6 (scripts/contention_probe.py), 45 us with s_setprio 3.
-// Built with -DPIVP_MAIN_PRIO=3 the sweep's small kernels run 2-4x faster beside the side stream (igemm_small 171 -> 43 us) but the
-// train step does not move (the sweep is bound by the matrix-pipe work of both streams together), and in a data-parallel job the
-// collective's long-lived waves, which win the oldest-first arbitration at equal priority, would lose it.  Default: 0 (no s_setprio).
-#ifndef PIVP_MAIN_PRIO
-#define PIVP_MAIN_PRIO 0
-#endif
-#define PIVP_SET_MAIN_PRIO() do { if (PIVP_MAIN_PRIO > 0) __builtin_amdgcn_s_setprio(PIVP_MAIN_PRIO); } while (0)
+// With priority 3 the sweep's small kernels run 2-4x faster beside the side stream (igemm_small 171 -> 43 us) and the single-GPU train step
+// gains 1.5 % (28.21 -> 27.78 ms fp32, 23.99 -> 23.34 three pieces, profiles/r04/NOTES.md); in a data-parallel job the collective's long-lived
+// waves, which win the oldest-first arbitration at equal priority, would lose it.  So it is a RUN-TIME switch (round 5): one device word per
+// translation unit (the library is built without relocatable device code), written by the unit's setter below on the plan's stream when the
+// wanted value changes -- pivp_plan_set_main_priority: on for plans without a gradient listener, off under data parallelism.  The word is per
+// device and process, not per plan: two plans that want different values on one device take turns (priority never changes results).
+namespace pivp {
+__attribute__((unused)) static __device__ int g_main_prio;
+}
+#define PIVP_SET_MAIN_PRIO() do { if (pivp::g_main_prio) __builtin_amdgcn_s_setprio(3); } while (0)
+#define PIVP_DEFINE_MAIN_PRIO_SETTER(unit)                                                                                              \
+    namespace pivp {                                                                                                                     \
+    int main_prio_set_##unit(int on, hipStream_t s) {                                                                                    \
+        static const int kVal[2] = {0, 1};    /* the copy is asynchronous: its source must outlive the call */                           \
+        return hipMemcpyToSymbolAsync(HIP_SYMBOL(g_main_prio), &kVal[on ? 1 : 0], sizeof(int), 0, hipMemcpyHostToDevice, s) == hipSuccess \
+                   ? PIVP_OK : PIVP_ERR_LAUNCH;                                                                                          \
+    }                                                                                                                                    \
+    }

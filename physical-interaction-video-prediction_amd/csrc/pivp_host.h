@@ -71,6 +71,13 @@ int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w
 long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin, int Win);
 int run_layernorm(const float* x, const float* g, const float* b, float* out, float* partials, int B, int n, int C,
                   int ldo, float eps, int relu, hipStream_t s, float* stat_out = nullptr, int fused_nparts = 0);
+// run-time wave priority of the main stream's kernels (pivp_common.h): every translation unit with such kernels, on stream s
+int main_prio_set_backward(int on, hipStream_t s);
+int main_prio_set_backward_heads(int on, hipStream_t s);
+int main_prio_set_convlstm_bf16(int on, hipStream_t s);
+int main_prio_set_deconv_tile(int on, hipStream_t s);
+int main_prio_set_igemm_f32(int on, hipStream_t s);
+int main_prio_set_igemm_small(int on, hipStream_t s);
 int run_select_frames(const float* gt, const float* gen, const unsigned char* take, float* out, int B, int frame_numel, hipStream_t s);
 
 }  // namespace pivp

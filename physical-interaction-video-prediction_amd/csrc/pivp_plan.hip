@@ -95,6 +95,7 @@ struct pivp_plan {
     bool x6_wgrad = false;            // bf16x6 mode: ... with three bf16 pieces (wgrad25_bf16_kernel<.., 3>), same schedule
     int lstm_planes = 1;              // 2: split mode (hi / lo planes, three MFMAs per product); 3: three pieces, six MFMAs (forward gate convs only: the
                                       // backward sweep and every other op of that mode are the fp32 ones)
+    int main_prio = -1;               // pivp_plan_set_main_priority: -1 = on unless a gradient listener is registered (data parallelism), 0 / 1 = as said
     int bf16_all = 0;                 // precision mode BF16: also the ConvLSTM gradients and the enc5 / enc6 transposed convs
     pivp_grad_group_cb grad_cb = nullptr; void* grad_cb_user = nullptr;   // gradient-group-final notifications (t = 0 sweep)
     int loss_nparts;
@@ -143,6 +144,21 @@ static float* G(const pivp_plan* p, int idx) { return p->params[idx].grad; }
 // ---- workspace carve (offsets in floats, 256-B aligned).  Runs at pivp_plan_create and again from pivp_plan_set_precision while no
 // workspace is bound: the ConvLSTM dG rings hold wg_cap timesteps per ring, and only the bf16 mode (or PIVP_WGRAD_BATCH) batches its weight
 // gradients -- an fp32 plan double-buffers with ONE slot per ring instead of 8 (2.5 GB less at 128 x 128, B = 32, T = 20). ----
+// PIVP_WGRAD_BATCH (tests, measurements): timesteps per ConvLSTM weight-gradient launch, whatever the precision mode; 0 = the mode's own choice
+static int wgrad_batch_env() {
+    static const int v = [] { const char* e = getenv("PIVP_WGRAD_BATCH"); return e ? atoi(e) : 0; }();
+    return v;
+}
+// dG ring slots per ring: timesteps t = T-2 .. 1 batch (t = 0, no h input, goes alone), as many slots as a launch may take timesteps.
+// (fp16-piece / three-piece weight gradients: TWO timesteps per launch on half the CUs -- measured grid, profiles/r04/fp16x3_train_wgrad_batch_slots.txt:
+// 8 per launch on every CU, what the bf16 mode does, leaves all of that work to the end of the sweep: 16.85 ms against 16.34)
+static int wg_cap_of(const pivp_plan* p) {
+    const int T = p->cfg.seq_len, e = wgrad_batch_env();
+    const int want = e ? e : (p->bf16_all ? WG_BATCH_MAX : (p->x3_wgrad || p->x6_wgrad) ? 2 : 1);
+    int cap = T - 2 < 1 ? 1 : (T - 2 > WG_BATCH_MAX ? WG_BATCH_MAX : T - 2);
+    if (want < cap) cap = want < 1 ? 1 : want;
+    return cap;
+}
 static void plan_layout(pivp_plan* p) {
     const pivp_config_t* cfg = &p->cfg;
     const int H = cfg->height, W = cfg->width, B = cfg->batch, T = cfg->seq_len;
@@ -167,15 +183,7 @@ static void plan_layout(pivp_plan* p) {
     for (int i = 0; i < 7; ++i)       // 2-byte elements in a float-counted workspace
         p->o_wbf16[i] = carve(lstm_bf16_weight_elems(kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C) * 3 / 2 + 64);   // room for the three planes of PIVP_PRECISION_BF16X6
     p->nslabs = train ? T - 1 : 2;
-    {   // timesteps t = T-2 .. 1 batch (t = 0, no h input, goes alone): as many ring slots as a launch may take timesteps
-        const char* e = getenv("PIVP_WGRAD_BATCH");
-        // (fp16-piece weight gradients: TWO timesteps per launch on half the CUs -- measured grid, profiles/r04/fp16x3_train_wgrad_batch_slots.txt: 8 per
-        // launch on every CU, what the bf16 mode does, leaves all of that work to the end of the sweep: 16.85 ms against 16.34)
-        const int want = e ? atoi(e) : (p->bf16_all ? WG_BATCH_MAX : (p->x3_wgrad || p->x6_wgrad) ? 2 : 1);
-        int cap = T - 2 < 1 ? 1 : (T - 2 > WG_BATCH_MAX ? WG_BATCH_MAX : T - 2);
-        if (want < cap) cap = want < 1 ? 1 : want;
-        p->wg_cap = cap;
-    }
+    p->wg_cap = wg_cap_of(p);
     p->slabs.resize(p->nslabs);
     for (int s = 0; s < p->nslabs; ++s) {
         Slab& S = p->slabs[s];
@@ -342,20 +350,25 @@ extern "C" int pivp_plan_set_precision(pivp_plan_t* plan, int precision) {
             if (!convlstm_bf16_ok(d)) return PIVP_ERR_BADARG;
         }
     }
-    plan->lstm_bf16 = precision != PIVP_PRECISION_F32;
-    plan->lstm_planes = precision == PIVP_PRECISION_BF16X3 ? 2 : precision == PIVP_PRECISION_BF16X6 ? 3 : precision == PIVP_PRECISION_FP16X3 ? -2 : 1;
-    // fp16 pieces in the sweep: the data gradients take dG times a power of two from its largest |value| (PIVP_X3_DGRAD=0: the three-bf16-piece form)
-    static const int x3_dgrad = [] { const char* e = getenv("PIVP_X3_DGRAD"); return e ? atoi(e) : 1; }();
-    plan->bwd_planes = plan->lstm_planes == -2 ? (x3_dgrad ? -2 : 3) : plan->lstm_planes;
-    // ... and the weight gradients (PIVP_X3_WGRAD=0: the fp32 kernel, one launch per cell and timestep)
-    static const int x3_wgrad = [] { const char* e = getenv("PIVP_X3_WGRAD"); return e ? atoi(e) : 1; }();
-    plan->x3_wgrad = plan->lstm_planes == -2 && x3_wgrad != 0;
-    static const int x6_wgrad = [] { const char* e = getenv("PIVP_X6_WGRAD"); return e ? atoi(e) : 1; }();      // 0: the fp32 kernel per cell and timestep
-    plan->x6_wgrad = plan->lstm_planes == 3 && x6_wgrad != 0;
-    plan->bf16_all = precision == PIVP_PRECISION_BF16;
-    plan->precision = precision;
-    plan->packs_valid = 0;
-    if (!plan->ws) plan_layout(plan);      // the dG rings' depth follows the precision; a bound workspace keeps the layout it was sized for
+    pivp_plan& m = *plan;
+    struct Modes { int lstm_bf16, lstm_planes, bwd_planes, bf16_all, precision; bool x3_wgrad, x6_wgrad; };
+    const Modes old{m.lstm_bf16, m.lstm_planes, m.bwd_planes, m.bf16_all, m.precision, m.x3_wgrad, m.x6_wgrad};
+    m.lstm_bf16 = precision != PIVP_PRECISION_F32;
+    m.lstm_planes = precision == PIVP_PRECISION_BF16X3 ? 2 : precision == PIVP_PRECISION_BF16X6 ? 3 : precision == PIVP_PRECISION_FP16X3 ? -2 : 1;
+    m.bwd_planes = m.lstm_planes;          // fp16 pieces in the sweep: the data gradients take dG times a power of two from its largest |value|
+    m.x3_wgrad = m.lstm_planes == -2;      // ... and the weight gradients two fp16 pieces, two timesteps per launch
+    m.x6_wgrad = m.lstm_planes == 3;       // three-piece mode: the weight gradients with three bf16 pieces, same schedule
+    m.bf16_all = precision == PIVP_PRECISION_BF16;
+    m.precision = precision;
+    // The dG rings' depth follows the precision, so the order is set_precision -> workspace_bytes -> set_workspace (include/pivp_hip.h).  With a
+    // workspace already bound the layout it was sized for stays; a mode that needs deeper rings than it has is refused, not run short.
+    if (m.ws && m.has_grads && wg_cap_of(plan) > m.wg_cap) {
+        m.lstm_bf16 = old.lstm_bf16; m.lstm_planes = old.lstm_planes; m.bwd_planes = old.bwd_planes; m.bf16_all = old.bf16_all;
+        m.precision = old.precision; m.x3_wgrad = old.x3_wgrad; m.x6_wgrad = old.x6_wgrad;
+        return PIVP_ERR_STATE;
+    }
+    m.packs_valid = 0;
+    if (!plan->ws) plan_layout(plan);
     return PIVP_OK;
 }
 // Inference with constant weights: keep the bf16 / fp16 weight packs across rollouts (on = 1) instead of rebuilding them at the start of each.  The
@@ -703,6 +716,23 @@ static int wait_slot(pivp_plan* p, int sl, hipStream_t stream) {
     for (int r = 0; r < 2; ++r) if (hipStreamWaitEvent(stream, p->ev_ring_done[sl][r], 0) != hipSuccess) return PIVP_ERR_LAUNCH;
     return PIVP_OK;
 }
+// Wave priority of the main stream's kernels during this plan's calls (csrc/pivp_common.h): the device word is rewritten only when the wanted value
+// differs from what this process last wrote on the device.
+static int apply_main_prio(pivp_plan* p, hipStream_t s) {
+    static int current[PIVP_MAX_DEV] = {};      // device words start at 0
+    const int want = p->main_prio < 0 ? (p->grad_cb ? 0 : 1) : (p->main_prio ? 1 : 0);
+    const int dev = pivp_current_device();
+    if (current[dev] == want) return PIVP_OK;
+    RC(main_prio_set_backward(want, s)); RC(main_prio_set_backward_heads(want, s)); RC(main_prio_set_convlstm_bf16(want, s));
+    RC(main_prio_set_deconv_tile(want, s)); RC(main_prio_set_igemm_f32(want, s)); RC(main_prio_set_igemm_small(want, s));
+    current[dev] = want;
+    return PIVP_OK;
+}
+extern "C" int pivp_plan_set_main_priority(pivp_plan_t* plan, int mode) {
+    if (!plan || mode < -1 || mode > 1) return PIVP_ERR_BADARG;
+    plan->main_prio = mode;
+    return PIVP_OK;
+}
 extern "C" int pivp_plan_set_group_join(pivp_plan_t* plan, int join) {
     if (!plan) return PIVP_ERR_BADARG;
     plan->group_join = join != 0;
@@ -989,12 +1019,13 @@ static int rollout_backward_sweep(pivp_plan_t* plan, const float* images, const 
     const float fscale = 2.0f / ((float)fr * (float)(T - ctx));              // d/d gen of mean-squared error / (T - ctx)
     const float sscale = 2.0f * 1e-4f / ((float)(B * 5) * (float)(T - ctx));
     RC(ensure_side(plan));
+    RC(apply_main_prio(plan, s));
     {   // Timesteps per ConvLSTM weight-gradient launch (PIVP_WGRAD_BATCH overrides, 1..wg_cap).  fp32: 1 (batches arrive in bursts and
         // overlap the sweep worse: 29.9 / 30.3 ms for 1 / 2, profiles/r02).  bf16 mode: as many as the rings hold -- its 25-tap kernel
         // fetches every operand tile once per 32 x 64 output slice, and what a block pays per launch (205 KB of atomics, the first tile's
         // latency) is amortised over the batch (csrc/wgrad_bf16.hip).
-        const char* e = getenv("PIVP_WGRAD_BATCH");
-        int gb = e ? atoi(e) : ((plan->bf16_all || plan->x3_wgrad || plan->x6_wgrad) ? plan->wg_cap : 1);
+        const int e = wgrad_batch_env();
+        int gb = e ? e : ((plan->bf16_all || plan->x3_wgrad || plan->x6_wgrad) ? plan->wg_cap : 1);
         if (gb < 1) gb = 1;
         if (gb > plan->wg_cap) gb = plan->wg_cap;
         plan->wg_batch = gb;

@@ -137,7 +137,7 @@ class Model(object):
 
     def __init__(self, num_masks, is_cdna=True, is_dna=False, is_stp=False, use_state=True,
                  scheduled_sampling_k=-1, num_frame_before_prediction=2, prefix=None,
-                 device='cuda:0', ln_eps=1e-6, stp_border='clamp', keep_activations=False, precision='fp32'):
+                 device='cuda:0', ln_eps=1e-6, stp_border='clamp', keep_activations=False, precision='fp32', main_priority=None):
         if is_cdna:                      # TM:531-542, precedence cdna > stp > dna
             self.model_type = 'CDNA'
         elif is_stp:
@@ -173,6 +173,7 @@ class Model(object):
         if precision not in ('fp32', 'bf16', 'bf16x3', 'bf16x6', 'fp16x3'):
             raise ValueError("precision must be 'fp32', 'bf16', 'bf16x3', 'bf16x6' or 'fp16x3'")
         self.precision = precision
+        self.main_priority = main_priority     # None / False / True: include/pivp_hip.h, pivp_plan_set_main_priority
         self._ref_pending = None       # reference-layout arrays loaded before the first call
         self._params = None            # name -> view into _flat_params (internal layout)
         self._flat_params = None
@@ -324,6 +325,8 @@ class Model(object):
                                   ln_eps=self.ln_eps, stp_zero_border=1 if self.stp_border == 'zeros' else 0)
             plan = _Plan(lib, cfg)
             _lib.check(lib.pivp_plan_set_pack_cache(plan.h, 1), 'pivp_plan_set_pack_cache')
+            if self.main_priority is not None:      # None: the library's rule (wave priority 3 for the sweep's kernels unless a gradient listener is registered)
+                _lib.check(lib.pivp_plan_set_main_priority(plan.h, 1 if self.main_priority else 0), 'pivp_plan_set_main_priority')
             if self.precision != 'fp32':
                 _lib.check(lib.pivp_plan_set_precision(plan.h, {'bf16': 1, 'bf16x3': 2, 'bf16x6': 3, 'fp16x3': 4}[self.precision]),
                            'pivp_plan_set_precision(%s)' % self.precision)

@@ -3,7 +3,8 @@
 Run from the repo root:  python tests/golden/make_golden.py
 The reference itself cannot run here (Chainer 2.0.1 / Python 2 absent), so these
 vectors pin HIP <-> oracle; oracle <-> reference is pinned by the KATs and the line map.
-Weights are NOT stored (36.85 MB): they are regenerated from `init_params(seed=1, scale=1.0)`,
+Weights are NOT stored (36.85 MB): they are regenerated from `init_params_widened(seed=1, scale=1.0)`
+(the float32 parameters the GPU tests load, widened: oracle and HIP path on identical weights),
 which uses numpy's frozen legacy RandomState stream; a checksum of them is stored instead.
 """
 import os
@@ -20,7 +21,7 @@ TAP_STRIDE = 97
 
 
 def run(model_type, num_masks, batch, seq_len, tap_steps):
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, num_masks=num_masks, model_type=model_type)
+    P = R.init_params_widened(num_masks=num_masks, model_type=model_type)
     imgs, acts, stas = R.synthetic_batch(batch, seq_len, seed=0)
     m = R.Model(num_masks, is_cdna=model_type == 'CDNA', is_stp=model_type == 'STP',
                 is_dna=model_type == 'DNA', params=P, dtype=np.float64, prefix='golden')
@@ -48,7 +49,7 @@ def run_full_batch(model_type, num_masks, batch, seq_len, smooth=False, fp32_err
     `fp32_error`: also run the oracle in float32 (the reference's own arithmetic, NumPy/BLAS) and keep ITS per-(step, sample)
     max per-pixel L2 from the float64 result: on STP with white-noise frames that alone exceeds 1e-4, so the HIP path is held
     to "no less accurate than plain float32" there (tests/test_gpu_model.py)."""
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, num_masks=num_masks, model_type=model_type, height=size, width=size)
+    P = R.init_params_widened(num_masks=num_masks, model_type=model_type, height=size, width=size)
     imgs, acts, stas = (R.smooth_batch if smooth else R.synthetic_batch)(batch, seq_len, size, size, seed=0)
     kw = dict(is_cdna=model_type == 'CDNA', is_stp=model_type == 'STP', is_dna=model_type == 'DNA')
     m = R.Model(num_masks, params=P, dtype=np.float64, prefix='golden', **kw)
@@ -81,7 +82,7 @@ def run_full_batch_grads(model_type, num_masks, batch, seq_len, size=64, trained
     import torch
     from oracle.torch_restatement import TorchModel
     torch.set_num_threads(8)
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, num_masks=num_masks, model_type=model_type, height=size, width=size)
+    P = R.init_params_widened(num_masks=num_masks, model_type=model_type, height=size, width=size)
     imgs, acts, stas = R.synthetic_batch(batch, seq_len, size, size, seed=0)
     if trained:                          # the TRAINED weights of tests/golden/<trained>.npz on held-out video (run_trained's inputs)
         sys.path.insert(0, OUT)

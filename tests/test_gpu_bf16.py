@@ -290,7 +290,7 @@ def test_bf16_mode_batched_weight_gradients_match_per_step(monkeypatch):
     import pivp_amd
     from oracle import restatement as R
     assert torch.cuda.is_available()
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0)
+    P = R.init_params_widened(seed=1, scale=1.0)
     imgs, acts, stas = R.synthetic_batch(2, 7)
     outs = {}
     for batch in ('1', '3', None):

@@ -67,7 +67,7 @@ def test_odd_and_ragged_batch_sizes(pivp, B):
 def test_odd_batch_gradients(pivp):
     # B = 3 through the whole backward (partial tiles in the data / weight gradient kernels, K-split choices of small M)
     from oracle.torch_restatement import TorchModel
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0)
+    P = R.init_params_widened(seed=1, scale=1.0)
     imgs, acts, stas = R.synthetic_batch(3, 4)
     tm = TorchModel(10, params=P, requires_grad=True)
     lt = tm([imgs, acts, stas], 0); lt.backward()

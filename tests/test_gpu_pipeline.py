@@ -88,7 +88,7 @@ def test_device_feeder_matches_the_synchronous_loop(pivp):
     rs = np.random.RandomState(3)
     data = [(rs.rand(4, 64, 64, 3).astype(np.float32), (rs.randn(4, 5) * 0.1).astype(np.float32), (rs.randn(4, 5) * 0.1).astype(np.float32))
             for _ in range(7)]
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0)
+    P = R.init_params_widened(seed=1, scale=1.0)
 
     def run(fed):
         m = pivp.Model(10, prefix='f', keep_activations=True)

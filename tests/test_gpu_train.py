@@ -68,7 +68,7 @@ def _check_grads(got, ref, tol, relu_flips=2):
 @pytest.mark.parametrize('T', [3, 5])
 def test_bptt_gradients_match_autograd_feedself(pivp, T):
     # T=5, ctx=2: steps 2,3 are fed their own predictions, so gradients also flow through the frames (TM:664-666)
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0)
+    P = R.init_params_widened(seed=1, scale=1.0)
     imgs, acts, stas = R.synthetic_batch(2, T)
     loss_ref, gref = _autograd(P, imgs, acts, stas)
     m = pivp.Model(10, prefix='t', keep_activations=True)
@@ -88,7 +88,7 @@ def test_bptt_gradients_match_autograd_feedself(pivp, T):
 
 
 def test_bptt_gradients_scheduled_sampling_detaches_frames(pivp):
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0)
+    P = R.init_params_widened(seed=1, scale=1.0)
     imgs, acts, stas = R.synthetic_batch(4, 5)
     loss_ref, gref = _autograd(P, imgs, acts, stas, k=2.0, it=1.0, seed=5)
     m = pivp.Model(10, prefix='t', keep_activations=True, scheduled_sampling_k=2.0)
@@ -102,7 +102,7 @@ def test_bptt_gradients_scheduled_sampling_detaches_frames(pivp):
 
 
 def test_adam_update_matches_chainer_rule(pivp):
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0)
+    P = R.init_params_widened(seed=1, scale=1.0)
     imgs, acts, stas = R.synthetic_batch(2, 4)
     # reference: two optimizer.update() steps with autograd gradients and Chainer's Adam rule
     Pr = {k: v.copy() for k, v in P.items()}
@@ -160,7 +160,7 @@ def test_data_parallel_equals_large_batch(pivp):
 
 def test_bptt_gradients_stp(pivp):
     # STP head (TM:434-475): gradients through the bilinear sampler into theta and, in feed-self mode, into the frames
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, model_type='STP')
+    P = R.init_params_widened(seed=1, scale=1.0, model_type='STP')
     imgs, acts, stas = R.synthetic_batch(2, 4)
     # smooth frames: the sampler's gradient w.r.t. theta is an image DIFFERENCE, ill-conditioned on white noise in fp32
     from numpy.lib.stride_tricks import sliding_window_view
@@ -179,7 +179,7 @@ def test_bptt_gradients_stp(pivp):
 def test_bptt_gradients_stp_128(pivp):
     """128 x 128 frames: d prev's three planes do not fit in LDS, so the STP composite backward keeps its +-12-row window and sends what
     falls outside it to global atomics (64 x 64: the whole frame is the window); same check as above, fed-back step included."""
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, model_type='STP', height=128, width=128)
+    P = R.init_params_widened(seed=1, scale=1.0, model_type='STP', height=128, width=128)
     imgs, acts, stas = R.smooth_batch(2, 4, height=128, width=128, seed=3)
     loss_ref, gref = _autograd(P, imgs, acts, stas, is_cdna=False, is_stp=True)
     m = pivp.Model(10, is_cdna=False, is_stp=True, prefix='t', keep_activations=True)
@@ -193,7 +193,7 @@ def test_bptt_gradients_stp_128(pivp):
 
 def test_bptt_gradients_dna(pivp):
     # DNA head (TM:368-417), num_masks = 1, with the reference's slice quirk in forward and backward
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, model_type='DNA', num_masks=1)
+    P = R.init_params_widened(seed=1, scale=1.0, model_type='DNA', num_masks=1)
     imgs, acts, stas = R.synthetic_batch(2, 4)
     loss_ref, gref = _autograd(P, imgs, acts, stas, is_cdna=False, is_dna=True, num_masks=1)
     m = pivp.Model(1, is_cdna=False, is_dna=True, prefix='t', keep_activations=True)
@@ -207,7 +207,7 @@ def test_bptt_gradients_dna(pivp):
 
 def test_bptt_gradients_cdna_four_masks(pivp):
     # num_masks = 4: softmax groups of 5, 3 live kernels + the dropped one (TM:726)
-    P = R.init_params(seed=2, dtype=np.float64, scale=1.0, num_masks=4)
+    P = R.init_params_widened(seed=2, scale=1.0, num_masks=4)
     imgs, acts, stas = R.synthetic_batch(2, 3)
     loss_ref, gref = _autograd(P, imgs, acts, stas, num_masks=4)
     m = pivp.Model(4, prefix='t', keep_activations=True)
@@ -235,7 +235,7 @@ def test_bptt_gradients_cdna_four_masks(pivp):
 def test_gradient_groups_are_final_when_announced(pivp):
     # DP overlap: backward(on_group=...) announces each contiguous gradient slice once no later kernel of the
     # sweep writes it.  Snapshot every slice at its announcement (stream-ordered copy) and compare with the final buffer.
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0)
+    P = R.init_params_widened(seed=1, scale=1.0)
     imgs, acts, stas = R.synthetic_batch(2, 4)
     m = pivp.Model(10, prefix='t', keep_activations=True)
     m.load_state_dict_reference(P)
@@ -270,7 +270,7 @@ def test_overlapped_allreduce_single_rank(pivp):
         dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29533', world_size=1, rank=0,
                                 device_id=torch.device('cuda:0'))
     try:
-        P = R.init_params(seed=1, dtype=np.float64, scale=1.0)
+        P = R.init_params_widened(seed=1, scale=1.0)
         imgs, acts, stas = R.synthetic_batch(2, 3)
         m = pivp.Model(10, prefix='t', keep_activations=True)
         m.load_state_dict_reference(P)
@@ -313,7 +313,7 @@ def test_bf16_gradient_payload_kernels_and_single_rank_path(pivp):
     if not dist.is_initialized():
         dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29534', world_size=1, rank=0, device_id=torch.device('cuda:0'))
     try:
-        P = R.init_params(seed=1, dtype=np.float64, scale=1.0)
+        P = R.init_params_widened(seed=1, scale=1.0)
         imgs, acts, stas = R.synthetic_batch(2, 3)
         m = pivp.Model(10, prefix='t', keep_activations=True)
         m.load_state_dict_reference(P)
@@ -374,7 +374,7 @@ def test_bptt_gradients_128x128(pivp):
     # sample's dy, everything else at 1e-6), and with B = 2 that one-pixel difference is visible in every tensor below it
     # (relative L2 4e-3, localised around the pixel).  The check is therefore on the relative L2 error and the median element error:
     # an indexing bug in any kernel moves these to O(0.1 - 1).
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, height=128, width=128)
+    P = R.init_params_widened(seed=1, scale=1.0, height=128, width=128)
     imgs, acts, stas = R.synthetic_batch(2, 3, 128, 128)
     loss_ref, gref = _autograd(P, imgs, acts, stas)
     m = pivp.Model(10, prefix='t', keep_activations=True)
@@ -393,7 +393,7 @@ def test_bptt_gradients_128x128(pivp):
 def test_batched_weight_gradients_match_per_step(pivp, monkeypatch):
     # WgradDesc::tcount: the ConvLSTM weight gradients of up to 4 timesteps in one launch (PIVP_WGRAD_BATCH) must give the gradients of
     # one launch per timestep (same products, other summation order), with and without the side stream
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0)
+    P = R.init_params_widened(seed=1, scale=1.0)
     imgs, acts, stas = R.synthetic_batch(2, 8)             # 7 steps: batches [6,5,4,3] [2,1] [0]
     outs = {}
     for batch, side in (('1', '1'), ('4', '1'), ('3', '0')):

@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), 'libpivp_hip.so does not export %s' % name
     assert declared == set(_lib.SIGNATURES), 'ctypes table and header disagree: %s' % (declared ^ set(_lib.SIGNATURES))
-    assert _lib.load().pivp_abi_version() == 13
+    assert _lib.load().pivp_abi_version() == 14
 
 
 def test_stale_library_is_refused(monkeypatch):
@@ -42,7 +42,22 @@ def test_stale_library_is_refused(monkeypatch):
     with pytest.raises(RuntimeError, match='stale'):
         _lib.load()
     monkeypatch.undo()
-    assert _lib.load().pivp_abi_version() == 13
+    assert _lib.load().pivp_abi_version() == 14
+
+
+def test_product_build_records_no_extra_flags_and_a_missing_source_tree_is_named(monkeypatch):
+    """pivp_build_flags(): '' for the product build (an instrumented variant -- PIVP_EXTRA_FLAGS -- has the product's source digest, so it must say
+    what it is).  And a package copied without csrc/ or include/ fails the digest check with a sentence, not a bare open() error."""
+    import __graft_entry__ as g
+    g.build()
+    from pivp_amd import _digest
+    assert _lib.build_flags() == ''
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_digest, 'HEADER', os.path.join(ROOT, 'include', 'no_such_header.h'))
+    with pytest.raises(RuntimeError, match='no_such_header.h is missing'):
+        _lib.load()
+    monkeypatch.undo()
+    assert _lib.load().pivp_abi_version() == 14
 
 
 def test_plan_param_table_matches_reference_keys():

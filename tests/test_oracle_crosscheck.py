@@ -62,7 +62,7 @@ def test_oracle_reproduces_golden(name, mt, nm):
     B, T = int(g['batch']), int(g['seq_len'])
     if name == 'cdna_b2_t10':
         T = 3   # keep the CPU suite fast: the first frames pin the fixture; full length runs on the GPU
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, num_masks=nm, model_type=mt)
+    P = R.init_params_widened(seed=1, scale=1.0, num_masks=nm, model_type=mt)
     assert abs(sum(float(np.abs(v).sum()) for v in P.values()) - float(g['param_checksum'])) < 1e-6
     imgs, acts, stas = R.synthetic_batch(B, int(g['seq_len']))
     m = R.Model(nm, is_cdna=mt == 'CDNA', is_stp=mt == 'STP', is_dna=mt == 'DNA',
@@ -95,7 +95,7 @@ def test_float32_arithmetic_itself_misses_1e4_on_white_noise_stp():
     gs = np.load(os.path.join(GOLD, 'stp_b32_t10_smooth.npz'))
     assert gs['fp32_oracle_max_l2'][:2].max() < 1e-5              # ground-truth-fed steps of video-like frames: 5e-6
     # and the stored numbers are what the oracle gives: re-run the first step (T = 2: one prediction) in both precisions
-    P = R.init_params(seed=1, dtype=np.float64, scale=1.0, num_masks=10, model_type='STP')
+    P = R.init_params_widened(seed=1, scale=1.0, num_masks=10, model_type='STP')
     imgs, acts, stas = R.synthetic_batch(32, 10)
     out = {}
     for dt in (np.float64, np.float32):
