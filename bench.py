@@ -90,6 +90,8 @@ def build_parser():
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'bf16x3', 'bf16x6', 'fp16x3'],
                     help='fp32: the parity path and the headline metric (config 2). bf16: ConvLSTM gate convolutions with bf16 operands, '
                          'fp32 accumulation (config 3); reports its per-pixel error instead of meeting the 1e-4 gate')
+    ap.add_argument('--main-priority', default='auto', choices=['auto', 'on', 'off'],
+                    help='wave priority 3 for the backward sweep\'s kernels (auto: the library\'s rule -- on unless a gradient listener is registered, i.e. on at 1 GPU)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
@@ -652,7 +654,8 @@ def main(argv=None):
                 tm = HostStubModel(sizes=(1 << 16, 1 << 14, 1 << 15, 1 << 15, 1 << 16, 1 << 14), value=float(rank + 1), precision=precision)
                 op = None
             else:
-                tm = pivp_amd.Model(nm, prefix='bench', device=dev, keep_activations=True, precision=precision, **kinds)
+                tm = pivp_amd.Model(nm, prefix='bench', device=dev, keep_activations=True, precision=precision,
+                                    main_priority={'auto': None, 'on': True, 'off': False}[args.main_priority], **kinds)
                 op = pivp_amd.Adam(alpha=0.001).setup(tm, data_parallel=dp)             # TM:860-861
                 tm([images, actions, states], 0)                                        # parameters are lazily sized: one forward first
             if dp is not None:

@@ -223,13 +223,12 @@ int pivp_convlstm_bf16x3(const float* x, int cx, int ldx, const float* h_prev, i
 int pivp_pack_lstm_bf16x6(const float* w, void* w_bf16, int cin_total, int C, void* stream);
 int pivp_convlstm_bf16x6(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
                          const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
-                         int* ln_nparts, int B, int H, int W, int nch, void* stream);   /* nch: 0 automatic; 1 = 16-channel blocks, weights through
-                         an LDS ring; 16 / 32 = 16- / 32-channel blocks (C % 32 == 0 for 32), weights from L2 straight into the operand registers */
+                         int* ln_nparts, int B, int H, int W, int nch, void* stream);   /* nch: 0 automatic; 16 / 32 = 16- / 32-channel blocks
+                         (C % 32 == 0 for 32), weights from L2 straight into the operand registers */
 
 /* Two-fp16-piece form (precision mode PIVP_PRECISION_FP16X3): hi = fp16(v), lo = fp16(v - hi); hi*hi on the main accumulator, lo*hi + hi*lo on a second one
  * (three fp16 MFMAs, fp32 accumulation).  C % 16 == 0; W % 16 == 0, or W % 8 == 0 with an even batch (a second kernel and pack layout).  w_bf16 = pivp_pack_lstm_fp16x3(w): 2 * pivp_lstm_bf16_weight_elems(cx + C, C) + 256 2-byte
- * elements (s w as two fp16 pieces, fragment-major; s and the maxima it was taken from in the 512-byte tail).  nch: 0 automatic, 16 / 32 channels per block (tiles of 8 x 16 anchors),
- * 256 = 16 channels on tiles of 16 x 16 anchors (H % 16 == 0, W % 16 == 0: half the weight bytes per multiply-add). */
+ * elements (s w as two fp16 pieces, fragment-major; s and the maxima it was taken from in the 512-byte tail).  nch: 0 automatic, 16 / 32 channels per block (tiles of 8 x 16 anchors). */
 int pivp_pack_lstm_fp16x3(const float* w, void* w_bf16, int cin_total, int C, int map_width, void* stream);   /* map_width: W of the call it is for */
 int pivp_convlstm_fp16x3(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
                          const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,

@@ -84,90 +84,6 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __rest
     *reinterpret_cast<f32x4*>(dc + idx) = dcn;
 }
 
-static int ln_bwd_param_groups(int B, int n);
-
-// The same with the norm's PARAMETER gradients (round 4): a block owns one 1024-element slice of the sample vector and the samples
-// b = blockIdx.y, + G, + 2G, ... (G = ln_bwd_param_groups): per sample it reduces the (sum g, sum g xhat) parts -- which the producer of
-// dy left in its epilogue, or ln_bwd_stats_kernel -- does the gate backward of its slice, and keeps sum_b dy * xhat and sum_b dy of its
-// four elements in registers; at the end it adds them into its group's plane of ln.param_part (plain loads and stores: the launches of a
-// norm are stream-ordered; ln_bwd_params_reduce sums the planes once per sweep).  ln_bwd_sums_params_kernel (one launch per cell and
-// timestep on the sweep's critical path: 63 per train step, 1.5-2.0 ms of kernel time) is no longer needed for the norms behind cells.
-__global__ __launch_bounds__(256) void lstm_gates_bwd_grp_kernel(const float* __restrict__ gates, const float* __restrict__ c_old,
-                                                                 const float* __restrict__ c_new, const float* __restrict__ dh_b, int ldb,
-                                                                 float* __restrict__ dc, int dc_valid, float* __restrict__ dG, int B, int npix,
-                                                                 int C, const LnFuse ln, float* __restrict__ zero, long long zero_f4) {
-    PIVP_SET_MAIN_PRIO();
-    __shared__ float sums[4][2];
-    const int n = npix * C, G = gridDim.y;
-    if (zero) {
-        const long long nthr = (long long)gridDim.x * gridDim.y * 256;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_f4; i += nthr) reinterpret_cast<f32x4*>(zero)[i] = z;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const bool valid = e0 < n;
-    const int e = valid ? e0 : 0;                              // clamped: every load below is unconditional
-    const int pix = e / C, ch = e - pix * C;
-    const f32x4 gm = *reinterpret_cast<const f32x4*>(ln.gamma + e);
-    f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
-    for (int b0 = blockIdx.y; b0 < B; b0 += 4 * G) {
-        {   // (m1, m2) of this trip's samples: wave j reduces the parts of sample b0 + j G in a fixed order
-            const int bj = b0 + wave * G;
-            float s1 = 0.f, s2 = 0.f;
-            if (bj < B)
-                for (int i = lane; i < ln.S; i += 64) { s1 += ln.partials[((size_t)bj * ln.S + i) * 2]; s2 += ln.partials[((size_t)bj * ln.S + i) * 2 + 1]; }
-            s1 = wave_sum(s1); s2 = wave_sum(s2);
-            if (lane == 0) { sums[wave][0] = s1 / (float)n; sums[wave][1] = s2 / (float)n; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int bj = b0 + j * G;
-            const int b = bj < B ? bj : B - 1;
-            const bool on = bj < B && valid;
-            const size_t m = (size_t)b * npix + pix;
-            const size_t idx = m * C + ch;
-            const float* g = gates + m * 4 * C + ch;
-            const f32x4 aj = *reinterpret_cast<const f32x4*>(g), ai = *reinterpret_cast<const f32x4*>(g + C);
-            const f32x4 af = *reinterpret_cast<const f32x4*>(g + 2 * C), ao = *reinterpret_cast<const f32x4*>(g + 3 * C);
-            const f32x4 cn = *reinterpret_cast<const f32x4*>(c_new + idx), co = *reinterpret_cast<const f32x4*>(c_old + idx);
-            const f32x4 dy = *reinterpret_cast<const f32x4*>(ln.dy + m * ln.lddy + ch);
-            const f32x4 hv = *reinterpret_cast<const f32x4*>(ln.h + idx);
-            f32x4 dhb = {0.f, 0.f, 0.f, 0.f}, dcv = {0.f, 0.f, 0.f, 0.f};
-            if (dh_b) dhb = *reinterpret_cast<const f32x4*>(dh_b + m * ldb + ch);
-            if (dc_valid) dcv = *reinterpret_cast<const f32x4*>(dc + idx);
-            const float mean = ln.stat[b * 2], rstd = ln.stat[b * 2 + 1], m1 = sums[j][0], m2 = sums[j][1];
-            f32x4 oj, oi, of, oo, dcn;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float xh = (hv[k] - mean) * rstd;
-                const float dh = rstd * (dy[k] * gm[k] - m1 - xh * m2) + dhb[k];
-                if (on) { ag[k] = fmaf(dy[k], xh, ag[k]); ab[k] += dy[k]; }
-                const float tc = fast_tanh_b(cn[k]);
-                const float dct = dh * ao[k] * (1.f - tc * tc) + dcv[k];
-                oj[k] = dct * ai[k] * (1.f - aj[k] * aj[k]);
-                oi[k] = dct * aj[k] * ai[k] * (1.f - ai[k]);
-                of[k] = dct * co[k] * af[k] * (1.f - af[k]);
-                oo[k] = dh * tc * ao[k] * (1.f - ao[k]);
-                dcn[k] = dct * af[k];
-            }
-            if (on) {
-                float* o = dG + m * 4 * C + ch;
-                *reinterpret_cast<f32x4*>(o) = oj; *reinterpret_cast<f32x4*>(o + C) = oi;
-                *reinterpret_cast<f32x4*>(o + 2 * C) = of; *reinterpret_cast<f32x4*>(o + 3 * C) = oo;
-                *reinterpret_cast<f32x4*>(dc + idx) = dcn;
-            }
-        }
-        __syncthreads();      // `sums` is rewritten by the next trip
-    }
-    if (!valid) return;
-    float* pg = ln.param_part + (size_t)blockIdx.y * 2 * n + e;
-    f32x4 og = *reinterpret_cast<f32x4*>(pg), ob = *reinterpret_cast<f32x4*>(pg + n);
-    og += ag; ob += ab;
-    *reinterpret_cast<f32x4*>(pg) = og; *reinterpret_cast<f32x4*>(pg + n) = ob;
-}
-
 int lstm_gates_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_a, int lda,
                    const float* dh_b, int ldb, float* dc, int dc_valid, float* dG, int M, int C, hipStream_t s, int B, const LnFuse* ln,
                    float* zero, long long zero_floats) {
@@ -182,11 +98,6 @@ int lstm_gates_bwd(const float* gates, const float* c_old, const float* c_new, c
     }
     const int npix = M / B;
     const int xb = (npix * C / 4 + 255) / 256;
-    if (lf.dy && lf.param_part) {     // the norm's parameter gradients ride along: blocks own sample GROUPS
-        hipLaunchKernelGGL(lstm_gates_bwd_grp_kernel, dim3(xb, ln_bwd_param_groups(B, npix * C)), dim3(256), 0, s, gates, c_old, c_new, dh_b, ldb, dc,
-                           dc_valid, dG, B, npix, C, lf, zero, zero ? zero_floats / 4 : 0);
-        return PIVP_LAUNCH_STATUS();
-    }
     hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(xb, B), dim3(256), 0, s, gates, c_old, c_new, dh_a, lda, dh_b, ldb, dc,
                        dc_valid, dG, npix, C, lf, zero, zero ? zero_floats / 4 : 0);
     return PIVP_LAUNCH_STATUS();
@@ -465,14 +376,6 @@ int ln_bwd_params_reduce(const float* part, float* dgamma, float* dbeta, int B, 
 }
 
 int ln_bwd_slices(int n) { return (n + LNB_SLICE - 1) / LNB_SLICE; }
-
-// the per-slice sums (sum g, sum g xhat) alone, for a consumer that forms dx AND the parameter gradients itself (lstm_gates_bwd with
-// LnFuse::param_part) when the kernel that produced dy could not leave them (IgemmDesc::lnb_part)
-int ln_bwd_sums(const float* dy, int lddy, const float* x, const float* stat, const float* gamma, float* partials, int B, int n, int C, hipStream_t s) {
-    PIVP_CHECK_ARG(dy && x && stat && gamma && partials && B > 0 && n > 0 && C > 0 && C % 4 == 0 && n % C == 0 && lddy >= C && lddy % 4 == 0);
-    hipLaunchKernelGGL(ln_bwd_stats_kernel, dim3(ln_bwd_slices(n), B), dim3(256), 0, s, dy, lddy, nullptr, 0, x, stat, gamma, partials, n, C, 0);
-    return PIVP_LAUNCH_STATUS();
-}
 
 int ln_backward(const float* dy, int lddy, const float* y, int ldy, const float* x, const float* stat, const float* gamma,
                 float* partials, float* dx, float* dgamma, float* dbeta, int B, int n, int C, int relu, hipStream_t s, float* param_part) {

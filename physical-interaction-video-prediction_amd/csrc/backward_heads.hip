@@ -36,8 +36,6 @@ int scaled_diff(const float* a, const float* b, float* out, long n, float scale,
 // ------------------------------------------------------------------------------------------
 // rows of the frame per block tile: 8 up to 64-wide frames, 4 for 128-wide ones (the tile's LDS images grow with W)
 static int composite_bwd_rows(int W) {
-    static const int force = [] { const char* e = getenv("PIVP_CB_ROWS"); return e ? atoi(e) : 0; }();   // tuning: 4 or 8
-    if (force == 4 || force == 8) return W <= 64 ? force : 4;
     return W <= 64 ? 8 : 4;
 }
 
@@ -845,7 +843,8 @@ int composite_bwd_stp(const float* prev, const float* logits, const float* layer
     PIVP_CHECK_ARG(prev && logits && layer0 && theta && go && dmk && dz && dthpart && B > 0 && H > 1 && W > 1 && NM >= 2 && NM <= 10);
     const int CB_TR = composite_bwd_rows(W);
     const int NP = NM + 1, np = CB_TR * W, win = np + 2 * (NP - 1), G = np / NP + 2;
-    static const int whole_on = [] { const char* e = getenv("PIVP_STP_WHOLE"); return e ? atoi(e) : 8; }();   // tuning: 0 = one block per tile and a +-12-row window; k = at most k blocks per sample (B = 32: 29.3 / 29.3 / 28.6 / 28.2 / 28.0 ms per STP train step for 0 / 1 / 2 / 4 / 8)
+    constexpr int whole_on = 8;      // at most this many blocks per sample, each with the whole frame's d prev in LDS (B = 32: 29.3 / 29.3 / 28.6 / 28.2 / 28.0 ms per STP
+                                     // train step for one block per tile with a +-12-row window / 1 / 2 / 4 / 8)
     const size_t lds_head = sizeof(float) * ((size_t)NP * win + 2 * NP * G);
     const int whole = (whole_on > 0 && dprev && lds_head + sizeof(float) * 3 * (size_t)H * W <= 96 * 1024) ? 1 : 0;
     const size_t lds = lds_head + sizeof(float) * 3 * (size_t)(whole ? H : CB_TR + 2 * CBS_R) * W;

@@ -265,10 +265,6 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
     const float bias = d.bias ? d.bias[col] : 0.f;
     const float inv_wscale = 1.0f / wscale;
     float s1 = 0.f;
-    // LayerNorm-backward sums of the output (data gradients, IgemmDesc::lnb_part): block-uniform switch
-    const bool lnb = d.lnb_part && nblk * 32 < d.lnb_C;
-    float lb1 = 0.f, lb2 = 0.f, lmean = 0.f, lrstd = 0.f;
-    if (lnb) { lmean = d.lnb_stat[b * 2]; lrstd = d.lnb_stat[b * 2 + 1]; }
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
@@ -284,19 +280,7 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
             *o = v;
             acc[ph][r] = v;
             s1 += v;
-            if (lnb && col < d.lnb_C) PIVP_LNB_ACC(d, v, b, oy * d.Wout + ox, col, d.Hout * d.Wout, lmean, lrstd, lb1, lb2);
         }
-    if (lnb) {           // fixed order: xor tree inside a wave, the four waves left to right
-        float* red = lds;
-        lb1 = wave_sum(lb1); lb2 = wave_sum(lb2);
-        __syncthreads();
-        if (lane == 0) { red[wave] = lb1; red[4 + wave] = lb2; }
-        __syncthreads();
-        if (tid == 0) {
-            float* pp = d.lnb_part + ((size_t)b * d.lnb_np + (size_t)trem * ((d.lnb_C + 31) >> 5) + nblk) * 2;
-            pp[0] = (red[0] + red[1]) + (red[2] + red[3]); pp[1] = (red[4] + red[5]) + (red[6] + red[7]);
-        }
-    }
     if (d.ln_part) {   // (count, mean, M2) of the block's 128 x 4 x 32 outputs: two passes over registers, fixed order
         float* red = lds;
         s1 = wave_sum(s1);
@@ -345,13 +329,6 @@ int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts, int prec
     dd.ln_nparts = (d.ln_part && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
-    {   // LayerNorm-backward sums of the output (data gradients): one part per block that owns norm columns
-        const int lnp = tpi * ((d.lnb_C + 31) / 32);
-        const bool ok = d.lnb_part && d.lnb_gamma && d.lnb_x && d.lnb_stat && d.lnb_C > 0 && d.lnb_C <= d.N && lnp <= d.lnb_cap && !d.ln_part;
-        dd.lnb_np = ok ? lnp : 0;
-        if (!ok) dd.lnb_part = nullptr;
-        if (d.lnb_np_out) *d.lnb_np_out = dd.lnb_np;
-    }
     const dim3 grid(d.B * tpi * nb);
     if (prec == 3) {
         if (d.in_g) hipLaunchKernelGGL((deconv3x3s2_tile_kernel<3, true>), grid, dim3(256), 2 * (A_HB + 9 * B_HB), stream, dd);

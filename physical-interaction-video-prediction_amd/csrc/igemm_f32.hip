@@ -43,10 +43,6 @@
 namespace pivp {
 
 constexpr int IG_P = 36;  // LDS row pitch in floats (A and B tiles)
-#ifndef PIVP_XCD_MAP
-#define PIVP_XCD_MAP 1
-#endif
-constexpr bool XCD_MAP = PIVP_XCD_MAP != 0;
 
 template <int WM, int NTB, int KG = 1>
 constexpr int ig_lds_bytes() { return KG * 2 * (32 * WM + 32 * NTB) * IG_P * 4; }
@@ -88,22 +84,21 @@ __device__ long long pivp_f32_stamps[2048 * 8];
 #define F32_STAMP(i)
 #endif
 
-// ABL: timing-only ablations for scripts/bench_lstm_layers.py (built with -DPIVP_ABLATE; outputs are wrong):
-//   1 = no global loads and no LDS stores, 2 = loads but no LDS stores, 3 = as 1 without the barrier,
-//   4 = as 2 with constant load addresses (no per-chunk address math), 5 = address math only.
+// (Rounds 1-4 carried timing-only ablations of this kernel -- no loads / no LDS stores / no barrier / no address math -- as a template parameter;
+// their numbers are in profiles/r01 .. r03/NOTES.md, the code in the history.)
 // KG = 2 (ConvLSTM on small maps, lstm5's 8 x 8): the block is TWO groups of 4 waves that each run HALF of the K chunks of the same
 // output tile through their own LDS buffers, in lockstep (same barriers); group 1 then hands its accumulators to group 0 through LDS
 // and group 0 runs the epilogue.  With M = 2048 anchors there are only 256 tiles of 32 x 128: one block per CU, one wave per SIMD,
 // MFMA pipe busy 0.62.  Measured: lstm5 110.6 -> 117 TFLOP/s only (rollout 8.69 -> 8.66 ms): the tile is not short of waves but of L2
 // bandwidth -- 256 blocks x 150 chunks x (4 KB of A + 16 KB of B) = 614 MB per launch in ~80 us, 7.7 TB/s; a 32-row tile uses every
 // weight byte for 32 MACs.  A square 64 x 64 tile (16 channels x 4 gates) would move 20 % less; not built.
-template <int WM, int WN, int NTB, bool LSTM, int ABL = 0, int KG = 1>
+template <int WM, int WN, int NTB, bool LSTM, int KG = 1>
 __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void igemm_f32_kernel(const IgemmDesc d) {
     F32_STAMP(0);
     PIVP_SET_MAIN_PRIO();
     static_assert(WM * WN == 4, "4 waves");
     static_assert(KG == 1 || (KG == 2 && LSTM), "the in-block K split serves the ConvLSTM tile only");
-    static_assert(!LSTM || NTB == 4 || (NTB == 2 && WN == 2), "ConvLSTM blocks own 4 gates x 32 channels, or 4 gates x 16 channels as 2 x 2 waves");
+    static_assert(!LSTM || NTB == 4, "ConvLSTM blocks own 4 gates x 32 channels");
     constexpr int BM = 32 * WM;
     constexpr int BN = 32 * NTB;
     constexpr int CB = 8 * NTB;   // LSTM: channels per block (its BN columns are the 4 gates of CB channels): 32, or 16 for the square 64 x 64 tile
@@ -126,10 +121,10 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
     // then holds one column block's weights (<= 2.5 MB for every layer here) and a contiguous band of anchors whose
     // 5x5 halos overlap each other, instead of every XCD streaming all weights and all of the image.
     int lid = blockIdx.x;
-    if (XCD_MAP && (gridDim.x & 7) == 0) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if ((gridDim.x & 7) == 0) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int n_mblk = gridDim.x / n_nblk;
-    const int nblk = XCD_MAP ? lid / n_mblk : lid % n_nblk;
-    const int mblk = XCD_MAP ? lid % n_mblk : lid / n_nblk;
+    const int nblk = lid / n_mblk;
+    const int mblk = lid % n_mblk;
     const int m0 = mblk * BM;
     const int cin = d.c0 + d.c1;
     const int ncc = cin >> 5;
@@ -253,12 +248,9 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
         if constexpr (j < NA) {
             const bool ok = (a_mask[j] & s_bit) != 0;
             unsigned off = ok ? (unsigned)((s_first ? a_off0[j] : a_off1[j]) + s_delta) : OOB;
-            if constexpr (ABL == 4) off = (unsigned)a_off0[j];                       // loads without the address math
-            if constexpr (ABL == 5) { asm volatile("" :: "v"(off)); return; }        // address math without the loads
             ra[j] = __builtin_bit_cast(f32x4, s_first ? __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0)
                                                       : __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
         } else if constexpr (j < NA + NB) {
-            if constexpr (ABL == 5) return;
             rb[j - NA] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, b_goff[j - NA], s_wbase, 0));
         }
     };
@@ -322,8 +314,8 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
     // LOAD: this chunk issues the loads of chunk +2 into register set SET; STORE: it writes set SET^1 (chunk +1) to the other
     // LDS buffer
     auto chunk = [&](auto LOAD, auto STORE, auto SET, auto PAR, int buf) {   // PAR: parity of the chunk's index (accumulator chain)
-        constexpr bool do_load = decltype(LOAD)::value && ABL != 1 && ABL != 3;
-        constexpr bool do_store = decltype(STORE)::value && ABL == 0;   // ABL 2, 4, 5: no LDS stores
+        constexpr bool do_load = decltype(LOAD)::value;
+        constexpr bool do_store = decltype(STORE)::value;
         using OTHER = std::integral_constant<int, decltype(SET)::value ^ 1>;
         const float* As = lds + buf * A_FLOATS + a_off;
         const float* Bs = lds + buf * B_FLOATS;
@@ -356,14 +348,6 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
         qgroup(std::integral_constant<int, 0>{}); qgroup(std::integral_constant<int, 1>{});
         qgroup(std::integral_constant<int, 2>{}); qgroup(std::integral_constant<int, 3>{});
     };
-    auto keep = [&]() {   // ABL 2 / 4: keep the loaded registers alive without writing LDS
-        if (ABL == 2 || ABL == 4) {
-#pragma unroll
-            for (int jj = 0; jj < NA; ++jj) { asm volatile("" :: "v"(ras[0][jj])); asm volatile("" :: "v"(ras[1][jj])); }
-#pragma unroll
-            for (int jj = 0; jj < NB; ++jj) { asm volatile("" :: "v"(rbs[0][jj])); asm volatile("" :: "v"(rbs[1][jj])); }
-        }
-    };
     using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
     auto load_all = [&](auto SET) {
         load_piece(SET, std::integral_constant<int, 0>{}); load_piece(SET, std::integral_constant<int, 1>{});
@@ -377,7 +361,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
         store_piece(SET, std::integral_constant<int, 4>{}, buf); store_piece(SET, std::integral_constant<int, 5>{}, buf);
         store_piece(SET, std::integral_constant<int, 6>{}, buf); store_piece(SET, std::integral_constant<int, 7>{}, buf);
     };
-    auto sync = [&]() { keep(); if (ABL != 3) __syncthreads(); };
+    auto sync = [&]() { __syncthreads(); };
 
     // ConvLSTM: bias and c_{t-1} of the cells this lane will update are requested here, in front of the K loop.  Read in the
     // epilogue they cost one exposed HBM round trip per accumulator row, 16 in a row (measured on the bf16 kernel, where the
@@ -554,11 +538,6 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
         const int oy0 = deconv ? py : 0, ox0 = deconv ? px : 0;
         float sv[16 * TPW];
         unsigned long long own = 0;
-        // LayerNorm-backward sums of the output (data gradients, IgemmDesc::lnb_part; tiles lie inside one sample): block-uniform switch.
-        // K-split blocks add the sums of their own partial tile (the sums are linear in the output).
-        const bool lnb = d.lnb_part && nblk * BN < d.lnb_C;
-        float lb1 = 0.f, lb2 = 0.f, lmean = 0.f, lrstd = 0.f;
-        if (lnb) { const int bb = m0 / HWg; lmean = d.lnb_stat[bb * 2]; lrstd = d.lnb_stat[bb * 2 + 1]; }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -573,30 +552,15 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
                 for (int t = 0; t < TPW; ++t) {
                     const int col = nblk * BN + (wn * TPW + t) * 32 + l31;
                     if (ksplit > 1) {
-                        if (nchunks > 0) {
-                            atomicAdd(d.out + o + col, acc[t][r]);
-                            if (lnb && col < d.lnb_C) PIVP_LNB_ACC(d, acc[t][r], b, opix, col, d.Hout * d.Wout, lmean, lrstd, lb1, lb2);
-                        }
+                        if (nchunks > 0) atomicAdd(d.out + o + col, acc[t][r]);
                     } else {
                         float v = acc[t][r] + (d.bias ? d.bias[col] : 0.f);
                         if (d.relu) v = fmaxf(v, 0.f);
                         if (d.accum) v += d.out[o + col];
                         d.out[o + col] = v;
                         sv[t * 16 + r] = v; own |= 1ull << (t * 16 + r);
-                        if (lnb && col < d.lnb_C) PIVP_LNB_ACC(d, v, b, opix, col, d.Hout * d.Wout, lmean, lrstd, lb1, lb2);
                     }
                 }
-            }
-        }
-        if (lnb) {           // fixed order: xor tree inside a wave, the four waves left to right
-            lb1 = wave_sum(lb1); lb2 = wave_sum(lb2);
-            __syncthreads();   // every wave is past its last LDS tile read
-            if (lane == 0) { lds[16 + wave] = lb1; lds[20 + wave] = lb2; }
-            __syncthreads();
-            if (tid == 0) {
-                const int bb = m0 / HWg, nb_ln = (d.lnb_C + BN - 1) / BN;
-                float* pp = d.lnb_part + ((size_t)bb * d.lnb_np + ((size_t)((m0 - bb * HWg) / BM) * nb_ln + nblk) * ksplit + (int)blockIdx.z) * 2;
-                pp[0] = (lds[16] + lds[17]) + (lds[18] + lds[19]); pp[1] = (lds[20] + lds[21]) + (lds[22] + lds[23]);
             }
         }
         if (d.ln_part) {
@@ -611,14 +575,14 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
 #endif
 }
 
-template <int WM, int WN, int NTB, bool LSTM, int ABL = 0, int KG = 1>
+template <int WM, int WN, int NTB, bool LSTM, int KG = 1>
 static int launch_igemm(const IgemmDesc& d, hipStream_t stream, int ksplit = 1, int* ln_nparts = nullptr) {
     constexpr int BM = 32 * WM, BN = 32 * NTB;
     const int n_nblk = LSTM ? (d.C / (8 * NTB)) : (d.N / BN);
     const int mblk = (d.M + BM - 1) / BM;
     constexpr int lds_bytes = ig_lds_bytes<WM, NTB, KG>();
     static PerDeviceOnce once;
-    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&igemm_f32_kernel<WM, WN, NTB, LSTM, ABL, KG>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&igemm_f32_kernel<WM, WN, NTB, LSTM, KG>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     dim3 grid(mblk * n_nblk, d.nphase, ksplit);
     IgemmDesc dd = d;
     // fused LayerNorm partials: only when no tile straddles two samples and the caller's buffer holds them
@@ -627,16 +591,7 @@ static int launch_igemm(const IgemmDesc& d, hipStream_t stream, int ksplit = 1, 
     dd.ln_nparts = (d.ln_part && ksplit == 1 && hwg % BM == 0 && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
-    if (!LSTM) {   // LayerNorm-backward sums of the output (data gradients): one part per (tile, K split) that owns norm columns
-        const int nb_ln = d.lnb_part ? (d.lnb_C + BN - 1) / BN : 0;
-        const int lnp = (hwg / BM) * nb_ln * ksplit;
-        const bool ok = d.lnb_part && d.lnb_gamma && d.lnb_x && d.lnb_stat && d.lnb_C > 0 && d.lnb_C <= d.N && hwg % BM == 0 && d.nphase == 1 &&
-                        KG == 1 && lnp <= d.lnb_cap && !d.ln_part;
-        dd.lnb_np = ok ? lnp : 0;
-        if (!ok) dd.lnb_part = nullptr;
-        if (d.lnb_np_out) *d.lnb_np_out = dd.lnb_np;
-    }
-    hipLaunchKernelGGL((igemm_f32_kernel<WM, WN, NTB, LSTM, ABL, KG>), grid, dim3(256 * KG), lds_bytes, stream, dd);
+    hipLaunchKernelGGL((igemm_f32_kernel<WM, WN, NTB, LSTM, KG>), grid, dim3(256 * KG), lds_bytes, stream, dd);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -665,29 +620,6 @@ int igemm_validate(const IgemmDesc& d, bool lstm) {
 int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant, int* ln_nparts) {
     int rc = igemm_validate(d, true);
     if (rc != PIVP_OK) return rc;
-#ifdef PIVP_ABLATE
-    if (variant >= 11 && variant <= 13) {   // timing-only diagnostic builds of the 4x1 tile (outputs are wrong)
-        if (variant == 11) return launch_igemm<4, 1, 4, true, 1>(d, stream, 1, ln_nparts);
-        if (variant == 12) return launch_igemm<4, 1, 4, true, 2>(d, stream, 1, ln_nparts);
-        return launch_igemm<4, 1, 4, true, 3>(d, stream, 1, ln_nparts);
-    }
-    if (variant >= 21 && variant <= 23) {   // the same ablations on the 2x2 tile
-        if (variant == 21) return launch_igemm<2, 2, 4, true, 1>(d, stream, 1, ln_nparts);
-        if (variant == 22) return launch_igemm<2, 2, 4, true, 2>(d, stream, 1, ln_nparts);
-        return launch_igemm<2, 2, 4, true, 3>(d, stream, 1, ln_nparts);
-    }
-    if (variant == 24) return launch_igemm<2, 2, 4, true, 4>(d, stream, 1, ln_nparts);
-    if (variant == 25) return launch_igemm<2, 2, 4, true, 5>(d, stream, 1, ln_nparts);
-    if (variant >= 31 && variant <= 33) {   // ... and on the 1x4 tile
-        if (variant == 31) return launch_igemm<1, 4, 4, true, 1>(d, stream, 1, ln_nparts);
-        if (variant == 32) return launch_igemm<1, 4, 4, true, 2>(d, stream, 1, ln_nparts);
-        return launch_igemm<1, 4, 4, true, 3>(d, stream, 1, ln_nparts);
-    }
-#endif
-    // PIVP_LSTM_SQ (tuning): the square 64 x 64 tile (16 channels x 4 gates per block; variants 5 / 6) where the automatic choice would take
-    // the 32-row tile (1: small maps, lstm5's 8 x 8 at B = 32) and also where exactly one 64 x 128 block per CU cannot split its odd chunk
-    // count over two K groups (2: lstm3).  A 32 x 128 tile streams 20 KB of operands per chunk, the square one 16 KB for the same MACs.
-    static const int sq = [] { const char* e = getenv("PIVP_LSTM_SQ"); return e ? atoi(e) : 0; }();
     if (variant == 0) {
         // Two resident blocks per CU (64-row tile, 240 VGPRs) beat the 128-row tile (320 VGPRs: one block, one wave per SIMD) at every grid
         // size: at M = 131072 / 32768 (config 5's maps, scripts/bench_lstm_layers.py 128) 139.9 against 132.3 TFLOP/s over the seven layers,
@@ -696,28 +628,22 @@ int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant, int* ln_npar
         if ((long)(d.M / 64) * nb >= 512) variant = 2;
         else if ((long)(d.M / 64) * nb >= 256) variant = 4;      // one 64-row block per CU: as two K groups (falls back to variant 2 on an odd chunk count)
         else variant = 3;
-        const bool even = ((25 * ((d.c0 + d.c1) >> 5)) & 1) == 0;
-        if (variant == 3 && sq >= 1 && d.C % 16 == 0 && d.M % 64 == 0) variant = even ? 6 : 5;
-        else if (variant == 4 && !even && sq >= 2) variant = 5;
     }
+    // (A square 64 x 64 tile, 16 channels x 4 gates per block, 20 % less operand traffic per MAC -- round 4's variants 5 / 6 -- was slower on every
+    // layer, profiles/r04/NOTES.md 3: in the history.)
     // (128-row tiles as ONE 8-wave block per CU, two K groups -- a third less L2 traffic, half the staging per MFMA -- were measured on the
     // layers that fill the chip: lstm1 126 -> 119.5 TF, lstm7 135.5 -> 132, rollout 8.67 -> 8.86 ms; 46 VGPRs spill under the 256 cap.  Not kept.)
     switch (variant) {
         case 4:   // 64-row tile as two K groups of 4 waves (two waves per SIMD where the grid gives every CU one block): lstm4 106.6 -> 104.6 us,
                   // lstm6 153.6 -> 150.2 at B = 32; needs an even chunk count (lstm3 has 75)
-            if (((25 * ((d.c0 + d.c1) >> 5)) & 1) == 0) return launch_igemm<2, 2, 4, true, 0, 2>(d, stream, 1, ln_nparts);
+            if (((25 * ((d.c0 + d.c1) >> 5)) & 1) == 0) return launch_igemm<2, 2, 4, true, 2>(d, stream, 1, ln_nparts);
             return launch_igemm<2, 2, 4, true>(d, stream, 1, ln_nparts);
-        case 5: return launch_igemm<2, 2, 2, true>(d, stream, 1, ln_nparts);          // 64 x 64 (16 channels x 4 gates)
-        case 6:                                                                         // ... as two K groups of 4 waves
-            if (((25 * ((d.c0 + d.c1) >> 5)) & 1) == 0) return launch_igemm<2, 2, 2, true, 0, 2>(d, stream, 1, ln_nparts);
-            return launch_igemm<2, 2, 2, true>(d, stream, 1, ln_nparts);
         case 1: return launch_igemm<4, 1, 4, true>(d, stream, 1, ln_nparts);
         case 2: return launch_igemm<2, 2, 4, true>(d, stream, 1, ln_nparts);
         case 3: {
             // the in-block K split needs an even number of chunks (25 taps x (c0 + c1) / 32: always even when the channel count is a multiple of 64)
-            static const int kg = [] { const char* e = getenv("PIVP_LSTM_KG"); return e ? atoi(e) : 2; }();   // tuning: 1 = one group
             const int ncc = (d.c0 + d.c1) >> 5;
-            if (kg == 2 && ((25 * ncc) & 1) == 0) return launch_igemm<1, 4, 4, true, 0, 2>(d, stream, 1, ln_nparts);
+            if (((25 * ncc) & 1) == 0) return launch_igemm<1, 4, 4, true, 2>(d, stream, 1, ln_nparts);
             return launch_igemm<1, 4, 4, true>(d, stream, 1, ln_nparts);
         }
     }
@@ -743,18 +669,14 @@ static bool dgrad_choice(const IgemmDesc& d, int& bt, int& bks) {
     static const double fixed_taps[] = {3.0, 1.5, 1.0, 1.0};
     static const double alone[] = {0.80, 1.0, 1.0, 1.0};      // one wave per SIMD hides none of its own waits
     const int cus = pivp_cu_count();
-    static const int force_t = [] { const char* e = getenv("PIVP_DGRAD_TILE"); return e ? atoi(e) : -1; }();   // tuning
-    static const int force_k = [] { const char* e = getenv("PIVP_DGRAD_KS"); return e ? atoi(e) : 0; }();
     bt = -1; bks = 1;
     double bcost = 1e300;
     const int nchunks = d.ksize * d.ksize * ((d.c0 + d.c1) / 32);
     for (int t = 0; t < 7; ++t) {
         if (nt % tiles[t].ntb) continue;
-        if (force_t >= 0 && t != force_t) continue;
         const int bm = 32 * tiles[t].wm, bn = 32 * tiles[t].ntb;
         const long mb = (d.M + bm - 1) / bm, nb = d.N / bn;
         for (int ks = 1; ks <= 10 && ks * 8 <= nchunks; ++ks) {          // >= 8 chunks per split
-            if (force_k > 0 && ks != force_k) continue;
             const long blocks = mb * nb * ks;
             const long per_cu = (blocks + cus - 1) / cus;
             const int res = (int)(per_cu < tiles[t].resident ? per_cu : tiles[t].resident);
@@ -770,34 +692,16 @@ int igemm_conv_ksplit(const IgemmDesc& d) {
     return dgrad_choice(d, bt, bks) ? bks : 1;
 }
 
-// does igemm_conv hand d to igemm_small?  (the same decisions, in the same order, as igemm_conv below)
-bool igemm_conv_takes_small(const IgemmDesc& d) {
-    if (igemm_validate(d, false) != PIVP_OK) return false;
-    const int nt = d.N / 32;
-    if (deconv_tile_ok(d) && !(getenv("PIVP_DECONV_TILE") && atoi(getenv("PIVP_DECONV_TILE")) == 0) &&
-        (long)d.B * (d.Hin / 8) * (d.Win / 16) * nt >= 16) return false;
-    int bt, bks;
-    if (dgrad_choice(d, bt, bks)) return false;
-    static const int mode = [] { const char* e = getenv("PIVP_IGEMM_SMALL"); return e ? atoi(e) : -1; }();
-    const bool can = d.ldo % 4 == 0 && ((uintptr_t)d.out & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0);
-    const long full = (long)((d.M + 127) / 128) * d.nphase, big = full * ((nt + 3) / 4);
-    const int chunks = (d.deconv ? 4 : d.ksize * d.ksize) * ((d.c0 + d.c1) / 32);
-    return can && (mode == 1 || (mode != 0 && (big < 128 || chunks <= 40)));
-}
-
 int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     int rc = igemm_validate(d, false);
     if (rc != PIVP_OK) return rc;
     const int nt = d.N / 32;
     // transposed conv on maps that tile into 8 x 16 input patches: all four parities per block (deconv_tile.hip), unless the grid would be tiny
-    if (deconv_tile_ok(d) && !(getenv("PIVP_DECONV_TILE") && atoi(getenv("PIVP_DECONV_TILE")) == 0) &&
-        (long)d.B * (d.Hin / 8) * (d.Win / 16) * nt >= 16)
+    if (deconv_tile_ok(d) && (long)d.B * (d.Hin / 8) * (d.Win / 16) * nt >= 16)
         return deconv_tile(d, stream, ln_nparts, d.bf16);
     const long full = (long)((d.M + 127) / 128) * d.nphase;   // blocks with BM = 128 and the whole N in one block
     int bt = -1, bks = 1;
     if (dgrad_choice(d, bt, bks)) {
-        static const bool dbg = getenv("PIVP_DGRAD_DEBUG") != nullptr;   // tuning: which tile / split a shape gets (scripts/dgrad_ks_scan.sh)
-        if (dbg) fprintf(stderr, "dgrad M=%d N=%d K=%d tile=%d ks=%d\n", d.M, d.N, d.ksize * d.ksize * (d.c0 + d.c1), bt, bks);
         switch (bt) {
             case 0: return launch_igemm<2, 2, 2, false>(d, stream, bks, ln_nparts);
             case 1: return launch_igemm<4, 1, 1, false>(d, stream, bks, ln_nparts);
@@ -813,11 +717,10 @@ int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     // 32-row tiles with K split over the waves (igemm_small.hip).  Measured at B = 32 (scripts/bench_tail_ops.py):
     // enc1 15.0 -> 6.6 us, enc2 21.4 -> 9.7, enc4 19.3 -> 14.2, enc5 33.7 -> 23.8, enc6 47.6 -> 39.5.
     {
-        static const int mode = [] { const char* e = getenv("PIVP_IGEMM_SMALL"); return e ? atoi(e) : -1; }();   // tuning: 0 never, 1 always
         const bool can = d.ldo % 4 == 0 && ((uintptr_t)d.out & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0);
         const long big = full * ((nt + 3) / 4);
         const int chunks = (d.deconv ? 4 : d.ksize * d.ksize) * ((d.c0 + d.c1) / 32);
-        if (can && (mode == 1 || (mode != 0 && (big < 128 || chunks <= 40)))) {
+        if (can && (big < 128 || chunks <= 40)) {
             return igemm_small(d, stream, ln_nparts);
         }
     }

@@ -14,7 +14,6 @@
 #include <type_traits>
 
 #include "pivp_kernels.h"
-#include "skinny_linear.h"
 
 namespace pivp {
 
@@ -25,7 +24,8 @@ constexpr int TILE = 32 * SP;
 
 // NTB: 32-column tiles per block (the A fragment is reused NTB times; fewer, longer-running blocks).
 template <int NTB, bool IN_LN = false>
-__device__ __forceinline__ void igemm_small_body(const IgemmDesc& d, const int bx, const int by, const int gdy) {   // (bx, by) of a grid (., gdy)
+__global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
+    const int bx = blockIdx.x, by = blockIdx.y, gdy = gridDim.y;
     PIVP_SET_MAIN_PRIO();
     constexpr int BN = 32 * NTB;
     constexpr int RP = BN + 4;                                    // row pitch of the partial-sum image
@@ -182,12 +182,6 @@ __device__ __forceinline__ void igemm_small_body(const IgemmDesc& d, const int b
     const int oy0 = deconv ? py : 0, ox0 = deconv ? px : 0;
     float* orow = d.out + ((size_t)(b * d.Hout + ay * d.out_step + oy0) * d.Wout + ax * d.out_step + ox0) * d.ldo + nblk * BN;
     float sv[4 * NTB];   // this thread's outputs, for the fused LayerNorm partial
-    // LayerNorm-backward sums of the output (data gradients, IgemmDesc::lnb_part): block-uniform switch
-    const int nb_ln = d.lnb_part ? (d.lnb_C + BN - 1) / BN : 0;
-    const bool lnb = nblk < nb_ln;
-    float lb1 = 0.f, lb2 = 0.f, lmean = 0.f, lrstd = 0.f;
-    const int opix = (ay * d.out_step + oy0) * d.Wout + ax * d.out_step + ox0;
-    if (lnb) { lmean = d.lnb_stat[b * 2]; lrstd = d.lnb_stat[b * 2 + 1]; }
 #pragma unroll
     for (int t = 0; t < NTB; ++t) {
         const int cl = t * 32 + cvec * 4;   // column within the block tile
@@ -202,23 +196,6 @@ __device__ __forceinline__ void igemm_small_body(const IgemmDesc& d, const int b
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) sv[t * 4 + e] = v[e];
-        if (lnb && valid && nblk * BN + cl < d.lnb_C) {       // (lnb_C is a multiple of 4: a float4 is inside or outside)
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(d.lnb_gamma + (size_t)opix * d.lnb_C + nblk * BN + cl);
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(d.lnb_x + ((size_t)b * d.Hout * d.Wout + opix) * d.lnb_C + nblk * BN + cl);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float gg = v[e] * gv[e]; lb1 += gg; lb2 = fmaf(gg, (xv[e] - lmean) * lrstd, lb2); }
-        }
-    }
-    if (lnb) {           // fixed order: xor tree inside a wave, the four waves left to right
-        __syncthreads();   // the partial-sum image is dead
-        lb1 = wave_sum(lb1); lb2 = wave_sum(lb2);
-        if (lane == 0) { lds[16 + wave] = lb1; lds[20 + wave] = lb2; }
-        __syncthreads();
-        if (tid == 0) {
-            const int bb = m0 / HWg;
-            float* pp = d.lnb_part + ((size_t)bb * d.lnb_np + (((m0 - bb * HWg) >> 5) * nb_ln + nblk) * gdy + phase) * 2;
-            pp[0] = (lds[16] + lds[17]) + (lds[18] + lds[19]); pp[1] = (lds[20] + lds[21]) + (lds[22] + lds[23]);
-        }
     }
     if (d.ln_part) {   // (count, mean, M2) of the block's outputs, two passes over registers, fixed summation order
         __syncthreads();   // the partial-sum image is dead
@@ -245,43 +222,15 @@ __device__ __forceinline__ void igemm_small_body(const IgemmDesc& d, const int b
     }
 }
 
-template <int NTB, bool IN_LN = false>
-__global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
-    igemm_small_body<NTB, IN_LN>(d, blockIdx.x, blockIdx.y, gridDim.y);
-}
-
-// Two independent, latency-bound launches of the rollout in ONE grid (round 4): the conv `d` (enc4: the 4-phase transposed conv on the 8-wide
-// map, 1,024 blocks of 32 x 32) and the K-slice partial sums of the motion head's Linear (256 blocks).  Both read only hidden5, neither
-// fills the chip, and on one stream they ran back to back: 12.7 + 9.2 us and a launch boundary.  The first gridDim.x - conv_bx block columns,
-// taken phase-major, are the Linear's (K slice, batch group); the rest are the conv's.  Same arithmetic, same order: results are those of the two launches.
-template <bool DBL>
-__global__ __launch_bounds__(256) void igemm_small_partials_kernel(const IgemmDesc d, int conv_bx, const float* __restrict__ x,
-                                                                    const float* __restrict__ wt, float* __restrict__ partials, int B, int K, int KS, int ngrp) {
-    // the Linear's blocks FIRST: workgroups are dispatched in index order, and behind the conv's 1,024 blocks they only started when those had
-    // drained (21.4 us for the grid = the two launches back to back); in front, one per CU, the conv's blocks fill the CUs around them
-    const int part_bx = (int)gridDim.x - conv_bx;
-    if ((int)blockIdx.x >= part_bx) {
-        igemm_small_body<1, false>(d, (int)blockIdx.x - part_bx, blockIdx.y, gridDim.y);
-    } else {
-        const int pi = (int)blockIdx.x * (int)gridDim.y + (int)blockIdx.y;
-        if (pi < KS * ngrp) {
-            if (DBL) skinny_linear_partials_body<double>(x, wt, partials, B, K, pi % KS, pi / KS, KS);
-            else skinny_linear_partials_body<float>(x, wt, partials, B, K, pi % KS, pi / KS, KS);
-        }
-    }
-}
-
 // d has been validated by igemm_validate (igemm_f32.hip); additionally needs 16-B aligned out / bias rows.
 int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     PIVP_CHECK_ARG(d.ldo % 4 == 0 && ((uintptr_t)d.out & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0));
     const int mblk = (d.M + 31) / 32, nt = d.N / 32;
     // widest column block that still leaves >= 4 blocks per CU (enc4: 1 tile 14.2 us vs 2 tiles 15.3; enc5: 3 tiles 23.8 vs 1 tile
     // 25.7; enc6: 2 tiles 39.5 vs 1 tile 44.9)
-    static const int force = [] { const char* e = getenv("PIVP_SMALL_NTB"); return e ? atoi(e) : 0; }();   // tuning
     int ntb = 1;
     if (nt % 3 == 0 && (long)mblk * (nt / 3) * d.nphase >= 1024) ntb = 3;
     else if (nt % 2 == 0 && (long)mblk * (nt / 2) * d.nphase >= 1024) ntb = 2;
-    if (force >= 1 && force <= 3 && nt % force == 0) ntb = force;
     dim3 grid(mblk * (nt / ntb), d.nphase);
     IgemmDesc dd = d;   // fused LayerNorm partials: one per block, when no tile straddles two samples
     const int hwg = d.Hg * d.Wg;
@@ -289,15 +238,6 @@ int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     dd.ln_nparts = (d.ln_part && hwg % 32 == 0 && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
-    {   // LayerNorm-backward sums of the output (data gradients): one part per block that owns norm columns
-        const int bn = 32 * ntb, nb_ln = d.lnb_part ? (d.lnb_C + bn - 1) / bn : 0;
-        const int lnp = (hwg / 32) * nb_ln * d.nphase;
-        const bool ok = d.lnb_part && d.lnb_gamma && d.lnb_x && d.lnb_stat && d.lnb_C > 0 && d.lnb_C % 4 == 0 && d.lnb_C <= d.N &&
-                        hwg % 32 == 0 && lnp <= d.lnb_cap && !d.ln_part;
-        dd.lnb_np = ok ? lnp : 0;
-        if (!ok) dd.lnb_part = nullptr;
-        if (d.lnb_np_out) *d.lnb_np_out = dd.lnb_np;
-    }
     if (d.in_g) {      // LayerNorm-on-load (see IgemmDesc::in_g): one sample per tile, one source, a plain conv
         PIVP_CHECK_ARG(igemm_in_ln_ok(d) && d.in_b && d.in_part && d.in_np > 0);
         if (ntb == 3) hipLaunchKernelGGL((igemm_small_kernel<3, true>), grid, dim3(256), 0, stream, dd);
@@ -308,24 +248,6 @@ int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     if (ntb == 3) hipLaunchKernelGGL(igemm_small_kernel<3>, grid, dim3(256), 0, stream, dd);
     else if (ntb == 2) hipLaunchKernelGGL(igemm_small_kernel<2>, grid, dim3(256), 0, stream, dd);
     else hipLaunchKernelGGL(igemm_small_kernel<1>, grid, dim3(256), 0, stream, dd);
-    return PIVP_LAUNCH_STATUS();
-}
-
-// the conv d (which must be one igemm_small would run with 32-column blocks, no fused epilogues) and the motion head's partial sums in one
-// launch; PIVP_ERR_BADARG when d does not qualify (the caller then launches the two separately)
-int igemm_small_with_partials(const IgemmDesc& d, hipStream_t stream, const float* hidden5, const float* wt, float* partials, int B, int K, int dbl) {
-    PIVP_CHECK_ARG(d.ldo % 4 == 0 && ((uintptr_t)d.out & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0));
-    PIVP_CHECK_ARG(hidden5 && wt && partials && B > 0 && K > 0 && !d.in_g && !d.ln_part && !d.lnb_part);
-    const int mblk = (d.M + 31) / 32, nt = d.N / 32;
-    static const int force = [] { const char* e = getenv("PIVP_SMALL_NTB"); return e ? atoi(e) : 0; }();
-    PIVP_CHECK_ARG(force <= 1 && !(nt % 3 == 0 && (long)mblk * (nt / 3) * d.nphase >= 1024) && !(nt % 2 == 0 && (long)mblk * (nt / 2) * d.nphase >= 1024));
-    const int KS = cdna_kernel_partials_slices(K), ngrp = (B + LIN_BG - 1) / LIN_BG;
-    const int conv_bx = mblk * nt, part_bx = (KS * ngrp + d.nphase - 1) / d.nphase;
-    IgemmDesc dd = d;
-    dd.ln_nparts = 0; dd.lnb_np = 0;
-    const dim3 grid(conv_bx + part_bx, d.nphase);
-    if (dbl) hipLaunchKernelGGL(igemm_small_partials_kernel<true>, grid, dim3(256), 0, stream, dd, conv_bx, hidden5, wt, partials, B, K, KS, ngrp);
-    else hipLaunchKernelGGL(igemm_small_partials_kernel<false>, grid, dim3(256), 0, stream, dd, conv_bx, hidden5, wt, partials, B, K, KS, ngrp);
     return PIVP_LAUNCH_STATUS();
 }
 

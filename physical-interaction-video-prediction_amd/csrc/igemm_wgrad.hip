@@ -13,13 +13,10 @@
 
 #include "pivp_kernels.h"
 
-// timing-only ablations of wgrad5x5_kernel (results wrong): 1 = no global loads / LDS stores in the loop, 2 = also no LDS reads,
-// 3 = loads without stores, 4 = stores without loads.  lstm7 (us): full 265, 1: 222, 2: 208, 3: 221, 4: 217 -- loads and stores
-// cost nothing on their own and 43 us together, i.e. what costs is LDS contents that CHANGE between chunks (not understood; round 3,
-// scripts/wgrad_data_dependence.py: the full kernel is 13 % faster whenever one of its operands is all zeros, at an unchanged 2.39 GHz).
-#ifndef PIVP_WG_ABL
-#define PIVP_WG_ABL 0
-#endif
+// (Timing-only ablations of wgrad5x5_kernel, round 2/3, in the history: no global loads / LDS stores in the loop 222 us, also no LDS reads 208,
+// loads without stores 221, stores without loads 217 against the full kernel's 265 on lstm7 -- loads and stores cost nothing on their own and 43 us
+// together, i.e. what costs is LDS contents that CHANGE between chunks; scripts/wgrad_data_dependence.py: the full kernel is 13 % faster whenever
+// one of its operands is all zeros, at an unchanged 2.39 GHz.)
 
 namespace pivp {
 
@@ -272,16 +269,16 @@ __global__ __launch_bounds__(256) void igemm_wgrad_reduce_kernel(const WgradDesc
 // lstm4 130 -> 118, lstm5 101 -> 92, lstm6 183 -> 169, lstm7 238 -> 224; train step 31.0 -> 30.7 ms.  (Keeping NTW = 2 and dropping to one
 // LDS buffer + one staging register set per wave instead spilled 76-97 VGPRs: 32.3 -> 35.0 ms.)  A second round of blocks costs 8-9 us
 // per launch (prologue + block reduction + atomics + the first loads' latency): the grid stays at one round of resident blocks.
-// OCC = 3 (round 4): THREE resident blocks per CU -- one LDS buffer and one staging register set per wave (the loads of the wave's next
-// chunk are issued at the top of a chunk and written over the buffer behind its last k-step), <= 168 registers, 42 KB of LDS -- so that a
-// SIMD holds three of these barrier-free workers instead of two, and the grid (tiles x pixel splits) fills 768 slots instead of 480 of 512.
-template <int NTW, int SW, int OCC = 2>   // NTW: 32-column tiles per wave (1 or 2); SW: pixels of one image row inside a chunk (min(W, 32))
-__global__ __launch_bounds__(256, NTW == 1 ? OCC : 1) void wgrad5x5_kernel(const WgradDesc d) {
+// (Round 4 also built THREE resident blocks per CU -- one LDS buffer and one staging register set per wave, <= 168 registers, 42 KB of LDS: slower on
+// every layer, profiles/r04/NOTES.md 5; and the NTW = 2 form stayed selectable until round 5.  Both are in the history.)
+template <int SW>   // SW: pixels of one image row inside a chunk (min(W, 32))
+__global__ __launch_bounds__(256, 2) void wgrad5x5_kernel(const WgradDesc d) {
+    constexpr int NTW = 1;                      // 32-column tiles per wave
     constexpr int R = 32 / SW;                  // image rows per chunk
     constexpr int SP = R * (SW + 4);            // strip pixels
     constexpr int XP = 32, YP = 32 * NTW;       // LDS row lengths (floats): lane-contiguous reads, no padding needed
     constexpr int WBUF = SP * XP + 32 * YP;     // floats per wave per buffer
-    constexpr int NBUF = OCC == 3 ? 1 : 2;      // LDS buffers per wave
+    constexpr int NBUF = 2;                     // LDS buffers per wave
     constexpr int NACC = 5 * NTW;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -373,14 +370,11 @@ __global__ __launch_bounds__(256, NTW == 1 ? OCC : 1) void wgrad5x5_kernel(const
     using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
     int c = c_begin + wave;
     if (c < c_end) { issue(S0{}, c); store(S0{}, 0); }
-    if (NBUF == 2 && c + 4 < c_end) issue(S1{}, c + 4);
+    if (c + 4 < c_end) issue(S1{}, c + 4);
     int buf = 0;
     auto iter = [&](auto SET) {     // chunk c from LDS buffer `buf`; SET = register set that receives chunk c+8
         using OTHER = std::integral_constant<int, decltype(SET)::value ^ 1>;
-#if PIVP_WG_ABL < 1 || PIVP_WG_ABL == 3
-        if (NBUF == 2) { if (c + 8 < c_end) issue(SET, c + 8); }
-        else if (c + 4 < c_end) issue(S0{}, c + 4);        // one set: the wave's NEXT chunk, stored behind this chunk's last k-step
-#endif
+        if (c + 8 < c_end) issue(SET, c + 8);
         const float* xs = wbase + buf * WBUF + l31;
         const float* ys = xs - l31 + SP * XP + l31;
         // operands of k-step s2+1 are read from LDS BEFORE the 5*NTW MFMAs of k-step s2 are issued, and the order is pinned:
@@ -397,9 +391,7 @@ __global__ __launch_bounds__(256, NTW == 1 ? OCC : 1) void wgrad5x5_kernel(const
         };
         auto kstep = [&](auto S2) {
             constexpr int s2 = decltype(S2)::value, cur = s2 & 1;
-#if PIVP_WG_ABL < 2
             if constexpr (s2 + 1 < 16) read_step(std::integral_constant<int, s2 + 1>{}, cur ^ 1);
-#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < NTW; ++t) bsum[t] += bv[cur][t];
@@ -417,16 +409,13 @@ __global__ __launch_bounds__(256, NTW == 1 ? OCC : 1) void wgrad5x5_kernel(const
         kstep(std::integral_constant<int, 9>{}); kstep(std::integral_constant<int, 10>{}); kstep(std::integral_constant<int, 11>{});
         kstep(std::integral_constant<int, 12>{}); kstep(std::integral_constant<int, 13>{}); kstep(std::integral_constant<int, 14>{});
         kstep(std::integral_constant<int, 15>{});
-#if PIVP_WG_ABL < 1 || PIVP_WG_ABL == 4
-        if (NBUF == 2) { if (c + 4 < c_end) store(OTHER{}, buf ^ 1); }
-        else if (c + 4 < c_end) store(S0{}, 0);            // (in-order LDS: the k-steps' reads of this buffer are behind us)
-#endif
-        if (NBUF == 2) buf ^= 1;
+        if (c + 4 < c_end) store(OTHER{}, buf ^ 1);
+        buf ^= 1;
         c += 4;
     };
     while (c < c_end) {
         iter(S0{});
-        if (NBUF == 2 && c < c_end) iter(S1{});
+        if (c < c_end) iter(S1{});
     }
     // ---- bias gradient: the blocks of kernel row 2 / channel block 0 have fed every dY element of their pixel range through
     // the MFMAs exactly once; lane (n, half) holds the sum over its half's pixels ---------------------------------------
@@ -472,37 +461,33 @@ __global__ __launch_bounds__(256, NTW == 1 ? OCC : 1) void wgrad5x5_kernel(const
         const int kx = t / NTW, tt = t - kx * NTW;
         const int tap = ky * 5 + kx;
         float* g = d.dw + (((size_t)tap * (d.wcin >> 5) + cb) * d.N + n0 + tt * 32 + n) * 32 + ci;
-#ifdef PIVP_WG_NOATOMIC   // timing-only ablation (results wrong): these contiguous atomics cost 2 % of the kernel (160 -> 157 us on lstm7), unlike the
-                          // generic kernel's scattered ones (85 -> 31 us), which is why only that one got per-block partial sums
-        if (sm[t * IT + n * 33 + ci] == 12345.678f) *g = 1.f;
-#else
+        // (these contiguous atomics cost 2 % of the kernel, 160 -> 157 us on lstm7 without them, unlike the generic kernel's scattered ones,
+        // 85 -> 31 us, which is why only that one got per-block partial sums)
         atomicAdd(g, sm[t * IT + n * 33 + ci]);
-#endif
     }
     // bias gradient for free: the kernel-row 0 / channel-block 0 blocks have every dY pixel of their chunks in LDS... not kept; see bias_grad
 }
 
-template <int NTW, int SW, int OCC = 2>
+template <int SW>
 static int launch_wgrad5x5(const WgradDesc& d, hipStream_t s) {
+    constexpr int NTW = 1, OCC = 2;      // 32-column tiles per wave, resident blocks per CU (the kernel's launch bounds)
     constexpr int R = 32 / SW, SP = R * (SW + 4);
     constexpr int WBUF = SP * 32 + 32 * 32 * NTW;
     constexpr int IMG = 5 * NTW * 32 * 33;
-    constexpr int NBUF = OCC == 3 ? 1 : 2;
+    constexpr int NBUF = 2;
     constexpr int lds_floats = (4 * NBUF * WBUF > 2 * IMG) ? 4 * NBUF * WBUF : 2 * IMG;
     constexpr int lds_bytes = lds_floats * 4;
     static PerDeviceOnce once;
-    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&wgrad5x5_kernel<NTW, SW, OCC>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&wgrad5x5_kernel<SW>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     const int tiles = 5 * (d.cin / 32) * (d.N / (32 * NTW));
     const int chunks = d.M / 32 * (d.tcount > 1 ? d.tcount : 1);
     // One block per CU is resident (~100 KB of LDS), so the grid is sized to whole rounds of the chip's CUs: the first
     // version asked for "about 512" blocks and got 520-600, i.e. a third round that ran 8-88 blocks on 256 CUs (lstm7: 264 us
     // for 171 us of MFMA work).  Take the fewest rounds (1..3) whose last round is at least 90 % full.
-    static const int slots = [] { const char* e = getenv("PIVP_WGRAD_SLOTS"); return e ? atoi(e) : 0; }();   // tuning: blocks per round
-    const int cus = slots > 0 ? slots : pivp_cu_count() * (NTW == 1 ? OCC : 1);   // resident blocks (NTW = 1: two or three per CU)
+    const int cus = pivp_cu_count() * OCC;   // resident blocks
     int nsplit = 1;
     double best = 0.0;
-    static const int rmin = [] { const char* e = getenv("PIVP_WGRAD_ROUNDS"); return e ? atoi(e) : 1; }();   // tuning
-    for (int r = rmin; r <= 3; ++r) {
+    for (int r = 1; r <= 3; ++r) {
         int ns = (cus * r) / tiles;
         if (ns > chunks / 16) ns = chunks / 16;          // >= 4 chunks per wave
         if (ns < 1) ns = 1;
@@ -511,7 +496,7 @@ static int launch_wgrad5x5(const WgradDesc& d, hipStream_t s) {
         if (fill > best + 0.02) { best = fill; nsplit = ns; }
         if (best >= 0.9) break;
     }
-    hipLaunchKernelGGL((wgrad5x5_kernel<NTW, SW, OCC>), dim3(tiles, nsplit), dim3(256), lds_bytes, s, d);
+    hipLaunchKernelGGL((wgrad5x5_kernel<SW>), dim3(tiles, nsplit), dim3(256), lds_bytes, s, d);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -528,8 +513,7 @@ static void generic_grid(const WgradDesc& d, int& wg_n, int& tiles, int& nsplit)
     // direct path: every block ends with a tile of atomics (64 x 128), so no more pixel splits than fill the chip twice (3 blocks fit a
     // CU) and >= 8 chunks (256 pixels) per block (enc4 with 4: 63 -> 94 us, atomics); kept for the partial-sum path, where a split
     // costs 16-32 KB of traffic instead
-    static const int gslots = [] { const char* e = getenv("PIVP_WGRAD_GEN_SLOTS"); return e ? atoi(e) : 512; }();   // tuning
-    nsplit = (gslots + tiles - 1) / tiles;
+    nsplit = (512 + tiles - 1) / tiles;
     if (nsplit > chunks / 8) nsplit = chunks / 8;
     if (nsplit < 1) nsplit = 1;
 }
@@ -542,15 +526,7 @@ int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done) {
     PIVP_CHECK_ARG(d.bytes0 > 0 && d.bytesy > 0 && (d.c1 == 0 || d.bytes1 > 0));
     if (takes_fast_path(d)) {
         if (bias_done) *bias_done = d.db ? 1 : 0;
-        static const int ntw = [] { const char* e = getenv("PIVP_WGRAD_NTW"); return e ? atoi(e) : 1; }();   // tuning
-        static const int ntw8 = [] { const char* e = getenv("PIVP_WGRAD_NTW8"); return e ? atoi(e) : 1; }();
-        static const int occ = [] { const char* e = getenv("PIVP_WGRAD_OCC"); return e ? atoi(e) : 2; }();   // tuning: resident blocks per CU (2 or 3)
-        if (occ == 3 && ntw == 1 && ntw8 == 1)
-            return d.Wg == 8 ? launch_wgrad5x5<1, 8, 3>(d, s) : d.Wg == 16 ? launch_wgrad5x5<1, 16, 3>(d, s) : launch_wgrad5x5<1, 32, 3>(d, s);
-        if (d.Wg == 8) return ntw8 == 1 ? launch_wgrad5x5<1, 8>(d, s) : launch_wgrad5x5<2, 8>(d, s);
-        if (ntw == 1) return d.Wg == 16 ? launch_wgrad5x5<1, 16>(d, s) : launch_wgrad5x5<1, 32>(d, s);
-        if (d.Wg == 16) return launch_wgrad5x5<2, 16>(d, s);
-        return launch_wgrad5x5<2, 32>(d, s);
+        return d.Wg == 8 ? launch_wgrad5x5<8>(d, s) : d.Wg == 16 ? launch_wgrad5x5<16>(d, s) : launch_wgrad5x5<32>(d, s);
     }
     int wg_n, tiles, nsplit;
     generic_grid(d, wg_n, tiles, nsplit);

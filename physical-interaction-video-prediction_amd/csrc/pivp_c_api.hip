@@ -15,12 +15,6 @@ namespace pivp {
 // extent in bytes of an NHWC view with pixel stride ld (for the kernels' buffer descriptors)
 long long view_bytes(int B, int H, int W, int ld) { return (long long)B * H * W * ld * 4; }
 bool fits31(long long v) { return v > 0 && v < (1LL << 31); }
-void lnb_apply(IgemmDesc& d, const LnbSpec* l) {
-    if (!l) return;
-    if (l->np) *l->np = 0;
-    d.lnb_gamma = l->gamma; d.lnb_x = l->x; d.lnb_stat = l->stat; d.lnb_part = l->part; d.lnb_C = l->C; d.lnb_cap = l->cap; d.lnb_np_out = l->np;
-}
-
 int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                  const float* c_in, float* c_out, float* h_out, int B, int H, int W, hipStream_t s, int variant,
                  float* gates_out, float* ln_part, int ln_cap, int* ln_nparts, const unsigned short* w_bf16, int bf16_planes, const LnIn* ln_in) {
@@ -48,8 +42,7 @@ int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, co
     // (three pieces: maps the three-plane tile does not serve -- 8 wide -- take the fp32 kernel, which is what that mode stands in for)
     // (two fp16 pieces: 8-wide maps take the ring kernel's fp16 form when its tiles fit -- an even batch --, whose pack is laid out differently: the caller's)
     if (w_bf16 && !convlstm_bf16x6_ok(d) && (bf16_planes == 3 || (bf16_planes == -2 && !convlstm_bf16_ok(d)))) return w ? igemm_lstm(d, s, 0, ln_nparts) : PIVP_ERR_BADARG;
-    if (w_bf16) return convlstm_bf16(d, w_bf16, s, ln_nparts, ((bf16_planes == 3 && variant != 1 && variant != 2 && variant != 16 && variant != 32) ||
-                                                        (bf16_planes == -2 && variant != 16 && variant != 32 && variant != 256)) ? 0 : variant, bf16_planes);
+    if (w_bf16) return convlstm_bf16(d, w_bf16, s, ln_nparts, ((bf16_planes == 3 || bf16_planes == -2) && variant != 16 && variant != 32) ? 0 : variant, bf16_planes);
     return igemm_lstm(d, s, variant, ln_nparts);
 }
 
@@ -58,7 +51,7 @@ bool convlstm_ln_in_ok(int planes, int cx, int ldx, int C, int B, int H, int W) 
     return (planes == 3 || planes == -2) && cx <= 64 && ldx == cx && cx % 8 == 0 && C % 16 == 0 && H % 8 == 0 && W % 16 == 0;
 }
 int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
-                  int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum, const LnbSpec* lnb) {
+                  int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum) {
     if (Hin % 2 || Win % 2) return PIVP_ERR_BADARG;
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
@@ -70,7 +63,6 @@ int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float*
     if (!fits31(b0) || !fits31(bw)) return PIVP_ERR_BADARG;
     d.bytes0 = (int)b0; d.bytesw = (int)bw;
     d.out_step = 1; d.Hout = d.Hg; d.Wout = d.Wg; d.out = out; d.ldo = ldo; d.relu = relu; d.accum = accum;
-    lnb_apply(d, lnb);
     return igemm_conv(d, s);
 }
 
@@ -105,7 +97,7 @@ int run_conv3x3s2_ln(const float* x_raw, int cin, const float* w, const float* b
 
 int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                     int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum, float* ln_part, int ln_cap,
-                    int* ln_nparts, int bf16, const LnbSpec* lnb, const float* wscale_part) {
+                    int* ln_nparts, int bf16, const float* wscale_part) {
     IgemmDesc d;
     memset(&d, 0, sizeof(d));
     if (bf16 == 3 && !wscale_part) return PIVP_ERR_BADARG;
@@ -120,7 +112,6 @@ int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const floa
     d.bytes0 = (int)b0; d.bytesw = (int)bw;
     d.out_step = 2; d.Hout = 2 * Hin; d.Wout = 2 * Win; d.out = out; d.ldo = ldo; d.relu = relu; d.accum = accum;
     d.ln_part = ln_part; d.ln_cap = ln_cap;
-    lnb_apply(d, lnb);
     return igemm_conv(d, s, ln_nparts);
 }
 
@@ -140,13 +131,8 @@ int run_deconv3x3s2_and_partials(const float* x, int cin, const float* w, const 
     d.bytes0 = (int)b0; d.bytesw = (int)bw;
     d.out_step = 2; d.Hout = 2 * Hin; d.Wout = 2 * Win; d.out = out; d.ldo = ldo; d.relu = relu;
     const int K = Hin * Win * cin;
-    // PIVP_ENC4_PARTIALS=1: one grid.  MEASURED (profiles/r04/NOTES.md): the grid takes 21.4-22.0 us, the two launches 12.7 + 9.2, whichever
-    // kind of block is dispatched first, and the rollout does not move (8.46 against 8.46 ms): they do not overlap.  Default: two launches.
-    static const int fuse = [] { const char* e = getenv("PIVP_ENC4_PARTIALS"); return e ? atoi(e) : 0; }();
-    if (fuse && igemm_conv_takes_small(d)) {
-        const int rc = igemm_small_with_partials(d, s, x, wt, partials, B, K, dbl);
-        if (rc != PIVP_ERR_BADARG) return rc;
-    }
+    // (Both in ONE grid -- round 4's igemm_small_partials_kernel -- took 21.4-22.0 us against 12.7 + 9.2 for the two launches, whichever kind of block
+    // was dispatched first, and the rollout did not move: profiles/r04/NOTES.md.  Two launches; the fused grid is in the history.)
     int rc = igemm_conv(d, s);
     if (rc != PIVP_OK) return rc;
     return motion_partials(x, wt, partials, B, K, dbl, s);
@@ -170,8 +156,7 @@ static int deconv3x3s2_ln_desc(IgemmDesc& d, const float* h_raw, int c_ln, const
 }
 bool deconv3x3s2_ln_ok(int c_ln, int c1, int cout, int B, int Hin, int Win) {
     if (c_ln <= 0 || c_ln % 32 || c1 < 0 || c1 % 32 || cout % 32 || Hin % 8 || Win % 16) return false;
-    static const bool off = getenv("PIVP_DECONV_TILE") && atoi(getenv("PIVP_DECONV_TILE")) == 0;
-    return !off && (long)B * (Hin / 8) * (Win / 16) * (cout / 32) >= 16;
+    return (long)B * (Hin / 8) * (Win / 16) * (cout / 32) >= 16;
 }
 int run_deconv3x3s2_ln(const float* h_raw, int c_ln, const float* x1, int c1, int ld1, const float* w, const float* bias, float* out, int cout,
                        int ldo, int relu, int B, int Hin, int Win, hipStream_t s, const float* gamma, const float* beta, const float* partials,
@@ -218,11 +203,10 @@ bool conv_s1_splits_k(int cin, int cout, int ldo, int ksize, int B, int H, int W
     return d.ksplit_ok && igemm_conv_ksplit(d) > 1;
 }
 int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, int cout, int ldo, int ksize, int B, int H, int W,
-                hipStream_t s, int accum, int wN, int dest_zeroed, const LnbSpec* lnb) {
+                hipStream_t s, int accum, int wN, int dest_zeroed) {
     IgemmDesc d;
     int rc = conv_s1_desc(d, x, cin, ldx, w, out, cout, ldo, ksize, B, H, W, accum, wN);
     if (rc != PIVP_OK) return rc;
-    lnb_apply(d, lnb);
     if (d.ksplit_ok && !dest_zeroed && igemm_conv_ksplit(d) > 1 &&
         hipMemsetAsync(out, 0, (size_t)B * H * W * ldo * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     return igemm_conv(d, s);
@@ -304,7 +288,7 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
                           const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                           float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
                           int B, int H, int W, hipStream_t s, int wt_ready, unsigned short* wt_bf16, int bf16_planes, const SideFork* fork,
-                          const LnFuse* ln, int dx_only, const LnbSpec* dx_lnb, float* dg_absmax) {
+                          const LnFuse* ln, int dx_only, float* dg_absmax) {
     const int M = B * H * W, cin = cx + C, N = 4 * C;
     if (wt_bf16 && bf16_planes == -2 && !dg_absmax) return PIVP_ERR_BADARG;
     // a K-split data gradient adds into d_in: the gate kernel clears it on the side (one launch less than a memset per cell and timestep)
@@ -332,12 +316,11 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
             rc = pack_lstm_bf16(wt, wt_bf16, N, cin, s, conv5x5_bf16_rows(cin), bf16_planes, (bf16_planes == -2 && W % 16) ? 2 : 1);
             if (rc != PIVP_OK) return rc;
         }
-        if (dx_lnb && dx_lnb->np) *dx_lnb->np = 0;      // (the bf16 data-gradient kernel has no LayerNorm-backward epilogue: the caller runs ln_bwd_sums)
         rc = run_conv5x5_bf16(dG, N, N, wt_bf16, d_in, cin, cin, 0, B, H, W, s, bf16_planes, zero, dg_absmax);
     } else {
         // d[x,h] = conv5x5(dG, W^T flipped); dx_only: the x columns alone (the pack's first cx of cin; the h columns of d_in stay unwritten)
-        rc = dx_only ? run_conv_s1(dG, N, N, wt, d_in, cx, cin, 5, B, H, W, s, 0, cin, zero, dx_lnb)
-                     : run_conv_s1(dG, N, N, wt, d_in, cin, cin, 5, B, H, W, s, 0, 0, zero, dx_lnb);
+        rc = dx_only ? run_conv_s1(dG, N, N, wt, d_in, cx, cin, 5, B, H, W, s, 0, cin, zero)
+                     : run_conv_s1(dG, N, N, wt, d_in, cin, cin, 5, B, H, W, s, 0, 0, zero);
     }
     if (rc != PIVP_OK) return rc;
     if (!dW) return PIVP_OK;   // the caller batches this layer's weight gradient over several timesteps itself (pivp_plan.hip)
@@ -378,7 +361,7 @@ int run_select_frames(const float* gt, const float* gen, const unsigned char* ta
 // conv3x3s2 (mode 0) / deconv3x3s2 (mode 1) backward.  dy is masked in place by (y > 0) when y != null (fused ReLU).
 int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w, float* dy, int cout, int ldy, const float* y, int ldyy,
                       float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, hipStream_t s,
-                      int wt_ready, const SideFork* fork, float* part, WgradDesc* desc_out, const float* dy_add, int ld_add, const LnbSpec* dx_lnb) {
+                      int wt_ready, const SideFork* fork, float* part, WgradDesc* desc_out, const float* dy_add, int ld_add) {
     const int Hout = mode ? 2 * Hin : Hin / 2, Wout = mode ? 2 * Win : Win / 2;
     int rc = PIVP_OK;
     if (y) { rc = relu_mask(dy, ldy, y, ldyy, cout, (long)B * Hout * Wout, s, dy_add, ld_add); if (rc != PIVP_OK) return rc; }
@@ -391,8 +374,8 @@ int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w
             rc = repack_transpose(w, wt, 9, cin, cout, 0, s);
             if (rc != PIVP_OK) return rc;
         }
-        rc = mode ? run_conv3x3s2(dy, cout, ldy, wt, nullptr, dx, cin, lddx, 0, B, Hout, Wout, s, accum_dx, dx_lnb)
-                  : run_deconv3x3s2(dy, cout, ldy, wt, nullptr, dx, cin, lddx, 0, B, Hout, Wout, s, accum_dx, nullptr, 0, nullptr, 0, dx_lnb);
+        rc = mode ? run_conv3x3s2(dy, cout, ldy, wt, nullptr, dx, cin, lddx, 0, B, Hout, Wout, s, accum_dx)
+                  : run_deconv3x3s2(dy, cout, ldy, wt, nullptr, dx, cin, lddx, 0, B, Hout, Wout, s, accum_dx);
         if (rc != PIVP_OK) return rc;
     }
     int bias_done = 0;     // the weight-gradient kernel sums dY's columns on the side when it can
@@ -432,7 +415,7 @@ extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_pre
 }
 extern "C" int pivp_convlstm_v(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                                const float* c_in, float* c_out, float* h_out, int B, int H, int W, int variant, void* stream) {
-    if (!x || !w || !bias || !c_in || !c_out || !h_out || variant < 0 || variant > 33) return PIVP_ERR_BADARG;
+    if (!x || !w || !bias || !c_in || !c_out || !h_out || variant < 0 || variant > 4) return PIVP_ERR_BADARG;
     return run_convlstm(x, cx, ldx, h_prev, C, w, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, variant);
 }
 extern "C" int pivp_convlstm_train(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
@@ -633,7 +616,7 @@ extern "C" int pivp_convlstm_ln(const float* x, int cx, int ldx, const float* h_
                                 const float* c_in, float* c_out, float* h_out, const float* gamma, const float* beta,
                                 float* ln_out, int ldo, float* partials, float eps, int B, int H, int W, int variant, int* fused,
                                 void* stream) {
-    if (!x || !w || !bias || !c_in || !c_out || !h_out || !gamma || !beta || !ln_out || !partials || variant < 0 || variant > 6)
+    if (!x || !w || !bias || !c_in || !c_out || !h_out || !gamma || !beta || !ln_out || !partials || variant < 0 || variant > 4)
         return PIVP_ERR_BADARG;
     if (C <= 0 || C % 32) return PIVP_ERR_BADARG;
     int np = 0;
@@ -653,7 +636,7 @@ extern "C" int pivp_layernorm_backward(const float* dy, int lddy, const float* y
     return ln_backward(dy, lddy, y, ldy, x, stat, gamma, partials, dx, dgamma, dbeta, B, n, C, relu, (hipStream_t)stream);
 }
 // LayerNorm backward of the norm behind a ConvLSTM + the cell's gate backward, the way the BPTT sweep runs the pair (pivp_plan.hip:
-// lnb_cell + lstmb): sums + parameter planes in one launch, then the gate kernel forms the norm's dx from the partials on the fly.
+// lnb_cell + lstmb): sums + parameter planes in one launch (ln_bwd_sums_params_kernel), then the gate kernel forms the norm's dx from the sums on the fly.
 extern "C" long long pivp_gates_backward_ln_scratch_floats(int B, int n) {
     if (B <= 0 || n <= 0) return PIVP_ERR_BADARG;
     return (long long)B * ln_bwd_slices(n) * 2 + ln_bwd_param_part_floats(n);
@@ -672,8 +655,8 @@ extern "C" int pivp_gates_backward_ln(const float* gates, const float* c_old, co
     LnFuse lf;
     memset(&lf, 0, sizeof(lf));
     lf.dy = dy; lf.lddy = lddy; lf.gamma = gamma; lf.stat = stat; lf.h = h;
-    lf.partials = partials; lf.S = ln_bwd_slices(n); lf.param_part = part;      // the gate kernel accumulates dgamma / dbeta itself
-    int rc = ln_bwd_sums(dy, lddy, h, stat, gamma, partials, B, n, C, s);
+    lf.partials = partials; lf.S = ln_bwd_slices(n);
+    int rc = ln_backward(dy, lddy, nullptr, 0, h, stat, gamma, partials, nullptr, dgamma, dbeta, B, n, C, 0, s, part);
     if (rc != PIVP_OK) return rc;
     rc = lstm_gates_bwd(gates, c_old, c_new, nullptr, 0, dh_b, ldb, dc, dc_valid, dG, B * npix, C, s, B, &lf);
     if (rc != PIVP_OK) return rc;
@@ -738,7 +721,7 @@ extern "C" int pivp_deconv3x3s2_fp16x3(const float* x, int cin, int ldx, const f
     if (!x || !w || !out || !scratch || cin <= 0 || cout <= 0) return PIVP_ERR_BADARG;
     int rc = absmax_partials(w, 9L * cin * cout, scratch, (hipStream_t)stream);
     if (rc != PIVP_OK) return rc;
-    return run_deconv3x3s2(x, cin, ldx, w, bias, out, cout, ldo, relu, B, Hin, Win, (hipStream_t)stream, 0, nullptr, 0, nullptr, 3, nullptr, scratch);
+    return run_deconv3x3s2(x, cin, ldx, w, bias, out, cout, ldo, relu, B, Hin, Win, (hipStream_t)stream, 0, nullptr, 0, nullptr, 3, scratch);
 }
 extern "C" int pivp_conv_enc0(const float* img, const float* w, const float* bias, float* out, int B, int H, int W, void* stream) {
     return conv_enc0(img, w, bias, out, B, H, W, (hipStream_t)stream);

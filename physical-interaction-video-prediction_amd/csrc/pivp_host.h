@@ -4,10 +4,6 @@
 
 namespace pivp {
 
-// A data gradient whose first C output columns are the dy of a LayerNorm (IgemmDesc::lnb_part): the launch leaves the norm's backward sums in
-// `part` ([B][*np][2], room for `cap` parts per sample) and their count in *np (0: the kernel that served the call has no such epilogue)
-struct LnbSpec { const float* gamma; const float* x; const float* stat; float* part; int C, cap; int* np; };
-void lnb_apply(IgemmDesc& d, const LnbSpec* l);
 long long view_bytes(int B, int H, int W, int ld);
 bool fits31(long long v);
 // the x operand of a ConvLSTM launch as a RAW tensor whose LayerNorm is applied while it is staged (split precision modes' eight-wave kernels)
@@ -18,7 +14,7 @@ int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, co
                  float* gates_out = nullptr, float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr,
                  const unsigned short* w_bf16 = nullptr, int bf16_planes = 1, const LnIn* ln_in = nullptr);
 int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
-                  int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0, const LnbSpec* lnb = nullptr);
+                  int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0);
 // conv3x3s2 of LayerNorm(x_raw) with the norm applied while the input is staged (IgemmDesc::in_g); conv3x3s2_ln_ok tells whether the
 // geometry qualifies (output tiles of 32 anchors inside one sample)
 bool conv3x3s2_ln_ok(int cin, int cout, int B, int Hin, int Win);
@@ -26,7 +22,7 @@ int run_conv3x3s2_ln(const float* x_raw, int cin, const float* w, const float* b
                      int B, int Hin, int Win, hipStream_t s, const float* gamma, const float* beta, const float* partials, int nparts, float eps);
 int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                     int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0,
-                    float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr, int bf16 = 0, const LnbSpec* lnb = nullptr,
+                    float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr, int bf16 = 0,
                     const float* wscale_part = nullptr);   // bf16 == 3 (two fp16 pieces): absmax_partials(w)
 int run_deconv3x3s2_and_partials(const float* x, int cin, const float* w, const float* bias, float* out, int cout, int ldo, int relu,
                                  int B, int Hin, int Win, hipStream_t s, const float* wt, float* partials, int dbl);   // + motion_partials(x, wt, ...) in the same grid
@@ -40,8 +36,7 @@ int run_deconv3x3s2_ln(const float* h_raw, int c_ln, const float* x1, int c1, in
                        const float* wscale_part = nullptr);
 int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, int cout, int ldo, int ksize, int B, int H, int W,
                 hipStream_t s, int accum = 0, int wN = 0,    // wN: columns of the weight pack when only its first `cout` are wanted
-                int dest_zeroed = 0,                         // 1: the caller has cleared `out` (see conv_s1_splits_k)
-                const LnbSpec* lnb = nullptr);
+                int dest_zeroed = 0);                        // 1: the caller has cleared `out` (see conv_s1_splits_k)
 bool conv_s1_splits_k(int cin, int cout, int ldo, int ksize, int B, int H, int W, int wN);
 bool conv5x5_bf16_splits_k(int cin, int cout, int ldo, int B, int H, int W, int planes = 1);
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
@@ -56,7 +51,6 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
                           int B, int H, int W, hipStream_t s, int wt_ready = 0, unsigned short* wt_bf16 = nullptr, int bf16_planes = 1,
                           const SideFork* fork = nullptr, const LnFuse* ln = nullptr,    // ln: dh_a is formed from the LayerNorm behind the cell
                           int dx_only = 0,    // 1: d h_{t-1} is not needed (the sweep's last timestep): only the cx columns of d_in are computed
-                          const LnbSpec* dx_lnb = nullptr,    // the x columns of d_in are the dy of the norm in front of this cell
                           float* dg_absmax = nullptr);        // 66 floats: receives dG's partial maxima (absmax_partials), the scale of the fp16-piece data gradient
                                                               // (bf16_planes == -2 needs it) and of the fp16-piece weight gradient (WgradDesc::dy_absmax)
 int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb, float* out, int cout, int ldo, int accum,
@@ -65,8 +59,7 @@ int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb,
 int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w, float* dy, int cout, int ldy, const float* y, int ldyy,
                       float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, hipStream_t s,
                       int wt_ready = 0, const SideFork* fork = nullptr, float* part = nullptr, WgradDesc* desc_out = nullptr,
-                      const float* dy_add = nullptr, int ld_add = 0,    // dy_add: a second gradient into the same output, added in the ReLU-mask pass
-                      const LnbSpec* dx_lnb = nullptr);                 // the first dx_lnb->C columns of dx are the dy of a LayerNorm
+                      const float* dy_add = nullptr, int ld_add = 0);   // dy_add: a second gradient into the same output, added in the ReLU-mask pass
 // floats of WgradDesc::part a conv3x3s2 (mode 0) / deconv3x3s2 (mode 1) weight gradient of these sizes needs
 long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin, int Win);
 int run_layernorm(const float* x, const float* g, const float* b, float* out, float* partials, int B, int n, int C,
@@ -75,6 +68,7 @@ int run_layernorm(const float* x, const float* g, const float* b, float* out, fl
 int main_prio_set_backward(int on, hipStream_t s);
 int main_prio_set_backward_heads(int on, hipStream_t s);
 int main_prio_set_convlstm_bf16(int on, hipStream_t s);
+int main_prio_set_conv5x5_bf16(int on, hipStream_t s);
 int main_prio_set_deconv_tile(int on, hipStream_t s);
 int main_prio_set_igemm_f32(int on, hipStream_t s);
 int main_prio_set_igemm_small(int on, hipStream_t s);

@@ -48,23 +48,7 @@ struct IgemmDesc {
     // deconv_tile only (training plans): also WRITE the normalised x0 ([B][Hin*Win] pixels at stride in_out_ld; each pixel by the one block
     // that owns it) and the samples' (mean, rstd) ([B][2]) -- what ln_apply would have left behind for the backward sweep
     float* in_out; int in_out_ld; float* in_stat_out;
-    // LayerNorm BACKWARD sums of the OUTPUT, for data gradients (round 4).  The first lnb_C output columns are the gradient dy arriving at
-    // the OUTPUT of a LayerNormalizationConv2D (TM:203-208) whose input x = lnb_x ([B * Hout * Wout][lnb_C] dense: a cell's raw h), per-element
-    // gamma = lnb_gamma ([Hout * Wout][lnb_C]) and forward statistics lnb_stat ([B][2] mean, rstd) are given: every block adds up
-    // g = dy * gamma and g * xhat over its tile and writes the two sums to lnb_part[(b * np + slot) * 2]; the norm's backward
-    // (lstm_gates_bwd with LnFuse) reduces the np parts of a sample.  Linear in dy, so the K-split blocks of a data gradient each add
-    // the sums of their own partial tile.  The launcher that serves the call writes np to *lnb_np_out (host; the caller presets 0 =
-    // "not produced": tiles straddling samples, more than lnb_cap parts, a kernel without the epilogue -> ln_bwd_sums instead).
-    const float* lnb_gamma; const float* lnb_x; const float* lnb_stat; float* lnb_part; int lnb_C, lnb_cap, lnb_np; int* lnb_np_out;
 };
-
-// one output value v of sample-local pixel opix / column col (< lnb_C) into the running LayerNorm-backward sums (see IgemmDesc::lnb_part)
-#define PIVP_LNB_ACC(d, v, b, opix, col, npix_out, mean, rstd, s1, s2)                                            \
-    do {                                                                                                          \
-        const float gg_ = (v) * (d).lnb_gamma[(size_t)(opix) * (d).lnb_C + (col)];                                 \
-        const float xh_ = ((d).lnb_x[((size_t)(b) * (npix_out) + (opix)) * (d).lnb_C + (col)] - (mean)) * (rstd); \
-        s1 += gg_; s2 = fmaf(gg_, xh_, s2);                                                                       \
-    } while (0)
 
 // weight gradient of a conv / transposed conv (csrc/igemm_wgrad.hip)
 // Where the WEIGHT-gradient half of a conv backward runs.  A weight gradient feeds nothing but the optimizer, while the data gradient
@@ -117,10 +101,6 @@ int igemm_conv(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr)
 int igemm_conv_ksplit(const IgemmDesc& d);   // the K split igemm_conv will use for d (> 1: atomics into a destination the caller must zero)
 int igemm_validate(const IgemmDesc& d, bool lstm);   // argument checks shared by the igemm launchers (igemm_f32.hip)
 int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts = nullptr);
-bool igemm_conv_takes_small(const IgemmDesc& d);   // would igemm_conv hand d to igemm_small?
-// the conv d and the K-slice partial sums of the motion head's Linear (motion_partials) in ONE grid; PIVP_ERR_BADARG (nothing launched)
-// when d is not a conv igemm_small runs with 32-column blocks and no fused epilogue
-int igemm_small_with_partials(const IgemmDesc& d, hipStream_t stream, const float* hidden5, const float* wt, float* partials, int B, int K, int dbl);
 bool igemm_in_ln_ok(const IgemmDesc& d);   // can igemm_small apply d.in_g's LayerNorm while staging x0?
 // transposed 3x3 s2 conv, all four output parities per block (csrc/deconv_tile.hip); d validated by igemm_validate
 bool deconv_tile_ok(const IgemmDesc& d);
@@ -213,12 +193,9 @@ struct LnFuse {
     const float* dy; int lddy;       // gradient arriving at the norm's OUTPUT (may be a channel slice of a concat buffer)
     const float* gamma;              // [n] NHWC-flat
     const float* stat;               // [B][2] mean, rstd of the forward pass
-    const float* partials; int S;    // [B][S][2] sums of (g, g * xhat), g = dy * gamma, over S parts of a sample: ln_bwd_stats_kernel's slices
-                                     // (S = ln_bwd_slices(n)), or the tiles of the kernel that PRODUCED dy (IgemmDesc::lnb_part)
+    const float* partials; int S;    // [B][S][2] sums of (g, g * xhat), g = dy * gamma, over the S = ln_bwd_slices(n) slices of a sample
+                                     // (ln_bwd_sums_params_kernel, which also forms the norm's parameter gradients)
     const float* h;                  // the norm's input = the cell's h_t, [M][C]
-    float* param_part;               // optional [groups][2][n] (ln_bwd_param_part_floats): the gate kernel then also accumulates the norm's
-                                     // parameter gradients (dgamma += dy * xhat, dbeta += dy) -- lstm_gates_bwd_grp_kernel -- and no other
-                                     // kernel has to pass over dy and h for them
 };
 int lstm_gates_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_a, int lda,
                    const float* dh_b, int ldb, float* dc, int dc_valid, float* dG, int M, int C, hipStream_t s, int B = 1,
@@ -233,7 +210,6 @@ int ln_bwd_slices(int n);
 int ln_backward(const float* dy, int lddy, const float* y, int ldy, const float* x, const float* stat, const float* gamma,
                 float* partials, float* dx, float* dgamma, float* dbeta, int B, int n, int C, int relu, hipStream_t s,
                 float* param_part = nullptr);
-int ln_bwd_sums(const float* dy, int lddy, const float* x, const float* stat, const float* gamma, float* partials, int B, int n, int C, hipStream_t s);
 long long ln_bwd_param_part_floats(int n);
 int ln_bwd_params_reduce(const float* part, float* dgamma, float* dbeta, int B, int n, hipStream_t s);
 int adam_step(float* p, const float* g, float* m, float* v, long n, double lr_t, double beta1, double beta2, double eps,

@@ -110,8 +110,9 @@ struct pivp_plan {
     // the plan is created) keeps everything on the caller's stream.
     static constexpr int NSLOT = 14;      // 12: enc0's weight gradient, 13: the motion head's Linear (cdna_kernels / stp_input)
     bool use_side = true;
-    hipStream_t side = nullptr, side2 = nullptr;   // side2 (PIVP_SIDE_STREAMS=2 only): the odd slots' weight gradients run on a second side stream
-    hipStream_t side_of(int slot) const { return (side2 && (slot & 1)) ? side2 : side; }
+    hipStream_t side = nullptr;
+    hipStream_t side_of(int) const { return side; }      // (a second side stream for the odd slots, round 3: fp32 no change, bf16 12.25 -> 12.05 ms, but with two
+                                                         // processes on one GPU the step went from 65 ms to 78 SECONDS -- the hardware queues oversubscribe)
     hipEvent_t ev_ready[NSLOT] = {}, ev_done[NSLOT] = {};
     hipEvent_t ev_ring_done[7][2] = {};        // ConvLSTM slots: one `done` per dG ring (slots 0..6 of ev_done are unused)
     int wg_cap = 1;                            // dG ring slots per ring = min(T - 2, WG_BATCH_MAX), fixed when the workspace is laid out
@@ -128,11 +129,9 @@ struct pivp_plan {
             if (ev_done[i]) { (void)hipEventDestroy(ev_done[i]); ev_done[i] = nullptr; }
         }
         if (side) { (void)hipStreamDestroy(side); side = nullptr; }
-        if (side2) { (void)hipStreamDestroy(side2); side2 = nullptr; }
     }
     ~pivp_plan() {
         if (side) (void)hipStreamSynchronize(side);      // a sweep that failed half-way may have left weight-gradient kernels in flight
-        if (side2) (void)hipStreamSynchronize(side2);
         for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
         destroy_side();
     }
@@ -411,14 +410,6 @@ static int ensure_side(pivp_plan* plan) {
         plan->side = nullptr; plan->use_side = false; (void)hipGetLastError();      // single-stream sweeps from here on
         return PIVP_OK;
     }
-    {   // PIVP_SIDE_STREAMS=2: a second side stream for the odd slots (two weight-gradient kernels in flight).  fp32: no change (28.33 / 28.42
-        // vs 28.35 / 28.34 ms); bf16 mode: 12.25 -> 12.05 ms.  NOT the default: with two processes on one GPU (bench.py --share-gpu, gloo) the
-        // bf16 train step went from 65 ms to 78 SECONDS -- five streams per process oversubscribe the hardware queues -- and a data-parallel rank
-        // already adds the collective's stream to main + side.
-        const char* e = getenv("PIVP_SIDE_STREAMS");
-        const bool two = e && atoi(e) == 2;
-        if (two && hipStreamCreateWithPriority(&plan->side2, hipStreamNonBlocking, least) != hipSuccess) plan->side2 = nullptr;
-    }
     bool ok = true;
     for (int i = 0; i < pivp_plan::NSLOT && ok; ++i)
         ok = hipEventCreateWithFlags(&plan->ev_ready[i], hipEventDisableTiming) == hipSuccess &&
@@ -479,10 +470,9 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     RC(lstm(0, ws + S.cat7 + 32, 64, p->H2, p->W2));
     // Inference rollouts in the split precision modes: hidden1 / hidden3 feed only lstm2 / lstm4, whose eight-wave kernels apply the norm while
     // they stage their patch (the partials of their own output go to the second buffer: their blocks finish while others still read the input's).
-    static const int fold_lstm = [] { const char* e = getenv("PIVP_LN_FOLD_LSTM"); return e ? atoi(e) : 1; }();
     float* const lnpA = ws + p->o_lnpart, * const lnpB = ws + p->o_lnpart2;
     auto other = [&](float* q) { return q == lnpA ? lnpB : lnpA; };
-    const bool fold_l2 = !train && fold_lstm && p->lstm_bf16 && np > 0 && convlstm_ln_in_ok(p->lstm_planes, 32, 32, 32, B, p->H2, p->W2) &&
+    const bool fold_l2 = !train && p->lstm_bf16 && np > 0 && convlstm_ln_in_ok(p->lstm_planes, 32, 32, 32, B, p->H2, p->W2) &&
                          (long)B * (p->H2 / 8) * (p->W2 / 16) >= 128;
     if (fold_l2) {
         const LnIn li{P(p, p->i_ln_g[1]), P(p, p->i_ln_b[1]), lnp, np, eps};
@@ -495,8 +485,7 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     }
     // Inference rollouts: hidden2 / hidden4 feed only enc1 / enc2, so their norms are applied while those convs stage their input
     // (run_conv3x3s2_ln) instead of by a launch of their own; training keeps the materialised tensors (the backward sweep reads them).
-    static const int fold_ln = [] { const char* e = getenv("PIVP_LN_FOLD"); return e ? atoi(e) : 3; }();   // tuning: 0 = always a separate ln_apply, 1 = only enc1 / enc2 fold theirs (inference), 2 = + enc5 / enc6 (inference), 3 = + enc5 / enc6 in training plans
-    if (!train && fold_ln && np > 0 && conv3x3s2_ln_ok(32, 32, B, p->H2, p->W2)) {
+    if (!train && np > 0 && conv3x3s2_ln_ok(32, 32, B, p->H2, p->W2)) {
         RC(run_conv3x3s2_ln(ws + S.h[1], 32, P(p, p->i_enc_w[1]), P(p, p->i_enc_b[1]), ws + S.cat6 + 64, 32, 96, 1, B, p->H2, p->W2, s,
                             P(p, p->i_ln_g[2]), P(p, p->i_ln_b[2]), lnp, np, eps));
     } else {
@@ -505,7 +494,7 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     }
     // group 2 (TM:597)
     RC(lstm(2, ws + S.cat6 + 64, 96, p->H4, p->W4));
-    const bool fold_l4 = !train && fold_lstm && p->lstm_bf16 && np > 0 && convlstm_ln_in_ok(p->lstm_planes, 64, 64, 64, B, p->H4, p->W4) &&
+    const bool fold_l4 = !train && p->lstm_bf16 && np > 0 && convlstm_ln_in_ok(p->lstm_planes, 64, 64, 64, B, p->H4, p->W4) &&
                          (long)B * (p->H4 / 8) * (p->W4 / 16) >= 64;
     if (fold_l4) {
         const LnIn li{P(p, p->i_ln_g[3]), P(p, p->i_ln_b[3]), lnp, np, eps};
@@ -516,7 +505,7 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
         RC(ln(3, ws + S.h[2], ws + S.n3, n4, 64, 64, 0, np));
         RC(lstm(3, ws + S.n3, 64, p->H4, p->W4));
     }
-    if (!train && fold_ln && np > 0 && conv3x3s2_ln_ok(64, 64, B, p->H4, p->W4)) {
+    if (!train && np > 0 && conv3x3s2_ln_ok(64, 64, B, p->H4, p->W4)) {
         RC(run_conv3x3s2_ln(ws + S.h[3], 64, P(p, p->i_enc_w[2]), P(p, p->i_enc_b[2]), ws + S.e2, 64, 64, 1, B, p->H4, p->W4, s,
                             P(p, p->i_ln_g[4]), P(p, p->i_ln_b[4]), lnp, np, eps));
     } else {
@@ -533,8 +522,7 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     RC(ln(5, ws + S.h[4], ws + S.n5, n8, 128, 128, 0, np));
     // enc4 and the motion head's Linear both read hidden5 and nothing else: when the output side runs as frame_head (which finishes the
     // Linear's partial sums itself), the two share ONE grid here -- 1,024 + 256 blocks that each filled a fraction of the chip
-    static const int use_fh = [] { const char* e = getenv("PIVP_FRAME_HEAD"); return e ? atoi(e) : 1; }();
-    const bool fh = use_fh && (use_fh >= 2 ? frame_head_ok(c.model_type, B, H, W, c.num_masks) : frame_head_pays(c.model_type, B, H, W, c.num_masks));
+    const bool fh = frame_head_pays(c.model_type, B, H, W, c.num_masks);
     const bool fh_fin = fh && c.model_type != PIVP_MODEL_DNA && frame_head_finishes(p->K5);
     bool partials_done = false;
     if (fh_fin && !p->bf16_all && p->lstm_planes != 2) {
@@ -554,20 +542,19 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     // Only while the norm is a launch-bound 5-us kernel (<= 6 MB of hidden tensor: 64 x 64 frames at B = 32): the consumer's column blocks
     // each stage the patch and its gamma / beta again, which at config 5's 128 x 128 costs more than one bandwidth-bound ln_apply pass
     // (B = 32, T = 20: rollout 65.5 -> 65.9 ms with the fold, so it is not taken there).
-    const bool fold_dec = train ? fold_ln >= 3 : fold_ln >= 2;
-    auto fold_small = [&](long long floats) { return fold_ln >= 4 || floats * 4 <= 6LL << 20; };      // 4 = whatever the size
-    if (fold_dec && np > 0 && fold_small((long long)B * n4) && deconv3x3s2_ln_ok(64, 32, 96, B, p->H4, p->W4)) {
+    auto fold_small = [&](long long floats) { return floats * 4 <= 6LL << 20; };
+    if (np > 0 && fold_small((long long)B * n4) && deconv3x3s2_ln_ok(64, 32, 96, B, p->H4, p->W4)) {
         RC(run_deconv3x3s2_ln(ws + S.h[5], 64, ws + S.cat6 + 64, 32, 96, P(p, p->i_enc_w[5]), P(p, p->i_enc_b[5]), ws + S.e5, 96, 96, 1, B, p->H4, p->W4,
                               s, P(p, p->i_ln_g[6]), P(p, p->i_ln_b[6]), lnp, np, eps, nullptr, 0, nullptr, dprec,
                               train ? ws + S.cat6 : nullptr, 96, train ? ws + S.lnstat + (size_t)6 * B * 2 : nullptr, ws + p->o_wabs[0]));
     } else {
         RC(ln(6, ws + S.h[5], ws + S.cat6, n4, 64, 96, 0, np));
         RC(run_deconv3x3s2(ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), P(p, p->i_enc_b[5]), ws + S.e5, 96, 96, 1, B, p->H4, p->W4, s, 0,
-                           nullptr, 0, nullptr, dprec, nullptr, ws + p->o_wabs[0]));
+                           nullptr, 0, nullptr, dprec, ws + p->o_wabs[0]));
     }
     // group 6 (TM:601): lstm7 -> hidden7 -> concat(., enc0) -> enc6 -> norm_enc6 -> relu
     RC(lstm(6, ws + S.e5, 96, p->H2, p->W2));
-    if (fold_dec && np > 0 && fold_small((long long)B * n2) && deconv3x3s2_ln_ok(32, 32, 64, B, p->H2, p->W2)) {
+    if (np > 0 && fold_small((long long)B * n2) && deconv3x3s2_ln_ok(32, 32, 64, B, p->H2, p->W2)) {
         // enc6's blocks write the partials of norm_enc6 while others still read hidden7's: the second partial buffer
         float* lnp2 = other(lnp);
         const int np_in = np;
@@ -578,11 +565,11 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     } else {
         RC(ln(7, ws + S.h[6], ws + S.cat7, n2, 32, 64, 0, np));
         RC(run_deconv3x3s2(ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), P(p, p->i_enc_b[6]), ws + S.e6raw, 64, 64, 0, B, p->H2, p->W2, s, 0,
-                           lnp, ln_cap, &np, dprec, nullptr, ws + p->o_wabs[1]));
+                           lnp, ln_cap, &np, dprec, ws + p->o_wabs[1]));
     }
     // heads (TM:711-728).  One launch (csrc/frame_head.hip) for norm_enc6 + relu + the 1x1 heads + the motion head's finisher + flat softmax +
     // transform + compositing, behind the Linear's partial sums: bit-identical to the four launches below it, which remain for geometries
-    // it does not take or where it is slower (frames wider than 64: frame_head_pays; PIVP_FRAME_HEAD=0 forces them, 2 forces the fused launch).  The softmaxed masks are kept for the rollout's last step only (pivp_get_tap).
+    // it does not take or where it is slower (frames wider than 64: frame_head_pays).  The softmaxed masks are kept for the rollout's last step only (pivp_get_tap).
     if (fh && np > 0) {
         const bool fin = c.model_type == PIVP_MODEL_DNA || frame_head_finishes(p->K5);
         FrameHeadArgs a;
@@ -723,7 +710,7 @@ static int apply_main_prio(pivp_plan* p, hipStream_t s) {
     const int want = p->main_prio < 0 ? (p->grad_cb ? 0 : 1) : (p->main_prio ? 1 : 0);
     const int dev = pivp_current_device();
     if (current[dev] == want) return PIVP_OK;
-    RC(main_prio_set_backward(want, s)); RC(main_prio_set_backward_heads(want, s)); RC(main_prio_set_convlstm_bf16(want, s));
+    RC(main_prio_set_backward(want, s)); RC(main_prio_set_backward_heads(want, s)); RC(main_prio_set_convlstm_bf16(want, s)); RC(main_prio_set_conv5x5_bf16(want, s));
     RC(main_prio_set_deconv_tile(want, s)); RC(main_prio_set_igemm_f32(want, s)); RC(main_prio_set_igemm_small(want, s));
     current[dev] = want;
     return PIVP_OK;
@@ -780,43 +767,21 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         return hipStreamWaitEvent(s, p->ev_done[slot], 0) == hipSuccess ? PIVP_OK : PIVP_ERR_LAUNCH;   // never recorded: returns at once
     };
     const long long slab_bytes = p->nslabs > 1 ? ((long long)p->slabs[1].cat7 - (long long)p->slabs[0].cat7) * 4 : 0;
-    // LayerNorm behind ConvLSTM i (hidden<i+1>).  Its dx AND its parameter gradients are formed inside the cell's gate backward
-    // (lstm_gates_bwd_grp_kernel); the two sums per sample that needs come from the epilogue of the kernel that produced dy (pnp[i] parts:
-    // IgemmDesc::lnb_part), or from a sums-only launch when that kernel has no such epilogue (the bf16 mode's 5x5 data gradients; steps no
-    // gradient reaches).  Round 3 ran ln_bwd_sums_params_kernel here, 63 launches per train step on the main stream.
-    // PIVP_LN_BWD: 2 as described, 1 = always the sums-only launch, 0 (DEFAULT) = round 3's pair of kernels.  Measured (one box, A/B/A/B,
-    // profiles/r04/NOTES.md): fp32 train step 28.21 / 28.26 (0), 28.28 / 28.38 (1), 28.48 / 28.58 ms (2); bf16 11.85 / 11.79, 11.85 / 11.78,
-    // 11.89 / 11.93.  63 launches fewer per step and the step got SLOWER: the two loads per output element that the epilogues add to the
-    // data gradients (K-split ones pay them once per split) cost more than the 6-us launches they replace, and those launches were not
-    // what bounds the sweep (the matrix-pipe work of both streams is).  All gradient fixtures pass in all three modes.
-    static const int ln_bwd_mode = [] { const char* e = getenv("PIVP_LN_BWD"); return e ? atoi(e) : 0; }();
+    // LayerNorm behind ConvLSTM i (hidden<i+1>): one launch leaves the two sums per sample and the norm's partial parameter planes
+    // (ln_bwd_sums_params_kernel); the norm's dx is formed inside the cell's gate backward (lstm_gates_bwd_kernel with LnFuse) and never written.
+    // (Round 4 also built the sums from the data gradients' epilogues and the parameter gradients inside the gate kernel -- 63 launches fewer per
+    // step, and the step got SLOWER: fp32 28.21 -> 28.48 ms, bf16 11.85 -> 11.89, profiles/r04/NOTES.md 2.  Removed in round 5; in the history.)
     LnFuse lf[7];
-    int pnp[7] = {0, 0, 0, 0, 0, 0, 0};
-    const int lnb_cap = ln_bwd_slices((int)(64 * HW));       // parts per sample g.lnpart holds
-    LnbSpec lsp[7];
-    auto lnb_spec = [&](int i, int C) -> const LnbSpec* {  // for the launch that produces the dy of the norm behind cell i
-        if (ln_bwd_mode < 2) return nullptr;
-        const int j = i + 1;
-        lsp[i] = LnbSpec{P(p, p->i_ln_g[j]), ws + S.h[i], ws + S.lnstat + (size_t)j * B * 2, lnpart, C, lnb_cap, &pnp[i]};
-        return &lsp[i];
-    };
     auto lnb_cell = [&](int i, const float* dy, int lddy, int n, int C) -> int {
         const int j = i + 1;
         memset(&lf[i], 0, sizeof(lf[i]));
         lf[i].dy = dy; lf[i].lddy = lddy; lf[i].gamma = P(p, p->i_ln_g[j]); lf[i].stat = ws + S.lnstat + (size_t)j * B * 2;
         lf[i].partials = lnpart; lf[i].S = ln_bwd_slices(n); lf[i].h = ws + S.h[i];
         p->ln_touched[j] = true;
-        if (ln_bwd_mode == 0) {
-            RC(ln_backward(dy, lddy, nullptr, 0, ws + S.h[i], lf[i].stat, lf[i].gamma, lnpart, nullptr,
-                           G(p, p->i_ln_g[j]), G(p, p->i_ln_b[j]), B, n, C, 0, s, ws + g.ln_ppart[j]));
-            return PIVP_OK;
-        }
-        lf[i].param_part = ws + g.ln_ppart[j];
-        if (pnp[i] > 0) lf[i].S = pnp[i];          // the producer's epilogue left the sums
-        else RC(ln_bwd_sums(dy, lddy, ws + S.h[i], lf[i].stat, lf[i].gamma, lnpart, B, n, C, s));
-        return PIVP_OK;
+        return ln_backward(dy, lddy, nullptr, 0, ws + S.h[i], lf[i].stat, lf[i].gamma, lnpart, nullptr,
+                           G(p, p->i_ln_g[j]), G(p, p->i_ln_b[j]), B, n, C, 0, s, ws + g.ln_ppart[j]);
     };
-    auto lstmb = [&](int i, const float* x, int ldx, int hh, int wwid, const LnbSpec* dx_lnb = nullptr) -> int {
+    auto lstmb = [&](int i, const float* x, int ldx, int hh, int wwid) -> int {
         const LstmSpec& L = kLstm[i];
         const int cin = L.cx + L.C, N = 4 * L.C;
         const size_t dG1 = (size_t)B * hh * wwid * N;                      // floats of one timestep's dG
@@ -833,7 +798,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                                  ring + (size_t)wg_slot * dG1, ws + g.wt_lstm[i], ws + g.din[i][par], nullptr, nullptr, B, hh, wwid,
                                  s, 1, (p->lstm_bf16 && (p->bwd_planes != 3 || wwid % 16 == 0) && (p->bwd_planes != -2 || wwid % 16 == 0 || B % 2 == 0)) ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->bwd_planes,
                                  wg_flush ? fork_of(i, f) : nullptr, &lf[i],    // dW = null: only the fork's `ready` (behind the gate math) is used
-                                 t == 0 ? 1 : 0, dx_lnb,
+                                 t == 0 ? 1 : 0,
                                  (p->bwd_planes == -2 || p->x3_wgrad) ? ws + g.dg_absmax + ((size_t)(i * 2 + wg_ring) * p->wg_cap + wg_slot) * 72 : nullptr));    // t = 0: nobody reads d h_{-1}
         if (t == 0) RC(ln_finish(i + 1));       // the sweep's last timestep: the norm's partial parameter planes (written by the gate kernel) become its gradient
         if (!wg_flush) return PIVP_OK;
@@ -886,8 +851,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         RC(join(7));       // d e6raw
         RC(lnb(8, ws + g.e6, 64, ws + S.e6, 64, ws + S.e6raw, ws + g.e6raw, 64 * HW, 64, 1));
         RC(run_conv_backward(1, ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), ws + g.e6raw, 64, 64, nullptr, 0, ws + g.wt_enc[6], ws + g.cat7, 64, 0,
-                             G(p, p->i_enc_w[6]), G(p, p->i_enc_b[6]), B, p->H2, p->W2, s, 1, fork_of(7, fe), ws + g.wg_part[0], &p->enc_desc[0],
-                             nullptr, 0, lnb_spec(6, 32)));
+                             G(p, p->i_enc_w[6]), G(p, p->i_enc_b[6]), B, p->H2, p->W2, s, 1, fork_of(7, fe), ws + g.wg_part[0], &p->enc_desc[0]));
     p->enc_desc_valid[0] = true;
     } else {
         // no gradient reaches this step's frame: only the recurrent paths are live
@@ -928,8 +892,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(join(11));          // enc1's dY lives in d cat6, which enc5's data gradient rewrites
     // group 5 (TM:600): d e5 = x-part of lstm7's d_in (ReLU fused in enc5) <- enc5 deconv <- [hidden6 | enc1]
     RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ws + S.e5, 96, ws + g.wt_enc[5], ws + g.cat6, 96, 0,
-                         G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1, fork_of(8, fe), ws + g.wg_part[1], &p->enc_desc[1],
-                         nullptr, 0, lnb_spec(5, 64)));
+                         G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1, fork_of(8, fe), ws + g.wg_part[1], &p->enc_desc[1]));
     p->enc_desc_valid[1] = true;
     RC(lnb_cell(5, ws + g.cat6, 96, n4, 64));
     RC(join(9));           // enc4's dY = the x part of lstm6's d_in of this parity
@@ -937,8 +900,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(done(2));
     // group 4 (TM:599): d e4 = x-part of lstm6's d_in <- enc4 deconv <- hidden5 (also read by the CDNA kernel generator)
     RC(run_conv_backward(1, ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), ws + g.din[5][par], 128, 192, ws + S.e4, 128, ws + g.wt_enc[4], ws + g.n5, 128, 1,
-                         G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s, 1, fork_of(9, fe), ws + g.wg_part[2], &p->enc_desc[2],
-                         nullptr, 0, lnb_spec(4, 128)));
+                         G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s, 1, fork_of(9, fe), ws + g.wg_part[2], &p->enc_desc[2]));
     p->enc_desc_valid[2] = true;
     RC(lnb_cell(4, ws + g.n5, 128, n8, 128));
     RC(lstmb(4, ws + S.e3, 64, p->H8, p->W8));
@@ -951,21 +913,20 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                       B, p->H8 * p->W8, c.use_state, s, 1));      // d e2 comes out masked by enc2's ReLU
     // group 2 (TM:597): enc2 conv (ReLU) <- hidden4 <- lstm4 <- hidden3 <- lstm3 <- enc1
     RC(run_conv_backward(0, ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), ws + g.e2, 64, 64, nullptr, 0, ws + g.wt_enc[2], ws + g.n4, 64, 0,
-                         G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s, 1, fork_of(10, fe), ws + g.wg_part[3], &p->enc_desc[3],
-                         nullptr, 0, lnb_spec(3, 64)));
+                         G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s, 1, fork_of(10, fe), ws + g.wg_part[3], &p->enc_desc[3]));
     p->enc_desc_valid[3] = true;
     RC(lnb_cell(3, ws + g.n4, 64, n4, 64));
-    RC(lstmb(3, ws + S.n3, 64, p->H4, p->W4, lnb_spec(2, 64)));      // its data gradient's x columns = the dy of hidden3
+    RC(lstmb(3, ws + S.n3, 64, p->H4, p->W4));      // its data gradient's x columns = the dy of hidden3
     RC(lnb_cell(2, ws + g.din[3][par], 128, n4, 64));
     RC(lstmb(2, ws + S.cat6 + 64, 96, p->H4, p->W4));
     RC(done(4));
     // group 1 (TM:596): enc1 conv (ReLU) <- hidden2 <- lstm2 <- hidden1 <- lstm1 <- enc0
     RC(run_conv_backward(0, ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), ws + g.cat6 + 64, 32, 96, ws + S.cat6 + 64, 96, ws + g.wt_enc[1], ws + g.n2, 32, 0,
                          G(p, p->i_enc_w[1]), G(p, p->i_enc_b[1]), B, p->H2, p->W2, s, 1, fork_of(11, fe), ws + g.wg_part[4], &p->enc_desc[4],
-                         ws + g.din[2][par], 96, lnb_spec(1, 32)));      // d enc1 = enc5's concat part (in d cat6) + lstm3's x gradient, summed in the ReLU-mask pass
+                         ws + g.din[2][par], 96));      // d enc1 = enc5's concat part (in d cat6) + lstm3's x gradient, summed in the ReLU-mask pass
     p->enc_desc_valid[4] = true;
     RC(lnb_cell(1, ws + g.n2, 32, n2, 32));
-    RC(lstmb(1, ws + S.n1, 32, p->H2, p->W2, lnb_spec(0, 32)));      // ... of hidden1
+    RC(lstmb(1, ws + S.n1, 32, p->H2, p->W2));      // ... of hidden1
     RC(lnb_cell(0, ws + g.din[1][par], 64, n2, 32));
     RC(lstmb(0, ws + S.cat7 + 32, 64, p->H2, p->W2));
     RC(add_strided(ws + g.cat7 + 32, 64, ws + g.din[0][par], 64, 32, px2, s));          // d enc0: from enc6's concat + from lstm1
@@ -997,7 +958,6 @@ extern "C" int pivp_rollout_backward(pivp_plan_t* plan, const float* images, con
         }
         if (!joined) {
             (void)hipStreamSynchronize(plan->side);
-            if (plan->side2) (void)hipStreamSynchronize(plan->side2);
             (void)hipStreamSynchronize(s);
             return rc != PIVP_OK ? rc : PIVP_ERR_LAUNCH;
         }

@@ -1,15 +1,12 @@
-// Skinny Linear on flatten(hidden5) (the motion head's generator, TM:321-323 / TM:457-458): the K-slice partial-sum body, shared by
-// skinny_linear_partials_kernel (heads.hip) and the launch that runs it beside enc4 (igemm_small.hip).
+// Skinny Linear on flatten(hidden5) (the motion head's generator, TM:321-323 / TM:457-458): the K-slice partial-sum body of
+// skinny_linear_partials_kernel (heads.hip).
 #pragma once
 #include "pivp_kernels.h"
 
 namespace pivp {
 
 constexpr int LIN_KS = 64;    // K per slice
-#ifndef PIVP_LIN_BG
-#define PIVP_LIN_BG 16
-#endif
-constexpr int LIN_BG = PIVP_LIN_BG;    // batch rows per block
+constexpr int LIN_BG = 16;    // batch rows per block
 
 // grid (K/64 slices, B/16 groups): 256 blocks at B = 32, K = 8192, so the 8 MB weight matrix streams across the
 // whole chip (twice: once per batch group).  A block's 64 weight loads per thread are all issued before the first FMA.  ACC = float for the CDNA kernels, double for the STP regressor (its output steers a bilinear warp

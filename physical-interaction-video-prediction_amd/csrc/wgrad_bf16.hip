@@ -192,11 +192,7 @@ __global__ __launch_bounds__(256, 2) void wgrad5x5_bf16_kernel(const WgradDesc d
         float* base = d.dw + ((size_t)((ky * 5 + kx) * (d.wcin >> 5) + cb) * N + nb * 128 + wave * 32) * 32 + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-#ifdef PIVP_WGB_NOATOMIC   // timing-only ablation (results wrong): what do the epilogue's atomics cost?
-            if (acc[kx][r] == 12345.678f) base[((r & 3) + 8 * (r >> 2) + 4 * half) * 32] = 1.f;
-#else
             atomicAdd(base + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32, acc[kx][r]);
-#endif
         }
     }
     if (do_bias) {   // thread (tid / 32, n4 = tid % 32) holds the sums of columns 4 n4 .. 4 n4 + 3 over its pixels: lanes l and l + 32 pair up
@@ -485,11 +481,7 @@ __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d,
                 const float inv = 1.0f / gscale;                 // (1 without pieces; a power of two with them: exact)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-#ifdef PIVP_WGB_NOATOMIC   // timing-only ablation (results wrong): what do the epilogue's atomics cost?
-                    if (acc[i][r] == 12345.678f) base[((r & 3) + 8 * (r >> 2) + 4 * half) * 32] = inv;
-#else
-                    atomicAdd(base + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32, acc[i][r] * inv);
-#endif
+                    atomicAdd(base + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32, acc[i][r] * inv);      // (a build without them: 0.5 / 0.2 ms of a train step, profiles/r04)
                 }
             }
         }
@@ -524,11 +516,10 @@ static int launch_wgrad25(const WgradDesc& d, hipStream_t s) {
     const int n_tiles = (d.B / ti_n) * (d.Hx / 8) * (d.Wx / tw) * (d.tcount > 1 ? d.tcount : 1);
     const int gx = (d.cin / 32) * (d.N / 64);
     // Pixel splits: one block per CU (8 waves, ~70 KB of LDS), at least 2 tiles per block; every split ends with 25 x 32 x 64 atomic adds
-    // (205 KB: the batch of timesteps is what amortises them).  PIVP_WGB_SLOTS: block target (tuning).
-    static const int slots = [] { const char* e = getenv("PIVP_WGB_SLOTS"); return e ? atoi(e) : 0; }();
+    // (205 KB: the batch of timesteps is what amortises them).
     // (fp16 pieces: its 8-wave blocks hold a CU's whole register file, and the sweep's small kernels need CUs without one: half the CUs)
     // bf16: three quarters (train step 11.86 -> 11.66 ms, profiles/r04/bf16_train_wgrad_batch_slots.txt)
-    const int target = slots > 0 ? slots : (PCS >= 2 ? pivp_cu_count() / 2 : pivp_cu_count() * 3 / 4);
+    const int target = PCS >= 2 ? pivp_cu_count() / 2 : pivp_cu_count() * 3 / 4;
     int ns = (target + gx - 1) / gx;
     if (ns > n_tiles / 2) ns = n_tiles / 2;
     if (ns < 1) ns = 1;
@@ -544,26 +535,13 @@ int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s) {
     PIVP_CHECK_ARG(d.x0 && d.dy && d.dw && wgrad5x5_bf16_ok(d) && (d.c1 == 0 || d.x1) && d.wcin >= d.cin && d.wcin % 32 == 0);
     // A batch of timesteps goes to the 25-tap kernel (per timestep at B = 32, all seven layers: 168 us at 8 per launch, 225 us at 4); ONE
     // timestep to the kernel-row kernel below, whose 5 x cin/32 blocks per tile are then the better use of the chip (389 us against 580:
-    // the sweep's t = 0 launches, sequences too short to batch).  PIVP_WGB_KERNEL = 5 / 25 forces one of them (tuning).
-    static const int kernel = [] { const char* e = getenv("PIVP_WGB_KERNEL"); return e ? atoi(e) : 0; }();
+    // the sweep's t = 0 launches, sequences too short to batch).
     if (d.dy_absmax) {       // two fp16 pieces per operand: the 25-tap kernel, whatever the batch
         PIVP_CHECK_ARG(d.dy_absmax_stride >= 66 || d.tcount <= 1);
         return launch_wgrad25<2>(d, s);
     }
     if (d.pieces == 3) return launch_wgrad25<3>(d, s);      // three bf16 pieces per operand, likewise
-    if (kernel == 25 || (kernel != 5 && d.tcount > 1)) return launch_wgrad25<1>(d, s);
-    if (d.tcount > 1) {      // PIVP_WGB_KERNEL=5 with a batched descriptor: the kernel-row kernel takes one timestep, so one launch per timestep
-        for (int j = 0; j < d.tcount; ++j) {
-            WgradDesc dj = d;
-            dj.tcount = 1;
-            dj.x0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d.x0) + j * d.ts_x0);
-            if (d.x1) dj.x1 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d.x1) + j * d.ts_x1);
-            dj.dy = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d.dy) + j * d.ts_dy);
-            const int rc = wgrad5x5_bf16(dj, s);
-            if (rc != PIVP_OK) return rc;
-        }
-        return PIVP_OK;
-    }
+    if (d.tcount > 1) return launch_wgrad25<1>(d, s);
     constexpr int lds_bytes = G_BYTES + X_BYTES;
     static PerDeviceOnce once16, once8;
     if (pivp_ensure_dyn_lds(once16, reinterpret_cast<const void*>(&wgrad5x5_bf16_kernel<16>), lds_bytes) != PIVP_OK ||
@@ -577,8 +555,7 @@ int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s) {
     // other splits of its tile (timing-only build without them: 72 -> 43 us on lstm1 at 52 splits) -- and it runs on the side stream, where
     // a grid that fills every CU's registers starves the main stream's small kernels (a 5 us add_strided took 34 us beside it).
     // Train step in the bf16 mode against the block target: 512: 13.93 ms, 256: 13.00, 192: 12.73, 128: 12.54, 96: 13.08, 64: 14.57.
-    static const int slots = [] { const char* e = getenv("PIVP_WGB_SLOTS"); return e ? atoi(e) : 0; }();   // tuning
-    const int target = slots > 0 ? slots : pivp_cu_count() / 2;
+    const int target = pivp_cu_count() / 2;
     int ns = (target + gx - 1) / gx;
     if (ns > n_tiles / 2) ns = n_tiles / 2;
     if (ns < 1) ns = 1;

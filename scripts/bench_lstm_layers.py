@@ -19,8 +19,6 @@ X3 = os.environ.get('PIVP_BENCH_BF16', '0') == '3'
 X6 = os.environ.get('PIVP_BENCH_BF16', '0') == '6'
 H3 = os.environ.get('PIVP_BENCH_BF16', '0') == 'h3'      # two fp16 pieces, three MFMAs per product
 DATA = os.environ.get('PIVP_BENCH_DATA', 'random')   # random | zero | const: does the MFMA rate depend on the operand values?
-if os.environ.get('PIVP_BENCH_LIB'):      # a variant build of the library (scripts/r04/build_x6_variants.sh): timing experiments only
-    _lib.LIB_PATH = os.path.abspath(os.environ['PIVP_BENCH_LIB'])
 lib = _lib.load()
 dev = 'cuda:0'
 st = torch.cuda.current_stream().cuda_stream

@@ -1,6 +1,5 @@
 """ConvLSTM weight gradient in the bf16 mode, per layer at B = 32 (config 3's per-GPU batch): microseconds and TFLOP/s per launch for one
-timestep and for a batch of timesteps per launch (pivp_wgrad5x5_bf16_batch).  PIVP_WGB_KERNEL=5 selects the round-2 kernel (one kernel row
-per block, one timestep per launch) for comparison:   python3 scripts/bench_wgrad_bf16.py [B] [tcount ...]"""
+timestep and for a batch of timesteps per launch (pivp_wgrad5x5_bf16_batch):   python3 scripts/bench_wgrad_bf16.py [B] [tcount ...]"""
 import sys
 
 import numpy as np

@@ -22,7 +22,7 @@ for name, cx, C, H in [('lstm1', 32, 32, 32), ('lstm5', 64, 128, 8) if not X6 el
     def launch():
         if X6:
             assert lib.pivp_convlstm_bf16x6(x.data_ptr(), cx, cx, h.data_ptr(), C, wb.data_ptr(), b.data_ptr(), c.data_ptr(), co.data_ptr(),
-                                            ho.data_ptr(), None, None, 0, None, B, H, H, int(os.environ.get('PIVP_X6_NCH', '0')), st) == 0
+                                            ho.data_ptr(), None, None, 0, None, B, H, H, 0, st) == 0
             return
         assert lib.pivp_convlstm_bf16(x.data_ptr(), cx, cx, h.data_ptr(), C, wb.data_ptr(), b.data_ptr(), c.data_ptr(), co.data_ptr(),
                                       ho.data_ptr(), None, None, 0, None, B, H, H, 0, st) == 0
