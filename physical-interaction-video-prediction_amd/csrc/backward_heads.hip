@@ -11,17 +11,25 @@ namespace pivp {
 // and 1e-4 times the same for the predicted states.  out = scale * (a - b)  (+ out when accum).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void scaled_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
-                                                          long n, float scale, int accum) {
+                                                          long n, float scale, int accum, int vec) {
     PIVP_SET_MAIN_PRIO();
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long n4 = vec ? n >> 2 : 0;       // float4 body when the three pointers are 16-byte aligned, scalar tail
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 va = reinterpret_cast<const f32x4*>(a)[i], vb = reinterpret_cast<const f32x4*>(b)[i];
+        f32x4 v = (va - vb) * scale;
+        if (accum) v += reinterpret_cast<const f32x4*>(out)[i];
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float v = scale * (a[i] - b[i]);
         out[i] = accum ? out[i] + v : v;
     }
 }
 int scaled_diff(const float* a, const float* b, float* out, long n, float scale, int accum, hipStream_t s) {
     PIVP_CHECK_ARG(a && b && out && n > 0);
-    const long blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(scaled_diff_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, a, b, out, n, scale, accum);
+    const int vec = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0;
+    const long blocks = ((vec ? n / 4 + 3 : n) + 255) / 256;
+    hipLaunchKernelGGL(scaled_diff_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, a, b, out, n, scale, accum, vec);
     return PIVP_LAUNCH_STATUS();
 }
 

@@ -34,6 +34,7 @@ int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t strea
     const bool wide = Np % 128 == 0;
     const int nb = Np / (wide ? 128 : 64);
     const int ks = conv5x5_bf16_ksplit(d, planes);
+    PIVP_CHECK_ARG(!dd.ep_mode || (ks == 1 && dd.ep_src && dd.ep_ld >= dd.ep_cols && (dd.ep_mode == 1 || dd.ep_mode == 2)));      // the caller asks conv5x5_bf16_ksplit first
     if (planes == 3)     // three pieces (wb packed with planes = 3, plain = 1): 64-column blocks, weights from L2 into the operand registers, eight
         return launch_x6g_plain<3>(dd, wb, stream, Np / 64, ks, d.N);      // waves (the k-step-ring form of it measured 118 us per launch in the sweep against 100)
     if (planes == -2 && d.Win % 16)     // ... on an 8-wide map (an even batch): the ring kernel's two-image tiles, wb packed with plain = 2

@@ -1,6 +1,8 @@
 // The bf16 / split-precision ConvLSTM cell (BASELINE.json config 3 and the fp32-grade split modes): weight packs, the tensors' power-of-two scales,
 // and the dispatcher over the two kernel families -- convlstm_bf16_kernel (csrc/convlstm_ring.h) and convlstm_x6g_kernel (csrc/convlstm_l2direct.h).
 // Their plain-convolution forms (the data gradient) are instantiated in conv5x5_bf16.hip.  Reference op: BasicConvLSTMCell.__call__, TM:234-276.
+#include <string.h>
+
 #include "convlstm_ring.h"
 #include "convlstm_l2direct.h"
 
@@ -87,6 +89,66 @@ __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned shor
     if (pl >= 1) { v -= (float)h; h = (__bf16)v; }
     if (pl == 2) { v -= (float)h; h = (__bf16)v; }
     wb[i] = __builtin_bit_cast(unsigned short, h);
+}
+
+// ---- several weight preparations in one launch (WeightPrepJob, pivp_kernels.h) ----------------------------------------------------------------
+struct WeightPrepTable { int n; int blk0[WEIGHT_PREP_MAX + 1]; WeightPrepJob j[WEIGHT_PREP_MAX]; };
+__global__ __launch_bounds__(256) void weight_prep_kernel(const WeightPrepTable t) {
+    __shared__ float tile[32][33];
+    int k = 0;
+    while (k + 1 < t.n && (int)blockIdx.x >= t.blk0[k + 1]) ++k;        // block-uniform: which job this block belongs to
+    const WeightPrepJob& job = t.j[k];
+    const int blk = (int)blockIdx.x - t.blk0[k];
+    if (job.kind == 0) {      // repack_transpose_kernel's tile: W packed [tap][cin/32][N][32] -> Wt packed [tap'][N/32][cin][32]
+        const int taps = job.p0, cin = job.p1, N = job.p2, flip = job.p3;
+        const int nn = N >> 5, nc_ = cin >> 5;
+        const int nc = blk % nn, cc = (blk / nn) % nc_, tap = blk / (nn * nc_);
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        const float* src = job.src + (((size_t)tap * nc_ + cc) * N + nc * 32) * 32;
+        for (int r = ty; r < 32; r += 8) tile[r][tx] = src[r * 32 + tx];
+        __syncthreads();
+        const int tap2 = flip ? taps - 1 - tap : tap;
+        float* dst = reinterpret_cast<float*>(job.dst) + (((size_t)tap2 * nn + nc) * cin + cc * 32) * 32;
+        for (int r = ty; r < 32; r += 8) dst[r * 32 + tx] = tile[tx][r];
+        return;
+    }
+    // one bf16 plane [ceil(wcin/64)][25][Np][64] of pack_lstm_bf16_kernel
+    const int wcin = job.p0, N = job.p1, Np = job.p2;
+    const long total = (long)((wcin + 63) / 64) * 25 * Np * 64;
+    const long i = (long)blk * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c64 = (int)(i & 63);
+    long r = i >> 6;
+    const int n = (int)(r % Np); r /= Np;
+    const int tap = (int)(r % 25);
+    const int ch = (int)(r / 25) * 64 + c64;
+    float v = 0.f;
+    if (ch < wcin && n < N) v = job.src[(((long)tap * (wcin >> 5) + (ch >> 5)) * N + n) * 32 + (ch & 31)];
+    reinterpret_cast<unsigned short*>(job.dst)[i] = __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+int weight_prep_batch(const WeightPrepJob* jobs, int n, hipStream_t s) {
+    PIVP_CHECK_ARG(jobs && n > 0 && n <= WEIGHT_PREP_MAX);
+    WeightPrepTable t;
+    memset(&t, 0, sizeof(t));
+    t.n = n;
+    long blocks = 0;
+    for (int k = 0; k < n; ++k) {
+        const WeightPrepJob& j = jobs[k];
+        PIVP_CHECK_ARG(j.src && j.dst && (j.kind == 0 || j.kind == 1));
+        t.blk0[k] = (int)blocks;
+        if (j.kind == 0) {
+            PIVP_CHECK_ARG(j.p0 > 0 && j.p1 > 0 && j.p1 % 32 == 0 && j.p2 > 0 && j.p2 % 32 == 0);
+            blocks += (long)j.p0 * (j.p1 / 32) * (j.p2 / 32);
+        } else {
+            PIVP_CHECK_ARG(j.p0 > 0 && j.p0 % 32 == 0 && j.p1 > 0 && j.p2 >= j.p1);
+            blocks += ((long)lstm_bf16_weight_elems(j.p0, j.p2) + 255) / 256;
+        }
+        t.j[k] = j;
+    }
+    t.blk0[n] = (int)blocks;
+    PIVP_CHECK_ARG(blocks > 0 && blocks < (1L << 31));
+    hipLaunchKernelGGL(weight_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t);
+    return PIVP_LAUNCH_STATUS();
 }
 
 // PL = 3 pack, FRAGMENT-MAJOR: [group][tap][k-step][plane][8-channel group c8][lane][8 bf16] -- one B fragment of

@@ -339,9 +339,14 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
                 const int col = (nblk * NWN + wn) * 32 + l31;
                 if (col < ncols) {                      // the pack's rows past the real column count are zero padding
                     float* o = d.out + m * d.ldo + col;
-                    if (gridDim.y > 1) atomicAdd(o, acc[mt][r]);
-                    else if (d.accum) *o += acc[mt][r];
-                    else *o = acc[mt][r];
+                    float v = acc[mt][r];
+                    if (d.ep_mode && col < d.ep_cols) {         // (unsplit grids only: the launcher clears ep_mode otherwise)
+                        const float e = d.ep_src[m * d.ep_ld + col];
+                        v = d.ep_mode == 1 ? (e > 0.f ? v : 0.f) : v + e;
+                    }
+                    if (gridDim.y > 1) atomicAdd(o, v);
+                    else if (d.accum) *o += v;
+                    else *o = v;
                 }
             }
         return;

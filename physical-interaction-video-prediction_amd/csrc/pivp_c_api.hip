@@ -232,11 +232,16 @@ bool conv5x5_bf16_splits_k(int cin, int cout, int ldo, int B, int H, int W, int 
     return d.ksplit_ok && conv5x5_bf16_ksplit(d, planes) > 1;
 }
 int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb, float* out, int cout, int ldo, int accum,
-                     int B, int H, int W, hipStream_t s, int planes, int dest_zeroed, const float* ascale_part) {
+                     int B, int H, int W, hipStream_t s, int planes, int dest_zeroed, const float* ascale_part, const EpSpec* ep) {
     IgemmDesc d;
     int rc = conv5x5_bf16_desc(d, x, cin, ldx, out, cout, ldo, accum, B, H, W);
     if (rc != PIVP_OK) return rc;
     d.wscale_part = ascale_part;
+    if (ep && ep->applied) *ep->applied = 0;
+    if (ep && ep->src && ep->mode && !(d.ksplit_ok && conv5x5_bf16_ksplit(d, planes) > 1)) {
+        d.ep_src = ep->src; d.ep_ld = ep->ld; d.ep_cols = ep->cols < cout ? ep->cols : cout; d.ep_mode = ep->mode;
+        if (ep->applied) *ep->applied = 1;
+    }
     if (d.ksplit_ok && !dest_zeroed && conv5x5_bf16_ksplit(d, planes) > 1 &&
         hipMemsetAsync(out, 0, (size_t)B * H * W * cout * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     return conv5x5_bf16(d, wb, s, planes);
@@ -288,7 +293,7 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
                           const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                           float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,
                           int B, int H, int W, hipStream_t s, int wt_ready, unsigned short* wt_bf16, int bf16_planes, const SideFork* fork,
-                          const LnFuse* ln, int dx_only, float* dg_absmax) {
+                          const LnFuse* ln, int dx_only, float* dg_absmax, const EpSpec* ep) {
     const int M = B * H * W, cin = cx + C, N = 4 * C;
     if (wt_bf16 && bf16_planes == -2 && !dg_absmax) return PIVP_ERR_BADARG;
     // a K-split data gradient adds into d_in: the gate kernel clears it on the side (one launch less than a memset per cell and timestep)
@@ -316,8 +321,9 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
             rc = pack_lstm_bf16(wt, wt_bf16, N, cin, s, conv5x5_bf16_rows(cin), bf16_planes, (bf16_planes == -2 && W % 16) ? 2 : 1);
             if (rc != PIVP_OK) return rc;
         }
-        rc = run_conv5x5_bf16(dG, N, N, wt_bf16, d_in, cin, cin, 0, B, H, W, s, bf16_planes, zero, dg_absmax);
+        rc = run_conv5x5_bf16(dG, N, N, wt_bf16, d_in, cin, cin, 0, B, H, W, s, bf16_planes, zero, dg_absmax, ep);
     } else {
+        if (ep && ep->applied) *ep->applied = 0;      // (the fp32 data-gradient kernels have no such hook)
         // d[x,h] = conv5x5(dG, W^T flipped); dx_only: the x columns alone (the pack's first cx of cin; the h columns of d_in stay unwritten)
         rc = dx_only ? run_conv_s1(dG, N, N, wt, d_in, cx, cin, 5, B, H, W, s, 0, cin, zero)
                      : run_conv_s1(dG, N, N, wt, d_in, cin, cin, 5, B, H, W, s, 0, 0, zero);

@@ -39,6 +39,9 @@ int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, in
                 int dest_zeroed = 0);                        // 1: the caller has cleared `out` (see conv_s1_splits_k)
 bool conv_s1_splits_k(int cin, int cout, int ldo, int ksize, int B, int H, int W, int wN);
 bool conv5x5_bf16_splits_k(int cin, int cout, int ldo, int B, int H, int W, int planes = 1);
+// IgemmDesc::ep_*: a second tensor met in the plain 5x5 bf16 convolution's epilogue (mode 1 ReLU mask, 2 add) on its first `cols` output columns.
+// *applied (host) tells the caller whether the launch took it (unsplit grid) or the separate pass is still the caller's to run.
+struct EpSpec { const float* src; int ld, cols, mode; int* applied; };
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
               float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s,
               float* db = nullptr, int* bias_done = nullptr, int bf16 = 0,    // 5x5 ConvLSTM case: 1 = operands rounded to bf16, 3 = three bf16 pieces each (fp32-grade)
@@ -51,11 +54,13 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
                           int B, int H, int W, hipStream_t s, int wt_ready = 0, unsigned short* wt_bf16 = nullptr, int bf16_planes = 1,
                           const SideFork* fork = nullptr, const LnFuse* ln = nullptr,    // ln: dh_a is formed from the LayerNorm behind the cell
                           int dx_only = 0,    // 1: d h_{t-1} is not needed (the sweep's last timestep): only the cx columns of d_in are computed
-                          float* dg_absmax = nullptr);        // 66 floats: receives dG's partial maxima (absmax_partials), the scale of the fp16-piece data gradient
+                          float* dg_absmax = nullptr,         // 66 floats: receives dG's partial maxima (absmax_partials), the scale of the fp16-piece data gradient
+                          const EpSpec* ep = nullptr);        // the data gradient's epilogue hook (bf16 / split-precision data gradients on unsplit grids)
                                                               // (bf16_planes == -2 needs it) and of the fp16-piece weight gradient (WgradDesc::dy_absmax)
 int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb, float* out, int cout, int ldo, int accum,
                      int B, int H, int W, hipStream_t s, int planes = 1, int dest_zeroed = 0,
-                     const float* ascale_part = nullptr);     // planes == -2: absmax_partials(x) (the activations' power-of-two scale)
+                     const float* ascale_part = nullptr,      // planes == -2: absmax_partials(x) (the activations' power-of-two scale)
+                     const EpSpec* ep = nullptr);
 int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w, float* dy, int cout, int ldy, const float* y, int ldyy,
                       float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, hipStream_t s,
                       int wt_ready = 0, const SideFork* fork = nullptr, float* part = nullptr, WgradDesc* desc_out = nullptr,

@@ -48,6 +48,11 @@ struct IgemmDesc {
     // deconv_tile only (training plans): also WRITE the normalised x0 ([B][Hin*Win] pixels at stride in_out_ld; each pixel by the one block
     // that owns it) and the samples' (mean, rstd) ([B][2]) -- what ln_apply would have left behind for the backward sweep
     float* in_out; int in_out_ld; float* in_stat_out;
+    // Plain 5x5 bf16 / split-precision convolution only (the ConvLSTM data gradient), unsplit grids only (no atomics): a second tensor met in the
+    // epilogue, so that the pass that would follow the launch disappears.  ep_mode 1: ReLU mask -- out = ep_src > 0 ? out : 0 (the x columns of a
+    // cell's input gradient are the dY of the enc conv that produced x: relu_mask_kernel's job); 2: out += ep_src (a second gradient path into the
+    // same tensor: add_strided_kernel's job).  Applies to output columns < ep_cols; ep_src[pixel * ep_ld + column].
+    const float* ep_src; int ep_ld, ep_cols, ep_mode;
 };
 
 // weight gradient of a conv / transposed conv (csrc/igemm_wgrad.hip)
@@ -94,6 +99,12 @@ int igemm_wgrad_reduce(const WgradDesc& d, hipStream_t s);   // dw += sum over t
 bool wgrad5x5_bf16_ok(const WgradDesc& d);
 int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s);
 int repack_transpose(const float* w, float* wt, int taps, int cin, int N, int flip, hipStream_t s);
+// Several weight preparations in ONE launch (the weights change once per optimizer step, so every train step rebuilds its packs: 7 + 12 + 7 launches
+// of a few microseconds each in the bf16 mode before round 5).  kind 0: repack_transpose(src, dst, taps = p0, cin = p1, N = p2, flip = p3);
+// kind 1: pack_lstm_bf16(src, dst, wcin = p0, N = p1, Np = p2) with one bf16 plane.  Jobs of one call must not depend on each other.
+struct WeightPrepJob { int kind; const float* src; void* dst; int p0, p1, p2, p3; };
+constexpr int WEIGHT_PREP_MAX = 16;
+int weight_prep_batch(const WeightPrepJob* jobs, int n, hipStream_t s);
 
 // ln_nparts (optional): receives the number of LayerNorm partials per sample the launch writes to d.ln_part (0: none)
 int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant = 0, int* ln_nparts = nullptr);  // 0 auto, 1: 4x1 waves, 2: 2x2, 3: 1x4

@@ -61,7 +61,8 @@ struct Slab {
 struct Grads {   // gradient workspace (single copy, reused by every timestep of the backward sweep)
     size_t cat7, n2, cat6, n4, e2, n5, e6, e6raw, e0raw;
     size_t din[7][2], dc[7];
-    size_t dG[7], go[2], dmk, dz, dkpart, dv, dstate, lnpart;   // dG: gate pre-activation gradients per ConvLSTM: 2 rings x wg_cap timesteps (batched weight gradients)
+    size_t dG[7], go, dmk, dz, dkpart, dv, dstate, lnpart;   // dG: gate pre-activation gradients per ConvLSTM: 2 rings x wg_cap timesteps (batched weight gradients)
+                                                             // go: d loss / d gen[t] for every t ([T-1] frames: the loss terms of all of them come from ONE launch)
     size_t wt_lstm[7], wt_enc[7];   // re-packed (transposed) weights for the data gradients, rebuilt once per backward
     size_t ln_ppart[9], ln_ppart_floats;   // per-norm partial parameter gradients (ln_backward's param_part), one contiguous region
     size_t wg_part[5], wg_part_floats;   // per-block partial weight gradients of enc6, enc5, enc4, enc2, enc1 (WgradDesc::part), one contiguous region
@@ -214,7 +215,7 @@ static void plan_layout(pivp_plan* p) {
             g.wt_enc[i] = (i == 0 || i == 3) ? 0 : carve((size_t)encw[i]);
         }
         g.dg_absmax = carve((size_t)7 * 2 * p->wg_cap * 72);     // dG's partial maxima per (cell, ring, slot): the fp16-piece gradients' scales
-        g.go[0] = carve((size_t)B * 3 * HW); g.go[1] = carve((size_t)B * 3 * HW);
+        g.go = carve((size_t)(T - 1) * B * 3 * HW);
         g.dmk = carve((size_t)B * p->NP * HW); g.dz = carve((size_t)B * p->NE * HW);
         g.dkpart = carve((size_t)B * composite_bwd_tiles(H, W) * 256); g.dv = carve((size_t)B * 256);
         g.dstate = carve((size_t)T * B * 5);
@@ -655,7 +656,12 @@ extern "C" int pivp_rollout_forward(pivp_plan_t* plan, const float* images, cons
         RC(absmax_partials(P(plan, plan->i_enc_w[5]), 9L * 96 * 96, plan->ws + plan->o_wabs[0], s));
         RC(absmax_partials(P(plan, plan->i_enc_w[6]), 9L * 64 * 64, plan->ws + plan->o_wabs[1], s));
     }
-    if (repack && plan->lstm_bf16)
+    if (repack && plan->lstm_bf16 && plan->lstm_planes == 1) {      // one bf16 plane: the seven packs in one launch
+        WeightPrepJob jobs[7];
+        for (int i = 0; i < 7; ++i)
+            jobs[i] = WeightPrepJob{1, P(plan, plan->i_lstm_w[i]), plan->ws + plan->o_wbf16[i], kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C, 4 * kLstm[i].C, 0};
+        RC(weight_prep_batch(jobs, 7, s));
+    } else if (repack && plan->lstm_bf16)
         for (int i = 0; i < 7; ++i)
             RC(pack_lstm_bf16(P(plan, plan->i_lstm_w[i]), reinterpret_cast<unsigned short*>(plan->ws + plan->o_wbf16[i]),
                               kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C, s, 0, plan->lstm_planes,
@@ -781,7 +787,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         return ln_backward(dy, lddy, nullptr, 0, ws + S.h[i], lf[i].stat, lf[i].gamma, lnpart, nullptr,
                            G(p, p->i_ln_g[j]), G(p, p->i_ln_b[j]), B, n, C, 0, s, ws + g.ln_ppart[j]);
     };
-    auto lstmb = [&](int i, const float* x, int ldx, int hh, int wwid) -> int {
+    auto lstmb = [&](int i, const float* x, int ldx, int hh, int wwid, const EpSpec* ep = nullptr) -> int {
         const LstmSpec& L = kLstm[i];
         const int cin = L.cx + L.C, N = 4 * L.C;
         const size_t dG1 = (size_t)B * hh * wwid * N;                      // floats of one timestep's dG
@@ -799,7 +805,8 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                                  s, 1, (p->lstm_bf16 && (p->bwd_planes != 3 || wwid % 16 == 0) && (p->bwd_planes != -2 || wwid % 16 == 0 || B % 2 == 0)) ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->bwd_planes,
                                  wg_flush ? fork_of(i, f) : nullptr, &lf[i],    // dW = null: only the fork's `ready` (behind the gate math) is used
                                  t == 0 ? 1 : 0,
-                                 (p->bwd_planes == -2 || p->x3_wgrad) ? ws + g.dg_absmax + ((size_t)(i * 2 + wg_ring) * p->wg_cap + wg_slot) * 72 : nullptr));    // t = 0: nobody reads d h_{-1}
+                                 (p->bwd_planes == -2 || p->x3_wgrad) ? ws + g.dg_absmax + ((size_t)(i * 2 + wg_ring) * p->wg_cap + wg_slot) * 72 : nullptr,    // t = 0: nobody reads d h_{-1}
+                                 ep));
         if (t == 0) RC(ln_finish(i + 1));       // the sweep's last timestep: the norm's partial parameter planes (written by the gate kernel) become its gradient
         if (!wg_flush) return PIVP_OK;
         // weight + bias gradient of the whole batch: timestep j of it reads slab (first - j) and ring slot j; on the side stream it
@@ -887,19 +894,24 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(done(0));
     RC(lnb_cell(6, ws + g.cat7, 64, n2, 32));
     RC(join(8));           // enc5's dY = the x part of lstm7's d_in of this parity (two timesteps ago)
-    RC(lstmb(6, ws + S.e5, 96, p->H2, p->W2));
+    // The x columns of a cell's input gradient are the dY of the enc conv in front of the cell: its ReLU mask (enc5, enc4) or the second gradient path into
+    // the same tensor (enc0: + enc6's concat part) is met in the data gradient's epilogue where that kernel has the hook and its grid is unsplit (the bf16 /
+    // split-precision forms: 27 relu_mask / add_strided launches fewer per train step at B = 32); otherwise the separate pass runs as before.
+    int ep_ok6 = 0, ep_ok5 = 0, ep_ok0 = 0;
+    const EpSpec ep6{ws + S.e5, 96, 96, 1, &ep_ok6}, ep5{ws + S.e4, 128, 128, 1, &ep_ok5}, ep0{ws + g.cat7 + 32, 64, 32, 2, &ep_ok0};
+    RC(lstmb(6, ws + S.e5, 96, p->H2, p->W2, &ep6));
     RC(done(1));
     RC(join(11));          // enc1's dY lives in d cat6, which enc5's data gradient rewrites
     // group 5 (TM:600): d e5 = x-part of lstm7's d_in (ReLU fused in enc5) <- enc5 deconv <- [hidden6 | enc1]
-    RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ws + S.e5, 96, ws + g.wt_enc[5], ws + g.cat6, 96, 0,
+    RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ep_ok6 ? nullptr : ws + S.e5, 96, ws + g.wt_enc[5], ws + g.cat6, 96, 0,
                          G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1, fork_of(8, fe), ws + g.wg_part[1], &p->enc_desc[1]));
     p->enc_desc_valid[1] = true;
     RC(lnb_cell(5, ws + g.cat6, 96, n4, 64));
     RC(join(9));           // enc4's dY = the x part of lstm6's d_in of this parity
-    RC(lstmb(5, ws + S.e4, 128, p->H4, p->W4));
+    RC(lstmb(5, ws + S.e4, 128, p->H4, p->W4, &ep5));
     RC(done(2));
     // group 4 (TM:599): d e4 = x-part of lstm6's d_in <- enc4 deconv <- hidden5 (also read by the CDNA kernel generator)
-    RC(run_conv_backward(1, ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), ws + g.din[5][par], 128, 192, ws + S.e4, 128, ws + g.wt_enc[4], ws + g.n5, 128, 1,
+    RC(run_conv_backward(1, ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), ws + g.din[5][par], 128, 192, ep_ok5 ? nullptr : ws + S.e4, 128, ws + g.wt_enc[4], ws + g.n5, 128, 1,
                          G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s, 1, fork_of(9, fe), ws + g.wg_part[2], &p->enc_desc[2]));
     p->enc_desc_valid[2] = true;
     RC(lnb_cell(4, ws + g.n5, 128, n8, 128));
@@ -928,11 +940,11 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(lnb_cell(1, ws + g.n2, 32, n2, 32));
     RC(lstmb(1, ws + S.n1, 32, p->H2, p->W2));      // ... of hidden1
     RC(lnb_cell(0, ws + g.din[1][par], 64, n2, 32));
-    RC(lstmb(0, ws + S.cat7 + 32, 64, p->H2, p->W2));
-    RC(add_strided(ws + g.cat7 + 32, 64, ws + g.din[0][par], 64, 32, px2, s));          // d enc0: from enc6's concat + from lstm1
+    RC(lstmb(0, ws + S.cat7 + 32, 64, p->H2, p->W2, &ep0));
+    if (!ep_ok0) RC(add_strided(ws + g.cat7 + 32, 64, ws + g.din[0][par], 64, 32, px2, s));          // d enc0: from enc6's concat + from lstm1
     // group 0 (TM:595): norm_enc0 (+relu) <- enc0 conv <- frame
     RC(join(12));          // d e0raw
-    RC(lnb(0, ws + g.cat7 + 32, 64, ws + S.cat7 + 32, 64, ws + S.e0raw, ws + g.e0raw, n2, 32, 1));
+    RC(lnb(0, ep_ok0 ? ws + g.din[0][par] : ws + g.cat7 + 32, 64, ws + S.cat7 + 32, 64, ws + S.e0raw, ws + g.e0raw, n2, 32, 1));
     RC(enc0_bwd(prev, P(p, p->i_enc_w[0]), ws + g.e0raw, G(p, p->i_enc_w[0]), G(p, p->i_enc_b[0]), prev_has_grad ? go_prev : nullptr, 1,
                 B, H, W, s, fork_of(12, fe)));
     RC(done(5));
@@ -997,36 +1009,43 @@ static int rollout_backward_sweep(pivp_plan_t* plan, const float* images, const 
     for (int k = 0; k < 5; ++k) plan->enc_desc_valid[k] = false;
     // d loss / d gen_states[t] for every t (zero before ctx-1), later accumulated with the state recurrence
     if (hipMemsetAsync(ws + g.dstate, 0, (size_t)T * B * 5 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
-    for (int t = ctx - 1; t < T - 1; ++t)
-        RC(scaled_diff(gen_states + (size_t)t * B * 5, states + (size_t)(t + 1) * B * 5, ws + g.dstate + (size_t)t * B * 5, (long)B * 5, sscale, 0, s));
-    // weights are constant during the sweep: build the transposed packs for the data gradients once
-    for (int i = 0; i < 7; ++i)
-        RC(repack_transpose(P(plan, plan->i_lstm_w[i]), ws + g.wt_lstm[i], 25, kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C, 1, s));
-    if (plan->lstm_bf16)        // bf16 / split modes: the ConvLSTM data gradients run on these packs (one plane, the hi / lo pair, or the three pieces)
+    // (gen_states[t] against states[t + 1], t = ctx-1 .. T-2: contiguous in t, one launch; likewise the frames' loss terms below -- 16 launches per sweep before)
+    RC(scaled_diff(gen_states + (size_t)(ctx - 1) * B * 5, states + (size_t)ctx * B * 5, ws + g.dstate + (size_t)(ctx - 1) * B * 5, (long)(T - ctx) * B * 5, sscale, 0, s));
+    // d loss / d gen[t], t = ctx-1 .. T-2 (gen[t] is compared with images[t + 1]); the sweep adds the feed-back terms of step t + 1 into frame t in place
+    RC(scaled_diff(gen_images + (size_t)(ctx - 1) * fr, images + (size_t)ctx * fr, ws + g.go + (size_t)(ctx - 1) * fr, (long)(T - ctx) * (long)fr, fscale, 0, s));
+    // weights are constant during the sweep: the transposed packs for the data gradients, all twelve in one launch (7 + 5 launches before round 5)
+    {
+        const int ecin[7] = {0, 32, 64, 0, 128, 96, 64};
+        WeightPrepJob jobs[12];
+        int n = 0;
+        for (int i = 0; i < 7; ++i)
+            jobs[n++] = WeightPrepJob{0, P(plan, plan->i_lstm_w[i]), ws + g.wt_lstm[i], 25, kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C, 1};
+        for (int i : {1, 2, 4, 5, 6}) jobs[n++] = WeightPrepJob{0, P(plan, plan->i_enc_w[i]), ws + g.wt_enc[i], 9, ecin[i], ecin[i], 0};
+        RC(weight_prep_batch(jobs, n, s));
+    }
+    if (plan->lstm_bf16 && plan->bwd_planes == 1) {      // bf16 mode: the ConvLSTM data gradients run on one-plane bf16 packs of those: one launch
+        WeightPrepJob jobs[7];
+        for (int i = 0; i < 7; ++i) {
+            const int cin = kLstm[i].cx + kLstm[i].C;
+            jobs[i] = WeightPrepJob{1, ws + g.wt_lstm[i], ws + g.wtb_lstm[i], 4 * kLstm[i].C, cin, conv5x5_bf16_rows(cin), 0};
+        }
+        RC(weight_prep_batch(jobs, 7, s));
+    } else if (plan->lstm_bf16)        // split modes: the hi / lo pair, the three pieces or the fp16 pieces (their own pack kernels, per layer)
         for (int i = 0; i < 7; ++i) {
             const int cin = kLstm[i].cx + kLstm[i].C;
             RC(pack_lstm_bf16(ws + g.wt_lstm[i], reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]), 4 * kLstm[i].C, cin, s,
                               conv5x5_bf16_rows(cin), plan->bwd_planes,
                               (plan->bwd_planes == -2 && lstm_w_of(plan, i) % 16) ? 2 : 1));      // (fp16 pieces on an 8-wide map: the ring kernel's layout)
         }
-    {
-        const int ecin[7] = {0, 32, 64, 0, 128, 96, 64};
-        for (int i : {1, 2, 4, 5, 6}) RC(repack_transpose(P(plan, plan->i_enc_w[i]), ws + g.wt_enc[i], 9, ecin[i], ecin[i], 0, s));
-    }
     bool has_go = false;
     for (int t = T - 2; t >= 0; --t) {
-        float* go = ws + g.go[t & 1];
-        float* go_prev = ws + g.go[(t & 1) ^ 1];
+        float* go = ws + g.go + (size_t)t * fr;
+        float* go_prev = t >= 1 ? ws + g.go + (size_t)(t - 1) * fr : nullptr;
         const bool last = t == T - 2;
-        if (last) {   // d gen[T-2] comes from the loss only
-            RC(scaled_diff(gen_images + (size_t)t * fr, images + (size_t)(t + 1) * fr, go, (long)fr, fscale, 0, s));
-            has_go = true;
-        }
+        if (last) has_go = true;                                            // d gen[T-2] comes from the loss only
         const bool prev_has_grad = (t >= ctx) && !gt_select;                // feed-self: prev = gen[t-1] is differentiable (TM:664-666)
-        // prepare d gen[t-1] = loss term (if any); this step's composite / enc0 backward add the feed-back term
+        // d gen[t-1] holds its loss term (if it has one: t - 1 >= ctx - 1, which prev_has_grad implies); this step's composite / enc0 backward add the feed-back term
         const bool next_loss = (t - 1) >= ctx - 1 && t >= 1;
-        if (next_loss) RC(scaled_diff(gen_images + (size_t)(t - 1) * fr, images + (size_t)t * fr, go_prev, (long)fr, fscale, 0, s));
-        else if (prev_has_grad) { if (hipMemsetAsync(go_prev, 0, fr * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH; }
         const float* prev = step_input(plan, t, images, gt_select, gen_images, fr);
         const float* st_prev = t == 0 ? states : gen_states + (size_t)(t - 1) * B * 5;
         // the ConvLSTM weight gradients: batches of wg_batch timesteps counted from the top of the sweep; t = 0 on its own
