@@ -631,7 +631,7 @@ def main(argv=None):
                            # evaluations then drift apart by a factor per fed-back step: NOT the parity figure -- that is the next field
                            'max_l2_vs_f32_rollout': max(l2_steps),
                            'max_l2_vs_f32_rollout_per_step': [float('%.3g' % v) for v in l2_steps],
-                           'dtype': 'f32 operands of the ConvLSTM forward as %s (layers on 8-wide maps: the f32 kernel)' % what}
+                           'dtype': 'f32 operands of the ConvLSTM forward as %s' % what}
                     obj.update(trained_fixture_distance(mode, dev, np, torch, pivp_amd))
                     if not args.no_roofline:
                         r6 = roofline_pass(args, m6, x6_step, t6, np, torch, precision=mode)
@@ -853,9 +853,9 @@ def roofline_pass(args, model, step, elapsed, np, torch, precision=None):
         ms_tot += np.array(ms[:]); n_tot += np.array(n[:]); flops += np.array(fl[:])
     lib.pivp_plan_set_profiling(plan.h, 0)
     layers = list(range(7))
-    if precision in ('bf16x6', 'fp16x3'):      # layers on maps that are not a multiple of 16 wide run the fp32 kernel in this mode: not part of its fraction
+    if precision in ('bf16x6', 'fp16x3'):      # layers whose map these kernels' tiles do not serve run the fp32 kernel in this mode: not part of its fraction
         widths = [args.size // 2, args.size // 2, args.size // 4, args.size // 4, args.size // 8, args.size // 4, args.size // 2]
-        layers = [i for i in range(7) if widths[i] % 16 == 0 or (precision == 'fp16x3' and widths[i] % 8 == 0 and args.batch % 2 == 0)]     # (fp16 pieces: 8-wide maps too)
+        layers = [i for i in range(7) if widths[i] % 16 == 0 or (widths[i] % 8 == 0 and args.batch % 2 == 0)]     # (8-wide maps: tiles of two images, an even batch)
     total_flops = float(flops[layers].sum())
     total_s = float(ms_tot[layers].sum()) * 1e-3
     achieved = total_flops / total_s / 1e12

@@ -88,8 +88,9 @@ int pivp_plan_set_param(pivp_plan_t* plan, int idx, const float* dptr);
  * and a product is three bf16 MFMAs, 16 bits of product mantissa, fp32 accumulation -- and the result stays inside the 1e-4 per-pixel gate
  * (4.4e-5 on the config 1 rollout; tests/test_gpu_bf16.py); the backward pass and every other op are the fp32 ones.
  * PIVP_PRECISION_BF16X6 = three bf16 pieces per fp32 operand (hi + mid + lo = v exactly) and the six products of weight >= 2^-16, i.e. fp32-grade
- * gate pre-activations computed on the bf16 matrix cores: the gate convolutions and, in the backward sweep, their DATA gradients, of layers whose map is a
- * multiple of 16 wide (8-wide maps -- lstm5 on 64 x 64 frames -- run the fp32 kernels), and their WEIGHT gradients (two timesteps per launch); every other op is the fp32 one.
+ * gate pre-activations computed on the bf16 matrix cores: the gate convolutions and, in the backward sweep, their DATA gradients (maps a multiple of 16 wide,
+ * or -- since round 5 -- 8 wide with an even batch: lstm5 on 64 x 64 frames; anything else runs the fp32 kernels), and their WEIGHT gradients (two timesteps per
+ * launch); every other op is the fp32 one.
  * PIVP_PRECISION_FP16X3 = the forward gate convolutions (and the enc5 / enc6 transposed convs) with every fp32 operand as TWO FP16 pieces (22 bits of mantissa; a layer's weights are packed times the
  * power of two that puts the largest in [2^14, 2^15), so that the second piece of any weight down to 2^-18 of it stays a normal fp16 number; the sum is scaled
  * back exactly) and three MFMAs per product; activations beyond +-65504 saturate, activations below 0.06 carry up to 3e-8 of absolute error.  Its truncation error is a quarter of the fp32 path's own rounding error (scripts/split_fp16_study.py).  The backward sweep's
@@ -219,7 +220,7 @@ int pivp_convlstm_bf16x3(const float* x, int cx, int ldx, const float* h_prev, i
 
 /* Three-piece form (precision mode PIVP_PRECISION_BF16X6): hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid); a product is hi*hi on the main
  * accumulator plus lo*hi + hi*lo + mid*mid + mid*hi + hi*mid on a second one (six bf16 MFMAs, fp32 accumulation): what is dropped is below 2^-24 of the
- * product.  W % 16 == 0 and C % 16 == 0 only.  w_bf16 = pivp_pack_lstm_bf16x6(w): 3 * pivp_lstm_bf16_weight_elems(cx + C, C) 2-byte elements. */
+ * product.  C % 16 == 0; W % 16 == 0, or W % 8 == 0 with an even batch (tiles of two images).  w_bf16 = pivp_pack_lstm_bf16x6(w): 3 * pivp_lstm_bf16_weight_elems(cx + C, C) 2-byte elements. */
 int pivp_pack_lstm_bf16x6(const float* w, void* w_bf16, int cin_total, int C, void* stream);
 int pivp_convlstm_bf16x6(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
                          const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
@@ -256,7 +257,7 @@ int pivp_conv5x5_bf16(const float* x, int cin, int ldx, const float* w, void* w_
 /* ... in the split mode (two bf16 pieces per operand, three MFMAs per product); w_bf16: twice the elements */
 int pivp_conv5x5_bf16x3(const float* x, int cin, int ldx, const float* w, void* w_bf16, float* out, int cout, int ldo, int accum,
                         int B, int H, int W, void* stream);
-/* ... and as three pieces per operand, six MFMAs per product (fp32-grade; PIVP_PRECISION_BF16X6's data gradient): W % 16 == 0; w_bf16 holds
+/* ... and as three pieces per operand, six MFMAs per product (fp32-grade; PIVP_PRECISION_BF16X6's data gradient): W % 16 == 0, or W % 8 == 0 with an even batch; w_bf16 holds
  * 3 * pivp_conv5x5_bf16_weight_elems(cin, cout) 2-byte elements */
 int pivp_conv5x5_bf16x6(const float* x, int cin, int ldx, const float* w, void* w_bf16, float* out, int cout, int ldo, int accum,
                         int B, int H, int W, void* stream);

@@ -27,7 +27,7 @@ int conv5x5_bf16_ksplit(const IgemmDesc& d, int planes) {
 
 int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int planes) {
     PIVP_CHECK_ARG(wb && bf16_geometry_ok(d) && d.out && d.N > 0 && d.ldo >= d.N && d.x0 && d.c0 > 0 && ((planes >= 1 && planes <= 3) || planes == -2) &&
-                   (planes != 3 || d.Win % 16 == 0) && (planes != -2 || (d.wscale_part && d.c1 == 0)));
+                   (planes != -2 || (d.wscale_part && d.c1 == 0)));
     const int Np = conv5x5_bf16_rows(d.N);
     IgemmDesc dd = d;
     dd.N = Np;                                         // the kernel's weight-row count
@@ -35,6 +35,8 @@ int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t strea
     const int nb = Np / (wide ? 128 : 64);
     const int ks = conv5x5_bf16_ksplit(d, planes);
     PIVP_CHECK_ARG(!dd.ep_mode || (ks == 1 && dd.ep_src && dd.ep_ld >= dd.ep_cols && (dd.ep_mode == 1 || dd.ep_mode == 2)));      // the caller asks conv5x5_bf16_ksplit first
+    if (planes == 3 && d.Win % 16)     // ... on an 8-wide map (an even batch): tiles of two images
+        return launch_x6g_plain<3, true>(dd, wb, stream, Np / 64, ks, d.N);
     if (planes == 3)     // three pieces (wb packed with planes = 3, plain = 1): 64-column blocks, weights from L2 into the operand registers, eight
         return launch_x6g_plain<3>(dd, wb, stream, Np / 64, ks, d.N);      // waves (the k-step-ring form of it measured 118 us per launch in the sweep against 100)
     if (planes == -2 && d.Win % 16)     // ... on an 8-wide map (an even batch): the ring kernel's two-image tiles, wb packed with plain = 2

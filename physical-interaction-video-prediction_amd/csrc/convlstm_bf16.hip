@@ -270,6 +270,11 @@ int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stre
     PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0)) && ((planes >= 1 && planes <= 3) || planes == -2));
     // LayerNorm-on-load (d.in_g) exists in the L2-direct kernels only (launch_x6g): every other form would consume the raw tensor
     PIVP_CHECK_ARG(!d.in_g || ((planes == 3 || planes == -2) && convlstm_bf16x6_ok(d)));
+    if (planes == 3 && !convlstm_bf16x6_ok(d)) {    // three pieces on an 8-wide map (an even batch: convlstm_bf16_ok): the L2-direct kernel on tiles of two images
+        const long b32 = d.C % 32 ? 0 : (long)(d.B / 2) * (d.Hin / TH) * (d.Win / 8) * (d.C / 32);
+        if ((nch == 32 && b32 > 0) || (nch == 0 && b32 >= pivp_cu_count())) return launch_x6g_w8<2, 4>(d, wb, stream, ln_nparts);
+        return launch_x6g_w8<4, 2>(d, wb, stream, ln_nparts);
+    }
     if (planes == -2 && !convlstm_bf16x6_ok(d)) {   // 8-wide maps: the ring kernel with fp16 pieces (wb = pack_lstm_bf16(..., planes = -2, plain = 2))
         const int tw2 = 8, ti2 = 2;
         const long b32 = d.C % 32 ? 0 : (long)(d.B / ti2) * (d.Hin / TH) * (d.Win / tw2) * (d.C / 32);
@@ -282,8 +287,7 @@ int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stre
         if ((nch == 32 && b32 > 0) || (nch == 0 && b32 >= pivp_cu_count())) return launch_x6g<2, 4, 2>(d, wb, stream, ln_nparts);
         return launch_x6g<4, 2, 2>(d, wb, stream, ln_nparts);
     }
-    if (planes == 3) {   // three pieces: 16-wide tiles and 16-channel blocks only (convlstm_bf16x6_ok); 8-wide maps are the caller's to route elsewhere
-        PIVP_CHECK_ARG(convlstm_bf16x6_ok(d));
+    if (planes == 3) {   // three pieces, 16-wide tiles
         // weights straight from L2: 32-channel blocks where they give every CU a block, else 16-channel blocks
         const long b32 = d.C % 32 ? 0 : (long)d.B * (d.Hin / TH) * (d.Win / 16) * (d.C / 32);
         if ((nch == 32 && b32 > 0) || (nch == 0 && b32 >= pivp_cu_count())) return launch_x6g<2, 4>(d, wb, stream, ln_nparts);

@@ -24,20 +24,27 @@ namespace pivp {
 // IN_LN: the x operand (d.x0, c0 <= 64 channels) is a RAW ConvLSTM output whose LayerNorm (per-element gamma / beta d.in_g / d.in_b [H W][c0], statistics
 // merged from the producer's partials d.in_part) is applied while the patch is staged -- the expression of ln_apply_kernel; out-of-image pixels load 0
 // for v, gamma and beta alike and stay 0.  Inference rollouts: hidden1 -> lstm2 and hidden3 -> lstm4 lose their ln_apply launch.
-template <int NWM, int NWN, bool LSTM = true, int PCS = 3, bool IN_LN = false>
+// W8 (round 5): maps 8 pixels wide (lstm5 on 64 x 64 frames) -- the block's 128 anchors are 8 x 8 pixels of TWO images (an even batch), the patch two
+// 12 x 12-pixel images with the ring kernel's row pitch RP8 (three planes: 138 KB, which is why the LDS-ring form never had room for it); everything
+// else -- fragments, k-steps, epilogue -- is the 16-wide form's.  Not with IN_LN (two images = two sets of statistics).
+template <int NWM, int NWN, bool LSTM = true, int PCS = 3, bool IN_LN = false, bool W8 = false>
 __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int wbytes, int ncols) {
     constexpr int THX = TH, PHX = PH;                  // anchor rows per tile, patch rows
-    constexpr int PB = PHX * RP16;                     // one patch plane: 36,864 B
+    constexpr int TW = W8 ? 8 : 16, TIN = W8 ? 2 : 1;  // tile width in pixels, images per tile
+    constexpr int RP = W8 ? RP8 : RP16;                // patch row pitch (bytes)
+    constexpr int PB = TIN * PHX * RP;                 // one patch plane: 36,864 B (W8: 46,080 B)
+    static_assert(!(W8 && IN_LN), "LayerNorm-on-load: one image per tile");
     static_assert(PCS == 3 || PCS == 2, "pieces");
     static_assert(NWM * NWN == 8, "eight waves, two per SIMD");
-    constexpr int PW = 20;
+    constexpr int PW = TW + 4;
     constexpr int NW = NWM * NWN;                      // waves
     constexpr int MT = THX / 2 / NWM;                  // 32-anchor M tiles per wave
     constexpr int NT = 64 * NW;                        // threads
     constexpr int PPP = NT / 8;                        // patch pixels per staging pass
     constexpr int NPJX = IN_LN ? 2 : 4;                // staging passes per round: 4 x 64 pixels cover the patch's 240 with 512 threads (IN_LN: gamma and beta
                                                        // travel with the pixels: two rounds of 2, or the prologue spills);
-    constexpr int NRND = (PHX * PW + NPJX * PPP - 1) / (NPJX * PPP);     // 256 threads take two rounds of 4 x 32 (eight passes in one round put the staged pixels in scratch)
+    constexpr int NPIX = TIN * PHX * PW;               // patch pixels: 240 (W8: 288)
+    constexpr int NRND = (NPIX + NPJX * PPP - 1) / (NPJX * PPP);     // 256 threads take two rounds of 4 x 32 (eight passes in one round put the staged pixels in scratch)
     constexpr int RD = 4;                              // k-steps (one tap) of B fragments in registers
     PIVP_SET_MAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -49,13 +56,18 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     const int C = d.C;
     const int n_nblk = LSTM ? C / (8 * NWN) : d.N / (32 * NWN);      // (plain: d.N = rows of the padded pack, a multiple of 64)
     const int H = d.Hin, W = d.Win;
-    const int tpr = W / 16, tpi = (H / THX) * tpr;
-    const int n_tiles = d.B * tpi;
+    const int tpr = W / TW, tpi = (H / THX) * tpr;
+    const int n_tiles = (d.B / TIN) * tpi;
     int lid = blockIdx.x;
     if ((gridDim.x & 7) == 0) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware, column-block major
     const int nblk = lid / n_tiles, tile = lid - nblk * n_tiles;
-    const int b0 = tile / tpi, trem = tile - b0 * tpi;
-    const int y0 = (trem / tpr) * THX, x0 = (trem - (trem / tpr) * tpr) * 16;
+    const int b0 = (tile / tpi) * TIN, trem = tile - (tile / tpi) * tpi;
+    const int y0 = (trem / tpr) * THX, x0 = (trem - (trem / tpr) * tpr) * TW;
+    // anchor i of the block's 128 -> (image of the tile, row, column): 8 x 16 of one image, or 8 x 8 of two
+    auto anchor = [&](int i, int& ti, int& ay, int& ax) {
+        if constexpr (W8) { ti = i >> 6; ay = (i >> 3) & 7; ax = i & 7; }
+        else { ti = 0; ay = i >> 4; ax = i & 15; }
+    };
     BF_STAMP(0);
     const int c0 = d.c0, ld0 = d.ld0, ld1 = d.ld1;
     const int cin = c0 + d.c1;
@@ -72,11 +84,12 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     // (pixel -> image / patch offsets are recomputed where they are used: ten index registers held across the tap loop cost more than the divisions)
     auto pix_of = [&](int j, int& a_pix, int& a_lds) {      // j: pass index over all rounds
         const int p = (tid >> 3) + PPP * j;
-        const int py = p / PW, px = p - py * PW;
+        const int ti = W8 ? p / (PHX * PW) : 0, pr = p - ti * (PHX * PW);
+        const int py = pr / PW, px = pr - py * PW;
         const int iy = y0 - 2 + py, ix = x0 - 2 + px;
-        const bool ok = p < PHX * PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        a_pix = ok ? (b0 * H + iy) * W + ix : -1;
-        a_lds = p < PHX * PW ? py * RP16 + px * PP : PW * PP;
+        const bool ok = p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        a_pix = ok ? ((b0 + ti) * H + iy) * W + ix : -1;
+        a_lds = p < NPIX ? (ti * PHX + py) * RP + px * PP : PW * PP;
     };
     float a_scale = 1.0f;                              // (plain form with fp16 pieces: see inv_wscale below)
     if constexpr (PCS == 2 && !LSTM) a_scale = pivp_x3_scale_wave(d.wscale_part);
@@ -166,8 +179,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     int a_off[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int i = 32 * MT * wm + 32 * mt + l31;
-        a_off[mt] = (i >> 4) * RP16 + (i & 15) * PP + half * 16;
+        int ti, ay, ax;
+        anchor(32 * MT * wm + 32 * mt + l31, ti, ay, ax);
+        a_off[mt] = (ti * PHX + ay) * RP + ax * PP + half * 16;
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
 
@@ -278,7 +292,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
         if constexpr (PCS * MT > 3) read_a(S0{}, K0{}, I3{}, ab);
         if constexpr (PCS * MT > 4) { read_a(S0{}, K0{}, I4{}, ab); read_a(S0{}, K0{}, I5{}, ab); }
     };
-    auto a_base = [&](int tp) { const int ty = tp / 5; return lds0 + ty * RP16 + (tp - ty * 5) * PP; };
+    auto a_base = [&](int tp) { const int ty = tp / 5; return lds0 + ty * RP + (tp - ty * 5) * PP; };
 
     for (int g = 0; g < ncg; ++g) {                    // 64 input channels of concat(x, h) at a time
         if (g > 0) {                                   // every wave is done with the old patch
@@ -296,8 +310,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int r = k * 4 + grp;
-                    const int i = 32 * MT * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const int m = (b0 * H + y0 + (i >> 4)) * W + x0 + (i & 15);
+                    int ti, ay, ax;
+                    anchor(32 * MT * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half, ti, ay, ax);
+                    const int m = ((b0 + ti) * H + y0 + ay) * W + x0 + ax;
                     cpre[mt][k] = d.cstate_in[(size_t)m * C + ch];
                 }
         }
@@ -330,20 +345,33 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
 
     if constexpr (!LSTM) {
         // ---- plain epilogue: accumulator row = anchor, column = output channel; 32 lanes write 128 contiguous bytes -------------------
+        // (the epilogue hook's second tensor is requested for all of the lane's outputs first: see convlstm_bf16_kernel)
+        float ev[MT][16];
+        if (d.ep_mode) {                                // block-uniform
+            const int col = (nblk * NWN + wn) * 32 + l31;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int ti, ay, ax;
+                    anchor(32 * MT * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half, ti, ay, ax);
+                    const size_t m = (size_t)(((b0 + ti) * H + y0 + ay) * W + x0 + ax);
+                    ev[mt][r] = (col < ncols && col < d.ep_cols) ? d.ep_src[m * d.ep_ld + col] : (d.ep_mode == 1 ? 1.f : 0.f);
+                }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = 32 * MT * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const size_t m = (size_t)((b0 * H + y0 + (i >> 4)) * W + x0 + (i & 15));
+                int ti, ay, ax;
+                anchor(32 * MT * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half, ti, ay, ax);
+                const size_t m = (size_t)(((b0 + ti) * H + y0 + ay) * W + x0 + ax);
                 const int col = (nblk * NWN + wn) * 32 + l31;
                 if (col < ncols) {                      // the pack's rows past the real column count are zero padding
                     float* o = d.out + m * d.ldo + col;
                     float v = acc[mt][r];
-                    if (d.ep_mode && col < d.ep_cols) {         // (unsplit grids only: the launcher clears ep_mode otherwise)
-                        const float e = d.ep_src[m * d.ep_ld + col];
-                        v = d.ep_mode == 1 ? (e > 0.f ? v : 0.f) : v + e;
-                    }
+                    if (d.ep_mode == 1) v = ev[mt][r] > 0.f ? v : 0.f;         // (unsplit grids only: the launcher clears ep_mode otherwise)
+                    else if (d.ep_mode == 2) v += ev[mt][r];
                     if (gridDim.y > 1) atomicAdd(o, v);
                     else if (d.accum) *o += v;
                     else *o = v;
@@ -370,8 +398,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
 #pragma unroll
             for (int g = 0; g < 4; ++g) g4[g] = pick(val, g ^ grp);
             const int r = k * 4 + grp;
-            const int i = 32 * MT * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int m = (b0 * H + y0 + (i >> 4)) * W + x0 + (i & 15);
+            int ti, ay, ax;
+            anchor(32 * MT * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half, ti, ay, ax);
+            const int m = ((b0 + ti) * H + y0 + ay) * W + x0 + ax;
             const size_t o = (size_t)m * C + ch;
             const float aj = b_tanh(g4[0] + bj), ai = b_sigmoid(g4[1] + bi);
             const float af = b_sigmoid(g4[2] + bf), ao = b_sigmoid(g4[3] + bo);
@@ -401,44 +430,73 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
         __syncthreads();
         if (lane == 0) red[wave8] = s1;
         __syncthreads();
-        const float cnt = (float)NW * 64.f * 4.f * MT;
-        float ssum = (red[0] + red[1]) + (red[2] + red[3]);
-        if constexpr (NW == 8) ssum += (red[4] + red[5]) + (red[6] + red[7]);
-        const float mean = ssum / cnt;
-        float q = 0.f;
+        if constexpr (!W8) {
+            const float cnt = (float)NW * 64.f * 4.f * MT;
+            const float ssum = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+            const float mean = ssum / cnt;
+            float q = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const float dd = sv[mt][k] - mean; q = fmaf(dd, dd, q); }
-        q = wave_sum(q);
-        if (lane == 0) red[8 + wave8] = q;
-        __syncthreads();
-        if (tid == 0) {
-            float* p = d.ln_part + ((size_t)b0 * d.ln_nparts + (size_t)trem * n_nblk + nblk) * 4;
-            float qs = (red[8] + red[9]) + (red[10] + red[11]);
-            if constexpr (NW == 8) qs += (red[12] + red[13]) + (red[14] + red[15]);
-            p[0] = cnt; p[1] = mean; p[2] = qs; p[3] = 0.f;
+                for (int k = 0; k < 4; ++k) { const float dd = sv[mt][k] - mean; q = fmaf(dd, dd, q); }
+            q = wave_sum(q);
+            if (lane == 0) red[8 + wave8] = q;
+            __syncthreads();
+            if (tid == 0) {
+                float* p = d.ln_part + ((size_t)b0 * d.ln_nparts + (size_t)trem * n_nblk + nblk) * 4;
+                const float qs = ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
+                p[0] = cnt; p[1] = mean; p[2] = qs; p[3] = 0.f;
+            }
+        } else {
+            // two images per tile: the waves wm < NWM / 2 (of every wave column) own image 0, the others image 1 -- a wave's 32 MT anchors lie inside one image
+            const int img = (wm * MT) >> 1;
+            const float cnt = (float)(NW / 2) * 64.f * 4.f * MT;
+            float ssum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) ssum += ((((w % NWM) * MT) >> 1) == img) ? red[w] : 0.f;      // fixed order
+            const float mean = ssum / cnt;
+            float q = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float dd = sv[mt][k] - mean; q = fmaf(dd, dd, q); }
+            q = wave_sum(q);
+            if (lane == 0) red[8 + wave8] = q;
+            __syncthreads();
+            if (lane == 0 && wn == 0 && wm == img * (NWM / 2)) {      // one writer per image
+                float* p = d.ln_part + ((size_t)(b0 + img) * d.ln_nparts + (size_t)trem * n_nblk + nblk) * 4;
+                float qs = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) qs += ((((w % NWM) * MT) >> 1) == img) ? red[8 + w] : 0.f;
+                p[0] = cnt; p[1] = mean; p[2] = qs; p[3] = 0.f;
+            }
         }
     }
 }
 
-template <int NWM, int NWN, int PCS, bool IN_LN>
+template <int NWM, int NWN, int PCS, bool IN_LN, bool W8 = false>
 static int launch_x6g_impl(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts) {
-    constexpr int THX = TH, lds_bytes = PCS * PH * RP16;
+    constexpr int THX = TH, lds_bytes = PCS * (W8 ? PATCH_BYTES : PH * RP16);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
     static PerDeviceOnce once;
-    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<NWM, NWN, true, PCS, IN_LN>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
-    PIVP_CHECK_ARG(d.Hin % THX == 0);
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<NWM, NWN, true, PCS, IN_LN, W8>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
+    PIVP_CHECK_ARG(d.Hin % THX == 0 && d.Win % (W8 ? 8 : 16) == 0 && (!W8 || d.B % 2 == 0));
     IgemmDesc dd = d;
-    const int tpi = (d.Hin / THX) * (d.Win / 16), nb = d.C / (8 * NWN);
+    const int tpi = (d.Hin / THX) * (d.Win / (W8 ? 8 : 16)), nb = d.C / (8 * NWN);
     const int np = tpi * nb;
     dd.ln_nparts = (d.ln_part && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
     const long long wbytes = (long long)lstm_bf16_weight_elems(d.c0 + (d.c1 ? d.c1 : d.C), 4 * d.C) * PCS * 2;
     if (wbytes >= (1LL << 31)) return PIVP_ERR_BADARG;
-    hipLaunchKernelGGL((convlstm_x6g_kernel<NWM, NWN, true, PCS, IN_LN>), dim3(d.B * tpi * nb), dim3(64 * NWM * NWN), lds_bytes, stream, dd, wb, (int)wbytes, 0);
+    hipLaunchKernelGGL((convlstm_x6g_kernel<NWM, NWN, true, PCS, IN_LN, W8>), dim3((d.B / (W8 ? 2 : 1)) * tpi * nb), dim3(64 * NWM * NWN), lds_bytes, stream, dd, wb, (int)wbytes, 0);
     return PIVP_LAUNCH_STATUS();
+}
+// ... on maps 8 pixels wide (an even batch): tiles of two images
+template <int NWM, int NWN, int PCS = 3>
+static int launch_x6g_w8(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts) {
+    PIVP_CHECK_ARG(!d.in_g);
+    return launch_x6g_impl<NWM, NWN, PCS, false, true>(d, wb, stream, ln_nparts);
 }
 template <int NWM, int NWN, int PCS = 3>
 static int launch_x6g(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts) {
@@ -450,15 +508,16 @@ static int launch_x6g(const IgemmDesc& d, const unsigned short* wb, hipStream_t 
 }
 
 // the plain 5x5 convolution on the same kernel: dd.N = rows of the padded pack, nb = its 64-column blocks, ks = split of the channel groups
-template <int PCS>
+template <int PCS, bool W8 = false>
 static int launch_x6g_plain(const IgemmDesc& dd, const unsigned short* wb, hipStream_t stream, int nb, int ks, int ncols) {
-    constexpr int lds_bytes = PCS * PH * RP16;
+    constexpr int lds_bytes = PCS * (W8 ? PATCH_BYTES : PH * RP16);
     static PerDeviceOnce once;
-    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<4, 2, false, PCS>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
-    const int tpi = (dd.Hin / TH) * (dd.Win / 16);
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<4, 2, false, PCS, false, W8>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
+    PIVP_CHECK_ARG(dd.Win % (W8 ? 8 : 16) == 0 && (!W8 || dd.B % 2 == 0));
+    const int tpi = (dd.Hin / TH) * (dd.Win / (W8 ? 8 : 16));
     const long long wbytes = (long long)lstm_bf16_weight_elems(dd.c0 + dd.c1, dd.N) * PCS * 2;
     if (wbytes >= (1LL << 31)) return PIVP_ERR_BADARG;
-    hipLaunchKernelGGL((convlstm_x6g_kernel<4, 2, false, PCS>), dim3(dd.B * tpi * nb, ks), dim3(512), lds_bytes, stream, dd, wb, (int)wbytes, ncols);
+    hipLaunchKernelGGL((convlstm_x6g_kernel<4, 2, false, PCS, false, W8>), dim3((dd.B / (W8 ? 2 : 1)) * tpi * nb, ks), dim3(512), lds_bytes, stream, dd, wb, (int)wbytes, ncols);
     return PIVP_LAUNCH_STATUS();
 }
 

@@ -41,7 +41,7 @@ int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, co
     // w_bf16: the bf16 pack of w (pack_lstm_bf16) selects the bf16-operand kernel; variant then is its channels per block
     // (three pieces: maps the three-plane tile does not serve -- 8 wide -- take the fp32 kernel, which is what that mode stands in for)
     // (two fp16 pieces: 8-wide maps take the ring kernel's fp16 form when its tiles fit -- an even batch --, whose pack is laid out differently: the caller's)
-    if (w_bf16 && !convlstm_bf16x6_ok(d) && (bf16_planes == 3 || (bf16_planes == -2 && !convlstm_bf16_ok(d)))) return w ? igemm_lstm(d, s, 0, ln_nparts) : PIVP_ERR_BADARG;
+    if (w_bf16 && (bf16_planes == 3 || bf16_planes == -2) && !convlstm_bf16_ok(d)) return w ? igemm_lstm(d, s, 0, ln_nparts) : PIVP_ERR_BADARG;      // (an 8-wide map with an odd batch: the fp32 kernel)
     if (w_bf16) return convlstm_bf16(d, w_bf16, s, ln_nparts, ((bf16_planes == 3 || bf16_planes == -2) && variant != 16 && variant != 32) ? 0 : variant, bf16_planes);
     return igemm_lstm(d, s, variant, ln_nparts);
 }
@@ -503,7 +503,7 @@ extern "C" int pivp_pack_lstm_bf16x6(const float* w, void* w_bf16, int cin_total
 extern "C" int pivp_convlstm_bf16x6(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
                                     const float* c_in, float* c_out, float* h_out, float* gates_out, float* ln_part, int ln_cap,
                                     int* ln_nparts, int B, int H, int W, int nch, void* stream) {
-    if (!x || !w_bf16 || !bias || !c_in || !c_out || !h_out || (nch != 0 && nch != 1 && nch != 2 && nch != 16 && nch != 32)) return PIVP_ERR_BADARG;
+    if (!x || !w_bf16 || !bias || !c_in || !c_out || !h_out || (nch != 0 && nch != 16 && nch != 32)) return PIVP_ERR_BADARG;
     return run_convlstm(x, cx, ldx, h_prev, C, nullptr, bias, c_in, c_out, h_out, B, H, W, (hipStream_t)stream, nch, gates_out,
                         ln_part, ln_cap, ln_nparts, (const unsigned short*)w_bf16, 3);
 }
@@ -558,7 +558,7 @@ extern "C" int pivp_conv5x5_bf16x3(const float* x, int cin, int ldx, const float
 // three-piece form (six MFMAs per product, fp32-grade): w_bf16 holds 3 * pivp_conv5x5_bf16_weight_elems(cin, cout) elements; W % 16 == 0
 extern "C" int pivp_conv5x5_bf16x6(const float* x, int cin, int ldx, const float* w, void* w_bf16, float* out, int cout, int ldo, int accum,
                                    int B, int H, int W, void* stream) {
-    if (!x || !w || !w_bf16 || !out || cin <= 0 || cout <= 0 || W % 16) return PIVP_ERR_BADARG;
+    if (!x || !w || !w_bf16 || !out || cin <= 0 || cout <= 0 || (W % 16 && (W % 8 || B % 2))) return PIVP_ERR_BADARG;
     int rc = pack_lstm_bf16(w, (unsigned short*)w_bf16, cin, cout, (hipStream_t)stream, conv5x5_bf16_rows(cout), 3, 1);
     if (rc != PIVP_OK) return rc;
     return run_conv5x5_bf16(x, cin, ldx, (const unsigned short*)w_bf16, out, cout, ldo, accum, B, H, W, (hipStream_t)stream, 3);

@@ -59,9 +59,11 @@ struct Slab {
 };
 
 struct Grads {   // gradient workspace (single copy, reused by every timestep of the backward sweep)
-    size_t cat7, n2, cat6, n4, e2, n5, e6, e6raw, e0raw;
+    size_t cat7, n2, n4, n5, e6;
+    size_t cat6[2], e2[2], e6raw[2], e0raw[2], dv[2];   // the dY tensors the side stream's weight gradients read, by timestep parity: a step rewrites the buffer the
+                                                        // weight gradients of TWO steps ago read, so the main stream never waits for the previous step's (round 5)
     size_t din[7][2], dc[7];
-    size_t dG[7], go, dmk, dz, dkpart, dv, dstate, lnpart;   // dG: gate pre-activation gradients per ConvLSTM: 2 rings x wg_cap timesteps (batched weight gradients)
+    size_t dG[7], go, dmk, dz, dkpart, dstate, lnpart;   // dG: gate pre-activation gradients per ConvLSTM: 2 rings x wg_cap timesteps (batched weight gradients)
                                                              // go: d loss / d gen[t] for every t ([T-1] frames: the loss terms of all of them come from ONE launch)
     size_t wt_lstm[7], wt_enc[7];   // re-packed (transposed) weights for the data gradients, rebuilt once per backward
     size_t ln_ppart[9], ln_ppart_floats;   // per-norm partial parameter gradients (ln_backward's param_part), one contiguous region
@@ -114,7 +116,7 @@ struct pivp_plan {
     hipStream_t side = nullptr;
     hipStream_t side_of(int) const { return side; }      // (a second side stream for the odd slots, round 3: fp32 no change, bf16 12.25 -> 12.05 ms, but with two
                                                          // processes on one GPU the step went from 65 ms to 78 SECONDS -- the hardware queues oversubscribe)
-    hipEvent_t ev_ready[NSLOT] = {}, ev_done[NSLOT] = {};
+    hipEvent_t ev_ready[NSLOT][2] = {}, ev_done[NSLOT][2] = {};      // by timestep parity (slots 7..13; see Grads::cat6)
     hipEvent_t ev_ring_done[7][2] = {};        // ConvLSTM slots: one `done` per dG ring (slots 0..6 of ev_done are unused)
     int wg_cap = 1;                            // dG ring slots per ring = min(T - 2, WG_BATCH_MAX), fixed when the workspace is laid out
     int wg_batch = 1;                          // timesteps per weight-gradient launch (<= wg_cap)
@@ -126,8 +128,10 @@ struct pivp_plan {
     void destroy_side() {
         for (int i = 0; i < 7; ++i) for (int r = 0; r < 2; ++r) if (ev_ring_done[i][r]) { (void)hipEventDestroy(ev_ring_done[i][r]); ev_ring_done[i][r] = nullptr; }
         for (int i = 0; i < NSLOT; ++i) {
-            if (ev_ready[i]) { (void)hipEventDestroy(ev_ready[i]); ev_ready[i] = nullptr; }
-            if (ev_done[i]) { (void)hipEventDestroy(ev_done[i]); ev_done[i] = nullptr; }
+            for (int r = 0; r < 2; ++r) {
+                if (ev_ready[i][r]) { (void)hipEventDestroy(ev_ready[i][r]); ev_ready[i][r] = nullptr; }
+                if (ev_done[i][r]) { (void)hipEventDestroy(ev_done[i][r]); ev_done[i][r] = nullptr; }
+            }
         }
         if (side) { (void)hipStreamDestroy(side); side = nullptr; }
     }
@@ -202,9 +206,12 @@ static void plan_layout(pivp_plan* p) {
     p->has_grads = train;
     if (p->has_grads) {
         Grads& g = p->g;
-        g.cat7 = carve(B * HW2 * 64); g.n2 = carve(B * HW2 * 32); g.cat6 = carve(B * HW4 * 96); g.n4 = carve(B * HW4 * 64);
-        g.e2 = carve(B * HW8 * 64); g.n5 = carve(B * HW8 * 128); g.e6 = carve(B * HW * 64); g.e6raw = carve(B * HW * 64);
-        g.e0raw = carve(B * HW2 * 32);
+        g.cat7 = carve(B * HW2 * 64); g.n2 = carve(B * HW2 * 32); g.n4 = carve(B * HW4 * 64);
+        g.n5 = carve(B * HW8 * 128); g.e6 = carve(B * HW * 64);
+        for (int r = 0; r < 2; ++r) {
+            g.cat6[r] = carve(B * HW4 * 96); g.e2[r] = carve(B * HW8 * 64); g.e6raw[r] = carve(B * HW * 64); g.e0raw[r] = carve(B * HW2 * 32);
+            g.dv[r] = carve((size_t)B * 256);
+        }
         for (int i = 0; i < 7; ++i) {
             const size_t M = hsz[i] / kLstm[i].C * B;
             g.dc[i] = carve(B * hsz[i]);   // (d h of a cell is never materialised: the LayerNorm backward is folded into the gate backward)
@@ -217,7 +224,7 @@ static void plan_layout(pivp_plan* p) {
         g.dg_absmax = carve((size_t)7 * 2 * p->wg_cap * 72);     // dG's partial maxima per (cell, ring, slot): the fp16-piece gradients' scales
         g.go = carve((size_t)(T - 1) * B * 3 * HW);
         g.dmk = carve((size_t)B * p->NP * HW); g.dz = carve((size_t)B * p->NE * HW);
-        g.dkpart = carve((size_t)B * composite_bwd_tiles(H, W) * 256); g.dv = carve((size_t)B * 256);
+        g.dkpart = carve((size_t)B * composite_bwd_tiles(H, W) * 256);
         g.dstate = carve((size_t)T * B * 5);
         g.lnpart = carve((size_t)B * ln_bwd_slices((int)(64 * HW)) * 2);
         g.ln_ppart_floats = 0;
@@ -413,8 +420,9 @@ static int ensure_side(pivp_plan* plan) {
     }
     bool ok = true;
     for (int i = 0; i < pivp_plan::NSLOT && ok; ++i)
-        ok = hipEventCreateWithFlags(&plan->ev_ready[i], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&plan->ev_done[i], hipEventDisableTiming) == hipSuccess;
+        for (int r = 0; r < 2 && ok; ++r)
+            ok = hipEventCreateWithFlags(&plan->ev_ready[i][r], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&plan->ev_done[i][r], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 7 && ok; ++i)
         for (int r = 0; r < 2 && ok; ++r)
             ok = hipEventCreateWithFlags(&plan->ev_ring_done[i][r], hipEventDisableTiming) == hipSuccess;
@@ -705,8 +713,8 @@ static const int kGroupSlots[6][4] = {{7, 13, -1, -1}, {6, -1, -1, -1}, {8, 5, -
 // legacy default stream, a perfectly good stream to wait on -- never a "no stream" marker.
 static int wait_slot(pivp_plan* p, int sl, hipStream_t stream) {
     if (!p->side) return PIVP_OK;
-    if (sl >= 7) return hipStreamWaitEvent(stream, p->ev_done[sl], 0) == hipSuccess ? PIVP_OK : PIVP_ERR_LAUNCH;
-    for (int r = 0; r < 2; ++r) if (hipStreamWaitEvent(stream, p->ev_ring_done[sl][r], 0) != hipSuccess) return PIVP_ERR_LAUNCH;
+    for (int r = 0; r < 2; ++r)
+        if (hipStreamWaitEvent(stream, sl >= 7 ? p->ev_done[sl][r] : p->ev_ring_done[sl][r], 0) != hipSuccess) return PIVP_ERR_LAUNCH;
     return PIVP_OK;
 }
 // Wave priority of the main stream's kernels during this plan's calls (csrc/pivp_common.h): the device word is rewritten only when the wanted value
@@ -765,12 +773,12 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     // weight-gradient slots (pivp_plan::NSLOT): join = the main stream waits for the slot's last weight-gradient kernels
     auto fork_of = [&](int slot, SideFork& f) -> const SideFork* {
         if (!p->side) return nullptr;
-        f.side = p->side_of(slot); f.ready = p->ev_ready[slot]; f.done = p->ev_done[slot];
+        f.side = p->side_of(slot); f.ready = p->ev_ready[slot][par]; f.done = p->ev_done[slot][par];
         return &f;
     };
     auto join = [&](int slot) -> int {
         if (!p->side) return PIVP_OK;
-        return hipStreamWaitEvent(s, p->ev_done[slot], 0) == hipSuccess ? PIVP_OK : PIVP_ERR_LAUNCH;   // never recorded: returns at once
+        return hipStreamWaitEvent(s, p->ev_done[slot][par], 0) == hipSuccess ? PIVP_OK : PIVP_ERR_LAUNCH;   // this parity's last use: two timesteps ago (never recorded: returns at once)
     };
     const long long slab_bytes = p->nslabs > 1 ? ((long long)p->slabs[1].cat7 - (long long)p->slabs[0].cat7) * 4 : 0;
     // LayerNorm behind ConvLSTM i (hidden<i+1>): one launch leaves the two sums per sample and the norm's partial parameter planes
@@ -802,7 +810,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                                  Sp ? ws + Sp->c[i] : ws + p->o_zero, ws + S.c[i], nullptr, L.C,
                                  last_step ? nullptr : ws + g.din[i][npar] + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
                                  ring + (size_t)wg_slot * dG1, ws + g.wt_lstm[i], ws + g.din[i][par], nullptr, nullptr, B, hh, wwid,
-                                 s, 1, (p->lstm_bf16 && (p->bwd_planes != 3 || wwid % 16 == 0) && (p->bwd_planes != -2 || wwid % 16 == 0 || B % 2 == 0)) ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->bwd_planes,
+                                 s, 1, (p->lstm_bf16 && ((p->bwd_planes != 3 && p->bwd_planes != -2) || wwid % 16 == 0 || B % 2 == 0)) ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->bwd_planes,
                                  wg_flush ? fork_of(i, f) : nullptr, &lf[i],    // dW = null: only the fork's `ready` (behind the gate math) is used
                                  t == 0 ? 1 : 0,
                                  (p->bwd_planes == -2 || p->x3_wgrad) ? ws + g.dg_absmax + ((size_t)(i * 2 + wg_ring) * p->wg_cap + wg_slot) * 72 : nullptr,    // t = 0: nobody reads d h_{-1}
@@ -847,17 +855,17 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                      G(p, p->i_masks_b), G(p, p->i_enc7_w), G(p, p->i_enc7_b), B, HW, p->NP, p->NE, s));
         RC(join(13));      // d v (the kernel generator's weight gradient reads it)
         if (c.model_type == PIVP_MODEL_CDNA)
-            RC(cdna_kernels_bwd(ws + S.n5, P(p, p->i_head_w), ws + S.vpre, ws + g.dkpart, composite_bwd_tiles(H, W), ws + g.dv, ws + g.n5, 0,
+            RC(cdna_kernels_bwd(ws + S.n5, P(p, p->i_head_w), ws + S.vpre, ws + g.dkpart, composite_bwd_tiles(H, W), ws + g.dv[par], ws + g.n5, 0,
                                 G(p, p->i_head_w), G(p, p->i_head_b), B, p->K5, c.num_masks, s, fork_of(13, fe)));
         else if (c.model_type == PIVP_MODEL_STP)
             RC(stp_params_bwd(ws + S.n5, P(p, p->i_head_w), ws + S.vpre, P(p, p->i_head2_w), ws + g.dkpart, composite_bwd_tiles(H, W),
-                              ws + g.dv, ws + g.n5, G(p, p->i_head_w), G(p, p->i_head_b), G(p, p->i_head2_w), G(p, p->i_head2_b),
+                              ws + g.dv[par], ws + g.n5, G(p, p->i_head_w), G(p, p->i_head_b), G(p, p->i_head2_w), G(p, p->i_head2_b),
                               B, p->K5, s));
         else if (hipMemsetAsync(ws + g.n5, 0, (size_t)px8 * 128 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;   // DNA: no hidden5 head
         // group 6 (TM:601), reversed: norm_enc6 (+relu) <- enc6 deconv <- [hidden7 | enc0]
         RC(join(7));       // d e6raw
-        RC(lnb(8, ws + g.e6, 64, ws + S.e6, 64, ws + S.e6raw, ws + g.e6raw, 64 * HW, 64, 1));
-        RC(run_conv_backward(1, ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), ws + g.e6raw, 64, 64, nullptr, 0, ws + g.wt_enc[6], ws + g.cat7, 64, 0,
+        RC(lnb(8, ws + g.e6, 64, ws + S.e6, 64, ws + S.e6raw, ws + g.e6raw[par], 64 * HW, 64, 1));
+        RC(run_conv_backward(1, ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), ws + g.e6raw[par], 64, 64, nullptr, 0, ws + g.wt_enc[6], ws + g.cat7, 64, 0,
                              G(p, p->i_enc_w[6]), G(p, p->i_enc_b[6]), B, p->H2, p->W2, s, 1, fork_of(7, fe), ws + g.wg_part[0], &p->enc_desc[0]));
     p->enc_desc_valid[0] = true;
     } else {
@@ -872,7 +880,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         p->enc_desc_valid[k] = false;
         hipStream_t sw = p->side ? p->side_of(7 + k) : s;
         RC(igemm_wgrad_reduce(p->enc_desc[k], sw));
-        if (p->side && hipEventRecord(p->ev_done[7 + k], sw) != hipSuccess) return PIVP_ERR_LAUNCH;
+        if (p->side && hipEventRecord(p->ev_done[7 + k][0], sw) != hipSuccess) return PIVP_ERR_LAUNCH;      // (t = 0: parity 0, behind this step's own launch)
         return PIVP_OK;
     };
     // t = 0 is the sweep's final timestep: a gradient group is final once the side stream's weight gradients of its layers are in too
@@ -903,10 +911,10 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(done(1));
     RC(join(11));          // enc1's dY lives in d cat6, which enc5's data gradient rewrites
     // group 5 (TM:600): d e5 = x-part of lstm7's d_in (ReLU fused in enc5) <- enc5 deconv <- [hidden6 | enc1]
-    RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ep_ok6 ? nullptr : ws + S.e5, 96, ws + g.wt_enc[5], ws + g.cat6, 96, 0,
+    RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ep_ok6 ? nullptr : ws + S.e5, 96, ws + g.wt_enc[5], ws + g.cat6[par], 96, 0,
                          G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1, fork_of(8, fe), ws + g.wg_part[1], &p->enc_desc[1]));
     p->enc_desc_valid[1] = true;
-    RC(lnb_cell(5, ws + g.cat6, 96, n4, 64));
+    RC(lnb_cell(5, ws + g.cat6[par], 96, n4, 64));
     RC(join(9));           // enc4's dY = the x part of lstm6's d_in of this parity
     RC(lstmb(5, ws + S.e4, 128, p->H4, p->W4, &ep5));
     RC(done(2));
@@ -920,11 +928,11 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     // group 3 (TM:598) + state predictor (TM:730): d e3 = x-part of lstm5's d_in (ld 192)
     RC(join(10));          // d e2
     RC(enc3_state_bwd(ws + S.e2, ws + S.e3, ws + g.din[4][par], 192, action, state_prev, P(p, p->i_enc_w[3]), P(p, p->i_cs_w),
-                      ws + g.dstate + (size_t)t * B * 5, ws + g.e2, G(p, p->i_enc_w[3]), G(p, p->i_enc_b[3]), G(p, p->i_cs_w),
+                      ws + g.dstate + (size_t)t * B * 5, ws + g.e2[par], G(p, p->i_enc_w[3]), G(p, p->i_enc_b[3]), G(p, p->i_cs_w),
                       G(p, p->i_cs_b), t > 0 ? ws + g.dstate + (size_t)(t - 1) * B * 5 : ws + g.dstate + (size_t)(c.seq_len - 1) * B * 5,
                       B, p->H8 * p->W8, c.use_state, s, 1));      // d e2 comes out masked by enc2's ReLU
     // group 2 (TM:597): enc2 conv (ReLU) <- hidden4 <- lstm4 <- hidden3 <- lstm3 <- enc1
-    RC(run_conv_backward(0, ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), ws + g.e2, 64, 64, nullptr, 0, ws + g.wt_enc[2], ws + g.n4, 64, 0,
+    RC(run_conv_backward(0, ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), ws + g.e2[par], 64, 64, nullptr, 0, ws + g.wt_enc[2], ws + g.n4, 64, 0,
                          G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s, 1, fork_of(10, fe), ws + g.wg_part[3], &p->enc_desc[3]));
     p->enc_desc_valid[3] = true;
     RC(lnb_cell(3, ws + g.n4, 64, n4, 64));
@@ -933,7 +941,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(lstmb(2, ws + S.cat6 + 64, 96, p->H4, p->W4));
     RC(done(4));
     // group 1 (TM:596): enc1 conv (ReLU) <- hidden2 <- lstm2 <- hidden1 <- lstm1 <- enc0
-    RC(run_conv_backward(0, ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), ws + g.cat6 + 64, 32, 96, ws + S.cat6 + 64, 96, ws + g.wt_enc[1], ws + g.n2, 32, 0,
+    RC(run_conv_backward(0, ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), ws + g.cat6[par] + 64, 32, 96, ws + S.cat6 + 64, 96, ws + g.wt_enc[1], ws + g.n2, 32, 0,
                          G(p, p->i_enc_w[1]), G(p, p->i_enc_b[1]), B, p->H2, p->W2, s, 1, fork_of(11, fe), ws + g.wg_part[4], &p->enc_desc[4],
                          ws + g.din[2][par], 96));      // d enc1 = enc5's concat part (in d cat6) + lstm3's x gradient, summed in the ReLU-mask pass
     p->enc_desc_valid[4] = true;
@@ -944,8 +952,8 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     if (!ep_ok0) RC(add_strided(ws + g.cat7 + 32, 64, ws + g.din[0][par], 64, 32, px2, s));          // d enc0: from enc6's concat + from lstm1
     // group 0 (TM:595): norm_enc0 (+relu) <- enc0 conv <- frame
     RC(join(12));          // d e0raw
-    RC(lnb(0, ep_ok0 ? ws + g.din[0][par] : ws + g.cat7 + 32, 64, ws + S.cat7 + 32, 64, ws + S.e0raw, ws + g.e0raw, n2, 32, 1));
-    RC(enc0_bwd(prev, P(p, p->i_enc_w[0]), ws + g.e0raw, G(p, p->i_enc_w[0]), G(p, p->i_enc_b[0]), prev_has_grad ? go_prev : nullptr, 1,
+    RC(lnb(0, ep_ok0 ? ws + g.din[0][par] : ws + g.cat7 + 32, 64, ws + S.cat7 + 32, 64, ws + S.e0raw, ws + g.e0raw[par], n2, 32, 1));
+    RC(enc0_bwd(prev, P(p, p->i_enc_w[0]), ws + g.e0raw[par], G(p, p->i_enc_w[0]), G(p, p->i_enc_b[0]), prev_has_grad ? go_prev : nullptr, 1,
                 B, H, W, s, fork_of(12, fe)));
     RC(done(5));
     return PIVP_OK;
@@ -964,7 +972,8 @@ extern "C" int pivp_rollout_backward(pivp_plan_t* plan, const float* images, con
         hipStream_t s = (hipStream_t)stream;
         bool joined = rc == PIVP_OK;
         if (joined) {
-            for (int i = 7; i < pivp_plan::NSLOT && joined; ++i) joined = hipStreamWaitEvent(s, plan->ev_done[i], 0) == hipSuccess;
+            for (int i = 7; i < pivp_plan::NSLOT && joined; ++i)
+                for (int r = 0; r < 2 && joined; ++r) joined = hipStreamWaitEvent(s, plan->ev_done[i][r], 0) == hipSuccess;
             for (int i = 0; i < 7 && joined; ++i)
                 for (int r = 0; r < 2 && joined; ++r) joined = hipStreamWaitEvent(s, plan->ev_ring_done[i][r], 0) == hipSuccess;
         }
@@ -1049,9 +1058,15 @@ static int rollout_backward_sweep(pivp_plan_t* plan, const float* images, const 
         const float* prev = step_input(plan, t, images, gt_select, gen_images, fr);
         const float* st_prev = t == 0 ? states : gen_states + (size_t)(t - 1) * B * 5;
         // the ConvLSTM weight gradients: batches of wg_batch timesteps counted from the top of the sweep; t = 0 on its own
-        const int G = plan->wg_batch, k = T - 2 - t;
-        const int wg_b = t >= 1 ? k / G : (T - 2 + G - 1) / G, wg_slot = t >= 1 ? k % G : 0;
-        const bool wg_flush = t <= 1 || wg_slot == G - 1;
+        // With deep batches (G > 2: the bf16 mode's 8) the LAST TWO batched timesteps (t = 2, 1) form a batch of their own: one batch of everything
+        // is launched at t = 1, when two timesteps of main-stream work are left for 1.4 ms of weight gradients to hide behind -- the sweep then ended with
+        // the main stream waiting ~0.2 ms per step for the side stream (profiles/r05/NOTES.md).
+        const int G = plan->wg_batch, k = T - 2 - t, n = T - 2;
+        const int tail = (G > 2 && n > 2) ? 2 : 0, body = n - tail, nb_body = (body + G - 1) / G;
+        int wg_b, wg_slot; bool wg_flush;
+        if (t == 0) { wg_b = nb_body + (tail ? 1 : 0); wg_slot = 0; wg_flush = true; }
+        else if (k < body) { wg_b = k / G; wg_slot = k % G; wg_flush = wg_slot == G - 1 || k == body - 1; }
+        else { wg_b = nb_body; wg_slot = k - body; wg_flush = k == n - 1; }
         RC(backward_step(plan, t, prev, prev_has_grad && has_go, actions + (size_t)t * B * 5, st_prev, has_go, go, go_prev, last,
                          wg_b & 1, wg_slot, wg_flush, s));
         has_go = next_loss || (prev_has_grad && has_go);

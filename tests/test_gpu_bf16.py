@@ -373,7 +373,7 @@ def test_convlstm_bf16x6_is_fp32_grade(ops, B, cx, C, H, nch):
 
 
 def test_convlstm_bf16x6_first_step_and_narrow_maps(ops):
-    # t = 0 (no h operand: its K range is skipped) on a 16-wide map; an 8-wide map is not the three-piece kernel's: the call is the fp32 kernel's then
+    # t = 0 (no h operand: its K range is skipped) on a 16-wide map; 8-wide maps: tiles of two images (an even batch), an odd batch is refused
     x, h, c, W, b = [np.asarray(a, dtype=np.float32).astype(np.float64) for a in _case(2, 32, 32, 16, 5)]
     hr, cr, _ = _lstm_ref(x, h * 0, c, W, b)
     for nch in (16, 32):
@@ -395,11 +395,29 @@ def test_convlstm_bf16x6_first_step_and_narrow_maps(ops):
     import torch
     z = torch.zeros(1 << 20, device='cuda')
     rc = lib.pivp_convlstm_bf16x6(z.data_ptr(), 64, 64, z.data_ptr(), 128, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(),
-                                  None, None, 0, None, 2, 8, 8, 0, None)
-    assert rc == -1            # PIVP_ERR_BADARG: the per-op entry has no fp32 weights to fall back on (the plan does)
+                                  None, None, 0, None, 3, 8, 8, 0, None)
+    assert rc == -1            # PIVP_ERR_BADARG (8-wide map, odd batch): the per-op entry has no fp32 weights to fall back on (the plan does)
+    # 8-wide maps (lstm5 at 64 x 64 frames: 64 + 128 -> 128), both block widths, t = 0 too, and the LayerNorm partials of the two images of a tile
+    x8, h8, c8, W8, b8 = [np.asarray(a, dtype=np.float32).astype(np.float64) for a in _case(4, 64, 128, 8, 11)]
+    hr8, cr8, _ = _lstm_ref(x8, h8, c8, W8, b8)
+    hf8, cf8 = ops.convlstm(x8, h8, c8, W8, b8)
+    ef8 = max(np.abs(hf8 - hr8).max(), np.abs(cf8 - cr8).max())
+    for nch in (16, 32):
+        h6, c6, (p6, n6) = ops.convlstm_bf16x6(x8, h8, c8, W8, b8, nch=nch, want_ln=True)
+        e6 = max(np.abs(h6 - hr8).max(), np.abs(c6 - cr8).max())
+        print('8-wide map, %d-channel blocks: max |err| three-piece %.2e, fp32 kernel %.2e' % (nch, e6, ef8))
+        assert e6 < 2e-6 and e6 < 2.0 * ef8
+        assert n6 == 128 // nch
+        cnt = p6[:, :, 0].sum(axis=1)
+        mean = (p6[:, :, 0] * p6[:, :, 1]).sum(axis=1) / cnt
+        var = (p6[:, :, 2] + p6[:, :, 0] * (p6[:, :, 1] - mean[:, None]) ** 2).sum(axis=1) / cnt
+        assert np.allclose(cnt, 128 * 64) and np.allclose(mean, h6.reshape(4, -1).mean(axis=1), atol=1e-6) and np.allclose(var, h6.reshape(4, -1).var(axis=1), rtol=1e-4)
+    hr0, cr0, _ = _lstm_ref(x8, h8 * 0, c8, W8, b8)
+    h0, c0 = ops.convlstm_bf16x6(x8, h8, c8, W8, b8, h_is_zero=True)
+    assert np.abs(h0 - hr0).max() < 2e-6 and np.abs(c0 - cr0).max() < 2e-6
 
 
-@pytest.mark.parametrize('B,cin,cout,H', [(2, 128, 64, 32), (2, 256, 96, 16), (2, 256, 128, 16), (32, 256, 192, 16), (1, 128, 128, 32)])
+@pytest.mark.parametrize('B,cin,cout,H', [(2, 128, 64, 32), (2, 256, 96, 16), (2, 256, 128, 16), (32, 256, 192, 16), (1, 128, 128, 32), (4, 512, 192, 8), (32, 512, 192, 8)])    # 8-wide maps: tiles of two images (lstm5's data gradient)
 def test_conv5x5_bf16x6(ops, B, cin, cout, H):
     # the data gradients of the three-piece mode: 64-column blocks on the k-step ring, padded columns (96), K split over the channel groups (B = 32
     # on a 16 x 16 map: 64 tiles x 3 column blocks), against the float64 convolution and the fp32 kernel
@@ -436,7 +454,7 @@ def test_conv5x5_fp16x3(ops, B, cin, cout, H, scale):
     ref = R.conv2d(x, W, np.zeros(cout), 1, 2)
     unit = np.sqrt((ref ** 2).mean())
     e3 = (ops.conv5x5_bf16(x, W, pieces='fp16x3') - ref) / unit
-    ef = ((ops.conv5x5_bf16(x, W, pieces=3) if H % 16 == 0 else ops.conv5x5_bf16(x, W, pieces='fp16x3')) - ref) / unit        # the three-bf16-piece form it replaces in the fp16x3 mode's sweep (16-wide maps)
+    ef = (ops.conv5x5_bf16(x, W, pieces=3) - ref) / unit        # the three-bf16-piece form it replaces in the fp16x3 mode's sweep
     print('conv5x5 %d->%d @%d, x scale %s: two fp16 pieces max |err| %.2e rms %.2e of the output rms; three bf16 pieces max %.2e rms %.2e'
           % (cin, cout, H, scale, np.abs(e3).max(), np.sqrt((e3 ** 2).mean()), np.abs(ef).max(), np.sqrt((ef ** 2).mean())))
     assert np.abs(e3).max() < 2e-5 and np.sqrt((e3 ** 2).mean()) < 7e-7      # (observed up to 7.8e-6 / 5.3e-7; the K-split sums meet by atomic adds in any order)
@@ -560,7 +578,7 @@ def test_split_entry_points_refuse_what_they_cannot_serve():
     z = torch.zeros(1 << 22, device='cuda')
     p = z.data_ptr()
     # three bf16 pieces: 8-wide map (no fp32 weights to fall back on in the per-op call), channels not a multiple of 16, bad block code
-    assert lib.pivp_convlstm_bf16x6(p, 64, 64, p, 128, p, p, p, p, p, None, None, 0, None, 2, 8, 8, 0, None) == -1
+    assert lib.pivp_convlstm_bf16x6(p, 64, 64, p, 128, p, p, p, p, p, None, None, 0, None, 3, 8, 8, 0, None) == -1
     assert lib.pivp_convlstm_bf16x6(p, 32, 32, p, 24, p, p, p, p, p, None, None, 0, None, 2, 16, 16, 0, None) == -1
     assert lib.pivp_convlstm_bf16x6(p, 32, 32, p, 32, p, p, p, p, p, None, None, 0, None, 2, 16, 16, 7, None) == -1
     # two fp16 pieces: odd batch on an 8-wide map, map height not a multiple of 8, missing buffers
@@ -568,7 +586,7 @@ def test_split_entry_points_refuse_what_they_cannot_serve():
     assert lib.pivp_convlstm_fp16x3(p, 32, 32, p, 32, p, p, p, p, p, None, None, 0, None, 2, 12, 16, 0, None) == -1
     assert lib.pivp_convlstm_fp16x3(p, 32, 32, p, 32, None, p, p, p, p, None, None, 0, None, 2, 16, 16, 0, None) == -1
     assert lib.pivp_pack_lstm_fp16x3(p, p, 64, 32, 0, None) == -1
-    assert lib.pivp_conv5x5_bf16x6(p, 128, 128, p, p, p, 64, 64, 0, 2, 8, 8, None) == -1            # 8-wide map
+    assert lib.pivp_conv5x5_bf16x6(p, 128, 128, p, p, p, 64, 64, 0, 3, 8, 8, None) == -1            # 8-wide map and an odd batch
     assert lib.pivp_conv5x5_fp16x3(p, 128, 128, p, p, p, 64, 64, 0, 3, 8, 8, p, None) == -1         # 8-wide map and an odd batch
     assert lib.pivp_conv5x5_fp16x3(p, 128, 256, p, p, p, 64, 64, 0, 2, 16, 16, p, None) == -1       # x not contiguous: its maximum is taken over one span
     assert lib.pivp_conv5x5_fp16x3(p, 128, 128, p, p, p, 64, 64, 0, 2, 16, 16, None, None) == -1    # no scratch for x's maxima
