@@ -39,8 +39,8 @@ int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t strea
         return launch_x6g_plain<3, true>(dd, wb, stream, Np / 64, ks, d.N);
     if (planes == 3)     // three pieces (wb packed with planes = 3, plain = 1): 64-column blocks, weights from L2 into the operand registers, eight
         return launch_x6g_plain<3>(dd, wb, stream, Np / 64, ks, d.N);      // waves (the k-step-ring form of it measured 118 us per launch in the sweep against 100)
-    if (planes == -2 && d.Win % 16)     // ... on an 8-wide map (an even batch): the ring kernel's two-image tiles, wb packed with plain = 2
-        return launch_bf16<16, false, 2, true>(dd, wb, stream, nullptr, Np / 64, ks, d.N);
+    if (planes == -2 && d.Win % 16)     // ... on an 8-wide map (an even batch): tiles of two images
+        return launch_x6g_plain<2, true>(dd, wb, stream, Np / 64, ks, d.N);
     if (planes == -2)    // two fp16 pieces (wb packed with planes = -2, plain = 1; d.wscale_part = absmax_partials(d.x0): the activations' scale)
         return launch_x6g_plain<2>(dd, wb, stream, Np / 64, ks, d.N);
     if (planes == 2)     // split mode (wb packed with planes = 2): 128-column blocks run the two-slot schedule, 64-column ones the four-slot one

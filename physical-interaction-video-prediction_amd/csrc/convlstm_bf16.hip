@@ -54,20 +54,8 @@ __device__ __forceinline__ float x3_scale_of(const float* tail) {      // every 
 // fp32 K-inner packed weights [25][wcin/32][N][32] -> bf16 [ceil(wcin/64)][25][PL][Np][64], channels past wcin and rows past N zero.
 // PL = 1: plane 0 = bf16(w).  PL = 2 (split mode): plane 0 = hi = bf16(w), plane 1 = lo = bf16(w - hi).  PL = 3 (three pieces): plane 1 =
 // mid = bf16(w - hi), plane 2 = lo = bf16((w - hi) - mid); both differences are exact in fp32, so hi + mid + lo = w.
-// fp16 = 1 (PL = 2): the two planes are FP16 pieces of s w, s = the tensor's power-of-two scale from the partial maxima absmax_partials_kernel left
-// in the pack's tail (the ring kernel's form of the fp16x3 mode: the layers on 8-wide maps)
-__global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int N, int Np, int PL, long total, int fp16) {
+__global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wb, int wcin, int N, int Np, int PL, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    float wscale = 1.0f;
-    if (fp16) {
-        __shared__ float sc;
-        if (threadIdx.x == 0) {
-            sc = x3_scale_of(reinterpret_cast<const float*>(wb + total));
-            if (blockIdx.x == 0) reinterpret_cast<float*>(wb + total)[0] = sc;
-        }
-        __syncthreads();
-        wscale = sc;
-    }
     if (i >= total) return;
     const int c64 = (int)(i & 63);
     long r = i >> 6;
@@ -78,13 +66,6 @@ __global__ void pack_lstm_bf16_kernel(const float* __restrict__ w, unsigned shor
     const int ch = cg * 64 + c64;
     float v = 0.f;
     if (ch < wcin && n < N) v = w[(((long)tap * (wcin >> 5) + (ch >> 5)) * N + n) * 32 + (ch & 31)];
-    if (fp16) {
-        v = __builtin_fminf(__builtin_fmaxf(v * wscale, -65504.f), 65504.f);
-        _Float16 hh = (_Float16)v;
-        if (pl == 1) { v -= (float)hh; hh = (_Float16)v; }
-        wb[i] = __builtin_bit_cast(unsigned short, hh);
-        return;
-    }
     __bf16 h = (__bf16)v;
     if (pl >= 1) { v -= (float)h; h = (__bf16)v; }
     if (pl == 2) { v -= (float)h; h = (__bf16)v; }
@@ -245,11 +226,6 @@ int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStrea
     PIVP_CHECK_ARG(w && wb && wcin > 0 && wcin % 32 == 0 && N > 0 && Np >= N && ((planes >= 1 && planes <= 3) || planes == -2));
     const int pieces = planes == -2 ? 2 : planes;
     const long total = (long)lstm_bf16_weight_elems(wcin, Np) * pieces;
-    if (planes == -2 && plain == 2) {     // two fp16 pieces in the RING kernel's layout (layers on 8-wide maps: convlstm_bf16_kernel<NCH, true, 2, true>)
-        hipLaunchKernelGGL(absmax_partials_kernel, dim3(64), dim3(512), 0, s, w, (long)25 * wcin * N, reinterpret_cast<float*>(wb + total));
-        hipLaunchKernelGGL(pack_lstm_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, 2, total, 1);
-        return PIVP_LAUNCH_STATUS();
-    }
     if (planes == -2)        // the tensor's scale first: 64 partial maxima into the pack's tail
         hipLaunchKernelGGL(absmax_partials_kernel, dim3(64), dim3(512), 0, s, w, (long)25 * wcin * N, reinterpret_cast<float*>(wb + total));
     if (planes == 3 || planes == -2) {       // the three-piece kernels' fragment-major pack: the cell's (N = 4 C, gate-interleaved fragments) or a plain conv's
@@ -258,7 +234,7 @@ int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStrea
         hipLaunchKernelGGL(pack_lstm_x6_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, plain, pieces, nthreads);
         return PIVP_LAUNCH_STATUS();
     }
-    hipLaunchKernelGGL(pack_lstm_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, planes, total, 0);
+    hipLaunchKernelGGL(pack_lstm_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, planes, total);
     return PIVP_LAUNCH_STATUS();
 }
 
@@ -275,11 +251,10 @@ int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stre
         if ((nch == 32 && b32 > 0) || (nch == 0 && b32 >= pivp_cu_count())) return launch_x6g_w8<2, 4>(d, wb, stream, ln_nparts);
         return launch_x6g_w8<4, 2>(d, wb, stream, ln_nparts);
     }
-    if (planes == -2 && !convlstm_bf16x6_ok(d)) {   // 8-wide maps: the ring kernel with fp16 pieces (wb = pack_lstm_bf16(..., planes = -2, plain = 2))
-        const int tw2 = 8, ti2 = 2;
-        const long b32 = d.C % 32 ? 0 : (long)(d.B / ti2) * (d.Hin / TH) * (d.Win / tw2) * (d.C / 32);
-        (void)tw2; (void)ti2; (void)b32;      // 16-channel blocks only: with the second accumulator a 32-channel block would need 286 registers
-        return launch_bf16<16, true, 2, true>(d, wb, stream, ln_nparts, d.C / 16, 1, 0);
+    if (planes == -2 && !convlstm_bf16x6_ok(d)) {   // two fp16 pieces on an 8-wide map (an even batch): the L2-direct kernel on tiles of two images
+        const long b32 = d.C % 32 ? 0 : (long)(d.B / 2) * (d.Hin / TH) * (d.Win / 8) * (d.C / 32);
+        if ((nch == 32 && b32 > 0) || (nch == 0 && b32 >= pivp_cu_count())) return launch_x6g_w8<2, 4, 2>(d, wb, stream, ln_nparts);
+        return launch_x6g_w8<4, 2, 2>(d, wb, stream, ln_nparts);
     }
     if (planes == -2) {   // two fp16 pieces, three MFMAs per product (wb = pack_lstm_bf16(..., planes = -2)): the L2-direct kernel, 16-wide tiles
         PIVP_CHECK_ARG(convlstm_bf16x6_ok(d));

@@ -28,12 +28,10 @@ namespace pivp {
 // PL = 2: split mode.  Every fp32 operand travels as TWO bf16 numbers, hi = bf16(v) and lo = bf16(v - hi) (two patch planes, two weight
 // planes per ring slot), and a product a * b is formed as a_lo * b_hi + a_hi * b_lo + a_hi * b_hi on three MFMAs (each exact in fp32):
 // 16 bits of product mantissa instead of 8, 3e-5 instead of 2e-2 per-pixel on the config 1 rollout (scripts/split_bf16_study.py).
-// F16 (PL = 2, LSTM): the two planes are FP16 pieces (the weights times the power of two in the pack's tail, the sums scaled back): the fp16x3
-// mode's cell on maps this kernel's 8 x 8 tiles serve and the L2-direct kernel's 16-wide ones do not.
-template <int NCH, bool LSTM, int PL = 1, bool F16 = false>
+// (Round 4's fp16-piece form of this kernel -- the fp16x3 mode's layers on 8-wide maps -- went in round 5: the L2-direct kernel's two-image tiles
+// serve them at the same speed, convlstm_l2direct.h.)
+template <int NCH, bool LSTM, int PL = 1>
 __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d, const unsigned short* __restrict__ wb, int tw, int ncols) {
-    static_assert(!F16 || (PL == 2 && NCH == 16), "fp16 pieces: the split form, 16-channel / 64-column blocks");
-    // (F16 without LSTM: the data gradient on 8-wide maps; the activations -- gradients -- are staged times d.wscale_part's power of two, as in convlstm_x6g_kernel)
     constexpr int BN = 4 * NCH;                 // block columns: [gate][channel]
     constexpr int PLANE = BN * 128;             // one weight plane of a ring slot: BN rows x 64 bf16
     constexpr int SLOT = PL * PLANE;            // bytes of one ring slot
@@ -118,26 +116,11 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
             }
         }
     };
-    float a_scale = 1.0f;
-    if constexpr (F16 && !LSTM) a_scale = pivp_x3_scale_wave(d.wscale_part);
     auto patch_store = [&]() {
 #pragma unroll
         for (int j = 0; j < NPJ; ++j) {
             // unconditional (pixels past npix write their zeros into the padding behind row 0, which nobody reads): a predicated write
             // leaves the loads "pending" on the skipped path for hipcc's wait-count pass, which then drains vmcnt inside the tap loop
-            if constexpr (F16) {
-                float r[8] = {plo[j][0], plo[j][1], plo[j][2], plo[j][3], phi[j][0], phi[j][1], phi[j][2], phi[j][3]};
-                if constexpr (!LSTM) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) r[e] *= a_scale;
-                }
-                uint4 hh, ll;
-                hh.x = pivp_pack2h_rest(r[0], r[1]); hh.y = pivp_pack2h_rest(r[2], r[3]); hh.z = pivp_pack2h_rest(r[4], r[5]); hh.w = pivp_pack2h_rest(r[6], r[7]);
-                ll.x = pivp_pack2h_rest(r[0], r[1]); ll.y = pivp_pack2h_rest(r[2], r[3]); ll.z = pivp_pack2h_rest(r[4], r[5]); ll.w = pivp_pack2h_rest(r[6], r[7]);
-                *reinterpret_cast<uint4*>(patch + a_lds[j] + cpiece * 16) = hh;
-                *reinterpret_cast<uint4*>(patch + PB + a_lds[j] + cpiece * 16) = ll;
-                continue;
-            }
             uint4 v;
             v.x = pack2(plo[j][0], plo[j][1]); v.y = pack2(plo[j][2], plo[j][3]);
             v.z = pack2(phi[j][0], phi[j][1]); v.w = pack2(phi[j][2], phi[j][3]);
@@ -285,15 +268,6 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     bf16x8 fa[2][2], fb[2][TPW];                       // [register set][tile]
     bf16x8 fal[2][2], fbl[2][TPW];                     // ... and their second planes (split modes)
-    f32x16 accl[2][TPW];                               // F16: the two cross terms' accumulator
-    if constexpr (F16) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int t = 0; t < TPW; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) accl[mt][t][r] = 0.f;
-    }
     auto wait_frags = [&](auto SET) {
         constexpr int st = decltype(SET)::value;
         if constexpr (PL == 2 && TPW == 2) wait_lgkm(fa[st][0], fa[st][1], fb[st][0], fb[st][1], fal[st][0], fal[st][1], fbl[st][0], fbl[st][1]);
@@ -323,15 +297,6 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
-                if constexpr (F16) {
-                    auto h = [](const bf16x8& v) { return __builtin_bit_cast(pivp_f16x8, v); };
-                    // (the cross terms on their own accumulator: on ONE the three roundings per k-step over K = 4800 measured 1.56 x the fp32
-                    // kernel's rms error, with two it is at the L2-direct form's 0.95 x)
-                    accl[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fal[st][mt]), h(fb[st][t]), accl[mt][t], 0, 0, 0);
-                    accl[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[st][mt]), h(fbl[st][t]), accl[mt][t], 0, 0, 0);
-                    acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[st][mt]), h(fb[st][t]), acc[mt][t], 0, 0, 0);
-                    continue;
-                }
                 if constexpr (PL == 2) {               // the two cross terms first, the leading term last
                     acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[st][mt], fb[st][t], acc[mt][t], 0, 0, 0);
                     acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], fbl[st][t], acc[mt][t], 0, 0, 0);
@@ -426,17 +391,6 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         __builtin_amdgcn_sched_barrier(0);
     }
     }   // !LATE
-    if constexpr (F16) {           // the weights were packed times a power of two (the pack's tail, behind its [groups][25][2][N][64] elements)
-        float inv = 1.0f / *reinterpret_cast<const float*>(wb + (size_t)((d.wcin + 63) >> 6) * 25 * 2 * N * 64);      // (d.wcin: the pack's channels, also at t = 0)
-        if constexpr (!LSTM) inv *= 1.0f / a_scale;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int t = 0; t < TPW; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][t][r] = (acc[mt][t][r] + accl[mt][t][r]) * inv;
-    }
-
     if constexpr (!LSTM) {
         // ---- plain epilogue: accumulator row = anchor, column = output channel; 32 lanes write 128 contiguous bytes ----------
         // The epilogue hook's second tensor (d.ep_src) is requested for ALL of the lane's outputs first and met below: read next to each store
@@ -576,11 +530,11 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     }
 }
 
-template <int NCH, bool LSTM, int PL = 1, bool F16 = false>
+template <int NCH, bool LSTM, int PL = 1>
 static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nb, int ksplit, int ncols) {
     constexpr int lds_bytes = PL * patch_plane_bytes<PL>() + (ring_depth<NCH, PL>() + 1) * PL * 4 * NCH * 128;
     static PerDeviceOnce once;
-    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_bf16_kernel<NCH, LSTM, PL, F16>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
+    if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_bf16_kernel<NCH, LSTM, PL>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     IgemmDesc dd = d;
     const int tw = d.Win % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
     const int tpi = (d.Hin / TH) * (d.Win / tw);
@@ -589,7 +543,7 @@ static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
     const int blocks = (d.B / ti_n) * tpi * nb;
-    hipLaunchKernelGGL((convlstm_bf16_kernel<NCH, LSTM, PL, F16>), dim3(blocks, ksplit), dim3(512), lds_bytes, stream, dd, wb, tw, ncols);
+    hipLaunchKernelGGL((convlstm_bf16_kernel<NCH, LSTM, PL>), dim3(blocks, ksplit), dim3(512), lds_bytes, stream, dd, wb, tw, ncols);
     return PIVP_LAUNCH_STATUS();
 }
 

@@ -673,7 +673,7 @@ extern "C" int pivp_rollout_forward(pivp_plan_t* plan, const float* images, cons
         for (int i = 0; i < 7; ++i)
             RC(pack_lstm_bf16(P(plan, plan->i_lstm_w[i]), reinterpret_cast<unsigned short*>(plan->ws + plan->o_wbf16[i]),
                               kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C, s, 0, plan->lstm_planes,
-                              (plan->lstm_planes == -2 && lstm_w_of(plan, i) % 16) ? 2 : 0));      // (fp16 pieces on an 8-wide map: the ring kernel's layout)
+                              0));
     plan->packs_valid = 1;
     for (int t = 0; t < T - 1; ++t) {
         if (t >= ctx && gt_select)                                     // TM:667-670
@@ -839,6 +839,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     // front of the first kernel that rewrites its buffer, not here -- at the top of a timestep the side stream still has the previous
     // timestep's last launches (lstm1's and enc0's weight gradients) in front of it, and the main stream sat idle for ~40 us per timestep.
     SideFork fe;
+    const int encp = p->bf16_all ? 1 : 0;      // bf16 mode: the enc convs' weight gradients (and enc1's data gradient: the tile kernel) on bf16 operands too
     // ---- heads (TM:711-728) ----
     if (has_go) {
         if (c.model_type == PIVP_MODEL_CDNA)
@@ -866,7 +867,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         RC(join(7));       // d e6raw
         RC(lnb(8, ws + g.e6, 64, ws + S.e6, 64, ws + S.e6raw, ws + g.e6raw[par], 64 * HW, 64, 1));
         RC(run_conv_backward(1, ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), ws + g.e6raw[par], 64, 64, nullptr, 0, ws + g.wt_enc[6], ws + g.cat7, 64, 0,
-                             G(p, p->i_enc_w[6]), G(p, p->i_enc_b[6]), B, p->H2, p->W2, s, 1, fork_of(7, fe), ws + g.wg_part[0], &p->enc_desc[0]));
+                             G(p, p->i_enc_w[6]), G(p, p->i_enc_b[6]), B, p->H2, p->W2, s, 1, fork_of(7, fe), ws + g.wg_part[0], &p->enc_desc[0], nullptr, 0, encp));
     p->enc_desc_valid[0] = true;
     } else {
         // no gradient reaches this step's frame: only the recurrent paths are live
@@ -912,7 +913,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(join(11));          // enc1's dY lives in d cat6, which enc5's data gradient rewrites
     // group 5 (TM:600): d e5 = x-part of lstm7's d_in (ReLU fused in enc5) <- enc5 deconv <- [hidden6 | enc1]
     RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ep_ok6 ? nullptr : ws + S.e5, 96, ws + g.wt_enc[5], ws + g.cat6[par], 96, 0,
-                         G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1, fork_of(8, fe), ws + g.wg_part[1], &p->enc_desc[1]));
+                         G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1, fork_of(8, fe), ws + g.wg_part[1], &p->enc_desc[1], nullptr, 0, encp));
     p->enc_desc_valid[1] = true;
     RC(lnb_cell(5, ws + g.cat6[par], 96, n4, 64));
     RC(join(9));           // enc4's dY = the x part of lstm6's d_in of this parity
@@ -920,7 +921,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(done(2));
     // group 4 (TM:599): d e4 = x-part of lstm6's d_in <- enc4 deconv <- hidden5 (also read by the CDNA kernel generator)
     RC(run_conv_backward(1, ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), ws + g.din[5][par], 128, 192, ep_ok5 ? nullptr : ws + S.e4, 128, ws + g.wt_enc[4], ws + g.n5, 128, 1,
-                         G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s, 1, fork_of(9, fe), ws + g.wg_part[2], &p->enc_desc[2]));
+                         G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s, 1, fork_of(9, fe), ws + g.wg_part[2], &p->enc_desc[2], nullptr, 0, encp));
     p->enc_desc_valid[2] = true;
     RC(lnb_cell(4, ws + g.n5, 128, n8, 128));
     RC(lstmb(4, ws + S.e3, 64, p->H8, p->W8));
@@ -933,7 +934,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                       B, p->H8 * p->W8, c.use_state, s, 1));      // d e2 comes out masked by enc2's ReLU
     // group 2 (TM:597): enc2 conv (ReLU) <- hidden4 <- lstm4 <- hidden3 <- lstm3 <- enc1
     RC(run_conv_backward(0, ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), ws + g.e2[par], 64, 64, nullptr, 0, ws + g.wt_enc[2], ws + g.n4, 64, 0,
-                         G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s, 1, fork_of(10, fe), ws + g.wg_part[3], &p->enc_desc[3]));
+                         G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s, 1, fork_of(10, fe), ws + g.wg_part[3], &p->enc_desc[3], nullptr, 0, encp));
     p->enc_desc_valid[3] = true;
     RC(lnb_cell(3, ws + g.n4, 64, n4, 64));
     RC(lstmb(3, ws + S.n3, 64, p->H4, p->W4));      // its data gradient's x columns = the dy of hidden3
@@ -943,7 +944,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     // group 1 (TM:596): enc1 conv (ReLU) <- hidden2 <- lstm2 <- hidden1 <- lstm1 <- enc0
     RC(run_conv_backward(0, ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), ws + g.cat6[par] + 64, 32, 96, ws + S.cat6 + 64, 96, ws + g.wt_enc[1], ws + g.n2, 32, 0,
                          G(p, p->i_enc_w[1]), G(p, p->i_enc_b[1]), B, p->H2, p->W2, s, 1, fork_of(11, fe), ws + g.wg_part[4], &p->enc_desc[4],
-                         ws + g.din[2][par], 96));      // d enc1 = enc5's concat part (in d cat6) + lstm3's x gradient, summed in the ReLU-mask pass
+                         ws + g.din[2][par], 96, encp));      // d enc1 = enc5's concat part (in d cat6) + lstm3's x gradient, summed in the ReLU-mask pass
     p->enc_desc_valid[4] = true;
     RC(lnb_cell(1, ws + g.n2, 32, n2, 32));
     RC(lstmb(1, ws + S.n1, 32, p->H2, p->W2));      // ... of hidden1
@@ -1044,7 +1045,7 @@ static int rollout_backward_sweep(pivp_plan_t* plan, const float* images, const 
             const int cin = kLstm[i].cx + kLstm[i].C;
             RC(pack_lstm_bf16(ws + g.wt_lstm[i], reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]), 4 * kLstm[i].C, cin, s,
                               conv5x5_bf16_rows(cin), plan->bwd_planes,
-                              (plan->bwd_planes == -2 && lstm_w_of(plan, i) % 16) ? 2 : 1));      // (fp16 pieces on an 8-wide map: the ring kernel's layout)
+                              1));
         }
     bool has_go = false;
     for (int t = T - 2; t >= 0; --t) {
