@@ -40,7 +40,7 @@ extern "C" {
 #define PIVP_PRECISION_BF16X6 3
 #define PIVP_PRECISION_FP16X3 4
 
-int pivp_abi_version(void);   /* 15 (15: + pivp_conv_wgrad_partial_bf16; 14: + pivp_build_flags, pivp_plan_set_main_priority; 13: + pivp_wgrad5x5_bf16x6_batch; 12: + pivp_wgrad5x5_fp16x3_batch; 11: + pivp_conv5x5_fp16x3; 10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3, pivp_deconv3x3s2_fp16x3, pivp_plan_set_pack_cache, pivp_plan_params_changed; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+int pivp_abi_version(void);   /* 14 (14: + pivp_build_flags, pivp_plan_set_main_priority; 13: + pivp_wgrad5x5_bf16x6_batch; 12: + pivp_wgrad5x5_fp16x3_batch; 11: + pivp_conv5x5_fp16x3; 10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3, pivp_deconv3x3s2_fp16x3, pivp_plan_set_pack_cache, pivp_plan_params_changed; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
                                  5: + bf16 ConvLSTM, pivp_plan_set_precision, 6: + pivp_plan_set_group_join / pivp_plan_group_wait) */
 
 /* sha256 (hex) of the sources this library was compiled from (every .hip and .h under csrc/, and this header), embedded by build.py.  The Python
@@ -308,10 +308,6 @@ int pivp_conv_backward(int mode, const float* x, int cin, int ldx, const float* 
 long long pivp_conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin, int Win);
 int pivp_conv_wgrad_partial(int mode, const float* x, int cin, int ldx, const float* dy, int cout, int ldy, float* part,
                             float* dW, float* db, int B, int Hin, int Win, int repeats, void* stream);
-/* ... with x and dy rounded to bf16 on their way into the matrix pipe (v_mfma_f32_32x32x16_bf16 fed by transposing LDS reads; fp32 accumulation, partial
- * sums, reduction and bias gradient): the enc convs' weight gradients of PIVP_PRECISION_BF16's sweep (round 5) */
-int pivp_conv_wgrad_partial_bf16(int mode, const float* x, int cin, int ldx, const float* dy, int cout, int ldy, float* part,
-                                 float* dW, float* db, int B, int Hin, int Win, int repeats, void* stream);
 /* pivp_convlstm_backward for the sweep's last timestep (t = 0; TM:254-257: the state before it is zero and nothing reads its
  * gradient): only the cx columns of d_in (d x) are computed, the C columns of d h_{-1} are not computed (left as they are, or cleared). */
 int pivp_convlstm_backward_dx_only(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,

@@ -26,38 +26,15 @@ constexpr int WG_XP = WG_CI + 4;   // LDS pitches (floats); +4 keeps 16-B alignm
 
 // NT: 32-column MFMA tiles per wave; the block covers 64 input channels x 64*NT output columns.  NT = 1 for layers with at most
 // 64 output channels (enc1, enc2, enc6): with 128 columns half of the waves multiplied zero padding.
-// BF16 (round 5, the bf16 precision mode's enc convs: VERDICT r04 item 2a): the operands are rounded to bf16 on their way into LDS and multiplied on
-// v_mfma_f32_32x32x16_bf16 -- the reduction runs over PIXELS, so both operands need 8 consecutive pixels per lane out of pixel-major images:
-// gfx950's transposing LDS read (ds_read_b64_tr_b16, as in wgrad_bf16.hip) delivers them.  A 32-pixel chunk is two k-steps = 2 NT MFMAs per wave
-// instead of 16 NT fp32 ones, so these launches stop being fp32 matrix-pipe work beside the sweep's critical path.  fp32 accumulation, partial
-// sums, reduction and bias gradient (column sums taken in fp32 from the staging registers) as in the fp32 form.
-namespace {
-typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 wg_bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
-constexpr int WG_HP = 320;             // bf16 images: row pitch in bytes = 64 (mod 256), the transposing reads' conflict-free pitch; holds up to 128 columns
-__device__ __forceinline__ unsigned wg_pack2(float a, float b) {
-    wg_f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wg_bf16x2));
-}
-template <int OFF>
-__device__ __forceinline__ wg_bf16x4 wg_read_tr(unsigned addr) {     // 4 rows x 16 columns of 16-bit elements, transposed: this lane's column, the 4 rows
-    wg_bf16x4 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-}  // namespace
-template <int NT, bool BF16 = false>
+template <int NT>
 __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) {
     constexpr int WG_N = 64 * NT;      // output columns per block
     constexpr int WG_YP = WG_N + 4;
     constexpr int YL = 16 * NT;        // float4 lanes per dY row
     constexpr int YRP = 256 / YL;      // dY rows per staging pass
     constexpr int NYL = WG_PIX / YRP;  // passes
-    // fp32: [32 pixels][channels + 4] float images; BF16: [32 pixels] rows of WG_HP bytes (the X image in xs, the dY image in ys)
-    __shared__ __attribute__((aligned(16))) float xs[2][BF16 ? WG_PIX * WG_HP / 4 : WG_PIX * WG_XP];
-    __shared__ __attribute__((aligned(16))) float ys[2][BF16 ? WG_PIX * WG_HP / 4 : WG_PIX * WG_YP];
+    __shared__ __attribute__((aligned(16))) float xs[2][WG_PIX * WG_XP];
+    __shared__ __attribute__((aligned(16))) float ys[2][WG_PIX * WG_YP];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;             // wave tile: 32 ci x 32*NT n
@@ -151,27 +128,9 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
             rY[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0));
         }
     };
-    f32x4 bsum4 = {0.f, 0.f, 0.f, 0.f};      // BF16: this thread's fp32 column sums of the dY values it staged (columns n0 + yc .. + 3)
-    const bool bias_blk = d.db != nullptr && cb == 0;      // (the tap test is at the end)
     auto store = [&](auto SET, int buf) {
         const f32x4 (&rx)[2] = rxs[decltype(SET)::value];
         const f32x4 (&rY)[NYL] = rYs[decltype(SET)::value];
-        if constexpr (BF16) {
-            unsigned char* xb = reinterpret_cast<unsigned char*>(xs[buf]);
-            unsigned char* yb = reinterpret_cast<unsigned char*>(ys[buf]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                uint2 v; v.x = wg_pack2(rx[j][0], rx[j][1]); v.y = wg_pack2(rx[j][2], rx[j][3]);
-                *reinterpret_cast<uint2*>(xb + (xr + 16 * j) * WG_HP + xc * 2) = v;
-            }
-#pragma unroll
-            for (int j = 0; j < NYL; ++j) {
-                if (bias_blk) bsum4 += rY[j];
-                uint2 v; v.x = wg_pack2(rY[j][0], rY[j][1]); v.y = wg_pack2(rY[j][2], rY[j][3]);
-                *reinterpret_cast<uint2*>(yb + (yr + YRP * j) * WG_HP + yc * 2) = v;
-            }
-            return;
-        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(&xs[buf][(xr + 16 * j) * WG_XP + xc]) = rx[j];
 #pragma unroll
@@ -194,36 +153,7 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
     for (int t = 0; t < NT; ++t) bsum[t] = 0.f;
     if (c_begin < c_end) {
         using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
-        // BF16: transposing read j (0, 1) of k-step s: lane (group g = lane / 16, q = (lane % 16) / 4, p = lane % 4) supplies the address of pixel
-        // k = 16 s + 8 (g / 2) + 4 j + q, columns 16 (g % 2) + 4 p .. + 3 of the operand's 32 (wgrad_bf16.hip); A = X (rows = ci), B = dY (columns = n)
-        const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-        const unsigned xs0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&xs[0][0];
-        const unsigned ys0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&ys[0][0];
-        const unsigned ta = (8 * (tg >> 1) + tq) * WG_HP + (wm * 32 + 16 * (tg & 1) + 4 * tp) * 2;
-        const unsigned tb = (8 * (tg >> 1) + tq) * WG_HP + (wn * 32 * NT + 16 * (tg & 1) + 4 * tp) * 2;
         auto mma = [&](int buf) {
-            if constexpr (BF16) {
-                constexpr int BUFB = (int)sizeof(xs[0]);
-                const unsigned xa = xs0 + buf * BUFB + ta, ya = ys0 + buf * BUFB + tb;
-                wg_bf16x4 a00 = wg_read_tr<0>(xa), a01 = wg_read_tr<4 * WG_HP>(xa), a10 = wg_read_tr<16 * WG_HP>(xa), a11 = wg_read_tr<20 * WG_HP>(xa);
-                wg_bf16x4 b0[NT][2], b1[NT][2];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    b0[t][0] = wg_read_tr<0>(ya + t * 64); b0[t][1] = wg_read_tr<4 * WG_HP>(ya + t * 64);
-                    b1[t][0] = wg_read_tr<16 * WG_HP>(ya + t * 64); b1[t][1] = wg_read_tr<20 * WG_HP>(ya + t * 64);
-                }
-                // (inline asm: the wait is explicit and tied to the fragments so that no MFMA moves above it)
-                if constexpr (NT == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11), "+v"(b0[0][0]), "+v"(b0[0][1]), "+v"(b1[0][0]), "+v"(b1[0][1]));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11), "+v"(b0[0][0]), "+v"(b0[0][1]), "+v"(b1[0][0]), "+v"(b1[0][1]),
-                                  "+v"(b0[NT - 1][0]), "+v"(b0[NT - 1][1]), "+v"(b1[NT - 1][0]), "+v"(b1[NT - 1][1]));
-                const wg_bf16x8 fa0 = __builtin_shufflevector(a00, a01, 0, 1, 2, 3, 4, 5, 6, 7), fa1 = __builtin_shufflevector(a10, a11, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, __builtin_shufflevector(b0[t][0], b0[t][1], 0, 1, 2, 3, 4, 5, 6, 7), acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, __builtin_shufflevector(b1[t][0], b1[t][1], 0, 1, 2, 3, 4, 5, 6, 7), acc[t], 0, 0, 0);
-                }
-                return;
-            }
             const float* X = &xs[buf][wm * 32 + l31];
             const float* Y = &ys[buf][wn * 32 * NT + l31];
 #pragma unroll
@@ -254,19 +184,7 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
         }
         if (c < c_end) mma(0);
     }
-    if (BF16 && bias_blk && (d.deconv ? (tap == 4 || tap == 5 || tap == 7 || tap == 8) : tap == 0)) {
-        // threads tid % YL share the columns n0 + 4 (tid % YL) .. + 3: inside a wave the lanes l, l + YL, ... pair up first
-        f32x4 v = bsum4;
-#pragma unroll
-        for (int o = 32; o >= YL; o >>= 1)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], o, 64);
-        if (lane < YL) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (n0 + yc + e < d.N) atomicAdd(d.db + n0 + yc + e, v[e]);
-        }
-    }
-    if (!BF16 && do_bias) {
+    if (do_bias) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const float v = bsum[t] + __shfl_xor(bsum[t], 32, 64);
@@ -617,11 +535,6 @@ int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done) {
     WgradDesc dd = d;
     if (!bias_here) dd.db = nullptr;
     if (bias_done) *bias_done = bias_here ? 1 : 0;
-    if (d.bf16_operands) {      // the bf16 precision mode's enc convs (rounded operands, fp32 accumulation)
-        if (wg_n == 64) hipLaunchKernelGGL((igemm_wgrad_kernel<1, true>), dim3(tiles, nsplit), dim3(256), 0, s, dd);
-        else hipLaunchKernelGGL((igemm_wgrad_kernel<2, true>), dim3(tiles, nsplit), dim3(256), 0, s, dd);
-        return PIVP_LAUNCH_STATUS();
-    }
     if (wg_n == 64) hipLaunchKernelGGL(igemm_wgrad_kernel<1>, dim3(tiles, nsplit), dim3(256), 0, s, dd);
     else hipLaunchKernelGGL(igemm_wgrad_kernel<2>, dim3(tiles, nsplit), dim3(256), 0, s, dd);
     return PIVP_LAUNCH_STATUS();

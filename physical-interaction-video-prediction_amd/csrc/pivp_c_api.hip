@@ -267,10 +267,8 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
     d.part = part;
     d.dy_absmax = dy_absmax; d.dy_absmax_stride = dy_absmax_stride;
     d.pieces = bf16 == 3 ? 3 : 0;       // (bf16: 1 = operands rounded to bf16; 3 = three bf16 pieces per operand, fp32-grade)
-    const bool lstm5x5 = !mode && ksize == 5 && pad == 2 && stride == 1;
-    d.bf16_operands = (bf16 == 1 && !lstm5x5) ? 1 : 0;      // the enc convs' weight gradients in the bf16 mode: the generic kernel's bf16 form
     if (desc_out) *desc_out = d;
-    if ((bf16 || dy_absmax) && lstm5x5) {   // precision modes, the 5x5 ConvLSTM case: operands rounded to bf16 (or as pieces), fp32 accumulation; db summed on the side in fp32
+    if (bf16 || dy_absmax) {   // bf16 precision mode (5x5 ConvLSTM case only): operands rounded to bf16, fp32 accumulation; db summed on the side in fp32
         if (bias_done) *bias_done = db != nullptr;
         return wgrad5x5_bf16(d, s);
     }
@@ -387,7 +385,7 @@ int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w
         if (rc != PIVP_OK) return rc;
     }
     int bias_done = 0;     // the weight-gradient kernel sums dY's columns on the side when it can
-    rc = run_wgrad(mode, x, cin, ldx, nullptr, 0, 0, cin, dy, ldy, cout, dW, B, Hin, Win, Hout, Wout, 3, 1, 2, sw, db, &bias_done, prec == 1 ? 1 : 0,
+    rc = run_wgrad(mode, x, cin, ldx, nullptr, 0, 0, cin, dy, ldy, cout, dW, B, Hin, Win, Hout, Wout, 3, 1, 2, sw, db, &bias_done, 0,
                    1, 0, 0, 0, part, desc_out);
     if (rc != PIVP_OK) return rc;
     if (!bias_done) { rc = bias_grad(dy, ldy, cout, B * Hout * Wout, db, sw); if (rc != PIVP_OK) return rc; }
@@ -414,7 +412,7 @@ extern "C" const char* pivp_build_digest(void) { return PIVP_BUILD_DIGEST; }
 #define PIVP_BUILD_FLAGS ""                // the compile flags beyond build.py's standard set (PIVP_EXTRA_FLAGS): "" = the product build
 #endif
 extern "C" const char* pivp_build_flags(void) { return PIVP_BUILD_FLAGS; }
-extern "C" int pivp_abi_version(void) { return 15; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
+extern "C" int pivp_abi_version(void) { return 14; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
 
 extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                              const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream) {
@@ -455,28 +453,19 @@ extern "C" long long pivp_conv_backward_part_floats(int mode, int cin, int cout,
     if (mode < 0 || mode > 1 || cin <= 0 || cout <= 0 || B <= 0 || Hin <= 0 || Win <= 0) return PIVP_ERR_BADARG;
     return conv_backward_part_floats(mode, cin, cout, B, Hin, Win);
 }
-static int conv_wgrad_partial(int mode, const float* x, int cin, int ldx, const float* dy, int cout, int ldy, float* part,
-                              float* dW, float* db, int B, int Hin, int Win, int repeats, void* stream, int bf16) {
+extern "C" int pivp_conv_wgrad_partial(int mode, const float* x, int cin, int ldx, const float* dy, int cout, int ldy, float* part,
+                                       float* dW, float* db, int B, int Hin, int Win, int repeats, void* stream) {
     if (!x || !dy || !part || !dW || !db || mode < 0 || mode > 1 || repeats < 1) return PIVP_ERR_BADARG;
     const int Hout = mode ? 2 * Hin : Hin / 2, Wout = mode ? 2 * Win : Win / 2;
     WgradDesc desc;
     for (int r = 0; r < repeats; ++r) {
         int bias_done = 0;
         int rc = run_wgrad(mode, x, cin, ldx, nullptr, 0, 0, cin, dy, ldy, cout, dW, B, Hin, Win, Hout, Wout, 3, 1, 2, (hipStream_t)stream, db,
-                           &bias_done, bf16, 1, 0, 0, 0, part, &desc);
+                           &bias_done, 0, 1, 0, 0, 0, part, &desc);
         if (rc != PIVP_OK) return rc;
         if (!bias_done) { rc = bias_grad(dy, ldy, cout, B * Hout * Wout, db, (hipStream_t)stream); if (rc != PIVP_OK) return rc; }
     }
     return igemm_wgrad_reduce(desc, (hipStream_t)stream);
-}
-extern "C" int pivp_conv_wgrad_partial(int mode, const float* x, int cin, int ldx, const float* dy, int cout, int ldy, float* part,
-                                       float* dW, float* db, int B, int Hin, int Win, int repeats, void* stream) {
-    return conv_wgrad_partial(mode, x, cin, ldx, dy, cout, ldy, part, dW, db, B, Hin, Win, repeats, stream, 0);
-}
-// ... with the operands rounded to bf16 on their way into the matrix pipe (fp32 accumulation, partial sums and bias gradient): the bf16 precision mode's form
-extern "C" int pivp_conv_wgrad_partial_bf16(int mode, const float* x, int cin, int ldx, const float* dy, int cout, int ldy, float* part,
-                                            float* dW, float* db, int B, int Hin, int Win, int repeats, void* stream) {
-    return conv_wgrad_partial(mode, x, cin, ldx, dy, cout, ldy, part, dW, db, B, Hin, Win, repeats, stream, 1);
 }
 // pivp_convlstm_backward for the sweep's LAST timestep (t = 0): nobody reads d h_{-1}, so only the cx columns of d_in are computed
 // (the data gradient runs on the first cx columns of the transposed weight pack) and the h columns of d_in are not computed (left as they are, or cleared with the rest of d_in for a K-split data gradient).

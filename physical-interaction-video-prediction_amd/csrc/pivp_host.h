@@ -65,8 +65,9 @@ int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w
                       float* wt, float* dx, int lddx, int accum_dx, float* dW, float* db, int B, int Hin, int Win, hipStream_t s,
                       int wt_ready = 0, const SideFork* fork = nullptr, float* part = nullptr, WgradDesc* desc_out = nullptr,
                       const float* dy_add = nullptr, int ld_add = 0,    // dy_add: a second gradient into the same output, added in the ReLU-mask pass
-                      int prec = 0);                                    // 1 (the bf16 precision mode): operands of the weight gradient, and of the data gradient where the
-                                                                        // transposed conv's tile kernel takes it, rounded to bf16 (fp32 accumulation)
+                      int prec = 0);                                    // 1 (the bf16 precision mode): the data gradient's operands rounded to bf16 where the transposed
+                                                                        // conv's tile kernel takes it (enc1's); the weight gradient stays fp32 (its bf16 form -- transposing
+                                                                        // LDS reads, 2 MFMAs per 32-pixel chunk -- was built and is slower: profiles/r05/NOTES.md)
 // floats of WgradDesc::part a conv3x3s2 (mode 0) / deconv3x3s2 (mode 1) weight gradient of these sizes needs
 long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin, int Win);
 int run_layernorm(const float* x, const float* g, const float* b, float* out, float* partials, int B, int n, int C,

@@ -839,7 +839,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     // front of the first kernel that rewrites its buffer, not here -- at the top of a timestep the side stream still has the previous
     // timestep's last launches (lstm1's and enc0's weight gradients) in front of it, and the main stream sat idle for ~40 us per timestep.
     SideFork fe;
-    const int encp = p->bf16_all ? 1 : 0;      // bf16 mode: the enc convs' weight gradients (and enc1's data gradient: the tile kernel) on bf16 operands too
+    const int encp = p->bf16_all ? 1 : 0;      // bf16 mode: enc1's data gradient (the transposed conv's tile kernel) on bf16 operands too
     // ---- heads (TM:711-728) ----
     if (has_go) {
         if (c.model_type == PIVP_MODEL_CDNA)
