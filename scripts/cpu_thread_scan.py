@@ -4,7 +4,7 @@ import numpy as np, torch
 sys.path.insert(0, 'scripts')
 from cpu_baseline import rollout_rate
 for B in (2, 32):
-    for th in (1, 4, 8, 16, 32, 64):
+    for th in (1, 4, 8, 16, 32, 64, 128, 256):
         torch.set_num_threads(th)
         r, n = rollout_rate(B, 10, 6.0)
         print('B=%d threads=%d rollout %.1f frames/s (%d calls)' % (B, th, r, n), flush=True)
