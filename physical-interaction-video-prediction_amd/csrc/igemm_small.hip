@@ -23,19 +23,15 @@ constexpr int TILE = 32 * SP;
 }
 
 // NTB: 32-column tiles per block (the A fragment is reused NTB times; fewer, longer-running blocks).
-// G (round 5): K chunks per STAGE.  With one chunk per stage a block's life is nchunks x (loads in flight -> LDS -> barrier -> 4 NTB MFMAs): 9-36 barriers
-// for kernels of 6-14 us whose matrix-pipe share is 0.05-0.19 (profiles/r04/roofline_table.md) -- they run at the latency of that chain.  G chunks are
-// loaded, stored and multiplied together: a third or a quarter of the barriers and G times the loads in flight per round trip.  The chunk sequence, the
-// per-wave k ranges and the order of a wave's MFMAs are unchanged, so results are bit-identical to G = 1.  The launcher takes the largest G (<= 4) that
-// divides every phase's chunk count and keeps the stage images inside 96 KB.
-template <int NTB, bool IN_LN = false, int G = 1>
+template <int NTB, bool IN_LN = false>
 __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     const int bx = blockIdx.x, by = blockIdx.y, gdy = gridDim.y;
     PIVP_SET_MAIN_PRIO();
     constexpr int BN = 32 * NTB;
     constexpr int RP = BN + 4;                                    // row pitch of the partial-sum image
-    constexpr int A_OFF = 0, B_OFF = 2 * G * TILE;                // A[buffer][g] | B[buffer][g][NTB tiles]
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // max(stage images, partial-sum image): igemm_small_lds_bytes
+    constexpr int A_OFF = 0, B_OFF = 2 * TILE;                    // A0 A1 | B0 B1 (NTB tiles each)
+    constexpr int STAGE_FLOATS = 2 * TILE + 2 * NTB * TILE, RED_FLOATS = 4 * 32 * RP;
+    __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -86,13 +82,11 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     }
     int l_cc = 0, l_ty = 0, l_tx = 0;
     // two register sets: chunk i+2 is loaded while chunk i is multiplied and written to LDS at the end of chunk i+1
-    f32x4 ras[2][G], rbs[2][G][NTB];
-    f32x4 rgs[2][IN_LN ? G : 1], rbe[2][IN_LN ? G : 1];              // in_ln: gamma / beta of the staged float4
-    auto load_next = [&](auto SET) {   // the stage's G chunks from (l_ty, l_tx, l_cc) on -> register set SET, advancing
-#pragma unroll
-      for (int gi = 0; gi < G; ++gi) {
-        f32x4& ra = ras[decltype(SET)::value][gi];
-        f32x4 (&rb)[NTB] = rbs[decltype(SET)::value][gi];
+    f32x4 ras[2], rbs[2][NTB];
+    f32x4 rgs[2], rbe[2];              // in_ln: gamma / beta of the staged float4
+    auto load_next = [&](auto SET) {   // chunk (l_ty, l_tx, l_cc) -> register set SET, then advance
+        f32x4& ra = ras[decltype(SET)::value];
+        f32x4 (&rb)[NTB] = rbs[decltype(SET)::value];
         int dy, dx, wi;
         if (deconv) {
             const int ky = py ? 2 * l_ty : 1, kx = px ? 2 * l_tx : 1;
@@ -112,29 +106,25 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
                                              : __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
         if constexpr (IN_LN) {         // element (iy, ix, channel) of the sample: [Hin*Win][c0]
             const unsigned goff = ok ? (unsigned)(((iy * d.Win + ix) * d.c0 + ch + cvec * 4) * 4) : OOB;
-            rgs[decltype(SET)::value][gi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, goff, 0, 0));
-            rbe[decltype(SET)::value][gi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, goff, 0, 0));
+            rgs[decltype(SET)::value] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, goff, 0, 0));
+            rbe[decltype(SET)::value] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, goff, 0, 0));
         }
 #pragma unroll
         for (int t = 0; t < NTB; ++t) rb[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, b_goff[t], wbase, 0));
         if (++l_cc == ncc) { l_cc = 0; if (++l_tx == ntx) { l_tx = 0; ++l_ty; } }
-      }
     };
     auto store_regs = [&](auto SET, int buf) {
-#pragma unroll
-      for (int gi = 0; gi < G; ++gi) {
-        f32x4 ra = ras[decltype(SET)::value][gi];
-        const f32x4 (&rb)[NTB] = rbs[decltype(SET)::value][gi];
+        f32x4 ra = ras[decltype(SET)::value];
+        const f32x4 (&rb)[NTB] = rbs[decltype(SET)::value];
         if constexpr (IN_LN) {
             const float mean = in_stat[0], rstd = in_stat[1];
-            const f32x4 g = rgs[decltype(SET)::value][gi], be = rbe[decltype(SET)::value][gi];
+            const f32x4 g = rgs[decltype(SET)::value], be = rbe[decltype(SET)::value];
 #pragma unroll
             for (int e = 0; e < 4; ++e) ra[e] = (ra[e] - mean) * rstd * g[e] + be[e];
         }
-        *reinterpret_cast<f32x4*>(lds + A_OFF + (buf * G + gi) * TILE + lds_w) = ra;
+        *reinterpret_cast<f32x4*>(lds + A_OFF + buf * TILE + lds_w) = ra;
 #pragma unroll
-        for (int t = 0; t < NTB; ++t) *reinterpret_cast<f32x4*>(lds + B_OFF + ((buf * G + gi) * NTB + t) * TILE + lds_w) = rb[t];
-      }
+        for (int t = 0; t < NTB; ++t) *reinterpret_cast<f32x4*>(lds + B_OFF + (buf * NTB + t) * TILE + lds_w) = rb[t];
     };
 
     f32x16 acc[NTB];
@@ -144,39 +134,35 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int frag = l31 * SP + 8 * wave + 4 * half;   // k-group `wave` of row l31
 
-    const int nstages = nchunks / G;                // (the launcher picks a G that divides every phase's chunk count)
-    if (nstages > 0) {
+    if (nchunks > 0) {
         using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
         auto mma = [&](int buf) {
+            const f32x4 fa = *reinterpret_cast<const f32x4*>(lds + A_OFF + buf * TILE + frag);
+            f32x4 fb[NTB];
 #pragma unroll
-            for (int gi = 0; gi < G; ++gi) {
-                const f32x4 fa = *reinterpret_cast<const f32x4*>(lds + A_OFF + (buf * G + gi) * TILE + frag);
-                f32x4 fb[NTB];
+            for (int t = 0; t < NTB; ++t) fb[t] = *reinterpret_cast<const f32x4*>(lds + B_OFF + (buf * NTB + t) * TILE + frag);
 #pragma unroll
-                for (int t = 0; t < NTB; ++t) fb[t] = *reinterpret_cast<const f32x4*>(lds + B_OFF + ((buf * G + gi) * NTB + t) * TILE + frag);
+            for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-                    for (int t = 0; t < NTB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s2], fb[t][s2], acc[t], 0, 0, 0);
-            }
+                for (int t = 0; t < NTB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s2], fb[t][s2], acc[t], 0, 0, 0);
         };
         load_next(S0{});
         if constexpr (IN_LN) __syncthreads();   // in_stat
         store_regs(S0{}, 0);
-        if (nstages > 1) load_next(S1{});
+        if (nchunks > 1) load_next(S1{});
         __syncthreads();
         int it = 0;
-        for (; it + 1 < nstages; it += 2) {     // stages it (LDS buffer 0) and it+1 (buffer 1)
-            if (it + 2 < nstages) load_next(S0{});
+        for (; it + 1 < nchunks; it += 2) {     // chunks it (LDS buffer 0) and it+1 (buffer 1)
+            if (it + 2 < nchunks) load_next(S0{});
             mma(0);
-            store_regs(S1{}, 1);                // stage it+1
+            store_regs(S1{}, 1);                // chunk it+1
             __syncthreads();
-            if (it + 3 < nstages) load_next(S1{});
+            if (it + 3 < nchunks) load_next(S1{});
             mma(1);
-            if (it + 2 < nstages) store_regs(S0{}, 0);
+            if (it + 2 < nchunks) store_regs(S0{}, 0);
             __syncthreads();
         }
-        if (it < nstages) mma(0);               // odd count: the last stage sits in buffer 0
+        if (it < nchunks) mma(0);               // odd count: the last chunk sits in buffer 0
         __syncthreads();
     }
 
@@ -236,28 +222,6 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     }
 }
 
-// bytes of LDS the kernel needs: the stage images (two buffers of G chunks: one A tile + NTB B tiles each) or the four waves' partial-sum image
-static constexpr int igemm_small_lds_bytes(int ntb, int g) {
-    const int stage = 2 * g * TILE * (1 + ntb), red = 4 * 32 * (32 * ntb + 4);
-    return (stage > red ? stage : red) * 4;
-}
-template <int NTB, bool IN_LN, int G>
-static int launch_small(const IgemmDesc& dd, dim3 grid, hipStream_t stream) {
-    constexpr int bytes = igemm_small_lds_bytes(NTB, G);
-    static_assert(bytes <= 96 * 1024, "stage images");
-    static PerDeviceOnce once;
-    if (bytes > 64 * 1024 && pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&igemm_small_kernel<NTB, IN_LN, G>), bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
-    hipLaunchKernelGGL((igemm_small_kernel<NTB, IN_LN, G>), grid, dim3(256), bytes, stream, dd);
-    return PIVP_LAUNCH_STATUS();
-}
-template <int NTB, bool IN_LN>
-static int launch_small_g(const IgemmDesc& dd, dim3 grid, hipStream_t stream, int g) {
-    if constexpr (NTB == 1) { if (g == 4) return launch_small<NTB, IN_LN, 4>(dd, grid, stream); }
-    if constexpr (NTB <= 2) { if (g == 3) return launch_small<NTB, IN_LN, 3>(dd, grid, stream); }
-    if (g == 2) return launch_small<NTB, IN_LN, 2>(dd, grid, stream);
-    return launch_small<NTB, IN_LN, 1>(dd, grid, stream);
-}
-
 // d has been validated by igemm_validate (igemm_f32.hip); additionally needs 16-B aligned out / bias rows.
 int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     PIVP_CHECK_ARG(d.ldo % 4 == 0 && ((uintptr_t)d.out & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0));
@@ -274,21 +238,17 @@ int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     dd.ln_nparts = (d.ln_part && hwg % 32 == 0 && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
-    // chunks per stage: the largest G <= 4 that divides every phase's chunk count (conv: k^2 ncc; transposed conv: 1 / 2 / 2 / 4 taps x ncc -> G | ncc)
-    // with G (1 + ntb) <= 10 tiles per buffer (92 KB of stage images at most) and, for the LayerNorm-on-load form, G <= 3 (its gamma / beta registers)
-    const int ncc = (d.c0 + d.c1) >> 5, unit = d.deconv ? ncc : d.ksize * d.ksize * ncc;
-    int g = 1;
-    for (int c = 4; c >= 2; --c)
-        if (unit % c == 0 && c * (1 + ntb) <= 10 && !(d.in_g && c > 3) && !(ntb == 2 && c > 3) && !(ntb == 3 && c > 2)) { g = c; break; }
     if (d.in_g) {      // LayerNorm-on-load (see IgemmDesc::in_g): one sample per tile, one source, a plain conv
         PIVP_CHECK_ARG(igemm_in_ln_ok(d) && d.in_b && d.in_part && d.in_np > 0);
-        if (ntb == 3) return launch_small_g<3, true>(dd, grid, stream, g);
-        if (ntb == 2) return launch_small_g<2, true>(dd, grid, stream, g);
-        return launch_small_g<1, true>(dd, grid, stream, g);
+        if (ntb == 3) hipLaunchKernelGGL((igemm_small_kernel<3, true>), grid, dim3(256), 0, stream, dd);
+        else if (ntb == 2) hipLaunchKernelGGL((igemm_small_kernel<2, true>), grid, dim3(256), 0, stream, dd);
+        else hipLaunchKernelGGL((igemm_small_kernel<1, true>), grid, dim3(256), 0, stream, dd);
+        return PIVP_LAUNCH_STATUS();
     }
-    if (ntb == 3) return launch_small_g<3, false>(dd, grid, stream, g);
-    if (ntb == 2) return launch_small_g<2, false>(dd, grid, stream, g);
-    return launch_small_g<1, false>(dd, grid, stream, g);
+    if (ntb == 3) hipLaunchKernelGGL(igemm_small_kernel<3>, grid, dim3(256), 0, stream, dd);
+    else if (ntb == 2) hipLaunchKernelGGL(igemm_small_kernel<2>, grid, dim3(256), 0, stream, dd);
+    else hipLaunchKernelGGL(igemm_small_kernel<1>, grid, dim3(256), 0, stream, dd);
+    return PIVP_LAUNCH_STATUS();
 }
 
 // geometry the LayerNorm-on-load form serves: a conv (not the 4-phase transposed form) on one source whose rows are exactly the c0
