@@ -6,8 +6,6 @@ sys.path.insert(0, '.')
 import pivp_amd
 from pivp_amd import _lib
 X6 = os.environ.get('PIVP_STAMP_MODE', '1') == '6'      # the three-piece kernel (16-channel blocks, 16-wide maps)
-if os.environ.get('PIVP_BENCH_LIB'):                    # a stamped variant build shipped next to the library (scripts/r04/build_x6_variants.sh)
-    _lib.LIB_PATH = os.path.abspath(os.environ['PIVP_BENCH_LIB'])
 lib = _lib.load()
 so = ctypes.CDLL(_lib.LIB_PATH)
 dev = 'cuda:0'; B = 32

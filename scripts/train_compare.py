@@ -1,6 +1,6 @@
 """The same 150 Adam steps (config 2's shapes at B = 8: CDNA, T = 10, 64 x 64, random-init weights, one fixed synthetic batch, feed-self) in the fp32
 kernels and in the split modes: do the loss curves of fp32-grade arithmetic stay together?  (A train step's gradient is within 5e-5 of the fp32 kernels';
-this asks what 150 optimizer steps make of that.)   python scripts/r04/train_compare.py [steps]"""
+this asks what 150 optimizer steps make of that.)   python scripts/train_compare.py [steps]"""
 import sys
 import numpy as np
 import torch
