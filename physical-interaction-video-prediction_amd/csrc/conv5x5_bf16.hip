@@ -15,7 +15,7 @@ int conv5x5_bf16_ksplit(const IgemmDesc& d, int planes) {
     const int Np = conv5x5_bf16_rows(d.N);
     const int tw = d.Win % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
     const int tiles = (d.B / ti_n) * (d.Hin / TH) * (d.Win / tw);
-    const int ncg = (d.c0 + d.c1 + 63) / 64, nb = Np / ((Np % 128 == 0 && planes != 3 && planes != -2 && planes != -1) ? 128 : 64);     // (three pieces / fp16 pieces: 64-column blocks only)
+    const int ncg = (d.c0 + d.c1 + 63) / 64, nb = Np / ((Np % 128 == 0 && planes != 3 && planes != -2) ? 128 : 64);     // (three pieces / fp16 pieces: 64-column blocks only)
     // split only up to ONE round of blocks (the kernel is one 8-wave block per CU): 512 blocks = two rounds of half-length blocks with
     // atomics and a zeroed destination were slower than 256 whole ones (bf16 train step 12.56 -> 12.36 ms)
     const int target = pivp_cu_count();
@@ -26,7 +26,7 @@ int conv5x5_bf16_ksplit(const IgemmDesc& d, int planes) {
 }
 
 int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int planes) {
-    PIVP_CHECK_ARG(wb && bf16_geometry_ok(d) && d.out && d.N > 0 && d.ldo >= d.N && d.x0 && d.c0 > 0 && ((planes >= 1 && planes <= 3) || planes == -2 || planes == -1) &&
+    PIVP_CHECK_ARG(wb && bf16_geometry_ok(d) && d.out && d.N > 0 && d.ldo >= d.N && d.x0 && d.c0 > 0 && ((planes >= 1 && planes <= 3) || planes == -2) &&
                    (planes != -2 || (d.wscale_part && d.c1 == 0)));
     const int Np = conv5x5_bf16_rows(d.N);
     IgemmDesc dd = d;
@@ -35,8 +35,6 @@ int conv5x5_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t strea
     const int nb = Np / (wide ? 128 : 64);
     const int ks = conv5x5_bf16_ksplit(d, planes);
     PIVP_CHECK_ARG(!dd.ep_mode || (ks == 1 && dd.ep_src && dd.ep_ld >= dd.ep_cols && (dd.ep_mode == 1 || dd.ep_mode == 2)));      // the caller asks conv5x5_bf16_ksplit first
-    if (planes == -1)    // plain bf16 operands on the L2-direct kernel (wb packed with planes = -1, plain = 1)
-        return d.Win % 16 ? launch_x6g_plain<1, true>(dd, wb, stream, Np / 64, ks, d.N) : launch_x6g_plain<1>(dd, wb, stream, Np / 64, ks, d.N);
     if (planes == 3 && d.Win % 16)     // ... on an 8-wide map (an even batch): tiles of two images
         return launch_x6g_plain<3, true>(dd, wb, stream, Np / 64, ks, d.N);
     if (planes == 3)     // three pieces (wb packed with planes = 3, plain = 1): 64-column blocks, weights from L2 into the operand registers, eight

@@ -223,12 +223,12 @@ int conv5x5_bf16_rows(int N) { return N % 128 == 0 ? N : (N + 63) / 64 * 64; }
 // planes = 3: three bf16 pieces, fragment-major; planes = -2: two fp16 pieces of 256 w, fragment-major (lstm_bf16_weight_elems * 2 elements)
 int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s, int Np, int planes, int plain) {
     if (Np == 0) Np = N;
-    PIVP_CHECK_ARG(w && wb && wcin > 0 && wcin % 32 == 0 && N > 0 && Np >= N && ((planes >= 1 && planes <= 3) || planes == -2 || planes == -1));
-    const int pieces = planes == -2 ? 2 : planes == -1 ? 1 : planes;      // (-1: one bf16 plane in the L2-direct kernel's fragment-major layout)
+    PIVP_CHECK_ARG(w && wb && wcin > 0 && wcin % 32 == 0 && N > 0 && Np >= N && ((planes >= 1 && planes <= 3) || planes == -2));
+    const int pieces = planes == -2 ? 2 : planes;
     const long total = (long)lstm_bf16_weight_elems(wcin, Np) * pieces;
     if (planes == -2)        // the tensor's scale first: 64 partial maxima into the pack's tail
         hipLaunchKernelGGL(absmax_partials_kernel, dim3(64), dim3(512), 0, s, w, (long)25 * wcin * N, reinterpret_cast<float*>(wb + total));
-    if (planes == 3 || planes == -2 || planes == -1) {       // the three-piece kernels' fragment-major pack: the cell's (N = 4 C, gate-interleaved fragments) or a plain conv's
+    if (planes == 3 || planes == -2) {       // the three-piece kernels' fragment-major pack: the cell's (N = 4 C, gate-interleaved fragments) or a plain conv's
         PIVP_CHECK_ARG(Np % 64 == 0 && (plain || (Np == N && N % 32 == 0)));
         const long nthreads = (long)lstm_bf16_weight_elems(wcin, Np) / 8;
         hipLaunchKernelGGL(pack_lstm_x6_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, w, wb, wcin, N, Np, plain, pieces, nthreads);
@@ -243,18 +243,7 @@ bool convlstm_bf16x6_ok(const IgemmDesc& d) { return convlstm_bf16_ok(d) && d.Wi
 
 // d as for igemm_lstm (validated by the caller's igemm_validate(d, true) equivalent); wb = pack_lstm_bf16(d.w, ..., planes).
 int convlstm_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts, int nch, int planes) {
-    PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0)) && ((planes >= 1 && planes <= 3) || planes == -2 || planes == -1));
-    if (planes == -1) {     // plain bf16 operands on the L2-direct kernel (wb = pack_lstm_bf16(..., planes = -1))
-        PIVP_CHECK_ARG(!d.in_g);
-        if (!convlstm_bf16x6_ok(d)) {
-            const long b32 = d.C % 32 ? 0 : (long)(d.B / 2) * (d.Hin / TH) * (d.Win / 8) * (d.C / 32);
-            if ((nch == 32 && b32 > 0) || (nch == 0 && b32 >= pivp_cu_count())) return launch_x6g_w8<2, 4, 1>(d, wb, stream, ln_nparts);
-            return launch_x6g_w8<4, 2, 1>(d, wb, stream, ln_nparts);
-        }
-        const long b32 = d.C % 32 ? 0 : (long)d.B * (d.Hin / TH) * (d.Win / 16) * (d.C / 32);
-        if ((nch == 32 && b32 > 0) || (nch == 0 && b32 >= pivp_cu_count())) return launch_x6g<2, 4, 1>(d, wb, stream, ln_nparts);
-        return launch_x6g<4, 2, 1>(d, wb, stream, ln_nparts);
-    }
+    PIVP_CHECK_ARG(wb && convlstm_bf16_ok(d) && (nch == 0 || nch == 16 || (nch == 32 && d.C % 32 == 0)) && ((planes >= 1 && planes <= 3) || planes == -2));
     // LayerNorm-on-load (d.in_g) exists in the L2-direct kernels only (launch_x6g): every other form would consume the raw tensor
     PIVP_CHECK_ARG(!d.in_g || ((planes == 3 || planes == -2) && convlstm_bf16x6_ok(d)));
     if (planes == 3 && !convlstm_bf16x6_ok(d)) {    // three pieces on an 8-wide map (an even batch: convlstm_bf16_ok): the L2-direct kernel on tiles of two images

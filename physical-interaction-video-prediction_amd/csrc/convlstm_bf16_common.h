@@ -84,9 +84,6 @@ __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x
 __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& e, bf16x8& f, bf16x8& g, bf16x8& h, bf16x8& i) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i));
 }
-__device__ __forceinline__ void wait_lgkm(bf16x8& a) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a));
-}
 __device__ __forceinline__ void wait_lgkm(bf16x8& a, bf16x8& b) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
 }

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     constexpr int RP = W8 ? RP8 : RP16;                // patch row pitch (bytes)
     constexpr int PB = TIN * PHX * RP;                 // one patch plane: 36,864 B (W8: 46,080 B)
     static_assert(!(W8 && IN_LN), "LayerNorm-on-load: one image per tile");
-    static_assert(PCS >= 1 && PCS <= 3, "pieces");      // 1: plain bf16 operands (one plane; round 5 experiment against the ring kernel)
+    static_assert(PCS == 3 || PCS == 2, "pieces");
     static_assert(NWM * NWN == 8, "eight waves, two per SIMD");
     constexpr int PW = TW + 4;
     constexpr int NW = NWM * NWN;                      // waves
@@ -153,7 +153,6 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
             uint4 v;
             v.x = pack2(r[0], r[1]); v.y = pack2(r[2], r[3]); v.z = pack2(r[4], r[5]); v.w = pack2(r[6], r[7]);
             *reinterpret_cast<uint4*>(patch + a_lds + cpiece * 16) = v;
-            if constexpr (PCS == 1) continue;
             auto rest = [&](unsigned p2, int i) {          // r[i], r[i + 1] become the remainders (exact in fp32); returns them as bf16
                 r[i] -= __builtin_bit_cast(float, p2 << 16); r[i + 1] -= __builtin_bit_cast(float, p2 & 0xffff0000u);
                 return pack2(r[i], r[i + 1]);
@@ -219,9 +218,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     bf16x8 fa[2][MT], fal[2][MT], fa3[2][MT];          // [register set][M tile]: the A fragments of a k-step, hi / mid / lo planes
     auto wait_a = [&](auto SET) {
         constexpr int st = decltype(SET)::value;
-        if constexpr (PCS == 1 && MT == 2) wait_lgkm(fa[st][0], fa[st][1]);
-        else if constexpr (PCS == 1) wait_lgkm(fa[st][0]);
-        else if constexpr (PCS == 2 && MT == 2) wait_lgkm(fa[st][0], fa[st][1], fal[st][0], fal[st][1]);
+        if constexpr (PCS == 2 && MT == 2) wait_lgkm(fa[st][0], fa[st][1], fal[st][0], fal[st][1]);
         else if constexpr (PCS == 2) wait_lgkm(fa[st][0], fal[st][0]);
         else if constexpr (MT == 2) wait_lgkm(fa[st][0], fa[st][1], fal[st][0], fal[st][1], fa3[st][0], fa3[st][1]);
         else wait_lgkm(fa[st][0], fal[st][0], fa3[st][0]);
@@ -234,10 +231,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     // twelve MFMAs of register set CUR against the fragments b[3] (hi, mid, lo); corrections into accl, the leading term into acc
     auto mfma = [&](auto CUR, auto I, const bf16x8 (&b)[PCS]) {
         constexpr int st = decltype(CUR)::value, i = decltype(I)::value, term = i / MT, mt = i % MT;
-        if constexpr (PCS == 1) {
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][mt], b[0], acc[mt], 0, 0, 0);
-            return;
-        } else if constexpr (PCS == 2) {      // fp16 pieces: lo * hi, hi * lo into the corrections, hi * hi into the main accumulator
+        if constexpr (PCS == 2) {      // fp16 pieces: lo * hi, hi * lo into the corrections, hi * hi into the main accumulator
             auto h = [](const bf16x8& v) { return __builtin_bit_cast(f16x8, v); };
             if constexpr (term == 0) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fal[st][mt]), h(b[0]), accl[mt], 0, 0, 0);
             else if constexpr (term == 1) accl[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h(fa[st][mt]), h(b[1]), accl[mt], 0, 0, 0);
@@ -261,12 +255,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
 #define PIVP_X6_R(I) if constexpr (rd) read_a(NXT, KSN, std::integral_constant<int, I>{}, abn);
 #define PIVP_X6_S __builtin_amdgcn_sched_barrier(0);
         PIVP_X6_S
-        if constexpr (PCS == 1 && MT == 2) {
-            PIVP_X6_M(0) PIVP_X6_R(0) PIVP_X6_R(1) PIVP_X6_S
-            PIVP_X6_M(1)
-        } else if constexpr (PCS == 1) {
-            PIVP_X6_M(0) PIVP_X6_R(0)
-        } else if constexpr (PCS == 2 && MT == 2) {
+        if constexpr (PCS == 2 && MT == 2) {
             PIVP_X6_M(0) PIVP_X6_R(0) PIVP_X6_R(1) PIVP_X6_S
             PIVP_X6_M(1) PIVP_X6_R(2) PIVP_X6_R(3) PIVP_X6_S
             PIVP_X6_M(2) PIVP_X6_S
@@ -298,8 +287,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
     auto read_a_all = [&](unsigned ab) {               // the first k-step of a tap into set 0 (prologue, and behind a restaged patch)
-        read_a(S0{}, K0{}, I0{}, ab);
-        if constexpr (PCS * MT > 1) read_a(S0{}, K0{}, I1{}, ab);
+        read_a(S0{}, K0{}, I0{}, ab); read_a(S0{}, K0{}, I1{}, ab);
         if constexpr (PCS * MT > 2) read_a(S0{}, K0{}, I2{}, ab);
         if constexpr (PCS * MT > 3) read_a(S0{}, K0{}, I3{}, ab);
         if constexpr (PCS * MT > 4) { read_a(S0{}, K0{}, I4{}, ab); read_a(S0{}, K0{}, I5{}, ab); }

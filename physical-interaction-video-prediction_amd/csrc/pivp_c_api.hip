@@ -41,8 +41,8 @@ int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, co
     // w_bf16: the bf16 pack of w (pack_lstm_bf16) selects the bf16-operand kernel; variant then is its channels per block
     // (three pieces: maps the three-plane tile does not serve -- 8 wide -- take the fp32 kernel, which is what that mode stands in for)
     // (two fp16 pieces: 8-wide maps take the ring kernel's fp16 form when its tiles fit -- an even batch --, whose pack is laid out differently: the caller's)
-    if (w_bf16 && (bf16_planes == 3 || bf16_planes == -2 || bf16_planes == -1) && !convlstm_bf16_ok(d)) return w ? igemm_lstm(d, s, 0, ln_nparts) : PIVP_ERR_BADARG;      // (an 8-wide map with an odd batch: the fp32 kernel)
-    if (w_bf16) return convlstm_bf16(d, w_bf16, s, ln_nparts, ((bf16_planes == 3 || bf16_planes == -2 || bf16_planes == -1) && variant != 16 && variant != 32) ? 0 : variant, bf16_planes);
+    if (w_bf16 && (bf16_planes == 3 || bf16_planes == -2) && !convlstm_bf16_ok(d)) return w ? igemm_lstm(d, s, 0, ln_nparts) : PIVP_ERR_BADARG;      // (an 8-wide map with an odd batch: the fp32 kernel)
+    if (w_bf16) return convlstm_bf16(d, w_bf16, s, ln_nparts, ((bf16_planes == 3 || bf16_planes == -2) && variant != 16 && variant != 32) ? 0 : variant, bf16_planes);
     return igemm_lstm(d, s, variant, ln_nparts);
 }
 

@@ -366,8 +366,6 @@ extern "C" int pivp_plan_set_precision(pivp_plan_t* plan, int precision) {
     m.x3_wgrad = m.lstm_planes == -2;      // ... and the weight gradients two fp16 pieces, two timesteps per launch
     m.x6_wgrad = m.lstm_planes == 3;       // three-piece mode: the weight gradients with three bf16 pieces, same schedule
     m.bf16_all = precision == PIVP_PRECISION_BF16;
-    { static const int tmpl2 = [] { const char* e = getenv("PIVP_TMP_BF16_L2"); return e ? atoi(e) : 0; }();      // EXPERIMENT (not to be committed): the bf16 mode's gate convs / data gradients on the L2-direct kernel
-      if (m.bf16_all && tmpl2) { if (tmpl2 & 1) m.lstm_planes = -1; if (tmpl2 & 2) m.bwd_planes = -1; } }
     m.precision = precision;
     // The dG rings' depth follows the precision, so the order is set_precision -> workspace_bytes -> set_workspace (include/pivp_hip.h).  With a
     // workspace already bound the layout it was sized for stays; a mode that needs deeper rings than it has is refused, not run short.

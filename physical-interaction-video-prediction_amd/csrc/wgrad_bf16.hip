@@ -230,20 +230,27 @@ constexpr int W25_X_BYTES = W25_XPIX * 64;
 // roundings per 16 products, where the fp32 MFMA rounds eight times.  LDS: two planes of each image, 74 KB.
 // PCS = 3: THREE BF16 pieces (hi + mid + lo = v exactly, fp32's exponent range: no scale) and the six products of weight >= 2^-16 (the bf16x6 mode's form):
 // three planes of each image (111 KB), the taps of a k-step in two passes so that their fragments fit the registers.
-template <int TW, int PCS = 1>
-__global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d, int tiles_per_split) {
+// NW = 4 (round 5; PCS = 1 only): FOUR waves own all 25 taps of a 32-channel x 32-column slice (wave w: taps w + 4 i).  One wave per SIMD and ~210
+// registers leave 300 registers per SIMD to the main stream's 8-wave blocks (149 each), so this side-stream kernel CO-RESIDES with the sweep's gate
+// convolutions instead of time-slicing whole CUs with them (profiles/r05/NOTES.md 3: the bf16 step is bound by CU time, not by the matrix pipe).
+template <int TW, int PCS = 1, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 1) void wgrad25_bf16_kernel(const WgradDesc d, int tiles_per_split) {
+    static_assert(NW == 8 || (NW == 4 && PCS == 1), "four waves: the plain bf16 form");
     constexpr int tw = TW;
-    constexpr int GB = W25_G_BYTES, XB = W25_X_BYTES;         // bytes of one plane of the dG tile / of the X patch
+    constexpr int NCOL = NW == 8 ? 64 : 32;                   // gate columns per block
+    constexpr int GB = NW == 8 ? W25_G_BYTES : W25_GH, XB = W25_X_BYTES;         // bytes of one plane of the dG tile / of the X patch
     constexpr int ti_n = tw == 16 ? 1 : 2;
     constexpr int PWC = tw + 4;                               // patch columns
     constexpr int NPIX = ti_n * 12 * PWC;                     // 240 / 288
-    constexpr int NXJ = (NPIX + 63) / 64;                     // staging passes of the patch (64 pixels x 8 float4 each)
+    constexpr int XPP = 8 * NW;                               // patch pixels per staging pass (8 float4 each)
+    constexpr int NXJ = (NPIX + XPP - 1) / XPP;               // staging passes of the patch
+    constexpr int GL = NCOL / 4;                              // float4 lanes per dG row (16 / 8): 32 pixels per pass either way
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // dG halves | X patch
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = d.Hx, W = d.Wx, N = d.N;
     const int ncb = d.cin >> 5;
-    const int cb = blockIdx.x % ncb, nb = blockIdx.x / ncb;   // 32 input channels x 64 gate columns
+    const int cb = blockIdx.x % ncb, nb = blockIdx.x / ncb;   // 32 input channels x NCOL gate columns
     const int tpr = W / tw, tpi = (H / 8) * tpr;
     const int n_tiles = (d.B / ti_n) * tpi;                   // per timestep
     const int tcount = d.tcount > 1 ? d.tcount : 1;
@@ -272,14 +279,14 @@ __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d,
         const int y0 = (trem / tpr) * 8, x0 = (trem - (trem / tpr) * tpr) * tw;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int i = (tid >> 4) + 32 * j;                // anchor of the tile
+            const int i = tid / GL + 32 * j;                  // anchor of the tile
             const int ti = tw == 16 ? 0 : i >> 6, ay = tw == 16 ? i >> 4 : (i >> 3) & 7, ax = tw == 16 ? i & 15 : i & 7;
             const int m = ((b0 + ti) * H + y0 + ay) * W + x0 + ax;
-            rg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy, (unsigned)((m * d.ldy + nb * 64 + (tid & 15) * 4) * 4), 0, 0));
+            rg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsy, (unsigned)((m * d.ldy + nb * NCOL + (tid % GL) * 4) * 4), 0, 0));
         }
 #pragma unroll
         for (int j = 0; j < NXJ; ++j) {
-            const int p = (tid >> 3) + 64 * j;                // patch pixel: [image][row][column]
+            const int p = (tid >> 3) + XPP * j;               // patch pixel: [image][row][column]
             const int ti = p / (12 * PWC), pr = p - ti * (12 * PWC);
             const int py = pr / PWC, px = pr - py * PWC;
             const int iy = y0 + py - 2, ix = x0 + px - 2;
@@ -304,10 +311,10 @@ __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d,
 #pragma unroll
             for (int j = 0; j < 4; ++j) bsum += rg[j];
         }
-        const int n4 = tid & 15;
+        const int n4 = tid % GL;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            unsigned char* dst = lds + (n4 >> 3) * W25_GH + ((tid >> 4) + 32 * j) * 64 + (n4 & 7) * 8;
+            unsigned char* dst = lds + (n4 >> 3) * W25_GH + (tid / GL + 32 * j) * 64 + (n4 & 7) * 8;
             if constexpr (PCS == 2) {
                 float r0 = rg[j][0] * gscale, r1 = rg[j][1] * gscale, r2 = rg[j][2] * gscale, r3 = rg[j][3] * gscale;
                 uint2 h, l;
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d,
         }
 #pragma unroll
         for (int j = 0; j < NXJ; ++j) {
-            unsigned char* dst = lds + PCS * GB + ((tid >> 3) + 64 * j) * 64 + (tid & 7) * 8;
+            unsigned char* dst = lds + PCS * GB + ((tid >> 3) + XPP * j) * 64 + (tid & 7) * 8;
             if constexpr (PCS == 2) {
                 float r0 = rx[j][0], r1 = rx[j][1], r2 = rx[j][2], r3 = rx[j][3];
                 uint2 h, l;
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d,
     // k = 16 s + 8 (g / 2) + 4 j + q of k-step s, columns 16 (g % 2) + 4 p .. + 3 of the operand's 32
     const int g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    const int nt = wave & 1, tg = wave >> 1;                  // this wave's 32 columns; its taps are tg, tg + 4, ... (< 25)
+    const int nt = NW == 8 ? wave & 1 : 0, tg = NW == 8 ? wave >> 1 : wave;      // this wave's 32 columns; its taps are tg, tg + 4, ... (< 25)
     const unsigned a_base = lds0 + nt * W25_GH + (8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * p4) * 2;
     const unsigned b_lane = lds0 + PCS * GB + (TW == 16 ? 8 * (g >> 1) + q : (g >> 1) * PWC + q) * 64 + (16 * (g & 1) + 4 * p4) * 2;
     unsigned b_base[7];
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d,
         for (int i = 0; i < 7; ++i) {
             const int tap = tg + 4 * i;
             if (tap < 25) {
-                float* base = d.dw + ((size_t)(tap * (d.wcin >> 5) + cb) * N + nb * 64 + nt * 32) * 32 + l31;
+                float* base = d.dw + ((size_t)(tap * (d.wcin >> 5) + cb) * N + nb * NCOL + nt * 32) * 32 + l31;
                 const float inv = 1.0f / gscale;                 // (1 without pieces; a power of two with them: exact)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -486,12 +493,13 @@ __global__ __launch_bounds__(512, 1) void wgrad25_bf16_kernel(const WgradDesc d,
             }
         }
     }
-    if (do_bias) {   // thread (tid / 16, n4 = tid % 16) holds the sums of columns 4 n4 .. 4 n4 + 3 over its pixels: lanes l, l ^ 16, l ^ 32, l ^ 48 pair up
+    if (do_bias) {   // thread (tid / GL, n4 = tid % GL) holds the sums of columns 4 n4 .. 4 n4 + 3 over its pixels: the lanes l ^ GL, l ^ 2 GL, ... pair up
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float v = bsum[e];
-            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-            if (lane < 16) atomicAdd(d.db + nb * 64 + lane * 4 + e, v);
+#pragma unroll
+            for (int o = 32; o >= GL; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane < GL) atomicAdd(d.db + nb * NCOL + lane * 4 + e, v);
         }
     }
 }
@@ -505,6 +513,21 @@ bool wgrad5x5_bf16_ok(const WgradDesc& d) {
 }
 
 // the 25-tap kernel: grid = (cin / 32) x (N / 64) output slices x pixel splits over the tiles of ALL timesteps of the batch
+// four-wave blocks (bf16 mode): one per CU beside the main stream's kernels
+static int launch_wgrad25_nw4(const WgradDesc& d, hipStream_t s) {
+    constexpr int lds_bytes = W25_GH + W25_X_BYTES;
+    const int tw = d.Wx % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
+    const int n_tiles = (d.B / ti_n) * (d.Hx / 8) * (d.Wx / tw) * (d.tcount > 1 ? d.tcount : 1);
+    const int gx = (d.cin / 32) * (d.N / 32);
+    int ns = (pivp_cu_count() + gx - 1) / gx;      // about one block per CU
+    if (ns > n_tiles / 2) ns = n_tiles / 2;
+    if (ns < 1) ns = 1;
+    const int tps = (n_tiles + ns - 1) / ns;
+    ns = (n_tiles + tps - 1) / tps;
+    if (tw == 16) hipLaunchKernelGGL((wgrad25_bf16_kernel<16, 1, 4>), dim3(gx, ns), dim3(256), lds_bytes, s, d, tps);
+    else hipLaunchKernelGGL((wgrad25_bf16_kernel<8, 1, 4>), dim3(gx, ns), dim3(256), lds_bytes, s, d, tps);
+    return PIVP_LAUNCH_STATUS();
+}
 template <int PCS>
 static int launch_wgrad25(const WgradDesc& d, hipStream_t s) {
     constexpr int lds_bytes = PCS * (W25_G_BYTES + W25_X_BYTES);
@@ -541,6 +564,10 @@ int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s) {
         return launch_wgrad25<2>(d, s);
     }
     if (d.pieces == 3) return launch_wgrad25<3>(d, s);      // three bf16 pieces per operand, likewise
+    {   // EXPERIMENT (PIVP_TMP_WG4=1): the four-wave form, co-resident with the main stream's blocks
+        static const int wg4 = [] { const char* e = getenv("PIVP_TMP_WG4"); return e ? atoi(e) : 0; }();
+        if (wg4 && (d.tcount > 1 || wg4 >= 2)) return launch_wgrad25_nw4(d, s);
+    }
     if (d.tcount > 1) return launch_wgrad25<1>(d, s);
     constexpr int lds_bytes = G_BYTES + X_BYTES;
     static PerDeviceOnce once16, once8;
