@@ -230,9 +230,11 @@ constexpr int W25_X_BYTES = W25_XPIX * 64;
 // roundings per 16 products, where the fp32 MFMA rounds eight times.  LDS: two planes of each image, 74 KB.
 // PCS = 3: THREE BF16 pieces (hi + mid + lo = v exactly, fp32's exponent range: no scale) and the six products of weight >= 2^-16 (the bf16x6 mode's form):
 // three planes of each image (111 KB), the taps of a k-step in two passes so that their fragments fit the registers.
-// NW = 4 (round 5; PCS = 1 only): FOUR waves own all 25 taps of a 32-channel x 32-column slice (wave w: taps w + 4 i).  One wave per SIMD and ~210
-// registers leave 300 registers per SIMD to the main stream's 8-wave blocks (149 each), so this side-stream kernel CO-RESIDES with the sweep's gate
-// convolutions instead of time-slicing whole CUs with them (profiles/r05/NOTES.md 3: the bf16 step is bound by CU time, not by the matrix pipe).
+// NW = 4 (round 5; PCS = 1 only): FOUR waves own all 25 taps of a 32-channel x 32-column slice (wave w: taps w + 4 i), one block per CU.  One wave per
+// SIMD (122 + 112 registers) leaves half of every SIMD's registers to whatever the main stream runs: the sweep's small kernels (gate backward, LayerNorm
+// sums, 3x3 convs) CO-RESIDE with this side-stream kernel instead of time-slicing whole CUs with the 8-wave form's blocks (profiles/r05/NOTES.md 3: the
+// bf16 step is bound by CU time, not by the matrix pipe).  Config 3 train step 11.45 -> 11.29-11.33 ms (A/B/A/B in one call).  The bf16 gate convs' 8-wave
+// blocks (2 x 149-221 registers per SIMD) still do not fit beside it; capping this kernel at 208 registers spills 41-56 of them.
 template <int TW, int PCS = 1, int NW = 8>
 __global__ __launch_bounds__(64 * NW, 1) void wgrad25_bf16_kernel(const WgradDesc d, int tiles_per_split) {
     static_assert(NW == 8 || (NW == 4 && PCS == 1), "four waves: the plain bf16 form");
@@ -513,13 +515,14 @@ bool wgrad5x5_bf16_ok(const WgradDesc& d) {
 }
 
 // the 25-tap kernel: grid = (cin / 32) x (N / 64) output slices x pixel splits over the tiles of ALL timesteps of the batch
-// four-wave blocks (bf16 mode): one per CU beside the main stream's kernels
+// four-wave blocks (the bf16 mode's batched launches): about one per CU, beside the main stream's kernels
 static int launch_wgrad25_nw4(const WgradDesc& d, hipStream_t s) {
     constexpr int lds_bytes = W25_GH + W25_X_BYTES;
     const int tw = d.Wx % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
     const int n_tiles = (d.B / ti_n) * (d.Hx / 8) * (d.Wx / tw) * (d.tcount > 1 ? d.tcount : 1);
     const int gx = (d.cin / 32) * (d.N / 32);
-    int ns = (pivp_cu_count() + gx - 1) / gx;      // about one block per CU
+    static const int tmp_slots = [] { const char* e = getenv("PIVP_TMP_WG4_SLOTS"); return e ? atoi(e) : 0; }();      // EXPERIMENT, to be removed
+    int ns = ((tmp_slots > 0 ? tmp_slots : pivp_cu_count()) + gx - 1) / gx;      // about one block per CU
     if (ns > n_tiles / 2) ns = n_tiles / 2;
     if (ns < 1) ns = 1;
     const int tps = (n_tiles + ns - 1) / ns;
@@ -564,11 +567,7 @@ int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s) {
         return launch_wgrad25<2>(d, s);
     }
     if (d.pieces == 3) return launch_wgrad25<3>(d, s);      // three bf16 pieces per operand, likewise
-    {   // EXPERIMENT (PIVP_TMP_WG4=1): the four-wave form, co-resident with the main stream's blocks
-        static const int wg4 = [] { const char* e = getenv("PIVP_TMP_WG4"); return e ? atoi(e) : 0; }();
-        if (wg4 && (d.tcount > 1 || wg4 >= 2)) return launch_wgrad25_nw4(d, s);
-    }
-    if (d.tcount > 1) return launch_wgrad25<1>(d, s);
+    if (d.tcount > 1) return launch_wgrad25_nw4(d, s);      // (one timestep on the four-wave form: 11.36 against 11.29 ms: the kernel-row kernel below stays)
     constexpr int lds_bytes = G_BYTES + X_BYTES;
     static PerDeviceOnce once16, once8;
     if (pivp_ensure_dyn_lds(once16, reinterpret_cast<const void*>(&wgrad5x5_bf16_kernel<16>), lds_bytes) != PIVP_OK ||
