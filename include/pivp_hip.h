@@ -40,7 +40,7 @@ extern "C" {
 #define PIVP_PRECISION_BF16X6 3
 #define PIVP_PRECISION_FP16X3 4
 
-int pivp_abi_version(void);   /* 14 (14: + pivp_build_flags, pivp_plan_set_main_priority; 13: + pivp_wgrad5x5_bf16x6_batch; 12: + pivp_wgrad5x5_fp16x3_batch; 11: + pivp_conv5x5_fp16x3; 10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3, pivp_deconv3x3s2_fp16x3, pivp_plan_set_pack_cache, pivp_plan_params_changed; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+int pivp_abi_version(void);   /* 15 (15: + pivp_wgrad5x5_bf16_batch_form; 14: + pivp_build_flags, pivp_plan_set_main_priority; 13: + pivp_wgrad5x5_bf16x6_batch; 12: + pivp_wgrad5x5_fp16x3_batch; 11: + pivp_conv5x5_fp16x3; 10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3, pivp_deconv3x3s2_fp16x3, pivp_plan_set_pack_cache, pivp_plan_params_changed; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
                                  5: + bf16 ConvLSTM, pivp_plan_set_precision, 6: + pivp_plan_set_group_join / pivp_plan_group_wait) */
 
 /* sha256 (hex) of the sources this library was compiled from (every .hip and .h under csrc/, and this header), embedded by build.py.  The Python
@@ -278,6 +278,10 @@ int pivp_wgrad5x5_bf16(const float* x, int cx, int ldx, const float* h_prev, int
  * (byte strides, multiples of 16, may be negative). */
 int pivp_wgrad5x5_bf16_batch(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW, float* db,
                              int B, int H, int W, int tcount, long long ts_x, long long ts_h, long long ts_dG, void* stream);
+/* ... with the block form chosen by the caller: 0 = by size (what pivp_wgrad5x5_bf16_batch and the plan do), 1 = four-wave blocks (one per CU, co-resident with
+ * the sweep's small kernels: the form of frames up to 64 x 64 at B = 32), 2 = eight-wave blocks */
+int pivp_wgrad5x5_bf16_batch_form(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW, float* db,
+                                  int B, int H, int W, int tcount, long long ts_x, long long ts_h, long long ts_dG, int form, void* stream);
 /* ... with every operand as three bf16 pieces and six MFMAs per product (fp32-grade, fp32's exponent range; PIVP_PRECISION_BF16X6's weight gradient) */
 int pivp_wgrad5x5_bf16x6_batch(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW, float* db,
                                int B, int H, int W, int tcount, long long ts_x, long long ts_h, long long ts_dG, void* stream);

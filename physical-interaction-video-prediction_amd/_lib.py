@@ -82,6 +82,7 @@ SIGNATURES = {
     'pivp_deconv3x3s2_bf16': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'pivp_wgrad5x5_bf16': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pivp_wgrad5x5_bf16_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _vp]),
+    'pivp_wgrad5x5_bf16_batch_form': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
     'pivp_wgrad5x5_bf16x6_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _vp]),
     'pivp_wgrad5x5_fp16x3_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _vp, _vp]),
     'pivp_convlstm_train': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

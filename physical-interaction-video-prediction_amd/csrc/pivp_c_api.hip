@@ -251,7 +251,7 @@ int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb,
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
               float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s, float* db,
               int* bias_done, int bf16, int tcount, long long ts_x0, long long ts_x1, long long ts_dy, float* part, WgradDesc* desc_out,
-              const float* dy_absmax, int dy_absmax_stride) {
+              const float* dy_absmax, int dy_absmax_stride, int form) {
     WgradDesc d;
     memset(&d, 0, sizeof(d));
     d.x0 = x0; d.c0 = c0; d.ld0 = ld0; d.x1 = x1; d.c1 = x1 ? c1 : 0; d.ld1 = ld1; d.cin = c0 + (x1 ? c1 : 0); d.wcin = wcin;
@@ -267,6 +267,7 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
     d.part = part;
     d.dy_absmax = dy_absmax; d.dy_absmax_stride = dy_absmax_stride;
     d.pieces = bf16 == 3 ? 3 : 0;       // (bf16: 1 = operands rounded to bf16; 3 = three bf16 pieces per operand, fp32-grade)
+    d.form = form;
     if (desc_out) *desc_out = d;
     if (bf16 || dy_absmax) {   // bf16 precision mode (5x5 ConvLSTM case only): operands rounded to bf16, fp32 accumulation; db summed on the side in fp32
         if (bias_done) *bias_done = db != nullptr;
@@ -412,7 +413,7 @@ extern "C" const char* pivp_build_digest(void) { return PIVP_BUILD_DIGEST; }
 #define PIVP_BUILD_FLAGS ""                // the compile flags beyond build.py's standard set (PIVP_EXTRA_FLAGS): "" = the product build
 #endif
 extern "C" const char* pivp_build_flags(void) { return PIVP_BUILD_FLAGS; }
-extern "C" int pivp_abi_version(void) { return 14; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
+extern "C" int pivp_abi_version(void) { return 15; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
 
 extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                              const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream) {
@@ -609,6 +610,14 @@ extern "C" int pivp_wgrad5x5_bf16_batch(const float* x, int cx, int ldx, const f
     if (!x || !dG || !dW || C <= 0 || cx <= 0 || tcount < 1) return PIVP_ERR_BADARG;
     return run_wgrad(0, x, cx, ldx, h_prev, C, C, cx + C, dG, 4 * C, 4 * C, dW, B, H, W, H, W, 5, 2, 1, (hipStream_t)stream, db,
                      nullptr, 1, tcount, ts_x, ts_h, ts_dG);
+}
+// ... with the block form chosen by the caller: 1 = four-wave blocks (32 channels x 32 columns, about one per CU: they co-reside with the backward sweep's
+// small kernels), 2 = eight-wave blocks (32 x 64: half the patch traffic per multiply-add), 0 = by size as pivp_wgrad5x5_bf16_batch does
+extern "C" int pivp_wgrad5x5_bf16_batch_form(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW, float* db,
+                                             int B, int H, int W, int tcount, long long ts_x, long long ts_h, long long ts_dG, int form, void* stream) {
+    if (!x || !dG || !dW || C <= 0 || cx <= 0 || tcount < 1 || form < 0 || form > 2) return PIVP_ERR_BADARG;
+    return run_wgrad(0, x, cx, ldx, h_prev, C, C, cx + C, dG, 4 * C, 4 * C, dW, B, H, W, H, W, 5, 2, 1, (hipStream_t)stream, db,
+                     nullptr, 1, tcount, ts_x, ts_h, ts_dG, nullptr, nullptr, nullptr, 0, form);
 }
 static int convlstm_ln_cap(int H, int W, int C) {
     const int tiles = ((H * W + 31) / 32) * (C / 32), slices = ln_stats_slices(H * W * C);

@@ -91,6 +91,8 @@ struct WgradDesc {
     // |value| of the whole batch into [2^14, 2^15) -- gradients lie far below fp16's normal range -- and the sums are scaled back exactly.  null: bf16 operands.
     const float* dy_absmax; int dy_absmax_stride;
     int pieces;                          // wgrad5x5_bf16 only: 3 = three bf16 pieces per operand, six MFMAs per product (the bf16x6 mode's weight gradient)
+    int form;                            // wgrad5x5_bf16, plain bf16 operands, a batch of timesteps: 0 = by size (four-wave blocks that co-reside with the main stream's
+                                         // kernels for maps of up to 32 x 32 x 32 pixels per timestep, else eight-wave blocks), 1 = four-wave, 2 = eight-wave
 };
 int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done = nullptr);
 long long igemm_wgrad_part_floats(const WgradDesc& d);    // 0 when the ConvLSTM fast path would take this descriptor

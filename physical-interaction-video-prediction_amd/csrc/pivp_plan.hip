@@ -826,7 +826,8 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                      G(p, p->i_lstm_b[i]), &bias_done, p->bf16_all ? 1 : (p->x6_wgrad && (wwid % 16 == 0 || B % 2 == 0)) ? 3 : 0, cnt, -slab_bytes, -slab_bytes,
                      (long long)dG1 * 4, nullptr, nullptr,
                      // (fp16 pieces; an 8-wide map with an odd batch does not fit that kernel's two-image tiles: the fp32 kernel takes the batch)
-                     (p->x3_wgrad && (wwid % 16 == 0 || B % 2 == 0)) ? ws + g.dg_absmax + (size_t)(i * 2 + wg_ring) * p->wg_cap * 72 : nullptr, 72));
+                     (p->x3_wgrad && (wwid % 16 == 0 || B % 2 == 0)) ? ws + g.dg_absmax + (size_t)(i * 2 + wg_ring) * p->wg_cap * 72 : nullptr, 72,
+                     (long)B * c.height * c.width > 32L * 64 * 64 ? 2 : 0));      // (frames above 64 x 64 x 32: the eight-wave weight gradient on every layer, WgradDesc::form)
         if (!bias_done)
             for (int j = 0; j < cnt; ++j) RC(bias_grad(ring + (size_t)j * dG1, N, N, B * hh * wwid, G(p, p->i_lstm_b[i]), sw));
         if (p->side && hipEventRecord(p->ev_ring_done[i][wg_ring], p->side_of(i)) != hipSuccess) return PIVP_ERR_LAUNCH;

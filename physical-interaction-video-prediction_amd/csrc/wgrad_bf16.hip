@@ -521,8 +521,7 @@ static int launch_wgrad25_nw4(const WgradDesc& d, hipStream_t s) {
     const int tw = d.Wx % 16 == 0 ? 16 : 8, ti_n = tw == 16 ? 1 : 2;
     const int n_tiles = (d.B / ti_n) * (d.Hx / 8) * (d.Wx / tw) * (d.tcount > 1 ? d.tcount : 1);
     const int gx = (d.cin / 32) * (d.N / 32);
-    static const int tmp_slots = [] { const char* e = getenv("PIVP_TMP_WG4_SLOTS"); return e ? atoi(e) : 0; }();      // EXPERIMENT, to be removed
-    int ns = ((tmp_slots > 0 ? tmp_slots : pivp_cu_count()) + gx - 1) / gx;      // about one block per CU
+    int ns = (pivp_cu_count() + gx - 1) / gx;      // about one block per CU (config 3's step against the block target: 128: 11.84 ms, 256: 11.28, 384: 11.25, 512: 11.60)
     if (ns > n_tiles / 2) ns = n_tiles / 2;
     if (ns < 1) ns = 1;
     const int tps = (n_tiles + ns - 1) / ns;
@@ -567,7 +566,11 @@ int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s) {
         return launch_wgrad25<2>(d, s);
     }
     if (d.pieces == 3) return launch_wgrad25<3>(d, s);      // three bf16 pieces per operand, likewise
-    if (d.tcount > 1) return launch_wgrad25_nw4(d, s);      // (one timestep on the four-wave form: 11.36 against 11.29 ms: the kernel-row kernel below stays)
+    // A batch of timesteps (WgradDesc::form): the four-wave form (co-resident with the main stream's small kernels) on maps of up to 32 x 32 x 32 pixels per
+    // timestep, the eight-wave form (half the patch traffic per multiply-add) on larger ones; the plan asks for the eight-wave form on every layer of frames
+    // above 64 x 64 x 32 -- config 5, whose main-stream kernels fill the chip by themselves: 68.2 ms with the four-wave form everywhere against 66.3.
+    // (One timestep on the four-wave form: config 3 11.36 against 11.29 ms: the kernel-row kernel below stays.)
+    if (d.tcount > 1) return (d.form == 1 || (d.form == 0 && (long)d.B * d.Hx * d.Wx <= 32L * 32 * 32)) ? launch_wgrad25_nw4(d, s) : launch_wgrad25<1>(d, s);
     constexpr int lds_bytes = G_BYTES + X_BYTES;
     static PerDeviceOnce once16, once8;
     if (pivp_ensure_dyn_lds(once16, reinterpret_cast<const void*>(&wgrad5x5_bf16_kernel<16>), lds_bytes) != PIVP_OK ||

@@ -404,7 +404,7 @@ def wgrad5x5_bf16(x, h, dG, h_is_zero=False):
     return pivp_amd.from_internal('lstm1/conv/W', dW.cpu().numpy(), (4 * C, cx + C, 5, 5)), db.cpu().numpy()
 
 
-def wgrad5x5_bf16_batch(xs, hs, dGs, fp16x3=False, h_is_zero=False, bf16x6=False):
+def wgrad5x5_bf16_batch(xs, hs, dGs, fp16x3=False, h_is_zero=False, bf16x6=False, form=0):
     """The batched form: lists of per-timestep x (B,cx,H,W), h (B,C,H,W), dG (B,4C,H,W); operands are laid out LAST timestep first with
     negative strides for x / h (as the backward sweep's slabs are) and positive for dG (as its ring is)."""
     lib = _lib.load()
@@ -427,8 +427,12 @@ def wgrad5x5_bf16_batch(xs, hs, dGs, fp16x3=False, h_is_zero=False, bf16x6=False
                                                   db.data_ptr(), B, H, Wd, T, -sx, -sh, sg, scratch.data_ptr(), stream()), 'wgrad5x5_fp16x3_batch')
         torch.cuda.synchronize()
         return pivp_amd.from_internal('lstm1/conv/W', dW.cpu().numpy(), (4 * C, cx + C, 5, 5)), db.cpu().numpy()
-    _lib.check(lib.pivp_wgrad5x5_bf16_batch(xd[T - 1].data_ptr(), cx, cx, hd[T - 1].data_ptr(), C, gd.data_ptr(), dW.data_ptr(), db.data_ptr(),
-                                            B, H, Wd, T, -sx, -sh, sg, stream()), 'wgrad5x5_bf16_batch')
+    if form:         # 1: four-wave blocks, 2: eight-wave blocks (pivp_wgrad5x5_bf16_batch picks by size)
+        _lib.check(lib.pivp_wgrad5x5_bf16_batch_form(xd[T - 1].data_ptr(), cx, cx, hd[T - 1].data_ptr(), C, gd.data_ptr(), dW.data_ptr(), db.data_ptr(),
+                                                     B, H, Wd, T, -sx, -sh, sg, form, stream()), 'wgrad5x5_bf16_batch_form')
+    else:
+        _lib.check(lib.pivp_wgrad5x5_bf16_batch(xd[T - 1].data_ptr(), cx, cx, hd[T - 1].data_ptr(), C, gd.data_ptr(), dW.data_ptr(), db.data_ptr(),
+                                                B, H, Wd, T, -sx, -sh, sg, stream()), 'wgrad5x5_bf16_batch')
     torch.cuda.synchronize()
     return pivp_amd.from_internal('lstm1/conv/W', dW.cpu().numpy(), (4 * C, cx + C, 5, 5)), db.cpu().numpy()
 

@@ -240,14 +240,15 @@ def test_wgrad5x5_bf16_first_step_leaves_h_rows_alone(ops):
     assert np.all(got[:, cx:] == 0)
 
 
+@pytest.mark.parametrize('form', [0, 1, 2])      # 1: four-wave blocks (co-resident with the sweep's small kernels; what 0 picks at these sizes), 2: eight-wave blocks
 @pytest.mark.parametrize('B,cx,C,H,T', [(2, 32, 32, 32, 3), (2, 32, 64, 16, 4), (4, 64, 128, 8, 3), (1, 96, 32, 32, 2)])
-def test_wgrad5x5_bf16_batch_of_timesteps(ops, B, cx, C, H, T):
+def test_wgrad5x5_bf16_batch_of_timesteps(ops, B, cx, C, H, T, form):
     # one launch for T timesteps (operands at signed byte strides) = the sum of the per-timestep gradients
     rs = np.random.RandomState(B + cx + C + H + T)
     xs = [_bf16(rs.randn(B, cx, H, H)) for _ in range(T)]; hs = [_bf16(rs.randn(B, C, H, H) * 0.5) for _ in range(T)]
     dGs = [_bf16(rs.randn(B, 4 * C, H, H) * 0.1) for _ in range(T)]
     ref = sum(_wgrad_ref(x, h, g) for x, h, g in zip(xs, hs, dGs))
-    got, db = ops.wgrad5x5_bf16_batch(xs, hs, dGs)
+    got, db = ops.wgrad5x5_bf16_batch(xs, hs, dGs, form=form)
     assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
     assert np.abs(db - sum(g.sum(axis=(0, 2, 3)) for g in dGs)).max() < 4e-4
 
