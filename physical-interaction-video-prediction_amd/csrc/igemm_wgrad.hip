@@ -513,6 +513,8 @@ static void generic_grid(const WgradDesc& d, int& wg_n, int& tiles, int& nsplit)
     // direct path: every block ends with a tile of atomics (64 x 128), so no more pixel splits than fill the chip twice (3 blocks fit a
     // CU) and >= 8 chunks (256 pixels) per block (enc4 with 4: 63 -> 94 us, atomics); kept for the partial-sum path, where a split
     // costs 16-32 KB of traffic instead
+    // (round 5, call 15: a target of 256 / 384 / 1024 blocks instead of 512 gives config 3 11.50 / 11.27 / 11.27 ms against 11.18-11.22,
+    // fp32 train 28.02 against 27.85 with 256: 512 stays)
     nsplit = (512 + tiles - 1) / tiles;
     if (nsplit > chunks / 8) nsplit = chunks / 8;
     if (nsplit < 1) nsplit = 1;
