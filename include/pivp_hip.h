@@ -312,6 +312,15 @@ int pivp_conv_backward(int mode, const float* x, int cin, int ldx, const float* 
 long long pivp_conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin, int Win);
 int pivp_conv_wgrad_partial(int mode, const float* x, int cin, int ldx, const float* dy, int cout, int ldy, float* part,
                             float* dW, float* db, int B, int Hin, int Win, int repeats, void* stream);
+/* ... and as the sweep runs it since round 5: ONE launch takes a batch of `tcount` timesteps (operand j at x + j * x_step_bytes and
+ * dy + j * dy_step_bytes; the steps may be negative) into the partial planes -- overwrite != 0: stored instead of added, so the planes' first launch
+ * needs no zeroing -- and pivp_conv_wgrad_partial_reduce adds the planes' sum into dW (and the column sums of dy the launches left there into db;
+ * the per-tap kernel adds those into db at launch).  The stride-2 3x3 shapes of the model (anchor map a multiple
+ * of 4 x 8, channels multiples of 32) run all nine taps from one staging of the operands (csrc/wgrad3x3s2.hip). */
+int pivp_conv_wgrad_partial_batch(int mode, const float* x, int cin, int ldx, long long x_step_bytes, const float* dy, int cout, int ldy,
+                                  long long dy_step_bytes, int tcount, int overwrite, float* part, float* dW, float* db, int B, int Hin, int Win,
+                                  void* stream);
+int pivp_conv_wgrad_partial_reduce(int mode, int cin, int cout, float* part, float* dW, float* db, int B, int Hin, int Win, void* stream);
 /* pivp_convlstm_backward for the sweep's last timestep (t = 0; TM:254-257: the state before it is zero and nothing reads its
  * gradient): only the cx columns of d_in (d x) are computed, the C columns of d h_{-1} are not computed (left as they are, or cleared). */
 int pivp_convlstm_backward_dx_only(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,

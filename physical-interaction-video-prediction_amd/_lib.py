@@ -91,6 +91,8 @@ SIGNATURES = {
     'pivp_conv_backward': (_i, [_i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     'pivp_conv_backward_part_floats': (_ll, [_i, _i, _i, _i, _i, _i]),
     'pivp_conv_wgrad_partial': (_i, [_i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'pivp_conv_wgrad_partial_batch': (_i, [_i, _vp, _i, _i, _ll, _vp, _i, _i, _ll, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'pivp_conv_wgrad_partial_reduce': (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'pivp_convlstm_backward_dx_only': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp,
                                             _i, _i, _i, _vp]),
     'pivp_layernorm_train': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void igemm_wgrad_kernel(const WgradDesc d) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float* q = pt + (wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * WG_N + wn * 32 * NT + t * 32 + l31;
-                *q += acc[t][r];
+                *q = d.part_overwrite ? acc[t][r] : *q + acc[t][r];
             }
         return;
     }
@@ -509,7 +509,7 @@ static void generic_grid(const WgradDesc& d, int& wg_n, int& tiles, int& nsplit)
     wg_n = d.N <= 64 ? 64 : 128;
     const int ncb = (d.cin + WG_CI - 1) / WG_CI, nnb = (d.N + wg_n - 1) / wg_n;
     tiles = d.ksize * d.ksize * ncb * nnb;
-    const int chunks = (d.M + WG_PIX - 1) / WG_PIX * (d.tcount > 1 ? d.tcount : 1);
+    const int chunks = (d.M + WG_PIX - 1) / WG_PIX;      // of ONE timestep: a batched launch, a single one and the reduction must agree on the planes
     // direct path: every block ends with a tile of atomics (64 x 128), so no more pixel splits than fill the chip twice (3 blocks fit a
     // CU) and >= 8 chunks (256 pixels) per block (enc4 with 4: 63 -> 94 us, atomics); kept for the partial-sum path, where a split
     // costs 16-32 KB of traffic instead
@@ -530,6 +530,10 @@ int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done) {
         if (bias_done) *bias_done = d.db ? 1 : 0;
         return d.Wg == 8 ? launch_wgrad5x5<8>(d, s) : d.Wg == 16 ? launch_wgrad5x5<16>(d, s) : launch_wgrad5x5<32>(d, s);
     }
+    if (d.part && wgrad3x3s2_ok(d)) {      // stride-2 3x3: all nine taps from one staging (wgrad3x3s2.hip); the column sums ride along
+        if (bias_done) *bias_done = d.db ? 1 : 0;
+        return wgrad3x3s2(d, s);
+    }
     int wg_n, tiles, nsplit;
     generic_grid(d, wg_n, tiles, nsplit);
     // the column sums ride along when the tap set qualifies: a 3x3 conv, or the transposed 3x3 s2 conv (see the kernel)
@@ -544,6 +548,7 @@ int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done) {
 
 long long igemm_wgrad_part_floats(const WgradDesc& d) {
     if (takes_fast_path(d)) return 0;
+    if (wgrad3x3s2_ok(d)) return wgrad3x3s2_part_floats(d);
     int wg_n, tiles, nsplit;
     generic_grid(d, wg_n, tiles, nsplit);
     return (long long)tiles * nsplit * 64 * wg_n;
@@ -551,6 +556,7 @@ long long igemm_wgrad_part_floats(const WgradDesc& d) {
 
 int igemm_wgrad_reduce(const WgradDesc& d, hipStream_t s) {
     PIVP_CHECK_ARG(d.part && d.dw && !takes_fast_path(d));
+    if (wgrad3x3s2_ok(d)) return wgrad3x3s2_reduce(d, s);
     int wg_n, tiles, nsplit;
     generic_grid(d, wg_n, tiles, nsplit);
     hipLaunchKernelGGL(igemm_wgrad_reduce_kernel, dim3((64 * wg_n + 255) / 256, tiles), dim3(256), 0, s, d, wg_n, nsplit);

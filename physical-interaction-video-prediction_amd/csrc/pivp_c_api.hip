@@ -251,7 +251,7 @@ int run_conv5x5_bf16(const float* x, int cin, int ldx, const unsigned short* wb,
 int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c1, int ld1, int wcin, const float* dy, int ldy, int N,
               float* dw, int B, int Hx, int Wx, int Hy, int Wy, int ksize, int pad, int stride, hipStream_t s, float* db,
               int* bias_done, int bf16, int tcount, long long ts_x0, long long ts_x1, long long ts_dy, float* part, WgradDesc* desc_out,
-              const float* dy_absmax, int dy_absmax_stride, int form) {
+              const float* dy_absmax, int dy_absmax_stride, int form, int part_overwrite) {
     WgradDesc d;
     memset(&d, 0, sizeof(d));
     d.x0 = x0; d.c0 = c0; d.ld0 = ld0; d.x1 = x1; d.c1 = x1 ? c1 : 0; d.ld1 = ld1; d.cin = c0 + (x1 ? c1 : 0); d.wcin = wcin;
@@ -264,7 +264,7 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
     d.bytes0 = (int)b0; d.bytes1 = (int)b1; d.bytesy = (int)by;
     d.db = db;
     d.tcount = tcount; d.ts_x0 = ts_x0; d.ts_x1 = ts_x1; d.ts_dy = ts_dy;
-    d.part = part;
+    d.part = part; d.part_overwrite = part_overwrite;
     d.dy_absmax = dy_absmax; d.dy_absmax_stride = dy_absmax_stride;
     d.pieces = bf16 == 3 ? 3 : 0;       // (bf16: 1 = operands rounded to bf16; 3 = three bf16 pieces per operand, fp32-grade)
     d.form = form;
@@ -397,7 +397,7 @@ long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin,
     const int Hout = mode ? 2 * Hin : Hin / 2, Wout = mode ? 2 * Win : Win / 2;
     WgradDesc d;
     memset(&d, 0, sizeof(d));
-    d.c0 = cin; d.cin = cin; d.wcin = cin; d.N = cout; d.B = B; d.Hx = Hin; d.Wx = Win; d.Hy = Hout; d.Wy = Wout;
+    d.c0 = cin; d.ld0 = cin; d.cin = cin; d.wcin = cin; d.N = cout; d.ldy = cout; d.B = B; d.Hx = Hin; d.Wx = Win; d.Hy = Hout; d.Wy = Wout;
     d.deconv = mode; d.ksize = 3; d.pad = 1; d.stride = 2;
     d.Hg = mode ? Hin : Hout; d.Wg = mode ? Win : Wout; d.M = B * d.Hg * d.Wg;
     return igemm_wgrad_part_floats(d);
@@ -413,7 +413,7 @@ extern "C" const char* pivp_build_digest(void) { return PIVP_BUILD_DIGEST; }
 #define PIVP_BUILD_FLAGS ""                // the compile flags beyond build.py's standard set (PIVP_EXTRA_FLAGS): "" = the product build
 #endif
 extern "C" const char* pivp_build_flags(void) { return PIVP_BUILD_FLAGS; }
-extern "C" int pivp_abi_version(void) { return 15; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
+extern "C" int pivp_abi_version(void) { return 16; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
 
 extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                              const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream) {
@@ -467,6 +467,36 @@ extern "C" int pivp_conv_wgrad_partial(int mode, const float* x, int cin, int ld
         if (!bias_done) { rc = bias_grad(dy, ldy, cout, B * Hout * Wout, db, (hipStream_t)stream); if (rc != PIVP_OK) return rc; }
     }
     return igemm_wgrad_reduce(desc, (hipStream_t)stream);
+}
+// One launch of that weight gradient over a BATCH of timesteps (WgradDesc::tcount; operand j at x + j * x_step_bytes, dy + j * dy_step_bytes,
+// negative steps allowed: the sweep walks the forward slabs backwards) into the partial planes -- overwrite != 0: stored, not added (the planes'
+// first launch needs no zeroing) -- and the reduction into dW as a call of its own.
+extern "C" int pivp_conv_wgrad_partial_batch(int mode, const float* x, int cin, int ldx, long long x_step_bytes, const float* dy, int cout, int ldy,
+                                             long long dy_step_bytes, int tcount, int overwrite, float* part, float* dW, float* db, int B, int Hin, int Win,
+                                             void* stream) {
+    if (!x || !dy || !part || !dW || !db || mode < 0 || mode > 1 || tcount < 1) return PIVP_ERR_BADARG;
+    const int Hout = mode ? 2 * Hin : Hin / 2, Wout = mode ? 2 * Win : Win / 2;
+    int bias_done = 0;
+    int rc = run_wgrad(mode, x, cin, ldx, nullptr, 0, 0, cin, dy, ldy, cout, dW, B, Hin, Win, Hout, Wout, 3, 1, 2, (hipStream_t)stream, db, &bias_done, 0,
+                       tcount, x_step_bytes, 0, dy_step_bytes, part, nullptr, nullptr, 0, 0, overwrite ? 1 : 0);
+    if (rc != PIVP_OK) return rc;
+    if (!bias_done)
+        for (int j = 0; j < tcount; ++j) {
+            rc = bias_grad(reinterpret_cast<const float*>(reinterpret_cast<const char*>(dy) + j * dy_step_bytes), ldy, cout, B * Hout * Wout, db, (hipStream_t)stream);
+            if (rc != PIVP_OK) return rc;
+        }
+    return PIVP_OK;
+}
+extern "C" int pivp_conv_wgrad_partial_reduce(int mode, int cin, int cout, float* part, float* dW, float* db, int B, int Hin, int Win, void* stream) {
+    if (!part || !dW || !db || mode < 0 || mode > 1) return PIVP_ERR_BADARG;
+    const int Hout = mode ? 2 * Hin : Hin / 2, Wout = mode ? 2 * Win : Win / 2;
+    WgradDesc d;
+    memset(&d, 0, sizeof(d));
+    d.c0 = cin; d.ld0 = cin; d.cin = cin; d.wcin = cin; d.N = cout; d.ldy = cout; d.B = B; d.Hx = Hin; d.Wx = Win; d.Hy = Hout; d.Wy = Wout;
+    d.deconv = mode; d.ksize = 3; d.pad = 1; d.stride = 2;
+    d.Hg = mode ? Hin : Hout; d.Wg = mode ? Win : Wout; d.M = B * d.Hg * d.Wg;
+    d.part = part; d.dw = dW; d.db = db;      // (the nine-tap kernel leaves its column sums in the planes: the reduction adds them into db)
+    return igemm_wgrad_reduce(d, (hipStream_t)stream);
 }
 // pivp_convlstm_backward for the sweep's LAST timestep (t = 0): nobody reads d h_{-1}, so only the cx columns of d_in are computed
 // (the data gradient runs on the first cx columns of the transposed weight pack) and the h columns of d_in are not computed (left as they are, or cleared with the rest of d_in for a K-split data gradient).

@@ -48,7 +48,8 @@ int run_wgrad(int mode, const float* x0, int c0, int ld0, const float* x1, int c
               int tcount = 1, long long ts_x0 = 0, long long ts_x1 = 0, long long ts_dy = 0,    // a batch of timesteps: WgradDesc
               float* part = nullptr, WgradDesc* desc_out = nullptr,    // part: WgradDesc::part; desc_out: the descriptor that was launched
               const float* dy_absmax = nullptr, int dy_absmax_stride = 0,    // two fp16 pieces per operand (WgradDesc::dy_absmax; 5x5 ConvLSTM case only)
-              int form = 0);                                                  // WgradDesc::form (bf16 operands, a batch of timesteps: four- / eight-wave blocks)
+              int form = 0,                                                   // WgradDesc::form (bf16 operands, a batch of timesteps: four- / eight-wave blocks)
+              int part_overwrite = 0);                                        // WgradDesc::part_overwrite
 int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* gates,
                           const float* c_old, const float* c_new, const float* dh_a, int lda, const float* dh_b, int ldb,
                           float* dc, int dc_valid, float* dG, float* wt, float* d_in, float* dW, float* db,

@@ -86,6 +86,7 @@ struct WgradDesc {
     // loads and stores; igemm_wgrad_reduce(d) then sums the splits into dw.  The scattered atomics of the direct path cost 54 of the
     // 85 us of an enc5 / enc6 launch (64 adds per address from 500 blocks).  The launches that share a slot must be stream-ordered.
     float* part;
+    int part_overwrite;                  // 1: this launch is the slot's first since the caller last consumed it: store instead of add (no zeroing needed)
     // wgrad5x5_bf16 only: two FP16 pieces per operand, three MFMAs per product (the fp16x3 mode's weight gradient).  dy_absmax = the absmax_partials tail of
     // timestep j's dy at dy_absmax + j * dy_absmax_stride floats (64 partial maxima at [2..65]): dy is staged times the power of two that puts the largest
     // |value| of the whole batch into [2^14, 2^15) -- gradients lie far below fp16's normal range -- and the sums are scaled back exactly.  null: bf16 operands.
@@ -97,6 +98,12 @@ struct WgradDesc {
 int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done = nullptr);
 long long igemm_wgrad_part_floats(const WgradDesc& d);    // 0 when the ConvLSTM fast path would take this descriptor
 int igemm_wgrad_reduce(const WgradDesc& d, hipStream_t s);   // dw += sum over the splits of d.part
+// the stride-2 3x3 convs / transposed convs with all nine taps from one staging of the operands (csrc/wgrad3x3s2.hip): partial-sum path only;
+// igemm_wgrad / igemm_wgrad_part_floats / igemm_wgrad_reduce route to it when wgrad3x3s2_ok(d) and d.part is given
+bool wgrad3x3s2_ok(const WgradDesc& d);
+long long wgrad3x3s2_part_floats(const WgradDesc& d);
+int wgrad3x3s2(const WgradDesc& d, hipStream_t s);
+int wgrad3x3s2_reduce(const WgradDesc& d, hipStream_t s);
 // bf16-operand form of the ConvLSTM weight gradient (csrc/wgrad_bf16.hip); the bias gradient is left to bias_grad
 bool wgrad5x5_bf16_ok(const WgradDesc& d);
 int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s);

@@ -222,6 +222,50 @@ def test_conv_weight_gradient_through_partial_planes(env, mode, B, cin, cout, H,
     assert _rel(db.cpu().numpy(), repeats * tb.grad.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize('mode,B,cin,cout,H,T', [(0, 3, 32, 32, 32, 3), (0, 5, 64, 64, 16, 4), (1, 3, 128, 128, 8, 3), (1, 5, 96, 96, 16, 2), (1, 2, 64, 64, 32, 3),
+                                                 (0, 1, 32, 32, 64, 2), (1, 7, 64, 64, 8, 5), (1, 2, 64, 64, 64, 2), (1, 2, 32, 32, 16, 2), (0, 2, 32, 32, 24, 2)])
+def test_conv_weight_gradient_batched_over_timesteps(env, mode, B, cin, cout, H, T):
+    """The sweep's form since round 5: ONE launch takes a batch of timesteps (x walked backwards through the forward slabs: a negative step; dY forwards
+    through its ring), the first launch of a sweep stores into the partial planes (no zeroing: they start as garbage here), a second launch adds, one
+    reduction.  The model's shapes run all nine taps from one staging (wgrad3x3s2.hip); 32 -> 32 transposed and the 12 x 12 anchor map fall to the
+    per-tap kernel.  dW = sum over timesteps, against float64 autograd."""
+    pivp, _lib, lib = env
+    rs = np.random.RandomState(cin + mode + B + T)
+    Ho = 2 * H if mode else H // 2
+    x = rs.randn(T, B, cin, H, H); dy = rs.randn(T, B, cout, Ho, Ho)
+    if mode:
+        W = rs.randn(cin, cout, 3, 3) / np.sqrt(9 * cin); key = 'enc4/W'
+    else:
+        W = rs.randn(cout, cin, 3, 3) / np.sqrt(9 * cin); key = 'enc1/W'
+    tW = torch.tensor(W, dtype=torch.float64, requires_grad=True); tb = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    tot = 0
+    for t in range(T):
+        tx = torch.tensor(x[t], dtype=torch.float64)
+        y = F.conv_transpose2d(tx, tW, tb, stride=2, padding=1, output_padding=1) if mode else F.conv2d(tx, tW, tb, stride=2, padding=1)
+        tot = tot + (y * torch.tensor(dy[t])).sum()
+    tot.backward()
+    # forward slabs hold x[t] at slab t; the sweep runs t = T-1 .. 0 and its dY ring slot j holds timestep T-1-j
+    xd = _t(np.ascontiguousarray(x.transpose(0, 1, 3, 4, 2)))
+    dyd = _t(np.ascontiguousarray(dy[::-1].transpose(0, 1, 3, 4, 2)))
+    n = lib.pivp_conv_backward_part_floats(mode, cin, cout, B, H, H)
+    assert n > 0
+    part = torch.full((n,), float('nan'), dtype=torch.float32, device=DEV)
+    prior = rs.randn(W.size).astype(np.float32) * 0.01
+    dW = _t(prior); db = torch.zeros(cout, dtype=torch.float32, device=DEV)
+    xs, ys = xd[0].numel() * 4, dyd[0].numel() * 4
+    first = max(1, T - 1)          # a batch of T - 1 timesteps (stored), then the last one alone (added)
+    _lib.check(lib.pivp_conv_wgrad_partial_batch(mode, xd.data_ptr() + (T - 1) * xs, cin, cin, -xs, dyd.data_ptr(), cout, cout, ys, first, 1,
+                                                 part.data_ptr(), dW.data_ptr(), db.data_ptr(), B, H, H, _st()), 'batch 1')
+    if first < T:
+        _lib.check(lib.pivp_conv_wgrad_partial_batch(mode, xd.data_ptr(), cin, cin, -xs, dyd.data_ptr() + (T - 1) * ys, cout, cout, ys, 1, 0,
+                                                     part.data_ptr(), dW.data_ptr(), db.data_ptr(), B, H, H, _st()), 'batch 2')
+    _lib.check(lib.pivp_conv_wgrad_partial_reduce(mode, cin, cout, part.data_ptr(), dW.data_ptr(), db.data_ptr(), B, H, H, _st()), 'reduce')
+    torch.cuda.synchronize()
+    got = pivp.from_internal(key, dW.cpu().numpy() - prior, W.shape)
+    assert _rel(got, tW.grad.numpy()) < 2e-5
+    assert _rel(db.cpu().numpy(), tb.grad.numpy()) < 2e-5
+
+
 @pytest.mark.parametrize('B,cx,C,H', [(3, 32, 32, 32), (5, 32, 64, 16), (3, 64, 128, 8), (1, 96, 32, 32), (2, 128, 64, 16)])
 def test_convlstm_backward_last_timestep_computes_dx_only(env, B, cx, C, H):
     """t = 0 of the sweep: the data gradient runs on the first cx columns of the transposed weight pack (IgemmDesc::wN); d x, d c, dW, db
