@@ -385,6 +385,7 @@ int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w
                   : run_deconv3x3s2(dy, cout, ldy, wt, nullptr, dx, cin, lddx, 0, B, Hout, Wout, s, accum_dx, nullptr, 0, nullptr, prec == 1 ? 1 : 0);
         if (rc != PIVP_OK) return rc;
     }
+    if (!dW) return PIVP_OK;     // the caller batches this layer's weight gradient over several timesteps itself (pivp_plan.hip); the fork's `ready` is recorded
     int bias_done = 0;     // the weight-gradient kernel sums dY's columns on the side when it can
     rc = run_wgrad(mode, x, cin, ldx, nullptr, 0, 0, cin, dy, ldy, cout, dW, B, Hin, Win, Hout, Wout, 3, 1, 2, sw, db, &bias_done, 0,
                    1, 0, 0, 0, part, desc_out);

@@ -60,9 +60,13 @@ struct Slab {
 
 struct Grads {   // gradient workspace (single copy, reused by every timestep of the backward sweep)
     size_t cat7, n2, n4, n5, e6;
-    size_t cat6[2], e2[2], e6raw[2], e0raw[2], dv[2];   // the dY tensors the side stream's weight gradients read, by timestep parity: a step rewrites the buffer the
-                                                        // weight gradients of TWO steps ago read, so the main stream never waits for the previous step's (round 5)
-    size_t din[7][2], dc[7];
+    size_t e0raw[2], dv[2];   // dY tensors the side stream's weight gradients read, by timestep parity: a step rewrites the buffer the weight gradients of
+                              // TWO steps ago read, so the main stream never waits for the previous step's (round 5)
+    // The dY tensors of the five stride-2 3x3 layers live in RINGS like the ConvLSTMs' dG: 2 rings x eg_cap timesteps, one weight-gradient launch per
+    // batch (wgrad3x3s2.hip).  enc6: d e6raw; enc2: d e2; enc1: columns 64.. of d cat6; enc5 / enc4: the x columns of lstm7's / lstm6's input gradient,
+    // din[6] / din[5] -- so those two hold ring slots as well (the other cells' din: two buffers by timestep parity).  *_sz: floats per slot.
+    size_t cat6, e2, e6raw, cat6_sz, e2_sz, e6raw_sz;
+    size_t din[7], din_sz[7], dc[7];
     size_t dG[7], go, dmk, dz, dkpart, dstate, lnpart;   // dG: gate pre-activation gradients per ConvLSTM: 2 rings x wg_cap timesteps (batched weight gradients)
                                                              // go: d loss / d gen[t] for every t ([T-1] frames: the loss terms of all of them come from ONE launch)
     size_t wt_lstm[7], wt_enc[7];   // re-packed (transposed) weights for the data gradients, rebuilt once per backward
@@ -124,6 +128,10 @@ struct pivp_plan {
     bool group_join = true;                                 // pivp_plan_set_group_join
     bool ln_touched[9] = {};                                // norms whose partial parameter gradients still await their reduction
     WgradDesc enc_desc[5]; bool enc_desc_valid[5] = {};     // enc6, enc5, enc4, enc2, enc1: what this sweep launched (for the reduction of the partial sums)
+    int eg_cap = 1;                                         // slots per enc dY ring (Grads::cat6): min(T - 2, WG_BATCH_MAX)
+    int enc_cnt[5] = {};                                    // timesteps in each layer's open batch (enc6 only counts the steps a frame gradient reaches)
+    const float* enc_x0[5] = {};                            // ... and the forward input of the batch's first timestep
+    bool enc_started[5] = {};                               // the layer has launched in this sweep: its partial planes hold sums (before: stored, not added)
     // the side stream(s) and every fork / join event, back to "never created" (the destructor; ensure_side's partial-failure path)
     void destroy_side() {
         for (int i = 0; i < 7; ++i) for (int r = 0; r < 2; ++r) if (ev_ring_done[i][r]) { (void)hipEventDestroy(ev_ring_done[i][r]); ev_ring_done[i][r] = nullptr; }
@@ -188,6 +196,7 @@ static void plan_layout(pivp_plan* p) {
         p->o_wbf16[i] = carve(lstm_bf16_weight_elems(kLstm[i].cx + kLstm[i].C, 4 * kLstm[i].C) * 3 / 2 + 64);   // room for the three planes of PIVP_PRECISION_BF16X6
     p->nslabs = train ? T - 1 : 2;
     p->wg_cap = wg_cap_of(p);
+    p->eg_cap = T - 2 < 1 ? 1 : (T - 2 > WG_BATCH_MAX ? WG_BATCH_MAX : T - 2);      // whatever the precision mode: every mode batches these
     p->slabs.resize(p->nslabs);
     for (int s = 0; s < p->nslabs; ++s) {
         Slab& S = p->slabs[s];
@@ -208,14 +217,14 @@ static void plan_layout(pivp_plan* p) {
         Grads& g = p->g;
         g.cat7 = carve(B * HW2 * 64); g.n2 = carve(B * HW2 * 32); g.n4 = carve(B * HW4 * 64);
         g.n5 = carve(B * HW8 * 128); g.e6 = carve(B * HW * 64);
-        for (int r = 0; r < 2; ++r) {
-            g.cat6[r] = carve(B * HW4 * 96); g.e2[r] = carve(B * HW8 * 64); g.e6raw[r] = carve(B * HW * 64); g.e0raw[r] = carve(B * HW2 * 32);
-            g.dv[r] = carve((size_t)B * 256);
-        }
+        for (int r = 0; r < 2; ++r) { g.e0raw[r] = carve(B * HW2 * 32); g.dv[r] = carve((size_t)B * 256); }
+        const size_t nq = (size_t)2 * p->eg_cap;      // slots per enc dY ring pair
+        auto slots = [&](size_t n, size_t count, size_t& sz) { sz = (n + 63) / 64 * 64; return carve(sz * count); };
+        g.cat6 = slots(B * HW4 * 96, nq, g.cat6_sz); g.e2 = slots(B * HW8 * 64, nq, g.e2_sz); g.e6raw = slots(B * HW * 64, nq, g.e6raw_sz);
         for (int i = 0; i < 7; ++i) {
             const size_t M = hsz[i] / kLstm[i].C * B;
             g.dc[i] = carve(B * hsz[i]);   // (d h of a cell is never materialised: the LayerNorm backward is folded into the gate backward)
-            g.din[i][0] = carve(M * (kLstm[i].cx + kLstm[i].C)); g.din[i][1] = carve(M * (kLstm[i].cx + kLstm[i].C));
+            g.din[i] = slots(M * (kLstm[i].cx + kLstm[i].C), i >= 5 ? nq : 2, g.din_sz[i]);
             g.dG[i] = carve(M * 4 * kLstm[i].C * 2 * p->wg_cap);
             g.wt_lstm[i] = carve((size_t)25 * (kLstm[i].cx + kLstm[i].C) * 4 * kLstm[i].C);
             g.wtb_lstm[i] = carve(lstm_bf16_weight_elems(4 * kLstm[i].C, conv5x5_bf16_rows(kLstm[i].cx + kLstm[i].C)) * 3 / 2 + 64);   // up to three planes
@@ -745,9 +754,11 @@ extern "C" int pivp_plan_group_wait(pivp_plan_t* plan, int group, void* stream) 
     return PIVP_OK;
 }
 
-// wg_ring / wg_slot: where this step's gate gradients go in the ConvLSTMs' dG rings; wg_flush: this step closes its batch
+// wg_ring / wg_slot: where this step's gate gradients go in the ConvLSTMs' dG rings; wg_flush: this step closes its batch.
+// eg_ring / eg_slot / eg_flush: the same for the dY rings of the five stride-2 3x3 layers (Grads::cat6); eq_next: the ring slot step t + 1 used.
 static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_grad, const float* action, const float* state_prev,
-                         bool has_go, float* go, float* go_prev, bool last_step, int wg_ring, int wg_slot, bool wg_flush, hipStream_t s) {
+                         bool has_go, float* go, float* go_prev, bool last_step, int wg_ring, int wg_slot, bool wg_flush,
+                         int eg_ring, int eg_slot, bool eg_flush, int eq_next, hipStream_t s) {
     const pivp_config_t& c = p->cfg;
     const int B = c.batch, H = c.height, W = c.width, HW = H * W;
     float* ws = p->ws;
@@ -755,6 +766,12 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     const Slab* Sp = t > 0 ? &p->slabs[t - 1] : nullptr;
     const Grads& g = p->g;
     const int par = t & 1, npar = par ^ 1;
+    const int eq = eg_ring * p->eg_cap + eg_slot;                              // this step's slot of the enc dY rings
+    float* const d_cat6 = ws + g.cat6 + (size_t)eq * g.cat6_sz;
+    float* const d_e2 = ws + g.e2 + (size_t)eq * g.e2_sz;
+    float* const d_e6raw = ws + g.e6raw + (size_t)eq * g.e6raw_sz;
+    // a cell's input gradient: this step's buffer (cur) or the one step t + 1 wrote (its h columns are this step's d h)
+    auto DIN = [&](int i, bool cur) -> float* { return ws + g.din[i] + (size_t)(i >= 5 ? (cur ? eq : eq_next) : (cur ? par : npar)) * g.din_sz[i]; };
     const int n2 = 32 * p->H2 * p->W2, n4 = 64 * p->H4 * p->W4, n8 = 128 * p->H8 * p->W8;
     float* lnpart = ws + g.lnpart;
     const long long ln_n[9] = {n2, n2, n2, n4, n4, n8, n4, n2, 64LL * HW};   // elements per sample of norm_enc0, hidden1..7, norm_enc6
@@ -773,11 +790,16 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     // weight-gradient slots (pivp_plan::NSLOT): join = the main stream waits for the slot's last weight-gradient kernels
     auto fork_of = [&](int slot, SideFork& f) -> const SideFork* {
         if (!p->side) return nullptr;
-        f.side = p->side_of(slot); f.ready = p->ev_ready[slot][par]; f.done = p->ev_done[slot][par];
+        const int r = slot >= 7 && slot < 12 ? eg_ring : par;
+        f.side = p->side_of(slot); f.ready = p->ev_ready[slot][r]; f.done = p->ev_done[slot][r];
         return &f;
     };
     auto join = [&](int slot) -> int {
         if (!p->side) return PIVP_OK;
+        if (slot >= 7 && slot < 12) {      // an enc layer's dY ring: only a batch's first step meets a slot the ring's previous launch (two batches ago) read
+            if (eg_slot) return PIVP_OK;
+            return hipStreamWaitEvent(s, p->ev_done[slot][eg_ring], 0) == hipSuccess ? PIVP_OK : PIVP_ERR_LAUNCH;
+        }
         return hipStreamWaitEvent(s, p->ev_done[slot][par], 0) == hipSuccess ? PIVP_OK : PIVP_ERR_LAUNCH;   // this parity's last use: two timesteps ago (never recorded: returns at once)
     };
     const long long slab_bytes = p->nslabs > 1 ? ((long long)p->slabs[1].cat7 - (long long)p->slabs[0].cat7) * 4 : 0;
@@ -808,8 +830,8 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         }
         RC(run_convlstm_backward(x, L.cx, ldx, h_prev, L.C, P(p, p->i_lstm_w[i]), ws + S.gates[i],
                                  Sp ? ws + Sp->c[i] : ws + p->o_zero, ws + S.c[i], nullptr, L.C,
-                                 last_step ? nullptr : ws + g.din[i][npar] + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
-                                 ring + (size_t)wg_slot * dG1, ws + g.wt_lstm[i], ws + g.din[i][par], nullptr, nullptr, B, hh, wwid,
+                                 last_step ? nullptr : DIN(i, false) + L.cx, cin, ws + g.dc[i], last_step ? 0 : 1,
+                                 ring + (size_t)wg_slot * dG1, ws + g.wt_lstm[i], DIN(i, true), nullptr, nullptr, B, hh, wwid,
                                  s, 1, (p->lstm_bf16 && ((p->bwd_planes != 3 && p->bwd_planes != -2) || wwid % 16 == 0 || B % 2 == 0)) ? reinterpret_cast<unsigned short*>(ws + g.wtb_lstm[i]) : nullptr, p->bwd_planes,
                                  wg_flush ? fork_of(i, f) : nullptr, &lf[i],    // dW = null: only the fork's `ready` (behind the gate math) is used
                                  t == 0 ? 1 : 0,
@@ -841,6 +863,39 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     // timestep's last launches (lstm1's and enc0's weight gradients) in front of it, and the main stream sat idle for ~40 us per timestep.
     SideFork fe;
     const int encp = p->bf16_all ? 1 : 0;      // bf16 mode: enc1's data gradient (the transposed conv's tile kernel) on bf16 operands too
+    // Weight gradients of the stride-2 3x3 layers (k = 0..4: enc6, enc5, enc4, enc2, enc1): a step adds itself to the layer's open batch -- its dY sits in slot
+    // eg_slot of the ring, its forward input one slab below the previous step's -- and the step that closes the batch launches ONE weight gradient over all of
+    // them on the side stream (wgrad3x3s2.hip: per launch a block pays 37-150 KB of partial planes, per timestep nothing).  run_conv_backward (dW = null) has
+    // recorded the fork's `ready` behind the final dY and in front of the data gradient.
+    struct EncSpec { int mode, layer, c, ldx, ldy, Hin, Win; };
+    const EncSpec kEnc[5] = {{1, 6, 64, 64, 64, p->H2, p->W2}, {1, 5, 96, 96, 128, p->H4, p->W4}, {1, 4, 128, 128, 192, p->H8, p->W8},
+                             {0, 2, 64, 64, 64, p->H4, p->W4}, {0, 1, 32, 32, 96, p->H2, p->W2}};
+    auto enc_add = [&](int k, const float* x) { if (!p->enc_cnt[k]++) p->enc_x0[k] = x; };
+    auto enc_flush = [&](int k, bool forked) -> int {
+        const int cnt = p->enc_cnt[k];
+        if (!cnt) return PIVP_OK;
+        const EncSpec& E = kEnc[k];
+        const size_t ring0 = (size_t)eg_ring * p->eg_cap;
+        const float* dy0 = k == 0 ? ws + g.e6raw + ring0 * g.e6raw_sz : k == 1 ? ws + g.din[6] + ring0 * g.din_sz[6] : k == 2 ? ws + g.din[5] + ring0 * g.din_sz[5]
+                         : k == 3 ? ws + g.e2 + ring0 * g.e2_sz : ws + g.cat6 + ring0 * g.cat6_sz + 64;
+        const long long dy_step = 4LL * (long long)(k == 0 ? g.e6raw_sz : k == 1 ? g.din_sz[6] : k == 2 ? g.din_sz[5] : k == 3 ? g.e2_sz : g.cat6_sz);
+        hipStream_t sw = s;
+        if (p->side) {
+            if (!forked && (hipEventRecord(p->ev_ready[7 + k][eg_ring], s) != hipSuccess ||
+                            hipStreamWaitEvent(p->side, p->ev_ready[7 + k][eg_ring], 0) != hipSuccess)) return PIVP_ERR_LAUNCH;
+            sw = p->side_of(7 + k);
+        }
+        const int Hout = E.mode ? 2 * E.Hin : E.Hin / 2, Wout = E.mode ? 2 * E.Win : E.Win / 2;
+        int bias_done = 0;
+        RC(run_wgrad(E.mode, p->enc_x0[k], E.c, E.ldx, nullptr, 0, 0, E.c, dy0, E.ldy, E.c, G(p, p->i_enc_w[E.layer]), B, E.Hin, E.Win, Hout, Wout, 3, 1, 2, sw,
+                     G(p, p->i_enc_b[E.layer]), &bias_done, 0, cnt, -slab_bytes, 0, dy_step, ws + g.wg_part[k], &p->enc_desc[k], nullptr, 0, 0,
+                     p->enc_started[k] ? 0 : 1));
+        if (!bias_done)
+            for (int j = 0; j < cnt; ++j) RC(bias_grad(dy0 + (size_t)j * (dy_step / 4), E.ldy, E.c, B * Hout * Wout, G(p, p->i_enc_b[E.layer]), sw));
+        if (p->side && hipEventRecord(p->ev_done[7 + k][eg_ring], sw) != hipSuccess) return PIVP_ERR_LAUNCH;
+        p->enc_started[k] = true; p->enc_desc_valid[k] = true; p->enc_cnt[k] = 0;
+        return PIVP_OK;
+    };
     // ---- heads (TM:711-728) ----
     if (has_go) {
         if (c.model_type == PIVP_MODEL_CDNA)
@@ -866,11 +921,13 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         else if (hipMemsetAsync(ws + g.n5, 0, (size_t)px8 * 128 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;   // DNA: no hidden5 head
         // group 6 (TM:601), reversed: norm_enc6 (+relu) <- enc6 deconv <- [hidden7 | enc0]
         RC(join(7));       // d e6raw
-        RC(lnb(8, ws + g.e6, 64, ws + S.e6, 64, ws + S.e6raw, ws + g.e6raw[par], 64 * HW, 64, 1));
-        RC(run_conv_backward(1, ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), ws + g.e6raw[par], 64, 64, nullptr, 0, ws + g.wt_enc[6], ws + g.cat7, 64, 0,
-                             G(p, p->i_enc_w[6]), G(p, p->i_enc_b[6]), B, p->H2, p->W2, s, 1, fork_of(7, fe), ws + g.wg_part[0], &p->enc_desc[0], nullptr, 0, encp));
-    p->enc_desc_valid[0] = true;
+        RC(lnb(8, ws + g.e6, 64, ws + S.e6, 64, ws + S.e6raw, d_e6raw, 64 * HW, 64, 1));
+        enc_add(0, ws + S.cat7);
+        RC(run_conv_backward(1, ws + S.cat7, 64, 64, P(p, p->i_enc_w[6]), d_e6raw, 64, 64, nullptr, 0, ws + g.wt_enc[6], ws + g.cat7, 64, 0,
+                             nullptr, nullptr, B, p->H2, p->W2, s, 1, eg_flush ? fork_of(7, fe) : nullptr, nullptr, nullptr, nullptr, 0, encp));
+        if (eg_flush) RC(enc_flush(0, true));
     } else {
+        if (eg_flush) RC(enc_flush(0, false));      // a batch whose last steps no frame gradient reaches
         // no gradient reaches this step's frame: only the recurrent paths are live
         if (hipMemsetAsync(ws + g.cat7, 0, (size_t)px2 * 64 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
         if (hipMemsetAsync(ws + g.n5, 0, (size_t)px8 * 128 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
@@ -882,7 +939,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
         p->enc_desc_valid[k] = false;
         hipStream_t sw = p->side ? p->side_of(7 + k) : s;
         RC(igemm_wgrad_reduce(p->enc_desc[k], sw));
-        if (p->side && hipEventRecord(p->ev_done[7 + k][0], sw) != hipSuccess) return PIVP_ERR_LAUNCH;      // (t = 0: parity 0, behind this step's own launch)
+        if (p->side && hipEventRecord(p->ev_done[7 + k][eg_ring], sw) != hipSuccess) return PIVP_ERR_LAUNCH;      // (t = 0: behind this step's own launch, same ring)
         return PIVP_OK;
     };
     // t = 0 is the sweep's final timestep: a gradient group is final once the side stream's weight gradients of its layers are in too
@@ -913,48 +970,52 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     RC(done(1));
     RC(join(11));          // enc1's dY lives in d cat6, which enc5's data gradient rewrites
     // group 5 (TM:600): d e5 = x-part of lstm7's d_in (ReLU fused in enc5) <- enc5 deconv <- [hidden6 | enc1]
-    RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), ws + g.din[6][par], 96, 128, ep_ok6 ? nullptr : ws + S.e5, 96, ws + g.wt_enc[5], ws + g.cat6[par], 96, 0,
-                         G(p, p->i_enc_w[5]), G(p, p->i_enc_b[5]), B, p->H4, p->W4, s, 1, fork_of(8, fe), ws + g.wg_part[1], &p->enc_desc[1], nullptr, 0, encp));
-    p->enc_desc_valid[1] = true;
-    RC(lnb_cell(5, ws + g.cat6[par], 96, n4, 64));
+    enc_add(1, ws + S.cat6);
+    RC(run_conv_backward(1, ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), DIN(6, true), 96, 128, ep_ok6 ? nullptr : ws + S.e5, 96, ws + g.wt_enc[5], d_cat6, 96, 0,
+                         nullptr, nullptr, B, p->H4, p->W4, s, 1, eg_flush ? fork_of(8, fe) : nullptr, nullptr, nullptr, nullptr, 0, encp));
+    if (eg_flush) RC(enc_flush(1, true));
+    RC(lnb_cell(5, d_cat6, 96, n4, 64));
     RC(join(9));           // enc4's dY = the x part of lstm6's d_in of this parity
     RC(lstmb(5, ws + S.e4, 128, p->H4, p->W4, &ep5));
     RC(done(2));
     // group 4 (TM:599): d e4 = x-part of lstm6's d_in <- enc4 deconv <- hidden5 (also read by the CDNA kernel generator)
-    RC(run_conv_backward(1, ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), ws + g.din[5][par], 128, 192, ep_ok5 ? nullptr : ws + S.e4, 128, ws + g.wt_enc[4], ws + g.n5, 128, 1,
-                         G(p, p->i_enc_w[4]), G(p, p->i_enc_b[4]), B, p->H8, p->W8, s, 1, fork_of(9, fe), ws + g.wg_part[2], &p->enc_desc[2], nullptr, 0, encp));
-    p->enc_desc_valid[2] = true;
+    enc_add(2, ws + S.n5);
+    RC(run_conv_backward(1, ws + S.n5, 128, 128, P(p, p->i_enc_w[4]), DIN(5, true), 128, 192, ep_ok5 ? nullptr : ws + S.e4, 128, ws + g.wt_enc[4], ws + g.n5, 128, 1,
+                         nullptr, nullptr, B, p->H8, p->W8, s, 1, eg_flush ? fork_of(9, fe) : nullptr, nullptr, nullptr, nullptr, 0, encp));
+    if (eg_flush) RC(enc_flush(2, true));
     RC(lnb_cell(4, ws + g.n5, 128, n8, 128));
     RC(lstmb(4, ws + S.e3, 64, p->H8, p->W8));
     RC(done(3));
     // group 3 (TM:598) + state predictor (TM:730): d e3 = x-part of lstm5's d_in (ld 192)
     RC(join(10));          // d e2
-    RC(enc3_state_bwd(ws + S.e2, ws + S.e3, ws + g.din[4][par], 192, action, state_prev, P(p, p->i_enc_w[3]), P(p, p->i_cs_w),
-                      ws + g.dstate + (size_t)t * B * 5, ws + g.e2[par], G(p, p->i_enc_w[3]), G(p, p->i_enc_b[3]), G(p, p->i_cs_w),
+    RC(enc3_state_bwd(ws + S.e2, ws + S.e3, DIN(4, true), 192, action, state_prev, P(p, p->i_enc_w[3]), P(p, p->i_cs_w),
+                      ws + g.dstate + (size_t)t * B * 5, d_e2, G(p, p->i_enc_w[3]), G(p, p->i_enc_b[3]), G(p, p->i_cs_w),
                       G(p, p->i_cs_b), t > 0 ? ws + g.dstate + (size_t)(t - 1) * B * 5 : ws + g.dstate + (size_t)(c.seq_len - 1) * B * 5,
                       B, p->H8 * p->W8, c.use_state, s, 1));      // d e2 comes out masked by enc2's ReLU
     // group 2 (TM:597): enc2 conv (ReLU) <- hidden4 <- lstm4 <- hidden3 <- lstm3 <- enc1
-    RC(run_conv_backward(0, ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), ws + g.e2[par], 64, 64, nullptr, 0, ws + g.wt_enc[2], ws + g.n4, 64, 0,
-                         G(p, p->i_enc_w[2]), G(p, p->i_enc_b[2]), B, p->H4, p->W4, s, 1, fork_of(10, fe), ws + g.wg_part[3], &p->enc_desc[3], nullptr, 0, encp));
-    p->enc_desc_valid[3] = true;
+    enc_add(3, ws + S.n4);
+    RC(run_conv_backward(0, ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), d_e2, 64, 64, nullptr, 0, ws + g.wt_enc[2], ws + g.n4, 64, 0,
+                         nullptr, nullptr, B, p->H4, p->W4, s, 1, eg_flush ? fork_of(10, fe) : nullptr, nullptr, nullptr, nullptr, 0, encp));
+    if (eg_flush) RC(enc_flush(3, true));
     RC(lnb_cell(3, ws + g.n4, 64, n4, 64));
     RC(lstmb(3, ws + S.n3, 64, p->H4, p->W4));      // its data gradient's x columns = the dy of hidden3
-    RC(lnb_cell(2, ws + g.din[3][par], 128, n4, 64));
+    RC(lnb_cell(2, DIN(3, true), 128, n4, 64));
     RC(lstmb(2, ws + S.cat6 + 64, 96, p->H4, p->W4));
     RC(done(4));
     // group 1 (TM:596): enc1 conv (ReLU) <- hidden2 <- lstm2 <- hidden1 <- lstm1 <- enc0
-    RC(run_conv_backward(0, ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), ws + g.cat6[par] + 64, 32, 96, ws + S.cat6 + 64, 96, ws + g.wt_enc[1], ws + g.n2, 32, 0,
-                         G(p, p->i_enc_w[1]), G(p, p->i_enc_b[1]), B, p->H2, p->W2, s, 1, fork_of(11, fe), ws + g.wg_part[4], &p->enc_desc[4],
-                         ws + g.din[2][par], 96, encp));      // d enc1 = enc5's concat part (in d cat6) + lstm3's x gradient, summed in the ReLU-mask pass
-    p->enc_desc_valid[4] = true;
+    enc_add(4, ws + S.n2);
+    RC(run_conv_backward(0, ws + S.n2, 32, 32, P(p, p->i_enc_w[1]), d_cat6 + 64, 32, 96, ws + S.cat6 + 64, 96, ws + g.wt_enc[1], ws + g.n2, 32, 0,
+                         nullptr, nullptr, B, p->H2, p->W2, s, 1, eg_flush ? fork_of(11, fe) : nullptr, nullptr, nullptr,
+                         DIN(2, true), 96, encp));      // d enc1 = enc5's concat part (in d cat6) + lstm3's x gradient, summed in the ReLU-mask pass
+    if (eg_flush) RC(enc_flush(4, true));
     RC(lnb_cell(1, ws + g.n2, 32, n2, 32));
     RC(lstmb(1, ws + S.n1, 32, p->H2, p->W2));      // ... of hidden1
-    RC(lnb_cell(0, ws + g.din[1][par], 64, n2, 32));
+    RC(lnb_cell(0, DIN(1, true), 64, n2, 32));
     RC(lstmb(0, ws + S.cat7 + 32, 64, p->H2, p->W2, &ep0));
-    if (!ep_ok0) RC(add_strided(ws + g.cat7 + 32, 64, ws + g.din[0][par], 64, 32, px2, s));          // d enc0: from enc6's concat + from lstm1
+    if (!ep_ok0) RC(add_strided(ws + g.cat7 + 32, 64, DIN(0, true), 64, 32, px2, s));          // d enc0: from enc6's concat + from lstm1
     // group 0 (TM:595): norm_enc0 (+relu) <- enc0 conv <- frame
     RC(join(12));          // d e0raw
-    RC(lnb(0, ep_ok0 ? ws + g.din[0][par] : ws + g.cat7 + 32, 64, ws + S.cat7 + 32, 64, ws + S.e0raw, ws + g.e0raw[par], n2, 32, 1));
+    RC(lnb(0, ep_ok0 ? DIN(0, true) : ws + g.cat7 + 32, 64, ws + S.cat7 + 32, 64, ws + S.e0raw, ws + g.e0raw[par], n2, 32, 1));
     RC(enc0_bwd(prev, P(p, p->i_enc_w[0]), ws + g.e0raw[par], G(p, p->i_enc_w[0]), G(p, p->i_enc_b[0]), prev_has_grad ? go_prev : nullptr, 1,
                 B, H, W, s, fork_of(12, fe)));
     RC(done(5));
@@ -1013,11 +1074,11 @@ static int rollout_backward_sweep(pivp_plan_t* plan, const float* images, const 
         if (gb > plan->wg_cap) gb = plan->wg_cap;
         plan->wg_batch = gb;
     }
-    // the enc convs' per-block partial weight gradients and the norms' partial parameter gradients start from zero every sweep
-    if (hipMemsetAsync(ws + g.wg_part[0], 0, g.wg_part_floats * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
+    // the norms' partial parameter gradients start from zero every sweep; the enc convs' partial planes are STORED by each layer's first launch of the
+    // sweep (WgradDesc::part_overwrite; 240 MB of planes at B = 32: a memset of them would cost what the weight gradients do)
     if (hipMemsetAsync(ws + g.ln_ppart[0], 0, g.ln_ppart_floats * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     for (int j = 0; j < 9; ++j) plan->ln_touched[j] = false;
-    for (int k = 0; k < 5; ++k) plan->enc_desc_valid[k] = false;
+    for (int k = 0; k < 5; ++k) { plan->enc_desc_valid[k] = false; plan->enc_cnt[k] = 0; plan->enc_started[k] = false; }
     // d loss / d gen_states[t] for every t (zero before ctx-1), later accumulated with the state recurrence
     if (hipMemsetAsync(ws + g.dstate, 0, (size_t)T * B * 5 * 4, s) != hipSuccess) return PIVP_ERR_LAUNCH;
     // (gen_states[t] against states[t + 1], t = ctx-1 .. T-2: contiguous in t, one launch; likewise the frames' loss terms below -- 16 launches per sweep before)
@@ -1049,6 +1110,7 @@ static int rollout_backward_sweep(pivp_plan_t* plan, const float* images, const 
                               1));
         }
     bool has_go = false;
+    int eq_next = 0;      // the enc dY ring slot of step t + 1 (unused at t = T - 2)
     for (int t = T - 2; t >= 0; --t) {
         float* go = ws + g.go + (size_t)t * fr;
         float* go_prev = t >= 1 ? ws + g.go + (size_t)(t - 1) * fr : nullptr;
@@ -1063,14 +1125,19 @@ static int rollout_backward_sweep(pivp_plan_t* plan, const float* images, const 
         // With deep batches (G > 2: the bf16 mode's 8) the LAST TWO batched timesteps (t = 2, 1) form a batch of their own: one batch of everything
         // is launched at t = 1, when two timesteps of main-stream work are left for 1.4 ms of weight gradients to hide behind -- the sweep then ended with
         // the main stream waiting ~0.2 ms per step for the side stream (profiles/r05/NOTES.md).
-        const int G = plan->wg_batch, k = T - 2 - t, n = T - 2;
-        const int tail = (G > 2 && n > 2) ? 2 : 0, body = n - tail, nb_body = (body + G - 1) / G;
-        int wg_b, wg_slot; bool wg_flush;
-        if (t == 0) { wg_b = nb_body + (tail ? 1 : 0); wg_slot = 0; wg_flush = true; }
-        else if (k < body) { wg_b = k / G; wg_slot = k % G; wg_flush = wg_slot == G - 1 || k == body - 1; }
-        else { wg_b = nb_body; wg_slot = k - body; wg_flush = k == n - 1; }
+        auto sched = [&](int G, int& b, int& slot, bool& flush) {
+            const int k = T - 2 - t, n = T - 2;
+            const int tail = (G > 2 && n > 2) ? 2 : 0, body = n - tail, nb_body = (body + G - 1) / G;
+            if (t == 0) { b = nb_body + (tail ? 1 : 0); slot = 0; flush = true; }
+            else if (k < body) { b = k / G; slot = k % G; flush = slot == G - 1 || k == body - 1; }
+            else { b = nb_body; slot = k - body; flush = k == n - 1; }
+        };
+        int wg_b, wg_slot, eg_b, eg_slot; bool wg_flush, eg_flush;
+        sched(plan->wg_batch, wg_b, wg_slot, wg_flush);
+        sched(plan->eg_cap, eg_b, eg_slot, eg_flush);      // the stride-2 3x3 layers' weight gradients: as many timesteps per launch as their rings hold, every mode
         RC(backward_step(plan, t, prev, prev_has_grad && has_go, actions + (size_t)t * B * 5, st_prev, has_go, go, go_prev, last,
-                         wg_b & 1, wg_slot, wg_flush, s));
+                         wg_b & 1, wg_slot, wg_flush, eg_b & 1, eg_slot, eg_flush, eq_next, s));
+        eq_next = (eg_b & 1) * plan->eg_cap + eg_slot;
         has_go = next_loss || (prev_has_grad && has_go);
     }
     return PIVP_OK;      // the side stream is joined by the caller, pivp_rollout_backward, on every path
