@@ -1134,6 +1134,7 @@ static int rollout_backward_sweep(pivp_plan_t* plan, const float* images, const 
         };
         int wg_b, wg_slot, eg_b, eg_slot; bool wg_flush, eg_flush;
         sched(plan->wg_batch, wg_b, wg_slot, wg_flush);
+        // (1 / 2 / 4 timesteps per launch instead of the rings' 8, r05_c23: config 3 11.63 / 11.24 / 11.22 ms against 11.10, fp32 train 28.08 / 27.90 / 27.67 against 27.41)
         sched(plan->eg_cap, eg_b, eg_slot, eg_flush);      // the stride-2 3x3 layers' weight gradients: as many timesteps per launch as their rings hold, every mode
         RC(backward_step(plan, t, prev, prev_has_grad && has_go, actions + (size_t)t * B * 5, st_prev, has_go, go, go_prev, last,
                          wg_b & 1, wg_slot, wg_flush, eg_b & 1, eg_slot, eg_flush, eq_next, s));
