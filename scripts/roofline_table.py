@@ -85,7 +85,7 @@ def train_table(rows):
         ('ConvLSTM data gradients (igemm_f32_kernel<..,false>)', lambda n: 'igemm_f32_kernel' in n and 'false' in n, dgrad),
         ('ConvLSTM weight gradients (wgrad5x5_kernel, side stream)', lambda n: 'wgrad5x5_kernel' in n, wgrad),
         ('3x3 conv / deconv: forward + data gradients (igemm_small, deconv3x3s2_tile)', lambda n: 'igemm_small' in n or 'deconv3x3s2_tile' in n, 2 * small),
-        ('3x3 conv / deconv weight gradients (igemm_wgrad_kernel + reduce, side stream)', lambda n: 'igemm_wgrad' in n, small),
+        ('3x3 conv / deconv weight gradients (wgrad3x3s2_kernel: nine taps, batches of timesteps, + reduce; side stream)', lambda n: 'igemm_wgrad' in n or 'wgrad3x3s2' in n, small),
         ('gate math backward (lstm_gates_bwd*)', lambda n: 'lstm_gates_bwd' in n, 0.0),
         ('LayerNorm backward (ln_bwd_*)', lambda n: 'ln_bwd' in n, 0.0),
         ('LayerNorm apply', lambda n: 'ln_apply' in n, 0.0),
