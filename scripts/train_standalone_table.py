@@ -20,7 +20,9 @@ FAMILIES = [   # (label, substrings (all must match), matrix pipe?)
     ('ConvLSTM weight gradient (bf16, one timestep)', ('wgrad5x5_bf16_kernel',), True),
     ('3x3 conv / deconv forward + data gradients (igemm_small)', ('igemm_small_kernel',), True),
     ('3x3 deconv forward + data gradient (tile kernel)', ('deconv3x3s2_tile_kernel',), True),
-    ('3x3 conv / deconv weight gradients', ('igemm_wgrad_kernel',), True),
+    ('3x3 conv / deconv weight gradients: nine taps, batches of timesteps', ('wgrad3x3s2_kernel',), True),
+    ('... their partial planes\' reduction', ('wgrad3x3s2_reduce',), False),
+    ('3x3 conv / deconv weight gradients (per-tap kernel)', ('igemm_wgrad_kernel',), True),
     ('... their partial-sum reduction', ('igemm_wgrad_reduce',), False),
     ('gate backward (+ LayerNorm dx)', ('lstm_gates_bwd',), False),
     ('LayerNorm backward: sums + parameter planes', ('ln_bwd_sums_params',), False),

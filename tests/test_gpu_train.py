@@ -87,6 +87,23 @@ def test_bptt_gradients_match_autograd_feedself(pivp, T):
     assert np.allclose(got2['lstm5/conv/W'], 2 * got['lstm5/conv/W'], rtol=1e-3, atol=1e-9)
 
 
+@pytest.mark.parametrize('ctx,T', [(3, 5), (1, 4), (3, 7)])
+def test_bptt_gradients_other_context_lengths(pivp, ctx, T):
+    """num_frame_before_prediction != 2 (TM:484) moves the timestep below which no gradient reaches a frame.  The sweep batches the stride-2 3x3 layers' weight
+    gradients over timesteps (csrc/wgrad3x3s2.hip), and enc6 only takes part in the steps a frame gradient reaches: with ctx = 3 a batch ends on such a
+    step with enc6's own, shorter batch still open (T = 5: the batch of t = 2, 1; T = 7: of t = 2, 1 behind a body batch of three); with ctx = 1 every
+    step down to t = 0 has one."""
+    P = R.init_params_widened(seed=3, scale=1.0)
+    imgs, acts, stas = R.synthetic_batch(2, T)
+    loss_ref, gref = _autograd(P, imgs, acts, stas, num_frame_before_prediction=ctx)
+    m = pivp.Model(10, prefix='t', keep_activations=True, num_frame_before_prediction=ctx)
+    m.load_state_dict_reference(P)
+    loss = float(m([imgs, acts, stas], 0))
+    m.cleargrads(); m.backward()
+    assert abs(loss - loss_ref) < 1e-6
+    _check_grads(m.grads_reference(), gref, 2e-3)
+
+
 def test_bptt_gradients_scheduled_sampling_detaches_frames(pivp):
     P = R.init_params_widened(seed=1, scale=1.0)
     imgs, acts, stas = R.synthetic_batch(4, 5)
