@@ -45,6 +45,9 @@ def conv_case(name, cin, cout, H):
     def _(): return lib.pivp_conv3x3s2(x.data_ptr(), cin, cin, w.data_ptr(), b.data_ptr(), o.data_ptr(), cout, cout, 1, B, H, H, st)
 conv_case('enc1 conv3x3s2 32->32 @32', 32, 32, 32)
 conv_case('enc2 conv3x3s2 64->64 @16', 64, 64, 16)
+conv_case('enc6 dgrad = conv3x3s2 64->64 @64', 64, 64, 64)
+conv_case('enc5 dgrad = conv3x3s2 96->96 @32', 96, 96, 32)
+conv_case('enc4 dgrad = conv3x3s2 128->128 @16', 128, 128, 16)
 
 def deconv_case(name, cin, cout, H):
     x = R(B, H, H, cin); w = R(9 * cin * cout); b = R(cout); o = E(B, 2 * H, 2 * H, cout)
