@@ -120,7 +120,7 @@ struct pivp_plan {
     hipStream_t side = nullptr;
     hipStream_t side_of(int) const { return side; }      // (a second side stream for the odd slots, round 3: fp32 no change, bf16 12.25 -> 12.05 ms, but with two
                                                          // processes on one GPU the step went from 65 ms to 78 SECONDS -- the hardware queues oversubscribe)
-    hipEvent_t ev_ready[NSLOT][2] = {}, ev_done[NSLOT][2] = {};      // by timestep parity (slots 7..13; see Grads::cat6)
+    hipEvent_t ev_ready[NSLOT][2] = {}, ev_done[NSLOT][2] = {};      // slots 7..11 (the stride-2 3x3 layers): by dY ring; 12, 13: by timestep parity (Grads::cat6, e0raw)
     hipEvent_t ev_ring_done[7][2] = {};        // ConvLSTM slots: one `done` per dG ring (slots 0..6 of ev_done are unused)
     int wg_cap = 1;                            // dG ring slots per ring = min(T - 2, WG_BATCH_MAX), fixed when the workspace is laid out
     int wg_batch = 1;                          // timesteps per weight-gradient launch (<= wg_cap)
@@ -857,10 +857,10 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     };
     const long px2 = (long)B * p->H2 * p->W2, px8 = (long)B * p->H8 * p->W8;
 
-    // the enc convs' weight gradients of the previous (later) timestep read dY buffers that this step is about to rewrite
-    // The enc convs' weight gradients of the previous (later) timestep read dY buffers that this step rewrites: each is joined right in
-    // front of the first kernel that rewrites its buffer, not here -- at the top of a timestep the side stream still has the previous
-    // timestep's last launches (lstm1's and enc0's weight gradients) in front of it, and the main stream sat idle for ~40 us per timestep.
+    // The side stream's weight gradients read dY buffers that a later step rewrites (enc0 / the motion head: the buffer of two timesteps ago; the stride-2
+    // 3x3 layers: a ring slot of two batches ago): each is joined right in front of the first kernel that rewrites its buffer, not here -- at the top of a
+    // timestep the side stream still has the previous timestep's last launches (lstm1's and enc0's weight gradients) in front of it, and the main stream
+    // sat idle for ~40 us per timestep.
     SideFork fe;
     const int encp = p->bf16_all ? 1 : 0;      // bf16 mode: enc1's data gradient (the transposed conv's tile kernel) on bf16 operands too
     // Weight gradients of the stride-2 3x3 layers (k = 0..4: enc6, enc5, enc4, enc2, enc1): a step adds itself to the layer's open batch -- its dY sits in slot
@@ -960,7 +960,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
     };
     RC(done(0));
     RC(lnb_cell(6, ws + g.cat7, 64, n2, 32));
-    RC(join(8));           // enc5's dY = the x part of lstm7's d_in of this parity (two timesteps ago)
+    RC(join(8));           // enc5's dY = the x part of lstm7's d_in: a ring slot (a batch's first step waits for the ring's previous weight-gradient launch)
     // The x columns of a cell's input gradient are the dY of the enc conv in front of the cell: its ReLU mask (enc5, enc4) or the second gradient path into
     // the same tensor (enc0: + enc6's concat part) is met in the data gradient's epilogue where that kernel has the hook and its grid is unsplit (the bf16 /
     // split-precision forms: 27 relu_mask / add_strided launches fewer per train step at B = 32); otherwise the separate pass runs as before.
@@ -975,7 +975,7 @@ static int backward_step(pivp_plan* p, int t, const float* prev, bool prev_has_g
                          nullptr, nullptr, B, p->H4, p->W4, s, 1, eg_flush ? fork_of(8, fe) : nullptr, nullptr, nullptr, nullptr, 0, encp));
     if (eg_flush) RC(enc_flush(1, true));
     RC(lnb_cell(5, d_cat6, 96, n4, 64));
-    RC(join(9));           // enc4's dY = the x part of lstm6's d_in of this parity
+    RC(join(9));           // enc4's dY = the x part of lstm6's d_in, likewise
     RC(lstmb(5, ws + S.e4, 128, p->H4, p->W4, &ep5));
     RC(done(2));
     // group 4 (TM:599): d e4 = x-part of lstm6's d_in <- enc4 deconv <- hidden5 (also read by the CDNA kernel generator)
