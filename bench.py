@@ -112,6 +112,7 @@ RENDEZVOUS_TIMEOUT_S = int(os.environ.get('PIVP_RENDEZVOUS_TIMEOUT', '240'))
 # Every rank is done -- line printed, process gone -- this many seconds after the JOB started (the launcher's start; under an outer torchrun, that
 # launcher's).  The driver gives `bench.py` 600 s: a run that cannot finish says what it has measured inside that limit instead of being killed mute.
 BUDGET_S = float(os.environ.get('PIVP_BENCH_BUDGET', '450'))
+MAX_IMPORT_ALLOWANCE_S = 240.0   # a job start older than this is not believed (see _job_start): imports + rendezvous of N ranks on a fresh box
 LAUNCH_GRACE_S = 30.0           # the launcher waits this much longer than the ranks' own budget: 480 s for the default arguments
 
 
@@ -137,17 +138,43 @@ def _proc_start_epoch(pid):
         return None
 
 
+def _parent_is_torchrun(pid):
+    """is process `pid` a torch.distributed launcher (torchrun / `python -m torch.distributed.run|launch`)?  Only such a parent's age is the job's age: a
+    long-lived shell, a driver that exports WORLD_SIZE, a PyTorchJob entrypoint or an elastic agent restarting workers can be hours old."""
+    try:
+        with open('/proc/%d/cmdline' % pid, 'rb') as f:
+            words = f.read().decode('utf-8', 'replace').split('\0')
+    except Exception:
+        return False
+    joined = ' '.join(words)
+    return ('torch.distributed.run' in joined or 'torch.distributed.launch' in joined or
+            any(os.path.basename(w) == 'torchrun' for w in words[:3]))
+
+
 def _job_start():
     """When the job this process belongs to started: the launcher's clock (PIVP_BENCH_T0), else -- a rank under somebody else's torchrun -- the
-    start of that parent process (its `import torch` can take minutes on a fresh box and counts against the caller's limit), else now."""
+    start of that launcher (its `import torch` can take minutes on a fresh box and counts against the caller's limit), else this process's own
+    start.  Whatever the source, the start is never taken to be older than MAX_IMPORT_ALLOWANCE_S: a stale clock (a parent that is not the
+    launcher, a PIVP_BENCH_T0 inherited from an earlier job) must not put `Run.deadline` in the past before the first leg has run.
+    Returns (t0, source)."""
+    now = time.time()
     env = os.environ.get('PIVP_BENCH_T0')
+    t, src = None, None
     if env:
-        return float(env)
-    if os.environ.get('WORLD_SIZE') is not None:
+        try:
+            t, src = float(env), 'PIVP_BENCH_T0'
+        except ValueError:
+            t = None
+    if t is None and os.environ.get('WORLD_SIZE') is not None and _parent_is_torchrun(os.getppid()):
         t = _proc_start_epoch(os.getppid())
-        if t is not None:
-            return t
-    return _proc_start_epoch(os.getpid()) or time.time()
+        src = 'start of the parent launcher (pid %d)' % os.getppid()
+    if t is None:
+        t, src = _proc_start_epoch(os.getpid()), 'start of this process'
+    if t is None:
+        t, src = now, 'now'
+    if now - t > MAX_IMPORT_ALLOWANCE_S or t > now:
+        t, src = now - min(MAX_IMPORT_ALLOWANCE_S, max(0.0, now - (_proc_start_epoch(os.getpid()) or now))), src + ', clamped (stale clock)'
+    return t, src
 
 
 def _assemble_from_partial(path, reason):
@@ -276,8 +303,11 @@ class Run(object):
     def __init__(self, rank, world, value_leg):
         import threading
         self.rank, self.world, self.value_leg = rank, world, value_leg
-        self.t0 = _job_start()
+        self.t0, self.t0_source = _job_start()
         self.deadline = self.t0 + BUDGET_S
+        if world > 1:
+            sys.stderr.write('bench.py: rank %d: job start = %s, %.0f s ago; %.0f s of the %.0f s budget left\n'
+                             % (rank, self.t0_source, time.time() - self.t0, self.deadline - time.time(), BUDGET_S))
         self.line = {}              # the contract line, as far as it is measured (rank 0)
         self.planned = []           # the legs of this run, in order
         self.finished = []

@@ -40,7 +40,7 @@ extern "C" {
 #define PIVP_PRECISION_BF16X6 3
 #define PIVP_PRECISION_FP16X3 4
 
-int pivp_abi_version(void);   /* 15 (15: + pivp_wgrad5x5_bf16_batch_form; 14: + pivp_build_flags, pivp_plan_set_main_priority; 13: + pivp_wgrad5x5_bf16x6_batch; 12: + pivp_wgrad5x5_fp16x3_batch; 11: + pivp_conv5x5_fp16x3; 10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3, pivp_deconv3x3s2_fp16x3, pivp_plan_set_pack_cache, pivp_plan_params_changed; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+int pivp_abi_version(void);   /* 16 (16: + pivp_conv_wgrad_partial_batch, pivp_conv_wgrad_partial_reduce; 15: + pivp_wgrad5x5_bf16_batch_form; 14: + pivp_build_flags, pivp_plan_set_main_priority; 13: + pivp_wgrad5x5_bf16x6_batch; 12: + pivp_wgrad5x5_fp16x3_batch; 11: + pivp_conv5x5_fp16x3; 10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3, pivp_deconv3x3s2_fp16x3, pivp_plan_set_pack_cache, pivp_plan_params_changed; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
                                  5: + bf16 ConvLSTM, pivp_plan_set_precision, 6: + pivp_plan_set_group_join / pivp_plan_group_wait) */
 
 /* sha256 (hex) of the sources this library was compiled from (every .hip and .h under csrc/, and this header), embedded by build.py.  The Python
@@ -108,6 +108,10 @@ int pivp_plan_get_precision(const pivp_plan_t* plan);
 int pivp_plan_set_pack_cache(pivp_plan_t* plan, int on);
 int pivp_plan_params_changed(pivp_plan_t* plan);
 
+/* Size of a TRAINING plan's workspace, for orientation (fp32 mode): T - 1 activation slabs + the gradient workspace.  Since round 5 the dY tensors of
+ * the five stride-2 3x3 layers are kept as 2 x eg rings of timesteps (one batched weight-gradient launch per ring), eg = min(T - 2, 8) cut so that the
+ * rings together stay within 2 GiB: +0.97 GB at B = 32, T = 10 on 64 x 64 frames (eg = 8), +1.9 GB at B = 32, T = 20 on 128 x 128 (eg = 4).  All of it is
+ * caller-owned memory: the plan never allocates. */
 long long pivp_plan_workspace_bytes(const pivp_plan_t* plan);
 int pivp_plan_set_workspace(pivp_plan_t* plan, void* dptr, long long bytes);
 

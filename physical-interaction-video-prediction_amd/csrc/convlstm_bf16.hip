@@ -224,6 +224,7 @@ int conv5x5_bf16_rows(int N) { return N % 128 == 0 ? N : (N + 63) / 64 * 64; }
 int pack_lstm_bf16(const float* w, unsigned short* wb, int wcin, int N, hipStream_t s, int Np, int planes, int plain) {
     if (Np == 0) Np = N;
     PIVP_CHECK_ARG(w && wb && wcin > 0 && wcin % 32 == 0 && N > 0 && Np >= N && ((planes >= 1 && planes <= 3) || planes == -2));
+    PIVP_CHECK_ARG(plain == 0 || plain == 1);      // a layout selector, not a flag: a future third layout must not be read as "plain"
     const int pieces = planes == -2 ? 2 : planes;
     const long total = (long)lstm_bf16_weight_elems(wcin, Np) * pieces;
     if (planes == -2)        // the tensor's scale first: 64 partial maxima into the pack's tail

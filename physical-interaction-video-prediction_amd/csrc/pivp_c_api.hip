@@ -40,7 +40,7 @@ int run_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, co
     d.ln_part = ln_part; d.ln_cap = ln_cap;
     // w_bf16: the bf16 pack of w (pack_lstm_bf16) selects the bf16-operand kernel; variant then is its channels per block
     // (three pieces: maps the three-plane tile does not serve -- 8 wide -- take the fp32 kernel, which is what that mode stands in for)
-    // (two fp16 pieces: 8-wide maps take the ring kernel's fp16 form when its tiles fit -- an even batch --, whose pack is laid out differently: the caller's)
+    // (two fp16 pieces: 8-wide maps need an even batch for the tile to fit)
     if (w_bf16 && (bf16_planes == 3 || bf16_planes == -2) && !convlstm_bf16_ok(d)) return w ? igemm_lstm(d, s, 0, ln_nparts) : PIVP_ERR_BADARG;      // (an 8-wide map with an odd batch: the fp32 kernel)
     if (w_bf16) return convlstm_bf16(d, w_bf16, s, ln_nparts, ((bf16_planes == 3 || bf16_planes == -2) && variant != 16 && variant != 32) ? 0 : variant, bf16_planes);
     return igemm_lstm(d, s, variant, ln_nparts);
@@ -319,7 +319,7 @@ int run_convlstm_backward(const float* x, int cx, int ldx, const float* h_prev, 
     }
     if (wt_bf16) {   // bf16 precision mode: the data gradient with bf16 operands (wt_bf16 = bf16 pack of wt, built here unless wt_ready)
         if (!wt_ready) {
-            rc = pack_lstm_bf16(wt, wt_bf16, N, cin, s, conv5x5_bf16_rows(cin), bf16_planes, (bf16_planes == -2 && W % 16) ? 2 : 1);
+            rc = pack_lstm_bf16(wt, wt_bf16, N, cin, s, conv5x5_bf16_rows(cin), bf16_planes, 1);      // fragment-major plain pack, every map width
             if (rc != PIVP_OK) return rc;
         }
         rc = run_conv5x5_bf16(dG, N, N, wt_bf16, d_in, cin, cin, 0, B, H, W, s, bf16_planes, zero, dg_absmax, ep);
@@ -541,7 +541,7 @@ extern "C" int pivp_convlstm_bf16x6(const float* x, int cx, int ldx, const float
 }
 extern "C" int pivp_pack_lstm_fp16x3(const float* w, void* w_bf16, int cin_total, int C, int map_width, void* stream) {
     if (C <= 0 || map_width <= 0) return PIVP_ERR_BADARG;
-    // (maps that are a multiple of 16 wide: fragment-major, for the L2-direct kernel; 8-wide ones: the ring kernel's layout)
+    // (fragment-major for every map width; map_width is kept in the signature for ABI stability)
     return pack_lstm_bf16(w, (unsigned short*)w_bf16, cin_total, 4 * C, (hipStream_t)stream, 0, -2, 0);
 }
 extern "C" int pivp_convlstm_fp16x3(const float* x, int cx, int ldx, const float* h_prev, int C, const void* w_bf16, const float* bias,
@@ -601,7 +601,7 @@ extern "C" int pivp_conv5x5_bf16x6(const float* x, int cin, int ldx, const float
 extern "C" int pivp_conv5x5_fp16x3(const float* x, int cin, int ldx, const float* w, void* w_bf16, float* out, int cout, int ldo, int accum,
                                    int B, int H, int W, float* scratch, void* stream) {
     if (!x || !w || !w_bf16 || !out || !scratch || cin <= 0 || cout <= 0 || (W % 16 && (W % 8 || B % 2)) || ldx != cin || B <= 0 || H <= 0) return PIVP_ERR_BADARG;
-    int rc = pack_lstm_bf16(w, (unsigned short*)w_bf16, cin, cout, (hipStream_t)stream, conv5x5_bf16_rows(cout), -2, 1);      // (8-wide maps: the ring kernel's pack)
+    int rc = pack_lstm_bf16(w, (unsigned short*)w_bf16, cin, cout, (hipStream_t)stream, conv5x5_bf16_rows(cout), -2, 1);
     if (rc != PIVP_OK) return rc;
     rc = absmax_partials(x, (long)B * H * W * cin, scratch, (hipStream_t)stream);
     if (rc != PIVP_OK) return rc;

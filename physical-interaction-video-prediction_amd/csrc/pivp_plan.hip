@@ -2,6 +2,7 @@
 // Chainer's autograd performs under optimizer.update (TM:950), sequenced in native code on one HIP stream.
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -46,6 +47,7 @@ static int ln_partial_cap(int HW) {
 // gradients then arrive in bursts instead of filling the gaps of every step.  So the default is one timestep per launch
 // (PIVP_WGRAD_BATCH=1), the dG rings then simply double-buffer; the batched path stays for larger per-GPU batches and is tested
 // (tests/test_gpu_train.py).  Timestep 0 is always its own batch (its h_{-1} = 0 half is skipped).
+constexpr size_t ENC_RING_BYTES_MAX = (size_t)2 << 30;   // the five stride-2 3x3 layers' dY rings together (pivp_plan::eg_cap is cut to fit)
 constexpr int WG_BATCH_MAX = 8;   // most timesteps one ConvLSTM weight-gradient launch can take (dG ring slots per ring: pivp_plan::wg_cap <= this)
 
 struct Slab {
@@ -128,7 +130,7 @@ struct pivp_plan {
     bool group_join = true;                                 // pivp_plan_set_group_join
     bool ln_touched[9] = {};                                // norms whose partial parameter gradients still await their reduction
     WgradDesc enc_desc[5]; bool enc_desc_valid[5] = {};     // enc6, enc5, enc4, enc2, enc1: what this sweep launched (for the reduction of the partial sums)
-    int eg_cap = 1;                                         // slots per enc dY ring (Grads::cat6): min(T - 2, WG_BATCH_MAX)
+    int eg_cap = 1;                                         // slots per enc dY ring (Grads::cat6): min(T - 2, WG_BATCH_MAX), cut to ENC_RING_BYTES_MAX
     int enc_cnt[5] = {};                                    // timesteps in each layer's open batch (enc6 only counts the steps a frame gradient reaches)
     const float* enc_x0[5] = {};                            // ... and the forward input of the batch's first timestep
     bool enc_started[5] = {};                               // the layer has launched in this sweep: its partial planes hold sums (before: stored, not added)
@@ -197,6 +199,15 @@ static void plan_layout(pivp_plan* p) {
     p->nslabs = train ? T - 1 : 2;
     p->wg_cap = wg_cap_of(p);
     p->eg_cap = T - 2 < 1 ? 1 : (T - 2 > WG_BATCH_MAX ? WG_BATCH_MAX : T - 2);      // whatever the precision mode: every mode batches these
+    if (train) {
+        // ... bounded by bytes: a ring slot holds the dY of all five layers (60 MB at B = 32 on 64 x 64 frames, 240 MB on 128 x 128), and there are
+        // 2 x eg_cap of them.  ENC_RING_BYTES_MAX keeps config 2 at 8 timesteps per launch (0.97 GB) and gives config 5 four (1.9 GB instead of
+        // 3.9 GB; 4 against 8 per launch measured 11.22 against 11.10 ms on config 3, profiles/r05/NOTES.md).  include/pivp_hip.h documents the growth.
+        const size_t r64 = 63;
+        const size_t slot_floats = (((size_t)B * HW4 * 96 + r64) & ~r64) + (((size_t)B * HW8 * 64 + r64) & ~r64) + (((size_t)B * HW * 64 + r64) & ~r64) +
+                                   (((size_t)B * HW4 * (kLstm[5].cx + kLstm[5].C) + r64) & ~r64) + (((size_t)B * HW2 * (kLstm[6].cx + kLstm[6].C) + r64) & ~r64);
+        while (p->eg_cap > 1 && (size_t)2 * p->eg_cap * slot_floats * 4 > ENC_RING_BYTES_MAX) --p->eg_cap;
+    }
     p->slabs.resize(p->nslabs);
     for (int s = 0; s < p->nslabs; ++s) {
         Slab& S = p->slabs[s];
@@ -728,11 +739,17 @@ static int wait_slot(pivp_plan* p, int sl, hipStream_t stream) {
 }
 // Wave priority of the main stream's kernels during this plan's calls (csrc/pivp_common.h): the device word is rewritten only when the wanted value
 // differs from what this process last wrote on the device.
+// The cache of what the device words hold is process-wide (the words are per device, not per plan): guarded by a mutex, marked unknown while the
+// seven copies are being enqueued and valid only once all of them were accepted.  Plans with DIFFERENT wishes driven concurrently on one device (other
+// host threads / streams) may each run with either value: the copies are stream-ordered on the enqueuing plan's stream only.  Results never depend on it.
 static int apply_main_prio(pivp_plan* p, hipStream_t s) {
-    static int current[PIVP_MAX_DEV] = {};      // device words start at 0
+    static std::mutex mu;
+    static int current[PIVP_MAX_DEV] = {};      // device words start at 0; -1 = unknown (a setter failed midway)
     const int want = p->main_prio < 0 ? (p->grad_cb ? 0 : 1) : (p->main_prio ? 1 : 0);
     const int dev = pivp_current_device();
+    std::lock_guard<std::mutex> lock(mu);
     if (current[dev] == want) return PIVP_OK;
+    current[dev] = -1;
     RC(main_prio_set_backward(want, s)); RC(main_prio_set_backward_heads(want, s)); RC(main_prio_set_convlstm_bf16(want, s)); RC(main_prio_set_conv5x5_bf16(want, s));
     RC(main_prio_set_deconv_tile(want, s)); RC(main_prio_set_igemm_f32(want, s)); RC(main_prio_set_igemm_small(want, s));
     current[dev] = want;

@@ -146,3 +146,30 @@ def test_no_value_no_line():
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
     assert 'injected failure' in p.stderr
+
+
+def test_a_stale_parent_does_not_spend_the_budget_before_the_first_leg():
+    """a rank whose parent is NOT a torch launcher (a long-lived shell or agent that exports WORLD_SIZE) must not take that parent's
+    age for the job's; and an inherited, hours-old PIVP_BENCH_T0 is clamped.  Either way the deadline lies in the future when the run starts."""
+    sys.path.insert(0, ROOT)
+    import time
+    import bench
+    saved = {k: os.environ.get(k) for k in ('WORLD_SIZE', 'PIVP_BENCH_T0')}
+    try:
+        os.environ['WORLD_SIZE'] = '1'
+        os.environ.pop('PIVP_BENCH_T0', None)
+        assert not bench._parent_is_torchrun(os.getppid())            # pytest's parent is a shell / runner, not torchrun
+        t0, src = bench._job_start()
+        assert 'parent' not in src and time.time() - t0 <= bench.MAX_IMPORT_ALLOWANCE_S + 1.0
+        os.environ['PIVP_BENCH_T0'] = repr(time.time() - 3000.0)
+        t0, src = bench._job_start()
+        assert 'clamped' in src and t0 + bench.BUDGET_S > time.time() + 100.0
+        os.environ['PIVP_BENCH_T0'] = repr(time.time() - 5.0)         # a fresh launcher clock is believed as it is
+        t0, src = bench._job_start()
+        assert src == 'PIVP_BENCH_T0' and 4.0 < time.time() - t0 < 7.0
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
