@@ -40,7 +40,7 @@ extern "C" {
 #define PIVP_PRECISION_BF16X6 3
 #define PIVP_PRECISION_FP16X3 4
 
-int pivp_abi_version(void);   /* 16 (16: + pivp_conv_wgrad_partial_batch, pivp_conv_wgrad_partial_reduce; 15: + pivp_wgrad5x5_bf16_batch_form; 14: + pivp_build_flags, pivp_plan_set_main_priority; 13: + pivp_wgrad5x5_bf16x6_batch; 12: + pivp_wgrad5x5_fp16x3_batch; 11: + pivp_conv5x5_fp16x3; 10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3, pivp_deconv3x3s2_fp16x3, pivp_plan_set_pack_cache, pivp_plan_params_changed; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+int pivp_abi_version(void);   /* 17 (17: + pivp_wgrad5x5_f32_part_floats, pivp_wgrad5x5_f32_batch, pivp_wgrad5x5_f32_reduce, pivp_conv5x5_f32; 16: + pivp_conv_wgrad_partial_batch, pivp_conv_wgrad_partial_reduce; 15: + pivp_wgrad5x5_bf16_batch_form; 14: + pivp_build_flags, pivp_plan_set_main_priority; 13: + pivp_wgrad5x5_bf16x6_batch; 12: + pivp_wgrad5x5_fp16x3_batch; 11: + pivp_conv5x5_fp16x3; 10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3, pivp_deconv3x3s2_fp16x3, pivp_plan_set_pack_cache, pivp_plan_params_changed; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
                                  5: + bf16 ConvLSTM, pivp_plan_set_precision, 6: + pivp_plan_set_group_join / pivp_plan_group_wait) */
 
 /* sha256 (hex) of the sources this library was compiled from (every .hip and .h under csrc/, and this header), embedded by build.py.  The Python
@@ -294,6 +294,23 @@ int pivp_wgrad5x5_bf16x6_batch(const float* x, int cx, int ldx, const float* h_p
  * scratch: 72 * tcount floats (every timestep's partial maxima). */
 int pivp_wgrad5x5_fp16x3_batch(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* dW, float* db,
                                int B, int H, int W, int tcount, long long ts_x, long long ts_h, long long ts_dG, float* scratch, void* stream);
+
+/* The fp32 ConvLSTM weight gradient on its own (backward of TM:262-266; the sweep of pivp_rollout_backward runs it on its side stream): a batch of
+ * `tcount` timesteps per launch, operands as pivp_wgrad5x5_bf16_batch.  part == NULL: the round-2 kernel, fp32 atomics straight into dW / db.
+ * part != NULL (pivp_wgrad5x5_f32_part_floats floats, caller-owned): the round-6 kernel (csrc/wgrad5x5p.hip: LDS-DMA staging, an XCD-aware balanced
+ * partition of the (tile, pixel) work, no atomics) ADDS its segments into their slots of `part` -- overwrite != 0: stores them, so the first launch of a
+ * sweep needs no zeroing -- and pivp_wgrad5x5_f32_reduce adds the slots' sum into dW and, when db is given, the column sums of dG into db, in a fixed
+ * order: the result is bit-identical from run to run.  Launches that share `part` must be stream-ordered and describe the same (cx, C, B, H, W) AND agree on
+ * whether h_prev is given (has_h): a launch without it (the sweep's t = 0) cuts the x rows' tiles its own way, so reduce before switching and store first.
+ * form (the same in all three calls): 0 = by shape, 1 / 2 = 32 / 64 gate columns per wave.
+ * Needs H, W powers of two (W >= 8), B*H*W % 16 == 0, cx % 32 == 0, C % 32 == 0; pivp_wgrad5x5_f32_part_floats returns 0 for shapes it does not serve. */
+long long pivp_wgrad5x5_f32_part_floats(int cx, int C, int B, int H, int W, int form);
+int pivp_wgrad5x5_f32_batch(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* part, int overwrite,
+                            float* dW, float* db, int B, int H, int W, int tcount, long long ts_x, long long ts_h, long long ts_dG, int form, void* stream);
+int pivp_wgrad5x5_f32_reduce(int cx, int C, int has_h, float* part, float* dW, float* db, int B, int H, int W, int form, void* stream);
+/* The fp32 ConvLSTM data gradient on its own: plain 5x5 stride-1 pad-2 convolution, x [B*H*W][cin] (pixel stride ldx), wt packed [25][cin/32][cout][32]
+ * (for the data gradient: the flipped, transposed weight the sweep builds once per backward), out [B*H*W][cout] contiguous, overwritten. */
+int pivp_conv5x5_f32(const float* x, int cin, int ldx, const float* wt, float* out, int cout, int B, int H, int W, void* stream);
 
 /* --- training (what Chainer's autograd does under optimizer.update, TM:950) ---------------------------------- */
 /* pivp_convlstm with the gate activations kept for BPTT: gates_out [B*H*W][4C] = tanh(j), s(i), s(f+1), s(o). */

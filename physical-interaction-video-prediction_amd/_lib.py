@@ -122,6 +122,10 @@ SIGNATURES = {
     'pivp_composite': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'pivp_resize_images': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'pivp_select_frames': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'pivp_wgrad5x5_f32_part_floats': (_ll, [_i, _i, _i, _i, _i, _i]),
+    'pivp_wgrad5x5_f32_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
+    'pivp_wgrad5x5_f32_reduce': (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'pivp_conv5x5_f32': (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['igemm_f32.hip', 'igemm_small.hip', 'deconv_tile.hip', 'convlstm_bf16.hip', 'conv5x5_bf16.hip', 'igemm_wgrad.hip', 'wgrad3x3s2.hip', 'wgrad_bf16.hip', 'small_kernels.hip', 'heads.hip', 'frame_head.hip', 'backward.hip', 'backward_heads.hip', 'pivp_c_api.hip', 'pivp_plan.hip']
+SOURCES = ['igemm_f32.hip', 'igemm_small.hip', 'deconv_tile.hip', 'convlstm_bf16.hip', 'conv5x5_bf16.hip', 'igemm_wgrad.hip', 'wgrad3x3s2.hip', 'wgrad5x5p.hip', 'wgrad_bf16.hip', 'small_kernels.hip', 'heads.hip', 'frame_head.hip', 'backward.hip', 'backward_heads.hip', 'pivp_c_api.hip', 'pivp_plan.hip']
 LIB = os.path.join(HERE, 'libpivp_hip.so')
 STAMP = os.path.join(HERE, '.libpivp_hip.stamp')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']

@@ -18,6 +18,15 @@
 // together, i.e. what costs is LDS contents that CHANGE between chunks; scripts/wgrad_data_dependence.py: the full kernel is 13 % faster whenever
 // one of its operands is all zeros, at an unchanged 2.39 GHz.)
 
+#ifdef PIVP_WG_STAMPS   // per-block phase stamps of the ConvLSTM weight-gradient kernels (scripts/wgrad_stamps.py): [block][entry, loop start, loop end, done] in
+// 10 ns ticks (constant-rate counter), then the same points on the shader-cycle counter: cycles / wall = the clock the chip holds in that phase
+__device__ long long pivp_wg_stamps[2048 * 8];
+#define WG_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 2048) { const int sb_ = blockIdx.y * gridDim.x + blockIdx.x; \
+    pivp_wg_stamps[sb_ * 4 + (i)] = (long long)wall_clock64(); pivp_wg_stamps[2048 * 4 + sb_ * 4 + (i)] = (long long)clock64(); } } while (0)
+#else
+#define WG_STAMP(i)
+#endif
+
 namespace pivp {
 
 constexpr int WG_PIX = 32;     // pixels (GEMM K) per chunk
@@ -281,6 +290,7 @@ __global__ __launch_bounds__(256, 2) void wgrad5x5_kernel(const WgradDesc d) {
     constexpr int NBUF = 2;                     // LDS buffers per wave
     constexpr int NACC = 5 * NTW;
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    WG_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -413,10 +423,12 @@ __global__ __launch_bounds__(256, 2) void wgrad5x5_kernel(const WgradDesc d) {
         buf ^= 1;
         c += 4;
     };
+    WG_STAMP(1);
     while (c < c_end) {
         iter(S0{});
         if (c < c_end) iter(S1{});
     }
+    WG_STAMP(2);
     // ---- bias gradient: the blocks of kernel row 2 / channel block 0 have fed every dY element of their pixel range through
     // the MFMAs exactly once; lane (n, half) holds the sum over its half's pixels ---------------------------------------
     if (d.db && ky == 2 && cb == 0) {
@@ -465,7 +477,10 @@ __global__ __launch_bounds__(256, 2) void wgrad5x5_kernel(const WgradDesc d) {
         // 85 -> 31 us, which is why only that one got per-block partial sums)
         atomicAdd(g, sm[t * IT + n * 33 + ci]);
     }
-    // bias gradient for free: the kernel-row 0 / channel-block 0 blocks have every dY pixel of their chunks in LDS... not kept; see bias_grad
+#ifdef PIVP_WG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WG_STAMP(3);
+#endif
 }
 
 template <int SW>
@@ -526,6 +541,10 @@ int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done) {
     PIVP_CHECK_ARG(d.cin == d.c0 + d.c1 && d.wcin >= d.cin && d.wcin % 32 == 0 && d.N > 0 && d.N % 32 == 0);
     PIVP_CHECK_ARG(d.M == d.B * d.Hg * d.Wg && d.M > 0 && d.ksize >= 1 && d.ksize <= 7);
     PIVP_CHECK_ARG(d.bytes0 > 0 && d.bytesy > 0 && (d.c1 == 0 || d.bytes1 > 0));
+    if (d.part && wgrad5x5p_ok(d)) {        // ConvLSTM 5x5, partial-slot form (round 6): no atomics; the column sums ride along
+        if (bias_done) *bias_done = d.db ? 1 : 0;
+        return wgrad5x5p(d, s);
+    }
     if (takes_fast_path(d)) {
         if (bias_done) *bias_done = d.db ? 1 : 0;
         return d.Wg == 8 ? launch_wgrad5x5<8>(d, s) : d.Wg == 16 ? launch_wgrad5x5<16>(d, s) : launch_wgrad5x5<32>(d, s);
@@ -547,6 +566,7 @@ int igemm_wgrad(const WgradDesc& d, hipStream_t s, int* bias_done) {
 }
 
 long long igemm_wgrad_part_floats(const WgradDesc& d) {
+    if (wgrad5x5p_ok(d)) return wgrad5x5p_part_floats(d);
     if (takes_fast_path(d)) return 0;
     if (wgrad3x3s2_ok(d)) return wgrad3x3s2_part_floats(d);
     int wg_n, tiles, nsplit;
@@ -555,7 +575,9 @@ long long igemm_wgrad_part_floats(const WgradDesc& d) {
 }
 
 int igemm_wgrad_reduce(const WgradDesc& d, hipStream_t s) {
-    PIVP_CHECK_ARG(d.part && d.dw && !takes_fast_path(d));
+    PIVP_CHECK_ARG(d.part && d.dw);
+    if (wgrad5x5p_ok(d)) return wgrad5x5p_reduce(d, s);
+    PIVP_CHECK_ARG(!takes_fast_path(d));
     if (wgrad3x3s2_ok(d)) return wgrad3x3s2_reduce(d, s);
     int wg_n, tiles, nsplit;
     generic_grid(d, wg_n, tiles, nsplit);
@@ -588,3 +610,9 @@ int repack_transpose(const float* w, float* wt, int taps, int cin, int N, int fl
 }
 
 }  // namespace pivp
+
+#ifdef PIVP_WG_STAMPS
+extern "C" int pivp_debug_wg_stamps(long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pivp_wg_stamps), sizeof(long long) * n) == hipSuccess ? 0 : -2;
+}
+#endif

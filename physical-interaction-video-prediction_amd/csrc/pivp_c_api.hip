@@ -403,6 +403,32 @@ long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin,
     d.Hg = mode ? Hin : Hout; d.Wg = mode ? Win : Wout; d.M = B * d.Hg * d.Wg;
     return igemm_wgrad_part_floats(d);
 }
+// descriptor of a ConvLSTM weight gradient's ONE-timestep geometry (what the partial buffer's size and the reduction depend on)
+static void lstm_wgrad_geom(WgradDesc& d, int cx, int C, int B, int H, int W) {
+    memset(&d, 0, sizeof(d));
+    d.c0 = cx; d.ld0 = cx; d.c1 = C; d.ld1 = C; d.cin = cx + C; d.wcin = cx + C; d.N = 4 * C; d.ldy = 4 * C;
+    d.B = B; d.Hx = H; d.Wx = W; d.Hy = H; d.Wy = W; d.Hg = H; d.Wg = W; d.M = B * H * W;
+    d.ksize = 5; d.pad = 2; d.stride = 1;
+}
+// (the sweep's t = 0 has no h operand: its launch differentiates the x rows only -- fewer tiles, another partition of the same buffer, reduced on its own)
+long long lstm_wgrad_part_floats(int cx, int C, int B, int H, int W, int form) {
+    WgradDesc d;
+    lstm_wgrad_geom(d, cx, C, B, H, W);
+    d.form = form;
+    if (!wgrad5x5p_ok(d)) return 0;
+    const long long full = wgrad5x5p_part_floats(d);
+    d.c1 = 0; d.cin = cx;
+    const long long xonly = wgrad5x5p_part_floats(d);
+    return full > xonly ? full : xonly;
+}
+int lstm_wgrad_reduce(int cx, int C, int has_h, float* part, float* dW, float* db, int B, int H, int W, hipStream_t s, int form) {
+    WgradDesc d;
+    lstm_wgrad_geom(d, cx, C, B, H, W);
+    d.form = form;
+    if (!has_h) { d.c1 = 0; d.cin = cx; }
+    d.part = part; d.dw = dW; d.db = db;
+    return igemm_wgrad_reduce(d, s);
+}
 
 }  // namespace pivp
 
@@ -414,7 +440,7 @@ extern "C" const char* pivp_build_digest(void) { return PIVP_BUILD_DIGEST; }
 #define PIVP_BUILD_FLAGS ""                // the compile flags beyond build.py's standard set (PIVP_EXTRA_FLAGS): "" = the product build
 #endif
 extern "C" const char* pivp_build_flags(void) { return PIVP_BUILD_FLAGS; }
-extern "C" int pivp_abi_version(void) { return 16; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
+extern "C" int pivp_abi_version(void) { return 17; }   // 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln (op entry of the norm + gate backward pair); 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries
 
 extern "C" int pivp_convlstm(const float* x, int cx, int ldx, const float* h_prev, int C, const float* w, const float* bias,
                              const float* c_in, float* c_out, float* h_out, int B, int H, int W, void* stream) {
@@ -498,6 +524,38 @@ extern "C" int pivp_conv_wgrad_partial_reduce(int mode, int cin, int cout, float
     d.Hg = mode ? Hin : Hout; d.Wg = mode ? Win : Wout; d.M = B * d.Hg * d.Wg;
     d.part = part; d.dw = dW; d.db = db;      // (the nine-tap kernel leaves its column sums in the planes: the reduction adds them into db)
     return igemm_wgrad_reduce(d, (hipStream_t)stream);
+}
+// The fp32 ConvLSTM weight gradient on its own (the sweep runs it on the side stream): a batch of `tcount` timesteps per launch as pivp_wgrad5x5_bf16_batch.
+// part == NULL: the round-2 kernel (atomics straight into dW / db).  part != NULL (pivp_wgrad5x5_f32_part_floats floats): the round-6 kernel adds -- overwrite
+// != 0: stores -- its segments into the partial slots; pivp_wgrad5x5_f32_reduce then adds the slots' sum into dW and db (fixed order: bit-reproducible).
+extern "C" long long pivp_wgrad5x5_f32_part_floats(int cx, int C, int B, int H, int W, int form) {
+    if (cx <= 0 || C <= 0 || B <= 0 || H <= 0 || W <= 0 || form < 0 || form > 2) return PIVP_ERR_BADARG;
+    return lstm_wgrad_part_floats(cx, C, B, H, W, form);
+}
+extern "C" int pivp_wgrad5x5_f32_batch(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* part, int overwrite,
+                                       float* dW, float* db, int B, int H, int W, int tcount, long long ts_x, long long ts_h, long long ts_dG, int form,
+                                       void* stream) {
+    if (!x || !dG || !dW || tcount < 1 || form < 0 || form > 2 || (part && lstm_wgrad_part_floats(cx, C, B, H, W, form) <= 0)) return PIVP_ERR_BADARG;
+    int bias_done = 0;
+    int rc = run_wgrad(0, x, cx, ldx, h_prev, C, C, cx + C, dG, 4 * C, 4 * C, dW, B, H, W, H, W, 5, 2, 1, (hipStream_t)stream, db, &bias_done, 0,
+                       tcount, ts_x, ts_h, ts_dG, part, nullptr, nullptr, 0, form, overwrite ? 1 : 0);
+    if (rc != PIVP_OK) return rc;
+    if (db && !bias_done)
+        for (int j = 0; j < tcount; ++j) {
+            rc = bias_grad(reinterpret_cast<const float*>(reinterpret_cast<const char*>(dG) + j * ts_dG), 4 * C, 4 * C, B * H * W, db, (hipStream_t)stream);
+            if (rc != PIVP_OK) return rc;
+        }
+    return PIVP_OK;
+}
+extern "C" int pivp_wgrad5x5_f32_reduce(int cx, int C, int has_h, float* part, float* dW, float* db, int B, int H, int W, int form, void* stream) {
+    if (!part || !dW || form < 0 || form > 2 || lstm_wgrad_part_floats(cx, C, B, H, W, form) <= 0) return PIVP_ERR_BADARG;
+    return lstm_wgrad_reduce(cx, C, has_h, part, dW, db, B, H, W, (hipStream_t)stream, form);
+}
+// The fp32 ConvLSTM data gradient on its own: a plain 5x5 stride-1 pad-2 convolution of x [B*H*W][cin] with wt (packed [25][cin/32][cout][32]: for the data
+// gradient the flipped, transposed weight) into out [B*H*W][cout] (contiguous); tile and K split as the sweep chooses them (out is cleared first when K is split).
+extern "C" int pivp_conv5x5_f32(const float* x, int cin, int ldx, const float* wt, float* out, int cout, int B, int H, int W, void* stream) {
+    if (!x || !wt || !out) return PIVP_ERR_BADARG;
+    return run_conv_s1(x, cin, ldx, wt, out, cout, cout, 5, B, H, W, (hipStream_t)stream, 0, 0, 0);
 }
 // pivp_convlstm_backward for the sweep's LAST timestep (t = 0): nobody reads d h_{-1}, so only the cx columns of d_in are computed
 // (the data gradient runs on the first cx columns of the transposed weight pack) and the h columns of d_in are not computed (left as they are, or cleared with the rest of d_in for a K-split data gradient).

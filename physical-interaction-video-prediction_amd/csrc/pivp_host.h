@@ -72,6 +72,10 @@ int run_conv_backward(int mode, const float* x, int cin, int ldx, const float* w
                                                                         // LDS reads, 2 MFMAs per 32-pixel chunk -- was built and is slower: profiles/r05/NOTES.md)
 // floats of WgradDesc::part a conv3x3s2 (mode 0) / deconv3x3s2 (mode 1) weight gradient of these sizes needs
 long long conv_backward_part_floats(int mode, int cin, int cout, int B, int Hin, int Win);
+// the fp32 ConvLSTM weight gradient's partial slots (csrc/wgrad5x5p.hip): floats of WgradDesc::part (0: the shape is not served), and the reduction
+// (has_h = 0: of launches without an h operand -- the sweep's t = 0 --, which cut the x rows' tiles their own way: reduce before switching)
+long long lstm_wgrad_part_floats(int cx, int C, int B, int H, int W, int form = 0);      // form: WgradDesc::form (0 by shape, 1 / 2 = 32 / 64 columns per wave)
+int lstm_wgrad_reduce(int cx, int C, int has_h, float* part, float* dW, float* db, int B, int H, int W, hipStream_t s, int form = 0);
 int run_layernorm(const float* x, const float* g, const float* b, float* out, float* partials, int B, int n, int C,
                   int ldo, float eps, int relu, hipStream_t s, float* stat_out = nullptr, int fused_nparts = 0);
 // run-time wave priority of the main stream's kernels (pivp_common.h): every translation unit with such kernels, on stream s

@@ -104,6 +104,12 @@ bool wgrad3x3s2_ok(const WgradDesc& d);
 long long wgrad3x3s2_part_floats(const WgradDesc& d);
 int wgrad3x3s2(const WgradDesc& d, hipStream_t s);
 int wgrad3x3s2_reduce(const WgradDesc& d, hipStream_t s);
+// the fp32 ConvLSTM weight gradient with LDS-DMA staging, an XCD-aware balanced partition and per-segment partial slots (csrc/wgrad5x5p.hip): partial-sum
+// path only; igemm_wgrad / igemm_wgrad_part_floats / igemm_wgrad_reduce route to it when wgrad5x5p_ok(d) and d.part is given (db: column sums in the slots)
+bool wgrad5x5p_ok(const WgradDesc& d);
+long long wgrad5x5p_part_floats(const WgradDesc& d);
+int wgrad5x5p(const WgradDesc& d, hipStream_t s);
+int wgrad5x5p_reduce(const WgradDesc& d, hipStream_t s);
 // bf16-operand form of the ConvLSTM weight gradient (csrc/wgrad_bf16.hip); the bias gradient is left to bias_grad
 bool wgrad5x5_bf16_ok(const WgradDesc& d);
 int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s);

@@ -465,3 +465,35 @@ def deconv3x3s2_of_norm_concat(h, gamma, beta, x1, W, b, relu, eps=1e-6, precisi
         _lib.check(fn(cat.data_ptr(), cin, cin, wd.data_ptr(), bd.data_ptr(), out.data_ptr(), cout, cout, int(relu), B, H, Wd, stream()), 'deconv3x3s2')
     torch.cuda.synchronize()
     return nchw(out, B, 2 * H, 2 * Wd, cout)
+
+
+def wgrad5x5_f32_batch(launches, slots=True, h_is_zero=False, form=0):
+    """The fp32 ConvLSTM weight gradient on its own.  launches: a list of (xs, hs, dGs) batches (lists of per-timestep x (B,cx,H,W), h (B,C,H,W),
+    dG (B,4C,H,W)), one launch each, laid out as the sweep's slabs and rings are (see wgrad5x5_bf16_batch).  slots: the round-6 kernel (the first launch
+    stores into the NaN-initialised partial slots, the others add; one reduction at the end) -- else the round-2 kernel (atomics).  -> (dW, db, raw dW)."""
+    lib = _lib.load()
+    B, cx, H, Wd = launches[0][0][0].shape
+    C = launches[0][1][0].shape[1]
+    dW = torch.zeros(25 * (cx + C) * 4 * C, dtype=torch.float32, device=DEV)
+    db = torch.zeros(4 * C, dtype=torch.float32, device=DEV)
+    part = None
+    if slots:
+        n = lib.pivp_wgrad5x5_f32_part_floats(cx, C, B, H, Wd, form)
+        assert n > 0
+        part = torch.full((n,), float('nan'), dtype=torch.float32, device=DEV)
+    keep = []
+    for li, (xs, hs, dGs) in enumerate(launches):
+        T = len(xs)
+        xd = torch.stack([nhwc(x) for x in xs]); hd = torch.stack([nhwc(h) for h in hs])
+        gd = torch.stack([nhwc(g) for g in dGs[::-1]])
+        keep.append((xd, hd, gd))
+        sx, sh, sg = xd[0].numel() * 4, hd[0].numel() * 4, gd[0].numel() * 4
+        _lib.check(lib.pivp_wgrad5x5_f32_batch(xd[T - 1].data_ptr(), cx, cx, None if h_is_zero else hd[T - 1].data_ptr(), C, gd.data_ptr(),
+                                               part.data_ptr() if slots else None, 1 if li == 0 else 0, dW.data_ptr(), db.data_ptr(), B, H, Wd, T,
+                                               -sx, -sh, sg, form, stream()), 'wgrad5x5_f32_batch')
+    if slots:
+        _lib.check(lib.pivp_wgrad5x5_f32_reduce(cx, C, 0 if h_is_zero else 1, part.data_ptr(), dW.data_ptr(), db.data_ptr(), B, H, Wd, form, stream()),
+                   'wgrad5x5_f32_reduce')
+    torch.cuda.synchronize()
+    raw = dW.cpu().numpy().copy()
+    return pivp_amd.from_internal('lstm1/conv/W', dW.cpu().numpy(), (4 * C, cx + C, 5, 5)), db.cpu().numpy(), raw

@@ -355,3 +355,52 @@ def test_layernorm_plus_gate_backward_pair(env, B, C, H, lddy, recurrent):
     assert _rel(dgm.cpu().numpy() - 0.5, tg.grad.numpy().reshape(-1)) < 2e-5
     assert _rel(dbt.cpu().numpy() + 0.25, tb.grad.numpy().reshape(-1)) < 2e-5
     assert off == 0 or float(dyw[:, :off].min()) == 7.0
+
+
+def _lstm_wgrad_ref(x, h, dG):
+    """dW[n, ci, ky, kx] = sum_{b,y,x} concat(x, h)[b, ci, y+ky-2, x+kx-2] * dG[b, n, y, x] (zero outside the image), float64 (TM:262-266 backward)."""
+    xin = np.concatenate([x, h], 1) if h is not None else x
+    H, W = xin.shape[2:]
+    pad = np.pad(xin, ((0, 0), (0, 0), (2, 2), (2, 2)))
+    dW = np.zeros((dG.shape[1], xin.shape[1], 5, 5))
+    for ky in range(5):
+        for kx in range(5):
+            dW[:, :, ky, kx] = np.einsum('bnyx,bcyx->nc', dG, pad[:, :, ky:ky + H, kx:kx + W])
+    return dW
+
+
+# (B, cx, C, H, timesteps per launch): every map width of the model (8 ... 64) and 128 (config 5), odd batches, cx != C, partitions with one and several
+# pixel parts, segments that cross tile boundaries, a batch of timesteps per launch and several launches into the same slots
+@pytest.mark.parametrize('B,cx,C,H,Ts', [(2, 32, 32, 32, (1,)), (3, 32, 32, 32, (2, 1)), (2, 32, 64, 16, (1, 1, 1)), (5, 64, 64, 16, (3,)), (3, 64, 128, 8, (1, 2)),
+                                         (1, 96, 32, 32, (1,)), (2, 128, 64, 16, (2,)), (2, 32, 32, 64, (1,)), (1, 32, 32, 128, (1,)), (32, 64, 128, 8, (1,)),
+                                         (8, 96, 32, 32, (1,))])
+@pytest.mark.parametrize('form', [1, 2])      # 32 / 64 gate columns per wave
+def test_convlstm_weight_gradient_in_partial_slots(env, B, cx, C, H, Ts, form):
+    """Round 6's fp32 ConvLSTM weight gradient (csrc/wgrad5x5p.hip): launches add into NaN-initialised partial slots (the first one stores), one reduction
+    forms dW and db.  Against float64 sums; against the round-2 kernel; and bit-identical when repeated."""
+    import hip_ops as ops
+    rs = np.random.RandomState(B * 7 + cx + C + H)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    launches = []
+    ref = 0.0; dbr = 0.0
+    for T in Ts:
+        xs = [f32(rs.randn(B, cx, H, H)) for _ in range(T)]; hs = [f32(rs.randn(B, C, H, H) * 0.5) for _ in range(T)]
+        dGs = [f32(rs.randn(B, 4 * C, H, H) * 0.1) for _ in range(T)]
+        launches.append((xs, hs, dGs))
+        ref = ref + sum(_lstm_wgrad_ref(x, h, g) for x, h, g in zip(xs, hs, dGs))
+        dbr = dbr + sum(g.sum(axis=(0, 2, 3)) for g in dGs)
+    got, db, raw = ops.wgrad5x5_f32_batch(launches, form=form)
+    unit = np.sqrt((ref ** 2).mean())
+    err = np.abs(got - ref).max() / unit
+    old, dbo, _ = ops.wgrad5x5_f32_batch(launches, slots=False)
+    err_old = np.abs(old - ref).max() / unit
+    print('lstm wgrad form %d %d+%d @%d B %d launches %s: slots max |err| %.2e of the gradient rms, round-2 kernel %.2e' % (form, cx, C, H, B, Ts, err, err_old))
+    assert np.isfinite(got).all() and err < 2e-5 and err <= 3.0 * err_old + 1e-7
+    assert np.abs(db - dbr).max() < 2e-5 * np.abs(dbr).max() + 1e-6
+    got2, db2, raw2 = ops.wgrad5x5_f32_batch(launches, form=form)
+    assert np.array_equal(raw, raw2) and np.array_equal(db, db2)          # no atomics: bit-identical
+    if len(Ts) == 1 and Ts[0] == 1:      # the sweep's t = 0: no h operand, only the x rows are differentiated (their own partition of the slots)
+        xs, hs, dGs = launches[0]
+        got0, db0, _ = ops.wgrad5x5_f32_batch(launches, h_is_zero=True, form=form)
+        assert np.abs(got0[:, :cx] - ref[:, :cx]).max() < 2e-5 * unit and np.all(got0[:, cx:] == 0)
+        assert np.abs(db0 - dbr).max() < 2e-5 * np.abs(dbr).max() + 1e-6

@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), 'libpivp_hip.so does not export %s' % name
     assert declared == set(_lib.SIGNATURES), 'ctypes table and header disagree: %s' % (declared ^ set(_lib.SIGNATURES))
-    assert _lib.load().pivp_abi_version() == 16
+    assert _lib.load().pivp_abi_version() == 17
 
 
 def test_stale_library_is_refused(monkeypatch):
@@ -42,7 +42,7 @@ def test_stale_library_is_refused(monkeypatch):
     with pytest.raises(RuntimeError, match='stale'):
         _lib.load()
     monkeypatch.undo()
-    assert _lib.load().pivp_abi_version() == 16
+    assert _lib.load().pivp_abi_version() == 17
 
 
 def test_product_build_records_no_extra_flags_and_a_missing_source_tree_is_named(monkeypatch):
@@ -57,7 +57,7 @@ def test_product_build_records_no_extra_flags_and_a_missing_source_tree_is_named
     with pytest.raises(RuntimeError, match='no_such_header.h is missing'):
         _lib.load()
     monkeypatch.undo()
-    assert _lib.load().pivp_abi_version() == 16
+    assert _lib.load().pivp_abi_version() == 17
 
 
 def test_plan_param_table_matches_reference_keys():
