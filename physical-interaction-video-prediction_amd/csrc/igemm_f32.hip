@@ -534,6 +534,33 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
             const int b = m0 / HWg;
             tile_stats(sv, own, std::integral_constant<int, OWNR>{}, b, ((m0 - b * HWg) / BM) * n_nblk + nblk);
         }
+    } else if (!deconv && d.out_step == 1 && d.Hout == d.Hg && d.Wout == d.Wg && !d.bias && !d.relu && !d.accum && !d.ln_part &&
+               (long long)d.M * d.ldo * 4 < (1LL << 31)) {
+        // The ConvLSTM data gradient's epilogue (plain stride-1 conv: output pixel = anchor, no bias / ReLU / statistics): as the gate epilogue above, the
+        // lane-dependent part of an element's address is ONE 32-bit offset of a buffer descriptor, the row of the accumulator register a scalar offset,
+        // rows past M fall outside the descriptor and are dropped -- no divisions, no 64-bit address arithmetic, no exec-mask region per row.  (The general
+        // form below divides twice per accumulator row: blocks spent 15-16 us between their last MFMA and their last store on lstm1 / lstm7 at B = 32 against
+        // the gate epilogue's 4.6, which is all of the 8-11 us per launch by which the data gradient trailed the forward kernel: profiles/r06/NOTES.md 2.)
+        const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, d.M * d.ldo * 4, 0x00020000);
+        const int vo = ((m0 + wm * 32 + 4 * half) * d.ldo + nblk * BN + wn * TPW * 32 + l31) * 4;
+        const int row4 = __builtin_amdgcn_readfirstlane(d.ldo * 4);
+        if (ksplit > 1) {
+            if (nchunks > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t)
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[t][r], rso, vo + t * 128, ((r & 3) + 8 * (r >> 2)) * row4, 0);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    const float v = acc[t][r];      // (a copy: __builtin_bit_cast applied to the vector ELEMENT acc[t][r] reads element 0 for every r with this hipcc)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rso, vo + t * 128, ((r & 3) + 8 * (r >> 2)) * row4, 0);
+                }
+        }
     } else {
         const int oy0 = deconv ? py : 0, ox0 = deconv ? px : 0;
         float sv[16 * TPW];
@@ -667,11 +694,14 @@ static bool dgrad_choice(const IgemmDesc& d, int& bt, int& bks) {
     struct Tile { int wm, wn, ntb; double eff; int resident; };
     static const Tile tiles[] = {{2, 2, 2, 0.80, 4}, {4, 1, 1, 0.70, 3}, {4, 1, 2, 0.90, 2}, {4, 1, 3, 0.95, 2}, {4, 1, 4, 1.00, 1}, {2, 2, 4, 0.95, 2}, {1, 4, 4, 0.80, 3}};
     static const double fixed_taps[] = {3.0, 1.5, 1.0, 1.0};
-    static const double alone[] = {0.80, 1.0, 1.0, 1.0};      // one wave per SIMD hides none of its own waits
+    static const double alone[] = {0.90, 1.0, 1.0, 1.0};      // one wave per SIMD hides none of its own waits (0.80 until round 6: see the split penalty below)
     const int cus = pivp_cu_count();
     bt = -1; bks = 1;
     double bcost = 1e300;
     const int nchunks = d.ksize * d.ksize * ((d.c0 + d.c1) / 32);
+    // a split output is cleared first and then takes ks atomic adds per element: what that costs grows with the rows (lstm1 / lstm2 at B = 32, 32,768 rows x 64
+    // columns: 128 x 64 unsplit 107.4 us against 112 in two splits once the epilogue stopped dividing -- r06_c13; before, the split hid a 15-us epilogue)
+    const double split_penalty = 1.01 + 0.14 * (d.M >= 32768 ? 1.0 : d.M / 32768.0);
     for (int t = 0; t < 7; ++t) {
         if (nt % tiles[t].ntb) continue;
         const int bm = 32 * tiles[t].wm, bn = 32 * tiles[t].ntb;
@@ -681,7 +711,7 @@ static bool dgrad_choice(const IgemmDesc& d, int& bt, int& bks) {
             const long per_cu = (blocks + cus - 1) / cus;
             const int res = (int)(per_cu < tiles[t].resident ? per_cu : tiles[t].resident);
             const double taps = (double)(d.ksize * d.ksize) / ks;       // taps of one split
-            const double cost = (double)per_cu * bm * bn * (taps + fixed_taps[res - 1]) / (tiles[t].eff * alone[res - 1]) * (ks > 1 ? 1.01 : 1.0);
+            const double cost = (double)per_cu * bm * bn * (taps + fixed_taps[res - 1]) / (tiles[t].eff * alone[res - 1]) * (ks > 1 ? split_penalty : 1.0);
             if (cost < bcost) { bcost = cost; bt = t; bks = ks; }
         }
     }
