@@ -13,6 +13,13 @@
 
 #include "pivp_kernels.h"
 
+#ifdef PIVP_DT_STAMPS   // per-block phase stamps (scripts/deconv_stamps.py): [block][entry, statistics merged, first chunk staged, loop done, stores done]
+__device__ long long pivp_dt_stamps[2048 * 8];
+#define DT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) pivp_dt_stamps[blockIdx.x * 8 + (i)] = (long long)wall_clock64(); } while (0)
+#else
+#define DT_STAMP(i)
+#endif
+
 namespace pivp {
 
 namespace {
@@ -45,6 +52,7 @@ __device__ __forceinline__ unsigned dpack2(float a, float b) {
 template <int PREC, bool IN_LN>
 __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDesc d) {
     PIVP_SET_MAIN_PRIO();
+    DT_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) float lds[];   // A patch | the 9 weight tiles
     float* const At = lds;
     float* const Bt = lds + A_FL;
@@ -74,6 +82,7 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
         ln_merge_partials(d.in_part, b, d.in_np, d.in_eps, ln_mean, ln_rstd);      // every wave for itself: a few partials per sample
         if (d.in_stat_out && nblk == 0 && trem == 0 && tid == 0) { d.in_stat_out[b * 2] = ln_mean; d.in_stat_out[b * 2 + 1] = ln_rstd; }
     }
+    DT_STAMP(1);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, d.bytesw, 0x00020000);
     float wscale = 1.0f;
     if constexpr (PREC == 3) wscale = d.wscale_part ? pivp_x3_scale_wave(d.wscale_part) : 1.0f;
@@ -248,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
     load_chunk(0);
     store_chunk();
     __syncthreads();
+    DT_STAMP(2);
     for (int cc = 0; cc < ncc; ++cc) {
         if (cc + 1 < ncc) load_chunk(cc + 1);
         tap_mfmas(std::integral_constant<int, 0>{}); tap_mfmas(std::integral_constant<int, 1>{}); tap_mfmas(std::integral_constant<int, 2>{});
@@ -260,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
         }
     }
 
+    DT_STAMP(3);
     // ---- epilogue: accumulator row i -> anchor (2 wave + i / 16, i % 16), parity (py, px) -> output pixel (2 y + py, 2 x + px) ----------
     const int col = nblk * 32 + l31;
     const float bias = d.bias ? d.bias[col] : 0.f;
@@ -302,6 +313,11 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
             p[0] = cnt; p[1] = mean; p[2] = (red[4] + red[5]) + (red[6] + red[7]); p[3] = 0.f;
         }
     }
+#ifdef PIVP_DT_STAMPS
+    DT_STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DT_STAMP(5);
+#endif
 }
 
 bool deconv_tile_ok(const IgemmDesc& d) {
@@ -346,3 +362,9 @@ int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts, int prec
 }  // namespace pivp
 
 PIVP_DEFINE_MAIN_PRIO_SETTER(deconv_tile)
+
+#ifdef PIVP_DT_STAMPS
+extern "C" int pivp_debug_dt_stamps(long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pivp_dt_stamps), sizeof(long long) * n) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -104,38 +104,28 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
-// Chan et al. pairwise combination of (count, mean, M2).
-__device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
-    if (nb == 0.f) return;
-    const float nt = n + nb;
-    const float d = mb - mean;
-    const float r = nb / nt;
-    mean += d * r;
-    m2 += m2b + d * d * n * r;
-    n = nt;
-}
-
 // Merge the S (count, mean, M2) LayerNorm partials of sample b; call with the 64 lanes of ONE wave.
-// Every lane returns the same (mean, 1/sqrt(var + eps)); the merge order is fixed (bitwise reproducible).
+// Every lane returns the same (mean, 1/sqrt(var + eps)); the summation order is fixed (bitwise reproducible).
+// Two weighted sums instead of a tree of pairwise Chan merges (round 6): mean = sum n_i mean_i / sum n_i, then M2 = sum (M2_i + n_i (mean_i - mean)^2) --
+// three xor-tree wave sums and ONE division, where the pairwise form paid a division and two dependent shuffles per tree level.  Every consumer of a
+// producer's partials runs this in front of its first useful instruction (nine kernels per timestep: the four ln_apply, enc1 / enc2 / enc5 / enc6 with the
+// norm folded into their staging, frame_head): 2.0 us of each of them by the stamps of deconv3x3s2_tile_kernel (profiles/r06/NOTES.md 3).
 __device__ __forceinline__ void ln_merge_partials(const float* __restrict__ partials, int b, int S, float eps, float& mean_out,
                                                   float& rstd_out) {
     const int lane = threadIdx.x & 63;
-    float cn = 0.f, mean = 0.f, m2 = 0.f;
-    for (int i = lane; i < S; i += 64) {
-        const float* p = partials + ((size_t)b * S + i) * 4;
-        chan_combine(cn, mean, m2, p[0], p[1], p[2]);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float on = __shfl_xor(cn, off, 64), om = __shfl_xor(mean, off, 64), o2 = __shfl_xor(m2, off, 64);
-        // symmetric merge so both partners end with the same value
-        float a_n = cn, a_m = mean, a_2 = m2;
-        if ((lane & off) == 0) { chan_combine(a_n, a_m, a_2, on, om, o2); }
-        else { a_n = on; a_m = om; a_2 = o2; chan_combine(a_n, a_m, a_2, cn, mean, m2); }
-        cn = a_n; mean = a_m; m2 = a_2;
-    }
+    const f32x4* p = reinterpret_cast<const f32x4*>(partials) + (size_t)b * S;
+    // the first partial of a lane stays in registers for the second pass (S <= 64 wherever the producer is a tile kernel)
+    const f32x4 first = lane < S ? p[lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+    float cn = first[0], cs = first[0] > 0.f ? first[0] * first[1] : 0.f;
+    for (int i = lane + 64; i < S; i += 64) { const f32x4 v = p[i]; cn += v[0]; cs += v[0] > 0.f ? v[0] * v[1] : 0.f; }
+    cn = wave_sum(cn); cs = wave_sum(cs);
+    const float mean = cs / cn;
+    float d = first[1] - mean;
+    float q = first[0] > 0.f ? fmaf(first[0] * d, d, first[2]) : 0.f;      // (a slot with count 0 carries nothing: its other fields are not read into the sums)
+    for (int i = lane + 64; i < S; i += 64) { const f32x4 v = p[i]; d = v[1] - mean; q += v[0] > 0.f ? fmaf(v[0] * d, d, v[2]) : 0.f; }
+    q = wave_sum(q);
     mean_out = mean;
-    rstd_out = 1.0f / sqrtf(m2 / cn + eps);
+    rstd_out = 1.0f / sqrtf(q / cn + eps);
 }
 
 }  // namespace pivp
