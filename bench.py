@@ -598,7 +598,9 @@ def main(argv=None):
                                    B, T, S, S, nm),
                        'global_batch': world * B, 'frames_per_step': world * B * (T - 1),
                        'parallelism': ('dp%d (RCCL all-reduce of the flat gradient)' if train_mode else 'replicas x%d') % world,
-                       'loss': loss_val},
+                       'loss': loss_val,
+                       # objects a reader of an N > 1 record should not look for: they are measured by the 1-GPU line only (rank 0's host cores / one GPU's legs)
+                       **({'single_rank_only': ['cpu_baseline', 'rollout_bf16x6', 'rollout_fp16x3', 'train_bf16x6', 'train_fp16x3']} if world > 1 else {})},
             'roofline': None,
             'cpu_baseline': None,
         })

@@ -78,10 +78,8 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
     const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN_LN ? d.in_g : d.x0), 0, IN_LN ? H * W * d.c0 * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN_LN ? d.in_b : d.x0), 0, IN_LN ? H * W * d.c0 * 4 : 0, 0x00020000);
     float ln_mean = 0.f, ln_rstd = 1.f;
-    if constexpr (IN_LN) {
-        ln_merge_partials(d.in_part, b, d.in_np, d.in_eps, ln_mean, ln_rstd);      // every wave for itself: a few partials per sample
-        if (d.in_stat_out && nblk == 0 && trem == 0 && tid == 0) { d.in_stat_out[b * 2] = ln_mean; d.in_stat_out[b * 2 + 1] = ln_rstd; }
-    }
+    f32x4 ln_first = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (IN_LN) ln_first = ln_partial_first(d.in_part, b, d.in_np);      // requested here, merged behind the first chunk's loads (below)
     DT_STAMP(1);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, d.bytesw, 0x00020000);
     float wscale = 1.0f;
@@ -255,6 +253,10 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
 
     // ---- main loop over the 32-channel chunks ----------------------------------------------------------------------------------------
     load_chunk(0);
+    if constexpr (IN_LN) {
+        ln_merge_partials(ln_first, d.in_part, b, d.in_np, d.in_eps, ln_mean, ln_rstd);      // every wave for itself: a few partials per sample
+        if (d.in_stat_out && nblk == 0 && trem == 0 && tid == 0) { d.in_stat_out[b * 2] = ln_mean; d.in_stat_out[b * 2 + 1] = ln_rstd; }
+    }
     store_chunk();
     __syncthreads();
     DT_STAMP(2);

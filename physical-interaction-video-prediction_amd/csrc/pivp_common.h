@@ -110,12 +110,17 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // three xor-tree wave sums and ONE division, where the pairwise form paid a division and two dependent shuffles per tree level.  Every consumer of a
 // producer's partials runs this in front of its first useful instruction (nine kernels per timestep: the four ln_apply, enc1 / enc2 / enc5 / enc6 with the
 // norm folded into their staging, frame_head): 2.0 us of each of them by the stamps of deconv3x3s2_tile_kernel (profiles/r06/NOTES.md 3).
-__device__ __forceinline__ void ln_merge_partials(const float* __restrict__ partials, int b, int S, float eps, float& mean_out,
+// ln_partial_first: the lane's first partial, requested early (a consumer issues it, then its own first loads, then merges: the partials' round trip and
+// the merge's arithmetic run under the consumer's loads instead of in front of them).
+__device__ __forceinline__ f32x4 ln_partial_first(const float* __restrict__ partials, int b, int S) {
+    const int lane = threadIdx.x & 63;
+    return lane < S ? reinterpret_cast<const f32x4*>(partials)[(size_t)b * S + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void ln_merge_partials(f32x4 first, const float* __restrict__ partials, int b, int S, float eps, float& mean_out,
                                                   float& rstd_out) {
     const int lane = threadIdx.x & 63;
     const f32x4* p = reinterpret_cast<const f32x4*>(partials) + (size_t)b * S;
     // the first partial of a lane stays in registers for the second pass (S <= 64 wherever the producer is a tile kernel)
-    const f32x4 first = lane < S ? p[lane] : f32x4{0.f, 0.f, 0.f, 0.f};
     float cn = first[0], cs = first[0] > 0.f ? first[0] * first[1] : 0.f;
     for (int i = lane + 64; i < S; i += 64) { const f32x4 v = p[i]; cn += v[0]; cs += v[0] > 0.f ? v[0] * v[1] : 0.f; }
     cn = wave_sum(cn); cs = wave_sum(cs);
@@ -126,6 +131,9 @@ __device__ __forceinline__ void ln_merge_partials(const float* __restrict__ part
     q = wave_sum(q);
     mean_out = mean;
     rstd_out = 1.0f / sqrtf(q / cn + eps);
+}
+__device__ __forceinline__ void ln_merge_partials(const float* __restrict__ partials, int b, int S, float eps, float& mean_out, float& rstd_out) {
+    ln_merge_partials(ln_partial_first(partials, b, S), partials, b, S, eps, mean_out, rstd_out);
 }
 
 }  // namespace pivp

@@ -63,6 +63,8 @@ def test_eight_ranks_dry():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 8 and out['config']['global_batch'] == 256 and out['config']['frames_per_step'] == 8 * 32 * 9
     assert out['train']['rccl_ranks'] == 8 and out['train']['backend'] == 'gloo'
+    # an N > 1 record names the objects only the 1-GPU line carries
+    assert 'cpu_baseline' in out['config']['single_rank_only'] and out.get('cpu_baseline') is None
 
 
 def test_launcher_times_out_with_a_reason():

@@ -59,6 +59,16 @@ def test_rollout_matches_golden(pivp, name, mt, nm, precision):
     assert l2[:ctx].max() < GATE
     if mt != 'STP':                                             # STP fed-back steps: see the note at the top and test_config4_stp_batch32
         assert l2.max() < GATE
+    else:
+        # White-noise frames put plain float32 itself within a factor of two of the gate (note at the top), so the absolute gate alone would let a
+        # summation-order change pass or fail by a few per cent.  The statement that fails loudly: on these frames the HIP path is no less accurate than
+        # the float32 evaluation of the reference's arithmetic (the NumPy oracle in float32), ground-truth-fed steps and all steps, printed side by side.
+        ref32 = R.Model(nm, is_cdna=False, is_stp=True, params=P, dtype=np.float32, prefix='x'); ref32.train = False
+        ref32([imgs, acts, stas], 0)
+        l32 = R.per_pixel_l2(np.stack(ref32.gen_images), g['gen_images'])
+        print('%s (%s): max per-pixel L2, ground-truth-fed steps %.3e (float32 oracle %.3e), all steps %.3e (float32 oracle %.3e)'
+              % (name, precision, l2[:ctx].max(), l32[:ctx].max(), l2.max(), l32.max()))
+        assert l2[:ctx].max() < max(5e-5, 1.5 * l32[:ctx].max()) and l2.max() < max(5e-5, 2.0 * l32.max())
     assert np.sqrt((l2 ** 2).mean()) < 2e-5
     assert abs(loss - float(g['loss'])) < 1e-5
     assert abs(float(m.psnr_all) - float(g['psnr_all'])) < 1e-2
@@ -242,8 +252,9 @@ def test_config4_stp_batch32(pivp, name):
     assert (ratio < STP_VS_FP32_PER_STEP).all()
     assert np.exp(np.log(ratio).mean()) < STP_VS_FP32_OVERALL
     assert (mx(l2) < STP_VS_FP32_MAX * mx(ref32)).all()
+    print(name, 'max over all steps: HIP %.3e, float32 oracle %.3e' % (mx(l2).max(), mx(ref32).max()))
     if smooth:
-        assert mx(l2)[:2].max() < GATE                           # ground-truth-fed steps of video-like frames
+        assert mx(l2)[:2].max() < 5e-5                           # ground-truth-fed steps of video-like frames: 2.8e-6 measured, half the 1e-4 gate asked
     assert abs(loss - float(g['loss'])) < 1e-5
 
 
