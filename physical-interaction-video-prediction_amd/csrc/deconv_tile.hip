@@ -9,7 +9,6 @@
 // wave's four 32 x 32 accumulator tiles become a 2 x 2 output pixel block per input pixel.  Weights ([tap][Cin / 32][N][32]: nine 4 KB
 // tiles per channel chunk) and the patch travel global -> register -> LDS one channel chunk ahead, so the 9 taps run without a barrier.  Epilogue: bias, ReLU, optional accumulate, optional LayerNorm
 // partial of the block's 16,384 outputs (the norm behind enc6).  Results equal igemm_small's up to fp32 summation order.
-#include <stdlib.h>
 #include <type_traits>
 
 #include "pivp_kernels.h"
@@ -67,19 +66,11 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
     const int H = d.Hin, W = d.Win, N = d.N;
     const int n_nblk = N >> 5, tpr = W >> 4, tpi = (H >> 3) * tpr;
     const int n_tiles = d.B * tpi;
-    // A block works on the tiles t = blockIdx.x, blockIdx.x + gridDim.x, ... of the n_nblk * n_tiles of the launch (one tile per block when the grid is that
-    // large; a smaller, resident grid runs them back to back: the next tile's first chunk is requested in front of this tile's epilogue).
-    const int total = n_nblk * n_tiles;
-    int nblk, b, trem, y0, x0;
-    auto tile_index = [&](int t) {
-        int lid = t;
-        if ((total & 7) == 0) lid = (t & 7) * (total >> 3) + (t >> 3);   // XCD-aware, column-block major
-        nblk = lid / n_tiles;
-        const int tile = lid - nblk * n_tiles;
-        b = tile / tpi; trem = tile - b * tpi;
-        y0 = (trem / tpr) * 8; x0 = (trem - (trem / tpr) * tpr) * 16;
-    };
-    tile_index(blockIdx.x);
+    int lid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware, column-block major
+    const int nblk = lid / n_tiles, tile = lid - nblk * n_tiles;
+    const int b = tile / tpi, trem = tile - b * tpi;
+    const int y0 = (trem / tpr) * 8, x0 = (trem - (trem / tpr) * tpr) * 16;
     const int ncc0 = d.c0 >> 5, ncc = (d.c0 + d.c1) >> 5;
 
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x0), 0, d.bytes0, 0x00020000);
@@ -99,23 +90,19 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
     // patch: 153 pixels x 8 float4: thread -> (pixel tid / 8 + 32 j, c4 = tid % 8), j < 5
     const int c4 = tid & 7;
     unsigned a_go[5], a_g1[5], g_go[5];
-    int b_go = 0;
-    auto tile_offsets = [&]() {
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int p = (tid >> 3) + 32 * j;
-            const int py = p / PC, px = p - py * PC;
-            const int iy = y0 + py, ix = x0 + px;
-            const bool ok = p < PR * PC && iy < H && ix < W;
-            a_go[j] = ok ? (unsigned)((((b * H + iy) * W + ix) * d.ld0 + c4 * 4) * 4) : OOB;
-            a_g1[j] = ok ? (unsigned)((((b * H + iy) * W + ix) * d.ld1 + c4 * 4) * 4) : OOB;
-            g_go[j] = ok ? (unsigned)(((iy * W + ix) * d.c0 + c4 * 4) * 4) : OOB;
-        }
-        b_go = (((nblk * 32 + (tid >> 3)) * 32) + c4 * 4) * 4;
-    };
-    tile_offsets();
+    for (int j = 0; j < 5; ++j) {
+        const int p = (tid >> 3) + 32 * j;
+        const int py = p / PC, px = p - py * PC;
+        const int iy = y0 + py, ix = x0 + px;
+        const bool ok = p < PR * PC && iy < H && ix < W;
+        a_go[j] = ok ? (unsigned)((((b * H + iy) * W + ix) * d.ld0 + c4 * 4) * 4) : OOB;
+        a_g1[j] = ok ? (unsigned)((((b * H + iy) * W + ix) * d.ld1 + c4 * 4) * 4) : OOB;
+        g_go[j] = ok ? (unsigned)(((iy * W + ix) * d.c0 + c4 * 4) * 4) : OOB;
+    }
     // Per 32-channel chunk the patch AND the weight tiles of all 9 taps ([9][32 columns][32 k], 41 KB) are staged together, so the 9 taps
     // (144 MFMAs per wave) run without a barrier; the next chunk's 14 float4 per thread are in flight in registers meanwhile.
+    const int b_go = (((nblk * 32 + (tid >> 3)) * 32) + c4 * 4) * 4;
     const int b_lw = (tid >> 3) * DP + c4 * 4;
     f32x4 rp[5], rw[9];
     f32x4 rgm[5], rbt[5];              // IN_LN: gamma / beta of the staged float4s
@@ -212,7 +199,11 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
         }
     };
 
-    f32x16 acc[4];                     // output parity (py, px) -> acc[2 py + px] (cleared per tile)
+    f32x16 acc[4];                     // output parity (py, px) -> acc[2 py + px]
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ph][r] = 0.f;
 
     // A fragment: row l31 of the wave's 32 anchors = patch pixel (2 wave + l31 / 16, l31 % 16), shifted by the tap; B: column l31
     const int a_lane = ((2 * wave + (l31 >> 4)) * PC + (l31 & 15)) * DP + 4 * half;
@@ -260,25 +251,15 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
         }
     };
 
-    // ---- main loop over the block's tiles and their 32-channel chunks ---------------------------------------------------------------------
+    // ---- main loop over the 32-channel chunks ----------------------------------------------------------------------------------------
     load_chunk(0);
-    int ln_b = -1;                     // the sample whose statistics ln_mean / ln_rstd hold
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
     if constexpr (IN_LN) {
-        if (b != ln_b) {
-            if (ln_b >= 0) ln_first = ln_partial_first(d.in_part, b, d.in_np);
-            ln_merge_partials(ln_first, d.in_part, b, d.in_np, d.in_eps, ln_mean, ln_rstd);      // every wave for itself: a few partials per sample
-            ln_b = b;
-        }
+        ln_merge_partials(ln_first, d.in_part, b, d.in_np, d.in_eps, ln_mean, ln_rstd);      // every wave for itself: a few partials per sample
         if (d.in_stat_out && nblk == 0 && trem == 0 && tid == 0) { d.in_stat_out[b * 2] = ln_mean; d.in_stat_out[b * 2 + 1] = ln_rstd; }
     }
-#pragma unroll
-    for (int ph = 0; ph < 4; ++ph)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ph][r] = 0.f;
     store_chunk();
     __syncthreads();
-    if (t == (int)blockIdx.x) DT_STAMP(2);
+    DT_STAMP(2);
     for (int cc = 0; cc < ncc; ++cc) {
         if (cc + 1 < ncc) load_chunk(cc + 1);
         tap_mfmas(std::integral_constant<int, 0>{}); tap_mfmas(std::integral_constant<int, 1>{}); tap_mfmas(std::integral_constant<int, 2>{});
@@ -291,13 +272,9 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
         }
     }
 
-    if (t == (int)blockIdx.x) DT_STAMP(3);
-    // the next tile's first chunk goes out in front of this tile's stores (its registers are free; its LDS images are written behind the epilogue)
-    const int e_nblk = nblk, e_b = b, e_trem = trem, e_y0 = y0, e_x0 = x0;
-    const bool more = t + (int)gridDim.x < total;
-    if (more) { tile_index(t + gridDim.x); tile_offsets(); load_chunk(0); }
+    DT_STAMP(3);
     // ---- epilogue: accumulator row i -> anchor (2 wave + i / 16, i % 16), parity (py, px) -> output pixel (2 y + py, 2 x + px) ----------
-    const int col = e_nblk * 32 + l31;
+    const int col = nblk * 32 + l31;
     const float bias = d.bias ? d.bias[col] : 0.f;
     const float inv_wscale = 1.0f / wscale;
     float s1 = 0.f;
@@ -306,8 +283,8 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int oy = 2 * (e_y0 + 2 * wave + (i >> 4)) + (ph >> 1), ox = 2 * (e_x0 + (i & 15)) + (ph & 1);
-            float* o = d.out + ((size_t)(e_b * d.Hout + oy) * d.Wout + ox) * d.ldo + col;
+            const int oy = 2 * (y0 + 2 * wave + (i >> 4)) + (ph >> 1), ox = 2 * (x0 + (i & 15)) + (ph & 1);
+            float* o = d.out + ((size_t)(b * d.Hout + oy) * d.Wout + ox) * d.ldo + col;
             float v = acc[ph][r];
             if constexpr (PREC == 3) v *= inv_wscale;
             v += bias;
@@ -334,12 +311,10 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
         if (lane == 0) red[4 + wave] = q;
         __syncthreads();
         if (tid == 0) {
-            float* p = d.ln_part + ((size_t)e_b * d.ln_nparts + (size_t)e_trem * n_nblk + e_nblk) * 4;
+            float* p = d.ln_part + ((size_t)b * d.ln_nparts + (size_t)trem * n_nblk + nblk) * 4;
             p[0] = cnt; p[1] = mean; p[2] = (red[4] + red[5]) + (red[6] + red[7]); p[3] = 0.f;
         }
     }
-    if (more) __syncthreads();         // the statistics' scratch is the next tile's image space
-    }      // tiles
 #ifdef PIVP_DT_STAMPS
     DT_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -372,9 +347,7 @@ int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts, int prec
     dd.ln_nparts = (d.ln_part && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
-    int nblocks = d.B * tpi * nb;
-    { const char* e = getenv("PIVP_DT_GRID"); if (e && atoi(e) > 0 && atoi(e) < nblocks) nblocks = atoi(e); }      // EXPERIMENT
-    const dim3 grid(nblocks);
+    const dim3 grid(d.B * tpi * nb);
     if (prec == 3) {
         if (d.in_g) hipLaunchKernelGGL((deconv3x3s2_tile_kernel<3, true>), grid, dim3(256), 2 * (A_HB + 9 * B_HB), stream, dd);
         else hipLaunchKernelGGL((deconv3x3s2_tile_kernel<3, false>), grid, dim3(256), 2 * (A_HB + 9 * B_HB), stream, dd);
