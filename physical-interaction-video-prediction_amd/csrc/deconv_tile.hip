@@ -49,12 +49,8 @@ __device__ __forceinline__ unsigned dpack2(float a, float b) {
 // and with IN_LN the x0 part is a RAW ConvLSTM output whose LayerNorm (TM:203-208: per-element gamma / beta [Hin*Win][c0], statistics merged
 // from the producer's partials d.in_part) is applied while the patch is staged -- the expression of ln_apply_kernel, bit-identical to the
 // two-launch form; pixels outside the image load 0 for v, gamma and beta alike and stay 0.  Inference rollouts use it for enc5 / enc6.
-// KG = 2 (fp32 only; launches with fewer blocks than CUs: enc5 at B = 32 is 192 blocks of one wave per SIMD): eight waves per block, the nine taps dealt to the two
-// wave groups BY OUTPUT PARITY -- group 0 the four taps of parity (1, 1), group 1 the five taps of the other three parities -- so that no accumulator ever crosses
-// groups: each group stages half of the chunk's pieces, multiplies its own taps against the shared images and stores its own parities.
-template <int PREC, bool IN_LN, int KG = 1>
-__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void deconv3x3s2_tile_kernel(const IgemmDesc d) {
-    static_assert(KG == 1 || (KG == 2 && PREC == 0), "the two-group form serves the fp32 kernel");
+template <int PREC, bool IN_LN>
+__global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDesc d) {
     PIVP_SET_MAIN_PRIO();
     DT_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) float lds[];   // A patch | the 9 weight tiles
@@ -64,12 +60,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void deconv3x3s2_tile_ke
     constexpr int HPL = A_HB + 9 * B_HB;                                     // bytes of one plane of bf16 images (patch | 9 weight tiles)
     unsigned char* const Ah = reinterpret_cast<unsigned char*>(lds);       // BF16: byte-addressed images; split mode: the lo plane at + HPL
     unsigned char* const Bh = Ah + A_HB;
-    const int tid = threadIdx.x & 255, lane = tid & 63;                      // (thread of its wave group)
-    const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);  // (wave of its group: the group's 32 anchors)
-    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);         // wave group (0 when KG == 1)
-    const bool leader = threadIdx.x == 0;
-    auto own_p = [&](int j) { return KG == 1 || (j < 3) == (grp == 0); };     // patch pieces / weight tiles this group stages: 3 + 4 and 2 + 5 float4 per thread
-    auto own_w = [&](int t) { return KG == 1 || (t < 4) == (grp == 0); };
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int H = d.Hin, W = d.Win, N = d.N;
     const int n_nblk = N >> 5, tpr = W >> 4, tpi = (H >> 3) * tpr;
@@ -121,15 +113,13 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void deconv3x3s2_tile_ke
         ln_cc = cc;
 #pragma unroll
         for (int j = 0; j < 5; ++j)
-            if (own_p(j))
-                rp[j] = __builtin_bit_cast(f32x4, first ? __builtin_amdgcn_raw_buffer_load_b128(rsx, a_go[j], cc * 128, 0)
-                                                        : __builtin_amdgcn_raw_buffer_load_b128(rsx1, a_g1[j], (cc - ncc0) * 128, 0));
+            rp[j] = __builtin_bit_cast(f32x4, first ? __builtin_amdgcn_raw_buffer_load_b128(rsx, a_go[j], cc * 128, 0)
+                                                    : __builtin_amdgcn_raw_buffer_load_b128(rsx1, a_g1[j], (cc - ncc0) * 128, 0));
         if constexpr (IN_LN) {
             ln_chunk = first;
             if (first) {
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
-                    if (!own_p(j)) continue;
                     rgm[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, g_go[j], cc * 128, 0));
                     rbt[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, g_go[j], cc * 128, 0));
                 }
@@ -137,7 +127,6 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void deconv3x3s2_tile_ke
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            if (!own_w(t)) continue;
             const int sbase = __builtin_amdgcn_readfirstlane((t * (d.wcin >> 5) + cc) * N * 128);
             rw[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, b_go, sbase, 0));
         }
@@ -147,13 +136,11 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void deconv3x3s2_tile_ke
             if (ln_chunk) {
 #pragma unroll
                 for (int j = 0; j < 5; ++j)
-                    if (own_p(j))
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) rp[j][e] = (rp[j][e] - ln_mean) * ln_rstd * rgm[j][e] + rbt[j][e];
+                    for (int e = 0; e < 4; ++e) rp[j][e] = (rp[j][e] - ln_mean) * ln_rstd * rgm[j][e] + rbt[j][e];
                 if (d.in_out && nblk == 0) {      // the tile's own 8 x 16 pixels (not the halo), by the first column block
 #pragma unroll
                     for (int j = 0; j < 5; ++j) {
-                        if (!own_p(j)) continue;
                         const int p = (tid >> 3) + 32 * j;
                         const int py = p / PC, px = p - py * PC;
                         if (py < 8 && px < 16)
@@ -206,10 +193,9 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void deconv3x3s2_tile_ke
         } else {
 #pragma unroll
             for (int j = 0; j < 5; ++j)      // unconditional: 160 pixel rows are allocated, rows past 153 receive zeros
-                if (own_p(j)) *reinterpret_cast<f32x4*>(At + ((tid >> 3) + 32 * j) * DP + c4 * 4) = rp[j];
+                *reinterpret_cast<f32x4*>(At + ((tid >> 3) + 32 * j) * DP + c4 * 4) = rp[j];
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
-                if (own_w(t)) *reinterpret_cast<f32x4*>(Bt + t * B_FL + b_lw) = rw[t];
+            for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(Bt + t * B_FL + b_lw) = rw[t];
         }
     };
 
@@ -269,21 +255,16 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void deconv3x3s2_tile_ke
     load_chunk(0);
     if constexpr (IN_LN) {
         ln_merge_partials(ln_first, d.in_part, b, d.in_np, d.in_eps, ln_mean, ln_rstd);      // every wave for itself: a few partials per sample
-        if (d.in_stat_out && nblk == 0 && trem == 0 && leader) { d.in_stat_out[b * 2] = ln_mean; d.in_stat_out[b * 2 + 1] = ln_rstd; }
+        if (d.in_stat_out && nblk == 0 && trem == 0 && tid == 0) { d.in_stat_out[b * 2] = ln_mean; d.in_stat_out[b * 2 + 1] = ln_rstd; }
     }
     store_chunk();
     __syncthreads();
     DT_STAMP(2);
     for (int cc = 0; cc < ncc; ++cc) {
         if (cc + 1 < ncc) load_chunk(cc + 1);
-        if (KG == 1 || grp == 0) {      // the four taps of parity (1, 1): (0, 0), (0, 2), (2, 0), (2, 2)
-            tap_mfmas(std::integral_constant<int, 0>{}); tap_mfmas(std::integral_constant<int, 2>{});
-            tap_mfmas(std::integral_constant<int, 6>{}); tap_mfmas(std::integral_constant<int, 8>{});
-        }
-        if (KG == 1 || grp == 1) {      // the five taps of parities (0, 0), (0, 1), (1, 0)
-            tap_mfmas(std::integral_constant<int, 1>{}); tap_mfmas(std::integral_constant<int, 3>{}); tap_mfmas(std::integral_constant<int, 4>{});
-            tap_mfmas(std::integral_constant<int, 5>{}); tap_mfmas(std::integral_constant<int, 7>{});
-        }
+        tap_mfmas(std::integral_constant<int, 0>{}); tap_mfmas(std::integral_constant<int, 1>{}); tap_mfmas(std::integral_constant<int, 2>{});
+        tap_mfmas(std::integral_constant<int, 3>{}); tap_mfmas(std::integral_constant<int, 4>{}); tap_mfmas(std::integral_constant<int, 5>{});
+        tap_mfmas(std::integral_constant<int, 6>{}); tap_mfmas(std::integral_constant<int, 7>{}); tap_mfmas(std::integral_constant<int, 8>{});
         if (cc + 1 < ncc) {
             __syncthreads();               // every wave is done with this chunk's images
             store_chunk();
@@ -301,7 +282,6 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void deconv3x3s2_tile_ke
     for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if (KG == 2 && (ph == 3) != (grp == 0)) continue;      // the parity of the other wave group
             const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
             const int oy = 2 * (y0 + 2 * wave + (i >> 4)) + (ph >> 1), ox = 2 * (x0 + (i & 15)) + (ph & 1);
             float* o = d.out + ((size_t)(b * d.Hout + oy) * d.Wout + ox) * d.ldo + col;
@@ -316,31 +296,23 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void deconv3x3s2_tile_ke
         }
     if (d.ln_part) {   // (count, mean, M2) of the block's 128 x 4 x 32 outputs: two passes over registers, fixed order
         float* red = lds;
-        const int wslot = grp * 4 + wave;
         s1 = wave_sum(s1);
         __syncthreads();
-        if (lane == 0) red[wslot] = s1;
+        if (lane == 0) red[wave] = s1;
         __syncthreads();
         const float cnt = 16384.f;
-        float tot = (red[0] + red[1]) + (red[2] + red[3]);
-        if (KG == 2) tot += (red[4] + red[5]) + (red[6] + red[7]);
-        const float mean = tot / cnt;
+        const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / cnt;
         float q = 0.f;
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (KG == 2 && (ph == 3) != (grp == 0)) continue;
-                const float dd = acc[ph][r] - mean; q = fmaf(dd, dd, q);
-            }
+            for (int r = 0; r < 16; ++r) { const float dd = acc[ph][r] - mean; q = fmaf(dd, dd, q); }
         q = wave_sum(q);
-        if (lane == 0) red[8 + wslot] = q;
+        if (lane == 0) red[4 + wave] = q;
         __syncthreads();
-        if (leader) {
+        if (tid == 0) {
             float* p = d.ln_part + ((size_t)b * d.ln_nparts + (size_t)trem * n_nblk + nblk) * 4;
-            float m2 = (red[8] + red[9]) + (red[10] + red[11]);
-            if (KG == 2) m2 += (red[12] + red[13]) + (red[14] + red[15]);
-            p[0] = cnt; p[1] = mean; p[2] = m2; p[3] = 0.f;
+            p[0] = cnt; p[1] = mean; p[2] = (red[4] + red[5]) + (red[6] + red[7]); p[3] = 0.f;
         }
     }
 #ifdef PIVP_DT_STAMPS
@@ -379,13 +351,6 @@ int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts, int prec
     if (prec == 3) {
         if (d.in_g) hipLaunchKernelGGL((deconv3x3s2_tile_kernel<3, true>), grid, dim3(256), 2 * (A_HB + 9 * B_HB), stream, dd);
         else hipLaunchKernelGGL((deconv3x3s2_tile_kernel<3, false>), grid, dim3(256), 2 * (A_HB + 9 * B_HB), stream, dd);
-    } else if (prec == 0 && (int)grid.x < pivp_cu_count()) {
-        // fewer blocks than CUs (enc5 at B = 32: 192): eight waves per block, the taps dealt to two wave groups by output parity
-        static PerDeviceOnce once8, once8n;
-        if (pivp_ensure_dyn_lds(once8, reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<0, false, 2>), lds_f32) != PIVP_OK ||
-            pivp_ensure_dyn_lds(once8n, reinterpret_cast<const void*>(&deconv3x3s2_tile_kernel<0, true, 2>), lds_f32) != PIVP_OK) return PIVP_ERR_LAUNCH;
-        if (d.in_g) hipLaunchKernelGGL((deconv3x3s2_tile_kernel<0, true, 2>), grid, dim3(512), lds_f32, stream, dd);
-        else hipLaunchKernelGGL((deconv3x3s2_tile_kernel<0, false, 2>), grid, dim3(512), lds_f32, stream, dd);
     } else if (d.in_g) {
         if (prec == 2) hipLaunchKernelGGL((deconv3x3s2_tile_kernel<2, true>), grid, dim3(256), 2 * (A_HB + 9 * B_HB), stream, dd);
         else if (prec == 1) hipLaunchKernelGGL((deconv3x3s2_tile_kernel<1, true>), grid, dim3(256), A_HB + 9 * B_HB, stream, dd);
