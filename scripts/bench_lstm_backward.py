@@ -94,6 +94,11 @@ for name, cx, C, H in LAYERS:
     def fwd():
         assert lib.pivp_convlstm_v(x.data_ptr(), cx, cx, h.data_ptr(), C, w.data_ptr(), bias.data_ptr(), c.data_ptr(), co.data_ptr(), ho.data_ptr(), B, H, H, 0, st) == 0
 
+    gates = torch.empty(M, N, device=dev)
+
+    def fwd_train():
+        assert lib.pivp_convlstm_train(x.data_ptr(), cx, cx, h.data_ptr(), C, w.data_ptr(), bias.data_ptr(), c.data_ptr(), co.data_ptr(), ho.data_ptr(), gates.data_ptr(), B, H, H, st) == 0
+
     print('%s: cin %d N %d map %d x %d B %d: %.2f GFLOP, floor %.1f us at 157.3 TF; partial slots %.1f MB' % (name, cin, N, H, H, B, flop / 1e9, floor, nslot * 4 / 1e6))
     t = timed(wg_old); tot['wg_old'] += mult * t
     print('   weight gradient, round-2 kernel (atomics)   %7.1f us  %.3f of peak' % (t, floor / t)); s = stamps('pivp_debug_wg_stamps', 1024); print(s) if s else None
@@ -108,8 +113,10 @@ for name, cx, C, H in LAYERS:
     print('   data gradient                               %7.1f us  %.3f of peak' % (t, floor / t)); s = stamps('pivp_debug_f32_stamps', 512); print(s) if s else None
     t = timed(fwd); tot['fwd'] += mult * t
     print('   forward gate conv (inference)               %7.1f us  %.3f of peak' % (t, floor / t)); s = stamps('pivp_debug_f32_stamps', 512); print(s) if s else None
+    t = timed(fwd_train); tot['fwd_train'] = tot.get('fwd_train', 0.0) + mult * t
+    print('   forward gate conv (training: + gate activations) %5.1f us  %.3f of peak' % (t, floor / t)); s = stamps('pivp_debug_f32_stamps', 512); print(s) if s else None
     tot['floor'] += mult * floor
 if not only:
-    print('seven layers (lstm2 = lstm1): floor %.1f us; weight gradient round-2 %.1f (%.3f), round-6 %.1f (%.3f); data gradient %.1f (%.3f); forward %.1f (%.3f)' % (
+    print('seven layers (lstm2 = lstm1): floor %.1f us; weight gradient round-2 %.1f (%.3f), round-6 %.1f (%.3f); data gradient %.1f (%.3f); forward %.1f (%.3f), in training %.1f (%.3f)' % (
         tot['floor'], tot['wg_old'], tot['floor'] / tot['wg_old'], tot['wg_new'], tot['floor'] / max(tot['wg_new'], 1e-9), tot['dgrad'], tot['floor'] / tot['dgrad'],
-        tot['fwd'], tot['floor'] / tot['fwd']))
+        tot['fwd'], tot['floor'] / tot['fwd'], tot.get('fwd_train', 1e-9), tot['floor'] / tot.get('fwd_train', 1e-9)))
