@@ -40,7 +40,7 @@ extern "C" {
 #define PIVP_PRECISION_BF16X6 3
 #define PIVP_PRECISION_FP16X3 4
 
-int pivp_abi_version(void);   /* 17 (17: + pivp_wgrad5x5_f32_part_floats, pivp_wgrad5x5_f32_batch, pivp_wgrad5x5_f32_reduce, pivp_conv5x5_f32; 16: + pivp_conv_wgrad_partial_batch, pivp_conv_wgrad_partial_reduce; 15: + pivp_wgrad5x5_bf16_batch_form; 14: + pivp_build_flags, pivp_plan_set_main_priority; 13: + pivp_wgrad5x5_bf16x6_batch; 12: + pivp_wgrad5x5_fp16x3_batch; 11: + pivp_conv5x5_fp16x3; 10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3, pivp_deconv3x3s2_fp16x3, pivp_plan_set_pack_cache, pivp_plan_params_changed; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
+int pivp_abi_version(void);   /* 17 (17: + pivp_wgrad5x5_f32_part_floats, pivp_wgrad5x5_f32_batch, pivp_wgrad5x5_f32_reduce, pivp_wgrad5x5_f32_partition, pivp_conv5x5_f32; 16: + pivp_conv_wgrad_partial_batch, pivp_conv_wgrad_partial_reduce; 15: + pivp_wgrad5x5_bf16_batch_form; 14: + pivp_build_flags, pivp_plan_set_main_priority; 13: + pivp_wgrad5x5_bf16x6_batch; 12: + pivp_wgrad5x5_fp16x3_batch; 11: + pivp_conv5x5_fp16x3; 10: + PIVP_PRECISION_BF16X6 / _FP16X3, pivp_pack_lstm_bf16x6, pivp_convlstm_bf16x6, pivp_conv5x5_bf16x6, pivp_pack_lstm_fp16x3, pivp_convlstm_fp16x3, pivp_deconv3x3s2_fp16x3, pivp_plan_set_pack_cache, pivp_plan_params_changed; 9: + pivp_build_digest, pivp_grad_sum_shards, pivp_frame_head; 8: + pivp_gates_backward_ln, pivp_deconv3x3s2_ln; 7: + bf16 gradient payload, batched bf16 weight gradient, partial-plane / dx-only op entries; 2: + training entry points, 3: + pivp_convlstm_ln, 4: + gradient groups / callback,
                                  5: + bf16 ConvLSTM, pivp_plan_set_precision, 6: + pivp_plan_set_group_join / pivp_plan_group_wait) */
 
 /* sha256 (hex) of the sources this library was compiled from (every .hip and .h under csrc/, and this header), embedded by build.py.  The Python
@@ -308,6 +308,12 @@ long long pivp_wgrad5x5_f32_part_floats(int cx, int C, int B, int H, int W, int 
 int pivp_wgrad5x5_f32_batch(const float* x, int cx, int ldx, const float* h_prev, int C, const float* dG, float* part, int overwrite,
                             float* dW, float* db, int B, int H, int W, int tcount, long long ts_x, long long ts_h, long long ts_dG, int form, void* stream);
 int pivp_wgrad5x5_f32_reduce(int cx, int C, int has_h, float* part, float* dW, float* db, int B, int H, int W, int form, void* stream);
+/* Host-only (no GPU work): the slot kernel's partition as the kernel and the reduction walk it, for tests and for sizing.  geom8 = {blocks per XCD, pixel parts,
+ * tile parts, 32-column tiles per wave, tiles, 16-pixel chunks per timestep, slots per block, floats per slot}; segs (may be NULL): (block, segment, tile, first
+ * chunk, end chunk) per segment; slots (may be NULL): (tile, slot) pairs in the reduction's order; at most seg_cap / slot_cap entries are written, the counts are
+ * always returned. */
+int pivp_wgrad5x5_f32_partition(int cx, int C, int has_h, int B, int H, int W, int form, int* geom8, int* segs, int seg_cap, int* nsegs,
+                                int* slots, int slot_cap, int* nslots);
 /* The fp32 ConvLSTM data gradient on its own: plain 5x5 stride-1 pad-2 convolution, x [B*H*W][cin] (pixel stride ldx), wt packed [25][cin/32][cout][32]
  * (for the data gradient: the flipped, transposed weight the sweep builds once per backward), out [B*H*W][cout] contiguous, overwritten. */
 int pivp_conv5x5_f32(const float* x, int cin, int ldx, const float* wt, float* out, int cout, int B, int H, int W, void* stream);

@@ -126,6 +126,7 @@ SIGNATURES = {
     'pivp_wgrad5x5_f32_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
     'pivp_wgrad5x5_f32_reduce': (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'pivp_conv5x5_f32': (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'pivp_wgrad5x5_f32_partition': (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
 }
 
 _lib = None

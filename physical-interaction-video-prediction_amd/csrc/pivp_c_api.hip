@@ -551,6 +551,20 @@ extern "C" int pivp_wgrad5x5_f32_reduce(int cx, int C, int has_h, float* part, f
     if (!part || !dW || form < 0 || form > 2 || lstm_wgrad_part_floats(cx, C, B, H, W, form) <= 0) return PIVP_ERR_BADARG;
     return lstm_wgrad_reduce(cx, C, has_h, part, dW, db, B, H, W, (hipStream_t)stream, form);
 }
+// The slot kernel's partition walked on the host (no GPU work): geom8 = {blocks per XCD, pixel parts, tile parts, 32-column tiles per wave, tiles, 16-pixel chunks per
+// timestep, slots per block, floats per slot}; segs: (block, segment, tile, first chunk, end chunk) per segment in kernel order; slots: (tile, slot) pairs in the
+// reduction's order.  The caps bound what is written; the counts are always returned.  tests/test_host.py checks that every (tile, chunk) is covered exactly once and
+// that the reduction reads exactly the slots the kernel writes.
+extern "C" int pivp_wgrad5x5_f32_partition(int cx, int C, int has_h, int B, int H, int W, int form, int* geom8, int* segs, int seg_cap, int* nsegs,
+                                           int* slots, int slot_cap, int* nslots) {
+    if (cx <= 0 || C <= 0 || B <= 0 || H <= 0 || W <= 0 || form < 0 || form > 2 || !geom8 || !nsegs || !nslots) return PIVP_ERR_BADARG;
+    WgradDesc d;
+    lstm_wgrad_geom(d, cx, C, B, H, W);
+    d.form = form;
+    if (!has_h) { d.c1 = 0; d.cin = cx; }
+    if (!wgrad5x5p_ok(d)) return PIVP_ERR_BADARG;
+    return wgrad5x5p_partition(d, geom8, segs, seg_cap, nsegs, slots, slot_cap, nslots);
+}
 // The fp32 ConvLSTM data gradient on its own: a plain 5x5 stride-1 pad-2 convolution of x [B*H*W][cin] with wt (packed [25][cin/32][cout][32]: for the data
 // gradient the flipped, transposed weight) into out [B*H*W][cout] (contiguous); tile and K split as the sweep chooses them (out is cleared first when K is split).
 extern "C" int pivp_conv5x5_f32(const float* x, int cin, int ldx, const float* wt, float* out, int cout, int B, int H, int W, void* stream) {

@@ -110,6 +110,7 @@ bool wgrad5x5p_ok(const WgradDesc& d);
 long long wgrad5x5p_part_floats(const WgradDesc& d);
 int wgrad5x5p(const WgradDesc& d, hipStream_t s);
 int wgrad5x5p_reduce(const WgradDesc& d, hipStream_t s);
+int wgrad5x5p_partition(const WgradDesc& d, int* geom8, int* segs, int seg_cap, int* nsegs, int* slots, int slot_cap, int* nslots);   // host walk of the partition (tests)
 // bf16-operand form of the ConvLSTM weight gradient (csrc/wgrad_bf16.hip); the bias gradient is left to bias_grad
 bool wgrad5x5_bf16_ok(const WgradDesc& d);
 int wgrad5x5_bf16(const WgradDesc& d, hipStream_t s);

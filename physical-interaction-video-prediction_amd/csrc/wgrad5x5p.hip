@@ -75,6 +75,36 @@ __host__ __device__ inline WpRange wp_range(const WpGeom& g, int x, int j) {
     return r;
 }
 
+// the next segment of a block's item range [i, i1): tile (local index tl) and chunk range [k0, k1) of the part; advances i
+__host__ __device__ inline void wp_next_segment(const WpRange& r, long long& i, int& tl, int& k0, int& k1) {
+    tl = (int)(i / r.len); k0 = (int)(i - (long long)tl * r.len);
+    const long long left = r.i1 - i;
+    k1 = left < (long long)(r.len - k0) ? k0 + (int)left : r.len;
+    i += k1 - k0;
+}
+// the slots (block * maxseg + segment) that hold partial sums of `tile`, in the reduction's fixed order: pixel parts ascending, blocks ascending
+template <class F>
+__host__ __device__ inline int wp_for_each_slot(const WpGeom& g, int tile, F f) {
+    int tx = 0, n = 0;                   // the tile part that holds this tile
+    while (tx + 1 < g.TP && (int)((long long)g.T * (tx + 1) / g.TP) <= tile) ++tx;
+    for (int px = 0; px < g.PP; ++px) {
+        const int x = tx * g.PP + px;
+        const WpRange r0 = wp_range(g, x, 0);
+        if (r0.len <= 0 || r0.nt <= 0) continue;
+        const int tl = tile - r0.t_lo;
+        const long long tot = (long long)r0.nt * r0.len, lo = (long long)tl * r0.len, hi = lo + r0.len;
+        int j = (int)(lo * g.J / tot);
+        if (j > 0) --j;
+        long long b0 = tot * j / g.J;
+        for (; j < g.J && b0 < hi; ++j) {
+            const long long b1 = tot * (j + 1) / g.J;
+            if (b1 > lo && b1 > b0) { f(n, (unsigned)((j * 8 + x) * g.maxseg + (tl - (int)(b0 / r0.len)))); ++n; }
+            b0 = b1;
+        }
+    }
+    return n;
+}
+
 inline bool wp_ok_shape(const WgradDesc& d) {
     if (d.deconv || d.ksize != 5 || d.pad != 2 || d.stride != 1 || d.Hx != d.Hy || d.Wx != d.Wy) return false;
     if (d.Wg < 8 || (d.Wg & (d.Wg - 1)) || (d.Hg & (d.Hg - 1)) || d.Hg < 2) return false;
@@ -164,10 +194,8 @@ __global__ __launch_bounds__(256, 2) void wgrad5x5p_kernel(const WgradDesc d, co
     long long i = rg.i0;
     for (int seg = 0; i < rg.i1; ++seg) {
         // ---- this segment: tile and chunk range (block-uniform) ---------------------------------------------------------------------------
-        const int tl = (int)(i / rg.len), k0 = (int)(i - (long long)tl * rg.len);
-        const long long left = rg.i1 - i;
-        const int k1 = left < (long long)(rg.len - k0) ? k0 + (int)left : rg.len;
-        i += k1 - k0;
+        int tl, k0, k1;
+        wp_next_segment(rg, i, tl, k0, k1);
         const int tile = rg.t_lo + tl;
         const int ky = tile % 5, cb = (tile / 5) % ncb, nb = tile / (5 * ncb);
         const int ci0 = cb * 32, n0 = nb * YP;
@@ -392,29 +420,7 @@ __global__ __launch_bounds__(256) void wgrad5x5p_reduce_kernel(const WgradDesc d
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     float sb = 0.f;
     for (int base = 0;; base += MAXC) {          // (one window with this model's layers: a tile has 2..24 slots)
-        if (tid == 0) {
-            int tx = 0, n = 0;                   // the tile part that holds this tile
-            while (tx + 1 < g.TP && (int)((long long)g.T * (tx + 1) / g.TP) <= tile) ++tx;
-            for (int px = 0; px < g.PP; ++px) {
-                const int x = tx * g.PP + px;
-                const WpRange r0 = wp_range(g, x, 0);
-                if (r0.len <= 0 || r0.nt <= 0) continue;
-                const int tl = tile - r0.t_lo;
-                const long long tot = (long long)r0.nt * r0.len, lo = (long long)tl * r0.len, hi = lo + r0.len;
-                int j = (int)(lo * g.J / tot);
-                if (j > 0) --j;
-                long long b0 = tot * j / g.J;
-                for (; j < g.J && b0 < hi; ++j) {
-                    const long long b1 = tot * (j + 1) / g.J;
-                    if (b1 > lo && b1 > b0) {
-                        if (n >= base && n < base + MAXC) offs[n - base] = (unsigned)((j * 8 + x) * g.maxseg + (tl - (int)(b0 / r0.len)));
-                        ++n;
-                    }
-                    b0 = b1;
-                }
-            }
-            cnt = n;
-        }
+        if (tid == 0) cnt = wp_for_each_slot(g, tile, [&](int n, unsigned slot) { if (n >= base && n < base + MAXC) offs[n - base] = slot; });
         __syncthreads();
         const int total = cnt, n = total - base < MAXC ? total - base : MAXC;
         int c = 0;
@@ -443,6 +449,31 @@ __global__ __launch_bounds__(256) void wgrad5x5p_reduce_kernel(const WgradDesc d
 }
 
 bool wgrad5x5p_ok(const WgradDesc& d) { return wp_ok_shape(d); }
+
+// The partition as the kernel and the reduction see it, walked on the host (tests/test_host.py: no GPU).  segs: one (block, segment, tile, first chunk, end chunk)
+// quintuple per segment in the kernel's order; slots: per tile, the reduction's list as (tile, slot) pairs.  Returns the counts; nothing is written past the caps.
+int wgrad5x5p_partition(const WgradDesc& d, int* geom8, int* segs, int seg_cap, int* nsegs, int* slots, int slot_cap, int* nslots) {
+    PIVP_CHECK_ARG(wp_ok_shape(d) && geom8 && nsegs && nslots);
+    const WpGeom g = wp_geom(d);
+    geom8[0] = g.J; geom8[1] = g.PP; geom8[2] = g.TP; geom8[3] = g.NTW; geom8[4] = g.T; geom8[5] = g.cpt; geom8[6] = g.maxseg; geom8[7] = wp_slot(g.NTW);
+    int ns = 0;
+    for (int L = 0; L < 8 * g.J; ++L) {
+        const WpRange rg = wp_range(g, L & 7, L >> 3);
+        long long i = rg.i0;
+        for (int seg = 0; i < rg.i1; ++seg) {
+            int tl, k0, k1;
+            wp_next_segment(rg, i, tl, k0, k1);
+            if (segs && ns < seg_cap) { int* q = segs + 5 * ns; q[0] = L; q[1] = seg; q[2] = rg.t_lo + tl; q[3] = rg.c_lo + k0; q[4] = rg.c_lo + k1; }
+            ++ns;
+        }
+    }
+    *nsegs = ns;
+    int nl = 0;
+    for (int tile = 0; tile < g.T; ++tile)
+        nl += wp_for_each_slot(g, tile, [&](int n, unsigned slot) { if (slots && nl + n < slot_cap) { slots[2 * (nl + n)] = tile; slots[2 * (nl + n) + 1] = (int)slot; } });
+    *nslots = nl;
+    return PIVP_OK;
+}
 
 long long wgrad5x5p_part_floats(const WgradDesc& d) {
     if (!wp_ok_shape(d)) return 0;

@@ -195,3 +195,74 @@ def test_graft_entry_build_in_a_fresh_interpreter():
     r = subprocess.run([sys.executable, '-c', 'import __graft_entry__ as g; g.build(); print("ok")'], cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-2000:]
+
+
+# the ConvLSTM layers of the model at rank sizes (cx, C, B, H, W), as tests/test_gpu_backward_ops.py runs them on the GPU, plus ragged cuts
+_WGRAD_SLOT_SHAPES = [(32, 32, 32, 32, 32), (32, 32, 4, 32, 32), (32, 64, 32, 16, 16), (64, 64, 32, 16, 16), (64, 128, 32, 8, 8), (128, 128, 32, 8, 8),
+                      (256, 64, 32, 16, 16), (96, 32, 32, 32, 32), (32, 32, 1, 8, 8), (64, 32, 3, 16, 8), (32, 96, 5, 4, 16), (32, 32, 16, 64, 64)]
+
+
+@pytest.mark.parametrize('form', [0, 1, 2])
+@pytest.mark.parametrize('has_h', [1, 0])
+def test_weight_gradient_slot_partition_covers_every_item_once(form, has_h):
+    """wgrad5x5p.hip cuts one timestep's (tile, 16-pixel chunk) items into per-block segments, each with a slot of its own, and the reduction adds a tile's
+    slots in a fixed order.  Walked on the host through pivp_wgrad5x5_f32_partition (no GPU): every item lies in exactly one segment, no block has more than
+    `maxseg` segments, the reduction reads exactly the slots the kernel writes for that tile -- each once, pixel parts then blocks ascending -- and the
+    buffer size the sizing entry returns holds them all."""
+    lib = _lib.load()
+    for cx, C, B, H, W in _WGRAD_SLOT_SHAPES:
+        if form == 2 and (4 * C) % 64:
+            continue
+        geom = np.zeros(8, np.int32)
+        ns, nl = ctypes.c_int(0), ctypes.c_int(0)
+        args = (cx, C, has_h, B, H, W, form)
+        assert lib.pivp_wgrad5x5_f32_partition(*args, geom.ctypes.data, None, 0, ctypes.byref(ns), None, 0, ctypes.byref(nl)) == 0
+        J, PP, TP, NTW, T, cpt, maxseg, slot_floats = (int(v) for v in geom)
+        cin = cx + (C if has_h else 0)
+        assert PP * TP == 8 and NTW in (1, 2) and (form == 0 or NTW == form)
+        assert T == 5 * (cin // 32) * (4 * C // (32 * NTW)) and cpt == B * H * W // 16 and slot_floats == 5 * NTW * 1024 + 64
+        segs = np.zeros((ns.value, 5), np.int32)
+        slots = np.zeros((nl.value, 2), np.int32)
+        assert lib.pivp_wgrad5x5_f32_partition(*args, geom.ctypes.data, segs.ctypes.data, len(segs), ctypes.byref(ns), slots.ctypes.data, len(slots),
+                                               ctypes.byref(nl)) == 0
+        assert ns.value == len(segs) and nl.value == len(slots)
+        blk, seg, tile, k0, k1 = segs.T
+        assert (k1 > k0).all() and (seg < maxseg).all() and (blk < 8 * J).all() and (tile < T).all() and (k0 >= 0).all() and (k1 <= cpt).all()
+        cover = np.zeros((T, cpt + 1), np.int64)                   # difference array over chunks, per tile
+        np.add.at(cover, (tile, k0), 1)
+        np.add.at(cover, (tile, k1), -1)
+        assert (np.cumsum(cover, 1)[:, :cpt] == 1).all(), (cx, C, B, H, W)
+        # a block's segments are numbered 0, 1, ... in the order it works through them, and an XCD (block % 8) holds one (pixel part, tile part) pair
+        for b in np.unique(blk):
+            assert (seg[blk == b] == np.arange((blk == b).sum())).all()
+        written = {}
+        for b, s, t in zip(blk, seg, tile):
+            written.setdefault(int(t), []).append(int(b) * maxseg + int(s))
+        read = {}
+        for t, s in slots:
+            read.setdefault(int(t), []).append(int(s))
+        assert set(read) == set(written) == set(range(T))
+        for t in range(T):
+            assert sorted(read[t]) == sorted(written[t]) and len(set(read[t])) == len(read[t]), (cx, C, B, H, W, t)
+            # the fixed order: by pixel part (the XCD's low digit), then by block within the part
+            order = [((s // maxseg) % 8 % PP, s // maxseg // 8) for s in read[t]]
+            assert order == sorted(order)
+        floats = lib.pivp_wgrad5x5_f32_part_floats(cx, C, B, H, W, form)
+        assert floats >= 8 * J * maxseg * slot_floats and (max(max(v) for v in written.values()) + 1) * slot_floats <= floats
+        # the work is balanced: no block has more than one item above the mean of its part
+        items = np.zeros(8 * J, np.int64)
+        np.add.at(items, blk, k1 - k0)
+        for x in range(8):
+            part = items[x::8]
+            assert part.max() - part.min() <= 1
+
+
+def test_weight_gradient_slot_entries_refuse_shapes_the_kernel_does_not_serve():
+    lib = _lib.load()
+    geom = np.zeros(8, np.int32)
+    n = ctypes.c_int(0)
+    for cx, C, B, H, W, form in [(32, 32, 2, 24, 24, 0), (32, 32, 2, 16, 4, 0), (16, 32, 2, 16, 16, 0), (32, 24, 2, 16, 16, 0), (32, 32, 0, 16, 16, 0),
+                                 (32, 32, 2, 16, 16, 3), (32, 32, 2, 16, 16, -1)]:
+        assert lib.pivp_wgrad5x5_f32_partition(cx, C, 1, B, H, W, form, geom.ctypes.data, None, 0, ctypes.byref(n), None, 0, ctypes.byref(n)) != 0
+        assert lib.pivp_wgrad5x5_f32_part_floats(cx, C, B, H, W, form) <= 0
+    assert lib.pivp_wgrad5x5_f32_partition(32, 32, 1, 2, 16, 16, 0, None, None, 0, ctypes.byref(n), None, 0, ctypes.byref(n)) != 0
