@@ -32,8 +32,7 @@ __global__ __launch_bounds__(512) void absmax_partials_kernel(const float* __res
         const f32x4 v = w4[i];
         m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+    m = wave_max(m);
     __shared__ float red[8];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();

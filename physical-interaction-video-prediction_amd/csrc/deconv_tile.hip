@@ -12,6 +12,7 @@
 #include <type_traits>
 
 #include "pivp_kernels.h"
+#include "skinny_linear.h"
 
 #ifdef PIVP_DT_STAMPS   // per-block phase stamps (scripts/deconv_stamps.py): [block][entry, statistics merged, first chunk staged, loop done, stores done]
 __device__ long long pivp_dt_stamps[2048 * 8];
@@ -54,6 +55,13 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
     PIVP_SET_MAIN_PRIO();
     DT_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) float lds[];   // A patch | the 9 weight tiles
+    const int gx = (int)gridDim.x - d.rd_blocks;                  // the launch's own tiles; behind them: the motion head's finisher, one block per sample
+    if (d.rd_blocks && (int)blockIdx.x >= gx) {
+        const int rb = (int)blockIdx.x - gx;
+        if (d.rd_mode == 1) cdna_finish_block(d.rd_partials, d.rd_bias, d.rd_out, d.rd_blocks, d.rd_KS, d.rd_nout, d.rd_vpre, rb, lds);
+        else stp_finish_block(d.rd_partials, d.rd_bias, d.rd_w2, d.rd_b2, d.rd_out, d.rd_blocks, d.rd_KS, d.rd_vpre, rb, lds);
+        return;
+    }
     float* const At = lds;
     float* const Bt = lds + A_FL;
     constexpr bool BF16 = PREC != 0;
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
     const int n_nblk = N >> 5, tpr = W >> 4, tpi = (H >> 3) * tpr;
     const int n_tiles = d.B * tpi;
     int lid = blockIdx.x;
-    if ((gridDim.x & 7) == 0) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware, column-block major
+    if ((gx & 7) == 0) lid = (blockIdx.x & 7) * (gx >> 3) + (blockIdx.x >> 3);   // XCD-aware, column-block major
     const int nblk = lid / n_tiles, tile = lid - nblk * n_tiles;
     const int b = tile / tpi, trem = tile - b * tpi;
     const int y0 = (trem / tpr) * 8, x0 = (trem - (trem / tpr) * tpr) * 16;
@@ -347,7 +355,10 @@ int deconv_tile(const IgemmDesc& d, hipStream_t stream, int* ln_nparts, int prec
     dd.ln_nparts = (d.ln_part && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
-    const dim3 grid(d.B * tpi * nb);
+    PIVP_CHECK_ARG(d.rd_mode == 0 || ((d.rd_mode == 1 || d.rd_mode == 2) && d.rd_blocks == d.B && d.rd_partials && d.rd_bias && d.rd_out && d.rd_KS >= 1 &&
+                                      (d.rd_mode == 1 ? (d.rd_nout >= 25 && d.rd_nout <= 256) : (d.rd_w2 && d.rd_b2))));
+    if (!d.rd_mode) dd.rd_blocks = 0;
+    const dim3 grid(d.B * tpi * nb + dd.rd_blocks);
     if (prec == 3) {
         if (d.in_g) hipLaunchKernelGGL((deconv3x3s2_tile_kernel<3, true>), grid, dim3(256), 2 * (A_HB + 9 * B_HB), stream, dd);
         else hipLaunchKernelGGL((deconv3x3s2_tile_kernel<3, false>), grid, dim3(256), 2 * (A_HB + 9 * B_HB), stream, dd);

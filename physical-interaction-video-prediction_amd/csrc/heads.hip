@@ -144,40 +144,11 @@ __global__ __launch_bounds__(256) void skinny_linear_partials_kernel(const float
     skinny_linear_partials_body<ACC>(x, wt, partials, B, K, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
-// sum of the K-slice partials of output o of sample b, fixed order (bitwise reproducible), 4 independent chains
-__device__ __forceinline__ double sum_partials(const float* __restrict__ partials, int B, int KS, int b, int o) {
-    // chain c takes slices c, c+4, c+8, ... in increasing order; 32 loads are in flight per round trip
-    double a[4] = {0, 0, 0, 0};
-    for (int ks0 = 0; ks0 < KS; ks0 += 32) {
-        float v[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) v[u] = partials[((size_t)b * KS + min(ks0 + u, KS - 1)) * 256 + o];   // clamped, not
-#pragma unroll                                                       // predicated: a uniform predicate becomes a branch + vmcnt(0) per load
-        for (int u = 0; u < 32; ++u) a[u & 3] += ks0 + u < KS ? (double)v[u] : 0.0;
-    }
-    return (a[0] + a[1]) + (a[2] + a[3]);
-}
-
-// CDNA finisher (TM:326-329): + bias, relu(k - RELU_SHIFT) + RELU_SHIFT, divide by the 5x5 sum.
+// CDNA finisher (TM:326-329): cdna_finish_block of skinny_linear.h, one block per sample
 __global__ __launch_bounds__(256) void cdna_kernels_finish_kernel(const float* __restrict__ partials, const float* __restrict__ bias,
                                                                   float* __restrict__ kerns, int B, int KS, int nout, float* __restrict__ vpre) {
     __shared__ float v[256];
-    const int b = blockIdx.x, o = threadIdx.x;
-    float acc = 0.f;
-    if (o < nout) {
-        const double a = (double)bias[o] + sum_partials(partials, B, KS, b, o);
-        if (vpre) vpre[(size_t)b * 256 + o] = (float)a;
-        acc = fmaxf((float)a - 1e-12f, 0.f) + 1e-12f;
-    }
-    v[o] = acc;
-    __syncthreads();
-    if (o < nout) {
-        const int g = (o / 25) * 25;
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 25; ++i) sum += v[g + i];
-        kerns[(size_t)b * nout + o] = acc / sum;
-    }
+    cdna_finish_block(partials, bias, kerns, B, KS, nout, vpre, blockIdx.x, v);
 }
 
 int cdna_kernels(const float* hidden5, const float* wt, const float* bias, float* partials, float* kerns,
@@ -198,23 +169,12 @@ int motion_partials(const float* hidden5, const float* wt, float* partials, int 
     return PIVP_LAUNCH_STATUS();
 }
 
-// STP finisher (TM:458-468): relu(Linear(100)) -> shared Linear(6) + identity.  w2 reference layout (6,100).
+// STP finisher (TM:458-468): stp_finish_block of skinny_linear.h
 __global__ __launch_bounds__(128) void stp_params_finish_kernel(const float* __restrict__ partials, const float* __restrict__ b1,
                                                                 const float* __restrict__ w2, const float* __restrict__ b2,
                                                                 float* __restrict__ theta, int B, int KS, float* __restrict__ s1_out) {
     __shared__ float s1[100];
-    const int b = blockIdx.x, o = threadIdx.x;
-    if (o < 100) {
-        const double acc = (double)b1[o] + sum_partials(partials, B, KS, b, o);
-        s1[o] = fmaxf((float)acc, 0.f);
-        if (s1_out) s1_out[(size_t)b * 256 + o] = s1[o];
-    }
-    __syncthreads();
-    if (o < 6) {
-        double acc = b2[o];
-        for (int i = 0; i < 100; ++i) acc = fma((double)w2[o * 100 + i], (double)s1[i], acc);
-        theta[b * 6 + o] = (float)(acc + ((o == 0 || o == 4) ? 1.0 : 0.0));
-    }
+    stp_finish_block(partials, b1, w2, b2, theta, B, KS, s1_out, blockIdx.x, s1);
 }
 
 int stp_params(const float* hidden5, const float* wt1, const float* b1, const float* w2, const float* b2,

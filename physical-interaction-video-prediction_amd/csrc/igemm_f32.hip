@@ -446,8 +446,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
 #pragma unroll
         for (int i = 0; i < nv; ++i)
             if ((ownmask >> i) & 1) { s1 += v[i]; c1 += 1.f; }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); c1 += __shfl_xor(c1, off, 64); }
+        s1 = wave_sum(s1); c1 = wave_sum(c1);
         __syncthreads();   // every wave is past its last LDS tile read: the tiles are dead, reuse their space
         if (lane == 0) { lds[wave] = s1; lds[4 + wave] = c1; }
         __syncthreads();
@@ -457,8 +456,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
 #pragma unroll
         for (int i = 0; i < nv; ++i)
             if ((ownmask >> i) & 1) { const float dd = v[i] - mean; q = fmaf(dd, dd, q); }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+        q = wave_sum(q);
         if (lane == 0) lds[8 + wave] = q;
         __syncthreads();
         if (tid == 0) {

@@ -161,7 +161,7 @@ bool deconv3x3s2_ln_ok(int c_ln, int c1, int cout, int B, int Hin, int Win) {
 int run_deconv3x3s2_ln(const float* h_raw, int c_ln, const float* x1, int c1, int ld1, const float* w, const float* bias, float* out, int cout,
                        int ldo, int relu, int B, int Hin, int Win, hipStream_t s, const float* gamma, const float* beta, const float* partials,
                        int nparts, float eps, float* ln_part, int ln_cap, int* ln_nparts, int bf16, float* norm_out, int norm_ld, float* stat_out,
-                       const float* wscale_part) {
+                       const float* wscale_part, const MotionRider* rider) {
     if (!h_raw || !w || !out || !gamma || !beta || !partials || nparts <= 0 || !deconv3x3s2_ln_ok(c_ln, x1 ? c1 : 0, cout, B, Hin, Win)) return PIVP_ERR_BADARG;
     if (norm_out && (norm_ld < c_ln || norm_ld % 4 || ((uintptr_t)norm_out & 15))) return PIVP_ERR_BADARG;
     if (ln_part && ln_part == partials) return PIVP_ERR_BADARG;      // blocks finish (and write their output partial) while others still read the input's
@@ -173,6 +173,10 @@ int run_deconv3x3s2_ln(const float* h_raw, int c_ln, const float* x1, int c1, in
     d.in_g = gamma; d.in_b = beta; d.in_part = partials; d.in_np = nparts; d.in_eps = eps;
     d.ln_part = ln_part; d.ln_cap = ln_cap;
     d.in_out = norm_out; d.in_out_ld = norm_ld; d.in_stat_out = stat_out;
+    if (rider && rider->mode) {
+        d.rd_mode = rider->mode; d.rd_blocks = B; d.rd_KS = rider->KS; d.rd_nout = rider->nout;
+        d.rd_partials = rider->partials; d.rd_bias = rider->bias; d.rd_w2 = rider->w2; d.rd_b2 = rider->b2; d.rd_out = rider->out; d.rd_vpre = rider->vpre;
+    }
     rc = igemm_validate(d, false);
     if (rc != PIVP_OK) return rc;
     if (!deconv_tile_ok(d)) return PIVP_ERR_BADARG;

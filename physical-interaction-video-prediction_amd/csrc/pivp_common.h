@@ -71,22 +71,47 @@ __device__ __forceinline__ float pivp_x3_scale_of_max(float m) {
     k = k < -60 ? -60 : k > 60 ? 60 : k;
     return __builtin_ldexpf(1.0f, k);
 }
-__device__ __forceinline__ float pivp_x3_scale_wave(const float* tail) {       // one partial per lane, xor-tree maximum: every lane returns the scale
-    float m = tail[2 + (threadIdx.x & 63)];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
-    return pivp_x3_scale_of_max(m);
-}
 
+// Wave-wide xor butterflies (levels 32, 16, 8, 4, 2, 1; every lane gets the result) without the LDS crossbar (round 6): __shfl_xor is ds_bpermute_b32, six
+// dependent LDS round trips per reduction (188 ns; scripts/micro/wave_sum.hip).  The two levels that cross 16-lane rows use gfx950's
+// v_permlane32_swap / v_permlane16_swap, the rest DPP: the same pairs in the same order -- bit-identical to the shuffle form -- in 79 ns.
+// (The swaps through inline asm: __builtin_amdgcn_permlane32_swap(v, v) with one value for both operands is folded to {v, v} by this compiler.)
+__device__ __forceinline__ void wave_swap_halves(float v, bool wide, float& a, float& b) {      // a, b: v and v[lane ^ 32] (wide) / v[lane ^ 16], in either order
+    a = v;
+    if (wide) asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "=&v"(b));
+    else asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "=&v"(b));
+}
+template <int CTRL, int BANKM = 0xf>
+__device__ __forceinline__ float wave_dpp(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf, BANKM, false));
+}
+__device__ __forceinline__ float wave_xor4(float v) {           // v[lane ^ 4]: row_shl:4 into banks 0 and 2, row_shr:4 into banks 1 and 3
+    return wave_dpp<0x114, 0xa>(wave_dpp<0x104, 0x5>(v, v), v);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    float a, b;
+    wave_swap_halves(v, true, a, b); v = a + b;
+    wave_swap_halves(v, false, a, b); v = a + b;
+    v += wave_dpp<0x128>(v, v);          // row_ror:8 = lane ^ 8
+    v += wave_xor4(v);
+    v += wave_dpp<0x4e>(v, v);           // quad_perm [2,3,0,1]
+    v += wave_dpp<0xb1>(v, v);           // quad_perm [1,0,3,2]
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    float a, b;
+    wave_swap_halves(v, true, a, b); v = fmaxf(a, b);
+    wave_swap_halves(v, false, a, b); v = fmaxf(a, b);
+    v = fmaxf(v, wave_dpp<0x128>(v, v));
+    v = fmaxf(v, wave_xor4(v));
+    v = fmaxf(v, wave_dpp<0x4e>(v, v));
+    v = fmaxf(v, wave_dpp<0xb1>(v, v));
     return v;
+}
+
+__device__ __forceinline__ float pivp_x3_scale_wave(const float* tail) {       // one partial per lane, xor-tree maximum: every lane returns the scale
+    float m = tail[2 + (threadIdx.x & 63)];
+    return pivp_x3_scale_of_max(wave_max(m));
 }
 
 // Block-wide sum for blockDim.x == NT (multiple of 64); `red` is LDS scratch of >= NT/64 floats.

@@ -29,11 +29,14 @@ int run_deconv3x3s2_and_partials(const float* x, int cin, const float* w, const 
 // deconv3x3s2 of concat(LayerNorm(h_raw) [c_ln channels], x1 [c1 channels, stride ld1]) with the norm applied while the tile kernel stages its
 // patch (IgemmDesc::in_g); `partials` = the producer's (count, mean, M2) partials of h_raw, never the same buffer as ln_part (the output's)
 bool deconv3x3s2_ln_ok(int c_ln, int c1, int cout, int B, int Hin, int Win);
+// the motion head's finisher carried by a transposed-conv launch as B blocks behind its tiles (IgemmDesc::rd_*): mode 1 CDNA (out = kerns [B][nout],
+// vpre [B][256] or null), 2 STP (out = theta [B][6], vpre = relu(Linear(100)) [B][256] or null)
+struct MotionRider { int mode, KS, nout; const float* partials; const float* bias; const float* w2; const float* b2; float* out; float* vpre; };
 int run_deconv3x3s2_ln(const float* h_raw, int c_ln, const float* x1, int c1, int ld1, const float* w, const float* bias, float* out, int cout,
                        int ldo, int relu, int B, int Hin, int Win, hipStream_t s, const float* gamma, const float* beta, const float* partials,
                        int nparts, float eps, float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr, int bf16 = 0,
                        float* norm_out = nullptr, int norm_ld = 0, float* stat_out = nullptr,    // training plans: the normalised tensor and (mean, rstd) are kept
-                       const float* wscale_part = nullptr);
+                       const float* wscale_part = nullptr, const MotionRider* rider = nullptr);
 int run_conv_s1(const float* x, int cin, int ldx, const float* w, float* out, int cout, int ldo, int ksize, int B, int H, int W,
                 hipStream_t s, int accum = 0, int wN = 0,    // wN: columns of the weight pack when only its first `cout` are wanted
                 int dest_zeroed = 0);                        // 1: the caller has cleared `out` (see conv_s1_splits_k)

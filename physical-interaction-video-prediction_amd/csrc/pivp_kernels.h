@@ -53,6 +53,12 @@ struct IgemmDesc {
     // cell's input gradient are the dY of the enc conv that produced x: relu_mask_kernel's job); 2: out += ep_src (a second gradient path into the
     // same tensor: add_strided_kernel's job).  Applies to output columns < ep_cols; ep_src[pixel * ep_ld + column].
     const float* ep_src; int ep_ld, ep_cols, ep_mode;
+    // deconv_tile only: "rider" blocks behind the launch's own tiles (round 6).  rd_mode 1 / 2: the last rd_blocks (= B) blocks of the grid run the CDNA /
+    // STP finisher of the motion head (cdna_finish_block / stp_finish_block, skinny_linear.h) for one sample each and return -- per-sample work that
+    // frame_head otherwise repeats in each of its 16 bands per sample (128 KB of partial sums per block), put where the chip has idle CUs (enc5's grid
+    // is 192 tiles on 256 CUs at B = 32).  The partial sums must be complete before the launch (they are: the Linear runs in front of lstm6).
+    int rd_mode, rd_blocks, rd_KS, rd_nout;
+    const float* rd_partials; const float* rd_bias; const float* rd_w2; const float* rd_b2; float* rd_out; float* rd_vpre;
 };
 
 // weight gradient of a conv / transposed conv (csrc/igemm_wgrad.hip)

@@ -119,6 +119,7 @@ struct pivp_plan {
     // the plan is created) keeps everything on the caller's stream.
     static constexpr int NSLOT = 14;      // 12: enc0's weight gradient, 13: the motion head's Linear (cdna_kernels / stp_input)
     bool use_side = true;
+    bool rider = true;                  // the motion head's finisher rides behind enc5's tiles (PIVP_FINISH_RIDER=0: inside frame_head, as rounds 4-5)
     hipStream_t side = nullptr;
     hipStream_t side_of(int) const { return side; }      // (a second side stream for the odd slots, round 3: fp32 no change, bf16 12.25 -> 12.05 ms, but with two
                                                          // processes on one GPU the step went from 65 ms to 78 SECONDS -- the hardware queues oversubscribe)
@@ -284,6 +285,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
     p->K5 = 128 * p->H8 * p->W8;
     p->ws = nullptr; p->ws_floats = 0; p->last_steps = 0; p->last_sched = false;
     { const char* e = getenv("PIVP_SIDE_STREAM"); p->use_side = !(e && e[0] == '0'); }
+    { const char* e = getenv("PIVP_FINISH_RIDER"); p->rider = !(e && e[0] == '0'); }
 
     auto add = [&](const std::string& name, long long n) { p->params.push_back({name, n, nullptr, nullptr, grad_group_of(name)}); return (int)p->params.size() - 1; };
     const int cin3 = 64 + (cfg->use_state ? 10 : 0);
@@ -572,10 +574,23 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     // each stage the patch and its gamma / beta again, which at config 5's 128 x 128 costs more than one bandwidth-bound ln_apply pass
     // (B = 32, T = 20: rollout 65.5 -> 65.9 ms with the fold, so it is not taken there).
     auto fold_small = [&](long long floats) { return floats * 4 <= 6LL << 20; };
+    // The motion head's finisher (sum of the Linear's K-slice partials, bias, activation, normalisation: per-SAMPLE work) rides behind enc5's tiles as
+    // B extra blocks (192 tiles on 256 CUs at B = 32) instead of being repeated by each of frame_head's 16 bands per sample (round 6).
+    bool finished = false;
     if (np > 0 && fold_small((long long)B * n4) && deconv3x3s2_ln_ok(64, 32, 96, B, p->H4, p->W4)) {
+        MotionRider rd;
+        memset(&rd, 0, sizeof(rd));
+        if (fh_fin && p->rider) {
+            if (!partials_done) { RC(motion_partials(ws + S.n5, P(p, p->i_head_w), ws + p->o_linpart, B, p->K5, c.model_type == PIVP_MODEL_STP ? 1 : 0, s)); partials_done = true; }
+            rd.mode = c.model_type == PIVP_MODEL_STP ? 2 : 1; rd.KS = cdna_kernel_partials_slices(p->K5); rd.nout = 25 * c.num_masks;
+            rd.partials = ws + p->o_linpart; rd.bias = P(p, p->i_head_b); rd.vpre = ws + S.vpre;
+            if (rd.mode == 2) { rd.w2 = P(p, p->i_head2_w); rd.b2 = P(p, p->i_head2_b); rd.out = ws + S.theta; }
+            else rd.out = ws + S.kerns;
+            finished = true;
+        }
         RC(run_deconv3x3s2_ln(ws + S.h[5], 64, ws + S.cat6 + 64, 32, 96, P(p, p->i_enc_w[5]), P(p, p->i_enc_b[5]), ws + S.e5, 96, 96, 1, B, p->H4, p->W4,
                               s, P(p, p->i_ln_g[6]), P(p, p->i_ln_b[6]), lnp, np, eps, nullptr, 0, nullptr, dprec,
-                              train ? ws + S.cat6 : nullptr, 96, train ? ws + S.lnstat + (size_t)6 * B * 2 : nullptr, ws + p->o_wabs[0]));
+                              train ? ws + S.cat6 : nullptr, 96, train ? ws + S.lnstat + (size_t)6 * B * 2 : nullptr, ws + p->o_wabs[0], &rd));
     } else {
         RC(ln(6, ws + S.h[5], ws + S.cat6, n4, 64, 96, 0, np));
         RC(run_deconv3x3s2(ws + S.cat6, 96, 96, P(p, p->i_enc_w[5]), P(p, p->i_enc_b[5]), ws + S.e5, 96, 96, 1, B, p->H4, p->W4, s, 0,
@@ -600,10 +615,12 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     // transform + compositing, behind the Linear's partial sums: bit-identical to the four launches below it, which remain for geometries
     // it does not take or where it is slower (frames wider than 64: frame_head_pays).  The softmaxed masks are kept for the rollout's last step only (pivp_get_tap).
     if (fh && np > 0) {
-        const bool fin = c.model_type == PIVP_MODEL_DNA || frame_head_finishes(p->K5);
+        const bool fin = !finished && (c.model_type == PIVP_MODEL_DNA || frame_head_finishes(p->K5));
         FrameHeadArgs a;
         memset(&a, 0, sizeof(a));
-        if (c.model_type == PIVP_MODEL_CDNA) {
+        if (finished) {
+            a.aux = c.model_type == PIVP_MODEL_STP ? ws + S.theta : ws + S.kerns;
+        } else if (c.model_type == PIVP_MODEL_CDNA) {
             if (fin) { if (!partials_done) RC(motion_partials(ws + S.n5, P(p, p->i_head_w), ws + p->o_linpart, B, p->K5, 0, s)); }
             else RC(cdna_kernels(ws + S.n5, P(p, p->i_head_w), P(p, p->i_head_b), ws + p->o_linpart, ws + S.kerns, B, p->K5, c.num_masks, s, ws + S.vpre));
             a.aux = ws + S.kerns; a.kerns_out = ws + S.kerns;

@@ -61,5 +61,58 @@ __device__ __forceinline__ void skinny_linear_partials_body(const float* __restr
     for (int bb = 0; bb < nb; ++bb) partials[((size_t)(b0 + bb) * KS + ks) * 256 + o] = (float)acc[bb];
 }
 
+// sum of the K-slice partials of output o of sample b, fixed order (bitwise reproducible), 4 independent chains
+__device__ __forceinline__ double sum_partials(const float* __restrict__ partials, int B, int KS, int b, int o) {
+    // chain c takes slices c, c+4, c+8, ... in increasing order; 32 loads are in flight per round trip
+    double a[4] = {0, 0, 0, 0};
+    for (int ks0 = 0; ks0 < KS; ks0 += 32) {
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = partials[((size_t)b * KS + min(ks0 + u, KS - 1)) * 256 + o];   // clamped, not
+#pragma unroll                                                       // predicated: a uniform predicate becomes a branch + vmcnt(0) per load
+        for (int u = 0; u < 32; ++u) a[u & 3] += ks0 + u < KS ? (double)v[u] : 0.0;
+    }
+    return (a[0] + a[1]) + (a[2] + a[3]);
+}
+
+// The finishers of the motion head as block bodies (256 threads, sample b; v: 256 floats of LDS).  Bodies of cdna_kernels_finish_kernel /
+// stp_params_finish_kernel (heads.hip) and of the "rider" blocks a transposed-conv launch carries behind its own tiles (deconv_tile.hip, round 6).
+// CDNA (TM:326-329): + bias, relu(k - RELU_SHIFT) + RELU_SHIFT, divide by the 5x5 sum.
+__device__ __forceinline__ void cdna_finish_block(const float* __restrict__ partials, const float* __restrict__ bias, float* __restrict__ kerns,
+                                                  int B, int KS, int nout, float* __restrict__ vpre, int b, float* v) {
+    const int o = threadIdx.x;
+    float acc = 0.f;
+    if (o < nout) {
+        const double a = (double)bias[o] + sum_partials(partials, B, KS, b, o);
+        if (vpre) vpre[(size_t)b * 256 + o] = (float)a;
+        acc = fmaxf((float)a - 1e-12f, 0.f) + 1e-12f;
+    }
+    if (o < 256) v[o] = acc;
+    __syncthreads();
+    if (o < nout) {
+        const int g = (o / 25) * 25;
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 25; ++i) sum += v[g + i];
+        kerns[(size_t)b * nout + o] = acc / sum;
+    }
+}
+// STP (TM:458-468): relu(Linear(100)) -> shared Linear(6) + identity.  w2 reference layout (6,100).
+__device__ __forceinline__ void stp_finish_block(const float* __restrict__ partials, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                 const float* __restrict__ b2, float* __restrict__ theta, int B, int KS, float* __restrict__ s1_out,
+                                                 int b, float* s1) {
+    const int o = threadIdx.x;
+    if (o < 100) {
+        const double acc = (double)b1[o] + sum_partials(partials, B, KS, b, o);
+        s1[o] = fmaxf((float)acc, 0.f);
+        if (s1_out) s1_out[(size_t)b * 256 + o] = s1[o];
+    }
+    __syncthreads();
+    if (o < 6) {
+        double acc = b2[o];
+        for (int i = 0; i < 100; ++i) acc = fma((double)w2[o * 100 + i], (double)s1[i], acc);
+        theta[b * 6 + o] = (float)(acc + ((o == 0 || o == 4) ? 1.0 : 0.0));
+    }
+}
 
 }  // namespace pivp

@@ -304,8 +304,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad25_bf16_kernel(const WgradDes
     if constexpr (PCS == 2) {
         float m = 0.f;
         for (int j = 0; j < tcount; ++j) m = __builtin_fmaxf(m, d.dy_absmax[(size_t)j * d.dy_absmax_stride + 2 + lane]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+        m = wave_max(m);
         gscale = pivp_x3_scale_of_max(m);
     }
     auto store_tile = [&]() {
