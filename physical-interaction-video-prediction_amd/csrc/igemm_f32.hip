@@ -122,9 +122,9 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
     // 5x5 halos overlap each other, instead of every XCD streaming all weights and all of the image.
     int lid = blockIdx.x;
     if ((gridDim.x & 7) == 0) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int n_mblk = gridDim.x / n_nblk;
-    const int nblk = lid / n_mblk;
-    const int mblk = lid % n_mblk;
+    const int n_mblk = d.n_mblk;                       // gridDim.x / n_nblk, and the multiplier / shift that divide by it (launch_igemm)
+    const int nblk = pivp_fdiv(lid, d.fd_mb_mul, d.fd_mb_sh);
+    const int mblk = lid - nblk * n_mblk;
     const int m0 = mblk * BM;
     const int cin = d.c0 + d.c1;
     const int ncc = cin >> 5;
@@ -132,14 +132,15 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
     // tap set: conv K x K (rows ky, cols kx) or, for the transposed 3x3 s2 conv, the taps of output parity
     // (py, px): oy = 2*iy - 1 + ky  =>  ky = 1 (py = 0) or ky in {0, 2} (py = 1), iy = a + (py + 1 - ky)/2.
     const bool deconv = LSTM ? false : d.deconv != 0;
-    const int nty_all = deconv ? 1 + py : d.ksize;
-    const int ntx = deconv ? 1 + px : d.ksize;
+    const int ksz = LSTM ? 5 : d.ksize, pad = LSTM ? 2 : d.pad;      // the gate convolution is 5 x 5, pad 2 (igemm_validate): constants there
+    const int nty_all = deconv ? 1 + py : ksz;
+    const int ntx = deconv ? 1 + px : ksz;
     // optional split of K over blockIdx.z (data gradients of small-M layers): contiguous ranges of the chunk sequence
     // (kernel row, kernel column, 32-channel chunk), equal to within one chunk; partial sums are atomically added into a pre-zeroed output
-    const int ksplit = gridDim.z;
+    const int ksplit = LSTM ? 1 : (int)gridDim.z;                      // (the gate kernels never split K over the grid)
     const int nchunks_tot = nty_all * ntx * ncc;
-    const int z_begin = ksplit > 1 ? (int)(((long)nchunks_tot * (int)blockIdx.z) / ksplit) : 0;
-    const int z_end = ksplit > 1 ? (int)(((long)nchunks_tot * ((int)blockIdx.z + 1)) / ksplit) : nchunks_tot;
+    const int z_begin = ksplit > 1 ? (int)((unsigned)(nchunks_tot * (int)blockIdx.z) / (unsigned)ksplit) : 0;          // (<= 25 * 32 chunks x 64 splits: 32 bits)
+    const int z_end = ksplit > 1 ? (int)((unsigned)(nchunks_tot * ((int)blockIdx.z + 1)) / (unsigned)ksplit) : nchunks_tot;
     const int nchunks_all = z_end - z_begin;
     const int nchunks = nchunks_all / KG;               // (KG = 2: the launcher only takes this form for an even chunk count)
     const int chunk0 = z_begin + gid * nchunks;         // this block's / group's first chunk
@@ -156,30 +157,41 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, d.bytesw, 0x00020000);
     int a_off0[NA], a_off1[NA];   // anchor pixel's byte offset in either source
     unsigned a_mask[NA];          // bit (ty * 5 + tx): tap (ty, tx) of this anchor reads inside the image (ksize <= 5)
+    auto anchors = [&]() {        // (called in the prologue, behind the first chunk's weight loads)
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
         const int m = m0 + prow + 32 * j;
         if (m < d.M && prow + 32 * j < BM) {
-            const int b = m / HWg;
+            const int b = pivp_fdiv(m, d.fd_hw_mul, d.fd_hw_sh);
             const int rem = m - b * HWg;
-            const int ay = rem / d.Wg;
+            const int ay = pivp_fdiv(rem, d.fd_w_mul, d.fd_w_sh);
             const int ax = rem - ay * d.Wg;
             const int iy0 = ay * d.in_step, ix0 = ax * d.in_step;
             const int pix = b * d.Hin * d.Win + iy0 * d.Win + ix0;
             a_off0[j] = (pix * d.ld0 + cvec * 4) * 4;
             a_off1[j] = (pix * d.ld1 + cvec * 4) * 4;
-            // validity is separable: row ty is inside for all columns or none.  Ten range checks here replace two adds, two
+            // validity is separable: row ty is inside for all columns or none.  Two masks here replace two adds, two
             // compares and an s_and per gathered piece and chunk in the loop.
             unsigned colm = 0, m25 = 0;
+            if (deconv) {
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                const int dxx = deconv ? ((px + 1 - (px ? 2 * t : 1)) >> 1) : t - d.pad;
-                if (t < ntx && (unsigned)(ix0 + dxx) < (unsigned)d.Win) colm |= 1u << t;
-            }
+                for (int t = 0; t < 5; ++t) {
+                    const int dxx = (px + 1 - (px ? 2 * t : 1)) >> 1;
+                    if (t < ntx && (unsigned)(ix0 + dxx) < (unsigned)d.Win) colm |= 1u << t;
+                }
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                const int dyy = deconv ? ((py + 1 - (py ? 2 * t : 1)) >> 1) : t - d.pad;
-                if (t < nty_all && (unsigned)(iy0 + dyy) < (unsigned)d.Hin) m25 |= colm << (5 * t);
+                for (int t = 0; t < 5; ++t) {
+                    const int dyy = (py + 1 - (py ? 2 * t : 1)) >> 1;
+                    if (t < nty_all && (unsigned)(iy0 + dyy) < (unsigned)d.Hin) m25 |= colm << (5 * t);
+                }
+            } else {
+                // tap t of a row / column is inside iff pad - x0 <= t <= extent - 1 + pad - x0: one contiguous run of bits per axis; the rows' run is
+                // spread to bits 0, 5, .., 20 and multiplied with the columns' 5 bits (no carries: the products do not overlap)
+                auto run = [](int lo, int hi) -> unsigned { return hi >= lo ? ((2u << hi) - 1u) & ~((1u << lo) - 1u) : 0u; };
+                colm = run(max(pad - ix0, 0), min(d.Win - 1 + pad - ix0, ntx - 1));
+                const int rlo = max(pad - iy0, 0), rhi = min(d.Hin - 1 + pad - iy0, nty_all - 1);
+                const unsigned rows = rhi >= rlo ? 0x108421u & ((2u << (5 * rhi)) - 1u) & ~((1u << (5 * rlo)) - 1u) : 0u;
+                m25 = colm * rows;
             }
             a_mask[j] = m25;
         } else {
@@ -187,6 +199,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
             a_mask[j] = 0;            // never in range
         }
     }
+    };
     int b_goff[NB];                           // byte offset of this thread's float4 inside a [N][32] weight chunk
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -203,7 +216,10 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
 
     // scalar state of the NEXT chunk to load: channel chunk l_cc of tap (l_ty, l_tx); no division, no branch
     int l_cc = 0, l_ty = 0, l_tx = 0;
-    if (KG > 1 || ksplit > 1) { const int tap = chunk0 / ncc; l_cc = chunk0 - tap * ncc; l_ty = tap / ntx; l_tx = tap - (tap / ntx) * ntx; }
+    if (KG > 1 || ksplit > 1) {
+        const int tap = pivp_fdiv(chunk0, d.fd_cc_mul, d.fd_cc_sh);
+        l_cc = chunk0 - tap * ncc; l_ty = LSTM ? tap / 5 : tap / ntx; l_tx = tap - l_ty * ntx;
+    }
     int s_delta = 0, s_ld = 0, s_wbase = 0;
     unsigned s_bit = 0;
     bool s_first = true;
@@ -217,7 +233,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
             const int ky = py ? 2 * l_ty : 1, kx = px ? 2 * l_tx : 1;
             t_dy = (py + 1 - ky) >> 1; t_dx = (px + 1 - kx) >> 1; t_wi = ky * 3 + kx;
         } else {
-            t_dy = l_ty - d.pad; t_dx = l_tx - d.pad; t_wi = l_ty * d.ksize + l_tx;
+            t_dy = l_ty - pad; t_dx = l_tx - pad; t_wi = l_ty * ksz + l_tx;
         }
         s_bit = __builtin_amdgcn_readfirstlane(1u << (l_ty * 5 + l_tx));
         const int ch = l_cc << 5;
@@ -270,13 +286,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
     // ~1.25x the rounding error of the blocked BLAS sum the reference's NumPy path uses; the STP warp of white-noise frames turns
     // that into pixels (tests/test_gpu_model.py: stp_b2_t4 at the 1e-4 gate).  Costs 16 accumulator registers per extra chain.
     constexpr int NACC = LSTM ? (TPW == 1 ? 4 : TPW == 2 ? 2 : 1) : 1;
-    f32x16 accs[NACC][TPW];
-#pragma unroll
-    for (int a = 0; a < NACC; ++a)
-#pragma unroll
-        for (int n = 0; n < TPW; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accs[a][n][r] = 0.f;
+    f32x16 accs[NACC][TPW];       // (cleared in the prologue, while the first chunk's loads are in flight)
     f32x16 (&acc)[TPW] = accs[0];
 
     const int half = lane >> 5;
@@ -362,6 +372,29 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
         store_piece(SET, std::integral_constant<int, 6>{}, buf); store_piece(SET, std::integral_constant<int, 7>{}, buf);
     };
     auto sync = [&]() { __syncthreads(); };
+    auto load_b = [&](auto SET) {       // the weight pieces of a chunk: pieces NA .. NA + NB - 1
+        if constexpr (NB > 0) load_piece(SET, std::integral_constant<int, NA + 0>{});
+        if constexpr (NB > 1) load_piece(SET, std::integral_constant<int, NA + 1>{});
+        if constexpr (NB > 2) load_piece(SET, std::integral_constant<int, NA + 2>{});
+        if constexpr (NB > 3) load_piece(SET, std::integral_constant<int, NA + 3>{});
+    };
+    auto load_a = [&](auto SET) {
+        if constexpr (NA > 0) load_piece(SET, std::integral_constant<int, 0>{});
+        if constexpr (NA > 1) load_piece(SET, std::integral_constant<int, 1>{});
+        if constexpr (NA > 2) load_piece(SET, std::integral_constant<int, 2>{});
+        if constexpr (NA > 3) load_piece(SET, std::integral_constant<int, 3>{});
+    };
+    static_assert(NA <= 4 && NB <= 4, "load_a / load_b unroll four pieces each");
+
+    // The prologue in the order that gets the first loads out soonest (round 6: ~880 instructions ran in front of the first tile load -- divisions, tap masks,
+    // 64-bit addresses, the accumulators' clears; with two waves per SIMD in the same phase that was the 3-4 us in front of the K loop): the first
+    // chunk's weight pieces need only the block's column and the thread's slot, so they go first; the anchors' offsets and tap masks are computed
+    // under their round trip; then the anchors' loads, bias and c_{t-1}; the accumulators are cleared while all of those are in flight.
+    if (nchunks > 0) { stage_begin(); load_b(S0{}); }
+    __builtin_amdgcn_sched_barrier(0);
+    anchors();
+    if (nchunks > 0) load_a(S0{});
+    __builtin_amdgcn_sched_barrier(0);
 
     // ConvLSTM: bias and c_{t-1} of the cells this lane will update are requested here, in front of the K loop.  Read in the
     // epilogue they cost one exposed HBM round trip per accumulator row, 16 in a row (measured on the bf16 kernel, where the
@@ -370,19 +403,28 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
     float cpre[OWNR];
     float bj = 0.f, bi = 0.f, bf = 0.f, bo = 0.f;
     if constexpr (LSTM) {
+        // (through a buffer descriptor, addressed as the epilogue's stores: one 32-bit lane offset, the cell's row as a scalar offset, rows past M
+        // read 0 -- their cells are dropped by the stores' descriptor.  The 64-bit address of each of the 8-16 loads was 40 % of them.)
         const int C = d.C, ch = nblk * CB + wn * CPW + (l31 % CPW), grp = l31 / CPW;
         bj = d.bias[ch]; bi = d.bias[C + ch]; bf = d.bias[2 * C + ch] + 1.0f; bo = d.bias[3 * C + ch];
+        const __amdgpu_buffer_rsrc_t rsci = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.cstate_in), 0, d.M * C * 4, 0x00020000);
+        const int voc = ((m0 + wm * 32 + 4 * half + (GPT > 1 ? grp : 0)) * C + ch) * 4;
 #pragma unroll
         for (int k = 0; k < OWNR; ++k) {
-            const int r = k * GPT + grp;
-            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            cpre[k] = d.cstate_in[(size_t)(m < d.M ? m : d.M - 1) * C + ch];
+            const int srow = GPT == 1 ? (k & 3) + 8 * (k >> 2) : GPT == 2 ? 2 * (k & 1) + 8 * (k >> 1) : 8 * k;
+            cpre[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsci, voc, srow * C * 4, 0));
         }
     }
 
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int n = 0; n < TPW; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accs[a][n][r] = 0.f;
     // prologue: chunk 0 straight into buffer 0, chunk 1 into register set 1
     if (nchunks > 0) {
-        stage_begin(); load_all(S0{}); store_all(S0{}, 0);
+        store_all(S0{}, 0);
         if (nchunks > 1) { stage_begin(); load_all(S1{}); }
         if constexpr (PRE > 0) stage_begin();   // parameters of chunk 2, loaded while chunk 0 is consumed
         __syncthreads();
@@ -529,7 +571,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
             }
         }
         if (d.ln_part) {
-            const int b = m0 / HWg;
+            const int b = pivp_fdiv(m0, d.fd_hw_mul, d.fd_hw_sh);
             tile_stats(sv, own, std::integral_constant<int, OWNR>{}, b, ((m0 - b * HWg) / BM) * n_nblk + nblk);
         }
     } else if (!deconv && d.out_step == 1 && d.Hout == d.Hg && d.Wout == d.Wg && !d.bias && !d.relu && !d.accum && !d.ln_part &&
@@ -567,9 +609,9 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (m < d.M) {
-                const int b = m / HWg;
+                const int b = pivp_fdiv(m, d.fd_hw_mul, d.fd_hw_sh);
                 const int rem = m - b * HWg;
-                const int ay = rem / d.Wg;
+                const int ay = pivp_fdiv(rem, d.fd_w_mul, d.fd_w_sh);
                 const int ax = rem - ay * d.Wg;
                 const int opix = (ay * d.out_step + oy0) * d.Wout + ax * d.out_step + ox0;
                 const size_t o = ((size_t)b * d.Hout * d.Wout + opix) * d.ldo;
@@ -589,7 +631,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 1 && LSTM && WM < 4) ? 2 : 1) void
             }
         }
         if (d.ln_part) {
-            const int b = m0 / HWg;
+            const int b = pivp_fdiv(m0, d.fd_hw_mul, d.fd_hw_sh);
             tile_stats(sv, own, std::integral_constant<int, 16 * TPW>{}, b,
                        (((m0 - b * HWg) / BM) * n_nblk + nblk) * (int)gridDim.y + phase);
         }
@@ -610,6 +652,11 @@ static int launch_igemm(const IgemmDesc& d, hipStream_t stream, int ksplit = 1, 
     if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&igemm_f32_kernel<WM, WN, NTB, LSTM, KG>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
     dim3 grid(mblk * n_nblk, d.nphase, ksplit);
     IgemmDesc dd = d;
+    dd.n_mblk = mblk;
+    pivp_fastdiv((unsigned)mblk, &dd.fd_mb_mul, &dd.fd_mb_sh);
+    pivp_fastdiv((unsigned)(d.Hg * d.Wg), &dd.fd_hw_mul, &dd.fd_hw_sh);
+    pivp_fastdiv((unsigned)d.Wg, &dd.fd_w_mul, &dd.fd_w_sh);
+    pivp_fastdiv((unsigned)((d.c0 + d.c1) >> 5), &dd.fd_cc_mul, &dd.fd_cc_sh);
     // fused LayerNorm partials: only when no tile straddles two samples and the caller's buffer holds them
     const int hwg = d.Hg * d.Wg;
     const int np = (hwg / BM) * n_nblk * d.nphase;
@@ -631,7 +678,8 @@ int igemm_validate(const IgemmDesc& d, bool lstm) {
     PIVP_CHECK_ARG(d.wcin >= d.c0 + d.c1 && d.wcin % 32 == 0);
     if (lstm) {
         PIVP_CHECK_ARG(d.C > 0 && d.C % 32 == 0 && d.N == 4 * d.C && d.bias && d.cstate_in && d.cstate_out && d.hout);
-        PIVP_CHECK_ARG(d.nphase == 1 && d.in_step == 1 && d.Hg == d.Hin && d.Wg == d.Win);
+        PIVP_CHECK_ARG(d.nphase == 1 && d.in_step == 1 && d.Hg == d.Hin && d.Wg == d.Win && d.ksize == 5 && d.pad == 2 && !d.deconv);
+        PIVP_CHECK_ARG((long long)d.M * d.C * 4 < (1LL << 31));         // c / h through 32-bit buffer offsets
     } else {
         PIVP_CHECK_ARG(d.out && d.N % 32 == 0 && d.N >= 32 && d.ldo >= d.N);
         PIVP_CHECK_ARG(d.out_step >= 1 && d.Hout > 0 && d.Wout > 0);

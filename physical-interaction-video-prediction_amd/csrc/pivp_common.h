@@ -72,6 +72,16 @@ __device__ __forceinline__ float pivp_x3_scale_of_max(float m) {
     return __builtin_ldexpf(1.0f, k);
 }
 
+// n / d for 0 <= n < 2^31 and a run-time d >= 1 without the division sequence: sh = ceil(log2 d), mul = floor(2^32 (2^sh - d) / d) + 1,
+// n / d = (mulhi(mul, n) + n) >> sh  (Granlund & Montgomery's round-up form; d a power of two: mul = 1, the quotient is n >> sh)
+inline void pivp_fastdiv(unsigned d, unsigned* mul, unsigned* sh) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    *sh = l;
+    *mul = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+}
+__device__ __forceinline__ int pivp_fdiv(int n, unsigned mul, unsigned sh) { return (int)((__umulhi(mul, (unsigned)n) + (unsigned)n) >> sh); }
+
 // Wave-wide xor butterflies (levels 32, 16, 8, 4, 2, 1; every lane gets the result) without the LDS crossbar (round 6): __shfl_xor is ds_bpermute_b32, six
 // dependent LDS round trips per reduction (188 ns; scripts/micro/wave_sum.hip).  The two levels that cross 16-lane rows use gfx950's
 // v_permlane32_swap / v_permlane16_swap, the rest DPP: the same pairs in the same order -- bit-identical to the shuffle form -- in 79 ns.

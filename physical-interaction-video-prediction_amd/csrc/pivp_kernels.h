@@ -57,6 +57,10 @@ struct IgemmDesc {
     // STP finisher of the motion head (cdna_finish_block / stp_finish_block, skinny_linear.h) for one sample each and return -- per-sample work that
     // frame_head otherwise repeats in each of its 16 bands per sample (128 KB of partial sums per block), put where the chip has idle CUs (enc5's grid
     // is 192 tiles on 256 CUs at B = 32).  The partial sums must be complete before the launch (they are: the Linear runs in front of lstm6).
+    // igemm_f32 only, filled by its launcher (round 6): exact division by a run-time divisor as multiply-high + add + shift (pivp_fastdiv): the tile
+    // column count n_mblk, the anchors per sample Hg * Wg and the anchor row Wg -- integer division is a ~35-instruction sequence, and a block's
+    // prologue is priced by its instruction count
+    int n_mblk; unsigned fd_mb_mul, fd_mb_sh, fd_hw_mul, fd_hw_sh, fd_w_mul, fd_w_sh, fd_cc_mul, fd_cc_sh;   // (.., and the 32-channel chunks per tap)
     int rd_mode, rd_blocks, rd_KS, rd_nout;
     const float* rd_partials; const float* rd_bias; const float* rd_w2; const float* rd_b2; float* rd_out; float* rd_vpre;
 };
