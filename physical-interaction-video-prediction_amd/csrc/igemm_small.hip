@@ -35,8 +35,8 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int n_nblk = d.N / BN;
-    const int nblk = bx % n_nblk, mblk = bx / n_nblk;
+    const int n_nblk = d.n_mblk;                                  // d.N / BN, with the multiplier / shift that divide by it (igemm_small below)
+    const int mblk = pivp_fdiv(bx, d.fd_mb_mul, d.fd_mb_sh), nblk = bx - mblk * n_nblk;
     const int m0 = mblk * 32;
     const int phase = by, py = phase >> 1, px = phase & 1;
     const bool deconv = d.deconv != 0;
@@ -52,17 +52,17 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.c1 ? d.x1 : d.x0), 0, d.c1 ? d.bytes1 : d.bytes0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, d.bytesw, 0x00020000);
     int a_off0 = 0, a_off1 = 0, a_iy0 = -(1 << 20), a_ix0 = 0;
-    {
+    auto anchor = [&]() {          // (called behind the first chunk's weight loads)
         const int m = m0 + prow;
         if (m < d.M) {
-            const int b = m / HWg, rem = m - b * HWg;
-            const int ay = rem / d.Wg, ax = rem - ay * d.Wg;
+            const int b = pivp_fdiv(m, d.fd_hw_mul, d.fd_hw_sh), rem = m - b * HWg;
+            const int ay = pivp_fdiv(rem, d.fd_w_mul, d.fd_w_sh), ax = rem - ay * d.Wg;
             a_iy0 = ay * d.in_step; a_ix0 = ax * d.in_step;
             const int pix = b * d.Hin * d.Win + a_iy0 * d.Win + a_ix0;
             a_off0 = (pix * d.ld0 + cvec * 4) * 4;
             a_off1 = (pix * d.ld1 + cvec * 4) * 4;
         }
-    }
+    };
     int b_goff[NTB];
 #pragma unroll
     for (int t = 0; t < NTB; ++t) b_goff[t] = ((nblk * BN + t * 32 + prow) * 32 + cvec * 4) * 4;
@@ -77,14 +77,17 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_ln ? d.in_b : d.x0), 0, in_ln ? d.Hin * d.Win * d.c0 * 4 : 0, 0x00020000);
     if (IN_LN && tid < 64) {
         float mean, rstd;
-        ln_merge_partials(d.in_part, m0 / HWg, d.in_np, d.in_eps, mean, rstd);
+        ln_merge_partials(d.in_part, pivp_fdiv(m0, d.fd_hw_mul, d.fd_hw_sh), d.in_np, d.in_eps, mean, rstd);
         if (tid == 0) { in_stat[0] = mean; in_stat[1] = rstd; }
     }
     int l_cc = 0, l_ty = 0, l_tx = 0;
     // two register sets: chunk i+2 is loaded while chunk i is multiplied and written to LDS at the end of chunk i+1
     f32x4 ras[2], rbs[2][NTB];
     f32x4 rgs[2], rbe[2];              // in_ln: gamma / beta of the staged float4
-    auto load_next = [&](auto SET) {   // chunk (l_ty, l_tx, l_cc) -> register set SET, then advance
+    // PART 0: the whole chunk; 1: its weight tiles only (no advance); 2: the rest, then advance -- the first chunk's weights go out before the anchor's
+    // address arithmetic (a block's prologue is priced by the instructions in front of its first load: 244 of this kernel's 960 before round 6)
+    auto load_next = [&](auto SET, auto PART) {   // chunk (l_ty, l_tx, l_cc) -> register set SET, then advance
+        constexpr int part = decltype(PART)::value;
         f32x4& ra = ras[decltype(SET)::value];
         f32x4 (&rb)[NTB] = rbs[decltype(SET)::value];
         int dy, dx, wi;
@@ -99,19 +102,23 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
         const int ld = first ? d.ld0 : d.ld1;
         const int delta = ((dy * d.Win + dx) * ld + (first ? ch : ch - d.c0)) * 4;
         const int wbase = (wi * (d.wcin >> 5) + l_cc) * (d.wN ? d.wN : d.N) * 128;
-        const int iy = a_iy0 + dy, ix = a_ix0 + dx;
-        const bool ok = (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
-        const unsigned off = ok ? (unsigned)((first ? a_off0 : a_off1) + delta) : OOB;
-        ra = __builtin_bit_cast(f32x4, first ? __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0)
-                                             : __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
-        if constexpr (IN_LN) {         // element (iy, ix, channel) of the sample: [Hin*Win][c0]
-            const unsigned goff = ok ? (unsigned)(((iy * d.Win + ix) * d.c0 + ch + cvec * 4) * 4) : OOB;
-            rgs[decltype(SET)::value] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, goff, 0, 0));
-            rbe[decltype(SET)::value] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, goff, 0, 0));
+        if constexpr (part != 1) {
+            const int iy = a_iy0 + dy, ix = a_ix0 + dx;
+            const bool ok = (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+            const unsigned off = ok ? (unsigned)((first ? a_off0 : a_off1) + delta) : OOB;
+            ra = __builtin_bit_cast(f32x4, first ? __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0)
+                                                 : __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
+            if constexpr (IN_LN) {         // element (iy, ix, channel) of the sample: [Hin*Win][c0]
+                const unsigned goff = ok ? (unsigned)(((iy * d.Win + ix) * d.c0 + ch + cvec * 4) * 4) : OOB;
+                rgs[decltype(SET)::value] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, goff, 0, 0));
+                rbe[decltype(SET)::value] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, goff, 0, 0));
+            }
         }
+        if constexpr (part != 2) {
 #pragma unroll
-        for (int t = 0; t < NTB; ++t) rb[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, b_goff[t], wbase, 0));
-        if (++l_cc == ncc) { l_cc = 0; if (++l_tx == ntx) { l_tx = 0; ++l_ty; } }
+            for (int t = 0; t < NTB; ++t) rb[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, b_goff[t], wbase, 0));
+        }
+        if constexpr (part != 1) { if (++l_cc == ncc) { l_cc = 0; if (++l_tx == ntx) { l_tx = 0; ++l_ty; } } }
     };
     auto store_regs = [&](auto SET, int buf) {
         f32x4 ra = ras[decltype(SET)::value];
@@ -127,6 +134,9 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
         for (int t = 0; t < NTB; ++t) *reinterpret_cast<f32x4*>(lds + B_OFF + (buf * NTB + t) * TILE + lds_w) = rb[t];
     };
 
+    if (nchunks > 0) load_next(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});      // the first chunk's weight tiles
+    __builtin_amdgcn_sched_barrier(0);
+    anchor();
     f32x16 acc[NTB];
 #pragma unroll
     for (int t = 0; t < NTB; ++t)
@@ -136,6 +146,7 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
 
     if (nchunks > 0) {
         using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+        using P0 = std::integral_constant<int, 0>; using P2 = std::integral_constant<int, 2>;
         auto mma = [&](int buf) {
             const f32x4 fa = *reinterpret_cast<const f32x4*>(lds + A_OFF + buf * TILE + frag);
             f32x4 fb[NTB];
@@ -146,18 +157,18 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
 #pragma unroll
                 for (int t = 0; t < NTB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s2], fb[t][s2], acc[t], 0, 0, 0);
         };
-        load_next(S0{});
+        load_next(S0{}, P2{});
         if constexpr (IN_LN) __syncthreads();   // in_stat
         store_regs(S0{}, 0);
-        if (nchunks > 1) load_next(S1{});
+        if (nchunks > 1) load_next(S1{}, P0{});
         __syncthreads();
         int it = 0;
         for (; it + 1 < nchunks; it += 2) {     // chunks it (LDS buffer 0) and it+1 (buffer 1)
-            if (it + 2 < nchunks) load_next(S0{});
+            if (it + 2 < nchunks) load_next(S0{}, P0{});
             mma(0);
             store_regs(S1{}, 1);                // chunk it+1
             __syncthreads();
-            if (it + 3 < nchunks) load_next(S1{});
+            if (it + 3 < nchunks) load_next(S1{}, P0{});
             mma(1);
             if (it + 2 < nchunks) store_regs(S0{}, 0);
             __syncthreads();
@@ -177,8 +188,8 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     __syncthreads();
     const int m = m0 + prow;
     const bool valid = m < d.M;
-    const int b = valid ? m / HWg : 0, rem = m - b * HWg;
-    const int ay = rem / d.Wg, ax = rem - ay * d.Wg;
+    const int b = valid ? pivp_fdiv(m, d.fd_hw_mul, d.fd_hw_sh) : 0, rem = m - b * HWg;
+    const int ay = pivp_fdiv(rem, d.fd_w_mul, d.fd_w_sh), ax = rem - ay * d.Wg;
     const int oy0 = deconv ? py : 0, ox0 = deconv ? px : 0;
     float* orow = d.out + ((size_t)(b * d.Hout + ay * d.out_step + oy0) * d.Wout + ax * d.out_step + ox0) * d.ldo + nblk * BN;
     float sv[4 * NTB];   // this thread's outputs, for the fused LayerNorm partial
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
         if (lane == 0) lds[8 + wave] = q;
         __syncthreads();
         if (tid == 0) {
-            const int bb = m0 / HWg;
+            const int bb = pivp_fdiv(m0, d.fd_hw_mul, d.fd_hw_sh);
             float* pp = d.ln_part + ((size_t)bb * d.ln_nparts + (((m0 - bb * HWg) >> 5) * n_nblk + nblk) * gdy + phase) * 4;
             pp[0] = cnt; pp[1] = mean; pp[2] = (lds[8] + lds[9]) + (lds[10] + lds[11]); pp[3] = 0.f;
         }
@@ -238,6 +249,10 @@ int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     dd.ln_nparts = (d.ln_part && hwg % 32 == 0 && np <= d.ln_cap) ? np : 0;
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
+    dd.n_mblk = nt / ntb;                                        // (here: the column blocks, the divisor of blockIdx.x)
+    pivp_fastdiv((unsigned)(nt / ntb), &dd.fd_mb_mul, &dd.fd_mb_sh);
+    pivp_fastdiv((unsigned)hwg, &dd.fd_hw_mul, &dd.fd_hw_sh);
+    pivp_fastdiv((unsigned)d.Wg, &dd.fd_w_mul, &dd.fd_w_sh);
     if (d.in_g) {      // LayerNorm-on-load (see IgemmDesc::in_g): one sample per tile, one source, a plain conv
         PIVP_CHECK_ARG(igemm_in_ln_ok(d) && d.in_b && d.in_part && d.in_np > 0);
         if (ntb == 3) hipLaunchKernelGGL((igemm_small_kernel<3, true>), grid, dim3(256), 0, stream, dd);
