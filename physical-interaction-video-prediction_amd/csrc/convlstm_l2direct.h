@@ -60,9 +60,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     const int n_tiles = (d.B / TIN) * tpi;
     int lid = blockIdx.x;
     if ((gridDim.x & 7) == 0) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware, column-block major
-    const int nblk = lid / n_tiles, tile = lid - nblk * n_tiles;
-    const int b0 = (tile / tpi) * TIN, trem = tile - (tile / tpi) * tpi;
-    const int y0 = (trem / tpr) * THX, x0 = (trem - (trem / tpr) * tpr) * TW;
+    const int nblk = pivp_fdiv(lid, d.fd_mb_mul, d.fd_mb_sh), tile = lid - nblk * n_tiles;      // (the launcher's multipliers: pivp_fastdiv)
+    const int timg = pivp_fdiv(tile, d.fd_hw_mul, d.fd_hw_sh);
+    const int b0 = timg * TIN, trem = tile - timg * tpi;
+    const int trow = pivp_fdiv(trem, d.fd_w_mul, d.fd_w_sh);
+    const int y0 = trow * THX, x0 = (trem - trow * tpr) * TW;
     // anchor i of the block's 128 -> (image of the tile, row, column): 8 x 16 of one image, or 8 x 8 of two
     auto anchor = [&](int i, int& ti, int& ay, int& ax) {
         if constexpr (W8) { ti = i >> 6; ay = (i >> 3) & 7; ax = i & 7; }
@@ -474,6 +476,12 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     }
 }
 
+// the divisors of a block's tile decode (tiles, tiles per image, tiles per row) as multiplier / shift pairs
+static inline void x6g_decode_divisors(IgemmDesc& dd, int n_tiles, int tpi, int tpr) {
+    pivp_fastdiv((unsigned)n_tiles, &dd.fd_mb_mul, &dd.fd_mb_sh);
+    pivp_fastdiv((unsigned)tpi, &dd.fd_hw_mul, &dd.fd_hw_sh);
+    pivp_fastdiv((unsigned)tpr, &dd.fd_w_mul, &dd.fd_w_sh);
+}
 template <int NWM, int NWN, int PCS, bool IN_LN, bool W8 = false>
 static int launch_x6g_impl(const IgemmDesc& d, const unsigned short* wb, hipStream_t stream, int* ln_nparts) {
     constexpr int THX = TH, lds_bytes = PCS * (W8 ? PATCH_BYTES : PH * RP16);
@@ -489,6 +497,7 @@ static int launch_x6g_impl(const IgemmDesc& d, const unsigned short* wb, hipStre
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
     const long long wbytes = (long long)lstm_bf16_weight_elems(d.c0 + (d.c1 ? d.c1 : d.C), 4 * d.C) * PCS * 2;
     if (wbytes >= (1LL << 31)) return PIVP_ERR_BADARG;
+    x6g_decode_divisors(dd, (d.B / (W8 ? 2 : 1)) * tpi, tpi, d.Win / (W8 ? 8 : 16));
     hipLaunchKernelGGL((convlstm_x6g_kernel<NWM, NWN, true, PCS, IN_LN, W8>), dim3((d.B / (W8 ? 2 : 1)) * tpi * nb), dim3(64 * NWM * NWN), lds_bytes, stream, dd, wb, (int)wbytes, 0);
     return PIVP_LAUNCH_STATUS();
 }
@@ -509,7 +518,8 @@ static int launch_x6g(const IgemmDesc& d, const unsigned short* wb, hipStream_t 
 
 // the plain 5x5 convolution on the same kernel: dd.N = rows of the padded pack, nb = its 64-column blocks, ks = split of the channel groups
 template <int PCS, bool W8 = false>
-static int launch_x6g_plain(const IgemmDesc& dd, const unsigned short* wb, hipStream_t stream, int nb, int ks, int ncols) {
+static int launch_x6g_plain(const IgemmDesc& dsc, const unsigned short* wb, hipStream_t stream, int nb, int ks, int ncols) {
+    IgemmDesc dd = dsc;
     constexpr int lds_bytes = PCS * (W8 ? PATCH_BYTES : PH * RP16);
     static PerDeviceOnce once;
     if (pivp_ensure_dyn_lds(once, reinterpret_cast<const void*>(&convlstm_x6g_kernel<4, 2, false, PCS, false, W8>), lds_bytes) != PIVP_OK) return PIVP_ERR_LAUNCH;
@@ -517,6 +527,7 @@ static int launch_x6g_plain(const IgemmDesc& dd, const unsigned short* wb, hipSt
     const int tpi = (dd.Hin / TH) * (dd.Win / (W8 ? 8 : 16));
     const long long wbytes = (long long)lstm_bf16_weight_elems(dd.c0 + dd.c1, dd.N) * PCS * 2;
     if (wbytes >= (1LL << 31)) return PIVP_ERR_BADARG;
+    x6g_decode_divisors(dd, (dd.B / (W8 ? 2 : 1)) * tpi, tpi, dd.Win / (W8 ? 8 : 16));
     hipLaunchKernelGGL((convlstm_x6g_kernel<4, 2, false, PCS, false, W8>), dim3((dd.B / (W8 ? 2 : 1)) * tpi * nb, ks), dim3(512), lds_bytes, stream, dd, wb, (int)wbytes, ncols);
     return PIVP_LAUNCH_STATUS();
 }

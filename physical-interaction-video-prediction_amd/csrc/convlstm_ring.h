@@ -70,9 +70,13 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
     const int n_tiles = (d.B / ti_n) * tpi;
     int lid = blockIdx.x;
     if ((gridDim.x & 7) == 0) lid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware, column-block major
-    const int nblk = lid / n_tiles, tile = lid - nblk * n_tiles;
-    const int b0 = (tile / tpi) * ti_n, trem = tile - (tile / tpi) * tpi;
-    const int y0 = (trem / tpr) * TH, x0 = (trem - (trem / tpr) * tpr) * tw;
+    // (divisions by run-time values through the launcher's multipliers, pivp_fastdiv: a block's time in front of its first load is its instruction count --
+    // 600 instructions here before round 6, most of them the division sequences of this decode and of the patch pixels below)
+    const int nblk = pivp_fdiv(lid, d.fd_mb_mul, d.fd_mb_sh), tile = lid - nblk * n_tiles;
+    const int timg = pivp_fdiv(tile, d.fd_hw_mul, d.fd_hw_sh);
+    const int b0 = timg * ti_n, trem = tile - timg * tpi;
+    const int trow = pivp_fdiv(trem, d.fd_w_mul, d.fd_w_sh);
+    const int y0 = trow * TH, x0 = (trem - trow * tpr) * tw;
     BF_STAMP(0);
     const int c0 = d.c0, ld0 = d.ld0, ld1 = d.ld1;
     const int cin = c0 + d.c1;
@@ -92,8 +96,8 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
 #pragma unroll
     for (int j = 0; j < NPJ; ++j) {
         const int p = (tid >> 3) + 64 * j;
-        const int ti = p / (PH * PW), pr = p - ti * (PH * PW);
-        const int py = pr / PW, px = pr - py * PW;
+        const int ti = tw == 16 ? p / (PH * 20) : p / (PH * 12), pr = p - ti * (PH * PW);      // PW is 20 or 12: constant divisors
+        const int py = tw == 16 ? pr / 20 : pr / 12, px = pr - py * PW;
         const int iy = y0 - 2 + py, ix = x0 - 2 + px;
         const bool ok = p < npix && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
         a_pix[j] = ok ? ((b0 + ti) * H + iy) * W + ix : -1;
@@ -543,6 +547,9 @@ static int launch_bf16(const IgemmDesc& d, const unsigned short* wb, hipStream_t
     if (!dd.ln_nparts) dd.ln_part = nullptr;
     if (ln_nparts) *ln_nparts = dd.ln_nparts;
     const int blocks = (d.B / ti_n) * tpi * nb;
+    pivp_fastdiv((unsigned)((d.B / ti_n) * tpi), &dd.fd_mb_mul, &dd.fd_mb_sh);      // tiles, tiles per image, tiles per row: the block's decode
+    pivp_fastdiv((unsigned)tpi, &dd.fd_hw_mul, &dd.fd_hw_sh);
+    pivp_fastdiv((unsigned)(d.Win / tw), &dd.fd_w_mul, &dd.fd_w_sh);
     hipLaunchKernelGGL((convlstm_bf16_kernel<NCH, LSTM, PL>), dim3(blocks, ksplit), dim3(512), lds_bytes, stream, dd, wb, tw, ncols);
     return PIVP_LAUNCH_STATUS();
 }

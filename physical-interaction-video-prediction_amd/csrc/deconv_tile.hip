@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void deconv3x3s2_tile_kernel(const IgemmDes
             v += bias;
             if (d.relu) v = fmaxf(v, 0.f);
             if (d.accum) v += *o;
-            *o = v;
+            *o = v;      // (as a nontemporal store: enc5 / enc6 -1.3 us per launch, frame_head +1.0 reading what then comes from memory: not taken, profiles/r06/NOTES.md 5)
             acc[ph][r] = v;
             s1 += v;
         }
