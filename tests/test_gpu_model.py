@@ -288,3 +288,29 @@ def test_other_mask_counts(pivp, mt, nm):
     else:
         assert l2.max() < GATE
     assert abs(loss - float(ref.loss)) < 1e-5
+
+
+@pytest.mark.parametrize('mt,nm', [('CDNA', 10), ('CDNA', 3), ('STP', 10)])
+@pytest.mark.parametrize('train', [False, True])
+def test_motion_finisher_behind_enc5_is_bit_identical(pivp, monkeypatch, mt, nm, train):
+    """Round 6: the motion head's finisher (sum of the Linear's K-slice partials, bias, activation, normalisation: TM:326-329 / 458-468) runs as B "rider"
+    blocks behind enc5's tiles instead of inside each of frame_head's 16 bands per sample (PIVP_FINISH_RIDER, read when the plan is made).
+    Same arithmetic in the same order: frames and loss are bit-identical with the switch off; in training mode the gradients agree to the
+    last bits the sweep's atomics leave undetermined."""
+    B, T = 3, 4
+    P = R.init_params(seed=5, dtype=np.float32, scale=1.0, num_masks=nm, model_type=mt)
+    imgs, acts, stas = R.synthetic_batch(B, T)
+    out = {}
+    for rider in ('1', '0'):
+        monkeypatch.setenv('PIVP_FINISH_RIDER', rider)
+        m, loss, gen = _run(pivp, mt, nm, imgs, acts, stas, P, train=train, keep_activations=train)
+        grads = None
+        if train:
+            m.cleargrads(); m.backward()
+            grads = m.grads_reference()
+        out[rider] = (loss, gen, grads)
+    assert out['1'][0] == out['0'][0] and np.array_equal(out['1'][1], out['0'][1])
+    if train:
+        for k in out['1'][2]:
+            a, b = np.asarray(out['1'][2][k]), np.asarray(out['0'][2][k])
+            assert np.abs(a - b).max() <= 2e-5 * max(1e-30, np.abs(a).max()), k

@@ -37,6 +37,19 @@ def test_convlstm_parity(ops, B, cx, C, H, variant):
     assert np.abs(hg - hr).max() < TOL and np.abs(cg - cr).max() < TOL
 
 
+@pytest.mark.parametrize("variant", [0, 2, 3])
+@pytest.mark.parametrize('B,cx,C,H,Wd', [(2, 32, 32, 12, 20), (3, 64, 32, 10, 6), (1, 32, 64, 7, 24)])
+def test_convlstm_on_maps_that_are_not_powers_of_two(ops, B, cx, C, H, Wd, variant):
+    # the kernels divide by Hg * Wg, Wg and the tile counts through multiply-high + shift (pivp_fastdiv, round 6): divisors that are not
+    # powers of two, tiles that straddle rows and samples
+    rs = np.random.RandomState(B * 100 + C + Wd)
+    x = rs.randn(B, cx, H, Wd); h = rs.randn(B, C, H, Wd) * 0.5; c = rs.randn(B, C, H, Wd)
+    W = rs.randn(4 * C, cx + C, 5, 5) / np.sqrt(25 * (cx + C)); b = rs.randn(4 * C) * 0.1
+    hr, cr = _lstm_ref(x, h, c, W, b)
+    hg, cg = ops.convlstm(x, h, c, W, b, variant)
+    assert np.abs(hg - hr).max() < TOL and np.abs(cg - cr).max() < TOL
+
+
 @pytest.mark.parametrize('variant', [1, 2, 3, 4])
 def test_convlstm_first_step_skips_zero_h(ops, variant):
     # h_prev = NULL (all zeros after reset_state, TM:254-257): the h half of K is skipped, result identical
