@@ -708,7 +708,7 @@ int igemm_lstm(const IgemmDesc& d, hipStream_t stream, int variant, int* ln_npar
     // layers that fill the chip: lstm1 126 -> 119.5 TF, lstm7 135.5 -> 132, rollout 8.67 -> 8.86 ms; 46 VGPRs spill under the 256 cap.  Not kept.)
     switch (variant) {
         case 4:   // 64-row tile as two K groups of 4 waves (two waves per SIMD where the grid gives every CU one block): lstm4 106.6 -> 104.6 us,
-                  // lstm6 153.6 -> 150.2 at B = 32; needs an even chunk count (lstm3 has 75)
+                  // lstm6 153.6 -> 150.2 at B = 32; needs an even chunk count (lstm3 has 75; round 6 gave group 1 a null chunk -- tap 25 loads zeros -- so that lstm3 could take this form: 122 TFLOP/s either way, not kept)
             if (((25 * ((d.c0 + d.c1) >> 5)) & 1) == 0) return launch_igemm<2, 2, 4, true, 2>(d, stream, 1, ln_nparts);
             return launch_igemm<2, 2, 4, true>(d, stream, 1, ln_nparts);
         case 1: return launch_igemm<4, 1, 4, true>(d, stream, 1, ln_nparts);
