@@ -150,6 +150,10 @@ __global__ __launch_bounds__(FH_NT, 2) void frame_head_kernel(const FrameHeadArg
             tp[c][u] = pb[(size_t)c * HW + iy * W + ix];           // clamped address, zeroed below: no predicate around the load
         }
     if (wave < ntile) issue(wave, 0);
+    // the statistics merge here, under the round trip of everything requested above (its one partial per lane was requested first): three wave
+    // sums, two divisions and a square root that sat between the staging stores and barrier (1) before (1.1 us of the block's chain)
+    float mean, rstd;
+    ln_merge_partials(ln_first, a.ln_part, b, a.ln_nparts, a.eps, mean, rstd);
     if (prow) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -181,8 +185,6 @@ __global__ __launch_bounds__(FH_NT, 2) void frame_head_kernel(const FrameHeadArg
         th[tid] = kv0[0];
     }
     FH_STAMP(1);
-    float mean, rstd;
-    ln_merge_partials(ln_first, a.ln_part, b, a.ln_nparts, a.eps, mean, rstd);
     if (a.stat_out && blockIdx.x == 0 && tid == 0) { a.stat_out[b * 2] = mean; a.stat_out[b * 2 + 1] = rstd; }
     FH_STAMP(2);
     // the halo pixels' rows, normalised, into LDS: relu((v - mean) rstd gamma + beta), the band tiles' expression
