@@ -27,7 +27,7 @@ fam = [   # (label, substring(s) of the kernel name, GFLOP per rollout, MB per r
      T1 * B * (32 * 32 * 96 * 2 + 64 * 64 * 64 + 16 * 16 * 96) * 4 / MB),
     ('enc1 / enc2 / enc4 (igemm_small)', ('igemm_small',), 2 * MAC['enc124'] * B * T1 / 1e9, 0.0),
     ('LayerNorm apply x 4 (norm_enc0, hidden1, hidden3, hidden5; hidden2 / 4 / 6 / 7: inside enc1 / 2 / 5 / 6)', ('ln_apply',), 0.0, T1 * B * 2 * (2 * 32768 + 16384 + 8192) * 4 / MB),
-    ('frame head: norm_enc6 + 1x1 heads + kernel finisher + softmax + CDNA transform + blend, one launch (round 4)', ('frame_head_kernel',),
+    ('frame head: norm_enc6 + 1x1 heads + softmax + CDNA transform + blend, one launch (round 4; round 6: the kernel finisher rides behind enc5)', ('frame_head_kernel',),
      2 * (MAC['heads'] + MAC['cdna']) * B * T1 / 1e9, T1 * (B * HW * 64 * 4 + 2 * HW * 64 * 4 + B * HW * (3 + 3 + 3) * 4) / MB),
     ('heads 1x1 + norm_enc6 + ReLU', ('heads_1x1',), 2 * MAC['heads'] * B * T1 / 1e9, T1 * (B * HW * 64 * 4 + 2 * HW * 64 * 4 + B * HW * 17 * 4) / MB),
     ('composite (softmax + CDNA transform + blend)', ('composite_kernel',), 2 * MAC['cdna'] * B * T1 / 1e9, T1 * B * HW * (3 + 11 + 3 + 3) * 4 / MB),
