@@ -51,14 +51,17 @@ static int composite_bwd_rows(int W) {
 // threads every wait was exposed: 68.3 us per launch, 512 threads 45.5, 1024 threads 40.4)
 constexpr int CBC_NT = 1024;
 
-template <int CB_TR>
+// NMC / WC / HC (round 6): num_masks and the frame size as compile-time constants (0 = from the arguments) for the reference's geometry (10 masks, 64 x 64):
+// the kernel is a chain of LDS-fed loops whose trip counts and predicates hang on them (frame_head.hip has the measurement of what that costs)
+template <int CB_TR, int NMC = 0, int WC = 0, int HC = 0>
 __global__ __launch_bounds__(CBC_NT) void composite_bwd_cdna_kernel(const float* __restrict__ prev, const float* __restrict__ logits,
                                                                  const float* __restrict__ layer0, const float* __restrict__ kerns,
                                                                  const float* __restrict__ go, float* __restrict__ dmk,
                                                                  float* __restrict__ dz, float* __restrict__ dkpart,
-                                                                 float* __restrict__ dprev, int dprev_accum, int H, int W, int NM) {
+                                                                 float* __restrict__ dprev, int dprev_accum, int H_, int W_, int NM_) {
     PIVP_SET_MAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int H = HC ? HC : H_, W = WC ? WC : W_, NM = NMC ? NMC : NM_;
     const int NP = NM + 1, HW = H * W, NK = NM - 1;
     const int b = blockIdx.y, y0 = blockIdx.x * CB_TR;
     const int rows = min(CB_TR, H - y0);
@@ -80,48 +83,42 @@ __global__ __launch_bounds__(CBC_NT) void composite_bwd_cdna_kernel(const float*
     // independent loads in flight per thread (the flat-index loops of the first version made one L2 round trip per element)
     const unsigned magic = 0xFFFFFFFFu / (unsigned)NP + 1u;
     auto div_np = [&](int x) { return (int)__umulhi((unsigned)x, magic); };
-    if (tid < 256)
-    for (int m = 0; m < NP; ++m) {
-        const int F0 = m * HW + ep0 - (NP - 1);
-        for (int j0 = tid; j0 < win; j0 += 1024) {
-            float t[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const int j = j0 + 256 * u, F = F0 + j; t[u] = (j < win && F >= 0 && F < NP * HW) ? lgb[F] : 0.f; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (j0 + 256 * u < win) lg[m * win + j0 + 256 * u] = t[u];
-        }
-    }
+    // Staging: EVERY load of the block is requested before the first LDS store, by all 1,024 threads (round 6).  Before, 256 threads walked the
+    // logits planes four loads at a time -- plane after plane: 11 serial L2 round trips --, then the go planes (3 more) behind the frame tile.
     const float* pb = prev + (size_t)b * 3 * HW;
-    {
-        const int x = tid % PW, r0 = tid / PW, rstep = 256 / PW;   // PW <= 256 (checked by the launcher)
-        if (tid < rstep * PW)
-            for (int rb = r0; rb < PR; rb += 4 * rstep) {
-                float t[3][4];
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int r = rb + u * rstep, iy = y0 + r - 2, ix = x - 2;
-                        t[c][u] = (r < PR && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? pb[(size_t)c * HW + iy * W + ix] : 0.f;
-                    }
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { const int r = rb + u * rstep; if (r < PR) prevt[(c * PR + r) * PW + x] = t[c][u]; }
-            }
-    }
     const float* gb = go + (size_t)b * 3 * HW;
-    if (tid < 256)
+    constexpr int LU = 2;                        // window / tile elements per thread and plane (win, enp, PR * PW <= 2,048: checked by the launcher)
+    float tl[12][LU], tg[3][LU], tp[3][LU];
+#pragma unroll
+    for (int m = 0; m < 12; ++m)
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int j = tid + CBC_NT * u, F = m * HW + ep0 - (NP - 1) + j;
+            tl[m][u] = (m < NP && j < win && F >= 0 && F < NP * HW) ? lgb[F] : 0.f;
+        }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-        for (int p0_ = tid; p0_ < enp; p0_ += 1024) {
-            float t[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int pp = p0_ + 256 * u; t[u] = pp < enp ? gb[(size_t)c * HW + ep0 + pp] : 0.f; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (p0_ + 256 * u < enp) gox[c * PR * W + p0_ + 256 * u] = t[u];
+        for (int u = 0; u < LU; ++u) {
+            const int pp = tid + CBC_NT * u;
+            tg[c][u] = pp < enp ? gb[(size_t)c * HW + ep0 + pp] : 0.f;
+            const int r = pp / PW, x = pp - r * PW, iy = y0 + r - 2, ix = x - 2;
+            tp[c][u] = (r < PR && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? pb[(size_t)c * HW + iy * W + ix] : 0.f;
         }
-    if (tid < NM * 25) kl[tid] = kerns[(size_t)b * NM * 25 + tid];
+    const float kv = tid < NM * 25 ? kerns[(size_t)b * NM * 25 + tid] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 12; ++m)
+#pragma unroll
+        for (int u = 0; u < LU; ++u) { const int j = tid + CBC_NT * u; if (m < NP && j < win) lg[m * win + j] = tl[m][u]; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int pp = tid + CBC_NT * u;
+            if (pp < enp) gox[c * PR * W + pp] = tg[c][u];
+            if (pp < PR * PW) prevt[c * PR * PW + pp] = tp[c][u];
+        }
+    if (tid < NM * 25) kl[tid] = kv;
     __syncthreads();
     for (int i = tid; i < NP * G; i += CBC_NT) {
         const int m = i / G, gi = i - m * G;
@@ -258,8 +255,12 @@ int composite_bwd_cdna(const float* prev, const float* logits, const float* laye
     const int enp = PR * W, win = enp + 2 * (NP - 1), G = enp / NP + 2;
     const size_t lds = sizeof(float) * ((size_t)NP * win + 2 * NP * G + (size_t)NP * PR * W + 3 * PR * W + 3 * PR * (W + 4) + ((NM * 25 + 3) & ~3) +
                                         (size_t)CB_TR * CBC_NT);      // ... + the kernel-gradient row partials
-    PIVP_CHECK_ARG(lds <= 160 * 1024 && W + 4 <= 256 && NM * 25 <= 256);
-    if (CB_TR == 8) {
+    PIVP_CHECK_ARG(lds <= 160 * 1024 && W + 4 <= 256 && NM * 25 <= 256 && win <= 2 * CBC_NT && PR * (W + 4) <= 2 * CBC_NT);
+    if (CB_TR == 8 && NM == 10 && W == 64 && H == 64) {      // the reference's geometry: the constant-folded instance
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_cdna_kernel<8, 10, 64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((composite_bwd_cdna_kernel<8, 10, 64, 64>), dim3(composite_bwd_tiles(H, W), B), dim3(CBC_NT), lds, s, prev, logits, layer0, kerns, go,
+                           dmk, dz, dkpart, dprev, dprev_accum, H, W, NM);
+    } else if (CB_TR == 8) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_cdna_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(composite_bwd_cdna_kernel<8>, dim3(composite_bwd_tiles(H, W), B), dim3(CBC_NT), lds, s, prev, logits, layer0, kerns, go,
                            dmk, dz, dkpart, dprev, dprev_accum, H, W, NM);
