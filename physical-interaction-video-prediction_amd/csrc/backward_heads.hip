@@ -462,9 +462,16 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
     __shared__ float wl[HB_MAXOUT * 64];                                  // [output][k]
     const int tid = threadIdx.x, NO = NP + NE, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < HB_MAXOUT * 64; i += 256) {
-        const int o = i >> 6, k = i & 63;
-        wl[i] = o < NP ? wm[k * NP + o] : (o < NO ? we[k * NE + (o - NP)] : 0.f);
+    {   // the weight table: all eight loads of a thread go out before the first LDS store (a loop of lds[i] = g[i] is one L2 round trip per trip)
+        float wv[HB_MAXOUT * 64 / 256];
+#pragma unroll
+        for (int u = 0; u < HB_MAXOUT * 64 / 256; ++u) {
+            const int i = tid + 256 * u, o = i >> 6, k = i & 63, oc = min(o, NO - 1);
+            const float v = oc < NP ? wm[k * NP + oc] : we[k * NE + (oc - NP)];
+            wv[u] = o < NO ? v : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < HB_MAXOUT * 64 / 256; ++u) wl[tid + 256 * u] = wv[u];
     }
     for (int i = tid; i < HB_MAXOUT * HB_DP; i += 256) dpt[i] = 0.f;      // rows >= NO stay zero for the whole block
     const int KO = (NO + 1) >> 1;                                         // k-steps of the d e6 contraction
@@ -537,10 +544,16 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
             dwacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xt[p * 68 + l31], b, dwacc[0], 0, 0, 0);
             dwacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xt[p * 68 + 32 + l31], b, dwacc[1], 0, 0, 0);
         }
-        if (tid < NO) {
-            float a = dbacc;
-            for (int p = 0; p < HB_PX; ++p) a += dpt[tid * HB_DP + p];
-            dbacc = a;
+        {   // column sums of dp (bias gradients): eight threads per output take 16 pixels each and meet through DPP (before: one thread per output
+            // walked its 128 pixels, a serial chain of 128 LDS reads in one wave while the other three waited at the next barrier)
+            const int o = tid >> 3, q8 = tid & 7;
+            float a = 0.f;
+#pragma unroll
+            for (int p = 0; p < HB_PX / 8; ++p) a += dpt[o * HB_DP + q8 * (HB_PX / 8) + p];      // rows >= NO are zero
+            a += wave_xor4(a);
+            a += wave_dpp<0x4e>(a, a);
+            a += wave_dpp<0xb1>(a, a);
+            dbacc += a;          // every thread of the eight holds output o's sum
         }
     }
     // block reduction of the four waves' dW tiles through LDS ([wave][k tile][k][33]), then one atomic per (k, output)
@@ -557,7 +570,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
         const float v = (red[idx] + red[2 * 32 * 33 + idx]) + (red[4 * 32 * 33 + idx] + red[6 * 32 * 33 + idx]);
         if (o < NP) atomicAdd(dwm + k * NP + o, v); else atomicAdd(dwe + k * NE + (o - NP), v);
     }
-    if (tid < NO) { if (tid < NP) atomicAdd(dbm + tid, dbacc); else atomicAdd(dbe + (tid - NP), dbacc); }
+    if ((tid & 7) == 0 && (tid >> 3) < NO) { const int o = tid >> 3; if (o < NP) atomicAdd(dbm + o, dbacc); else atomicAdd(dbe + (o - NP), dbacc); }
 }
 int heads_bwd(const float* e6, const float* wm, const float* we, const float* dpm, const float* dpe, float* de6,
               float* dwm, float* dbm, float* dwe, float* dbe, int B, int HW, int NP, int NE, hipStream_t s) {
@@ -657,8 +670,12 @@ __global__ __launch_bounds__(256) void skinny_linear_bwd_w_kernel(const float* _
             xl[r * 33 + bb] = (b0 + bb < B && k0 + r < K) ? x[(size_t)(b0 + bb) * K + k0 + r] : 0.f;
         }
         __syncthreads();
-        for (int bb = 0; bb < 32 && b0 + bb < B; ++bb) {
-            const float d = dv[(size_t)(b0 + bb) * 256 + o];
+        float dvr[32];      // the 32 samples' dv of this column: requested together (inside the loop below each was a round trip of its own)
+#pragma unroll
+        for (int bb = 0; bb < 32; ++bb) dvr[bb] = dv[(size_t)min(b0 + bb, B - 1) * 256 + o];
+#pragma unroll
+        for (int bb = 0; bb < 32; ++bb) {
+            const float d = b0 + bb < B ? dvr[bb] : 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc[r] = fmaf(xl[r * 33 + bb], d, acc[r]);
         }
@@ -1078,7 +1095,14 @@ __global__ __launch_bounds__(256) void enc0_dgrad_kernel(const float* __restrict
                                                          int accum, int B, int H, int W) {
     PIVP_SET_MAIN_PRIO();
     __shared__ __attribute__((aligned(16))) float wl[75 * 32];
-    for (int i = threadIdx.x; i < 75 * 32; i += 256) wl[i] = w[i];
+    {   // 2,400 weights: ten loads per thread requested together, then the LDS stores (the loop lds[i] = g[i] was ten serial L2 round trips
+        // in front of a 14-us kernel on the sweep's critical path)
+        float wv[10];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) wv[u] = w[min((int)threadIdx.x + 256 * u, 75 * 32 - 1)];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) { const int i = threadIdx.x + 256 * u; if (i < 75 * 32) wl[i] = wv[u]; }
+    }
     __syncthreads();
     const int H2 = H >> 1, W2 = W >> 1;
     const int py = blockIdx.y >> 1, px = blockIdx.y & 1;          // parity of (y, x): taps ky = py, py + 2, (py + 4), likewise kx
