@@ -102,14 +102,17 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
     const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN_LN ? d.in_g : d.x0), 0, IN_LN ? H * W * c0 * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN_LN ? d.in_b : d.x0), 0, IN_LN ? H * W * c0 * 4 : 0, 0x00020000);
     auto patch_load = [&](int cg, int rnd) {
-        const int ch = cg * 64 + cpiece * 8;
+        const int gch = cg * 64;                          // block-uniform: the source choice below is a uniform branch (see convlstm_ring.h: as a
+        const int ch = gch + cpiece * 8;                  // per-lane choice of descriptor every load was a 14-instruction waterfall loop)
         const bool s0 = ch < c0, s1 = !s0 && ch < cin;
-        const int ld = s0 ? ld0 : ld1, co = s0 ? ch : ch - c0;
+        const bool use0 = gch < c0, use1 = gch + 64 > c0 && gch < cin;
+        const int co = s0 ? ch : ch - c0;
 #pragma unroll
         for (int j = 0; j < NPJX; ++j) {
             int a_pix, a_lds;
             pix_of(rnd * NPJX + j, a_pix, a_lds);
-            const unsigned off = (a_pix >= 0 && (s0 || s1)) ? (unsigned)((a_pix * ld + co) * 4) : OOB;
+            const unsigned off0 = (a_pix >= 0 && s0) ? (unsigned)((a_pix * ld0 + ch) * 4) : OOB;
+            const unsigned off1 = (a_pix >= 0 && s1) ? (unsigned)((a_pix * ld1 + ch - c0) * 4) : OOB;
             if constexpr (IN_LN) {          // (pieces of h channels and pixels outside the image: the zeros of an out-of-range load)
                 const unsigned go = (a_pix >= 0 && s0) ? (unsigned)(((a_pix - b0 * H * W) * c0 + co) * 4) : OOB;
                 glo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, go, 0, 0));
@@ -117,12 +120,18 @@ __global__ __launch_bounds__(64 * NWM * NWN, 1) void convlstm_x6g_kernel(const I
                 blo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, go, 0, 0));
                 bhi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, go, 16, 0));
             }
-            if (s0) {
-                plo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
-                phi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 16, 0));
+            if (use0 && use1) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 alo = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off0, 0, 0)), ahi = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off0, 16, 0));
+                const u32x4 blo2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off1, 0, 0)), bhi2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off1, 16, 0));
+                plo[j] = __builtin_bit_cast(f32x4, alo | blo2);      // (one of the two is the hardware's zeros)
+                phi[j] = __builtin_bit_cast(f32x4, ahi | bhi2);
+            } else if (use0) {
+                plo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off0, 0, 0));
+                phi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off0, 16, 0));
             } else {
-                plo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
-                phi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 16, 0));
+                plo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off1, 0, 0));
+                phi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off1, 16, 0));
             }
         }
     };

@@ -104,19 +104,34 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         a_lds[j] = p < npix ? (ti * PH + py) * RP + px * PP : PW * PP;
     }
     f32x4 plo[NPJ], phi[NPJ];                          // a patch in flight (live only between the two halves of a staging)
+    // The source of a thread's 8-channel piece (x or h) differs between the lanes of a wave only in the ONE 64-channel group that straddles c0.
+    // Written as a per-lane choice of descriptor (rounds 2-5) every load became a waterfall loop -- readfirstlane x 4, two 64-bit compares, exec
+    // juggling: 14 instructions per load, 42-107 such loops per kernel.  Now the choice is block-uniform: a group inside one source loads from
+    // it; the straddling group loads from both with the other source's lanes out of range (the hardware's zeros) and ORs the two.
     auto patch_load = [&](int cg) {
-        const int ch = (cgbase + cg) * 64 + cpiece * 8;   // first of this thread's 8 channels of concat(x, h)
+        const int gch = (cgbase + cg) * 64;               // the group's first channel: block-uniform
+        const int ch = gch + cpiece * 8;                  // first of this thread's 8 channels of concat(x, h)
         const bool s0 = ch < c0, s1 = !s0 && ch < cin;
-        const int ld = s0 ? ld0 : ld1, co = s0 ? ch : ch - c0;
+        const bool use0 = gch < c0, use1 = gch + 64 > c0 && gch < cin;
+        auto ld2 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off, f32x4& lo, f32x4& hi) {
+            lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 16, 0));
+        };
 #pragma unroll
         for (int j = 0; j < NPJ; ++j) {
-            const unsigned off = (a_pix[j] >= 0 && (s0 || s1)) ? (unsigned)((a_pix[j] * ld + co) * 4) : OOB;
-            if (s0) {
-                plo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0));
-                phi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 16, 0));
+            const unsigned off0 = (a_pix[j] >= 0 && s0) ? (unsigned)((a_pix[j] * ld0 + ch) * 4) : OOB;
+            const unsigned off1 = (a_pix[j] >= 0 && s1) ? (unsigned)((a_pix[j] * ld1 + ch - c0) * 4) : OOB;
+            if (use0 && use1) {
+                f32x4 blo, bhi;
+                ld2(rs0, off0, plo[j], phi[j]);
+                ld2(rs1, off1, blo, bhi);
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                plo[j] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, plo[j]) | __builtin_bit_cast(u32x4, blo));
+                phi[j] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, phi[j]) | __builtin_bit_cast(u32x4, bhi));
+            } else if (use0) {
+                ld2(rs0, off0, plo[j], phi[j]);
             } else {
-                plo[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
-                phi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 16, 0));
+                ld2(rs1, off1, plo[j], phi[j]);           // (a group past cin: every lane out of range)
             }
         }
     };
