@@ -415,6 +415,56 @@ __global__ __launch_bounds__(512, 1) void convlstm_bf16_kernel(const IgemmDesc d
         // The epilogue hook's second tensor (d.ep_src) is requested for ALL of the lane's outputs first and met below: read next to each store
         // it cost one exposed round trip per accumulator row (the data gradients ran 9-11 us longer per launch with it, more than the pass it
         // replaces).  Neutral elements where the hook does not apply: 1 for the mask, 0 for the sum.
+        const long long out_bytes = (long long)d.B * H * W * d.ldo * 4, ep_bytes = d.ep_mode ? (long long)d.B * H * W * d.ep_ld * 4 : 0;
+        if (out_bytes < (1LL << 31) && ep_bytes < (1LL << 31)) {
+            // Round 6: as the fp32 data gradient's epilogue (igemm_f32.hip): the lane-dependent part of an element's address is ONE 32-bit offset of a
+            // buffer descriptor (wave tile base, + 4 * half rows, + column), the accumulator register's row a scalar offset, columns past the pack's
+            // real count an out-of-range offset the hardware drops -- instead of a 64-bit address, a tile decode and a predicate per element
+            // (~25 instructions each, 32-64 elements per lane, run by four of the block's eight waves while the others idle).
+            const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, (int)out_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rse = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.ep_mode ? d.ep_src : d.out), 0, d.ep_mode ? (int)ep_bytes : 0, 0x00020000);
+            const int basem = ((b0 + (tw == 16 ? 0 : wm)) * H + y0 + (tw == 16 ? 4 * wm : 0)) * W + x0 + 4 * half;      // anchor of accumulator row 0 of M tile 0
+            constexpr unsigned OOBX = 0xC0000000u;
+            unsigned vo[TPW], ve[TPW];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int col = nblk * BN + (wn * TPW + t) * 32 + l31;
+                vo[t] = col < ncols ? (unsigned)((basem * d.ldo + col) * 4) : OOBX;
+                ve[t] = (col < ncols && col < d.ep_cols) ? (unsigned)((basem * d.ep_ld + col) * 4) : OOBX;
+            }
+            auto srow = [&](int mt, int r) -> int {     // anchors between accumulator row r of M tile mt and row 0 of tile 0 (block-uniform)
+                return tw == 16 ? (2 * mt + (r >> 3)) * W + (r & 3) + 8 * ((r >> 2) & 1) : (4 * mt + (r >> 2)) * W + (r & 3);
+            };
+            float ev[2][TPW][16];
+            if (d.ep_mode) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int t = 0; t < TPW; ++t)
+                            ev[mt][t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rse, ve[t], srow(mt, r) * d.ep_ld * 4, 0));
+            }
+            const int mode = d.ep_mode, split = gridDim.y > 1, accum = d.accum;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int so = srow(mt, r) * d.ldo * 4;
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) {
+                        float v = acc[mt][t][r];
+                        if (mode == 1) v = (ve[t] != OOBX ? ev[mt][t][r] > 0.f : true) ? v : 0.f;      // (columns the hook does not cover: unmasked)
+                        else if (mode == 2) v += ev[mt][t][r];                                       // (out-of-range loads returned 0)
+                        if (split) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rso, vo[t], so, 0);
+                        else {
+                            if (accum) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rso, vo[t], so, 0));
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rso, vo[t], so, 0);
+                        }
+                    }
+                }
+            return;
+        }
         float ev[2][TPW][16];
         if (d.ep_mode) {                                // block-uniform
 #pragma unroll
