@@ -14,7 +14,8 @@
  *     are idempotent.  A plan that runs a backward sweep owns one internal low-priority stream and its events for the weight
  *     gradients (created on the first pivp_rollout_backward, destroyed with the plan); everything it enqueues there is fenced
  *     against the caller's stream with events, so the caller still only ever synchronises its own stream.  PIVP_SIDE_STREAM=0
- *     (read at pivp_plan_create) keeps all work on the caller's stream.
+ *     (read at pivp_plan_create) keeps all work on the caller's stream.  PIVP_FINISH_RIDER=0 (read there too) runs the motion head's finisher
+ *     inside the frame-head launch instead of as extra blocks of enc5's launch: bit-identical results either way, it exists for A/B timing.
  *   - feature maps are NHWC with an explicit pixel stride `ld` (floats); frames and mask planes are
  *     planar NCHW exactly as the reference holds them
  */
