@@ -381,40 +381,48 @@ int frame_sqerr_partials(const float* a, const float* b, float* partials, int n,
 }
 
 // results: [0] loss, [1] psnr_all, [2..2+nf) recon_cost, [2+nf..2+2nf) psnr, [2+2nf..2+3nf) state_cost
-__global__ __launch_bounds__(64) void loss_finalize_kernel(const float* __restrict__ fp, int nparts, int nframes,
-                                                           int frame_numel, const float* __restrict__ st,
-                                                           const float* __restrict__ sg, int state_numel, float denom,
-                                                           float* __restrict__ results) {
-    float loss = 0.f, psnr_all = 0.f;
-    for (int f = 0; f < nframes; ++f) {
+// One WAVE per frame (round 6: one wave walked the frames one after the other -- two dependent round trips, a log and two wave sums per frame,
+// 15-18 us at the end of every rollout); thread 0 then adds the per-frame terms in frame order (the same sum as before), reading them back
+// from `results` behind the block barrier (any number of frames).
+constexpr int LF_WAVES = 16;
+__global__ __launch_bounds__(64 * LF_WAVES) void loss_finalize_kernel(const float* __restrict__ fp, int nparts, int nframes,
+                                                                     int frame_numel, const float* __restrict__ st,
+                                                                     const float* __restrict__ sg, int state_numel, float denom,
+                                                                     float* __restrict__ results) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int f = wave; f < nframes; f += LF_WAVES) {
         float acc = 0.f;
-        for (int i = threadIdx.x; i < nparts; i += 64) acc += fp[f * nparts + i];
-        acc = wave_sum(acc);
-        const float mse = acc / (float)frame_numel;
-        const float psnr = 10.0f * logf(1.0f / mse) / 2.302585092994046f;
+        for (int i = lane; i < nparts; i += 64) acc += fp[f * nparts + i];
         float sacc = 0.f;
-        for (int i = threadIdx.x; i < state_numel; i += 64) {
+        for (int i = lane; i < state_numel; i += 64) {
             const float dd = st[f * state_numel + i] - sg[f * state_numel + i];
             sacc = fmaf(dd, dd, sacc);
         }
+        acc = wave_sum(acc);
         sacc = wave_sum(sacc);
+        const float mse = acc / (float)frame_numel;
+        const float psnr = 10.0f * logf(1.0f / mse) / 2.302585092994046f;
         const float scost = sacc / (float)state_numel * 1e-4f;
-        loss += mse + scost;
-        psnr_all += psnr;
-        if (threadIdx.x == 0) {
+        if (lane == 0) {
             results[2 + f] = mse;
             results[2 + nframes + f] = psnr;
             results[2 + 2 * nframes + f] = scost;
         }
     }
-    if (threadIdx.x == 0) { results[0] = loss / denom; results[1] = psnr_all; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float loss = 0.f, psnr_all = 0.f;
+        const volatile float* rv = results;          // written by the other waves of this block in front of the barrier
+        for (int f = 0; f < nframes; ++f) { loss += rv[2 + f] + rv[2 + 2 * nframes + f]; psnr_all += rv[2 + nframes + f]; }
+        results[0] = loss / denom; results[1] = psnr_all;
+    }
 }
 
 int loss_finalize(const float* frame_partials, int nparts, int nframes, int frame_numel,
                   const float* states_true, const float* states_gen, int state_numel,
                   float denom, float* results, hipStream_t s) {
     PIVP_CHECK_ARG(frame_partials && states_true && states_gen && results && nparts > 0 && nframes >= 0 && denom != 0.f);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, frame_partials, nparts, nframes, frame_numel,
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64 * LF_WAVES), 0, s, frame_partials, nparts, nframes, frame_numel,
                        states_true, states_gen, state_numel, denom, results);
     return PIVP_LAUNCH_STATUS();
 }
