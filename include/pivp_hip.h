@@ -16,6 +16,7 @@
  *     against the caller's stream with events, so the caller still only ever synchronises its own stream.  PIVP_SIDE_STREAM=0
  *     (read at pivp_plan_create) keeps all work on the caller's stream.  PIVP_FINISH_RIDER=0 (read there too) runs the motion head's finisher
  *     inside the frame-head launch instead of as extra blocks of enc5's launch: bit-identical results either way, it exists for A/B timing.
+ *     PIVP_FUSE_ENC3=0 likewise keeps group 3 (smear + 1x1 conv) and the state predictor in a launch of their own instead of enc2's epilogue.
  *   - feature maps are NHWC with an explicit pixel stride `ld` (floats); frames and mask planes are
  *     planar NCHW exactly as the reference holds them
  */

@@ -23,8 +23,9 @@ constexpr int TILE = 32 * SP;
 }
 
 // NTB: 32-column tiles per block (the A fragment is reused NTB times; fewer, longer-running blocks).
-template <int NTB, bool IN_LN = false>
+template <int NTB, bool IN_LN = false, bool FUSE3 = false>
 __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
+    static_assert(!FUSE3 || NTB == 2, "the fused 1x1 needs all 64 channels of a pixel in one block");
     const int bx = blockIdx.x, by = blockIdx.y, gdy = gridDim.y;
     PIVP_SET_MAIN_PRIO();
     constexpr int BN = 32 * NTB;
@@ -137,6 +138,19 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     if (nchunks > 0) load_next(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});      // the first chunk's weight tiles
     __builtin_amdgcn_sched_barrier(0);
     anchor();
+    // FUSE3: this wave's operands of the 1x1 that follows -- its 16 output columns' weights (16 k-steps x 4 k) and the per-sample bias
+    // b3 + W3s . (action, state) -- are requested here, a whole K loop ahead of their use.  Wave w owns output columns 16 w .. 16 w + 15.
+    float f3w[FUSE3 ? 16 : 1], f3c = 0.f;
+    if constexpr (FUSE3) {
+        const int col = 16 * wave + (lane & 15), kg = lane >> 4, bs = pivp_fdiv(m0, d.fd_hw_mul, d.fd_hw_sh);
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) f3w[s4] = d.f3_w[(4 * s4 + kg) * 64 + col];
+        f3c = d.f3_b[col];
+        if (d.f3_use_state) {
+#pragma unroll
+            for (int j = 0; j < 10; ++j) f3c = fmaf(j < 5 ? d.f3_action[bs * 5 + j] : d.f3_state[bs * 5 + j - 5], d.f3_w[(64 + j) * 64 + col], f3c);
+        }
+    }
     f32x16 acc[NTB];
 #pragma unroll
     for (int t = 0; t < NTB; ++t)
@@ -208,6 +222,39 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) sv[t * 4 + e] = v[e];
     }
+    if constexpr (FUSE3) {
+        // e3 = relu(f3c + tile . W3x): [32 px x 64] x [64 x 64] on v_mfma_f32_16x16x4_f32, wave w its 16 output columns for both 16-pixel row tiles.
+        // C = the bias, instruction s fed k = 4 s + lane group: the fmaf chain of enc3_state_kernel in its order (bias, smear terms, k ascending): bit-identical.
+        __syncthreads();                             // the partial-sum image is dead: the tile (after bias / ReLU) takes its place, [32][68]
+#pragma unroll
+        for (int t = 0; t < NTB; ++t)
+            *reinterpret_cast<f32x4*>(lds + prow * 68 + t * 32 + cvec * 4) = f32x4{sv[t * 4], sv[t * 4 + 1], sv[t * 4 + 2], sv[t * 4 + 3]};
+        __syncthreads();
+        const int li = lane & 15, kg = lane >> 4;
+        f32x4 c3[2];
+        c3[0] = f32x4{f3c, f3c, f3c, f3c}; c3[1] = c3[0];
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                c3[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[(16 * mt + li) * 68 + 4 * s4 + kg], f3w[s4], c3[mt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mm = m0 + 16 * mt + 4 * kg + r;       // accumulator register r: pixel row 4 (lane >> 4) + r of the 16-row tile, column lane & 15
+                if (mm < d.M) d.f3_out[(size_t)mm * 64 + 16 * wave + li] = fmaxf(c3[mt][r], 0.f);
+            }
+        const int bs3 = pivp_fdiv(m0, d.fd_hw_mul, d.fd_hw_sh);
+        if (d.f3_state_out && m0 == bs3 * HWg && tid < 5) {      // current_state = Linear(state_action) (TM:730): once per sample
+            const int bs = bs3;
+            float v = d.f3_bcs[tid];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) v = fmaf(d.f3_wcs[tid * 10 + j], j < 5 ? d.f3_action[bs * 5 + j] : d.f3_state[bs * 5 + j - 5], v);
+            d.f3_state_out[bs * 5 + tid] = v;
+        }
+    }
     if (d.ln_part) {   // (count, mean, M2) of the block's outputs, two passes over registers, fixed summation order
         __syncthreads();   // the partial-sum image is dead
         float s1 = 0.f;
@@ -242,6 +289,11 @@ int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     int ntb = 1;
     if (nt % 3 == 0 && (long)mblk * (nt / 3) * d.nphase >= 1024) ntb = 3;
     else if (nt % 2 == 0 && (long)mblk * (nt / 2) * d.nphase >= 1024) ntb = 2;
+    if (d.f3_out) {      // the fused 1x1 behind this conv: 64 columns in one block, tiles inside one sample, LayerNorm-on-load form only
+        PIVP_CHECK_ARG(d.in_g && nt == 2 && d.nphase == 1 && (d.Hg * d.Wg) % 32 == 0 && !d.accum && !d.ln_part);
+        PIVP_CHECK_ARG(d.f3_w && d.f3_b && d.f3_action && d.f3_state && (!d.f3_state_out || (d.f3_wcs && d.f3_bcs)));
+        ntb = 2;
+    }
     dim3 grid(mblk * (nt / ntb), d.nphase);
     IgemmDesc dd = d;   // fused LayerNorm partials: one per block, when no tile straddles two samples
     const int hwg = d.Hg * d.Wg;
@@ -255,6 +307,7 @@ int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     pivp_fastdiv((unsigned)d.Wg, &dd.fd_w_mul, &dd.fd_w_sh);
     if (d.in_g) {      // LayerNorm-on-load (see IgemmDesc::in_g): one sample per tile, one source, a plain conv
         PIVP_CHECK_ARG(igemm_in_ln_ok(d) && d.in_b && d.in_part && d.in_np > 0);
+        if (d.f3_out) { hipLaunchKernelGGL((igemm_small_kernel<2, true, true>), grid, dim3(256), 0, stream, dd); return PIVP_LAUNCH_STATUS(); }
         if (ntb == 3) hipLaunchKernelGGL((igemm_small_kernel<3, true>), grid, dim3(256), 0, stream, dd);
         else if (ntb == 2) hipLaunchKernelGGL((igemm_small_kernel<2, true>), grid, dim3(256), 0, stream, dd);
         else hipLaunchKernelGGL((igemm_small_kernel<1, true>), grid, dim3(256), 0, stream, dd);

@@ -84,12 +84,18 @@ bool conv3x3s2_ln_ok(int cin, int cout, int B, int Hin, int Win) {
     return igemm_in_ln_ok(d) && fits31(view_bytes(B, Hin, Win, cin)) && fits31(9LL * cin * cout * 4);
 }
 int run_conv3x3s2_ln(const float* x_raw, int cin, const float* w, const float* bias, float* out, int cout, int ldo, int relu,
-                     int B, int Hin, int Win, hipStream_t s, const float* gamma, const float* beta, const float* partials, int nparts, float eps) {
+                     int B, int Hin, int Win, hipStream_t s, const float* gamma, const float* beta, const float* partials, int nparts, float eps,
+                     const Enc3Fuse* fuse3) {
     if (!x_raw || !w || !out || !gamma || !beta || !partials || nparts <= 0 || !conv3x3s2_ln_ok(cin, cout, B, Hin, Win)) return PIVP_ERR_BADARG;
     IgemmDesc d;
     conv3x3s2_ln_desc(d, x_raw, cin, w, bias, out, cout, ldo, relu, B, Hin, Win);
     d.bytes0 = (int)view_bytes(B, Hin, Win, cin); d.bytesw = (int)(9LL * cin * cout * 4);
     d.in_g = gamma; d.in_b = beta; d.in_part = partials; d.in_np = nparts; d.in_eps = eps;
+    if (fuse3 && fuse3->e3) {
+        if (cout != 64 || ldo != 64 || !relu || !bias) return PIVP_ERR_BADARG;
+        d.f3_w = fuse3->w3; d.f3_b = fuse3->b3; d.f3_action = fuse3->action; d.f3_state = fuse3->state; d.f3_wcs = fuse3->wcs; d.f3_bcs = fuse3->bcs;
+        d.f3_out = fuse3->e3; d.f3_state_out = fuse3->state_out; d.f3_use_state = fuse3->use_state;
+    }
     int rc = igemm_validate(d, false);
     if (rc != PIVP_OK) return rc;
     return igemm_small(d, s);

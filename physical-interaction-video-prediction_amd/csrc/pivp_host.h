@@ -18,8 +18,11 @@ int run_conv3x3s2(const float* x, int cin, int ldx, const float* w, const float*
 // conv3x3s2 of LayerNorm(x_raw) with the norm applied while the input is staged (IgemmDesc::in_g); conv3x3s2_ln_ok tells whether the
 // geometry qualifies (output tiles of 32 anchors inside one sample)
 bool conv3x3s2_ln_ok(int cin, int cout, int B, int Hin, int Win);
+// group 3 (1x1 conv with the smeared action / state) + the state predictor in the epilogue of the conv that feeds them (IgemmDesc::f3_*)
+struct Enc3Fuse { const float* w3; const float* b3; const float* action; const float* state; const float* wcs; const float* bcs; float* e3; float* state_out; int use_state; };
 int run_conv3x3s2_ln(const float* x_raw, int cin, const float* w, const float* bias, float* out, int cout, int ldo, int relu,
-                     int B, int Hin, int Win, hipStream_t s, const float* gamma, const float* beta, const float* partials, int nparts, float eps);
+                     int B, int Hin, int Win, hipStream_t s, const float* gamma, const float* beta, const float* partials, int nparts, float eps,
+                     const Enc3Fuse* fuse3 = nullptr);
 int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                     int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0,
                     float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr, int bf16 = 0,

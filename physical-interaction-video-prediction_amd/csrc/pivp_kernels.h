@@ -61,6 +61,12 @@ struct IgemmDesc {
     // column count n_mblk, the anchors per sample Hg * Wg and the anchor row Wg -- integer division is a ~35-instruction sequence, and a block's
     // prologue is priced by its instruction count
     int n_mblk; unsigned fd_mb_mul, fd_mb_sh, fd_hw_mul, fd_hw_sh, fd_w_mul, fd_w_sh, fd_cc_mul, fd_cc_sh;   // (.., and the 32-channel chunks per tap)
+    // igemm_small only (inference plans, round 6): group 3 of the op program (TM:598: smear(state_action) -> concat -> 1x1 conv 74 -> 64 -> ReLU) and the
+    // state predictor (TM:730) run in the epilogue of the conv that produces their input (enc2, TM:502), on the block's own 32 pixels x 64 channels:
+    // f3_out [M][64] = relu(b3 + W3s . sa + W3x . out_tile); the launch that enc3_state_kernel was (6.3 us + a boundary per timestep) disappears.
+    // Needs N == 64 in one column block and 32-anchor tiles inside one sample; `out` is still written.
+    const float* f3_w; const float* f3_b; const float* f3_action; const float* f3_state; const float* f3_wcs; const float* f3_bcs;
+    float* f3_out; float* f3_state_out; int f3_use_state;
     int rd_mode, rd_blocks, rd_KS, rd_nout;
     const float* rd_partials; const float* rd_bias; const float* rd_w2; const float* rd_b2; float* rd_out; float* rd_vpre;
 };

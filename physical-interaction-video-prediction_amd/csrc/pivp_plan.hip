@@ -119,6 +119,7 @@ struct pivp_plan {
     // the plan is created) keeps everything on the caller's stream.
     static constexpr int NSLOT = 14;      // 12: enc0's weight gradient, 13: the motion head's Linear (cdna_kernels / stp_input)
     bool use_side = true;
+    bool fuse_enc3 = true;              // inference: enc3 + state predictor in enc2's epilogue (PIVP_FUSE_ENC3=0: their own launch)
     bool rider = true;                  // the motion head's finisher rides behind enc5's tiles (PIVP_FINISH_RIDER=0: inside frame_head, as rounds 4-5)
     hipStream_t side = nullptr;
     hipStream_t side_of(int) const { return side; }      // (a second side stream for the odd slots, round 3: fp32 no change, bf16 12.25 -> 12.05 ms, but with two
@@ -286,6 +287,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
     p->ws = nullptr; p->ws_floats = 0; p->last_steps = 0; p->last_sched = false;
     { const char* e = getenv("PIVP_SIDE_STREAM"); p->use_side = !(e && e[0] == '0'); }
     { const char* e = getenv("PIVP_FINISH_RIDER"); p->rider = !(e && e[0] == '0'); }
+    { const char* e = getenv("PIVP_FUSE_ENC3"); p->fuse_enc3 = !(e && e[0] == '0'); }
 
     auto add = [&](const std::string& name, long long n) { p->params.push_back({name, n, nullptr, nullptr, grad_group_of(name)}); return (int)p->params.size() - 1; };
     const int cin3 = 64 + (cfg->use_state ? 10 : 0);
@@ -536,14 +538,25 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
         RC(ln(3, ws + S.h[2], ws + S.n3, n4, 64, 64, 0, np));
         RC(lstm(3, ws + S.n3, 64, p->H4, p->W4));
     }
+    bool enc3_done = false;
     if (!train && np > 0 && conv3x3s2_ln_ok(64, 64, B, p->H4, p->W4)) {
+        // Inference: group 3 (TM:598) and the state predictor (TM:730) in enc2's epilogue (round 6): enc3_state_kernel's launch
+        // disappears; bit-identical to it (the same fmaf chain on the matrix cores).  PIVP_FUSE_ENC3=0: two launches, as before.
+        Enc3Fuse f3;
+        memset(&f3, 0, sizeof(f3));
+        if (p->fuse_enc3 && (p->H8 * p->W8) % 32 == 0) {
+            f3.w3 = P(p, p->i_enc_w[3]); f3.b3 = P(p, p->i_enc_b[3]); f3.action = action; f3.state = state_prev; f3.wcs = P(p, p->i_cs_w); f3.bcs = P(p, p->i_cs_b);
+            f3.e3 = ws + S.e3; f3.state_out = state_out; f3.use_state = c.use_state;
+            enc3_done = true;
+        }
         RC(run_conv3x3s2_ln(ws + S.h[3], 64, P(p, p->i_enc_w[2]), P(p, p->i_enc_b[2]), ws + S.e2, 64, 64, 1, B, p->H4, p->W4, s,
-                            P(p, p->i_ln_g[4]), P(p, p->i_ln_b[4]), lnp, np, eps));
+                            P(p, p->i_ln_g[4]), P(p, p->i_ln_b[4]), lnp, np, eps, &f3));
     } else {
         RC(ln(4, ws + S.h[3], ws + S.n4, n4, 64, 64, 0, np));
         RC(run_conv3x3s2(ws + S.n4, 64, 64, P(p, p->i_enc_w[2]), P(p, p->i_enc_b[2]), ws + S.e2, 64, 64, 1, B, p->H4, p->W4, s));
     }
     // group 3 (TM:598) + state predictor (TM:730)
+    if (!enc3_done)
     RC(enc3_state(ws + S.e2, action, state_prev, P(p, p->i_enc_w[3]), P(p, p->i_enc_b[3]), P(p, p->i_cs_w), P(p, p->i_cs_b),
                   ws + S.e3, state_out, B, p->H8 * p->W8, c.use_state, s));
     // group 4 (TM:599)

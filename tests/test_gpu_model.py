@@ -314,3 +314,20 @@ def test_motion_finisher_behind_enc5_is_bit_identical(pivp, monkeypatch, mt, nm,
         for k in out['1'][2]:
             a, b = np.asarray(out['1'][2][k]), np.asarray(out['0'][2][k])
             assert np.abs(a - b).max() <= 2e-5 * max(1e-30, np.abs(a).max()), k
+
+
+@pytest.mark.parametrize('mt,nm,use_state', [('CDNA', 10, True), ('CDNA', 10, False), ('STP', 10, True), ('DNA', 1, True)])
+def test_group3_in_enc2s_epilogue_is_bit_identical(pivp, monkeypatch, mt, nm, use_state):
+    """Round 6: in inference plans the smear + 1x1 conv + ReLU of group 3 (TM:598) and the state predictor (TM:730) run in the
+    epilogue of enc2's launch (PIVP_FUSE_ENC3, read when the plan is made) -- the same fmaf chain on the matrix cores: frames, predicted states and
+    loss are bit-identical to the two-launch form."""
+    import torch
+    B, T = 3, 4
+    P = R.init_params(seed=7, dtype=np.float32, scale=1.0, num_masks=nm, model_type=mt, use_state=use_state)
+    imgs, acts, stas = R.synthetic_batch(B, T)
+    out = {}
+    for fuse in ('1', '0'):
+        monkeypatch.setenv('PIVP_FUSE_ENC3', fuse)
+        m, loss, gen = _run(pivp, mt, nm, imgs, acts, stas, P, use_state=use_state)
+        out[fuse] = (loss, gen, torch.stack(m.gen_states).cpu().numpy())
+    assert out['1'][0] == out['0'][0] and np.array_equal(out['1'][1], out['0'][1]) and np.array_equal(out['1'][2], out['0'][2])
