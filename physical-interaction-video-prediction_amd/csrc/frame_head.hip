@@ -6,7 +6,10 @@
 //   and the flat-(num_masks+1) softmax + transform + compositing of the next frame              (TM:720-728 with TM:341-349 / 469-470 / 392-415).
 // Before: heads_1x1_kernel -> skinny_linear_partials_kernel -> *_finish_kernel -> composite_kernel, four launches and a round trip of the
 // 14 logit / enc7 / layer0 planes through HBM per timestep (425 us of a config-2 rollout).  Now the partial sums are the only launch in
-// front of this one.
+// front of this one.  Round 6: the finisher is per-SAMPLE work that every band of a sample repeated (128 KB of partial sums per block); the
+// plan now runs it as B "rider" blocks of enc5's launch (deconv_tile.hip) and this kernel reads the sample's kernels / parameters from a.aux
+// with its first loads.  The in-kernel finisher (a.partials != NULL) remains for callers without that launch in front (PIVP_FINISH_RIDER=0,
+// the per-op API).  Round 6 also took the block's chain from 23 to 12.7 us: profiles/r06/NOTES.md 5.
 //
 // Block = one sample x FH_TR image rows.  The flat softmax groups of a band reach NP - 1 elements past either end of the band IN THE
 // FLAT [plane][pixel] ORDER (TM:720-722 reshapes the NCHW tensor to (-1, NP)): for plane m these are the NP - 1 pixels in front of /
@@ -18,7 +21,8 @@
 //
 // Each WAVE owns 64 consecutive pixels per tile, loads them with coalesced 16-B loads, applies the LayerNorm, and turns "lane = 4
 // channels of a pixel" into "lane = pixel" through a private LDS tile -- 32 channels at a time (two passes), so that the wave tiles
-// are 37 KB instead of 70 and two blocks share a CU.  The group maxima of the compositing phase reuse that space.
+// are 37 KB instead of 70 and two blocks share a CU.  The blend phase reuses the tiles for the blended CDNA kernels (MFMA outputs back to
+// "lane = pixel"); the group maxima live in the (dead) halo rows.
 #include "pivp_kernels.h"
 
 namespace pivp {
