@@ -83,8 +83,12 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     }
     int l_cc = 0, l_ty = 0, l_tx = 0;
     // two register sets: chunk i+2 is loaded while chunk i is multiplied and written to LDS at the end of chunk i+1
-    f32x4 ras[2], rbs[2][NTB];
-    f32x4 rgs[2], rbe[2];              // in_ln: gamma / beta of the staged float4
+    // NS register sets (round 6: 4, before 2): chunk c travels in set c % NS, is loaded NS chunks ahead of its multiplies and written to LDS one chunk
+    // ahead.  With two sets a chunk's loads had ~1.5 chunk times (~700 cycles) to come back from L2 / MALL -- less than their latency under load: the loop
+    // ran at ~930 cycles per chunk (enc2's 18 chunks against enc1's 9: +3.5 us) for ~340 cycles of instructions and 256 of MFMAs.
+    constexpr int NS = 4;
+    f32x4 ras[NS], rbs[NS][NTB];
+    f32x4 rgs[NS], rbe[NS];            // in_ln: gamma / beta of the staged float4
     // PART 0: the whole chunk; 1: its weight tiles only (no advance); 2: the rest, then advance -- the first chunk's weights go out before the anchor's
     // address arithmetic (a block's prologue is priced by the instructions in front of its first load: 244 of this kernel's 960 before round 6)
     auto load_next = [&](auto SET, auto PART) {   // chunk (l_ty, l_tx, l_cc) -> register set SET, then advance
@@ -171,24 +175,33 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
 #pragma unroll
                 for (int t = 0; t < NTB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s2], fb[t][s2], acc[t], 0, 0, 0);
         };
+        using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
+        // (requests past the last chunk are made all the same: their tap is past the tap set, so the weight offset is outside the pack's descriptor --
+        // zeros, no traffic -- and the activation load is an in-image read nobody uses.  A run-time condition around a request makes hipcc's wait-count
+        // pass assume nothing about the loads in flight: s_waitcnt vmcnt(0) in front of every LDS write, i.e. no prefetch at all.)
         load_next(S0{}, P2{});
+        load_next(S1{}, P0{});
+        load_next(S2{}, P0{});
+        load_next(S3{}, P0{});
         if constexpr (IN_LN) __syncthreads();   // in_stat
         store_regs(S0{}, 0);
-        if (nchunks > 1) load_next(S1{}, P0{});
         __syncthreads();
+        // chunk c: LDS buffer c & 1, register set c % 4.  Its trip: request chunk c + 4 into the set chunk c left when it was written to LDS, multiply,
+        // write chunk c + 1 into the other buffer (every wave left that buffer's chunk c - 1 at the last barrier), barrier.
+        // (no run-time condition inside a trip -- the write of a chunk past the end puts zeros into the buffer nobody reads again -- and none between the four
+        // trips of the steady loop: every wait in it is a counted vmcnt)
+        auto trip = [&](auto SET, auto NEXT) {
+            constexpr int buf = decltype(SET)::value & 1;
+            load_next(SET, P0{});
+            mma(buf);
+            store_regs(NEXT, buf ^ 1);
+            __syncthreads();
+        };
         int it = 0;
-        for (; it + 1 < nchunks; it += 2) {     // chunks it (LDS buffer 0) and it+1 (buffer 1)
-            if (it + 2 < nchunks) load_next(S0{}, P0{});
-            mma(0);
-            store_regs(S1{}, 1);                // chunk it+1
-            __syncthreads();
-            if (it + 3 < nchunks) load_next(S1{}, P0{});
-            mma(1);
-            if (it + 2 < nchunks) store_regs(S0{}, 0);
-            __syncthreads();
-        }
-        if (it < nchunks) mma(0);               // odd count: the last chunk sits in buffer 0
-        __syncthreads();
+        for (; it + NS <= nchunks; it += NS) { trip(S0{}, S1{}); trip(S1{}, S2{}); trip(S2{}, S3{}); trip(S3{}, S0{}); }
+        if (it < nchunks) trip(S0{}, S1{});
+        if (it + 1 < nchunks) trip(S1{}, S2{});
+        if (it + 2 < nchunks) trip(S2{}, S3{});
     }
 
     // sum of the four waves' partial tiles, then the epilogue on float4 rows
