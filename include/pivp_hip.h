@@ -17,6 +17,7 @@
  *     (read at pivp_plan_create) keeps all work on the caller's stream.  PIVP_FINISH_RIDER=0 (read there too) runs the motion head's finisher
  *     inside the frame-head launch instead of as extra blocks of enc5's launch: bit-identical results either way, it exists for A/B timing.
  *     PIVP_FUSE_ENC3=0 likewise keeps group 3 (smear + 1x1 conv) and the state predictor in a launch of their own instead of enc2's epilogue.
+ *     PIVP_LN_FOLD_TRAIN=0: training plans apply the norms of hidden2 / hidden4 with ln_apply launches instead of inside enc1 / enc2's launches.
  *   - feature maps are NHWC with an explicit pixel stride `ld` (floats); frames and mask planes are
  *     planar NCHW exactly as the reference holds them
  */

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x0), 0, d.bytes0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.c1 ? d.x1 : d.x0), 0, d.c1 ? d.bytes1 : d.bytes0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, d.bytesw, 0x00020000);
-    int a_off0 = 0, a_off1 = 0, a_iy0 = -(1 << 20), a_ix0 = 0;
+    int a_off0 = 0, a_off1 = 0, a_iy0 = -(1 << 20), a_ix0 = 0, a_pix0 = 0;
     auto anchor = [&]() {          // (called behind the first chunk's weight loads)
         const int m = m0 + prow;
         if (m < d.M) {
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
             const int ay = pivp_fdiv(rem, d.fd_w_mul, d.fd_w_sh), ax = rem - ay * d.Wg;
             a_iy0 = ay * d.in_step; a_ix0 = ax * d.in_step;
             const int pix = b * d.Hin * d.Win + a_iy0 * d.Win + a_ix0;
+            a_pix0 = pix;
             a_off0 = (pix * d.ld0 + cvec * 4) * 4;
             a_off1 = (pix * d.ld1 + cvec * 4) * 4;
         }
@@ -79,7 +80,11 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     if (IN_LN && tid < 64) {
         float mean, rstd;
         ln_merge_partials(d.in_part, pivp_fdiv(m0, d.fd_hw_mul, d.fd_hw_sh), d.in_np, d.in_eps, mean, rstd);
-        if (tid == 0) { in_stat[0] = mean; in_stat[1] = rstd; }
+        if (tid == 0) {
+            in_stat[0] = mean; in_stat[1] = rstd;
+            const int bs = pivp_fdiv(m0, d.fd_hw_mul, d.fd_hw_sh);
+            if (d.in_stat_out && nblk == 0 && m0 == bs * HWg) { d.in_stat_out[bs * 2] = mean; d.in_stat_out[bs * 2 + 1] = rstd; }      // kept for the backward pass
+        }
     }
     int l_cc = 0, l_ty = 0, l_tx = 0;
     // two register sets: chunk i+2 is loaded while chunk i is multiplied and written to LDS at the end of chunk i+1
@@ -89,6 +94,8 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
     constexpr int NS = 4;
     f32x4 ras[NS], rbs[NS][NTB];
     f32x4 rgs[NS], rbe[NS];            // in_ln: gamma / beta of the staged float4
+    int roo[NS];                       // in_ln with d.in_out (training plans): where the staged float4, normalised, is ALSO written (float index, or -1).  Each
+                                       // input pixel of a stride-2 3x3 conv is the tap (1..2, 1..2) of exactly one anchor: that anchor's thread owns it.
     // PART 0: the whole chunk; 1: its weight tiles only (no advance); 2: the rest, then advance -- the first chunk's weights go out before the anchor's
     // address arithmetic (a block's prologue is priced by the instructions in front of its first load: 244 of this kernel's 960 before round 6)
     auto load_next = [&](auto SET, auto PART) {   // chunk (l_ty, l_tx, l_cc) -> register set SET, then advance
@@ -114,6 +121,8 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
             ra = __builtin_bit_cast(f32x4, first ? __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0)
                                                  : __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0));
             if constexpr (IN_LN) {         // element (iy, ix, channel) of the sample: [Hin*Win][c0]
+                const bool own = d.in_out && nblk == 0 && ok && l_ty >= 1 && l_tx >= 1 && l_ty < nty;      // (not the requests past the last chunk)
+                roo[decltype(SET)::value] = own ? (a_pix0 + dy * d.Win + dx) * d.in_out_ld + ch + cvec * 4 : -1;
                 const unsigned goff = ok ? (unsigned)(((iy * d.Win + ix) * d.c0 + ch + cvec * 4) * 4) : OOB;
                 rgs[decltype(SET)::value] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, goff, 0, 0));
                 rbe[decltype(SET)::value] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, goff, 0, 0));
@@ -133,6 +142,7 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const IgemmDesc d) {
             const f32x4 g = rgs[decltype(SET)::value], be = rbe[decltype(SET)::value];
 #pragma unroll
             for (int e = 0; e < 4; ++e) ra[e] = (ra[e] - mean) * rstd * g[e] + be[e];
+            if (d.in_out && roo[decltype(SET)::value] >= 0) *reinterpret_cast<f32x4*>(d.in_out + roo[decltype(SET)::value]) = ra;
         }
         *reinterpret_cast<f32x4*>(lds + A_OFF + buf * TILE + lds_w) = ra;
 #pragma unroll
@@ -320,6 +330,9 @@ int igemm_small(const IgemmDesc& d, hipStream_t stream, int* ln_nparts) {
     pivp_fastdiv((unsigned)d.Wg, &dd.fd_w_mul, &dd.fd_w_sh);
     if (d.in_g) {      // LayerNorm-on-load (see IgemmDesc::in_g): one sample per tile, one source, a plain conv
         PIVP_CHECK_ARG(igemm_in_ln_ok(d) && d.in_b && d.in_part && d.in_np > 0);
+        // the write-back of the normalised input (training plans): every input pixel must be the tap (1..2, 1..2) of one anchor -- the 3x3 stride-2 pad-1 conv
+        PIVP_CHECK_ARG(!d.in_out || (d.ksize == 3 && d.pad == 1 && d.in_step == 2 && d.Hin == 2 * d.Hg && d.Win == 2 * d.Wg && d.in_out_ld >= d.c0 && d.in_out_ld % 4 == 0 &&
+                                     ((uintptr_t)d.in_out & 15) == 0 && (long long)d.B * d.Hin * d.Win * d.in_out_ld < (1LL << 31)));
         if (d.f3_out) { hipLaunchKernelGGL((igemm_small_kernel<2, true, true>), grid, dim3(256), 0, stream, dd); return PIVP_LAUNCH_STATUS(); }
         if (ntb == 3) hipLaunchKernelGGL((igemm_small_kernel<3, true>), grid, dim3(256), 0, stream, dd);
         else if (ntb == 2) hipLaunchKernelGGL((igemm_small_kernel<2, true>), grid, dim3(256), 0, stream, dd);

@@ -85,12 +85,13 @@ bool conv3x3s2_ln_ok(int cin, int cout, int B, int Hin, int Win) {
 }
 int run_conv3x3s2_ln(const float* x_raw, int cin, const float* w, const float* bias, float* out, int cout, int ldo, int relu,
                      int B, int Hin, int Win, hipStream_t s, const float* gamma, const float* beta, const float* partials, int nparts, float eps,
-                     const Enc3Fuse* fuse3) {
+                     const Enc3Fuse* fuse3, float* norm_out, int norm_ld, float* stat_out) {
     if (!x_raw || !w || !out || !gamma || !beta || !partials || nparts <= 0 || !conv3x3s2_ln_ok(cin, cout, B, Hin, Win)) return PIVP_ERR_BADARG;
     IgemmDesc d;
     conv3x3s2_ln_desc(d, x_raw, cin, w, bias, out, cout, ldo, relu, B, Hin, Win);
     d.bytes0 = (int)view_bytes(B, Hin, Win, cin); d.bytesw = (int)(9LL * cin * cout * 4);
     d.in_g = gamma; d.in_b = beta; d.in_part = partials; d.in_np = nparts; d.in_eps = eps;
+    d.in_out = norm_out; d.in_out_ld = norm_ld; d.in_stat_out = stat_out;
     if (fuse3 && fuse3->e3) {
         if (cout != 64 || ldo != 64 || !relu || !bias) return PIVP_ERR_BADARG;
         d.f3_w = fuse3->w3; d.f3_b = fuse3->b3; d.f3_action = fuse3->action; d.f3_state = fuse3->state; d.f3_wcs = fuse3->wcs; d.f3_bcs = fuse3->bcs;

@@ -22,7 +22,7 @@ bool conv3x3s2_ln_ok(int cin, int cout, int B, int Hin, int Win);
 struct Enc3Fuse { const float* w3; const float* b3; const float* action; const float* state; const float* wcs; const float* bcs; float* e3; float* state_out; int use_state; };
 int run_conv3x3s2_ln(const float* x_raw, int cin, const float* w, const float* bias, float* out, int cout, int ldo, int relu,
                      int B, int Hin, int Win, hipStream_t s, const float* gamma, const float* beta, const float* partials, int nparts, float eps,
-                     const Enc3Fuse* fuse3 = nullptr);
+                     const Enc3Fuse* fuse3 = nullptr, float* norm_out = nullptr, int norm_ld = 0, float* stat_out = nullptr);      // training plans: the normalised input and (mean, rstd) are kept
 int run_deconv3x3s2(const float* x, int cin, int ldx, const float* w, const float* bias, float* out, int cout,
                     int ldo, int relu, int B, int Hin, int Win, hipStream_t s, int accum = 0,
                     float* ln_part = nullptr, int ln_cap = 0, int* ln_nparts = nullptr, int bf16 = 0,

@@ -119,6 +119,7 @@ struct pivp_plan {
     // the plan is created) keeps everything on the caller's stream.
     static constexpr int NSLOT = 14;      // 12: enc0's weight gradient, 13: the motion head's Linear (cdna_kernels / stp_input)
     bool use_side = true;
+    bool ln_fold_train = true;          // training: the norms of hidden2 / hidden4 applied (and written) by enc1 / enc2's launches (PIVP_LN_FOLD_TRAIN=0: ln_apply launches)
     bool fuse_enc3 = true;              // inference: enc3 + state predictor in enc2's epilogue (PIVP_FUSE_ENC3=0: their own launch)
     bool rider = true;                  // the motion head's finisher rides behind enc5's tiles (PIVP_FINISH_RIDER=0: inside frame_head, as rounds 4-5)
     hipStream_t side = nullptr;
@@ -288,6 +289,7 @@ extern "C" int pivp_plan_create(const pivp_config_t* cfg, pivp_plan_t** out) {
     { const char* e = getenv("PIVP_SIDE_STREAM"); p->use_side = !(e && e[0] == '0'); }
     { const char* e = getenv("PIVP_FINISH_RIDER"); p->rider = !(e && e[0] == '0'); }
     { const char* e = getenv("PIVP_FUSE_ENC3"); p->fuse_enc3 = !(e && e[0] == '0'); }
+    { const char* e = getenv("PIVP_LN_FOLD_TRAIN"); p->ln_fold_train = !(e && e[0] == '0'); }
 
     auto add = [&](const std::string& name, long long n) { p->params.push_back({name, n, nullptr, nullptr, grad_group_of(name)}); return (int)p->params.size() - 1; };
     const int cin3 = 64 + (cfg->use_state ? 10 : 0);
@@ -518,7 +520,13 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
     }
     // Inference rollouts: hidden2 / hidden4 feed only enc1 / enc2, so their norms are applied while those convs stage their input
     // (run_conv3x3s2_ln) instead of by a launch of their own; training keeps the materialised tensors (the backward sweep reads them).
-    if (!train && np > 0 && conv3x3s2_ln_ok(32, 32, B, p->H2, p->W2)) {
+    // Training plans take the same launch (round 6) and have it WRITE the normalised hidden2 / hidden4 (every input pixel of a stride-2 3x3 conv is the
+    // tap (1..2, 1..2) of exactly one anchor) and the samples' (mean, rstd) for the backward sweep: two ln_apply launches per timestep less.
+    if (np > 0 && p->ln_fold_train && conv3x3s2_ln_ok(32, 32, B, p->H2, p->W2)) {
+        RC(run_conv3x3s2_ln(ws + S.h[1], 32, P(p, p->i_enc_w[1]), P(p, p->i_enc_b[1]), ws + S.cat6 + 64, 32, 96, 1, B, p->H2, p->W2, s,
+                            P(p, p->i_ln_g[2]), P(p, p->i_ln_b[2]), lnp, np, eps, nullptr,
+                            train ? ws + S.n2 : nullptr, 32, train ? ws + S.lnstat + (size_t)2 * B * 2 : nullptr));
+    } else if (!train && np > 0 && conv3x3s2_ln_ok(32, 32, B, p->H2, p->W2)) {
         RC(run_conv3x3s2_ln(ws + S.h[1], 32, P(p, p->i_enc_w[1]), P(p, p->i_enc_b[1]), ws + S.cat6 + 64, 32, 96, 1, B, p->H2, p->W2, s,
                             P(p, p->i_ln_g[2]), P(p, p->i_ln_b[2]), lnp, np, eps));
     } else {
@@ -539,6 +547,10 @@ static int run_step(pivp_plan* p, int t, const float* prev, const float* action,
         RC(lstm(3, ws + S.n3, 64, p->H4, p->W4));
     }
     bool enc3_done = false;
+    if (train && np > 0 && p->ln_fold_train && conv3x3s2_ln_ok(64, 64, B, p->H4, p->W4)) {
+        RC(run_conv3x3s2_ln(ws + S.h[3], 64, P(p, p->i_enc_w[2]), P(p, p->i_enc_b[2]), ws + S.e2, 64, 64, 1, B, p->H4, p->W4, s,
+                            P(p, p->i_ln_g[4]), P(p, p->i_ln_b[4]), lnp, np, eps, nullptr, ws + S.n4, 64, ws + S.lnstat + (size_t)4 * B * 2));
+    } else
     if (!train && np > 0 && conv3x3s2_ln_ok(64, 64, B, p->H4, p->W4)) {
         // Inference: group 3 (TM:598) and the state predictor (TM:730) in enc2's epilogue (round 6): enc3_state_kernel's launch
         // disappears; bit-identical to it (the same fmaf chain on the matrix cores).  PIVP_FUSE_ENC3=0: two launches, as before.

@@ -331,3 +331,22 @@ def test_group3_in_enc2s_epilogue_is_bit_identical(pivp, monkeypatch, mt, nm, us
         m, loss, gen = _run(pivp, mt, nm, imgs, acts, stas, P, use_state=use_state)
         out[fuse] = (loss, gen, torch.stack(m.gen_states).cpu().numpy())
     assert out['1'][0] == out['0'][0] and np.array_equal(out['1'][1], out['0'][1]) and np.array_equal(out['1'][2], out['0'][2])
+
+
+def test_training_plans_apply_the_norms_of_hidden2_and_hidden4_inside_enc1_and_enc2(pivp, monkeypatch):
+    """Round 6: in training plans too enc1 / enc2's launches apply the LayerNorm of their input while staging it -- and WRITE the normalised tensor and the
+    samples' (mean, rstd) that the backward sweep reads (PIVP_LN_FOLD_TRAIN=0: the two ln_apply launches per timestep, as before).  The expression is
+    ln_apply's: frames and loss bit-identical, gradients equal to the last bits the sweep's atomics leave undetermined."""
+    B, T = 3, 4
+    P = R.init_params(seed=11, dtype=np.float32, scale=1.0)
+    imgs, acts, stas = R.synthetic_batch(B, T)
+    out = {}
+    for fold in ('1', '0'):
+        monkeypatch.setenv('PIVP_LN_FOLD_TRAIN', fold)
+        m, loss, gen = _run(pivp, 'CDNA', 10, imgs, acts, stas, P, train=True, keep_activations=True)
+        m.cleargrads(); m.backward()
+        out[fold] = (loss, gen, m.grads_reference())
+    assert out['1'][0] == out['0'][0] and np.array_equal(out['1'][1], out['0'][1])
+    for k in out['1'][2]:
+        a, b = np.asarray(out['1'][2][k]), np.asarray(out['0'][2][k])
+        assert np.abs(a - b).max() <= 2e-5 * max(1e-30, np.abs(a).max()), k
